@@ -1,0 +1,66 @@
+"""Plain-object stand-ins for the attributes ``SAC_CBF_CLF`` reads from ``env``.
+
+The reference builds gym environments (``envs/unicycle_env.py``); ``gym`` is
+not part of this build and the simulators are out of scope (SURVEY.md §2 row
+8).  The update path only reads constants from ``env``:
+``dynamics_mode``, ``dt``, ``hazards_locations``, ``hazards_radius``,
+``safe_action_space.low/high``, ``action_space.{shape,high,low,seed,sample}``
+and ``seed()``.  A real gym env exposing the same attributes works unchanged.
+
+Constants follow ``U/envs/unicycle_env.py:14-40`` (bounds ±3.5/±12, seven
+hazards on a 1.5-spaced grid, radius 0.5, dt 0.02, goal (2.5, 2.5)).
+"""
+import numpy as np
+
+
+class Box:
+    """Minimal ``gym.spaces.Box`` look-alike (shape/low/high/seed/sample)."""
+
+    def __init__(self, low, high, shape=None, dtype=np.float32):
+        low = np.asarray(low, dtype=dtype)
+        high = np.asarray(high, dtype=dtype)
+        if shape is not None and low.shape != tuple(shape):
+            low = np.full(shape, low, dtype=dtype)
+            high = np.full(shape, high, dtype=dtype)
+        self.low, self.high = low, high
+        self.shape = low.shape
+        self.dtype = dtype
+        self._rng = np.random.RandomState()
+
+    def seed(self, s=None):
+        self._rng = np.random.RandomState(s)
+        return [s]
+
+    def sample(self):
+        return self._rng.uniform(self.low, self.high).astype(self.dtype)
+
+
+class UnicycleSpec:
+    """Constants of ``UnicycleEnv`` (U/envs/unicycle_env.py:14-40)."""
+
+    dynamics_mode = "Unicycle"
+    n_s, n_u, obs_dim, lya_in = 3, 2, 7, 2
+
+    def __init__(self, seed=0):
+        lo = np.array([-3.5, -12.0])
+        hi = np.array([3.5, 12.0])
+        self.safe_action_space = Box(lo, hi)
+        self.action_space = Box(lo, hi)
+        self.observation_space = Box(-1e10, 1e10, shape=(7,))
+        self.hazards_radius = 0.5
+        self.hazards_locations = np.array(
+            [[0., 0.], [0., 1.], [0., -1.], [-1., 1.], [-1., -1.], [1., -1.], [1., 1.]]) * 1.5
+        self.dt = 0.02
+        self.goal_pos = np.array([2.5, 2.5])
+        self.max_episode_steps = 1200
+        self.seed(seed)
+
+    def seed(self, s=None):
+        self.action_space.seed(s)
+        return [s]
+
+
+def make_env(name, seed=0):
+    if name == "Unicycle":
+        return UnicycleSpec(seed)
+    raise Exception("Dynamics mode not supported.")

@@ -1,0 +1,130 @@
+"""Deterministic synthetic replay transitions and network weights.
+
+Everything here is generated from ``numpy.random.RandomState`` (a frozen
+stream), so the golden-fixture generator (``oracle/gen_golden.py``), the
+tests and ``bench.py`` reproduce identical inputs from a seed alone — the
+fixtures then only need to hold expected outputs.
+
+Transition layout follows SURVEY.md §8(d) "Synthetic inputs": the obs vector
+is built like ``U/envs/unicycle_env.py:257-273``, the next state is one true
+env Euler step (``:102-103``), centre / next-centre are the look-ahead points
+(``:95-107``) and the minibatch field order is that of
+``U/sac_cbf_clf/replay_memory.py:24-25``.
+"""
+import numpy as np
+
+L_P = 0.03  # look-ahead distance, U/sac_cbf_clf/sac_cbf_clf.py:13
+
+FIELDS = ("obs", "action", "reward", "constraint", "center", "next_center",
+          "next_obs", "mask", "t", "next_t")
+
+
+def _unicycle_obs(state, goal):
+    x, y, th = state[:, 0], state[:, 1], state[:, 2]
+    rel = goal[None, :] - state[:, :2]
+    dist = np.linalg.norm(rel, axis=1)
+    c, s = np.cos(th), np.sin(th)
+    # vec @ R with R = [[c,-s],[s,c]]
+    v0 = rel[:, 0] * c + rel[:, 1] * s
+    v1 = -rel[:, 0] * s + rel[:, 1] * c
+    n = np.sqrt(v0 * v0 + v1 * v1) + 0.001
+    return np.stack([x, y, c, s, v0 / n, v1 / n, np.exp(-dist)], axis=1)
+
+
+def unicycle_transitions(n, seed=1, env=None):
+    """Return a dict of float64 numpy arrays (the reference replay holds
+    float64 numpy rows too), ``n`` transitions."""
+    from .envspec import UnicycleSpec
+    env = env or UnicycleSpec()
+    rs = np.random.RandomState(seed)
+    dt, goal = env.dt, env.goal_pos
+    state = np.stack([rs.uniform(-3, 3, n), rs.uniform(-3, 3, n),
+                      rs.uniform(-np.pi, np.pi, n)], axis=1)
+    lo, hi = env.action_space.low.astype(np.float64), env.action_space.high.astype(np.float64)
+    action = rs.uniform(lo, hi, size=(n, 2))
+    obs = _unicycle_obs(state, goal)
+    center = state[:, :2] + L_P * np.stack([np.cos(state[:, 2]), np.sin(state[:, 2])], 1)
+    # one env Euler step: x += dt * g(x) u ; then the small drag term
+    nxt = state.copy()
+    nxt[:, 0] += dt * np.cos(state[:, 2]) * action[:, 0]
+    nxt[:, 1] += dt * np.sin(state[:, 2]) * action[:, 0]
+    nxt[:, 2] += dt * action[:, 1]
+    drag = np.cos(nxt[:, 2])
+    nxt[:, 0] -= dt * 0.1 * np.cos(nxt[:, 2]) * drag
+    nxt[:, 1] -= dt * 0.1 * np.sin(nxt[:, 2]) * drag
+    next_obs = _unicycle_obs(nxt, goal)
+    next_center = nxt[:, :2] + L_P * np.stack([np.cos(nxt[:, 2]), np.sin(nxt[:, 2])], 1)
+    d_prev = np.linalg.norm(goal[None] - center, axis=1)
+    d_next = np.linalg.norm(goal[None] - next_center, axis=1)
+    reward = -np.square(action[:, 0] - 2.5) * 0.1 + (d_prev - d_next) * 30
+    t = rs.randint(1, 1200, n).astype(np.float64) * dt
+    return dict(obs=obs, action=action, reward=reward, constraint=d_next,
+                center=center, next_center=next_center, next_obs=next_obs,
+                mask=np.ones(n), t=t, next_t=t + dt)
+
+
+# ---------------------------------------------------------------------------
+# network shapes (reference key names; U/sac_cbf_clf/model.py:37-133,177-206)
+# ---------------------------------------------------------------------------
+
+def qnet_shapes(num_inputs, num_actions, hidden):
+    i = num_inputs + num_actions
+    return [("linear1", hidden, i), ("linear2", hidden, hidden), ("linear3", 1, hidden),
+            ("linear4", hidden, i), ("linear5", hidden, hidden), ("linear6", 1, hidden)]
+
+
+def lya_shapes(num_inputs, hidden):
+    return [("linear1", hidden, num_inputs), ("linear2", hidden, hidden), ("linear3", 1, hidden)]
+
+
+def policy_shapes(num_inputs, num_actions, hidden):
+    return [("linear1", hidden, num_inputs), ("linear2", hidden, hidden),
+            ("mean_linear", num_actions, hidden), ("log_std_linear", num_actions, hidden)]
+
+
+def node_affine_shapes(n_s, n_u, hidden=100, f_hidden_layers=4, g_hidden_layers=3):
+    f = [("f_net.0", hidden, n_s)]
+    f += [("f_net.%d" % (2 * i), hidden, hidden) for i in range(1, f_hidden_layers)]
+    f += [("f_net.%d" % (2 * f_hidden_layers), n_s, hidden)]
+    g = [("g_net.0", hidden, n_s)]
+    g += [("g_net.%d" % (2 * i), hidden, hidden) for i in range(1, g_hidden_layers)]
+    g += [("g_net.%d" % (2 * g_hidden_layers), n_s * n_u, hidden)]
+    return f + g
+
+
+def synth_state_dict(shapes, seed, kind="xavier"):
+    """Deterministic float32 weights for a list of (name, out, in) layers.
+
+    ``xavier``: W ~ U(±sqrt(6/(in+out))) (reference rule ``model.py:14-17``),
+    biases small non-zero so bias gradients/updates are exercised.
+    ``default``: W, b ~ U(±1/sqrt(in)) (PyTorch ``nn.Linear`` default, which
+    the reference NODE keeps, ``model.py:186-206``).
+    """
+    rs = np.random.RandomState(seed)
+    sd = {}
+    for name, n_out, n_in in shapes:
+        if kind == "xavier":
+            bw = np.sqrt(6.0 / (n_in + n_out))
+            bb = 0.05
+        else:
+            bw = bb = 1.0 / np.sqrt(n_in)
+        sd[name + ".weight"] = rs.uniform(-bw, bw, size=(n_out, n_in)).astype(np.float32)
+        sd[name + ".bias"] = rs.uniform(-bb, bb, size=(n_out,)).astype(np.float32)
+    return sd
+
+
+def unicycle_agent_weights(hidden, seed=0):
+    """All seven Unicycle nets (targets start as copies, like hard_update)."""
+    critic = synth_state_dict(qnet_shapes(7, 2, hidden), seed * 10 + 1)
+    lya = synth_state_dict(lya_shapes(2, hidden), seed * 10 + 2)
+    policy = synth_state_dict(policy_shapes(7, 2, hidden), seed * 10 + 3)
+    backup = synth_state_dict(policy_shapes(7, 2, hidden), seed * 10 + 4)
+    node = synth_state_dict(node_affine_shapes(3, 2), seed * 10 + 5, kind="default")
+    return dict(critic=critic, lyapunov=lya, policy=policy, backup_policy=backup, node=node)
+
+
+def normal_eps(n_draws, batch, n_u, seed):
+    """Pre-drawn reparameterisation noise ε ~ N(0,1), float32, one (B, n_u)
+    array per policy sample in the reference draw order."""
+    rs = np.random.RandomState(seed)
+    return [rs.standard_normal((batch, n_u)).astype(np.float32) for _ in range(n_draws)]

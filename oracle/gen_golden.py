@@ -1,0 +1,215 @@
+"""Golden-vector generator — runs ONLY in the build container (needs
+``/root/reference``).  Test infrastructure, not product code.
+
+Imports the reference's own Unicycle modules
+(``NLBAC_Unicycle_RL_training/Unicycle_RL_training/sac_cbf_clf/*``) on CPU,
+drives ``SAC_CBF_CLF.update_parameters`` with seeded synthetic minibatches,
+pre-drawn policy noise and deterministic weights (all regenerated from seeds
+by ``nlbac_amd.synth``) and writes the observed outputs to
+``tests/golden/unicycle_<solver>_B<batch>.npz`` (data only: numbers the
+reference computed; no reference source text).
+
+What has to be faked to import the reference here:
+  * ``torchdiffeq`` is not installed: a module of that name exposing this
+    repo's ``oracle.nlbac_oracle.odeint`` is injected.  With the reference's
+    hard-coded ``method='euler'`` on ``t=[0,dt]`` that is exactly one explicit
+    Euler step — the reference's real behaviour, so the Euler fixtures are
+    true reference outputs.  The rk4 / dopri5 fixtures are "reference agent +
+    this repo's restatement of torchdiffeq" => solver semantics UNPINNED.
+  * ``sac_cbf_clf.model.device`` is hard-coded ``cuda`` -> rebound to CPU.
+  * ``env`` is a plain object (gym is absent): ``nlbac_amd.envspec``.
+
+Usage:  python oracle/gen_golden.py
+"""
+import os
+import sys
+import types
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+sys.dont_write_bytecode = True
+
+import nlbac_amd  # noqa: E402
+from nlbac_amd import synth  # noqa: E402
+from nlbac_amd.envspec import make_env  # noqa: E402
+from oracle import nlbac_oracle as O  # noqa: E402
+
+REF = "/root/reference/NLBAC_Unicycle_RL_training/Unicycle_RL_training"
+
+
+def import_reference():
+    td = types.ModuleType("torchdiffeq")
+    td.odeint = lambda func, y0, t, method=None, atol=None, rtol=None, **kw: O.odeint(
+        func, y0, t, method=method, atol=atol, rtol=rtol)
+    sys.modules["torchdiffeq"] = td
+    sys.path.insert(0, REF)
+    import sac_cbf_clf.model as M
+    M.device = torch.device("cpu")
+    import sac_cbf_clf.sac_cbf_clf as S
+    return M, S
+
+
+class FakeMemory:
+    """Duck-typed ``ReplayMemory``: ``sample`` hands back a fixed minibatch in
+    the field order of replay_memory.py:24-25."""
+
+    def __init__(self, tr, idx):
+        self.rows = tuple(tr[f][idx] for f in synth.FIELDS)
+        self.position = len(idx)
+
+    def sample(self, batch_size):
+        assert batch_size == len(self.rows[0])
+        return self.rows
+
+
+def load_sd(module, sd_np):
+    module.load_state_dict({k: torch.from_numpy(v) for k, v in sd_np.items()})
+
+
+def flat_grads(params):
+    return torch.cat([p.grad.reshape(-1) for p in params]).clone()
+
+
+def flat_params(module_or_list):
+    ps = module_or_list.parameters() if hasattr(module_or_list, "parameters") else module_or_list
+    return torch.cat([p.detach().reshape(-1) for p in ps])
+
+
+def summarize(prefix, vec, out, n_head=48):
+    v = vec.detach().double()
+    out[prefix + "_norm"] = float(v.norm())
+    out[prefix + "_sum"] = float(v.sum())
+    out[prefix + "_head"] = vec[:n_head].detach().numpy().copy()
+    out[prefix + "_tail"] = vec[-n_head:].detach().numpy().copy()
+
+
+def run_case(S, solver, B, hidden=256, seed=0, node_B=512, calls=(0, 1, 8)):
+    env = make_env("Unicycle", seed)
+    args = O.Args(batch_size=B, hidden_size=hidden, seed=seed)
+    args.gamma_b = 50.0
+    agent = S.SAC_CBF_CLF(7, env.action_space, env, args)
+    agent.solver = solver
+    W = synth.unicycle_agent_weights(hidden, seed)
+    load_sd(agent.critic, W["critic"]); load_sd(agent.critic_target, W["critic"])
+    load_sd(agent.lyapunovNet, W["lyapunov"]); load_sd(agent.lyapunovNet_target, W["lyapunov"])
+    load_sd(agent.policy, W["policy"]); load_sd(agent.backup_policy, W["backup_policy"])
+    load_sd(agent.neural_ode_model, W["node"])
+
+    class Dyn:  # reference DynamicsModel needs args.cuda; build it directly
+        pass
+    from sac_cbf_clf.dynamics import DynamicsModel
+    dyn = DynamicsModel(env, args)
+
+    tr = synth.unicycle_transitions(4096, seed=seed + 1, env=env)
+    out = {"meta_solver": solver, "meta_B": B, "meta_hidden": hidden, "meta_seed": seed,
+           "meta_node_B": node_B, "meta_calls": np.array(calls)}
+
+    # instrumentation -------------------------------------------------------
+    rec = {}
+    opts = dict(critic=agent.critic_optim, lya=agent.lyaNet_optim, policy=agent.policy_optim,
+                backup=agent.backup_policy_optim, node=agent.neural_ode_model_optimizer)
+    for name, opt in opts.items():
+        orig = opt.step
+
+        def step(closure=None, _orig=orig, _name=name, _opt=opt):
+            rec["g_" + _name] = flat_grads(_opt.param_groups[0]["params"])
+            return _orig()
+        opt.step = step
+
+    eps_queue = []
+    orig_rsample = torch.distributions.Normal.rsample
+
+    def rsample(self, sample_shape=torch.Size()):
+        e = eps_queue.pop(0)
+        assert e.shape == self.loc.shape
+        return self.loc + e * self.scale
+    torch.distributions.Normal.rsample = rsample
+
+    where_rec = []
+    orig_where = torch.where
+
+    def where(*a, **k):
+        r = orig_where(*a, **k)
+        if len(a) == 3:
+            where_rec.append((a[1].detach().clone(), r.detach().clone()))
+        return r
+
+    node_out = []
+    td = sys.modules["torchdiffeq"]
+    orig_odeint = S.odeint
+
+    def odeint_rec(func, y0, t, **kw):
+        info = {}
+        y = O.odeint(func, y0, t, method=kw.get("method"), atol=kw.get("atol"),
+                     rtol=kw.get("rtol"), info=info)
+        node_out.append((y[-1].detach().clone(), info))
+        return y
+    S.odeint = odeint_rec
+
+    try:
+        for ci, updates in enumerate(calls):
+            rs = np.random.RandomState(1000 * seed + 17 * ci + B)
+            idx = rs.choice(4096, B, replace=False)
+            nidx = rs.choice(4096, node_B, replace=False)
+            eps = synth.normal_eps(3, B, 2, seed=100 * seed + ci)
+            eps_queue[:] = [torch.from_numpy(e) for e in eps]
+            where_rec.clear(); node_out.clear(); rec.clear()
+            torch.where = where
+            ret = agent.update_parameters(FakeMemory(tr, idx), B, updates, dyn,
+                                          FakeMemory(tr, nidx), 10)
+            torch.where = orig_where
+            p = "c%d_" % ci
+            out[p + "updates"] = updates
+            out[p + "idx"], out[p + "nidx"] = idx, nidx
+            out[p + "ret"] = np.array(ret, dtype=np.float64)
+            (matr, filt), (bmatr, bfilt) = where_rec[0], where_rec[1]
+            out[p + "required"] = (filt.sum(0) / B).reshape(-1).numpy()
+            out[p + "brequired"] = (bfilt.sum(0) / B).reshape(-1).numpy()
+            out[p + "lambdas"] = np.array([float(x) for x in agent.lambda_values])
+            out[p + "backup_lambdas"] = np.array([float(x) for x in agent.backup_lambda_values])
+            out[p + "augmented_term"] = float(agent.augmented_term)
+            out[p + "backup_alpha"] = float(agent.backup_alpha)
+            out[p + "x_next"] = node_out[0][0][:, :3].numpy()
+            out[p + "bx_next"] = node_out[1][0][:, :3].numpy()
+            if solver == "dopri5":
+                out[p + "ode_steps"] = np.array(node_out[0][1]["steps"], dtype=np.float64)
+                out[p + "bode_steps"] = np.array(node_out[1][1]["steps"], dtype=np.float64)
+            if B <= 16:
+                out[p + "matr"] = matr.reshape(B, -1).numpy()
+                out[p + "bmatr"] = bmatr.reshape(B, -1).numpy()
+            for name in opts:
+                if "g_" + name in rec:
+                    summarize(p + "g_" + name, rec["g_" + name], out)
+            for name, mod in (("critic", agent.critic), ("lya", agent.lyapunovNet),
+                              ("policy", agent.policy), ("backup", agent.backup_policy),
+                              ("node", agent.neural_ode_model),
+                              ("critic_target", agent.critic_target),
+                              ("lya_target", agent.lyapunovNet_target)):
+                summarize(p + "p_" + name, flat_params(mod), out)
+            out[p + "log_alpha"] = float(agent.log_alpha)
+            out[p + "backup_log_alpha"] = float(agent.backup_log_alpha)
+    finally:
+        torch.where = orig_where
+        torch.distributions.Normal.rsample = orig_rsample
+        S.odeint = orig_odeint
+    return out
+
+
+def main():
+    M, S = import_reference()
+    torch.set_num_threads(1)   # deterministic reduction order for the fixtures
+    gold = os.path.join(ROOT, "tests", "golden")
+    os.makedirs(gold, exist_ok=True)
+    for solver in ("euler", "rk4", "dopri5"):
+        for B in (8, 128):
+            out = run_case(S, solver, B)
+            path = os.path.join(gold, "unicycle_%s_B%d.npz" % (solver, B))
+            np.savez_compressed(path, **out)
+            print(path, os.path.getsize(path), "bytes; ret(c0) =", out["c0_ret"])
+
+
+if __name__ == "__main__":
+    main()

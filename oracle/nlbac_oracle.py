@@ -1,0 +1,452 @@
+"""ORACLE — test infrastructure, NOT product code.
+
+CPU (PyTorch fp32 + autograd) restatement of the NLBAC hot path for the
+Unicycle agent.  Only ``tests/``, ``__graft_entry__.smoke()`` and the
+``cpu_baseline`` leg of ``bench.py`` may import this module; the product
+package never does.
+
+Pinned by ``tests/golden/unicycle_*.npz`` which ``oracle/gen_golden.py``
+produced by importing the reference's own modules in the build container
+(Euler: the only solver configuration the reference executes, exact).
+rk4 / dopri5 follow torchdiffeq 0.2.3 *from recollection* (the package is
+not in the container) — PARITY UNPINNED for those two solvers.
+
+Reference lines restated (U = NLBAC_Unicycle_RL_training/Unicycle_RL_training):
+  update_parameters        U/sac_cbf_clf/sac_cbf_clf.py:181-319
+  get_policy_loss_2        U/sac_cbf_clf/sac_cbf_clf.py:408-530
+  backup_get_policy_loss_2 U/sac_cbf_clf/sac_cbf_clf.py:532-640
+  QNetwork/LyaNetwork/GaussianPolicy  U/sac_cbf_clf/model.py:37-133
+  NeuralODEModel.forward   U/sac_cbf_clf/model.py:208-217
+  train_step               U/sac_cbf_clf/model.py:221-260
+  get_state                U/sac_cbf_clf/dynamics.py:27-69
+  soft_update              U/sac_cbf_clf/utils.py:75-79
+"""
+import math
+
+import numpy as np
+import torch
+import torch.nn.functional as F
+
+LOG_SIG_MAX, LOG_SIG_MIN, EPS = 2.0, -20.0, 1e-6
+L_P = 0.03
+
+
+# ---------------------------------------------------------------------------
+# networks (functional; parameters live in dicts keyed like the reference)
+# ---------------------------------------------------------------------------
+
+def _lin(sd, name, x):
+    return F.linear(x, sd[name + ".weight"], sd[name + ".bias"])
+
+
+def qnet(sd, obs, act):
+    """model.py:53-64"""
+    xu = torch.cat([obs, act], 1)
+    x1 = _lin(sd, "linear3", F.relu(_lin(sd, "linear2", F.relu(_lin(sd, "linear1", xu)))))
+    x2 = _lin(sd, "linear6", F.relu(_lin(sd, "linear5", F.relu(_lin(sd, "linear4", xu)))))
+    return x1, x2
+
+
+def lyanet(sd, x):
+    """model.py:77-83"""
+    return _lin(sd, "linear3", F.relu(_lin(sd, "linear2", F.relu(_lin(sd, "linear1", x)))))
+
+
+def policy_sample(sd, obs, eps, scale, bias):
+    """model.py:108-128 with the N(0,1) draw supplied by the caller."""
+    x = F.relu(_lin(sd, "linear2", F.relu(_lin(sd, "linear1", obs))))
+    mean = _lin(sd, "mean_linear", x)
+    log_std = torch.clamp(_lin(sd, "log_std_linear", x), min=LOG_SIG_MIN, max=LOG_SIG_MAX)
+    std = log_std.exp()
+    x_t = mean + eps * std
+    y_t = torch.tanh(x_t)
+    action = y_t * scale + bias
+    var = std ** 2
+    log_prob = -((x_t - mean) ** 2) / (2 * var) - log_std - math.log(math.sqrt(2 * math.pi))
+    log_prob = log_prob - torch.log(scale * (1 - y_t.pow(2)) + EPS)
+    log_prob = log_prob.sum(1, keepdim=True)
+    return action, log_prob, torch.tanh(mean) * scale + bias
+
+
+class AffineNode:
+    """model.py:177-217: ds/dt = f(x) + g(x) u ; action columns carried."""
+
+    def __init__(self, sd, n_s=3, n_u=2, f_layers=5, g_layers=4):
+        self.sd, self.n_s, self.n_u = sd, n_s, n_u
+        self.f_names = ["f_net.%d" % (2 * i) for i in range(f_layers)]
+        self.g_names = ["g_net.%d" % (2 * i) for i in range(g_layers)]
+        self.nfe = 0
+
+    def _mlp(self, names, x):
+        for n in names[:-1]:
+            x = F.relu(_lin(self.sd, n, x))
+        return _lin(self.sd, names[-1], x)
+
+    def __call__(self, t, s):
+        self.nfe += 1
+        x, u = s[..., :self.n_s], s[..., self.n_s:self.n_s + self.n_u]
+        f = self._mlp(self.f_names, x)
+        g = self._mlp(self.g_names, x).reshape(-1, self.n_s, self.n_u)
+        ds = f + torch.bmm(g, u.reshape(-1, self.n_u, 1)).squeeze(-1)
+        return torch.cat((ds, torch.zeros_like(u)), -1)
+
+
+# ---------------------------------------------------------------------------
+# odeint restatement (torchdiffeq 0.2.3 semantics; see module docstring)
+# ---------------------------------------------------------------------------
+
+_DP_ALPHA = [1 / 5, 3 / 10, 4 / 5, 8 / 9, 1.0, 1.0]
+_DP_BETA = [
+    [1 / 5],
+    [3 / 40, 9 / 40],
+    [44 / 45, -56 / 15, 32 / 9],
+    [19372 / 6561, -25360 / 2187, 64448 / 6561, -212 / 729],
+    [9017 / 3168, -355 / 33, 46732 / 5247, 49 / 176, -5103 / 18656],
+    [35 / 384, 0, 500 / 1113, 125 / 192, -2187 / 6784, 11 / 84],
+]
+_DP_C_SOL = [35 / 384, 0, 500 / 1113, 125 / 192, -2187 / 6784, 11 / 84, 0]
+_DP_C_ERR = [
+    35 / 384 - 1951 / 21600, 0, 500 / 1113 - 22642 / 50085, 125 / 192 - 451 / 720,
+    -2187 / 6784 - -12231 / 42400, 11 / 84 - 649 / 6300, -1. / 60.,
+]
+_DP_C_MID = [
+    6025192743 / 30085553152 / 2, 0, 51252292925 / 65400821598 / 2,
+    -2691868925 / 45128329728 / 2, 187940372067 / 1594534317056 / 2,
+    -1776094331 / 19743644256 / 2, 11237099 / 235043384 / 2,
+]
+
+
+def _rms(x):
+    return float(x.detach().double().pow(2).mean().sqrt())
+
+
+def dopri5_initial_step(func, t0, y0, f0, rtol, atol, order=4):
+    """Hairer's rule as in torchdiffeq ``_select_initial_step``; returns a
+    python float (step sizes carry no gradient in this restatement)."""
+    with torch.no_grad():
+        scale = atol + y0.abs() * rtol
+        d0, d1 = _rms(y0 / scale), _rms(f0 / scale)
+        h0 = 1e-6 if (d0 < 1e-5 or d1 < 1e-5) else 0.01 * d0 / d1
+        y1 = y0 + np.float32(h0) * f0
+        f1 = func(t0 + h0, y1)
+        d2 = _rms((f1 - f0) / scale) / h0
+        if d1 <= 1e-15 and d2 <= 1e-15:
+            h1 = max(1e-6, h0 * 1e-3)
+        else:
+            h1 = (0.01 / max(d1, d2)) ** (1.0 / float(order + 1))
+        return min(100 * h0, h1)
+
+
+def dopri5_step(func, t0, h, y0, f0):
+    """One Dormand–Prince 5(4) step (FSAL): returns y1, f1, err, k list."""
+    hf = np.float32(h)
+    k = [f0]
+    yi = y0
+    for a, beta in zip(_DP_ALPHA, _DP_BETA):
+        yi = y0
+        for bj, kj in zip(beta, k):
+            if bj != 0:
+                yi = yi + kj * (np.float32(bj) * hf)
+        k.append(func(t0 + a * h, yi))
+    y1, f1 = yi, k[-1]
+    err = sum(kj * (np.float32(c) * hf) for c, kj in zip(_DP_C_ERR, k))
+    return y1, f1, err, k
+
+
+def dopri5_interp(y0, y1, k, h, x):
+    """4th-order interpolant through (y0, y_mid, y1) evaluated at
+    x = (t - t0)/h (torchdiffeq ``_interp_fit`` / ``_interp_evaluate``)."""
+    hf = np.float32(h)
+    y_mid = y0 + sum(kj * (np.float32(c) * hf) for c, kj in zip(_DP_C_MID, k) if c != 0)
+    f0, f1 = k[0], k[-1]
+    a = 2 * hf * (f1 - f0) - 8 * (y1 + y0) + 16 * y_mid
+    b = hf * (5 * f0 - 3 * f1) + 18 * y0 + 14 * y1 - 32 * y_mid
+    c = hf * (f1 - 4 * f0) - 11 * y0 - 5 * y1 + 16 * y_mid
+    d = hf * f0
+    xf = np.float32(x)
+    return y0 + xf * (d + xf * (c + xf * (b + xf * a)))
+
+
+def odeint(func, y0, t, method="euler", atol=1e-7, rtol=1e-5, info=None):
+    """IVP solve on the grid ``t`` (only ``t=[t0,t1]`` is used on this path).
+
+    euler / rk4: one fixed step over [t0,t1] (fixed-grid solvers step on the
+    output grid when no ``step_size`` is given).  dopri5: adaptive, one shared
+    step size for the whole batch tensor, steps are not clipped to t1 — the
+    result is the interpolant at t1.
+    """
+    assert len(t) == 2
+    t0, t1 = float(t[0]), float(t[1])
+    dt = (t[1] - t[0]).to(y0.dtype) if torch.is_tensor(t) else np.float32(t1 - t0)
+    if method == "euler":
+        y1 = y0 + dt * func(t0, y0)
+    elif method == "rk4":  # 3/8 rule
+        k1 = func(t0, y0)
+        k2 = func(t0 + (t1 - t0) / 3, y0 + dt * k1 * (1.0 / 3.0))
+        k3 = func(t0 + (t1 - t0) * 2 / 3, y0 + dt * (k2 - k1 * (1.0 / 3.0)))
+        k4 = func(t1, y0 + dt * (k1 - k2 + k3))
+        y1 = y0 + (k1 + 3 * (k2 + k3) + k4) * dt * 0.125
+    elif method == "dopri5":
+        f0 = func(t0, y0)
+        h = dopri5_initial_step(func, t0, y0, f0, rtol, atol)
+        tc, yc, fc = t0, y0, f0
+        steps = []
+        n = 0
+        while True:
+            assert n < 1000, "max_num_steps exceeded"
+            n += 1
+            yn, fn, err, k = dopri5_step(func, tc, h, yc, fc)
+            with torch.no_grad():
+                tol = atol + rtol * torch.max(yc.abs(), yn.abs())
+                ratio = _rms(err / tol)
+            accept = ratio <= 1
+            steps.append((h, ratio, accept))
+            if ratio == 0:
+                fac = 10.0
+            else:
+                dfac = 1.0 if ratio < 1 else 0.2
+                fac = min(10.0, max(0.9 / ratio ** 0.2, dfac))
+            h_next = h * fac
+            if accept:
+                if tc + h >= t1:
+                    y1 = dopri5_interp(yc, yn, k, h, (t1 - tc) / h)
+                    break
+                tc, yc, fc = tc + h, yn, fn
+            h = h_next
+        if info is not None:
+            info["steps"] = steps
+    else:
+        raise ValueError(method)
+    return torch.stack([y0, y1])
+
+
+# ---------------------------------------------------------------------------
+# the agent
+# ---------------------------------------------------------------------------
+
+def _leafify(sd_np):
+    return {k: torch.tensor(np.asarray(v), dtype=torch.float32, requires_grad=True)
+            for k, v in sd_np.items()}
+
+
+def _flat(ts):
+    return torch.cat([t.reshape(-1) for t in ts])
+
+
+class Args:
+    """Defaults of U/main.py:191-239 that the agent reads."""
+    gamma = 0.99
+    gamma_b = 50.0
+    tau = 0.005
+    alpha = 0.2
+    lr = 3e-4
+    batch_size = 128
+    hidden_size = 256
+    target_update_interval = 1
+    Lagrangian_multiplier_update_interval = 8
+    automatic_entropy_tuning = True
+    policy = "Gaussian"
+    seed = 0
+    cuda = False
+
+    def __init__(self, **kw):
+        for k, v in kw.items():
+            setattr(self, k, v)
+
+
+class OracleUnicycleAgent:
+    """Restatement of ``SAC_CBF_CLF`` (Unicycle copy) with explicit noise."""
+
+    def __init__(self, env, args, weights, solver="euler"):
+        self.env, self.args, self.solver = env, args, solver
+        self.gamma, self.gamma_b, self.tau = args.gamma, args.gamma_b, args.tau
+        self.alpha = args.alpha
+        self.backup_alpha = args.alpha
+        self.batch_size = args.batch_size
+        self.critic = _leafify(weights["critic"])
+        self.critic_target = {k: v.detach().clone() for k, v in self.critic.items()}
+        self.lya = _leafify(weights["lyapunov"])
+        self.lya_target = {k: v.detach().clone() for k, v in self.lya.items()}
+        self.policy = _leafify(weights["policy"])
+        self.backup = _leafify(weights["backup_policy"])
+        self.node = _leafify(weights["node"])
+        self.log_alpha = torch.zeros(1, requires_grad=True)
+        self.backup_log_alpha = torch.zeros(1, requires_grad=True)
+        A = torch.optim.Adam
+        self.opt = dict(
+            critic=A(self.critic.values(), lr=4e-4), lya=A(self.lya.values(), lr=4e-4),
+            policy=A(self.policy.values(), lr=args.lr), backup=A(self.backup.values(), lr=args.lr),
+            alpha=A([self.log_alpha], lr=args.lr), backup_alpha=A([self.backup_log_alpha], lr=args.lr),
+            node=A(self.node.values(), lr=1e-3))
+        hi = torch.tensor(env.action_space.high, dtype=torch.float32)
+        lo = torch.tensor(env.action_space.low, dtype=torch.float32)
+        self.scale, self.bias = (hi - lo) / 2.0, (hi + lo) / 2.0
+        self.target_entropy = -float(env.action_space.shape[0])
+        self.num_cbfs = len(env.hazards_locations)
+        self.num_constraints = self.num_cbfs + 1
+        self.lambda_values = [0.0] * self.num_constraints
+        self.backup_lambda_values = [0.0] * self.num_cbfs
+        self.augmented_term, self.augmented_ratio = 1.0, 1.0005
+        self.cost_limit = 0.0
+        self.hazards = torch.tensor(np.asarray(env.hazards_locations), dtype=torch.float32)
+        self.node_fn = AffineNode(self.node)
+
+    # -- helpers ------------------------------------------------------------
+    @staticmethod
+    def get_state(obs):
+        """dynamics.py:53-58 — atan2 in float64 on the host, cast back."""
+        o = obs.detach().double().numpy()
+        st = np.zeros((o.shape[0], 3))
+        st[:, 0], st[:, 1], st[:, 2] = o[:, 0], o[:, 1], np.arctan2(o[:, 3], o[:, 2])
+        return torch.from_numpy(st).float()
+
+    def _set_grads(self, params, grads):
+        for p, g in zip(params, grads):
+            p.grad = g
+
+    def _rollout(self, state, action):
+        y0 = torch.cat((state, action), -1)
+        t = torch.tensor([0, self.env.dt])
+        info = {}
+        y = odeint(self.node_fn, y0, t, method=self.solver, atol=1e-7, rtol=1e-5, info=info)[-1]
+        return y[:, :3], info
+
+    def _lookahead(self, st):
+        th = st[:, 2]
+        return torch.stack([st[:, 0] + L_P * torch.cos(th), st[:, 1] + L_P * torch.sin(th)], 1)
+
+    def _cbf_terms(self, ps, ps_next):
+        r = 1.05 * self.env.hazards_radius
+        hs = 0.5 * (((ps[:, None, :] - self.hazards[None]) ** 2).sum(2) - r ** 2)
+        hn = 0.5 * (((ps_next[:, None, :] - self.hazards[None]) ** 2).sum(2) - r ** 2)
+        return -((hn - hs) / self.env.dt) - self.gamma_b * hs
+
+    def _auglag(self, required, lambdas, updates, with_clf):
+        """sac_cbf_clf.py:506-528 (primary) / :623-638 (backup)."""
+        out = {}
+        ratio = 1.0
+        if with_clf:
+            other = torch.abs(torch.mean(required[:-1] - self.cost_limit))
+            lyac = torch.abs(required[-1] - self.cost_limit)
+            ratio = float(other / lyac)
+        req_d = required.detach()
+        if updates % self.args.Lagrangian_multiplier_update_interval == 0:
+            for i in range(len(lambdas)):
+                new = torch.as_tensor(lambdas[i], dtype=torch.float32) + self.augmented_term * req_d[i]
+                lambdas[i] = float(torch.clamp(new, 0.01, 400.0))
+        self.augmented_term = min(self.augmented_term * self.augmented_ratio, 200)
+        rho = self.augmented_term
+        n_cbf = len(required) - (1 if with_clf else 0)
+        loss = 0.0
+        for i in range(n_cbf):
+            g = required[i] - self.cost_limit
+            loss = loss + float(lambdas[i]) * g + rho / 2.0 * g * g
+        if with_clf:
+            g = required[-1] - self.cost_limit
+            loss = loss + float(lambdas[-1]) * ratio * g + ratio * ratio * rho / 2.0 * g * g
+        out.update(ratio=ratio, loss=loss)
+        return out
+
+    # -- NODE fit -------------------------------------------------------------
+    def train_step(self, node_obs, node_action, node_next_obs):
+        """model.py:221-260 via sac_cbf_clf.py:205-219."""
+        st, nst = self.get_state(node_obs), self.get_state(node_next_obs)
+        self.opt["node"].zero_grad()
+        pred, _ = self._rollout(st, node_action)
+        loss = F.mse_loss(pred, nst)
+        g = torch.autograd.grad(loss, list(self.node.values()))
+        self._set_grads(self.node.values(), g)
+        self.opt["node"].step()
+        return float(loss), _flat(g)
+
+    # -- one update -----------------------------------------------------------
+    def update(self, batch, eps, updates, node_batch=None):
+        """``batch``: dict of float32 tensors (obs, action, reward, constraint,
+        center, next_center, next_obs, mask); ``eps``: three (B,2) draws in the
+        reference order (next_obs sample, obs sample, backup sample)."""
+        R = {}
+        if node_batch is not None:
+            R["node_loss"], R["g_node"] = self.train_step(*node_batch)
+        obs, nobs, act = batch["obs"], batch["next_obs"], batch["action"]
+        rew, con = batch["reward"].unsqueeze(1), batch["constraint"].unsqueeze(1)
+        cen, ncen, mask = batch["center"], batch["next_center"], batch["mask"].unsqueeze(1)
+        dt = self.env.dt
+
+        with torch.no_grad():
+            na, nlogp, _ = policy_sample(self.policy, nobs, eps[0], self.scale, self.bias)
+            q1t, q2t = qnet(self.critic_target, nobs, na)
+            next_q = rew + mask * self.gamma * (torch.min(q1t, q2t) - self.alpha * nlogp)
+            next_l = con + mask * self.gamma * lyanet(self.lya_target, ncen)
+        q1, q2 = qnet(self.critic, obs, act)
+        qf1_loss, qf2_loss = F.mse_loss(q1, next_q), F.mse_loss(q2, next_q)
+        lf_loss = F.mse_loss(lyanet(self.lya, cen), next_l)
+        gc = torch.autograd.grad(qf1_loss + qf2_loss, list(self.critic.values()))
+        gl = torch.autograd.grad(lf_loss, list(self.lya.values()))
+        self._set_grads(self.critic.values(), gc)
+        self.opt["critic"].step()
+        self._set_grads(self.lya.values(), gl)
+        self.opt["lya"].step()
+        R.update(g_critic=_flat(gc), g_lya=_flat(gl), next_q=next_q, next_l=next_l)
+
+        pi, log_pi, _ = policy_sample(self.policy, obs, eps[1], self.scale, self.bias)
+        min_q_pi = torch.min(*qnet(self.critic, obs, pi))
+        bpi, blog_pi, _ = policy_sample(self.backup, obs, eps[2], self.scale, self.bias)
+        bmin_q = torch.min(*qnet(self.critic, obs, bpi))
+        policy_loss_1 = ((self.alpha * log_pi) - min_q_pi).mean()
+        backup_loss_1 = ((self.backup_alpha * blog_pi) - bmin_q).mean()
+
+        # primary: CLF + CBFs (sac_cbf_clf.py:364-386, 408-530)
+        state = self.get_state(obs)
+        V = lyanet(self.lya, cen).detach()
+        ps = self._lookahead(state)
+        x_next, info = self._rollout(state, pi)
+        ps_next = self._lookahead(x_next)
+        V_next = lyanet(self.lya, ps_next)
+        lya_term = ((V_next - V) / dt) + 1.0 * V
+        matr = torch.cat((self._cbf_terms(ps, ps_next), lya_term), 1)
+        required = torch.where(matr > 0, matr, torch.zeros_like(matr)).sum(0) / self.batch_size
+        al = self._auglag(required, self.lambda_values, updates, True)
+        R.update(x_next=x_next.detach(), matr=matr.detach(), required=required.detach(),
+                 ratio=al["ratio"], ode_info=info)
+
+        # backup: CBFs only (:388-406, 532-640)
+        bx_next, binfo = self._rollout(state, bpi)
+        bps_next = self._lookahead(bx_next)
+        bmatr = self._cbf_terms(ps, bps_next)
+        brequired = torch.where(bmatr > 0, bmatr, torch.zeros_like(bmatr)).sum(0) / self.batch_size
+        bal = self._auglag(brequired, self.backup_lambda_values, updates, False)
+        R.update(bx_next=bx_next.detach(), bmatr=bmatr.detach(), brequired=brequired.detach(),
+                 bode_info=binfo)
+
+        policy_loss = policy_loss_1 + al["loss"]
+        backup_loss = backup_loss_1 + bal["loss"]
+        gp = torch.autograd.grad(policy_loss, list(self.policy.values()))
+        gb = torch.autograd.grad(backup_loss, list(self.backup.values()))
+        self._set_grads(self.policy.values(), gp)
+        self.opt["policy"].step()
+        self._set_grads(self.backup.values(), gb)
+        self.opt["backup"].step()
+        R.update(g_policy=_flat(gp), g_backup=_flat(gb),
+                 policy_loss_2=float(al["loss"]), backup_policy_loss_2=float(bal["loss"]))
+
+        alpha_loss = -(self.log_alpha * (log_pi + self.target_entropy).detach()).mean()
+        self.log_alpha.grad = torch.autograd.grad(alpha_loss, self.log_alpha)[0]
+        self.opt["alpha"].step()
+        self.alpha = float(self.log_alpha.exp())
+        balpha_loss = -(self.backup_log_alpha * (blog_pi + self.target_entropy).detach()).mean()
+        self.backup_log_alpha.grad = torch.autograd.grad(balpha_loss, self.backup_log_alpha)[0]
+        self.opt["backup_alpha"].step()
+        self.backup_alpha = float(self.backup_log_alpha.exp())
+
+        if updates % self.args.target_update_interval == 0:
+            with torch.no_grad():
+                for tgt, src in ((self.critic_target, self.critic), (self.lya_target, self.lya)):
+                    for k in tgt:
+                        tgt[k].copy_(tgt[k] * (1.0 - self.tau) + src[k] * self.tau)
+
+        R["ret"] = (float(qf1_loss), float(qf2_loss), float(lf_loss), float(policy_loss_1),
+                    float(alpha_loss), float(self.alpha))
+        R.update(backup_policy_loss_1=float(backup_loss_1), backup_alpha=self.backup_alpha,
+                 lambdas=list(self.lambda_values), backup_lambdas=list(self.backup_lambda_values),
+                 augmented_term=self.augmented_term, log_pi=log_pi.detach(), pi=pi.detach())
+        return R
