@@ -1,0 +1,229 @@
+/*
+ * nlbac_hip.h — C ABI of the MI355X (gfx950) NLBAC hot path.
+ *
+ * The reference (pure Python) has no native interface; what a drop-in has to
+ * replace are the PyTorch/ATen op sequences behind these reference call sites
+ * (U = NLBAC_Unicycle_RL_training/Unicycle_RL_training):
+ *
+ *   nlbac_mlp_*            QNetwork / LyaNetwork / GaussianPolicy.forward and the
+ *                          autograd backward through them   U/sac_cbf_clf/model.py:37-114
+ *                          f_net / g_net of NeuralODEModel   U/sac_cbf_clf/model.py:186-206
+ *   nlbac_gauss_*          GaussianPolicy.sample             U/sac_cbf_clf/model.py:116-128
+ *   nlbac_td_targets       target / MSE block                U/sac_cbf_clf/sac_cbf_clf.py:231-246
+ *   nlbac_unicycle_*       get_state + get_policy_loss_2 / backup_get_policy_loss_2
+ *                                                            U/sac_cbf_clf/dynamics.py:53-58
+ *                                                            U/sac_cbf_clf/sac_cbf_clf.py:408-640
+ *   nlbac_ode_*            torchdiffeq.odeint call sites     U/sac_cbf_clf/sac_cbf_clf.py:453,577
+ *                                                            U/sac_cbf_clf/model.py:252
+ *   nlbac_adam_* / soft    torch.optim.Adam.step, soft_update
+ *                                                            U/sac_cbf_clf/sac_cbf_clf.py:249-255,284-308
+ *                                                            U/sac_cbf_clf/utils.py:75-79
+ *
+ * Conventions: every pointer is a DEVICE pointer to fp32 unless stated; no
+ * entry point allocates, frees or synchronises; all work is enqueued on the
+ * caller's stream (a hipStream_t passed as void*).  Return 0 on success,
+ * <0 on error (text via nlbac_last_error()).  Matrices are row-major with an
+ * explicit leading dimension (`*_ld`, in floats).
+ */
+#ifndef NLBAC_HIP_H
+#define NLBAC_HIP_H
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define NLBAC_ABI_VERSION 1
+#define NLBAC_MAX_LAYERS 6
+#define NLBAC_MAX_NETS 8
+#define NLBAC_MLP_TILE 32 /* samples per workgroup in the MLP kernels */
+
+typedef void *nlbac_stream_t; /* hipStream_t */
+
+int nlbac_abi_version(void);
+const char *nlbac_last_error(void);
+
+/* ------------------------------------------------------------------------
+ * ReLU MLP:  in_dim -> hid -> ... -> hid -> out_dim   (n_layers Linear layers;
+ * layers 0..n_layers-2 are "wide" (hid outputs, ReLU, run on MFMA), the last
+ * layer is "skinny" (out_dim <= 16, no activation, run on VALU).
+ *
+ * Parameters live in ONE flat fp32 buffer in the layout of
+ * torch.nn.Linear: W_l [N_l][K_l] row-major at params+w_off[l], bias at
+ * params+b_off[l].  Gradients use the same offsets inside a "grad slab".
+ * `packed` holds MFMA-fragment-ordered copies of the wide layers, written by
+ * nlbac_mlp_pack() after every optimiser step:
+ *   pf_off[l]  forward pack of layer l      (B operand of  Y = X W^T)
+ *   pb_off[l]  backward pack of layer l>=1  (B operand of dX = dY W ), -1 if none
+ * ---------------------------------------------------------------------- */
+typedef struct nlbac_mlp {
+    int n_layers, in_dim, hid, out_dim;
+    const float *params;
+    int w_off[NLBAC_MAX_LAYERS];
+    int b_off[NLBAC_MAX_LAYERS];
+    float *packed;
+    int pf_off[NLBAC_MAX_LAYERS];
+    int pb_off[NLBAC_MAX_LAYERS];
+} nlbac_mlp;
+
+/* Per-launch tensors of one net.  Unused pointers are NULL. */
+typedef struct nlbac_mlp_io {
+    const float *x0; int x0_dim, x0_ld; /* input columns [0, x0_dim)                */
+    const float *x1; int x1_dim, x1_ld; /* input columns [x0_dim, in_dim) or NULL   */
+    float *y; int y_ld;                 /* fwd out: (B, out_dim)                    */
+    float *acts;                        /* [n_layers-1][B][hid] post-ReLU, saved by fwd */
+    const float *dy; int dy_ld;         /* bwd in:  (B, out_dim)                    */
+    float *dz;                          /* [n_layers-1][B][hid] pre-activation grads (bwd_data out, bwd_weights in) */
+    float *dx; int dx_ld;               /* bwd_data out: (B, in_dim) or NULL        */
+    float *grad;                        /* bwd_weights out: slab 0 of the flat grad (same offsets as params) */
+} nlbac_mlp_io;
+
+/* number of floats nlbac_mlp_pack needs in `packed`, and the offsets it will use */
+int nlbac_mlp_pack_layout(nlbac_mlp *net /* in: n_layers,in_dim,hid ; out: pf_off,pb_off */);
+int nlbac_mlp_pack(const nlbac_mlp *nets, int n_nets, nlbac_stream_t s);
+
+/* y = MLP(x) for n_nets independent nets over the same B rows (grid.y = net). */
+int nlbac_mlp_fwd(const nlbac_mlp *nets, const nlbac_mlp_io *io, int n_nets, int B, nlbac_stream_t s);
+/* dz (all wide layers) and optionally dx from dy and the saved activations. */
+int nlbac_mlp_bwd_data(const nlbac_mlp *nets, const nlbac_mlp_io *io, int n_nets, int B, nlbac_stream_t s);
+/* grad slabs [n_slabs][slab_stride] += nothing: each slab s receives the sum over
+ * its row range [s*rows_per_slab, ...) — slabs are fully overwritten for the
+ * nets given (deterministic; reduce with nlbac_adam_step / nlbac_reduce_slabs). */
+int nlbac_mlp_bwd_weights(const nlbac_mlp *nets, const nlbac_mlp_io *io, int n_nets, int B,
+                          int n_slabs, long slab_stride, nlbac_stream_t s);
+
+/* ------------------------------------------------------------------------
+ * Optimiser (torch.optim.Adam defaults: betas .9/.999, eps 1e-8, no decay).
+ * `state` = {int step; float step_size; float bc2_sqrt; float pad} on device.
+ * ---------------------------------------------------------------------- */
+int nlbac_adam_prepare(void *state, double lr, nlbac_stream_t s); /* ++step, bias corrections */
+/* p,m,v: n floats; grad: n_slabs slabs (summed in slab order); if target!=NULL:
+ * target = (1-tau) target + tau p_new  (soft_update fused; tau<0 disables). */
+int nlbac_adam_step(float *p, float *m, float *v, const float *grad, int n_slabs, long slab_stride,
+                    long n, const void *state, float *target, float tau, nlbac_stream_t s);
+int nlbac_reduce_slabs(float *out, const float *grad, int n_slabs, long slab_stride, long n, nlbac_stream_t s);
+int nlbac_soft_update(float *target, const float *src, long n, float tau, nlbac_stream_t s);
+
+/* ------------------------------------------------------------------------
+ * Squashed-Gaussian policy head (model.py:116-128).  heads = (n, 2*n_u):
+ * [mean | log_std]; eps ~ N(0,1) supplied by the caller (n, n_u).
+ * ---------------------------------------------------------------------- */
+int nlbac_gauss_sample_fwd(const float *heads, int heads_ld, const float *eps, const float *scale,
+                           const float *bias, int n_u, int n, float *action, int action_ld,
+                           float *logp, nlbac_stream_t s);
+/* d heads from d action = da0+da1+da2 (each (n,n_u) with its own ld, may be NULL)
+ * and a uniform d logp = alpha[row / rows_per_problem] * dlogp_mul. */
+int nlbac_gauss_sample_bwd(const float *heads, int heads_ld, const float *eps, const float *scale,
+                           int n_u, int n, int rows_per_problem, const float *da0, int da0_ld,
+                           const float *da1, int da1_ld, const float *da2, int da2_ld,
+                           const float *alpha, float dlogp_mul, float *dheads, int dheads_ld,
+                           nlbac_stream_t s);
+
+/* ------------------------------------------------------------------------
+ * Scalars block `sc` (device, NLBAC_SC_SIZE floats): alpha, lambdas, rho,
+ * loss coefficients and per-update loss outputs.  Layout: csrc/scalars.h
+ * (mirrored in nlbac_amd/sac_cbf_clf/_layout.py).
+ * ---------------------------------------------------------------------- */
+#define NLBAC_SC_SIZE 128
+
+/* TD / Lyapunov targets, MSE partial sums and dL/dq (sac_cbf_clf.py:231-246).
+ * All q-like arguments are (B) vectors; alpha = sc+SC_ALPHA.
+ * partials: [ceil(B/256)][3] squared-error sums (qf1, qf2, lf). */
+int nlbac_td_targets(const float *q1t, const float *q2t, const float *lt, const float *nlogp,
+                     const float *reward, const float *constraint, const float *mask,
+                     const float *q1, const float *q2, const float *lf, const float *alpha,
+                     float gamma, int B, float *dq1, float *dq2, float *dlf, float *next_q,
+                     float *next_l, float *partials, nlbac_stream_t s);
+
+/* policy_loss_1 pieces for P controllers (rows p*B..): d min(Q1,Q2)/dq * (-1/B) and
+ * partials [P][ceil(B/256)][2] = sums of (alpha_p*logp - minq, logp)
+ * (sac_cbf_clf.py:258-273). */
+int nlbac_actor_q_terms(const float *q1, const float *q2, const float *logp, const float *alpha,
+                        int B, int P, float *dq1, float *dq2, float *partials, nlbac_stream_t s);
+/* policy_loss_1, alpha_loss into sc; d alpha_loss / d log_alpha into g_log_alpha
+ * (sac_cbf_clf.py:292-308).  log_alpha[p*stride]. */
+int nlbac_actor_scalars(const float *partials, int n_blk, int B, int P, float target_entropy,
+                        const float *log_alpha, int log_alpha_stride, float *g_log_alpha, float *sc,
+                        nlbac_stream_t s);
+/* sc[SC_ALPHA+p] = exp(log_alpha[p*stride])  (sac_cbf_clf.py:299,308) */
+int nlbac_alpha_refresh(const float *log_alpha, int log_alpha_stride, int P, float *sc, nlbac_stream_t s);
+
+/* Unicycle geometry: obs -> state (atan2 in fp64 then cast, dynamics.py:53-58) and look-ahead
+ * p(x) = xy + l_p (cos th, sin th) (sac_cbf_clf.py:429-437, 455-469). */
+int nlbac_unicycle_state(const float *obs, int obs_ld, int B, float l_p, float *state /*(B,3)*/,
+                         float *ps /*(B,2) or NULL*/, nlbac_stream_t s);
+int nlbac_unicycle_lookahead(const float *x /*(n,3)*/, int n, float l_p, float *ps /*(n,2)*/, nlbac_stream_t s);
+int nlbac_unicycle_lookahead_bwd(const float *x, const float *dps, const float *dps2 /*or NULL*/, int n,
+                                 float l_p, float *dx /*(n,3)*/, nlbac_stream_t s);
+
+/* CBF/CLF terms, relu filter and column partial sums (sac_cbf_clf.py:471-504, 596-621).
+ * ps (B,2); ps_next (2B,2): primary rows then backup rows.  matr (B,n_hz+1) and bmatr (B,n_hz)
+ * are kept for the backward.  partials [ceil(B/256)][2*n_hz+1]. */
+int nlbac_unicycle_constraints_fwd(const float *ps, const float *ps_next, const float *V,
+                                   const float *V_next, const float *hazards, int n_hz, float r_coll,
+                                   float dt, float gamma_b, float gamma_l, int B, float *matr,
+                                   float *bmatr, float *partials, nlbac_stream_t s);
+/* required_matrix, ratio, lambda update (clamp [lam_lo,lam_hi]), rho *= 1.0005 (cap 200), loss values and
+ * loss coefficients, primary then backup (sac_cbf_clf.py:502-528, 619-638).
+ * ratio_mode: 0 none (NU), 1 plain (U), 2 clamp at 0.002 (C/P/NP).  shared_rho: U/C share augmented_term. */
+int nlbac_auglag(const float *partials, int n_blk, int n_cbf, int n_clf, float batch_size,
+                 int do_lambda_update, int ratio_mode, int shared_rho, float lam_lo, float lam_hi,
+                 float *sc, nlbac_stream_t s);
+/* d ps_next (2B,2) [CBF part] and dV_next (B) from the coefficients in sc. */
+int nlbac_unicycle_constraints_bwd(const float *ps_next, const float *matr, const float *bmatr,
+                                   const float *hazards, int n_hz, float dt, float batch_size, int B,
+                                   const float *sc, float *dps_next, float *dV_next, nlbac_stream_t s);
+
+/* nn.MSELoss('mean') over (n,d): dpred and per-block squared-error partials [ceil(n/256)] (model.py:256). */
+int nlbac_mse_fwd_bwd(const float *pred, int pred_ld, const float *target, int target_ld, int n, int d,
+                      float *dpred, int dpred_ld, float *partials, nlbac_stream_t s);
+
+/* ------------------------------------------------------------------------
+ * Control-affine NODE field  k = f(x) + g(x) u  (model.py:208-217) and the
+ * explicit RK algebra of odeint on t=[t0,t1] (euler, rk4 3/8-rule, dopri5).
+ * Rows are P problems x rows_per_problem; stage derivatives are stage-major
+ * K[stage][row][n_s].  A step size is per problem: h_host[P] (host floats,
+ * passed by value) unless h_dev != NULL (device doubles, stride in doubles).
+ * ---------------------------------------------------------------------- */
+int nlbac_affine_combine_fwd(const float *f, const float *g, const float *u, int n_s, int n_u, int n,
+                             float *k, nlbac_stream_t s);
+/* dg[r][c] = dk[r] u[c] (dg may be NULL); du[c] (+)= mul * sum_r g[r][c] dk[r] (du may be NULL); df == dk */
+int nlbac_affine_combine_bwd(const float *dk, const float *g, const float *u, int n_s, int n_u, int n,
+                             float mul, float *dg, float *du, int accumulate_du, nlbac_stream_t s);
+/* out = (y0 ? y0 : 0) + sum_{j<n_k} (coef[j]*h_p) K[j] */
+int nlbac_rk_combine(const float *y0, const float *K, int n_k, const float *coef, const float *h_host,
+                     const double *h_dev, int h_dev_stride, int P, int rows_per_problem, int n_s,
+                     float *out, nlbac_stream_t s);
+/* dY = dYup + dXf + dXg (any may be NULL; dX* have leading dim dx_ld);
+ * dy0 (+)= dY (dy0 may be NULL); dK[j] += coef[j]*h_p*dY for j<n_k */
+int nlbac_rk_stage_bwd(const float *dYup, const float *dXf, const float *dXg, int dx_ld, int n_k,
+                       const float *coef, const float *h_host, const double *h_dev, int h_dev_stride,
+                       int P, int rows_per_problem, int n_s, float *dK, float *dy0, int accumulate_dy0,
+                       nlbac_stream_t s);
+/* dopri5 step control on the device.  ctl: per problem NLBAC_DOPRI_CTL doubles
+ * {h, t, ratio, accept, done, x, h0, d0, d1, d2, n_steps, h_used}.
+ * norm partials [P][ceil(rows/256)][2]; mode 0: (y0/scale, f0/scale) with a=f0;
+ * mode 1: (f1-f0)/scale with a=f1,b=f0; mode 2: err/tol with a=err. */
+#define NLBAC_DOPRI_CTL 16
+int nlbac_dopri_norm_partials(const float *a, const float *b, const float *y0, const float *y1,
+                              const float *u, int mode, float rtol, float atol, int n_s, int n_u,
+                              int rows_per_problem, int P, float *partials, nlbac_stream_t s);
+int nlbac_dopri_control(const float *partials, int n_blk_per_problem, int mode, int n_s, int n_u,
+                        int rows_per_problem, int P, double t_end, double *ctl, nlbac_stream_t s);
+/* y(t_end) from the accepted step's stages (4th-order interpolant, x=(t_end-t)/h) and its backward
+ * (writes dy0, dy1, dK[0..6]). */
+int nlbac_dopri_interp_fwd(const float *y0, const float *y1, const float *K, const float *h_host,
+                           const float *x_host, int P, int rows_per_problem, int n_s, float *out,
+                           nlbac_stream_t s);
+int nlbac_dopri_interp_bwd(const float *dout, const float *h_host, const float *x_host, int P,
+                           int rows_per_problem, int n_s, float *dy0, float *dy1, float *dK,
+                           nlbac_stream_t s);
+
+/* small utilities */
+int nlbac_axpby(float a, const float *x, float b, const float *y /*or NULL*/, long n, float *out, nlbac_stream_t s);
+int nlbac_fill(float *p, float v, long n, nlbac_stream_t s);
+int nlbac_sum_partials(const float *partials, int n_blk, int n_cols, float mul, float *out, nlbac_stream_t s);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* NLBAC_HIP_H */

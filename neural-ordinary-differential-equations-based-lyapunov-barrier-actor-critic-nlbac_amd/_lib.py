@@ -1,0 +1,139 @@
+"""ctypes binding of ``lib/libnlbac_hip.so`` (the C ABI in ``include/nlbac_hip.h``).
+
+There is no fallback: if the library is missing or an entry point is absent,
+importing/using this module raises.  ``build()`` compiles it in-tree with
+hipcc for gfx950 (cross-compiles without a GPU).
+"""
+import ctypes as C
+import os
+import subprocess
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "lib", "libnlbac_hip.so")
+CSRC = os.path.join(_HERE, "csrc")
+
+MAX_LAYERS, MAX_NETS, MLP_TILE = 6, 8, 32
+SC_SIZE, DOPRI_CTL = 128, 16
+
+c_float_p = C.POINTER(C.c_float)
+c_double_p = C.POINTER(C.c_double)
+
+
+class NlbacError(RuntimeError):
+    pass
+
+
+class Mlp(C.Structure):
+    """``struct nlbac_mlp``"""
+    _fields_ = [("n_layers", C.c_int), ("in_dim", C.c_int), ("hid", C.c_int), ("out_dim", C.c_int),
+                ("params", C.c_void_p),
+                ("w_off", C.c_int * MAX_LAYERS), ("b_off", C.c_int * MAX_LAYERS),
+                ("packed", C.c_void_p),
+                ("pf_off", C.c_int * MAX_LAYERS), ("pb_off", C.c_int * MAX_LAYERS)]
+
+
+class MlpIO(C.Structure):
+    """``struct nlbac_mlp_io``"""
+    _fields_ = [("x0", C.c_void_p), ("x0_dim", C.c_int), ("x0_ld", C.c_int),
+                ("x1", C.c_void_p), ("x1_dim", C.c_int), ("x1_ld", C.c_int),
+                ("y", C.c_void_p), ("y_ld", C.c_int),
+                ("acts", C.c_void_p),
+                ("dy", C.c_void_p), ("dy_ld", C.c_int),
+                ("dz", C.c_void_p),
+                ("dx", C.c_void_p), ("dx_ld", C.c_int),
+                ("grad", C.c_void_p)]
+
+
+_P, _I, _F, _D, _L = C.c_void_p, C.c_int, C.c_float, C.c_double, C.c_long
+
+# name -> argtypes (return type is always int unless listed in _RESTYPE)
+_PROTOS = {
+    "nlbac_abi_version": [],
+    "nlbac_last_error": [],
+    "nlbac_mlp_pack_layout": [C.POINTER(Mlp)],
+    "nlbac_mlp_pack": [C.POINTER(Mlp), _I, _P],
+    "nlbac_mlp_fwd": [C.POINTER(Mlp), C.POINTER(MlpIO), _I, _I, _P],
+    "nlbac_mlp_bwd_data": [C.POINTER(Mlp), C.POINTER(MlpIO), _I, _I, _P],
+    "nlbac_mlp_bwd_weights": [C.POINTER(Mlp), C.POINTER(MlpIO), _I, _I, _I, _L, _P],
+    "nlbac_adam_prepare": [_P, _D, _P],
+    "nlbac_adam_step": [_P, _P, _P, _P, _I, _L, _L, _P, _P, _F, _P],
+    "nlbac_reduce_slabs": [_P, _P, _I, _L, _L, _P],
+    "nlbac_soft_update": [_P, _P, _L, _F, _P],
+    "nlbac_gauss_sample_fwd": [_P, _I, _P, _P, _P, _I, _I, _P, _I, _P, _P],
+    "nlbac_gauss_sample_bwd": [_P, _I, _P, _P, _I, _I, _I, _P, _I, _P, _I, _P, _I, _P, _F, _P, _I, _P],
+    "nlbac_td_targets": [_P] * 11 + [_F, _I] + [_P] * 6 + [_P],
+    "nlbac_actor_q_terms": [_P, _P, _P, _P, _I, _I, _P, _P, _P, _P],
+    "nlbac_actor_scalars": [_P, _I, _I, _I, _F, _P, _I, _P, _P, _P],
+    "nlbac_alpha_refresh": [_P, _I, _I, _P, _P],
+    "nlbac_unicycle_state": [_P, _I, _I, _F, _P, _P, _P],
+    "nlbac_unicycle_lookahead": [_P, _I, _F, _P, _P],
+    "nlbac_unicycle_lookahead_bwd": [_P, _P, _P, _I, _F, _P, _P],
+    "nlbac_unicycle_constraints_fwd": [_P, _P, _P, _P, _P, _I, _F, _F, _F, _F, _I, _P, _P, _P, _P],
+    "nlbac_auglag": [_P, _I, _I, _I, _F, _I, _I, _I, _F, _F, _P, _P],
+    "nlbac_unicycle_constraints_bwd": [_P, _P, _P, _P, _I, _F, _F, _I, _P, _P, _P, _P],
+    "nlbac_mse_fwd_bwd": [_P, _I, _P, _I, _I, _I, _P, _I, _P, _P],
+    "nlbac_affine_combine_fwd": [_P, _P, _P, _I, _I, _I, _P, _P],
+    "nlbac_affine_combine_bwd": [_P, _P, _P, _I, _I, _I, _F, _P, _P, _I, _P],
+    "nlbac_rk_combine": [_P, _P, _I, c_float_p, c_float_p, _P, _I, _I, _I, _I, _P, _P],
+    "nlbac_rk_stage_bwd": [_P, _P, _P, _I, _I, c_float_p, c_float_p, _P, _I, _I, _I, _I, _P, _P, _I, _P],
+    "nlbac_dopri_norm_partials": [_P, _P, _P, _P, _P, _I, _F, _F, _I, _I, _I, _I, _P, _P],
+    "nlbac_dopri_control": [_P, _I, _I, _I, _I, _I, _I, _D, _P, _P],
+    "nlbac_dopri_interp_fwd": [_P, _P, _P, c_float_p, c_float_p, _I, _I, _I, _P, _P],
+    "nlbac_dopri_interp_bwd": [_P, c_float_p, c_float_p, _I, _I, _I, _P, _P, _P, _P],
+    "nlbac_axpby": [_F, _P, _F, _P, _L, _P, _P],
+    "nlbac_fill": [_P, _F, _L, _P],
+    "nlbac_sum_partials": [_P, _I, _I, _F, _P, _P],
+}
+_RESTYPE = {"nlbac_last_error": C.c_char_p}
+
+EXPORTS = tuple(_PROTOS)
+
+_lib = None
+
+
+def build(verbose=False):
+    """Compile every HIP source for gfx950 into lib/libnlbac_hip.so (in-tree)."""
+    r = subprocess.run(["make", "-C", CSRC, "-j4"], capture_output=True, text=True)
+    if verbose or r.returncode != 0:
+        print(r.stdout[-4000:])
+        print(r.stderr[-4000:])
+    if r.returncode != 0:
+        raise NlbacError("hipcc build failed (see output above)")
+    return LIB_PATH
+
+
+def load():
+    """Load the shared library once and type every entry point."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise NlbacError("HIP extension missing: %s (run __graft_entry__.build() / make -C %s); "
+                         "there is no CPU fallback" % (LIB_PATH, CSRC))
+    lib = C.CDLL(LIB_PATH)
+    for name, argtypes in _PROTOS.items():
+        fn = getattr(lib, name)   # AttributeError if the symbol is not exported
+        fn.argtypes = argtypes
+        fn.restype = _RESTYPE.get(name, C.c_int)
+    if lib.nlbac_abi_version() != 1:
+        raise NlbacError("ABI version mismatch")
+    _lib = lib
+    return lib
+
+
+def check(rc, what=""):
+    if rc != 0:
+        raise NlbacError("%s failed: %s" % (what, load().nlbac_last_error().decode()))
+
+
+def call(name, *args):
+    """Call an int-returning entry point and raise on error."""
+    lib = load()
+    rc = getattr(lib, name)(*args)
+    if rc != 0:
+        raise NlbacError("%s: %s" % (name, lib.nlbac_last_error().decode()))
+
+
+def fptr(*vals):
+    """Host float array argument (passed by value into kernel args)."""
+    return (C.c_float * len(vals))(*vals)

@@ -1,0 +1,157 @@
+"""Flat device buffers for parameters / gradients / Adam state, and the MLP
+descriptors (``struct nlbac_mlp``) that point into them.
+
+HBM layout (one ``Arena`` per optimiser group):
+
+    theta   [n]                canonical fp32 parameters (torch.nn.Linear layout);
+                               every ``nn.Parameter`` of the bound modules is a
+                               *view* into it, so ``state_dict()`` keeps the
+                               reference key names and checkpoints interoperate
+    grad    [n_slabs][n]       per-row-range gradient slabs written by
+                               ``nlbac_mlp_bwd_weights`` (deterministic), summed
+                               in slab order inside ``nlbac_adam_step``
+    m, v    [n]                Adam moments
+    target  [n] (optional)     Polyak-averaged copy (critic/Lyapunov targets)
+    state   16 B               {step, lr/(1-b1^t), sqrt(1-b2^t)} on device
+
+Every tensor group starts on a 16-byte boundary (float4 loads in the kernels).
+"""
+import ctypes as C
+
+import torch
+
+from . import _lib
+from ._lib import MAX_LAYERS, Mlp, MlpIO
+
+
+def _align4(n):
+    return (n + 3) & ~3
+
+
+class Arena:
+    def __init__(self, device, n_slabs=8, with_target=False):
+        self.device = torch.device(device)
+        self.n_slabs = n_slabs
+        self.with_target = with_target
+        self._pending = []      # (param, offset)
+        self.size = 0
+        self.theta = None
+
+    def add_group(self, params):
+        """Reserve contiguous space for a list of nn.Parameters (no padding
+        between them); returns their offsets."""
+        offs = []
+        self.size = _align4(self.size)
+        for p in params:
+            offs.append(self.size)
+            self._pending.append((p, self.size))
+            self.size += p.numel()
+        return offs
+
+    def finalize(self):
+        n = _align4(self.size)
+        self.n = n
+        dev = self.device
+        self.theta = torch.zeros(n, dtype=torch.float32, device=dev)
+        self.grad = torch.zeros(self.n_slabs, n, dtype=torch.float32, device=dev)
+        self.m = torch.zeros(n, dtype=torch.float32, device=dev)
+        self.v = torch.zeros(n, dtype=torch.float32, device=dev)
+        self.target = torch.zeros(n, dtype=torch.float32, device=dev) if self.with_target else None
+        self.state = torch.zeros(4, dtype=torch.int32, device=dev)   # AdamState
+        self.offset_of = {}
+        with torch.no_grad():
+            for p, off in self._pending:
+                view = self.theta[off:off + p.numel()].view(p.shape)
+                view.copy_(p.data.to(dev))
+                p.data = view
+                self.offset_of[id(p)] = off
+        return self
+
+    def hard_update_target(self):
+        self.target.copy_(self.theta)
+
+    def grad_view(self, p, slab=None):
+        off = self.offset_of[id(p)]
+        g = self.grad[:, off:off + p.numel()]
+        return g.sum(0).view(p.shape) if slab is None else g[slab].view(p.shape)
+
+
+class MlpHandle:
+    """One ReLU MLP inside an Arena: builds ``struct nlbac_mlp`` (for the live
+    parameters and optionally for the target copy) and owns the packed weights."""
+
+    def __init__(self, arena, layers, name=""):
+        """layers: list of (weight_param(s), bias_param(s)); the last entry may
+        hold lists (policy heads: [mean_W, logstd_W], [mean_b, logstd_b])."""
+        self.arena, self.name = arena, name
+        self.layers = layers
+        flat = []
+        for W, b in layers:
+            Ws = list(W) if isinstance(W, (list, tuple)) else [W]
+            bs = list(b) if isinstance(b, (list, tuple)) else [b]
+            flat.append((Ws, bs))
+        self._flat = flat
+        self.n_layers = len(flat)
+        assert 2 <= self.n_layers <= MAX_LAYERS
+        W0 = flat[0][0][0]
+        self.in_dim, self.hid = W0.shape[1], W0.shape[0]
+        self.out_dim = sum(w.shape[0] for w in flat[-1][0])
+        for Ws, bs in flat:               # contiguous groups: W's then b's
+            arena.add_group(Ws)
+            arena.add_group(bs)
+        self.desc = None
+        self.desc_target = None
+
+    def bind(self):
+        a = self.arena
+        d = Mlp()
+        d.n_layers, d.in_dim, d.hid, d.out_dim = self.n_layers, self.in_dim, self.hid, self.out_dim
+        for l, (Ws, bs) in enumerate(self._flat):
+            d.w_off[l] = a.offset_of[id(Ws[0])]
+            d.b_off[l] = a.offset_of[id(bs[0])]
+        lib = _lib.load()
+        n_packed = lib.nlbac_mlp_pack_layout(C.byref(d))
+        self.packed = torch.zeros(max(n_packed, 4), dtype=torch.float32, device=a.device)
+        d.params = a.theta.data_ptr()
+        d.packed = self.packed.data_ptr()
+        self.desc = d
+        if a.with_target:
+            t = Mlp()
+            C.memmove(C.byref(t), C.byref(d), C.sizeof(Mlp))
+            self.packed_target = torch.zeros_like(self.packed)
+            t.params = a.target.data_ptr()
+            t.packed = self.packed_target.data_ptr()
+            self.desc_target = t
+        return self
+
+    def params(self):
+        out = []
+        for Ws, bs in self._flat:
+            out += Ws + bs
+        return out
+
+
+def mlp_array(descs):
+    arr = (Mlp * len(descs))()
+    for i, d in enumerate(descs):
+        C.memmove(C.byref(arr, i * C.sizeof(Mlp)), C.byref(d), C.sizeof(Mlp))
+    return arr
+
+
+def io_array(n):
+    return (MlpIO * n)()
+
+
+def ptr(t):
+    return t.data_ptr() if t is not None else None
+
+
+def stream_ptr():
+    return torch.cuda.current_stream().cuda_stream
+
+
+def pack(handles, target=False):
+    descs = [h.desc_target if target else h.desc for h in handles]
+    for i in range(0, len(descs), _lib.MAX_NETS):
+        chunk = descs[i:i + _lib.MAX_NETS]
+        _lib.call("nlbac_mlp_pack", mlp_array(chunk), len(chunk), stream_ptr())

@@ -1,0 +1,504 @@
+// Per-sample (elementwise + reduction) kernels of the SAC / CLF / CBF update:
+// squashed-Gaussian sampling, TD targets, Unicycle geometry, constraint
+// terms, augmented-Lagrangian scalars.  One lane per sample, coalesced
+// row reads, wavefront shuffle + LDS block reductions to per-block partials
+// that a single fixed-order pass sums (deterministic).
+//
+// Reference lines (U = NLBAC_Unicycle_RL_training/Unicycle_RL_training):
+//   GaussianPolicy.sample            U/sac_cbf_clf/model.py:116-128
+//   targets + MSE                    U/sac_cbf_clf/sac_cbf_clf.py:231-246
+//   policy_loss_1 / alpha loss       U/sac_cbf_clf/sac_cbf_clf.py:258-273, 292-308
+//   get_state                        U/sac_cbf_clf/dynamics.py:53-58
+//   get_policy_loss_2                U/sac_cbf_clf/sac_cbf_clf.py:408-530
+//   backup_get_policy_loss_2         U/sac_cbf_clf/sac_cbf_clf.py:532-640
+#include "common.h"
+#include "scalars.h"
+
+#define LOG_SIG_MAX 2.0f
+#define LOG_SIG_MIN (-20.0f)
+#define SAMPLE_EPS 1e-6f
+#define MAX_NU 4
+
+// ---------------------------------------------------------------------------
+// GaussianPolicy.sample forward
+// ---------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void gauss_fwd_kernel(const float* heads, int heads_ld, const float* eps,
+                                                        const float* scale, const float* bias, int n_u, int n,
+                                                        float* action, int action_ld, float* logp) {
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    float lp = 0.f;
+    for (int c = 0; c < n_u; ++c) {
+        const float mean = heads[(long)i * heads_ld + c];
+        float ls = heads[(long)i * heads_ld + n_u + c];
+        ls = fminf(fmaxf(ls, LOG_SIG_MIN), LOG_SIG_MAX);
+        const float std = expf(ls);
+        const float e = eps[(long)i * n_u + c];
+        const float x = mean + e * std;
+        const float y = tanhf(x);
+        action[(long)i * action_ld + c] = y * scale[c] + bias[c];
+        const float var = std * std;
+        const float d = x - mean;
+        float l = -(d * d) / (2.0f * var) - ls - 0.91893853320467274178f;   // log(sqrt(2 pi))
+        l -= logf(scale[c] * (1.0f - y * y) + SAMPLE_EPS);
+        lp += l;
+    }
+    logp[i] = lp;
+}
+
+// backward: d heads from d action (sum of up to three sources) and d logp = alpha[p] * dlogp_mul
+__global__ __launch_bounds__(256) void gauss_bwd_kernel(const float* heads, int heads_ld, const float* eps,
+                                                        const float* scale, int n_u, int n, int rows_per_problem,
+                                                        const float* da0, int da0_ld, const float* da1, int da1_ld,
+                                                        const float* da2, int da2_ld, const float* alpha,
+                                                        float dlogp_mul, float* dheads, int dheads_ld) {
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    const float dlp = alpha[i / rows_per_problem] * dlogp_mul;
+    for (int c = 0; c < n_u; ++c) {
+        const float mean = heads[(long)i * heads_ld + c];
+        const float ls_raw = heads[(long)i * heads_ld + n_u + c];
+        const float ls = fminf(fmaxf(ls_raw, LOG_SIG_MIN), LOG_SIG_MAX);
+        const float std = expf(ls);
+        const float e = eps[(long)i * n_u + c];
+        const float y = tanhf(mean + e * std);
+        float da = 0.f;
+        if (da0) da += da0[(long)i * da0_ld + c];
+        if (da1) da += da1[(long)i * da1_ld + c];
+        if (da2) da += da2[(long)i * da2_ld + c];
+        const float one_m = 1.0f - y * y;
+        const float s1 = scale[c] * one_m;
+        // dx through a = scale*tanh(x)+bias and through -log(scale(1-y^2)+eps)
+        const float gx = da * s1 + dlp * (2.0f * y * s1 / (s1 + SAMPLE_EPS));
+        // the -(x-mean)^2/(2 var) term is constant (-eps^2/2) under reparameterisation
+        const float dmean = gx;
+        const float dstd = gx * e;
+        const bool in_range = (ls_raw >= LOG_SIG_MIN) && (ls_raw <= LOG_SIG_MAX);
+        const float dls = in_range ? (dstd * std - dlp) : 0.f;
+        dheads[(long)i * dheads_ld + c] = dmean;
+        dheads[(long)i * dheads_ld + n_u + c] = dls;
+    }
+}
+
+// ---------------------------------------------------------------------------
+// TD / Lyapunov targets, MSE partial sums and dL/dq
+// ---------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void td_targets_kernel(const float* q1t, const float* q2t, const float* lt,
+                                                         const float* nlogp, const float* reward,
+                                                         const float* constraint, const float* mask,
+                                                         const float* q1, const float* q2, const float* lf,
+                                                         const float* alpha, float gamma, int B, float* dq1,
+                                                         float* dq2, float* dlf, float* next_q, float* next_l,
+                                                         float* partials) {
+    __shared__ float red[12];
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    float v[3] = {0.f, 0.f, 0.f};
+    if (i < B) {
+        const float a = alpha[0];
+        const float mq = fminf(q1t[i], q2t[i]) - a * nlogp[i];
+        const float yq = reward[i] + mask[i] * gamma * mq;
+        const float yl = constraint[i] + mask[i] * gamma * lt[i];
+        const float norm = (float)(2.0 / (double)B);
+        const float e1 = q1[i] - yq, e2 = q2[i] - yq, e3 = lf[i] - yl;
+        dq1[i] = norm * e1; dq2[i] = norm * e2; dlf[i] = norm * e3;
+        if (next_q) next_q[i] = yq;
+        if (next_l) next_l[i] = yl;
+        v[0] = e1 * e1; v[1] = e2 * e2; v[2] = e3 * e3;
+    }
+    block_sum_256<3>(v, red);
+    if (threadIdx.x == 0) {
+        partials[blockIdx.x * 3 + 0] = v[0];
+        partials[blockIdx.x * 3 + 1] = v[1];
+        partials[blockIdx.x * 3 + 2] = v[2];
+    }
+}
+
+// ---------------------------------------------------------------------------
+// min(Q1,Q2)(s, pi) branch gradients and partial sums for policy_loss_1 / alpha loss.
+// Rows: P problems (primary, backup) x B.  partials: [P][nblk][2]
+// ---------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void actor_q_terms_kernel(const float* q1, const float* q2, const float* logp,
+                                                            const float* alpha, int B, float* dq1, float* dq2,
+                                                            float* partials) {
+    __shared__ float red[8];
+    const int p = blockIdx.y;
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    float v[2] = {0.f, 0.f};
+    if (i < B) {
+        const long r = (long)p * B + i;
+        const float a = q1[r], b = q2[r];
+        const float g = -(1.0f / (float)B);
+        dq1[r] = (a < b) ? g : ((a == b) ? 0.5f * g : 0.f);
+        dq2[r] = (b < a) ? g : ((a == b) ? 0.5f * g : 0.f);
+        v[0] = alpha[p] * logp[r] - fminf(a, b);
+        v[1] = logp[r];
+    }
+    block_sum_256<2>(v, red);
+    if (threadIdx.x == 0) {
+        partials[((long)p * gridDim.x + blockIdx.x) * 2 + 0] = v[0];
+        partials[((long)p * gridDim.x + blockIdx.x) * 2 + 1] = v[1];
+    }
+}
+
+// policy_loss_1, alpha losses, d log_alpha  (one thread)
+__global__ void actor_scalars_kernel(const float* partials, int nblk, int B, int P, float target_entropy,
+                                     const float* log_alpha, int log_alpha_stride, float* g_log_alpha, float* sc) {
+    if (threadIdx.x != 0 || blockIdx.x != 0) return;
+    for (int p = 0; p < P; ++p) {
+        float s0 = 0.f, s1 = 0.f;
+        for (int b = 0; b < nblk; ++b) {
+            s0 += partials[((long)p * nblk + b) * 2 + 0];
+            s1 += partials[((long)p * nblk + b) * 2 + 1];
+        }
+        const float pl1 = s0 / (float)B;
+        const float mean_lp = s1 / (float)B;
+        const float la = log_alpha[p * log_alpha_stride];
+        // alpha_loss = -(log_alpha * (logp + H)).mean()
+        const float aloss = -(la * (mean_lp + target_entropy));
+        sc[(p == 0) ? SC_PL1 : SC_BPL1] = pl1;
+        sc[(p == 0) ? SC_ALOSS : SC_BALOSS] = aloss;
+        sc[(p == 0) ? SC_MEAN_LOGP : SC_MEAN_BLOGP] = mean_lp;
+        g_log_alpha[p * log_alpha_stride] = -(mean_lp + target_entropy);
+    }
+}
+
+__global__ void alpha_refresh_kernel(const float* log_alpha, int log_alpha_stride, int P, float* sc) {
+    if (threadIdx.x == 0 && blockIdx.x == 0)
+        for (int p = 0; p < P; ++p) sc[SC_ALPHA + p] = expf(log_alpha[p * log_alpha_stride]);
+}
+
+// ---------------------------------------------------------------------------
+// Unicycle geometry
+// ---------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void unicycle_state_kernel(const float* obs, int obs_ld, int B, float l_p,
+                                                             float* state, float* ps) {
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= B) return;
+    const float* o = obs + (long)i * obs_ld;
+    // the reference computes arctan2 on the host in float64 and casts back
+    const float th = (float)atan2((double)o[3], (double)o[2]);
+    state[i * 3 + 0] = o[0]; state[i * 3 + 1] = o[1]; state[i * 3 + 2] = th;
+    if (ps) {
+        ps[i * 2 + 0] = o[0] + l_p * cosf(th);
+        ps[i * 2 + 1] = o[1] + l_p * sinf(th);
+    }
+}
+
+__global__ __launch_bounds__(256) void unicycle_lookahead_kernel(const float* x, int n, float l_p, float* ps) {
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    const float th = x[i * 3 + 2];
+    ps[i * 2 + 0] = x[i * 3 + 0] + l_p * cosf(th);
+    ps[i * 2 + 1] = x[i * 3 + 1] + l_p * sinf(th);
+}
+
+__global__ __launch_bounds__(256) void unicycle_lookahead_bwd_kernel(const float* x, const float* dps,
+                                                                     const float* dps2, int n, float l_p, float* dx) {
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    float d0 = dps[i * 2 + 0], d1 = dps[i * 2 + 1];
+    if (dps2) { d0 += dps2[i * 2 + 0]; d1 += dps2[i * 2 + 1]; }
+    const float th = x[i * 3 + 2];
+    dx[i * 3 + 0] = d0;
+    dx[i * 3 + 1] = d1;
+    dx[i * 3 + 2] = l_p * (-sinf(th) * d0 + cosf(th) * d1);
+}
+
+// ---------------------------------------------------------------------------
+// CBF / CLF terms.  ps (B,2); ps_next (2B,2): rows [0,B) primary, [B,2B) backup.
+// matr (B, n_hz+1) = [cbf_1..cbf_nhz, clf],  bmatr (B, n_hz).
+// partials [nblk][2*n_hz+1] = column sums of the relu-filtered terms.
+// ---------------------------------------------------------------------------
+template <int NH>
+__global__ __launch_bounds__(256) void unicycle_constraints_fwd_kernel(const float* ps, const float* ps_next,
+                                                                       const float* V, const float* V_next,
+                                                                       const float* hazards, float r2, float dt,
+                                                                       float gamma_b, float gamma_l, int B,
+                                                                       float* matr, float* bmatr, float* partials) {
+    __shared__ float red[4 * (2 * NH + 1)];
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    float v[2 * NH + 1];
+#pragma unroll
+    for (int c = 0; c < 2 * NH + 1; ++c) v[c] = 0.f;
+    if (i < B) {
+        const float p0 = ps[i * 2], p1 = ps[i * 2 + 1];
+        const float n0 = ps_next[i * 2], n1 = ps_next[i * 2 + 1];
+        const float b0 = ps_next[(long)(B + i) * 2], b1 = ps_next[(long)(B + i) * 2 + 1];
+#pragma unroll
+        for (int h = 0; h < NH; ++h) {
+            const float hx = hazards[h * 2], hy = hazards[h * 2 + 1];
+            const float hs = 0.5f * (((p0 - hx) * (p0 - hx) + (p1 - hy) * (p1 - hy)) - r2);
+            const float hn = 0.5f * (((n0 - hx) * (n0 - hx) + (n1 - hy) * (n1 - hy)) - r2);
+            const float hb = 0.5f * (((b0 - hx) * (b0 - hx) + (b1 - hy) * (b1 - hy)) - r2);
+            const float t = -((hn - hs) / dt) - gamma_b * hs;
+            const float tb = -((hb - hs) / dt) - gamma_b * hs;
+            matr[(long)i * (NH + 1) + h] = t;
+            bmatr[(long)i * NH + h] = tb;
+            v[h] = t > 0.f ? t : 0.f;
+            v[NH + 1 + h] = tb > 0.f ? tb : 0.f;
+        }
+        const float vv = V[i];
+        const float lya = ((V_next[i] - vv) / dt) + gamma_l * vv;
+        matr[(long)i * (NH + 1) + NH] = lya;
+        v[NH] = lya > 0.f ? lya : 0.f;
+    }
+    block_sum_256<2 * NH + 1>(v, red);
+    if (threadIdx.x == 0)
+#pragma unroll
+        for (int c = 0; c < 2 * NH + 1; ++c) partials[(long)blockIdx.x * (2 * NH + 1) + c] = v[c];
+}
+
+// Augmented-Lagrangian scalars (one thread).  Shared rho for primary and
+// backup (Unicycle / SimulatedCars); lambda clamp [lam_lo, lam_hi].
+__global__ void auglag_kernel(const float* partials, int n_blk, int n_cbf, int n_clf, float batch_size,
+                              int do_lambda_update, int ratio_mode /*0 none,1 plain,2 clamp .002*/,
+                              int shared_rho, float lam_lo, float lam_hi, float* sc) {
+    if (threadIdx.x != 0 || blockIdx.x != 0) return;
+    const int nc = n_cbf + n_clf, ncol = nc + n_cbf;
+    double* rho_p = reinterpret_cast<double*>(sc + SC_RHO_F64);
+    double* brho_p = shared_rho ? rho_p : reinterpret_cast<double*>(sc + SC_BRHO_F64);
+    for (int c = 0; c < ncol; ++c) {
+        float s = 0.f;
+        for (int b = 0; b < n_blk; ++b) s += partials[(long)b * ncol + c];
+        s = s / batch_size;
+        if (c < nc) sc[SC_REQ + c] = s; else sc[SC_BREQ + (c - nc)] = s;
+    }
+    // ---- primary (sac_cbf_clf.py:506-528)
+    {
+        const float* req = sc + SC_REQ;
+        float* lam = sc + SC_LAMBDA;
+        double ratio = 1.0;
+        if (n_clf && ratio_mode) {
+            float m = 0.f;
+            for (int c = 0; c < n_cbf; ++c) m += req[c];
+            m = fabsf(m / (float)n_cbf);
+            float r = m / fabsf(req[nc - 1]);
+            if (ratio_mode == 2) r = fmaxf(r, 0.002f);
+            ratio = (double)r;
+        }
+        sc[SC_RATIO] = (float)ratio;
+        double rho = *rho_p;
+        if (do_lambda_update)
+            for (int c = 0; c < nc; ++c)
+                lam[c] = fminf(fmaxf(lam[c] + (float)rho * req[c], lam_lo), lam_hi);
+        rho = fmin(rho * 1.0005, 200.0);
+        *rho_p = rho;
+        const float ch = (float)(rho / 2.0);
+        float loss = 0.f;
+        for (int c = 0; c < n_cbf; ++c) {
+            const float g = req[c];
+            loss += lam[c] * g + ch * g * g;
+            sc[SC_COEF + c] = lam[c] + (ch * g + ch * g);
+        }
+        if (n_clf) {
+            const float g = req[nc - 1];
+            const float l1 = (float)((double)lam[nc - 1] * ratio);
+            const float c2 = (float)(ratio * ratio * rho / 2.0);
+            loss += l1 * g + c2 * g * g;
+            sc[SC_COEF + nc - 1] = l1 + (c2 * g + c2 * g);
+        }
+        sc[SC_PL2] = loss;
+    }
+    // ---- backup (sac_cbf_clf.py:623-638)
+    {
+        const float* req = sc + SC_BREQ;
+        float* lam = sc + SC_BLAMBDA;
+        double rho = *brho_p;
+        if (do_lambda_update)
+            for (int c = 0; c < n_cbf; ++c)
+                lam[c] = fminf(fmaxf(lam[c] + (float)rho * req[c], lam_lo), lam_hi);
+        rho = fmin(rho * 1.0005, 200.0);
+        *brho_p = rho;
+        const float ch = (float)(rho / 2.0);
+        float loss = 0.f;
+        for (int c = 0; c < n_cbf; ++c) {
+            const float g = req[c];
+            loss += lam[c] * g + ch * g * g;
+            sc[SC_BCOEF + c] = lam[c] + (ch * g + ch * g);
+        }
+        sc[SC_BPL2] = loss;
+    }
+}
+
+// d ps_next (2B,2) from the CBF terms and dV_next (B) from the CLF term
+template <int NH>
+__global__ __launch_bounds__(256) void unicycle_constraints_bwd_kernel(const float* ps_next, const float* matr,
+                                                                       const float* bmatr, const float* hazards,
+                                                                       float dt, float batch_size, int B,
+                                                                       const float* sc, float* dps_next,
+                                                                       float* dV_next) {
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= B) return;
+    const float n0 = ps_next[i * 2], n1 = ps_next[i * 2 + 1];
+    const float b0 = ps_next[(long)(B + i) * 2], b1 = ps_next[(long)(B + i) * 2 + 1];
+    float d0 = 0.f, d1 = 0.f, e0 = 0.f, e1 = 0.f;
+#pragma unroll
+    for (int h = 0; h < NH; ++h) {
+        const float hx = hazards[h * 2], hy = hazards[h * 2 + 1];
+        // d required_h / d term = 1/batch_size on the active set; term = -(hn - hs)/dt - ...
+        if (matr[(long)i * (NH + 1) + h] > 0.f) {
+            const float g = -((sc[SC_COEF + h] / batch_size) / dt);
+            d0 += g * (n0 - hx); d1 += g * (n1 - hy);
+        }
+        if (bmatr[(long)i * NH + h] > 0.f) {
+            const float g = -((sc[SC_BCOEF + h] / batch_size) / dt);
+            e0 += g * (b0 - hx); e1 += g * (b1 - hy);
+        }
+    }
+    dps_next[i * 2] = d0; dps_next[i * 2 + 1] = d1;
+    dps_next[(long)(B + i) * 2] = e0; dps_next[(long)(B + i) * 2 + 1] = e1;
+    dV_next[i] = (matr[(long)i * (NH + 1) + NH] > 0.f) ? ((sc[SC_COEF + NH] / batch_size) / dt) : 0.f;
+}
+
+// MSE (mean over n*d) partial sums and gradient
+__global__ __launch_bounds__(256) void mse_kernel(const float* pred, int pred_ld, const float* target, int target_ld,
+                                                  int n, int d, float* dpred, int dpred_ld, float* partials) {
+    __shared__ float red[4];
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    float v[1] = {0.f};
+    if (i < n) {
+        const float norm = (float)(2.0 / ((double)n * d));
+        for (int c = 0; c < d; ++c) {
+            const float e = pred[(long)i * pred_ld + c] - target[(long)i * target_ld + c];
+            dpred[(long)i * dpred_ld + c] = norm * e;
+            v[0] += e * e;
+        }
+    }
+    block_sum_256<1>(v, red);
+    if (threadIdx.x == 0) partials[blockIdx.x] = v[0];
+}
+
+// ---------------------------------------------------------------------------
+// C ABI
+// ---------------------------------------------------------------------------
+#define GRID1(n) dim3(nlbac_ceil_div((n), 256)), dim3(256), 0, (hipStream_t)s
+
+extern "C" int nlbac_gauss_sample_fwd(const float* heads, int heads_ld, const float* eps, const float* scale,
+                                      const float* bias, int n_u, int n, float* action, int action_ld,
+                                      float* logp, nlbac_stream_t s) {
+    NLBAC_REQUIRE(heads && eps && scale && bias && action && logp, "nlbac_gauss_sample_fwd: null pointer");
+    NLBAC_REQUIRE(n_u >= 1 && n_u <= MAX_NU && n >= 1, "nlbac_gauss_sample_fwd: bad sizes");
+    hipLaunchKernelGGL(gauss_fwd_kernel, GRID1(n), heads, heads_ld, eps, scale, bias, n_u, n, action, action_ld, logp);
+    NLBAC_CHECK_LAUNCH("nlbac_gauss_sample_fwd");
+    return 0;
+}
+
+extern "C" int nlbac_gauss_sample_bwd(const float* heads, int heads_ld, const float* eps, const float* scale,
+                                      int n_u, int n, int rows_per_problem, const float* da0, int da0_ld,
+                                      const float* da1, int da1_ld, const float* da2, int da2_ld,
+                                      const float* alpha, float dlogp_mul, float* dheads, int dheads_ld,
+                                      nlbac_stream_t s) {
+    NLBAC_REQUIRE(heads && eps && scale && alpha && dheads, "nlbac_gauss_sample_bwd: null pointer");
+    NLBAC_REQUIRE(n_u >= 1 && n_u <= MAX_NU && n >= 1 && rows_per_problem >= 1, "nlbac_gauss_sample_bwd: bad sizes");
+    hipLaunchKernelGGL(gauss_bwd_kernel, GRID1(n), heads, heads_ld, eps, scale, n_u, n, rows_per_problem, da0,
+                       da0_ld, da1, da1_ld, da2, da2_ld, alpha, dlogp_mul, dheads, dheads_ld);
+    NLBAC_CHECK_LAUNCH("nlbac_gauss_sample_bwd");
+    return 0;
+}
+
+extern "C" int nlbac_td_targets(const float* q1t, const float* q2t, const float* lt, const float* nlogp,
+                                const float* reward, const float* constraint, const float* mask,
+                                const float* q1, const float* q2, const float* lf, const float* alpha,
+                                float gamma, int B, float* dq1, float* dq2, float* dlf, float* next_q,
+                                float* next_l, float* partials, nlbac_stream_t s) {
+    NLBAC_REQUIRE(q1t && q2t && lt && nlogp && reward && constraint && mask && q1 && q2 && lf && alpha && dq1 &&
+                      dq2 && dlf && partials, "nlbac_td_targets: null pointer");
+    hipLaunchKernelGGL(td_targets_kernel, GRID1(B), q1t, q2t, lt, nlogp, reward, constraint, mask, q1, q2, lf,
+                       alpha, gamma, B, dq1, dq2, dlf, next_q, next_l, partials);
+    NLBAC_CHECK_LAUNCH("nlbac_td_targets");
+    return 0;
+}
+
+extern "C" int nlbac_actor_q_terms(const float* q1, const float* q2, const float* logp, const float* alpha,
+                                   int B, int P, float* dq1, float* dq2, float* partials, nlbac_stream_t s) {
+    NLBAC_REQUIRE(q1 && q2 && logp && alpha && dq1 && dq2 && partials, "nlbac_actor_q_terms: null pointer");
+    hipLaunchKernelGGL(actor_q_terms_kernel, dim3(nlbac_ceil_div(B, 256), P), dim3(256), 0, (hipStream_t)s, q1, q2,
+                       logp, alpha, B, dq1, dq2, partials);
+    NLBAC_CHECK_LAUNCH("nlbac_actor_q_terms");
+    return 0;
+}
+
+extern "C" int nlbac_actor_scalars(const float* partials, int n_blk, int B, int P, float target_entropy,
+                                   const float* log_alpha, int log_alpha_stride, float* g_log_alpha, float* sc,
+                                   nlbac_stream_t s) {
+    NLBAC_REQUIRE(partials && log_alpha && g_log_alpha && sc && P >= 1 && P <= 2, "nlbac_actor_scalars: bad arguments");
+    hipLaunchKernelGGL(actor_scalars_kernel, dim3(1), dim3(64), 0, (hipStream_t)s, partials, n_blk, B, P,
+                       target_entropy, log_alpha, log_alpha_stride, g_log_alpha, sc);
+    NLBAC_CHECK_LAUNCH("nlbac_actor_scalars");
+    return 0;
+}
+
+extern "C" int nlbac_alpha_refresh(const float* log_alpha, int log_alpha_stride, int P, float* sc, nlbac_stream_t s) {
+    NLBAC_REQUIRE(log_alpha && sc && P >= 1 && P <= 2, "nlbac_alpha_refresh: bad arguments");
+    hipLaunchKernelGGL(alpha_refresh_kernel, dim3(1), dim3(64), 0, (hipStream_t)s, log_alpha, log_alpha_stride, P, sc);
+    NLBAC_CHECK_LAUNCH("nlbac_alpha_refresh");
+    return 0;
+}
+
+extern "C" int nlbac_unicycle_state(const float* obs, int obs_ld, int B, float l_p, float* state, float* ps,
+                                    nlbac_stream_t s) {
+    NLBAC_REQUIRE(obs && state, "nlbac_unicycle_state: null pointer");
+    hipLaunchKernelGGL(unicycle_state_kernel, GRID1(B), obs, obs_ld, B, l_p, state, ps);
+    NLBAC_CHECK_LAUNCH("nlbac_unicycle_state");
+    return 0;
+}
+
+extern "C" int nlbac_unicycle_lookahead(const float* x, int n, float l_p, float* ps, nlbac_stream_t s) {
+    NLBAC_REQUIRE(x && ps, "nlbac_unicycle_lookahead: null pointer");
+    hipLaunchKernelGGL(unicycle_lookahead_kernel, GRID1(n), x, n, l_p, ps);
+    NLBAC_CHECK_LAUNCH("nlbac_unicycle_lookahead");
+    return 0;
+}
+
+extern "C" int nlbac_unicycle_lookahead_bwd(const float* x, const float* dps, const float* dps2, int n, float l_p,
+                                            float* dx, nlbac_stream_t s) {
+    NLBAC_REQUIRE(x && dps && dx, "nlbac_unicycle_lookahead_bwd: null pointer");
+    hipLaunchKernelGGL(unicycle_lookahead_bwd_kernel, GRID1(n), x, dps, dps2, n, l_p, dx);
+    NLBAC_CHECK_LAUNCH("nlbac_unicycle_lookahead_bwd");
+    return 0;
+}
+
+extern "C" int nlbac_unicycle_constraints_fwd(const float* ps, const float* ps_next, const float* V,
+                                              const float* V_next, const float* hazards, int n_hz, float r_coll,
+                                              float dt, float gamma_b, float gamma_l, int B, float* matr,
+                                              float* bmatr, float* partials, nlbac_stream_t s) {
+    NLBAC_REQUIRE(ps && ps_next && V && V_next && hazards && matr && bmatr && partials,
+                  "nlbac_unicycle_constraints_fwd: null pointer");
+    NLBAC_REQUIRE(n_hz == 7, "nlbac_unicycle_constraints_fwd: built for n_hz == 7 (got %d)", n_hz);
+    const float r2 = (float)((double)r_coll * (double)r_coll);
+    hipLaunchKernelGGL(unicycle_constraints_fwd_kernel<7>, GRID1(B), ps, ps_next, V, V_next, hazards, r2, dt,
+                       gamma_b, gamma_l, B, matr, bmatr, partials);
+    NLBAC_CHECK_LAUNCH("nlbac_unicycle_constraints_fwd");
+    return 0;
+}
+
+extern "C" int nlbac_auglag(const float* partials, int n_blk, int n_cbf, int n_clf, float batch_size,
+                            int do_lambda_update, int ratio_mode, int shared_rho, float lam_lo, float lam_hi,
+                            float* sc, nlbac_stream_t s) {
+    NLBAC_REQUIRE(partials && sc, "nlbac_auglag: null pointer");
+    NLBAC_REQUIRE(n_cbf >= 1 && n_cbf + n_clf <= NLBAC_NC_MAX && n_clf >= 0 && n_clf <= 1, "nlbac_auglag: bad constraint counts");
+    hipLaunchKernelGGL(auglag_kernel, dim3(1), dim3(64), 0, (hipStream_t)s, partials, n_blk, n_cbf, n_clf,
+                       batch_size, do_lambda_update, ratio_mode, shared_rho, lam_lo, lam_hi, sc);
+    NLBAC_CHECK_LAUNCH("nlbac_auglag");
+    return 0;
+}
+
+extern "C" int nlbac_unicycle_constraints_bwd(const float* ps_next, const float* matr, const float* bmatr,
+                                              const float* hazards, int n_hz, float dt, float batch_size, int B,
+                                              const float* sc, float* dps_next, float* dV_next, nlbac_stream_t s) {
+    NLBAC_REQUIRE(ps_next && matr && bmatr && hazards && sc && dps_next && dV_next,
+                  "nlbac_unicycle_constraints_bwd: null pointer");
+    NLBAC_REQUIRE(n_hz == 7, "nlbac_unicycle_constraints_bwd: built for n_hz == 7 (got %d)", n_hz);
+    hipLaunchKernelGGL(unicycle_constraints_bwd_kernel<7>, GRID1(B), ps_next, matr, bmatr, hazards, dt, batch_size,
+                       B, sc, dps_next, dV_next);
+    NLBAC_CHECK_LAUNCH("nlbac_unicycle_constraints_bwd");
+    return 0;
+}
+
+extern "C" int nlbac_mse_fwd_bwd(const float* pred, int pred_ld, const float* target, int target_ld, int n, int d,
+                                 float* dpred, int dpred_ld, float* partials, nlbac_stream_t s) {
+    NLBAC_REQUIRE(pred && target && dpred && partials, "nlbac_mse_fwd_bwd: null pointer");
+    hipLaunchKernelGGL(mse_kernel, GRID1(n), pred, pred_ld, target, target_ld, n, d, dpred, dpred_ld, partials);
+    NLBAC_CHECK_LAUNCH("nlbac_mse_fwd_bwd");
+    return 0;
+}

@@ -1,0 +1,47 @@
+// Shared host/device helpers for the nlbac HIP library (gfx950 only).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <cstdio>
+#include <cstring>
+#include "../../include/nlbac_hip.h"
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+extern thread_local char nlbac_err_buf[512];
+
+#define NLBAC_FAIL(...)                                              \
+    do {                                                             \
+        snprintf(nlbac_err_buf, sizeof(nlbac_err_buf), __VA_ARGS__); \
+        return -1;                                                   \
+    } while (0)
+
+#define NLBAC_CHECK_LAUNCH(name)                                                           \
+    do {                                                                                   \
+        hipError_t e_ = hipGetLastError();                                                 \
+        if (e_ != hipSuccess) NLBAC_FAIL("%s: launch failed: %s", name, hipGetErrorString(e_)); \
+    } while (0)
+
+#define NLBAC_REQUIRE(cond, ...) \
+    do {                         \
+        if (!(cond)) NLBAC_FAIL(__VA_ARGS__); \
+    } while (0)
+
+static inline int nlbac_ceil_div(long a, long b) { return (int)((a + b - 1) / b); }
+
+// Block-wide deterministic sum of NV values per thread (256-thread blocks):
+// wave shuffle tree, then a fixed-order combine of the 4 wave results.
+template <int NV>
+__device__ __forceinline__ void block_sum_256(float (&v)[NV], float* lds /* >= 4*NV floats */) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+#pragma unroll
+    for (int i = 0; i < NV; ++i) {
+        float x = v[i];
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) x += __shfl_down(x, off, 64);
+        if (lane == 0) lds[wave * NV + i] = x;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int i = 0; i < NV; ++i) v[i] = (lds[i] + lds[NV + i]) + (lds[2 * NV + i] + lds[3 * NV + i]);
+    __syncthreads();
+}

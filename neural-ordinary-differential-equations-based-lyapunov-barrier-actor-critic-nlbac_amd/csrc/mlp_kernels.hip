@@ -1,0 +1,623 @@
+// Fused ReLU-MLP kernels for gfx950 (MI355X): forward, backward-data and
+// backward-weights, fp32 in / fp32 accumulate on v_mfma_f32_32x32x2_f32 (exact
+// fp32 FMA chain, so results stay within fp32 rounding of the reference's
+// ATen GEMMs).
+//
+// Replaces the op sequences of QNetwork / LyaNetwork / GaussianPolicy.forward
+// (U/sac_cbf_clf/model.py:53-64, 77-83, 108-114), f_net / g_net of
+// NeuralODEModel (model.py:186-206) and autograd's backward through them.
+//
+// Work decomposition (CDNA4: 64-lane waves, 4 SIMDs per CU, one MFMA pipe per
+// SIMD):
+//   * one workgroup = 4 waves = one tile of 32 samples of ONE net; grid.y
+//     batches independent nets (twin Q, Lyapunov, policies, f/g nets) so a
+//     4096-sample minibatch still fills the 256 CUs;
+//   * activations of the tile ping-pong between two LDS buffers [32][hid+4]
+//     (row stride = 4 mod 8 dwords -> conflict-free ds_read_b128 A fragments);
+//   * weights are read as the MFMA B operand straight from an L2-resident,
+//     fragment-ordered packed copy (nlbac_mlp_pack): one fully coalesced
+//     1 KiB global_load_dwordx4 per wave per 8-deep K chunk, two chunks in
+//     flight, no LDS round trip (each wave owns its own output columns);
+//   * the skinny first-input / last-output contractions (K or N <= 16) stay
+//     on the VALU.
+#include "common.h"
+
+struct MlpLaunch {
+    nlbac_mlp net[NLBAC_MAX_NETS];
+    nlbac_mlp_io io[NLBAC_MAX_NETS];
+    int B;
+    int ld;          // LDS row stride in floats
+    int n_slabs;     // bwd_weights only
+    int rows_per_slab;
+    long slab_stride;
+};
+
+__device__ __forceinline__ int pad8(int x) { return (x + 7) & ~7; }
+__device__ __forceinline__ int pad32(int x) { return (x + 31) & ~31; }
+
+// row of accumulator register r for lane-half h in a 32x32 MFMA result
+__device__ __forceinline__ int acc_row(int r, int h) { return (r & 3) + 8 * (r >> 2) + 4 * h; }
+
+// ---------------------------------------------------------------------------
+// weight packing
+//   forward pack of W[N][K]  : P[((tile*KC + kc)*64 + lane)*4 + j] = W[32*tile + (lane&31)][8*kc + 4*(lane>>5) + j]
+//   backward pack            : same formula applied to W^T (tile over K, chunks over N)
+// ---------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void mlp_pack_kernel(const MlpLaunch L) {
+    const nlbac_mlp& net = L.net[blockIdx.y];
+    const int nwide = net.n_layers - 1;
+    const int hid = net.hid;
+    const long gid = (long)blockIdx.x * 256 + threadIdx.x;
+    const long stride = (long)gridDim.x * 256;
+    for (int l = 0; l < nwide; ++l) {
+        const int K = (l == 0) ? net.in_dim : hid;
+        const float* W = net.params + net.w_off[l];
+        {   // forward pack: tiles over N=hid, chunks over K
+            const int KC = pad8(K) >> 3, NT = pad32(hid) >> 5;
+            float* P = net.packed + net.pf_off[l];
+            const long total = (long)NT * KC * 256;
+            for (long i = gid; i < total; i += stride) {
+                const int j = i & 3, lane = (i >> 2) & 63;
+                const long tc = i >> 8;
+                const int kc = tc % KC, tile = tc / KC;
+                const int n = 32 * tile + (lane & 31), k = 8 * kc + 4 * (lane >> 5) + j;
+                P[i] = (n < hid && k < K) ? W[(long)n * K + k] : 0.f;
+            }
+        }
+        if (l >= 1 && net.pb_off[l] >= 0) {   // backward pack: tiles over K(=hid), chunks over N(=hid)
+            const int NC = pad8(hid) >> 3, KT = pad32(K) >> 5;
+            float* P = net.packed + net.pb_off[l];
+            const long total = (long)KT * NC * 256;
+            for (long i = gid; i < total; i += stride) {
+                const int j = i & 3, lane = (i >> 2) & 63;
+                const long tc = i >> 8;
+                const int nc = tc % NC, tile = tc / NC;
+                const int k = 32 * tile + (lane & 31), n = 8 * nc + 4 * (lane >> 5) + j;
+                P[i] = (n < hid && k < K) ? W[(long)n * K + k] : 0.f;
+            }
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------
+// C[32 x 32*NTW] += A_lds[32 x 8*KC] * Bpacked      (one wave, NTW = 1 or 2 tiles)
+// ---------------------------------------------------------------------------
+template <int NTW>
+__device__ __forceinline__ void wave_gemm(const float* __restrict__ a_lds, int LD,
+                                          const float4* __restrict__ pk, int KC, int tile0,
+                                          f32x16 (&acc)[2], int lane) {
+    const float4* p0 = pk + (long)tile0 * KC * 64 + lane;
+    const float4* p1 = pk + (long)(tile0 + 4) * KC * 64 + lane;
+    const float* arow = a_lds + (lane & 31) * LD + (lane >> 5) * 4;
+    float4 b0c = p0[0], b1c = make_float4(0, 0, 0, 0);
+    float4 b0n = (KC > 1) ? p0[64] : b0c, b1n = b1c;
+    if (NTW == 2) { b1c = p1[0]; b1n = (KC > 1) ? p1[64] : b1c; }
+    float4 ac = *reinterpret_cast<const float4*>(arow);
+    for (int kc = 0; kc < KC; ++kc) {
+        float4 b0f = b0n, b1f = b1n, an = ac;
+        if (kc + 2 < KC) {
+            b0f = p0[(long)(kc + 2) * 64];
+            if (NTW == 2) b1f = p1[(long)(kc + 2) * 64];
+        }
+        if (kc + 1 < KC) an = *reinterpret_cast<const float4*>(arow + (kc + 1) * 8);
+        acc[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(ac.x, b0c.x, acc[0], 0, 0, 0);
+        if (NTW == 2) acc[1] = __builtin_amdgcn_mfma_f32_32x32x2f32(ac.x, b1c.x, acc[1], 0, 0, 0);
+        acc[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(ac.y, b0c.y, acc[0], 0, 0, 0);
+        if (NTW == 2) acc[1] = __builtin_amdgcn_mfma_f32_32x32x2f32(ac.y, b1c.y, acc[1], 0, 0, 0);
+        acc[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(ac.z, b0c.z, acc[0], 0, 0, 0);
+        if (NTW == 2) acc[1] = __builtin_amdgcn_mfma_f32_32x32x2f32(ac.z, b1c.z, acc[1], 0, 0, 0);
+        acc[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(ac.w, b0c.w, acc[0], 0, 0, 0);
+        if (NTW == 2) acc[1] = __builtin_amdgcn_mfma_f32_32x32x2f32(ac.w, b1c.w, acc[1], 0, 0, 0);
+        b0c = b0n; b0n = b0f; ac = an;
+        if (NTW == 2) { b1c = b1n; b1n = b1f; }
+    }
+}
+
+// ---------------------------------------------------------------------------
+// forward
+// ---------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void mlp_fwd_kernel(const MlpLaunch L) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    const nlbac_mlp& net = L.net[blockIdx.y];
+    const nlbac_mlp_io& io = L.io[blockIdx.y];
+    const int B = L.B, LD = L.ld;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, half = lane >> 5;
+    const int row0 = blockIdx.x * NLBAC_MLP_TILE;
+    const int hid = net.hid, NT = pad32(hid) >> 5, hidp8 = pad8(hid);
+    const int nwide = net.n_layers - 1;
+    const int inp = pad8(net.in_dim);
+    float* in = smem;
+    float* out = smem + NLBAC_MLP_TILE * LD;
+
+    for (int idx = tid; idx < NLBAC_MLP_TILE * inp; idx += 256) {
+        const int r = idx / inp, c = idx - r * inp, row = row0 + r;
+        float v = 0.f;
+        if (row < B) {
+            if (c < io.x0_dim) v = io.x0[(long)row * io.x0_ld + c];
+            else if (c < net.in_dim) v = io.x1[(long)row * io.x1_ld + (c - io.x0_dim)];
+        }
+        in[r * LD + c] = v;
+    }
+    __syncthreads();
+
+    for (int l = 0; l < nwide; ++l) {
+        const int KC = ((l == 0) ? inp : hidp8) >> 3;
+        const float4* pk = reinterpret_cast<const float4*>(net.packed + net.pf_off[l]);
+        const float* bias = net.params + net.b_off[l];
+        float* acts = io.acts ? io.acts + (long)l * B * hid : nullptr;
+        if (wave < NT) {
+            f32x16 acc[2];
+#pragma unroll
+            for (int r = 0; r < 16; ++r) { acc[0][r] = 0.f; acc[1][r] = 0.f; }
+            const bool two = (wave + 4) < NT;
+            if (two) wave_gemm<2>(in, LD, pk, KC, wave, acc, lane);
+            else wave_gemm<1>(in, LD, pk, KC, wave, acc, lane);
+#pragma unroll
+            for (int t = 0; t < 2; ++t) {
+                if (t == 1 && !two) break;
+                const int col = (wave + 4 * t) * 32 + (lane & 31);
+                const float b = (col < hid) ? bias[col] : 0.f;
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int m = acc_row(r, half);
+                    const float v = fmaxf(acc[t][r] + b, 0.f);
+                    out[m * LD + col] = v;
+                    if (acts && col < hid && row0 + m < B) acts[(long)(row0 + m) * hid + col] = v;
+                }
+            }
+        }
+        __syncthreads();
+        float* tmp = in; in = out; out = tmp;
+    }
+
+    // skinny output layer on the VALU: 8 lanes per sample row
+    {
+        const int l = nwide;
+        const float* W = net.params + net.w_off[l];
+        const float* bias = net.params + net.b_off[l];
+        const int m = tid >> 3, part = tid & 7, row = row0 + m;
+        for (int o0 = 0; o0 < net.out_dim; o0 += 4) {
+            float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
+            const int no = min(4, net.out_dim - o0);
+            for (int k = part * 4; k < hid; k += 32) {
+                const float4 h = *reinterpret_cast<const float4*>(in + m * LD + k);
+                const float4 w0 = *reinterpret_cast<const float4*>(W + (long)(o0 + 0) * hid + k);
+                a0 += h.x * w0.x + h.y * w0.y + h.z * w0.z + h.w * w0.w;
+                if (no > 1) { const float4 w = *reinterpret_cast<const float4*>(W + (long)(o0 + 1) * hid + k);
+                              a1 += h.x * w.x + h.y * w.y + h.z * w.z + h.w * w.w; }
+                if (no > 2) { const float4 w = *reinterpret_cast<const float4*>(W + (long)(o0 + 2) * hid + k);
+                              a2 += h.x * w.x + h.y * w.y + h.z * w.z + h.w * w.w; }
+                if (no > 3) { const float4 w = *reinterpret_cast<const float4*>(W + (long)(o0 + 3) * hid + k);
+                              a3 += h.x * w.x + h.y * w.y + h.z * w.z + h.w * w.w; }
+            }
+#pragma unroll
+            for (int off = 1; off < 8; off <<= 1) {
+                a0 += __shfl_xor(a0, off, 64); a1 += __shfl_xor(a1, off, 64);
+                a2 += __shfl_xor(a2, off, 64); a3 += __shfl_xor(a3, off, 64);
+            }
+            if (part == 0 && row < B) {
+                float* y = io.y + (long)row * io.y_ld + o0;
+                y[0] = a0 + bias[o0];
+                if (no > 1) y[1] = a1 + bias[o0 + 1];
+                if (no > 2) y[2] = a2 + bias[o0 + 2];
+                if (no > 3) y[3] = a3 + bias[o0 + 3];
+            }
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------
+// backward, data path:  dz[j] for every wide layer j and (optionally) dx
+//   dz[nwide-1] = (dy W_last) * [acts[nwide-1] > 0]
+//   dz[j-1]     = (dz[j] W_j) * [acts[j-1] > 0]            (MFMA, backward pack)
+//   dx          =  dz[0] W_0                                (VALU)
+// ---------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void mlp_bwd_data_kernel(const MlpLaunch L) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    const nlbac_mlp& net = L.net[blockIdx.y];
+    const nlbac_mlp_io& io = L.io[blockIdx.y];
+    const int B = L.B, LD = L.ld;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, half = lane >> 5;
+    const int row0 = blockIdx.x * NLBAC_MLP_TILE;
+    const int hid = net.hid, NT = pad32(hid) >> 5, hidp8 = pad8(hid), hidp32 = NT * 32;
+    const int nwide = net.n_layers - 1;
+    float* in = smem;
+    float* out = smem + NLBAC_MLP_TILE * LD;
+    float* sdy = smem + 2 * NLBAC_MLP_TILE * LD;   // [32][16]
+
+    for (int idx = tid; idx < NLBAC_MLP_TILE * 16; idx += 256) {
+        const int r = idx >> 4, c = idx & 15, row = row0 + r;
+        sdy[idx] = (row < B && c < net.out_dim) ? io.dy[(long)row * io.dy_ld + c] : 0.f;
+    }
+    __syncthreads();
+
+    {   // top (skinny) layer: thread = hidden column
+        const int k = tid;
+        const float* W = net.params + net.w_off[nwide];
+        float s[NLBAC_MLP_TILE];
+#pragma unroll
+        for (int m = 0; m < NLBAC_MLP_TILE; ++m) s[m] = 0.f;
+        if (k < hid) {
+            for (int o0 = 0; o0 < net.out_dim; o0 += 4) {
+                const int no = min(4, net.out_dim - o0);
+                const float w0 = W[(long)o0 * hid + k];
+                const float w1 = no > 1 ? W[(long)(o0 + 1) * hid + k] : 0.f;
+                const float w2 = no > 2 ? W[(long)(o0 + 2) * hid + k] : 0.f;
+                const float w3 = no > 3 ? W[(long)(o0 + 3) * hid + k] : 0.f;
+#pragma unroll
+                for (int m = 0; m < NLBAC_MLP_TILE; ++m) {
+                    const float4 d = *reinterpret_cast<const float4*>(sdy + m * 16 + o0);
+                    s[m] += d.x * w0 + d.y * w1 + d.z * w2 + d.w * w3;
+                }
+            }
+        }
+        const float* acts = io.acts + (long)(nwide - 1) * B * hid;
+        float* dz = io.dz ? io.dz + (long)(nwide - 1) * B * hid : nullptr;
+        if (k < hidp32) {
+#pragma unroll
+            for (int m = 0; m < NLBAC_MLP_TILE; ++m) {
+                const int row = row0 + m;
+                float v = 0.f;
+                if (k < hid && row < B) {
+                    v = acts[(long)row * hid + k] > 0.f ? s[m] : 0.f;
+                    if (dz) dz[(long)row * hid + k] = v;
+                }
+                in[m * LD + k] = v;
+            }
+        }
+    }
+    __syncthreads();
+
+    for (int j = nwide - 1; j >= 1; --j) {
+        const int KC = hidp8 >> 3;
+        const float4* pk = reinterpret_cast<const float4*>(net.packed + net.pb_off[j]);
+        const float* acts = io.acts + (long)(j - 1) * B * hid;
+        float* dz = io.dz ? io.dz + (long)(j - 1) * B * hid : nullptr;
+        if (wave < NT) {
+            f32x16 acc[2];
+#pragma unroll
+            for (int r = 0; r < 16; ++r) { acc[0][r] = 0.f; acc[1][r] = 0.f; }
+            const bool two = (wave + 4) < NT;
+            if (two) wave_gemm<2>(in, LD, pk, KC, wave, acc, lane);
+            else wave_gemm<1>(in, LD, pk, KC, wave, acc, lane);
+#pragma unroll
+            for (int t = 0; t < 2; ++t) {
+                if (t == 1 && !two) break;
+                const int col = (wave + 4 * t) * 32 + (lane & 31);
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int m = acc_row(r, half), row = row0 + m;
+                    float v = 0.f;
+                    if (col < hid && row < B) {
+                        v = acts[(long)row * hid + col] > 0.f ? acc[t][r] : 0.f;
+                        if (dz) dz[(long)row * hid + col] = v;
+                    }
+                    out[m * LD + col] = v;
+                }
+            }
+        }
+        __syncthreads();
+        float* tmp = in; in = out; out = tmp;
+    }
+
+    if (io.dx) {   // dx[m][i] = sum_n dz0[m][n] W0[n][i]
+        const float* W = net.params + net.w_off[0];
+        const int idim = net.in_dim;
+        const int m = tid >> 3, part = tid & 7, row = row0 + m;
+        for (int i0 = 0; i0 < idim; i0 += 4) {
+            const int ni = min(4, idim - i0);
+            float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
+            for (int n = part * 4; n < hid; n += 32) {
+                const float4 d = *reinterpret_cast<const float4*>(in + m * LD + n);
+                const float dd[4] = {d.x, d.y, d.z, d.w};
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    const float* w = W + (long)(n + q) * idim + i0;
+                    a0 += dd[q] * w[0];
+                    if (ni > 1) a1 += dd[q] * w[1];
+                    if (ni > 2) a2 += dd[q] * w[2];
+                    if (ni > 3) a3 += dd[q] * w[3];
+                }
+            }
+#pragma unroll
+            for (int off = 1; off < 8; off <<= 1) {
+                a0 += __shfl_xor(a0, off, 64); a1 += __shfl_xor(a1, off, 64);
+                a2 += __shfl_xor(a2, off, 64); a3 += __shfl_xor(a3, off, 64);
+            }
+            if (part == 0 && row < B) {
+                float* dx = io.dx + (long)row * io.dx_ld + i0;
+                dx[0] = a0;
+                if (ni > 1) dx[1] = a1;
+                if (ni > 2) dx[2] = a2;
+                if (ni > 3) dx[3] = a3;
+            }
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------
+// backward, weights of the hidden->hidden layers:
+//   dW_j[n][k] = sum_b dz[j][b][n] * acts[j-1][b][k]      (j = 1..nwide-1)
+// grid.x = (layer, 64x64 output tile), grid.y = row slab, grid.z = net.
+// Both operands are staged through LDS in 16-row chunks; each of the 4 waves
+// owns one 32x32 MFMA tile.
+// ---------------------------------------------------------------------------
+#define DW_CHUNK 16
+#define DW_LDS_LD 68
+__global__ __launch_bounds__(256) void mlp_bwd_wide_kernel(const MlpLaunch L) {
+    __shared__ __attribute__((aligned(16))) float sA[2][DW_CHUNK][DW_LDS_LD];
+    __shared__ __attribute__((aligned(16))) float sB[2][DW_CHUNK][DW_LDS_LD];
+    const nlbac_mlp& net = L.net[blockIdx.z];
+    const nlbac_mlp_io& io = L.io[blockIdx.z];
+    const int B = L.B, hid = net.hid, nwide = net.n_layers - 1;
+    const int T = (hid + 63) >> 6;
+    const int per_layer = T * T;
+    if ((int)blockIdx.x >= (nwide - 1) * per_layer) return;
+    const int j = 1 + blockIdx.x / per_layer;
+    const int tt = blockIdx.x % per_layer;
+    const int n0 = (tt / T) * 64, k0 = (tt % T) * 64;
+    const int slab = blockIdx.y;
+    const int rb = slab * L.rows_per_slab, re = min(B, rb + L.rows_per_slab);
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, half = lane >> 5;
+    const int wn = wave >> 1, wk = wave & 1;
+    const float* dz = io.dz + (long)j * B * hid;
+    const float* at = io.acts + (long)(j - 1) * B * hid;
+    const int lr = tid >> 4, lc = (tid & 15) * 4;
+
+    f32x16 acc;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+
+    auto load = [&](int r0, float4& va, float4& vb) {
+        const int row = r0 + lr;
+        va = make_float4(0, 0, 0, 0); vb = va;
+        if (row < re) {
+            if (n0 + lc < hid) va = *reinterpret_cast<const float4*>(dz + (long)row * hid + n0 + lc);
+            if (k0 + lc < hid) vb = *reinterpret_cast<const float4*>(at + (long)row * hid + k0 + lc);
+        }
+    };
+    float4 va, vb;
+    int buf = 0;
+    if (rb < re) {
+        load(rb, va, vb);
+        *reinterpret_cast<float4*>(&sA[0][lr][lc]) = va;
+        *reinterpret_cast<float4*>(&sB[0][lr][lc]) = vb;
+    }
+    __syncthreads();
+    for (int r0 = rb; r0 < re; r0 += DW_CHUNK) {
+        const bool more = (r0 + DW_CHUNK) < re;
+        if (more) load(r0 + DW_CHUNK, va, vb);
+#pragma unroll
+        for (int bb = 0; bb < DW_CHUNK / 2; ++bb) {
+            const float a = sA[buf][2 * bb + half][wn * 32 + (lane & 31)];
+            const float b = sB[buf][2 * bb + half][wk * 32 + (lane & 31)];
+            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, acc, 0, 0, 0);
+        }
+        if (more) {
+            *reinterpret_cast<float4*>(&sA[buf ^ 1][lr][lc]) = va;
+            *reinterpret_cast<float4*>(&sB[buf ^ 1][lr][lc]) = vb;
+        }
+        __syncthreads();
+        buf ^= 1;
+    }
+    float* g = io.grad + (long)slab * L.slab_stride + net.w_off[j];
+    const int k = k0 + wk * 32 + (lane & 31);
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+        const int n = n0 + wn * 32 + acc_row(r, half);
+        if (n < hid && k < hid) g[(long)n * hid + k] = acc[r];
+    }
+}
+
+// ---------------------------------------------------------------------------
+// backward, skinny weights and all biases (column reductions over the slab rows):
+//   db_j[n]      = sum_b dz[j][b][n]
+//   dW_0[n][i]   = sum_b dz[0][b][n] x[b][i]
+//   dW_L[o][k]   = sum_b dy[b][o] acts[nwide-1][b][k],  db_L[o] = sum_b dy[b][o]
+// grid = (slab, net); 1024 threads = 4 row groups x 256 hidden columns.
+// ---------------------------------------------------------------------------
+#define SK_MAX_IN 12
+#define SK_MAX_OUT 16
+__global__ __launch_bounds__(1024) void mlp_bwd_skinny_kernel(const MlpLaunch L) {
+    __shared__ float red[8][4][256];
+    __shared__ float sx[4][SK_MAX_IN + SK_MAX_OUT];
+    const nlbac_mlp& net = L.net[blockIdx.y];
+    const nlbac_mlp_io& io = L.io[blockIdx.y];
+    const int B = L.B, hid = net.hid, nwide = net.n_layers - 1;
+    const int idim = net.in_dim, odim = net.out_dim;
+    const int slab = blockIdx.x;
+    const int rb = slab * L.rows_per_slab, re = min(B, rb + L.rows_per_slab);
+    const int col = threadIdx.x & 255, rg = threadIdx.x >> 8;
+    const bool live = col < hid;
+    float dW0[SK_MAX_IN], dWL[SK_MAX_OUT], db[NLBAC_MAX_LAYERS];
+#pragma unroll
+    for (int i = 0; i < SK_MAX_IN; ++i) dW0[i] = 0.f;
+#pragma unroll
+    for (int o = 0; o < SK_MAX_OUT; ++o) dWL[o] = 0.f;
+#pragma unroll
+    for (int j = 0; j < NLBAC_MAX_LAYERS; ++j) db[j] = 0.f;
+    float dbL = 0.f;
+    const float* aL = io.acts + (long)(nwide - 1) * B * hid;
+
+    for (int r = rb + rg; r < re + rg; r += 4) {   // uniform trip count for the barriers
+        const bool ok = r < re;
+        // stage this row group's x row and dy row (broadcast operands)
+        if (col < idim + odim) {
+            float v = 0.f;
+            if (ok) {
+                if (col < idim)
+                    v = (col < io.x0_dim) ? io.x0[(long)r * io.x0_ld + col]
+                                          : io.x1[(long)r * io.x1_ld + (col - io.x0_dim)];
+                else
+                    v = io.dy[(long)r * io.dy_ld + (col - idim)];
+            }
+            sx[rg][col < idim ? col : SK_MAX_IN + (col - idim)] = v;
+        }
+        __syncthreads();
+        if (ok && live) {
+            const float z0 = io.dz[(long)r * hid + col];
+            db[0] += z0;
+#pragma unroll
+            for (int i = 0; i < SK_MAX_IN; ++i)
+                if (i < idim) dW0[i] += z0 * sx[rg][i];
+#pragma unroll
+            for (int j = 1; j < NLBAC_MAX_LAYERS - 1; ++j)
+                if (j < nwide) db[j] += io.dz[((long)j * B + r) * hid + col];
+            const float a = aL[(long)r * hid + col];
+#pragma unroll
+            for (int o = 0; o < SK_MAX_OUT; ++o)
+                if (o < odim) dWL[o] += sx[rg][SK_MAX_IN + o] * a;
+        }
+        if (ok && col < odim) dbL += sx[rg][SK_MAX_IN + col];
+        __syncthreads();
+    }
+
+    float* g = io.grad + (long)slab * L.slab_stride;
+    // cross-row-group reduction in batches of 8 quantities (fixed order => deterministic)
+    auto flush = [&](float (&q)[8], int nq, auto&& store) {
+#pragma unroll
+        for (int i = 0; i < 8; ++i) red[i][rg][col] = q[i];
+        __syncthreads();
+        if (rg == 0) {
+#pragma unroll
+            for (int i = 0; i < 8; ++i)
+                if (i < nq) store(i, (red[i][0][col] + red[i][1][col]) + (red[i][2][col] + red[i][3][col]));
+        }
+        __syncthreads();
+    };
+    float q[8];
+    // biases of the wide layers (+ last-layer bias in slot 7 via column index)
+#pragma unroll
+    for (int i = 0; i < 8; ++i) q[i] = (i < NLBAC_MAX_LAYERS) ? db[i] : 0.f;
+    q[7] = dbL;
+    flush(q, 8, [&](int i, float v) {
+        if (i < nwide) { if (live) g[net.b_off[i] + col] = v; }
+        else if (i == 7 && col < odim) g[net.b_off[nwide] + col] = v;
+    });
+    for (int i0 = 0; i0 < idim; i0 += 8) {
+#pragma unroll
+        for (int i = 0; i < 8; ++i) q[i] = 0.f;
+#pragma unroll
+        for (int i = 0; i < SK_MAX_IN; ++i)
+            if (i >= i0 && i < i0 + 8) q[i - i0] = dW0[i];
+        flush(q, min(8, idim - i0), [&](int i, float v) {
+            if (live) g[net.w_off[0] + (long)col * idim + i0 + i] = v;
+        });
+    }
+    for (int o0 = 0; o0 < odim; o0 += 8) {
+#pragma unroll
+        for (int i = 0; i < 8; ++i) q[i] = 0.f;
+#pragma unroll
+        for (int o = 0; o < SK_MAX_OUT; ++o)
+            if (o >= o0 && o < o0 + 8) q[o - o0] = dWL[o];
+        flush(q, min(8, odim - o0), [&](int i, float v) {
+            if (live) g[net.w_off[nwide] + (long)(o0 + i) * hid + col] = v;
+        });
+    }
+}
+
+// ---------------------------------------------------------------------------
+// host side
+// ---------------------------------------------------------------------------
+static int check_net(const nlbac_mlp& n, const char* who) {
+    NLBAC_REQUIRE(n.n_layers >= 2 && n.n_layers <= NLBAC_MAX_LAYERS, "%s: n_layers %d out of [2,%d]", who, n.n_layers, NLBAC_MAX_LAYERS);
+    NLBAC_REQUIRE(n.in_dim >= 1 && n.in_dim <= SK_MAX_IN, "%s: in_dim %d out of [1,%d]", who, n.in_dim, SK_MAX_IN);
+    NLBAC_REQUIRE(n.out_dim >= 1 && n.out_dim <= SK_MAX_OUT, "%s: out_dim %d out of [1,%d]", who, n.out_dim, SK_MAX_OUT);
+    NLBAC_REQUIRE(n.hid >= 4 && n.hid <= 256 && n.hid % 4 == 0, "%s: hid %d must be a multiple of 4 in [4,256]", who, n.hid);
+    NLBAC_REQUIRE(n.params && n.packed, "%s: params/packed must be set", who);
+    return 0;
+}
+
+static int fill_launch(MlpLaunch& L, const nlbac_mlp* nets, const nlbac_mlp_io* io, int n_nets, int B, const char* who) {
+    NLBAC_REQUIRE(n_nets >= 1 && n_nets <= NLBAC_MAX_NETS, "%s: n_nets %d out of [1,%d]", who, n_nets, NLBAC_MAX_NETS);
+    NLBAC_REQUIRE(B >= 1, "%s: B must be >= 1", who);
+    memset(&L, 0, sizeof(L));
+    int ld = 0;
+    for (int i = 0; i < n_nets; ++i) {
+        if (check_net(nets[i], who)) return -1;
+        L.net[i] = nets[i];
+        if (io) L.io[i] = io[i];
+        int w = ((nets[i].hid + 31) & ~31);
+        int ip = (nets[i].in_dim + 7) & ~7;
+        if (ip > w) w = ip;
+        if (w + 4 > ld) ld = w + 4;
+    }
+    L.B = B;
+    L.ld = ld;
+    return 0;
+}
+
+extern "C" int nlbac_mlp_pack_layout(nlbac_mlp* net) {
+    NLBAC_REQUIRE(net, "nlbac_mlp_pack_layout: null net");
+    const int nwide = net->n_layers - 1, hid = net->hid;
+    long off = 0;
+    for (int l = 0; l < NLBAC_MAX_LAYERS; ++l) { net->pf_off[l] = -1; net->pb_off[l] = -1; }
+    for (int l = 0; l < nwide; ++l) {
+        const int K = (l == 0) ? net->in_dim : hid;
+        net->pf_off[l] = (int)off;
+        off += (long)(((hid + 31) & ~31) >> 5) * (((K + 7) & ~7) >> 3) * 256;
+        if (l >= 1) {
+            net->pb_off[l] = (int)off;
+            off += (long)(((K + 31) & ~31) >> 5) * (((hid + 7) & ~7) >> 3) * 256;
+        }
+    }
+    return (int)off;
+}
+
+extern "C" int nlbac_mlp_pack(const nlbac_mlp* nets, int n_nets, nlbac_stream_t s) {
+    MlpLaunch L;
+    if (fill_launch(L, nets, nullptr, n_nets, 1, "nlbac_mlp_pack")) return -1;
+    hipLaunchKernelGGL(mlp_pack_kernel, dim3(64, n_nets), dim3(256), 0, (hipStream_t)s, L);
+    NLBAC_CHECK_LAUNCH("nlbac_mlp_pack");
+    return 0;
+}
+
+extern "C" int nlbac_mlp_fwd(const nlbac_mlp* nets, const nlbac_mlp_io* io, int n_nets, int B, nlbac_stream_t s) {
+    MlpLaunch L;
+    if (fill_launch(L, nets, io, n_nets, B, "nlbac_mlp_fwd")) return -1;
+    for (int i = 0; i < n_nets; ++i) {
+        NLBAC_REQUIRE(io[i].x0 && io[i].y, "nlbac_mlp_fwd: net %d needs x0 and y", i);
+        NLBAC_REQUIRE(io[i].x0_dim == nets[i].in_dim || (io[i].x1 && io[i].x0_dim + io[i].x1_dim == nets[i].in_dim),
+                      "nlbac_mlp_fwd: net %d input dims %d+%d != in_dim %d", i, io[i].x0_dim, io[i].x1_dim, nets[i].in_dim);
+    }
+    const size_t lds = (size_t)2 * NLBAC_MLP_TILE * L.ld * sizeof(float);
+    hipLaunchKernelGGL(mlp_fwd_kernel, dim3(nlbac_ceil_div(B, NLBAC_MLP_TILE), n_nets), dim3(256), lds, (hipStream_t)s, L);
+    NLBAC_CHECK_LAUNCH("nlbac_mlp_fwd");
+    return 0;
+}
+
+extern "C" int nlbac_mlp_bwd_data(const nlbac_mlp* nets, const nlbac_mlp_io* io, int n_nets, int B, nlbac_stream_t s) {
+    MlpLaunch L;
+    if (fill_launch(L, nets, io, n_nets, B, "nlbac_mlp_bwd_data")) return -1;
+    for (int i = 0; i < n_nets; ++i)
+        NLBAC_REQUIRE(io[i].dy && io[i].acts, "nlbac_mlp_bwd_data: net %d needs dy and acts", i);
+    const size_t lds = ((size_t)2 * NLBAC_MLP_TILE * L.ld + NLBAC_MLP_TILE * 16) * sizeof(float);
+    hipLaunchKernelGGL(mlp_bwd_data_kernel, dim3(nlbac_ceil_div(B, NLBAC_MLP_TILE), n_nets), dim3(256), lds, (hipStream_t)s, L);
+    NLBAC_CHECK_LAUNCH("nlbac_mlp_bwd_data");
+    return 0;
+}
+
+extern "C" int nlbac_mlp_bwd_weights(const nlbac_mlp* nets, const nlbac_mlp_io* io, int n_nets, int B,
+                                     int n_slabs, long slab_stride, nlbac_stream_t s) {
+    MlpLaunch L;
+    if (fill_launch(L, nets, io, n_nets, B, "nlbac_mlp_bwd_weights")) return -1;
+    NLBAC_REQUIRE(n_slabs >= 1, "nlbac_mlp_bwd_weights: n_slabs must be >= 1");
+    int max_blocks = 0;
+    for (int i = 0; i < n_nets; ++i) {
+        NLBAC_REQUIRE(io[i].dy && io[i].acts && io[i].dz && io[i].grad && io[i].x0,
+                      "nlbac_mlp_bwd_weights: net %d needs x0, dy, acts, dz, grad", i);
+        const int T = (nets[i].hid + 63) >> 6;
+        const int nb = (nets[i].n_layers - 2) * T * T;
+        if (nb > max_blocks) max_blocks = nb;
+    }
+    int rps = nlbac_ceil_div(B, n_slabs);
+    rps = (rps + DW_CHUNK - 1) / DW_CHUNK * DW_CHUNK;
+    L.n_slabs = n_slabs; L.rows_per_slab = rps; L.slab_stride = slab_stride;
+    if (max_blocks > 0) {
+        hipLaunchKernelGGL(mlp_bwd_wide_kernel, dim3(max_blocks, n_slabs, n_nets), dim3(256), 0, (hipStream_t)s, L);
+        NLBAC_CHECK_LAUNCH("nlbac_mlp_bwd_weights(wide)");
+    }
+    hipLaunchKernelGGL(mlp_bwd_skinny_kernel, dim3(n_slabs, n_nets), dim3(1024), 0, (hipStream_t)s, L);
+    NLBAC_CHECK_LAUNCH("nlbac_mlp_bwd_weights(skinny)");
+    return 0;
+}

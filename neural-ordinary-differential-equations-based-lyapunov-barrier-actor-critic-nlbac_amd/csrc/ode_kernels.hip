@@ -1,0 +1,346 @@
+// Explicit Runge-Kutta machinery of odeint on t=[t0,t1] for the control-affine
+// NODE field  k = f(x) + g(x) u  (U/sac_cbf_clf/model.py:208-217), replacing
+// the torchdiffeq.odeint call sites U/sac_cbf_clf/sac_cbf_clf.py:453,577 and
+// U/sac_cbf_clf/model.py:252.  euler / rk4 (3/8 rule) / dopri5 (FSAL, RMS
+// error norm over the whole batch tensor incl. the carried action columns,
+// one shared step per problem, 4th-order interpolant at t1).
+//
+// The heavy part of every stage (f_net / g_net) runs in mlp_kernels.hip; the
+// kernels here are the per-row stage algebra: rows are P problems x B rows,
+// state dimension n_s <= 8, action dimension n_u <= 4.  Stage derivatives are
+// kept stage-major: K[stage][row][n_s].
+#include "common.h"
+
+#define MAX_NS 8
+#define MAX_NUA 4
+#define MAX_STAGES 8
+#define MAX_PROBLEMS 8
+
+struct RkCoef { float c[MAX_STAGES]; float h[MAX_PROBLEMS]; };
+
+__device__ __forceinline__ float step_of(const RkCoef& rc, const double* h_dev, int h_stride, int p) {
+    return h_dev ? (float)h_dev[(long)p * h_stride] : rc.h[p];
+}
+
+// k[r] = f[r] + sum_c g[r][c] u[c]
+__global__ __launch_bounds__(256) void affine_fwd_kernel(const float* f, const float* g, const float* u, int n_s,
+                                                         int n_u, int n, float* k) {
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    for (int r = 0; r < n_s; ++r) {
+        float a = f[(long)i * n_s + r];
+        for (int c = 0; c < n_u; ++c) a += g[(long)i * n_s * n_u + r * n_u + c] * u[(long)i * n_u + c];
+        k[(long)i * n_s + r] = a;
+    }
+}
+
+// dg[r][c] = dk[r] u[c] ; du[c] (+)= mul * sum_r g[r][c] dk[r]   (df == dk, no copy)
+__global__ __launch_bounds__(256) void affine_bwd_kernel(const float* dk, const float* g, const float* u, int n_s,
+                                                         int n_u, int n, float mul, float* dg, float* du, int acc) {
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    for (int c = 0; c < n_u; ++c) {
+        float a = 0.f;
+        const float uc = u[(long)i * n_u + c];
+        for (int r = 0; r < n_s; ++r) {
+            const float d = dk[(long)i * n_s + r];
+            a += g[(long)i * n_s * n_u + r * n_u + c] * d;
+            if (dg) dg[(long)i * n_s * n_u + r * n_u + c] = d * uc;
+        }
+        if (du) du[(long)i * n_u + c] = (acc ? du[(long)i * n_u + c] : 0.f) + mul * a;
+    }
+}
+
+// out = (y0 ? y0 : 0) + sum_j (coef[j]*h_p) * K[j]
+__global__ __launch_bounds__(256) void rk_combine_kernel(const float* y0, const float* K, int n_k, const RkCoef rc,
+                                                         const double* h_dev, int h_stride, int rpp, int n_s, int n,
+                                                         float* out) {
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    const float h = step_of(rc, h_dev, h_stride, i / rpp);
+    for (int r = 0; r < n_s; ++r) {
+        float a = y0 ? y0[(long)i * n_s + r] : 0.f;
+        for (int j = 0; j < n_k; ++j)
+            if (rc.c[j] != 0.f) a = a + K[((long)j * n + i) * n_s + r] * (rc.c[j] * h);
+        out[(long)i * n_s + r] = a;
+    }
+}
+
+// Stage backward:  dY = (dYup?) + (dXf?) + (dXg?) ;  dy0 (+)= dY ; dK[j] += coef[j]*h*dY (j<n_k)
+// (dXf/dXg are the input grads of f_net/g_net at this stage, ld = dx_ld)
+__global__ __launch_bounds__(256) void rk_stage_bwd_kernel(const float* dYup, const float* dXf, const float* dXg,
+                                                           int dx_ld, int n_k, const RkCoef rc, const double* h_dev,
+                                                           int h_stride, int rpp, int n_s, int n, float* dK,
+                                                           float* dy0, int acc_dy0) {
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    const float h = step_of(rc, h_dev, h_stride, i / rpp);
+    for (int r = 0; r < n_s; ++r) {
+        float d = dYup ? dYup[(long)i * n_s + r] : 0.f;
+        if (dXf) d += dXf[(long)i * dx_ld + r];
+        if (dXg) d += dXg[(long)i * dx_ld + r];
+        if (dy0) dy0[(long)i * n_s + r] = (acc_dy0 ? dy0[(long)i * n_s + r] : 0.f) + d;
+        for (int j = 0; j < n_k; ++j)
+            if (rc.c[j] != 0.f) dK[((long)j * n + i) * n_s + r] += (rc.c[j] * h) * d;
+    }
+}
+
+// ---------------------------------------------------------------------------
+// dopri5 step-size control.  ctl: per problem NLBAC_DOPRI_CTL doubles.
+// ---------------------------------------------------------------------------
+enum { C_H = 0, C_T = 1, C_RATIO = 2, C_ACCEPT = 3, C_DONE = 4, C_X = 5, C_H0 = 6, C_D0 = 7, C_D1 = 8, C_D2 = 9,
+       C_NSTEPS = 10, C_HUSED = 11 };
+
+// partial sums of squared scaled quantities; partials [P][nblk][2]
+//  mode 0: col0 = sum (y0/scale)^2 (+ (u/scale_u)^2), col1 = sum (a/scale)^2          a = f0
+//  mode 1: col0 = sum ((a-b)/scale)^2                                                  a = f1, b = f0
+//  mode 2: col0 = sum (a/tol)^2, tol = atol + rtol*max(|y0|,|y1|)                      a = err
+__global__ __launch_bounds__(256) void dopri_norm_kernel(const float* a, const float* b, const float* y0,
+                                                         const float* y1, const float* u, int mode, float rtol,
+                                                         float atol, int n_s, int n_u, int rpp, float* partials) {
+    __shared__ float red[8];
+    const int p = blockIdx.y;
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    float v[2] = {0.f, 0.f};
+    if (i < rpp) {
+        const long row = (long)p * rpp + i;
+        for (int r = 0; r < n_s; ++r) {
+            const float y = y0[row * n_s + r];
+            if (mode == 2) {
+                const float tol = atol + rtol * fmaxf(fabsf(y), fabsf(y1[row * n_s + r]));
+                const float q = a[row * n_s + r] / tol;
+                v[0] += q * q;
+            } else {
+                const float sc = atol + fabsf(y) * rtol;
+                if (mode == 0) {
+                    const float q0 = y / sc, q1 = a[row * n_s + r] / sc;
+                    v[0] += q0 * q0; v[1] += q1 * q1;
+                } else {
+                    const float q = (a[row * n_s + r] - b[row * n_s + r]) / sc;
+                    v[0] += q * q;
+                }
+            }
+        }
+        if (mode == 0)
+            for (int c = 0; c < n_u; ++c) {
+                const float y = u[row * n_u + c];
+                const float q = y / (atol + fabsf(y) * rtol);
+                v[0] += q * q;
+            }
+    }
+    block_sum_256<2>(v, red);
+    if (threadIdx.x == 0) {
+        partials[((long)p * gridDim.x + blockIdx.x) * 2 + 0] = v[0];
+        partials[((long)p * gridDim.x + blockIdx.x) * 2 + 1] = v[1];
+    }
+}
+
+__global__ void dopri_control_kernel(const float* partials, int nblk, int mode, int n_s, int n_u, int rpp,
+                                     double t_end, double* ctl) {
+    const int p = blockIdx.x;
+    if (threadIdx.x != 0) return;
+    double* c = ctl + (long)p * NLBAC_DOPRI_CTL;
+    double s0 = 0.0, s1 = 0.0;
+    for (int b = 0; b < nblk; ++b) {
+        s0 += (double)partials[((long)p * nblk + b) * 2 + 0];
+        s1 += (double)partials[((long)p * nblk + b) * 2 + 1];
+    }
+    const double cnt = (double)rpp * (double)(n_s + n_u);
+    if (mode == 0) {
+        const double d0 = sqrt(s0 / cnt), d1 = sqrt(s1 / cnt);
+        c[C_D0] = d0; c[C_D1] = d1;
+        c[C_H0] = (d0 < 1e-5 || d1 < 1e-5) ? 1e-6 : 0.01 * d0 / d1;
+        c[C_T] = 0.0; c[C_NSTEPS] = 0.0; c[C_DONE] = 0.0;
+    } else if (mode == 1) {
+        const double h0 = c[C_H0], d1 = c[C_D1];
+        const double d2 = sqrt(s0 / cnt) / h0;
+        c[C_D2] = d2;
+        double h1;
+        if (d1 <= 1e-15 && d2 <= 1e-15) h1 = fmax(1e-6, h0 * 1e-3);
+        else h1 = pow(0.01 / fmax(d1, d2), 1.0 / 5.0);
+        c[C_H] = fmin(100.0 * h0, h1);
+    } else {
+        const double ratio = sqrt(s0 / cnt);
+        const double h = c[C_H], t = c[C_T];
+        const bool accept = ratio <= 1.0;
+        double fac;
+        if (ratio == 0.0) fac = 10.0;
+        else {
+            const double dfac = (ratio < 1.0) ? 1.0 : 0.2;
+            fac = fmin(10.0, fmax(0.9 / pow(ratio, 0.2), dfac));
+        }
+        c[C_RATIO] = ratio; c[C_ACCEPT] = accept ? 1.0 : 0.0; c[C_HUSED] = h;
+        c[C_NSTEPS] += 1.0;
+        if (accept && t + h >= t_end) {
+            c[C_DONE] = 1.0;
+            c[C_X] = (t_end - t) / h;
+        } else {
+            if (accept) c[C_T] = t + h;
+            c[C_H] = h * fac;
+        }
+    }
+}
+
+#define DPM0 (6025192743.0 / 30085553152.0 / 2.0)
+#define DPM2 (51252292925.0 / 65400821598.0 / 2.0)
+#define DPM3 (-2691868925.0 / 45128329728.0 / 2.0)
+#define DPM4 (187940372067.0 / 1594534317056.0 / 2.0)
+#define DPM5 (-1776094331.0 / 19743644256.0 / 2.0)
+#define DPM6 (11237099.0 / 235043384.0 / 2.0)
+
+struct InterpArg { float h[MAX_PROBLEMS]; float x[MAX_PROBLEMS]; };
+
+// y(t_end) = y0 + x(d + x(c + x(b + x a)))   (K: [7][n][n_s])
+__global__ __launch_bounds__(256) void dopri_interp_fwd_kernel(const float* y0, const float* y1, const float* K,
+                                                               const InterpArg ia, int rpp, int n_s, int n,
+                                                               float* out) {
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    const float h = ia.h[i / rpp], x = ia.x[i / rpp];
+    const float cm[7] = {(float)DPM0, 0.f, (float)DPM2, (float)DPM3, (float)DPM4, (float)DPM5, (float)DPM6};
+    for (int r = 0; r < n_s; ++r) {
+        const float a0 = y0[(long)i * n_s + r], a1 = y1[(long)i * n_s + r];
+        float ym = a0;
+#pragma unroll
+        for (int j = 0; j < 7; ++j)
+            if (cm[j] != 0.f) ym = ym + K[((long)j * n + i) * n_s + r] * (cm[j] * h);
+        const float f0 = K[(long)i * n_s + r], f1 = K[((long)6 * n + i) * n_s + r];
+        const float a = 2.f * h * (f1 - f0) - 8.f * (a1 + a0) + 16.f * ym;
+        const float b = h * (5.f * f0 - 3.f * f1) + 18.f * a0 + 14.f * a1 - 32.f * ym;
+        const float c = h * (f1 - 4.f * f0) - 11.f * a0 - 5.f * a1 + 16.f * ym;
+        const float d = h * f0;
+        out[(long)i * n_s + r] = a0 + x * (d + x * (c + x * (b + x * a)));
+    }
+}
+
+// backward of the interpolant: writes dy0, dy1 and dK[0..6]
+__global__ __launch_bounds__(256) void dopri_interp_bwd_kernel(const float* dout, const InterpArg ia, int rpp,
+                                                               int n_s, int n, float* dy0, float* dy1, float* dK) {
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    const float h = ia.h[i / rpp], x = ia.x[i / rpp];
+    const float cm[7] = {(float)DPM0, 0.f, (float)DPM2, (float)DPM3, (float)DPM4, (float)DPM5, (float)DPM6};
+    const float x2 = x * x, x3 = x2 * x, x4 = x2 * x2;
+    for (int r = 0; r < n_s; ++r) {
+        const float g = dout[(long)i * n_s + r];
+        const float A = x4 * g, Bc = x3 * g, C = x2 * g, D = x * g;
+        const float ym = 16.f * A - 32.f * Bc + 16.f * C;
+        dy0[(long)i * n_s + r] = g - 8.f * A + 18.f * Bc - 11.f * C + ym;
+        dy1[(long)i * n_s + r] = -8.f * A + 14.f * Bc - 5.f * C;
+        const float f0b = h * (-2.f * A + 5.f * Bc - 4.f * C + D);
+        const float f1b = h * (2.f * A - 3.f * Bc + C);
+#pragma unroll
+        for (int j = 0; j < 7; ++j) {
+            float v = (cm[j] * h) * ym;
+            if (j == 0) v += f0b;
+            if (j == 6) v += f1b;
+            dK[((long)j * n + i) * n_s + r] = v;
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------
+#define GRID1(n) dim3(nlbac_ceil_div((n), 256)), dim3(256), 0, (hipStream_t)s
+
+static int fill_rc(RkCoef& rc, const float* coef, int n_k, const float* h_host, int P, const char* who) {
+    NLBAC_REQUIRE(n_k >= 0 && n_k <= MAX_STAGES, "%s: n_k %d out of range", who, n_k);
+    NLBAC_REQUIRE(P >= 1 && P <= MAX_PROBLEMS, "%s: P %d out of range", who, P);
+    memset(&rc, 0, sizeof(rc));
+    for (int j = 0; j < n_k; ++j) rc.c[j] = coef[j];
+    for (int p = 0; p < P; ++p) rc.h[p] = h_host ? h_host[p] : 1.f;
+    return 0;
+}
+
+extern "C" int nlbac_affine_combine_fwd(const float* f, const float* g, const float* u, int n_s, int n_u, int n,
+                                        float* k, nlbac_stream_t s) {
+    NLBAC_REQUIRE(f && g && u && k, "nlbac_affine_combine_fwd: null pointer");
+    NLBAC_REQUIRE(n_s <= MAX_NS && n_u <= MAX_NUA, "nlbac_affine_combine_fwd: dims too large");
+    hipLaunchKernelGGL(affine_fwd_kernel, GRID1(n), f, g, u, n_s, n_u, n, k);
+    NLBAC_CHECK_LAUNCH("nlbac_affine_combine_fwd");
+    return 0;
+}
+
+extern "C" int nlbac_affine_combine_bwd(const float* dk, const float* g, const float* u, int n_s, int n_u, int n,
+                                        float mul, float* dg, float* du, int accumulate_du, nlbac_stream_t s) {
+    NLBAC_REQUIRE(dk && g && u, "nlbac_affine_combine_bwd: null pointer");
+    hipLaunchKernelGGL(affine_bwd_kernel, GRID1(n), dk, g, u, n_s, n_u, n, mul, dg, du, accumulate_du);
+    NLBAC_CHECK_LAUNCH("nlbac_affine_combine_bwd");
+    return 0;
+}
+
+extern "C" int nlbac_rk_combine(const float* y0, const float* K, int n_k, const float* coef, const float* h_host,
+                                const double* h_dev, int h_dev_stride, int P, int rows_per_problem, int n_s,
+                                float* out, nlbac_stream_t s) {
+    RkCoef rc;
+    NLBAC_REQUIRE(K && out && coef, "nlbac_rk_combine: null pointer");
+    if (fill_rc(rc, coef, n_k, h_host, P, "nlbac_rk_combine")) return -1;
+    const int n = P * rows_per_problem;
+    hipLaunchKernelGGL(rk_combine_kernel, GRID1(n), y0, K, n_k, rc, h_dev, h_dev_stride, rows_per_problem, n_s, n, out);
+    NLBAC_CHECK_LAUNCH("nlbac_rk_combine");
+    return 0;
+}
+
+extern "C" int nlbac_rk_stage_bwd(const float* dYup, const float* dXf, const float* dXg, int dx_ld, int n_k,
+                                  const float* coef, const float* h_host, const double* h_dev, int h_dev_stride,
+                                  int P, int rows_per_problem, int n_s, float* dK, float* dy0, int accumulate_dy0,
+                                  nlbac_stream_t s) {
+    RkCoef rc;
+    NLBAC_REQUIRE(n_k == 0 || (dK && coef), "nlbac_rk_stage_bwd: null pointer");
+    if (fill_rc(rc, coef, n_k, h_host, P, "nlbac_rk_stage_bwd")) return -1;
+    const int n = P * rows_per_problem;
+    hipLaunchKernelGGL(rk_stage_bwd_kernel, GRID1(n), dYup, dXf, dXg, dx_ld, n_k, rc, h_dev, h_dev_stride,
+                       rows_per_problem, n_s, n, dK, dy0, accumulate_dy0);
+    NLBAC_CHECK_LAUNCH("nlbac_rk_stage_bwd");
+    return 0;
+}
+
+extern "C" int nlbac_dopri_norm_partials(const float* a, const float* b, const float* y0, const float* y1,
+                                         const float* u, int mode, float rtol, float atol, int n_s, int n_u,
+                                         int rows_per_problem, int P, float* partials, nlbac_stream_t s) {
+    NLBAC_REQUIRE(a && y0 && partials && mode >= 0 && mode <= 2, "nlbac_dopri_norm_partials: bad arguments");
+    NLBAC_REQUIRE((mode != 0 || u) && (mode != 1 || b) && (mode != 2 || y1), "nlbac_dopri_norm_partials: missing operand");
+    hipLaunchKernelGGL(dopri_norm_kernel, dim3(nlbac_ceil_div(rows_per_problem, 256), P), dim3(256), 0,
+                       (hipStream_t)s, a, b, y0, y1, u, mode, rtol, atol, n_s, n_u, rows_per_problem, partials);
+    NLBAC_CHECK_LAUNCH("nlbac_dopri_norm_partials");
+    return 0;
+}
+
+extern "C" int nlbac_dopri_control(const float* partials, int n_blk_per_problem, int mode, int n_s, int n_u,
+                                   int rows_per_problem, int P, double t_end, double* ctl, nlbac_stream_t s) {
+    NLBAC_REQUIRE(partials && ctl && mode >= 0 && mode <= 2, "nlbac_dopri_control: bad arguments");
+    hipLaunchKernelGGL(dopri_control_kernel, dim3(P), dim3(64), 0, (hipStream_t)s, partials, n_blk_per_problem, mode,
+                       n_s, n_u, rows_per_problem, t_end, ctl);
+    NLBAC_CHECK_LAUNCH("nlbac_dopri_control");
+    return 0;
+}
+
+static int fill_ia(InterpArg& ia, const float* h_host, const float* x_host, int P, const char* who) {
+    NLBAC_REQUIRE(h_host && x_host && P >= 1 && P <= MAX_PROBLEMS, "%s: bad arguments", who);
+    memset(&ia, 0, sizeof(ia));
+    for (int p = 0; p < P; ++p) { ia.h[p] = h_host[p]; ia.x[p] = x_host[p]; }
+    return 0;
+}
+
+extern "C" int nlbac_dopri_interp_fwd(const float* y0, const float* y1, const float* K, const float* h_host,
+                                      const float* x_host, int P, int rows_per_problem, int n_s, float* out,
+                                      nlbac_stream_t s) {
+    InterpArg ia;
+    NLBAC_REQUIRE(y0 && y1 && K && out, "nlbac_dopri_interp_fwd: null pointer");
+    if (fill_ia(ia, h_host, x_host, P, "nlbac_dopri_interp_fwd")) return -1;
+    const int n = P * rows_per_problem;
+    hipLaunchKernelGGL(dopri_interp_fwd_kernel, GRID1(n), y0, y1, K, ia, rows_per_problem, n_s, n, out);
+    NLBAC_CHECK_LAUNCH("nlbac_dopri_interp_fwd");
+    return 0;
+}
+
+extern "C" int nlbac_dopri_interp_bwd(const float* dout, const float* h_host, const float* x_host, int P,
+                                      int rows_per_problem, int n_s, float* dy0, float* dy1, float* dK,
+                                      nlbac_stream_t s) {
+    InterpArg ia;
+    NLBAC_REQUIRE(dout && dy0 && dy1 && dK, "nlbac_dopri_interp_bwd: null pointer");
+    if (fill_ia(ia, h_host, x_host, P, "nlbac_dopri_interp_bwd")) return -1;
+    const int n = P * rows_per_problem;
+    hipLaunchKernelGGL(dopri_interp_bwd_kernel, GRID1(n), dout, ia, rows_per_problem, n_s, n, dy0, dy1, dK);
+    NLBAC_CHECK_LAUNCH("nlbac_dopri_interp_bwd");
+    return 0;
+}

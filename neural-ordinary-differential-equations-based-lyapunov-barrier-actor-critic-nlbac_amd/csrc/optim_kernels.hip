@@ -1,0 +1,181 @@
+// Adam (torch.optim.Adam single-tensor arithmetic), gradient-slab reduction and
+// soft target update.  Replaces torch.optim.Adam.step at
+// U/sac_cbf_clf/sac_cbf_clf.py:249-255,284-308, U/sac_cbf_clf/model.py:258 and
+// soft_update at U/sac_cbf_clf/utils.py:75-79.
+//
+// HBM-bound streaming kernels: one float4 per lane, grid capped at 2048 blocks.
+#include "common.h"
+
+thread_local char nlbac_err_buf[512] = "";
+
+extern "C" int nlbac_abi_version(void) { return NLBAC_ABI_VERSION; }
+extern "C" const char* nlbac_last_error(void) { return nlbac_err_buf; }
+
+struct AdamState {
+    int step;
+    float step_size;   // lr / (1 - beta1^t)
+    float bc2_sqrt;    // sqrt(1 - beta2^t)
+    float pad;
+};
+
+__global__ void adam_prepare_kernel(AdamState* st, double lr) {
+    if (threadIdx.x == 0 && blockIdx.x == 0) {
+        const int t = st->step + 1;
+        st->step = t;
+        const double bc1 = 1.0 - pow(0.9, (double)t);
+        const double bc2 = 1.0 - pow(0.999, (double)t);
+        st->step_size = (float)(lr / bc1);
+        st->bc2_sqrt = (float)sqrt(bc2);
+    }
+}
+
+__device__ __forceinline__ float adam_one(float& p, float& m, float& v, float g, float step_size, float bc2_sqrt) {
+    // exp_avg.lerp_(grad, 1-beta1); exp_avg_sq.mul_(beta2).addcmul_(grad, grad, 1-beta2)
+    // (the scalars are python doubles cast to fp32 at use, as ATen does)
+    m = m + (g - m) * (float)(1.0 - 0.9);
+    v = v * 0.999f + ((float)(1.0 - 0.999) * g) * g;
+    const float denom = sqrtf(v) / bc2_sqrt + 1e-8f;
+    p = p + ((-step_size) * m) / denom;   // addcdiv_: self + value * t1 / t2
+    return p;
+}
+
+__global__ __launch_bounds__(256) void adam_step_kernel(float* __restrict__ p, float* __restrict__ m,
+                                                        float* __restrict__ v, const float* __restrict__ grad,
+                                                        int n_slabs, long slab_stride, long n,
+                                                        const AdamState* __restrict__ st,
+                                                        float* __restrict__ target, float tau) {
+    const float step_size = st->step_size, bc2_sqrt = st->bc2_sqrt;
+    const long n4 = n >> 2;
+    const long stride = (long)gridDim.x * blockDim.x;
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += stride) {
+        float4 g = reinterpret_cast<const float4*>(grad)[i];
+        for (int s = 1; s < n_slabs; ++s) {
+            const float4 gs = reinterpret_cast<const float4*>(grad + s * slab_stride)[i];
+            g.x += gs.x; g.y += gs.y; g.z += gs.z; g.w += gs.w;
+        }
+        float4 pp = reinterpret_cast<float4*>(p)[i];
+        float4 mm = reinterpret_cast<float4*>(m)[i];
+        float4 vv = reinterpret_cast<float4*>(v)[i];
+        adam_one(pp.x, mm.x, vv.x, g.x, step_size, bc2_sqrt);
+        adam_one(pp.y, mm.y, vv.y, g.y, step_size, bc2_sqrt);
+        adam_one(pp.z, mm.z, vv.z, g.z, step_size, bc2_sqrt);
+        adam_one(pp.w, mm.w, vv.w, g.w, step_size, bc2_sqrt);
+        reinterpret_cast<float4*>(p)[i] = pp;
+        reinterpret_cast<float4*>(m)[i] = mm;
+        reinterpret_cast<float4*>(v)[i] = vv;
+        if (target) {
+            float4 t = reinterpret_cast<float4*>(target)[i];
+            t.x = t.x * (1.0f - tau) + pp.x * tau; t.y = t.y * (1.0f - tau) + pp.y * tau;
+            t.z = t.z * (1.0f - tau) + pp.z * tau; t.w = t.w * (1.0f - tau) + pp.w * tau;
+            reinterpret_cast<float4*>(target)[i] = t;
+        }
+    }
+    // tail (n not a multiple of 4)
+    for (long i = (n4 << 2) + (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
+        float g = grad[i];
+        for (int s = 1; s < n_slabs; ++s) g += grad[s * slab_stride + i];
+        float pp = p[i], mm = m[i], vv = v[i];
+        adam_one(pp, mm, vv, g, step_size, bc2_sqrt);
+        p[i] = pp; m[i] = mm; v[i] = vv;
+        if (target) target[i] = target[i] * (1.0f - tau) + pp * tau;
+    }
+}
+
+__global__ __launch_bounds__(256) void reduce_slabs_kernel(float* __restrict__ out, const float* __restrict__ grad,
+                                                           int n_slabs, long slab_stride, long n) {
+    const long stride = (long)gridDim.x * blockDim.x;
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
+        float g = grad[i];
+        for (int s = 1; s < n_slabs; ++s) g += grad[s * slab_stride + i];
+        out[i] = g;
+    }
+}
+
+__global__ __launch_bounds__(256) void soft_update_kernel(float* __restrict__ target, const float* __restrict__ src,
+                                                          long n, float tau) {
+    const long stride = (long)gridDim.x * blockDim.x;
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride)
+        target[i] = target[i] * (1.0f - tau) + src[i] * tau;
+}
+
+__global__ __launch_bounds__(256) void axpby_kernel(float a, const float* x, float b, const float* y, long n, float* out) {
+    const long stride = (long)gridDim.x * blockDim.x;
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride)
+        out[i] = a * x[i] + (y ? b * y[i] : 0.f);
+}
+
+__global__ __launch_bounds__(256) void fill_kernel(float* p, float v, long n) {
+    const long stride = (long)gridDim.x * blockDim.x;
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) p[i] = v;
+}
+
+// out[c] = mul * sum_b partials[b][c]   (fixed order; one thread per column)
+__global__ void sum_partials_kernel(const float* partials, int n_blk, int n_cols, float mul, float* out) {
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= n_cols) return;
+    float s = 0.f;
+    for (int b = 0; b < n_blk; ++b) s += partials[(long)b * n_cols + c];
+    out[c] = s * mul;
+}
+
+static inline int stream_grid(long n, int per_thread = 1) {
+    long b = (n / per_thread + 255) / 256;
+    if (b < 1) b = 1;
+    if (b > 2048) b = 2048;
+    return (int)b;
+}
+
+extern "C" int nlbac_adam_prepare(void* state, double lr, nlbac_stream_t s) {
+    NLBAC_REQUIRE(state, "nlbac_adam_prepare: null state");
+    hipLaunchKernelGGL(adam_prepare_kernel, dim3(1), dim3(64), 0, (hipStream_t)s, (AdamState*)state, lr);
+    NLBAC_CHECK_LAUNCH("nlbac_adam_prepare");
+    return 0;
+}
+
+extern "C" int nlbac_adam_step(float* p, float* m, float* v, const float* grad, int n_slabs, long slab_stride,
+                               long n, const void* state, float* target, float tau, nlbac_stream_t s) {
+    NLBAC_REQUIRE(p && m && v && grad && state, "nlbac_adam_step: null pointer");
+    NLBAC_REQUIRE(n_slabs >= 1 && n >= 1, "nlbac_adam_step: bad sizes");
+    NLBAC_REQUIRE(((uintptr_t)p | (uintptr_t)m | (uintptr_t)v | (uintptr_t)grad | (uintptr_t)target) % 16 == 0 &&
+                      slab_stride % 4 == 0,
+                  "nlbac_adam_step: buffers must be 16-byte aligned");
+    hipLaunchKernelGGL(adam_step_kernel, dim3(stream_grid(n, 4)), dim3(256), 0, (hipStream_t)s, p, m, v, grad,
+                       n_slabs, slab_stride, n, (const AdamState*)state, (tau >= 0.f) ? target : nullptr, tau);
+    NLBAC_CHECK_LAUNCH("nlbac_adam_step");
+    return 0;
+}
+
+extern "C" int nlbac_reduce_slabs(float* out, const float* grad, int n_slabs, long slab_stride, long n, nlbac_stream_t s) {
+    NLBAC_REQUIRE(out && grad && n_slabs >= 1, "nlbac_reduce_slabs: bad arguments");
+    hipLaunchKernelGGL(reduce_slabs_kernel, dim3(stream_grid(n)), dim3(256), 0, (hipStream_t)s, out, grad, n_slabs, slab_stride, n);
+    NLBAC_CHECK_LAUNCH("nlbac_reduce_slabs");
+    return 0;
+}
+
+extern "C" int nlbac_soft_update(float* target, const float* src, long n, float tau, nlbac_stream_t s) {
+    NLBAC_REQUIRE(target && src, "nlbac_soft_update: null pointer");
+    hipLaunchKernelGGL(soft_update_kernel, dim3(stream_grid(n)), dim3(256), 0, (hipStream_t)s, target, src, n, tau);
+    NLBAC_CHECK_LAUNCH("nlbac_soft_update");
+    return 0;
+}
+
+extern "C" int nlbac_axpby(float a, const float* x, float b, const float* y, long n, float* out, nlbac_stream_t s) {
+    NLBAC_REQUIRE(x && out, "nlbac_axpby: null pointer");
+    hipLaunchKernelGGL(axpby_kernel, dim3(stream_grid(n)), dim3(256), 0, (hipStream_t)s, a, x, b, y, n, out);
+    NLBAC_CHECK_LAUNCH("nlbac_axpby");
+    return 0;
+}
+
+extern "C" int nlbac_fill(float* p, float v, long n, nlbac_stream_t s) {
+    NLBAC_REQUIRE(p, "nlbac_fill: null pointer");
+    hipLaunchKernelGGL(fill_kernel, dim3(stream_grid(n)), dim3(256), 0, (hipStream_t)s, p, v, n);
+    NLBAC_CHECK_LAUNCH("nlbac_fill");
+    return 0;
+}
+
+extern "C" int nlbac_sum_partials(const float* partials, int n_blk, int n_cols, float mul, float* out, nlbac_stream_t s) {
+    NLBAC_REQUIRE(partials && out && n_blk >= 1 && n_cols >= 1, "nlbac_sum_partials: bad arguments");
+    hipLaunchKernelGGL(sum_partials_kernel, dim3(nlbac_ceil_div(n_cols, 64)), dim3(64), 0, (hipStream_t)s, partials, n_blk, n_cols, mul, out);
+    NLBAC_CHECK_LAUNCH("nlbac_sum_partials");
+    return 0;
+}

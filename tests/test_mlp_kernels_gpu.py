@@ -1,0 +1,177 @@
+"""GPU: fused MLP kernels (forward / backward-data / backward-weights, Adam)
+through the C ABI vs a plain PyTorch fp32 reference of the same op.
+
+Tolerance: 1e-4 relative to each tensor's scale (BASELINE.json north_star:
+"within 1e-4 rel fp32"); the kernels use exact-fp32 MFMA so they typically
+land at ~1e-6.
+"""
+import ctypes as C
+
+import numpy as np
+import pytest
+import torch
+import torch.nn as nn
+
+from common import vec_close
+
+pytestmark = pytest.mark.gpu
+
+TOL = 1e-4
+
+
+def build(in_dim, hid, out_dim, n_layers, seed, n_slabs=4):
+    from nlbac_amd import arena as A
+    torch.manual_seed(seed)
+    dims = [in_dim] + [hid] * (n_layers - 1) + [out_dim]
+    lins = [nn.Linear(dims[i], dims[i + 1]) for i in range(n_layers)]
+    for l in lins:
+        nn.init.uniform_(l.bias, -0.3, 0.3)
+    ref = [(l.weight.detach().clone(), l.bias.detach().clone()) for l in lins]
+    ar = A.Arena("cuda", n_slabs=n_slabs)
+    h = A.MlpHandle(ar, [(l.weight, l.bias) for l in lins])
+    ar.finalize()
+    h.bind()
+    A.pack([h])
+    return ar, h, lins, ref
+
+
+def torch_ref(ref, x, dy):
+    ws = [(w.clone().requires_grad_(), b.clone().requires_grad_()) for w, b in ref]
+    x = x.clone().requires_grad_()
+    h = x
+    acts = []
+    for i, (w, b) in enumerate(ws):
+        h = torch.nn.functional.linear(h, w, b)
+        if i < len(ws) - 1:
+            h = torch.relu(h)
+            acts.append(h)
+    h.backward(dy)
+    return h.detach(), [a.detach() for a in acts], x.grad, [(w.grad, b.grad) for w, b in ws]
+
+
+@pytest.mark.parametrize("in_dim,hid,out_dim,n_layers,B,split", [
+    (9, 256, 1, 3, 100, 7),      # Q-net: obs(7) || action(2)
+    (2, 256, 1, 3, 33, 0),       # Lyapunov net
+    (7, 256, 4, 3, 4096, 0),     # policy heads at the headline batch
+    (3, 100, 3, 5, 77, 0),       # f_net (hidden 100 -> padded tiles)
+    (3, 100, 6, 4, 32, 0),       # g_net
+    (12, 64, 10, 4, 50, 10),     # SimulatedCars NODE shape
+    (3, 8, 2, 2, 5, 0),          # smallest legal net
+])
+def test_mlp_fwd_bwd_matches_torch(in_dim, hid, out_dim, n_layers, B, split):
+    from nlbac_amd import _lib, arena as A
+    ar, h, lins, ref = build(in_dim, hid, out_dim, n_layers, seed=B)
+    dev = "cuda"
+    g = torch.Generator().manual_seed(B + 1)
+    x = torch.randn(B, in_dim, generator=g)
+    dy = torch.randn(B, out_dim, generator=g)
+    y_ref, acts_ref, dx_ref, grads_ref = torch_ref(ref, x, dy)
+
+    xd, dyd = x.to(dev), dy.to(dev)
+    if split:
+        x0 = xd[:, :split].contiguous()
+        x1 = xd[:, split:].contiguous()
+    nw = n_layers - 1
+    y = torch.full((B, out_dim), float("nan"), device=dev)
+    acts = torch.full((nw, B, hid), float("nan"), device=dev)
+    dz = torch.full((nw, B, hid), float("nan"), device=dev)
+    dx = torch.full((B, in_dim), float("nan"), device=dev)
+    io = A.io_array(1)
+    if split:
+        io[0].x0, io[0].x0_dim, io[0].x0_ld = x0.data_ptr(), split, split
+        io[0].x1, io[0].x1_dim, io[0].x1_ld = x1.data_ptr(), in_dim - split, in_dim - split
+    else:
+        io[0].x0, io[0].x0_dim, io[0].x0_ld = xd.data_ptr(), in_dim, in_dim
+    io[0].y, io[0].y_ld = y.data_ptr(), out_dim
+    io[0].acts = acts.data_ptr()
+    io[0].dy, io[0].dy_ld = dyd.data_ptr(), out_dim
+    io[0].dz = dz.data_ptr()
+    io[0].dx, io[0].dx_ld = dx.data_ptr(), in_dim
+    io[0].grad = ar.grad.data_ptr()
+    nets = A.mlp_array([h.desc])
+    s = A.stream_ptr()
+    _lib.call("nlbac_mlp_fwd", nets, io, 1, B, s)
+    _lib.call("nlbac_mlp_bwd_data", nets, io, 1, B, s)
+    _lib.call("nlbac_mlp_bwd_weights", nets, io, 1, B, ar.n_slabs, ar.n, s)
+    torch.cuda.synchronize()
+
+    vec_close(y.cpu(), y_ref, TOL, "y")
+    for l in range(nw):
+        vec_close(acts[l].cpu(), acts_ref[l], TOL, "acts%d" % l)
+    vec_close(dx.cpu(), dx_ref, TOL, "dx")
+    for l, lin in enumerate(lins):
+        gw = ar.grad_view(lin.weight).cpu()
+        gb = ar.grad_view(lin.bias).cpu()
+        vec_close(gw, grads_ref[l][0], TOL, "dW%d" % l)
+        vec_close(gb, grads_ref[l][1], TOL, "db%d" % l)
+
+
+def test_multi_net_launch_and_adam_soft_update():
+    """Three nets in one launch (grid.y) + Adam with slab reduction + fused Polyak update
+    vs torch.optim.Adam / the reference's soft_update arithmetic."""
+    from nlbac_amd import _lib, arena as A
+    torch.manual_seed(0)
+    B, hid = 96, 256
+    mods = [[nn.Linear(9, hid), nn.Linear(hid, hid), nn.Linear(hid, 1)] for _ in range(2)]
+    mods.append([nn.Linear(2, hid), nn.Linear(hid, hid), nn.Linear(hid, 1)])
+    ref = [[(l.weight.detach().clone(), l.bias.detach().clone()) for l in m] for m in mods]
+    ar = A.Arena("cuda", n_slabs=3, with_target=True)
+    hs = [A.MlpHandle(ar, [(l.weight, l.bias) for l in m]) for m in mods]
+    ar.finalize()
+    ar.hard_update_target()
+    for h in hs:
+        h.bind()
+    A.pack(hs)
+    g = torch.Generator().manual_seed(5)
+    xs = [torch.randn(B, 9, generator=g), torch.randn(B, 9, generator=g), torch.randn(B, 2, generator=g)]
+    dys = [torch.randn(B, 1, generator=g) for _ in range(3)]
+    io = A.io_array(3)
+    keep = []
+    for i in range(3):
+        xd, dyd = xs[i].cuda(), dys[i].cuda()
+        y = torch.empty(B, 1, device="cuda")
+        acts = torch.empty(2, B, hid, device="cuda")
+        dz = torch.empty(2, B, hid, device="cuda")
+        keep += [xd, dyd, y, acts, dz]
+        io[i].x0, io[i].x0_dim, io[i].x0_ld = xd.data_ptr(), xs[i].shape[1], xs[i].shape[1]
+        io[i].y, io[i].y_ld = y.data_ptr(), 1
+        io[i].acts, io[i].dz = acts.data_ptr(), dz.data_ptr()
+        io[i].dy, io[i].dy_ld = dyd.data_ptr(), 1
+        io[i].grad = ar.grad.data_ptr()
+    nets = A.mlp_array([h.desc for h in hs])
+    s = A.stream_ptr()
+    tau, lr = 0.005, 4e-4
+    # torch reference: two Adam steps + soft updates
+    tparams = [[(w.clone().requires_grad_(), b.clone().requires_grad_()) for w, b in m] for m in ref]
+    flat = [t for m in tparams for wb in m for t in wb]
+    opt = torch.optim.Adam(flat, lr=lr)
+    targ = [t.detach().clone() for t in flat]
+    for it in range(2):
+        _lib.call("nlbac_mlp_fwd", nets, io, 3, B, s)
+        _lib.call("nlbac_mlp_bwd_data", nets, io, 3, B, s)
+        _lib.call("nlbac_mlp_bwd_weights", nets, io, 3, B, ar.n_slabs, ar.n, s)
+        _lib.call("nlbac_adam_prepare", ar.state.data_ptr(), lr, s)
+        _lib.call("nlbac_adam_step", ar.theta.data_ptr(), ar.m.data_ptr(), ar.v.data_ptr(), ar.grad.data_ptr(),
+                  ar.n_slabs, ar.n, ar.n, ar.state.data_ptr(), ar.target.data_ptr(), tau, s)
+        A.pack(hs)
+        opt.zero_grad()
+        for i in range(3):
+            h = xs[i]
+            for j, (w, b) in enumerate(tparams[i]):
+                h = torch.nn.functional.linear(h, w, b)
+                if j < 2:
+                    h = torch.relu(h)
+            h.backward(dys[i])
+        opt.step()
+        with torch.no_grad():
+            for t, p in zip(targ, flat):
+                t.copy_(t * (1.0 - tau) + p * tau)
+    torch.cuda.synchronize()
+    k = 0
+    for i, m in enumerate(mods):
+        for l in m:
+            for p in (l.weight, l.bias):
+                vec_close(p.detach().cpu(), flat[k].detach(), 2e-6, "param %d" % k)
+                off = ar.offset_of[id(p)]
+                vec_close(ar.target[off:off + p.numel()].cpu().view(p.shape), targ[k], 2e-6, "target %d" % k)
+                k += 1
