@@ -71,6 +71,8 @@ typedef struct nlbac_mlp_io {
     const float *x1; int x1_dim, x1_ld; /* input columns [x0_dim, in_dim) or NULL   */
     float *y; int y_ld;                 /* fwd out: (B, out_dim)                    */
     float *acts;                        /* [n_layers-1][B][hid] post-ReLU, saved by fwd */
+    long acts_ls;                       /* layer stride of acts/dz in floats; 0 = B*hid.  Lets several
+                                           launches (RK stages) fill row blocks of one [layer][rows][hid] buffer */
     const float *dy; int dy_ld;         /* bwd in:  (B, out_dim)                    */
     float *dz;                          /* [n_layers-1][B][hid] pre-activation grads (bwd_data out, bwd_weights in) */
     float *dx; int dx_ld;               /* bwd_data out: (B, in_dim) or NULL        */

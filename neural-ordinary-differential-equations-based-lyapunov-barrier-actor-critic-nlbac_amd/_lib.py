@@ -37,7 +37,7 @@ class MlpIO(C.Structure):
     _fields_ = [("x0", C.c_void_p), ("x0_dim", C.c_int), ("x0_ld", C.c_int),
                 ("x1", C.c_void_p), ("x1_dim", C.c_int), ("x1_ld", C.c_int),
                 ("y", C.c_void_p), ("y_ld", C.c_int),
-                ("acts", C.c_void_p),
+                ("acts", C.c_void_p), ("acts_ls", C.c_long),
                 ("dy", C.c_void_p), ("dy_ld", C.c_int),
                 ("dz", C.c_void_p),
                 ("dx", C.c_void_p), ("dx_ld", C.c_int),

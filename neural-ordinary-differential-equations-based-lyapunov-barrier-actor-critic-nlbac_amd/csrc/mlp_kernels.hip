@@ -144,7 +144,7 @@ __global__ __launch_bounds__(256) void mlp_fwd_kernel(const MlpLaunch L) {
         const int KC = ((l == 0) ? inp : hidp8) >> 3;
         const float4* pk = reinterpret_cast<const float4*>(net.packed + net.pf_off[l]);
         const float* bias = net.params + net.b_off[l];
-        float* acts = io.acts ? io.acts + (long)l * B * hid : nullptr;
+        float* acts = io.acts ? io.acts + (long)l * (io.acts_ls ? io.acts_ls : (long)B * hid) : nullptr;
         if (wave < NT) {
             f32x16 acc[2];
 #pragma unroll
@@ -251,8 +251,9 @@ __global__ __launch_bounds__(256) void mlp_bwd_data_kernel(const MlpLaunch L) {
                 }
             }
         }
-        const float* acts = io.acts + (long)(nwide - 1) * B * hid;
-        float* dz = io.dz ? io.dz + (long)(nwide - 1) * B * hid : nullptr;
+        const long ls = io.acts_ls ? io.acts_ls : (long)B * hid;
+        const float* acts = io.acts + (long)(nwide - 1) * ls;
+        float* dz = io.dz ? io.dz + (long)(nwide - 1) * ls : nullptr;
         if (k < hidp32) {
 #pragma unroll
             for (int m = 0; m < NLBAC_MLP_TILE; ++m) {
@@ -271,8 +272,9 @@ __global__ __launch_bounds__(256) void mlp_bwd_data_kernel(const MlpLaunch L) {
     for (int j = nwide - 1; j >= 1; --j) {
         const int KC = hidp8 >> 3;
         const float4* pk = reinterpret_cast<const float4*>(net.packed + net.pb_off[j]);
-        const float* acts = io.acts + (long)(j - 1) * B * hid;
-        float* dz = io.dz ? io.dz + (long)(j - 1) * B * hid : nullptr;
+        const long ls = io.acts_ls ? io.acts_ls : (long)B * hid;
+        const float* acts = io.acts + (long)(j - 1) * ls;
+        float* dz = io.dz ? io.dz + (long)(j - 1) * ls : nullptr;
         if (wave < NT) {
             f32x16 acc[2];
 #pragma unroll
@@ -360,8 +362,9 @@ __global__ __launch_bounds__(256) void mlp_bwd_wide_kernel(const MlpLaunch L) {
     const int rb = slab * L.rows_per_slab, re = min(B, rb + L.rows_per_slab);
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, half = lane >> 5;
     const int wn = wave >> 1, wk = wave & 1;
-    const float* dz = io.dz + (long)j * B * hid;
-    const float* at = io.acts + (long)(j - 1) * B * hid;
+    const long ls = io.acts_ls ? io.acts_ls : (long)B * hid;
+    const float* dz = io.dz + (long)j * ls;
+    const float* at = io.acts + (long)(j - 1) * ls;
     const int lr = tid >> 4, lc = (tid & 15) * 4;
 
     f32x16 acc;
@@ -437,7 +440,8 @@ __global__ __launch_bounds__(1024) void mlp_bwd_skinny_kernel(const MlpLaunch L)
 #pragma unroll
     for (int j = 0; j < NLBAC_MAX_LAYERS; ++j) db[j] = 0.f;
     float dbL = 0.f;
-    const float* aL = io.acts + (long)(nwide - 1) * B * hid;
+    const long ls = io.acts_ls ? io.acts_ls : (long)B * hid;
+    const float* aL = io.acts + (long)(nwide - 1) * ls;
 
     for (int r = rb + rg; r < re + rg; r += 4) {   // uniform trip count for the barriers
         const bool ok = r < re;
@@ -462,7 +466,7 @@ __global__ __launch_bounds__(1024) void mlp_bwd_skinny_kernel(const MlpLaunch L)
                 if (i < idim) dW0[i] += z0 * sx[rg][i];
 #pragma unroll
             for (int j = 1; j < NLBAC_MAX_LAYERS - 1; ++j)
-                if (j < nwide) db[j] += io.dz[((long)j * B + r) * hid + col];
+                if (j < nwide) db[j] += io.dz[(long)j * ls + (long)r * hid + col];
             const float a = aL[(long)r * hid + col];
 #pragma unroll
             for (int o = 0; o < SK_MAX_OUT; ++o)

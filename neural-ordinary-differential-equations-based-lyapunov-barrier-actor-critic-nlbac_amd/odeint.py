@@ -1,0 +1,319 @@
+"""Batched IVP solve of the learned control-affine dynamics on ``t = [0, dt]``
+and its exact (discretise-then-differentiate) backward — the device
+replacement of the ``torchdiffeq.odeint`` call sites
+``U/sac_cbf_clf/sac_cbf_clf.py:453,577`` and ``U/sac_cbf_clf/model.py:252``.
+
+Solvers (same semantics as ``oracle/nlbac_oracle.odeint``):
+  * ``euler``  one explicit Euler step over [0, dt] — the reference's setting
+  * ``rk4``    one 3/8-rule step
+  * ``dopri5`` Dormand–Prince 5(4), FSAL, one shared adaptive step per problem
+               (RMS error norm over the whole (rows, n_s+n_u) tensor), result =
+               4th-order interpolant at dt.  Step sizes carry no gradient.
+
+Rows are ``P`` problems x ``rpp`` rows (e.g. primary and backup controller
+actions on the same states).  Every stage costs one batched f_net/g_net
+launch (``nlbac_mlp_fwd``) plus two per-row algebra kernels; the step-size
+controller runs on the device and the host reads one 128-byte control block
+per attempted step.
+"""
+import ctypes as C
+
+import torch
+
+from . import _lib
+from ._lib import fptr
+from .arena import io_array, mlp_array, stream_ptr
+
+DP_BETA = [
+    [1 / 5],
+    [3 / 40, 9 / 40],
+    [44 / 45, -56 / 15, 32 / 9],
+    [19372 / 6561, -25360 / 2187, 64448 / 6561, -212 / 729],
+    [9017 / 3168, -355 / 33, 46732 / 5247, 49 / 176, -5103 / 18656],
+    [35 / 384, 0, 500 / 1113, 125 / 192, -2187 / 6784, 11 / 84],
+]
+DP_C_ERR = [35 / 384 - 1951 / 21600, 0, 500 / 1113 - 22642 / 50085, 125 / 192 - 451 / 720,
+            -2187 / 6784 - -12231 / 42400, 11 / 84 - 649 / 6300, -1. / 60.]
+
+TABLEAU = {
+    "euler": dict(beta=[], c_sol=[1.0]),
+    "rk4": dict(beta=[[1 / 3], [-1 / 3, 1.0], [1.0, -1.0, 1.0]], c_sol=[1 / 8, 3 / 8, 3 / 8, 1 / 8]),
+    "dopri5": dict(beta=DP_BETA, c_sol=None),
+}
+
+
+class _StepWS:
+    """Device buffers of one RK step for n rows (stage-major)."""
+
+    def __init__(self, solver, n, S):
+        dev, ns, nu = solver.device, solver.n_s, solver.n_u
+        f, g = solver.f, solver.g
+        self.n, self.S = n, S
+        z = lambda *s: torch.zeros(*s, dtype=torch.float32, device=dev)
+        self.K = z(S, n, ns)
+        self.Y = z(S, n, ns)
+        self.fout = z(n, ns)
+        self.gout = z(S, n, ns * nu)
+        self.acts_f = z(f.n_layers - 1, S * n, f.hid)
+        self.acts_g = z(g.n_layers - 1, S * n, g.hid)
+        self.y1 = z(n, ns)
+        self.err = z(n, ns)
+        self._bwd = None
+
+    def bwd(self, solver):
+        if self._bwd is None:
+            dev, ns, nu, n, S = solver.device, solver.n_s, solver.n_u, self.n, self.S
+            f, g = solver.f, solver.g
+            z = lambda *s: torch.zeros(*s, dtype=torch.float32, device=dev)
+            self.dK = z(S, n, ns)
+            self.dG = z(S, n, ns * nu)
+            self.dz_f = z(f.n_layers - 1, S * n, f.hid)
+            self.dz_g = z(g.n_layers - 1, S * n, g.hid)
+            self.dXf = z(n, f.in_dim)
+            self.dXg = z(n, g.in_dim)
+            self.dy0 = z(n, ns)
+            self.dy1 = z(n, ns)
+            self._bwd = True
+        return self
+
+
+class AffineNodeSolver:
+    """odeint for ``dx/dt = f(x) + g(x) u`` with u constant over the step."""
+
+    def __init__(self, node, device):
+        self.node, self.f, self.g = node, node.f, node.g
+        self.n_s, self.n_u = node.n_s, node.n_u
+        self.device = torch.device(device)
+        self._ws = {}          # (n, S, idx) -> _StepWS
+        self._scratch = {}
+        self.nfe = 0
+
+    # -- workspace -----------------------------------------------------------
+    def _step_ws(self, n, S, idx):
+        key = (n, S, idx)
+        if key not in self._ws:
+            self._ws[key] = _StepWS(self, n, S)
+        return self._ws[key]
+
+    def _buf(self, name, *shape, dtype=torch.float32):
+        key = (name, shape, dtype)
+        if key not in self._scratch:
+            self._scratch[key] = torch.zeros(*shape, dtype=dtype, device=self.device)
+        return self._scratch[key]
+
+    # -- one field evaluation k = f(x) + g(x) u -----------------------------------
+    def _eval(self, x, u, n, k_out, g_out, acts_f=None, acts_g=None, ls_f=0, ls_g=0):
+        io = io_array(2)
+        ns, nu = self.n_s, self.n_u
+        fout = self._buf("fout", n, ns)
+        for i, (y, ld, acts, ls) in enumerate(((fout, ns, acts_f, ls_f), (g_out, ns * nu, acts_g, ls_g))):
+            io[i].x0, io[i].x0_dim, io[i].x0_ld = x.data_ptr(), ns, ns
+            io[i].y, io[i].y_ld = y.data_ptr(), ld
+            if acts is not None:
+                io[i].acts, io[i].acts_ls = acts.data_ptr(), ls
+        s = stream_ptr()
+        _lib.call("nlbac_mlp_fwd", mlp_array([self.f.desc, self.g.desc]), io, 2, n, s)
+        _lib.call("nlbac_affine_combine_fwd", fout.data_ptr(), g_out.data_ptr(), u.data_ptr(), ns, nu, n,
+                  k_out.data_ptr(), s)
+        self.nfe += 1
+
+    def _stage_eval(self, ws, st, u):
+        n, S = ws.n, ws.S
+        f, g = self.f, self.g
+        self._eval(ws.Y[st], u, n, ws.K[st], ws.gout[st],
+                   ws.acts_f[:, st * n:], ws.acts_g[:, st * n:], S * n * f.hid, S * n * g.hid)
+
+    def _combine(self, y0, K, n_k, coef, h, P, rpp, out):
+        _lib.call("nlbac_rk_combine", y0.data_ptr() if y0 is not None else None, K.data_ptr(), n_k,
+                  fptr(*coef), fptr(*h), None, 0, P, rpp, self.n_s, out.data_ptr(), stream_ptr())
+
+    # -- forward ---------------------------------------------------------------
+    def forward(self, y0, u, P, rpp, method, dt, atol=1e-7, rtol=1e-5):
+        """y0: (P*rpp, n_s), u: (P*rpp, n_u) contiguous device tensors.
+        Returns x(dt) (P*rpp, n_s) (a solver-owned buffer, valid until the next call)."""
+        n = P * rpp
+        assert y0.shape == (n, self.n_s) and u.shape == (n, self.n_u)
+        self.ctx = dict(method=method, P=P, rpp=rpp, n=n, u=u, y0=y0, steps=[])
+        if method in ("euler", "rk4"):
+            tab = TABLEAU[method]
+            S = len(tab["c_sol"])
+            ws = self._step_ws(n, S, 0)
+            h = [float(dt)] * P
+            ws.Y[0].copy_(y0)
+            for st in range(S):
+                self._stage_eval(ws, st, u)
+                if st + 1 < S:
+                    self._combine(y0, ws.K, st + 1, tab["beta"][st], h, P, rpp, ws.Y[st + 1])
+            self._combine(y0, ws.K, S, tab["c_sol"], h, P, rpp, ws.y1)
+            self.ctx["steps"].append(dict(ws=ws, h=h, first=True))
+            self.ctx["out"] = ws.y1
+            return ws.y1
+        if method == "dopri5":
+            return self._forward_dopri5(y0, u, P, rpp, float(dt), atol, rtol)
+        raise ValueError("unknown solver %r" % (method,))
+
+    def _ctl(self, P):
+        return self._buf("ctl", P, _lib.DOPRI_CTL, dtype=torch.float64)
+
+    def _forward_dopri5(self, y0, u, P, rpp, t_end, atol, rtol):
+        n, ns, nu, S = P * rpp, self.n_s, self.n_u, 7
+        s = stream_ptr()
+        nblk = (rpp + 255) // 256
+        part = self._buf("part", P, nblk, 2)
+        ctl = self._ctl(P)
+        ws = self._step_ws(n, S, 0)
+        # f0 and the initial step size (Hairer's rule)
+        ws.Y[0].copy_(y0)
+        self._stage_eval(ws, 0, u)
+        _lib.call("nlbac_dopri_norm_partials", ws.K[0].data_ptr(), None, y0.data_ptr(), None, u.data_ptr(), 0,
+                  rtol, atol, ns, nu, rpp, P, part.data_ptr(), s)
+        _lib.call("nlbac_dopri_control", part.data_ptr(), nblk, 0, ns, nu, rpp, P, t_end, ctl.data_ptr(), s)
+        ytmp, ktmp, gtmp = self._buf("ytmp", n, ns), self._buf("ktmp", n, ns), self._buf("gtmp", n, ns * nu)
+        h0_dev = ctl.data_ptr() + 6 * 8           # C_H0
+        _lib.call("nlbac_rk_combine", y0.data_ptr(), ws.K.data_ptr(), 1, fptr(1.0), None, h0_dev, _lib.DOPRI_CTL,
+                  P, rpp, ns, ytmp.data_ptr(), s)
+        self._eval(ytmp, u, n, ktmp, gtmp)
+        _lib.call("nlbac_dopri_norm_partials", ktmp.data_ptr(), ws.K[0].data_ptr(), y0.data_ptr(), None, None, 1,
+                  rtol, atol, ns, nu, rpp, P, part.data_ptr(), s)
+        _lib.call("nlbac_dopri_control", part.data_ptr(), nblk, 1, ns, nu, rpp, P, t_end, ctl.data_ptr(), s)
+
+        h_dev = ctl.data_ptr()                    # C_H
+        steps, info = [], []
+        cur_y0, idx = y0, 0
+        for attempt in range(1000):
+            ws = self._step_ws(n, S, idx)
+            if idx > 0 and not steps[-1].get("linked"):
+                prev = steps[-1]["ws"]
+                ws.Y[0].copy_(prev.y1)
+                ws.K[0].copy_(prev.K[6])          # FSAL
+                steps[-1]["linked"] = True
+            for st in range(1, S):
+                _lib.call("nlbac_rk_combine", cur_y0.data_ptr(), ws.K.data_ptr(), st, fptr(*DP_BETA[st - 1]), None,
+                          h_dev, _lib.DOPRI_CTL, P, rpp, ns, ws.Y[st].data_ptr(), s)
+                self._stage_eval(ws, st, u)
+            _lib.call("nlbac_rk_combine", None, ws.K.data_ptr(), S, fptr(*DP_C_ERR), None, h_dev, _lib.DOPRI_CTL,
+                      P, rpp, ns, ws.err.data_ptr(), s)
+            y1 = ws.Y[6]
+            _lib.call("nlbac_dopri_norm_partials", ws.err.data_ptr(), None, cur_y0.data_ptr(), y1.data_ptr(), None,
+                      2, rtol, atol, ns, nu, rpp, P, part.data_ptr(), s)
+            _lib.call("nlbac_dopri_control", part.data_ptr(), nblk, 2, ns, nu, rpp, P, t_end, ctl.data_ptr(), s)
+            c = ctl.cpu()                         # the one host sync per attempted step
+            acc = [bool(c[p, 3] > 0) for p in range(P)]
+            done = [bool(c[p, 4] > 0) for p in range(P)]
+            info.append([(float(c[p, 11]), float(c[p, 2]), acc[p]) for p in range(P)])
+            if any(a != acc[0] for a in acc) or any(d != done[0] for d in done):
+                raise _lib.NlbacError("dopri5: problems in one batch took different accept/finish decisions; "
+                                      "solve them in separate calls (P=1)")
+            if acc[0]:
+                ws.y1.copy_(y1)
+                steps.append(dict(ws=ws, h=[float(c[p, 11]) for p in range(P)], first=(idx == 0)))
+                if done[0]:
+                    x = [float(c[p, 5]) for p in range(P)]
+                    steps[-1]["x"] = x
+                    out = self._buf("dopri_out", n, ns)
+                    _lib.call("nlbac_dopri_interp_fwd", cur_y0.data_ptr(), ws.y1.data_ptr(), ws.K.data_ptr(),
+                              fptr(*steps[-1]["h"]), fptr(*x), P, rpp, ns, out.data_ptr(), s)
+                    self.ctx.update(steps=steps, out=out, info=info)
+                    return out
+                cur_y0 = ws.y1
+                idx += 1
+        raise _lib.NlbacError("dopri5: max_num_steps exceeded")
+
+    # -- backward --------------------------------------------------------------
+    def backward(self, dout, need_du=True, need_params=False, need_dy0=False):
+        """dout: (n, n_s).  Returns (du or None, dy0 or None).  With
+        ``need_params`` the pre-activation grads of every stage are kept for
+        ``accumulate_param_grads``."""
+        ctx = self.ctx
+        P, rpp, n, u, method = ctx["P"], ctx["rpp"], ctx["n"], ctx["u"], ctx["method"]
+        ns, nu = self.n_s, self.n_u
+        s = stream_ptr()
+        du = self._buf("du", n, nu) if need_du else None
+        if du is not None:
+            du.zero_()
+        steps = ctx["steps"]
+        dy_carry = None          # grad wrt the y1 of the step being processed
+        dk_carry = None          # grad wrt f1 (=K[6]) of that step, from the next step's FSAL stage 0
+        for si in range(len(steps) - 1, -1, -1):
+            step = steps[si]
+            ws = step["ws"].bwd(self)
+            S, h = ws.S, step["h"]
+            last = si == len(steps) - 1
+            ws.dK.zero_()
+            if method == "dopri5":
+                beta, first_eval = DP_BETA, step["first"]
+                if last:
+                    _lib.call("nlbac_dopri_interp_bwd", dout.data_ptr(), fptr(*h), fptr(*step["x"]), P, rpp, ns,
+                              ws.dy0.data_ptr(), ws.dy1.data_ptr(), ws.dK.data_ptr(), s)
+                else:
+                    ws.dy0.zero_()
+                    ws.dy1.copy_(dy_carry)
+                    ws.dK[6].add_(dk_carry)
+                top_up = ws.dy1           # y1 == stage-6 input
+            else:
+                tab = TABLEAU[method]
+                beta, first_eval = tab["beta"], True
+                # out = y0 + h sum c_j K_j
+                _lib.call("nlbac_rk_stage_bwd", dout.data_ptr(), None, None, 0, S, fptr(*tab["c_sol"]), fptr(*h),
+                          None, 0, P, rpp, ns, ws.dK.data_ptr(), ws.dy0.data_ptr(), 0, s)
+                top_up = None
+            for st in range(S - 1, -1, -1):
+                if st == 0 and not first_eval:
+                    break                  # FSAL alias of the previous step's last stage
+                need_dx = (st > 0) or need_dy0
+                # field backward at stage st
+                _lib.call("nlbac_affine_combine_bwd", ws.dK[st].data_ptr(), ws.gout[st].data_ptr(), u.data_ptr(),
+                          ns, nu, n, 1.0, ws.dG[st].data_ptr() if (need_dx or need_params) else None,
+                          du.data_ptr() if du is not None else None, 1, s)
+                if need_dx or need_params:
+                    io = io_array(2)
+                    f, g = self.f, self.g
+                    for i, (net, dy, ld, acts, dz, dx) in enumerate((
+                            (f, ws.dK[st], ns, ws.acts_f, ws.dz_f, ws.dXf),
+                            (g, ws.dG[st], ns * nu, ws.acts_g, ws.dz_g, ws.dXg))):
+                        io[i].dy, io[i].dy_ld = dy.data_ptr(), ld
+                        io[i].acts = acts[:, st * ws.n:].data_ptr()
+                        io[i].acts_ls = S * ws.n * net.hid
+                        if need_params:
+                            io[i].dz = dz[:, st * ws.n:].data_ptr()
+                        if need_dx:
+                            io[i].dx, io[i].dx_ld = dx.data_ptr(), net.in_dim
+                    _lib.call("nlbac_mlp_bwd_data", mlp_array([f.desc, g.desc]), io, 2, n, s)
+                if need_dx:
+                    up = top_up if (st == S - 1 and top_up is not None) else None
+                    coef = beta[st - 1] if st > 0 else []
+                    _lib.call("nlbac_rk_stage_bwd", up.data_ptr() if up is not None else None, ws.dXf.data_ptr(),
+                              ws.dXg.data_ptr(), self.f.in_dim, st, fptr(*coef) if coef else None, fptr(*h), None, 0,
+                              P, rpp, ns, ws.dK.data_ptr(), ws.dy0.data_ptr(), 1, s)
+            dy_carry = ws.dy0
+            dk_carry = ws.dK[0]
+        dy0 = steps[0]["ws"].dy0 if need_dy0 else None
+        return du, dy0
+
+    def accumulate_param_grads(self, arena, slabs_per_step):
+        """dW/db of f_net and g_net over every evaluated stage of every accepted
+        step; step i writes slabs [i*slabs_per_step, (i+1)*slabs_per_step).
+        Returns the number of slabs written."""
+        ctx = self.ctx
+        s = stream_ptr()
+        n_used = 0
+        for si, step in enumerate(ctx["steps"]):
+            ws = step["ws"]
+            S, n = ws.S, ws.n
+            st0 = 0 if step["first"] or ctx["method"] != "dopri5" else 1
+            rows = (S - st0) * n
+            io = io_array(2)
+            for i, (net, x, dy, ld, acts, dz) in enumerate((
+                    (self.f, ws.Y, ws.dK, self.n_s, ws.acts_f, ws.dz_f),
+                    (self.g, ws.Y, ws.dG, self.n_s * self.n_u, ws.acts_g, ws.dz_g))):
+                io[i].x0, io[i].x0_dim, io[i].x0_ld = x[st0:].data_ptr(), self.n_s, self.n_s
+                io[i].dy, io[i].dy_ld = dy[st0:].data_ptr(), ld
+                io[i].acts = acts[:, st0 * n:].data_ptr()
+                io[i].dz = dz[:, st0 * n:].data_ptr()
+                io[i].acts_ls = S * n * net.hid
+                io[i].grad = arena.grad[n_used:].data_ptr()
+            assert n_used + slabs_per_step <= arena.n_slabs, "arena has too few gradient slabs"
+            _lib.call("nlbac_mlp_bwd_weights", mlp_array([self.f.desc, self.g.desc]), io, 2, rows, slabs_per_step,
+                      arena.n, s)
+            n_used += slabs_per_step
+        return n_used

@@ -1,0 +1,142 @@
+"""Network containers of the agent.
+
+Same classes, constructor signatures, ``state_dict`` key names and weight
+initialisation as the reference (``U/sac_cbf_clf/model.py:14-17, 37-133,
+177-206``): actor / critic / Lyapunov layers are Xavier-uniform with zero
+bias, the NODE keeps PyTorch's default ``nn.Linear`` init.  The modules only
+*hold* parameters (as views into a flat HBM arena, see ``nlbac_amd.arena``);
+all arithmetic runs in the HIP kernels — ``forward`` here is the thin
+inference path used by ``select_action``.
+"""
+import torch
+import torch.nn as nn
+
+from .. import _lib
+from ..arena import MlpHandle, io_array, mlp_array, stream_ptr
+
+LOG_SIG_MAX = 2
+LOG_SIG_MIN = -20
+epsilon = 1e-6
+
+
+def weights_init_(m):
+    if isinstance(m, nn.Linear):
+        torch.nn.init.xavier_uniform_(m.weight, gain=1)
+        torch.nn.init.constant_(m.bias, 0)
+
+
+def _run_fwd(handles, ios, B, target=False):
+    descs = [h.desc_target if target else h.desc for h in handles]
+    _lib.call("nlbac_mlp_fwd", mlp_array(descs), ios, len(descs), B, stream_ptr())
+
+
+class QNetwork(nn.Module):
+    """Twin Q: linear1-3 and linear4-6 over cat(state, action)."""
+
+    def __init__(self, num_inputs, num_actions, hidden_dim):
+        super().__init__()
+        i = num_inputs + num_actions
+        self.linear1 = nn.Linear(i, hidden_dim)
+        self.linear2 = nn.Linear(hidden_dim, hidden_dim)
+        self.linear3 = nn.Linear(hidden_dim, 1)
+        self.linear4 = nn.Linear(i, hidden_dim)
+        self.linear5 = nn.Linear(hidden_dim, hidden_dim)
+        self.linear6 = nn.Linear(hidden_dim, 1)
+        self.apply(weights_init_)
+
+    def attach(self, arena):
+        self.q1 = MlpHandle(arena, [(l.weight, l.bias) for l in (self.linear1, self.linear2, self.linear3)], "q1")
+        self.q2 = MlpHandle(arena, [(l.weight, l.bias) for l in (self.linear4, self.linear5, self.linear6)], "q2")
+        return [self.q1, self.q2]
+
+
+class LyaNetwork(nn.Module):
+    """Lyapunov critic (also the shape of the NBC variants' BarrierNetwork)."""
+
+    def __init__(self, num_inputs, hidden_dim):
+        super().__init__()
+        self.linear1 = nn.Linear(num_inputs, hidden_dim)
+        self.linear2 = nn.Linear(hidden_dim, hidden_dim)
+        self.linear3 = nn.Linear(hidden_dim, 1)
+        self.apply(weights_init_)
+
+    def attach(self, arena):
+        self.net = MlpHandle(arena, [(l.weight, l.bias) for l in (self.linear1, self.linear2, self.linear3)], "lya")
+        return [self.net]
+
+
+BarrierNetwork = LyaNetwork
+
+
+class GaussianPolicy(nn.Module):
+    """Squashed-Gaussian actor; mean / log_std heads share one skinny layer on device."""
+
+    def __init__(self, num_inputs, num_actions, hidden_dim, action_space=None):
+        super().__init__()
+        self.linear1 = nn.Linear(num_inputs, hidden_dim)
+        self.linear2 = nn.Linear(hidden_dim, hidden_dim)
+        self.mean_linear = nn.Linear(hidden_dim, num_actions)
+        self.log_std_linear = nn.Linear(hidden_dim, num_actions)
+        self.apply(weights_init_)
+        self.num_actions = num_actions
+        if action_space is None:
+            self.action_scale = torch.ones(num_actions)
+            self.action_bias = torch.zeros(num_actions)
+        else:
+            self.action_scale = torch.FloatTensor((action_space.high - action_space.low) / 2.)
+            self.action_bias = torch.FloatTensor((action_space.high + action_space.low) / 2.)
+
+    def attach(self, arena):
+        self.net = MlpHandle(arena, [
+            (self.linear1.weight, self.linear1.bias), (self.linear2.weight, self.linear2.bias),
+            ([self.mean_linear.weight, self.log_std_linear.weight],
+             [self.mean_linear.bias, self.log_std_linear.bias])], "policy")
+        return [self.net]
+
+    def to(self, device):
+        self.action_scale = self.action_scale.to(device)
+        self.action_bias = self.action_bias.to(device)
+        return super().to(device)
+
+    def sample(self, state, eps=None):
+        """(action, log_prob, tanh(mean)*scale+bias) for a (n, obs) device tensor."""
+        n, A = state.shape[0], self.num_actions
+        state = state.contiguous().float()
+        heads = torch.empty(n, 2 * A, device=state.device)
+        io = io_array(1)
+        io[0].x0, io[0].x0_dim, io[0].x0_ld = state.data_ptr(), state.shape[1], state.shape[1]
+        io[0].y, io[0].y_ld = heads.data_ptr(), 2 * A
+        _run_fwd([self.net], io, n)
+        if eps is None:
+            eps = torch.randn(n, A, device=state.device)
+        action = torch.empty(n, A, device=state.device)
+        logp = torch.empty(n, device=state.device)
+        _lib.call("nlbac_gauss_sample_fwd", heads.data_ptr(), 2 * A, eps.data_ptr(), self.action_scale.data_ptr(),
+                  self.action_bias.data_ptr(), A, n, action.data_ptr(), A, logp.data_ptr(), stream_ptr())
+        mean = torch.tanh(heads[:, :A]) * self.action_scale + self.action_bias
+        return action, logp.unsqueeze(1), mean
+
+
+class NeuralODEModel(nn.Module):
+    """Learned dynamics.  ``NeuralODEModel(input_dim, output_dim1, output_dim2)``
+    is the control-affine field f(x) + g(x) u with f_net 5 and g_net 4 Linear
+    layers of width 100 (model.py:177-206)."""
+
+    def __init__(self, input_dim, output_dim1, output_dim2, hidden_dim=100, f_depth=5, g_depth=4):
+        super().__init__()
+        self.input_dim, self.output_dim1, self.output_dim2 = input_dim, output_dim1, output_dim2
+        self.n_s, self.n_u = output_dim1, output_dim2 // output_dim1
+
+        def seq(depth, out):
+            layers = [nn.Linear(input_dim, hidden_dim), nn.ReLU()]
+            for _ in range(depth - 2):
+                layers += [nn.Linear(hidden_dim, hidden_dim), nn.ReLU()]
+            layers += [nn.Linear(hidden_dim, out)]
+            return nn.Sequential(*layers)
+        self.f_net = seq(f_depth, output_dim1)
+        self.g_net = seq(g_depth, output_dim2)
+
+    def attach(self, arena):
+        self.f = MlpHandle(arena, [(m.weight, m.bias) for m in self.f_net if isinstance(m, nn.Linear)], "f_net")
+        self.g = MlpHandle(arena, [(m.weight, m.bias) for m in self.g_net if isinstance(m, nn.Linear)], "g_net")
+        return [self.f, self.g]

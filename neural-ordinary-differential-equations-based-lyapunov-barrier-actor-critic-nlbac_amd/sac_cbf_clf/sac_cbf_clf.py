@@ -1,0 +1,514 @@
+"""``SAC_CBF_CLF`` — drop-in for the reference agent class
+(``U/sac_cbf_clf/sac_cbf_clf.py:26-656``) whose ``update_parameters`` runs
+entirely on one MI355X through the C ABI in ``include/nlbac_hip.h``.
+
+Same constructor arguments, public methods, return values, checkpoint files
+and ``state_dict`` key names as the reference.  Differences that are visible
+to a caller:
+  * CUDA(HIP)-only: ``args.cuda`` must be true (no CPU fallback);
+  * ``self.solver`` may be ``'euler'`` (reference default), ``'rk4'`` or
+    ``'dopri5'``; the NODE-fit and CBF/CLF rollouts use it;
+  * Lagrange multipliers / augmented term / alpha live on the device
+    (``lambda_values`` etc. are read-back properties);
+  * policy noise comes from the device generator unless ``set_noise`` is
+    given pre-drawn N(0,1) samples (parity tests).
+
+One update = the launch sequence in ``_update_device``: every
+per-sample quantity is computed in fused HIP kernels, the only host<->device
+traffic is the minibatch upload and one 512-byte scalars read-back.
+"""
+import random
+
+import numpy as np
+import torch
+import torch.nn as nn
+
+from .. import _lib
+from ..arena import Arena, io_array, mlp_array, pack, stream_ptr
+from ..odeint import AffineNodeSolver
+from . import _layout as SC
+from .model import GaussianPolicy, LyaNetwork, NeuralODEModel, QNetwork
+from .utils import to_tensor
+
+DYNAMICS_MODE = {'Unicycle': {'n_s': 3, 'n_u': 2}}
+l_p = 0.03
+
+
+class PoseLoss(nn.Module):
+    """MSE('mean') — kept for API parity; the fit computes it on device."""
+
+    def forward(self, predicted_state, true_state):
+        return nn.functional.mse_loss(predicted_state, true_state)
+
+
+class _Workspace:
+    """Per-batch-size device buffers (allocated once, reused every update)."""
+
+    def __init__(self, B, H, dev, n_hz):
+        z = lambda *s: torch.zeros(*s, dtype=torch.float32, device=dev)
+        self.B = B
+        self.mb = z(B, 24)                       # minibatch rows: obs7 act2 r c cen2 ncen2 nobs7 mask (+pad)
+        self.eps = z(3, B, 2)
+        self.heads_n, self.na, self.nlogp = z(B, 4), z(B, 2), z(B)
+        self.q6 = z(6, B)                        # q1t q2t lt q1 q2 lf
+        self.dq3 = z(3, B)
+        self.next_q, self.next_l = z(B), z(B)
+        self.acts_c = z(3, 2, B, H)              # Q1,Q2,L saved activations
+        self.dz_c = z(3, 2, B, H)
+        self.nblk = (B + 255) // 256
+        self.part_td = z(self.nblk, 3)
+        self.heads2, self.pi2, self.logp2 = z(2 * B, 4), z(2 * B, 2), z(2 * B)
+        self.acts_p = z(2, 2, B, H)
+        self.dz_p = z(2, 2, B, H)
+        self.state, self.ps = z(B, 3), z(B, 2)
+        self.y0_2 = z(2 * B, 3)
+        self.qpi = z(2, 2 * B)
+        self.acts_q = z(4, 2, B, H)
+        self.V, self.Vn, self.dVn = z(B), z(B), z(B)
+        self.acts_vn = z(2, B, H)
+        self.dq_pi = z(2, 2 * B)
+        self.part_q = z(2, self.nblk, 2)
+        self.ps_next2, self.dps_next2, self.dps_v2 = z(2 * B, 2), z(2 * B, 2), z(2 * B, 2)
+        self.matr, self.bmatr = z(B, n_hz + 1), z(B, n_hz)
+        self.part_c = z(self.nblk, 2 * n_hz + 1)
+        self.dx_next2 = z(2 * B, 3)
+        self.dxq = z(2, 2 * B, 9)
+        self.dheads2 = z(2 * B, 4)
+
+
+class SAC_CBF_CLF(object):
+
+    def __init__(self, num_inputs, action_space, env, args):
+        self.gamma = args.gamma
+        self.gamma_b = args.gamma_b
+        self.tau = args.tau
+        self.center_pos_num = 2
+        self.policy_type = args.policy
+        self.batch_size = args.batch_size
+        self.target_update_interval = args.target_update_interval
+        self.Lagrangian_multiplier_update_interval = args.Lagrangian_multiplier_update_interval
+        self.automatic_entropy_tuning = args.automatic_entropy_tuning
+        self.action_space = action_space
+        self.action_space.seed(args.seed)
+        if not args.cuda or not torch.cuda.is_available():
+            raise RuntimeError("nlbac_amd.SAC_CBF_CLF runs on an MI355X only (pass --cuda on a GPU box); "
+                               "there is no CPU fallback")
+        if self.policy_type != "Gaussian":
+            raise NotImplementedError("only the Gaussian policy is on the device path")
+        _lib.load()
+        self.device = torch.device("cuda")
+        self.critic_lyapunov_lr = 0.0004
+        self.lr = args.lr
+        hidden = args.hidden_size
+        n_act = action_space.shape[0]
+        self.num_inputs, self.n_act, self.hidden = num_inputs, n_act, hidden
+        self.n_grad_slabs = int(getattr(args, "grad_slabs", 8))
+
+        # --- same construction order (and RNG consumption) as the reference ---
+        self.critic = QNetwork(num_inputs, n_act, hidden)
+        self.lyapunovNet = LyaNetwork(self.center_pos_num, hidden)
+        QNetwork(num_inputs, n_act, hidden)          # the reference builds target nets here
+        LyaNetwork(self.center_pos_num, hidden)      # (then hard-copies): consume the same RNG
+        self.cost_limit = 0.0
+        self.augmented_ratio = 1.0005
+        if args.seed >= 0:
+            env.seed(args.seed)
+            random.seed(args.seed)
+            env.action_space.seed(args.seed)
+            torch.manual_seed(args.seed)
+            np.random.seed(args.seed)
+            torch.cuda.manual_seed_all(args.seed)
+        self.target_entropy = -float(np.prod(action_space.shape))
+        self.log_alpha = nn.Parameter(torch.zeros(1))
+        self.backup_log_alpha = nn.Parameter(torch.zeros(1))
+        self.policy = GaussianPolicy(num_inputs, n_act, hidden, action_space)
+        self.backup_policy = GaussianPolicy(num_inputs, n_act, hidden, action_space)
+
+        self.env = env
+        if self.env.dynamics_mode not in DYNAMICS_MODE:
+            raise Exception('Dynamics mode not supported.')
+        self.num_cbfs = len(env.hazards_locations)
+        self.l_p = l_p
+        self.action_dim = env.action_space.shape[0]
+        self.u_min, self.u_max = self.get_control_bounds()
+        self.num_constraints = self.num_cbfs + 1
+        self.neural_ode_model = NeuralODEModel(3, 3, 6)
+        self.solver = 'euler'
+        self.model_loss_func = PoseLoss()
+        self.atol, self.rtol = 1e-7, 1e-5
+
+        # --- flat HBM arenas, one per optimiser group --------------------------
+        dev = self.device
+        self.ar_c = Arena(dev, self.n_grad_slabs, with_target=True)     # critic + Lyapunov (lr 4e-4)
+        self.ar_a = Arena(dev, self.n_grad_slabs)                        # policies + log alphas (lr args.lr)
+        self.ar_n = Arena(dev, self.n_grad_slabs * 2)                    # NODE (lr 1e-3)
+        self.h_q1, self.h_q2 = self.critic.attach(self.ar_c)
+        (self.h_l,) = self.lyapunovNet.attach(self.ar_c)
+        (self.h_p,) = self.policy.attach(self.ar_a)
+        (self.h_b,) = self.backup_policy.attach(self.ar_a)
+        self.ar_a.add_group([self.log_alpha])
+        self.ar_a.add_group([self.backup_log_alpha])
+        self.h_f, self.h_g = self.neural_ode_model.attach(self.ar_n)
+        for ar in (self.ar_c, self.ar_a, self.ar_n):
+            ar.finalize()
+        self.ar_c.hard_update_target()
+        self.policy.to(dev)
+        self.backup_policy.to(dev)
+        for h in (self.h_q1, self.h_q2, self.h_l, self.h_p, self.h_b, self.h_f, self.h_g):
+            h.bind()
+        self.la_off = self.ar_a.offset_of[id(self.log_alpha)]
+        self.la_stride = self.ar_a.offset_of[id(self.backup_log_alpha)] - self.la_off
+        # target networks as modules over the Polyak buffer (state_dict / inspection)
+        self.critic_target = _TargetView(self.critic, self.ar_c)
+        self.lyapunovNet_target = _TargetView(self.lyapunovNet, self.ar_c)
+        self.repack_all()
+
+        # --- device scalars: alpha, lambdas, augmented term --------------------
+        self.sc = torch.zeros(SC.SC_SIZE, dtype=torch.float32, device=dev)
+        sc_host = np.zeros(SC.SC_SIZE, dtype=np.float32)
+        sc_host[SC.SC_ALPHA] = sc_host[SC.SC_BALPHA] = args.alpha
+        sc_host[SC.SC_RHO_F64:SC.SC_RHO_F64 + 2] = np.array([1.0], dtype=np.float64).view(np.float32)
+        sc_host[SC.SC_BRHO_F64:SC.SC_BRHO_F64 + 2] = np.array([1.0], dtype=np.float64).view(np.float32)
+        self.sc.copy_(torch.from_numpy(sc_host))
+        self.hazards = torch.tensor(np.asarray(env.hazards_locations), dtype=torch.float32, device=dev).contiguous()
+        self.node_solver = AffineNodeSolver(self.neural_ode_model, dev)      # policy-loss rollouts (2B rows)
+        self.fit_solver = AffineNodeSolver(self.neural_ode_model, dev)       # NODE fit rollouts
+        self._ws = {}
+        self._noise = None
+        self._fit_ws = {}
+        self.last_debug = {}
+
+    # ------------------------------------------------------------------ utils
+    def repack_all(self):
+        pack([self.h_q1, self.h_q2, self.h_l, self.h_p, self.h_b, self.h_f, self.h_g])
+        pack([self.h_q1, self.h_q2, self.h_l], target=True)
+
+    def set_noise(self, eps_list):
+        """Pre-drawn N(0,1) draws for the next update, reference order:
+        [next_obs sample, obs sample, backup sample], each (B, n_u)."""
+        self._noise = [torch.as_tensor(e, dtype=torch.float32) for e in eps_list]
+
+    def _scalars(self):
+        return self.sc.cpu().numpy()
+
+    @property
+    def alpha(self):
+        return float(self._scalars()[SC.SC_ALPHA])
+
+    @property
+    def backup_alpha(self):
+        return float(self._scalars()[SC.SC_BALPHA])
+
+    @property
+    def lambda_values(self):
+        return [float(x) for x in self._scalars()[SC.SC_LAMBDA:SC.SC_LAMBDA + self.num_constraints]]
+
+    @property
+    def backup_lambda_values(self):
+        return [float(x) for x in self._scalars()[SC.SC_BLAMBDA:SC.SC_BLAMBDA + self.num_cbfs]]
+
+    @property
+    def augmented_term(self):
+        return float(self._scalars()[SC.SC_RHO_F64:SC.SC_RHO_F64 + 2].view(np.float64)[0])
+
+    def get_control_bounds(self):
+        u_min = torch.tensor(self.env.safe_action_space.low).to(self.device)
+        u_max = torch.tensor(self.env.safe_action_space.high).to(self.device)
+        return u_min, u_max
+
+    # --------------------------------------------------------- action selection
+    def _select(self, policy, state, evaluate, warmup):
+        state = to_tensor(np.asarray(state, dtype=np.float64), torch.FloatTensor, self.device)
+        expand_dim = len(state.shape) == 1
+        if expand_dim:
+            state = state.unsqueeze(0)
+        if warmup:
+            action = torch.stack([torch.from_numpy(self.action_space.sample()) for _ in range(state.shape[0])])
+        else:
+            a, _, mean = policy.sample(state)
+            action = mean if evaluate else a
+        action = action.detach().cpu().numpy()
+        return action[0] if expand_dim else action
+
+    def select_action(self, state, evaluate=False, warmup=False):
+        return self._select(self.policy, state, evaluate, warmup)
+
+    def select_action_backup(self, state, evaluate=False, warmup=False):
+        return self._select(self.backup_policy, state, evaluate, warmup)
+
+    # ------------------------------------------------------------------ update
+    def update_parameters(self, memory, batch_size, updates, dynamics_model, NODE_memory, NODE_model_update_interval):
+        """Same contract as the reference (sac_cbf_clf.py:181-319): one sampled
+        minibatch -> 6 floats.  ``dynamics_model`` is accepted for signature
+        parity; obs->state runs on the device."""
+        batch = memory.sample(batch_size=batch_size)
+        node_batch = None
+        if updates % NODE_model_update_interval == 0:
+            nb = min(NODE_memory.position, 32768)
+            rows = NODE_memory.sample(batch_size=nb)
+            node_batch = (rows[0], rows[1], rows[6])
+        return self.update_from_host(batch, updates, node_batch)
+
+    def update_from_host(self, batch, updates, node_batch=None):
+        """batch: the 10-tuple of numpy arrays of ``ReplayMemory.sample``."""
+        state, action, reward, constraint, center, ncenter, nstate, mask = batch[:8]
+        B = state.shape[0]
+        ws = self._workspace(B)
+        host = np.empty((B, 24), dtype=np.float32)
+        host[:, 0:7], host[:, 7:9] = state, action
+        host[:, 9], host[:, 10] = reward, constraint
+        host[:, 11:13], host[:, 13:15] = center, ncenter
+        host[:, 15:22], host[:, 22] = nstate, mask
+        host[:, 23] = 0
+        ws.mb.copy_(torch.from_numpy(host), non_blocking=False)
+        if node_batch is not None:
+            nobs, nact, nnobs = (torch.as_tensor(np.asarray(a), dtype=torch.float32).to(self.device)
+                                 for a in node_batch)
+            self.fit_node(nobs, nact, nnobs)
+        return self.update_on_device(ws, updates)
+
+    def _workspace(self, B):
+        if B not in self._ws:
+            self._ws[B] = _Workspace(B, self.hidden, self.device, self.num_cbfs)
+        return self._ws[B]
+
+    # -- NODE fit (model.py:221-260 via sac_cbf_clf.py:205-219) -----------------
+    def fit_node(self, obs, action, next_obs):
+        """One Adam step of the NODE regression on device tensors (N,7),(N,2),(N,7)."""
+        N = obs.shape[0]
+        s = stream_ptr()
+        key = N
+        if key not in self._fit_ws:
+            z = lambda *sh: torch.zeros(*sh, dtype=torch.float32, device=self.device)
+            self._fit_ws[key] = dict(st=z(N, 3), nst=z(N, 3), dpred=z(N, 3), part=z((N + 255) // 256))
+        w = self._fit_ws[key]
+        obs, action, next_obs = obs.contiguous(), action.contiguous(), next_obs.contiguous()
+        _lib.call("nlbac_unicycle_state", obs.data_ptr(), obs.shape[1], N, self.l_p, w["st"].data_ptr(), None, s)
+        _lib.call("nlbac_unicycle_state", next_obs.data_ptr(), next_obs.shape[1], N, self.l_p, w["nst"].data_ptr(), None, s)
+        pred = self.fit_solver.forward(w["st"], action, 1, N, self.solver, self.env.dt, self.atol, self.rtol)
+        nblk = (N + 255) // 256
+        _lib.call("nlbac_mse_fwd_bwd", pred.data_ptr(), 3, w["nst"].data_ptr(), 3, N, 3, w["dpred"].data_ptr(), 3,
+                  w["part"].data_ptr(), s)
+        _lib.call("nlbac_sum_partials", w["part"].data_ptr(), nblk, 1, 1.0 / (N * 3),
+                  self.sc.data_ptr() + 4 * SC.SC_NODE_LOSS, s)
+        self.fit_solver.backward(w["dpred"], need_du=False, need_params=True)
+        used = self.fit_solver.accumulate_param_grads(self.ar_n, self.n_grad_slabs)
+        a = self.ar_n
+        _lib.call("nlbac_adam_prepare", a.state.data_ptr(), 1e-3, s)
+        _lib.call("nlbac_adam_step", a.theta.data_ptr(), a.m.data_ptr(), a.v.data_ptr(), a.grad.data_ptr(), used,
+                  a.n, a.n, a.state.data_ptr(), None, -1.0, s)
+        pack([self.h_f, self.h_g])
+
+    # -- the update proper --------------------------------------------------------
+    def update_on_device(self, ws, updates, sync=True):
+        """Minibatch already in ``ws.mb``; returns the reference's 6 floats."""
+        B, H = ws.B, self.hidden
+        s = stream_ptr()
+        mb = ws.mb
+        p_obs, p_act = mb.data_ptr(), mb.data_ptr() + 4 * 7
+        p_rew, p_con = mb.data_ptr() + 4 * 9, mb.data_ptr() + 4 * 10
+        p_cen, p_ncen = mb.data_ptr() + 4 * 11, mb.data_ptr() + 4 * 13
+        p_nobs, p_mask = mb.data_ptr() + 4 * 15, mb.data_ptr() + 4 * 22
+        LD = 24
+        if self._noise is not None:
+            for i in range(3):
+                ws.eps[i].copy_(self._noise[i].to(self.device))
+            self._noise = None
+        else:
+            ws.eps.normal_()
+        sc = self.sc.data_ptr()
+        call = _lib.call
+        dt = float(self.env.dt)
+        # strided column views of the minibatch need their own (B) vectors for the per-sample kernels
+        rew, con, mask = mb[:, 9].contiguous(), mb[:, 10].contiguous(), mb[:, 22].contiguous()
+
+        # ---- A. targets (no grad): pi(s'), Q_target(s', a'), L_target(c') ; critic / Lyapunov forward
+        io = io_array(1)
+        io[0].x0, io[0].x0_dim, io[0].x0_ld = p_nobs, 7, LD
+        io[0].y, io[0].y_ld = ws.heads_n.data_ptr(), 4
+        call("nlbac_mlp_fwd", mlp_array([self.h_p.desc]), io, 1, B, s)
+        pol = self.policy
+        call("nlbac_gauss_sample_fwd", ws.heads_n.data_ptr(), 4, ws.eps[0].data_ptr(), pol.action_scale.data_ptr(),
+             pol.action_bias.data_ptr(), 2, B, ws.na.data_ptr(), 2, ws.nlogp.data_ptr(), s)
+        io = io_array(6)
+        nets = [self.h_q1.desc_target, self.h_q2.desc_target, self.h_l.desc_target,
+                self.h_q1.desc, self.h_q2.desc, self.h_l.desc]
+        for i in range(6):
+            io[i].y, io[i].y_ld = ws.q6[i].data_ptr(), 1
+        for i in (0, 1):
+            io[i].x0, io[i].x0_dim, io[i].x0_ld = p_nobs, 7, LD
+            io[i].x1, io[i].x1_dim, io[i].x1_ld = ws.na.data_ptr(), 2, 2
+        io[2].x0, io[2].x0_dim, io[2].x0_ld = p_ncen, 2, LD
+        for i in (3, 4):
+            io[i].x0, io[i].x0_dim, io[i].x0_ld = p_obs, 7, LD
+            io[i].x1, io[i].x1_dim, io[i].x1_ld = p_act, 2, LD
+            io[i].acts = ws.acts_c[i - 3].data_ptr()
+        io[5].x0, io[5].x0_dim, io[5].x0_ld = p_cen, 2, LD
+        io[5].acts = ws.acts_c[2].data_ptr()
+        call("nlbac_mlp_fwd", mlp_array(nets), io, 6, B, s)
+        q = ws.q6
+        call("nlbac_td_targets", q[0].data_ptr(), q[1].data_ptr(), q[2].data_ptr(), ws.nlogp.data_ptr(),
+             rew.data_ptr(), con.data_ptr(), mask.data_ptr(), q[3].data_ptr(), q[4].data_ptr(), q[5].data_ptr(),
+             sc + 4 * SC.SC_ALPHA, self.gamma, B, ws.dq3[0].data_ptr(), ws.dq3[1].data_ptr(), ws.dq3[2].data_ptr(),
+             ws.next_q.data_ptr(), ws.next_l.data_ptr(), ws.part_td.data_ptr(), s)
+        call("nlbac_sum_partials", ws.part_td.data_ptr(), ws.nblk, 3, 1.0 / B, sc + 4 * SC.SC_QF1, s)
+
+        # ---- B. critic / Lyapunov backward + Adam (+ Polyak targets) ---------------
+        io = io_array(3)
+        cnets = mlp_array([self.h_q1.desc, self.h_q2.desc, self.h_l.desc])
+        for i in range(3):
+            io[i].dy, io[i].dy_ld = ws.dq3[i].data_ptr(), 1
+            io[i].acts, io[i].dz = ws.acts_c[i].data_ptr(), ws.dz_c[i].data_ptr()
+            io[i].grad = self.ar_c.grad.data_ptr()
+        for i in (0, 1):
+            io[i].x0, io[i].x0_dim, io[i].x0_ld = p_obs, 7, LD
+            io[i].x1, io[i].x1_dim, io[i].x1_ld = p_act, 2, LD
+        io[2].x0, io[2].x0_dim, io[2].x0_ld = p_cen, 2, LD
+        call("nlbac_mlp_bwd_data", cnets, io, 3, B, s)
+        a = self.ar_c
+        call("nlbac_mlp_bwd_weights", cnets, io, 3, B, a.n_slabs, a.n, s)
+        soft = (updates % self.target_update_interval == 0)
+        call("nlbac_adam_prepare", a.state.data_ptr(), self.critic_lyapunov_lr, s)
+        call("nlbac_adam_step", a.theta.data_ptr(), a.m.data_ptr(), a.v.data_ptr(), a.grad.data_ptr(), a.n_slabs,
+             a.n, a.n, a.state.data_ptr(), a.target.data_ptr(), self.tau if soft else -1.0, s)
+        pack([self.h_q1, self.h_q2, self.h_l])
+        if soft:
+            pack([self.h_q1, self.h_q2, self.h_l], target=True)
+
+        # ---- C. actors: sample, Q(s, pi), constraints through the NODE rollout -----
+        io = io_array(2)
+        for i, h in enumerate((self.h_p, self.h_b)):
+            io[i].x0, io[i].x0_dim, io[i].x0_ld = p_obs, 7, LD
+            io[i].y, io[i].y_ld = ws.heads2[i * B:].data_ptr(), 4
+            io[i].acts = ws.acts_p[i].data_ptr()
+        pnets = mlp_array([self.h_p.desc, self.h_b.desc])
+        call("nlbac_mlp_fwd", pnets, io, 2, B, s)
+        eps2 = ws.eps[1:3]                                     # (2,B,2) == (2B,2)
+        call("nlbac_gauss_sample_fwd", ws.heads2.data_ptr(), 4, eps2.data_ptr(), pol.action_scale.data_ptr(),
+             pol.action_bias.data_ptr(), 2, 2 * B, ws.pi2.data_ptr(), 2, ws.logp2.data_ptr(), s)
+        call("nlbac_unicycle_state", p_obs, LD, B, self.l_p, ws.state.data_ptr(), ws.ps.data_ptr(), s)
+        ws.y0_2[:B].copy_(ws.state)
+        ws.y0_2[B:].copy_(ws.state)
+        io = io_array(5)
+        qnets = mlp_array([self.h_q1.desc, self.h_q2.desc, self.h_q1.desc, self.h_q2.desc, self.h_l.desc])
+        for i in range(4):
+            half = i // 2                                      # 0 primary, 1 backup
+            io[i].x0, io[i].x0_dim, io[i].x0_ld = p_obs, 7, LD
+            io[i].x1, io[i].x1_dim, io[i].x1_ld = ws.pi2[half * B:].data_ptr(), 2, 2
+            io[i].y, io[i].y_ld = ws.qpi[i % 2, half * B:].data_ptr(), 1
+            io[i].acts = ws.acts_q[i].data_ptr()
+        io[4].x0, io[4].x0_dim, io[4].x0_ld = p_cen, 2, LD
+        io[4].y, io[4].y_ld = ws.V.data_ptr(), 1
+        call("nlbac_mlp_fwd", qnets, io, 5, B, s)
+        call("nlbac_actor_q_terms", ws.qpi[0].data_ptr(), ws.qpi[1].data_ptr(), ws.logp2.data_ptr(),
+             sc + 4 * SC.SC_ALPHA, B, 2, ws.dq_pi[0].data_ptr(), ws.dq_pi[1].data_ptr(), ws.part_q.data_ptr(), s)
+
+        x_next2 = self.node_solver.forward(ws.y0_2, ws.pi2, 2, B, self.solver, dt, self.atol, self.rtol)
+        call("nlbac_unicycle_lookahead", x_next2.data_ptr(), 2 * B, self.l_p, ws.ps_next2.data_ptr(), s)
+        io = io_array(1)
+        io[0].x0, io[0].x0_dim, io[0].x0_ld = ws.ps_next2.data_ptr(), 2, 2
+        io[0].y, io[0].y_ld = ws.Vn.data_ptr(), 1
+        io[0].acts = ws.acts_vn.data_ptr()
+        io[0].dy, io[0].dy_ld = ws.dVn.data_ptr(), 1
+        io[0].dx, io[0].dx_ld = ws.dps_v2.data_ptr(), 2
+        lnet = mlp_array([self.h_l.desc])
+        call("nlbac_mlp_fwd", lnet, io, 1, B, s)
+        r_coll = 1.05 * float(self.env.hazards_radius)
+        call("nlbac_unicycle_constraints_fwd", ws.ps.data_ptr(), ws.ps_next2.data_ptr(), ws.V.data_ptr(),
+             ws.Vn.data_ptr(), self.hazards.data_ptr(), self.num_cbfs, r_coll, dt, float(self.gamma_b), 1.0, B,
+             ws.matr.data_ptr(), ws.bmatr.data_ptr(), ws.part_c.data_ptr(), s)
+        lam_upd = 1 if updates % self.Lagrangian_multiplier_update_interval == 0 else 0
+        call("nlbac_auglag", ws.part_c.data_ptr(), ws.nblk, self.num_cbfs, 1, float(self.batch_size), lam_upd, 1, 1,
+             0.01, 400.0, sc, s)
+        call("nlbac_unicycle_constraints_bwd", ws.ps_next2.data_ptr(), ws.matr.data_ptr(), ws.bmatr.data_ptr(),
+             self.hazards.data_ptr(), self.num_cbfs, dt, float(self.batch_size), B, sc, ws.dps_next2.data_ptr(),
+             ws.dVn.data_ptr(), s)
+        call("nlbac_mlp_bwd_data", lnet, io, 1, B, s)          # dV_next -> d ps_next (rows [0,B))
+        call("nlbac_unicycle_lookahead_bwd", x_next2.data_ptr(), ws.dps_next2.data_ptr(), ws.dps_v2.data_ptr(), 2 * B,
+             self.l_p, ws.dx_next2.data_ptr(), s)
+        du2, _ = self.node_solver.backward(ws.dx_next2, need_du=True)
+
+        io = io_array(4)
+        for i in range(4):
+            half = i // 2
+            io[i].dy, io[i].dy_ld = ws.dq_pi[i % 2, half * B:].data_ptr(), 1
+            io[i].acts = ws.acts_q[i].data_ptr()
+            io[i].dx, io[i].dx_ld = ws.dxq[i % 2, half * B:].data_ptr(), 9
+        call("nlbac_mlp_bwd_data", qnets, io, 4, B, s)
+        call("nlbac_gauss_sample_bwd", ws.heads2.data_ptr(), 4, eps2.data_ptr(), pol.action_scale.data_ptr(), 2,
+             2 * B, B, ws.dxq[0].data_ptr() + 4 * 7, 9, ws.dxq[1].data_ptr() + 4 * 7, 9, du2.data_ptr(), 2,
+             sc + 4 * SC.SC_ALPHA, 1.0 / B, ws.dheads2.data_ptr(), 4, s)
+        io = io_array(2)
+        a = self.ar_a
+        for i in range(2):
+            io[i].x0, io[i].x0_dim, io[i].x0_ld = p_obs, 7, LD
+            io[i].dy, io[i].dy_ld = ws.dheads2[i * B:].data_ptr(), 4
+            io[i].acts, io[i].dz = ws.acts_p[i].data_ptr(), ws.dz_p[i].data_ptr()
+            io[i].grad = a.grad.data_ptr()
+        call("nlbac_mlp_bwd_data", pnets, io, 2, B, s)
+        call("nlbac_mlp_bwd_weights", pnets, io, 2, B, a.n_slabs, a.n, s)
+        la = a.theta.data_ptr() + 4 * self.la_off
+        call("nlbac_actor_scalars", ws.part_q.data_ptr(), ws.nblk, B, 2, self.target_entropy, la, self.la_stride,
+             a.grad.data_ptr() + 4 * self.la_off, sc, s)
+        if not self.automatic_entropy_tuning:
+            a.grad[0, self.la_off] = 0.0
+            a.grad[0, self.la_off + self.la_stride] = 0.0
+        call("nlbac_adam_prepare", a.state.data_ptr(), self.lr, s)
+        call("nlbac_adam_step", a.theta.data_ptr(), a.m.data_ptr(), a.v.data_ptr(), a.grad.data_ptr(), a.n_slabs,
+             a.n, a.n, a.state.data_ptr(), None, -1.0, s)
+        pack([self.h_p, self.h_b])
+        if self.automatic_entropy_tuning:
+            call("nlbac_alpha_refresh", la, self.la_stride, 2, sc, s)
+        if not sync:
+            return None
+        h = self._scalars()
+        alpha_loss = float(h[SC.SC_ALOSS]) if self.automatic_entropy_tuning else 0.0
+        return (float(h[SC.SC_QF1]), float(h[SC.SC_QF2]), float(h[SC.SC_LF]), float(h[SC.SC_PL1]),
+                alpha_loss, float(h[SC.SC_ALPHA]))
+
+    # ------------------------------------------------------------ checkpoints
+    def save_model(self, output):
+        print('Saving models in {}'.format(output))
+        torch.save(self.policy.state_dict(), '{}/actor.pkl'.format(output))
+        torch.save(self.critic.state_dict(), '{}/critic.pkl'.format(output))
+        torch.save(self.lyapunovNet.state_dict(), '{}/lyapunov.pkl'.format(output))
+        torch.save(self.neural_ode_model.state_dict(), '{}/node_model.pkl'.format(output))
+
+    def load_weights(self, output):
+        if output is None:
+            return
+        print('Loading models from {}'.format(output))
+        dev = torch.device(self.device)
+        self.policy.load_state_dict(torch.load('{}/actor.pkl'.format(output), map_location=dev, weights_only=True))
+        self.critic.load_state_dict(torch.load('{}/critic.pkl'.format(output), map_location=dev, weights_only=True))
+        self.lyapunovNet.load_state_dict(torch.load('{}/lyapunov.pkl'.format(output), map_location=dev, weights_only=True))
+        self.repack_all()
+
+    def load_model(self, actor_path, critic_path, lyapunov_path):
+        if actor_path is not None:
+            self.policy.load_state_dict(torch.load(actor_path, weights_only=True))
+        if critic_path is not None:
+            self.critic.load_state_dict(torch.load(critic_path, weights_only=True))
+        if lyapunov_path is not None:
+            self.lyapunovNet.load_state_dict(torch.load(lyapunov_path, weights_only=True))
+        self.repack_all()
+
+
+class _TargetView:
+    """state_dict-style access to a target network stored in ``arena.target``."""
+
+    def __init__(self, module, arena):
+        self.module, self.arena = module, arena
+
+    def state_dict(self):
+        out = {}
+        for k, p in self.module.named_parameters():
+            off = self.arena.offset_of[id(p)]
+            out[k] = self.arena.target[off:off + p.numel()].view(p.shape)
+        return out
+
+    def load_state_dict(self, sd):
+        cur = self.state_dict()
+        with torch.no_grad():
+            for k, v in sd.items():
+                cur[k].copy_(v)

@@ -1,0 +1,130 @@
+"""GPU: the HIP update path vs (a) golden fixtures produced by the reference
+itself and (b) the CPU oracle, on identical seeded minibatches, weights and
+policy noise.  Tolerance 1e-4 relative to each tensor's scale (BASELINE.json
+north_star); step sizes / error ratios of dopri5 get the looser bounds noted.
+"""
+import numpy as np
+import pytest
+import torch
+
+from common import case_inputs, load_golden, vec_close
+from nlbac_amd import synth
+from nlbac_amd.envspec import make_env
+
+pytestmark = pytest.mark.gpu
+TOL = 1e-4
+
+
+def make_agent(B, hidden, seed, solver):
+    from oracle.nlbac_oracle import Args
+    from nlbac_amd.sac_cbf_clf.sac_cbf_clf import SAC_CBF_CLF
+    env = make_env("Unicycle", seed)
+    args = Args(batch_size=B, hidden_size=hidden, seed=seed, cuda=True)
+    agent = SAC_CBF_CLF(7, env.action_space, env, args)
+    agent.solver = solver
+    W = synth.unicycle_agent_weights(hidden, seed)
+    t = lambda sd: {k: torch.from_numpy(v) for k, v in sd.items()}
+    agent.critic.load_state_dict(t(W["critic"]))
+    agent.critic_target.load_state_dict(t(W["critic"]))
+    agent.lyapunovNet.load_state_dict(t(W["lyapunov"]))
+    agent.lyapunovNet_target.load_state_dict(t(W["lyapunov"]))
+    agent.policy.load_state_dict(t(W["policy"]))
+    agent.backup_policy.load_state_dict(t(W["backup_policy"]))
+    agent.neural_ode_model.load_state_dict(t(W["node"]))
+    agent.repack_all()
+    return agent, env
+
+
+def flat_params(module):
+    return torch.cat([p.detach().reshape(-1) for p in module.parameters()]).cpu()
+
+
+def flat_sd(sd, order):
+    return torch.cat([sd[k].detach().reshape(-1) for k in order]).cpu()
+
+
+def flat_grad(agent, arena, module, n_slabs=None):
+    return torch.cat([arena.grad_view(p).reshape(-1) for p in module.parameters()]).cpu()
+
+
+@pytest.mark.parametrize("solver", ["euler", "rk4", "dopri5"])
+@pytest.mark.parametrize("B", [8, 128])
+def test_update_matches_reference_fixture_and_oracle(solver, B):
+    from oracle import nlbac_oracle as O
+    torch.set_num_threads(4)
+    g = load_golden(solver, B)
+    seed, hidden = int(g["meta_seed"]), int(g["meta_hidden"])
+    agent, env = make_agent(B, hidden, seed, solver)
+    oracle = O.OracleUnicycleAgent(make_env("Unicycle", seed), O.Args(batch_size=B, hidden_size=hidden, seed=seed),
+                                   synth.unicycle_agent_weights(hidden, seed), solver=solver)
+    tr = synth.unicycle_transitions(4096, seed=seed + 1, env=env)
+    from nlbac_amd.sac_cbf_clf import _layout as SC
+    for ci in range(len(g["meta_calls"])):
+        batch, eps, node, updates = case_inputs(g, ci, tr)
+        with_fit = updates % 10 == 0
+        R = oracle.update(batch, eps, updates, node_batch=node if with_fit else None)
+        agent.set_noise(eps)
+        host_batch = tuple(batch[f].numpy() for f in
+                           ("obs", "action", "reward", "constraint", "center", "next_center", "next_obs", "mask"))
+        node_np = tuple(t.numpy() for t in node) if with_fit else None
+        ret = agent.update_from_host(host_batch, updates, node_np)
+        torch.cuda.synchronize()
+        p = "c%d_" % ci
+        sc = agent.sc.cpu().numpy()
+        ws = agent._ws[B]
+        # ---- against the reference-generated fixture
+        vec_close(ret, g[p + "ret"], TOL, p + "ret vs golden")
+        vec_close(sc[SC.SC_REQ:SC.SC_REQ + 8], g[p + "required"], TOL, p + "required vs golden")
+        vec_close(sc[SC.SC_BREQ:SC.SC_BREQ + 7], g[p + "brequired"], TOL, p + "brequired vs golden")
+        vec_close(agent.lambda_values, g[p + "lambdas"], TOL, p + "lambdas vs golden")
+        vec_close(agent.backup_lambda_values, g[p + "backup_lambdas"], TOL, p + "blambdas vs golden")
+        assert abs(agent.augmented_term - float(g[p + "augmented_term"])) < 1e-12
+        xn = agent.node_solver.ctx["out"].cpu().numpy()
+        vec_close(xn[:B], g[p + "x_next"], TOL, p + "x_next vs golden")
+        vec_close(xn[B:], g[p + "bx_next"], TOL, p + "bx_next vs golden")
+        if B <= 16:
+            vec_close(ws.matr.cpu().numpy(), g[p + "matr"], TOL, p + "matr vs golden")
+            vec_close(ws.bmatr.cpu().numpy(), g[p + "bmatr"], TOL, p + "bmatr vs golden")
+        if solver == "dopri5":
+            info = agent.node_solver.ctx["info"]
+            for prob, key in ((0, "ode_steps"), (1, "bode_steps")):
+                st = np.array([a[prob] for a in info], dtype=np.float64)
+                gs = g[p + key]
+                assert st.shape == gs.shape
+                np.testing.assert_allclose(st[:, 0], gs[:, 0], rtol=1e-4)
+                np.testing.assert_allclose(st[:, 1], gs[:, 1], rtol=5e-2)   # cancellation noise
+                np.testing.assert_array_equal(st[:, 2], gs[:, 2])
+        for name, ar, mod in (("critic", agent.ar_c, agent.critic), ("lya", agent.ar_c, agent.lyapunovNet),
+                              ("policy", agent.ar_a, agent.policy), ("backup", agent.ar_a, agent.backup_policy),
+                              ("node", agent.ar_n, agent.neural_ode_model)):
+            if p + "g_%s_norm" % name not in g.files:
+                continue
+            v = flat_grad(agent, ar, mod)
+            assert abs(float(v.double().norm()) / float(g[p + "g_%s_norm" % name]) - 1) < TOL, name
+            okey = {"critic": "g_critic", "lya": "g_lya", "policy": "g_policy", "backup": "g_backup",
+                    "node": "g_node"}[name]
+            if okey in R:
+                vec_close(v, R[okey], TOL, p + "grad %s vs oracle (full vector)" % name)
+        order = None
+        for name, mod in (("critic", agent.critic), ("lya", agent.lyapunovNet), ("policy", agent.policy),
+                          ("backup", agent.backup_policy), ("node", agent.neural_ode_model)):
+            v = flat_params(mod)
+            assert abs(float(v.double().norm()) / float(g[p + "p_%s_norm" % name]) - 1) < 1e-5
+            vec_close(v[:48], g[p + "p_%s_head" % name], TOL, p + "params " + name)
+            vec_close(v[-48:], g[p + "p_%s_tail" % name], TOL, p + "params tail " + name)
+        for name, tv in (("critic_target", agent.critic_target), ("lya_target", agent.lyapunovNet_target)):
+            sd = tv.state_dict()
+            v = torch.cat([sd[k].reshape(-1) for k in sd]).cpu()
+            assert abs(float(v.double().norm()) / float(g[p + "p_%s_norm" % name]) - 1) < 1e-5
+            vec_close(v[:48], g[p + "p_%s_head" % name], TOL, p + "params " + name)
+        assert abs(float(agent.log_alpha) - float(g[p + "log_alpha"])) < 1e-5
+        assert abs(float(agent.backup_log_alpha) - float(g[p + "backup_log_alpha"])) < 1e-5
+        # ---- against the oracle on the full tensors
+        vec_close(ret, R["ret"], TOL, p + "ret vs oracle")
+        vec_close(ws.pi2[:B].cpu().numpy(), R["pi"], TOL, p + "pi vs oracle")
+        vec_close(ws.logp2[:B].cpu().numpy(), R["log_pi"].reshape(-1), TOL, p + "log_pi vs oracle")
+        vec_close(ws.next_q.cpu().numpy(), R["next_q"].reshape(-1), TOL, p + "next_q vs oracle")
+        for name, mod, osd in (("critic", agent.critic, oracle.critic), ("policy", agent.policy, oracle.policy),
+                               ("node", agent.neural_ode_model, oracle.node)):
+            ov = torch.cat([osd[k].detach().reshape(-1) for k in osd])
+            vec_close(flat_params(mod), ov, TOL, p + "all params %s vs oracle" % name)
