@@ -1,0 +1,192 @@
+"""CPU: the C-ABI library builds, loads and exports every symbol the header
+declares; host-side mirrors (replay, dynamics glue, arena layout, model
+containers) behave like the reference's.  No kernel is launched here."""
+import collections
+import os
+import random
+import re
+
+import numpy as np
+import pytest
+import torch
+
+import nlbac_amd  # noqa: F401
+from nlbac_amd import _lib, synth
+from nlbac_amd.envspec import make_env
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+@pytest.fixture(scope="module")
+def lib():
+    _lib.build()
+    return _lib.load()
+
+
+def header_functions():
+    txt = open(os.path.join(ROOT, "include", "nlbac_hip.h")).read()
+    txt = re.sub(r"/\*.*?\*/", "", txt, flags=re.S)
+    return sorted(set(re.findall(r"\b(nlbac_[a-z0-9_]+)\s*\(", txt)))
+
+
+def test_library_exports_every_declared_symbol(lib):
+    names = header_functions()
+    assert len(names) >= 30
+    for n in names:
+        assert hasattr(lib, n), "libnlbac_hip.so does not export %s" % n
+    assert set(names) == set(_lib.EXPORTS), set(names) ^ set(_lib.EXPORTS)
+    assert lib.nlbac_abi_version() == 1
+
+
+def test_ctypes_structs_match_header_sizes(lib):
+    # nlbac_mlp: 4 ints, ptr, 12 ints, ptr, 12 ints ; nlbac_mlp_io per header
+    assert _lib.C.sizeof(_lib.Mlp) == 16 + 8 + 48 + 8 + 48
+    io = _lib.MlpIO()
+    assert _lib.C.sizeof(io) % 8 == 0
+    net = _lib.Mlp()
+    net.n_layers, net.in_dim, net.hid, net.out_dim = 3, 9, 256, 1
+    n = lib.nlbac_mlp_pack_layout(_lib.C.byref(net))
+    # layer0 fwd: 8 tiles x 2 chunks ; layer1 fwd: 8 x 32 ; layer1 bwd: 8 x 32  (x256 floats)
+    assert n == (8 * 2 + 8 * 32 + 8 * 32) * 256
+    assert net.pf_off[0] == 0 and net.pb_off[0] == -1 and net.pb_off[1] > net.pf_off[1] > 0
+
+
+def test_error_reporting_is_loud(lib):
+    net = _lib.Mlp()
+    net.n_layers, net.in_dim, net.hid, net.out_dim = 3, 99, 256, 1     # in_dim too large
+    rc = lib.nlbac_mlp_pack(_lib.C.byref(net), 1, None)
+    assert rc != 0 and b"in_dim" in lib.nlbac_last_error()
+
+
+def test_missing_library_fails_loudly(monkeypatch):
+    monkeypatch.setattr(_lib, "_lib", None)
+    monkeypatch.setattr(_lib, "LIB_PATH", "/nonexistent/libnlbac_hip.so")
+    with pytest.raises(_lib.NlbacError, match="no CPU fallback"):
+        _lib.load()
+
+
+def test_agent_refuses_to_run_without_gpu():
+    if torch.cuda.is_available():
+        pytest.skip("GPU present")
+    from oracle.nlbac_oracle import Args
+    from nlbac_amd.sac_cbf_clf.sac_cbf_clf import SAC_CBF_CLF
+    env = make_env("Unicycle", 0)
+    with pytest.raises(RuntimeError, match="MI355X"):
+        SAC_CBF_CLF(7, env.action_space, env, Args(cuda=True))
+    with pytest.raises(RuntimeError, match="MI355X"):
+        SAC_CBF_CLF(7, env.action_space, env, Args(cuda=False))
+
+
+def test_replay_memory_matches_list_semantics():
+    """Same seed -> same transitions as the reference's list + random.sample + np.stack."""
+    from nlbac_amd.sac_cbf_clf.replay_memory import ReplayMemory
+    tr = synth.unicycle_transitions(300, seed=3)
+    mem = ReplayMemory(1000, seed=5, initial_rows=64)          # forces two grow steps
+    ref = []
+    for i in range(300):
+        row = tuple(tr[f][i] for f in synth.FIELDS)
+        mem.push(*row[:8], t=row[8], next_t=row[9])
+        ref.append(row)
+    assert len(mem) == 300 and mem.position == 300
+    random.seed(11)
+    got = mem.sample(32)
+    random.seed(11)
+    want = tuple(map(np.stack, zip(*random.sample(ref, 32))))
+    assert len(got) == 10
+    for a, b in zip(got, want):
+        np.testing.assert_array_equal(a, b)
+    # ring overwrite
+    small = ReplayMemory(4, seed=0)
+    for i in range(6):
+        small.push(np.full(7, i), np.zeros(2), i, 0., np.zeros(2), np.zeros(2), np.zeros(7), 1.)
+    assert len(small) == 4 and small.position == 2
+    assert sorted(small.sample(4)[2].tolist()) == [2., 3., 4., 5.]
+
+
+def test_dynamics_model_get_state_conventions():
+    from nlbac_amd.sac_cbf_clf.dynamics import DynamicsModel
+    from oracle.nlbac_oracle import Args
+    env = make_env("Unicycle", 0)
+    dyn = DynamicsModel(env, Args(cuda=False))
+    tr = synth.unicycle_transitions(16, seed=2)
+    st = dyn.get_state(tr["obs"])
+    assert st.dtype == np.float64 and st.shape == (16, 3)
+    np.testing.assert_allclose(st[:, 2], np.arctan2(tr["obs"][:, 3], tr["obs"][:, 2]))
+    assert dyn.get_state(tr["obs"][0]).shape == (3,)
+    t = dyn.get_state(torch.tensor(tr["obs"], dtype=torch.float32))
+    assert torch.is_tensor(t) and t.dtype == torch.float32 and not t.requires_grad
+    # tensor path = float32 obs -> float64 atan2 on the host -> cast back (dynamics.py:45-69)
+    want = dyn.get_state(tr["obs"].astype(np.float32).astype(np.float64)).astype(np.float32)
+    np.testing.assert_array_equal(t.numpy(), want)
+
+
+def test_arena_layout_and_state_dict_keys():
+    """Parameters become views into one flat buffer; key names/shapes are the reference's."""
+    from nlbac_amd.arena import Arena
+    from nlbac_amd.sac_cbf_clf.model import GaussianPolicy, LyaNetwork, NeuralODEModel, QNetwork
+    env = make_env("Unicycle", 0)
+    torch.manual_seed(0)
+    q, l = QNetwork(7, 2, 256), LyaNetwork(2, 256)
+    p, node = GaussianPolicy(7, 2, 256, env.action_space), NeuralODEModel(3, 3, 6)
+    before = {k: v.clone() for k, v in q.state_dict().items()}
+    ar = Arena("cpu", n_slabs=2, with_target=True)
+    hs = q.attach(ar) + l.attach(ar) + p.attach(ar) + node.attach(ar)
+    ar.finalize()
+    for h in hs:
+        h.bind()
+    W = synth.unicycle_agent_weights(256, 0)
+    for mod, key in ((q, "critic"), (l, "lyapunov"), (p, "policy"), (node, "node")):
+        assert list(mod.state_dict().keys()) == list(W[key].keys())
+        for k, v in mod.state_dict().items():
+            assert tuple(v.shape) == W[key][k].shape
+    for k, v in q.state_dict().items():          # values survived the move into the arena
+        assert torch.equal(v, before[k])
+    base = ar.theta.data_ptr()
+    for mod in (q, l, p, node):
+        for prm in mod.parameters():
+            off = (prm.data_ptr() - base) // 4
+            assert 0 <= off and off + prm.numel() <= ar.n
+    for h in hs:                                   # float4 alignment of every weight matrix
+        for lidx in range(h.n_layers):
+            assert h.desc.w_off[lidx] % 4 == 0
+    # policy heads are one contiguous (2*n_u, hid) block / (2*n_u) bias block
+    assert p.log_std_linear.weight.data_ptr() - p.mean_linear.weight.data_ptr() == 2 * 256 * 4
+    assert p.log_std_linear.bias.data_ptr() - p.mean_linear.bias.data_ptr() == 2 * 4
+    # in-place load keeps the storage
+    q.load_state_dict({k: torch.from_numpy(v) for k, v in W["critic"].items()})
+    assert q.linear1.weight.data_ptr() - base == ar.offset_of[id(q.linear1.weight)] * 4
+    np.testing.assert_array_equal(q.linear5.weight.detach().numpy(), W["critic"]["linear5.weight"])
+
+
+def test_model_init_follows_reference_rules():
+    from nlbac_amd.sac_cbf_clf.model import LyaNetwork, NeuralODEModel
+    torch.manual_seed(1)
+    l = LyaNetwork(2, 256)
+    assert float(l.linear2.bias.abs().max()) == 0.0
+    bound = np.sqrt(6.0 / (256 + 256))
+    assert float(l.linear2.weight.abs().max()) <= bound and float(l.linear2.weight.abs().max()) > 0.9 * bound
+    n = NeuralODEModel(3, 3, 6)
+    lin = n.f_net[2]
+    assert float(lin.weight.abs().max()) <= 1 / np.sqrt(100) + 1e-7 and float(lin.bias.abs().max()) > 0
+    assert sum(p.numel() for p in n.parameters()) == 52209
+
+
+def test_oracle_dopri5_agrees_with_scipy_rk45():
+    """Independent sanity of the from-memory dopri5 restatement: same field, tight-tolerance RK45."""
+    from scipy.integrate import solve_ivp
+    from oracle import nlbac_oracle as O
+    W = {k: torch.from_numpy(v) for k, v in synth.unicycle_agent_weights(64, 0)["node"].items()}
+    node = O.AffineNode(W)
+    rs = np.random.RandomState(0)
+    y0 = torch.tensor(np.concatenate([rs.uniform(-2, 2, (6, 3)), rs.uniform(-3, 3, (6, 2))], 1), dtype=torch.float32)
+    info = {}
+    with torch.no_grad():
+        y = O.odeint(node, y0, torch.tensor([0., 0.02]), method="dopri5", atol=1e-7, rtol=1e-5, info=info)[-1]
+        yr = O.odeint(node, y0, torch.tensor([0., 0.02]), method="rk4")[-1]
+    for i in range(6):
+        f = lambda t, s: node(t, torch.tensor(s[None], dtype=torch.float32)).double().numpy()[0]
+        with torch.no_grad():
+            sol = solve_ivp(f, (0, 0.02), y0[i].double().numpy(), method="RK45", rtol=1e-10, atol=1e-12)
+        np.testing.assert_allclose(y[i].numpy(), sol.y[:, -1], rtol=2e-5, atol=2e-6)
+        np.testing.assert_allclose(yr[i].numpy(), sol.y[:, -1], rtol=2e-5, atol=2e-6)
+    assert all(s[2] for s in info["steps"][-1:])
