@@ -1,0 +1,277 @@
+"""Headline benchmark: ODE-integrate+update samples/s (BASELINE.json metric).
+
+  python bench.py --gpus N --steps K --warmup W
+  (N>1: launched by torch.distributed.run, one rank per GPU, RCCL)
+
+A "step" is one ``update_parameters``-equivalent pass of the hot path over one
+synthetic minibatch already resident in HBM: NODE rollouts (primary + backup
+controller), actor / twin-Q / Lyapunov forward+backward, CBF/CLF augmented-
+Lagrangian loss, Adam steps, Polyak update, and — every 10th step — the NODE
+regression step on 32768 transitions.  Workload at N=1:
+BASELINE.json configs[1] (Unicycle, batch 4096, dopri5).  Weak scaling: every
+rank runs its own 4096-row shard of a 4096*N global batch.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+import numpy as np
+import torch
+
+import nlbac_amd  # noqa: F401
+from nlbac_amd import _lib, synth
+from nlbac_amd.envspec import make_env
+
+PEAK_F32_MFMA_TFLOPS = 157.3     # MI355X_MICROARCH.md, chip-level parameters
+NODE_FIT_ROWS, NODE_FIT_INTERVAL, REPLAY_ROWS = 32768, 10, 65536
+
+
+class Args:
+    gamma, gamma_b, tau, alpha, lr = 0.99, 50.0, 0.005, 0.2, 3e-4
+    hidden_size, target_update_interval, Lagrangian_multiplier_update_interval = 256, 1, 8
+    automatic_entropy_tuning, policy, seed, cuda = True, "Gaussian", 0, True
+
+    def __init__(self, batch_size):
+        self.batch_size = batch_size
+
+
+def replay_rows(tr):
+    n = tr["obs"].shape[0]
+    rows = np.zeros((n, 24), dtype=np.float32)
+    rows[:, 0:7], rows[:, 7:9] = tr["obs"], tr["action"]
+    rows[:, 9], rows[:, 10] = tr["reward"], tr["constraint"]
+    rows[:, 11:13], rows[:, 13:15] = tr["center"], tr["next_center"]
+    rows[:, 15:22], rows[:, 22] = tr["next_obs"], tr["mask"]
+    return rows
+
+
+# ---- algorithmic FLOPs of one MLP launch (real dims, 1 MAC = 2 FLOP) ------------------------------
+def _layer_macs(net):
+    dims = [net.in_dim] + [net.hid] * (net.n_layers - 1) + [net.out_dim]
+    return [dims[i] * dims[i + 1] for i in range(net.n_layers)]
+
+
+def launch_flops(name, args):
+    nets, io, n_nets, B = args[0], args[1], args[2], args[3]
+    total = 0
+    for i in range(n_nets):
+        macs = _layer_macs(nets[i])
+        if name == "nlbac_mlp_bwd_data":
+            m = macs[-1] + sum(macs[1:-1]) + (macs[0] if io[i].dx else 0)
+        else:
+            m = sum(macs)
+        total += 2 * B * m
+    return total
+
+
+class KernelTimer:
+    """HIP events (torch.cuda.Event on the launch stream) around every launch of the MLP kernels."""
+    NAMES = ("nlbac_mlp_fwd", "nlbac_mlp_bwd_data", "nlbac_mlp_bwd_weights")
+
+    def __init__(self):
+        self.records = {n: [] for n in self.NAMES}
+        self._orig = _lib.call
+
+    def __enter__(self):
+        def call(name, *args):
+            if name in self.records:
+                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                e0.record()
+                self._orig(name, *args)
+                e1.record()
+                self.records[name].append((e0, e1, launch_flops(name, args)))
+            else:
+                self._orig(name, *args)
+        _lib.call = call
+        return self
+
+    def __exit__(self, *a):
+        _lib.call = self._orig
+
+    def summary(self):
+        torch.cuda.synchronize()
+        out = {}
+        for n, recs in self.records.items():
+            if recs:
+                ms = sum(e0.elapsed_time(e1) for e0, e1, _ in recs)
+                fl = sum(f for _, _, f in recs)
+                out[n] = dict(launches=len(recs), ms=ms, flops=fl, avg_us=1e3 * ms / len(recs),
+                              tflops=fl / (ms * 1e-3) / 1e12)
+        return out
+
+
+def log(msg):
+    print("[bench %.1fs] %s" % (time.perf_counter() - _T0, msg), file=sys.stderr, flush=True)
+
+
+_T0 = time.perf_counter()
+
+
+def host_cores():
+    """CPU threads this process may really use: cgroup quota, affinity, capped at the GPU box's 16-core share."""
+    n = len(os.sched_getaffinity(0))
+    try:
+        q, per = open("/sys/fs/cgroup/cpu.max").read().split()
+        if q != "max":
+            n = min(n, max(1, int(int(q) / int(per))))
+    except Exception:
+        pass
+    return max(1, min(n, 16))
+
+
+def cpu_baseline(B, solver, seed=0):
+    """The oracle (CPU restatement pinned to the reference) timed on this box's host cores on a
+    bounded sample of the same workload: 2 updates at batch B + 1 NODE fit on 32768 rows."""
+    from oracle import nlbac_oracle as O
+    cores = host_cores()
+    torch.set_num_threads(cores)
+    log("cpu_baseline: oracle on %d host threads" % cores)
+    env = make_env("Unicycle", seed)
+    W = synth.unicycle_agent_weights(256, seed)
+    agent = O.OracleUnicycleAgent(env, O.Args(batch_size=B, hidden_size=256, seed=seed), W, solver=solver)
+    tr = synth.unicycle_transitions(REPLAY_ROWS, seed=1, env=env)
+    fields = ("obs", "action", "reward", "constraint", "center", "next_center", "next_obs", "mask")
+    rs = np.random.RandomState(0)
+
+    def mk(n):
+        idx = rs.choice(REPLAY_ROWS, n, replace=False)
+        return {f: torch.tensor(tr[f][idx], dtype=torch.float32) for f in fields}
+    eps = [torch.from_numpy(e) for e in synth.normal_eps(3, B, 2, seed=1)]
+    agent.update(mk(B), eps, 1)                      # warm-up (allocator, thread pool)
+    log("cpu_baseline: warm-up update done")
+    n_upd = 2
+    t0 = time.perf_counter()
+    for i in range(n_upd):
+        agent.update(mk(B), eps, 1 + i)
+    t_upd = (time.perf_counter() - t0) / n_upd
+    log("cpu_baseline: %.2f s per update" % t_upd)
+    nb = mk(NODE_FIT_ROWS)
+    t0 = time.perf_counter()
+    agent.train_step(nb["obs"], nb["action"], nb["next_obs"])
+    t_fit = time.perf_counter() - t0
+    per_update = t_upd + t_fit / NODE_FIT_INTERVAL
+    return dict(value=B / per_update, unit="samples/s", cores=cores, kind="port",
+                sample="oracle (PyTorch-CPU restatement): %d updates at B=%d (%.2f s each) + 1 NODE fit on %d rows "
+                       "(%.2f s, amortised /%d), solver %s" % (n_upd, B, t_upd, NODE_FIT_ROWS, t_fit,
+                                                                NODE_FIT_INTERVAL, solver))
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=200)
+    ap.add_argument("--warmup", type=int, default=20)
+    ap.add_argument("--batch", type=int, default=4096)
+    ap.add_argument("--solver", default="dopri5", choices=["euler", "rk4", "dopri5"])
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--profile-steps", type=int, default=20)
+    a = ap.parse_args()
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    assert world == a.gpus, "launch with torch.distributed.run --nproc-per-node %d" % a.gpus
+    torch.cuda.set_device(local_rank)
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+
+    from nlbac_amd.sac_cbf_clf.sac_cbf_clf import SAC_CBF_CLF
+    B = a.batch
+    env = make_env("Unicycle", 0)
+    agent = SAC_CBF_CLF(7, env.action_space, env, Args(B * world))   # global batch in the loss normalisation
+    agent.solver = a.solver
+    if world > 1:
+        agent.enable_data_parallel(dist)
+    dev = agent.device
+    replay = torch.from_numpy(replay_rows(synth.unicycle_transitions(REPLAY_ROWS, seed=1 + rank, env=env))).to(dev)
+    ws = agent._workspace(B)
+    fit_rows = torch.empty(NODE_FIT_ROWS, 24, device=dev)
+    gen = torch.Generator(device=dev)
+    gen.manual_seed(1234 + rank)
+
+    def step(i):
+        idx = torch.randint(0, REPLAY_ROWS, (B,), device=dev, generator=gen)
+        torch.index_select(replay, 0, idx, out=ws.mb)
+        if i % NODE_FIT_INTERVAL == 0:
+            nidx = torch.randint(0, REPLAY_ROWS, (NODE_FIT_ROWS,), device=dev, generator=gen)
+            torch.index_select(replay, 0, nidx, out=fit_rows)
+            agent.fit_node_rows(fit_rows)
+        return agent.update_on_device(ws, i)
+
+    def fence():
+        torch.cuda.synchronize()
+        if dist is not None:
+            dist.barrier()
+            torch.cuda.synchronize()
+
+    log("setup done; warm-up")
+    for i in range(a.warmup):
+        step(i)
+    fence()
+    log("timed region: %d steps" % a.steps)
+    t0 = time.perf_counter()
+    for i in range(a.steps):
+        ret = step(a.warmup + i)
+    fence()
+    elapsed = time.perf_counter() - t0
+    if dist is not None:
+        t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t)
+    value = B * world * a.steps / elapsed
+    log("timed region done: %.3f ms/step, %.0f samples/s" % (1e3 * elapsed / a.steps, value))
+
+    # ---- roofline of the dominant kernel: separate pass, HIP events around each MLP launch ----------
+    roofline = None
+    if rank == 0:
+        with KernelTimer() as kt:
+            for i in range(a.profile_steps):
+                step(a.warmup + a.steps + i)
+            ks = kt.summary()
+        dom = max(ks, key=lambda k: ks[k]["ms"])
+        kname = {"nlbac_mlp_fwd": "mlp_fwd_kernel", "nlbac_mlp_bwd_data": "mlp_bwd_data_kernel",
+                 "nlbac_mlp_bwd_weights": "mlp_bwd_wide_kernel+mlp_bwd_skinny_kernel"}[dom]
+        roofline = dict(bound="mfma", kernel=kname, achieved=ks[dom]["tflops"], peak=PEAK_F32_MFMA_TFLOPS,
+                        unit="TFLOP/s", frac=ks[dom]["tflops"] / PEAK_F32_MFMA_TFLOPS, traffic=None,
+                        avg_launch_us=ks[dom]["avg_us"], launches=ks[dom]["launches"],
+                        flops_per_launch=ks[dom]["flops"] / ks[dom]["launches"],
+                        all={k: dict(avg_us=round(v["avg_us"], 2), tflops=round(v["tflops"], 2),
+                                     launches=v["launches"]) for k, v in ks.items()})
+    elif a.profile_steps:
+        for i in range(a.profile_steps):
+            step(a.warmup + a.steps + i)
+    fence()
+
+    cpu = None
+    if rank == 0 and world == 1 and not a.no_cpu_baseline:
+        cpu = cpu_baseline(B, a.solver)
+
+    if rank == 0:
+        out = {
+            "metric": "ODE-integrate+update samples/sec, Unicycle batch 4096",
+            "value": value, "unit": "samples/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
+            "ms_per_step": 1e3 * elapsed / a.steps, "higher_is_better": True, "scaling": "weak",
+            "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": {"workload": "Unicycle B=%d %s (BASELINE.json configs[1]); NODE fit on %d rows every %d "
+                                   "updates; replay of %d synthetic transitions resident in HBM"
+                                   % (B, a.solver, NODE_FIT_ROWS, NODE_FIT_INTERVAL, REPLAY_ROWS),
+                       "solver": a.solver, "batch_per_gpu": B, "global_batch": B * world,
+                       "parallelism": "dp%d" % world, "last_losses": [float(x) for x in ret]},
+            "roofline": roofline, "cpu_baseline": cpu,
+        }
+        if cpu:
+            out["speedup_vs_cpu_baseline"] = value / cpu["value"]
+        print(json.dumps(out))
+    if dist is not None:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

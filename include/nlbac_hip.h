@@ -87,11 +87,15 @@ int nlbac_mlp_pack(const nlbac_mlp *nets, int n_nets, nlbac_stream_t s);
 int nlbac_mlp_fwd(const nlbac_mlp *nets, const nlbac_mlp_io *io, int n_nets, int B, nlbac_stream_t s);
 /* dz (all wide layers) and optionally dx from dy and the saved activations. */
 int nlbac_mlp_bwd_data(const nlbac_mlp *nets, const nlbac_mlp_io *io, int n_nets, int B, nlbac_stream_t s);
-/* grad slabs [n_slabs][slab_stride] += nothing: each slab s receives the sum over
- * its row range [s*rows_per_slab, ...) — slabs are fully overwritten for the
- * nets given (deterministic; reduce with nlbac_adam_step / nlbac_reduce_slabs). */
+/* Weight/bias gradients from x, dy, acts, dz.  The hidden->hidden matrices are
+ * reduced per row range into n_slabs gradient slabs (slab s = rows
+ * [s*rows_per_slab, ...), fully overwritten, deterministic); the skinny first/last
+ * layers and all biases are reduced over all rows into slab 0 through the caller's
+ * workspace `ws` (>= nlbac_mlp_bwd_weights_ws_floats() floats).  Slabs are summed
+ * in order by nlbac_adam_step / nlbac_reduce_slabs. */
+long nlbac_mlp_bwd_weights_ws_floats(const nlbac_mlp *nets, int n_nets, int B);
 int nlbac_mlp_bwd_weights(const nlbac_mlp *nets, const nlbac_mlp_io *io, int n_nets, int B,
-                          int n_slabs, long slab_stride, nlbac_stream_t s);
+                          int n_slabs, long slab_stride, float *ws, long ws_floats, nlbac_stream_t s);
 
 /* ------------------------------------------------------------------------
  * Optimiser (torch.optim.Adam defaults: betas .9/.999, eps 1e-8, no decay).

@@ -54,7 +54,8 @@ _PROTOS = {
     "nlbac_mlp_pack": [C.POINTER(Mlp), _I, _P],
     "nlbac_mlp_fwd": [C.POINTER(Mlp), C.POINTER(MlpIO), _I, _I, _P],
     "nlbac_mlp_bwd_data": [C.POINTER(Mlp), C.POINTER(MlpIO), _I, _I, _P],
-    "nlbac_mlp_bwd_weights": [C.POINTER(Mlp), C.POINTER(MlpIO), _I, _I, _I, _L, _P],
+    "nlbac_mlp_bwd_weights_ws_floats": [C.POINTER(Mlp), _I, _I],
+    "nlbac_mlp_bwd_weights": [C.POINTER(Mlp), C.POINTER(MlpIO), _I, _I, _I, _L, _P, _L, _P],
     "nlbac_adam_prepare": [_P, _D, _P],
     "nlbac_adam_step": [_P, _P, _P, _P, _I, _L, _L, _P, _P, _F, _P],
     "nlbac_reduce_slabs": [_P, _P, _I, _L, _L, _P],
@@ -84,7 +85,7 @@ _PROTOS = {
     "nlbac_fill": [_P, _F, _L, _P],
     "nlbac_sum_partials": [_P, _I, _I, _F, _P, _P],
 }
-_RESTYPE = {"nlbac_last_error": C.c_char_p}
+_RESTYPE = {"nlbac_last_error": C.c_char_p, "nlbac_mlp_bwd_weights_ws_floats": C.c_long}
 
 EXPORTS = tuple(_PROTOS)
 

@@ -155,3 +155,19 @@ def pack(handles, target=False):
     for i in range(0, len(descs), _lib.MAX_NETS):
         chunk = descs[i:i + _lib.MAX_NETS]
         _lib.call("nlbac_mlp_pack", mlp_array(chunk), len(chunk), stream_ptr())
+
+
+_BW_WS = {}
+
+
+def bwd_weights(nets, io, n_nets, B, n_slabs, slab_stride, device):
+    """nlbac_mlp_bwd_weights with a cached per-device workspace for the skinny-gradient partials."""
+    lib = _lib.load()
+    need = lib.nlbac_mlp_bwd_weights_ws_floats(nets, n_nets, B)
+    key = str(device)
+    ws = _BW_WS.get(key)
+    if ws is None or ws.numel() < need:
+        ws = torch.empty(max(need, 1 << 20), dtype=torch.float32, device=device)
+        _BW_WS[key] = ws
+    _lib.call("nlbac_mlp_bwd_weights", nets, io, n_nets, B, n_slabs, slab_stride, ws.data_ptr(), ws.numel(),
+              stream_ptr())

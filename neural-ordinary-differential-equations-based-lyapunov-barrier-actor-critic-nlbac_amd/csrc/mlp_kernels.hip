@@ -413,111 +413,138 @@ __global__ __launch_bounds__(256) void mlp_bwd_wide_kernel(const MlpLaunch L) {
 }
 
 // ---------------------------------------------------------------------------
-// backward, skinny weights and all biases (column reductions over the slab rows):
+// backward, skinny weights and all biases (column reductions over the rows):
 //   db_j[n]      = sum_b dz[j][b][n]
 //   dW_0[n][i]   = sum_b dz[0][b][n] x[b][i]
 //   dW_L[o][k]   = sum_b dy[b][o] acts[nwide-1][b][k],  db_L[o] = sum_b dy[b][o]
-// grid = (slab, net); 1024 threads = 4 row groups x 256 hidden columns.
+// Stage 1: grid = (row chunk, net), thread = hidden column; a barrier-free
+// streaming loop over the chunk's rows (coalesced 1 KiB row reads of dz/acts,
+// wave-uniform x/dy operands) writes one partial row-set per chunk:
+//   ws[net][chunk][q][256],  q = [db_0..db_{nwide-1} | dW_0[:,i] | dW_L[o,:] | db_L]
+// Stage 2: one thread per output element sums the chunks in order
+// (deterministic) and scatters into grad slab 0.
 // ---------------------------------------------------------------------------
 #define SK_MAX_IN 12
 #define SK_MAX_OUT 16
-__global__ __launch_bounds__(1024) void mlp_bwd_skinny_kernel(const MlpLaunch L) {
-    __shared__ float red[8][4][256];
-    __shared__ float sx[4][SK_MAX_IN + SK_MAX_OUT];
+#define SK_MAX_Q (NLBAC_MAX_LAYERS + SK_MAX_IN + SK_MAX_OUT + 1)
+
+struct SkinnyLaunch {
+    int rows_per_chunk, n_chunks;
+    long net_stride;      // floats between nets in ws
+};
+
+__device__ __forceinline__ int skinny_nq(const nlbac_mlp& net) {
+    return (net.n_layers - 1) + net.in_dim + net.out_dim + 1;
+}
+
+#define SK_ROWS_LDS 128
+__global__ __launch_bounds__(256) void mlp_bwd_skinny_partial_kernel(const MlpLaunch L, const SkinnyLaunch S,
+                                                                     float* __restrict__ ws) {
+    // x / dy rows of the current 128-row block, zero-padded to fixed widths so the
+    // inner loop has no data-dependent branches (every load is unconditional and
+    // can be issued ahead; a guarded load would serialise on s_waitcnt per element)
+    __shared__ __attribute__((aligned(16))) float sx[SK_ROWS_LDS][SK_MAX_IN];
+    __shared__ __attribute__((aligned(16))) float sdy[SK_ROWS_LDS][SK_MAX_OUT];
     const nlbac_mlp& net = L.net[blockIdx.y];
     const nlbac_mlp_io& io = L.io[blockIdx.y];
     const int B = L.B, hid = net.hid, nwide = net.n_layers - 1;
     const int idim = net.in_dim, odim = net.out_dim;
-    const int slab = blockIdx.x;
-    const int rb = slab * L.rows_per_slab, re = min(B, rb + L.rows_per_slab);
-    const int col = threadIdx.x & 255, rg = threadIdx.x >> 8;
+    const int chunk = blockIdx.x;
+    const int rb = chunk * S.rows_per_chunk, re = min(B, rb + S.rows_per_chunk);
+    const int col = threadIdx.x;
     const bool live = col < hid;
-    float dW0[SK_MAX_IN], dWL[SK_MAX_OUT], db[NLBAC_MAX_LAYERS];
+    const int c = live ? col : 0;
+    const long ls = io.acts_ls ? io.acts_ls : (long)B * hid;
+    float dW0[SK_MAX_IN], dWL[SK_MAX_OUT], db[NLBAC_MAX_LAYERS - 1];
 #pragma unroll
     for (int i = 0; i < SK_MAX_IN; ++i) dW0[i] = 0.f;
 #pragma unroll
     for (int o = 0; o < SK_MAX_OUT; ++o) dWL[o] = 0.f;
 #pragma unroll
-    for (int j = 0; j < NLBAC_MAX_LAYERS; ++j) db[j] = 0.f;
+    for (int j = 0; j < NLBAC_MAX_LAYERS - 1; ++j) db[j] = 0.f;
     float dbL = 0.f;
-    const long ls = io.acts_ls ? io.acts_ls : (long)B * hid;
-    const float* aL = io.acts + (long)(nwide - 1) * ls;
+    const float* aL = io.acts + (long)(nwide - 1) * ls + c;
+    const float* dzp[NLBAC_MAX_LAYERS - 1];
+#pragma unroll
+    for (int j = 0; j < NLBAC_MAX_LAYERS - 1; ++j) dzp[j] = io.dz + (long)min(j, nwide - 1) * ls + c;
+    const int x0d = io.x0_dim;
 
-    for (int r = rb + rg; r < re + rg; r += 4) {   // uniform trip count for the barriers
-        const bool ok = r < re;
-        // stage this row group's x row and dy row (broadcast operands)
-        if (col < idim + odim) {
+    for (int r0 = rb; r0 < re; r0 += SK_ROWS_LDS) {
+        const int nr = min(SK_ROWS_LDS, re - r0);
+        __syncthreads();
+        for (int idx = col; idx < SK_ROWS_LDS * SK_MAX_IN; idx += 256) {
+            const int r = idx / SK_MAX_IN, i = idx - r * SK_MAX_IN;
             float v = 0.f;
-            if (ok) {
-                if (col < idim)
-                    v = (col < io.x0_dim) ? io.x0[(long)r * io.x0_ld + col]
-                                          : io.x1[(long)r * io.x1_ld + (col - io.x0_dim)];
-                else
-                    v = io.dy[(long)r * io.dy_ld + (col - idim)];
+            if (r < nr && i < idim)
+                v = (i < x0d) ? io.x0[(long)(r0 + r) * io.x0_ld + i] : io.x1[(long)(r0 + r) * io.x1_ld + (i - x0d)];
+            sx[r][i] = v;
+        }
+        for (int idx = col; idx < SK_ROWS_LDS * SK_MAX_OUT; idx += 256) {
+            const int r = idx / SK_MAX_OUT, o = idx - r * SK_MAX_OUT;
+            sdy[r][o] = (r < nr && o < odim) ? io.dy[(long)(r0 + r) * io.dy_ld + o] : 0.f;
+        }
+        __syncthreads();
+#pragma unroll 4
+        for (int r = 0; r < nr; ++r) {
+            const long ro = (long)(r0 + r) * hid;
+            const float a = aL[ro];
+            float z[NLBAC_MAX_LAYERS - 1];
+#pragma unroll
+            for (int j = 0; j < NLBAC_MAX_LAYERS - 1; ++j) z[j] = dzp[j][ro];
+#pragma unroll
+            for (int j = 0; j < NLBAC_MAX_LAYERS - 1; ++j) db[j] += z[j];
+#pragma unroll
+            for (int i = 0; i < SK_MAX_IN; i += 4) {
+                const float4 xv = *reinterpret_cast<const float4*>(&sx[r][i]);
+                dW0[i] += z[0] * xv.x; dW0[i + 1] += z[0] * xv.y; dW0[i + 2] += z[0] * xv.z; dW0[i + 3] += z[0] * xv.w;
             }
-            sx[rg][col < idim ? col : SK_MAX_IN + (col - idim)] = v;
+#pragma unroll
+            for (int o = 0; o < SK_MAX_OUT; o += 4) {
+                const float4 dv = *reinterpret_cast<const float4*>(&sdy[r][o]);
+                dWL[o] += dv.x * a; dWL[o + 1] += dv.y * a; dWL[o + 2] += dv.z * a; dWL[o + 3] += dv.w * a;
+            }
+            if (col < SK_MAX_OUT) dbL += sdy[r][col];
         }
-        __syncthreads();
-        if (ok && live) {
-            const float z0 = io.dz[(long)r * hid + col];
-            db[0] += z0;
-#pragma unroll
-            for (int i = 0; i < SK_MAX_IN; ++i)
-                if (i < idim) dW0[i] += z0 * sx[rg][i];
-#pragma unroll
-            for (int j = 1; j < NLBAC_MAX_LAYERS - 1; ++j)
-                if (j < nwide) db[j] += io.dz[(long)j * ls + (long)r * hid + col];
-            const float a = aL[(long)r * hid + col];
-#pragma unroll
-            for (int o = 0; o < SK_MAX_OUT; ++o)
-                if (o < odim) dWL[o] += sx[rg][SK_MAX_IN + o] * a;
-        }
-        if (ok && col < odim) dbL += sx[rg][SK_MAX_IN + col];
-        __syncthreads();
     }
 
-    float* g = io.grad + (long)slab * L.slab_stride;
-    // cross-row-group reduction in batches of 8 quantities (fixed order => deterministic)
-    auto flush = [&](float (&q)[8], int nq, auto&& store) {
+    float* w = ws + (long)blockIdx.y * S.net_stride + (long)chunk * skinny_nq(net) * 256 + col;
+    int q = 0;
 #pragma unroll
-        for (int i = 0; i < 8; ++i) red[i][rg][col] = q[i];
-        __syncthreads();
-        if (rg == 0) {
+    for (int j = 0; j < NLBAC_MAX_LAYERS - 1; ++j)
+        if (j < nwide) { w[(long)q * 256] = live ? db[j] : 0.f; ++q; }
 #pragma unroll
-            for (int i = 0; i < 8; ++i)
-                if (i < nq) store(i, (red[i][0][col] + red[i][1][col]) + (red[i][2][col] + red[i][3][col]));
-        }
-        __syncthreads();
-    };
-    float q[8];
-    // biases of the wide layers (+ last-layer bias in slot 7 via column index)
+    for (int i = 0; i < SK_MAX_IN; ++i)
+        if (i < idim) { w[(long)q * 256] = live ? dW0[i] : 0.f; ++q; }
 #pragma unroll
-    for (int i = 0; i < 8; ++i) q[i] = (i < NLBAC_MAX_LAYERS) ? db[i] : 0.f;
-    q[7] = dbL;
-    flush(q, 8, [&](int i, float v) {
-        if (i < nwide) { if (live) g[net.b_off[i] + col] = v; }
-        else if (i == 7 && col < odim) g[net.b_off[nwide] + col] = v;
-    });
-    for (int i0 = 0; i0 < idim; i0 += 8) {
-#pragma unroll
-        for (int i = 0; i < 8; ++i) q[i] = 0.f;
-#pragma unroll
-        for (int i = 0; i < SK_MAX_IN; ++i)
-            if (i >= i0 && i < i0 + 8) q[i - i0] = dW0[i];
-        flush(q, min(8, idim - i0), [&](int i, float v) {
-            if (live) g[net.w_off[0] + (long)col * idim + i0 + i] = v;
-        });
+    for (int o = 0; o < SK_MAX_OUT; ++o)
+        if (o < odim) { w[(long)q * 256] = live ? dWL[o] : 0.f; ++q; }
+    w[(long)q * 256] = dbL;
+}
+
+__global__ __launch_bounds__(256) void mlp_bwd_skinny_reduce_kernel(const MlpLaunch L, const SkinnyLaunch S,
+                                                                    const float* __restrict__ ws) {
+    const nlbac_mlp& net = L.net[blockIdx.y];
+    const nlbac_mlp_io& io = L.io[blockIdx.y];
+    const int hid = net.hid, nwide = net.n_layers - 1, idim = net.in_dim, odim = net.out_dim;
+    const int nq = skinny_nq(net);
+    const int q = blockIdx.x, col = threadIdx.x;
+    if (q >= nq) return;
+    const float* w = ws + (long)blockIdx.y * S.net_stride + (long)q * 256 + col;
+    float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+    int ch = 0;
+    for (; ch + 4 <= S.n_chunks; ch += 4) {       // four fixed interleaved chains (deterministic)
+        s0 += w[(long)(ch + 0) * nq * 256];
+        s1 += w[(long)(ch + 1) * nq * 256];
+        s2 += w[(long)(ch + 2) * nq * 256];
+        s3 += w[(long)(ch + 3) * nq * 256];
     }
-    for (int o0 = 0; o0 < odim; o0 += 8) {
-#pragma unroll
-        for (int i = 0; i < 8; ++i) q[i] = 0.f;
-#pragma unroll
-        for (int o = 0; o < SK_MAX_OUT; ++o)
-            if (o >= o0 && o < o0 + 8) q[o - o0] = dWL[o];
-        flush(q, min(8, odim - o0), [&](int i, float v) {
-            if (live) g[net.w_off[nwide] + (long)(o0 + i) * hid + col] = v;
-        });
-    }
+    for (; ch < S.n_chunks; ++ch) s0 += w[(long)ch * nq * 256];
+    const float v = (s0 + s1) + (s2 + s3);
+    float* g = io.grad;
+    if (q < nwide) { if (col < hid) g[net.b_off[q] + col] = v; }
+    else if (q < nwide + idim) { if (col < hid) g[net.w_off[0] + (long)col * idim + (q - nwide)] = v; }
+    else if (q < nwide + idim + odim) { if (col < hid) g[net.w_off[nwide] + (long)(q - nwide - idim) * hid + col] = v; }
+    else if (col < odim) g[net.b_off[nwide] + col] = v;
 }
 
 // ---------------------------------------------------------------------------
@@ -601,19 +628,34 @@ extern "C" int nlbac_mlp_bwd_data(const nlbac_mlp* nets, const nlbac_mlp_io* io,
     return 0;
 }
 
+extern "C" long nlbac_mlp_bwd_weights_ws_floats(const nlbac_mlp* nets, int n_nets, int B) {
+    long per_net = 0;
+    const int rpc = (B + 1023) / 1024 > 128 ? (B + 1023) / 1024 : 128;
+    const int n_chunks = (B + rpc - 1) / rpc;
+    for (int i = 0; i < n_nets; ++i) {
+        const long nq = (nets[i].n_layers - 1) + nets[i].in_dim + nets[i].out_dim + 1;
+        if (nq * 256 * n_chunks > per_net) per_net = nq * 256 * n_chunks;
+    }
+    return per_net * n_nets;
+}
+
 extern "C" int nlbac_mlp_bwd_weights(const nlbac_mlp* nets, const nlbac_mlp_io* io, int n_nets, int B,
-                                     int n_slabs, long slab_stride, nlbac_stream_t s) {
+                                     int n_slabs, long slab_stride, float* ws, long ws_floats, nlbac_stream_t s) {
     MlpLaunch L;
     if (fill_launch(L, nets, io, n_nets, B, "nlbac_mlp_bwd_weights")) return -1;
     NLBAC_REQUIRE(n_slabs >= 1, "nlbac_mlp_bwd_weights: n_slabs must be >= 1");
-    int max_blocks = 0;
+    int max_blocks = 0, max_q = 0;
     for (int i = 0; i < n_nets; ++i) {
         NLBAC_REQUIRE(io[i].dy && io[i].acts && io[i].dz && io[i].grad && io[i].x0,
                       "nlbac_mlp_bwd_weights: net %d needs x0, dy, acts, dz, grad", i);
         const int T = (nets[i].hid + 63) >> 6;
         const int nb = (nets[i].n_layers - 2) * T * T;
         if (nb > max_blocks) max_blocks = nb;
+        const int nq = (nets[i].n_layers - 1) + nets[i].in_dim + nets[i].out_dim + 1;
+        if (nq > max_q) max_q = nq;
     }
+    const long need = nlbac_mlp_bwd_weights_ws_floats(nets, n_nets, B);
+    NLBAC_REQUIRE(ws && ws_floats >= need, "nlbac_mlp_bwd_weights: workspace too small (%ld < %ld floats)", ws_floats, need);
     int rps = nlbac_ceil_div(B, n_slabs);
     rps = (rps + DW_CHUNK - 1) / DW_CHUNK * DW_CHUNK;
     L.n_slabs = n_slabs; L.rows_per_slab = rps; L.slab_stride = slab_stride;
@@ -621,7 +663,13 @@ extern "C" int nlbac_mlp_bwd_weights(const nlbac_mlp* nets, const nlbac_mlp_io* 
         hipLaunchKernelGGL(mlp_bwd_wide_kernel, dim3(max_blocks, n_slabs, n_nets), dim3(256), 0, (hipStream_t)s, L);
         NLBAC_CHECK_LAUNCH("nlbac_mlp_bwd_weights(wide)");
     }
-    hipLaunchKernelGGL(mlp_bwd_skinny_kernel, dim3(n_slabs, n_nets), dim3(1024), 0, (hipStream_t)s, L);
-    NLBAC_CHECK_LAUNCH("nlbac_mlp_bwd_weights(skinny)");
+    SkinnyLaunch S;
+    S.rows_per_chunk = (B + 1023) / 1024 > 128 ? (B + 1023) / 1024 : 128;
+    S.n_chunks = (B + S.rows_per_chunk - 1) / S.rows_per_chunk;
+    S.net_stride = need / n_nets;
+    hipLaunchKernelGGL(mlp_bwd_skinny_partial_kernel, dim3(S.n_chunks, n_nets), dim3(256), 0, (hipStream_t)s, L, S, ws);
+    NLBAC_CHECK_LAUNCH("nlbac_mlp_bwd_weights(skinny partial)");
+    hipLaunchKernelGGL(mlp_bwd_skinny_reduce_kernel, dim3(max_q, n_nets), dim3(256), 0, (hipStream_t)s, L, S, ws);
+    NLBAC_CHECK_LAUNCH("nlbac_mlp_bwd_weights(skinny reduce)");
     return 0;
 }

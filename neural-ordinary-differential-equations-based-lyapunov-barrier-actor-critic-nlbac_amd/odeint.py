@@ -22,7 +22,7 @@ import torch
 
 from . import _lib
 from ._lib import fptr
-from .arena import io_array, mlp_array, stream_ptr
+from .arena import bwd_weights, io_array, mlp_array, stream_ptr
 
 DP_BETA = [
     [1 / 5],
@@ -313,7 +313,6 @@ class AffineNodeSolver:
                 io[i].acts_ls = S * n * net.hid
                 io[i].grad = arena.grad[n_used:].data_ptr()
             assert n_used + slabs_per_step <= arena.n_slabs, "arena has too few gradient slabs"
-            _lib.call("nlbac_mlp_bwd_weights", mlp_array([self.f.desc, self.g.desc]), io, 2, rows, slabs_per_step,
-                      arena.n, s)
+            bwd_weights(mlp_array([self.f.desc, self.g.desc]), io, 2, rows, slabs_per_step, arena.n, self.device)
             n_used += slabs_per_step
         return n_used

@@ -24,7 +24,7 @@ import torch
 import torch.nn as nn
 
 from .. import _lib
-from ..arena import Arena, io_array, mlp_array, pack, stream_ptr
+from ..arena import Arena, bwd_weights, io_array, mlp_array, pack, stream_ptr
 from ..odeint import AffineNodeSolver
 from . import _layout as SC
 from .model import GaussianPolicy, LyaNetwork, NeuralODEModel, QNetwork
@@ -275,16 +275,23 @@ class SAC_CBF_CLF(object):
     # -- NODE fit (model.py:221-260 via sac_cbf_clf.py:205-219) -----------------
     def fit_node(self, obs, action, next_obs):
         """One Adam step of the NODE regression on device tensors (N,7),(N,2),(N,7)."""
-        N = obs.shape[0]
-        s = stream_ptr()
-        key = N
-        if key not in self._fit_ws:
-            z = lambda *sh: torch.zeros(*sh, dtype=torch.float32, device=self.device)
-            self._fit_ws[key] = dict(st=z(N, 3), nst=z(N, 3), dpred=z(N, 3), part=z((N + 255) // 256))
-        w = self._fit_ws[key]
         obs, action, next_obs = obs.contiguous(), action.contiguous(), next_obs.contiguous()
-        _lib.call("nlbac_unicycle_state", obs.data_ptr(), obs.shape[1], N, self.l_p, w["st"].data_ptr(), None, s)
-        _lib.call("nlbac_unicycle_state", next_obs.data_ptr(), next_obs.shape[1], N, self.l_p, w["nst"].data_ptr(), None, s)
+        self._fit(obs.data_ptr(), obs.shape[1], action, next_obs.data_ptr(), next_obs.shape[1], obs.shape[0])
+
+    def fit_node_rows(self, rows):
+        """Same, for a device tensor of minibatch-layout rows (N,24): obs at column 0,
+        action at 7, next_obs at 15 (the layout ``update_from_host`` uploads)."""
+        self._fit(rows.data_ptr(), rows.shape[1], rows[:, 7:9].contiguous(), rows.data_ptr() + 4 * 15,
+                  rows.shape[1], rows.shape[0])
+
+    def _fit(self, p_obs, obs_ld, action, p_nobs, nobs_ld, N):
+        s = stream_ptr()
+        if N not in self._fit_ws:
+            z = lambda *sh: torch.zeros(*sh, dtype=torch.float32, device=self.device)
+            self._fit_ws[N] = dict(st=z(N, 3), nst=z(N, 3), dpred=z(N, 3), part=z((N + 255) // 256))
+        w = self._fit_ws[N]
+        _lib.call("nlbac_unicycle_state", p_obs, obs_ld, N, self.l_p, w["st"].data_ptr(), None, s)
+        _lib.call("nlbac_unicycle_state", p_nobs, nobs_ld, N, self.l_p, w["nst"].data_ptr(), None, s)
         pred = self.fit_solver.forward(w["st"], action, 1, N, self.solver, self.env.dt, self.atol, self.rtol)
         nblk = (N + 255) // 256
         _lib.call("nlbac_mse_fwd_bwd", pred.data_ptr(), 3, w["nst"].data_ptr(), 3, N, 3, w["dpred"].data_ptr(), 3,
@@ -366,7 +373,7 @@ class SAC_CBF_CLF(object):
         io[2].x0, io[2].x0_dim, io[2].x0_ld = p_cen, 2, LD
         call("nlbac_mlp_bwd_data", cnets, io, 3, B, s)
         a = self.ar_c
-        call("nlbac_mlp_bwd_weights", cnets, io, 3, B, a.n_slabs, a.n, s)
+        bwd_weights(cnets, io, 3, B, a.n_slabs, a.n, self.device)
         soft = (updates % self.target_update_interval == 0)
         call("nlbac_adam_prepare", a.state.data_ptr(), self.critic_lyapunov_lr, s)
         call("nlbac_adam_step", a.theta.data_ptr(), a.m.data_ptr(), a.v.data_ptr(), a.grad.data_ptr(), a.n_slabs,
@@ -446,7 +453,7 @@ class SAC_CBF_CLF(object):
             io[i].acts, io[i].dz = ws.acts_p[i].data_ptr(), ws.dz_p[i].data_ptr()
             io[i].grad = a.grad.data_ptr()
         call("nlbac_mlp_bwd_data", pnets, io, 2, B, s)
-        call("nlbac_mlp_bwd_weights", pnets, io, 2, B, a.n_slabs, a.n, s)
+        bwd_weights(pnets, io, 2, B, a.n_slabs, a.n, self.device)
         la = a.theta.data_ptr() + 4 * self.la_off
         call("nlbac_actor_scalars", ws.part_q.data_ptr(), ws.nblk, B, 2, self.target_entropy, la, self.la_stride,
              a.grad.data_ptr() + 4 * self.la_off, sc, s)

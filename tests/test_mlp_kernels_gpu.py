@@ -92,7 +92,7 @@ def test_mlp_fwd_bwd_matches_torch(in_dim, hid, out_dim, n_layers, B, split):
     s = A.stream_ptr()
     _lib.call("nlbac_mlp_fwd", nets, io, 1, B, s)
     _lib.call("nlbac_mlp_bwd_data", nets, io, 1, B, s)
-    _lib.call("nlbac_mlp_bwd_weights", nets, io, 1, B, ar.n_slabs, ar.n, s)
+    A.bwd_weights(nets, io, 1, B, ar.n_slabs, ar.n, "cuda")
     torch.cuda.synchronize()
 
     vec_close(y.cpu(), y_ref, TOL, "y")
@@ -149,7 +149,7 @@ def test_multi_net_launch_and_adam_soft_update():
     for it in range(2):
         _lib.call("nlbac_mlp_fwd", nets, io, 3, B, s)
         _lib.call("nlbac_mlp_bwd_data", nets, io, 3, B, s)
-        _lib.call("nlbac_mlp_bwd_weights", nets, io, 3, B, ar.n_slabs, ar.n, s)
+        A.bwd_weights(nets, io, 3, B, ar.n_slabs, ar.n, "cuda")
         _lib.call("nlbac_adam_prepare", ar.state.data_ptr(), lr, s)
         _lib.call("nlbac_adam_step", ar.theta.data_ptr(), ar.m.data_ptr(), ar.v.data_ptr(), ar.grad.data_ptr(),
                   ar.n_slabs, ar.n, ar.n, ar.state.data_ptr(), ar.target.data_ptr(), tau, s)
