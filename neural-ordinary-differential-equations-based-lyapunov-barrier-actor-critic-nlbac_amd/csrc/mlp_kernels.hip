@@ -81,42 +81,77 @@ __global__ __launch_bounds__(256) void mlp_pack_kernel(const MlpLaunch L) {
 
 // ---------------------------------------------------------------------------
 // C[32 x 32*NTW] += A_lds[32 x 8*KC] * Bpacked      (one wave, NTW = 1 or 2 tiles)
+// Four K-chunks of operands are kept in flight in statically indexed registers
+// (no register rotation), so the compiler emits counted s_waitcnt vmcnt(N) and
+// every B-fragment load has three chunks of MFMA time to land.
 // ---------------------------------------------------------------------------
+#define MFMA4(A, B0, B1)                                                                       \
+    acc[0] = __builtin_amdgcn_mfma_f32_32x32x2f32((A).x, (B0).x, acc[0], 0, 0, 0);             \
+    if (NTW == 2) acc[1] = __builtin_amdgcn_mfma_f32_32x32x2f32((A).x, (B1).x, acc[1], 0, 0, 0); \
+    acc[0] = __builtin_amdgcn_mfma_f32_32x32x2f32((A).y, (B0).y, acc[0], 0, 0, 0);             \
+    if (NTW == 2) acc[1] = __builtin_amdgcn_mfma_f32_32x32x2f32((A).y, (B1).y, acc[1], 0, 0, 0); \
+    acc[0] = __builtin_amdgcn_mfma_f32_32x32x2f32((A).z, (B0).z, acc[0], 0, 0, 0);             \
+    if (NTW == 2) acc[1] = __builtin_amdgcn_mfma_f32_32x32x2f32((A).z, (B1).z, acc[1], 0, 0, 0); \
+    acc[0] = __builtin_amdgcn_mfma_f32_32x32x2f32((A).w, (B0).w, acc[0], 0, 0, 0);             \
+    if (NTW == 2) acc[1] = __builtin_amdgcn_mfma_f32_32x32x2f32((A).w, (B1).w, acc[1], 0, 0, 0);
+
 template <int NTW>
 __device__ __forceinline__ void wave_gemm(const float* __restrict__ a_lds, int LD,
                                           const float4* __restrict__ pk, int KC, int tile0,
                                           f32x16 (&acc)[2], int lane) {
+    constexpr int D = 4;
     const float4* p0 = pk + (long)tile0 * KC * 64 + lane;
     const float4* p1 = pk + (long)(tile0 + 4) * KC * 64 + lane;
     const float* arow = a_lds + (lane & 31) * LD + (lane >> 5) * 4;
-    float4 b0c = p0[0], b1c = make_float4(0, 0, 0, 0);
-    float4 b0n = (KC > 1) ? p0[64] : b0c, b1n = b1c;
-    if (NTW == 2) { b1c = p1[0]; b1n = (KC > 1) ? p1[64] : b1c; }
-    float4 ac = *reinterpret_cast<const float4*>(arow);
-    for (int kc = 0; kc < KC; ++kc) {
-        float4 b0f = b0n, b1f = b1n, an = ac;
-        if (kc + 2 < KC) {
-            b0f = p0[(long)(kc + 2) * 64];
-            if (NTW == 2) b1f = p1[(long)(kc + 2) * 64];
+    const int last = KC - 1;
+    float4 b0[D], b1[D], a[D];
+#pragma unroll
+    for (int i = 0; i < D; ++i) {
+        const int c = min(i, last);
+        b0[i] = p0[(long)c * 64];
+        b1[i] = (NTW == 2) ? p1[(long)c * 64] : make_float4(0, 0, 0, 0);
+        a[i] = *reinterpret_cast<const float4*>(arow + c * 8);
+    }
+    int kc = 0;
+    for (; kc + D <= KC; kc += D) {
+#pragma unroll
+        for (int i = 0; i < D; ++i) {
+            MFMA4(a[i], b0[i], b1[i])
+            const int c = min(kc + i + D, last);
+            b0[i] = p0[(long)c * 64];
+            if (NTW == 2) b1[i] = p1[(long)c * 64];
+            a[i] = *reinterpret_cast<const float4*>(arow + c * 8);
+            __builtin_amdgcn_sched_barrier(0);   // keep each slot's refill right behind its MFMAs
         }
-        if (kc + 1 < KC) an = *reinterpret_cast<const float4*>(arow + (kc + 1) * 8);
-        acc[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(ac.x, b0c.x, acc[0], 0, 0, 0);
-        if (NTW == 2) acc[1] = __builtin_amdgcn_mfma_f32_32x32x2f32(ac.x, b1c.x, acc[1], 0, 0, 0);
-        acc[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(ac.y, b0c.y, acc[0], 0, 0, 0);
-        if (NTW == 2) acc[1] = __builtin_amdgcn_mfma_f32_32x32x2f32(ac.y, b1c.y, acc[1], 0, 0, 0);
-        acc[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(ac.z, b0c.z, acc[0], 0, 0, 0);
-        if (NTW == 2) acc[1] = __builtin_amdgcn_mfma_f32_32x32x2f32(ac.z, b1c.z, acc[1], 0, 0, 0);
-        acc[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(ac.w, b0c.w, acc[0], 0, 0, 0);
-        if (NTW == 2) acc[1] = __builtin_amdgcn_mfma_f32_32x32x2f32(ac.w, b1c.w, acc[1], 0, 0, 0);
-        b0c = b0n; b0n = b0f; ac = an;
-        if (NTW == 2) { b1c = b1n; b1n = b1f; }
+    }
+#pragma unroll
+    for (int i = 0; i < D - 1; ++i)
+        if (kc + i < KC) { MFMA4(a[i], b0[i], b1[i]) }
+}
+
+// skinny contraction helpers (VALU): NO outputs at once, every load unconditional
+template <int NO>
+__device__ __forceinline__ void skinny_dot(const float* __restrict__ lds_row, const float* __restrict__ W, int hid,
+                                           int part, float (&acc)[4]) {
+#pragma unroll 4
+    for (int it = 0; it < 8; ++it) {
+        const int k = part * 4 + 32 * it;
+        const bool ok = k < hid;
+        const int kk = ok ? k : 0;
+        float4 h = *reinterpret_cast<const float4*>(lds_row + kk);
+        if (!ok) h = make_float4(0, 0, 0, 0);
+#pragma unroll
+        for (int q = 0; q < NO; ++q) {
+            const float4 w = *reinterpret_cast<const float4*>(W + (long)q * hid + kk);
+            acc[q] += h.x * w.x + h.y * w.y + h.z * w.z + h.w * w.w;
+        }
     }
 }
 
 // ---------------------------------------------------------------------------
 // forward
 // ---------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void mlp_fwd_kernel(const MlpLaunch L) {
+__global__ __launch_bounds__(256, 2) void mlp_fwd_kernel(const MlpLaunch L) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     const nlbac_mlp& net = L.net[blockIdx.y];
     const nlbac_mlp_io& io = L.io[blockIdx.y];
@@ -140,6 +175,7 @@ __global__ __launch_bounds__(256) void mlp_fwd_kernel(const MlpLaunch L) {
     }
     __syncthreads();
 
+    const bool full_tile = row0 + NLBAC_MLP_TILE <= B;
     for (int l = 0; l < nwide; ++l) {
         const int KC = ((l == 0) ? inp : hidp8) >> 3;
         const float4* pk = reinterpret_cast<const float4*>(net.packed + net.pf_off[l]);
@@ -156,13 +192,24 @@ __global__ __launch_bounds__(256) void mlp_fwd_kernel(const MlpLaunch L) {
             for (int t = 0; t < 2; ++t) {
                 if (t == 1 && !two) break;
                 const int col = (wave + 4 * t) * 32 + (lane & 31);
-                const float b = (col < hid) ? bias[col] : 0.f;
+                const float b = bias[min(col, hid - 1)];
+                const bool colok = col < hid;
+                float v[16];
 #pragma unroll
                 for (int r = 0; r < 16; ++r) {
-                    const int m = acc_row(r, half);
-                    const float v = fmaxf(acc[t][r] + b, 0.f);
-                    out[m * LD + col] = v;
-                    if (acts && col < hid && row0 + m < B) acts[(long)(row0 + m) * hid + col] = v;
+                    v[r] = colok ? fmaxf(acc[t][r] + b, 0.f) : 0.f;
+                    out[acc_row(r, half) * LD + col] = v[r];
+                }
+                if (acts && colok) {
+                    float* ap = acts + (long)row0 * hid + col;
+                    if (full_tile) {
+#pragma unroll
+                        for (int r = 0; r < 16; ++r) ap[(long)acc_row(r, half) * hid] = v[r];
+                    } else {
+#pragma unroll
+                        for (int r = 0; r < 16; ++r)
+                            if (row0 + acc_row(r, half) < B) ap[(long)acc_row(r, half) * hid] = v[r];
+                    }
                 }
             }
         }
@@ -172,35 +219,29 @@ __global__ __launch_bounds__(256) void mlp_fwd_kernel(const MlpLaunch L) {
 
     // skinny output layer on the VALU: 8 lanes per sample row
     {
-        const int l = nwide;
-        const float* W = net.params + net.w_off[l];
-        const float* bias = net.params + net.b_off[l];
+        const float* W = net.params + net.w_off[nwide];
+        const float* bias = net.params + net.b_off[nwide];
         const int m = tid >> 3, part = tid & 7, row = row0 + m;
         for (int o0 = 0; o0 < net.out_dim; o0 += 4) {
-            float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
+            float a[4] = {0.f, 0.f, 0.f, 0.f};
             const int no = min(4, net.out_dim - o0);
-            for (int k = part * 4; k < hid; k += 32) {
-                const float4 h = *reinterpret_cast<const float4*>(in + m * LD + k);
-                const float4 w0 = *reinterpret_cast<const float4*>(W + (long)(o0 + 0) * hid + k);
-                a0 += h.x * w0.x + h.y * w0.y + h.z * w0.z + h.w * w0.w;
-                if (no > 1) { const float4 w = *reinterpret_cast<const float4*>(W + (long)(o0 + 1) * hid + k);
-                              a1 += h.x * w.x + h.y * w.y + h.z * w.z + h.w * w.w; }
-                if (no > 2) { const float4 w = *reinterpret_cast<const float4*>(W + (long)(o0 + 2) * hid + k);
-                              a2 += h.x * w.x + h.y * w.y + h.z * w.z + h.w * w.w; }
-                if (no > 3) { const float4 w = *reinterpret_cast<const float4*>(W + (long)(o0 + 3) * hid + k);
-                              a3 += h.x * w.x + h.y * w.y + h.z * w.z + h.w * w.w; }
-            }
+            const float* Wo = W + (long)o0 * hid;
+            const float* hrow = in + m * LD;
+            if (no == 1) skinny_dot<1>(hrow, Wo, hid, part, a);
+            else if (no == 2) skinny_dot<2>(hrow, Wo, hid, part, a);
+            else if (no == 3) skinny_dot<3>(hrow, Wo, hid, part, a);
+            else skinny_dot<4>(hrow, Wo, hid, part, a);
 #pragma unroll
             for (int off = 1; off < 8; off <<= 1) {
-                a0 += __shfl_xor(a0, off, 64); a1 += __shfl_xor(a1, off, 64);
-                a2 += __shfl_xor(a2, off, 64); a3 += __shfl_xor(a3, off, 64);
+                a[0] += __shfl_xor(a[0], off, 64); a[1] += __shfl_xor(a[1], off, 64);
+                a[2] += __shfl_xor(a[2], off, 64); a[3] += __shfl_xor(a[3], off, 64);
             }
             if (part == 0 && row < B) {
                 float* y = io.y + (long)row * io.y_ld + o0;
-                y[0] = a0 + bias[o0];
-                if (no > 1) y[1] = a1 + bias[o0 + 1];
-                if (no > 2) y[2] = a2 + bias[o0 + 2];
-                if (no > 3) y[3] = a3 + bias[o0 + 3];
+                y[0] = a[0] + bias[o0];
+                if (no > 1) y[1] = a[1] + bias[o0 + 1];
+                if (no > 2) y[2] = a[2] + bias[o0 + 2];
+                if (no > 3) y[3] = a[3] + bias[o0 + 3];
             }
         }
     }
@@ -212,7 +253,38 @@ __global__ __launch_bounds__(256) void mlp_fwd_kernel(const MlpLaunch L) {
 //   dz[j-1]     = (dz[j] W_j) * [acts[j-1] > 0]            (MFMA, backward pack)
 //   dx          =  dz[0] W_0                                (VALU)
 // ---------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void mlp_bwd_data_kernel(const MlpLaunch L) {
+template <int NO>
+__device__ __forceinline__ void top_layer_bwd(const float* __restrict__ sdy, const float* __restrict__ W, int hid,
+                                              int k, float (&s)[NLBAC_MLP_TILE]) {
+    float w[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int q = 0; q < NO; ++q) w[q] = W[(long)q * hid + k];
+#pragma unroll
+    for (int m = 0; m < NLBAC_MLP_TILE; ++m) {
+        const float4 d = *reinterpret_cast<const float4*>(sdy + m * 16);
+        s[m] += d.x * w[0] + d.y * w[1] + d.z * w[2] + d.w * w[3];
+    }
+}
+
+template <int NI>
+__device__ __forceinline__ void dx_dot(const float* __restrict__ lds_row, const float* __restrict__ W, int hid,
+                                       int idim, int part, float (&acc)[4]) {
+#pragma unroll 2
+    for (int it = 0; it < 8; ++it) {
+        const int n = part * 4 + 32 * it;
+        const bool ok = n < hid;
+        const int nn = ok ? n : 0;
+        float4 d = *reinterpret_cast<const float4*>(lds_row + nn);
+        if (!ok) d = make_float4(0, 0, 0, 0);
+        const float dd[4] = {d.x, d.y, d.z, d.w};
+#pragma unroll
+        for (int q = 0; q < 4; ++q)
+#pragma unroll
+            for (int i = 0; i < NI; ++i) acc[i] += dd[q] * W[(long)(nn + q) * idim + i];
+    }
+}
+
+__global__ __launch_bounds__(256, 2) void mlp_bwd_data_kernel(const MlpLaunch L) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     const nlbac_mlp& net = L.net[blockIdx.y];
     const nlbac_mlp_io& io = L.io[blockIdx.y];
@@ -221,6 +293,7 @@ __global__ __launch_bounds__(256) void mlp_bwd_data_kernel(const MlpLaunch L) {
     const int row0 = blockIdx.x * NLBAC_MLP_TILE;
     const int hid = net.hid, NT = pad32(hid) >> 5, hidp8 = pad8(hid), hidp32 = NT * 32;
     const int nwide = net.n_layers - 1;
+    const long ls = io.acts_ls ? io.acts_ls : (long)B * hid;
     float* in = smem;
     float* out = smem + NLBAC_MLP_TILE * LD;
     float* sdy = smem + 2 * NLBAC_MLP_TILE * LD;   // [32][16]
@@ -229,40 +302,34 @@ __global__ __launch_bounds__(256) void mlp_bwd_data_kernel(const MlpLaunch L) {
         const int r = idx >> 4, c = idx & 15, row = row0 + r;
         sdy[idx] = (row < B && c < net.out_dim) ? io.dy[(long)row * io.dy_ld + c] : 0.f;
     }
-    __syncthreads();
 
-    {   // top (skinny) layer: thread = hidden column
-        const int k = tid;
-        const float* W = net.params + net.w_off[nwide];
+    {   // top (skinny) layer: thread = hidden column; ReLU masks are fetched up front (clamped, unconditional)
+        const int k = tid, kc = min(k, hid - 1);
+        const float* acts = io.acts + (long)(nwide - 1) * ls;
+        float av[NLBAC_MLP_TILE];
+#pragma unroll
+        for (int m = 0; m < NLBAC_MLP_TILE; ++m) av[m] = acts[(long)min(row0 + m, B - 1) * hid + kc];
+        __syncthreads();
+        const float* W = net.params + net.w_off[nwide] + kc;
         float s[NLBAC_MLP_TILE];
 #pragma unroll
         for (int m = 0; m < NLBAC_MLP_TILE; ++m) s[m] = 0.f;
-        if (k < hid) {
-            for (int o0 = 0; o0 < net.out_dim; o0 += 4) {
-                const int no = min(4, net.out_dim - o0);
-                const float w0 = W[(long)o0 * hid + k];
-                const float w1 = no > 1 ? W[(long)(o0 + 1) * hid + k] : 0.f;
-                const float w2 = no > 2 ? W[(long)(o0 + 2) * hid + k] : 0.f;
-                const float w3 = no > 3 ? W[(long)(o0 + 3) * hid + k] : 0.f;
-#pragma unroll
-                for (int m = 0; m < NLBAC_MLP_TILE; ++m) {
-                    const float4 d = *reinterpret_cast<const float4*>(sdy + m * 16 + o0);
-                    s[m] += d.x * w0 + d.y * w1 + d.z * w2 + d.w * w3;
-                }
-            }
+        for (int o0 = 0; o0 < net.out_dim; o0 += 4) {
+            const int no = min(4, net.out_dim - o0);
+            const float* Wo = W + (long)o0 * hid;
+            if (no == 1) top_layer_bwd<1>(sdy + o0, Wo, hid, 0, s);
+            else if (no == 2) top_layer_bwd<2>(sdy + o0, Wo, hid, 0, s);
+            else if (no == 3) top_layer_bwd<3>(sdy + o0, Wo, hid, 0, s);
+            else top_layer_bwd<4>(sdy + o0, Wo, hid, 0, s);
         }
-        const long ls = io.acts_ls ? io.acts_ls : (long)B * hid;
-        const float* acts = io.acts + (long)(nwide - 1) * ls;
         float* dz = io.dz ? io.dz + (long)(nwide - 1) * ls : nullptr;
         if (k < hidp32) {
+            const bool colok = k < hid;
 #pragma unroll
             for (int m = 0; m < NLBAC_MLP_TILE; ++m) {
-                const int row = row0 + m;
-                float v = 0.f;
-                if (k < hid && row < B) {
-                    v = acts[(long)row * hid + k] > 0.f ? s[m] : 0.f;
-                    if (dz) dz[(long)row * hid + k] = v;
-                }
+                const bool ok = colok && (row0 + m < B);
+                const float v = (ok && av[m] > 0.f) ? s[m] : 0.f;
+                if (dz && ok) dz[(long)(row0 + m) * hid + k] = v;
                 in[m * LD + k] = v;
             }
         }
@@ -272,28 +339,35 @@ __global__ __launch_bounds__(256) void mlp_bwd_data_kernel(const MlpLaunch L) {
     for (int j = nwide - 1; j >= 1; --j) {
         const int KC = hidp8 >> 3;
         const float4* pk = reinterpret_cast<const float4*>(net.packed + net.pb_off[j]);
-        const long ls = io.acts_ls ? io.acts_ls : (long)B * hid;
         const float* acts = io.acts + (long)(j - 1) * ls;
         float* dz = io.dz ? io.dz + (long)(j - 1) * ls : nullptr;
         if (wave < NT) {
+            const bool two = (wave + 4) < NT;
+            // ReLU masks of this wave's output fragment, requested before the GEMM so they land under it
+            float av[2][16];
+#pragma unroll
+            for (int t = 0; t < 2; ++t) {
+                const int colc = min((wave + 4 * t) * 32 + (lane & 31), hid - 1);
+#pragma unroll
+                for (int r = 0; r < 16; ++r)
+                    av[t][r] = (t == 0 || two) ? acts[(long)min(row0 + acc_row(r, half), B - 1) * hid + colc] : 0.f;
+            }
             f32x16 acc[2];
 #pragma unroll
             for (int r = 0; r < 16; ++r) { acc[0][r] = 0.f; acc[1][r] = 0.f; }
-            const bool two = (wave + 4) < NT;
             if (two) wave_gemm<2>(in, LD, pk, KC, wave, acc, lane);
             else wave_gemm<1>(in, LD, pk, KC, wave, acc, lane);
 #pragma unroll
             for (int t = 0; t < 2; ++t) {
                 if (t == 1 && !two) break;
                 const int col = (wave + 4 * t) * 32 + (lane & 31);
+                const bool colok = col < hid;
 #pragma unroll
                 for (int r = 0; r < 16; ++r) {
-                    const int m = acc_row(r, half), row = row0 + m;
-                    float v = 0.f;
-                    if (col < hid && row < B) {
-                        v = acts[(long)row * hid + col] > 0.f ? acc[t][r] : 0.f;
-                        if (dz) dz[(long)row * hid + col] = v;
-                    }
+                    const int m = acc_row(r, half);
+                    const bool ok = colok && (row0 + m < B);
+                    const float v = (ok && av[t][r] > 0.f) ? acc[t][r] : 0.f;
+                    if (dz && ok) dz[(long)(row0 + m) * hid + col] = v;
                     out[m * LD + col] = v;
                 }
             }
@@ -308,30 +382,23 @@ __global__ __launch_bounds__(256) void mlp_bwd_data_kernel(const MlpLaunch L) {
         const int m = tid >> 3, part = tid & 7, row = row0 + m;
         for (int i0 = 0; i0 < idim; i0 += 4) {
             const int ni = min(4, idim - i0);
-            float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
-            for (int n = part * 4; n < hid; n += 32) {
-                const float4 d = *reinterpret_cast<const float4*>(in + m * LD + n);
-                const float dd[4] = {d.x, d.y, d.z, d.w};
-#pragma unroll
-                for (int q = 0; q < 4; ++q) {
-                    const float* w = W + (long)(n + q) * idim + i0;
-                    a0 += dd[q] * w[0];
-                    if (ni > 1) a1 += dd[q] * w[1];
-                    if (ni > 2) a2 += dd[q] * w[2];
-                    if (ni > 3) a3 += dd[q] * w[3];
-                }
-            }
+            float a[4] = {0.f, 0.f, 0.f, 0.f};
+            const float* drow = in + m * LD;
+            if (ni == 1) dx_dot<1>(drow, W + i0, hid, idim, part, a);
+            else if (ni == 2) dx_dot<2>(drow, W + i0, hid, idim, part, a);
+            else if (ni == 3) dx_dot<3>(drow, W + i0, hid, idim, part, a);
+            else dx_dot<4>(drow, W + i0, hid, idim, part, a);
 #pragma unroll
             for (int off = 1; off < 8; off <<= 1) {
-                a0 += __shfl_xor(a0, off, 64); a1 += __shfl_xor(a1, off, 64);
-                a2 += __shfl_xor(a2, off, 64); a3 += __shfl_xor(a3, off, 64);
+                a[0] += __shfl_xor(a[0], off, 64); a[1] += __shfl_xor(a[1], off, 64);
+                a[2] += __shfl_xor(a[2], off, 64); a[3] += __shfl_xor(a[3], off, 64);
             }
             if (part == 0 && row < B) {
                 float* dx = io.dx + (long)row * io.dx_ld + i0;
-                dx[0] = a0;
-                if (ni > 1) dx[1] = a1;
-                if (ni > 2) dx[2] = a2;
-                if (ni > 3) dx[3] = a3;
+                dx[0] = a[0];
+                if (ni > 1) dx[1] = a[1];
+                if (ni > 2) dx[2] = a[2];
+                if (ni > 3) dx[3] = a[3];
             }
         }
     }
