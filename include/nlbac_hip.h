@@ -132,19 +132,20 @@ int nlbac_gauss_sample_bwd(const float *heads, int heads_ld, const float *eps, c
 #define NLBAC_SC_SIZE 128
 
 /* TD / Lyapunov targets, MSE partial sums and dL/dq (sac_cbf_clf.py:231-246).
- * All q-like arguments are (B) vectors; alpha = sc+SC_ALPHA.
+ * All q-like arguments are (B) vectors; alpha = sc+SC_ALPHA.  Means are over B_norm rows
+ * (= B on one GPU, the global batch under data parallelism; the same holds for every *_norm below).
  * partials: [ceil(B/256)][3] squared-error sums (qf1, qf2, lf). */
 int nlbac_td_targets(const float *q1t, const float *q2t, const float *lt, const float *nlogp,
                      const float *reward, const float *constraint, const float *mask,
                      const float *q1, const float *q2, const float *lf, const float *alpha,
-                     float gamma, int B, float *dq1, float *dq2, float *dlf, float *next_q,
+                     float gamma, int B, int B_norm, float *dq1, float *dq2, float *dlf, float *next_q,
                      float *next_l, float *partials, nlbac_stream_t s);
 
 /* policy_loss_1 pieces for P controllers (rows p*B..): d min(Q1,Q2)/dq * (-1/B) and
  * partials [P][ceil(B/256)][2] = sums of (alpha_p*logp - minq, logp)
  * (sac_cbf_clf.py:258-273). */
 int nlbac_actor_q_terms(const float *q1, const float *q2, const float *logp, const float *alpha,
-                        int B, int P, float *dq1, float *dq2, float *partials, nlbac_stream_t s);
+                        int B, int B_norm, int P, float *dq1, float *dq2, float *partials, nlbac_stream_t s);
 /* policy_loss_1, alpha_loss into sc; d alpha_loss / d log_alpha into g_log_alpha
  * (sac_cbf_clf.py:292-308).  log_alpha[p*stride]. */
 int nlbac_actor_scalars(const float *partials, int n_blk, int B, int P, float target_entropy,
@@ -180,8 +181,8 @@ int nlbac_unicycle_constraints_bwd(const float *ps_next, const float *matr, cons
                                    const float *sc, float *dps_next, float *dV_next, nlbac_stream_t s);
 
 /* nn.MSELoss('mean') over (n,d): dpred and per-block squared-error partials [ceil(n/256)] (model.py:256). */
-int nlbac_mse_fwd_bwd(const float *pred, int pred_ld, const float *target, int target_ld, int n, int d,
-                      float *dpred, int dpred_ld, float *partials, nlbac_stream_t s);
+int nlbac_mse_fwd_bwd(const float *pred, int pred_ld, const float *target, int target_ld, int n, int n_norm,
+                      int d, float *dpred, int dpred_ld, float *partials, nlbac_stream_t s);
 
 /* ------------------------------------------------------------------------
  * Control-affine NODE field  k = f(x) + g(x) u  (model.py:208-217) and the

@@ -62,8 +62,8 @@ _PROTOS = {
     "nlbac_soft_update": [_P, _P, _L, _F, _P],
     "nlbac_gauss_sample_fwd": [_P, _I, _P, _P, _P, _I, _I, _P, _I, _P, _P],
     "nlbac_gauss_sample_bwd": [_P, _I, _P, _P, _I, _I, _I, _P, _I, _P, _I, _P, _I, _P, _F, _P, _I, _P],
-    "nlbac_td_targets": [_P] * 11 + [_F, _I] + [_P] * 6 + [_P],
-    "nlbac_actor_q_terms": [_P, _P, _P, _P, _I, _I, _P, _P, _P, _P],
+    "nlbac_td_targets": [_P] * 11 + [_F, _I, _I] + [_P] * 6 + [_P],
+    "nlbac_actor_q_terms": [_P, _P, _P, _P, _I, _I, _I, _P, _P, _P, _P],
     "nlbac_actor_scalars": [_P, _I, _I, _I, _F, _P, _I, _P, _P, _P],
     "nlbac_alpha_refresh": [_P, _I, _I, _P, _P],
     "nlbac_unicycle_state": [_P, _I, _I, _F, _P, _P, _P],
@@ -72,7 +72,7 @@ _PROTOS = {
     "nlbac_unicycle_constraints_fwd": [_P, _P, _P, _P, _P, _I, _F, _F, _F, _F, _I, _P, _P, _P, _P],
     "nlbac_auglag": [_P, _I, _I, _I, _F, _I, _I, _I, _F, _F, _P, _P],
     "nlbac_unicycle_constraints_bwd": [_P, _P, _P, _P, _I, _F, _F, _I, _P, _P, _P, _P],
-    "nlbac_mse_fwd_bwd": [_P, _I, _P, _I, _I, _I, _P, _I, _P, _P],
+    "nlbac_mse_fwd_bwd": [_P, _I, _P, _I, _I, _I, _I, _P, _I, _P, _P],
     "nlbac_affine_combine_fwd": [_P, _P, _P, _I, _I, _I, _P, _P],
     "nlbac_affine_combine_bwd": [_P, _P, _P, _I, _I, _I, _F, _P, _P, _I, _P],
     "nlbac_rk_combine": [_P, _P, _I, c_float_p, c_float_p, _P, _I, _I, _I, _I, _P, _P],

@@ -87,9 +87,9 @@ __global__ __launch_bounds__(256) void td_targets_kernel(const float* q1t, const
                                                          const float* nlogp, const float* reward,
                                                          const float* constraint, const float* mask,
                                                          const float* q1, const float* q2, const float* lf,
-                                                         const float* alpha, float gamma, int B, float* dq1,
-                                                         float* dq2, float* dlf, float* next_q, float* next_l,
-                                                         float* partials) {
+                                                         const float* alpha, float gamma, int B, int B_norm,
+                                                         float* dq1, float* dq2, float* dlf, float* next_q,
+                                                         float* next_l, float* partials) {
     __shared__ float red[12];
     const int i = blockIdx.x * 256 + threadIdx.x;
     float v[3] = {0.f, 0.f, 0.f};
@@ -98,7 +98,7 @@ __global__ __launch_bounds__(256) void td_targets_kernel(const float* q1t, const
         const float mq = fminf(q1t[i], q2t[i]) - a * nlogp[i];
         const float yq = reward[i] + mask[i] * gamma * mq;
         const float yl = constraint[i] + mask[i] * gamma * lt[i];
-        const float norm = (float)(2.0 / (double)B);
+        const float norm = (float)(2.0 / (double)B_norm);
         const float e1 = q1[i] - yq, e2 = q2[i] - yq, e3 = lf[i] - yl;
         dq1[i] = norm * e1; dq2[i] = norm * e2; dlf[i] = norm * e3;
         if (next_q) next_q[i] = yq;
@@ -118,8 +118,8 @@ __global__ __launch_bounds__(256) void td_targets_kernel(const float* q1t, const
 // Rows: P problems (primary, backup) x B.  partials: [P][nblk][2]
 // ---------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void actor_q_terms_kernel(const float* q1, const float* q2, const float* logp,
-                                                            const float* alpha, int B, float* dq1, float* dq2,
-                                                            float* partials) {
+                                                            const float* alpha, int B, int B_norm, float* dq1,
+                                                            float* dq2, float* partials) {
     __shared__ float red[8];
     const int p = blockIdx.y;
     const int i = blockIdx.x * 256 + threadIdx.x;
@@ -127,7 +127,7 @@ __global__ __launch_bounds__(256) void actor_q_terms_kernel(const float* q1, con
     if (i < B) {
         const long r = (long)p * B + i;
         const float a = q1[r], b = q2[r];
-        const float g = -(1.0f / (float)B);
+        const float g = -(1.0f / (float)B_norm);
         dq1[r] = (a < b) ? g : ((a == b) ? 0.5f * g : 0.f);
         dq2[r] = (b < a) ? g : ((a == b) ? 0.5f * g : 0.f);
         v[0] = alpha[p] * logp[r] - fminf(a, b);
@@ -352,12 +352,13 @@ __global__ __launch_bounds__(256) void unicycle_constraints_bwd_kernel(const flo
 
 // MSE (mean over n*d) partial sums and gradient
 __global__ __launch_bounds__(256) void mse_kernel(const float* pred, int pred_ld, const float* target, int target_ld,
-                                                  int n, int d, float* dpred, int dpred_ld, float* partials) {
+                                                  int n, int n_norm, int d, float* dpred, int dpred_ld,
+                                                  float* partials) {
     __shared__ float red[4];
     const int i = blockIdx.x * 256 + threadIdx.x;
     float v[1] = {0.f};
     if (i < n) {
-        const float norm = (float)(2.0 / ((double)n * d));
+        const float norm = (float)(2.0 / ((double)n_norm * d));
         for (int c = 0; c < d; ++c) {
             const float e = pred[(long)i * pred_ld + c] - target[(long)i * target_ld + c];
             dpred[(long)i * dpred_ld + c] = norm * e;
@@ -399,21 +400,22 @@ extern "C" int nlbac_gauss_sample_bwd(const float* heads, int heads_ld, const fl
 extern "C" int nlbac_td_targets(const float* q1t, const float* q2t, const float* lt, const float* nlogp,
                                 const float* reward, const float* constraint, const float* mask,
                                 const float* q1, const float* q2, const float* lf, const float* alpha,
-                                float gamma, int B, float* dq1, float* dq2, float* dlf, float* next_q,
+                                float gamma, int B, int B_norm, float* dq1, float* dq2, float* dlf, float* next_q,
                                 float* next_l, float* partials, nlbac_stream_t s) {
     NLBAC_REQUIRE(q1t && q2t && lt && nlogp && reward && constraint && mask && q1 && q2 && lf && alpha && dq1 &&
                       dq2 && dlf && partials, "nlbac_td_targets: null pointer");
     hipLaunchKernelGGL(td_targets_kernel, GRID1(B), q1t, q2t, lt, nlogp, reward, constraint, mask, q1, q2, lf,
-                       alpha, gamma, B, dq1, dq2, dlf, next_q, next_l, partials);
+                       alpha, gamma, B, B_norm, dq1, dq2, dlf, next_q, next_l, partials);
     NLBAC_CHECK_LAUNCH("nlbac_td_targets");
     return 0;
 }
 
 extern "C" int nlbac_actor_q_terms(const float* q1, const float* q2, const float* logp, const float* alpha,
-                                   int B, int P, float* dq1, float* dq2, float* partials, nlbac_stream_t s) {
+                                   int B, int B_norm, int P, float* dq1, float* dq2, float* partials,
+                                   nlbac_stream_t s) {
     NLBAC_REQUIRE(q1 && q2 && logp && alpha && dq1 && dq2 && partials, "nlbac_actor_q_terms: null pointer");
     hipLaunchKernelGGL(actor_q_terms_kernel, dim3(nlbac_ceil_div(B, 256), P), dim3(256), 0, (hipStream_t)s, q1, q2,
-                       logp, alpha, B, dq1, dq2, partials);
+                       logp, alpha, B, B_norm, dq1, dq2, partials);
     NLBAC_CHECK_LAUNCH("nlbac_actor_q_terms");
     return 0;
 }
@@ -495,10 +497,10 @@ extern "C" int nlbac_unicycle_constraints_bwd(const float* ps_next, const float*
     return 0;
 }
 
-extern "C" int nlbac_mse_fwd_bwd(const float* pred, int pred_ld, const float* target, int target_ld, int n, int d,
-                                 float* dpred, int dpred_ld, float* partials, nlbac_stream_t s) {
+extern "C" int nlbac_mse_fwd_bwd(const float* pred, int pred_ld, const float* target, int target_ld, int n,
+                                 int n_norm, int d, float* dpred, int dpred_ld, float* partials, nlbac_stream_t s) {
     NLBAC_REQUIRE(pred && target && dpred && partials, "nlbac_mse_fwd_bwd: null pointer");
-    hipLaunchKernelGGL(mse_kernel, GRID1(n), pred, pred_ld, target, target_ld, n, d, dpred, dpred_ld, partials);
+    hipLaunchKernelGGL(mse_kernel, GRID1(n), pred, pred_ld, target, target_ld, n, n_norm, d, dpred, dpred_ld, partials);
     NLBAC_CHECK_LAUNCH("nlbac_mse_fwd_bwd");
     return 0;
 }

@@ -87,6 +87,7 @@ class AffineNodeSolver:
         self._ws = {}          # (n, S, idx) -> _StepWS
         self._scratch = {}
         self.nfe = 0
+        self.comm = None       # nlbac_amd.parallel.DataParallel: global dopri5 error norms
 
     # -- workspace -----------------------------------------------------------
     def _step_ws(self, n, S, idx):
@@ -155,6 +156,20 @@ class AffineNodeSolver:
     def _ctl(self, P):
         return self._buf("ctl", P, _lib.DOPRI_CTL, dtype=torch.float64)
 
+    def _control(self, part, nblk, mode, P, rpp, t_end, ctl):
+        """Step-size controller; under data parallelism the squared-norm sums are all-reduced first so every
+        rank takes the decision the single-device run over the global batch would take."""
+        ns, nu, s = self.n_s, self.n_u, stream_ptr()
+        if self.comm is not None and self.comm.world > 1:
+            sums = self._buf("psum", P, 1, 2)
+            for p in range(P):
+                _lib.call("nlbac_sum_partials", part[p].data_ptr(), nblk, 2, 1.0, sums[p].data_ptr(), s)
+            self.comm.all_reduce_(sums)
+            _lib.call("nlbac_dopri_control", sums.data_ptr(), 1, mode, ns, nu, rpp * self.comm.world, P, t_end,
+                      ctl.data_ptr(), s)
+        else:
+            _lib.call("nlbac_dopri_control", part.data_ptr(), nblk, mode, ns, nu, rpp, P, t_end, ctl.data_ptr(), s)
+
     def _forward_dopri5(self, y0, u, P, rpp, t_end, atol, rtol):
         n, ns, nu, S = P * rpp, self.n_s, self.n_u, 7
         s = stream_ptr()
@@ -167,7 +182,7 @@ class AffineNodeSolver:
         self._stage_eval(ws, 0, u)
         _lib.call("nlbac_dopri_norm_partials", ws.K[0].data_ptr(), None, y0.data_ptr(), None, u.data_ptr(), 0,
                   rtol, atol, ns, nu, rpp, P, part.data_ptr(), s)
-        _lib.call("nlbac_dopri_control", part.data_ptr(), nblk, 0, ns, nu, rpp, P, t_end, ctl.data_ptr(), s)
+        self._control(part, nblk, 0, P, rpp, t_end, ctl)
         ytmp, ktmp, gtmp = self._buf("ytmp", n, ns), self._buf("ktmp", n, ns), self._buf("gtmp", n, ns * nu)
         h0_dev = ctl.data_ptr() + 6 * 8           # C_H0
         _lib.call("nlbac_rk_combine", y0.data_ptr(), ws.K.data_ptr(), 1, fptr(1.0), None, h0_dev, _lib.DOPRI_CTL,
@@ -175,7 +190,7 @@ class AffineNodeSolver:
         self._eval(ytmp, u, n, ktmp, gtmp)
         _lib.call("nlbac_dopri_norm_partials", ktmp.data_ptr(), ws.K[0].data_ptr(), y0.data_ptr(), None, None, 1,
                   rtol, atol, ns, nu, rpp, P, part.data_ptr(), s)
-        _lib.call("nlbac_dopri_control", part.data_ptr(), nblk, 1, ns, nu, rpp, P, t_end, ctl.data_ptr(), s)
+        self._control(part, nblk, 1, P, rpp, t_end, ctl)
 
         h_dev = ctl.data_ptr()                    # C_H
         steps, info = [], []
@@ -196,7 +211,7 @@ class AffineNodeSolver:
             y1 = ws.Y[6]
             _lib.call("nlbac_dopri_norm_partials", ws.err.data_ptr(), None, cur_y0.data_ptr(), y1.data_ptr(), None,
                       2, rtol, atol, ns, nu, rpp, P, part.data_ptr(), s)
-            _lib.call("nlbac_dopri_control", part.data_ptr(), nblk, 2, ns, nu, rpp, P, t_end, ctl.data_ptr(), s)
+            self._control(part, nblk, 2, P, rpp, t_end, ctl)
             c = ctl.cpu()                         # the one host sync per attempted step
             acc = [bool(c[p, 3] > 0) for p in range(P)]
             done = [bool(c[p, 4] > 0) for p in range(P)]

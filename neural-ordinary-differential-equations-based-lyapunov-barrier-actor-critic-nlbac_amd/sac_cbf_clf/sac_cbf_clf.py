@@ -176,7 +176,58 @@ class SAC_CBF_CLF(object):
         self._ws = {}
         self._noise = None
         self._fit_ws = {}
-        self.last_debug = {}
+        self.dp = None          # nlbac_amd.parallel.DataParallel when sharded over GPUs
+        self._xb = {}
+
+    # ------------------------------------------------------------ data parallel
+    def enable_data_parallel(self, dist, group=None):
+        """Shard minibatches over the ranks of ``dist`` (one process per GPU).  Every rank then passes its
+        own rows to ``update_*``; losses are normalised by the global batch (``args.batch_size`` must be
+        the global size) and gradients / constraint sums are all-reduced (nlbac_amd/parallel.py)."""
+        from ..parallel import DataParallel
+        self.dp = DataParallel(dist, group)
+        for ar in (self.ar_c, self.ar_a, self.ar_n):
+            self.dp.broadcast_(ar.theta)
+        self.ar_c.hard_update_target()
+        self.dp.broadcast_(self.sc)
+        self.repack_all()
+        self.node_solver.comm = self.dp
+        self.fit_solver.comm = self.dp
+        return self
+
+    @property
+    def world(self):
+        return self.dp.world if self.dp is not None else 1
+
+    def _exchange_buf(self, name, n):
+        if name not in self._xb:
+            self._xb[name] = torch.zeros(n, dtype=torch.float32, device=self.device)
+        return self._xb[name]
+
+    def _adam(self, arena, lr, n_slabs, extra=None, target=None, tau=-1.0, before_step=None):
+        """Adam on a whole arena.  One GPU: slab sum fused into the step.  Data parallel: local slab sum ->
+        flat buffer (+ ``extra`` scalars riding along) -> all-reduce -> step on the reduced gradient."""
+        s = stream_ptr()
+        a = arena
+        _lib.call("nlbac_adam_prepare", a.state.data_ptr(), lr, s)
+        if self.world == 1:
+            if before_step is not None:
+                before_step(a.grad.data_ptr())
+            _lib.call("nlbac_adam_step", a.theta.data_ptr(), a.m.data_ptr(), a.v.data_ptr(), a.grad.data_ptr(),
+                      n_slabs, a.n, a.n, a.state.data_ptr(), target, tau, s)
+            return
+        n_extra = 0 if extra is None else extra.numel()
+        xb = self._exchange_buf("g%d" % id(a), a.n + 4)
+        _lib.call("nlbac_reduce_slabs", xb.data_ptr(), a.grad.data_ptr(), n_slabs, a.n, a.n, s)
+        if n_extra:
+            xb[a.n:a.n + n_extra].copy_(extra)
+        self.dp.all_reduce_(xb)
+        if n_extra:
+            extra.copy_(xb[a.n:a.n + n_extra])
+        if before_step is not None:
+            before_step(xb.data_ptr())
+        _lib.call("nlbac_adam_step", a.theta.data_ptr(), a.m.data_ptr(), a.v.data_ptr(), xb.data_ptr(), 1, a.n, a.n,
+                  a.state.data_ptr(), target, tau, s)
 
     # ------------------------------------------------------------------ utils
     def repack_all(self):
@@ -294,22 +345,21 @@ class SAC_CBF_CLF(object):
         _lib.call("nlbac_unicycle_state", p_nobs, nobs_ld, N, self.l_p, w["nst"].data_ptr(), None, s)
         pred = self.fit_solver.forward(w["st"], action, 1, N, self.solver, self.env.dt, self.atol, self.rtol)
         nblk = (N + 255) // 256
-        _lib.call("nlbac_mse_fwd_bwd", pred.data_ptr(), 3, w["nst"].data_ptr(), 3, N, 3, w["dpred"].data_ptr(), 3,
+        NG = N * self.world
+        _lib.call("nlbac_mse_fwd_bwd", pred.data_ptr(), 3, w["nst"].data_ptr(), 3, N, NG, 3, w["dpred"].data_ptr(), 3,
                   w["part"].data_ptr(), s)
-        _lib.call("nlbac_sum_partials", w["part"].data_ptr(), nblk, 1, 1.0 / (N * 3),
+        _lib.call("nlbac_sum_partials", w["part"].data_ptr(), nblk, 1, 1.0 / (NG * 3),
                   self.sc.data_ptr() + 4 * SC.SC_NODE_LOSS, s)
         self.fit_solver.backward(w["dpred"], need_du=False, need_params=True)
         used = self.fit_solver.accumulate_param_grads(self.ar_n, self.n_grad_slabs)
-        a = self.ar_n
-        _lib.call("nlbac_adam_prepare", a.state.data_ptr(), 1e-3, s)
-        _lib.call("nlbac_adam_step", a.theta.data_ptr(), a.m.data_ptr(), a.v.data_ptr(), a.grad.data_ptr(), used,
-                  a.n, a.n, a.state.data_ptr(), None, -1.0, s)
+        self._adam(self.ar_n, 1e-3, used, extra=self.sc[SC.SC_NODE_LOSS:SC.SC_NODE_LOSS + 1])
         pack([self.h_f, self.h_g])
 
     # -- the update proper --------------------------------------------------------
     def update_on_device(self, ws, updates, sync=True):
         """Minibatch already in ``ws.mb``; returns the reference's 6 floats."""
         B, H = ws.B, self.hidden
+        G = B * self.world                      # rows the batch means run over
         s = stream_ptr()
         mb = ws.mb
         p_obs, p_act = mb.data_ptr(), mb.data_ptr() + 4 * 7
@@ -356,9 +406,9 @@ class SAC_CBF_CLF(object):
         q = ws.q6
         call("nlbac_td_targets", q[0].data_ptr(), q[1].data_ptr(), q[2].data_ptr(), ws.nlogp.data_ptr(),
              rew.data_ptr(), con.data_ptr(), mask.data_ptr(), q[3].data_ptr(), q[4].data_ptr(), q[5].data_ptr(),
-             sc + 4 * SC.SC_ALPHA, self.gamma, B, ws.dq3[0].data_ptr(), ws.dq3[1].data_ptr(), ws.dq3[2].data_ptr(),
+             sc + 4 * SC.SC_ALPHA, self.gamma, B, G, ws.dq3[0].data_ptr(), ws.dq3[1].data_ptr(), ws.dq3[2].data_ptr(),
              ws.next_q.data_ptr(), ws.next_l.data_ptr(), ws.part_td.data_ptr(), s)
-        call("nlbac_sum_partials", ws.part_td.data_ptr(), ws.nblk, 3, 1.0 / B, sc + 4 * SC.SC_QF1, s)
+        call("nlbac_sum_partials", ws.part_td.data_ptr(), ws.nblk, 3, 1.0 / G, sc + 4 * SC.SC_QF1, s)
 
         # ---- B. critic / Lyapunov backward + Adam (+ Polyak targets) ---------------
         io = io_array(3)
@@ -375,9 +425,8 @@ class SAC_CBF_CLF(object):
         a = self.ar_c
         bwd_weights(cnets, io, 3, B, a.n_slabs, a.n, self.device)
         soft = (updates % self.target_update_interval == 0)
-        call("nlbac_adam_prepare", a.state.data_ptr(), self.critic_lyapunov_lr, s)
-        call("nlbac_adam_step", a.theta.data_ptr(), a.m.data_ptr(), a.v.data_ptr(), a.grad.data_ptr(), a.n_slabs,
-             a.n, a.n, a.state.data_ptr(), a.target.data_ptr(), self.tau if soft else -1.0, s)
+        self._adam(a, self.critic_lyapunov_lr, a.n_slabs, extra=self.sc[SC.SC_QF1:SC.SC_QF1 + 3],
+                   target=a.target.data_ptr(), tau=self.tau if soft else -1.0)
         pack([self.h_q1, self.h_q2, self.h_l])
         if soft:
             pack([self.h_q1, self.h_q2, self.h_l], target=True)
@@ -408,7 +457,7 @@ class SAC_CBF_CLF(object):
         io[4].y, io[4].y_ld = ws.V.data_ptr(), 1
         call("nlbac_mlp_fwd", qnets, io, 5, B, s)
         call("nlbac_actor_q_terms", ws.qpi[0].data_ptr(), ws.qpi[1].data_ptr(), ws.logp2.data_ptr(),
-             sc + 4 * SC.SC_ALPHA, B, 2, ws.dq_pi[0].data_ptr(), ws.dq_pi[1].data_ptr(), ws.part_q.data_ptr(), s)
+             sc + 4 * SC.SC_ALPHA, B, G, 2, ws.dq_pi[0].data_ptr(), ws.dq_pi[1].data_ptr(), ws.part_q.data_ptr(), s)
 
         x_next2 = self.node_solver.forward(ws.y0_2, ws.pi2, 2, B, self.solver, dt, self.atol, self.rtol)
         call("nlbac_unicycle_lookahead", x_next2.data_ptr(), 2 * B, self.l_p, ws.ps_next2.data_ptr(), s)
@@ -425,7 +474,16 @@ class SAC_CBF_CLF(object):
              ws.Vn.data_ptr(), self.hazards.data_ptr(), self.num_cbfs, r_coll, dt, float(self.gamma_b), 1.0, B,
              ws.matr.data_ptr(), ws.bmatr.data_ptr(), ws.part_c.data_ptr(), s)
         lam_upd = 1 if updates % self.Lagrangian_multiplier_update_interval == 0 else 0
-        call("nlbac_auglag", ws.part_c.data_ptr(), ws.nblk, self.num_cbfs, 1, float(self.batch_size), lam_upd, 1, 1,
+        ncol = 2 * self.num_cbfs + 1
+        p_part_c, p_part_q, n_part = ws.part_c.data_ptr(), ws.part_q.data_ptr(), ws.nblk
+        if self.world > 1:      # global constraint / actor sums before anything nonlinear in them
+            xs = self._exchange_buf("sums", 64)
+            call("nlbac_sum_partials", ws.part_c.data_ptr(), ws.nblk, ncol, 1.0, xs.data_ptr(), s)
+            for pp in range(2):
+                call("nlbac_sum_partials", ws.part_q[pp].data_ptr(), ws.nblk, 2, 1.0, xs.data_ptr() + 4 * (32 + 2 * pp), s)
+            self.dp.all_reduce_(xs)
+            p_part_c, p_part_q, n_part = xs.data_ptr(), xs.data_ptr() + 4 * 32, 1
+        call("nlbac_auglag", p_part_c, n_part, self.num_cbfs, 1, float(self.batch_size), lam_upd, 1, 1,
              0.01, 400.0, sc, s)
         call("nlbac_unicycle_constraints_bwd", ws.ps_next2.data_ptr(), ws.matr.data_ptr(), ws.bmatr.data_ptr(),
              self.hazards.data_ptr(), self.num_cbfs, dt, float(self.batch_size), B, sc, ws.dps_next2.data_ptr(),
@@ -444,7 +502,7 @@ class SAC_CBF_CLF(object):
         call("nlbac_mlp_bwd_data", qnets, io, 4, B, s)
         call("nlbac_gauss_sample_bwd", ws.heads2.data_ptr(), 4, eps2.data_ptr(), pol.action_scale.data_ptr(), 2,
              2 * B, B, ws.dxq[0].data_ptr() + 4 * 7, 9, ws.dxq[1].data_ptr() + 4 * 7, 9, du2.data_ptr(), 2,
-             sc + 4 * SC.SC_ALPHA, 1.0 / B, ws.dheads2.data_ptr(), 4, s)
+             sc + 4 * SC.SC_ALPHA, 1.0 / G, ws.dheads2.data_ptr(), 4, s)
         io = io_array(2)
         a = self.ar_a
         for i in range(2):
@@ -455,14 +513,18 @@ class SAC_CBF_CLF(object):
         call("nlbac_mlp_bwd_data", pnets, io, 2, B, s)
         bwd_weights(pnets, io, 2, B, a.n_slabs, a.n, self.device)
         la = a.theta.data_ptr() + 4 * self.la_off
-        call("nlbac_actor_scalars", ws.part_q.data_ptr(), ws.nblk, B, 2, self.target_entropy, la, self.la_stride,
-             a.grad.data_ptr() + 4 * self.la_off, sc, s)
-        if not self.automatic_entropy_tuning:
-            a.grad[0, self.la_off] = 0.0
-            a.grad[0, self.la_off + self.la_stride] = 0.0
-        call("nlbac_adam_prepare", a.state.data_ptr(), self.lr, s)
-        call("nlbac_adam_step", a.theta.data_ptr(), a.m.data_ptr(), a.v.data_ptr(), a.grad.data_ptr(), a.n_slabs,
-             a.n, a.n, a.state.data_ptr(), None, -1.0, s)
+        tune = self.automatic_entropy_tuning
+
+        def alpha_grads(p_grad):
+            # policy_loss_1 / alpha losses from the (global) partial sums; d log_alpha goes straight into
+            # the gradient the Adam step reads (it is already a global mean: it must not be all-reduced)
+            call("nlbac_actor_scalars", p_part_q, n_part, G, 2, self.target_entropy, la, self.la_stride,
+                 p_grad + 4 * self.la_off, sc, s)
+            if not tune:
+                z = torch.zeros(1, device=self.device)
+                for off in (self.la_off, self.la_off + self.la_stride):
+                    call("nlbac_axpby", 0.0, z.data_ptr(), 0.0, None, 1, p_grad + 4 * off, s)
+        self._adam(a, self.lr, a.n_slabs, before_step=alpha_grads)
         pack([self.h_p, self.h_b])
         if self.automatic_entropy_tuning:
             call("nlbac_alpha_refresh", la, self.la_stride, 2, sc, s)

@@ -1,0 +1,95 @@
+"""Data-parallel path: world_size-2 runs (gloo, rendezvous on 127.0.0.1).
+
+CPU test: the DataParallel exchange layer reproduces full-batch gradients from row shards
+(global normalisation + SUM all-reduce), broadcasts parameters, and shards rows contiguously.
+GPU test: two ranks sharing the test box's one MI355X run the product agent on half of a
+golden-fixture minibatch each; every rank must land on the single-device reference outputs.
+"""
+import os
+import socket
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+import torch
+
+from common import load_golden, vec_close
+from nlbac_amd import synth
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+
+
+def free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    return port
+
+
+def launch(world, args, timeout=300):
+    port = free_port()
+    procs = []
+    for r in range(world):
+        env = dict(os.environ, RANK=str(r), WORLD_SIZE=str(world), LOCAL_RANK=str(r), MASTER_ADDR="127.0.0.1",
+                   MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY="0")
+        procs.append(subprocess.Popen([sys.executable, os.path.join(HERE, "dp_worker.py")] + args, env=env,
+                                      stdout=subprocess.PIPE, stderr=subprocess.STDOUT))
+    outs = []
+    for p in procs:
+        try:
+            o, _ = p.communicate(timeout=timeout)
+        except subprocess.TimeoutExpired:
+            for q in procs:
+                q.kill()
+            raise
+        outs.append(o.decode())
+    for r, p in enumerate(procs):
+        assert p.returncode == 0, "rank %d failed:\n%s" % (r, outs[r][-3000:])
+
+
+def test_exchange_layer_world2_cpu(tmp_path):
+    from oracle import nlbac_oracle as O
+    out = str(tmp_path / "dp")
+    launch(2, ["--device", "cpu", "--out", out])
+    r0, r1 = np.load(out + ".rank0.npz"), np.load(out + ".rank1.npz")
+    assert (int(r0["lo"]), int(r0["hi"]), int(r1["lo"]), int(r1["hi"])) == (0, 32, 32, 64)
+    np.testing.assert_array_equal(r0["flat"], r1["flat"])          # every rank holds the same reduced buffer
+    np.testing.assert_array_equal(r0["theta"], r1["theta"])        # broadcast from rank 0
+    # full-batch reference
+    B, hidden, seed = 64, 64, 3
+    W = synth.unicycle_agent_weights(hidden, seed)
+    tr = synth.unicycle_transitions(256, seed=5)
+    obs = torch.tensor(tr["obs"][:B], dtype=torch.float32)
+    act = torch.tensor(tr["action"][:B], dtype=torch.float32)
+    y = torch.tensor(tr["reward"][:B], dtype=torch.float32).unsqueeze(1)
+    crit = {k: torch.tensor(v, requires_grad=True) for k, v in W["critic"].items()}
+    q1, q2 = O.qnet(crit, obs, act)
+    loss = torch.nn.functional.mse_loss(q1, y) + torch.nn.functional.mse_loss(q2, y)
+    g = torch.cat([t.reshape(-1) for t in torch.autograd.grad(loss, list(crit.values()))])
+    vec_close(r0["flat"][:-1], g.numpy(), 1e-5, "sharded grads")
+    assert abs(float(r0["flat"][-1]) / float(loss) - 1) < 1e-5
+    np.testing.assert_array_equal(r0["theta"], np.concatenate([v.reshape(-1) for v in W["critic"].values()]))
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("solver", ["euler", "dopri5"])
+def test_two_rank_sharded_update_matches_single_device_reference(tmp_path, solver):
+    out = str(tmp_path / "dpgpu")
+    launch(2, ["--device", "cuda", "--out", out, "--solver", solver], timeout=600)
+    g = load_golden(solver, 128)
+    for r in range(2):
+        res = np.load(out + ".rank%d.npz" % r)
+        for ci in range(len(g["meta_calls"])):
+            p = "c%d_" % ci
+            vec_close(res[p + "ret"], g[p + "ret"], 1e-4, "rank %d %s ret" % (r, p))
+            vec_close(res[p + "required"], g[p + "required"], 1e-4, "rank %d %s required" % (r, p))
+            vec_close(res[p + "lambdas"], g[p + "lambdas"], 1e-4, "rank %d %s lambdas" % (r, p))
+            for name in ("critic", "policy", "node"):
+                v = res[p + "p_" + name]
+                assert abs(np.linalg.norm(v.astype(np.float64)) / float(g[p + "p_%s_norm" % name]) - 1) < 1e-5
+                vec_close(v[:48], g[p + "p_%s_head" % name], 1e-4, "rank %d %s params %s" % (r, p, name))
+    a, b = np.load(out + ".rank0.npz"), np.load(out + ".rank1.npz")
+    for k in a.files:                                            # replicas stay bit-identical
+        np.testing.assert_array_equal(a[k], b[k])
