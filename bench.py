@@ -169,6 +169,8 @@ def main():
     ap.add_argument("--batch", type=int, default=4096)
     ap.add_argument("--solver", default="dopri5", choices=["euler", "rk4", "dopri5"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--graphs", action="store_true",
+                    help="replay the update as hipGraphs (measured equal to eager launches once descriptors are cached)")
     ap.add_argument("--profile-steps", type=int, default=20)
     a = ap.parse_args()
 
@@ -187,6 +189,7 @@ def main():
     env = make_env("Unicycle", 0)
     agent = SAC_CBF_CLF(7, env.action_space, env, Args(B * world))   # global batch in the loss normalisation
     agent.solver = a.solver
+    agent.use_graphs = (world == 1) and a.graphs
     if world > 1:
         agent.enable_data_parallel(dist)
     dev = agent.device
@@ -230,11 +233,14 @@ def main():
 
     # ---- roofline of the dominant kernel: separate pass, HIP events around each MLP launch ----------
     roofline = None
-    if rank == 0:
+    if rank == 0 and a.profile_steps > 0:
+        graphs_on = agent.use_graphs
+        agent.use_graphs = False       # the event-timed pass launches the same kernels one by one
         with KernelTimer() as kt:
             for i in range(a.profile_steps):
                 step(a.warmup + a.steps + i)
             ks = kt.summary()
+        agent.use_graphs = graphs_on
         dom = max(ks, key=lambda k: ks[k]["ms"])
         kname = {"nlbac_mlp_fwd": "mlp_fwd_kernel", "nlbac_mlp_bwd_data": "mlp_bwd_data_kernel",
                  "nlbac_mlp_bwd_weights": "mlp_bwd_wide_kernel+mlp_bwd_skinny_kernel"}[dom]
@@ -263,7 +269,8 @@ def main():
                                    "updates; replay of %d synthetic transitions resident in HBM"
                                    % (B, a.solver, NODE_FIT_ROWS, NODE_FIT_INTERVAL, REPLAY_ROWS),
                        "solver": a.solver, "batch_per_gpu": B, "global_batch": B * world,
-                       "parallelism": "dp%d" % world, "last_losses": [float(x) for x in ret]},
+                       "parallelism": "dp%d" % world, "hipgraph": bool(agent.use_graphs),
+                       "rollout_solver_stats": dict(agent.node_solver.stats), "last_losses": [float(x) for x in ret]},
             "roofline": roofline, "cpu_baseline": cpu,
         }
         if cpu:

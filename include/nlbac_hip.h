@@ -132,11 +132,12 @@ int nlbac_gauss_sample_bwd(const float *heads, int heads_ld, const float *eps, c
 #define NLBAC_SC_SIZE 128
 
 /* TD / Lyapunov targets, MSE partial sums and dL/dq (sac_cbf_clf.py:231-246).
- * All q-like arguments are (B) vectors; alpha = sc+SC_ALPHA.  Means are over B_norm rows
+ * All q-like arguments are (B) vectors; reward/constraint/mask are read with stride rcm_ld (columns of
+ * the minibatch rows); alpha = sc+SC_ALPHA.  Means are over B_norm rows
  * (= B on one GPU, the global batch under data parallelism; the same holds for every *_norm below).
  * partials: [ceil(B/256)][3] squared-error sums (qf1, qf2, lf). */
 int nlbac_td_targets(const float *q1t, const float *q2t, const float *lt, const float *nlogp,
-                     const float *reward, const float *constraint, const float *mask,
+                     const float *reward, const float *constraint, const float *mask, int rcm_ld,
                      const float *q1, const float *q2, const float *lf, const float *alpha,
                      float gamma, int B, int B_norm, float *dq1, float *dq2, float *dlf, float *next_q,
                      float *next_l, float *partials, nlbac_stream_t s);
@@ -217,12 +218,13 @@ int nlbac_dopri_norm_partials(const float *a, const float *b, const float *y0, c
 int nlbac_dopri_control(const float *partials, int n_blk_per_problem, int mode, int n_s, int n_u,
                         int rows_per_problem, int P, double t_end, double *ctl, nlbac_stream_t s);
 /* y(t_end) from the accepted step's stages (4th-order interpolant, x=(t_end-t)/h) and its backward
- * (writes dy0, dy1, dK[0..6]). */
+ * (writes dy0, dy1, dK[0..6]).  h and x come from the device control block `ctl` (h_used, x) when it is
+ * non-NULL — hipGraph-replay safe — else from the host arrays. */
 int nlbac_dopri_interp_fwd(const float *y0, const float *y1, const float *K, const float *h_host,
-                           const float *x_host, int P, int rows_per_problem, int n_s, float *out,
-                           nlbac_stream_t s);
-int nlbac_dopri_interp_bwd(const float *dout, const float *h_host, const float *x_host, int P,
-                           int rows_per_problem, int n_s, float *dy0, float *dy1, float *dK,
+                           const float *x_host, const double *ctl, int P, int rows_per_problem, int n_s,
+                           float *out, nlbac_stream_t s);
+int nlbac_dopri_interp_bwd(const float *dout, const float *h_host, const float *x_host, const double *ctl,
+                           int P, int rows_per_problem, int n_s, float *dy0, float *dy1, float *dK,
                            nlbac_stream_t s);
 
 /* small utilities */

@@ -62,7 +62,7 @@ _PROTOS = {
     "nlbac_soft_update": [_P, _P, _L, _F, _P],
     "nlbac_gauss_sample_fwd": [_P, _I, _P, _P, _P, _I, _I, _P, _I, _P, _P],
     "nlbac_gauss_sample_bwd": [_P, _I, _P, _P, _I, _I, _I, _P, _I, _P, _I, _P, _I, _P, _F, _P, _I, _P],
-    "nlbac_td_targets": [_P] * 11 + [_F, _I, _I] + [_P] * 6 + [_P],
+    "nlbac_td_targets": [_P] * 7 + [_I] + [_P] * 4 + [_F, _I, _I] + [_P] * 6 + [_P],
     "nlbac_actor_q_terms": [_P, _P, _P, _P, _I, _I, _I, _P, _P, _P, _P],
     "nlbac_actor_scalars": [_P, _I, _I, _I, _F, _P, _I, _P, _P, _P],
     "nlbac_alpha_refresh": [_P, _I, _I, _P, _P],
@@ -79,8 +79,8 @@ _PROTOS = {
     "nlbac_rk_stage_bwd": [_P, _P, _P, _I, _I, c_float_p, c_float_p, _P, _I, _I, _I, _I, _P, _P, _I, _P],
     "nlbac_dopri_norm_partials": [_P, _P, _P, _P, _P, _I, _F, _F, _I, _I, _I, _I, _P, _P],
     "nlbac_dopri_control": [_P, _I, _I, _I, _I, _I, _I, _D, _P, _P],
-    "nlbac_dopri_interp_fwd": [_P, _P, _P, c_float_p, c_float_p, _I, _I, _I, _P, _P],
-    "nlbac_dopri_interp_bwd": [_P, c_float_p, c_float_p, _I, _I, _I, _P, _P, _P, _P],
+    "nlbac_dopri_interp_fwd": [_P, _P, _P, c_float_p, c_float_p, _P, _I, _I, _I, _P, _P],
+    "nlbac_dopri_interp_bwd": [_P, c_float_p, c_float_p, _P, _I, _I, _I, _P, _P, _P, _P],
     "nlbac_axpby": [_F, _P, _F, _P, _L, _P, _P],
     "nlbac_fill": [_P, _F, _L, _P],
     "nlbac_sum_partials": [_P, _I, _I, _F, _P, _P],

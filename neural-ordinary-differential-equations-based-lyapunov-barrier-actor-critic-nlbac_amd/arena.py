@@ -151,10 +151,21 @@ def stream_ptr():
 
 
 def pack(handles, target=False):
-    descs = [h.desc_target if target else h.desc for h in handles]
-    for i in range(0, len(descs), _lib.MAX_NETS):
-        chunk = descs[i:i + _lib.MAX_NETS]
-        _lib.call("nlbac_mlp_pack", mlp_array(chunk), len(chunk), stream_ptr())
+    # descriptor arrays are cached on the first handle (they die with it; a global cache keyed by id()
+    # would hand stale pointers to a new net that happens to reuse a freed object's id)
+    cache = handles[0].__dict__.setdefault("_pack_cache", {})
+    key = (tuple(id(h) for h in handles), target)
+    arrs = cache.get(key)
+    if arrs is None:
+        descs = [h.desc_target if target else h.desc for h in handles]
+        arrs = [(mlp_array(descs[i:i + _lib.MAX_NETS]), len(descs[i:i + _lib.MAX_NETS]))
+                for i in range(0, len(descs), _lib.MAX_NETS)]
+        cache[key] = (arrs, list(handles))       # keep the other handles alive as long as the entry exists
+    else:
+        arrs = arrs[0]
+    s = stream_ptr()
+    for arr, n in arrs:
+        _lib.call("nlbac_mlp_pack", arr, n, s)
 
 
 _BW_WS = {}

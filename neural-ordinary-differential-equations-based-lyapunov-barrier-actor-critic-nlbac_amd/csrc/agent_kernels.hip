@@ -85,7 +85,7 @@ __global__ __launch_bounds__(256) void gauss_bwd_kernel(const float* heads, int 
 // ---------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void td_targets_kernel(const float* q1t, const float* q2t, const float* lt,
                                                          const float* nlogp, const float* reward,
-                                                         const float* constraint, const float* mask,
+                                                         const float* constraint, const float* mask, int rcm_ld,
                                                          const float* q1, const float* q2, const float* lf,
                                                          const float* alpha, float gamma, int B, int B_norm,
                                                          float* dq1, float* dq2, float* dlf, float* next_q,
@@ -96,8 +96,9 @@ __global__ __launch_bounds__(256) void td_targets_kernel(const float* q1t, const
     if (i < B) {
         const float a = alpha[0];
         const float mq = fminf(q1t[i], q2t[i]) - a * nlogp[i];
-        const float yq = reward[i] + mask[i] * gamma * mq;
-        const float yl = constraint[i] + mask[i] * gamma * lt[i];
+        const float mk = mask[(long)i * rcm_ld];
+        const float yq = reward[(long)i * rcm_ld] + mk * gamma * mq;
+        const float yl = constraint[(long)i * rcm_ld] + mk * gamma * lt[i];
         const float norm = (float)(2.0 / (double)B_norm);
         const float e1 = q1[i] - yq, e2 = q2[i] - yq, e3 = lf[i] - yl;
         dq1[i] = norm * e1; dq2[i] = norm * e2; dlf[i] = norm * e3;
@@ -398,13 +399,13 @@ extern "C" int nlbac_gauss_sample_bwd(const float* heads, int heads_ld, const fl
 }
 
 extern "C" int nlbac_td_targets(const float* q1t, const float* q2t, const float* lt, const float* nlogp,
-                                const float* reward, const float* constraint, const float* mask,
+                                const float* reward, const float* constraint, const float* mask, int rcm_ld,
                                 const float* q1, const float* q2, const float* lf, const float* alpha,
                                 float gamma, int B, int B_norm, float* dq1, float* dq2, float* dlf, float* next_q,
                                 float* next_l, float* partials, nlbac_stream_t s) {
     NLBAC_REQUIRE(q1t && q2t && lt && nlogp && reward && constraint && mask && q1 && q2 && lf && alpha && dq1 &&
                       dq2 && dlf && partials, "nlbac_td_targets: null pointer");
-    hipLaunchKernelGGL(td_targets_kernel, GRID1(B), q1t, q2t, lt, nlogp, reward, constraint, mask, q1, q2, lf,
+    hipLaunchKernelGGL(td_targets_kernel, GRID1(B), q1t, q2t, lt, nlogp, reward, constraint, mask, rcm_ld, q1, q2, lf,
                        alpha, gamma, B, B_norm, dq1, dq2, dlf, next_q, next_l, partials);
     NLBAC_CHECK_LAUNCH("nlbac_td_targets");
     return 0;

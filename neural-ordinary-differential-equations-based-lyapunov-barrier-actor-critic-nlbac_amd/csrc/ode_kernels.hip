@@ -188,7 +188,18 @@ __global__ void dopri_control_kernel(const float* partials, int nblk, int mode, 
 #define DPM5 (-1776094331.0 / 19743644256.0 / 2.0)
 #define DPM6 (11237099.0 / 235043384.0 / 2.0)
 
-struct InterpArg { float h[MAX_PROBLEMS]; float x[MAX_PROBLEMS]; };
+struct InterpArg { float h[MAX_PROBLEMS]; float x[MAX_PROBLEMS]; const double* ctl; };
+
+// step size / interpolation abscissa of problem p: from the device control block when given
+// (so a captured hipGraph replays with the current values), else by value
+__device__ __forceinline__ void interp_hx(const InterpArg& ia, int p, float& h, float& x) {
+    if (ia.ctl) {
+        h = (float)ia.ctl[(long)p * NLBAC_DOPRI_CTL + C_HUSED];
+        x = (float)ia.ctl[(long)p * NLBAC_DOPRI_CTL + C_X];
+    } else {
+        h = ia.h[p]; x = ia.x[p];
+    }
+}
 
 // y(t_end) = y0 + x(d + x(c + x(b + x a)))   (K: [7][n][n_s])
 __global__ __launch_bounds__(256) void dopri_interp_fwd_kernel(const float* y0, const float* y1, const float* K,
@@ -196,7 +207,8 @@ __global__ __launch_bounds__(256) void dopri_interp_fwd_kernel(const float* y0, 
                                                                float* out) {
     const int i = blockIdx.x * 256 + threadIdx.x;
     if (i >= n) return;
-    const float h = ia.h[i / rpp], x = ia.x[i / rpp];
+    float h, x;
+    interp_hx(ia, i / rpp, h, x);
     const float cm[7] = {(float)DPM0, 0.f, (float)DPM2, (float)DPM3, (float)DPM4, (float)DPM5, (float)DPM6};
     for (int r = 0; r < n_s; ++r) {
         const float a0 = y0[(long)i * n_s + r], a1 = y1[(long)i * n_s + r];
@@ -218,7 +230,8 @@ __global__ __launch_bounds__(256) void dopri_interp_bwd_kernel(const float* dout
                                                                int n_s, int n, float* dy0, float* dy1, float* dK) {
     const int i = blockIdx.x * 256 + threadIdx.x;
     if (i >= n) return;
-    const float h = ia.h[i / rpp], x = ia.x[i / rpp];
+    float h, x;
+    interp_hx(ia, i / rpp, h, x);
     const float cm[7] = {(float)DPM0, 0.f, (float)DPM2, (float)DPM3, (float)DPM4, (float)DPM5, (float)DPM6};
     const float x2 = x * x, x3 = x2 * x, x4 = x2 * x2;
     for (int r = 0; r < n_s; ++r) {
@@ -314,31 +327,34 @@ extern "C" int nlbac_dopri_control(const float* partials, int n_blk_per_problem,
     return 0;
 }
 
-static int fill_ia(InterpArg& ia, const float* h_host, const float* x_host, int P, const char* who) {
-    NLBAC_REQUIRE(h_host && x_host && P >= 1 && P <= MAX_PROBLEMS, "%s: bad arguments", who);
+static int fill_ia(InterpArg& ia, const float* h_host, const float* x_host, const double* ctl, int P,
+                   const char* who) {
+    NLBAC_REQUIRE(((h_host && x_host) || ctl) && P >= 1 && P <= MAX_PROBLEMS, "%s: bad arguments", who);
     memset(&ia, 0, sizeof(ia));
-    for (int p = 0; p < P; ++p) { ia.h[p] = h_host[p]; ia.x[p] = x_host[p]; }
+    ia.ctl = ctl;
+    if (!ctl)
+        for (int p = 0; p < P; ++p) { ia.h[p] = h_host[p]; ia.x[p] = x_host[p]; }
     return 0;
 }
 
 extern "C" int nlbac_dopri_interp_fwd(const float* y0, const float* y1, const float* K, const float* h_host,
-                                      const float* x_host, int P, int rows_per_problem, int n_s, float* out,
-                                      nlbac_stream_t s) {
+                                      const float* x_host, const double* ctl, int P, int rows_per_problem, int n_s,
+                                      float* out, nlbac_stream_t s) {
     InterpArg ia;
     NLBAC_REQUIRE(y0 && y1 && K && out, "nlbac_dopri_interp_fwd: null pointer");
-    if (fill_ia(ia, h_host, x_host, P, "nlbac_dopri_interp_fwd")) return -1;
+    if (fill_ia(ia, h_host, x_host, ctl, P, "nlbac_dopri_interp_fwd")) return -1;
     const int n = P * rows_per_problem;
     hipLaunchKernelGGL(dopri_interp_fwd_kernel, GRID1(n), y0, y1, K, ia, rows_per_problem, n_s, n, out);
     NLBAC_CHECK_LAUNCH("nlbac_dopri_interp_fwd");
     return 0;
 }
 
-extern "C" int nlbac_dopri_interp_bwd(const float* dout, const float* h_host, const float* x_host, int P,
-                                      int rows_per_problem, int n_s, float* dy0, float* dy1, float* dK,
-                                      nlbac_stream_t s) {
+extern "C" int nlbac_dopri_interp_bwd(const float* dout, const float* h_host, const float* x_host,
+                                      const double* ctl, int P, int rows_per_problem, int n_s, float* dy0,
+                                      float* dy1, float* dK, nlbac_stream_t s) {
     InterpArg ia;
     NLBAC_REQUIRE(dout && dy0 && dy1 && dK, "nlbac_dopri_interp_bwd: null pointer");
-    if (fill_ia(ia, h_host, x_host, P, "nlbac_dopri_interp_bwd")) return -1;
+    if (fill_ia(ia, h_host, x_host, ctl, P, "nlbac_dopri_interp_bwd")) return -1;
     const int n = P * rows_per_problem;
     hipLaunchKernelGGL(dopri_interp_bwd_kernel, GRID1(n), dout, ia, rows_per_problem, n_s, n, dy0, dy1, dK);
     NLBAC_CHECK_LAUNCH("nlbac_dopri_interp_bwd");

@@ -59,6 +59,7 @@ class _StepWS:
         self.y1 = z(n, ns)
         self.err = z(n, ns)
         self._bwd = None
+        self.io_fwd, self.io_bwd = {}, {}
 
     def bwd(self, solver):
         if self._bwd is None:
@@ -87,6 +88,10 @@ class AffineNodeSolver:
         self._ws = {}          # (n, S, idx) -> _StepWS
         self._scratch = {}
         self.nfe = 0
+        self._net_arr = None
+        self._coefs = {}
+        self._children = {}    # per-problem solvers for batches whose problems diverge (dopri5)
+        self.stats = dict(solves=0, single_step=0, multi_attempt=0, split=0)
         self.comm = None       # nlbac_amd.parallel.DataParallel: global dopri5 error norms
 
     # -- workspace -----------------------------------------------------------
@@ -103,26 +108,40 @@ class AffineNodeSolver:
         return self._scratch[key]
 
     # -- one field evaluation k = f(x) + g(x) u -----------------------------------
-    def _eval(self, x, u, n, k_out, g_out, acts_f=None, acts_g=None, ls_f=0, ls_g=0):
+    def _nets(self):
+        if self._net_arr is None:
+            self._net_arr = mlp_array([self.f.desc, self.g.desc])
+        return self._net_arr
+
+    def _eval_io(self, x, g_out, acts_f=None, acts_g=None, ls_f=0, ls_g=0):
         io = io_array(2)
         ns, nu = self.n_s, self.n_u
-        fout = self._buf("fout", n, ns)
+        fout = self._buf("fout", x.shape[0], ns)
         for i, (y, ld, acts, ls) in enumerate(((fout, ns, acts_f, ls_f), (g_out, ns * nu, acts_g, ls_g))):
             io[i].x0, io[i].x0_dim, io[i].x0_ld = x.data_ptr(), ns, ns
             io[i].y, io[i].y_ld = y.data_ptr(), ld
             if acts is not None:
                 io[i].acts, io[i].acts_ls = acts.data_ptr(), ls
+        return io, fout
+
+    def _eval(self, x, u, n, k_out, g_out, io=None):
+        if io is None:
+            io = self._eval_io(x, g_out)
+        io, fout = io
         s = stream_ptr()
-        _lib.call("nlbac_mlp_fwd", mlp_array([self.f.desc, self.g.desc]), io, 2, n, s)
-        _lib.call("nlbac_affine_combine_fwd", fout.data_ptr(), g_out.data_ptr(), u.data_ptr(), ns, nu, n,
+        _lib.call("nlbac_mlp_fwd", self._nets(), io, 2, n, s)
+        _lib.call("nlbac_affine_combine_fwd", fout.data_ptr(), g_out.data_ptr(), u.data_ptr(), self.n_s, self.n_u, n,
                   k_out.data_ptr(), s)
         self.nfe += 1
 
     def _stage_eval(self, ws, st, u):
         n, S = ws.n, ws.S
-        f, g = self.f, self.g
-        self._eval(ws.Y[st], u, n, ws.K[st], ws.gout[st],
-                   ws.acts_f[:, st * n:], ws.acts_g[:, st * n:], S * n * f.hid, S * n * g.hid)
+        io = ws.io_fwd.get(st)
+        if io is None:       # pointers are static per (workspace, stage): build the descriptors once
+            f, g = self.f, self.g
+            io = ws.io_fwd[st] = self._eval_io(ws.Y[st], ws.gout[st], ws.acts_f[:, st * n:], ws.acts_g[:, st * n:],
+                                               S * n * f.hid, S * n * g.hid)
+        self._eval(ws.Y[st], u, n, ws.K[st], ws.gout[st], io)
 
     def _combine(self, y0, K, n_k, coef, h, P, rpp, out):
         _lib.call("nlbac_rk_combine", y0.data_ptr() if y0 is not None else None, K.data_ptr(), n_k,
@@ -132,9 +151,17 @@ class AffineNodeSolver:
     def forward(self, y0, u, P, rpp, method, dt, atol=1e-7, rtol=1e-5):
         """y0: (P*rpp, n_s), u: (P*rpp, n_u) contiguous device tensors.
         Returns x(dt) (P*rpp, n_s) (a solver-owned buffer, valid until the next call)."""
+        self.forward_begin(y0, u, P, rpp, method, dt, atol, rtol)
+        return self.forward_finish()
+
+    def forward_begin(self, y0, u, P, rpp, method, dt, atol=1e-7, rtol=1e-5):
+        """Enqueue everything up to the first point where the host has to look at a result (dopri5: the
+        accept/reject decision of the first attempted step); euler/rk4 run to completion.  No host sync."""
         n = P * rpp
         assert y0.shape == (n, self.n_s) and u.shape == (n, self.n_u)
-        self.ctx = dict(method=method, P=P, rpp=rpp, n=n, u=u, y0=y0, steps=[])
+        self.stats["solves"] += 1
+        self.ctx = dict(method=method, P=P, rpp=rpp, n=n, u=u, y0=y0, steps=[], t_end=float(dt), atol=atol,
+                        rtol=rtol)
         if method in ("euler", "rk4"):
             tab = TABLEAU[method]
             S = len(tab["c_sol"])
@@ -148,10 +175,29 @@ class AffineNodeSolver:
             self._combine(y0, ws.K, S, tab["c_sol"], h, P, rpp, ws.y1)
             self.ctx["steps"].append(dict(ws=ws, h=h, first=True))
             self.ctx["out"] = ws.y1
-            return ws.y1
-        if method == "dopri5":
-            return self._forward_dopri5(y0, u, P, rpp, float(dt), atol, rtol)
-        raise ValueError("unknown solver %r" % (method,))
+        elif method == "dopri5":
+            self._dopri_begin(y0, u, P, rpp)
+        else:
+            raise ValueError("unknown solver %r" % (method,))
+
+    def forward_finish(self, assume_single_step=False):
+        """Complete the solve and return x(dt).  dopri5: reads the 128-byte/problem control block (one host
+        sync) and continues with further attempts if the first step was rejected or stopped short of dt.
+        ``assume_single_step``: skip the read (the caller has already checked ``first_step_done``) — this
+        variant enqueues only device work with device-resident step size, so it can be hipGraph-captured."""
+        if self.ctx["method"] != "dopri5":
+            return self.ctx["out"]
+        if assume_single_step:
+            return self._dopri_accept_first(None)
+        return self._dopri_continue()
+
+    def first_step_done(self):
+        """dopri5, after forward_begin: True iff every problem accepted its first step and reached dt
+        (the overwhelmingly common case at dt=0.02).  One small D2H read."""
+        P = self.ctx["P"]
+        c = self._ctl(P).cpu()
+        self.ctx["ctl_host"] = c
+        return all(bool(c[p, 3] > 0) and bool(c[p, 4] > 0) for p in range(P))
 
     def _ctl(self, P):
         return self._buf("ctl", P, _lib.DOPRI_CTL, dtype=torch.float64)
@@ -170,13 +216,41 @@ class AffineNodeSolver:
         else:
             _lib.call("nlbac_dopri_control", part.data_ptr(), nblk, mode, ns, nu, rpp, P, t_end, ctl.data_ptr(), s)
 
-    def _forward_dopri5(self, y0, u, P, rpp, t_end, atol, rtol):
+    def _dopri_attempt(self, ws, cur_y0, u, P, rpp):
+        """Stages 1..6 of one attempted step, error estimate, norm and controller (all on the device)."""
+        ns, nu, S = self.n_s, self.n_u, 7
+        s = stream_ptr()
+        ctx = self.ctx
+        nblk = (rpp + 255) // 256
+        part = self._buf("part", P, nblk, 2)
+        ctl = self._ctl(P)
+        h_dev = ctl.data_ptr()                    # C_H
+        for st in range(1, S):
+            _lib.call("nlbac_rk_combine", cur_y0.data_ptr(), ws.K.data_ptr(), st, self._coef(("b", st)), None,
+                      h_dev, _lib.DOPRI_CTL, P, rpp, ns, ws.Y[st].data_ptr(), s)
+            self._stage_eval(ws, st, u)
+        _lib.call("nlbac_rk_combine", None, ws.K.data_ptr(), S, self._coef("err"), None, h_dev, _lib.DOPRI_CTL,
+                  P, rpp, ns, ws.err.data_ptr(), s)
+        _lib.call("nlbac_dopri_norm_partials", ws.err.data_ptr(), None, cur_y0.data_ptr(), ws.Y[6].data_ptr(), None,
+                  2, ctx["rtol"], ctx["atol"], ns, nu, rpp, P, part.data_ptr(), s)
+        self._control(part, nblk, 2, P, rpp, ctx["t_end"], ctl)
+
+    def _coef(self, key):
+        c = self._coefs.get(key)
+        if c is None:
+            vals = DP_C_ERR if key == "err" else ([1.0] if key == "one" else DP_BETA[key[1] - 1])
+            c = self._coefs[key] = fptr(*vals)
+        return c
+
+    def _dopri_begin(self, y0, u, P, rpp):
         n, ns, nu, S = P * rpp, self.n_s, self.n_u, 7
+        ctx = self.ctx
         s = stream_ptr()
         nblk = (rpp + 255) // 256
         part = self._buf("part", P, nblk, 2)
         ctl = self._ctl(P)
         ws = self._step_ws(n, S, 0)
+        rtol, atol, t_end = ctx["rtol"], ctx["atol"], ctx["t_end"]
         # f0 and the initial step size (Hairer's rule)
         ws.Y[0].copy_(y0)
         self._stage_eval(ws, 0, u)
@@ -185,54 +259,103 @@ class AffineNodeSolver:
         self._control(part, nblk, 0, P, rpp, t_end, ctl)
         ytmp, ktmp, gtmp = self._buf("ytmp", n, ns), self._buf("ktmp", n, ns), self._buf("gtmp", n, ns * nu)
         h0_dev = ctl.data_ptr() + 6 * 8           # C_H0
-        _lib.call("nlbac_rk_combine", y0.data_ptr(), ws.K.data_ptr(), 1, fptr(1.0), None, h0_dev, _lib.DOPRI_CTL,
-                  P, rpp, ns, ytmp.data_ptr(), s)
-        self._eval(ytmp, u, n, ktmp, gtmp)
+        _lib.call("nlbac_rk_combine", y0.data_ptr(), ws.K.data_ptr(), 1, self._coef("one"), None, h0_dev,
+                  _lib.DOPRI_CTL, P, rpp, ns, ytmp.data_ptr(), s)
+        if "tmp_io" not in self._scratch:
+            self._scratch["tmp_io"] = {}
+        tio = self._scratch["tmp_io"].get(n)
+        if tio is None:
+            tio = self._scratch["tmp_io"][n] = self._eval_io(ytmp, gtmp)
+        self._eval(ytmp, u, n, ktmp, gtmp, tio)
         _lib.call("nlbac_dopri_norm_partials", ktmp.data_ptr(), ws.K[0].data_ptr(), y0.data_ptr(), None, None, 1,
                   rtol, atol, ns, nu, rpp, P, part.data_ptr(), s)
         self._control(part, nblk, 1, P, rpp, t_end, ctl)
+        self._dopri_attempt(ws, y0, u, P, rpp)
 
-        h_dev = ctl.data_ptr()                    # C_H
+    def _dopri_accept_first(self, c):
+        """First step accepted and past dt: interpolate.  Step size and abscissa are read from the device
+        control block by the kernels (identical arithmetic with or without a host copy of them)."""
+        ctx = self.ctx
+        self.stats["single_step"] += 1
+        P, rpp, n, ns = ctx["P"], ctx["rpp"], ctx["n"], self.n_s
+        ws = self._step_ws(n, 7, 0)
+        ctl = self._ctl(P)
+        ws.y1.copy_(ws.Y[6])
+        out = self._buf("dopri_out", n, ns)
+        _lib.call("nlbac_dopri_interp_fwd", ctx["y0"].data_ptr(), ws.y1.data_ptr(), ws.K.data_ptr(), None, None,
+                  ctl.data_ptr(), P, rpp, ns, out.data_ptr(), stream_ptr())
+        step = dict(ws=ws, first=True, dev=True)
+        if c is not None:
+            step["h"] = [float(c[p, 11]) for p in range(P)]
+            step["x"] = [float(c[p, 5]) for p in range(P)]
+            ctx["info"] = [[(float(c[p, 11]), float(c[p, 2]), True) for p in range(P)]]
+        ctx.update(steps=[step], out=out)
+        return out
+
+    def _dopri_continue(self):
+        ctx = self.ctx
+        P, rpp, n, u, y0 = ctx["P"], ctx["rpp"], ctx["n"], ctx["u"], ctx["y0"]
+        ns, S = self.n_s, 7
+        s = stream_ptr()
+        ctl = self._ctl(P)
         steps, info = [], []
         cur_y0, idx = y0, 0
+        ws = self._step_ws(n, S, 0)
         for attempt in range(1000):
-            ws = self._step_ws(n, S, idx)
-            if idx > 0 and not steps[-1].get("linked"):
-                prev = steps[-1]["ws"]
-                ws.Y[0].copy_(prev.y1)
-                ws.K[0].copy_(prev.K[6])          # FSAL
-                steps[-1]["linked"] = True
-            for st in range(1, S):
-                _lib.call("nlbac_rk_combine", cur_y0.data_ptr(), ws.K.data_ptr(), st, fptr(*DP_BETA[st - 1]), None,
-                          h_dev, _lib.DOPRI_CTL, P, rpp, ns, ws.Y[st].data_ptr(), s)
-                self._stage_eval(ws, st, u)
-            _lib.call("nlbac_rk_combine", None, ws.K.data_ptr(), S, fptr(*DP_C_ERR), None, h_dev, _lib.DOPRI_CTL,
-                      P, rpp, ns, ws.err.data_ptr(), s)
-            y1 = ws.Y[6]
-            _lib.call("nlbac_dopri_norm_partials", ws.err.data_ptr(), None, cur_y0.data_ptr(), y1.data_ptr(), None,
-                      2, rtol, atol, ns, nu, rpp, P, part.data_ptr(), s)
-            self._control(part, nblk, 2, P, rpp, t_end, ctl)
-            c = ctl.cpu()                         # the one host sync per attempted step
+            c = ctx.pop("ctl_host", None)
+            if c is None:
+                c = ctl.cpu()                     # the one host sync per attempted step
             acc = [bool(c[p, 3] > 0) for p in range(P)]
             done = [bool(c[p, 4] > 0) for p in range(P)]
-            info.append([(float(c[p, 11]), float(c[p, 2]), acc[p]) for p in range(P)])
             if any(a != acc[0] for a in acc) or any(d != done[0] for d in done):
-                raise _lib.NlbacError("dopri5: problems in one batch took different accept/finish decisions; "
-                                      "solve them in separate calls (P=1)")
+                return self._solve_split()
+            if attempt == 0 and acc[0] and done[0]:
+                return self._dopri_accept_first(c)
+            info.append([(float(c[p, 11]), float(c[p, 2]), acc[p]) for p in range(P)])
+            if attempt == 0:
+                self.stats["multi_attempt"] += 1
             if acc[0]:
-                ws.y1.copy_(y1)
+                ws.y1.copy_(ws.Y[6])
                 steps.append(dict(ws=ws, h=[float(c[p, 11]) for p in range(P)], first=(idx == 0)))
                 if done[0]:
                     x = [float(c[p, 5]) for p in range(P)]
                     steps[-1]["x"] = x
                     out = self._buf("dopri_out", n, ns)
                     _lib.call("nlbac_dopri_interp_fwd", cur_y0.data_ptr(), ws.y1.data_ptr(), ws.K.data_ptr(),
-                              fptr(*steps[-1]["h"]), fptr(*x), P, rpp, ns, out.data_ptr(), s)
-                    self.ctx.update(steps=steps, out=out, info=info)
+                              fptr(*steps[-1]["h"]), fptr(*x), None, P, rpp, ns, out.data_ptr(), s)
+                    ctx.update(steps=steps, out=out, info=info)
                     return out
                 cur_y0 = ws.y1
                 idx += 1
+                prev = ws
+                ws = self._step_ws(n, S, idx)
+                ws.Y[0].copy_(prev.y1)
+                ws.K[0].copy_(prev.K[6])          # FSAL
+            self._dopri_attempt(ws, cur_y0, u, P, rpp)
         raise _lib.NlbacError("dopri5: max_num_steps exceeded")
+
+    def _solve_split(self):
+        """The problems of one batch want different step sequences (one accepted / finished, another not):
+        each has its own adaptive step size in the reference too (separate odeint calls), so redo the solve
+        problem by problem with child solvers on the row ranges."""
+        ctx = self.ctx
+        self.stats["split"] += 1
+        P, rpp, n = ctx["P"], ctx["rpp"], ctx["n"]
+        out = self._buf("dopri_out", n, self.n_s)
+        kids, info = [], []
+        for p in range(P):
+            if p not in self._children:
+                self._children[p] = AffineNodeSolver(self.node, self.device)
+            k = self._children[p]
+            k.comm = self.comm
+            rows = slice(p * rpp, (p + 1) * rpp)
+            o = k.forward(ctx["y0"][rows], ctx["u"][rows], 1, rpp, "dopri5", ctx["t_end"], ctx["atol"], ctx["rtol"])
+            out[rows].copy_(o)
+            kids.append(k)
+            info.append(k.ctx.get("info"))
+        ctx.update(split=kids, out=out, steps=[], info_split=info)
+        ctx.pop("info", None)
+        return out
 
     # -- backward --------------------------------------------------------------
     def backward(self, dout, need_du=True, need_params=False, need_dy0=False):
@@ -240,6 +363,19 @@ class AffineNodeSolver:
         ``need_params`` the pre-activation grads of every stage are kept for
         ``accumulate_param_grads``."""
         ctx = self.ctx
+        if ctx.get("split"):
+            assert not need_params, "parameter gradients are only taken on single-problem solves"
+            rpp = ctx["rpp"]
+            du = self._buf("du", ctx["n"], self.n_u) if need_du else None
+            dy0 = self._buf("dy0_split", ctx["n"], self.n_s) if need_dy0 else None
+            for p, k in enumerate(ctx["split"]):
+                rows = slice(p * rpp, (p + 1) * rpp)
+                du_p, dy0_p = k.backward(dout[rows], need_du=need_du, need_dy0=need_dy0)
+                if du is not None:
+                    du[rows].copy_(du_p)
+                if dy0 is not None:
+                    dy0[rows].copy_(dy0_p)
+            return du, dy0
         P, rpp, n, u, method = ctx["P"], ctx["rpp"], ctx["n"], ctx["u"], ctx["method"]
         ns, nu = self.n_s, self.n_u
         s = stream_ptr()
@@ -252,13 +388,18 @@ class AffineNodeSolver:
         for si in range(len(steps) - 1, -1, -1):
             step = steps[si]
             ws = step["ws"].bwd(self)
-            S, h = ws.S, step["h"]
+            S = ws.S
+            dev = step.get("dev", False)       # step size lives in the device control block
+            h_host = None if dev else fptr(*step["h"])
+            h_dev = self._ctl(P).data_ptr() + 8 * 11 if dev else None      # C_HUSED
+            h_stride = _lib.DOPRI_CTL if dev else 0
             last = si == len(steps) - 1
             ws.dK.zero_()
             if method == "dopri5":
                 beta, first_eval = DP_BETA, step["first"]
                 if last:
-                    _lib.call("nlbac_dopri_interp_bwd", dout.data_ptr(), fptr(*h), fptr(*step["x"]), P, rpp, ns,
+                    _lib.call("nlbac_dopri_interp_bwd", dout.data_ptr(), h_host, None if dev else fptr(*step["x"]),
+                              self._ctl(P).data_ptr() if dev else None, P, rpp, ns,
                               ws.dy0.data_ptr(), ws.dy1.data_ptr(), ws.dK.data_ptr(), s)
                 else:
                     ws.dy0.zero_()
@@ -269,7 +410,7 @@ class AffineNodeSolver:
                 tab = TABLEAU[method]
                 beta, first_eval = tab["beta"], True
                 # out = y0 + h sum c_j K_j
-                _lib.call("nlbac_rk_stage_bwd", dout.data_ptr(), None, None, 0, S, fptr(*tab["c_sol"]), fptr(*h),
+                _lib.call("nlbac_rk_stage_bwd", dout.data_ptr(), None, None, 0, S, fptr(*tab["c_sol"]), h_host,
                           None, 0, P, rpp, ns, ws.dK.data_ptr(), ws.dy0.data_ptr(), 0, s)
                 top_up = None
             for st in range(S - 1, -1, -1):
@@ -281,25 +422,28 @@ class AffineNodeSolver:
                           ns, nu, n, 1.0, ws.dG[st].data_ptr() if (need_dx or need_params) else None,
                           du.data_ptr() if du is not None else None, 1, s)
                 if need_dx or need_params:
-                    io = io_array(2)
-                    f, g = self.f, self.g
-                    for i, (net, dy, ld, acts, dz, dx) in enumerate((
-                            (f, ws.dK[st], ns, ws.acts_f, ws.dz_f, ws.dXf),
-                            (g, ws.dG[st], ns * nu, ws.acts_g, ws.dz_g, ws.dXg))):
-                        io[i].dy, io[i].dy_ld = dy.data_ptr(), ld
-                        io[i].acts = acts[:, st * ws.n:].data_ptr()
-                        io[i].acts_ls = S * ws.n * net.hid
-                        if need_params:
-                            io[i].dz = dz[:, st * ws.n:].data_ptr()
-                        if need_dx:
-                            io[i].dx, io[i].dx_ld = dx.data_ptr(), net.in_dim
-                    _lib.call("nlbac_mlp_bwd_data", mlp_array([f.desc, g.desc]), io, 2, n, s)
+                    key = (st, need_params, need_dx)
+                    io = ws.io_bwd.get(key)
+                    if io is None:
+                        io = ws.io_bwd[key] = io_array(2)
+                        f, g = self.f, self.g
+                        for i, (net, dy, ld, acts, dz, dx) in enumerate((
+                                (f, ws.dK[st], ns, ws.acts_f, ws.dz_f, ws.dXf),
+                                (g, ws.dG[st], ns * nu, ws.acts_g, ws.dz_g, ws.dXg))):
+                            io[i].dy, io[i].dy_ld = dy.data_ptr(), ld
+                            io[i].acts = acts[:, st * ws.n:].data_ptr()
+                            io[i].acts_ls = S * ws.n * net.hid
+                            if need_params:
+                                io[i].dz = dz[:, st * ws.n:].data_ptr()
+                            if need_dx:
+                                io[i].dx, io[i].dx_ld = dx.data_ptr(), net.in_dim
+                    _lib.call("nlbac_mlp_bwd_data", self._nets(), io, 2, n, s)
                 if need_dx:
                     up = top_up if (st == S - 1 and top_up is not None) else None
                     coef = beta[st - 1] if st > 0 else []
                     _lib.call("nlbac_rk_stage_bwd", up.data_ptr() if up is not None else None, ws.dXf.data_ptr(),
-                              ws.dXg.data_ptr(), self.f.in_dim, st, fptr(*coef) if coef else None, fptr(*h), None, 0,
-                              P, rpp, ns, ws.dK.data_ptr(), ws.dy0.data_ptr(), 1, s)
+                              ws.dXg.data_ptr(), self.f.in_dim, st, fptr(*coef) if coef else None, h_host, h_dev,
+                              h_stride, P, rpp, ns, ws.dK.data_ptr(), ws.dy0.data_ptr(), 1, s)
             dy_carry = ws.dy0
             dk_carry = ws.dK[0]
         dy0 = steps[0]["ws"].dy0 if need_dy0 else None
@@ -328,6 +472,6 @@ class AffineNodeSolver:
                 io[i].acts_ls = S * n * net.hid
                 io[i].grad = arena.grad[n_used:].data_ptr()
             assert n_used + slabs_per_step <= arena.n_slabs, "arena has too few gradient slabs"
-            bwd_weights(mlp_array([self.f.desc, self.g.desc]), io, 2, rows, slabs_per_step, arena.n, self.device)
+            bwd_weights(self._nets(), io, 2, rows, slabs_per_step, arena.n, self.device)
             n_used += slabs_per_step
         return n_used

@@ -18,6 +18,7 @@ per-sample quantity is computed in fused HIP kernels, the only host<->device
 traffic is the minibatch upload and one 512-byte scalars read-back.
 """
 import random
+import types
 
 import numpy as np
 import torch
@@ -60,8 +61,10 @@ class _Workspace:
         self.heads2, self.pi2, self.logp2 = z(2 * B, 4), z(2 * B, 2), z(2 * B)
         self.acts_p = z(2, 2, B, H)
         self.dz_p = z(2, 2, B, H)
-        self.state, self.ps = z(B, 3), z(B, 2)
+        self.ps = z(B, 2)
         self.y0_2 = z(2 * B, 3)
+        self.plan = None
+        self.graphs, self.warm = {}, 0
         self.qpi = z(2, 2 * B)
         self.acts_q = z(4, 2, B, H)
         self.V, self.Vn, self.dVn = z(B), z(B), z(B)
@@ -176,6 +179,7 @@ class SAC_CBF_CLF(object):
         self._ws = {}
         self._noise = None
         self._fit_ws = {}
+        self.use_graphs = False  # replay the update as hipGraphs (single GPU; see update_on_device)
         self.dp = None          # nlbac_amd.parallel.DataParallel when sharded over GPUs
         self._xb = {}
 
@@ -332,18 +336,43 @@ class SAC_CBF_CLF(object):
     def fit_node_rows(self, rows):
         """Same, for a device tensor of minibatch-layout rows (N,24): obs at column 0,
         action at 7, next_obs at 15 (the layout ``update_from_host`` uploads)."""
-        self._fit(rows.data_ptr(), rows.shape[1], rows[:, 7:9].contiguous(), rows.data_ptr() + 4 * 15,
+        self._fit(rows.data_ptr(), rows.shape[1], rows[:, 7:9], rows.data_ptr() + 4 * 15,
                   rows.shape[1], rows.shape[0])
 
     def _fit(self, p_obs, obs_ld, action, p_nobs, nobs_ld, N):
-        s = stream_ptr()
         if N not in self._fit_ws:
             z = lambda *sh: torch.zeros(*sh, dtype=torch.float32, device=self.device)
-            self._fit_ws[N] = dict(st=z(N, 3), nst=z(N, 3), dpred=z(N, 3), part=z((N + 255) // 256))
+            self._fit_ws[N] = dict(st=z(N, 3), nst=z(N, 3), dpred=z(N, 3), part=z((N + 255) // 256), u=z(N, 2),
+                                   graphs={}, warm=0)
         w = self._fit_ws[N]
+        w["u"].copy_(action)
+        key = (p_obs, obs_ld, p_nobs, nobs_ld, self.solver)
+        part1 = lambda: self._fit_part1(w, p_obs, obs_ld, p_nobs, nobs_ld, N)
+        if not (self.use_graphs and self.world == 1) or w["warm"] < 1:
+            w["warm"] += 1
+            part1()
+            self._fit_part2(w, N, self.fit_solver.forward_finish())
+            return
+        g = w["graphs"]
+        if ("p1",) + key not in g:
+            g[("p1",) + key] = self._capture(part1)
+        g[("p1",) + key].replay()
+        if self.solver == "dopri5" and not self.fit_solver.first_step_done():
+            self._fit_part2(w, N, self.fit_solver.forward_finish())      # rare: finish this one eagerly
+            return
+        if ("p2",) + key not in g:
+            g[("p2",) + key] = self._capture(
+                lambda: self._fit_part2(w, N, self.fit_solver.forward_finish(assume_single_step=True)))
+        g[("p2",) + key].replay()
+
+    def _fit_part1(self, w, p_obs, obs_ld, p_nobs, nobs_ld, N):
+        s = stream_ptr()
         _lib.call("nlbac_unicycle_state", p_obs, obs_ld, N, self.l_p, w["st"].data_ptr(), None, s)
         _lib.call("nlbac_unicycle_state", p_nobs, nobs_ld, N, self.l_p, w["nst"].data_ptr(), None, s)
-        pred = self.fit_solver.forward(w["st"], action, 1, N, self.solver, self.env.dt, self.atol, self.rtol)
+        self.fit_solver.forward_begin(w["st"], w["u"], 1, N, self.solver, self.env.dt, self.atol, self.rtol)
+
+    def _fit_part2(self, w, N, pred):
+        s = stream_ptr()
         nblk = (N + 255) // 256
         NG = N * self.world
         _lib.call("nlbac_mse_fwd_bwd", pred.data_ptr(), 3, w["nst"].data_ptr(), 3, N, NG, 3, w["dpred"].data_ptr(), 3,
@@ -355,76 +384,161 @@ class SAC_CBF_CLF(object):
         self._adam(self.ar_n, 1e-3, used, extra=self.sc[SC.SC_NODE_LOSS:SC.SC_NODE_LOSS + 1])
         pack([self.h_f, self.h_g])
 
+    def _capture(self, fn):
+        """Record the launches of ``fn`` into a hipGraph (all kernel arguments are static device pointers /
+        constants; per-update scalars live in device memory)."""
+        torch.cuda.synchronize()
+        g = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(g):
+            fn()
+        return g
+
     # -- the update proper --------------------------------------------------------
+    def _plan(self, ws):
+        """ctypes launch descriptors of one workspace: every pointer is static (arenas, workspace tensors),
+        so they are built once; an update is then a plain sequence of C calls."""
+        if ws.plan is not None:
+            return ws.plan
+        B = ws.B
+        mb = ws.mb.data_ptr()
+        LD = 24
+        col = lambda c: mb + 4 * c
+        p_obs, p_act, p_cen, p_ncen, p_nobs = col(0), col(7), col(11), col(13), col(15)
+
+        def x(io, i, p0, d0, ld0, p1=None, d1=0, ld1=0):
+            io[i].x0, io[i].x0_dim, io[i].x0_ld = p0, d0, ld0
+            if p1 is not None:
+                io[i].x1, io[i].x1_dim, io[i].x1_ld = p1, d1, ld1
+        P = types.SimpleNamespace()
+        P.p_obs, P.p_rew, P.p_con, P.p_mask, P.LD = p_obs, col(9), col(10), col(22), LD
+        q1, q2, l, pi, pb = self.h_q1, self.h_q2, self.h_l, self.h_p, self.h_b
+        # A: pi(s')
+        P.n_pol, P.io_pol_next = mlp_array([pi.desc]), io_array(1)
+        x(P.io_pol_next, 0, p_nobs, 7, LD)
+        P.io_pol_next[0].y, P.io_pol_next[0].y_ld = ws.heads_n.data_ptr(), 4
+        # A: targets + critic / Lyapunov forward (6 nets)
+        P.n_six = mlp_array([q1.desc_target, q2.desc_target, l.desc_target, q1.desc, q2.desc, l.desc])
+        io = P.io_six = io_array(6)
+        for i in range(6):
+            io[i].y, io[i].y_ld = ws.q6[i].data_ptr(), 1
+        for i in (0, 1):
+            x(io, i, p_nobs, 7, LD, ws.na.data_ptr(), 2, 2)
+        x(io, 2, p_ncen, 2, LD)
+        for i in (3, 4):
+            x(io, i, p_obs, 7, LD, p_act, 2, LD)
+            io[i].acts = ws.acts_c[i - 3].data_ptr()
+        x(io, 5, p_cen, 2, LD)
+        io[5].acts = ws.acts_c[2].data_ptr()
+        # B: critic / Lyapunov backward
+        P.n_crit = mlp_array([q1.desc, q2.desc, l.desc])
+        io = P.io_crit = io_array(3)
+        for i in range(3):
+            io[i].dy, io[i].dy_ld = ws.dq3[i].data_ptr(), 1
+            io[i].acts, io[i].dz = ws.acts_c[i].data_ptr(), ws.dz_c[i].data_ptr()
+            io[i].grad = self.ar_c.grad.data_ptr()
+        for i in (0, 1):
+            x(io, i, p_obs, 7, LD, p_act, 2, LD)
+        x(io, 2, p_cen, 2, LD)
+        # C: both actors (forward and backward share one descriptor)
+        P.n_act = mlp_array([pi.desc, pb.desc])
+        io = P.io_act = io_array(2)
+        for i in range(2):
+            x(io, i, p_obs, 7, LD)
+            io[i].y, io[i].y_ld = ws.heads2[i * B:].data_ptr(), 4
+            io[i].acts, io[i].dz = ws.acts_p[i].data_ptr(), ws.dz_p[i].data_ptr()
+            io[i].dy, io[i].dy_ld = ws.dheads2[i * B:].data_ptr(), 4
+            io[i].grad = self.ar_a.grad.data_ptr()
+        # C: Q(s, pi) for primary / backup + V(centre)
+        P.n_q5 = mlp_array([q1.desc, q2.desc, q1.desc, q2.desc, l.desc])
+        io = P.io_q5 = io_array(5)
+        for i in range(4):
+            half = i // 2                                      # 0 primary, 1 backup
+            x(io, i, p_obs, 7, LD, ws.pi2[half * B:].data_ptr(), 2, 2)
+            io[i].y, io[i].y_ld = ws.qpi[i % 2, half * B:].data_ptr(), 1
+            io[i].acts = ws.acts_q[i].data_ptr()
+            io[i].dy, io[i].dy_ld = ws.dq_pi[i % 2, half * B:].data_ptr(), 1
+            io[i].dx, io[i].dx_ld = ws.dxq[i % 2, half * B:].data_ptr(), 9
+        x(io, 4, p_cen, 2, LD)
+        io[4].y, io[4].y_ld = ws.V.data_ptr(), 1
+        # C: V(p(x')) forward + data backward
+        P.n_l = mlp_array([l.desc])
+        io = P.io_vn = io_array(1)
+        x(io, 0, ws.ps_next2.data_ptr(), 2, 2)
+        io[0].y, io[0].y_ld = ws.Vn.data_ptr(), 1
+        io[0].acts = ws.acts_vn.data_ptr()
+        io[0].dy, io[0].dy_ld = ws.dVn.data_ptr(), 1
+        io[0].dx, io[0].dx_ld = ws.dps_v2.data_ptr(), 2
+        ws.plan = P
+        return P
+
     def update_on_device(self, ws, updates, sync=True):
         """Minibatch already in ``ws.mb``; returns the reference's 6 floats."""
-        B, H = ws.B, self.hidden
-        G = B * self.world                      # rows the batch means run over
-        s = stream_ptr()
-        mb = ws.mb
-        p_obs, p_act = mb.data_ptr(), mb.data_ptr() + 4 * 7
-        p_rew, p_con = mb.data_ptr() + 4 * 9, mb.data_ptr() + 4 * 10
-        p_cen, p_ncen = mb.data_ptr() + 4 * 11, mb.data_ptr() + 4 * 13
-        p_nobs, p_mask = mb.data_ptr() + 4 * 15, mb.data_ptr() + 4 * 22
-        LD = 24
         if self._noise is not None:
             for i in range(3):
                 ws.eps[i].copy_(self._noise[i].to(self.device))
             self._noise = None
         else:
             ws.eps.normal_()
+        soft = (updates % self.target_update_interval == 0)
+        lam_upd = 1 if updates % self.Lagrangian_multiplier_update_interval == 0 else 0
+        solver = self.node_solver
+        if not (self.use_graphs and self.world == 1) or ws.warm < 1:
+            ws.warm += 1
+            self._upd_part1(ws, soft)
+            self._upd_part2(ws, lam_upd, solver.forward_finish())
+        else:
+            # hipGraph replay: part 1 up to the dopri5 accept decision, one 256-byte read, part 2
+            g = ws.graphs
+            k1, k2 = ("p1", soft, self.solver), ("p2", lam_upd, self.solver)
+            if k1 not in g:
+                g[k1] = self._capture(lambda: self._upd_part1(ws, soft))
+            g[k1].replay()
+            if self.solver == "dopri5" and not solver.first_step_done():
+                self._upd_part2(ws, lam_upd, solver.forward_finish())          # rare: finish eagerly
+            else:
+                if k2 not in g:
+                    g[k2] = self._capture(
+                        lambda: self._upd_part2(ws, lam_upd, solver.forward_finish(assume_single_step=True)))
+                g[k2].replay()
+        return self._returns(sync)
+
+    def _returns(self, sync):
+        if not sync:
+            return None
+        h = self._scalars()
+        alpha_loss = float(h[SC.SC_ALOSS]) if self.automatic_entropy_tuning else 0.0
+        return (float(h[SC.SC_QF1]), float(h[SC.SC_QF2]), float(h[SC.SC_LF]), float(h[SC.SC_PL1]),
+                alpha_loss, float(h[SC.SC_ALPHA]))
+
+    def _upd_part1(self, ws, soft):
+        """Phases A, B and the forward half of C up to the rollout's first host decision point."""
+        B = ws.B
+        G = B * self.world                      # rows the batch means run over
+        s = stream_ptr()
+        P = self._plan(ws)
+        LD = P.LD
         sc = self.sc.data_ptr()
         call = _lib.call
         dt = float(self.env.dt)
-        # strided column views of the minibatch need their own (B) vectors for the per-sample kernels
-        rew, con, mask = mb[:, 9].contiguous(), mb[:, 10].contiguous(), mb[:, 22].contiguous()
+        pol = self.policy
+        p_scale, p_bias = pol.action_scale.data_ptr(), pol.action_bias.data_ptr()
 
         # ---- A. targets (no grad): pi(s'), Q_target(s', a'), L_target(c') ; critic / Lyapunov forward
-        io = io_array(1)
-        io[0].x0, io[0].x0_dim, io[0].x0_ld = p_nobs, 7, LD
-        io[0].y, io[0].y_ld = ws.heads_n.data_ptr(), 4
-        call("nlbac_mlp_fwd", mlp_array([self.h_p.desc]), io, 1, B, s)
-        pol = self.policy
-        call("nlbac_gauss_sample_fwd", ws.heads_n.data_ptr(), 4, ws.eps[0].data_ptr(), pol.action_scale.data_ptr(),
-             pol.action_bias.data_ptr(), 2, B, ws.na.data_ptr(), 2, ws.nlogp.data_ptr(), s)
-        io = io_array(6)
-        nets = [self.h_q1.desc_target, self.h_q2.desc_target, self.h_l.desc_target,
-                self.h_q1.desc, self.h_q2.desc, self.h_l.desc]
-        for i in range(6):
-            io[i].y, io[i].y_ld = ws.q6[i].data_ptr(), 1
-        for i in (0, 1):
-            io[i].x0, io[i].x0_dim, io[i].x0_ld = p_nobs, 7, LD
-            io[i].x1, io[i].x1_dim, io[i].x1_ld = ws.na.data_ptr(), 2, 2
-        io[2].x0, io[2].x0_dim, io[2].x0_ld = p_ncen, 2, LD
-        for i in (3, 4):
-            io[i].x0, io[i].x0_dim, io[i].x0_ld = p_obs, 7, LD
-            io[i].x1, io[i].x1_dim, io[i].x1_ld = p_act, 2, LD
-            io[i].acts = ws.acts_c[i - 3].data_ptr()
-        io[5].x0, io[5].x0_dim, io[5].x0_ld = p_cen, 2, LD
-        io[5].acts = ws.acts_c[2].data_ptr()
-        call("nlbac_mlp_fwd", mlp_array(nets), io, 6, B, s)
+        call("nlbac_mlp_fwd", P.n_pol, P.io_pol_next, 1, B, s)
+        call("nlbac_gauss_sample_fwd", ws.heads_n.data_ptr(), 4, ws.eps[0].data_ptr(), p_scale, p_bias, 2, B,
+             ws.na.data_ptr(), 2, ws.nlogp.data_ptr(), s)
+        call("nlbac_mlp_fwd", P.n_six, P.io_six, 6, B, s)
         q = ws.q6
         call("nlbac_td_targets", q[0].data_ptr(), q[1].data_ptr(), q[2].data_ptr(), ws.nlogp.data_ptr(),
-             rew.data_ptr(), con.data_ptr(), mask.data_ptr(), q[3].data_ptr(), q[4].data_ptr(), q[5].data_ptr(),
+             P.p_rew, P.p_con, P.p_mask, LD, q[3].data_ptr(), q[4].data_ptr(), q[5].data_ptr(),
              sc + 4 * SC.SC_ALPHA, self.gamma, B, G, ws.dq3[0].data_ptr(), ws.dq3[1].data_ptr(), ws.dq3[2].data_ptr(),
              ws.next_q.data_ptr(), ws.next_l.data_ptr(), ws.part_td.data_ptr(), s)
         call("nlbac_sum_partials", ws.part_td.data_ptr(), ws.nblk, 3, 1.0 / G, sc + 4 * SC.SC_QF1, s)
 
         # ---- B. critic / Lyapunov backward + Adam (+ Polyak targets) ---------------
-        io = io_array(3)
-        cnets = mlp_array([self.h_q1.desc, self.h_q2.desc, self.h_l.desc])
-        for i in range(3):
-            io[i].dy, io[i].dy_ld = ws.dq3[i].data_ptr(), 1
-            io[i].acts, io[i].dz = ws.acts_c[i].data_ptr(), ws.dz_c[i].data_ptr()
-            io[i].grad = self.ar_c.grad.data_ptr()
-        for i in (0, 1):
-            io[i].x0, io[i].x0_dim, io[i].x0_ld = p_obs, 7, LD
-            io[i].x1, io[i].x1_dim, io[i].x1_ld = p_act, 2, LD
-        io[2].x0, io[2].x0_dim, io[2].x0_ld = p_cen, 2, LD
-        call("nlbac_mlp_bwd_data", cnets, io, 3, B, s)
+        call("nlbac_mlp_bwd_data", P.n_crit, P.io_crit, 3, B, s)
         a = self.ar_c
-        bwd_weights(cnets, io, 3, B, a.n_slabs, a.n, self.device)
-        soft = (updates % self.target_update_interval == 0)
+        bwd_weights(P.n_crit, P.io_crit, 3, B, a.n_slabs, a.n, self.device)
         self._adam(a, self.critic_lyapunov_lr, a.n_slabs, extra=self.sc[SC.SC_QF1:SC.SC_QF1 + 3],
                    target=a.target.data_ptr(), tau=self.tau if soft else -1.0)
         pack([self.h_q1, self.h_q2, self.h_l])
@@ -432,48 +546,37 @@ class SAC_CBF_CLF(object):
             pack([self.h_q1, self.h_q2, self.h_l], target=True)
 
         # ---- C. actors: sample, Q(s, pi), constraints through the NODE rollout -----
-        io = io_array(2)
-        for i, h in enumerate((self.h_p, self.h_b)):
-            io[i].x0, io[i].x0_dim, io[i].x0_ld = p_obs, 7, LD
-            io[i].y, io[i].y_ld = ws.heads2[i * B:].data_ptr(), 4
-            io[i].acts = ws.acts_p[i].data_ptr()
-        pnets = mlp_array([self.h_p.desc, self.h_b.desc])
-        call("nlbac_mlp_fwd", pnets, io, 2, B, s)
+        call("nlbac_mlp_fwd", P.n_act, P.io_act, 2, B, s)
         eps2 = ws.eps[1:3]                                     # (2,B,2) == (2B,2)
-        call("nlbac_gauss_sample_fwd", ws.heads2.data_ptr(), 4, eps2.data_ptr(), pol.action_scale.data_ptr(),
-             pol.action_bias.data_ptr(), 2, 2 * B, ws.pi2.data_ptr(), 2, ws.logp2.data_ptr(), s)
-        call("nlbac_unicycle_state", p_obs, LD, B, self.l_p, ws.state.data_ptr(), ws.ps.data_ptr(), s)
-        ws.y0_2[:B].copy_(ws.state)
-        ws.y0_2[B:].copy_(ws.state)
-        io = io_array(5)
-        qnets = mlp_array([self.h_q1.desc, self.h_q2.desc, self.h_q1.desc, self.h_q2.desc, self.h_l.desc])
-        for i in range(4):
-            half = i // 2                                      # 0 primary, 1 backup
-            io[i].x0, io[i].x0_dim, io[i].x0_ld = p_obs, 7, LD
-            io[i].x1, io[i].x1_dim, io[i].x1_ld = ws.pi2[half * B:].data_ptr(), 2, 2
-            io[i].y, io[i].y_ld = ws.qpi[i % 2, half * B:].data_ptr(), 1
-            io[i].acts = ws.acts_q[i].data_ptr()
-        io[4].x0, io[4].x0_dim, io[4].x0_ld = p_cen, 2, LD
-        io[4].y, io[4].y_ld = ws.V.data_ptr(), 1
-        call("nlbac_mlp_fwd", qnets, io, 5, B, s)
+        call("nlbac_gauss_sample_fwd", ws.heads2.data_ptr(), 4, eps2.data_ptr(), p_scale, p_bias, 2, 2 * B,
+             ws.pi2.data_ptr(), 2, ws.logp2.data_ptr(), s)
+        # state (twice: primary and backup rows of the rollout) and look-ahead point
+        call("nlbac_unicycle_state", P.p_obs, LD, B, self.l_p, ws.y0_2.data_ptr(), ws.ps.data_ptr(), s)
+        call("nlbac_unicycle_state", P.p_obs, LD, B, self.l_p, ws.y0_2[B:].data_ptr(), None, s)
+        call("nlbac_mlp_fwd", P.n_q5, P.io_q5, 5, B, s)
         call("nlbac_actor_q_terms", ws.qpi[0].data_ptr(), ws.qpi[1].data_ptr(), ws.logp2.data_ptr(),
              sc + 4 * SC.SC_ALPHA, B, G, 2, ws.dq_pi[0].data_ptr(), ws.dq_pi[1].data_ptr(), ws.part_q.data_ptr(), s)
 
-        x_next2 = self.node_solver.forward(ws.y0_2, ws.pi2, 2, B, self.solver, dt, self.atol, self.rtol)
+        self.node_solver.forward_begin(ws.y0_2, ws.pi2, 2, B, self.solver, dt, self.atol, self.rtol)
+
+    def _upd_part2(self, ws, lam_upd, x_next2):
+        """Constraints, augmented-Lagrangian scalars, the whole actor backward and the actor Adam step."""
+        B = ws.B
+        G = B * self.world
+        s = stream_ptr()
+        P = self._plan(ws)
+        sc = self.sc.data_ptr()
+        call = _lib.call
+        dt = float(self.env.dt)
+        pol = self.policy
+        p_scale = pol.action_scale.data_ptr()
+        eps2 = ws.eps[1:3]
         call("nlbac_unicycle_lookahead", x_next2.data_ptr(), 2 * B, self.l_p, ws.ps_next2.data_ptr(), s)
-        io = io_array(1)
-        io[0].x0, io[0].x0_dim, io[0].x0_ld = ws.ps_next2.data_ptr(), 2, 2
-        io[0].y, io[0].y_ld = ws.Vn.data_ptr(), 1
-        io[0].acts = ws.acts_vn.data_ptr()
-        io[0].dy, io[0].dy_ld = ws.dVn.data_ptr(), 1
-        io[0].dx, io[0].dx_ld = ws.dps_v2.data_ptr(), 2
-        lnet = mlp_array([self.h_l.desc])
-        call("nlbac_mlp_fwd", lnet, io, 1, B, s)
+        call("nlbac_mlp_fwd", P.n_l, P.io_vn, 1, B, s)
         r_coll = 1.05 * float(self.env.hazards_radius)
         call("nlbac_unicycle_constraints_fwd", ws.ps.data_ptr(), ws.ps_next2.data_ptr(), ws.V.data_ptr(),
              ws.Vn.data_ptr(), self.hazards.data_ptr(), self.num_cbfs, r_coll, dt, float(self.gamma_b), 1.0, B,
              ws.matr.data_ptr(), ws.bmatr.data_ptr(), ws.part_c.data_ptr(), s)
-        lam_upd = 1 if updates % self.Lagrangian_multiplier_update_interval == 0 else 0
         ncol = 2 * self.num_cbfs + 1
         p_part_c, p_part_q, n_part = ws.part_c.data_ptr(), ws.part_q.data_ptr(), ws.nblk
         if self.world > 1:      # global constraint / actor sums before anything nonlinear in them
@@ -488,30 +591,18 @@ class SAC_CBF_CLF(object):
         call("nlbac_unicycle_constraints_bwd", ws.ps_next2.data_ptr(), ws.matr.data_ptr(), ws.bmatr.data_ptr(),
              self.hazards.data_ptr(), self.num_cbfs, dt, float(self.batch_size), B, sc, ws.dps_next2.data_ptr(),
              ws.dVn.data_ptr(), s)
-        call("nlbac_mlp_bwd_data", lnet, io, 1, B, s)          # dV_next -> d ps_next (rows [0,B))
+        call("nlbac_mlp_bwd_data", P.n_l, P.io_vn, 1, B, s)    # dV_next -> d ps_next (rows [0,B))
         call("nlbac_unicycle_lookahead_bwd", x_next2.data_ptr(), ws.dps_next2.data_ptr(), ws.dps_v2.data_ptr(), 2 * B,
              self.l_p, ws.dx_next2.data_ptr(), s)
         du2, _ = self.node_solver.backward(ws.dx_next2, need_du=True)
 
-        io = io_array(4)
-        for i in range(4):
-            half = i // 2
-            io[i].dy, io[i].dy_ld = ws.dq_pi[i % 2, half * B:].data_ptr(), 1
-            io[i].acts = ws.acts_q[i].data_ptr()
-            io[i].dx, io[i].dx_ld = ws.dxq[i % 2, half * B:].data_ptr(), 9
-        call("nlbac_mlp_bwd_data", qnets, io, 4, B, s)
-        call("nlbac_gauss_sample_bwd", ws.heads2.data_ptr(), 4, eps2.data_ptr(), pol.action_scale.data_ptr(), 2,
+        call("nlbac_mlp_bwd_data", P.n_q5, P.io_q5, 4, B, s)   # the four Q(s, pi) nets: dx only
+        call("nlbac_gauss_sample_bwd", ws.heads2.data_ptr(), 4, eps2.data_ptr(), p_scale, 2,
              2 * B, B, ws.dxq[0].data_ptr() + 4 * 7, 9, ws.dxq[1].data_ptr() + 4 * 7, 9, du2.data_ptr(), 2,
              sc + 4 * SC.SC_ALPHA, 1.0 / G, ws.dheads2.data_ptr(), 4, s)
-        io = io_array(2)
         a = self.ar_a
-        for i in range(2):
-            io[i].x0, io[i].x0_dim, io[i].x0_ld = p_obs, 7, LD
-            io[i].dy, io[i].dy_ld = ws.dheads2[i * B:].data_ptr(), 4
-            io[i].acts, io[i].dz = ws.acts_p[i].data_ptr(), ws.dz_p[i].data_ptr()
-            io[i].grad = a.grad.data_ptr()
-        call("nlbac_mlp_bwd_data", pnets, io, 2, B, s)
-        bwd_weights(pnets, io, 2, B, a.n_slabs, a.n, self.device)
+        call("nlbac_mlp_bwd_data", P.n_act, P.io_act, 2, B, s)
+        bwd_weights(P.n_act, P.io_act, 2, B, a.n_slabs, a.n, self.device)
         la = a.theta.data_ptr() + 4 * self.la_off
         tune = self.automatic_entropy_tuning
 
@@ -528,12 +619,6 @@ class SAC_CBF_CLF(object):
         pack([self.h_p, self.h_b])
         if self.automatic_entropy_tuning:
             call("nlbac_alpha_refresh", la, self.la_stride, 2, sc, s)
-        if not sync:
-            return None
-        h = self._scalars()
-        alpha_loss = float(h[SC.SC_ALOSS]) if self.automatic_entropy_tuning else 0.0
-        return (float(h[SC.SC_QF1]), float(h[SC.SC_QF2]), float(h[SC.SC_LF]), float(h[SC.SC_PL1]),
-                alpha_loss, float(h[SC.SC_ALPHA]))
 
     # ------------------------------------------------------------ checkpoints
     def save_model(self, output):

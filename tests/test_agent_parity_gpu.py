@@ -47,14 +47,16 @@ def flat_grad(agent, arena, module, n_slabs=None):
     return torch.cat([arena.grad_view(p).reshape(-1) for p in module.parameters()]).cpu()
 
 
+@pytest.mark.parametrize("graphs", [False, True], ids=["eager", "hipgraph"])
 @pytest.mark.parametrize("solver", ["euler", "rk4", "dopri5"])
 @pytest.mark.parametrize("B", [8, 128])
-def test_update_matches_reference_fixture_and_oracle(solver, B):
+def test_update_matches_reference_fixture_and_oracle(solver, B, graphs):
     from oracle import nlbac_oracle as O
     torch.set_num_threads(4)
     g = load_golden(solver, B)
     seed, hidden = int(g["meta_seed"]), int(g["meta_hidden"])
     agent, env = make_agent(B, hidden, seed, solver)
+    agent.use_graphs = graphs      # call 0 warms up eagerly, calls 1 and 2 capture + replay hipGraphs
     oracle = O.OracleUnicycleAgent(make_env("Unicycle", seed), O.Args(batch_size=B, hidden_size=hidden, seed=seed),
                                    synth.unicycle_agent_weights(hidden, seed), solver=solver)
     tr = synth.unicycle_transitions(4096, seed=seed + 1, env=env)
@@ -85,7 +87,7 @@ def test_update_matches_reference_fixture_and_oracle(solver, B):
         if B <= 16:
             vec_close(ws.matr.cpu().numpy(), g[p + "matr"], TOL, p + "matr vs golden")
             vec_close(ws.bmatr.cpu().numpy(), g[p + "bmatr"], TOL, p + "bmatr vs golden")
-        if solver == "dopri5":
+        if solver == "dopri5" and "info" in agent.node_solver.ctx and not (graphs and ci > 0):
             info = agent.node_solver.ctx["info"]
             for prob, key in ((0, "ode_steps"), (1, "bode_steps")):
                 st = np.array([a[prob] for a in info], dtype=np.float64)
@@ -128,3 +130,34 @@ def test_update_matches_reference_fixture_and_oracle(solver, B):
                                ("node", agent.neural_ode_model, oracle.node)):
             ov = torch.cat([osd[k].detach().reshape(-1) for k in osd])
             vec_close(flat_params(mod), ov, TOL, p + "all params %s vs oracle" % name)
+
+
+@pytest.mark.parametrize("solver", ["euler", "dopri5"])
+def test_hipgraph_replay_is_bit_identical_to_eager(solver):
+    """12 consecutive updates (NODE fit at updates 0 and 10, lambda updates at 0 and 8): the captured graphs
+    replay the same kernels with the same arguments, so every parameter must match bit for bit."""
+    B, hidden, seed = 256, 256, 0
+    tr = synth.unicycle_transitions(4096, seed=3)
+    fields = ("obs", "action", "reward", "constraint", "center", "next_center", "next_obs", "mask")
+    agents = []
+    for graphs in (False, True):
+        agent, env = make_agent(B, hidden, seed, solver)
+        agent.use_graphs = graphs
+        rs = np.random.RandomState(5)
+        rets = []
+        for updates in range(12):
+            idx = rs.choice(4096, B, replace=False)
+            nidx = rs.choice(4096, 1024, replace=False)
+            agent.set_noise(synth.normal_eps(3, B, 2, seed=updates))
+            host = tuple(tr[f][idx] for f in fields)
+            node = tuple(tr[f][nidx] for f in ("obs", "action", "next_obs")) if updates % 10 == 0 else None
+            rets.append(agent.update_from_host(host, updates, node))
+        torch.cuda.synchronize()
+        agents.append((agent, rets))
+    (a0, r0), (a1, r1) = agents
+    assert len(a1._ws[B].graphs) >= 3, "graphs were not captured"
+    np.testing.assert_array_equal(np.array(r0), np.array(r1))
+    for ar0, ar1 in ((a0.ar_c, a1.ar_c), (a0.ar_a, a1.ar_a), (a0.ar_n, a1.ar_n)):
+        assert torch.equal(ar0.theta, ar1.theta) and torch.equal(ar0.m, ar1.m) and torch.equal(ar0.v, ar1.v)
+    assert torch.equal(a0.ar_c.target, a1.ar_c.target)
+    assert torch.equal(a0.sc, a1.sc)
