@@ -207,6 +207,18 @@ int nlbac_rk_stage_bwd(const float *dYup, const float *dXf, const float *dXg, in
                        const float *coef, const float *h_host, const double *h_dev, int h_dev_stride,
                        int P, int rows_per_problem, int n_s, float *dK, float *dy0, int accumulate_dy0,
                        nlbac_stream_t s);
+/* Fused RK step: one launch evaluates stages [stage_begin, stage_end) of an explicit RK step with
+ * n_stages_total stages for P problems x rows_per_problem rows: stage inputs
+ * Y_s = y0 + h_p sum_{j<s} beta[s][j] K_j, f_net and g_net (two wave groups of one workgroup),
+ * K_s = f + g u, and optionally out = y0 + h sum c_out[j] K_j and err = h sum c_err[j] K_j.
+ * K / Y / G are [n_stages_total][n][.] stage-major; stages < stage_begin are read from K (FSAL, f0).
+ * acts_* ([layer][n_stages_total*n][hid], layer stride *_ls) may be NULL when no backward follows. */
+int nlbac_node_rk_fwd(const nlbac_mlp *f, const nlbac_mlp *g, const float *y0, const float *u, int P,
+                      int rows_per_problem, int stage_begin, int stage_end, int n_stages_total,
+                      const float *beta, const float *c_out, int n_out, const float *c_err, int n_err,
+                      const float *h_host, const double *h_dev, int h_dev_stride, float *K, float *Y,
+                      float *G, float *acts_f, long acts_f_ls, float *acts_g, long acts_g_ls, float *out,
+                      float *err, nlbac_stream_t s);
 /* dopri5 step control on the device.  ctl: per problem NLBAC_DOPRI_CTL doubles
  * {h, t, ratio, accept, done, x, h0, d0, d1, d2, n_steps, h_used}.
  * norm partials [P][ceil(rows/256)][2]; mode 0: (y0/scale, f0/scale) with a=f0;

@@ -9,7 +9,7 @@ import os
 import subprocess
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "lib", "libnlbac_hip.so")
+LIB_PATH = os.environ.get("NLBAC_HIP_LIB") or os.path.join(_HERE, "lib", "libnlbac_hip.so")   # env: kernel experiments
 CSRC = os.path.join(_HERE, "csrc")
 
 MAX_LAYERS, MAX_NETS, MLP_TILE = 6, 8, 32
@@ -77,6 +77,8 @@ _PROTOS = {
     "nlbac_affine_combine_bwd": [_P, _P, _P, _I, _I, _I, _F, _P, _P, _I, _P],
     "nlbac_rk_combine": [_P, _P, _I, c_float_p, c_float_p, _P, _I, _I, _I, _I, _P, _P],
     "nlbac_rk_stage_bwd": [_P, _P, _P, _I, _I, c_float_p, c_float_p, _P, _I, _I, _I, _I, _P, _P, _I, _P],
+    "nlbac_node_rk_fwd": [C.POINTER(Mlp), C.POINTER(Mlp), _P, _P, _I, _I, _I, _I, _I, c_float_p, c_float_p, _I,
+                          c_float_p, _I, c_float_p, _P, _I, _P, _P, _P, _P, _L, _P, _L, _P, _P, _P],
     "nlbac_dopri_norm_partials": [_P, _P, _P, _P, _P, _I, _F, _F, _I, _I, _I, _I, _P, _P],
     "nlbac_dopri_control": [_P, _I, _I, _I, _I, _I, _I, _D, _P, _P],
     "nlbac_dopri_interp_fwd": [_P, _P, _P, c_float_p, c_float_p, _P, _I, _I, _I, _P, _P],

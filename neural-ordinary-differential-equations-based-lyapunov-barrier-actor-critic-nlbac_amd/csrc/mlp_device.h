@@ -1,0 +1,269 @@
+// Device-side building blocks shared by the MLP kernels (mlp_kernels.hip) and the fused
+// Runge-Kutta step kernel (node_kernels.hip): MFMA tile GEMM with LDS-resident activations and
+// fragment-packed weights, and the VALU skinny-layer contraction.
+#pragma once
+#include "common.h"
+
+__device__ __forceinline__ int pad8(int x) { return (x + 7) & ~7; }
+__device__ __forceinline__ int pad32(int x) { return (x + 31) & ~31; }
+
+// row of accumulator register r for lane-half h in a 32x32 MFMA result
+__device__ __forceinline__ int acc_row(int r, int h) { return (r & 3) + 8 * (r >> 2) + 4 * h; }
+
+// ---------------------------------------------------------------------------
+// C[32 x 32*NTW] += A_lds[32 x 8*KC] * Bpacked      (one wave, NTW = 1 or 2 tiles)
+// Four K-chunks of operands are kept in flight in statically indexed registers
+// (no register rotation), so the compiler emits counted s_waitcnt vmcnt(N) and
+// every B-fragment load has three chunks of MFMA time to land.
+// ---------------------------------------------------------------------------
+#define MFMA4(A, B0, B1)                                                                       \
+    acc[0] = __builtin_amdgcn_mfma_f32_32x32x2f32((A).x, (B0).x, acc[0], 0, 0, 0);             \
+    if (NTW == 2) acc[1] = __builtin_amdgcn_mfma_f32_32x32x2f32((A).x, (B1).x, acc[1], 0, 0, 0); \
+    acc[0] = __builtin_amdgcn_mfma_f32_32x32x2f32((A).y, (B0).y, acc[0], 0, 0, 0);             \
+    if (NTW == 2) acc[1] = __builtin_amdgcn_mfma_f32_32x32x2f32((A).y, (B1).y, acc[1], 0, 0, 0); \
+    acc[0] = __builtin_amdgcn_mfma_f32_32x32x2f32((A).z, (B0).z, acc[0], 0, 0, 0);             \
+    if (NTW == 2) acc[1] = __builtin_amdgcn_mfma_f32_32x32x2f32((A).z, (B1).z, acc[1], 0, 0, 0); \
+    acc[0] = __builtin_amdgcn_mfma_f32_32x32x2f32((A).w, (B0).w, acc[0], 0, 0, 0);             \
+    if (NTW == 2) acc[1] = __builtin_amdgcn_mfma_f32_32x32x2f32((A).w, (B1).w, acc[1], 0, 0, 0);
+
+// One wave's B-operand (weight) fragments form a stream that does not depend on the activations:
+// chunk 0..KC-1 of this layer, then chunk 0.. of the next layer.  WaveGemm keeps four chunks of it
+// in statically indexed registers; while a layer's last chunks are being multiplied the freed slots
+// are refilled with the NEXT layer's first chunks, so after the inter-layer barrier the MFMAs start
+// on registers that are already loaded (only the LDS-resident A fragments are fetched then).
+// What follows the current layer in one wave's weight stream: the next layer's fragments and, for the
+// slots the next layer is too short to use (layer 0 has 1-2 chunks), the layer after it.
+struct NextFrags {
+    const float4 *n0, *n1; int KCn;
+    const float4 *nn0, *nn1; int KCnn;
+    __device__ __forceinline__ const float4* at0(int i) const { return (i < KCn) ? n0 + (long)i * 64 : nn0 + (long)min(i, KCnn - 1) * 64; }
+    __device__ __forceinline__ const float4* at1(int i) const { return (i < KCn) ? n1 + (long)i * 64 : nn1 + (long)min(i, KCnn - 1) * 64; }
+};
+
+template <int NTW>
+struct WaveGemm {
+    float4 b0[4], b1[4];
+
+    // slot i <- chunk i of this layer, or the upcoming stream's slot-i fragment when this layer is shorter
+    __device__ __forceinline__ void prime(const float4* p0, const float4* p1, int KC, const NextFrags& nx) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            b0[i] = *((i < KC) ? p0 + (long)i * 64 : nx.at0(i));
+            b1[i] = (NTW == 2) ? *((i < KC) ? p1 + (long)i * 64 : nx.at1(i)) : make_float4(0, 0, 0, 0);
+        }
+    }
+
+    // acc += A_lds[32 x 8*KC] * B ; p*: this layer's fragments (already in the slots), nx: what comes next
+    __device__ __forceinline__ void run(const float* __restrict__ arow, const float4* __restrict__ p0,
+                                        const float4* __restrict__ p1, int KC, const NextFrags& nx,
+                                        f32x16 (&acc)[2]) {
+        const int last = KC - 1;
+        float4 a[4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) a[i] = *reinterpret_cast<const float4*>(arow + min(i, last) * 8);
+        int kc = 0;
+        for (; kc + 4 <= KC; kc += 4) {
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                MFMA4(a[i], b0[i], b1[i])
+                const int c = kc + i + 4;
+                const bool here = c <= last;
+                b0[i] = *(here ? p0 + (long)c * 64 : nx.at0(i));
+                if (NTW == 2) b1[i] = *(here ? p1 + (long)c * 64 : nx.at1(i));
+                a[i] = *reinterpret_cast<const float4*>(arow + min(c, last) * 8);
+                __builtin_amdgcn_sched_barrier(0);   // keep each slot's refill right behind its MFMAs
+            }
+        }
+#pragma unroll
+        for (int i = 0; i < 3; ++i)
+            if (kc + i < KC) {
+                MFMA4(a[i], b0[i], b1[i])
+                b0[i] = *nx.at0(i);
+                if (NTW == 2) b1[i] = *nx.at1(i);
+            }
+    }
+};
+
+// Fragment pointers of one wave for a packed layer (tiles wave and wave+4)
+__device__ __forceinline__ const float4* frag_ptr(const float* packed, int off, int KC, int tile, int lane) {
+    return reinterpret_cast<const float4*>(packed + off) + (long)tile * KC * 64 + lane;
+}
+
+// skinny contraction helpers (VALU): NO outputs at once, every load unconditional
+template <int NO>
+__device__ __forceinline__ void skinny_dot(const float* __restrict__ lds_row, const float* __restrict__ W, int hid,
+                                           int part, float (&acc)[4]) {
+#pragma unroll 4
+    for (int it = 0; it < 8; ++it) {
+        const int k = part * 4 + 32 * it;
+        const bool ok = k < hid;
+        const int kk = ok ? k : 0;
+        float4 h = *reinterpret_cast<const float4*>(lds_row + kk);
+        if (!ok) h = make_float4(0, 0, 0, 0);
+#pragma unroll
+        for (int q = 0; q < NO; ++q) {
+            const float4 w = *reinterpret_cast<const float4*>(W + (long)q * hid + kk);
+            acc[q] += h.x * w.x + h.y * w.y + h.z * w.z + h.w * w.w;
+        }
+    }
+}
+
+
+// Skinny output layer, one (row, output) dot product per thread: thread t < 32*out_dim handles row t&31,
+// output t>>5.  The 32 lanes of a half-wave read 32 different rows at the same k (ds_read_b128, row
+// stride = 4 mod 8 dwords: conflict-free) and broadcast-read the weight row; no cross-lane reduction.
+__device__ __forceinline__ float skinny_row_dot(const float* __restrict__ hrow, const float* __restrict__ w, int hid) {
+    float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
+    for (int k = 0; k < hid; k += 4) {
+        const float4 h = *reinterpret_cast<const float4*>(hrow + k);
+        const float4 ww = *reinterpret_cast<const float4*>(w + k);
+        a0 += h.x * ww.x; a1 += h.y * ww.y; a2 += h.z * ww.z; a3 += h.w * ww.w;
+    }
+    return (a0 + a1) + (a2 + a3);
+}
+
+// ---------------------------------------------------------------------------
+// Wide (MFMA) layers of one net for one 32-row tile, executed by a 4-wave group in lock step
+// (every wave of the workgroup must call this with the same nwide_run: it contains the barriers).
+//   forward : h_{l+1} = relu(h_l W_l^T + b_l),  l = 0..nwide-1, saved to acts when given
+//   wrap    : the weight stream continues with layer 0 after the last layer (next RK stage)
+// ---------------------------------------------------------------------------
+// upcoming stream after wide layer l of a forward pass (wrap: layer 0 follows the last layer)
+template <int NTW>
+__device__ __forceinline__ NextFrags fwd_next(const nlbac_mlp& net, int l, int inp, bool wrap, int wave, int lane) {
+    const int nwide = net.n_layers - 1, hidp8 = pad8(net.hid);
+    const int ln = (l + 1 < nwide) ? l + 1 : (wrap ? 0 : l);
+    const int lnn = (ln + 1 < nwide) ? ln + 1 : (wrap ? 0 : ln);
+    NextFrags nx;
+    nx.KCn = ((ln == 0) ? inp : hidp8) >> 3;
+    nx.KCnn = ((lnn == 0) ? inp : hidp8) >> 3;
+    nx.n0 = frag_ptr(net.packed, net.pf_off[ln], nx.KCn, wave, lane);
+    nx.nn0 = frag_ptr(net.packed, net.pf_off[lnn], nx.KCnn, wave, lane);
+    nx.n1 = (NTW == 2) ? frag_ptr(net.packed, net.pf_off[ln], nx.KCn, wave + 4, lane) : nx.n0;
+    nx.nn1 = (NTW == 2) ? frag_ptr(net.packed, net.pf_off[lnn], nx.KCnn, wave + 4, lane) : nx.nn0;
+    return nx;
+}
+
+template <int NTW>
+__device__ __forceinline__ void fwd_prime(WaveGemm<NTW>& wg, const nlbac_mlp& net, int inp, bool wrap, int wave,
+                                          int lane) {
+    const int KC = inp >> 3;
+    wg.prime(frag_ptr(net.packed, net.pf_off[0], KC, wave, lane),
+             frag_ptr(net.packed, net.pf_off[0], KC, (NTW == 2) ? wave + 4 : wave, lane), KC,
+             fwd_next<NTW>(net, 0, inp, wrap, wave, lane));
+}
+
+template <int NTW>
+__device__ __forceinline__ void fwd_wide_layers(WaveGemm<NTW>& wg, const nlbac_mlp& net, bool active, int wave, int lane,
+                                                int LD, int inp, float*& in, float*& out, float* acts_tile,
+                                                long acts_ls, int n_rows, int nwide_run, bool wrap) {
+    const int hid = net.hid, hidp8 = pad8(hid), nwide = net.n_layers - 1, half = lane >> 5;
+    for (int l = 0; l < nwide_run; ++l) {
+        if (l < nwide && active) {
+            const int KC = ((l == 0) ? inp : hidp8) >> 3;
+            const float4* p0 = frag_ptr(net.packed, net.pf_off[l], KC, wave, lane);
+            const float4* p1 = (NTW == 2) ? frag_ptr(net.packed, net.pf_off[l], KC, wave + 4, lane) : p0;
+            const NextFrags nx = fwd_next<NTW>(net, l, inp, wrap, wave, lane);
+            const float* bias = net.params + net.b_off[l];
+            float bv[2];
+#pragma unroll
+            for (int t = 0; t < NTW; ++t) bv[t] = bias[min((wave + 4 * t) * 32 + (lane & 31), hid - 1)];
+            f32x16 acc[2];
+#pragma unroll
+            for (int r = 0; r < 16; ++r) { acc[0][r] = 0.f; acc[1][r] = 0.f; }
+#ifndef EXP_NO_GEMM
+            wg.run(in + (lane & 31) * LD + half * 4, p0, p1, KC, nx, acc);
+#endif
+            float* acts = acts_tile ? acts_tile + (long)l * acts_ls : nullptr;
+#pragma unroll
+            for (int t = 0; t < NTW; ++t) {
+                const int col = (wave + 4 * t) * 32 + (lane & 31);
+                const bool colok = col < hid;
+                float v[16];
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    v[r] = colok ? fmaxf(acc[t][r] + bv[t], 0.f) : 0.f;
+                    out[acc_row(r, half) * LD + col] = v[r];
+                }
+                if (acts && colok) {
+                    float* ap = acts + col;
+                    if (n_rows == NLBAC_MLP_TILE) {
+#pragma unroll
+                        for (int r = 0; r < 16; ++r) ap[(long)acc_row(r, half) * hid] = v[r];
+                    } else {
+#pragma unroll
+                        for (int r = 0; r < 16; ++r)
+                            if (acc_row(r, half) < n_rows) ap[(long)acc_row(r, half) * hid] = v[r];
+                    }
+                }
+            }
+        }
+        __syncthreads();
+        if (l < nwide) { float* tmp = in; in = out; out = tmp; }
+    }
+}
+
+// backward wide layers: dz[j-1] = (dz[j] W_j) * [acts[j-1] > 0] for j = nwide-1 .. 1 (backward packs)
+template <int NTW>
+__device__ __forceinline__ NextFrags bwd_next(const nlbac_mlp& net, int j, int wave, int lane) {
+    const int KC = pad8(net.hid) >> 3;
+    const int jn = j > 1 ? j - 1 : j;
+    NextFrags nx;
+    nx.KCn = nx.KCnn = KC;
+    nx.n0 = nx.nn0 = frag_ptr(net.packed, net.pb_off[jn], KC, wave, lane);
+    nx.n1 = nx.nn1 = (NTW == 2) ? frag_ptr(net.packed, net.pb_off[jn], KC, wave + 4, lane) : nx.n0;
+    return nx;
+}
+
+template <int NTW>
+__device__ __forceinline__ void bwd_prime(WaveGemm<NTW>& wg, const nlbac_mlp& net, int wave, int lane) {
+    const int nwide = net.n_layers - 1, KC = pad8(net.hid) >> 3;
+    if (nwide < 2) return;
+    const int j = nwide - 1;
+    wg.prime(frag_ptr(net.packed, net.pb_off[j], KC, wave, lane),
+             frag_ptr(net.packed, net.pb_off[j], KC, (NTW == 2) ? wave + 4 : wave, lane), KC,
+             bwd_next<NTW>(net, j, wave, lane));
+}
+
+template <int NTW>
+__device__ __forceinline__ void bwd_wide_layers(WaveGemm<NTW>& wg, const nlbac_mlp& net, bool active, int wave, int lane,
+                                                int LD, float*& in, float*& out, const float* acts_tile,
+                                                float* dz_tile, long ls, int n_rows, int row_clamp) {
+    const int hid = net.hid, KC = pad8(hid) >> 3, nwide = net.n_layers - 1, half = lane >> 5;
+    for (int j = nwide - 1; j >= 1; --j) {
+        if (active) {
+            const float4* p0 = frag_ptr(net.packed, net.pb_off[j], KC, wave, lane);
+            const float4* p1 = (NTW == 2) ? frag_ptr(net.packed, net.pb_off[j], KC, wave + 4, lane) : p0;
+            const NextFrags nx = bwd_next<NTW>(net, j, wave, lane);
+            // ReLU masks of this wave's output fragment, requested before the GEMM so they land under it
+            const float* acts = acts_tile + (long)(j - 1) * ls;
+            float av[2][16];
+#pragma unroll
+            for (int t = 0; t < NTW; ++t) {
+                const int colc = min((wave + 4 * t) * 32 + (lane & 31), hid - 1);
+#pragma unroll
+                for (int r = 0; r < 16; ++r) av[t][r] = acts[(long)min(acc_row(r, half), row_clamp) * hid + colc];
+            }
+            f32x16 acc[2];
+#pragma unroll
+            for (int r = 0; r < 16; ++r) { acc[0][r] = 0.f; acc[1][r] = 0.f; }
+            wg.run(in + (lane & 31) * LD + half * 4, p0, p1, KC, nx, acc);
+            float* dz = dz_tile ? dz_tile + (long)(j - 1) * ls : nullptr;
+#pragma unroll
+            for (int t = 0; t < NTW; ++t) {
+                const int col = (wave + 4 * t) * 32 + (lane & 31);
+                const bool colok = col < hid;
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int m = acc_row(r, half);
+                    const bool ok = colok && (m < n_rows);
+                    const float v = (ok && av[t][r] > 0.f) ? acc[t][r] : 0.f;
+                    if (dz && ok) dz[(long)m * hid + col] = v;
+                    out[m * LD + col] = v;
+                }
+            }
+        }
+        __syncthreads();
+        float* tmp = in; in = out; out = tmp;
+    }
+}

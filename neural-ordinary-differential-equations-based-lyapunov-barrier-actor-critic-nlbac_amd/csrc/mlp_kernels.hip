@@ -21,6 +21,7 @@
 //   * the skinny first-input / last-output contractions (K or N <= 16) stay
 //     on the VALU.
 #include "common.h"
+#include "mlp_device.h"
 
 struct MlpLaunch {
     nlbac_mlp net[NLBAC_MAX_NETS];
@@ -31,12 +32,6 @@ struct MlpLaunch {
     int rows_per_slab;
     long slab_stride;
 };
-
-__device__ __forceinline__ int pad8(int x) { return (x + 7) & ~7; }
-__device__ __forceinline__ int pad32(int x) { return (x + 31) & ~31; }
-
-// row of accumulator register r for lane-half h in a 32x32 MFMA result
-__device__ __forceinline__ int acc_row(int r, int h) { return (r & 3) + 8 * (r >> 2) + 4 * h; }
 
 // ---------------------------------------------------------------------------
 // weight packing
@@ -80,90 +75,31 @@ __global__ __launch_bounds__(256) void mlp_pack_kernel(const MlpLaunch L) {
 }
 
 // ---------------------------------------------------------------------------
-// C[32 x 32*NTW] += A_lds[32 x 8*KC] * Bpacked      (one wave, NTW = 1 or 2 tiles)
-// Four K-chunks of operands are kept in flight in statically indexed registers
-// (no register rotation), so the compiler emits counted s_waitcnt vmcnt(N) and
-// every B-fragment load has three chunks of MFMA time to land.
-// ---------------------------------------------------------------------------
-#define MFMA4(A, B0, B1)                                                                       \
-    acc[0] = __builtin_amdgcn_mfma_f32_32x32x2f32((A).x, (B0).x, acc[0], 0, 0, 0);             \
-    if (NTW == 2) acc[1] = __builtin_amdgcn_mfma_f32_32x32x2f32((A).x, (B1).x, acc[1], 0, 0, 0); \
-    acc[0] = __builtin_amdgcn_mfma_f32_32x32x2f32((A).y, (B0).y, acc[0], 0, 0, 0);             \
-    if (NTW == 2) acc[1] = __builtin_amdgcn_mfma_f32_32x32x2f32((A).y, (B1).y, acc[1], 0, 0, 0); \
-    acc[0] = __builtin_amdgcn_mfma_f32_32x32x2f32((A).z, (B0).z, acc[0], 0, 0, 0);             \
-    if (NTW == 2) acc[1] = __builtin_amdgcn_mfma_f32_32x32x2f32((A).z, (B1).z, acc[1], 0, 0, 0); \
-    acc[0] = __builtin_amdgcn_mfma_f32_32x32x2f32((A).w, (B0).w, acc[0], 0, 0, 0);             \
-    if (NTW == 2) acc[1] = __builtin_amdgcn_mfma_f32_32x32x2f32((A).w, (B1).w, acc[1], 0, 0, 0);
-
-template <int NTW>
-__device__ __forceinline__ void wave_gemm(const float* __restrict__ a_lds, int LD,
-                                          const float4* __restrict__ pk, int KC, int tile0,
-                                          f32x16 (&acc)[2], int lane) {
-    constexpr int D = 4;
-    const float4* p0 = pk + (long)tile0 * KC * 64 + lane;
-    const float4* p1 = pk + (long)(tile0 + 4) * KC * 64 + lane;
-    const float* arow = a_lds + (lane & 31) * LD + (lane >> 5) * 4;
-    const int last = KC - 1;
-    float4 b0[D], b1[D], a[D];
-#pragma unroll
-    for (int i = 0; i < D; ++i) {
-        const int c = min(i, last);
-        b0[i] = p0[(long)c * 64];
-        b1[i] = (NTW == 2) ? p1[(long)c * 64] : make_float4(0, 0, 0, 0);
-        a[i] = *reinterpret_cast<const float4*>(arow + c * 8);
-    }
-    int kc = 0;
-    for (; kc + D <= KC; kc += D) {
-#pragma unroll
-        for (int i = 0; i < D; ++i) {
-            MFMA4(a[i], b0[i], b1[i])
-            const int c = min(kc + i + D, last);
-            b0[i] = p0[(long)c * 64];
-            if (NTW == 2) b1[i] = p1[(long)c * 64];
-            a[i] = *reinterpret_cast<const float4*>(arow + c * 8);
-            __builtin_amdgcn_sched_barrier(0);   // keep each slot's refill right behind its MFMAs
-        }
-    }
-#pragma unroll
-    for (int i = 0; i < D - 1; ++i)
-        if (kc + i < KC) { MFMA4(a[i], b0[i], b1[i]) }
-}
-
-// skinny contraction helpers (VALU): NO outputs at once, every load unconditional
-template <int NO>
-__device__ __forceinline__ void skinny_dot(const float* __restrict__ lds_row, const float* __restrict__ W, int hid,
-                                           int part, float (&acc)[4]) {
-#pragma unroll 4
-    for (int it = 0; it < 8; ++it) {
-        const int k = part * 4 + 32 * it;
-        const bool ok = k < hid;
-        const int kk = ok ? k : 0;
-        float4 h = *reinterpret_cast<const float4*>(lds_row + kk);
-        if (!ok) h = make_float4(0, 0, 0, 0);
-#pragma unroll
-        for (int q = 0; q < NO; ++q) {
-            const float4 w = *reinterpret_cast<const float4*>(W + (long)q * hid + kk);
-            acc[q] += h.x * w.x + h.y * w.y + h.z * w.z + h.w * w.w;
-        }
-    }
-}
-
-// ---------------------------------------------------------------------------
 // forward
 // ---------------------------------------------------------------------------
+// MODE 1: every net has <= 4 column tiles (one per wave); MODE 2: every net has 8 (two per wave);
+// MODE 0: mixed / other widths (both register sets live).
+template <int MODE>
 __global__ __launch_bounds__(256, 2) void mlp_fwd_kernel(const MlpLaunch L) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     const nlbac_mlp& net = L.net[blockIdx.y];
     const nlbac_mlp_io& io = L.io[blockIdx.y];
     const int B = L.B, LD = L.ld;
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, half = lane >> 5;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int row0 = blockIdx.x * NLBAC_MLP_TILE;
-    const int hid = net.hid, NT = pad32(hid) >> 5, hidp8 = pad8(hid);
+    const int hid = net.hid, NT = pad32(hid) >> 5;
     const int nwide = net.n_layers - 1;
     const int inp = pad8(net.in_dim);
     float* in = smem;
     float* out = smem + NLBAC_MLP_TILE * LD;
 
+    const bool active = wave < NT, two = (MODE == 2) || (MODE == 0 && (wave + 4) < NT);
+    WaveGemm<(MODE == 1) ? 1 : 2> wg2;      // MODE 1 never touches wg2 / MODE 2 never touches wg1:
+    WaveGemm<1> wg1;                        // the unused one is dead code
+    if (active) {          // weights do not depend on the input: start streaming them before staging it
+        if constexpr (MODE != 1) { if (two) fwd_prime<2>(wg2, net, inp, false, wave, lane); }
+        if constexpr (MODE != 2) { if (!two) fwd_prime<1>(wg1, net, inp, false, wave, lane); }
+    }
     for (int idx = tid; idx < NLBAC_MLP_TILE * inp; idx += 256) {
         const int r = idx / inp, c = idx - r * inp, row = row0 + r;
         float v = 0.f;
@@ -175,49 +111,21 @@ __global__ __launch_bounds__(256, 2) void mlp_fwd_kernel(const MlpLaunch L) {
     }
     __syncthreads();
 
-    const bool full_tile = row0 + NLBAC_MLP_TILE <= B;
-    for (int l = 0; l < nwide; ++l) {
-        const int KC = ((l == 0) ? inp : hidp8) >> 3;
-        const float4* pk = reinterpret_cast<const float4*>(net.packed + net.pf_off[l]);
-        const float* bias = net.params + net.b_off[l];
-        float* acts = io.acts ? io.acts + (long)l * (io.acts_ls ? io.acts_ls : (long)B * hid) : nullptr;
-        if (wave < NT) {
-            f32x16 acc[2];
-#pragma unroll
-            for (int r = 0; r < 16; ++r) { acc[0][r] = 0.f; acc[1][r] = 0.f; }
-            const bool two = (wave + 4) < NT;
-            if (two) wave_gemm<2>(in, LD, pk, KC, wave, acc, lane);
-            else wave_gemm<1>(in, LD, pk, KC, wave, acc, lane);
-#pragma unroll
-            for (int t = 0; t < 2; ++t) {
-                if (t == 1 && !two) break;
-                const int col = (wave + 4 * t) * 32 + (lane & 31);
-                const float b = bias[min(col, hid - 1)];
-                const bool colok = col < hid;
-                float v[16];
-#pragma unroll
-                for (int r = 0; r < 16; ++r) {
-                    v[r] = colok ? fmaxf(acc[t][r] + b, 0.f) : 0.f;
-                    out[acc_row(r, half) * LD + col] = v[r];
-                }
-                if (acts && colok) {
-                    float* ap = acts + (long)row0 * hid + col;
-                    if (full_tile) {
-#pragma unroll
-                        for (int r = 0; r < 16; ++r) ap[(long)acc_row(r, half) * hid] = v[r];
-                    } else {
-#pragma unroll
-                        for (int r = 0; r < 16; ++r)
-                            if (row0 + acc_row(r, half) < B) ap[(long)acc_row(r, half) * hid] = v[r];
-                    }
-                }
-            }
+    {
+        const long ls = io.acts_ls ? io.acts_ls : (long)B * hid;
+        float* acts_tile = io.acts ? io.acts + (long)row0 * hid : nullptr;
+        const int n_rows = min(NLBAC_MLP_TILE, B - row0);
+        if constexpr (MODE == 2) fwd_wide_layers<2>(wg2, net, active, wave, lane, LD, inp, in, out, acts_tile, ls, n_rows, nwide, false);
+        else if constexpr (MODE == 1) fwd_wide_layers<1>(wg1, net, active, wave, lane, LD, inp, in, out, acts_tile, ls, n_rows, nwide, false);
+        else {
+            if (two) fwd_wide_layers<2>(wg2, net, active, wave, lane, LD, inp, in, out, acts_tile, ls, n_rows, nwide, false);
+            else fwd_wide_layers<1>(wg1, net, active, wave, lane, LD, inp, in, out, acts_tile, ls, n_rows, nwide, false);
         }
-        __syncthreads();
-        float* tmp = in; in = out; out = tmp;
     }
 
-    // skinny output layer on the VALU: 8 lanes per sample row
+    // skinny output layer on the VALU: 8 lanes per sample row + shuffle reduction.  (With 1-4 outputs and
+    // hid = 256 this keeps all 256 threads busy; the one-dot-per-thread form used by the fused RK kernel
+    // measured 20 % slower here.)
     {
         const float* W = net.params + net.w_off[nwide];
         const float* bias = net.params + net.b_off[nwide];
@@ -284,20 +192,28 @@ __device__ __forceinline__ void dx_dot(const float* __restrict__ lds_row, const 
     }
 }
 
+template <int MODE>
 __global__ __launch_bounds__(256, 2) void mlp_bwd_data_kernel(const MlpLaunch L) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     const nlbac_mlp& net = L.net[blockIdx.y];
     const nlbac_mlp_io& io = L.io[blockIdx.y];
     const int B = L.B, LD = L.ld;
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, half = lane >> 5;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int row0 = blockIdx.x * NLBAC_MLP_TILE;
-    const int hid = net.hid, NT = pad32(hid) >> 5, hidp8 = pad8(hid), hidp32 = NT * 32;
+    const int hid = net.hid, NT = pad32(hid) >> 5, hidp32 = NT * 32;
     const int nwide = net.n_layers - 1;
     const long ls = io.acts_ls ? io.acts_ls : (long)B * hid;
     float* in = smem;
     float* out = smem + NLBAC_MLP_TILE * LD;
     float* sdy = smem + 2 * NLBAC_MLP_TILE * LD;   // [32][16]
 
+    const bool active = wave < NT, two = (MODE == 2) || (MODE == 0 && (wave + 4) < NT);
+    WaveGemm<(MODE == 1) ? 1 : 2> wg2;      // MODE 1 never touches wg2 / MODE 2 never touches wg1:
+    WaveGemm<1> wg1;                        // the unused one is dead code
+    if (active) {
+        if constexpr (MODE != 1) { if (two) bwd_prime<2>(wg2, net, wave, lane); }
+        if constexpr (MODE != 2) { if (!two) bwd_prime<1>(wg1, net, wave, lane); }
+    }
     for (int idx = tid; idx < NLBAC_MLP_TILE * 16; idx += 256) {
         const int r = idx >> 4, c = idx & 15, row = row0 + r;
         sdy[idx] = (row < B && c < net.out_dim) ? io.dy[(long)row * io.dy_ld + c] : 0.f;
@@ -336,44 +252,16 @@ __global__ __launch_bounds__(256, 2) void mlp_bwd_data_kernel(const MlpLaunch L)
     }
     __syncthreads();
 
-    for (int j = nwide - 1; j >= 1; --j) {
-        const int KC = hidp8 >> 3;
-        const float4* pk = reinterpret_cast<const float4*>(net.packed + net.pb_off[j]);
-        const float* acts = io.acts + (long)(j - 1) * ls;
-        float* dz = io.dz ? io.dz + (long)(j - 1) * ls : nullptr;
-        if (wave < NT) {
-            const bool two = (wave + 4) < NT;
-            // ReLU masks of this wave's output fragment, requested before the GEMM so they land under it
-            float av[2][16];
-#pragma unroll
-            for (int t = 0; t < 2; ++t) {
-                const int colc = min((wave + 4 * t) * 32 + (lane & 31), hid - 1);
-#pragma unroll
-                for (int r = 0; r < 16; ++r)
-                    av[t][r] = (t == 0 || two) ? acts[(long)min(row0 + acc_row(r, half), B - 1) * hid + colc] : 0.f;
-            }
-            f32x16 acc[2];
-#pragma unroll
-            for (int r = 0; r < 16; ++r) { acc[0][r] = 0.f; acc[1][r] = 0.f; }
-            if (two) wave_gemm<2>(in, LD, pk, KC, wave, acc, lane);
-            else wave_gemm<1>(in, LD, pk, KC, wave, acc, lane);
-#pragma unroll
-            for (int t = 0; t < 2; ++t) {
-                if (t == 1 && !two) break;
-                const int col = (wave + 4 * t) * 32 + (lane & 31);
-                const bool colok = col < hid;
-#pragma unroll
-                for (int r = 0; r < 16; ++r) {
-                    const int m = acc_row(r, half);
-                    const bool ok = colok && (row0 + m < B);
-                    const float v = (ok && av[t][r] > 0.f) ? acc[t][r] : 0.f;
-                    if (dz && ok) dz[(long)(row0 + m) * hid + col] = v;
-                    out[m * LD + col] = v;
-                }
-            }
+    {
+        const int n_rows = min(NLBAC_MLP_TILE, B - row0);
+        const float* acts_tile = io.acts + (long)row0 * hid;
+        float* dz_tile = io.dz ? io.dz + (long)row0 * hid : nullptr;
+        if constexpr (MODE == 2) bwd_wide_layers<2>(wg2, net, active, wave, lane, LD, in, out, acts_tile, dz_tile, ls, n_rows, n_rows - 1);
+        else if constexpr (MODE == 1) bwd_wide_layers<1>(wg1, net, active, wave, lane, LD, in, out, acts_tile, dz_tile, ls, n_rows, n_rows - 1);
+        else {
+            if (two) bwd_wide_layers<2>(wg2, net, active, wave, lane, LD, in, out, acts_tile, dz_tile, ls, n_rows, n_rows - 1);
+            else bwd_wide_layers<1>(wg1, net, active, wave, lane, LD, in, out, acts_tile, dz_tile, ls, n_rows, n_rows - 1);
         }
-        __syncthreads();
-        float* tmp = in; in = out; out = tmp;
     }
 
     if (io.dx) {   // dx[m][i] = sum_n dz0[m][n] W0[n][i]
@@ -626,6 +514,17 @@ static int check_net(const nlbac_mlp& n, const char* who) {
     return 0;
 }
 
+// 1: all nets <= 4 column tiles, 2: all nets exactly 8, 0: anything else
+static int tile_mode(const nlbac_mlp* nets, int n_nets) {
+    bool all_le4 = true, all_8 = true;
+    for (int i = 0; i < n_nets; ++i) {
+        const int nt = (nets[i].hid + 31) >> 5;
+        all_le4 = all_le4 && nt <= 4;
+        all_8 = all_8 && nt == 8;
+    }
+    return all_le4 ? 1 : (all_8 ? 2 : 0);
+}
+
 static int fill_launch(MlpLaunch& L, const nlbac_mlp* nets, const nlbac_mlp_io* io, int n_nets, int B, const char* who) {
     NLBAC_REQUIRE(n_nets >= 1 && n_nets <= NLBAC_MAX_NETS, "%s: n_nets %d out of [1,%d]", who, n_nets, NLBAC_MAX_NETS);
     NLBAC_REQUIRE(B >= 1, "%s: B must be >= 1", who);
@@ -679,7 +578,12 @@ extern "C" int nlbac_mlp_fwd(const nlbac_mlp* nets, const nlbac_mlp_io* io, int 
                       "nlbac_mlp_fwd: net %d input dims %d+%d != in_dim %d", i, io[i].x0_dim, io[i].x1_dim, nets[i].in_dim);
     }
     const size_t lds = (size_t)2 * NLBAC_MLP_TILE * L.ld * sizeof(float);
-    hipLaunchKernelGGL(mlp_fwd_kernel, dim3(nlbac_ceil_div(B, NLBAC_MLP_TILE), n_nets), dim3(256), lds, (hipStream_t)s, L);
+    const dim3 grid(nlbac_ceil_div(B, NLBAC_MLP_TILE), n_nets);
+    switch (tile_mode(nets, n_nets)) {
+        case 1: hipLaunchKernelGGL(mlp_fwd_kernel<1>, grid, dim3(256), lds, (hipStream_t)s, L); break;
+        case 2: hipLaunchKernelGGL(mlp_fwd_kernel<2>, grid, dim3(256), lds, (hipStream_t)s, L); break;
+        default: hipLaunchKernelGGL(mlp_fwd_kernel<0>, grid, dim3(256), lds, (hipStream_t)s, L);
+    }
     NLBAC_CHECK_LAUNCH("nlbac_mlp_fwd");
     return 0;
 }
@@ -690,7 +594,12 @@ extern "C" int nlbac_mlp_bwd_data(const nlbac_mlp* nets, const nlbac_mlp_io* io,
     for (int i = 0; i < n_nets; ++i)
         NLBAC_REQUIRE(io[i].dy && io[i].acts, "nlbac_mlp_bwd_data: net %d needs dy and acts", i);
     const size_t lds = ((size_t)2 * NLBAC_MLP_TILE * L.ld + NLBAC_MLP_TILE * 16) * sizeof(float);
-    hipLaunchKernelGGL(mlp_bwd_data_kernel, dim3(nlbac_ceil_div(B, NLBAC_MLP_TILE), n_nets), dim3(256), lds, (hipStream_t)s, L);
+    const dim3 grid(nlbac_ceil_div(B, NLBAC_MLP_TILE), n_nets);
+    switch (tile_mode(nets, n_nets)) {
+        case 1: hipLaunchKernelGGL(mlp_bwd_data_kernel<1>, grid, dim3(256), lds, (hipStream_t)s, L); break;
+        case 2: hipLaunchKernelGGL(mlp_bwd_data_kernel<2>, grid, dim3(256), lds, (hipStream_t)s, L); break;
+        default: hipLaunchKernelGGL(mlp_bwd_data_kernel<0>, grid, dim3(256), lds, (hipStream_t)s, L);
+    }
     NLBAC_CHECK_LAUNCH("nlbac_mlp_bwd_data");
     return 0;
 }

@@ -1,0 +1,240 @@
+// Fused Runge-Kutta step of the control-affine NODE  dx/dt = f(x) + g(x) u :
+// ONE launch evaluates all requested stages of an explicit RK step for a tile of
+// 32 rows — stage algebra, f_net and g_net (run concurrently by two 4-wave groups
+// of the workgroup), k = f + g u, and the step's output combinations.
+//
+// Replaces, per stage, the launch triple  rk_combine -> mlp_fwd[f,g] -> affine_fwd
+// of the un-fused path (kept in ode_kernels.hip / mlp_kernels.hip; the backward
+// still runs per stage and reads the buffers this kernel saves).  Reference call
+// sites: torchdiffeq.odeint at U/sac_cbf_clf/sac_cbf_clf.py:453,577 and
+// U/sac_cbf_clf/model.py:252 over NeuralODEModel.forward (model.py:208-217).
+//
+// CDNA4 mapping: 512-thread workgroup = 8 waves = 2 per SIMD; waves 0-3 own f_net,
+// waves 4-7 own g_net, each group with its own LDS ping-pong activation tile, so the
+// two nets' layer chains overlap on every SIMD (one wave's MFMAs under the other's
+// LDS/L2 latency).  Weights are NOT staged through LDS: each wave owns distinct
+// output columns, so a fragment-packed, L2-resident copy read straight into
+// registers (1 KiB per wave-instruction, 4 chunks in flight) moves every byte once
+// per wave; f_net+g_net packed are 340 KB and would not fit the 160 KB LDS anyway.
+// Stage derivatives of the tile stay in LDS across stages (sK); everything the
+// backward needs (Y, K, g(x), post-ReLU activations) is written once, coalesced.
+#include "mlp_device.h"
+
+#define RK_MAX_STAGES 8
+#define RK_MAX_NS 8
+#define RK_MAX_NU 4
+#define RK_MAX_GOUT (RK_MAX_NS * RK_MAX_NU)
+
+struct NodeRkLaunch {
+    nlbac_mlp net[2];                 // f, g
+    const float* y0; const float* u;
+    int n, rpp, n_s, n_u;
+    int stage_begin, stage_end, S_total;
+    float beta[RK_MAX_STAGES][RK_MAX_STAGES];
+    float c_out[RK_MAX_STAGES]; int n_out;
+    float c_err[RK_MAX_STAGES]; int n_err;
+    const double* h_dev; int h_stride; float h_val[8];
+    float* K; float* Y; float* G;
+    float* acts[2]; long acts_ls[2];
+    float* out; float* err;
+    int ld;
+    int sw_off1;                      // float offset of g_net's output-layer block behind f_net's in LDS
+};
+
+template <int MODE>   // 1: both nets <= 4 column tiles, 2: both 8, 0: mixed (see mlp_kernels.hip)
+__global__ __launch_bounds__(512) void node_rk_fwd_kernel(const NodeRkLaunch L) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    const int tid = threadIdx.x, grp = tid >> 8, t = tid & 255;
+    const int lane = t & 63, wave = t >> 6;
+    const int n = L.n, ns = L.n_s, nu = L.n_u, LD = L.ld;
+    const int row0 = blockIdx.x * NLBAC_MLP_TILE;
+    const nlbac_mlp& net = L.net[grp];
+    const int hid = net.hid, NT = pad32(hid) >> 5, hidp8 = pad8(hid);
+    const int nwide_own = net.n_layers - 1;
+    (void)hidp8;
+    const int nwide_max = max(L.net[0].n_layers, L.net[1].n_layers) - 1;
+    const int inp = pad8(ns);
+    const int n_rows = min(NLBAC_MLP_TILE, n - row0);
+    const bool active = wave < NT, two = (MODE == 2) || (MODE == 0 && (wave + 4) < NT);
+    WaveGemm<(MODE == 1) ? 1 : 2> wg2;
+    WaveGemm<1> wg1;
+    if (active) {
+        if constexpr (MODE != 1) { if (two) fwd_prime<2>(wg2, net, inp, (L.stage_end - L.stage_begin > 1), wave, lane); }
+        if constexpr (MODE != 2) { if (!two) fwd_prime<1>(wg1, net, inp, (L.stage_end - L.stage_begin > 1), wave, lane); }
+    }
+
+    // LDS carve (all offsets multiples of 16 B)
+    float* buf = smem + grp * 2 * NLBAC_MLP_TILE * LD;           // this group's ping-pong tiles
+    float* sK = smem + 4 * NLBAC_MLP_TILE * LD;                  // [stage][32][8]
+    float* sY0 = sK + RK_MAX_STAGES * NLBAC_MLP_TILE * RK_MAX_NS;   // [32][8]
+    float* sU = sY0 + NLBAC_MLP_TILE * RK_MAX_NS;                // [32][4]
+    float* sH = sU + NLBAC_MLP_TILE * RK_MAX_NU;                 // [32] step size per row
+    float* sF = sH + NLBAC_MLP_TILE;                             // [32][8]   f(x)
+    float* sG = sF + NLBAC_MLP_TILE * RK_MAX_NS;                 // [32][32]  g(x)
+    // output-layer weights + bias of both nets: constant over the stages, read once per launch
+    float* sW = sG + NLBAC_MLP_TILE * RK_MAX_GOUT + (grp ? L.sw_off1 : 0);   // [out_dim][hid] then [out_dim]
+    {
+        const float* W = net.params + net.w_off[nwide_own];
+        const float* bsrc = net.params + net.b_off[nwide_own];
+        const int nw = net.out_dim * hid;
+        for (int idx = t; idx < nw; idx += 256) sW[idx] = W[idx];
+        for (int idx = t; idx < net.out_dim; idx += 256) sW[nw + idx] = bsrc[idx];
+    }
+
+    // ---- tile constants: y0, u, h, already-known stages (FSAL / f0 from an earlier launch)
+    for (int idx = tid; idx < NLBAC_MLP_TILE * RK_MAX_NS; idx += 512) {
+        const int m = idx >> 3, c = idx & 7, row = row0 + m;
+        sY0[idx] = (row < n && c < ns) ? L.y0[(long)row * ns + c] : 0.f;
+    }
+    for (int idx = tid; idx < NLBAC_MLP_TILE * RK_MAX_NU; idx += 512) {
+        const int m = idx >> 2, c = idx & 3, row = row0 + m;
+        sU[idx] = (row < n && c < nu) ? L.u[(long)row * nu + c] : 0.f;
+    }
+    if (tid < NLBAC_MLP_TILE) {
+        const int p = min(row0 + tid, n - 1) / L.rpp;
+        sH[tid] = L.h_dev ? (float)L.h_dev[(long)p * L.h_stride] : L.h_val[p];
+    }
+    for (int idx = tid; idx < L.stage_begin * NLBAC_MLP_TILE * RK_MAX_NS; idx += 512) {
+        const int j = idx / (NLBAC_MLP_TILE * RK_MAX_NS), rem = idx - j * NLBAC_MLP_TILE * RK_MAX_NS;
+        const int m = rem >> 3, c = rem & 7, row = row0 + m;
+        sK[idx] = (row < n && c < ns) ? L.K[((long)j * n + row) * ns + c] : 0.f;
+    }
+    __syncthreads();
+
+    for (int st = L.stage_begin; st < L.stage_end; ++st) {
+        // ---- stage input  Y_st = y0 + h sum_j beta[st][j] K_j   (same op order as rk_combine_kernel)
+        float* in = buf;
+        float* out = buf + NLBAC_MLP_TILE * LD;
+        for (int idx = t; idx < NLBAC_MLP_TILE * inp; idx += 256) {
+            const int m = idx / inp, c = idx - m * inp;
+            float a = 0.f;
+            if (c < ns) {
+                a = sY0[m * RK_MAX_NS + c];
+                const float h = sH[m];
+                for (int j = 0; j < st; ++j)
+                    if (L.beta[st][j] != 0.f) a = a + sK[(j * NLBAC_MLP_TILE + m) * RK_MAX_NS + c] * (L.beta[st][j] * h);
+                if (grp == 0 && row0 + m < n) L.Y[((long)st * n + row0 + m) * ns + c] = a;
+            }
+            in[m * LD + c] = a;
+        }
+        __syncthreads();
+
+        // ---- wide layers of f_net (group 0) and g_net (group 1), in lock step; the weight stream of each
+        //      wave runs on across layers and stages (WaveGemm), only the LDS operands wait for the barriers
+        {
+            float* acts_tile = L.acts[grp] ? L.acts[grp] + ((long)st * n + row0) * hid : nullptr;
+            const bool wrap = st + 1 < L.stage_end;
+            if constexpr (MODE == 2)
+                fwd_wide_layers<2>(wg2, net, active, wave, lane, LD, inp, in, out, acts_tile, L.acts_ls[grp], n_rows, nwide_max, wrap);
+            else if constexpr (MODE == 1)
+                fwd_wide_layers<1>(wg1, net, active, wave, lane, LD, inp, in, out, acts_tile, L.acts_ls[grp], n_rows, nwide_max, wrap);
+            else {
+                if (two) fwd_wide_layers<2>(wg2, net, active, wave, lane, LD, inp, in, out, acts_tile, L.acts_ls[grp], n_rows, nwide_max, wrap);
+                else fwd_wide_layers<1>(wg1, net, active, wave, lane, LD, inp, in, out, acts_tile, L.acts_ls[grp], n_rows, nwide_max, wrap);
+            }
+        }
+
+        // ---- skinny output layers -> sF / sG (and g(x) to global for the backward)
+#ifndef EXP_NO_SKINNY
+        for (int idx = t; idx < NLBAC_MLP_TILE * net.out_dim; idx += 256) {
+            const int m = idx & 31, o = idx >> 5, row = row0 + m;
+            const float val = skinny_row_dot(in + m * LD, sW + o * hid, hid) + sW[net.out_dim * hid + o];
+            (grp == 0 ? sF + m * RK_MAX_NS : sG + m * RK_MAX_GOUT)[o] = val;
+            if (grp == 1 && row < n) L.G[((long)st * n + row) * (ns * nu) + o] = val;
+        }
+#endif
+        __syncthreads();
+
+        // ---- k = f + g u   (same op order as affine_fwd_kernel)
+        for (int idx = tid; idx < NLBAC_MLP_TILE * ns; idx += 512) {
+            const int m = idx / ns, r = idx - m * ns;
+            float a = sF[m * RK_MAX_NS + r];
+            for (int c = 0; c < nu; ++c) a += sG[m * RK_MAX_GOUT + r * nu + c] * sU[m * RK_MAX_NU + c];
+            sK[(st * NLBAC_MLP_TILE + m) * RK_MAX_NS + r] = a;
+            if (row0 + m < n) L.K[((long)st * n + row0 + m) * ns + r] = a;
+        }
+        __syncthreads();
+    }
+
+    // ---- step outputs
+    for (int idx = tid; idx < NLBAC_MLP_TILE * ns; idx += 512) {
+        const int m = idx / ns, r = idx - m * ns, row = row0 + m;
+        if (row >= n) continue;
+        const float h = sH[m];
+        if (L.out) {
+            float a = sY0[m * RK_MAX_NS + r];
+            for (int j = 0; j < L.n_out; ++j)
+                if (L.c_out[j] != 0.f) a = a + sK[(j * NLBAC_MLP_TILE + m) * RK_MAX_NS + r] * (L.c_out[j] * h);
+            L.out[(long)row * ns + r] = a;
+        }
+        if (L.err) {
+            float a = 0.f;
+            for (int j = 0; j < L.n_err; ++j)
+                if (L.c_err[j] != 0.f) a = a + sK[(j * NLBAC_MLP_TILE + m) * RK_MAX_NS + r] * (L.c_err[j] * h);
+            L.err[(long)row * ns + r] = a;
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------
+extern "C" int nlbac_node_rk_fwd(const nlbac_mlp* f, const nlbac_mlp* g, const float* y0, const float* u, int P,
+                                 int rows_per_problem, int stage_begin, int stage_end, int n_stages_total,
+                                 const float* beta /* [n_stages_total][n_stages_total] row-major */,
+                                 const float* c_out, int n_out, const float* c_err, int n_err,
+                                 const float* h_host, const double* h_dev, int h_dev_stride, float* K, float* Y,
+                                 float* G, float* acts_f, long acts_f_ls, float* acts_g, long acts_g_ls, float* out,
+                                 float* err, nlbac_stream_t s) {
+    NLBAC_REQUIRE(f && g && y0 && u && K && Y && G, "nlbac_node_rk_fwd: null pointer");
+    NLBAC_REQUIRE(P >= 1 && P <= 8 && rows_per_problem >= 1, "nlbac_node_rk_fwd: bad problem sizes");
+    NLBAC_REQUIRE(n_stages_total >= 1 && n_stages_total <= RK_MAX_STAGES && stage_begin >= 0 &&
+                      stage_begin < stage_end && stage_end <= n_stages_total, "nlbac_node_rk_fwd: bad stage range");
+    NLBAC_REQUIRE(f->in_dim == g->in_dim && f->in_dim <= RK_MAX_NS && f->out_dim == f->in_dim &&
+                      g->out_dim % f->in_dim == 0 && g->out_dim / f->in_dim <= RK_MAX_NU &&
+                      g->out_dim <= RK_MAX_GOUT, "nlbac_node_rk_fwd: f/g shapes are not a control-affine field");
+    NLBAC_REQUIRE(f->hid % 4 == 0 && g->hid % 4 == 0 && f->hid <= 256 && g->hid <= 256, "nlbac_node_rk_fwd: bad hid");
+    NLBAC_REQUIRE(h_dev || h_host, "nlbac_node_rk_fwd: no step size");
+    NLBAC_REQUIRE(n_out <= n_stages_total && n_err <= n_stages_total, "nlbac_node_rk_fwd: bad coefficient counts");
+    NodeRkLaunch L;
+    memset(&L, 0, sizeof(L));
+    L.net[0] = *f; L.net[1] = *g;
+    L.y0 = y0; L.u = u;
+    L.n = P * rows_per_problem; L.rpp = rows_per_problem;
+    L.n_s = f->in_dim; L.n_u = g->out_dim / f->in_dim;
+    L.stage_begin = stage_begin; L.stage_end = stage_end; L.S_total = n_stages_total;
+    if (beta)
+        for (int i = 0; i < n_stages_total; ++i)
+            for (int j = 0; j < n_stages_total; ++j) L.beta[i][j] = beta[i * n_stages_total + j];
+    for (int j = 0; j < n_out; ++j) L.c_out[j] = c_out[j];
+    for (int j = 0; j < n_err; ++j) L.c_err[j] = c_err[j];
+    L.n_out = out ? n_out : 0; L.n_err = err ? n_err : 0;
+    L.h_dev = h_dev; L.h_stride = h_dev_stride;
+    for (int p = 0; p < P; ++p) L.h_val[p] = h_host ? h_host[p] : 0.f;
+    L.K = K; L.Y = Y; L.G = G;
+    L.acts[0] = acts_f; L.acts[1] = acts_g; L.acts_ls[0] = acts_f_ls; L.acts_ls[1] = acts_g_ls;
+    L.out = out; L.err = err;
+    int w = ((f->hid > g->hid ? f->hid : g->hid) + 31) & ~31;
+    L.ld = w + 4;
+    L.sw_off1 = ((f->out_dim * (f->hid + 1)) + 3) & ~3;
+    const int sw_total = L.sw_off1 + (((g->out_dim * (g->hid + 1)) + 3) & ~3);
+    const size_t lds = ((size_t)4 * NLBAC_MLP_TILE * L.ld + RK_MAX_STAGES * NLBAC_MLP_TILE * RK_MAX_NS +
+                        NLBAC_MLP_TILE * (RK_MAX_NS + RK_MAX_NU + 1 + RK_MAX_NS + RK_MAX_GOUT) + sw_total) *
+                       sizeof(float);
+    NLBAC_REQUIRE(lds <= 160 * 1024, "nlbac_node_rk_fwd: LDS budget exceeded (%zu B)", lds);
+    static bool attr_set = false;
+    if (!attr_set) {
+        (void)hipFuncSetAttribute((const void*)node_rk_fwd_kernel<0>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        (void)hipFuncSetAttribute((const void*)node_rk_fwd_kernel<1>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        (void)hipFuncSetAttribute((const void*)node_rk_fwd_kernel<2>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        attr_set = true;
+    }
+    const int ntf = (f->hid + 31) >> 5, ntg = (g->hid + 31) >> 5;
+    const int mode = (ntf <= 4 && ntg <= 4) ? 1 : ((ntf == 8 && ntg == 8) ? 2 : 0);
+    const dim3 grid(nlbac_ceil_div(L.n, NLBAC_MLP_TILE));
+    switch (mode) {
+        case 1: hipLaunchKernelGGL(node_rk_fwd_kernel<1>, grid, dim3(512), lds, (hipStream_t)s, L); break;
+        case 2: hipLaunchKernelGGL(node_rk_fwd_kernel<2>, grid, dim3(512), lds, (hipStream_t)s, L); break;
+        default: hipLaunchKernelGGL(node_rk_fwd_kernel<0>, grid, dim3(512), lds, (hipStream_t)s, L);
+    }
+    NLBAC_CHECK_LAUNCH("nlbac_node_rk_fwd");
+    return 0;
+}

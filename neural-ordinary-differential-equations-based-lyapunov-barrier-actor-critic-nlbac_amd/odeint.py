@@ -90,6 +90,7 @@ class AffineNodeSolver:
         self.nfe = 0
         self._net_arr = None
         self._coefs = {}
+        self.fused = True      # one nlbac_node_rk_fwd launch per RK step instead of 3 launches per stage
         self._children = {}    # per-problem solvers for batches whose problems diverge (dopri5)
         self.stats = dict(solves=0, single_step=0, multi_attempt=0, split=0)
         self.comm = None       # nlbac_amd.parallel.DataParallel: global dopri5 error norms
@@ -143,6 +144,36 @@ class AffineNodeSolver:
                                                S * n * f.hid, S * n * g.hid)
         self._eval(ws.Y[st], u, n, ws.K[st], ws.gout[st], io)
 
+    def _beta(self, method):
+        key = ("beta", method)
+        b = self._coefs.get(key)
+        if b is None:
+            rows = TABLEAU[method]["beta"]
+            S = len(rows) + 1
+            flat = [0.0] * (S * S)
+            for i, r in enumerate(rows):
+                for j, v in enumerate(r):
+                    flat[(i + 1) * S + j] = v
+            b = self._coefs[key] = (fptr(*flat), S)
+        return b
+
+    def _rk_fused(self, ws, y0, u, P, rpp, method, st0, st1, h_host=None, h_dev=None, c_out=None, out=None,
+                  c_err=None, err=None, save_acts=True):
+        """One launch for stages [st0, st1) of ``method`` on the step workspace ``ws`` (nlbac_node_rk_fwd)."""
+        beta, S = self._beta(method)
+        f, g = self.f, self.g
+        n = P * rpp
+        _lib.call("nlbac_node_rk_fwd", C.byref(f.desc), C.byref(g.desc), y0.data_ptr(), u.data_ptr(), P, rpp,
+                  st0, st1, S, beta, c_out, len(c_out) if c_out is not None else 0,
+                  c_err, len(c_err) if c_err is not None else 0,
+                  fptr(*h_host) if h_host is not None else None, h_dev, _lib.DOPRI_CTL if h_dev else 0,
+                  ws.K.data_ptr(), ws.Y.data_ptr(), ws.gout.data_ptr(),
+                  ws.acts_f.data_ptr() if save_acts else None, ws.S * n * f.hid,
+                  ws.acts_g.data_ptr() if save_acts else None, ws.S * n * g.hid,
+                  out.data_ptr() if out is not None else None, err.data_ptr() if err is not None else None,
+                  stream_ptr())
+        self.nfe += st1 - st0
+
     def _combine(self, y0, K, n_k, coef, h, P, rpp, out):
         _lib.call("nlbac_rk_combine", y0.data_ptr() if y0 is not None else None, K.data_ptr(), n_k,
                   fptr(*coef), fptr(*h), None, 0, P, rpp, self.n_s, out.data_ptr(), stream_ptr())
@@ -167,6 +198,11 @@ class AffineNodeSolver:
             S = len(tab["c_sol"])
             ws = self._step_ws(n, S, 0)
             h = [float(dt)] * P
+            if self.fused:
+                self._rk_fused(ws, y0, u, P, rpp, method, 0, S, h_host=h, c_out=fptr(*tab["c_sol"]), out=ws.y1)
+                self.ctx["steps"].append(dict(ws=ws, h=h, first=True))
+                self.ctx["out"] = ws.y1
+                return
             ws.Y[0].copy_(y0)
             for st in range(S):
                 self._stage_eval(ws, st, u)
@@ -225,12 +261,15 @@ class AffineNodeSolver:
         part = self._buf("part", P, nblk, 2)
         ctl = self._ctl(P)
         h_dev = ctl.data_ptr()                    # C_H
-        for st in range(1, S):
-            _lib.call("nlbac_rk_combine", cur_y0.data_ptr(), ws.K.data_ptr(), st, self._coef(("b", st)), None,
-                      h_dev, _lib.DOPRI_CTL, P, rpp, ns, ws.Y[st].data_ptr(), s)
-            self._stage_eval(ws, st, u)
-        _lib.call("nlbac_rk_combine", None, ws.K.data_ptr(), S, self._coef("err"), None, h_dev, _lib.DOPRI_CTL,
-                  P, rpp, ns, ws.err.data_ptr(), s)
+        if self.fused:
+            self._rk_fused(ws, cur_y0, u, P, rpp, "dopri5", 1, S, h_dev=h_dev, c_err=self._coef("err"), err=ws.err)
+        else:
+            for st in range(1, S):
+                _lib.call("nlbac_rk_combine", cur_y0.data_ptr(), ws.K.data_ptr(), st, self._coef(("b", st)), None,
+                          h_dev, _lib.DOPRI_CTL, P, rpp, ns, ws.Y[st].data_ptr(), s)
+                self._stage_eval(ws, st, u)
+            _lib.call("nlbac_rk_combine", None, ws.K.data_ptr(), S, self._coef("err"), None, h_dev, _lib.DOPRI_CTL,
+                      P, rpp, ns, ws.err.data_ptr(), s)
         _lib.call("nlbac_dopri_norm_partials", ws.err.data_ptr(), None, cur_y0.data_ptr(), ws.Y[6].data_ptr(), None,
                   2, ctx["rtol"], ctx["atol"], ns, nu, rpp, P, part.data_ptr(), s)
         self._control(part, nblk, 2, P, rpp, ctx["t_end"], ctl)
@@ -252,8 +291,11 @@ class AffineNodeSolver:
         ws = self._step_ws(n, S, 0)
         rtol, atol, t_end = ctx["rtol"], ctx["atol"], ctx["t_end"]
         # f0 and the initial step size (Hairer's rule)
-        ws.Y[0].copy_(y0)
-        self._stage_eval(ws, 0, u)
+        if self.fused:
+            self._rk_fused(ws, y0, u, P, rpp, "dopri5", 0, 1, h_dev=ctl.data_ptr())
+        else:
+            ws.Y[0].copy_(y0)
+            self._stage_eval(ws, 0, u)
         _lib.call("nlbac_dopri_norm_partials", ws.K[0].data_ptr(), None, y0.data_ptr(), None, u.data_ptr(), 0,
                   rtol, atol, ns, nu, rpp, P, part.data_ptr(), s)
         self._control(part, nblk, 0, P, rpp, t_end, ctl)
@@ -261,12 +303,17 @@ class AffineNodeSolver:
         h0_dev = ctl.data_ptr() + 6 * 8           # C_H0
         _lib.call("nlbac_rk_combine", y0.data_ptr(), ws.K.data_ptr(), 1, self._coef("one"), None, h0_dev,
                   _lib.DOPRI_CTL, P, rpp, ns, ytmp.data_ptr(), s)
-        if "tmp_io" not in self._scratch:
-            self._scratch["tmp_io"] = {}
-        tio = self._scratch["tmp_io"].get(n)
-        if tio is None:
-            tio = self._scratch["tmp_io"][n] = self._eval_io(ytmp, gtmp)
-        self._eval(ytmp, u, n, ktmp, gtmp, tio)
+        if self.fused:
+            tws = self._step_ws(n, 1, "tmp")
+            self._rk_fused(tws, ytmp, u, P, rpp, "euler", 0, 1, h_host=[0.0] * P, save_acts=False)
+            ktmp = tws.K[0]
+        else:
+            if "tmp_io" not in self._scratch:
+                self._scratch["tmp_io"] = {}
+            tio = self._scratch["tmp_io"].get(n)
+            if tio is None:
+                tio = self._scratch["tmp_io"][n] = self._eval_io(ytmp, gtmp)
+            self._eval(ytmp, u, n, ktmp, gtmp, tio)
         _lib.call("nlbac_dopri_norm_partials", ktmp.data_ptr(), ws.K[0].data_ptr(), y0.data_ptr(), None, None, 1,
                   rtol, atol, ns, nu, rpp, P, part.data_ptr(), s)
         self._control(part, nblk, 1, P, rpp, t_end, ctl)
@@ -347,7 +394,7 @@ class AffineNodeSolver:
             if p not in self._children:
                 self._children[p] = AffineNodeSolver(self.node, self.device)
             k = self._children[p]
-            k.comm = self.comm
+            k.comm, k.fused = self.comm, self.fused
             rows = slice(p * rpp, (p + 1) * rpp)
             o = k.forward(ctx["y0"][rows], ctx["u"][rows], 1, rpp, "dopri5", ctx["t_end"], ctx["atol"], ctx["rtol"])
             out[rows].copy_(o)

@@ -161,3 +161,27 @@ def test_hipgraph_replay_is_bit_identical_to_eager(solver):
         assert torch.equal(ar0.theta, ar1.theta) and torch.equal(ar0.m, ar1.m) and torch.equal(ar0.v, ar1.v)
     assert torch.equal(a0.ar_c.target, a1.ar_c.target)
     assert torch.equal(a0.sc, a1.sc)
+
+
+@pytest.mark.parametrize("solver", ["euler", "rk4", "dopri5"])
+@pytest.mark.parametrize("rows", [96, 77])
+def test_fused_rk_step_kernel_matches_per_stage_launches(solver, rows):
+    """nlbac_node_rk_fwd (one launch per RK step) against the un-fused stage-by-stage path: same rollout,
+    same saved stage buffers, same action gradient (2 problems x rows, ragged last tile at rows=77)."""
+    from nlbac_amd.odeint import AffineNodeSolver
+    agent, env = make_agent(128, 256, 0, solver)
+    node = agent.neural_ode_model
+    g = torch.Generator().manual_seed(rows)
+    y0 = torch.cat([torch.rand(2 * rows, 2, generator=g) * 4 - 2, torch.rand(2 * rows, 1, generator=g) * 6 - 3], 1).cuda()
+    u = (torch.rand(2 * rows, 2, generator=g) * 2 - 1).cuda() * torch.tensor([3.5, 12.0]).cuda()
+    dout = torch.randn(2 * rows, 3, generator=g).cuda()
+    res = []
+    for fused in (False, True):
+        sol = AffineNodeSolver(node, "cuda")
+        sol.fused = fused
+        out = sol.forward(y0, u, 2, rows, solver, 0.02).clone()
+        du, dy0 = sol.backward(dout, need_du=True, need_dy0=True)
+        ws = sol.ctx["steps"][-1]["ws"]
+        res.append((out, du.clone(), dy0.clone(), ws.K.clone(), ws.Y.clone(), ws.gout.clone(), ws.acts_f.clone()))
+    for a, b, name in zip(res[0], res[1], ("out", "du", "dy0", "K", "Y", "g(x)", "acts_f")):
+        vec_close(b.cpu().numpy(), a.cpu().numpy(), 2e-6, "fused vs staged: " + name)
