@@ -299,8 +299,11 @@ __global__ __launch_bounds__(256, 2) void mlp_bwd_data_kernel(const MlpLaunch L)
 // Both operands are staged through LDS in 16-row chunks; each of the 4 waves
 // owns one 32x32 MFMA tile.
 // ---------------------------------------------------------------------------
-#define DW_CHUNK 16
+#define DW_CHUNK 32
 #define DW_LDS_LD 68
+__device__ __forceinline__ float4 sel4(bool c, const float4 v) {   // component selects stay in registers
+    return make_float4(c ? v.x : 0.f, c ? v.y : 0.f, c ? v.z : 0.f, c ? v.w : 0.f);
+}
 __global__ __launch_bounds__(256) void mlp_bwd_wide_kernel(const MlpLaunch L) {
     __shared__ __attribute__((aligned(16))) float sA[2][DW_CHUNK][DW_LDS_LD];
     __shared__ __attribute__((aligned(16))) float sB[2][DW_CHUNK][DW_LDS_LD];
@@ -320,43 +323,57 @@ __global__ __launch_bounds__(256) void mlp_bwd_wide_kernel(const MlpLaunch L) {
     const long ls = io.acts_ls ? io.acts_ls : (long)B * hid;
     const float* dz = io.dz + (long)j * ls;
     const float* at = io.acts + (long)(j - 1) * ls;
-    const int lr = tid >> 4, lc = (tid & 15) * 4;
+    const int lr = tid >> 4, lc = (tid & 15) * 4;        // this thread stages rows lr and lr+16 of a chunk
+    const bool a_ok = n0 + lc < hid, b_ok = k0 + lc < hid;
+    const float* pa = dz + n0 + (a_ok ? lc : 0);
+    const float* pb = at + k0 + (b_ok ? lc : 0);
 
     f32x16 acc;
 #pragma unroll
     for (int r = 0; r < 16; ++r) acc[r] = 0.f;
 
-    auto load = [&](int r0, float4& va, float4& vb) {
-        const int row = r0 + lr;
-        va = make_float4(0, 0, 0, 0); vb = va;
-        if (row < re) {
-            if (n0 + lc < hid) va = *reinterpret_cast<const float4*>(dz + (long)row * hid + n0 + lc);
-            if (k0 + lc < hid) vb = *reinterpret_cast<const float4*>(at + (long)row * hid + k0 + lc);
-        }
-    };
-    float4 va, vb;
-    int buf = 0;
-    if (rb < re) {
-        load(rb, va, vb);
-        *reinterpret_cast<float4*>(&sA[0][lr][lc]) = va;
-        *reinterpret_cast<float4*>(&sB[0][lr][lc]) = vb;
+    // operand rows are fetched two chunks ahead (registers) and written to LDS one chunk ahead, so a
+    // load has ~2 chunks (2 x 16 MFMAs per wave) to land; out-of-range rows/columns are clamped then zeroed
+#define DW_LOAD(r0_, A0, A1, B0, B1)                                                        \
+    {                                                                                       \
+        const int ra_ = min((r0_) + lr, re - 1), rb_ = min((r0_) + lr + 16, re - 1);        \
+        A0 = *reinterpret_cast<const float4*>(pa + (long)ra_ * hid);                        \
+        A1 = *reinterpret_cast<const float4*>(pa + (long)rb_ * hid);                        \
+        B0 = *reinterpret_cast<const float4*>(pb + (long)ra_ * hid);                        \
+        B1 = *reinterpret_cast<const float4*>(pb + (long)rb_ * hid);                        \
     }
-    __syncthreads();
-    for (int r0 = rb; r0 < re; r0 += DW_CHUNK) {
-        const bool more = (r0 + DW_CHUNK) < re;
-        if (more) load(r0 + DW_CHUNK, va, vb);
-#pragma unroll
-        for (int bb = 0; bb < DW_CHUNK / 2; ++bb) {
-            const float a = sA[buf][2 * bb + half][wn * 32 + (lane & 31)];
-            const float b = sB[buf][2 * bb + half][wk * 32 + (lane & 31)];
-            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, acc, 0, 0, 0);
-        }
-        if (more) {
-            *reinterpret_cast<float4*>(&sA[buf ^ 1][lr][lc]) = va;
-            *reinterpret_cast<float4*>(&sB[buf ^ 1][lr][lc]) = vb;
-        }
+#define DW_STAGE(r0_, A0, A1, B0, B1, buf_)                                                 \
+    {                                                                                       \
+        const bool lo_ = (r0_) + lr < re, hi_ = (r0_) + lr + 16 < re;                       \
+        *reinterpret_cast<float4*>(&sA[buf_][lr][lc]) = sel4(a_ok && lo_, A0);              \
+        *reinterpret_cast<float4*>(&sA[buf_][lr + 16][lc]) = sel4(a_ok && hi_, A1);         \
+        *reinterpret_cast<float4*>(&sB[buf_][lr][lc]) = sel4(b_ok && lo_, B0);              \
+        *reinterpret_cast<float4*>(&sB[buf_][lr + 16][lc]) = sel4(b_ok && hi_, B1);         \
+    }
+    if (rb < re) {
+        float4 c_a0, c_a1, c_b0, c_b1;      // chunk +1 (to be staged next)
+        float4 n_a0, n_a1, n_b0, n_b1;      // chunk +2 (in flight)
+        DW_LOAD(rb, c_a0, c_a1, c_b0, c_b1)
+        DW_STAGE(rb, c_a0, c_a1, c_b0, c_b1, 0)
+        DW_LOAD(rb + DW_CHUNK, c_a0, c_a1, c_b0, c_b1)
         __syncthreads();
-        buf ^= 1;
+        int buf = 0;
+        for (int r0 = rb; r0 < re; r0 += DW_CHUNK) {
+            const bool more = (r0 + DW_CHUNK) < re;
+            if (more) DW_LOAD(r0 + 2 * DW_CHUNK, n_a0, n_a1, n_b0, n_b1)
+#pragma unroll
+            for (int bb = 0; bb < DW_CHUNK / 2; ++bb) {
+                const float a = sA[buf][2 * bb + half][wn * 32 + (lane & 31)];
+                const float b = sB[buf][2 * bb + half][wk * 32 + (lane & 31)];
+                acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, acc, 0, 0, 0);
+            }
+            if (more) {
+                DW_STAGE(r0 + DW_CHUNK, c_a0, c_a1, c_b0, c_b1, buf ^ 1)
+                c_a0 = n_a0; c_a1 = n_a1; c_b0 = n_b0; c_b1 = n_b1;
+            }
+            __syncthreads();
+            buf ^= 1;
+        }
     }
     float* g = io.grad + (long)slab * L.slab_stride + net.w_off[j];
     const int k = k0 + wk * 32 + (lane & 31);

@@ -144,7 +144,8 @@ class SAC_CBF_CLF(object):
         dev = self.device
         self.ar_c = Arena(dev, self.n_grad_slabs, with_target=True)     # critic + Lyapunov (lr 4e-4)
         self.ar_a = Arena(dev, self.n_grad_slabs)                        # policies + log alphas (lr args.lr)
-        self.ar_n = Arena(dev, self.n_grad_slabs * 2)                    # NODE (lr 1e-3)
+        self.n_fit_slabs = int(getattr(args, "fit_grad_slabs", 16))      # per accepted RK step of a NODE fit
+        self.ar_n = Arena(dev, self.n_fit_slabs * 2)                     # NODE (lr 1e-3)
         self.h_q1, self.h_q2 = self.critic.attach(self.ar_c)
         (self.h_l,) = self.lyapunovNet.attach(self.ar_c)
         (self.h_p,) = self.policy.attach(self.ar_a)
@@ -380,7 +381,7 @@ class SAC_CBF_CLF(object):
         _lib.call("nlbac_sum_partials", w["part"].data_ptr(), nblk, 1, 1.0 / (NG * 3),
                   self.sc.data_ptr() + 4 * SC.SC_NODE_LOSS, s)
         self.fit_solver.backward(w["dpred"], need_du=False, need_params=True)
-        used = self.fit_solver.accumulate_param_grads(self.ar_n, self.n_grad_slabs)
+        used = self.fit_solver.accumulate_param_grads(self.ar_n, self.n_fit_slabs)
         self._adam(self.ar_n, 1e-3, used, extra=self.sc[SC.SC_NODE_LOSS:SC.SC_NODE_LOSS + 1])
         pack([self.h_f, self.h_g])
 
