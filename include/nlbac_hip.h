@@ -219,6 +219,18 @@ int nlbac_node_rk_fwd(const nlbac_mlp *f, const nlbac_mlp *g, const float *y0, c
                       const float *h_host, const double *h_dev, int h_dev_stride, float *K, float *Y,
                       float *G, float *acts_f, long acts_f_ls, float *acts_g, long acts_g_ls, float *out,
                       float *err, nlbac_stream_t s);
+/* Fused backward of the same step (exact gradient of the discrete step): processes stages st_hi-1 .. st_lo.
+ * In/out dK [n_stages_total][n][n_s] holds dL/dK_j (initialised by the caller from the step's output
+ * combination / interpolant); dYup (may be NULL) is dL/d(stage input) of the last stage (FSAL y1);
+ * dy0 (+= when dy0_in) and du (+= when du_acc) receive the gradients w.r.t. the step's initial state and the
+ * actions.  dx_stage0: also differentiate stage 0 w.r.t. its input (needed for dy0).  When dz_f/dz_g/dG are
+ * given, every stage's pre-activation grads and d g(x) are kept for nlbac_mlp_bwd_weights. */
+int nlbac_node_rk_bwd(const nlbac_mlp *f, const nlbac_mlp *g, const float *u, const float *G, int P,
+                      int rows_per_problem, int n_stages_total, int st_lo, int st_hi, int dx_stage0,
+                      const float *beta, const float *h_host, const double *h_dev, int h_dev_stride,
+                      const float *acts_f, long acts_f_ls, const float *acts_g, long acts_g_ls,
+                      float *dz_f, float *dz_g, float *dG, float *dK, const float *dYup, float *dy0,
+                      int dy0_in, float *du, int du_acc, nlbac_stream_t s);
 /* dopri5 step control on the device.  ctl: per problem NLBAC_DOPRI_CTL doubles
  * {h, t, ratio, accept, done, x, h0, d0, d1, d2, n_steps, h_used}.
  * norm partials [P][ceil(rows/256)][2]; mode 0: (y0/scale, f0/scale) with a=f0;

@@ -203,11 +203,26 @@ __device__ __forceinline__ void fwd_wide_layers(WaveGemm<NTW>& wg, const nlbac_m
     }
 }
 
+// top (skinny) layer of the backward: s[m] += sum_o dy[m][o] W_last[o][k] for this thread's column k
+template <int NO>
+__device__ __forceinline__ void top_layer_bwd(const float* __restrict__ sdy, const float* __restrict__ W, int hid,
+                                              int k, float (&s)[NLBAC_MLP_TILE]) {
+    float w[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int q = 0; q < NO; ++q) w[q] = W[(long)q * hid + k];
+#pragma unroll
+    for (int m = 0; m < NLBAC_MLP_TILE; ++m) {
+        const float4 d = *reinterpret_cast<const float4*>(sdy + m * 16);
+        s[m] += d.x * w[0] + d.y * w[1] + d.z * w[2] + d.w * w[3];
+    }
+}
+
 // backward wide layers: dz[j-1] = (dz[j] W_j) * [acts[j-1] > 0] for j = nwide-1 .. 1 (backward packs)
+// (wrap: after layer 1 the stream restarts at layer nwide-1 — the next RK stage of a fused backward)
 template <int NTW>
-__device__ __forceinline__ NextFrags bwd_next(const nlbac_mlp& net, int j, int wave, int lane) {
+__device__ __forceinline__ NextFrags bwd_next(const nlbac_mlp& net, int j, int wave, int lane, bool wrap = false) {
     const int KC = pad8(net.hid) >> 3;
-    const int jn = j > 1 ? j - 1 : j;
+    const int jn = j > 1 ? j - 1 : (wrap ? net.n_layers - 2 : j);
     NextFrags nx;
     nx.KCn = nx.KCnn = KC;
     nx.n0 = nx.nn0 = frag_ptr(net.packed, net.pb_off[jn], KC, wave, lane);
@@ -216,25 +231,29 @@ __device__ __forceinline__ NextFrags bwd_next(const nlbac_mlp& net, int j, int w
 }
 
 template <int NTW>
-__device__ __forceinline__ void bwd_prime(WaveGemm<NTW>& wg, const nlbac_mlp& net, int wave, int lane) {
+__device__ __forceinline__ void bwd_prime(WaveGemm<NTW>& wg, const nlbac_mlp& net, int wave, int lane,
+                                          bool wrap = false) {
     const int nwide = net.n_layers - 1, KC = pad8(net.hid) >> 3;
     if (nwide < 2) return;
     const int j = nwide - 1;
     wg.prime(frag_ptr(net.packed, net.pb_off[j], KC, wave, lane),
              frag_ptr(net.packed, net.pb_off[j], KC, (NTW == 2) ? wave + 4 : wave, lane), KC,
-             bwd_next<NTW>(net, j, wave, lane));
+             bwd_next<NTW>(net, j, wave, lane, wrap));
 }
 
 template <int NTW>
 __device__ __forceinline__ void bwd_wide_layers(WaveGemm<NTW>& wg, const nlbac_mlp& net, bool active, int wave, int lane,
                                                 int LD, float*& in, float*& out, const float* acts_tile,
-                                                float* dz_tile, long ls, int n_rows, int row_clamp) {
+                                                float* dz_tile, long ls, int n_rows, int row_clamp,
+                                                int n_run = -1, bool wrap = false) {
     const int hid = net.hid, KC = pad8(hid) >> 3, nwide = net.n_layers - 1, half = lane >> 5;
-    for (int j = nwide - 1; j >= 1; --j) {
-        if (active) {
+    if (n_run < 0) n_run = nwide - 1;          // lock-step iterations (>= nwide-1 when groups differ in depth)
+    for (int it = 0; it < n_run; ++it) {
+        const int j = nwide - 1 - it;
+        if (j >= 1 && active) {
             const float4* p0 = frag_ptr(net.packed, net.pb_off[j], KC, wave, lane);
             const float4* p1 = (NTW == 2) ? frag_ptr(net.packed, net.pb_off[j], KC, wave + 4, lane) : p0;
-            const NextFrags nx = bwd_next<NTW>(net, j, wave, lane);
+            const NextFrags nx = bwd_next<NTW>(net, j, wave, lane, wrap);
             // ReLU masks of this wave's output fragment, requested before the GEMM so they land under it
             const float* acts = acts_tile + (long)(j - 1) * ls;
             float av[2][16];
@@ -264,6 +283,6 @@ __device__ __forceinline__ void bwd_wide_layers(WaveGemm<NTW>& wg, const nlbac_m
             }
         }
         __syncthreads();
-        float* tmp = in; in = out; out = tmp;
+        if (j >= 1) { float* tmp = in; in = out; out = tmp; }
     }
 }

@@ -161,19 +161,6 @@ __global__ __launch_bounds__(256, 2) void mlp_fwd_kernel(const MlpLaunch L) {
 //   dz[j-1]     = (dz[j] W_j) * [acts[j-1] > 0]            (MFMA, backward pack)
 //   dx          =  dz[0] W_0                                (VALU)
 // ---------------------------------------------------------------------------
-template <int NO>
-__device__ __forceinline__ void top_layer_bwd(const float* __restrict__ sdy, const float* __restrict__ W, int hid,
-                                              int k, float (&s)[NLBAC_MLP_TILE]) {
-    float w[4] = {0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-    for (int q = 0; q < NO; ++q) w[q] = W[(long)q * hid + k];
-#pragma unroll
-    for (int m = 0; m < NLBAC_MLP_TILE; ++m) {
-        const float4 d = *reinterpret_cast<const float4*>(sdy + m * 16);
-        s[m] += d.x * w[0] + d.y * w[1] + d.z * w[2] + d.w * w[3];
-    }
-}
-
 template <int NI>
 __device__ __forceinline__ void dx_dot(const float* __restrict__ lds_row, const float* __restrict__ W, int hid,
                                        int idim, int part, float (&acc)[4]) {

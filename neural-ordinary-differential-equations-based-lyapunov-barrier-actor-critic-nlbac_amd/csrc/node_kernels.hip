@@ -44,7 +44,8 @@ struct NodeRkLaunch {
 template <int MODE>   // 1: both nets <= 4 column tiles, 2: both 8, 0: mixed (see mlp_kernels.hip)
 __global__ __launch_bounds__(512) void node_rk_fwd_kernel(const NodeRkLaunch L) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
-    const int tid = threadIdx.x, grp = tid >> 8, t = tid & 255;
+    const int tid = threadIdx.x, t = tid & 255;
+    const int grp = __builtin_amdgcn_readfirstlane(tid >> 8);   // wave-uniform: lets L.net[grp] etc. be scalar loads
     const int lane = t & 63, wave = t >> 6;
     const int n = L.n, ns = L.n_s, nu = L.n_u, LD = L.ld;
     const int row0 = blockIdx.x * NLBAC_MLP_TILE;
@@ -174,6 +175,268 @@ __global__ __launch_bounds__(512) void node_rk_fwd_kernel(const NodeRkLaunch L) 
             L.err[(long)row * ns + r] = a;
         }
     }
+}
+
+// ---------------------------------------------------------------------------
+// Fused backward of one RK step (discretise-then-differentiate, i.e. what autograd does through
+// torchdiffeq's fixed-step / dopri5 stages): for st = st_hi-1 .. st_lo
+//     dk = dK[st];  du += g(Y_st)^T dk;  df = dk, dg = dk u^T
+//     dX = J_f^T df + J_g^T dg          (f_net / g_net data backward, two wave groups)
+//     dY = [dYup at the last stage] + dX;  dy0 += dY;  dK[j] += beta[st][j] h dY  (j < st)
+// Replaces the per-stage launch triple affine_bwd -> mlp_bwd_data[f,g] -> rk_stage_bwd.
+// With dz/dG given it also leaves every stage's pre-activation grads for nlbac_mlp_bwd_weights (NODE fit).
+// ---------------------------------------------------------------------------
+struct NodeRkBwdLaunch {
+    nlbac_mlp net[2];
+    const float* u; const float* G;
+    const float* acts[2]; long acts_ls[2];
+    float* dz[2]; float* dG;
+    float* dK; const float* dYup;
+    float* dy0; int dy0_in;
+    float* du; int du_acc;
+    int n, rpp, n_s, n_u, S_total, st_lo, st_hi, dx_stage0;
+    float beta[RK_MAX_STAGES][RK_MAX_STAGES];
+    const double* h_dev; int h_stride; float h_val[8];
+    int ld, sw_off1;
+};
+
+template <int MODE>
+__global__ __launch_bounds__(512) void node_rk_bwd_kernel(const NodeRkBwdLaunch L) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    const int tid = threadIdx.x, t = tid & 255;
+    const int grp = __builtin_amdgcn_readfirstlane(tid >> 8);   // wave-uniform: lets L.net[grp] etc. be scalar loads
+    const int lane = t & 63, wave = t >> 6;
+    const int n = L.n, ns = L.n_s, nu = L.n_u, LD = L.ld, gout = ns * nu;
+    const int row0 = blockIdx.x * NLBAC_MLP_TILE;
+    const nlbac_mlp& net = L.net[grp];
+    const int hid = net.hid, NT = pad32(hid) >> 5, hidp32 = NT * 32;
+    const int nwide = net.n_layers - 1;
+    const int n_run = max(L.net[0].n_layers, L.net[1].n_layers) - 2;
+    const int n_rows = min(NLBAC_MLP_TILE, n - row0);
+    const bool keep_dz = L.dz[0] != nullptr;
+    const bool active = wave < NT, two = (MODE == 2) || (MODE == 0 && (wave + 4) < NT);
+
+    float* buf = smem + grp * 2 * NLBAC_MLP_TILE * LD;
+    float* sDK = smem + 4 * NLBAC_MLP_TILE * LD;                    // [stage][32][8]
+    float* sU = sDK + RK_MAX_STAGES * NLBAC_MLP_TILE * RK_MAX_NS;   // [32][4]
+    float* sH = sU + NLBAC_MLP_TILE * RK_MAX_NU;                    // [32]
+    float* sDY0 = sH + NLBAC_MLP_TILE;                              // [32][8]  running dy0
+    float* sDU = sDY0 + NLBAC_MLP_TILE * RK_MAX_NS;                 // [32][4]  running du
+    float* sDX = sDU + NLBAC_MLP_TILE * RK_MAX_NU;                  // [2][32][8]
+    float* sdy_all = sDX + 2 * NLBAC_MLP_TILE * RK_MAX_NS;          // [2][32][16] output-layer grads of f / g
+    float* sdy = sdy_all + grp * NLBAC_MLP_TILE * 16;
+    float* sW = sdy_all + 2 * NLBAC_MLP_TILE * 16 + (grp ? L.sw_off1 : 0);   // W_last [out][hid], then W_0^T [in][hid]
+    float* sW0t = sW + net.out_dim * hid;
+
+    const int st_lo = L.st_lo;
+    const bool stage0_data = L.dx_stage0 || keep_dz;
+#define has_data(st_) ((st_) >= st_lo && ((st_) > 0 || stage0_data))
+
+    WaveGemm<(MODE == 1) ? 1 : 2> wg2;
+    WaveGemm<1> wg1;
+    if (active && nwide >= 2 && has_data(L.st_hi - 1)) {
+        const bool wrap0 = has_data(L.st_hi - 2);
+        if constexpr (MODE != 1) { if (two) bwd_prime<2>(wg2, net, wave, lane, wrap0); }
+        if constexpr (MODE != 2) { if (!two) bwd_prime<1>(wg1, net, wave, lane, wrap0); }
+    }
+    {   // constants of the launch -> LDS
+        const float* Wl = net.params + net.w_off[nwide];
+        const float* W0 = net.params + net.w_off[0];
+        for (int idx = t; idx < net.out_dim * hid; idx += 256) sW[idx] = Wl[idx];
+        for (int idx = t; idx < net.in_dim * hid; idx += 256) {
+            const int i = idx / hid, k = idx - i * hid;
+            sW0t[idx] = W0[(long)k * net.in_dim + i];
+        }
+    }
+    for (int idx = tid; idx < NLBAC_MLP_TILE * RK_MAX_NU; idx += 512) {
+        const int m = idx >> 2, c = idx & 3, row = row0 + m;
+        const bool ok = row < n && c < nu;
+        sU[idx] = ok ? L.u[(long)row * nu + c] : 0.f;
+        sDU[idx] = (ok && L.du && L.du_acc) ? L.du[(long)row * nu + c] : 0.f;
+    }
+    for (int idx = tid; idx < NLBAC_MLP_TILE * RK_MAX_NS; idx += 512) {
+        const int m = idx >> 3, c = idx & 7, row = row0 + m;
+        sDY0[idx] = (row < n && c < ns && L.dy0 && L.dy0_in) ? L.dy0[(long)row * ns + c] : 0.f;
+    }
+    if (tid < NLBAC_MLP_TILE) {
+        const int p = min(row0 + tid, n - 1) / L.rpp;
+        sH[tid] = L.h_dev ? (float)L.h_dev[(long)p * L.h_stride] : L.h_val[p];
+    }
+    for (int idx = tid; idx < L.st_hi * NLBAC_MLP_TILE * RK_MAX_NS; idx += 512) {
+        const int j = idx / (NLBAC_MLP_TILE * RK_MAX_NS), rem = idx - j * NLBAC_MLP_TILE * RK_MAX_NS;
+        const int m = rem >> 3, c = rem & 7, row = row0 + m;
+        sDK[idx] = (row < n && c < ns) ? L.dK[((long)j * n + row) * ns + c] : 0.f;
+    }
+    __syncthreads();
+
+    for (int st = L.st_hi - 1; st >= L.st_lo; --st) {
+        const bool data = has_data(st);
+        // ---- output-layer gradients of both nets, du
+        const int k = t, kc = min(k, hid - 1);
+        const float* acts_tile = L.acts[grp] + ((long)st * n + row0) * hid;
+        for (int idx = tid; idx < 2 * NLBAC_MLP_TILE * 16; idx += 512) {
+            const int gsel = idx >> 9, rem = idx & 511, m = rem >> 4, o = rem & 15, row = row0 + m;
+            float v = 0.f;
+            if (gsel == 0) {
+                if (o < ns) v = sDK[(st * NLBAC_MLP_TILE + m) * RK_MAX_NS + o];
+            } else if (o < gout) {
+                v = sDK[(st * NLBAC_MLP_TILE + m) * RK_MAX_NS + o / nu] * sU[m * RK_MAX_NU + o % nu];
+                if (L.dG && row < n) L.dG[((long)st * n + row) * gout + o] = v;
+            }
+            sdy_all[idx] = v;
+        }
+        if (L.du)
+            for (int idx = tid; idx < NLBAC_MLP_TILE * nu; idx += 512) {
+                const int m = idx / nu, c = idx - m * nu, row = min(row0 + m, n - 1);
+                float a = 0.f;
+                for (int r = 0; r < ns; ++r)
+                    a += L.G[((long)st * n + row) * gout + r * nu + c] * sDK[(st * NLBAC_MLP_TILE + m) * RK_MAX_NS + r];
+                sDU[m * RK_MAX_NU + c] = sDU[m * RK_MAX_NU + c] + 1.0f * a;
+            }
+        if (!data) continue;              // uniform: nothing below is needed for this stage
+        __syncthreads();
+
+        float* in = buf;
+        float* out = buf + NLBAC_MLP_TILE * LD;
+        {   // top (skinny) layer: thread = hidden column (ReLU masks requested first, they land under the dots)
+            float av[NLBAC_MLP_TILE];
+            const float* atop = acts_tile + (long)(nwide - 1) * L.acts_ls[grp] + kc;
+#pragma unroll
+            for (int m = 0; m < NLBAC_MLP_TILE; ++m) av[m] = atop[(long)min(m, n_rows - 1) * hid];
+            float s[NLBAC_MLP_TILE];
+#pragma unroll
+            for (int m = 0; m < NLBAC_MLP_TILE; ++m) s[m] = 0.f;
+            for (int o0 = 0; o0 < net.out_dim; o0 += 4) {
+                const int no = min(4, net.out_dim - o0);
+                const float* Wo = sW + o0 * hid + kc;
+                if (no == 1) top_layer_bwd<1>(sdy + o0, Wo, hid, 0, s);
+                else if (no == 2) top_layer_bwd<2>(sdy + o0, Wo, hid, 0, s);
+                else if (no == 3) top_layer_bwd<3>(sdy + o0, Wo, hid, 0, s);
+                else top_layer_bwd<4>(sdy + o0, Wo, hid, 0, s);
+            }
+            float* dz = keep_dz ? L.dz[grp] + (long)(nwide - 1) * L.acts_ls[grp] + ((long)st * n + row0) * hid : nullptr;
+            if (k < hidp32) {
+                const bool colok = k < hid;
+#pragma unroll
+                for (int m = 0; m < NLBAC_MLP_TILE; ++m) {
+                    const bool ok = colok && (m < n_rows);
+                    const float v = (ok && av[m] > 0.f) ? s[m] : 0.f;
+                    if (dz && ok) dz[(long)m * hid + k] = v;
+                    in[m * LD + k] = v;
+                }
+            }
+        }
+        __syncthreads();
+
+        {
+            float* dz_tile = keep_dz ? L.dz[grp] + ((long)st * n + row0) * hid : nullptr;
+            const bool wrap = has_data(st - 1);
+            if constexpr (MODE == 2)
+                bwd_wide_layers<2>(wg2, net, active, wave, lane, LD, in, out, acts_tile, dz_tile, L.acts_ls[grp], n_rows, n_rows - 1, n_run, wrap);
+            else if constexpr (MODE == 1)
+                bwd_wide_layers<1>(wg1, net, active, wave, lane, LD, in, out, acts_tile, dz_tile, L.acts_ls[grp], n_rows, n_rows - 1, n_run, wrap);
+            else {
+                if (two) bwd_wide_layers<2>(wg2, net, active, wave, lane, LD, in, out, acts_tile, dz_tile, L.acts_ls[grp], n_rows, n_rows - 1, n_run, wrap);
+                else bwd_wide_layers<1>(wg1, net, active, wave, lane, LD, in, out, acts_tile, dz_tile, L.acts_ls[grp], n_rows, n_rows - 1, n_run, wrap);
+            }
+        }
+        if (st == 0 && !L.dx_stage0) continue;       // only the dz of stage 0 were wanted
+
+        // ---- dX = dz0 W_0 (one dot product per thread), then the stage algebra
+        for (int idx = t; idx < NLBAC_MLP_TILE * ns; idx += 256) {
+            const int m = idx & 31, i = idx >> 5;
+            sDX[(grp * NLBAC_MLP_TILE + m) * RK_MAX_NS + i] = skinny_row_dot(in + m * LD, sW0t + i * hid, hid);
+        }
+        __syncthreads();
+        for (int idx = tid; idx < NLBAC_MLP_TILE * ns; idx += 512) {
+            const int m = idx / ns, c = idx - m * ns, row = row0 + m;
+            float d = (L.dYup && st == L.S_total - 1 && row < n) ? L.dYup[(long)row * ns + c] : 0.f;
+            d += sDX[m * RK_MAX_NS + c];
+            d += sDX[(NLBAC_MLP_TILE + m) * RK_MAX_NS + c];
+            sDY0[m * RK_MAX_NS + c] = sDY0[m * RK_MAX_NS + c] + d;
+            const float h = sH[m];
+            for (int j = 0; j < st; ++j)
+                if (L.beta[st][j] != 0.f) sDK[(j * NLBAC_MLP_TILE + m) * RK_MAX_NS + c] += (L.beta[st][j] * h) * d;
+        }
+        __syncthreads();
+    }
+    __syncthreads();
+
+    for (int idx = tid; idx < L.st_hi * NLBAC_MLP_TILE * ns; idx += 512) {
+        const int j = idx / (NLBAC_MLP_TILE * ns), rem = idx - j * NLBAC_MLP_TILE * ns;
+        const int m = rem / ns, c = rem - m * ns, row = row0 + m;
+        if (row < n) L.dK[((long)j * n + row) * ns + c] = sDK[(j * NLBAC_MLP_TILE + m) * RK_MAX_NS + c];
+    }
+    if (L.dy0)
+        for (int idx = tid; idx < NLBAC_MLP_TILE * ns; idx += 512) {
+            const int m = idx / ns, c = idx - m * ns, row = row0 + m;
+            if (row < n) L.dy0[(long)row * ns + c] = sDY0[m * RK_MAX_NS + c];
+        }
+    if (L.du)
+        for (int idx = tid; idx < NLBAC_MLP_TILE * nu; idx += 512) {
+            const int m = idx / nu, c = idx - m * nu, row = row0 + m;
+            if (row < n) L.du[(long)row * nu + c] = sDU[m * RK_MAX_NU + c];
+        }
+#undef has_data
+}
+
+extern "C" int nlbac_node_rk_bwd(const nlbac_mlp* f, const nlbac_mlp* g, const float* u, const float* G, int P,
+                                 int rows_per_problem, int n_stages_total, int st_lo, int st_hi, int dx_stage0,
+                                 const float* beta, const float* h_host, const double* h_dev, int h_dev_stride,
+                                 const float* acts_f, long acts_f_ls, const float* acts_g, long acts_g_ls,
+                                 float* dz_f, float* dz_g, float* dG, float* dK, const float* dYup, float* dy0,
+                                 int dy0_in, float* du, int du_acc, nlbac_stream_t s) {
+    NLBAC_REQUIRE(f && g && u && G && acts_f && acts_g && dK, "nlbac_node_rk_bwd: null pointer");
+    NLBAC_REQUIRE(P >= 1 && P <= 8 && rows_per_problem >= 1, "nlbac_node_rk_bwd: bad problem sizes");
+    NLBAC_REQUIRE(n_stages_total >= 1 && n_stages_total <= RK_MAX_STAGES && st_lo >= 0 && st_lo < st_hi &&
+                      st_hi <= n_stages_total, "nlbac_node_rk_bwd: bad stage range");
+    NLBAC_REQUIRE(f->in_dim == g->in_dim && f->in_dim <= RK_MAX_NS && f->out_dim == f->in_dim &&
+                      g->out_dim % f->in_dim == 0 && g->out_dim / f->in_dim <= RK_MAX_NU && g->out_dim <= 16,
+                  "nlbac_node_rk_bwd: f/g shapes are not a supported control-affine field");
+    NLBAC_REQUIRE(f->hid % 4 == 0 && g->hid % 4 == 0 && f->hid <= 256 && g->hid <= 256, "nlbac_node_rk_bwd: bad hid");
+    NLBAC_REQUIRE((dz_f == nullptr) == (dz_g == nullptr) && (dz_f == nullptr) == (dG == nullptr),
+                  "nlbac_node_rk_bwd: dz_f, dz_g and dG go together");
+    NLBAC_REQUIRE(h_dev || h_host, "nlbac_node_rk_bwd: no step size");
+    NodeRkBwdLaunch L;
+    memset(&L, 0, sizeof(L));
+    L.net[0] = *f; L.net[1] = *g;
+    L.u = u; L.G = G;
+    L.acts[0] = acts_f; L.acts[1] = acts_g; L.acts_ls[0] = acts_f_ls; L.acts_ls[1] = acts_g_ls;
+    L.dz[0] = dz_f; L.dz[1] = dz_g; L.dG = dG;
+    L.dK = dK; L.dYup = dYup; L.dy0 = dy0; L.dy0_in = dy0_in; L.du = du; L.du_acc = du_acc;
+    L.n = P * rows_per_problem; L.rpp = rows_per_problem;
+    L.n_s = f->in_dim; L.n_u = g->out_dim / f->in_dim;
+    L.S_total = n_stages_total; L.st_lo = st_lo; L.st_hi = st_hi; L.dx_stage0 = dx_stage0;
+    if (beta)
+        for (int i = 0; i < n_stages_total; ++i)
+            for (int j = 0; j < n_stages_total; ++j) L.beta[i][j] = beta[i * n_stages_total + j];
+    L.h_dev = h_dev; L.h_stride = h_dev_stride;
+    for (int p = 0; p < P; ++p) L.h_val[p] = h_host ? h_host[p] : 0.f;
+    int w = ((f->hid > g->hid ? f->hid : g->hid) + 31) & ~31;
+    L.ld = w + 4;
+    L.sw_off1 = (((f->out_dim + f->in_dim) * f->hid) + 3) & ~3;
+    const int sw_total = L.sw_off1 + ((((g->out_dim + g->in_dim) * g->hid) + 3) & ~3);
+    const size_t lds = ((size_t)4 * NLBAC_MLP_TILE * L.ld + RK_MAX_STAGES * NLBAC_MLP_TILE * RK_MAX_NS +
+                        NLBAC_MLP_TILE * (RK_MAX_NU + 1 + RK_MAX_NS + RK_MAX_NU + 2 * RK_MAX_NS + 2 * 16) + sw_total) *
+                       sizeof(float);
+    NLBAC_REQUIRE(lds <= 160 * 1024, "nlbac_node_rk_bwd: LDS budget exceeded (%zu B)", lds);
+    static bool attr_set = false;
+    if (!attr_set) {
+        (void)hipFuncSetAttribute((const void*)node_rk_bwd_kernel<0>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        (void)hipFuncSetAttribute((const void*)node_rk_bwd_kernel<1>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        (void)hipFuncSetAttribute((const void*)node_rk_bwd_kernel<2>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        attr_set = true;
+    }
+    const int ntf = (f->hid + 31) >> 5, ntg = (g->hid + 31) >> 5;
+    const int mode = (ntf <= 4 && ntg <= 4) ? 1 : ((ntf == 8 && ntg == 8) ? 2 : 0);
+    const dim3 grid(nlbac_ceil_div(L.n, NLBAC_MLP_TILE));
+    switch (mode) {
+        case 1: hipLaunchKernelGGL(node_rk_bwd_kernel<1>, grid, dim3(512), lds, (hipStream_t)s, L); break;
+        case 2: hipLaunchKernelGGL(node_rk_bwd_kernel<2>, grid, dim3(512), lds, (hipStream_t)s, L); break;
+        default: hipLaunchKernelGGL(node_rk_bwd_kernel<0>, grid, dim3(512), lds, (hipStream_t)s, L);
+    }
+    NLBAC_CHECK_LAUNCH("nlbac_node_rk_bwd");
+    return 0;
 }
 
 // ---------------------------------------------------------------------------

@@ -460,6 +460,19 @@ class AffineNodeSolver:
                 _lib.call("nlbac_rk_stage_bwd", dout.data_ptr(), None, None, 0, S, fptr(*tab["c_sol"]), h_host,
                           None, 0, P, rpp, ns, ws.dK.data_ptr(), ws.dy0.data_ptr(), 0, s)
                 top_up = None
+            if self.fused:
+                beta_arr, S_tab = self._beta(method)
+                f, g = self.f, self.g
+                _lib.call("nlbac_node_rk_bwd", C.byref(f.desc), C.byref(g.desc), u.data_ptr(), ws.gout.data_ptr(), P, rpp,
+                          S, 0 if first_eval else 1, S, 1 if need_dy0 else 0, beta_arr, h_host, h_dev, h_stride,
+                          ws.acts_f.data_ptr(), S * ws.n * f.hid, ws.acts_g.data_ptr(), S * ws.n * g.hid,
+                          ws.dz_f.data_ptr() if need_params else None, ws.dz_g.data_ptr() if need_params else None,
+                          ws.dG.data_ptr() if need_params else None, ws.dK.data_ptr(),
+                          top_up.data_ptr() if top_up is not None else None, ws.dy0.data_ptr(), 1,
+                          du.data_ptr() if du is not None else None, 1, s)
+                dy_carry = ws.dy0
+                dk_carry = ws.dK[0]
+                continue
             for st in range(S - 1, -1, -1):
                 if st == 0 and not first_eval:
                     break                  # FSAL alias of the previous step's last stage
