@@ -57,6 +57,17 @@ def _layer_macs(net):
 
 
 def launch_flops(name, args):
+    if name == "nlbac_node_rk_fwd":       # (f, g, y0, u, P, rpp, st0, st1, ...): stages x rows x NODE eval
+        f, g, P, rpp, st0, st1 = args[0]._obj, args[1]._obj, args[4], args[5], args[6], args[7]
+        return 2 * P * rpp * (st1 - st0) * (sum(_layer_macs(f)) + sum(_layer_macs(g)) + g.out_dim)
+    if name == "nlbac_node_rk_bwd":       # (f, g, u, G, P, rpp, S, st_lo, st_hi, dx0, ...): data backward
+        f, g, P, rpp, st_lo, st_hi, dx0 = args[0]._obj, args[1]._obj, args[4], args[5], args[7], args[8], args[9]
+        per = 0
+        for net in (f, g):
+            m = _layer_macs(net)
+            per += m[-1] + sum(m[1:-1]) + m[0]
+        stages = (st_hi - st_lo) - (0 if (dx0 or st_lo > 0) else 1)
+        return 2 * P * rpp * stages * (per + 2 * g.out_dim)
     nets, io, n_nets, B = args[0], args[1], args[2], args[3]
     total = 0
     for i in range(n_nets):
@@ -71,7 +82,7 @@ def launch_flops(name, args):
 
 class KernelTimer:
     """HIP events (torch.cuda.Event on the launch stream) around every launch of the MLP kernels."""
-    NAMES = ("nlbac_mlp_fwd", "nlbac_mlp_bwd_data", "nlbac_mlp_bwd_weights")
+    NAMES = ("nlbac_mlp_fwd", "nlbac_mlp_bwd_data", "nlbac_mlp_bwd_weights", "nlbac_node_rk_fwd", "nlbac_node_rk_bwd")
 
     def __init__(self):
         self.records = {n: [] for n in self.NAMES}
@@ -243,7 +254,8 @@ def main():
         agent.use_graphs = graphs_on
         dom = max(ks, key=lambda k: ks[k]["ms"])
         kname = {"nlbac_mlp_fwd": "mlp_fwd_kernel", "nlbac_mlp_bwd_data": "mlp_bwd_data_kernel",
-                 "nlbac_mlp_bwd_weights": "mlp_bwd_wide_kernel+mlp_bwd_skinny_kernel"}[dom]
+                 "nlbac_mlp_bwd_weights": "mlp_bwd_wide_kernel+mlp_bwd_skinny_partial/reduce_kernel",
+                 "nlbac_node_rk_fwd": "node_rk_fwd_kernel", "nlbac_node_rk_bwd": "node_rk_bwd_kernel"}[dom]
         roofline = dict(bound="mfma", kernel=kname, achieved=ks[dom]["tflops"], peak=PEAK_F32_MFMA_TFLOPS,
                         unit="TFLOP/s", frac=ks[dom]["tflops"] / PEAK_F32_MFMA_TFLOPS, traffic=None,
                         avg_launch_us=ks[dom]["avg_us"], launches=ks[dom]["launches"],
