@@ -60,7 +60,31 @@ class UnicycleSpec:
         return [s]
 
 
+class SimulatedCarsSpec:
+    """Constants of ``SimulatedCarsEnv`` (C/envs/simulated_cars_env.py:16-40): five cars on a line, the
+    4th is controlled (acceleration in [-3, 3]); obs = state with positions /100 and velocities /30."""
+
+    dynamics_mode = "SimulatedCars"
+    n_s, n_u, obs_dim, lya_in = 10, 1, 10, 4
+
+    def __init__(self, seed=0):
+        self.action_space = Box(-3.0, 3.0, shape=(1,))
+        self.safe_action_space = Box(-3.0, 3.0, shape=(1,))
+        self.observation_space = Box(-1e10, 1e10, shape=(10,))
+        self.dt = 0.02
+        self.max_episode_steps = 300
+        self.kp, self.k_brake = 4.0, 20.0
+        self.should_keep = 9.5
+        self.seed(seed)
+
+    def seed(self, s=None):
+        self.action_space.seed(s)
+        return [s]
+
+
 def make_env(name, seed=0):
     if name == "Unicycle":
         return UnicycleSpec(seed)
+    if name == "SimulatedCars":
+        return SimulatedCarsSpec(seed)
     raise Exception("Dynamics mode not supported.")

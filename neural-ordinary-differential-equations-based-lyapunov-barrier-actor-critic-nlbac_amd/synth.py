@@ -63,6 +63,47 @@ def unicycle_transitions(n, seed=1, env=None):
                 mask=np.ones(n), t=t, next_t=t + dt)
 
 
+def cars_transitions(n, seed=1, env=None):
+    """Synthetic SimulatedCars transitions: states near the env's reset line-up
+    (C/envs/simulated_cars_env.py:158-176) with random spreads, one true env step (``:66-99``),
+    reward / constraint / Lyapunov inputs as ``step`` returns them (``:99-146``)."""
+    from .envspec import SimulatedCarsSpec
+    env = env or SimulatedCarsSpec()
+    rs = np.random.RandomState(seed)
+    dt = env.dt
+    pos = np.array([42.0, 34.0, 26.0, 18.0, 10.0])[None] + rs.uniform(-3, 3, (n, 5)) + rs.uniform(0, 20, (n, 1))
+    vel = 3.0 + rs.normal(0, 0.8, (n, 5))
+    t = rs.randint(0, 300, n).astype(np.float64) * dt
+    state = np.zeros((n, 10))
+    state[:, ::2], state[:, 1::2] = pos, vel
+    action = rs.uniform(-3.0, 3.0, (n, 1))
+    vels_des = 3.0 * np.ones((n, 5))
+    vels_des[:, 0] -= 4 * np.sin(t)
+    acc = env.kp * (vels_des - vel)
+    acc[:, 1] += -env.k_brake * (pos[:, 0] - pos[:, 1]) * ((pos[:, 0] - pos[:, 1]) < 6.5)
+    acc[:, 2] += -env.k_brake * (pos[:, 1] - pos[:, 2]) * ((pos[:, 1] - pos[:, 2]) < 6.5)
+    acc[:, 3] = 0.0
+    acc[:, 4] += -env.k_brake * (pos[:, 2] - pos[:, 4]) * ((pos[:, 2] - pos[:, 4]) < 13.0)
+    acc *= 1.1
+    f = np.zeros((n, 10))
+    f[:, ::2], f[:, 1::2] = vel, acc
+    f[:, 7] = 0.0
+    g = np.zeros((n, 10))
+    g[:, 7] = 1.0
+    nxt = state + dt * (f + g * action)
+
+    def to_obs(x):
+        o = x.copy()
+        o[:, ::2] /= 100.0
+        o[:, 1::2] /= 30.0
+        return o
+    d34 = nxt[:, 4] - nxt[:, 6]
+    reward = -0.5 * np.abs(action[:, 0] ** 2) / env.max_episode_steps + 2.0 * (np.abs(d34 - env.should_keep) < 0.5)
+    return dict(obs=to_obs(state), action=action, reward=reward, constraint=np.abs(d34 - env.should_keep),
+                center=state[:, 4:8].copy(), next_center=nxt[:, 4:8].copy(), next_obs=to_obs(nxt),
+                mask=np.ones(n), t=t, next_t=t + dt)
+
+
 # ---------------------------------------------------------------------------
 # network shapes (reference key names; U/sac_cbf_clf/model.py:37-133,177-206)
 # ---------------------------------------------------------------------------
@@ -90,6 +131,12 @@ def node_affine_shapes(n_s, n_u, hidden=100, f_hidden_layers=4, g_hidden_layers=
     g += [("g_net.%d" % (2 * i), hidden, hidden) for i in range(1, g_hidden_layers)]
     g += [("g_net.%d" % (2 * g_hidden_layers), n_s * n_u, hidden)]
     return f + g
+
+
+def node_single_shapes(in_dim, out_dim, hidden=64, depth=4):
+    """C/sac_cbf_clf/model.py:186-194: ``net`` = depth Linear layers (ReLU between)."""
+    dims = [in_dim] + [hidden] * (depth - 1) + [out_dim]
+    return [("net.%d" % (2 * i), dims[i + 1], dims[i]) for i in range(depth)]
 
 
 def synth_state_dict(shapes, seed, kind="xavier"):
@@ -121,6 +168,23 @@ def unicycle_agent_weights(hidden, seed=0):
     backup = synth_state_dict(policy_shapes(7, 2, hidden), seed * 10 + 4)
     node = synth_state_dict(node_affine_shapes(3, 2), seed * 10 + 5, kind="default")
     return dict(critic=critic, lyapunov=lya, policy=policy, backup_policy=backup, node=node)
+
+
+def cars_agent_weights(hidden, seed=0):
+    critic = synth_state_dict(qnet_shapes(10, 1, hidden), seed * 10 + 1)
+    lya = synth_state_dict(lya_shapes(4, hidden), seed * 10 + 2)
+    policy = synth_state_dict(policy_shapes(10, 1, hidden), seed * 10 + 3)
+    backup = synth_state_dict(policy_shapes(10, 1, hidden), seed * 10 + 4)
+    node = synth_state_dict(node_single_shapes(12, 10), seed * 10 + 5, kind="default")
+    return dict(critic=critic, lyapunov=lya, policy=policy, backup_policy=backup, node=node)
+
+
+def agent_weights(env_name, hidden, seed=0):
+    return {"Unicycle": unicycle_agent_weights, "SimulatedCars": cars_agent_weights}[env_name](hidden, seed)
+
+
+def transitions(env_name, n, seed=1, env=None):
+    return {"Unicycle": unicycle_transitions, "SimulatedCars": cars_transitions}[env_name](n, seed, env)
 
 
 def normal_eps(n_draws, batch, n_u, seed):

@@ -19,7 +19,8 @@ What has to be faked to import the reference here:
   * ``sac_cbf_clf.model.device`` is hard-coded ``cuda`` -> rebound to CPU.
   * ``env`` is a plain object (gym is absent): ``nlbac_amd.envspec``.
 
-Usage:  python oracle/gen_golden.py
+Usage:  python oracle/gen_golden.py [--env Unicycle|SimulatedCars]   (one env per process: the
+reference's env copies all use the package name ``sac_cbf_clf``)
 """
 import os
 import sys
@@ -37,10 +38,20 @@ from nlbac_amd import synth  # noqa: E402
 from nlbac_amd.envspec import make_env  # noqa: E402
 from oracle import nlbac_oracle as O  # noqa: E402
 
-REF = "/root/reference/NLBAC_Unicycle_RL_training/Unicycle_RL_training"
+REFS = {
+    "Unicycle": "/root/reference/NLBAC_Unicycle_RL_training/Unicycle_RL_training",
+    "SimulatedCars": "/root/reference/NLBAC_SimulatedCarsFollowing_RL_training/Simulated_Car_Following_RL_training",
+}
+# per env: fixture prefix, obs dim, action dim, gamma_b (README run commands), eps draws per update,
+# odeint calls per controller inside the loss
+CFG = {
+    "Unicycle": dict(prefix="unicycle", obs=7, act=2, gamma_b=50.0, n_eps=3, n_ode=1),
+    "SimulatedCars": dict(prefix="cars", obs=10, act=1, gamma_b=0.5, n_eps=5, n_ode=2),
+}
 
 
-def import_reference():
+def import_reference(env_name="Unicycle"):
+    REF = REFS[env_name]
     td = types.ModuleType("torchdiffeq")
     td.odeint = lambda func, y0, t, method=None, atol=None, rtol=None, **kw: O.odeint(
         func, y0, t, method=method, atol=atol, rtol=rtol)
@@ -86,13 +97,14 @@ def summarize(prefix, vec, out, n_head=48):
     out[prefix + "_tail"] = vec[-n_head:].detach().numpy().copy()
 
 
-def run_case(S, solver, B, hidden=256, seed=0, node_B=512, calls=(0, 1, 8)):
-    env = make_env("Unicycle", seed)
+def run_case(S, env_name, solver, B, hidden=256, seed=0, node_B=512, calls=(0, 1, 8)):
+    cfg = CFG[env_name]
+    env = make_env(env_name, seed)
     args = O.Args(batch_size=B, hidden_size=hidden, seed=seed)
-    args.gamma_b = 50.0
-    agent = S.SAC_CBF_CLF(7, env.action_space, env, args)
+    args.gamma_b = cfg["gamma_b"]
+    agent = S.SAC_CBF_CLF(cfg["obs"], env.action_space, env, args)
     agent.solver = solver
-    W = synth.unicycle_agent_weights(hidden, seed)
+    W = synth.agent_weights(env_name, hidden, seed)
     load_sd(agent.critic, W["critic"]); load_sd(agent.critic_target, W["critic"])
     load_sd(agent.lyapunovNet, W["lyapunov"]); load_sd(agent.lyapunovNet_target, W["lyapunov"])
     load_sd(agent.policy, W["policy"]); load_sd(agent.backup_policy, W["backup_policy"])
@@ -103,8 +115,9 @@ def run_case(S, solver, B, hidden=256, seed=0, node_B=512, calls=(0, 1, 8)):
     from sac_cbf_clf.dynamics import DynamicsModel
     dyn = DynamicsModel(env, args)
 
-    tr = synth.unicycle_transitions(4096, seed=seed + 1, env=env)
-    out = {"meta_solver": solver, "meta_B": B, "meta_hidden": hidden, "meta_seed": seed,
+    tr = synth.transitions(env_name, 4096, seed=seed + 1, env=env)
+    out = {"meta_env": env_name, "meta_gamma_b": cfg["gamma_b"],
+           "meta_solver": solver, "meta_B": B, "meta_hidden": hidden, "meta_seed": seed,
            "meta_node_B": node_B, "meta_calls": np.array(calls)}
 
     # instrumentation -------------------------------------------------------
@@ -154,7 +167,7 @@ def run_case(S, solver, B, hidden=256, seed=0, node_B=512, calls=(0, 1, 8)):
             rs = np.random.RandomState(1000 * seed + 17 * ci + B)
             idx = rs.choice(4096, B, replace=False)
             nidx = rs.choice(4096, node_B, replace=False)
-            eps = synth.normal_eps(3, B, 2, seed=100 * seed + ci)
+            eps = synth.normal_eps(cfg["n_eps"], B, cfg["act"], seed=100 * seed + ci)
             eps_queue[:] = [torch.from_numpy(e) for e in eps]
             where_rec.clear(); node_out.clear(); rec.clear()
             torch.where = where
@@ -172,11 +185,15 @@ def run_case(S, solver, B, hidden=256, seed=0, node_B=512, calls=(0, 1, 8)):
             out[p + "backup_lambdas"] = np.array([float(x) for x in agent.backup_lambda_values])
             out[p + "augmented_term"] = float(agent.augmented_term)
             out[p + "backup_alpha"] = float(agent.backup_alpha)
-            out[p + "x_next"] = node_out[0][0][:, :3].numpy()
-            out[p + "bx_next"] = node_out[1][0][:, :3].numpy()
+            ns, k = env.n_s, cfg["n_ode"]
+            out[p + "x_next"] = node_out[0][0][:, :ns].numpy()
+            out[p + "bx_next"] = node_out[k][0][:, :ns].numpy()
+            if k == 2:
+                out[p + "x_next2"] = node_out[1][0][:, :ns].numpy()
+                out[p + "bx_next2"] = node_out[3][0][:, :ns].numpy()
             if solver == "dopri5":
                 out[p + "ode_steps"] = np.array(node_out[0][1]["steps"], dtype=np.float64)
-                out[p + "bode_steps"] = np.array(node_out[1][1]["steps"], dtype=np.float64)
+                out[p + "bode_steps"] = np.array(node_out[k][1]["steps"], dtype=np.float64)
             if B <= 16:
                 out[p + "matr"] = matr.reshape(B, -1).numpy()
                 out[p + "bmatr"] = bmatr.reshape(B, -1).numpy()
@@ -199,14 +216,18 @@ def run_case(S, solver, B, hidden=256, seed=0, node_B=512, calls=(0, 1, 8)):
 
 
 def main():
-    M, S = import_reference()
+    import argparse
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--env", default="Unicycle", choices=sorted(REFS))
+    env_name = ap.parse_args().env
+    M, S = import_reference(env_name)
     torch.set_num_threads(1)   # deterministic reduction order for the fixtures
     gold = os.path.join(ROOT, "tests", "golden")
     os.makedirs(gold, exist_ok=True)
     for solver in ("euler", "rk4", "dopri5"):
         for B in (8, 128):
-            out = run_case(S, solver, B)
-            path = os.path.join(gold, "unicycle_%s_B%d.npz" % (solver, B))
+            out = run_case(S, env_name, solver, B)
+            path = os.path.join(gold, "%s_%s_B%d.npz" % (CFG[env_name]["prefix"], solver, B))
             np.savez_compressed(path, **out)
             print(path, os.path.getsize(path), "bytes; ret(c0) =", out["c0_ret"])
 

@@ -11,6 +11,11 @@ produced by importing the reference's own modules in the build container
 rk4 / dopri5 follow torchdiffeq 0.2.3 *from recollection* (the package is
 not in the container) — PARITY UNPINNED for those two solvers.
 
+SimulatedCars (C = NLBAC_SimulatedCarsFollowing_RL_training/Simulated_Car_Following_RL_training) is
+restated by ``OracleCarsAgent``: non-affine NODE C/sac_cbf_clf/model.py:179-205, two-step rollout and
+relative-degree-2 CBFs C/sac_cbf_clf/sac_cbf_clf.py:412-555 / 557-681, get_state/get_obs
+C/sac_cbf_clf/dynamics.py:25-96, train_step C/sac_cbf_clf/model.py:208-252.
+
 Reference lines restated (U = NLBAC_Unicycle_RL_training/Unicycle_RL_training):
   update_parameters        U/sac_cbf_clf/sac_cbf_clf.py:181-319
   get_policy_loss_2        U/sac_cbf_clf/sac_cbf_clf.py:408-530
@@ -89,6 +94,23 @@ class AffineNode:
         g = self._mlp(self.g_names, x).reshape(-1, self.n_s, self.n_u)
         ds = f + torch.bmm(g, u.reshape(-1, self.n_u, 1)).squeeze(-1)
         return torch.cat((ds, torch.zeros_like(u)), -1)
+
+
+class ConcatNode:
+    """C/sac_cbf_clf/model.py:179-205: ds/dt = net([x, u, t]); the action and time columns are carried."""
+
+    def __init__(self, sd, n_s=10, n_carry=2, depth=4):
+        self.sd, self.n_s, self.n_carry = sd, n_s, n_carry
+        self.names = ["net.%d" % (2 * i) for i in range(depth)]
+        self.nfe = 0
+
+    def __call__(self, t, s):
+        self.nfe += 1
+        x = s
+        for n in self.names[:-1]:
+            x = F.relu(_lin(self.sd, n, x))
+        ds = _lin(self.sd, self.names[-1], x)
+        return torch.cat((ds, torch.zeros_like(s[:, self.n_s:])), -1)
 
 
 # ---------------------------------------------------------------------------
@@ -254,8 +276,9 @@ class Args:
             setattr(self, k, v)
 
 
-class OracleUnicycleAgent:
-    """Restatement of ``SAC_CBF_CLF`` (Unicycle copy) with explicit noise."""
+class OracleAgentBase:
+    """Common part of the restated ``SAC_CBF_CLF`` (explicit noise); env copies subclass it."""
+    LAM_HI, RATIO_MIN, N_EPS = 400.0, None, 3
 
     def __init__(self, env, args, weights, solver="euler"):
         self.env, self.args, self.solver = env, args, solver
@@ -282,44 +305,17 @@ class OracleUnicycleAgent:
         lo = torch.tensor(env.action_space.low, dtype=torch.float32)
         self.scale, self.bias = (hi - lo) / 2.0, (hi + lo) / 2.0
         self.target_entropy = -float(env.action_space.shape[0])
-        self.num_cbfs = len(env.hazards_locations)
+        self.num_cbfs = self._num_cbfs(env)
         self.num_constraints = self.num_cbfs + 1
         self.lambda_values = [0.0] * self.num_constraints
         self.backup_lambda_values = [0.0] * self.num_cbfs
         self.augmented_term, self.augmented_ratio = 1.0, 1.0005
         self.cost_limit = 0.0
-        self.hazards = torch.tensor(np.asarray(env.hazards_locations), dtype=torch.float32)
-        self.node_fn = AffineNode(self.node)
-
-    # -- helpers ------------------------------------------------------------
-    @staticmethod
-    def get_state(obs):
-        """dynamics.py:53-58 — atan2 in float64 on the host, cast back."""
-        o = obs.detach().double().numpy()
-        st = np.zeros((o.shape[0], 3))
-        st[:, 0], st[:, 1], st[:, 2] = o[:, 0], o[:, 1], np.arctan2(o[:, 3], o[:, 2])
-        return torch.from_numpy(st).float()
+        self._setup_task(env)
 
     def _set_grads(self, params, grads):
         for p, g in zip(params, grads):
             p.grad = g
-
-    def _rollout(self, state, action):
-        y0 = torch.cat((state, action), -1)
-        t = torch.tensor([0, self.env.dt])
-        info = {}
-        y = odeint(self.node_fn, y0, t, method=self.solver, atol=1e-7, rtol=1e-5, info=info)[-1]
-        return y[:, :3], info
-
-    def _lookahead(self, st):
-        th = st[:, 2]
-        return torch.stack([st[:, 0] + L_P * torch.cos(th), st[:, 1] + L_P * torch.sin(th)], 1)
-
-    def _cbf_terms(self, ps, ps_next):
-        r = 1.05 * self.env.hazards_radius
-        hs = 0.5 * (((ps[:, None, :] - self.hazards[None]) ** 2).sum(2) - r ** 2)
-        hn = 0.5 * (((ps_next[:, None, :] - self.hazards[None]) ** 2).sum(2) - r ** 2)
-        return -((hn - hs) / self.env.dt) - self.gamma_b * hs
 
     def _auglag(self, required, lambdas, updates, with_clf):
         """sac_cbf_clf.py:506-528 (primary) / :623-638 (backup)."""
@@ -329,11 +325,13 @@ class OracleUnicycleAgent:
             other = torch.abs(torch.mean(required[:-1] - self.cost_limit))
             lyac = torch.abs(required[-1] - self.cost_limit)
             ratio = float(other / lyac)
+            if self.RATIO_MIN is not None and ratio < self.RATIO_MIN:
+                ratio = self.RATIO_MIN
         req_d = required.detach()
         if updates % self.args.Lagrangian_multiplier_update_interval == 0:
             for i in range(len(lambdas)):
                 new = torch.as_tensor(lambdas[i], dtype=torch.float32) + self.augmented_term * req_d[i]
-                lambdas[i] = float(torch.clamp(new, 0.01, 400.0))
+                lambdas[i] = float(torch.clamp(new, 0.01, self.LAM_HI))
         self.augmented_term = min(self.augmented_term * self.augmented_ratio, 200)
         rho = self.augmented_term
         n_cbf = len(required) - (1 if with_clf else 0)
@@ -346,18 +344,6 @@ class OracleUnicycleAgent:
             loss = loss + float(lambdas[-1]) * ratio * g + ratio * ratio * rho / 2.0 * g * g
         out.update(ratio=ratio, loss=loss)
         return out
-
-    # -- NODE fit -------------------------------------------------------------
-    def train_step(self, node_obs, node_action, node_next_obs):
-        """model.py:221-260 via sac_cbf_clf.py:205-219."""
-        st, nst = self.get_state(node_obs), self.get_state(node_next_obs)
-        self.opt["node"].zero_grad()
-        pred, _ = self._rollout(st, node_action)
-        loss = F.mse_loss(pred, nst)
-        g = torch.autograd.grad(loss, list(self.node.values()))
-        self._set_grads(self.node.values(), g)
-        self.opt["node"].step()
-        return float(loss), _flat(g)
 
     # -- one update -----------------------------------------------------------
     def update(self, batch, eps, updates, node_batch=None):
@@ -395,28 +381,15 @@ class OracleUnicycleAgent:
         policy_loss_1 = ((self.alpha * log_pi) - min_q_pi).mean()
         backup_loss_1 = ((self.backup_alpha * blog_pi) - bmin_q).mean()
 
-        # primary: CLF + CBFs (sac_cbf_clf.py:364-386, 408-530)
-        state = self.get_state(obs)
-        V = lyanet(self.lya, cen).detach()
-        ps = self._lookahead(state)
-        x_next, info = self._rollout(state, pi)
-        ps_next = self._lookahead(x_next)
-        V_next = lyanet(self.lya, ps_next)
-        lya_term = ((V_next - V) / dt) + 1.0 * V
-        matr = torch.cat((self._cbf_terms(ps, ps_next), lya_term), 1)
+        # primary: CLF + CBFs ; backup: CBFs only  (env-specific terms)
+        matr, extra = self._primary_terms(batch, pi, eps)
         required = torch.where(matr > 0, matr, torch.zeros_like(matr)).sum(0) / self.batch_size
         al = self._auglag(required, self.lambda_values, updates, True)
-        R.update(x_next=x_next.detach(), matr=matr.detach(), required=required.detach(),
-                 ratio=al["ratio"], ode_info=info)
-
-        # backup: CBFs only (:388-406, 532-640)
-        bx_next, binfo = self._rollout(state, bpi)
-        bps_next = self._lookahead(bx_next)
-        bmatr = self._cbf_terms(ps, bps_next)
+        R.update(matr=matr.detach(), required=required.detach(), ratio=al["ratio"], **extra)
+        bmatr, bextra = self._backup_terms(batch, bpi, eps)
         brequired = torch.where(bmatr > 0, bmatr, torch.zeros_like(bmatr)).sum(0) / self.batch_size
         bal = self._auglag(brequired, self.backup_lambda_values, updates, False)
-        R.update(bx_next=bx_next.detach(), bmatr=bmatr.detach(), brequired=brequired.detach(),
-                 bode_info=binfo)
+        R.update(bmatr=bmatr.detach(), brequired=brequired.detach(), **bextra)
 
         policy_loss = policy_loss_1 + al["loss"]
         backup_loss = backup_loss_1 + bal["loss"]
@@ -450,3 +423,154 @@ class OracleUnicycleAgent:
                  lambdas=list(self.lambda_values), backup_lambdas=list(self.backup_lambda_values),
                  augmented_term=self.augmented_term, log_pi=log_pi.detach(), pi=pi.detach())
         return R
+
+
+class OracleUnicycleAgent(OracleAgentBase):
+    """Unicycle copy (U/sac_cbf_clf/sac_cbf_clf.py): 7 CBFs + 1 CLF, control-affine NODE, one-step rollout."""
+
+    def _num_cbfs(self, env):
+        return len(env.hazards_locations)
+
+    def _setup_task(self, env):
+        self.hazards = torch.tensor(np.asarray(env.hazards_locations), dtype=torch.float32)
+        self.node_fn = AffineNode(self.node)
+
+    @staticmethod
+    def get_state(obs):
+        """dynamics.py:53-58 — atan2 in float64 on the host, cast back."""
+        o = obs.detach().double().numpy()
+        st = np.zeros((o.shape[0], 3))
+        st[:, 0], st[:, 1], st[:, 2] = o[:, 0], o[:, 1], np.arctan2(o[:, 3], o[:, 2])
+        return torch.from_numpy(st).float()
+
+    def _rollout(self, state, action):
+        y0 = torch.cat((state, action), -1)
+        t = torch.tensor([0, self.env.dt])
+        info = {}
+        y = odeint(self.node_fn, y0, t, method=self.solver, atol=1e-7, rtol=1e-5, info=info)[-1]
+        return y[:, :3], info
+
+    def _lookahead(self, st):
+        th = st[:, 2]
+        return torch.stack([st[:, 0] + L_P * torch.cos(th), st[:, 1] + L_P * torch.sin(th)], 1)
+
+    def _cbf_terms(self, ps, ps_next):
+        r = 1.05 * self.env.hazards_radius
+        hs = 0.5 * (((ps[:, None, :] - self.hazards[None]) ** 2).sum(2) - r ** 2)
+        hn = 0.5 * (((ps_next[:, None, :] - self.hazards[None]) ** 2).sum(2) - r ** 2)
+        return -((hn - hs) / self.env.dt) - self.gamma_b * hs
+
+    def train_step(self, node_obs, node_action, node_next_obs):
+        """model.py:221-260 via sac_cbf_clf.py:205-219."""
+        st, nst = self.get_state(node_obs), self.get_state(node_next_obs)
+        self.opt["node"].zero_grad()
+        pred, _ = self._rollout(st, node_action)
+        loss = F.mse_loss(pred, nst)
+        g = torch.autograd.grad(loss, list(self.node.values()))
+        self._set_grads(self.node.values(), g)
+        self.opt["node"].step()
+        return float(loss), _flat(g)
+
+    def _primary_terms(self, batch, pi, eps):
+        """sac_cbf_clf.py:364-386, 408-530"""
+        obs, cen, dt = batch["obs"], batch["center"], self.env.dt
+        state = self.get_state(obs)
+        V = lyanet(self.lya, cen).detach()
+        ps = self._lookahead(state)
+        x_next, info = self._rollout(state, pi)
+        ps_next = self._lookahead(x_next)
+        V_next = lyanet(self.lya, ps_next)
+        lya_term = ((V_next - V) / dt) + 1.0 * V
+        matr = torch.cat((self._cbf_terms(ps, ps_next), lya_term), 1)
+        self._ps = ps
+        return matr, dict(x_next=x_next.detach(), ode_info=info)
+
+    def _backup_terms(self, batch, bpi, eps):
+        """sac_cbf_clf.py:388-406, 532-640"""
+        state = self.get_state(batch["obs"])
+        bx_next, binfo = self._rollout(state, bpi)
+        return self._cbf_terms(self._ps, self._lookahead(bx_next)), dict(bx_next=bx_next.detach(), bode_info=binfo)
+
+
+class OracleCarsAgent(OracleAgentBase):
+    """SimulatedCars copy (C/sac_cbf_clf/sac_cbf_clf.py): two relative-degree-2 CBFs + 1 CLF, non-affine NODE
+    on [x, u, t], two-step rollout with a re-sampled (detached) second action."""
+    LAM_HI, RATIO_MIN, N_EPS = 300.0, 0.002, 5
+
+    def _num_cbfs(self, env):
+        return 2
+
+    def _setup_task(self, env):
+        self.node_fn = ConcatNode(self.node)
+
+    @staticmethod
+    def get_state(obs):
+        """C/dynamics.py:59-62 (numpy float64 on the host, cast back)."""
+        o = obs.detach().double().numpy().copy()
+        o[:, ::2] *= 100.0
+        o[:, 1::2] *= 30.0
+        return torch.from_numpy(o).float()
+
+    @staticmethod
+    def get_obs(state):
+        """C/dynamics.py:88-91 (torch, in place on a clone)."""
+        o = state.clone()
+        o[:, ::2] /= 100.0
+        o[:, 1::2] /= 30.0
+        return o
+
+    def _rollout(self, state, action, t):
+        y0 = torch.cat((state, action, t), -1)
+        ts = torch.tensor([0, self.env.dt])
+        info = {}
+        y = odeint(self.node_fn, y0, ts, method=self.solver, atol=1e-7, rtol=1e-5, info=info)[-1]
+        return y[:, :10], info
+
+    def train_step(self, node_obs, node_action, node_next_obs, node_t):
+        """C/model.py:208-252 via C/sac_cbf_clf.py:201-217."""
+        st, nst = self.get_state(node_obs), self.get_state(node_next_obs)
+        pred, _ = self._rollout(st, node_action, node_t.reshape(-1, 1))
+        loss = F.mse_loss(pred, nst)
+        g = torch.autograd.grad(loss, list(self.node.values()))
+        self._set_grads(self.node.values(), g)
+        self.opt["node"].step()
+        return float(loss), _flat(g)
+
+    def _terms(self, batch, action, sd_policy, eps_next, with_clf):
+        gamma_b, gamma_l, radius = self.gamma_b, 0.15, 4.5
+        state = self.get_state(batch["obs"])
+        t, nt = batch["t"].reshape(-1, 1), batch["next_t"].reshape(-1, 1)
+        x1, info1 = self._rollout(state, action, t)
+        with torch.no_grad():
+            pi_next, _, _ = policy_sample(sd_policy, self.get_obs(x1.detach()), eps_next, self.scale, self.bias)
+        x2, info2 = self._rollout(x1, pi_next, nt)
+
+        def h(x):
+            return (x[:, 4:5] - x[:, 6:7]) - radius, (x[:, 6:7] - x[:, 8:9]) - radius
+        h23_0, h34_0 = h(state)
+        h23_1, h34_1 = h(x1)
+        h23_2, h34_2 = h(x2)
+        l1_23 = h23_1 - h23_0 + gamma_b * h23_0
+        l1_34 = h34_1 - h34_0 + gamma_b * h34_0
+        l2_23 = h23_2 - h23_1 + gamma_b * h23_1
+        l2_34 = h34_2 - h34_1 + gamma_b * h34_1
+        cbf23 = -(l2_23 - l1_23) - gamma_b * l1_23
+        cbf34 = -(l2_34 - l1_34) - gamma_b * l1_34
+        cols = [cbf23, cbf34]
+        if with_clf:
+            V = lyanet(self.lya, batch["center"]).detach()
+            V1 = lyanet(self.lya, x1[:, 4:8])
+            cols.append((V1 - V) + gamma_l * V)
+        return torch.cat(cols, 1), x1.detach(), x2.detach(), (info1, info2)
+
+    def _primary_terms(self, batch, pi, eps):
+        matr, x1, x2, info = self._terms(batch, pi, self.policy, eps[3], True)
+        return matr, dict(x_next=x1, x_next2=x2, ode_info=info[0])
+
+    def _backup_terms(self, batch, bpi, eps):
+        bmatr, x1, x2, info = self._terms(batch, bpi, self.backup, eps[4], False)
+        return bmatr, dict(bx_next=x1, bx_next2=x2, bode_info=info[0])
+
+
+def make_oracle(env, args, weights, solver="euler"):
+    return {"Unicycle": OracleUnicycleAgent, "SimulatedCars": OracleCarsAgent}[env.dynamics_mode](env, args, weights, solver)

@@ -9,23 +9,30 @@ from nlbac_amd import synth
 from nlbac_amd.envspec import make_env
 
 GOLD = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
-BATCH_FIELDS = ("obs", "action", "reward", "constraint", "center", "next_center", "next_obs", "mask")
+BATCH_FIELDS = ("obs", "action", "reward", "constraint", "center", "next_center", "next_obs", "mask", "t", "next_t")
+PREFIX = {"Unicycle": "unicycle", "SimulatedCars": "cars"}
+N_EPS = {"Unicycle": 3, "SimulatedCars": 5}
+NODE_FIELDS = {"Unicycle": ("obs", "action", "next_obs"), "SimulatedCars": ("obs", "action", "next_obs", "t")}
 
 
-def load_golden(solver, B):
-    return np.load(os.path.join(GOLD, "unicycle_%s_B%d.npz" % (solver, B)))
+def load_golden(solver, B, env="Unicycle"):
+    return np.load(os.path.join(GOLD, "%s_%s_B%d.npz" % (PREFIX[env], solver, B)))
+
+
+def golden_env(g):
+    return str(g["meta_env"]) if "meta_env" in g.files else "Unicycle"
 
 
 def case_inputs(g, ci, transitions=None):
     """(batch dict of float32 tensors, eps list, node_batch tuple, updates)."""
-    seed = int(g["meta_seed"])
-    tr = transitions if transitions is not None else synth.unicycle_transitions(
-        4096, seed=seed + 1, env=make_env("Unicycle", seed))
+    seed, env_name = int(g["meta_seed"]), golden_env(g)
+    env = make_env(env_name, seed)
+    tr = transitions if transitions is not None else synth.transitions(env_name, 4096, seed=seed + 1, env=env)
     idx, nidx = g["c%d_idx" % ci], g["c%d_nidx" % ci]
     B = int(g["meta_B"])
     batch = {f: torch.tensor(tr[f][idx], dtype=torch.float32) for f in BATCH_FIELDS}
-    eps = [torch.from_numpy(e) for e in synth.normal_eps(3, B, 2, seed=100 * seed + ci)]
-    node = tuple(torch.tensor(tr[f][nidx], dtype=torch.float32) for f in ("obs", "action", "next_obs"))
+    eps = [torch.from_numpy(e) for e in synth.normal_eps(N_EPS[env_name], B, env.n_u, seed=100 * seed + ci)]
+    node = tuple(torch.tensor(tr[f][nidx], dtype=torch.float32) for f in NODE_FIELDS[env_name])
     return batch, eps, node, int(g["c%d_updates" % ci])
 
 

@@ -22,16 +22,19 @@ def flat_sd(sd):
     return torch.cat([v.detach().reshape(-1) for v in sd.values()])
 
 
+@pytest.mark.parametrize("env_name", ["Unicycle", "SimulatedCars"])
 @pytest.mark.parametrize("solver", ["euler", "rk4", "dopri5"])
 @pytest.mark.parametrize("B", [8, 128])
-def test_oracle_matches_reference_fixture(solver, B):
+def test_oracle_matches_reference_fixture(solver, B, env_name):
     torch.set_num_threads(1)
-    g = load_golden(solver, B)
+    g = load_golden(solver, B, env_name)
     seed, hidden = int(g["meta_seed"]), int(g["meta_hidden"])
-    env = make_env("Unicycle", seed)
+    env = make_env(env_name, seed)
     args = O.Args(batch_size=B, hidden_size=hidden, seed=seed)
-    agent = O.OracleUnicycleAgent(env, args, synth.unicycle_agent_weights(hidden, seed), solver=solver)
-    tr = synth.unicycle_transitions(4096, seed=seed + 1, env=env)
+    if "meta_gamma_b" in g.files:
+        args.gamma_b = float(g["meta_gamma_b"])
+    agent = O.make_oracle(env, args, synth.agent_weights(env_name, hidden, seed), solver=solver)
+    tr = synth.transitions(env_name, 4096, seed=seed + 1, env=env)
     for ci in range(len(g["meta_calls"])):
         batch, eps, node, updates = case_inputs(g, ci, tr)
         R = agent.update(batch, eps, updates, node_batch=node if updates % 10 == 0 else None)
@@ -44,6 +47,9 @@ def test_oracle_matches_reference_fixture(solver, B):
         assert abs(R["augmented_term"] - float(g[p + "augmented_term"])) < 1e-12
         vec_close(R["x_next"], g[p + "x_next"], TOL, p + "x_next")
         vec_close(R["bx_next"], g[p + "bx_next"], TOL, p + "bx_next")
+        if p + "x_next2" in g.files:
+            vec_close(R["x_next2"], g[p + "x_next2"], TOL, p + "x_next2")
+            vec_close(R["bx_next2"], g[p + "bx_next2"], TOL, p + "bx_next2")
         if B <= 16:
             vec_close(R["matr"], g[p + "matr"], TOL, p + "matr")
             vec_close(R["bmatr"], g[p + "bmatr"], TOL, p + "bmatr")
