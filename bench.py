@@ -29,6 +29,7 @@ from nlbac_amd.envspec import make_env
 
 PEAK_F32_MFMA_TFLOPS = 157.3     # MI355X_MICROARCH.md, chip-level parameters
 NODE_FIT_ROWS, NODE_FIT_INTERVAL, REPLAY_ROWS = 32768, 10, 65536
+GAMMA_B = {"Unicycle": 50.0, "SimulatedCars": 0.5}       # the reference README's run commands
 
 
 class Args:
@@ -40,14 +41,9 @@ class Args:
         self.batch_size = batch_size
 
 
-def replay_rows(tr):
-    n = tr["obs"].shape[0]
-    rows = np.zeros((n, 24), dtype=np.float32)
-    rows[:, 0:7], rows[:, 7:9] = tr["obs"], tr["action"]
-    rows[:, 9], rows[:, 10] = tr["reward"], tr["constraint"]
-    rows[:, 11:13], rows[:, 13:15] = tr["center"], tr["next_center"]
-    rows[:, 15:22], rows[:, 22] = tr["next_obs"], tr["mask"]
-    return rows
+def replay_rows(agent, tr):
+    """The synthetic replay as minibatch-layout rows (the agent's HBM row layout), built once on the host."""
+    return agent._rows_from_host(tuple(tr[f] for f in synth.FIELDS))
 
 
 # ---- algorithmic FLOPs of one MLP launch (real dims, 1 MAC = 2 FLOP) ------------------------------
@@ -135,24 +131,26 @@ def host_cores():
     return max(1, min(n, 16))
 
 
-def cpu_baseline(B, solver, seed=0):
+def cpu_baseline(B, solver, env_name="Unicycle", seed=0):
     """The oracle (CPU restatement pinned to the reference) timed on this box's host cores on a
     bounded sample of the same workload: 2 updates at batch B + 1 NODE fit on 32768 rows."""
     from oracle import nlbac_oracle as O
     cores = host_cores()
     torch.set_num_threads(cores)
     log("cpu_baseline: oracle on %d host threads" % cores)
-    env = make_env("Unicycle", seed)
-    W = synth.unicycle_agent_weights(256, seed)
-    agent = O.OracleUnicycleAgent(env, O.Args(batch_size=B, hidden_size=256, seed=seed), W, solver=solver)
-    tr = synth.unicycle_transitions(REPLAY_ROWS, seed=1, env=env)
-    fields = ("obs", "action", "reward", "constraint", "center", "next_center", "next_obs", "mask")
+    env = make_env(env_name, seed)
+    W = synth.agent_weights(env_name, 256, seed)
+    oargs = O.Args(batch_size=B, hidden_size=256, seed=seed)
+    oargs.gamma_b = GAMMA_B[env_name]
+    agent = O.make_oracle(env, oargs, W, solver=solver)
+    tr = synth.transitions(env_name, REPLAY_ROWS, seed=1, env=env)
+    fields = synth.FIELDS
     rs = np.random.RandomState(0)
 
     def mk(n):
         idx = rs.choice(REPLAY_ROWS, n, replace=False)
         return {f: torch.tensor(tr[f][idx], dtype=torch.float32) for f in fields}
-    eps = [torch.from_numpy(e) for e in synth.normal_eps(3, B, 2, seed=1)]
+    eps = [torch.from_numpy(e) for e in synth.normal_eps(agent.N_EPS, B, env.n_u, seed=1)]
     agent.update(mk(B), eps, 1)                      # warm-up (allocator, thread pool)
     log("cpu_baseline: warm-up update done")
     n_upd = 2
@@ -163,7 +161,8 @@ def cpu_baseline(B, solver, seed=0):
     log("cpu_baseline: %.2f s per update" % t_upd)
     nb = mk(NODE_FIT_ROWS)
     t0 = time.perf_counter()
-    agent.train_step(nb["obs"], nb["action"], nb["next_obs"])
+    agent.train_step(*[nb[f] for f in (("obs", "action", "next_obs", "t") if env_name == "SimulatedCars"
+                                       else ("obs", "action", "next_obs"))])
     t_fit = time.perf_counter() - t0
     per_update = t_upd + t_fit / NODE_FIT_INTERVAL
     return dict(value=B / per_update, unit="samples/s", cores=cores, kind="port",
@@ -179,6 +178,7 @@ def main():
     ap.add_argument("--warmup", type=int, default=20)
     ap.add_argument("--batch", type=int, default=4096)
     ap.add_argument("--solver", default="dopri5", choices=["euler", "rk4", "dopri5"])
+    ap.add_argument("--env", default="Unicycle", choices=["Unicycle", "SimulatedCars"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--graphs", action="store_true",
                     help="replay the update as hipGraphs (measured equal to eager launches once descriptors are cached)")
@@ -197,16 +197,18 @@ def main():
 
     from nlbac_amd.sac_cbf_clf.sac_cbf_clf import SAC_CBF_CLF
     B = a.batch
-    env = make_env("Unicycle", 0)
-    agent = SAC_CBF_CLF(7, env.action_space, env, Args(B * world))   # global batch in the loss normalisation
+    env = make_env(a.env, 0)
+    args = Args(B * world)                                            # global batch in the loss normalisation
+    args.gamma_b = GAMMA_B[a.env]
+    agent = SAC_CBF_CLF(env.obs_dim, env.action_space, env, args)
     agent.solver = a.solver
     agent.use_graphs = (world == 1) and a.graphs
     if world > 1:
         agent.enable_data_parallel(dist)
     dev = agent.device
-    replay = torch.from_numpy(replay_rows(synth.unicycle_transitions(REPLAY_ROWS, seed=1 + rank, env=env))).to(dev)
+    replay = replay_rows(agent, synth.transitions(a.env, REPLAY_ROWS, seed=1 + rank, env=env)).to(dev)
     ws = agent._workspace(B)
-    fit_rows = torch.empty(NODE_FIT_ROWS, 24, device=dev)
+    fit_rows = torch.empty(NODE_FIT_ROWS, agent.lay.LD, device=dev)
     gen = torch.Generator(device=dev)
     gen.manual_seed(1234 + rank)
 
@@ -269,17 +271,18 @@ def main():
 
     cpu = None
     if rank == 0 and world == 1 and not a.no_cpu_baseline:
-        cpu = cpu_baseline(B, a.solver)
+        cpu = cpu_baseline(B, a.solver, a.env)
 
     if rank == 0:
         out = {
-            "metric": "ODE-integrate+update samples/sec, Unicycle batch 4096",
+            "metric": "ODE-integrate+update samples/sec, Unicycle batch 4096" if a.env == "Unicycle" else
+                      "ODE-integrate+update samples/sec, %s batch %d" % (a.env, B),
             "value": value, "unit": "samples/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
             "ms_per_step": 1e3 * elapsed / a.steps, "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-            "config": {"workload": "Unicycle B=%d %s (BASELINE.json configs[1]); NODE fit on %d rows every %d "
+            "config": {"workload": "%s B=%d %s (BASELINE.json configs[%d]); NODE fit on %d rows every %d "
                                    "updates; replay of %d synthetic transitions resident in HBM"
-                                   % (B, a.solver, NODE_FIT_ROWS, NODE_FIT_INTERVAL, REPLAY_ROWS),
+                                   % (a.env, B, a.solver, 1 if a.env == "Unicycle" else 2, NODE_FIT_ROWS, NODE_FIT_INTERVAL, REPLAY_ROWS),
                        "solver": a.solver, "batch_per_gpu": B, "global_batch": B * world,
                        "parallelism": "dp%d" % world, "hipgraph": bool(agent.use_graphs),
                        "rollout_solver_stats": dict(agent.node_solver.stats), "last_losses": [float(x) for x in ret]},

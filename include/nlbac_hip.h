@@ -181,6 +181,21 @@ int nlbac_unicycle_constraints_bwd(const float *ps_next, const float *matr, cons
                                    const float *hazards, int n_hz, float dt, float batch_size, int B,
                                    const float *sc, float *dps_next, float *dV_next, nlbac_stream_t s);
 
+/* SimulatedCars: obs <-> state scaling (C/sac_cbf_clf/dynamics.py:59-62, 88-91), relative-degree-2 CBFs between
+ * cars 3-4 and 4-5 plus the CLF term over a two-step rollout (C/sac_cbf_clf/sac_cbf_clf.py:474-511, 618-645).
+ * state (B,10); x1/x2 (2B,10) = rollout after one / two steps, primary rows then backup rows.
+ * matr (B,3) = [cbf23, cbf34, clf], bmatr (B,2); partials [ceil(B/256)][5]; use nlbac_auglag(n_cbf=2). */
+int nlbac_cars_state(const float *obs, int obs_ld, int n, float *state, nlbac_stream_t s);
+int nlbac_cars_obs(const float *state, int n, float *obs, nlbac_stream_t s);
+int nlbac_cars_constraints_fwd(const float *state, const float *x1, const float *x2, const float *V,
+                               const float *V1, float gamma_b, float gamma_l, float radius, int B,
+                               float *matr, float *bmatr, float *partials, nlbac_stream_t s);
+int nlbac_cars_constraints_bwd(const float *matr, const float *bmatr, float gamma_b, float batch_size, int B,
+                               const float *sc, float *dx1, float *dx2, float *dV1, nlbac_stream_t s);
+/* dst[row][col0+c] += src[row][c] */
+int nlbac_add_cols(float *dst, int dst_ld, int col0, const float *src, int src_ld, int ncols, int n,
+                   nlbac_stream_t s);
+
 /* nn.MSELoss('mean') over (n,d): dpred and per-block squared-error partials [ceil(n/256)] (model.py:256). */
 int nlbac_mse_fwd_bwd(const float *pred, int pred_ld, const float *target, int target_ld, int n, int n_norm,
                       int d, float *dpred, int dpred_ld, float *partials, nlbac_stream_t s);
@@ -206,6 +221,7 @@ int nlbac_rk_combine(const float *y0, const float *K, int n_k, const float *coef
 int nlbac_rk_stage_bwd(const float *dYup, const float *dXf, const float *dXg, int dx_ld, int n_k,
                        const float *coef, const float *h_host, const double *h_dev, int h_dev_stride,
                        int P, int rows_per_problem, int n_s, float *dK, float *dy0, int accumulate_dy0,
+                       float *du_ext /* (n,n_ext) += dXf[:, n_s:n_s+n_ext]; NULL for the affine field */, int n_ext,
                        nlbac_stream_t s);
 /* Fused RK step: one launch evaluates stages [stage_begin, stage_end) of an explicit RK step with
  * n_stages_total stages for P problems x rows_per_problem rows: stage inputs

@@ -76,7 +76,12 @@ _PROTOS = {
     "nlbac_affine_combine_fwd": [_P, _P, _P, _I, _I, _I, _P, _P],
     "nlbac_affine_combine_bwd": [_P, _P, _P, _I, _I, _I, _F, _P, _P, _I, _P],
     "nlbac_rk_combine": [_P, _P, _I, c_float_p, c_float_p, _P, _I, _I, _I, _I, _P, _P],
-    "nlbac_rk_stage_bwd": [_P, _P, _P, _I, _I, c_float_p, c_float_p, _P, _I, _I, _I, _I, _P, _P, _I, _P],
+    "nlbac_rk_stage_bwd": [_P, _P, _P, _I, _I, c_float_p, c_float_p, _P, _I, _I, _I, _I, _P, _P, _I, _P, _I, _P],
+    "nlbac_cars_state": [_P, _I, _I, _P, _P],
+    "nlbac_cars_obs": [_P, _I, _P, _P],
+    "nlbac_cars_constraints_fwd": [_P, _P, _P, _P, _P, _F, _F, _F, _I, _P, _P, _P, _P],
+    "nlbac_cars_constraints_bwd": [_P, _P, _F, _F, _I, _P, _P, _P, _P, _P],
+    "nlbac_add_cols": [_P, _I, _I, _P, _I, _I, _I, _P],
     "nlbac_node_rk_fwd": [C.POINTER(Mlp), C.POINTER(Mlp), _P, _P, _I, _I, _I, _I, _I, c_float_p, c_float_p, _I,
                           c_float_p, _I, c_float_p, _P, _I, _P, _P, _P, _P, _L, _P, _L, _P, _P, _P],
     "nlbac_node_rk_bwd": [C.POINTER(Mlp), C.POINTER(Mlp), _P, _P, _I, _I, _I, _I, _I, _I, c_float_p, c_float_p, _P, _I,

@@ -351,6 +351,101 @@ __global__ __launch_bounds__(256) void unicycle_constraints_bwd_kernel(const flo
     dV_next[i] = (matr[(long)i * (NH + 1) + NH] > 0.f) ? ((sc[SC_COEF + NH] / batch_size) / dt) : 0.f;
 }
 
+// ---------------------------------------------------------------------------
+// SimulatedCars (C = NLBAC_SimulatedCarsFollowing_RL_training/Simulated_Car_Following_RL_training)
+//   get_state / get_obs         C/sac_cbf_clf/dynamics.py:59-62, 88-91
+//   relative-degree-2 CBFs+CLF  C/sac_cbf_clf/sac_cbf_clf.py:474-511 (primary), 618-645 (backup)
+// State = 5 x (position, velocity); h23 = x4 - x6 - r, h34 = x6 - x8 - r.
+// ---------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void cars_state_kernel(const float* obs, int obs_ld, int n, float* state) {
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+#pragma unroll
+    for (int c = 0; c < 10; ++c)      // the reference scales in float64 on the host, then casts
+        state[(long)i * 10 + c] = (float)((double)obs[(long)i * obs_ld + c] * ((c & 1) ? 30.0 : 100.0));
+}
+
+__global__ __launch_bounds__(256) void cars_obs_kernel(const float* state, int n, float* obs) {
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+#pragma unroll
+    for (int c = 0; c < 10; ++c) obs[(long)i * 10 + c] = state[(long)i * 10 + c] / ((c & 1) ? 30.0f : 100.0f);
+}
+
+__device__ __forceinline__ float cars_cbf(float h0, float h1, float h2, float gb) {
+    const float l1 = h1 - h0 + gb * h0;
+    const float l2 = h2 - h1 + gb * h1;
+    return -(l2 - l1) - gb * l1;
+}
+
+// state (B,10); x1, x2 (2B,10): primary rows then backup rows.  matr (B,3) = [cbf23, cbf34, clf], bmatr (B,2).
+__global__ __launch_bounds__(256) void cars_constraints_fwd_kernel(const float* state, const float* x1, const float* x2,
+                                                                   const float* V, const float* V1, float gamma_b,
+                                                                   float gamma_l, float radius, int B, float* matr,
+                                                                   float* bmatr, float* partials) {
+    __shared__ float red[20];
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    float v[5] = {0.f, 0.f, 0.f, 0.f, 0.f};
+    if (i < B) {
+        const float* s0 = state + (long)i * 10;
+        const float h23_0 = (s0[4] - s0[6]) + (-radius), h34_0 = (s0[6] - s0[8]) + (-radius);
+#pragma unroll
+        for (int p = 0; p < 2; ++p) {
+            const float* a = x1 + ((long)p * B + i) * 10;
+            const float* b = x2 + ((long)p * B + i) * 10;
+            const float c23 = cars_cbf(h23_0, (a[4] - a[6]) + (-radius), (b[4] - b[6]) + (-radius), gamma_b);
+            const float c34 = cars_cbf(h34_0, (a[6] - a[8]) + (-radius), (b[6] - b[8]) + (-radius), gamma_b);
+            if (p == 0) {
+                matr[(long)i * 3 + 0] = c23; matr[(long)i * 3 + 1] = c34;
+                v[0] = c23 > 0.f ? c23 : 0.f; v[1] = c34 > 0.f ? c34 : 0.f;
+            } else {
+                bmatr[(long)i * 2 + 0] = c23; bmatr[(long)i * 2 + 1] = c34;
+                v[3] = c23 > 0.f ? c23 : 0.f; v[4] = c34 > 0.f ? c34 : 0.f;
+            }
+        }
+        const float vv = V[i];
+        const float lya = (V1[i] - vv) + gamma_l * vv;
+        matr[(long)i * 3 + 2] = lya;
+        v[2] = lya > 0.f ? lya : 0.f;
+    }
+    block_sum_256<5>(v, red);
+    if (threadIdx.x == 0)
+#pragma unroll
+        for (int c = 0; c < 5; ++c) partials[(long)blockIdx.x * 5 + c] = v[c];
+}
+
+// dx1, dx2 (2B,10) and dV1 (B) from the loss coefficients in sc:  cbf = -h2 + 2(1-gb) h1 - (1-gb)^2 h0
+__global__ __launch_bounds__(256) void cars_constraints_bwd_kernel(const float* matr, const float* bmatr, float gamma_b,
+                                                                   float batch_size, int B, const float* sc,
+                                                                   float* dx1, float* dx2, float* dV1) {
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= B) return;
+#pragma unroll
+    for (int p = 0; p < 2; ++p) {
+        const float* m = p == 0 ? matr + (long)i * 3 : bmatr + (long)i * 2;
+        const float* coef = sc + (p == 0 ? SC_COEF : SC_BCOEF);
+        const float g23 = m[0] > 0.f ? coef[0] / batch_size : 0.f;
+        const float g34 = m[1] > 0.f ? coef[1] / batch_size : 0.f;
+        // d cbf/d h2 = -1 ; d cbf/d h1 = -(-1 + gb) + (1 - gb)  (the two autograd paths through l2 and l1)
+        const float c1 = -(-1.0f + gamma_b) + (1.0f - gamma_b);
+        float* a = dx1 + ((long)p * B + i) * 10;
+        float* b = dx2 + ((long)p * B + i) * 10;
+#pragma unroll
+        for (int c = 0; c < 10; ++c) { a[c] = 0.f; b[c] = 0.f; }
+        a[4] = g23 * c1; a[6] = -(g23 * c1) + g34 * c1; a[8] = -(g34 * c1);
+        b[4] = -g23; b[6] = g23 - g34; b[8] = g34;
+    }
+    dV1[i] = matr[(long)i * 3 + 2] > 0.f ? sc[SC_COEF + 2] / batch_size : 0.f;
+}
+
+// dst[row][col0 + c] += src[row][c]
+__global__ __launch_bounds__(256) void add_cols_kernel(float* dst, int dst_ld, int col0, const float* src, int src_ld,
+                                                       int ncols, int n) {
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    for (int c = 0; c < ncols; ++c) dst[(long)i * dst_ld + col0 + c] += src[(long)i * src_ld + c];
+}
+
 // MSE (mean over n*d) partial sums and gradient
 __global__ __launch_bounds__(256) void mse_kernel(const float* pred, int pred_ld, const float* target, int target_ld,
                                                   int n, int n_norm, int d, float* dpred, int dpred_ld,
@@ -503,5 +598,46 @@ extern "C" int nlbac_mse_fwd_bwd(const float* pred, int pred_ld, const float* ta
     NLBAC_REQUIRE(pred && target && dpred && partials, "nlbac_mse_fwd_bwd: null pointer");
     hipLaunchKernelGGL(mse_kernel, GRID1(n), pred, pred_ld, target, target_ld, n, n_norm, d, dpred, dpred_ld, partials);
     NLBAC_CHECK_LAUNCH("nlbac_mse_fwd_bwd");
+    return 0;
+}
+
+extern "C" int nlbac_cars_state(const float* obs, int obs_ld, int n, float* state, nlbac_stream_t s) {
+    NLBAC_REQUIRE(obs && state, "nlbac_cars_state: null pointer");
+    hipLaunchKernelGGL(cars_state_kernel, GRID1(n), obs, obs_ld, n, state);
+    NLBAC_CHECK_LAUNCH("nlbac_cars_state");
+    return 0;
+}
+
+extern "C" int nlbac_cars_obs(const float* state, int n, float* obs, nlbac_stream_t s) {
+    NLBAC_REQUIRE(obs && state, "nlbac_cars_obs: null pointer");
+    hipLaunchKernelGGL(cars_obs_kernel, GRID1(n), state, n, obs);
+    NLBAC_CHECK_LAUNCH("nlbac_cars_obs");
+    return 0;
+}
+
+extern "C" int nlbac_cars_constraints_fwd(const float* state, const float* x1, const float* x2, const float* V,
+                                          const float* V1, float gamma_b, float gamma_l, float radius, int B,
+                                          float* matr, float* bmatr, float* partials, nlbac_stream_t s) {
+    NLBAC_REQUIRE(state && x1 && x2 && V && V1 && matr && bmatr && partials, "nlbac_cars_constraints_fwd: null pointer");
+    hipLaunchKernelGGL(cars_constraints_fwd_kernel, GRID1(B), state, x1, x2, V, V1, gamma_b, gamma_l, radius, B, matr,
+                       bmatr, partials);
+    NLBAC_CHECK_LAUNCH("nlbac_cars_constraints_fwd");
+    return 0;
+}
+
+extern "C" int nlbac_cars_constraints_bwd(const float* matr, const float* bmatr, float gamma_b, float batch_size,
+                                          int B, const float* sc, float* dx1, float* dx2, float* dV1,
+                                          nlbac_stream_t s) {
+    NLBAC_REQUIRE(matr && bmatr && sc && dx1 && dx2 && dV1, "nlbac_cars_constraints_bwd: null pointer");
+    hipLaunchKernelGGL(cars_constraints_bwd_kernel, GRID1(B), matr, bmatr, gamma_b, batch_size, B, sc, dx1, dx2, dV1);
+    NLBAC_CHECK_LAUNCH("nlbac_cars_constraints_bwd");
+    return 0;
+}
+
+extern "C" int nlbac_add_cols(float* dst, int dst_ld, int col0, const float* src, int src_ld, int ncols, int n,
+                              nlbac_stream_t s) {
+    NLBAC_REQUIRE(dst && src && ncols >= 1, "nlbac_add_cols: bad arguments");
+    hipLaunchKernelGGL(add_cols_kernel, GRID1(n), dst, dst_ld, col0, src, src_ld, ncols, n);
+    NLBAC_CHECK_LAUNCH("nlbac_add_cols");
     return 0;
 }

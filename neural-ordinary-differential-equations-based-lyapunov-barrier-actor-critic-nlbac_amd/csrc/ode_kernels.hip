@@ -71,10 +71,13 @@ __global__ __launch_bounds__(256) void rk_combine_kernel(const float* y0, const 
 __global__ __launch_bounds__(256) void rk_stage_bwd_kernel(const float* dYup, const float* dXf, const float* dXg,
                                                            int dx_ld, int n_k, const RkCoef rc, const double* h_dev,
                                                            int h_stride, int rpp, int n_s, int n, float* dK,
-                                                           float* dy0, int acc_dy0) {
+                                                           float* dy0, int acc_dy0, float* du_ext, int n_ext) {
     const int i = blockIdx.x * 256 + threadIdx.x;
     if (i >= n) return;
     const float h = step_of(rc, h_dev, h_stride, i / rpp);
+    // non-affine field: columns n_s.. of the net's input gradient belong to the carried inputs (u, t)
+    if (du_ext && dXf)
+        for (int c = 0; c < n_ext; ++c) du_ext[(long)i * n_ext + c] += dXf[(long)i * dx_ld + n_s + c];
     for (int r = 0; r < n_s; ++r) {
         float d = dYup ? dYup[(long)i * n_s + r] : 0.f;
         if (dXf) d += dXf[(long)i * dx_ld + r];
@@ -296,13 +299,13 @@ extern "C" int nlbac_rk_combine(const float* y0, const float* K, int n_k, const 
 extern "C" int nlbac_rk_stage_bwd(const float* dYup, const float* dXf, const float* dXg, int dx_ld, int n_k,
                                   const float* coef, const float* h_host, const double* h_dev, int h_dev_stride,
                                   int P, int rows_per_problem, int n_s, float* dK, float* dy0, int accumulate_dy0,
-                                  nlbac_stream_t s) {
+                                  float* du_ext, int n_ext, nlbac_stream_t s) {
     RkCoef rc;
     NLBAC_REQUIRE(n_k == 0 || (dK && coef), "nlbac_rk_stage_bwd: null pointer");
     if (fill_rc(rc, coef, n_k, h_host, P, "nlbac_rk_stage_bwd")) return -1;
     const int n = P * rows_per_problem;
     hipLaunchKernelGGL(rk_stage_bwd_kernel, GRID1(n), dYup, dXf, dXg, dx_ld, n_k, rc, h_dev, h_dev_stride,
-                       rows_per_problem, n_s, n, dK, dy0, accumulate_dy0);
+                       rows_per_problem, n_s, n, dK, dy0, accumulate_dy0, du_ext, n_ext);
     NLBAC_CHECK_LAUNCH("nlbac_rk_stage_bwd");
     return 0;
 }

@@ -80,6 +80,7 @@ class _StepWS:
 
 class AffineNodeSolver:
     """odeint for ``dx/dt = f(x) + g(x) u`` with u constant over the step."""
+    STEP_WS = _StepWS
 
     def __init__(self, node, device):
         self.node, self.f, self.g = node, node.f, node.g
@@ -99,7 +100,7 @@ class AffineNodeSolver:
     def _step_ws(self, n, S, idx):
         key = (n, S, idx)
         if key not in self._ws:
-            self._ws[key] = _StepWS(self, n, S)
+            self._ws[key] = self.STEP_WS(self, n, S)
         return self._ws[key]
 
     def _buf(self, name, *shape, dtype=torch.float32):
@@ -134,6 +135,13 @@ class AffineNodeSolver:
         _lib.call("nlbac_affine_combine_fwd", fout.data_ptr(), g_out.data_ptr(), u.data_ptr(), self.n_s, self.n_u, n,
                   k_out.data_ptr(), s)
         self.nfe += 1
+
+    def _probe_eval(self, ytmp, u, n, ktmp, gtmp):
+        """field evaluation outside the step workspaces (dopri5 initial-step probe), nothing saved"""
+        tio = self._scratch.setdefault("tmp_io", {}).get(n)
+        if tio is None:
+            tio = self._scratch["tmp_io"][n] = self._eval_io(ytmp, gtmp)
+        self._eval(ytmp, u, n, ktmp, gtmp, tio)
 
     def _stage_eval(self, ws, st, u):
         n, S = ws.n, ws.S
@@ -308,12 +316,7 @@ class AffineNodeSolver:
             self._rk_fused(tws, ytmp, u, P, rpp, "euler", 0, 1, h_host=[0.0] * P, save_acts=False)
             ktmp = tws.K[0]
         else:
-            if "tmp_io" not in self._scratch:
-                self._scratch["tmp_io"] = {}
-            tio = self._scratch["tmp_io"].get(n)
-            if tio is None:
-                tio = self._scratch["tmp_io"][n] = self._eval_io(ytmp, gtmp)
-            self._eval(ytmp, u, n, ktmp, gtmp, tio)
+            self._probe_eval(ytmp, u, n, ktmp, gtmp)
         _lib.call("nlbac_dopri_norm_partials", ktmp.data_ptr(), ws.K[0].data_ptr(), y0.data_ptr(), None, None, 1,
                   rtol, atol, ns, nu, rpp, P, part.data_ptr(), s)
         self._control(part, nblk, 1, P, rpp, t_end, ctl)
@@ -392,7 +395,7 @@ class AffineNodeSolver:
         kids, info = [], []
         for p in range(P):
             if p not in self._children:
-                self._children[p] = AffineNodeSolver(self.node, self.device)
+                self._children[p] = type(self)(self.node, self.device)
             k = self._children[p]
             k.comm, k.fused = self.comm, self.fused
             rows = slice(p * rpp, (p + 1) * rpp)
@@ -458,7 +461,7 @@ class AffineNodeSolver:
                 beta, first_eval = tab["beta"], True
                 # out = y0 + h sum c_j K_j
                 _lib.call("nlbac_rk_stage_bwd", dout.data_ptr(), None, None, 0, S, fptr(*tab["c_sol"]), h_host,
-                          None, 0, P, rpp, ns, ws.dK.data_ptr(), ws.dy0.data_ptr(), 0, s)
+                          None, 0, P, rpp, ns, ws.dK.data_ptr(), ws.dy0.data_ptr(), 0, None, 0, s)
                 top_up = None
             if self.fused:
                 beta_arr, S_tab = self._beta(method)
@@ -477,37 +480,45 @@ class AffineNodeSolver:
                 if st == 0 and not first_eval:
                     break                  # FSAL alias of the previous step's last stage
                 need_dx = (st > 0) or need_dy0
-                # field backward at stage st
-                _lib.call("nlbac_affine_combine_bwd", ws.dK[st].data_ptr(), ws.gout[st].data_ptr(), u.data_ptr(),
-                          ns, nu, n, 1.0, ws.dG[st].data_ptr() if (need_dx or need_params) else None,
-                          du.data_ptr() if du is not None else None, 1, s)
-                if need_dx or need_params:
-                    key = (st, need_params, need_dx)
-                    io = ws.io_bwd.get(key)
-                    if io is None:
-                        io = ws.io_bwd[key] = io_array(2)
-                        f, g = self.f, self.g
-                        for i, (net, dy, ld, acts, dz, dx) in enumerate((
-                                (f, ws.dK[st], ns, ws.acts_f, ws.dz_f, ws.dXf),
-                                (g, ws.dG[st], ns * nu, ws.acts_g, ws.dz_g, ws.dXg))):
-                            io[i].dy, io[i].dy_ld = dy.data_ptr(), ld
-                            io[i].acts = acts[:, st * ws.n:].data_ptr()
-                            io[i].acts_ls = S * ws.n * net.hid
-                            if need_params:
-                                io[i].dz = dz[:, st * ws.n:].data_ptr()
-                            if need_dx:
-                                io[i].dx, io[i].dx_ld = dx.data_ptr(), net.in_dim
-                    _lib.call("nlbac_mlp_bwd_data", self._nets(), io, 2, n, s)
-                if need_dx:
-                    up = top_up if (st == S - 1 and top_up is not None) else None
-                    coef = beta[st - 1] if st > 0 else []
-                    _lib.call("nlbac_rk_stage_bwd", up.data_ptr() if up is not None else None, ws.dXf.data_ptr(),
-                              ws.dXg.data_ptr(), self.f.in_dim, st, fptr(*coef) if coef else None, h_host, h_dev,
-                              h_stride, P, rpp, ns, ws.dK.data_ptr(), ws.dy0.data_ptr(), 1, s)
+                up = top_up if (st == S - 1 and top_up is not None) else None
+                coef = beta[st - 1] if st > 0 else []
+                self._stage_backward(ws, st, need_dx, need_params, du, up, coef, h_host, h_dev, h_stride)
             dy_carry = ws.dy0
             dk_carry = ws.dK[0]
         dy0 = steps[0]["ws"].dy0 if need_dy0 else None
         return du, dy0
+
+    def _stage_backward(self, ws, st, need_dx, need_params, du, up, coef, h_host, h_dev, h_stride):
+        """Un-fused backward of one stage of the control-affine field: affine_bwd -> mlp_bwd_data[f,g] ->
+        rk_stage_bwd (kept as the cross-check of nlbac_node_rk_bwd)."""
+        ctx = self.ctx
+        P, rpp, n, u = ctx["P"], ctx["rpp"], ctx["n"], ctx["u"]
+        ns, nu, S = self.n_s, self.n_u, ws.S
+        s = stream_ptr()
+        _lib.call("nlbac_affine_combine_bwd", ws.dK[st].data_ptr(), ws.gout[st].data_ptr(), u.data_ptr(),
+                  ns, nu, n, 1.0, ws.dG[st].data_ptr() if (need_dx or need_params) else None,
+                  du.data_ptr() if du is not None else None, 1, s)
+        if need_dx or need_params:
+            key = (st, need_params, need_dx)
+            io = ws.io_bwd.get(key)
+            if io is None:
+                io = ws.io_bwd[key] = io_array(2)
+                f, g = self.f, self.g
+                for i, (net, dy, ld, acts, dz, dx) in enumerate((
+                        (f, ws.dK[st], ns, ws.acts_f, ws.dz_f, ws.dXf),
+                        (g, ws.dG[st], ns * nu, ws.acts_g, ws.dz_g, ws.dXg))):
+                    io[i].dy, io[i].dy_ld = dy.data_ptr(), ld
+                    io[i].acts = acts[:, st * ws.n:].data_ptr()
+                    io[i].acts_ls = S * ws.n * net.hid
+                    if need_params:
+                        io[i].dz = dz[:, st * ws.n:].data_ptr()
+                    if need_dx:
+                        io[i].dx, io[i].dx_ld = dx.data_ptr(), net.in_dim
+            _lib.call("nlbac_mlp_bwd_data", self._nets(), io, 2, n, s)
+        if need_dx:
+            _lib.call("nlbac_rk_stage_bwd", up.data_ptr() if up is not None else None, ws.dXf.data_ptr(),
+                      ws.dXg.data_ptr(), self.f.in_dim, st, fptr(*coef) if coef else None, h_host, h_dev,
+                      h_stride, P, rpp, ns, ws.dK.data_ptr(), ws.dy0.data_ptr(), 1, None, 0, s)
 
     def accumulate_param_grads(self, arena, slabs_per_step):
         """dW/db of f_net and g_net over every evaluated stage of every accepted
@@ -533,5 +544,127 @@ class AffineNodeSolver:
                 io[i].grad = arena.grad[n_used:].data_ptr()
             assert n_used + slabs_per_step <= arena.n_slabs, "arena has too few gradient slabs"
             bwd_weights(self._nets(), io, 2, rows, slabs_per_step, arena.n, self.device)
+            n_used += slabs_per_step
+        return n_used
+
+
+# ---------------------------------------------------------------------------
+# Non-affine field  dx/dt = net([x, c])  with carried inputs c = (u, t, ...) constant over the step
+# (SimulatedCars: C/sac_cbf_clf/model.py:179-205).  Same RK machinery, stage by stage on nlbac_mlp_*.
+# ---------------------------------------------------------------------------
+class _ConcatStepWS:
+    def __init__(self, solver, n, S):
+        dev, ns, nc = solver.device, solver.n_s, solver.n_u
+        net = solver.net
+        self.n, self.S = n, S
+        z = lambda *s: torch.zeros(*s, dtype=torch.float32, device=dev)
+        self.K = z(S, n, ns)
+        self.Y = z(S, n, ns)
+        self.acts = z(net.n_layers - 1, S * n, net.hid)
+        self.y1 = z(n, ns)
+        self.err = z(n, ns)
+        self.io_fwd, self.io_bwd = {}, {}
+        self._bwd = None
+
+    def bwd(self, solver):
+        if self._bwd is None:
+            dev, ns, nc, n, S = solver.device, solver.n_s, solver.n_u, self.n, self.S
+            net = solver.net
+            z = lambda *s: torch.zeros(*s, dtype=torch.float32, device=dev)
+            self.dK = z(S, n, ns)
+            self.dz = z(net.n_layers - 1, S * n, net.hid)
+            self.dX = z(n, net.in_dim)
+            self.dy0 = z(n, ns)
+            self.dy1 = z(n, ns)
+            self.c_rep = z(S * n, nc)      # carried inputs repeated per stage (first-layer weight gradients)
+            self._bwd = True
+        return self
+
+
+class ConcatNodeSolver(AffineNodeSolver):
+    """``u`` here is the (n, n_carry) block of carried inputs; ``backward`` returns its gradient."""
+    STEP_WS = _ConcatStepWS
+
+    def __init__(self, node, device):
+        self.node, self.net = node, node.net_handle
+        self.f = self.g = self.net            # (base-class bookkeeping only)
+        self.n_s, self.n_u = node.n_s, node.n_carry
+        self.device = torch.device(device)
+        self._ws, self._scratch = {}, {}
+        self.nfe = 0
+        self._net_arr, self._coefs, self._children = None, {}, {}
+        self.fused = False
+        self.stats = dict(solves=0, single_step=0, multi_attempt=0, split=0)
+        self.comm = None
+
+    def _nets(self):
+        if self._net_arr is None:
+            self._net_arr = mlp_array([self.net.desc])
+        return self._net_arr
+
+    def _eval_io(self, x, k_out, c, acts=None, ls=0):
+        io = io_array(1)
+        io[0].x0, io[0].x0_dim, io[0].x0_ld = x.data_ptr(), self.n_s, self.n_s
+        io[0].x1, io[0].x1_dim, io[0].x1_ld = c.data_ptr(), self.n_u, self.n_u
+        io[0].y, io[0].y_ld = k_out.data_ptr(), self.n_s
+        if acts is not None:
+            io[0].acts, io[0].acts_ls = acts.data_ptr(), ls
+        return io
+
+    def _eval(self, x, u, n, k_out, g_out, io=None):
+        if io is None:
+            io = self._eval_io(x, k_out, u)
+        _lib.call("nlbac_mlp_fwd", self._nets(), io, 1, n, stream_ptr())
+        self.nfe += 1
+
+    def _probe_eval(self, ytmp, u, n, ktmp, gtmp):
+        self._eval(ytmp, u, n, ktmp, None)
+
+    def _stage_eval(self, ws, st, u):
+        n, S = ws.n, ws.S
+        io = ws.io_fwd.get(st)
+        if io is None:
+            io = ws.io_fwd[st] = self._eval_io(ws.Y[st], ws.K[st], u, ws.acts[:, st * n:], S * n * self.net.hid)
+        self._eval(ws.Y[st], u, n, ws.K[st], None, io)
+
+    def _stage_backward(self, ws, st, need_dx, need_params, du, up, coef, h_host, h_dev, h_stride):
+        ctx = self.ctx
+        P, rpp, n = ctx["P"], ctx["rpp"], ctx["n"]
+        ns, S, net = self.n_s, ws.S, self.net
+        s = stream_ptr()
+        key = (st, need_params)
+        io = ws.io_bwd.get(key)
+        if io is None:
+            io = ws.io_bwd[key] = io_array(1)
+            io[0].dy, io[0].dy_ld = ws.dK[st].data_ptr(), ns
+            io[0].acts, io[0].acts_ls = ws.acts[:, st * n:].data_ptr(), S * n * net.hid
+            if need_params:
+                io[0].dz = ws.dz[:, st * n:].data_ptr()
+            io[0].dx, io[0].dx_ld = ws.dX.data_ptr(), net.in_dim
+        _lib.call("nlbac_mlp_bwd_data", self._nets(), io, 1, n, s)
+        # dY = [up] + dX[:, :n_s] ; dy0 += dY ; dK[j] += beta h dY ; d carried += dX[:, n_s:]
+        _lib.call("nlbac_rk_stage_bwd", up.data_ptr() if up is not None else None, ws.dX.data_ptr(), None,
+                  net.in_dim, st, fptr(*coef) if coef else None, h_host, h_dev, h_stride, P, rpp, ns,
+                  ws.dK.data_ptr(), ws.dy0.data_ptr(), 1, du.data_ptr() if du is not None else None, self.n_u, s)
+
+    def accumulate_param_grads(self, arena, slabs_per_step):
+        ctx = self.ctx
+        n_used = 0
+        for si, step in enumerate(ctx["steps"]):
+            ws = step["ws"]
+            S, n = ws.S, ws.n
+            st0 = 0 if step["first"] or ctx["method"] != "dopri5" else 1
+            rows = (S - st0) * n
+            ws.c_rep.view(S, n, self.n_u).copy_(ctx["u"].unsqueeze(0).expand(S, n, self.n_u))
+            io = io_array(1)
+            io[0].x0, io[0].x0_dim, io[0].x0_ld = ws.Y[st0:].data_ptr(), self.n_s, self.n_s
+            io[0].x1, io[0].x1_dim, io[0].x1_ld = ws.c_rep[st0 * n:].data_ptr(), self.n_u, self.n_u
+            io[0].dy, io[0].dy_ld = ws.dK[st0:].data_ptr(), self.n_s
+            io[0].acts = ws.acts[:, st0 * n:].data_ptr()
+            io[0].dz = ws.dz[:, st0 * n:].data_ptr()
+            io[0].acts_ls = S * n * self.net.hid
+            io[0].grad = arena.grad[n_used:].data_ptr()
+            assert n_used + slabs_per_step <= arena.n_slabs, "arena has too few gradient slabs"
+            bwd_weights(self._nets(), io, 1, rows, slabs_per_step, arena.n, self.device)
             n_used += slabs_per_step
         return n_used

@@ -118,25 +118,39 @@ class GaussianPolicy(nn.Module):
 
 
 class NeuralODEModel(nn.Module):
-    """Learned dynamics.  ``NeuralODEModel(input_dim, output_dim1, output_dim2)``
-    is the control-affine field f(x) + g(x) u with f_net 5 and g_net 4 Linear
-    layers of width 100 (model.py:177-206)."""
+    """Learned dynamics, both reference forms:
 
-    def __init__(self, input_dim, output_dim1, output_dim2, hidden_dim=100, f_depth=5, g_depth=4):
+    ``NeuralODEModel(input_dim, output_dim1, output_dim2)`` — control-affine field f(x) + g(x) u with f_net 5
+    and g_net 4 Linear layers of width 100 (U/sac_cbf_clf/model.py:177-206; Pvtol uses the same form);
+    ``NeuralODEModel(input_dim, output_dim)`` — one net of 4 Linear layers of width 64 on [x, u, t]
+    (C/sac_cbf_clf/model.py:179-194); the trailing ``input_dim - output_dim`` inputs are carried unchanged."""
+
+    def __init__(self, input_dim, output_dim1, output_dim2=None, hidden_dim=None, f_depth=5, g_depth=4, depth=4):
         super().__init__()
         self.input_dim, self.output_dim1, self.output_dim2 = input_dim, output_dim1, output_dim2
-        self.n_s, self.n_u = output_dim1, output_dim2 // output_dim1
+        self.affine = output_dim2 is not None
 
-        def seq(depth, out):
-            layers = [nn.Linear(input_dim, hidden_dim), nn.ReLU()]
+        def seq(in_dim, depth, out, hid):
+            layers = [nn.Linear(in_dim, hid), nn.ReLU()]
             for _ in range(depth - 2):
-                layers += [nn.Linear(hidden_dim, hidden_dim), nn.ReLU()]
-            layers += [nn.Linear(hidden_dim, out)]
+                layers += [nn.Linear(hid, hid), nn.ReLU()]
+            layers += [nn.Linear(hid, out)]
             return nn.Sequential(*layers)
-        self.f_net = seq(f_depth, output_dim1)
-        self.g_net = seq(g_depth, output_dim2)
+        if self.affine:
+            hid = hidden_dim or 100
+            self.n_s, self.n_u = output_dim1, output_dim2 // output_dim1
+            self.f_net = seq(input_dim, f_depth, output_dim1, hid)
+            self.g_net = seq(input_dim, g_depth, output_dim2, hid)
+        else:
+            hid = hidden_dim or 64
+            self.output_dim = output_dim1
+            self.n_s, self.n_carry = output_dim1, input_dim - output_dim1
+            self.net = seq(input_dim, depth, output_dim1, hid)
 
     def attach(self, arena):
-        self.f = MlpHandle(arena, [(m.weight, m.bias) for m in self.f_net if isinstance(m, nn.Linear)], "f_net")
-        self.g = MlpHandle(arena, [(m.weight, m.bias) for m in self.g_net if isinstance(m, nn.Linear)], "g_net")
-        return [self.f, self.g]
+        if self.affine:
+            self.f = MlpHandle(arena, [(m.weight, m.bias) for m in self.f_net if isinstance(m, nn.Linear)], "f_net")
+            self.g = MlpHandle(arena, [(m.weight, m.bias) for m in self.g_net if isinstance(m, nn.Linear)], "g_net")
+            return [self.f, self.g]
+        self.net_handle = MlpHandle(arena, [(m.weight, m.bias) for m in self.net if isinstance(m, nn.Linear)], "net")
+        return [self.net_handle]

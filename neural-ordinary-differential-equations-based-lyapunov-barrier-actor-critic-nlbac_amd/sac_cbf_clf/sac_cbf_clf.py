@@ -26,12 +26,12 @@ import torch.nn as nn
 
 from .. import _lib
 from ..arena import Arena, bwd_weights, io_array, mlp_array, pack, stream_ptr
-from ..odeint import AffineNodeSolver
 from . import _layout as SC
-from .model import GaussianPolicy, LyaNetwork, NeuralODEModel, QNetwork
+from .model import GaussianPolicy, LyaNetwork, QNetwork
+from .tasks import TASKS
 from .utils import to_tensor
 
-DYNAMICS_MODE = {'Unicycle': {'n_s': 3, 'n_u': 2}}
+DYNAMICS_MODE = {'Unicycle': {'n_s': 3, 'n_u': 2}, 'SimulatedCars': {'n_s': 10, 'n_u': 1}}
 l_p = 0.03
 
 
@@ -42,15 +42,31 @@ class PoseLoss(nn.Module):
         return nn.functional.mse_loss(predicted_state, true_state)
 
 
-class _Workspace:
-    """Per-batch-size device buffers (allocated once, reused every update)."""
+class _Layout:
+    """Column offsets of one minibatch row in HBM: the fields of ``ReplayMemory.sample``
+    (replay_memory.py:24-25) side by side, row stride padded to 16 bytes."""
 
-    def __init__(self, B, H, dev, n_hz):
+    def __init__(self, task):
+        self.obs_dim, self.act_dim, self.lya_dim = task.obs_dim, task.act_dim, task.lya_dim
+        c = 0
+        for name, w in (("obs", task.obs_dim), ("act", task.act_dim), ("rew", 1), ("con", 1), ("lya", task.lya_dim),
+                        ("nlya", task.lya_dim), ("nobs", task.obs_dim), ("mask", 1), ("t", 1), ("nt", 1)):
+            setattr(self, name, c)
+            c += w
+        self.width = c
+        self.LD = (c + 3) // 4 * 4
+
+
+class _Workspace:
+    """Per-batch-size device buffers (allocated once, reused every update); the task adds its own."""
+
+    def __init__(self, B, H, dev, lay, task):
         z = lambda *s: torch.zeros(*s, dtype=torch.float32, device=dev)
+        A, Do = lay.act_dim, lay.obs_dim
         self.B = B
-        self.mb = z(B, 24)                       # minibatch rows: obs7 act2 r c cen2 ncen2 nobs7 mask (+pad)
-        self.eps = z(3, B, 2)
-        self.heads_n, self.na, self.nlogp = z(B, 4), z(B, 2), z(B)
+        self.mb = z(B, lay.LD)                   # minibatch rows (see _Layout)
+        self.eps = z(task.n_eps, B, A)
+        self.heads_n, self.na, self.nlogp = z(B, 2 * A), z(B, A), z(B)
         self.q6 = z(6, B)                        # q1t q2t lt q1 q2 lf
         self.dq3 = z(3, B)
         self.next_q, self.next_l = z(B), z(B)
@@ -58,25 +74,18 @@ class _Workspace:
         self.dz_c = z(3, 2, B, H)
         self.nblk = (B + 255) // 256
         self.part_td = z(self.nblk, 3)
-        self.heads2, self.pi2, self.logp2 = z(2 * B, 4), z(2 * B, 2), z(2 * B)
+        self.heads2, self.pi2, self.logp2 = z(2 * B, 2 * A), z(2 * B, A), z(2 * B)
         self.acts_p = z(2, 2, B, H)
         self.dz_p = z(2, 2, B, H)
-        self.ps = z(B, 2)
-        self.y0_2 = z(2 * B, 3)
         self.plan = None
         self.graphs, self.warm = {}, 0
         self.qpi = z(2, 2 * B)
         self.acts_q = z(4, 2, B, H)
-        self.V, self.Vn, self.dVn = z(B), z(B), z(B)
-        self.acts_vn = z(2, B, H)
         self.dq_pi = z(2, 2 * B)
         self.part_q = z(2, self.nblk, 2)
-        self.ps_next2, self.dps_next2, self.dps_v2 = z(2 * B, 2), z(2 * B, 2), z(2 * B, 2)
-        self.matr, self.bmatr = z(B, n_hz + 1), z(B, n_hz)
-        self.part_c = z(self.nblk, 2 * n_hz + 1)
-        self.dx_next2 = z(2 * B, 3)
-        self.dxq = z(2, 2 * B, 9)
-        self.dheads2 = z(2 * B, 4)
+        self.dxq = z(2, 2 * B, Do + A)
+        self.dheads2 = z(2 * B, 2 * A)
+        task.alloc(self)
 
 
 class SAC_CBF_CLF(object):
@@ -85,7 +94,6 @@ class SAC_CBF_CLF(object):
         self.gamma = args.gamma
         self.gamma_b = args.gamma_b
         self.tau = args.tau
-        self.center_pos_num = 2
         self.policy_type = args.policy
         self.batch_size = args.batch_size
         self.target_update_interval = args.target_update_interval
@@ -98,8 +106,16 @@ class SAC_CBF_CLF(object):
                                "there is no CPU fallback")
         if self.policy_type != "Gaussian":
             raise NotImplementedError("only the Gaussian policy is on the device path")
+        if env.dynamics_mode not in TASKS:
+            raise Exception('Dynamics mode not supported.')
         _lib.load()
         self.device = torch.device("cuda")
+        self.env = env
+        self.task = task = TASKS[env.dynamics_mode](self, env, args)
+        self.lay = _Layout(task)
+        if num_inputs != task.obs_dim or action_space.shape[0] != task.act_dim:
+            raise ValueError("%s expects %d observations / %d actions" % (task.name, task.obs_dim, task.act_dim))
+        self.center_pos_num = task.lya_dim       # inputs of the Lyapunov network
         self.critic_lyapunov_lr = 0.0004
         self.lr = args.lr
         hidden = args.hidden_size
@@ -127,15 +143,12 @@ class SAC_CBF_CLF(object):
         self.policy = GaussianPolicy(num_inputs, n_act, hidden, action_space)
         self.backup_policy = GaussianPolicy(num_inputs, n_act, hidden, action_space)
 
-        self.env = env
-        if self.env.dynamics_mode not in DYNAMICS_MODE:
-            raise Exception('Dynamics mode not supported.')
-        self.num_cbfs = len(env.hazards_locations)
+        self.num_cbfs = task.num_cbfs
         self.l_p = l_p
         self.action_dim = env.action_space.shape[0]
         self.u_min, self.u_max = self.get_control_bounds()
         self.num_constraints = self.num_cbfs + 1
-        self.neural_ode_model = NeuralODEModel(3, 3, 6)
+        self.neural_ode_model = task.build_node()
         self.solver = 'euler'
         self.model_loss_func = PoseLoss()
         self.atol, self.rtol = 1e-7, 1e-5
@@ -152,13 +165,13 @@ class SAC_CBF_CLF(object):
         (self.h_b,) = self.backup_policy.attach(self.ar_a)
         self.ar_a.add_group([self.log_alpha])
         self.ar_a.add_group([self.backup_log_alpha])
-        self.h_f, self.h_g = self.neural_ode_model.attach(self.ar_n)
+        self.h_node = list(self.neural_ode_model.attach(self.ar_n))
         for ar in (self.ar_c, self.ar_a, self.ar_n):
             ar.finalize()
         self.ar_c.hard_update_target()
         self.policy.to(dev)
         self.backup_policy.to(dev)
-        for h in (self.h_q1, self.h_q2, self.h_l, self.h_p, self.h_b, self.h_f, self.h_g):
+        for h in [self.h_q1, self.h_q2, self.h_l, self.h_p, self.h_b] + self.h_node:
             h.bind()
         self.la_off = self.ar_a.offset_of[id(self.log_alpha)]
         self.la_stride = self.ar_a.offset_of[id(self.backup_log_alpha)] - self.la_off
@@ -174,15 +187,21 @@ class SAC_CBF_CLF(object):
         sc_host[SC.SC_RHO_F64:SC.SC_RHO_F64 + 2] = np.array([1.0], dtype=np.float64).view(np.float32)
         sc_host[SC.SC_BRHO_F64:SC.SC_BRHO_F64 + 2] = np.array([1.0], dtype=np.float64).view(np.float32)
         self.sc.copy_(torch.from_numpy(sc_host))
-        self.hazards = torch.tensor(np.asarray(env.hazards_locations), dtype=torch.float32, device=dev).contiguous()
-        self.node_solver = AffineNodeSolver(self.neural_ode_model, dev)      # policy-loss rollouts (2B rows)
-        self.fit_solver = AffineNodeSolver(self.neural_ode_model, dev)       # NODE fit rollouts
+        task.setup()
         self._ws = {}
         self._noise = None
         self._fit_ws = {}
         self.use_graphs = False  # replay the update as hipGraphs (single GPU; see update_on_device)
         self.dp = None          # nlbac_amd.parallel.DataParallel when sharded over GPUs
         self._xb = {}
+
+    @property
+    def node_solver(self):
+        return self.task.solvers[0]
+
+    @property
+    def fit_solver(self):
+        return self.task.fit_solver
 
     # ------------------------------------------------------------ data parallel
     def enable_data_parallel(self, dist, group=None):
@@ -196,8 +215,8 @@ class SAC_CBF_CLF(object):
         self.ar_c.hard_update_target()
         self.dp.broadcast_(self.sc)
         self.repack_all()
-        self.node_solver.comm = self.dp
-        self.fit_solver.comm = self.dp
+        for sv in self.task.solvers:
+            sv.comm = self.dp
         return self
 
     @property
@@ -236,12 +255,13 @@ class SAC_CBF_CLF(object):
 
     # ------------------------------------------------------------------ utils
     def repack_all(self):
-        pack([self.h_q1, self.h_q2, self.h_l, self.h_p, self.h_b, self.h_f, self.h_g])
+        pack([self.h_q1, self.h_q2, self.h_l, self.h_p, self.h_b] + self.h_node)
         pack([self.h_q1, self.h_q2, self.h_l], target=True)
 
     def set_noise(self, eps_list):
         """Pre-drawn N(0,1) draws for the next update, reference order:
-        [next_obs sample, obs sample, backup sample], each (B, n_u)."""
+        [next_obs sample, obs sample, backup sample (, SimulatedCars: second-step sample, second-step
+        backup sample)], each (B, n_u)."""
         self._noise = [torch.as_tensor(e, dtype=torch.float32) for e in eps_list]
 
     def _scalars(self):
@@ -298,92 +318,96 @@ class SAC_CBF_CLF(object):
         minibatch -> 6 floats.  ``dynamics_model`` is accepted for signature
         parity; obs->state runs on the device."""
         batch = memory.sample(batch_size=batch_size)
-        node_batch = None
+        node_rows = None
         if updates % NODE_model_update_interval == 0:
             nb = min(NODE_memory.position, 32768)
-            rows = NODE_memory.sample(batch_size=nb)
-            node_batch = (rows[0], rows[1], rows[6])
-        return self.update_from_host(batch, updates, node_batch)
+            node_rows = NODE_memory.sample(batch_size=nb)
+        return self.update_from_host(batch, updates, node_rows)
+
+    def _rows_from_host(self, batch):
+        """Pack the 10-tuple of ``ReplayMemory.sample`` into minibatch-layout rows (one H2D copy)."""
+        lay = self.lay
+        state, action, reward, constraint, lya_in, next_lya_in, nstate, mask = batch[:8]
+        n = np.asarray(state).shape[0]
+        host = np.zeros((n, lay.LD), dtype=np.float32)
+        host[:, lay.obs:lay.obs + lay.obs_dim] = state
+        host[:, lay.act:lay.act + lay.act_dim] = np.asarray(action).reshape(n, lay.act_dim)
+        host[:, lay.rew], host[:, lay.con] = reward, constraint
+        host[:, lay.lya:lay.lya + lay.lya_dim] = lya_in
+        host[:, lay.nlya:lay.nlya + lay.lya_dim] = next_lya_in
+        host[:, lay.nobs:lay.nobs + lay.obs_dim] = nstate
+        host[:, lay.mask] = mask
+        if len(batch) > 9 and batch[8] is not None and np.asarray(batch[8]).dtype != object:
+            host[:, lay.t], host[:, lay.nt] = batch[8], batch[9]
+        return torch.from_numpy(host)
 
     def update_from_host(self, batch, updates, node_batch=None):
-        """batch: the 10-tuple of numpy arrays of ``ReplayMemory.sample``."""
-        state, action, reward, constraint, center, ncenter, nstate, mask = batch[:8]
-        B = state.shape[0]
+        """batch / node_batch: tuples of numpy arrays in the field order of ``ReplayMemory.sample``
+        (node_batch may also be the short form (obs, action, next_obs[, t]))."""
+        B = np.asarray(batch[0]).shape[0]
         ws = self._workspace(B)
-        host = np.empty((B, 24), dtype=np.float32)
-        host[:, 0:7], host[:, 7:9] = state, action
-        host[:, 9], host[:, 10] = reward, constraint
-        host[:, 11:13], host[:, 13:15] = center, ncenter
-        host[:, 15:22], host[:, 22] = nstate, mask
-        host[:, 23] = 0
-        ws.mb.copy_(torch.from_numpy(host), non_blocking=False)
+        ws.mb.copy_(self._rows_from_host(batch), non_blocking=False)
         if node_batch is not None:
-            nobs, nact, nnobs = (torch.as_tensor(np.asarray(a), dtype=torch.float32).to(self.device)
-                                 for a in node_batch)
-            self.fit_node(nobs, nact, nnobs)
+            if len(node_batch) <= 4:       # (obs, action, next_obs[, t]) -> full field order
+                o, a_, no = node_batch[:3]
+                n = np.asarray(o).shape[0]
+                t = np.asarray(node_batch[3]).reshape(n) if len(node_batch) == 4 else np.zeros(n)
+                zl = np.zeros((n, self.lay.lya_dim))
+                node_batch = (o, a_, np.zeros(n), np.zeros(n), zl, zl, no, np.ones(n), t, t)
+            self.fit_node_rows(self._rows_from_host(node_batch).to(self.device))
         return self.update_on_device(ws, updates)
 
     def _workspace(self, B):
         if B not in self._ws:
-            self._ws[B] = _Workspace(B, self.hidden, self.device, self.num_cbfs)
+            self._ws[B] = _Workspace(B, self.hidden, self.device, self.lay, self.task)
         return self._ws[B]
 
     # -- NODE fit (model.py:221-260 via sac_cbf_clf.py:205-219) -----------------
-    def fit_node(self, obs, action, next_obs):
-        """One Adam step of the NODE regression on device tensors (N,7),(N,2),(N,7)."""
-        obs, action, next_obs = obs.contiguous(), action.contiguous(), next_obs.contiguous()
-        self._fit(obs.data_ptr(), obs.shape[1], action, next_obs.data_ptr(), next_obs.shape[1], obs.shape[0])
-
     def fit_node_rows(self, rows):
-        """Same, for a device tensor of minibatch-layout rows (N,24): obs at column 0,
-        action at 7, next_obs at 15 (the layout ``update_from_host`` uploads)."""
-        self._fit(rows.data_ptr(), rows.shape[1], rows[:, 7:9], rows.data_ptr() + 4 * 15,
-                  rows.shape[1], rows.shape[0])
+        """One Adam step of the NODE regression on a device tensor of minibatch-layout rows (N, LD)
+        (obs, action, next_obs and, where the model takes it, t are read in place)."""
+        self._fit(*self.task.fit_inputs(rows))
 
     def _fit(self, p_obs, obs_ld, action, p_nobs, nobs_ld, N):
+        task = self.task
         if N not in self._fit_ws:
-            z = lambda *sh: torch.zeros(*sh, dtype=torch.float32, device=self.device)
-            self._fit_ws[N] = dict(st=z(N, 3), nst=z(N, 3), dpred=z(N, 3), part=z((N + 255) // 256), u=z(N, 2),
-                                   graphs={}, warm=0)
+            w = task.fit_ws(N)
+            w.update(graphs={}, warm=0)
+            self._fit_ws[N] = w
         w = self._fit_ws[N]
         w["u"].copy_(action)
         key = (p_obs, obs_ld, p_nobs, nobs_ld, self.solver)
-        part1 = lambda: self._fit_part1(w, p_obs, obs_ld, p_nobs, nobs_ld, N)
-        if not (self.use_graphs and self.world == 1) or w["warm"] < 1:
+        part1 = lambda: task.fit_part1(w, p_obs, obs_ld, p_nobs, nobs_ld, N)
+        if not (self.use_graphs and self.world == 1 and task.graph_ok) or w["warm"] < 1:
             w["warm"] += 1
             part1()
-            self._fit_part2(w, N, self.fit_solver.forward_finish())
+            self._fit_part2(w, N, task.fit_solver.forward_finish())
             return
         g = w["graphs"]
         if ("p1",) + key not in g:
             g[("p1",) + key] = self._capture(part1)
         g[("p1",) + key].replay()
-        if self.solver == "dopri5" and not self.fit_solver.first_step_done():
-            self._fit_part2(w, N, self.fit_solver.forward_finish())      # rare: finish this one eagerly
+        if self.solver == "dopri5" and not task.fit_solver.first_step_done():
+            self._fit_part2(w, N, task.fit_solver.forward_finish())      # rare: finish this one eagerly
             return
         if ("p2",) + key not in g:
             g[("p2",) + key] = self._capture(
-                lambda: self._fit_part2(w, N, self.fit_solver.forward_finish(assume_single_step=True)))
+                lambda: self._fit_part2(w, N, task.fit_solver.forward_finish(assume_single_step=True)))
         g[("p2",) + key].replay()
-
-    def _fit_part1(self, w, p_obs, obs_ld, p_nobs, nobs_ld, N):
-        s = stream_ptr()
-        _lib.call("nlbac_unicycle_state", p_obs, obs_ld, N, self.l_p, w["st"].data_ptr(), None, s)
-        _lib.call("nlbac_unicycle_state", p_nobs, nobs_ld, N, self.l_p, w["nst"].data_ptr(), None, s)
-        self.fit_solver.forward_begin(w["st"], w["u"], 1, N, self.solver, self.env.dt, self.atol, self.rtol)
 
     def _fit_part2(self, w, N, pred):
         s = stream_ptr()
+        ns = self.task.n_s
         nblk = (N + 255) // 256
         NG = N * self.world
-        _lib.call("nlbac_mse_fwd_bwd", pred.data_ptr(), 3, w["nst"].data_ptr(), 3, N, NG, 3, w["dpred"].data_ptr(), 3,
-                  w["part"].data_ptr(), s)
-        _lib.call("nlbac_sum_partials", w["part"].data_ptr(), nblk, 1, 1.0 / (NG * 3),
+        _lib.call("nlbac_mse_fwd_bwd", pred.data_ptr(), ns, w["nst"].data_ptr(), ns, N, NG, ns, w["dpred"].data_ptr(),
+                  ns, w["part"].data_ptr(), s)
+        _lib.call("nlbac_sum_partials", w["part"].data_ptr(), nblk, 1, 1.0 / (NG * ns),
                   self.sc.data_ptr() + 4 * SC.SC_NODE_LOSS, s)
-        self.fit_solver.backward(w["dpred"], need_du=False, need_params=True)
-        used = self.fit_solver.accumulate_param_grads(self.ar_n, self.n_fit_slabs)
+        self.task.fit_solver.backward(w["dpred"], need_du=False, need_params=True)
+        used = self.task.fit_solver.accumulate_param_grads(self.ar_n, self.n_fit_slabs)
         self._adam(self.ar_n, 1e-3, used, extra=self.sc[SC.SC_NODE_LOSS:SC.SC_NODE_LOSS + 1])
-        pack([self.h_f, self.h_g])
+        pack(self.h_node)
 
     def _capture(self, fn):
         """Record the launches of ``fn`` into a hipGraph (all kernel arguments are static device pointers /
@@ -400,35 +424,35 @@ class SAC_CBF_CLF(object):
         so they are built once; an update is then a plain sequence of C calls."""
         if ws.plan is not None:
             return ws.plan
-        B = ws.B
+        B, lay = ws.B, self.lay
         mb = ws.mb.data_ptr()
-        LD = 24
+        LD, Do, Da, Dl = lay.LD, lay.obs_dim, lay.act_dim, lay.lya_dim
         col = lambda c: mb + 4 * c
-        p_obs, p_act, p_cen, p_ncen, p_nobs = col(0), col(7), col(11), col(13), col(15)
+        p_obs, p_act, p_cen, p_ncen, p_nobs = col(lay.obs), col(lay.act), col(lay.lya), col(lay.nlya), col(lay.nobs)
 
         def x(io, i, p0, d0, ld0, p1=None, d1=0, ld1=0):
             io[i].x0, io[i].x0_dim, io[i].x0_ld = p0, d0, ld0
             if p1 is not None:
                 io[i].x1, io[i].x1_dim, io[i].x1_ld = p1, d1, ld1
         P = types.SimpleNamespace()
-        P.p_obs, P.p_rew, P.p_con, P.p_mask, P.LD = p_obs, col(9), col(10), col(22), LD
+        P.p_obs, P.p_rew, P.p_con, P.p_mask, P.LD = p_obs, col(lay.rew), col(lay.con), col(lay.mask), LD
         q1, q2, l, pi, pb = self.h_q1, self.h_q2, self.h_l, self.h_p, self.h_b
         # A: pi(s')
         P.n_pol, P.io_pol_next = mlp_array([pi.desc]), io_array(1)
-        x(P.io_pol_next, 0, p_nobs, 7, LD)
-        P.io_pol_next[0].y, P.io_pol_next[0].y_ld = ws.heads_n.data_ptr(), 4
+        x(P.io_pol_next, 0, p_nobs, Do, LD)
+        P.io_pol_next[0].y, P.io_pol_next[0].y_ld = ws.heads_n.data_ptr(), 2 * Da
         # A: targets + critic / Lyapunov forward (6 nets)
         P.n_six = mlp_array([q1.desc_target, q2.desc_target, l.desc_target, q1.desc, q2.desc, l.desc])
         io = P.io_six = io_array(6)
         for i in range(6):
             io[i].y, io[i].y_ld = ws.q6[i].data_ptr(), 1
         for i in (0, 1):
-            x(io, i, p_nobs, 7, LD, ws.na.data_ptr(), 2, 2)
-        x(io, 2, p_ncen, 2, LD)
+            x(io, i, p_nobs, Do, LD, ws.na.data_ptr(), Da, Da)
+        x(io, 2, p_ncen, Dl, LD)
         for i in (3, 4):
-            x(io, i, p_obs, 7, LD, p_act, 2, LD)
+            x(io, i, p_obs, Do, LD, p_act, Da, LD)
             io[i].acts = ws.acts_c[i - 3].data_ptr()
-        x(io, 5, p_cen, 2, LD)
+        x(io, 5, p_cen, Dl, LD)
         io[5].acts = ws.acts_c[2].data_ptr()
         # B: critic / Lyapunov backward
         P.n_crit = mlp_array([q1.desc, q2.desc, l.desc])
@@ -438,55 +462,65 @@ class SAC_CBF_CLF(object):
             io[i].acts, io[i].dz = ws.acts_c[i].data_ptr(), ws.dz_c[i].data_ptr()
             io[i].grad = self.ar_c.grad.data_ptr()
         for i in (0, 1):
-            x(io, i, p_obs, 7, LD, p_act, 2, LD)
-        x(io, 2, p_cen, 2, LD)
+            x(io, i, p_obs, Do, LD, p_act, Da, LD)
+        x(io, 2, p_cen, Dl, LD)
         # C: both actors (forward and backward share one descriptor)
         P.n_act = mlp_array([pi.desc, pb.desc])
         io = P.io_act = io_array(2)
         for i in range(2):
-            x(io, i, p_obs, 7, LD)
-            io[i].y, io[i].y_ld = ws.heads2[i * B:].data_ptr(), 4
+            x(io, i, p_obs, Do, LD)
+            io[i].y, io[i].y_ld = ws.heads2[i * B:].data_ptr(), 2 * Da
             io[i].acts, io[i].dz = ws.acts_p[i].data_ptr(), ws.dz_p[i].data_ptr()
-            io[i].dy, io[i].dy_ld = ws.dheads2[i * B:].data_ptr(), 4
+            io[i].dy, io[i].dy_ld = ws.dheads2[i * B:].data_ptr(), 2 * Da
             io[i].grad = self.ar_a.grad.data_ptr()
-        # C: Q(s, pi) for primary / backup + V(centre)
+        # C: Q(s, pi) for primary / backup + V(current Lyapunov input)
         P.n_q5 = mlp_array([q1.desc, q2.desc, q1.desc, q2.desc, l.desc])
         io = P.io_q5 = io_array(5)
         for i in range(4):
             half = i // 2                                      # 0 primary, 1 backup
-            x(io, i, p_obs, 7, LD, ws.pi2[half * B:].data_ptr(), 2, 2)
+            x(io, i, p_obs, Do, LD, ws.pi2[half * B:].data_ptr(), Da, Da)
             io[i].y, io[i].y_ld = ws.qpi[i % 2, half * B:].data_ptr(), 1
             io[i].acts = ws.acts_q[i].data_ptr()
             io[i].dy, io[i].dy_ld = ws.dq_pi[i % 2, half * B:].data_ptr(), 1
-            io[i].dx, io[i].dx_ld = ws.dxq[i % 2, half * B:].data_ptr(), 9
-        x(io, 4, p_cen, 2, LD)
-        io[4].y, io[4].y_ld = ws.V.data_ptr(), 1
-        # C: V(p(x')) forward + data backward
-        P.n_l = mlp_array([l.desc])
-        io = P.io_vn = io_array(1)
-        x(io, 0, ws.ps_next2.data_ptr(), 2, 2)
-        io[0].y, io[0].y_ld = ws.Vn.data_ptr(), 1
-        io[0].acts = ws.acts_vn.data_ptr()
-        io[0].dy, io[0].dy_ld = ws.dVn.data_ptr(), 1
-        io[0].dx, io[0].dx_ld = ws.dps_v2.data_ptr(), 2
+            io[i].dx, io[i].dx_ld = ws.dxq[i % 2, half * B:].data_ptr(), Do + Da
+        self.task.value_now_io(ws, io, 4)
+        self.task.plan(ws, P)
         ws.plan = P
         return P
+
+    def auglag(self, ws, n_cbf, lam_upd):
+        """required_matrix, ratio, lambda / rho updates and loss coefficients from the constraint partial sums
+        (all-reduced first under data parallelism: they enter the loss nonlinearly)."""
+        s, call = stream_ptr(), _lib.call
+        ncol = 2 * n_cbf + 1
+        p_part_c, n_part = ws.part_c.data_ptr(), ws.nblk
+        ws.p_part_q, ws.n_part_q = ws.part_q.data_ptr(), ws.nblk
+        if self.world > 1:
+            xs = self._exchange_buf("sums", 64)
+            call("nlbac_sum_partials", ws.part_c.data_ptr(), ws.nblk, ncol, 1.0, xs.data_ptr(), s)
+            for pp in range(2):
+                call("nlbac_sum_partials", ws.part_q[pp].data_ptr(), ws.nblk, 2, 1.0, xs.data_ptr() + 4 * (32 + 2 * pp), s)
+            self.dp.all_reduce_(xs)
+            p_part_c, n_part = xs.data_ptr(), 1
+            ws.p_part_q, ws.n_part_q = xs.data_ptr() + 4 * 32, 1
+        call("nlbac_auglag", p_part_c, n_part, n_cbf, 1, float(self.batch_size), lam_upd, self.task.ratio_mode, 1,
+             0.01, self.task.lam_hi, self.sc.data_ptr(), s)
 
     def update_on_device(self, ws, updates, sync=True):
         """Minibatch already in ``ws.mb``; returns the reference's 6 floats."""
         if self._noise is not None:
-            for i in range(3):
-                ws.eps[i].copy_(self._noise[i].to(self.device))
+            assert len(self._noise) == self.task.n_eps, "set_noise needs %d draws" % self.task.n_eps
+            for i in range(self.task.n_eps):
+                ws.eps[i].copy_(self._noise[i].to(self.device).reshape(ws.eps[i].shape))
             self._noise = None
         else:
             ws.eps.normal_()
         soft = (updates % self.target_update_interval == 0)
         lam_upd = 1 if updates % self.Lagrangian_multiplier_update_interval == 0 else 0
-        solver = self.node_solver
-        if not (self.use_graphs and self.world == 1) or ws.warm < 1:
+        if not (self.use_graphs and self.world == 1 and self.task.graph_ok) or ws.warm < 1:
             ws.warm += 1
             self._upd_part1(ws, soft)
-            self._upd_part2(ws, lam_upd, solver.forward_finish())
+            self._upd_part2(ws, lam_upd, False)
         else:
             # hipGraph replay: part 1 up to the dopri5 accept decision, one 256-byte read, part 2
             g = ws.graphs
@@ -494,12 +528,11 @@ class SAC_CBF_CLF(object):
             if k1 not in g:
                 g[k1] = self._capture(lambda: self._upd_part1(ws, soft))
             g[k1].replay()
-            if self.solver == "dopri5" and not solver.first_step_done():
-                self._upd_part2(ws, lam_upd, solver.forward_finish())          # rare: finish eagerly
+            if self.solver == "dopri5" and not self.task.first_step_done():
+                self._upd_part2(ws, lam_upd, False)          # rare: finish eagerly
             else:
                 if k2 not in g:
-                    g[k2] = self._capture(
-                        lambda: self._upd_part2(ws, lam_upd, solver.forward_finish(assume_single_step=True)))
+                    g[k2] = self._capture(lambda: self._upd_part2(ws, lam_upd, True))
                 g[k2].replay()
         return self._returns(sync)
 
@@ -513,21 +546,20 @@ class SAC_CBF_CLF(object):
 
     def _upd_part1(self, ws, soft):
         """Phases A, B and the forward half of C up to the rollout's first host decision point."""
-        B = ws.B
+        B, A = ws.B, self.lay.act_dim
         G = B * self.world                      # rows the batch means run over
         s = stream_ptr()
         P = self._plan(ws)
         LD = P.LD
         sc = self.sc.data_ptr()
         call = _lib.call
-        dt = float(self.env.dt)
         pol = self.policy
         p_scale, p_bias = pol.action_scale.data_ptr(), pol.action_bias.data_ptr()
 
         # ---- A. targets (no grad): pi(s'), Q_target(s', a'), L_target(c') ; critic / Lyapunov forward
         call("nlbac_mlp_fwd", P.n_pol, P.io_pol_next, 1, B, s)
-        call("nlbac_gauss_sample_fwd", ws.heads_n.data_ptr(), 4, ws.eps[0].data_ptr(), p_scale, p_bias, 2, B,
-             ws.na.data_ptr(), 2, ws.nlogp.data_ptr(), s)
+        call("nlbac_gauss_sample_fwd", ws.heads_n.data_ptr(), 2 * A, ws.eps[0].data_ptr(), p_scale, p_bias, A, B,
+             ws.na.data_ptr(), A, ws.nlogp.data_ptr(), s)
         call("nlbac_mlp_fwd", P.n_six, P.io_six, 6, B, s)
         q = ws.q6
         call("nlbac_td_targets", q[0].data_ptr(), q[1].data_ptr(), q[2].data_ptr(), ws.nlogp.data_ptr(),
@@ -546,66 +578,39 @@ class SAC_CBF_CLF(object):
         if soft:
             pack([self.h_q1, self.h_q2, self.h_l], target=True)
 
-        # ---- C. actors: sample, Q(s, pi), constraints through the NODE rollout -----
+        # ---- C. actors: sample, Q(s, pi), then the rollout of the learned dynamics -----
         call("nlbac_mlp_fwd", P.n_act, P.io_act, 2, B, s)
-        eps2 = ws.eps[1:3]                                     # (2,B,2) == (2B,2)
-        call("nlbac_gauss_sample_fwd", ws.heads2.data_ptr(), 4, eps2.data_ptr(), p_scale, p_bias, 2, 2 * B,
-             ws.pi2.data_ptr(), 2, ws.logp2.data_ptr(), s)
-        # state (twice: primary and backup rows of the rollout) and look-ahead point
-        call("nlbac_unicycle_state", P.p_obs, LD, B, self.l_p, ws.y0_2.data_ptr(), ws.ps.data_ptr(), s)
-        call("nlbac_unicycle_state", P.p_obs, LD, B, self.l_p, ws.y0_2[B:].data_ptr(), None, s)
+        eps2 = ws.eps[1:3]                                     # (2,B,A) == (2B,A)
+        call("nlbac_gauss_sample_fwd", ws.heads2.data_ptr(), 2 * A, eps2.data_ptr(), p_scale, p_bias, A, 2 * B,
+             ws.pi2.data_ptr(), A, ws.logp2.data_ptr(), s)
         call("nlbac_mlp_fwd", P.n_q5, P.io_q5, 5, B, s)
         call("nlbac_actor_q_terms", ws.qpi[0].data_ptr(), ws.qpi[1].data_ptr(), ws.logp2.data_ptr(),
              sc + 4 * SC.SC_ALPHA, B, G, 2, ws.dq_pi[0].data_ptr(), ws.dq_pi[1].data_ptr(), ws.part_q.data_ptr(), s)
+        self.task.rollout_begin(ws, P)
 
-        self.node_solver.forward_begin(ws.y0_2, ws.pi2, 2, B, self.solver, dt, self.atol, self.rtol)
-
-    def _upd_part2(self, ws, lam_upd, x_next2):
+    def _upd_part2(self, ws, lam_upd, assume_single):
         """Constraints, augmented-Lagrangian scalars, the whole actor backward and the actor Adam step."""
-        B = ws.B
+        B, A, Do = ws.B, self.lay.act_dim, self.lay.obs_dim
         G = B * self.world
         s = stream_ptr()
         P = self._plan(ws)
         sc = self.sc.data_ptr()
         call = _lib.call
-        dt = float(self.env.dt)
-        pol = self.policy
-        p_scale = pol.action_scale.data_ptr()
+        p_scale = self.policy.action_scale.data_ptr()
         eps2 = ws.eps[1:3]
-        call("nlbac_unicycle_lookahead", x_next2.data_ptr(), 2 * B, self.l_p, ws.ps_next2.data_ptr(), s)
-        call("nlbac_mlp_fwd", P.n_l, P.io_vn, 1, B, s)
-        r_coll = 1.05 * float(self.env.hazards_radius)
-        call("nlbac_unicycle_constraints_fwd", ws.ps.data_ptr(), ws.ps_next2.data_ptr(), ws.V.data_ptr(),
-             ws.Vn.data_ptr(), self.hazards.data_ptr(), self.num_cbfs, r_coll, dt, float(self.gamma_b), 1.0, B,
-             ws.matr.data_ptr(), ws.bmatr.data_ptr(), ws.part_c.data_ptr(), s)
-        ncol = 2 * self.num_cbfs + 1
-        p_part_c, p_part_q, n_part = ws.part_c.data_ptr(), ws.part_q.data_ptr(), ws.nblk
-        if self.world > 1:      # global constraint / actor sums before anything nonlinear in them
-            xs = self._exchange_buf("sums", 64)
-            call("nlbac_sum_partials", ws.part_c.data_ptr(), ws.nblk, ncol, 1.0, xs.data_ptr(), s)
-            for pp in range(2):
-                call("nlbac_sum_partials", ws.part_q[pp].data_ptr(), ws.nblk, 2, 1.0, xs.data_ptr() + 4 * (32 + 2 * pp), s)
-            self.dp.all_reduce_(xs)
-            p_part_c, p_part_q, n_part = xs.data_ptr(), xs.data_ptr() + 4 * 32, 1
-        call("nlbac_auglag", p_part_c, n_part, self.num_cbfs, 1, float(self.batch_size), lam_upd, 1, 1,
-             0.01, 400.0, sc, s)
-        call("nlbac_unicycle_constraints_bwd", ws.ps_next2.data_ptr(), ws.matr.data_ptr(), ws.bmatr.data_ptr(),
-             self.hazards.data_ptr(), self.num_cbfs, dt, float(self.batch_size), B, sc, ws.dps_next2.data_ptr(),
-             ws.dVn.data_ptr(), s)
-        call("nlbac_mlp_bwd_data", P.n_l, P.io_vn, 1, B, s)    # dV_next -> d ps_next (rows [0,B))
-        call("nlbac_unicycle_lookahead_bwd", x_next2.data_ptr(), ws.dps_next2.data_ptr(), ws.dps_v2.data_ptr(), 2 * B,
-             self.l_p, ws.dx_next2.data_ptr(), s)
-        du2, _ = self.node_solver.backward(ws.dx_next2, need_du=True)
+        du2, du_ld = self.task.loss_and_backward(ws, P, lam_upd, assume_single)
 
         call("nlbac_mlp_bwd_data", P.n_q5, P.io_q5, 4, B, s)   # the four Q(s, pi) nets: dx only
-        call("nlbac_gauss_sample_bwd", ws.heads2.data_ptr(), 4, eps2.data_ptr(), p_scale, 2,
-             2 * B, B, ws.dxq[0].data_ptr() + 4 * 7, 9, ws.dxq[1].data_ptr() + 4 * 7, 9, du2.data_ptr(), 2,
-             sc + 4 * SC.SC_ALPHA, 1.0 / G, ws.dheads2.data_ptr(), 4, s)
+        D = Do + A
+        call("nlbac_gauss_sample_bwd", ws.heads2.data_ptr(), 2 * A, eps2.data_ptr(), p_scale, A,
+             2 * B, B, ws.dxq[0].data_ptr() + 4 * Do, D, ws.dxq[1].data_ptr() + 4 * Do, D, du2.data_ptr(), du_ld,
+             sc + 4 * SC.SC_ALPHA, 1.0 / G, ws.dheads2.data_ptr(), 2 * A, s)
         a = self.ar_a
         call("nlbac_mlp_bwd_data", P.n_act, P.io_act, 2, B, s)
         bwd_weights(P.n_act, P.io_act, 2, B, a.n_slabs, a.n, self.device)
         la = a.theta.data_ptr() + 4 * self.la_off
         tune = self.automatic_entropy_tuning
+        p_part_q, n_part = ws.p_part_q, ws.n_part_q
 
         def alpha_grads(p_grad):
             # policy_loss_1 / alpha losses from the (global) partial sums; d log_alpha goes straight into

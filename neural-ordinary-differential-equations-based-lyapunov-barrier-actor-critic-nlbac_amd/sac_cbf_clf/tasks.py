@@ -1,0 +1,265 @@
+"""Environment-specific halves of the update (the reference keeps one copy of
+``sac_cbf_clf.py`` per environment; here the shared SAC / Lyapunov machinery
+lives in ``sac_cbf_clf.SAC_CBF_CLF`` and each environment contributes a task):
+
+  * minibatch row layout dims, NODE model shape, number of policy-noise draws;
+  * the NODE fit (``train_step``);
+  * the rollout of the learned dynamics under both controllers, the CBF / CLF
+    terms, and the gradient of the augmented-Lagrangian loss w.r.t. the actions.
+
+``UnicycleTask``   U/sac_cbf_clf/sac_cbf_clf.py:364-640, U/sac_cbf_clf/model.py:177-260
+``CarsTask``       C/sac_cbf_clf/sac_cbf_clf.py:364-681, C/sac_cbf_clf/model.py:179-252
+"""
+import numpy as np
+import torch
+
+from .. import _lib
+from ..arena import io_array, mlp_array, stream_ptr
+from ..odeint import AffineNodeSolver, ConcatNodeSolver
+from . import _layout as SC
+from .model import NeuralODEModel
+
+
+class _Task:
+    name = None
+    obs_dim = act_dim = lya_dim = n_s = 0
+    n_eps = 3                 # N(0,1) draws per update: next-obs sample, obs sample, backup sample [, ...]
+    lam_hi = 400.0
+    ratio_mode = 1            # 1 plain ratio (U), 2 clamped at 0.002 (C)
+    graph_ok = False          # whole update replayable as hipGraphs
+
+    def __init__(self, agent, env, args):
+        self.agent, self.env = agent, env
+
+    def z(self, *shape):
+        return torch.zeros(*shape, dtype=torch.float32, device=self.agent.device)
+
+
+# =====================================================================================
+class UnicycleTask(_Task):
+    name = "Unicycle"
+    obs_dim, act_dim, lya_dim, n_s = 7, 2, 2, 3
+    graph_ok = True
+    l_p = 0.03
+
+    def __init__(self, agent, env, args):
+        super().__init__(agent, env, args)
+        self.num_cbfs = len(env.hazards_locations)
+        self.gamma_l = 1.0
+
+    def build_node(self):
+        return NeuralODEModel(3, 3, 6)
+
+    def setup(self):
+        a = self.agent
+        self.hazards = torch.tensor(np.asarray(self.env.hazards_locations), dtype=torch.float32,
+                                    device=a.device).contiguous()
+        self.solver = AffineNodeSolver(a.neural_ode_model, a.device)      # policy-loss rollouts (2B rows)
+        self.fit_solver = AffineNodeSolver(a.neural_ode_model, a.device)  # NODE fit rollouts
+        self.solvers = [self.solver, self.fit_solver]
+
+    def alloc(self, ws):
+        B, z, H = ws.B, self.z, self.agent.hidden
+        ws.ps = z(B, 2)
+        ws.y0_2 = z(2 * B, 3)
+        ws.V, ws.Vn, ws.dVn = z(B), z(B), z(B)
+        ws.acts_vn = z(2, B, H)
+        ws.ps_next2, ws.dps_next2, ws.dps_v2 = z(2 * B, 2), z(2 * B, 2), z(2 * B, 2)
+        ws.matr, ws.bmatr = z(B, self.num_cbfs + 1), z(B, self.num_cbfs)
+        ws.part_c = z(ws.nblk, 2 * self.num_cbfs + 1)
+        ws.dx_next2 = z(2 * B, 3)
+
+    def plan(self, ws, P):
+        a, lay = self.agent, self.agent.lay
+        P.n_l = mlp_array([a.h_l.desc])
+        io = P.io_vn = io_array(1)                 # V(p(x')) forward + data backward
+        io[0].x0, io[0].x0_dim, io[0].x0_ld = ws.ps_next2.data_ptr(), 2, 2
+        io[0].y, io[0].y_ld = ws.Vn.data_ptr(), 1
+        io[0].acts = ws.acts_vn.data_ptr()
+        io[0].dy, io[0].dy_ld = ws.dVn.data_ptr(), 1
+        io[0].dx, io[0].dx_ld = ws.dps_v2.data_ptr(), 2
+        P.io_vc = io_array(1)                      # V(centre), value only
+        P.io_vc[0].x0, P.io_vc[0].x0_dim, P.io_vc[0].x0_ld = ws.mb.data_ptr() + 4 * lay.lya, 2, lay.LD
+        P.io_vc[0].y, P.io_vc[0].y_ld = ws.V.data_ptr(), 1
+
+    # V(centre) rides in the 5-net launch of the shared part: tell it where to write
+    def value_now_io(self, ws, io, i):
+        lay = self.agent.lay
+        io[i].x0, io[i].x0_dim, io[i].x0_ld = ws.mb.data_ptr() + 4 * lay.lya, self.lya_dim, lay.LD
+        io[i].y, io[i].y_ld = ws.V.data_ptr(), 1
+
+    # -- rollout under both controllers ------------------------------------------------------
+    def rollout_begin(self, ws, P):
+        a, s = self.agent, stream_ptr()
+        B, LD = ws.B, a.lay.LD
+        p_obs = ws.mb.data_ptr()
+        # state (twice: primary and backup rows of the rollout) and look-ahead point
+        _lib.call("nlbac_unicycle_state", p_obs, LD, B, self.l_p, ws.y0_2.data_ptr(), ws.ps.data_ptr(), s)
+        _lib.call("nlbac_unicycle_state", p_obs, LD, B, self.l_p, ws.y0_2[B:].data_ptr(), None, s)
+        self.solver.forward_begin(ws.y0_2, ws.pi2, 2, B, a.solver, float(self.env.dt), a.atol, a.rtol)
+
+    def loss_and_backward(self, ws, P, lam_upd, assume_single):
+        """Constraint terms, augmented-Lagrangian scalars and d loss / d actions (2B, act_dim)."""
+        a, s, call = self.agent, stream_ptr(), _lib.call
+        B, sc, dt = ws.B, a.sc.data_ptr(), float(self.env.dt)
+        x_next2 = self.solver.forward_finish(assume_single_step=assume_single)
+        call("nlbac_unicycle_lookahead", x_next2.data_ptr(), 2 * B, self.l_p, ws.ps_next2.data_ptr(), s)
+        call("nlbac_mlp_fwd", P.n_l, P.io_vn, 1, B, s)
+        r_coll = 1.05 * float(self.env.hazards_radius)
+        call("nlbac_unicycle_constraints_fwd", ws.ps.data_ptr(), ws.ps_next2.data_ptr(), ws.V.data_ptr(),
+             ws.Vn.data_ptr(), self.hazards.data_ptr(), self.num_cbfs, r_coll, dt, float(a.gamma_b), self.gamma_l, B,
+             ws.matr.data_ptr(), ws.bmatr.data_ptr(), ws.part_c.data_ptr(), s)
+        a.auglag(ws, self.num_cbfs, lam_upd)
+        call("nlbac_unicycle_constraints_bwd", ws.ps_next2.data_ptr(), ws.matr.data_ptr(), ws.bmatr.data_ptr(),
+             self.hazards.data_ptr(), self.num_cbfs, dt, float(a.batch_size), B, sc, ws.dps_next2.data_ptr(),
+             ws.dVn.data_ptr(), s)
+        call("nlbac_mlp_bwd_data", P.n_l, P.io_vn, 1, B, s)    # dV_next -> d ps_next (rows [0,B))
+        call("nlbac_unicycle_lookahead_bwd", x_next2.data_ptr(), ws.dps_next2.data_ptr(), ws.dps_v2.data_ptr(), 2 * B,
+             self.l_p, ws.dx_next2.data_ptr(), s)
+        du2, _ = self.solver.backward(ws.dx_next2, need_du=True)
+        return du2, self.act_dim
+
+    def first_step_done(self):
+        return self.solver.first_step_done()
+
+    # -- NODE fit (U/model.py:221-260 via U/sac_cbf_clf.py:205-219) -------------------------------
+    def fit_inputs(self, rows):
+        """(obs ptr, ld, action (N,2), next_obs ptr, ld, N) of minibatch-layout rows."""
+        lay = self.agent.lay
+        return (rows.data_ptr(), rows.shape[1], rows[:, lay.act:lay.act + 2], rows.data_ptr() + 4 * lay.nobs,
+                rows.shape[1], rows.shape[0])
+
+    def fit_ws(self, N):
+        z = self.z
+        return dict(st=z(N, 3), nst=z(N, 3), dpred=z(N, 3), part=z((N + 255) // 256), u=z(N, 2))
+
+    def fit_part1(self, w, p_obs, obs_ld, p_nobs, nobs_ld, N):
+        a, s = self.agent, stream_ptr()
+        _lib.call("nlbac_unicycle_state", p_obs, obs_ld, N, self.l_p, w["st"].data_ptr(), None, s)
+        _lib.call("nlbac_unicycle_state", p_nobs, nobs_ld, N, self.l_p, w["nst"].data_ptr(), None, s)
+        self.fit_solver.forward_begin(w["st"], w["u"], 1, N, a.solver, self.env.dt, a.atol, a.rtol)
+
+
+# =====================================================================================
+class CarsTask(_Task):
+    """SimulatedCars: two-step rollout of a non-affine NODE on [x, u, t]; the second action is re-sampled from
+    the (detached) predicted observation and carries no gradient; relative-degree-2 CBFs between cars 3-4 and
+    4-5, CLF on (x3, v3, x4, v4)."""
+    name = "SimulatedCars"
+    obs_dim, act_dim, lya_dim, n_s = 10, 1, 4, 10
+    n_eps = 5
+    lam_hi = 300.0
+    ratio_mode = 2
+    collision_radius = 4.5
+
+    def __init__(self, agent, env, args):
+        super().__init__(agent, env, args)
+        self.num_cbfs = 2
+        self.gamma_l = 0.15
+
+    def build_node(self):
+        return NeuralODEModel(12, 10)
+
+    def setup(self):
+        a = self.agent
+        self.solver1 = ConcatNodeSolver(a.neural_ode_model, a.device)     # x_t   -> x_t+1 (2B rows)
+        self.solver2 = ConcatNodeSolver(a.neural_ode_model, a.device)     # x_t+1 -> x_t+2
+        self.fit_solver = ConcatNodeSolver(a.neural_ode_model, a.device)
+        self.solvers = [self.solver1, self.solver2, self.fit_solver]
+
+    def alloc(self, ws):
+        B, z, H = ws.B, self.z, self.agent.hidden
+        ws.state = z(B, 10)
+        ws.y0_2 = z(2 * B, 10)
+        ws.c1, ws.c2 = z(2 * B, 2), z(2 * B, 2)        # carried [action, time] of the two steps
+        ws.x1_2, ws.obs1_2 = z(2 * B, 10), z(2 * B, 10)
+        ws.heads_nx, ws.logp_nx = z(2 * B, 2), z(2 * B)
+        ws.V, ws.V1, ws.dV1 = z(B), z(B), z(B)
+        ws.acts_v1 = z(2, B, H)
+        ws.dlya = z(B, 4)
+        ws.matr, ws.bmatr = z(B, 3), z(B, 2)
+        ws.part_c = z(ws.nblk, 5)
+        ws.dx1, ws.dx2 = z(2 * B, 10), z(2 * B, 10)
+        ws.du2 = z(2 * B, 1)
+
+    def plan(self, ws, P):
+        a, B = self.agent, ws.B
+        P.n_l = mlp_array([a.h_l.desc])
+        io = P.io_v1 = io_array(1)                 # V(x_t+1[4:8]) forward + data backward
+        io[0].x0, io[0].x0_dim, io[0].x0_ld = ws.x1_2.data_ptr() + 4 * 4, 4, 10
+        io[0].y, io[0].y_ld = ws.V1.data_ptr(), 1
+        io[0].acts = ws.acts_v1.data_ptr()
+        io[0].dy, io[0].dy_ld = ws.dV1.data_ptr(), 1
+        io[0].dx, io[0].dx_ld = ws.dlya.data_ptr(), 4
+        io = P.io_nx = io_array(2)                 # both policies on the predicted next observation
+        for i in range(2):
+            io[i].x0, io[i].x0_dim, io[i].x0_ld = ws.obs1_2[i * B:].data_ptr(), 10, 10
+            io[i].y, io[i].y_ld = ws.heads_nx[i * B:].data_ptr(), 2
+
+    def value_now_io(self, ws, io, i):
+        lay = self.agent.lay
+        io[i].x0, io[i].x0_dim, io[i].x0_ld = ws.mb.data_ptr() + 4 * lay.lya, self.lya_dim, lay.LD
+        io[i].y, io[i].y_ld = ws.V.data_ptr(), 1
+
+    def rollout_begin(self, ws, P):
+        a, s = self.agent, stream_ptr()
+        B, lay = ws.B, a.lay
+        _lib.call("nlbac_cars_state", ws.mb.data_ptr(), lay.LD, B, ws.state.data_ptr(), s)
+        ws.y0_2[:B].copy_(ws.state)
+        ws.y0_2[B:].copy_(ws.state)
+        t, nt = ws.mb[:, lay.t], ws.mb[:, lay.nt]
+        ws.c1[:, 0].copy_(ws.pi2[:, 0])
+        ws.c1[:B, 1].copy_(t)
+        ws.c1[B:, 1].copy_(t)
+        ws.c2[:B, 1].copy_(nt)
+        ws.c2[B:, 1].copy_(nt)
+        self.solver1.forward_begin(ws.y0_2, ws.c1, 2, B, a.solver, float(self.env.dt), a.atol, a.rtol)
+
+    def loss_and_backward(self, ws, P, lam_upd, assume_single):
+        a, s, call = self.agent, stream_ptr(), _lib.call
+        B, sc, dt = ws.B, a.sc.data_ptr(), float(self.env.dt)
+        pol = a.policy
+        x1 = self.solver1.forward_finish()
+        ws.x1_2.copy_(x1)
+        # u_(t+1) ~ pi(. | get_obs(x_t+1)), detached (C/sac_cbf_clf.py:441-451, 585-595)
+        call("nlbac_cars_obs", ws.x1_2.data_ptr(), 2 * B, ws.obs1_2.data_ptr(), s)
+        call("nlbac_mlp_fwd", P.n_act, P.io_nx, 2, B, s)
+        call("nlbac_gauss_sample_fwd", ws.heads_nx.data_ptr(), 2, ws.eps[3:5].data_ptr(), pol.action_scale.data_ptr(),
+             pol.action_bias.data_ptr(), 1, 2 * B, ws.c2.data_ptr(), 2, ws.logp_nx.data_ptr(), s)
+        x2 = self.solver2.forward(ws.x1_2, ws.c2, 2, B, a.solver, dt, a.atol, a.rtol)
+        call("nlbac_mlp_fwd", P.n_l, P.io_v1, 1, B, s)
+        call("nlbac_cars_constraints_fwd", ws.state.data_ptr(), ws.x1_2.data_ptr(), x2.data_ptr(), ws.V.data_ptr(),
+             ws.V1.data_ptr(), float(a.gamma_b), self.gamma_l, self.collision_radius, B, ws.matr.data_ptr(),
+             ws.bmatr.data_ptr(), ws.part_c.data_ptr(), s)
+        a.auglag(ws, self.num_cbfs, lam_upd)
+        call("nlbac_cars_constraints_bwd", ws.matr.data_ptr(), ws.bmatr.data_ptr(), float(a.gamma_b),
+             float(a.batch_size), B, sc, ws.dx1.data_ptr(), ws.dx2.data_ptr(), ws.dV1.data_ptr(), s)
+        call("nlbac_mlp_bwd_data", P.n_l, P.io_v1, 1, B, s)               # dV1 -> d x1[0:B, 4:8]
+        call("nlbac_add_cols", ws.dx1.data_ptr(), 10, 4, ws.dlya.data_ptr(), 4, 4, B, s)
+        # x_t+2 depends on the first action only through x_t+1
+        _, dy0 = self.solver2.backward(ws.dx2, need_du=False, need_dy0=True)
+        call("nlbac_axpby", 1.0, ws.dx1.data_ptr(), 1.0, dy0.data_ptr(), 2 * B * 10, ws.dx1.data_ptr(), s)
+        dc, _ = self.solver1.backward(ws.dx1, need_du=True)               # (2B, 2): d/d[action, time]
+        return dc, 2
+
+    def first_step_done(self):
+        return self.solver1.first_step_done()
+
+    # -- NODE fit (C/model.py:208-252 via C/sac_cbf_clf.py:201-217) --------------------------------
+    def fit_inputs(self, rows):
+        lay = self.agent.lay
+        c = torch.stack((rows[:, lay.act], rows[:, lay.t]), 1)
+        return (rows.data_ptr(), rows.shape[1], c, rows.data_ptr() + 4 * lay.nobs, rows.shape[1], rows.shape[0])
+
+    def fit_ws(self, N):
+        z = self.z
+        return dict(st=z(N, 10), nst=z(N, 10), dpred=z(N, 10), part=z((N + 255) // 256), u=z(N, 2))
+
+    def fit_part1(self, w, p_obs, obs_ld, p_nobs, nobs_ld, N):
+        a, s = self.agent, stream_ptr()
+        _lib.call("nlbac_cars_state", p_obs, obs_ld, N, w["st"].data_ptr(), s)
+        _lib.call("nlbac_cars_state", p_nobs, nobs_ld, N, w["nst"].data_ptr(), s)
+        self.fit_solver.forward_begin(w["st"], w["u"], 1, N, a.solver, self.env.dt, a.atol, a.rtol)
+
+
+TASKS = {"Unicycle": UnicycleTask, "SimulatedCars": CarsTask}
