@@ -48,32 +48,32 @@ def run_cpu(dp, out):
     np.savez(out, flat=flat.numpy(), theta=theta.numpy(), lo=lo, hi=hi)
 
 
-def run_cuda(dp, out, solver):
+def run_cuda(dp, out, solver, env_name="Unicycle"):
     from common import case_inputs, load_golden
     from test_agent_parity_gpu import make_agent
     from nlbac_amd.sac_cbf_clf import _layout as SC
     B = 128
-    g = load_golden(solver, B)
+    g = load_golden(solver, B, env_name)
     seed, hidden = int(g["meta_seed"]), int(g["meta_hidden"])
+    gamma_b = float(g["meta_gamma_b"]) if "meta_gamma_b" in g.files else 50.0
     torch.cuda.set_device(0)
-    agent, env = make_agent(B, hidden, seed, solver)          # batch_size = global batch
+    agent, env = make_agent(B, hidden, seed, solver, env_name, gamma_b)          # batch_size = global batch
     agent.enable_data_parallel(dist)
-    tr = synth.unicycle_transitions(4096, seed=seed + 1, env=env)
+    tr = synth.transitions(env_name, 4096, seed=seed + 1, env=env)
     res = {}
     for ci in range(len(g["meta_calls"])):
         batch, eps, node, updates = case_inputs(g, ci, tr)
         lo, hi = dp.shard(B)
         nlo, nhi = dp.shard(node[0].shape[0])
         agent.set_noise([e[lo:hi] for e in eps])
-        host = tuple(batch[f][lo:hi].numpy() for f in
-                     ("obs", "action", "reward", "constraint", "center", "next_center", "next_obs", "mask"))
+        host = tuple(batch[f][lo:hi].numpy() for f in synth.FIELDS)
         node_np = tuple(t[nlo:nhi].numpy() for t in node) if updates % 10 == 0 else None
         ret = agent.update_from_host(host, updates, node_np)
         torch.cuda.synchronize()
         sc = agent.sc.cpu().numpy()
         p = "c%d_" % ci
         res[p + "ret"] = np.array(ret)
-        res[p + "required"] = sc[SC.SC_REQ:SC.SC_REQ + 8]
+        res[p + "required"] = sc[SC.SC_REQ:SC.SC_REQ + agent.num_constraints]
         res[p + "lambdas"] = np.array(agent.lambda_values)
         for name, mod in (("critic", agent.critic), ("policy", agent.policy), ("node", agent.neural_ode_model)):
             res[p + "p_" + name] = torch.cat([q.detach().reshape(-1) for q in mod.parameters()]).cpu().numpy()
@@ -85,6 +85,7 @@ if __name__ == "__main__":
     ap.add_argument("--device", default="cpu")
     ap.add_argument("--out", required=True)
     ap.add_argument("--solver", default="euler")
+    ap.add_argument("--env", default="Unicycle")
     a = ap.parse_args()
     dist.init_process_group("gloo")
     dp = DataParallel(dist)
@@ -92,6 +93,6 @@ if __name__ == "__main__":
     if a.device == "cpu":
         run_cpu(dp, out)
     else:
-        run_cuda(dp, out, a.solver)
+        run_cuda(dp, out, a.solver, a.env)
     dist.barrier()
     dist.destroy_process_group()

@@ -74,11 +74,12 @@ def test_exchange_layer_world2_cpu(tmp_path):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("solver", ["euler", "dopri5"])
-def test_two_rank_sharded_update_matches_single_device_reference(tmp_path, solver):
+@pytest.mark.parametrize("env_name,solver", [("Unicycle", "euler"), ("Unicycle", "dopri5"), ("SimulatedCars", "rk4"),
+                                             ("SimulatedCars", "dopri5")])
+def test_two_rank_sharded_update_matches_single_device_reference(tmp_path, env_name, solver):
     out = str(tmp_path / "dpgpu")
-    launch(2, ["--device", "cuda", "--out", out, "--solver", solver], timeout=600)
-    g = load_golden(solver, 128)
+    launch(2, ["--device", "cuda", "--out", out, "--solver", solver, "--env", env_name], timeout=600)
+    g = load_golden(solver, 128, env_name)
     for r in range(2):
         res = np.load(out + ".rank%d.npz" % r)
         for ci in range(len(g["meta_calls"])):
