@@ -112,6 +112,19 @@ class KernelTimer:
         return out
 
 
+def pmc_traffic(kernel, env_name, solver, B):
+    """HBM bytes per launch of ``kernel`` from the committed rocprofv3 --pmc passes of this same workload
+    (tools/gpu_pmc.sh: FETCH_SIZE and WRITE_SIZE in separate passes, gfx950 read-side x2 correction applied in
+    tools/pmc_summary.py).  Counters cannot be collected from inside the timed process, so this is read from
+    profiles/; None when no pass exists for the workload."""
+    path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles",
+                        "r01_pmc_hbm_traffic_%s_%s_B%d.json" % (env_name.lower(), solver, B))
+    if not os.path.exists(path):
+        return None
+    k = json.load(open(path))["kernels"].get(kernel.split("+")[0])
+    return None if k is None else k["hbm_bytes_per_launch"]
+
+
 def log(msg):
     print("[bench %.1fs] %s" % (time.perf_counter() - _T0, msg), file=sys.stderr, flush=True)
 
@@ -259,7 +272,8 @@ def main():
                  "nlbac_mlp_bwd_weights": "mlp_bwd_wide_kernel+mlp_bwd_skinny_partial/reduce_kernel",
                  "nlbac_node_rk_fwd": "node_rk_fwd_kernel", "nlbac_node_rk_bwd": "node_rk_bwd_kernel"}[dom]
         roofline = dict(bound="mfma", kernel=kname, achieved=ks[dom]["tflops"], peak=PEAK_F32_MFMA_TFLOPS,
-                        unit="TFLOP/s", frac=ks[dom]["tflops"] / PEAK_F32_MFMA_TFLOPS, traffic=None,
+                        unit="TFLOP/s", frac=ks[dom]["tflops"] / PEAK_F32_MFMA_TFLOPS,
+                        traffic=pmc_traffic(kname, a.env, a.solver, B),
                         avg_launch_us=ks[dom]["avg_us"], launches=ks[dom]["launches"],
                         flops_per_launch=ks[dom]["flops"] / ks[dom]["launches"],
                         all={k: dict(avg_us=round(v["avg_us"], 2), tflops=round(v["tflops"], 2),

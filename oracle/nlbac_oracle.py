@@ -1,11 +1,11 @@
 """ORACLE — test infrastructure, NOT product code.
 
 CPU (PyTorch fp32 + autograd) restatement of the NLBAC hot path for the
-Unicycle agent.  Only ``tests/``, ``__graft_entry__.smoke()`` and the
+Unicycle and SimulatedCars agents.  Only ``tests/``, ``__graft_entry__.smoke()`` and the
 ``cpu_baseline`` leg of ``bench.py`` may import this module; the product
 package never does.
 
-Pinned by ``tests/golden/unicycle_*.npz`` which ``oracle/gen_golden.py``
+Pinned by ``tests/golden/{unicycle,cars}_*.npz`` which ``oracle/gen_golden.py``
 produced by importing the reference's own modules in the build container
 (Euler: the only solver configuration the reference executes, exact).
 rk4 / dopri5 follow torchdiffeq 0.2.3 *from recollection* (the package is
