@@ -83,7 +83,9 @@ class SimulatedCarsSpec:
 
 
 def make_env(name, seed=0):
-    if name == "Unicycle":
+    """``UnicycleBarrier`` is the learned-barrier-certificate copy (``neural_barrier_certificate/``): the same
+    Unicycle constants (its ``dynamics_mode`` is still ``'Unicycle'``); the agent class differs, not the env."""
+    if name in ("Unicycle", "UnicycleBarrier"):
         return UnicycleSpec(seed)
     if name == "SimulatedCars":
         return SimulatedCarsSpec(seed)

@@ -63,6 +63,21 @@ def unicycle_transitions(n, seed=1, env=None):
                 mask=np.ones(n), t=t, next_t=t + dt)
 
 
+FIELDS_BARRIER = ("obs", "action", "reward", "constraint", "barrier_signal", "center", "next_center",
+                  "next_obs", "mask", "t", "next_t")     # NU/sac_cbf_clf/replay_memory.py:24-25
+
+
+def unicycle_barrier_transitions(n, seed=1, env=None):
+    """Unicycle transitions plus the barrier signal of the learned-certificate variant
+    (NU/envs/unicycle_env.py:116-144): 0, and -20 for every hazard whose disc holds the next look-ahead point."""
+    from .envspec import UnicycleSpec
+    env = env or UnicycleSpec()
+    tr = unicycle_transitions(n, seed, env)
+    d2 = ((tr["next_center"][:, None, :] - np.asarray(env.hazards_locations)[None]) ** 2).sum(2)
+    tr["barrier_signal"] = -20.0 * (d2 < env.hazards_radius ** 2).sum(1).astype(np.float64)
+    return tr
+
+
 def cars_transitions(n, seed=1, env=None):
     """Synthetic SimulatedCars transitions: states near the env's reset line-up
     (C/envs/simulated_cars_env.py:158-176) with random spreads, one true env step (``:66-99``),
@@ -179,12 +194,26 @@ def cars_agent_weights(hidden, seed=0):
     return dict(critic=critic, lyapunov=lya, policy=policy, backup_policy=backup, node=node)
 
 
+def unicycle_barrier_agent_weights(hidden, seed=0):
+    """NU: no backup policy; a BarrierNetwork on (obs, action) (NU/sac_cbf_clf/model.py:67-84)."""
+    W = unicycle_agent_weights(hidden, seed)
+    del W["backup_policy"]
+    W["barrier"] = synth_state_dict(lya_shapes(7 + 2, hidden), seed * 10 + 6)
+    return W
+
+
 def agent_weights(env_name, hidden, seed=0):
-    return {"Unicycle": unicycle_agent_weights, "SimulatedCars": cars_agent_weights}[env_name](hidden, seed)
+    return {"Unicycle": unicycle_agent_weights, "SimulatedCars": cars_agent_weights,
+            "UnicycleBarrier": unicycle_barrier_agent_weights}[env_name](hidden, seed)
 
 
 def transitions(env_name, n, seed=1, env=None):
-    return {"Unicycle": unicycle_transitions, "SimulatedCars": cars_transitions}[env_name](n, seed, env)
+    return {"Unicycle": unicycle_transitions, "SimulatedCars": cars_transitions,
+            "UnicycleBarrier": unicycle_barrier_transitions}[env_name](n, seed, env)
+
+
+def fields(env_name):
+    return FIELDS_BARRIER if env_name.endswith("Barrier") else FIELDS
 
 
 def normal_eps(n_draws, batch, n_u, seed):

@@ -19,7 +19,7 @@ What has to be faked to import the reference here:
   * ``sac_cbf_clf.model.device`` is hard-coded ``cuda`` -> rebound to CPU.
   * ``env`` is a plain object (gym is absent): ``nlbac_amd.envspec``.
 
-Usage:  python oracle/gen_golden.py [--env Unicycle|SimulatedCars]   (one env per process: the
+Usage:  python oracle/gen_golden.py [--env Unicycle|SimulatedCars|UnicycleBarrier]   (one env per process: the
 reference's env copies all use the package name ``sac_cbf_clf``)
 """
 import os
@@ -41,12 +41,15 @@ from oracle import nlbac_oracle as O  # noqa: E402
 REFS = {
     "Unicycle": "/root/reference/NLBAC_Unicycle_RL_training/Unicycle_RL_training",
     "SimulatedCars": "/root/reference/NLBAC_SimulatedCarsFollowing_RL_training/Simulated_Car_Following_RL_training",
+    "UnicycleBarrier": "/root/reference/neural_barrier_certificate/neural_barrier_certificate_NLBAC_Unicycle_RL_training/"
+                       "Unicycle_RL_training",
 }
 # per env: fixture prefix, obs dim, action dim, gamma_b (README run commands), eps draws per update,
 # odeint calls per controller inside the loss
 CFG = {
     "Unicycle": dict(prefix="unicycle", obs=7, act=2, gamma_b=50.0, n_eps=3, n_ode=1),
     "SimulatedCars": dict(prefix="cars", obs=10, act=1, gamma_b=0.5, n_eps=5, n_ode=2),
+    "UnicycleBarrier": dict(prefix="nbc_unicycle", obs=7, act=2, gamma_b=5.0, n_eps=3, n_ode=1),
 }
 
 
@@ -67,8 +70,8 @@ class FakeMemory:
     """Duck-typed ``ReplayMemory``: ``sample`` hands back a fixed minibatch in
     the field order of replay_memory.py:24-25."""
 
-    def __init__(self, tr, idx):
-        self.rows = tuple(tr[f][idx] for f in synth.FIELDS)
+    def __init__(self, tr, idx, fields=synth.FIELDS):
+        self.rows = tuple(tr[f][idx] for f in fields)
         self.position = len(idx)
 
     def sample(self, batch_size):
@@ -105,9 +108,15 @@ def run_case(S, env_name, solver, B, hidden=256, seed=0, node_B=512, calls=(0, 1
     agent = S.SAC_CBF_CLF(cfg["obs"], env.action_space, env, args)
     agent.solver = solver
     W = synth.agent_weights(env_name, hidden, seed)
+    barrier = env_name.endswith("Barrier")
+    fields = synth.fields(env_name)
     load_sd(agent.critic, W["critic"]); load_sd(agent.critic_target, W["critic"])
     load_sd(agent.lyapunovNet, W["lyapunov"]); load_sd(agent.lyapunovNet_target, W["lyapunov"])
-    load_sd(agent.policy, W["policy"]); load_sd(agent.backup_policy, W["backup_policy"])
+    load_sd(agent.policy, W["policy"])
+    if barrier:
+        load_sd(agent.BarrierNet, W["barrier"]); load_sd(agent.BarrierNet_target, W["barrier"])
+    else:
+        load_sd(agent.backup_policy, W["backup_policy"])
     load_sd(agent.neural_ode_model, W["node"])
 
     class Dyn:  # reference DynamicsModel needs args.cuda; build it directly
@@ -123,7 +132,11 @@ def run_case(S, env_name, solver, B, hidden=256, seed=0, node_B=512, calls=(0, 1
     # instrumentation -------------------------------------------------------
     rec = {}
     opts = dict(critic=agent.critic_optim, lya=agent.lyaNet_optim, policy=agent.policy_optim,
-                backup=agent.backup_policy_optim, node=agent.neural_ode_model_optimizer)
+                node=agent.neural_ode_model_optimizer)
+    if barrier:
+        opts["barrier"] = agent.BarrierNet_optim
+    else:
+        opts["backup"] = agent.backup_policy_optim
     for name, opt in opts.items():
         orig = opt.step
 
@@ -171,43 +184,49 @@ def run_case(S, env_name, solver, B, hidden=256, seed=0, node_B=512, calls=(0, 1
             eps_queue[:] = [torch.from_numpy(e) for e in eps]
             where_rec.clear(); node_out.clear(); rec.clear()
             torch.where = where
-            ret = agent.update_parameters(FakeMemory(tr, idx), B, updates, dyn,
-                                          FakeMemory(tr, nidx), 10)
+            ret = agent.update_parameters(FakeMemory(tr, idx, fields), B, updates, dyn,
+                                          FakeMemory(tr, nidx, fields), 10)
             torch.where = orig_where
             p = "c%d_" % ci
             out[p + "updates"] = updates
             out[p + "idx"], out[p + "nidx"] = idx, nidx
             out[p + "ret"] = np.array(ret, dtype=np.float64)
-            (matr, filt), (bmatr, bfilt) = where_rec[0], where_rec[1]
+            matr, filt = where_rec[0]
             out[p + "required"] = (filt.sum(0) / B).reshape(-1).numpy()
-            out[p + "brequired"] = (bfilt.sum(0) / B).reshape(-1).numpy()
             out[p + "lambdas"] = np.array([float(x) for x in agent.lambda_values])
-            out[p + "backup_lambdas"] = np.array([float(x) for x in agent.backup_lambda_values])
             out[p + "augmented_term"] = float(agent.augmented_term)
-            out[p + "backup_alpha"] = float(agent.backup_alpha)
             ns, k = env.n_s, cfg["n_ode"]
             out[p + "x_next"] = node_out[0][0][:, :ns].numpy()
-            out[p + "bx_next"] = node_out[k][0][:, :ns].numpy()
+            if not barrier:
+                bmatr, bfilt = where_rec[1]
+                out[p + "brequired"] = (bfilt.sum(0) / B).reshape(-1).numpy()
+                out[p + "backup_lambdas"] = np.array([float(x) for x in agent.backup_lambda_values])
+                out[p + "backup_alpha"] = float(agent.backup_alpha)
+                out[p + "bx_next"] = node_out[k][0][:, :ns].numpy()
             if k == 2:
                 out[p + "x_next2"] = node_out[1][0][:, :ns].numpy()
                 out[p + "bx_next2"] = node_out[3][0][:, :ns].numpy()
             if solver == "dopri5":
                 out[p + "ode_steps"] = np.array(node_out[0][1]["steps"], dtype=np.float64)
-                out[p + "bode_steps"] = np.array(node_out[k][1]["steps"], dtype=np.float64)
+                if not barrier:
+                    out[p + "bode_steps"] = np.array(node_out[k][1]["steps"], dtype=np.float64)
             if B <= 16:
                 out[p + "matr"] = matr.reshape(B, -1).numpy()
-                out[p + "bmatr"] = bmatr.reshape(B, -1).numpy()
+                if not barrier:
+                    out[p + "bmatr"] = bmatr.reshape(B, -1).numpy()
             for name in opts:
                 if "g_" + name in rec:
                     summarize(p + "g_" + name, rec["g_" + name], out)
-            for name, mod in (("critic", agent.critic), ("lya", agent.lyapunovNet),
-                              ("policy", agent.policy), ("backup", agent.backup_policy),
-                              ("node", agent.neural_ode_model),
-                              ("critic_target", agent.critic_target),
-                              ("lya_target", agent.lyapunovNet_target)):
+            mods = [("critic", agent.critic), ("lya", agent.lyapunovNet), ("policy", agent.policy),
+                    ("node", agent.neural_ode_model), ("critic_target", agent.critic_target),
+                    ("lya_target", agent.lyapunovNet_target)]
+            mods += ([("barrier", agent.BarrierNet), ("barrier_target", agent.BarrierNet_target)] if barrier
+                     else [("backup", agent.backup_policy)])
+            for name, mod in mods:
                 summarize(p + "p_" + name, flat_params(mod), out)
             out[p + "log_alpha"] = float(agent.log_alpha)
-            out[p + "backup_log_alpha"] = float(agent.backup_log_alpha)
+            if not barrier:
+                out[p + "backup_log_alpha"] = float(agent.backup_log_alpha)
     finally:
         torch.where = orig_where
         torch.distributions.Normal.rsample = orig_rsample

@@ -11,6 +11,9 @@ produced by importing the reference's own modules in the build container
 rk4 / dopri5 follow torchdiffeq 0.2.3 *from recollection* (the package is
 not in the container) — PARITY UNPINNED for those two solvers.
 
+The learned-barrier-certificate Unicycle copy (NU, fixtures ``nbc_unicycle_*.npz``) is restated by
+``OracleUnicycleBarrierAgent``.
+
 SimulatedCars (C = NLBAC_SimulatedCarsFollowing_RL_training/Simulated_Car_Following_RL_training) is
 restated by ``OracleCarsAgent``: non-affine NODE C/sac_cbf_clf/model.py:179-205, two-step rollout and
 relative-degree-2 CBFs C/sac_cbf_clf/sac_cbf_clf.py:412-555 / 557-681, get_state/get_obs
@@ -572,5 +575,123 @@ class OracleCarsAgent(OracleAgentBase):
         return bmatr, dict(bx_next=x1, bx_next2=x2, bode_info=info[0])
 
 
+class OracleUnicycleBarrierAgent(OracleUnicycleAgent):
+    """Learned-barrier-certificate Unicycle copy (NU = neural_barrier_certificate/
+    neural_barrier_certificate_NLBAC_Unicycle_RL_training/Unicycle_RL_training): one policy, a BarrierNetwork
+    B(obs, a) trained TD-style on the env's barrier signal (NU/sac_cbf_clf/sac_cbf_clf.py:214-246), one learned
+    CBF term -(B(obs', a') - B) - gamma_b B with obs' = get_obs(x') differentiable and a' re-sampled and detached
+    (:404-420), CLF as in U, no ratio in the loss (:474-475)."""
+    N_EPS = 3
+    GOAL = (2.5, 2.5)
+
+    def __init__(self, env, args, weights, solver="euler"):
+        self.env, self.args, self.solver = env, args, solver
+        self.gamma, self.gamma_b, self.tau = args.gamma, args.gamma_b, args.tau
+        self.alpha, self.batch_size = args.alpha, args.batch_size
+        self.critic, self.lya, self.barrier = (_leafify(weights[k]) for k in ("critic", "lyapunov", "barrier"))
+        clone = lambda sd: {k: v.detach().clone() for k, v in sd.items()}
+        self.critic_target, self.lya_target, self.barrier_target = clone(self.critic), clone(self.lya), clone(self.barrier)
+        self.policy, self.node = _leafify(weights["policy"]), _leafify(weights["node"])
+        self.log_alpha = torch.zeros(1, requires_grad=True)
+        A = torch.optim.Adam
+        self.opt = dict(critic=A(self.critic.values(), lr=4e-4), lya=A(self.lya.values(), lr=4e-4),
+                        barrier=A(self.barrier.values(), lr=4e-4), policy=A(self.policy.values(), lr=args.lr),
+                        alpha=A([self.log_alpha], lr=args.lr), node=A(self.node.values(), lr=1e-3))
+        hi = torch.tensor(env.action_space.high, dtype=torch.float32)
+        lo = torch.tensor(env.action_space.low, dtype=torch.float32)
+        self.scale, self.bias = (hi - lo) / 2.0, (hi + lo) / 2.0
+        self.target_entropy = -float(env.action_space.shape[0])
+        self.num_cbfs, self.num_constraints = 1, 2
+        self.lambda_values = [0.0, 0.0]
+        self.augmented_term, self.augmented_ratio, self.cost_limit = 1.0, 1.0005, 0.0
+        self._setup_task(env)
+
+    def get_obs(self, st):
+        """NU/sac_cbf_clf/dynamics.py:92-135 (differentiable): [x, y, cos, sin, compass(2), exp(-dist)]."""
+        c, s_ = torch.cos(st[:, 2]), torch.sin(st[:, 2])
+        rx, ry = self.GOAL[0] - st[:, 0], self.GOAL[1] - st[:, 1]
+        dist = torch.sqrt(rx * rx + ry * ry)
+        v0, v1 = c * rx + s_ * ry, -s_ * rx + c * ry
+        div = torch.sqrt(v0 * v0 + v1 * v1) + 0.001
+        return torch.stack([st[:, 0], st[:, 1], c, s_, v0 / div, v1 / div, torch.exp(-dist)], 1)
+
+    def update(self, batch, eps, updates, node_batch=None):
+        """NU/sac_cbf_clf/sac_cbf_clf.py:155-280; ``eps``: (next_obs sample, obs sample, sample on the predicted
+        next observation inside the loss)."""
+        R = {}
+        if node_batch is not None:
+            R["node_loss"], R["g_node"] = self.train_step(*node_batch)
+        obs, nobs, act = batch["obs"], batch["next_obs"], batch["action"]
+        rew, con, sig = (batch[k].unsqueeze(1) for k in ("reward", "constraint", "barrier_signal"))
+        cen, ncen, mask = batch["center"], batch["next_center"], batch["mask"].unsqueeze(1)
+        dt = self.env.dt
+        with torch.no_grad():
+            na, nlogp, _ = policy_sample(self.policy, nobs, eps[0], self.scale, self.bias)
+            q1t, q2t = qnet(self.critic_target, nobs, na)
+            next_q = rew + mask * self.gamma * (torch.min(q1t, q2t) - self.alpha * nlogp)
+            next_l = con + mask * self.gamma * lyanet(self.lya_target, ncen)
+            next_b = sig + mask * self.gamma * lyanet(self.barrier_target, torch.cat([nobs, na], 1))
+        q1, q2 = qnet(self.critic, obs, act)
+        qf1_loss, qf2_loss = F.mse_loss(q1, next_q), F.mse_loss(q2, next_q)
+        lf_loss = F.mse_loss(lyanet(self.lya, cen), next_l)
+        bf_loss = F.mse_loss(lyanet(self.barrier, torch.cat([obs, act], 1)), next_b)
+        for name, loss, sd in (("critic", qf1_loss + qf2_loss, self.critic), ("lya", lf_loss, self.lya),
+                               ("barrier", bf_loss, self.barrier)):
+            g = torch.autograd.grad(loss, list(sd.values()))
+            self._set_grads(sd.values(), g)
+            self.opt[name].step()
+            R["g_" + name] = _flat(g)
+        R.update(next_q=next_q, next_l=next_l, next_b=next_b, barrier_loss=float(bf_loss))
+
+        pi, log_pi, _ = policy_sample(self.policy, obs, eps[1], self.scale, self.bias)
+        policy_loss_1 = ((self.alpha * log_pi) - torch.min(*qnet(self.critic, obs, pi))).mean()
+        # get_cbf_clf_part / get_policy_loss_2 (:339-477)
+        state = self.get_state(obs)
+        V = lyanet(self.lya, cen).detach()
+        x_next, info = self._rollout(state, pi)
+        V_next = lyanet(self.lya, self._lookahead(x_next))
+        lya_term = ((V_next - V) / dt) + 1.0 * V
+        Bv = lyanet(self.barrier, torch.cat([obs, pi], 1)).detach()
+        obs_pred = self.get_obs(x_next)
+        pi_next, _, _ = policy_sample(self.policy, obs_pred.detach(), eps[2], self.scale, self.bias)
+        B_next = lyanet(self.barrier, torch.cat([obs_pred, pi_next.detach()], 1))
+        barrier_term = -(B_next - Bv) - self.gamma_b * Bv
+        matr = torch.cat((barrier_term, lya_term), 1)
+        required = torch.where(matr > 0, matr, torch.zeros_like(matr)).sum(0) / self.batch_size
+        req_d = required.detach()
+        if updates % self.args.Lagrangian_multiplier_update_interval == 0:
+            for i in range(2):
+                new = torch.as_tensor(self.lambda_values[i], dtype=torch.float32) + self.augmented_term * req_d[i]
+                self.lambda_values[i] = float(torch.clamp(new, 0.01, 400.0))
+        self.augmented_term = min(self.augmented_term * self.augmented_ratio, 200)
+        rho = self.augmented_term
+        loss2 = 0.0
+        for i in (0, 1):
+            g = required[i] - self.cost_limit
+            loss2 = loss2 + float(self.lambda_values[i]) * g + rho / 2.0 * g * g
+        gp = torch.autograd.grad(policy_loss_1 + loss2, list(self.policy.values()))
+        self._set_grads(self.policy.values(), gp)
+        self.opt["policy"].step()
+        alpha_loss = -(self.log_alpha * (log_pi + self.target_entropy).detach()).mean()
+        self.log_alpha.grad = torch.autograd.grad(alpha_loss, self.log_alpha)[0]
+        self.opt["alpha"].step()
+        self.alpha = float(self.log_alpha.exp())
+        if updates % self.args.target_update_interval == 0:
+            with torch.no_grad():
+                for tgt, src in ((self.critic_target, self.critic), (self.lya_target, self.lya),
+                                 (self.barrier_target, self.barrier)):
+                    for k in tgt:
+                        tgt[k].copy_(tgt[k] * (1.0 - self.tau) + src[k] * self.tau)
+        R["ret"] = (float(qf1_loss), float(qf2_loss), float(lf_loss), float(policy_loss_1), float(alpha_loss),
+                    float(self.alpha))
+        R.update(g_policy=_flat(gp), policy_loss_2=float(loss2), matr=matr.detach(), required=req_d,
+                 lambdas=list(self.lambda_values), augmented_term=self.augmented_term, x_next=x_next.detach(),
+                 ode_info=info, log_pi=log_pi.detach(), pi=pi.detach(), obs_pred=obs_pred.detach(),
+                 pi_next=pi_next.detach())
+        return R
+
+
 def make_oracle(env, args, weights, solver="euler"):
-    return {"Unicycle": OracleUnicycleAgent, "SimulatedCars": OracleCarsAgent}[env.dynamics_mode](env, args, weights, solver)
+    kind = env.dynamics_mode + ("Barrier" if "barrier" in weights else "")
+    return {"Unicycle": OracleUnicycleAgent, "SimulatedCars": OracleCarsAgent,
+            "UnicycleBarrier": OracleUnicycleBarrierAgent}[kind](env, args, weights, solver)

@@ -10,9 +10,10 @@ from nlbac_amd.envspec import make_env
 
 GOLD = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
 BATCH_FIELDS = ("obs", "action", "reward", "constraint", "center", "next_center", "next_obs", "mask", "t", "next_t")
-PREFIX = {"Unicycle": "unicycle", "SimulatedCars": "cars"}
-N_EPS = {"Unicycle": 3, "SimulatedCars": 5}
-NODE_FIELDS = {"Unicycle": ("obs", "action", "next_obs"), "SimulatedCars": ("obs", "action", "next_obs", "t")}
+PREFIX = {"Unicycle": "unicycle", "SimulatedCars": "cars", "UnicycleBarrier": "nbc_unicycle"}
+N_EPS = {"Unicycle": 3, "SimulatedCars": 5, "UnicycleBarrier": 3}
+NODE_FIELDS = {"Unicycle": ("obs", "action", "next_obs"), "SimulatedCars": ("obs", "action", "next_obs", "t"),
+               "UnicycleBarrier": ("obs", "action", "next_obs")}
 
 
 def load_golden(solver, B, env="Unicycle"):
@@ -30,7 +31,7 @@ def case_inputs(g, ci, transitions=None):
     tr = transitions if transitions is not None else synth.transitions(env_name, 4096, seed=seed + 1, env=env)
     idx, nidx = g["c%d_idx" % ci], g["c%d_nidx" % ci]
     B = int(g["meta_B"])
-    batch = {f: torch.tensor(tr[f][idx], dtype=torch.float32) for f in BATCH_FIELDS}
+    batch = {f: torch.tensor(tr[f][idx], dtype=torch.float32) for f in synth.fields(env_name)}
     eps = [torch.from_numpy(e) for e in synth.normal_eps(N_EPS[env_name], B, env.n_u, seed=100 * seed + ci)]
     node = tuple(torch.tensor(tr[f][nidx], dtype=torch.float32) for f in NODE_FIELDS[env_name])
     return batch, eps, node, int(g["c%d_updates" % ci])

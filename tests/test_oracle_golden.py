@@ -22,7 +22,7 @@ def flat_sd(sd):
     return torch.cat([v.detach().reshape(-1) for v in sd.values()])
 
 
-@pytest.mark.parametrize("env_name", ["Unicycle", "SimulatedCars"])
+@pytest.mark.parametrize("env_name", ["Unicycle", "SimulatedCars", "UnicycleBarrier"])
 @pytest.mark.parametrize("solver", ["euler", "rk4", "dopri5"])
 @pytest.mark.parametrize("B", [8, 128])
 def test_oracle_matches_reference_fixture(solver, B, env_name):
@@ -41,18 +41,20 @@ def test_oracle_matches_reference_fixture(solver, B, env_name):
         p = "c%d_" % ci
         vec_close(R["ret"], g[p + "ret"], TOL, p + "ret")
         vec_close(R["required"], g[p + "required"], TOL, p + "required")
-        vec_close(R["brequired"], g[p + "brequired"], TOL, p + "brequired")
         vec_close(R["lambdas"], g[p + "lambdas"], TOL, p + "lambdas")
-        vec_close(R["backup_lambdas"], g[p + "backup_lambdas"], TOL, p + "backup_lambdas")
         assert abs(R["augmented_term"] - float(g[p + "augmented_term"])) < 1e-12
         vec_close(R["x_next"], g[p + "x_next"], TOL, p + "x_next")
-        vec_close(R["bx_next"], g[p + "bx_next"], TOL, p + "bx_next")
+        if p + "brequired" in g.files:           # variants with a backup controller
+            vec_close(R["brequired"], g[p + "brequired"], TOL, p + "brequired")
+            vec_close(R["backup_lambdas"], g[p + "backup_lambdas"], TOL, p + "backup_lambdas")
+            vec_close(R["bx_next"], g[p + "bx_next"], TOL, p + "bx_next")
         if p + "x_next2" in g.files:
             vec_close(R["x_next2"], g[p + "x_next2"], TOL, p + "x_next2")
             vec_close(R["bx_next2"], g[p + "bx_next2"], TOL, p + "bx_next2")
         if B <= 16:
             vec_close(R["matr"], g[p + "matr"], TOL, p + "matr")
-            vec_close(R["bmatr"], g[p + "bmatr"], TOL, p + "bmatr")
+            if p + "bmatr" in g.files:
+                vec_close(R["bmatr"], g[p + "bmatr"], TOL, p + "bmatr")
         if solver == "dopri5":
             st, gs = np.array(R["ode_info"]["steps"], dtype=np.float64), g[p + "ode_steps"]
             assert st.shape == gs.shape
@@ -60,18 +62,21 @@ def test_oracle_matches_reference_fixture(solver, B, env_name):
             np.testing.assert_allclose(st[:, 1], gs[:, 1], rtol=2e-2)   # error ratio: cancellation noise
             np.testing.assert_array_equal(st[:, 2], gs[:, 2])           # accept flags
         for name, key in (("critic", "g_critic"), ("lya", "g_lya"), ("policy", "g_policy"),
-                          ("backup", "g_backup"), ("node", "g_node")):
+                          ("backup", "g_backup"), ("node", "g_node"), ("barrier", "g_barrier")):
             if p + "g_%s_norm" % name not in g.files or key not in R:
                 continue
             v = R[key]
             assert abs(float(v.double().norm()) / float(g[p + "g_%s_norm" % name]) - 1) < TOL
             vec_close(v[:48], g[p + "g_%s_head" % name], 5 * TOL, p + key + "_head")
             vec_close(v[-48:], g[p + "g_%s_tail" % name], 5 * TOL, p + key + "_tail")
-        for name, sd in (("critic", agent.critic), ("lya", agent.lya), ("policy", agent.policy),
-                         ("backup", agent.backup), ("node", agent.node),
-                         ("critic_target", agent.critic_target), ("lya_target", agent.lya_target)):
+        nets = [("critic", agent.critic), ("lya", agent.lya), ("policy", agent.policy), ("node", agent.node),
+                ("critic_target", agent.critic_target), ("lya_target", agent.lya_target)]
+        nets += ([("barrier", agent.barrier), ("barrier_target", agent.barrier_target)] if hasattr(agent, "barrier")
+                 else [("backup", agent.backup)])
+        for name, sd in nets:
             v = flat_sd(sd)
             assert abs(float(v.double().norm()) / float(g[p + "p_%s_norm" % name]) - 1) < 1e-6
             vec_close(v[:48], g[p + "p_%s_head" % name], TOL, p + "p_" + name)
         assert abs(float(agent.log_alpha) - float(g[p + "log_alpha"])) < 1e-6
-        assert abs(float(agent.backup_log_alpha) - float(g[p + "backup_log_alpha"])) < 1e-6
+        if p + "backup_log_alpha" in g.files:
+            assert abs(float(agent.backup_log_alpha) - float(g[p + "backup_log_alpha"])) < 1e-6
