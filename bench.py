@@ -29,7 +29,7 @@ from nlbac_amd.envspec import make_env
 
 PEAK_F32_MFMA_TFLOPS = 157.3     # MI355X_MICROARCH.md, chip-level parameters
 NODE_FIT_ROWS, NODE_FIT_INTERVAL, REPLAY_ROWS = 32768, 10, 65536
-GAMMA_B = {"Unicycle": 50.0, "SimulatedCars": 0.5}       # the reference README's run commands
+GAMMA_B = {"Unicycle": 50.0, "SimulatedCars": 0.5, "UnicycleBarrier": 5.0}       # the reference README's run commands
 
 
 class Args:
@@ -43,7 +43,7 @@ class Args:
 
 def replay_rows(agent, tr):
     """The synthetic replay as minibatch-layout rows (the agent's HBM row layout), built once on the host."""
-    return agent._rows_from_host(tuple(tr[f] for f in synth.FIELDS))
+    return agent._rows_from_host(tuple(tr[f] for f in (synth.FIELDS_BARRIER if agent.lay.sig is not None else synth.FIELDS)))
 
 
 # ---- algorithmic FLOPs of one MLP launch (real dims, 1 MAC = 2 FLOP) ------------------------------
@@ -157,7 +157,7 @@ def cpu_baseline(B, solver, env_name="Unicycle", seed=0):
     oargs.gamma_b = GAMMA_B[env_name]
     agent = O.make_oracle(env, oargs, W, solver=solver)
     tr = synth.transitions(env_name, REPLAY_ROWS, seed=1, env=env)
-    fields = synth.FIELDS
+    fields = synth.fields(env_name)
     rs = np.random.RandomState(0)
 
     def mk(n):
@@ -191,7 +191,7 @@ def main():
     ap.add_argument("--warmup", type=int, default=20)
     ap.add_argument("--batch", type=int, default=4096)
     ap.add_argument("--solver", default="dopri5", choices=["euler", "rk4", "dopri5"])
-    ap.add_argument("--env", default="Unicycle", choices=["Unicycle", "SimulatedCars"])
+    ap.add_argument("--env", default="Unicycle", choices=["Unicycle", "SimulatedCars", "UnicycleBarrier"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--graphs", action="store_true",
                     help="replay the update as hipGraphs (measured equal to eager launches once descriptors are cached)")
@@ -208,7 +208,10 @@ def main():
         import torch.distributed as dist
         dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
 
-    from nlbac_amd.sac_cbf_clf.sac_cbf_clf import SAC_CBF_CLF
+    if a.env.endswith("Barrier"):
+        from nlbac_amd.neural_barrier_certificate.sac_cbf_clf.sac_cbf_clf import SAC_CBF_CLF
+    else:
+        from nlbac_amd.sac_cbf_clf.sac_cbf_clf import SAC_CBF_CLF
     B = a.batch
     env = make_env(a.env, 0)
     args = Args(B * world)                                            # global batch in the loss normalisation
@@ -296,7 +299,7 @@ def main():
             "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {"workload": "%s B=%d %s (BASELINE.json configs[%d]); NODE fit on %d rows every %d "
                                    "updates; replay of %d synthetic transitions resident in HBM"
-                                   % (a.env, B, a.solver, 1 if a.env == "Unicycle" else 2, NODE_FIT_ROWS, NODE_FIT_INTERVAL, REPLAY_ROWS),
+                                   % (a.env, B, a.solver, {"Unicycle": 1, "SimulatedCars": 2, "UnicycleBarrier": 4}[a.env], NODE_FIT_ROWS, NODE_FIT_INTERVAL, REPLAY_ROWS),
                        "solver": a.solver, "batch_per_gpu": B, "global_batch": B * world,
                        "parallelism": "dp%d" % world, "hipgraph": bool(agent.use_graphs),
                        "rollout_solver_stats": dict(agent.node_solver.stats), "last_losses": [float(x) for x in ret]},

@@ -172,9 +172,11 @@ int nlbac_unicycle_constraints_fwd(const float *ps, const float *ps_next, const 
                                    float *bmatr, float *partials, nlbac_stream_t s);
 /* required_matrix, ratio, lambda update (clamp [lam_lo,lam_hi]), rho *= 1.0005 (cap 200), loss values and
  * loss coefficients, primary then backup (sac_cbf_clf.py:502-528, 619-638).
- * ratio_mode: 0 none (NU), 1 plain (U), 2 clamp at 0.002 (C/P/NP).  shared_rho: U/C share augmented_term. */
+ * ratio_mode: 0 none (NU), 1 plain (U), 2 clamp at 0.002 (C/P/NP).
+ * backup_mode: 0 no backup controller (NU/NP: partials have n_cbf+n_clf columns), 1 backup shares augmented_term
+ * with the primary (U/C), 2 backup keeps its own (P); with a backup, partials have 2*n_cbf+n_clf columns. */
 int nlbac_auglag(const float *partials, int n_blk, int n_cbf, int n_clf, float batch_size,
-                 int do_lambda_update, int ratio_mode, int shared_rho, float lam_lo, float lam_hi,
+                 int do_lambda_update, int ratio_mode, int backup_mode, float lam_lo, float lam_hi,
                  float *sc, nlbac_stream_t s);
 /* d ps_next (2B,2) [CBF part] and dV_next (B) from the coefficients in sc. */
 int nlbac_unicycle_constraints_bwd(const float *ps_next, const float *matr, const float *bmatr,
@@ -195,6 +197,26 @@ int nlbac_cars_constraints_bwd(const float *matr, const float *bmatr, float gamm
 /* dst[row][col0+c] += src[row][c] */
 int nlbac_add_cols(float *dst, int dst_ld, int col0, const float *src, int src_ld, int ncols, int n,
                    nlbac_stream_t s);
+
+/* Learned barrier certificate (NU = neural_barrier_certificate/.../Unicycle_RL_training).
+ * td_value: y = signal + mask*gamma*next_target, dpred = 2 (pred - y)/B_norm, per-block squared-error partials
+ *   (BarrierNet TD step, NU/sac_cbf_clf/sac_cbf_clf.py:224-233).
+ * unicycle_obs_fwd/bwd: get_obs(x') = [x, y, cos, sin, compass(2), exp(-dist to goal)] and its transpose-Jacobian
+ *   product into dx (n,3) (NU/sac_cbf_clf/dynamics.py:92-135; used differentiably at sac_cbf_clf.py:408).
+ * barrier_constraints: matr (B,2) = [-(B(obs',a') - B(obs,a)) - gamma_b B(obs,a), (V' - V)/dt + gamma_l V],
+ *   partials [ceil(B/256)][2]; bwd gives dB(obs',a') and dV' from the coefficients in sc (:412-440). */
+int nlbac_td_value(const float *next_target, const float *signal, int sig_ld, const float *mask, int mask_ld,
+                   const float *pred, float gamma, int B, int B_norm, float *dpred, float *next_out /*or NULL*/,
+                   float *partials, nlbac_stream_t s);
+int nlbac_unicycle_obs_fwd(const float *x /*(n,3)*/, int n, float goal_x, float goal_y, float *obs, int obs_ld,
+                           nlbac_stream_t s);
+int nlbac_unicycle_obs_bwd(const float *x, const float *dobs, int dobs_ld, int n, float goal_x, float goal_y,
+                           float *dx /*(n,3)*/, int accumulate, nlbac_stream_t s);
+int nlbac_barrier_constraints_fwd(const float *Bv, const float *Bn, const float *V, const float *Vn, float dt,
+                                  float gamma_b, float gamma_l, int B, float *matr, float *partials,
+                                  nlbac_stream_t s);
+int nlbac_barrier_constraints_bwd(const float *matr, float dt, float batch_size, int B, const float *sc,
+                                  float *dBn, float *dVn, nlbac_stream_t s);
 
 /* nn.MSELoss('mean') over (n,d): dpred and per-block squared-error partials [ceil(n/256)] (model.py:256). */
 int nlbac_mse_fwd_bwd(const float *pred, int pred_ld, const float *target, int target_ld, int n, int n_norm,

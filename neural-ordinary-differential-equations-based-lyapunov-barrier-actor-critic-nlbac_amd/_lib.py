@@ -82,6 +82,11 @@ _PROTOS = {
     "nlbac_cars_constraints_fwd": [_P, _P, _P, _P, _P, _F, _F, _F, _I, _P, _P, _P, _P],
     "nlbac_cars_constraints_bwd": [_P, _P, _F, _F, _I, _P, _P, _P, _P, _P],
     "nlbac_add_cols": [_P, _I, _I, _P, _I, _I, _I, _P],
+    "nlbac_td_value": [_P, _P, _I, _P, _I, _P, _F, _I, _I, _P, _P, _P, _P],
+    "nlbac_unicycle_obs_fwd": [_P, _I, _F, _F, _P, _I, _P],
+    "nlbac_unicycle_obs_bwd": [_P, _P, _I, _I, _F, _F, _P, _I, _P],
+    "nlbac_barrier_constraints_fwd": [_P, _P, _P, _P, _F, _F, _F, _I, _P, _P, _P],
+    "nlbac_barrier_constraints_bwd": [_P, _F, _F, _I, _P, _P, _P, _P],
     "nlbac_node_rk_fwd": [C.POINTER(Mlp), C.POINTER(Mlp), _P, _P, _I, _I, _I, _I, _I, c_float_p, c_float_p, _I,
                           c_float_p, _I, c_float_p, _P, _I, _P, _P, _P, _P, _L, _P, _L, _P, _P, _P],
     "nlbac_node_rk_bwd": [C.POINTER(Mlp), C.POINTER(Mlp), _P, _P, _I, _I, _I, _I, _I, _I, c_float_p, c_float_p, _P, _I,

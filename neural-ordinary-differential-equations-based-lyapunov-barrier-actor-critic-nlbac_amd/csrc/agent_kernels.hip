@@ -249,21 +249,25 @@ __global__ __launch_bounds__(256) void unicycle_constraints_fwd_kernel(const flo
         for (int c = 0; c < 2 * NH + 1; ++c) partials[(long)blockIdx.x * (2 * NH + 1) + c] = v[c];
 }
 
-// Augmented-Lagrangian scalars (one thread).  Shared rho for primary and
-// backup (Unicycle / SimulatedCars); lambda clamp [lam_lo, lam_hi].
+// Augmented-Lagrangian scalars.  One wave: lanes sum the partial columns, lane 0 does the scalar bookkeeping.
+// backup_mode: 0 no backup controller (learned-barrier copies), 1 backup shares rho with the primary
+// (Unicycle / SimulatedCars), 2 backup keeps its own rho (Pvtol); lambda clamp [lam_lo, lam_hi].
 __global__ void auglag_kernel(const float* partials, int n_blk, int n_cbf, int n_clf, float batch_size,
                               int do_lambda_update, int ratio_mode /*0 none,1 plain,2 clamp .002*/,
-                              int shared_rho, float lam_lo, float lam_hi, float* sc) {
-    if (threadIdx.x != 0 || blockIdx.x != 0) return;
-    const int nc = n_cbf + n_clf, ncol = nc + n_cbf;
-    double* rho_p = reinterpret_cast<double*>(sc + SC_RHO_F64);
-    double* brho_p = shared_rho ? rho_p : reinterpret_cast<double*>(sc + SC_BRHO_F64);
-    for (int c = 0; c < ncol; ++c) {
+                              int backup_mode, float lam_lo, float lam_hi, float* sc) {
+    const int nc = n_cbf + n_clf, ncol = nc + (backup_mode ? n_cbf : 0);
+    if (blockIdx.x != 0) return;
+    for (int c = threadIdx.x; c < ncol; c += blockDim.x) {
         float s = 0.f;
         for (int b = 0; b < n_blk; ++b) s += partials[(long)b * ncol + c];
         s = s / batch_size;
         if (c < nc) sc[SC_REQ + c] = s; else sc[SC_BREQ + (c - nc)] = s;
     }
+    __threadfence_block();
+    __syncthreads();
+    if (threadIdx.x != 0) return;
+    double* rho_p = reinterpret_cast<double*>(sc + SC_RHO_F64);
+    double* brho_p = backup_mode == 1 ? rho_p : reinterpret_cast<double*>(sc + SC_BRHO_F64);
     // ---- primary (sac_cbf_clf.py:506-528)
     {
         const float* req = sc + SC_REQ;
@@ -301,7 +305,7 @@ __global__ void auglag_kernel(const float* partials, int n_blk, int n_cbf, int n
         sc[SC_PL2] = loss;
     }
     // ---- backup (sac_cbf_clf.py:623-638)
-    {
+    if (backup_mode) {
         const float* req = sc + SC_BREQ;
         float* lam = sc + SC_BLAMBDA;
         double rho = *brho_p;
@@ -571,12 +575,13 @@ extern "C" int nlbac_unicycle_constraints_fwd(const float* ps, const float* ps_n
 }
 
 extern "C" int nlbac_auglag(const float* partials, int n_blk, int n_cbf, int n_clf, float batch_size,
-                            int do_lambda_update, int ratio_mode, int shared_rho, float lam_lo, float lam_hi,
+                            int do_lambda_update, int ratio_mode, int backup_mode, float lam_lo, float lam_hi,
                             float* sc, nlbac_stream_t s) {
     NLBAC_REQUIRE(partials && sc, "nlbac_auglag: null pointer");
+    NLBAC_REQUIRE(backup_mode >= 0 && backup_mode <= 2, "nlbac_auglag: backup_mode is 0, 1 or 2");
     NLBAC_REQUIRE(n_cbf >= 1 && n_cbf + n_clf <= NLBAC_NC_MAX && n_clf >= 0 && n_clf <= 1, "nlbac_auglag: bad constraint counts");
     hipLaunchKernelGGL(auglag_kernel, dim3(1), dim3(64), 0, (hipStream_t)s, partials, n_blk, n_cbf, n_clf,
-                       batch_size, do_lambda_update, ratio_mode, shared_rho, lam_lo, lam_hi, sc);
+                       batch_size, do_lambda_update, ratio_mode, backup_mode, lam_lo, lam_hi, sc);
     NLBAC_CHECK_LAUNCH("nlbac_auglag");
     return 0;
 }
@@ -639,5 +644,141 @@ extern "C" int nlbac_add_cols(float* dst, int dst_ld, int col0, const float* src
     NLBAC_REQUIRE(dst && src && ncols >= 1, "nlbac_add_cols: bad arguments");
     hipLaunchKernelGGL(add_cols_kernel, GRID1(n), dst, dst_ld, col0, src, src_ld, ncols, n);
     NLBAC_CHECK_LAUNCH("nlbac_add_cols");
+    return 0;
+}
+
+
+// ---------------------------------------------------------------------------
+// Learned-barrier-certificate copies (NU = neural_barrier_certificate/.../Unicycle_RL_training)
+//   barrier TD target + MSE     NU/sac_cbf_clf/sac_cbf_clf.py:224-233
+//   get_obs (differentiable)    NU/sac_cbf_clf/dynamics.py:92-135
+//   learned CBF + CLF terms     NU/sac_cbf_clf/sac_cbf_clf.py:399-420, 430-440
+// ---------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void td_value_kernel(const float* next_target, const float* signal, int sig_ld,
+                                                       const float* mask, int mask_ld, const float* pred, float gamma,
+                                                       int B, int B_norm, float* dpred, float* next_out,
+                                                       float* partials) {
+    __shared__ float red[4];
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    float v[1] = {0.f};
+    if (i < B) {
+        const float y = signal[(long)i * sig_ld] + mask[(long)i * mask_ld] * gamma * next_target[i];
+        const float e = pred[i] - y;
+        dpred[i] = (float)(2.0 / (double)B_norm) * e;
+        if (next_out) next_out[i] = y;
+        v[0] = e * e;
+    }
+    block_sum_256<1>(v, red);
+    if (threadIdx.x == 0) partials[blockIdx.x] = v[0];
+}
+
+__global__ __launch_bounds__(256) void unicycle_obs_fwd_kernel(const float* x, int n, float gx, float gy, float* obs,
+                                                               int obs_ld) {
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    const float px = x[i * 3], py = x[i * 3 + 1], th = x[i * 3 + 2];
+    const float c = cosf(th), s = sinf(th);
+    const float rx = gx - px, ry = gy - py;
+    const float dist = sqrtf(rx * rx + ry * ry);
+    const float v0 = c * rx + s * ry, v1 = -s * rx + c * ry;
+    const float div = sqrtf(v0 * v0 + v1 * v1) + 0.001f;
+    float* o = obs + (long)i * obs_ld;
+    o[0] = px; o[1] = py; o[2] = c; o[3] = s; o[4] = v0 / div; o[5] = v1 / div; o[6] = expf(-dist);
+}
+
+__global__ __launch_bounds__(256) void unicycle_obs_bwd_kernel(const float* x, const float* dobs, int dobs_ld, int n,
+                                                               float gx, float gy, float* dx, int accumulate) {
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    const float px = x[i * 3], py = x[i * 3 + 1], th = x[i * 3 + 2];
+    const float c = cosf(th), s = sinf(th);
+    const float rx = gx - px, ry = gy - py;
+    const float dist = sqrtf(rx * rx + ry * ry);
+    const float v0 = c * rx + s * ry, v1 = -s * rx + c * ry;
+    const float nv = sqrtf(v0 * v0 + v1 * v1), div = nv + 0.001f;
+    const float* d = dobs + (long)i * dobs_ld;
+    float gpx = d[0], gpy = d[1], gth = -s * d[2] + c * d[3];
+    float dv0 = d[4] / div, dv1 = d[5] / div;
+    const float dnv = -(d[4] * v0 + d[5] * v1) / (div * div);
+    if (nv > 0.f) { dv0 += dnv * v0 / nv; dv1 += dnv * v1 / nv; }
+    float drx = dv0 * c - dv1 * s, dry = dv0 * s + dv1 * c;
+    gth += dv0 * v1 - dv1 * v0;
+    if (dist > 0.f) {
+        const float dd = -d[6] * expf(-dist);
+        drx += dd * rx / dist; dry += dd * ry / dist;
+    }
+    gpx -= drx; gpy -= dry;
+    if (accumulate) { dx[i * 3] += gpx; dx[i * 3 + 1] += gpy; dx[i * 3 + 2] += gth; }
+    else { dx[i * 3] = gpx; dx[i * 3 + 1] = gpy; dx[i * 3 + 2] = gth; }
+}
+
+// matr (B,2) = [-(B' - B) - gamma_b B, (V' - V)/dt + gamma_l V]; partials [nblk][2]
+__global__ __launch_bounds__(256) void barrier_constraints_fwd_kernel(const float* Bv, const float* Bn, const float* V,
+                                                                      const float* Vn, float dt, float gamma_b,
+                                                                      float gamma_l, int B, float* matr,
+                                                                      float* partials) {
+    __shared__ float red[8];
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    float v[2] = {0.f, 0.f};
+    if (i < B) {
+        const float b = Bv[i], vv = V[i];
+        const float bt = -(Bn[i] - b) - gamma_b * b;
+        const float lt = ((Vn[i] - vv) / dt) + gamma_l * vv;
+        matr[i * 2] = bt; matr[i * 2 + 1] = lt;
+        v[0] = bt > 0.f ? bt : 0.f;
+        v[1] = lt > 0.f ? lt : 0.f;
+    }
+    block_sum_256<2>(v, red);
+    if (threadIdx.x == 0) { partials[blockIdx.x * 2] = v[0]; partials[blockIdx.x * 2 + 1] = v[1]; }
+}
+
+__global__ __launch_bounds__(256) void barrier_constraints_bwd_kernel(const float* matr, float dt, float batch_size,
+                                                                      int B, const float* sc, float* dBn, float* dVn) {
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= B) return;
+    dBn[i] = matr[i * 2] > 0.f ? -(sc[SC_COEF] / batch_size) : 0.f;
+    dVn[i] = matr[i * 2 + 1] > 0.f ? ((sc[SC_COEF + 1] / batch_size) / dt) : 0.f;
+}
+
+extern "C" int nlbac_td_value(const float* next_target, const float* signal, int sig_ld, const float* mask,
+                              int mask_ld, const float* pred, float gamma, int B, int B_norm, float* dpred,
+                              float* next_out, float* partials, nlbac_stream_t s) {
+    NLBAC_REQUIRE(next_target && signal && mask && pred && dpred && partials, "nlbac_td_value: null pointer");
+    hipLaunchKernelGGL(td_value_kernel, GRID1(B), next_target, signal, sig_ld, mask, mask_ld, pred, gamma, B, B_norm,
+                       dpred, next_out, partials);
+    NLBAC_CHECK_LAUNCH("nlbac_td_value");
+    return 0;
+}
+
+extern "C" int nlbac_unicycle_obs_fwd(const float* x, int n, float goal_x, float goal_y, float* obs, int obs_ld,
+                                      nlbac_stream_t s) {
+    NLBAC_REQUIRE(x && obs && obs_ld >= 7, "nlbac_unicycle_obs_fwd: bad arguments");
+    hipLaunchKernelGGL(unicycle_obs_fwd_kernel, GRID1(n), x, n, goal_x, goal_y, obs, obs_ld);
+    NLBAC_CHECK_LAUNCH("nlbac_unicycle_obs_fwd");
+    return 0;
+}
+
+extern "C" int nlbac_unicycle_obs_bwd(const float* x, const float* dobs, int dobs_ld, int n, float goal_x,
+                                      float goal_y, float* dx, int accumulate, nlbac_stream_t s) {
+    NLBAC_REQUIRE(x && dobs && dx && dobs_ld >= 7, "nlbac_unicycle_obs_bwd: bad arguments");
+    hipLaunchKernelGGL(unicycle_obs_bwd_kernel, GRID1(n), x, dobs, dobs_ld, n, goal_x, goal_y, dx, accumulate);
+    NLBAC_CHECK_LAUNCH("nlbac_unicycle_obs_bwd");
+    return 0;
+}
+
+extern "C" int nlbac_barrier_constraints_fwd(const float* Bv, const float* Bn, const float* V, const float* Vn,
+                                             float dt, float gamma_b, float gamma_l, int B, float* matr,
+                                             float* partials, nlbac_stream_t s) {
+    NLBAC_REQUIRE(Bv && Bn && V && Vn && matr && partials, "nlbac_barrier_constraints_fwd: null pointer");
+    hipLaunchKernelGGL(barrier_constraints_fwd_kernel, GRID1(B), Bv, Bn, V, Vn, dt, gamma_b, gamma_l, B, matr, partials);
+    NLBAC_CHECK_LAUNCH("nlbac_barrier_constraints_fwd");
+    return 0;
+}
+
+extern "C" int nlbac_barrier_constraints_bwd(const float* matr, float dt, float batch_size, int B, const float* sc,
+                                             float* dBn, float* dVn, nlbac_stream_t s) {
+    NLBAC_REQUIRE(matr && sc && dBn && dVn, "nlbac_barrier_constraints_bwd: null pointer");
+    hipLaunchKernelGGL(barrier_constraints_bwd_kernel, GRID1(B), matr, dt, batch_size, B, sc, dBn, dVn);
+    NLBAC_CHECK_LAUNCH("nlbac_barrier_constraints_bwd");
     return 0;
 }

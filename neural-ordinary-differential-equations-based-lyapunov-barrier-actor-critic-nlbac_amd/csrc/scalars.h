@@ -17,6 +17,7 @@ enum {
     SC_PL1 = 10, SC_BPL1 = 11,
     SC_ALOSS = 12, SC_BALOSS = 13,
     SC_NODE_LOSS = 14,
+    SC_XLOSS = 15,       // TD loss of the extra critic-type net (BarrierNet)
     SC_LAMBDA = 16,                       // [NC_MAX]
     SC_BLAMBDA = SC_LAMBDA + NLBAC_NC_MAX,   // 32
     SC_COEF = SC_BLAMBDA + NLBAC_NC_MAX,     // 48  dLoss/d required_i

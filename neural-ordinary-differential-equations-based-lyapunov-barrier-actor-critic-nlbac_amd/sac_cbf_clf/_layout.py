@@ -6,6 +6,7 @@ SC_QF1, SC_QF2, SC_LF = 7, 8, 9
 SC_PL1, SC_BPL1 = 10, 11
 SC_ALOSS, SC_BALOSS = 12, 13
 SC_NODE_LOSS = 14
+SC_XLOSS = 15      # TD loss of the extra critic-type net (BarrierNet)
 SC_LAMBDA = 16
 SC_BLAMBDA = SC_LAMBDA + NC_MAX
 SC_COEF = SC_BLAMBDA + NC_MAX

@@ -65,7 +65,16 @@ class LyaNetwork(nn.Module):
         return [self.net]
 
 
-BarrierNetwork = LyaNetwork
+class BarrierNetwork(LyaNetwork):
+    """Learned barrier certificate B(obs, action) (NU/sac_cbf_clf/model.py:67-84): the Lyapunov critic's shape
+    over cat(state, action)."""
+
+    def __init__(self, num_inputs, num_actions, hidden_dim):
+        super().__init__(num_inputs + num_actions, hidden_dim)
+
+    def attach(self, arena):
+        self.net = MlpHandle(arena, [(l.weight, l.bias) for l in (self.linear1, self.linear2, self.linear3)], "barrier")
+        return [self.net]
 
 
 class GaussianPolicy(nn.Module):

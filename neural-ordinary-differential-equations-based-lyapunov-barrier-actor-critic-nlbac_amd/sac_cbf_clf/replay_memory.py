@@ -36,7 +36,9 @@ class ReplayMemory:
 
     def push(self, state, action, reward, constraint, center_pos, next_center_pos, next_state, mask,
              t=None, next_t=None):
-        values = (state, action, reward, constraint, center_pos, next_center_pos, next_state, mask, t, next_t)
+        self._push((state, action, reward, constraint, center_pos, next_center_pos, next_state, mask, t, next_t))
+
+    def _push(self, values):
         if self._cols is None:
             self._alloc(values)
         if self.position >= self._rows:

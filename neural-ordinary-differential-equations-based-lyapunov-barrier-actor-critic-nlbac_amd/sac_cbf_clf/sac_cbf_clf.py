@@ -27,7 +27,7 @@ import torch.nn as nn
 from .. import _lib
 from ..arena import Arena, bwd_weights, io_array, mlp_array, pack, stream_ptr
 from . import _layout as SC
-from .model import GaussianPolicy, LyaNetwork, QNetwork
+from .model import BarrierNetwork, GaussianPolicy, LyaNetwork, QNetwork
 from .tasks import TASKS
 from .utils import to_tensor
 
@@ -49,8 +49,12 @@ class _Layout:
     def __init__(self, task):
         self.obs_dim, self.act_dim, self.lya_dim = task.obs_dim, task.act_dim, task.lya_dim
         c = 0
-        for name, w in (("obs", task.obs_dim), ("act", task.act_dim), ("rew", 1), ("con", 1), ("lya", task.lya_dim),
-                        ("nlya", task.lya_dim), ("nobs", task.obs_dim), ("mask", 1), ("t", 1), ("nt", 1)):
+        fields = [("obs", task.obs_dim), ("act", task.act_dim), ("rew", 1), ("con", 1), ("lya", task.lya_dim),
+                  ("nlya", task.lya_dim), ("nobs", task.obs_dim), ("mask", 1), ("t", 1), ("nt", 1)]
+        if task.has_signal:          # learned-barrier copies store a barrier signal after the constraint
+            fields.insert(4, ("sig", 1))
+        self.sig = None
+        for name, w in fields:
             setattr(self, name, c)
             c += w
         self.width = c
@@ -63,32 +67,35 @@ class _Workspace:
     def __init__(self, B, H, dev, lay, task):
         z = lambda *s: torch.zeros(*s, dtype=torch.float32, device=dev)
         A, Do = lay.act_dim, lay.obs_dim
+        NP, NX = task.n_pol, task.n_extra_critics      # controllers; critic-type nets beyond Q1, Q2, L
         self.B = B
         self.mb = z(B, lay.LD)                   # minibatch rows (see _Layout)
         self.eps = z(task.n_eps, B, A)
         self.heads_n, self.na, self.nlogp = z(B, 2 * A), z(B, A), z(B)
-        self.q6 = z(6, B)                        # q1t q2t lt q1 q2 lf
-        self.dq3 = z(3, B)
+        self.q6 = z(6 + 2 * NX, B)               # q1t q2t lt q1 q2 lf [xt x]...
+        self.dq3 = z(3 + NX, B)
         self.next_q, self.next_l = z(B), z(B)
-        self.acts_c = z(3, 2, B, H)              # Q1,Q2,L saved activations
-        self.dz_c = z(3, 2, B, H)
+        self.acts_c = z(3 + NX, 2, B, H)         # Q1,Q2,L[,extras] saved activations
+        self.dz_c = z(3 + NX, 2, B, H)
         self.nblk = (B + 255) // 256
         self.part_td = z(self.nblk, 3)
-        self.heads2, self.pi2, self.logp2 = z(2 * B, 2 * A), z(2 * B, A), z(2 * B)
-        self.acts_p = z(2, 2, B, H)
-        self.dz_p = z(2, 2, B, H)
+        self.part_tdx = z(max(NX, 1), self.nblk)
+        self.heads2, self.pi2, self.logp2 = z(NP * B, 2 * A), z(NP * B, A), z(NP * B)
+        self.acts_p = z(NP, 2, B, H)
+        self.dz_p = z(NP, 2, B, H)
         self.plan = None
         self.graphs, self.warm = {}, 0
-        self.qpi = z(2, 2 * B)
-        self.acts_q = z(4, 2, B, H)
-        self.dq_pi = z(2, 2 * B)
-        self.part_q = z(2, self.nblk, 2)
-        self.dxq = z(2, 2 * B, Do + A)
-        self.dheads2 = z(2 * B, 2 * A)
+        self.qpi = z(2, NP * B)
+        self.acts_q = z(2 * NP, 2, B, H)
+        self.dq_pi = z(2, NP * B)
+        self.part_q = z(NP, self.nblk, 2)
+        self.dxq = z(2, NP * B, Do + A)
+        self.dheads2 = z(NP * B, 2 * A)
         task.alloc(self)
 
 
 class SAC_CBF_CLF(object):
+    variant = ""         # "Barrier" in the learned-barrier-certificate copies (neural_barrier_certificate/)
 
     def __init__(self, num_inputs, action_space, env, args):
         self.gamma = args.gamma
@@ -106,12 +113,12 @@ class SAC_CBF_CLF(object):
                                "there is no CPU fallback")
         if self.policy_type != "Gaussian":
             raise NotImplementedError("only the Gaussian policy is on the device path")
-        if env.dynamics_mode not in TASKS:
+        if env.dynamics_mode + self.variant not in TASKS:
             raise Exception('Dynamics mode not supported.')
         _lib.load()
         self.device = torch.device("cuda")
         self.env = env
-        self.task = task = TASKS[env.dynamics_mode](self, env, args)
+        self.task = task = TASKS[env.dynamics_mode + self.variant](self, env, args)
         self.lay = _Layout(task)
         if num_inputs != task.obs_dim or action_space.shape[0] != task.act_dim:
             raise ValueError("%s expects %d observations / %d actions" % (task.name, task.obs_dim, task.act_dim))
@@ -126,8 +133,11 @@ class SAC_CBF_CLF(object):
         # --- same construction order (and RNG consumption) as the reference ---
         self.critic = QNetwork(num_inputs, n_act, hidden)
         self.lyapunovNet = LyaNetwork(self.center_pos_num, hidden)
+        self.BarrierNet = BarrierNetwork(num_inputs, n_act, hidden) if task.has_signal else None
         QNetwork(num_inputs, n_act, hidden)          # the reference builds target nets here
         LyaNetwork(self.center_pos_num, hidden)      # (then hard-copies): consume the same RNG
+        if task.has_signal:
+            BarrierNetwork(num_inputs, n_act, hidden)
         self.cost_limit = 0.0
         self.augmented_ratio = 1.0005
         if args.seed >= 0:
@@ -141,7 +151,7 @@ class SAC_CBF_CLF(object):
         self.log_alpha = nn.Parameter(torch.zeros(1))
         self.backup_log_alpha = nn.Parameter(torch.zeros(1))
         self.policy = GaussianPolicy(num_inputs, n_act, hidden, action_space)
-        self.backup_policy = GaussianPolicy(num_inputs, n_act, hidden, action_space)
+        self.backup_policy = GaussianPolicy(num_inputs, n_act, hidden, action_space) if task.n_pol == 2 else None
 
         self.num_cbfs = task.num_cbfs
         self.l_p = l_p
@@ -161,23 +171,32 @@ class SAC_CBF_CLF(object):
         self.ar_n = Arena(dev, self.n_fit_slabs * 2)                     # NODE (lr 1e-3)
         self.h_q1, self.h_q2 = self.critic.attach(self.ar_c)
         (self.h_l,) = self.lyapunovNet.attach(self.ar_c)
+        self.h_extra = list(self.BarrierNet.attach(self.ar_c)) if task.has_signal else []
         (self.h_p,) = self.policy.attach(self.ar_a)
-        (self.h_b,) = self.backup_policy.attach(self.ar_a)
+        self.h_pols = [self.h_p]
+        if task.n_pol == 2:
+            (self.h_b,) = self.backup_policy.attach(self.ar_a)
+            self.h_pols.append(self.h_b)
         self.ar_a.add_group([self.log_alpha])
-        self.ar_a.add_group([self.backup_log_alpha])
+        if task.n_pol == 2:
+            self.ar_a.add_group([self.backup_log_alpha])
         self.h_node = list(self.neural_ode_model.attach(self.ar_n))
         for ar in (self.ar_c, self.ar_a, self.ar_n):
             ar.finalize()
         self.ar_c.hard_update_target()
         self.policy.to(dev)
-        self.backup_policy.to(dev)
-        for h in [self.h_q1, self.h_q2, self.h_l, self.h_p, self.h_b] + self.h_node:
+        if self.backup_policy is not None:
+            self.backup_policy.to(dev)
+        self.h_crit = [self.h_q1, self.h_q2, self.h_l] + self.h_extra       # one Adam group, lr 4e-4
+        for h in self.h_crit + self.h_pols + self.h_node:
             h.bind()
         self.la_off = self.ar_a.offset_of[id(self.log_alpha)]
-        self.la_stride = self.ar_a.offset_of[id(self.backup_log_alpha)] - self.la_off
+        self.la_stride = (self.ar_a.offset_of[id(self.backup_log_alpha)] - self.la_off) if task.n_pol == 2 else 0
         # target networks as modules over the Polyak buffer (state_dict / inspection)
         self.critic_target = _TargetView(self.critic, self.ar_c)
         self.lyapunovNet_target = _TargetView(self.lyapunovNet, self.ar_c)
+        if task.has_signal:
+            self.BarrierNet_target = _TargetView(self.BarrierNet, self.ar_c)
         self.repack_all()
 
         # --- device scalars: alpha, lambdas, augmented term --------------------
@@ -255,8 +274,8 @@ class SAC_CBF_CLF(object):
 
     # ------------------------------------------------------------------ utils
     def repack_all(self):
-        pack([self.h_q1, self.h_q2, self.h_l, self.h_p, self.h_b] + self.h_node)
-        pack([self.h_q1, self.h_q2, self.h_l], target=True)
+        pack(self.h_crit + self.h_pols + self.h_node)
+        pack(self.h_crit, target=True)
 
     def set_noise(self, eps_list):
         """Pre-drawn N(0,1) draws for the next update, reference order:
@@ -310,6 +329,8 @@ class SAC_CBF_CLF(object):
         return self._select(self.policy, state, evaluate, warmup)
 
     def select_action_backup(self, state, evaluate=False, warmup=False):
+        if self.backup_policy is None:
+            raise AttributeError("this variant has no backup controller")
         return self._select(self.backup_policy, state, evaluate, warmup)
 
     # ------------------------------------------------------------------ update
@@ -327,9 +348,15 @@ class SAC_CBF_CLF(object):
     def _rows_from_host(self, batch):
         """Pack the 10-tuple of ``ReplayMemory.sample`` into minibatch-layout rows (one H2D copy)."""
         lay = self.lay
+        batch = tuple(batch)
+        sig = None
+        if lay.sig is not None:        # 11 fields: barrier_signal sits after the constraint
+            sig, batch = batch[4], batch[:4] + batch[5:]
         state, action, reward, constraint, lya_in, next_lya_in, nstate, mask = batch[:8]
         n = np.asarray(state).shape[0]
         host = np.zeros((n, lay.LD), dtype=np.float32)
+        if sig is not None:
+            host[:, lay.sig] = sig
         host[:, lay.obs:lay.obs + lay.obs_dim] = state
         host[:, lay.act:lay.act + lay.act_dim] = np.asarray(action).reshape(n, lay.act_dim)
         host[:, lay.rew], host[:, lay.con] = reward, constraint
@@ -353,7 +380,8 @@ class SAC_CBF_CLF(object):
                 n = np.asarray(o).shape[0]
                 t = np.asarray(node_batch[3]).reshape(n) if len(node_batch) == 4 else np.zeros(n)
                 zl = np.zeros((n, self.lay.lya_dim))
-                node_batch = (o, a_, np.zeros(n), np.zeros(n), zl, zl, no, np.ones(n), t, t)
+                node_batch = (o, a_, np.zeros(n), np.zeros(n)) + ((np.zeros(n),) if self.lay.sig is not None else ()) \
+                    + (zl, zl, no, np.ones(n), t, t)
             self.fit_node_rows(self._rows_from_host(node_batch).to(self.device))
         return self.update_on_device(ws, updates)
 
@@ -436,16 +464,24 @@ class SAC_CBF_CLF(object):
                 io[i].x1, io[i].x1_dim, io[i].x1_ld = p1, d1, ld1
         P = types.SimpleNamespace()
         P.p_obs, P.p_rew, P.p_con, P.p_mask, P.LD = p_obs, col(lay.rew), col(lay.con), col(lay.mask), LD
-        q1, q2, l, pi, pb = self.h_q1, self.h_q2, self.h_l, self.h_p, self.h_b
+        q1, q2, l, pi = self.h_q1, self.h_q2, self.h_l, self.h_p
+        NP, NX = self.task.n_pol, len(self.h_extra)
         # A: pi(s')
         P.n_pol, P.io_pol_next = mlp_array([pi.desc]), io_array(1)
         x(P.io_pol_next, 0, p_nobs, Do, LD)
         P.io_pol_next[0].y, P.io_pol_next[0].y_ld = ws.heads_n.data_ptr(), 2 * Da
         # A: targets + critic / Lyapunov forward (6 nets)
-        P.n_six = mlp_array([q1.desc_target, q2.desc_target, l.desc_target, q1.desc, q2.desc, l.desc])
-        io = P.io_six = io_array(6)
-        for i in range(6):
+        descs = [q1.desc_target, q2.desc_target, l.desc_target, q1.desc, q2.desc, l.desc]
+        for h in self.h_extra:
+            descs += [h.desc_target, h.desc]
+        P.n_six, P.n_six_count = mlp_array(descs), len(descs)
+        io = P.io_six = io_array(len(descs))
+        for i in range(len(descs)):
             io[i].y, io[i].y_ld = ws.q6[i].data_ptr(), 1
+        for k in range(NX):            # extra critic-type nets on (s', a') [target] and (s, a)
+            x(io, 6 + 2 * k, p_nobs, Do, LD, ws.na.data_ptr(), Da, Da)
+            x(io, 7 + 2 * k, p_obs, Do, LD, p_act, Da, LD)
+            io[7 + 2 * k].acts = ws.acts_c[3 + k].data_ptr()
         for i in (0, 1):
             x(io, i, p_nobs, Do, LD, ws.na.data_ptr(), Da, Da)
         x(io, 2, p_ncen, Dl, LD)
@@ -455,35 +491,38 @@ class SAC_CBF_CLF(object):
         x(io, 5, p_cen, Dl, LD)
         io[5].acts = ws.acts_c[2].data_ptr()
         # B: critic / Lyapunov backward
-        P.n_crit = mlp_array([q1.desc, q2.desc, l.desc])
-        io = P.io_crit = io_array(3)
-        for i in range(3):
+        P.n_crit = mlp_array([h.desc for h in self.h_crit])
+        io = P.io_crit = io_array(3 + NX)
+        for i in range(3 + NX):
             io[i].dy, io[i].dy_ld = ws.dq3[i].data_ptr(), 1
             io[i].acts, io[i].dz = ws.acts_c[i].data_ptr(), ws.dz_c[i].data_ptr()
             io[i].grad = self.ar_c.grad.data_ptr()
-        for i in (0, 1):
+        for i in [0, 1] + list(range(3, 3 + NX)):
             x(io, i, p_obs, Do, LD, p_act, Da, LD)
         x(io, 2, p_cen, Dl, LD)
         # C: both actors (forward and backward share one descriptor)
-        P.n_act = mlp_array([pi.desc, pb.desc])
-        io = P.io_act = io_array(2)
-        for i in range(2):
+        P.n_act = mlp_array([h.desc for h in self.h_pols])
+        io = P.io_act = io_array(NP)
+        for i in range(NP):
             x(io, i, p_obs, Do, LD)
             io[i].y, io[i].y_ld = ws.heads2[i * B:].data_ptr(), 2 * Da
             io[i].acts, io[i].dz = ws.acts_p[i].data_ptr(), ws.dz_p[i].data_ptr()
             io[i].dy, io[i].dy_ld = ws.dheads2[i * B:].data_ptr(), 2 * Da
             io[i].grad = self.ar_a.grad.data_ptr()
         # C: Q(s, pi) for primary / backup + V(current Lyapunov input)
-        P.n_q5 = mlp_array([q1.desc, q2.desc, q1.desc, q2.desc, l.desc])
-        io = P.io_q5 = io_array(5)
-        for i in range(4):
+        extra = self.task.extra_value_nets()
+        P.n_q5 = mlp_array([q1.desc, q2.desc] * NP + [l.desc] + [h.desc for h in extra])
+        P.n_q5_count = 2 * NP + 1 + len(extra)
+        io = P.io_q5 = io_array(P.n_q5_count)
+        for i in range(2 * NP):
             half = i // 2                                      # 0 primary, 1 backup
             x(io, i, p_obs, Do, LD, ws.pi2[half * B:].data_ptr(), Da, Da)
             io[i].y, io[i].y_ld = ws.qpi[i % 2, half * B:].data_ptr(), 1
             io[i].acts = ws.acts_q[i].data_ptr()
             io[i].dy, io[i].dy_ld = ws.dq_pi[i % 2, half * B:].data_ptr(), 1
             io[i].dx, io[i].dx_ld = ws.dxq[i % 2, half * B:].data_ptr(), Do + Da
-        self.task.value_now_io(ws, io, 4)
+        self.task.value_now_io(ws, io, 2 * NP)
+        self.task.extra_value_io(ws, io, 2 * NP + 1)
         self.task.plan(ws, P)
         ws.plan = P
         return P
@@ -492,19 +531,20 @@ class SAC_CBF_CLF(object):
         """required_matrix, ratio, lambda / rho updates and loss coefficients from the constraint partial sums
         (all-reduced first under data parallelism: they enter the loss nonlinearly)."""
         s, call = stream_ptr(), _lib.call
-        ncol = 2 * n_cbf + 1
+        NP = self.task.n_pol
+        ncol = n_cbf + 1 + (n_cbf if NP == 2 else 0)
         p_part_c, n_part = ws.part_c.data_ptr(), ws.nblk
         ws.p_part_q, ws.n_part_q = ws.part_q.data_ptr(), ws.nblk
         if self.world > 1:
             xs = self._exchange_buf("sums", 64)
             call("nlbac_sum_partials", ws.part_c.data_ptr(), ws.nblk, ncol, 1.0, xs.data_ptr(), s)
-            for pp in range(2):
+            for pp in range(NP):
                 call("nlbac_sum_partials", ws.part_q[pp].data_ptr(), ws.nblk, 2, 1.0, xs.data_ptr() + 4 * (32 + 2 * pp), s)
             self.dp.all_reduce_(xs)
             p_part_c, n_part = xs.data_ptr(), 1
             ws.p_part_q, ws.n_part_q = xs.data_ptr() + 4 * 32, 1
-        call("nlbac_auglag", p_part_c, n_part, n_cbf, 1, float(self.batch_size), lam_upd, self.task.ratio_mode, 1,
-             0.01, self.task.lam_hi, self.sc.data_ptr(), s)
+        call("nlbac_auglag", p_part_c, n_part, n_cbf, 1, float(self.batch_size), lam_upd, self.task.ratio_mode,
+             self.task.backup_mode, 0.01, self.task.lam_hi, self.sc.data_ptr(), s)
 
     def update_on_device(self, ws, updates, sync=True):
         """Minibatch already in ``ws.mb``; returns the reference's 6 floats."""
@@ -560,32 +600,38 @@ class SAC_CBF_CLF(object):
         call("nlbac_mlp_fwd", P.n_pol, P.io_pol_next, 1, B, s)
         call("nlbac_gauss_sample_fwd", ws.heads_n.data_ptr(), 2 * A, ws.eps[0].data_ptr(), p_scale, p_bias, A, B,
              ws.na.data_ptr(), A, ws.nlogp.data_ptr(), s)
-        call("nlbac_mlp_fwd", P.n_six, P.io_six, 6, B, s)
+        call("nlbac_mlp_fwd", P.n_six, P.io_six, P.n_six_count, B, s)
         q = ws.q6
         call("nlbac_td_targets", q[0].data_ptr(), q[1].data_ptr(), q[2].data_ptr(), ws.nlogp.data_ptr(),
              P.p_rew, P.p_con, P.p_mask, LD, q[3].data_ptr(), q[4].data_ptr(), q[5].data_ptr(),
              sc + 4 * SC.SC_ALPHA, self.gamma, B, G, ws.dq3[0].data_ptr(), ws.dq3[1].data_ptr(), ws.dq3[2].data_ptr(),
              ws.next_q.data_ptr(), ws.next_l.data_ptr(), ws.part_td.data_ptr(), s)
         call("nlbac_sum_partials", ws.part_td.data_ptr(), ws.nblk, 3, 1.0 / G, sc + 4 * SC.SC_QF1, s)
+        for k in range(len(self.h_extra)):      # barrier TD step (NU/sac_cbf_clf.py:224-233)
+            call("nlbac_td_value", q[6 + 2 * k].data_ptr(), ws.mb.data_ptr() + 4 * self.lay.sig, LD, P.p_mask, LD,
+                 q[7 + 2 * k].data_ptr(), self.gamma, B, G, ws.dq3[3 + k].data_ptr(), None, ws.part_tdx[k].data_ptr(), s)
+            call("nlbac_sum_partials", ws.part_tdx[k].data_ptr(), ws.nblk, 1, 1.0 / G, sc + 4 * SC.SC_XLOSS, s)
 
         # ---- B. critic / Lyapunov backward + Adam (+ Polyak targets) ---------------
-        call("nlbac_mlp_bwd_data", P.n_crit, P.io_crit, 3, B, s)
+        n_crit = len(self.h_crit)
+        call("nlbac_mlp_bwd_data", P.n_crit, P.io_crit, n_crit, B, s)
         a = self.ar_c
-        bwd_weights(P.n_crit, P.io_crit, 3, B, a.n_slabs, a.n, self.device)
+        bwd_weights(P.n_crit, P.io_crit, n_crit, B, a.n_slabs, a.n, self.device)
         self._adam(a, self.critic_lyapunov_lr, a.n_slabs, extra=self.sc[SC.SC_QF1:SC.SC_QF1 + 3],
                    target=a.target.data_ptr(), tau=self.tau if soft else -1.0)
-        pack([self.h_q1, self.h_q2, self.h_l])
+        pack(self.h_crit)
         if soft:
-            pack([self.h_q1, self.h_q2, self.h_l], target=True)
+            pack(self.h_crit, target=True)
 
         # ---- C. actors: sample, Q(s, pi), then the rollout of the learned dynamics -----
-        call("nlbac_mlp_fwd", P.n_act, P.io_act, 2, B, s)
-        eps2 = ws.eps[1:3]                                     # (2,B,A) == (2B,A)
-        call("nlbac_gauss_sample_fwd", ws.heads2.data_ptr(), 2 * A, eps2.data_ptr(), p_scale, p_bias, A, 2 * B,
+        NP = self.task.n_pol
+        call("nlbac_mlp_fwd", P.n_act, P.io_act, NP, B, s)
+        eps2 = ws.eps[1:1 + NP]                                # (NP,B,A) == (NP*B,A)
+        call("nlbac_gauss_sample_fwd", ws.heads2.data_ptr(), 2 * A, eps2.data_ptr(), p_scale, p_bias, A, NP * B,
              ws.pi2.data_ptr(), A, ws.logp2.data_ptr(), s)
-        call("nlbac_mlp_fwd", P.n_q5, P.io_q5, 5, B, s)
+        call("nlbac_mlp_fwd", P.n_q5, P.io_q5, P.n_q5_count, B, s)
         call("nlbac_actor_q_terms", ws.qpi[0].data_ptr(), ws.qpi[1].data_ptr(), ws.logp2.data_ptr(),
-             sc + 4 * SC.SC_ALPHA, B, G, 2, ws.dq_pi[0].data_ptr(), ws.dq_pi[1].data_ptr(), ws.part_q.data_ptr(), s)
+             sc + 4 * SC.SC_ALPHA, B, G, NP, ws.dq_pi[0].data_ptr(), ws.dq_pi[1].data_ptr(), ws.part_q.data_ptr(), s)
         self.task.rollout_begin(ws, P)
 
     def _upd_part2(self, ws, lam_upd, assume_single):
@@ -597,17 +643,18 @@ class SAC_CBF_CLF(object):
         sc = self.sc.data_ptr()
         call = _lib.call
         p_scale = self.policy.action_scale.data_ptr()
-        eps2 = ws.eps[1:3]
+        NP = self.task.n_pol
+        eps2 = ws.eps[1:1 + NP]
         du2, du_ld = self.task.loss_and_backward(ws, P, lam_upd, assume_single)
 
-        call("nlbac_mlp_bwd_data", P.n_q5, P.io_q5, 4, B, s)   # the four Q(s, pi) nets: dx only
+        call("nlbac_mlp_bwd_data", P.n_q5, P.io_q5, 2 * NP, B, s)   # the Q(s, pi) nets: dx only
         D = Do + A
         call("nlbac_gauss_sample_bwd", ws.heads2.data_ptr(), 2 * A, eps2.data_ptr(), p_scale, A,
-             2 * B, B, ws.dxq[0].data_ptr() + 4 * Do, D, ws.dxq[1].data_ptr() + 4 * Do, D, du2.data_ptr(), du_ld,
+             NP * B, B, ws.dxq[0].data_ptr() + 4 * Do, D, ws.dxq[1].data_ptr() + 4 * Do, D, du2.data_ptr(), du_ld,
              sc + 4 * SC.SC_ALPHA, 1.0 / G, ws.dheads2.data_ptr(), 2 * A, s)
         a = self.ar_a
-        call("nlbac_mlp_bwd_data", P.n_act, P.io_act, 2, B, s)
-        bwd_weights(P.n_act, P.io_act, 2, B, a.n_slabs, a.n, self.device)
+        call("nlbac_mlp_bwd_data", P.n_act, P.io_act, NP, B, s)
+        bwd_weights(P.n_act, P.io_act, NP, B, a.n_slabs, a.n, self.device)
         la = a.theta.data_ptr() + 4 * self.la_off
         tune = self.automatic_entropy_tuning
         p_part_q, n_part = ws.p_part_q, ws.n_part_q
@@ -615,16 +662,16 @@ class SAC_CBF_CLF(object):
         def alpha_grads(p_grad):
             # policy_loss_1 / alpha losses from the (global) partial sums; d log_alpha goes straight into
             # the gradient the Adam step reads (it is already a global mean: it must not be all-reduced)
-            call("nlbac_actor_scalars", p_part_q, n_part, G, 2, self.target_entropy, la, self.la_stride,
+            call("nlbac_actor_scalars", p_part_q, n_part, G, NP, self.target_entropy, la, self.la_stride,
                  p_grad + 4 * self.la_off, sc, s)
             if not tune:
                 z = torch.zeros(1, device=self.device)
-                for off in (self.la_off, self.la_off + self.la_stride):
+                for off in [self.la_off + k * self.la_stride for k in range(NP)]:
                     call("nlbac_axpby", 0.0, z.data_ptr(), 0.0, None, 1, p_grad + 4 * off, s)
         self._adam(a, self.lr, a.n_slabs, before_step=alpha_grads)
-        pack([self.h_p, self.h_b])
+        pack(self.h_pols)
         if self.automatic_entropy_tuning:
-            call("nlbac_alpha_refresh", la, self.la_stride, 2, sc, s)
+            call("nlbac_alpha_refresh", la, self.la_stride, NP, sc, s)
 
     # ------------------------------------------------------------ checkpoints
     def save_model(self, output):
@@ -632,6 +679,8 @@ class SAC_CBF_CLF(object):
         torch.save(self.policy.state_dict(), '{}/actor.pkl'.format(output))
         torch.save(self.critic.state_dict(), '{}/critic.pkl'.format(output))
         torch.save(self.lyapunovNet.state_dict(), '{}/lyapunov.pkl'.format(output))
+        if self.BarrierNet is not None:
+            torch.save(self.BarrierNet.state_dict(), '{}/barrier.pkl'.format(output))
         torch.save(self.neural_ode_model.state_dict(), '{}/node_model.pkl'.format(output))
 
     def load_weights(self, output):
@@ -642,15 +691,19 @@ class SAC_CBF_CLF(object):
         self.policy.load_state_dict(torch.load('{}/actor.pkl'.format(output), map_location=dev, weights_only=True))
         self.critic.load_state_dict(torch.load('{}/critic.pkl'.format(output), map_location=dev, weights_only=True))
         self.lyapunovNet.load_state_dict(torch.load('{}/lyapunov.pkl'.format(output), map_location=dev, weights_only=True))
+        if self.BarrierNet is not None:
+            self.BarrierNet.load_state_dict(torch.load('{}/barrier.pkl'.format(output), map_location=dev, weights_only=True))
         self.repack_all()
 
-    def load_model(self, actor_path, critic_path, lyapunov_path):
+    def load_model(self, actor_path, critic_path, lyapunov_path, barrier_path=None):
         if actor_path is not None:
             self.policy.load_state_dict(torch.load(actor_path, weights_only=True))
         if critic_path is not None:
             self.critic.load_state_dict(torch.load(critic_path, weights_only=True))
         if lyapunov_path is not None:
             self.lyapunovNet.load_state_dict(torch.load(lyapunov_path, weights_only=True))
+        if barrier_path is not None and self.BarrierNet is not None:
+            self.BarrierNet.load_state_dict(torch.load(barrier_path, weights_only=True))
         self.repack_all()
 
 

@@ -27,12 +27,23 @@ class _Task:
     lam_hi = 400.0
     ratio_mode = 1            # 1 plain ratio (U), 2 clamped at 0.002 (C)
     graph_ok = False          # whole update replayable as hipGraphs
+    n_pol = 2                 # controllers trained per update (primary + backup); 1 in the learned-barrier copies
+    backup_mode = 1           # nlbac_auglag: 0 no backup, 1 backup shares rho, 2 own rho
+    has_signal = False        # replay rows carry a barrier signal (learned-barrier copies)
+    n_extra_critics = 0       # critic-type nets trained beside Q1, Q2, L (BarrierNet)
 
     def __init__(self, agent, env, args):
         self.agent, self.env = agent, env
 
     def z(self, *shape):
         return torch.zeros(*shape, dtype=torch.float32, device=self.agent.device)
+
+    # value-only nets riding in the Q(s, pi) launch besides V(current Lyapunov input)
+    def extra_value_nets(self):
+        return []
+
+    def extra_value_io(self, ws, io, i):
+        pass
 
 
 # =====================================================================================
@@ -138,6 +149,99 @@ class UnicycleTask(_Task):
         _lib.call("nlbac_unicycle_state", p_obs, obs_ld, N, self.l_p, w["st"].data_ptr(), None, s)
         _lib.call("nlbac_unicycle_state", p_nobs, nobs_ld, N, self.l_p, w["nst"].data_ptr(), None, s)
         self.fit_solver.forward_begin(w["st"], w["u"], 1, N, a.solver, self.env.dt, a.atol, a.rtol)
+
+
+# =====================================================================================
+class UnicycleBarrierTask(UnicycleTask):
+    """Learned-barrier-certificate Unicycle (NU/sac_cbf_clf/sac_cbf_clf.py:339-477): one controller; the CBF is a
+    network B(obs, a) trained with the critics; its term needs the predicted next observation get_obs(x')
+    (differentiable) and a re-sampled, detached next action; no ratio in the loss."""
+    name = "UnicycleBarrier"
+    n_pol, backup_mode, has_signal, n_extra_critics = 1, 0, True, 1
+    ratio_mode = 0
+    n_eps = 3                 # next-obs sample, obs sample, sample on the predicted next observation
+    graph_ok = True
+    GOAL = (2.5, 2.5)         # NU/sac_cbf_clf/dynamics.py:104-105
+
+    def __init__(self, agent, env, args):
+        super().__init__(agent, env, args)
+        self.num_cbfs = 1
+
+    def alloc(self, ws):
+        B, z, H = ws.B, self.z, self.agent.hidden
+        ws.y0 = z(B, 3)
+        ws.V, ws.Vn, ws.dVn = z(B), z(B), z(B)
+        ws.acts_vn = z(2, B, H)
+        ws.ps_next, ws.dps_v = z(B, 2), z(B, 2)
+        ws.Bv, ws.Bn, ws.dBn = z(B), z(B), z(B)
+        ws.acts_bn = z(2, B, H)
+        ws.obs_pred, ws.heads_nx, ws.pi_next, ws.logp_nx = z(B, 7), z(B, 4), z(B, 2), z(B)
+        ws.dxb = z(B, 9)                               # d B(obs', a') / d [obs', a']
+        ws.matr = z(B, 2)
+        ws.part_c = z(ws.nblk, 2)
+        ws.dx_next = z(B, 3)
+
+    def extra_value_nets(self):
+        return [self.agent.h_extra[0]]
+
+    def extra_value_io(self, ws, io, i):               # B(obs, pi), value only (detached in the reference)
+        lay = self.agent.lay
+        io[i].x0, io[i].x0_dim, io[i].x0_ld = ws.mb.data_ptr() + 4 * lay.obs, 7, lay.LD
+        io[i].x1, io[i].x1_dim, io[i].x1_ld = ws.pi2.data_ptr(), 2, 2
+        io[i].y, io[i].y_ld = ws.Bv.data_ptr(), 1
+
+    def plan(self, ws, P):
+        a = self.agent
+        P.n_l = mlp_array([a.h_l.desc])
+        io = P.io_vn = io_array(1)                     # V(p(x')) forward + data backward
+        io[0].x0, io[0].x0_dim, io[0].x0_ld = ws.ps_next.data_ptr(), 2, 2
+        io[0].y, io[0].y_ld = ws.Vn.data_ptr(), 1
+        io[0].acts = ws.acts_vn.data_ptr()
+        io[0].dy, io[0].dy_ld = ws.dVn.data_ptr(), 1
+        io[0].dx, io[0].dx_ld = ws.dps_v.data_ptr(), 2
+        P.n_pi = mlp_array([a.h_p.desc])
+        io = P.io_nx = io_array(1)                     # policy on the predicted next observation
+        io[0].x0, io[0].x0_dim, io[0].x0_ld = ws.obs_pred.data_ptr(), 7, 7
+        io[0].y, io[0].y_ld = ws.heads_nx.data_ptr(), 4
+        P.n_bar = mlp_array([a.h_extra[0].desc])
+        io = P.io_bn = io_array(1)                     # B(obs', a') forward + data backward
+        io[0].x0, io[0].x0_dim, io[0].x0_ld = ws.obs_pred.data_ptr(), 7, 7
+        io[0].x1, io[0].x1_dim, io[0].x1_ld = ws.pi_next.data_ptr(), 2, 2
+        io[0].y, io[0].y_ld = ws.Bn.data_ptr(), 1
+        io[0].acts = ws.acts_bn.data_ptr()
+        io[0].dy, io[0].dy_ld = ws.dBn.data_ptr(), 1
+        io[0].dx, io[0].dx_ld = ws.dxb.data_ptr(), 9
+
+    def rollout_begin(self, ws, P):
+        a, s = self.agent, stream_ptr()
+        _lib.call("nlbac_unicycle_state", ws.mb.data_ptr(), a.lay.LD, ws.B, self.l_p, ws.y0.data_ptr(), None, s)
+        self.solver.forward_begin(ws.y0, ws.pi2, 1, ws.B, a.solver, float(self.env.dt), a.atol, a.rtol)
+
+    def loss_and_backward(self, ws, P, lam_upd, assume_single):
+        a, s, call = self.agent, stream_ptr(), _lib.call
+        B, sc, dt = ws.B, a.sc.data_ptr(), float(self.env.dt)
+        pol = a.policy
+        gx, gy = self.GOAL
+        x_next = self.solver.forward_finish(assume_single_step=assume_single)
+        call("nlbac_unicycle_lookahead", x_next.data_ptr(), B, self.l_p, ws.ps_next.data_ptr(), s)
+        call("nlbac_mlp_fwd", P.n_l, P.io_vn, 1, B, s)
+        call("nlbac_unicycle_obs_fwd", x_next.data_ptr(), B, gx, gy, ws.obs_pred.data_ptr(), 7, s)
+        call("nlbac_mlp_fwd", P.n_pi, P.io_nx, 1, B, s)
+        call("nlbac_gauss_sample_fwd", ws.heads_nx.data_ptr(), 4, ws.eps[2].data_ptr(), pol.action_scale.data_ptr(),
+             pol.action_bias.data_ptr(), 2, B, ws.pi_next.data_ptr(), 2, ws.logp_nx.data_ptr(), s)
+        call("nlbac_mlp_fwd", P.n_bar, P.io_bn, 1, B, s)
+        call("nlbac_barrier_constraints_fwd", ws.Bv.data_ptr(), ws.Bn.data_ptr(), ws.V.data_ptr(), ws.Vn.data_ptr(),
+             dt, float(a.gamma_b), self.gamma_l, B, ws.matr.data_ptr(), ws.part_c.data_ptr(), s)
+        a.auglag(ws, 1, lam_upd)
+        call("nlbac_barrier_constraints_bwd", ws.matr.data_ptr(), dt, float(a.batch_size), B, sc, ws.dBn.data_ptr(),
+             ws.dVn.data_ptr(), s)
+        call("nlbac_mlp_bwd_data", P.n_l, P.io_vn, 1, B, s)          # dV' -> d p(x')
+        call("nlbac_mlp_bwd_data", P.n_bar, P.io_bn, 1, B, s)        # dB' -> d [obs', a'] (a' is detached)
+        call("nlbac_unicycle_lookahead_bwd", x_next.data_ptr(), ws.dps_v.data_ptr(), None, B, self.l_p,
+             ws.dx_next.data_ptr(), s)
+        call("nlbac_unicycle_obs_bwd", x_next.data_ptr(), ws.dxb.data_ptr(), 9, B, gx, gy, ws.dx_next.data_ptr(), 1, s)
+        du, _ = self.solver.backward(ws.dx_next, need_du=True)
+        return du, self.act_dim
 
 
 # =====================================================================================
@@ -262,4 +366,4 @@ class CarsTask(_Task):
         self.fit_solver.forward_begin(w["st"], w["u"], 1, N, a.solver, self.env.dt, a.atol, a.rtol)
 
 
-TASKS = {"Unicycle": UnicycleTask, "SimulatedCars": CarsTask}
+TASKS = {"Unicycle": UnicycleTask, "SimulatedCars": CarsTask, "UnicycleBarrier": UnicycleBarrierTask}

@@ -66,7 +66,7 @@ def run_cuda(dp, out, solver, env_name="Unicycle"):
         lo, hi = dp.shard(B)
         nlo, nhi = dp.shard(node[0].shape[0])
         agent.set_noise([e[lo:hi] for e in eps])
-        host = tuple(batch[f][lo:hi].numpy() for f in synth.FIELDS)
+        host = tuple(batch[f][lo:hi].numpy() for f in synth.fields(env_name))
         node_np = tuple(t[nlo:nhi].numpy() for t in node) if updates % 10 == 0 else None
         ret = agent.update_from_host(host, updates, node_np)
         torch.cuda.synchronize()
