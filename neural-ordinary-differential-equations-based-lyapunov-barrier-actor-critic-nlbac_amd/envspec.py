@@ -82,6 +82,34 @@ class SimulatedCarsSpec:
         return [s]
 
 
+class PvtolSpec:
+    """Constants of ``PvtolEnv`` (P/envs/pvtol_env.py:16-62): planar VTOL, state [x, y, theta, vx, vy, thrust] plus
+    the x-position of a safety operator that follows the vehicle; obs (11) = [x, y, cos, sin, vx, vy, thrust,
+    operator x, compass(2), exp(-dist to goal)]."""
+
+    dynamics_mode = "Pvtol"
+    n_s, n_u, obs_dim, lya_in = 6, 2, 11, 11
+
+    def __init__(self, seed=0):
+        lo, hi = np.array([-3.5, -15.0]), np.array([3.5, 15.0])
+        self.action_space = Box(lo, hi)
+        self.safe_action_space = Box(lo, hi)
+        self.observation_space = Box(-1e10, 1e10, shape=(11,))
+        self.dt = 0.02
+        self.max_episode_steps = 2000
+        self.goal_pos = np.array([4.5, 4.5])
+        self.safety_operator_follow = 0.7
+        self.operator_dist = 1.0
+        self.y_min, self.y_max = -100.0, 100.0
+        self.hazard_locations = np.array([[-2.5, -2.5], [-2.5, 2.5], [0.0, -3.5], [0.0, 3.5], [-4.5, 0.0]])
+        self.hazards_radius = 0.25
+        self.seed(seed)
+
+    def seed(self, s=None):
+        self.action_space.seed(s)
+        return [s]
+
+
 def make_env(name, seed=0):
     """``UnicycleBarrier`` is the learned-barrier-certificate copy (``neural_barrier_certificate/``): the same
     Unicycle constants (its ``dynamics_mode`` is still ``'Unicycle'``); the agent class differs, not the env."""
@@ -89,4 +117,6 @@ def make_env(name, seed=0):
         return UnicycleSpec(seed)
     if name == "SimulatedCars":
         return SimulatedCarsSpec(seed)
+    if name == "Pvtol":
+        return PvtolSpec(seed)
     raise Exception("Dynamics mode not supported.")

@@ -119,6 +119,64 @@ def cars_transitions(n, seed=1, env=None):
                 mask=np.ones(n), t=t, next_t=t + dt)
 
 
+def _pvtol_obs(state, goal):
+    """P/envs/pvtol_env.py:361-406 (compass = (goal - xy) @ R(theta), normalised with +0.001)."""
+    th = state[:, 2]
+    rel = goal[None, :] - state[:, :2]
+    dist = np.linalg.norm(rel, axis=1)
+    c, s = np.cos(th), np.sin(th)
+    v0 = rel[:, 0] * c + rel[:, 1] * s
+    v1 = -rel[:, 0] * s + rel[:, 1] * c
+    n = np.sqrt(v0 * v0 + v1 * v1) + 0.001
+    return np.stack([state[:, 0], state[:, 1], c, s, state[:, 3], state[:, 4], state[:, 5], state[:, 6],
+                     v0 / n, v1 / n, np.exp(-dist)], axis=1)
+
+
+def pvtol_transitions(n, seed=1, env=None):
+    """Synthetic Pvtol transitions: random states around the flight corridor, one true env Euler step
+    (P/envs/pvtol_env.py:85-160); the Lyapunov inputs are the observations before / after the step, as
+    ``step`` returns them (``:82``)."""
+    from .envspec import PvtolSpec
+    env = env or PvtolSpec()
+    rs = np.random.RandomState(seed)
+    dt, goal = env.dt, env.goal_pos
+    st = np.zeros((n, 7))
+    st[:, 0], st[:, 1] = rs.uniform(-5.5, 5.5, n), rs.uniform(-5.5, 5.5, n)
+    # so that every CBF family is active on part of a minibatch: a quarter of the rows sit close to a hazard,
+    # a few far out in y (the y_max / y_min barriers act beyond |y| = 90), the operator offset straddles its limit
+    kind = rs.uniform(0, 1, n)
+    hz = np.asarray(env.hazard_locations)[rs.randint(0, len(env.hazard_locations), n)]
+    near = kind < 0.25
+    st[near, :2] = (hz + rs.uniform(-0.45, 0.45, (n, 2)))[near]
+    far = kind > 0.92
+    st[far, 1] = (np.sign(rs.uniform(-1, 1, n)) * rs.uniform(88.0, 95.0, n))[far]
+    st[:, 2] = rs.uniform(-0.8, 0.8, n)
+    st[:, 3], st[:, 4] = rs.normal(0, 1.0, n), rs.normal(0, 1.0, n)
+    st[:, 5] = rs.uniform(0.3, 1.8, n)
+    st[:, 6] = st[:, 0] + rs.uniform(-1.3, 1.3, n)
+    # the relative-degree-3 operator barrier is 0.001*(x - op) + 0.46 after three follow steps: it only bites for
+    # absurd offsets, which a few rows carry so that its gradient path is exercised
+    lag = (kind > 0.84) & (kind <= 0.92)
+    st[lag, 6] = (st[:, 0] + np.sign(rs.uniform(-1, 1, n)) * rs.uniform(500.0, 900.0, n))[lag]
+    lo, hi = env.action_space.low.astype(np.float64), env.action_space.high.astype(np.float64)
+    action = rs.uniform(lo, hi, size=(n, 2))
+    obs = _pvtol_obs(st, goal)
+    f = np.zeros((n, 6))
+    f[:, 0], f[:, 1] = st[:, 3], st[:, 4]
+    f[:, 3] = -np.sin(st[:, 2]) * st[:, 5]
+    f[:, 4] = np.cos(st[:, 2]) * st[:, 5] - 1.0
+    nxt = st.copy()
+    nxt[:, :6] += dt * f
+    nxt[:, 2] += dt * action[:, 1]
+    nxt[:, 5] += dt * action[:, 0]
+    nxt[:, 6] = st[:, 6] + env.safety_operator_follow * (nxt[:, 0] - st[:, 6])
+    next_obs = _pvtol_obs(nxt, goal)
+    dist = np.linalg.norm(goal[None] - nxt[:, :2], axis=1)
+    t = rs.randint(0, 2000, n).astype(np.float64) * dt
+    return dict(obs=obs, action=action, reward=-1e-3 * dist, constraint=dist, center=obs.copy(),
+                next_center=next_obs.copy(), next_obs=next_obs, mask=np.ones(n), t=t, next_t=t + dt)
+
+
 # ---------------------------------------------------------------------------
 # network shapes (reference key names; U/sac_cbf_clf/model.py:37-133,177-206)
 # ---------------------------------------------------------------------------
@@ -202,13 +260,22 @@ def unicycle_barrier_agent_weights(hidden, seed=0):
     return W
 
 
+def pvtol_agent_weights(hidden, seed=0):
+    critic = synth_state_dict(qnet_shapes(11, 2, hidden), seed * 10 + 1)
+    lya = synth_state_dict(lya_shapes(11, hidden), seed * 10 + 2)
+    policy = synth_state_dict(policy_shapes(11, 2, hidden), seed * 10 + 3)
+    backup = synth_state_dict(policy_shapes(11, 2, hidden), seed * 10 + 4)
+    node = synth_state_dict(node_affine_shapes(6, 2), seed * 10 + 5, kind="default")
+    return dict(critic=critic, lyapunov=lya, policy=policy, backup_policy=backup, node=node)
+
+
 def agent_weights(env_name, hidden, seed=0):
-    return {"Unicycle": unicycle_agent_weights, "SimulatedCars": cars_agent_weights,
+    return {"Unicycle": unicycle_agent_weights, "SimulatedCars": cars_agent_weights, "Pvtol": pvtol_agent_weights,
             "UnicycleBarrier": unicycle_barrier_agent_weights}[env_name](hidden, seed)
 
 
 def transitions(env_name, n, seed=1, env=None):
-    return {"Unicycle": unicycle_transitions, "SimulatedCars": cars_transitions,
+    return {"Unicycle": unicycle_transitions, "SimulatedCars": cars_transitions, "Pvtol": pvtol_transitions,
             "UnicycleBarrier": unicycle_barrier_transitions}[env_name](n, seed, env)
 
 

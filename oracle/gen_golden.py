@@ -19,7 +19,7 @@ What has to be faked to import the reference here:
   * ``sac_cbf_clf.model.device`` is hard-coded ``cuda`` -> rebound to CPU.
   * ``env`` is a plain object (gym is absent): ``nlbac_amd.envspec``.
 
-Usage:  python oracle/gen_golden.py [--env Unicycle|SimulatedCars|UnicycleBarrier]   (one env per process: the
+Usage:  python oracle/gen_golden.py [--env Unicycle|SimulatedCars|UnicycleBarrier|Pvtol]   (one env per process: the
 reference's env copies all use the package name ``sac_cbf_clf``)
 """
 import os
@@ -41,6 +41,7 @@ from oracle import nlbac_oracle as O  # noqa: E402
 REFS = {
     "Unicycle": "/root/reference/NLBAC_Unicycle_RL_training/Unicycle_RL_training",
     "SimulatedCars": "/root/reference/NLBAC_SimulatedCarsFollowing_RL_training/Simulated_Car_Following_RL_training",
+    "Pvtol": "/root/reference/NLBAC_pvtol_RL_training/Pvtol_RL_training",
     "UnicycleBarrier": "/root/reference/neural_barrier_certificate/neural_barrier_certificate_NLBAC_Unicycle_RL_training/"
                        "Unicycle_RL_training",
 }
@@ -50,6 +51,8 @@ CFG = {
     "Unicycle": dict(prefix="unicycle", obs=7, act=2, gamma_b=50.0, n_eps=3, n_ode=1),
     "SimulatedCars": dict(prefix="cars", obs=10, act=1, gamma_b=0.5, n_eps=5, n_ode=2),
     "UnicycleBarrier": dict(prefix="nbc_unicycle", obs=7, act=2, gamma_b=5.0, n_eps=3, n_ode=1),
+    # Pvtol: backup controller every 20 updates -> call 20 exercises it without a lambda update
+    "Pvtol": dict(prefix="pvtol", obs=11, act=2, gamma_b=0.8, n_eps=7, n_ode=3, calls=(0, 1, 8, 20)),
 }
 
 
@@ -100,8 +103,9 @@ def summarize(prefix, vec, out, n_head=48):
     out[prefix + "_tail"] = vec[-n_head:].detach().numpy().copy()
 
 
-def run_case(S, env_name, solver, B, hidden=256, seed=0, node_B=512, calls=(0, 1, 8)):
+def run_case(S, env_name, solver, B, hidden=256, seed=0, node_B=512, calls=None):
     cfg = CFG[env_name]
+    calls = calls or cfg.get("calls", (0, 1, 8))
     env = make_env(env_name, seed)
     args = O.Args(batch_size=B, hidden_size=hidden, seed=seed)
     args.gamma_b = cfg["gamma_b"]
@@ -184,8 +188,9 @@ def run_case(S, env_name, solver, B, hidden=256, seed=0, node_B=512, calls=(0, 1
             eps_queue[:] = [torch.from_numpy(e) for e in eps]
             where_rec.clear(); node_out.clear(); rec.clear()
             torch.where = where
+            extra = (0,) if env_name == "Pvtol" else ()          # P: trailing i_episode argument
             ret = agent.update_parameters(FakeMemory(tr, idx, fields), B, updates, dyn,
-                                          FakeMemory(tr, nidx, fields), 10)
+                                          FakeMemory(tr, nidx, fields), 10, *extra)
             torch.where = orig_where
             p = "c%d_" % ci
             out[p + "updates"] = updates
@@ -197,22 +202,31 @@ def run_case(S, env_name, solver, B, hidden=256, seed=0, node_B=512, calls=(0, 1
             out[p + "augmented_term"] = float(agent.augmented_term)
             ns, k = env.n_s, cfg["n_ode"]
             out[p + "x_next"] = node_out[0][0][:, :ns].numpy()
-            if not barrier:
+            has_backup = len(where_rec) > 1
+            if has_backup:
                 bmatr, bfilt = where_rec[1]
                 out[p + "brequired"] = (bfilt.sum(0) / B).reshape(-1).numpy()
+                out[p + "bx_next"] = node_out[k][0][:, :ns].numpy()
+            if not barrier:
                 out[p + "backup_lambdas"] = np.array([float(x) for x in agent.backup_lambda_values])
                 out[p + "backup_alpha"] = float(agent.backup_alpha)
-                out[p + "bx_next"] = node_out[k][0][:, :ns].numpy()
+                if hasattr(agent, "backup_augmented_term"):
+                    out[p + "backup_augmented_term"] = float(agent.backup_augmented_term)
             if k == 2:
                 out[p + "x_next2"] = node_out[1][0][:, :ns].numpy()
                 out[p + "bx_next2"] = node_out[3][0][:, :ns].numpy()
+            if k == 3:
+                out[p + "x_next2"] = node_out[1][0][:, :ns].numpy()
+                out[p + "x_next3"] = node_out[2][0][:, :ns].numpy()
+                if has_backup:
+                    out[p + "bx_next3"] = node_out[5][0][:, :ns].numpy()
             if solver == "dopri5":
                 out[p + "ode_steps"] = np.array(node_out[0][1]["steps"], dtype=np.float64)
-                if not barrier:
+                if has_backup:
                     out[p + "bode_steps"] = np.array(node_out[k][1]["steps"], dtype=np.float64)
             if B <= 16:
                 out[p + "matr"] = matr.reshape(B, -1).numpy()
-                if not barrier:
+                if has_backup:
                     out[p + "bmatr"] = bmatr.reshape(B, -1).numpy()
             for name in opts:
                 if "g_" + name in rec:

@@ -11,7 +11,8 @@ produced by importing the reference's own modules in the build container
 rk4 / dopri5 follow torchdiffeq 0.2.3 *from recollection* (the package is
 not in the container) — PARITY UNPINNED for those two solvers.
 
-The learned-barrier-certificate Unicycle copy (NU, fixtures ``nbc_unicycle_*.npz``) is restated by
+Pvtol (P = NLBAC_pvtol_RL_training/Pvtol_RL_training, fixtures ``pvtol_*.npz``) is restated by
+``OraclePvtolAgent``.  The learned-barrier-certificate Unicycle copy (NU, fixtures ``nbc_unicycle_*.npz``) is restated by
 ``OracleUnicycleBarrierAgent``.
 
 SimulatedCars (C = NLBAC_SimulatedCarsFollowing_RL_training/Simulated_Car_Following_RL_training) is
@@ -273,6 +274,7 @@ class Args:
     policy = "Gaussian"
     seed = 0
     cuda = False
+    backup_update_interval = 20     # Pvtol only (P/main.py:291)
 
     def __init__(self, **kw):
         for k, v in kw.items():
@@ -282,6 +284,8 @@ class Args:
 class OracleAgentBase:
     """Common part of the restated ``SAC_CBF_CLF`` (explicit noise); env copies subclass it."""
     LAM_HI, RATIO_MIN, N_EPS = 400.0, None, 3
+    EPS_BACKUP = 2            # index of the backup controller's draw in ``eps``
+    OWN_BACKUP_RHO = False    # Pvtol keeps a separate backup_augmented_term
 
     def __init__(self, env, args, weights, solver="euler"):
         self.env, self.args, self.solver = env, args, solver
@@ -313,16 +317,25 @@ class OracleAgentBase:
         self.lambda_values = [0.0] * self.num_constraints
         self.backup_lambda_values = [0.0] * self.num_cbfs
         self.augmented_term, self.augmented_ratio = 1.0, 1.0005
+        self.backup_augmented_term = 1.0
         self.cost_limit = 0.0
         self._setup_task(env)
+
+    def _backup_due(self, updates):
+        return True
+
+    def _lya_train_inputs(self, batch):
+        return batch["center"], batch["next_center"]
 
     def _set_grads(self, params, grads):
         for p, g in zip(params, grads):
             p.grad = g
 
-    def _auglag(self, required, lambdas, updates, with_clf):
+    def _auglag(self, required, lambdas, updates, with_clf, backup=False):
         """sac_cbf_clf.py:506-528 (primary) / :623-638 (backup)."""
         out = {}
+        rho_attr = "backup_augmented_term" if (backup and self.OWN_BACKUP_RHO) else "augmented_term"
+        interval = self.args.Lagrangian_multiplier_update_interval * (self._backup_lam_mul() if backup else 1)
         ratio = 1.0
         if with_clf:
             other = torch.abs(torch.mean(required[:-1] - self.cost_limit))
@@ -331,12 +344,12 @@ class OracleAgentBase:
             if self.RATIO_MIN is not None and ratio < self.RATIO_MIN:
                 ratio = self.RATIO_MIN
         req_d = required.detach()
-        if updates % self.args.Lagrangian_multiplier_update_interval == 0:
+        if updates % interval == 0:
             for i in range(len(lambdas)):
-                new = torch.as_tensor(lambdas[i], dtype=torch.float32) + self.augmented_term * req_d[i]
+                new = torch.as_tensor(lambdas[i], dtype=torch.float32) + getattr(self, rho_attr) * req_d[i]
                 lambdas[i] = float(torch.clamp(new, 0.01, self.LAM_HI))
-        self.augmented_term = min(self.augmented_term * self.augmented_ratio, 200)
-        rho = self.augmented_term
+        setattr(self, rho_attr, min(getattr(self, rho_attr) * self.augmented_ratio, 200))
+        rho = getattr(self, rho_attr)
         n_cbf = len(required) - (1 if with_clf else 0)
         loss = 0.0
         for i in range(n_cbf):
@@ -348,6 +361,9 @@ class OracleAgentBase:
         out.update(ratio=ratio, loss=loss)
         return out
 
+    def _backup_lam_mul(self):
+        return 1
+
     # -- one update -----------------------------------------------------------
     def update(self, batch, eps, updates, node_batch=None):
         """``batch``: dict of float32 tensors (obs, action, reward, constraint,
@@ -358,8 +374,9 @@ class OracleAgentBase:
             R["node_loss"], R["g_node"] = self.train_step(*node_batch)
         obs, nobs, act = batch["obs"], batch["next_obs"], batch["action"]
         rew, con = batch["reward"].unsqueeze(1), batch["constraint"].unsqueeze(1)
-        cen, ncen, mask = batch["center"], batch["next_center"], batch["mask"].unsqueeze(1)
+        (cen, ncen), mask = self._lya_train_inputs(batch), batch["mask"].unsqueeze(1)
         dt = self.env.dt
+        do_backup = self._backup_due(updates)
 
         with torch.no_grad():
             na, nlogp, _ = policy_sample(self.policy, nobs, eps[0], self.scale, self.bias)
@@ -379,40 +396,43 @@ class OracleAgentBase:
 
         pi, log_pi, _ = policy_sample(self.policy, obs, eps[1], self.scale, self.bias)
         min_q_pi = torch.min(*qnet(self.critic, obs, pi))
-        bpi, blog_pi, _ = policy_sample(self.backup, obs, eps[2], self.scale, self.bias)
-        bmin_q = torch.min(*qnet(self.critic, obs, bpi))
         policy_loss_1 = ((self.alpha * log_pi) - min_q_pi).mean()
-        backup_loss_1 = ((self.backup_alpha * blog_pi) - bmin_q).mean()
+        if do_backup:
+            bpi, blog_pi, _ = policy_sample(self.backup, obs, eps[self.EPS_BACKUP], self.scale, self.bias)
+            bmin_q = torch.min(*qnet(self.critic, obs, bpi))
+            backup_loss_1 = ((self.backup_alpha * blog_pi) - bmin_q).mean()
 
         # primary: CLF + CBFs ; backup: CBFs only  (env-specific terms)
         matr, extra = self._primary_terms(batch, pi, eps)
         required = torch.where(matr > 0, matr, torch.zeros_like(matr)).sum(0) / self.batch_size
         al = self._auglag(required, self.lambda_values, updates, True)
         R.update(matr=matr.detach(), required=required.detach(), ratio=al["ratio"], **extra)
-        bmatr, bextra = self._backup_terms(batch, bpi, eps)
-        brequired = torch.where(bmatr > 0, bmatr, torch.zeros_like(bmatr)).sum(0) / self.batch_size
-        bal = self._auglag(brequired, self.backup_lambda_values, updates, False)
-        R.update(bmatr=bmatr.detach(), brequired=brequired.detach(), **bextra)
-
         policy_loss = policy_loss_1 + al["loss"]
-        backup_loss = backup_loss_1 + bal["loss"]
         gp = torch.autograd.grad(policy_loss, list(self.policy.values()))
-        gb = torch.autograd.grad(backup_loss, list(self.backup.values()))
         self._set_grads(self.policy.values(), gp)
         self.opt["policy"].step()
-        self._set_grads(self.backup.values(), gb)
-        self.opt["backup"].step()
-        R.update(g_policy=_flat(gp), g_backup=_flat(gb),
-                 policy_loss_2=float(al["loss"]), backup_policy_loss_2=float(bal["loss"]))
+        R.update(g_policy=_flat(gp), policy_loss_2=float(al["loss"]))
+        if do_backup:
+            bmatr, bextra = self._backup_terms(batch, bpi, eps)
+            brequired = torch.where(bmatr > 0, bmatr, torch.zeros_like(bmatr)).sum(0) / self.batch_size
+            bal = self._auglag(brequired, self.backup_lambda_values, updates, False, backup=True)
+            R.update(bmatr=bmatr.detach(), brequired=brequired.detach(), **bextra)
+            backup_loss = backup_loss_1 + bal["loss"]
+            gb = torch.autograd.grad(backup_loss, list(self.backup.values()))
+            self._set_grads(self.backup.values(), gb)
+            self.opt["backup"].step()
+            R.update(g_backup=_flat(gb), backup_policy_loss_2=float(bal["loss"]),
+                     backup_policy_loss_1=float(backup_loss_1))
 
         alpha_loss = -(self.log_alpha * (log_pi + self.target_entropy).detach()).mean()
         self.log_alpha.grad = torch.autograd.grad(alpha_loss, self.log_alpha)[0]
         self.opt["alpha"].step()
         self.alpha = float(self.log_alpha.exp())
-        balpha_loss = -(self.backup_log_alpha * (blog_pi + self.target_entropy).detach()).mean()
-        self.backup_log_alpha.grad = torch.autograd.grad(balpha_loss, self.backup_log_alpha)[0]
-        self.opt["backup_alpha"].step()
-        self.backup_alpha = float(self.backup_log_alpha.exp())
+        if do_backup:
+            balpha_loss = -(self.backup_log_alpha * (blog_pi + self.target_entropy).detach()).mean()
+            self.backup_log_alpha.grad = torch.autograd.grad(balpha_loss, self.backup_log_alpha)[0]
+            self.opt["backup_alpha"].step()
+            self.backup_alpha = float(self.backup_log_alpha.exp())
 
         if updates % self.args.target_update_interval == 0:
             with torch.no_grad():
@@ -422,7 +442,7 @@ class OracleAgentBase:
 
         R["ret"] = (float(qf1_loss), float(qf2_loss), float(lf_loss), float(policy_loss_1),
                     float(alpha_loss), float(self.alpha))
-        R.update(backup_policy_loss_1=float(backup_loss_1), backup_alpha=self.backup_alpha,
+        R.update(backup_alpha=self.backup_alpha,
                  lambdas=list(self.lambda_values), backup_lambdas=list(self.backup_lambda_values),
                  augmented_term=self.augmented_term, log_pi=log_pi.detach(), pi=pi.detach())
         return R
@@ -575,6 +595,122 @@ class OracleCarsAgent(OracleAgentBase):
         return bmatr, dict(bx_next=x1, bx_next2=x2, bode_info=info[0])
 
 
+class OraclePvtolAgent(OracleAgentBase):
+    """Pvtol copy (P = NLBAC_pvtol_RL_training/Pvtol_RL_training, sac_cbf_clf/sac_cbf_clf.py): control-affine NODE on
+    the 6 dynamic states, three-step rollout with two re-sampled detached actions, relative-degree-3 CBFs (5 hazards,
+    2 safety-operator distances, y_max, y_min) + 1 CLF on the predicted observation; the backup controller is
+    updated every ``backup_update_interval`` updates with its own augmented term (:282-305, 1033-1034)."""
+    LAM_HI, RATIO_MIN, N_EPS = 400.0, 0.002, 7
+    EPS_BACKUP, OWN_BACKUP_RHO = 4, True
+    GOAL = (4.5, 4.5)
+
+    def _num_cbfs(self, env):
+        return len(env.hazard_locations) + 4
+
+    def _setup_task(self, env):
+        self.hazards = torch.tensor(np.asarray(env.hazard_locations), dtype=torch.float32)
+        self.node_fn = AffineNode(self.node, n_s=6, n_u=2)
+        self.backup_update_interval = int(getattr(self.args, "backup_update_interval", 20))
+
+    def _backup_due(self, updates):
+        return updates % self.backup_update_interval == 0
+
+    def _backup_lam_mul(self):
+        return self.backup_update_interval
+
+    def _lya_train_inputs(self, batch):
+        return batch["obs"], batch["next_obs"]          # P:243-252: the Lyapunov critic is trained on observations
+
+    @staticmethod
+    def get_state(obs):
+        """P/sac_cbf_clf/dynamics.py:50-66 — float64 on the host, cast back; (state7, state_dynamics6)."""
+        o = obs.detach().double().numpy()
+        st = np.zeros((o.shape[0], 7))
+        st[:, 0], st[:, 1], st[:, 2] = o[:, 0], o[:, 1], np.arctan2(o[:, 3], o[:, 2])
+        st[:, 3], st[:, 4], st[:, 5], st[:, 6] = o[:, 4], o[:, 5], o[:, 6], o[:, 7]
+        st = torch.from_numpy(st).float()
+        return st, st[:, :6]
+
+    def get_obs(self, st7):
+        """P/sac_cbf_clf/dynamics.py:97-153 (differentiable)."""
+        c, s_ = torch.cos(st7[:, 2]), torch.sin(st7[:, 2])
+        rx, ry = self.GOAL[0] - st7[:, 0], self.GOAL[1] - st7[:, 1]
+        dist = torch.sqrt(rx * rx + ry * ry)
+        v0, v1 = c * rx + s_ * ry, -s_ * rx + c * ry
+        div = torch.sqrt(v0 * v0 + v1 * v1) + 0.001
+        return torch.stack([st7[:, 0], st7[:, 1], c, s_, st7[:, 3], st7[:, 4], st7[:, 5], st7[:, 6], v0 / div,
+                            v1 / div, torch.exp(-dist)], 1)
+
+    def _rollout(self, state6, action):
+        y0 = torch.cat((state6, action), -1)
+        t = torch.tensor([0, self.env.dt])
+        info = {}
+        y = odeint(self.node_fn, y0, t, method=self.solver, atol=1e-7, rtol=1e-5, info=info)[-1]
+        return y[:, :6], info
+
+    def train_step(self, node_obs, node_action, node_next_obs):
+        """P/model.py:224-266 via P/sac_cbf_clf.py:205-219."""
+        (_, st), (_, nst) = self.get_state(node_obs), self.get_state(node_next_obs)
+        pred, _ = self._rollout(st, node_action)
+        loss = F.mse_loss(pred, nst)
+        g = torch.autograd.grad(loss, list(self.node.values()))
+        self._set_grads(self.node.values(), g)
+        self.opt["node"].step()
+        return float(loss), _flat(g)
+
+    def _step7(self, prev7, x6):
+        """Append the safety operator's next x-position (P:462-470)."""
+        op = prev7[:, 6] + self.env.safety_operator_follow * (x6[:, 0] - prev7[:, 6])
+        return torch.cat((x6, op.unsqueeze(1)), 1)
+
+    def _three_steps(self, obs, a0, policy, eps_a, eps_b):
+        st7, st6 = self.get_state(obs)
+        x1, info = self._rollout(st6, a0)
+        s1 = self._step7(st7, x1)
+        obs1 = self.get_obs(s1)
+        a1, _, _ = policy_sample(policy, obs1.detach(), eps_a, self.scale, self.bias)
+        x2, _ = self._rollout(x1, a1.detach())
+        s2 = self._step7(s1, x2)
+        a2, _, _ = policy_sample(policy, self.get_obs(s2).detach(), eps_b, self.scale, self.bias)
+        x3, _ = self._rollout(x2, a2.detach())
+        s3 = self._step7(s2, x3)
+        return (st7, s1, s2, s3), obs1, info
+
+    def _rd3(self, h0, h1, h2, h3):
+        """Relative-degree-3 composition, in the reference's operation order (P:575-587)."""
+        gb = self.gamma_b
+        t1 = h3 - h2 + gb * h2
+        t2 = h2 - h1 + gb * h1
+        t3 = h1 - h0 + gb * h0
+        return -(t1 - t2 + gb * t2 - (t2 - t3 + gb * t3) + gb * (t2 - t3 + gb * t3))
+
+    def _cbf_terms(self, states):
+        env = self.env
+        r = 1.2 * env.hazards_radius
+        hz = [0.5 * (((s_[:, None, :2] - self.hazards[None]) ** 2).sum(2) - r ** 2) for s_ in states]
+        d = 0.9 * env.operator_dist
+        h1 = [(s_[:, 0] - s_[:, 6] + d).unsqueeze(1) for s_ in states]
+        h2 = [(-s_[:, 0] + s_[:, 6] + d).unsqueeze(1) for s_ in states]
+        h3 = [(-s_[:, 1] + env.y_max - 10.0).unsqueeze(1) for s_ in states]
+        h4 = [(s_[:, 1] - env.y_min - 10.0).unsqueeze(1) for s_ in states]
+        return torch.cat([self._rd3(*h) for h in (hz, h1, h2, h3, h4)], 1)
+
+    def _primary_terms(self, batch, pi, eps):
+        """P:376-399, 424-757"""
+        states, obs1, info = self._three_steps(batch["obs"], pi, self.policy, eps[2], eps[3])
+        V = lyanet(self.lya, batch["center"]).detach()
+        lya_term = ((lyanet(self.lya, obs1) - V) / 1.0) + 0.1 * V
+        matr = torch.cat((self._cbf_terms(states), lya_term), 1)
+        return matr, dict(x_next=states[1][:, :6].detach(), x_next2=states[2][:, :6].detach(),
+                          x_next3=states[3][:, :6].detach(), ode_info=info)
+
+    def _backup_terms(self, batch, bpi, eps):
+        """P:401-422, 759-1048"""
+        states, _, binfo = self._three_steps(batch["obs"], bpi, self.backup, eps[5], eps[6])
+        return self._cbf_terms(states), dict(bx_next=states[1][:, :6].detach(), bx_next3=states[3][:, :6].detach(),
+                                             bode_info=binfo)
+
+
 class OracleUnicycleBarrierAgent(OracleUnicycleAgent):
     """Learned-barrier-certificate Unicycle copy (NU = neural_barrier_certificate/
     neural_barrier_certificate_NLBAC_Unicycle_RL_training/Unicycle_RL_training): one policy, a BarrierNetwork
@@ -693,5 +829,5 @@ class OracleUnicycleBarrierAgent(OracleUnicycleAgent):
 
 def make_oracle(env, args, weights, solver="euler"):
     kind = env.dynamics_mode + ("Barrier" if "barrier" in weights else "")
-    return {"Unicycle": OracleUnicycleAgent, "SimulatedCars": OracleCarsAgent,
+    return {"Unicycle": OracleUnicycleAgent, "SimulatedCars": OracleCarsAgent, "Pvtol": OraclePvtolAgent,
             "UnicycleBarrier": OracleUnicycleBarrierAgent}[kind](env, args, weights, solver)

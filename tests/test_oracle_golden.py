@@ -22,7 +22,7 @@ def flat_sd(sd):
     return torch.cat([v.detach().reshape(-1) for v in sd.values()])
 
 
-@pytest.mark.parametrize("env_name", ["Unicycle", "SimulatedCars", "UnicycleBarrier"])
+@pytest.mark.parametrize("env_name", ["Unicycle", "SimulatedCars", "UnicycleBarrier", "Pvtol"])
 @pytest.mark.parametrize("solver", ["euler", "rk4", "dopri5"])
 @pytest.mark.parametrize("B", [8, 128])
 def test_oracle_matches_reference_fixture(solver, B, env_name):
@@ -48,9 +48,12 @@ def test_oracle_matches_reference_fixture(solver, B, env_name):
             vec_close(R["brequired"], g[p + "brequired"], TOL, p + "brequired")
             vec_close(R["backup_lambdas"], g[p + "backup_lambdas"], TOL, p + "backup_lambdas")
             vec_close(R["bx_next"], g[p + "bx_next"], TOL, p + "bx_next")
-        if p + "x_next2" in g.files:
-            vec_close(R["x_next2"], g[p + "x_next2"], TOL, p + "x_next2")
-            vec_close(R["bx_next2"], g[p + "bx_next2"], TOL, p + "bx_next2")
+        for key in ("x_next2", "bx_next2", "x_next3", "bx_next3"):
+            if p + key in g.files:
+                vec_close(R[key], g[p + key], TOL, p + key)
+        if p + "backup_augmented_term" in g.files:
+            assert abs(agent.backup_augmented_term - float(g[p + "backup_augmented_term"])) < 1e-12
+            vec_close(agent.backup_lambda_values, g[p + "backup_lambdas"], TOL, p + "backup_lambdas (every call)")
         if B <= 16:
             vec_close(R["matr"], g[p + "matr"], TOL, p + "matr")
             if p + "bmatr" in g.files:
