@@ -148,12 +148,14 @@ int nlbac_td_targets(const float *q1t, const float *q2t, const float *lt, const 
 int nlbac_actor_q_terms(const float *q1, const float *q2, const float *logp, const float *alpha,
                         int B, int B_norm, int P, float *dq1, float *dq2, float *partials, nlbac_stream_t s);
 /* policy_loss_1, alpha_loss into sc; d alpha_loss / d log_alpha into g_log_alpha
- * (sac_cbf_clf.py:292-308).  log_alpha[p*stride]. */
-int nlbac_actor_scalars(const float *partials, int n_blk, int B, int P, float target_entropy,
+ * (sac_cbf_clf.py:292-308) for problems first_problem .. first_problem+P-1 (0 primary, 1 backup);
+ * partials is the base of all problems, log_alpha / g_log_alpha point at first_problem's entry (stride between). */
+int nlbac_actor_scalars(const float *partials, int n_blk, int B, int first_problem, int P, float target_entropy,
                         const float *log_alpha, int log_alpha_stride, float *g_log_alpha, float *sc,
                         nlbac_stream_t s);
 /* sc[SC_ALPHA+p] = exp(log_alpha[p*stride])  (sac_cbf_clf.py:299,308) */
-int nlbac_alpha_refresh(const float *log_alpha, int log_alpha_stride, int P, float *sc, nlbac_stream_t s);
+int nlbac_alpha_refresh(const float *log_alpha, int log_alpha_stride, int first_problem, int P, float *sc,
+                        nlbac_stream_t s);
 
 /* Unicycle geometry: obs -> state (atan2 in fp64 then cast, dynamics.py:53-58) and look-ahead
  * p(x) = xy + l_p (cos th, sin th) (sac_cbf_clf.py:429-437, 455-469). */
@@ -176,8 +178,8 @@ int nlbac_unicycle_constraints_fwd(const float *ps, const float *ps_next, const 
  * backup_mode: 0 no backup controller (NU/NP: partials have n_cbf+n_clf columns), 1 backup shares augmented_term
  * with the primary (U/C), 2 backup keeps its own (P); with a backup, partials have 2*n_cbf+n_clf columns. */
 int nlbac_auglag(const float *partials, int n_blk, int n_cbf, int n_clf, float batch_size,
-                 int do_lambda_update, int ratio_mode, int backup_mode, float lam_lo, float lam_hi,
-                 float *sc, nlbac_stream_t s);
+                 int do_lambda_update, int do_backup_lambda_update /* P updates them on different schedules */,
+                 int ratio_mode, int backup_mode, float lam_lo, float lam_hi, float *sc, nlbac_stream_t s);
 /* d ps_next (2B,2) [CBF part] and dV_next (B) from the coefficients in sc. */
 int nlbac_unicycle_constraints_bwd(const float *ps_next, const float *matr, const float *bmatr,
                                    const float *hazards, int n_hz, float dt, float batch_size, int B,
@@ -217,6 +219,28 @@ int nlbac_barrier_constraints_fwd(const float *Bv, const float *Bn, const float 
                                   nlbac_stream_t s);
 int nlbac_barrier_constraints_bwd(const float *matr, float dt, float batch_size, int B, const float *sc,
                                   float *dBn, float *dVn, nlbac_stream_t s);
+
+/* Pvtol (P = NLBAC_pvtol_RL_training/Pvtol_RL_training): dynamic state x6 = [x, y, theta, vx, vy, thrust] plus the
+ * safety operator's x-position op, which follows the vehicle: op' = op + follow (x' - op) (P/sac_cbf_clf.py:462-470).
+ * pvtol_state: get_state (P/sac_cbf_clf/dynamics.py:50-66).  pvtol_obs_fwd/bwd: get_obs of [x6, op'] (:97-153), obs
+ *   (n,11) = [x, y, cos, sin, vx, vy, thrust, op', compass(2), exp(-dist)]; op_prev has op_rows rows (row % op_rows);
+ *   bwd is the transpose-Jacobian product into dx (n,6) including the op' -> x path.
+ * pvtol_constraints: relative-degree-3 CBFs over the positions at t..t+3 (5 hazards, 2 operator distances, y_max,
+ *   y_min) and the CLF term (V1 - V)/1 + gamma_l V (P/sac_cbf_clf.py:543-690, 880-1010).  x1/x2/x3 (NP*B,6): primary
+ *   rows, then backup rows when NP == 2.  matr (B,10), bmatr (B,9); partials [ceil(B/256)][10 or 19]. */
+int nlbac_pvtol_state(const float *obs, int obs_ld, int n, float *st6, float *op /*or NULL*/, nlbac_stream_t s);
+int nlbac_pvtol_obs_fwd(const float *x6, const float *op_prev, int op_rows, float follow, float goal_x, float goal_y,
+                        int n, float *obs, int obs_ld, float *op_out /*or NULL*/, nlbac_stream_t s);
+int nlbac_pvtol_obs_bwd(const float *x6, const float *dobs, int dobs_ld, float follow, float goal_x, float goal_y,
+                        int n, float *dx, int accumulate, nlbac_stream_t s);
+int nlbac_pvtol_constraints_fwd(const float *st6, const float *op0, const float *x1, const float *x2, const float *x3,
+                                const float *V, const float *V1, const float *hazards, int n_hz, float r_coll,
+                                float d_op, float y_max, float y_min, float follow, float gamma_b, float gamma_l,
+                                int B, int NP, float *matr, float *bmatr, float *partials, nlbac_stream_t s);
+int nlbac_pvtol_constraints_bwd(const float *matr, const float *bmatr, const float *x1, const float *x2,
+                                const float *x3, const float *hazards, int n_hz, float follow, float gamma_b,
+                                float batch_size, int B, int NP, const float *sc, float *dx1, float *dx2, float *dx3,
+                                float *dV1, nlbac_stream_t s);
 
 /* nn.MSELoss('mean') over (n,d): dpred and per-block squared-error partials [ceil(n/256)] (model.py:256). */
 int nlbac_mse_fwd_bwd(const float *pred, int pred_ld, const float *target, int target_ld, int n, int n_norm,

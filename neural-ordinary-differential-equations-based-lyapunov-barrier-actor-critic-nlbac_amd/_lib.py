@@ -64,13 +64,13 @@ _PROTOS = {
     "nlbac_gauss_sample_bwd": [_P, _I, _P, _P, _I, _I, _I, _P, _I, _P, _I, _P, _I, _P, _F, _P, _I, _P],
     "nlbac_td_targets": [_P] * 7 + [_I] + [_P] * 4 + [_F, _I, _I] + [_P] * 6 + [_P],
     "nlbac_actor_q_terms": [_P, _P, _P, _P, _I, _I, _I, _P, _P, _P, _P],
-    "nlbac_actor_scalars": [_P, _I, _I, _I, _F, _P, _I, _P, _P, _P],
-    "nlbac_alpha_refresh": [_P, _I, _I, _P, _P],
+    "nlbac_actor_scalars": [_P, _I, _I, _I, _I, _F, _P, _I, _P, _P, _P],
+    "nlbac_alpha_refresh": [_P, _I, _I, _I, _P, _P],
     "nlbac_unicycle_state": [_P, _I, _I, _F, _P, _P, _P],
     "nlbac_unicycle_lookahead": [_P, _I, _F, _P, _P],
     "nlbac_unicycle_lookahead_bwd": [_P, _P, _P, _I, _F, _P, _P],
     "nlbac_unicycle_constraints_fwd": [_P, _P, _P, _P, _P, _I, _F, _F, _F, _F, _I, _P, _P, _P, _P],
-    "nlbac_auglag": [_P, _I, _I, _I, _F, _I, _I, _I, _F, _F, _P, _P],
+    "nlbac_auglag": [_P, _I, _I, _I, _F, _I, _I, _I, _I, _F, _F, _P, _P],
     "nlbac_unicycle_constraints_bwd": [_P, _P, _P, _P, _I, _F, _F, _I, _P, _P, _P, _P],
     "nlbac_mse_fwd_bwd": [_P, _I, _P, _I, _I, _I, _I, _P, _I, _P, _P],
     "nlbac_affine_combine_fwd": [_P, _P, _P, _I, _I, _I, _P, _P],
@@ -82,6 +82,11 @@ _PROTOS = {
     "nlbac_cars_constraints_fwd": [_P, _P, _P, _P, _P, _F, _F, _F, _I, _P, _P, _P, _P],
     "nlbac_cars_constraints_bwd": [_P, _P, _F, _F, _I, _P, _P, _P, _P, _P],
     "nlbac_add_cols": [_P, _I, _I, _P, _I, _I, _I, _P],
+    "nlbac_pvtol_state": [_P, _I, _I, _P, _P, _P],
+    "nlbac_pvtol_obs_fwd": [_P, _P, _I, _F, _F, _F, _I, _P, _I, _P, _P],
+    "nlbac_pvtol_obs_bwd": [_P, _P, _I, _F, _F, _F, _I, _P, _I, _P],
+    "nlbac_pvtol_constraints_fwd": [_P, _P, _P, _P, _P, _P, _P, _P, _I, _F, _F, _F, _F, _F, _F, _F, _I, _I, _P, _P, _P, _P],
+    "nlbac_pvtol_constraints_bwd": [_P, _P, _P, _P, _P, _P, _I, _F, _F, _F, _I, _I, _P, _P, _P, _P, _P, _P],
     "nlbac_td_value": [_P, _P, _I, _P, _I, _P, _F, _I, _I, _P, _P, _P, _P],
     "nlbac_unicycle_obs_fwd": [_P, _I, _F, _F, _P, _I, _P],
     "nlbac_unicycle_obs_bwd": [_P, _P, _I, _I, _F, _F, _P, _I, _P],

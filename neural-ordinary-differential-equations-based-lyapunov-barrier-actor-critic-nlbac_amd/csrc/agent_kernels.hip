@@ -142,10 +142,11 @@ __global__ __launch_bounds__(256) void actor_q_terms_kernel(const float* q1, con
 }
 
 // policy_loss_1, alpha losses, d log_alpha  (one thread)
-__global__ void actor_scalars_kernel(const float* partials, int nblk, int B, int P, float target_entropy,
+__global__ void actor_scalars_kernel(const float* partials, int nblk, int B, int p0, int P, float target_entropy,
                                      const float* log_alpha, int log_alpha_stride, float* g_log_alpha, float* sc) {
     if (threadIdx.x != 0 || blockIdx.x != 0) return;
-    for (int p = 0; p < P; ++p) {
+    // problems p0 .. p0+P-1 (0 primary, 1 backup); log_alpha / g_log_alpha point at problem p0's entry
+    for (int p = p0; p < p0 + P; ++p) {
         float s0 = 0.f, s1 = 0.f;
         for (int b = 0; b < nblk; ++b) {
             s0 += partials[((long)p * nblk + b) * 2 + 0];
@@ -153,19 +154,19 @@ __global__ void actor_scalars_kernel(const float* partials, int nblk, int B, int
         }
         const float pl1 = s0 / (float)B;
         const float mean_lp = s1 / (float)B;
-        const float la = log_alpha[p * log_alpha_stride];
+        const float la = log_alpha[(p - p0) * log_alpha_stride];
         // alpha_loss = -(log_alpha * (logp + H)).mean()
         const float aloss = -(la * (mean_lp + target_entropy));
         sc[(p == 0) ? SC_PL1 : SC_BPL1] = pl1;
         sc[(p == 0) ? SC_ALOSS : SC_BALOSS] = aloss;
         sc[(p == 0) ? SC_MEAN_LOGP : SC_MEAN_BLOGP] = mean_lp;
-        g_log_alpha[p * log_alpha_stride] = -(mean_lp + target_entropy);
+        g_log_alpha[(p - p0) * log_alpha_stride] = -(mean_lp + target_entropy);
     }
 }
 
-__global__ void alpha_refresh_kernel(const float* log_alpha, int log_alpha_stride, int P, float* sc) {
+__global__ void alpha_refresh_kernel(const float* log_alpha, int log_alpha_stride, int p0, int P, float* sc) {
     if (threadIdx.x == 0 && blockIdx.x == 0)
-        for (int p = 0; p < P; ++p) sc[SC_ALPHA + p] = expf(log_alpha[p * log_alpha_stride]);
+        for (int p = p0; p < p0 + P; ++p) sc[SC_ALPHA + p] = expf(log_alpha[(p - p0) * log_alpha_stride]);
 }
 
 // ---------------------------------------------------------------------------
@@ -253,8 +254,9 @@ __global__ __launch_bounds__(256) void unicycle_constraints_fwd_kernel(const flo
 // backup_mode: 0 no backup controller (learned-barrier copies), 1 backup shares rho with the primary
 // (Unicycle / SimulatedCars), 2 backup keeps its own rho (Pvtol); lambda clamp [lam_lo, lam_hi].
 __global__ void auglag_kernel(const float* partials, int n_blk, int n_cbf, int n_clf, float batch_size,
-                              int do_lambda_update, int ratio_mode /*0 none,1 plain,2 clamp .002*/,
-                              int backup_mode, float lam_lo, float lam_hi, float* sc) {
+                              int do_lambda_update, int do_backup_lambda_update,
+                              int ratio_mode /*0 none,1 plain,2 clamp .002*/, int backup_mode, float lam_lo,
+                              float lam_hi, float* sc) {
     const int nc = n_cbf + n_clf, ncol = nc + (backup_mode ? n_cbf : 0);
     if (blockIdx.x != 0) return;
     for (int c = threadIdx.x; c < ncol; c += blockDim.x) {
@@ -309,7 +311,7 @@ __global__ void auglag_kernel(const float* partials, int n_blk, int n_cbf, int n
         const float* req = sc + SC_BREQ;
         float* lam = sc + SC_BLAMBDA;
         double rho = *brho_p;
-        if (do_lambda_update)
+        if (do_backup_lambda_update)
             for (int c = 0; c < n_cbf; ++c)
                 lam[c] = fminf(fmaxf(lam[c] + (float)rho * req[c], lam_lo), lam_hi);
         rho = fmin(rho * 1.0005, 200.0);
@@ -520,19 +522,23 @@ extern "C" int nlbac_actor_q_terms(const float* q1, const float* q2, const float
     return 0;
 }
 
-extern "C" int nlbac_actor_scalars(const float* partials, int n_blk, int B, int P, float target_entropy,
-                                   const float* log_alpha, int log_alpha_stride, float* g_log_alpha, float* sc,
-                                   nlbac_stream_t s) {
-    NLBAC_REQUIRE(partials && log_alpha && g_log_alpha && sc && P >= 1 && P <= 2, "nlbac_actor_scalars: bad arguments");
-    hipLaunchKernelGGL(actor_scalars_kernel, dim3(1), dim3(64), 0, (hipStream_t)s, partials, n_blk, B, P,
+extern "C" int nlbac_actor_scalars(const float* partials, int n_blk, int B, int first_problem, int P,
+                                   float target_entropy, const float* log_alpha, int log_alpha_stride,
+                                   float* g_log_alpha, float* sc, nlbac_stream_t s) {
+    NLBAC_REQUIRE(partials && log_alpha && g_log_alpha && sc && P >= 1 && first_problem >= 0 && first_problem + P <= 2,
+                  "nlbac_actor_scalars: bad arguments");
+    hipLaunchKernelGGL(actor_scalars_kernel, dim3(1), dim3(64), 0, (hipStream_t)s, partials, n_blk, B, first_problem, P,
                        target_entropy, log_alpha, log_alpha_stride, g_log_alpha, sc);
     NLBAC_CHECK_LAUNCH("nlbac_actor_scalars");
     return 0;
 }
 
-extern "C" int nlbac_alpha_refresh(const float* log_alpha, int log_alpha_stride, int P, float* sc, nlbac_stream_t s) {
-    NLBAC_REQUIRE(log_alpha && sc && P >= 1 && P <= 2, "nlbac_alpha_refresh: bad arguments");
-    hipLaunchKernelGGL(alpha_refresh_kernel, dim3(1), dim3(64), 0, (hipStream_t)s, log_alpha, log_alpha_stride, P, sc);
+extern "C" int nlbac_alpha_refresh(const float* log_alpha, int log_alpha_stride, int first_problem, int P, float* sc,
+                                   nlbac_stream_t s) {
+    NLBAC_REQUIRE(log_alpha && sc && P >= 1 && first_problem >= 0 && first_problem + P <= 2,
+                  "nlbac_alpha_refresh: bad arguments");
+    hipLaunchKernelGGL(alpha_refresh_kernel, dim3(1), dim3(64), 0, (hipStream_t)s, log_alpha, log_alpha_stride,
+                       first_problem, P, sc);
     NLBAC_CHECK_LAUNCH("nlbac_alpha_refresh");
     return 0;
 }
@@ -575,13 +581,13 @@ extern "C" int nlbac_unicycle_constraints_fwd(const float* ps, const float* ps_n
 }
 
 extern "C" int nlbac_auglag(const float* partials, int n_blk, int n_cbf, int n_clf, float batch_size,
-                            int do_lambda_update, int ratio_mode, int backup_mode, float lam_lo, float lam_hi,
-                            float* sc, nlbac_stream_t s) {
+                            int do_lambda_update, int do_backup_lambda_update, int ratio_mode, int backup_mode,
+                            float lam_lo, float lam_hi, float* sc, nlbac_stream_t s) {
     NLBAC_REQUIRE(partials && sc, "nlbac_auglag: null pointer");
     NLBAC_REQUIRE(backup_mode >= 0 && backup_mode <= 2, "nlbac_auglag: backup_mode is 0, 1 or 2");
     NLBAC_REQUIRE(n_cbf >= 1 && n_cbf + n_clf <= NLBAC_NC_MAX && n_clf >= 0 && n_clf <= 1, "nlbac_auglag: bad constraint counts");
     hipLaunchKernelGGL(auglag_kernel, dim3(1), dim3(64), 0, (hipStream_t)s, partials, n_blk, n_cbf, n_clf,
-                       batch_size, do_lambda_update, ratio_mode, backup_mode, lam_lo, lam_hi, sc);
+                       batch_size, do_lambda_update, do_backup_lambda_update, ratio_mode, backup_mode, lam_lo, lam_hi, sc);
     NLBAC_CHECK_LAUNCH("nlbac_auglag");
     return 0;
 }
@@ -780,5 +786,255 @@ extern "C" int nlbac_barrier_constraints_bwd(const float* matr, float dt, float 
     NLBAC_REQUIRE(matr && sc && dBn && dVn, "nlbac_barrier_constraints_bwd: null pointer");
     hipLaunchKernelGGL(barrier_constraints_bwd_kernel, GRID1(B), matr, dt, batch_size, B, sc, dBn, dVn);
     NLBAC_CHECK_LAUNCH("nlbac_barrier_constraints_bwd");
+    return 0;
+}
+
+
+// ---------------------------------------------------------------------------
+// Pvtol (P = NLBAC_pvtol_RL_training/Pvtol_RL_training)
+//   get_state / get_obs                 P/sac_cbf_clf/dynamics.py:50-66, 97-153
+//   safety operator follow              P/sac_cbf_clf/sac_cbf_clf.py:462-470
+//   relative-degree-3 CBFs + CLF        P/sac_cbf_clf/sac_cbf_clf.py:543-690 (primary), 880-1010 (backup)
+// Dynamic state x = [x, y, theta, vx, vy, thrust]; op = x-position of the safety operator.
+// Rows of x1/x2/x3: NP problems (primary, backup) x B.
+// ---------------------------------------------------------------------------
+#define PV_NH 5
+#define PV_NC (PV_NH + 4)
+
+__global__ __launch_bounds__(256) void pvtol_state_kernel(const float* obs, int obs_ld, int n, float* st6, float* op) {
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    const float* o = obs + (long)i * obs_ld;
+    float* x = st6 + (long)i * 6;
+    x[0] = o[0]; x[1] = o[1];
+    x[2] = (float)atan2((double)o[3], (double)o[2]);      // float64 on the host in the reference, then cast
+    x[3] = o[4]; x[4] = o[5]; x[5] = o[6];
+    if (op) op[i] = o[7];
+}
+
+__global__ __launch_bounds__(256) void pvtol_obs_fwd_kernel(const float* x6, const float* op_prev, int op_rows,
+                                                            float follow, float gx, float gy, int n, float* obs,
+                                                            int obs_ld, float* op_out) {
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    const float* x = x6 + (long)i * 6;
+    const float o0 = op_prev[i % op_rows];
+    const float o1 = o0 + follow * (x[0] - o0);
+    const float c = cosf(x[2]), s = sinf(x[2]);
+    const float rx = gx - x[0], ry = gy - x[1];
+    const float dist = sqrtf(rx * rx + ry * ry);
+    const float v0 = c * rx + s * ry, v1 = -s * rx + c * ry;
+    const float div = sqrtf(v0 * v0 + v1 * v1) + 0.001f;
+    float* o = obs + (long)i * obs_ld;
+    o[0] = x[0]; o[1] = x[1]; o[2] = c; o[3] = s; o[4] = x[3]; o[5] = x[4]; o[6] = x[5]; o[7] = o1;
+    o[8] = v0 / div; o[9] = v1 / div; o[10] = expf(-dist);
+    if (op_out) op_out[i] = o1;
+}
+
+__global__ __launch_bounds__(256) void pvtol_obs_bwd_kernel(const float* x6, const float* dobs, int dobs_ld,
+                                                            float follow, float gx, float gy, int n, float* dx,
+                                                            int accumulate) {
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    const float* x = x6 + (long)i * 6;
+    const float c = cosf(x[2]), s = sinf(x[2]);
+    const float rx = gx - x[0], ry = gy - x[1];
+    const float dist = sqrtf(rx * rx + ry * ry);
+    const float v0 = c * rx + s * ry, v1 = -s * rx + c * ry;
+    const float nv = sqrtf(v0 * v0 + v1 * v1), div = nv + 0.001f;
+    const float* d = dobs + (long)i * dobs_ld;
+    float g[6];
+    g[0] = d[0] + follow * d[7];          // the operator's new position follows x
+    g[1] = d[1];
+    g[2] = -s * d[2] + c * d[3];
+    g[3] = d[4]; g[4] = d[5]; g[5] = d[6];
+    float dv0 = d[8] / div, dv1 = d[9] / div;
+    const float dnv = -(d[8] * v0 + d[9] * v1) / (div * div);
+    if (nv > 0.f) { dv0 += dnv * v0 / nv; dv1 += dnv * v1 / nv; }
+    float drx = dv0 * c - dv1 * s, dry = dv0 * s + dv1 * c;
+    g[2] += dv0 * v1 - dv1 * v0;
+    if (dist > 0.f) {
+        const float dd = -d[10] * expf(-dist);
+        drx += dd * rx / dist; dry += dd * ry / dist;
+    }
+    g[0] -= drx; g[1] -= dry;
+#pragma unroll
+    for (int k = 0; k < 6; ++k) {
+        if (accumulate) dx[(long)i * 6 + k] += g[k]; else dx[(long)i * 6 + k] = g[k];
+    }
+}
+
+// the reference's operation order (P:575-587)
+__device__ __forceinline__ float pv_rd3(float h0, float h1, float h2, float h3, float gb) {
+    const float t1 = h3 - h2 + gb * h2;
+    const float t2 = h2 - h1 + gb * h1;
+    const float t3 = h1 - h0 + gb * h0;
+    return -(t1 - t2 + gb * t2 - (t2 - t3 + gb * t3) + gb * (t2 - t3 + gb * t3));
+}
+
+__global__ __launch_bounds__(256) void pvtol_constraints_fwd_kernel(
+    const float* st6, const float* op0, const float* x1, const float* x2, const float* x3, const float* V,
+    const float* V1, const float* hazards, float r2, float d_op, float y_max, float y_min, float follow, float gb,
+    float gl, int B, int NP, float* matr, float* bmatr, float* partials) {
+    __shared__ float red[4 * (2 * PV_NC + 1)];
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    float v[2 * PV_NC + 1];
+#pragma unroll
+    for (int k = 0; k < 2 * PV_NC + 1; ++k) v[k] = 0.f;
+    if (i < B) {
+        const float px0 = st6[(long)i * 6], py0 = st6[(long)i * 6 + 1], o0 = op0[i];
+        for (int p = 0; p < NP; ++p) {
+            const long r = (long)p * B + i;
+            const float px1 = x1[r * 6], py1 = x1[r * 6 + 1];
+            const float px2 = x2[r * 6], py2 = x2[r * 6 + 1];
+            const float px3 = x3[r * 6], py3 = x3[r * 6 + 1];
+            const float o1 = o0 + follow * (px1 - o0);
+            const float o2 = o1 + follow * (px2 - o1);
+            const float o3 = o2 + follow * (px3 - o2);
+            float t[PV_NC];
+#pragma unroll
+            for (int h = 0; h < PV_NH; ++h) {
+                const float hx = hazards[h * 2], hy = hazards[h * 2 + 1];
+                const float a0 = 0.5f * ((px0 - hx) * (px0 - hx) + (py0 - hy) * (py0 - hy) - r2);
+                const float a1 = 0.5f * ((px1 - hx) * (px1 - hx) + (py1 - hy) * (py1 - hy) - r2);
+                const float a2 = 0.5f * ((px2 - hx) * (px2 - hx) + (py2 - hy) * (py2 - hy) - r2);
+                const float a3 = 0.5f * ((px3 - hx) * (px3 - hx) + (py3 - hy) * (py3 - hy) - r2);
+                t[h] = pv_rd3(a0, a1, a2, a3, gb);
+            }
+            t[PV_NH + 0] = pv_rd3(px0 - o0 + d_op, px1 - o1 + d_op, px2 - o2 + d_op, px3 - o3 + d_op, gb);
+            t[PV_NH + 1] = pv_rd3(-px0 + o0 + d_op, -px1 + o1 + d_op, -px2 + o2 + d_op, -px3 + o3 + d_op, gb);
+            t[PV_NH + 2] = pv_rd3(-py0 + y_max - 10.0f, -py1 + y_max - 10.0f, -py2 + y_max - 10.0f,
+                                  -py3 + y_max - 10.0f, gb);
+            t[PV_NH + 3] = pv_rd3(py0 - y_min - 10.0f, py1 - y_min - 10.0f, py2 - y_min - 10.0f,
+                                  py3 - y_min - 10.0f, gb);
+            if (p == 0) {
+                const float vv = V[i];
+                const float lt = ((V1[i] - vv) / 1.0f) + gl * vv;
+#pragma unroll
+                for (int k = 0; k < PV_NC; ++k) { matr[(long)i * (PV_NC + 1) + k] = t[k]; v[k] = t[k] > 0.f ? t[k] : 0.f; }
+                matr[(long)i * (PV_NC + 1) + PV_NC] = lt;
+                v[PV_NC] = lt > 0.f ? lt : 0.f;
+            } else {
+#pragma unroll
+                for (int k = 0; k < PV_NC; ++k) { bmatr[(long)i * PV_NC + k] = t[k]; v[PV_NC + 1 + k] = t[k] > 0.f ? t[k] : 0.f; }
+            }
+        }
+    }
+    block_sum_256<2 * PV_NC + 1>(v, red);
+    if (threadIdx.x == 0) {
+        const int ncol = PV_NC + 1 + (NP == 2 ? PV_NC : 0);
+        for (int k = 0; k < ncol; ++k) partials[(long)blockIdx.x * ncol + k] = v[k];
+    }
+}
+
+__global__ __launch_bounds__(256) void pvtol_constraints_bwd_kernel(
+    const float* matr, const float* bmatr, const float* x1, const float* x2, const float* x3, const float* hazards,
+    float follow, float gb, float batch_size, int B, int NP, const float* sc, float* dx1, float* dx2, float* dx3,
+    float* dV1) {
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= B) return;
+    const float a = gb - 1.0f;
+    const float ck[3] = {-3.0f * a * a, -3.0f * a, -1.0f};      // d term / d h(t+1), h(t+2), h(t+3)
+    for (int p = 0; p < NP; ++p) {
+        const long r = (long)p * B + i;
+        const float* xs[3] = {x1 + r * 6, x2 + r * 6, x3 + r * 6};
+        const float* m = p == 0 ? matr + (long)i * (PV_NC + 1) : bmatr + (long)i * PV_NC;
+        const float* coef = sc + (p == 0 ? SC_COEF : SC_BCOEF);
+        float gx[3] = {0.f, 0.f, 0.f}, gy[3] = {0.f, 0.f, 0.f}, gop[3] = {0.f, 0.f, 0.f};
+#pragma unroll
+        for (int h = 0; h < PV_NH; ++h) {
+            if (m[h] > 0.f) {
+                const float g = coef[h] / batch_size;
+                const float hx = hazards[h * 2], hy = hazards[h * 2 + 1];
+#pragma unroll
+                for (int k = 0; k < 3; ++k) {
+                    gx[k] += g * ck[k] * (xs[k][0] - hx);
+                    gy[k] += g * ck[k] * (xs[k][1] - hy);
+                }
+            }
+        }
+        if (m[PV_NH + 0] > 0.f) {                                 // x - op + d
+            const float g = coef[PV_NH + 0] / batch_size;
+#pragma unroll
+            for (int k = 0; k < 3; ++k) { gx[k] += g * ck[k]; gop[k] -= g * ck[k]; }
+        }
+        if (m[PV_NH + 1] > 0.f) {                                 // -x + op + d
+            const float g = coef[PV_NH + 1] / batch_size;
+#pragma unroll
+            for (int k = 0; k < 3; ++k) { gx[k] -= g * ck[k]; gop[k] += g * ck[k]; }
+        }
+        if (m[PV_NH + 2] > 0.f) {                                 // -y + y_max - 10
+            const float g = coef[PV_NH + 2] / batch_size;
+#pragma unroll
+            for (int k = 0; k < 3; ++k) gy[k] -= g * ck[k];
+        }
+        if (m[PV_NH + 3] > 0.f) {                                 // y - y_min - 10
+            const float g = coef[PV_NH + 3] / batch_size;
+#pragma unroll
+            for (int k = 0; k < 3; ++k) gy[k] += g * ck[k];
+        }
+        // op_k = op_(k-1) + follow (x_k - op_(k-1))
+        gx[2] += follow * gop[2]; gop[1] += (1.0f - follow) * gop[2];
+        gx[1] += follow * gop[1]; gop[0] += (1.0f - follow) * gop[1];
+        gx[0] += follow * gop[0];
+        float* outs[3] = {dx1 + r * 6, dx2 + r * 6, dx3 + r * 6};
+#pragma unroll
+        for (int k = 0; k < 3; ++k) {
+            outs[k][0] = gx[k]; outs[k][1] = gy[k];
+            outs[k][2] = 0.f; outs[k][3] = 0.f; outs[k][4] = 0.f; outs[k][5] = 0.f;
+        }
+        if (p == 0) dV1[i] = m[PV_NC] > 0.f ? ((sc[SC_COEF + PV_NC] / batch_size) / 1.0f) : 0.f;
+    }
+}
+
+extern "C" int nlbac_pvtol_state(const float* obs, int obs_ld, int n, float* st6, float* op, nlbac_stream_t s) {
+    NLBAC_REQUIRE(obs && st6 && obs_ld >= 8, "nlbac_pvtol_state: bad arguments");
+    hipLaunchKernelGGL(pvtol_state_kernel, GRID1(n), obs, obs_ld, n, st6, op);
+    NLBAC_CHECK_LAUNCH("nlbac_pvtol_state");
+    return 0;
+}
+
+extern "C" int nlbac_pvtol_obs_fwd(const float* x6, const float* op_prev, int op_rows, float follow, float goal_x,
+                                   float goal_y, int n, float* obs, int obs_ld, float* op_out, nlbac_stream_t s) {
+    NLBAC_REQUIRE(x6 && op_prev && obs && obs_ld >= 11 && op_rows >= 1, "nlbac_pvtol_obs_fwd: bad arguments");
+    hipLaunchKernelGGL(pvtol_obs_fwd_kernel, GRID1(n), x6, op_prev, op_rows, follow, goal_x, goal_y, n, obs, obs_ld,
+                       op_out);
+    NLBAC_CHECK_LAUNCH("nlbac_pvtol_obs_fwd");
+    return 0;
+}
+
+extern "C" int nlbac_pvtol_obs_bwd(const float* x6, const float* dobs, int dobs_ld, float follow, float goal_x,
+                                   float goal_y, int n, float* dx, int accumulate, nlbac_stream_t s) {
+    NLBAC_REQUIRE(x6 && dobs && dx && dobs_ld >= 11, "nlbac_pvtol_obs_bwd: bad arguments");
+    hipLaunchKernelGGL(pvtol_obs_bwd_kernel, GRID1(n), x6, dobs, dobs_ld, follow, goal_x, goal_y, n, dx, accumulate);
+    NLBAC_CHECK_LAUNCH("nlbac_pvtol_obs_bwd");
+    return 0;
+}
+
+extern "C" int nlbac_pvtol_constraints_fwd(const float* st6, const float* op0, const float* x1, const float* x2,
+                                           const float* x3, const float* V, const float* V1, const float* hazards,
+                                           int n_hz, float r_coll, float d_op, float y_max, float y_min, float follow,
+                                           float gamma_b, float gamma_l, int B, int NP, float* matr, float* bmatr,
+                                           float* partials, nlbac_stream_t s) {
+    NLBAC_REQUIRE(st6 && op0 && x1 && x2 && x3 && V && V1 && hazards && matr && partials && (NP == 1 || bmatr),
+                  "nlbac_pvtol_constraints_fwd: null pointer");
+    NLBAC_REQUIRE(n_hz == PV_NH && (NP == 1 || NP == 2), "nlbac_pvtol_constraints_fwd: built for 5 hazards, 1-2 problems");
+    const float r2 = (float)((double)r_coll * (double)r_coll);
+    hipLaunchKernelGGL(pvtol_constraints_fwd_kernel, GRID1(B), st6, op0, x1, x2, x3, V, V1, hazards, r2, d_op, y_max,
+                       y_min, follow, gamma_b, gamma_l, B, NP, matr, bmatr, partials);
+    NLBAC_CHECK_LAUNCH("nlbac_pvtol_constraints_fwd");
+    return 0;
+}
+
+extern "C" int nlbac_pvtol_constraints_bwd(const float* matr, const float* bmatr, const float* x1, const float* x2,
+                                           const float* x3, const float* hazards, int n_hz, float follow,
+                                           float gamma_b, float batch_size, int B, int NP, const float* sc, float* dx1,
+                                           float* dx2, float* dx3, float* dV1, nlbac_stream_t s) {
+    NLBAC_REQUIRE(matr && x1 && x2 && x3 && hazards && sc && dx1 && dx2 && dx3 && dV1 && (NP == 1 || bmatr),
+                  "nlbac_pvtol_constraints_bwd: null pointer");
+    NLBAC_REQUIRE(n_hz == PV_NH && (NP == 1 || NP == 2), "nlbac_pvtol_constraints_bwd: built for 5 hazards, 1-2 problems");
+    hipLaunchKernelGGL(pvtol_constraints_bwd_kernel, GRID1(B), matr, bmatr, x1, x2, x3, hazards, follow, gamma_b,
+                       batch_size, B, NP, sc, dx1, dx2, dx3, dV1);
+    NLBAC_CHECK_LAUNCH("nlbac_pvtol_constraints_bwd");
     return 0;
 }

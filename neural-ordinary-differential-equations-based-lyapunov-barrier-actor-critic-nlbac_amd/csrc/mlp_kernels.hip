@@ -383,7 +383,7 @@ __global__ __launch_bounds__(256) void mlp_bwd_wide_kernel(const MlpLaunch L) {
 // Stage 2: one thread per output element sums the chunks in order
 // (deterministic) and scatters into grad slab 0.
 // ---------------------------------------------------------------------------
-#define SK_MAX_IN 12
+#define SK_MAX_IN 16
 #define SK_MAX_OUT 16
 #define SK_MAX_Q (NLBAC_MAX_LAYERS + SK_MAX_IN + SK_MAX_OUT + 1)
 

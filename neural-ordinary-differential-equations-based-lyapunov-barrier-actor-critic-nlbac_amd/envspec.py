@@ -90,7 +90,7 @@ class PvtolSpec:
     dynamics_mode = "Pvtol"
     n_s, n_u, obs_dim, lya_in = 6, 2, 11, 11
 
-    def __init__(self, seed=0):
+    def __init__(self, seed=0, y_min=-100.0, y_max=100.0, operator_dist=1.0, safety_operator_follow=0.7):
         lo, hi = np.array([-3.5, -15.0]), np.array([3.5, 15.0])
         self.action_space = Box(lo, hi)
         self.safe_action_space = Box(lo, hi)
@@ -98,9 +98,9 @@ class PvtolSpec:
         self.dt = 0.02
         self.max_episode_steps = 2000
         self.goal_pos = np.array([4.5, 4.5])
-        self.safety_operator_follow = 0.7
-        self.operator_dist = 1.0
-        self.y_min, self.y_max = -100.0, 100.0
+        self.safety_operator_follow = safety_operator_follow
+        self.operator_dist = operator_dist
+        self.y_min, self.y_max = y_min, y_max
         self.hazard_locations = np.array([[-2.5, -2.5], [-2.5, 2.5], [0.0, -3.5], [0.0, 3.5], [-4.5, 0.0]])
         self.hazards_radius = 0.25
         self.seed(seed)
@@ -110,7 +110,7 @@ class PvtolSpec:
         return [s]
 
 
-def make_env(name, seed=0):
+def make_env(name, seed=0, **overrides):
     """``UnicycleBarrier`` is the learned-barrier-certificate copy (``neural_barrier_certificate/``): the same
     Unicycle constants (its ``dynamics_mode`` is still ``'Unicycle'``); the agent class differs, not the env."""
     if name in ("Unicycle", "UnicycleBarrier"):
@@ -118,5 +118,5 @@ def make_env(name, seed=0):
     if name == "SimulatedCars":
         return SimulatedCarsSpec(seed)
     if name == "Pvtol":
-        return PvtolSpec(seed)
+        return PvtolSpec(seed, **overrides)
     raise Exception("Dynamics mode not supported.")

@@ -31,7 +31,8 @@ from .model import BarrierNetwork, GaussianPolicy, LyaNetwork, QNetwork
 from .tasks import TASKS
 from .utils import to_tensor
 
-DYNAMICS_MODE = {'Unicycle': {'n_s': 3, 'n_u': 2}, 'SimulatedCars': {'n_s': 10, 'n_u': 1}}
+DYNAMICS_MODE = {'Unicycle': {'n_s': 3, 'n_u': 2}, 'SimulatedCars': {'n_s': 10, 'n_u': 1},
+                 'Pvtol': {'n_s': 6, 'n_u': 2}}
 l_p = 0.03
 
 
@@ -174,14 +175,18 @@ class SAC_CBF_CLF(object):
         self.h_extra = list(self.BarrierNet.attach(self.ar_c)) if task.has_signal else []
         (self.h_p,) = self.policy.attach(self.ar_a)
         self.h_pols = [self.h_p]
+        # a backup controller stepped on its own schedule (Pvtol: every 20th update) needs its own Adam state
+        self.ar_b = Arena(dev, self.n_grad_slabs) if (task.n_pol == 2 and task.backup_interval > 1) else None
+        ar_backup = self.ar_b if self.ar_b is not None else self.ar_a
         if task.n_pol == 2:
-            (self.h_b,) = self.backup_policy.attach(self.ar_a)
+            (self.h_b,) = self.backup_policy.attach(ar_backup)
             self.h_pols.append(self.h_b)
         self.ar_a.add_group([self.log_alpha])
         if task.n_pol == 2:
-            self.ar_a.add_group([self.backup_log_alpha])
+            ar_backup.add_group([self.backup_log_alpha])
         self.h_node = list(self.neural_ode_model.attach(self.ar_n))
-        for ar in (self.ar_c, self.ar_a, self.ar_n):
+        self.arenas = [a for a in (self.ar_c, self.ar_a, self.ar_b, self.ar_n) if a is not None]
+        for ar in self.arenas:
             ar.finalize()
         self.ar_c.hard_update_target()
         self.policy.to(dev)
@@ -190,8 +195,16 @@ class SAC_CBF_CLF(object):
         self.h_crit = [self.h_q1, self.h_q2, self.h_l] + self.h_extra       # one Adam group, lr 4e-4
         for h in self.h_crit + self.h_pols + self.h_node:
             h.bind()
-        self.la_off = self.ar_a.offset_of[id(self.log_alpha)]
-        self.la_stride = (self.ar_a.offset_of[id(self.backup_log_alpha)] - self.la_off) if task.n_pol == 2 else 0
+        la_off = self.ar_a.offset_of[id(self.log_alpha)]
+        G = types.SimpleNamespace
+        if self.ar_b is not None:       # two Adam groups: [policy, log_alpha] and [backup policy, backup log_alpha]
+            self.actor_groups = [G(arena=self.ar_a, first=0, count=1, la_off=la_off, la_stride=0),
+                                 G(arena=self.ar_b, first=1, count=1, la_stride=0,
+                                   la_off=self.ar_b.offset_of[id(self.backup_log_alpha)])]
+        else:
+            stride = (self.ar_a.offset_of[id(self.backup_log_alpha)] - la_off) if task.n_pol == 2 else 0
+            self.actor_groups = [G(arena=self.ar_a, first=0, count=task.n_pol, la_off=la_off, la_stride=stride)]
+        self.pol_arena = [self.ar_a] + ([ar_backup] if task.n_pol == 2 else [])
         # target networks as modules over the Polyak buffer (state_dict / inspection)
         self.critic_target = _TargetView(self.critic, self.ar_c)
         self.lyapunovNet_target = _TargetView(self.lyapunovNet, self.ar_c)
@@ -229,7 +242,7 @@ class SAC_CBF_CLF(object):
         the global size) and gradients / constraint sums are all-reduced (nlbac_amd/parallel.py)."""
         from ..parallel import DataParallel
         self.dp = DataParallel(dist, group)
-        for ar in (self.ar_c, self.ar_a, self.ar_n):
+        for ar in self.arenas:
             self.dp.broadcast_(ar.theta)
         self.ar_c.hard_update_target()
         self.dp.broadcast_(self.sc)
@@ -306,6 +319,11 @@ class SAC_CBF_CLF(object):
     def augmented_term(self):
         return float(self._scalars()[SC.SC_RHO_F64:SC.SC_RHO_F64 + 2].view(np.float64)[0])
 
+    @property
+    def backup_augmented_term(self):
+        """Pvtol keeps a separate coefficient for the backup controller (P:59, 1033-1034)."""
+        return float(self._scalars()[SC.SC_BRHO_F64:SC.SC_BRHO_F64 + 2].view(np.float64)[0])
+
     def get_control_bounds(self):
         u_min = torch.tensor(self.env.safe_action_space.low).to(self.device)
         u_max = torch.tensor(self.env.safe_action_space.high).to(self.device)
@@ -334,13 +352,15 @@ class SAC_CBF_CLF(object):
         return self._select(self.backup_policy, state, evaluate, warmup)
 
     # ------------------------------------------------------------------ update
-    def update_parameters(self, memory, batch_size, updates, dynamics_model, NODE_memory, NODE_model_update_interval):
+    def update_parameters(self, memory, batch_size, updates, dynamics_model, NODE_memory, NODE_model_update_interval,
+                          i_episode=None):
         """Same contract as the reference (sac_cbf_clf.py:181-319): one sampled
         minibatch -> 6 floats.  ``dynamics_model`` is accepted for signature
-        parity; obs->state runs on the device."""
+        parity; obs->state runs on the device.  ``i_episode`` is the Pvtol copy's trailing argument (P:181):
+        its NODE fit stops after episode 100 (P:205)."""
         batch = memory.sample(batch_size=batch_size)
         node_rows = None
-        if updates % NODE_model_update_interval == 0:
+        if updates % NODE_model_update_interval == 0 and self.task.fit_due(i_episode):
             nb = min(NODE_memory.position, 32768)
             node_rows = NODE_memory.sample(batch_size=nb)
         return self.update_from_host(batch, updates, node_rows)
@@ -447,16 +467,21 @@ class SAC_CBF_CLF(object):
         return g
 
     # -- the update proper --------------------------------------------------------
-    def _plan(self, ws):
+    def _plan(self, ws, NP=None):
         """ctypes launch descriptors of one workspace: every pointer is static (arenas, workspace tensors),
-        so they are built once; an update is then a plain sequence of C calls."""
-        if ws.plan is not None:
-            return ws.plan
+        so they are built once (per number of controllers updated: Pvtol trains its backup every 20th update);
+        an update is then a plain sequence of C calls."""
+        NP = NP or self.task.n_pol
+        if ws.plan is None:
+            ws.plan = {}
+        if NP in ws.plan:
+            return ws.plan[NP]
         B, lay = ws.B, self.lay
         mb = ws.mb.data_ptr()
         LD, Do, Da, Dl = lay.LD, lay.obs_dim, lay.act_dim, lay.lya_dim
         col = lambda c: mb + 4 * c
-        p_obs, p_act, p_cen, p_ncen, p_nobs = col(lay.obs), col(lay.act), col(lay.lya), col(lay.nlya), col(lay.nobs)
+        lc, lnc = self.task.lya_train_cols(lay)       # inputs the Lyapunov critic is regressed on
+        p_obs, p_act, p_cen, p_ncen, p_nobs = col(lay.obs), col(lay.act), col(lc), col(lnc), col(lay.nobs)
 
         def x(io, i, p0, d0, ld0, p1=None, d1=0, ld1=0):
             io[i].x0, io[i].x0_dim, io[i].x0_ld = p0, d0, ld0
@@ -465,7 +490,7 @@ class SAC_CBF_CLF(object):
         P = types.SimpleNamespace()
         P.p_obs, P.p_rew, P.p_con, P.p_mask, P.LD = p_obs, col(lay.rew), col(lay.con), col(lay.mask), LD
         q1, q2, l, pi = self.h_q1, self.h_q2, self.h_l, self.h_p
-        NP, NX = self.task.n_pol, len(self.h_extra)
+        P.NP, NX = NP, len(self.h_extra)
         # A: pi(s')
         P.n_pol, P.io_pol_next = mlp_array([pi.desc]), io_array(1)
         x(P.io_pol_next, 0, p_nobs, Do, LD)
@@ -501,14 +526,25 @@ class SAC_CBF_CLF(object):
             x(io, i, p_obs, Do, LD, p_act, Da, LD)
         x(io, 2, p_cen, Dl, LD)
         # C: both actors (forward and backward share one descriptor)
-        P.n_act = mlp_array([h.desc for h in self.h_pols])
+        def act_io(io, j, i):            # entry j of an io array describes controller i
+            x(io, j, p_obs, Do, LD)
+            io[j].y, io[j].y_ld = ws.heads2[i * B:].data_ptr(), 2 * Da
+            io[j].acts, io[j].dz = ws.acts_p[i].data_ptr(), ws.dz_p[i].data_ptr()
+            io[j].dy, io[j].dy_ld = ws.dheads2[i * B:].data_ptr(), 2 * Da
+            io[j].grad = self.pol_arena[i].grad.data_ptr()
+        P.n_act = mlp_array([h.desc for h in self.h_pols[:NP]])
         io = P.io_act = io_array(NP)
         for i in range(NP):
-            x(io, i, p_obs, Do, LD)
-            io[i].y, io[i].y_ld = ws.heads2[i * B:].data_ptr(), 2 * Da
-            io[i].acts, io[i].dz = ws.acts_p[i].data_ptr(), ws.dz_p[i].data_ptr()
-            io[i].dy, io[i].dy_ld = ws.dheads2[i * B:].data_ptr(), 2 * Da
-            io[i].grad = self.ar_a.grad.data_ptr()
+            act_io(io, i, i)
+        P.act_groups = []                # per Adam group: the nets whose weight gradients land in its arena
+        for g in self.actor_groups:
+            cnt = min(g.count, NP - g.first)
+            if cnt <= 0:
+                continue
+            gio = io_array(cnt)
+            for j in range(cnt):
+                act_io(gio, j, g.first + j)
+            P.act_groups.append((g, cnt, mlp_array([h.desc for h in self.h_pols[g.first:g.first + cnt]]), gio))
         # C: Q(s, pi) for primary / backup + V(current Lyapunov input)
         extra = self.task.extra_value_nets()
         P.n_q5 = mlp_array([q1.desc, q2.desc] * NP + [l.desc] + [h.desc for h in extra])
@@ -524,14 +560,14 @@ class SAC_CBF_CLF(object):
         self.task.value_now_io(ws, io, 2 * NP)
         self.task.extra_value_io(ws, io, 2 * NP + 1)
         self.task.plan(ws, P)
-        ws.plan = P
+        ws.plan[NP] = P
         return P
 
     def auglag(self, ws, n_cbf, lam_upd):
         """required_matrix, ratio, lambda / rho updates and loss coefficients from the constraint partial sums
         (all-reduced first under data parallelism: they enter the loss nonlinearly)."""
         s, call = stream_ptr(), _lib.call
-        NP = self.task.n_pol
+        NP = ws.np_now
         ncol = n_cbf + 1 + (n_cbf if NP == 2 else 0)
         p_part_c, n_part = ws.part_c.data_ptr(), ws.nblk
         ws.p_part_q, ws.n_part_q = ws.part_q.data_ptr(), ws.nblk
@@ -543,20 +579,24 @@ class SAC_CBF_CLF(object):
             self.dp.all_reduce_(xs)
             p_part_c, n_part = xs.data_ptr(), 1
             ws.p_part_q, ws.n_part_q = xs.data_ptr() + 4 * 32, 1
-        call("nlbac_auglag", p_part_c, n_part, n_cbf, 1, float(self.batch_size), lam_upd, self.task.ratio_mode,
-             self.task.backup_mode, 0.01, self.task.lam_hi, self.sc.data_ptr(), s)
+        call("nlbac_auglag", p_part_c, n_part, n_cbf, 1, float(self.batch_size), lam_upd, ws.blam_upd,
+             self.task.ratio_mode, self.task.backup_mode if NP == 2 else 0, 0.01, self.task.lam_hi,
+             self.sc.data_ptr(), s)
 
     def update_on_device(self, ws, updates, sync=True):
         """Minibatch already in ``ws.mb``; returns the reference's 6 floats."""
         if self._noise is not None:
             assert len(self._noise) == self.task.n_eps, "set_noise needs %d draws" % self.task.n_eps
-            for i in range(self.task.n_eps):
-                ws.eps[i].copy_(self._noise[i].to(self.device).reshape(ws.eps[i].shape))
+            order = self.task.eps_order or range(self.task.n_eps)     # device slot -> reference draw index
+            for i, j in enumerate(order):
+                ws.eps[i].copy_(self._noise[j].to(self.device).reshape(ws.eps[i].shape))
             self._noise = None
         else:
             ws.eps.normal_()
         soft = (updates % self.target_update_interval == 0)
         lam_upd = 1 if updates % self.Lagrangian_multiplier_update_interval == 0 else 0
+        NP = ws.np_now = self.task.n_pol_now(updates)
+        ws.blam_upd = self.task.backup_lam_due(updates, self.Lagrangian_multiplier_update_interval)
         if not (self.use_graphs and self.world == 1 and self.task.graph_ok) or ws.warm < 1:
             ws.warm += 1
             self._upd_part1(ws, soft)
@@ -564,7 +604,7 @@ class SAC_CBF_CLF(object):
         else:
             # hipGraph replay: part 1 up to the dopri5 accept decision, one 256-byte read, part 2
             g = ws.graphs
-            k1, k2 = ("p1", soft, self.solver), ("p2", lam_upd, self.solver)
+            k1, k2 = ("p1", soft, self.solver, NP), ("p2", lam_upd, ws.blam_upd, self.solver, NP)
             if k1 not in g:
                 g[k1] = self._capture(lambda: self._upd_part1(ws, soft))
             g[k1].replay()
@@ -589,7 +629,8 @@ class SAC_CBF_CLF(object):
         B, A = ws.B, self.lay.act_dim
         G = B * self.world                      # rows the batch means run over
         s = stream_ptr()
-        P = self._plan(ws)
+        NP = ws.np_now
+        P = self._plan(ws, NP)
         LD = P.LD
         sc = self.sc.data_ptr()
         call = _lib.call
@@ -624,7 +665,6 @@ class SAC_CBF_CLF(object):
             pack(self.h_crit, target=True)
 
         # ---- C. actors: sample, Q(s, pi), then the rollout of the learned dynamics -----
-        NP = self.task.n_pol
         call("nlbac_mlp_fwd", P.n_act, P.io_act, NP, B, s)
         eps2 = ws.eps[1:1 + NP]                                # (NP,B,A) == (NP*B,A)
         call("nlbac_gauss_sample_fwd", ws.heads2.data_ptr(), 2 * A, eps2.data_ptr(), p_scale, p_bias, A, NP * B,
@@ -639,11 +679,11 @@ class SAC_CBF_CLF(object):
         B, A, Do = ws.B, self.lay.act_dim, self.lay.obs_dim
         G = B * self.world
         s = stream_ptr()
-        P = self._plan(ws)
+        NP = ws.np_now
+        P = self._plan(ws, NP)
         sc = self.sc.data_ptr()
         call = _lib.call
         p_scale = self.policy.action_scale.data_ptr()
-        NP = self.task.n_pol
         eps2 = ws.eps[1:1 + NP]
         du2, du_ld = self.task.loss_and_backward(ws, P, lam_upd, assume_single)
 
@@ -652,26 +692,27 @@ class SAC_CBF_CLF(object):
         call("nlbac_gauss_sample_bwd", ws.heads2.data_ptr(), 2 * A, eps2.data_ptr(), p_scale, A,
              NP * B, B, ws.dxq[0].data_ptr() + 4 * Do, D, ws.dxq[1].data_ptr() + 4 * Do, D, du2.data_ptr(), du_ld,
              sc + 4 * SC.SC_ALPHA, 1.0 / G, ws.dheads2.data_ptr(), 2 * A, s)
-        a = self.ar_a
         call("nlbac_mlp_bwd_data", P.n_act, P.io_act, NP, B, s)
-        bwd_weights(P.n_act, P.io_act, NP, B, a.n_slabs, a.n, self.device)
-        la = a.theta.data_ptr() + 4 * self.la_off
         tune = self.automatic_entropy_tuning
         p_part_q, n_part = ws.p_part_q, ws.n_part_q
+        for g, cnt, nets, gio in P.act_groups:
+            a = g.arena
+            bwd_weights(nets, gio, cnt, B, a.n_slabs, a.n, self.device)
+            la = a.theta.data_ptr() + 4 * g.la_off
 
-        def alpha_grads(p_grad):
-            # policy_loss_1 / alpha losses from the (global) partial sums; d log_alpha goes straight into
-            # the gradient the Adam step reads (it is already a global mean: it must not be all-reduced)
-            call("nlbac_actor_scalars", p_part_q, n_part, G, NP, self.target_entropy, la, self.la_stride,
-                 p_grad + 4 * self.la_off, sc, s)
-            if not tune:
-                z = torch.zeros(1, device=self.device)
-                for off in [self.la_off + k * self.la_stride for k in range(NP)]:
-                    call("nlbac_axpby", 0.0, z.data_ptr(), 0.0, None, 1, p_grad + 4 * off, s)
-        self._adam(a, self.lr, a.n_slabs, before_step=alpha_grads)
-        pack(self.h_pols)
-        if self.automatic_entropy_tuning:
-            call("nlbac_alpha_refresh", la, self.la_stride, NP, sc, s)
+            def alpha_grads(p_grad, g=g, cnt=cnt, la=la):
+                # policy_loss_1 / alpha losses from the (global) partial sums; d log_alpha goes straight into
+                # the gradient the Adam step reads (it is already a global mean: it must not be all-reduced)
+                call("nlbac_actor_scalars", p_part_q, n_part, G, g.first, cnt, self.target_entropy, la, g.la_stride,
+                     p_grad + 4 * g.la_off, sc, s)
+                if not tune:
+                    z = torch.zeros(1, device=self.device)
+                    for off in [g.la_off + k * g.la_stride for k in range(cnt)]:
+                        call("nlbac_axpby", 0.0, z.data_ptr(), 0.0, None, 1, p_grad + 4 * off, s)
+            self._adam(a, self.lr, a.n_slabs, before_step=alpha_grads)
+            if tune:
+                call("nlbac_alpha_refresh", la, g.la_stride, g.first, cnt, sc, s)
+        pack(self.h_pols[:NP])
 
     # ------------------------------------------------------------ checkpoints
     def save_model(self, output):

@@ -31,12 +31,27 @@ class _Task:
     backup_mode = 1           # nlbac_auglag: 0 no backup, 1 backup shares rho, 2 own rho
     has_signal = False        # replay rows carry a barrier signal (learned-barrier copies)
     n_extra_critics = 0       # critic-type nets trained beside Q1, Q2, L (BarrierNet)
+    backup_interval = 1       # the backup controller is trained every n-th update (Pvtol: 20)
+    eps_order = None          # device noise slot -> index in the reference's draw order (None: identical)
 
     def __init__(self, agent, env, args):
         self.agent, self.env = agent, env
 
     def z(self, *shape):
         return torch.zeros(*shape, dtype=torch.float32, device=self.agent.device)
+
+    def n_pol_now(self, updates):
+        return self.n_pol
+
+    def backup_lam_due(self, updates, interval):
+        return 1 if updates % interval == 0 else 0
+
+    def fit_due(self, i_episode):
+        return True
+
+    def lya_train_cols(self, lay):
+        """Columns of the minibatch row the Lyapunov critic is regressed on: (input, next input)."""
+        return lay.lya, lay.nlya
 
     # value-only nets riding in the Q(s, pi) launch besides V(current Lyapunov input)
     def extra_value_nets(self):
@@ -366,4 +381,164 @@ class CarsTask(_Task):
         self.fit_solver.forward_begin(w["st"], w["u"], 1, N, a.solver, self.env.dt, a.atol, a.rtol)
 
 
-TASKS = {"Unicycle": UnicycleTask, "SimulatedCars": CarsTask, "UnicycleBarrier": UnicycleBarrierTask}
+# =====================================================================================
+class PvtolTask(_Task):
+    """Pvtol (P/sac_cbf_clf/sac_cbf_clf.py:376-1048): control-affine NODE on the six dynamic states, three-step
+    rollout (the second and third actions are re-sampled from the predicted observations and detached), the safety
+    operator's position follows the predicted x, relative-degree-3 CBFs (5 hazards, 2 operator distances, y_max,
+    y_min) + CLF on the predicted observation.  The backup controller is trained every ``backup_update_interval``
+    updates (P:282) with its own augmented term and Adam state."""
+    name = "Pvtol"
+    obs_dim, act_dim, lya_dim, n_s = 11, 2, 11, 6
+    n_eps = 7
+    # reference draw order: next-obs, obs, pi_next, pi_next_next [, backup, backup pi_next, backup pi_next_next];
+    # device slots keep each step's (primary, backup) draws adjacent
+    eps_order = [0, 1, 4, 2, 5, 3, 6]
+    lam_hi, ratio_mode, backup_mode = 400.0, 2, 2
+    GOAL = (4.5, 4.5)
+
+    def __init__(self, agent, env, args):
+        super().__init__(agent, env, args)
+        self.num_cbfs = len(env.hazard_locations) + 4
+        self.gamma_l = 0.1
+        self.backup_interval = int(getattr(args, "backup_update_interval", 20))
+        agent.backup_update_interval = self.backup_interval
+
+    def build_node(self):
+        return NeuralODEModel(6, 6, 12)
+
+    def n_pol_now(self, updates):
+        return 2 if updates % self.backup_interval == 0 else 1
+
+    def backup_lam_due(self, updates, interval):
+        return 1 if updates % (interval * self.backup_interval) == 0 else 0
+
+    def fit_due(self, i_episode):
+        return i_episode is None or i_episode <= 100
+
+    def lya_train_cols(self, lay):
+        return lay.obs, lay.nobs          # P:243-252: the Lyapunov critic is regressed on observations
+
+    def setup(self):
+        a = self.agent
+        self.hazards = torch.tensor(np.asarray(self.env.hazard_locations), dtype=torch.float32,
+                                    device=a.device).contiguous()
+        self.steps = [AffineNodeSolver(a.neural_ode_model, a.device) for _ in range(3)]
+        self.fit_solver = AffineNodeSolver(a.neural_ode_model, a.device)
+        self.solvers = self.steps + [self.fit_solver]
+
+    def alloc(self, ws):
+        B, z, H = ws.B, self.z, self.agent.hidden
+        ws.st6, ws.op0 = z(B, 6), z(B)
+        ws.y0 = z(2 * B, 6)
+        ws.x1, ws.x2, ws.x3 = z(2 * B, 6), z(2 * B, 6), z(2 * B, 6)
+        ws.obs1, ws.obs2 = z(2 * B, 11), z(2 * B, 11)
+        ws.op1, ws.op2 = z(2 * B), z(2 * B)
+        ws.heads_n1, ws.heads_n2 = z(2 * B, 4), z(2 * B, 4)
+        ws.a1, ws.a2, ws.logp_nx = z(2 * B, 2), z(2 * B, 2), z(2 * B)
+        ws.V, ws.V1, ws.dV1 = z(B), z(B), z(B)
+        ws.acts_v1 = z(2, B, H)
+        ws.dobs1 = z(B, 11)
+        ws.matr, ws.bmatr = z(B, self.num_cbfs + 1), z(B, self.num_cbfs)
+        ws.part_c = z(ws.nblk, 2 * self.num_cbfs + 1)
+        ws.dx1, ws.dx2, ws.dx3 = z(2 * B, 6), z(2 * B, 6), z(2 * B, 6)
+
+    def value_now_io(self, ws, io, i):
+        lay = self.agent.lay
+        io[i].x0, io[i].x0_dim, io[i].x0_ld = ws.mb.data_ptr() + 4 * lay.lya, self.lya_dim, lay.LD
+        io[i].y, io[i].y_ld = ws.V.data_ptr(), 1
+
+    def plan(self, ws, P):
+        a, B, NP = self.agent, ws.B, P.NP
+        P.n_l = mlp_array([a.h_l.desc])
+        io = P.io_v1 = io_array(1)                 # V(obs(x_t+1)) forward + data backward
+        io[0].x0, io[0].x0_dim, io[0].x0_ld = ws.obs1.data_ptr(), 11, 11
+        io[0].y, io[0].y_ld = ws.V1.data_ptr(), 1
+        io[0].acts = ws.acts_v1.data_ptr()
+        io[0].dy, io[0].dy_ld = ws.dV1.data_ptr(), 1
+        io[0].dx, io[0].dx_ld = ws.dobs1.data_ptr(), 11
+        P.n_pols = mlp_array([h.desc for h in a.h_pols[:NP]])
+        P.io_nx = []
+        for obs, heads in ((ws.obs1, ws.heads_n1), (ws.obs2, ws.heads_n2)):
+            io = io_array(NP)                      # each controller on its own rows of the predicted observation
+            for i in range(NP):
+                io[i].x0, io[i].x0_dim, io[i].x0_ld = obs[i * B:].data_ptr(), 11, 11
+                io[i].y, io[i].y_ld = heads[i * B:].data_ptr(), 4
+            P.io_nx.append(io)
+
+    def rollout_begin(self, ws, P):
+        a, s = self.agent, stream_ptr()
+        B, NP = ws.B, P.NP
+        _lib.call("nlbac_pvtol_state", ws.mb.data_ptr(), a.lay.LD, B, ws.st6.data_ptr(), ws.op0.data_ptr(), s)
+        for p in range(NP):
+            ws.y0[p * B:(p + 1) * B].copy_(ws.st6)
+        self.steps[0].forward_begin(ws.y0[:NP * B], ws.pi2[:NP * B], NP, B, a.solver, float(self.env.dt), a.atol,
+                                    a.rtol)
+
+    def loss_and_backward(self, ws, P, lam_upd, assume_single):
+        a, s, call = self.agent, stream_ptr(), _lib.call
+        B, NP, sc, dt, env = ws.B, P.NP, a.sc.data_ptr(), float(self.env.dt), self.env
+        n = NP * B
+        pol = a.policy
+        p_scale, p_bias = pol.action_scale.data_ptr(), pol.action_bias.data_ptr()
+        follow, (gx, gy) = float(env.safety_operator_follow), self.GOAL
+        s1, s2, s3 = self.steps
+        ws.x1[:n].copy_(s1.forward_finish())
+        # u_(t+1), u_(t+2) ~ pi(. | get_obs(x)), detached (P:474-526)
+        call("nlbac_pvtol_obs_fwd", ws.x1.data_ptr(), ws.op0.data_ptr(), B, follow, gx, gy, n, ws.obs1.data_ptr(), 11,
+             ws.op1.data_ptr(), s)
+        call("nlbac_mlp_fwd", P.n_pols, P.io_nx[0], NP, B, s)
+        call("nlbac_gauss_sample_fwd", ws.heads_n1.data_ptr(), 4, ws.eps[3:3 + NP].data_ptr(), p_scale, p_bias, 2, n,
+             ws.a1.data_ptr(), 2, ws.logp_nx.data_ptr(), s)
+        ws.x2[:n].copy_(s2.forward(ws.x1[:n], ws.a1[:n], NP, B, a.solver, dt, a.atol, a.rtol))
+        call("nlbac_pvtol_obs_fwd", ws.x2.data_ptr(), ws.op1.data_ptr(), n, follow, gx, gy, n, ws.obs2.data_ptr(), 11,
+             ws.op2.data_ptr(), s)
+        call("nlbac_mlp_fwd", P.n_pols, P.io_nx[1], NP, B, s)
+        call("nlbac_gauss_sample_fwd", ws.heads_n2.data_ptr(), 4, ws.eps[5:5 + NP].data_ptr(), p_scale, p_bias, 2, n,
+             ws.a2.data_ptr(), 2, ws.logp_nx.data_ptr(), s)
+        ws.x3[:n].copy_(s3.forward(ws.x2[:n], ws.a2[:n], NP, B, a.solver, dt, a.atol, a.rtol))
+        call("nlbac_mlp_fwd", P.n_l, P.io_v1, 1, B, s)
+        hz = self.hazards.data_ptr()
+        call("nlbac_pvtol_constraints_fwd", ws.st6.data_ptr(), ws.op0.data_ptr(), ws.x1.data_ptr(), ws.x2.data_ptr(),
+             ws.x3.data_ptr(), ws.V.data_ptr(), ws.V1.data_ptr(), hz, len(env.hazard_locations),
+             1.2 * float(env.hazards_radius), 0.9 * float(env.operator_dist), float(env.y_max), float(env.y_min),
+             follow, float(a.gamma_b), self.gamma_l, B, NP, ws.matr.data_ptr(), ws.bmatr.data_ptr(),
+             ws.part_c.data_ptr(), s)
+        a.auglag(ws, self.num_cbfs, lam_upd)
+        call("nlbac_pvtol_constraints_bwd", ws.matr.data_ptr(), ws.bmatr.data_ptr(), ws.x1.data_ptr(),
+             ws.x2.data_ptr(), ws.x3.data_ptr(), hz, len(env.hazard_locations), follow, float(a.gamma_b),
+             float(a.batch_size), B, NP, sc, ws.dx1.data_ptr(), ws.dx2.data_ptr(), ws.dx3.data_ptr(),
+             ws.dV1.data_ptr(), s)
+        call("nlbac_mlp_bwd_data", P.n_l, P.io_v1, 1, B, s)               # dV1 -> d obs(x_t+1) (primary rows)
+        call("nlbac_pvtol_obs_bwd", ws.x1.data_ptr(), ws.dobs1.data_ptr(), 11, follow, gx, gy, B, ws.dx1.data_ptr(),
+             1, s)
+        # x_t+3 and x_t+2 depend on the first action only through the state handed from step to step
+        _, dy0 = s3.backward(ws.dx3[:n], need_du=False, need_dy0=True)
+        call("nlbac_axpby", 1.0, ws.dx2.data_ptr(), 1.0, dy0.data_ptr(), n * 6, ws.dx2.data_ptr(), s)
+        _, dy0 = s2.backward(ws.dx2[:n], need_du=False, need_dy0=True)
+        call("nlbac_axpby", 1.0, ws.dx1.data_ptr(), 1.0, dy0.data_ptr(), n * 6, ws.dx1.data_ptr(), s)
+        du, _ = s1.backward(ws.dx1[:n], need_du=True)
+        return du, self.act_dim
+
+    def first_step_done(self):
+        return self.steps[0].first_step_done()
+
+    # -- NODE fit (P/model.py:224-266 via P/sac_cbf_clf.py:205-219) --------------------------------
+    def fit_inputs(self, rows):
+        lay = self.agent.lay
+        return (rows.data_ptr(), rows.shape[1], rows[:, lay.act:lay.act + 2], rows.data_ptr() + 4 * lay.nobs,
+                rows.shape[1], rows.shape[0])
+
+    def fit_ws(self, N):
+        z = self.z
+        return dict(st=z(N, 6), nst=z(N, 6), dpred=z(N, 6), part=z((N + 255) // 256), u=z(N, 2))
+
+    def fit_part1(self, w, p_obs, obs_ld, p_nobs, nobs_ld, N):
+        a, s = self.agent, stream_ptr()
+        _lib.call("nlbac_pvtol_state", p_obs, obs_ld, N, w["st"].data_ptr(), None, s)
+        _lib.call("nlbac_pvtol_state", p_nobs, nobs_ld, N, w["nst"].data_ptr(), None, s)
+        self.fit_solver.forward_begin(w["st"], w["u"], 1, N, a.solver, self.env.dt, a.atol, a.rtol)
+
+
+TASKS = {"Unicycle": UnicycleTask, "SimulatedCars": CarsTask, "UnicycleBarrier": UnicycleBarrierTask,
+         "Pvtol": PvtolTask}

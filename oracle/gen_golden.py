@@ -106,7 +106,7 @@ def summarize(prefix, vec, out, n_head=48):
 def run_case(S, env_name, solver, B, hidden=256, seed=0, node_B=512, calls=None):
     cfg = CFG[env_name]
     calls = calls or cfg.get("calls", (0, 1, 8))
-    env = make_env(env_name, seed)
+    env = synth.fixture_env(env_name, seed)
     args = O.Args(batch_size=B, hidden_size=hidden, seed=seed)
     args.gamma_b = cfg["gamma_b"]
     agent = S.SAC_CBF_CLF(cfg["obs"], env.action_space, env, args)

@@ -27,7 +27,7 @@ def golden_env(g):
 def case_inputs(g, ci, transitions=None):
     """(batch dict of float32 tensors, eps list, node_batch tuple, updates)."""
     seed, env_name = int(g["meta_seed"]), golden_env(g)
-    env = make_env(env_name, seed)
+    env = synth.fixture_env(env_name, seed)
     tr = transitions if transitions is not None else synth.transitions(env_name, 4096, seed=seed + 1, env=env)
     idx, nidx = g["c%d_idx" % ci], g["c%d_nidx" % ci]
     B = int(g["meta_B"])

@@ -21,7 +21,7 @@ def make_agent(B, hidden, seed, solver, env_name="Unicycle", gamma_b=None):
         from nlbac_amd.neural_barrier_certificate.sac_cbf_clf.sac_cbf_clf import SAC_CBF_CLF
     else:
         from nlbac_amd.sac_cbf_clf.sac_cbf_clf import SAC_CBF_CLF
-    env = make_env(env_name, seed)
+    env = synth.fixture_env(env_name, seed)
     args = Args(batch_size=B, hidden_size=hidden, seed=seed, cuda=True)
     if gamma_b is not None:
         args.gamma_b = gamma_b
@@ -47,13 +47,13 @@ def make_agent(B, hidden, seed, solver, env_name="Unicycle", gamma_b=None):
 def params_close(v, ov, step_bound, name):
     """Post-Adam parameters.  Adam divides by |g|+1e-8 (first step: the update is lr*g/(|g|+1e-8)), so the few
     entries whose gradient is ~1e-8 turn fp32 rounding differences of the gradient into O(lr) differences of the
-    update.  Bar: every entry within TOL of the tensor's scale, except at most 0.1 % of the entries, which must
+    update.  Bar: every entry within TOL of the tensor's scale, except at most 0.5 % of the entries, which must
     still be within the accumulated Adam step bound (lr per update)."""
     v, ov = np.asarray(v, dtype=np.float64), np.asarray(ov, dtype=np.float64)
     err = np.abs(v - ov)
     scale = np.abs(ov).max()
     bad = err > TOL * scale
-    assert bad.mean() <= 1e-3, "%s: %.4f %% of the entries off by more than %.0e" % (name, 100 * bad.mean(), TOL)
+    assert bad.mean() <= 5e-3, "%s: %.4f %% of the entries off by more than %.0e" % (name, 100 * bad.mean(), TOL)
     assert err.max() <= step_bound, "%s: max abs err %.3e beyond the Adam step bound %.1e" % (name, err.max(), step_bound)
 
 
@@ -70,8 +70,9 @@ def flat_grad(agent, arena, module, n_slabs=None):
 
 
 CASES = [("Unicycle", False), ("Unicycle", True), ("SimulatedCars", False), ("UnicycleBarrier", False),
-         ("UnicycleBarrier", True)]
-IDS = ["unicycle-eager", "unicycle-hipgraph", "cars-eager", "nbc-unicycle-eager", "nbc-unicycle-hipgraph"]
+         ("UnicycleBarrier", True), ("Pvtol", False)]
+IDS = ["unicycle-eager", "unicycle-hipgraph", "cars-eager", "nbc-unicycle-eager", "nbc-unicycle-hipgraph",
+       "pvtol-eager"]
 
 
 @pytest.mark.parametrize("env_name,graphs", CASES, ids=IDS)
@@ -87,7 +88,7 @@ def test_update_matches_reference_fixture_and_oracle(solver, B, env_name, graphs
     agent.use_graphs = graphs      # call 0 warms up eagerly, calls 1 and 2 capture + replay hipGraphs
     oargs = O.Args(batch_size=B, hidden_size=hidden, seed=seed)
     oargs.gamma_b = gamma_b
-    oracle = O.make_oracle(make_env(env_name, seed), oargs, synth.agent_weights(env_name, hidden, seed), solver=solver)
+    oracle = O.make_oracle(synth.fixture_env(env_name, seed), oargs, synth.agent_weights(env_name, hidden, seed), solver=solver)
     tr = synth.transitions(env_name, 4096, seed=seed + 1, env=env)
     n_cbf = agent.num_cbfs
     lr = dict(critic=4e-4, policy=3e-4, node=1e-3)
@@ -117,7 +118,14 @@ def test_update_matches_reference_fixture_and_oracle(solver, B, env_name, graphs
         vec_close(xn[:B], g[p + "x_next"], TOL, p + "x_next vs golden")
         if backup:
             vec_close(xn[B:], g[p + "bx_next"], TOL, p + "bx_next vs golden")
-        if p + "x_next2" in g.files:
+        if env_name == "Pvtol":
+            vec_close(ws.x2[:B].cpu().numpy(), g[p + "x_next2"], TOL, p + "x_next2 vs golden")
+            vec_close(ws.x3[:B].cpu().numpy(), g[p + "x_next3"], TOL, p + "x_next3 vs golden")
+            if backup:
+                vec_close(ws.x3[B:].cpu().numpy(), g[p + "bx_next3"], TOL, p + "bx_next3 vs golden")
+            assert abs(agent.backup_augmented_term - float(g[p + "backup_augmented_term"])) < 1e-12
+            vec_close(agent.backup_lambda_values, g[p + "backup_lambdas"], TOL, p + "blambdas (every call)")
+        elif p + "x_next2" in g.files:
             xn2 = agent.task.solver2.ctx["out"].cpu().numpy()
             vec_close(xn2[:B], g[p + "x_next2"], TOL, p + "x_next2 vs golden")
             vec_close(xn2[B:], g[p + "bx_next2"], TOL, p + "bx_next2 vs golden")
@@ -137,7 +145,7 @@ def test_update_matches_reference_fixture_and_oracle(solver, B, env_name, graphs
                 np.testing.assert_allclose(st[:, 1], gs[:, 1], rtol=5e-2, atol=1e-4)
                 np.testing.assert_array_equal(st[:, 2], gs[:, 2])
         for name, ar, mod in (("critic", agent.ar_c, agent.critic), ("lya", agent.ar_c, agent.lyapunovNet),
-                              ("policy", agent.ar_a, agent.policy), ("backup", agent.ar_a, agent.backup_policy),
+                              ("policy", agent.ar_a, agent.policy), ("backup", agent.pol_arena[-1], agent.backup_policy),
                               ("barrier", agent.ar_c, agent.BarrierNet), ("node", agent.ar_n, agent.neural_ode_model)):
             if p + "g_%s_norm" % name not in g.files:
                 continue

@@ -75,7 +75,7 @@ def test_exchange_layer_world2_cpu(tmp_path):
 
 @pytest.mark.gpu
 @pytest.mark.parametrize("env_name,solver", [("Unicycle", "euler"), ("Unicycle", "dopri5"), ("SimulatedCars", "rk4"),
-                                             ("SimulatedCars", "dopri5"), ("UnicycleBarrier", "rk4")])
+                                             ("SimulatedCars", "dopri5"), ("UnicycleBarrier", "rk4"), ("Pvtol", "dopri5")])
 def test_two_rank_sharded_update_matches_single_device_reference(tmp_path, env_name, solver):
     out = str(tmp_path / "dpgpu")
     launch(2, ["--device", "cuda", "--out", out, "--solver", solver, "--env", env_name], timeout=600)

@@ -56,6 +56,9 @@ def torch_ref(ref, x, dy):
     (3, 100, 3, 5, 77, 0),       # f_net (hidden 100 -> padded tiles)
     (3, 100, 6, 4, 32, 0),       # g_net
     (12, 64, 10, 4, 50, 10),     # SimulatedCars NODE shape
+    (13, 256, 1, 3, 70, 11),     # Pvtol Q-net: obs(11) || action(2)  (first layer spans two K chunks)
+    (6, 100, 12, 4, 45, 0),      # Pvtol g_net
+    (16, 64, 16, 3, 40, 0),      # widest skinny layers the weight-gradient kernel takes
     (3, 8, 2, 2, 5, 0),          # smallest legal net
 ])
 def test_mlp_fwd_bwd_matches_torch(in_dim, hid, out_dim, n_layers, B, split):

@@ -29,7 +29,7 @@ def test_oracle_matches_reference_fixture(solver, B, env_name):
     torch.set_num_threads(1)
     g = load_golden(solver, B, env_name)
     seed, hidden = int(g["meta_seed"]), int(g["meta_hidden"])
-    env = make_env(env_name, seed)
+    env = synth.fixture_env(env_name, seed)
     args = O.Args(batch_size=B, hidden_size=hidden, seed=seed)
     if "meta_gamma_b" in g.files:
         args.gamma_b = float(g["meta_gamma_b"])
