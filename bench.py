@@ -29,7 +29,7 @@ from nlbac_amd.envspec import make_env
 
 PEAK_F32_MFMA_TFLOPS = 157.3     # MI355X_MICROARCH.md, chip-level parameters
 NODE_FIT_ROWS, NODE_FIT_INTERVAL, REPLAY_ROWS = 32768, 10, 65536
-GAMMA_B = {"Unicycle": 50.0, "SimulatedCars": 0.5, "UnicycleBarrier": 5.0, "Pvtol": 0.8}       # the reference README's run commands
+GAMMA_B = {"Unicycle": 50.0, "SimulatedCars": 0.5, "UnicycleBarrier": 5.0, "Pvtol": 0.8, "PvtolBarrier": 1.0}       # the reference README's run commands
 
 
 class Args:
@@ -191,7 +191,7 @@ def main():
     ap.add_argument("--warmup", type=int, default=20)
     ap.add_argument("--batch", type=int, default=4096)
     ap.add_argument("--solver", default="dopri5", choices=["euler", "rk4", "dopri5"])
-    ap.add_argument("--env", default="Unicycle", choices=["Unicycle", "SimulatedCars", "UnicycleBarrier", "Pvtol"])
+    ap.add_argument("--env", default="Unicycle", choices=["Unicycle", "SimulatedCars", "UnicycleBarrier", "Pvtol", "PvtolBarrier"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--graphs", action="store_true",
                     help="replay the update as hipGraphs (measured equal to eager launches once descriptors are cached)")
@@ -299,7 +299,7 @@ def main():
             "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {"workload": "%s B=%d %s (BASELINE.json configs[%d]); NODE fit on %d rows every %d "
                                    "updates; replay of %d synthetic transitions resident in HBM"
-                                   % (a.env, B, a.solver, {"Unicycle": 1, "SimulatedCars": 2, "Pvtol": 3, "UnicycleBarrier": 4}[a.env], NODE_FIT_ROWS, NODE_FIT_INTERVAL, REPLAY_ROWS),
+                                   % (a.env, B, a.solver, {"Unicycle": 1, "SimulatedCars": 2, "Pvtol": 3, "UnicycleBarrier": 4, "PvtolBarrier": 4}[a.env], NODE_FIT_ROWS, NODE_FIT_INTERVAL, REPLAY_ROWS),
                        "solver": a.solver, "batch_per_gpu": B, "global_batch": B * world,
                        "parallelism": "dp%d" % world, "hipgraph": bool(agent.use_graphs),
                        "rollout_solver_stats": dict(agent.node_solver.stats), "last_losses": [float(x) for x in ret]},

@@ -117,6 +117,6 @@ def make_env(name, seed=0, **overrides):
         return UnicycleSpec(seed)
     if name == "SimulatedCars":
         return SimulatedCarsSpec(seed)
-    if name == "Pvtol":
+    if name in ("Pvtol", "PvtolBarrier"):
         return PvtolSpec(seed, **overrides)
     raise Exception("Dynamics mode not supported.")

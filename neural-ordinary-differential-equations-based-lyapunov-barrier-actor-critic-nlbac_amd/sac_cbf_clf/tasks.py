@@ -540,5 +540,112 @@ class PvtolTask(_Task):
         self.fit_solver.forward_begin(w["st"], w["u"], 1, N, a.solver, self.env.dt, a.atol, a.rtol)
 
 
+# =====================================================================================
+class PvtolBarrierTask(PvtolTask):
+    """Learned-barrier-certificate Pvtol (NP/sac_cbf_clf/sac_cbf_clf.py:334-480): one controller, one NODE step, the
+    learned CBF term on get_obs(x') with a re-sampled detached next action, CLF (V' - V)/1 + 0.1 V on the predicted
+    observation, ratio clamped at 0.002."""
+    name = "PvtolBarrier"
+    n_pol, backup_mode, has_signal, n_extra_critics = 1, 0, True, 1
+    n_eps, eps_order = 3, None
+    lam_hi, ratio_mode = 400.0, 2
+
+    def __init__(self, agent, env, args):
+        _Task.__init__(self, agent, env, args)
+        self.num_cbfs = 1
+        self.gamma_l = 0.1
+        self.backup_interval = 1
+
+    def n_pol_now(self, updates):
+        return 1
+
+    def backup_lam_due(self, updates, interval):
+        return 0
+
+    def setup(self):
+        a = self.agent
+        self.solver = AffineNodeSolver(a.neural_ode_model, a.device)
+        self.fit_solver = AffineNodeSolver(a.neural_ode_model, a.device)
+        self.solvers = [self.solver, self.fit_solver]
+
+    def alloc(self, ws):
+        B, z, H = ws.B, self.z, self.agent.hidden
+        ws.st6, ws.op0 = z(B, 6), z(B)
+        ws.V, ws.V1, ws.dV1 = z(B), z(B), z(B)
+        ws.acts_v1 = z(2, B, H)
+        ws.obs_pred, ws.dobs1 = z(B, 11), z(B, 11)
+        ws.heads_nx, ws.pi_next, ws.logp_nx = z(B, 4), z(B, 2), z(B)
+        ws.Bv, ws.Bn, ws.dBn = z(B), z(B), z(B)
+        ws.acts_bn = z(2, B, H)
+        ws.dxb = z(B, 13)                              # d B(obs', a') / d [obs', a']
+        ws.matr = z(B, 2)
+        ws.part_c = z(ws.nblk, 2)
+        ws.dx_next = z(B, 6)
+
+    def extra_value_nets(self):
+        return [self.agent.h_extra[0]]
+
+    def extra_value_io(self, ws, io, i):               # B(obs, pi), value only (detached in the reference)
+        lay = self.agent.lay
+        io[i].x0, io[i].x0_dim, io[i].x0_ld = ws.mb.data_ptr() + 4 * lay.obs, 11, lay.LD
+        io[i].x1, io[i].x1_dim, io[i].x1_ld = ws.pi2.data_ptr(), 2, 2
+        io[i].y, io[i].y_ld = ws.Bv.data_ptr(), 1
+
+    def plan(self, ws, P):
+        a = self.agent
+        P.n_l = mlp_array([a.h_l.desc])
+        io = P.io_v1 = io_array(1)                     # V(obs(x')) forward + data backward
+        io[0].x0, io[0].x0_dim, io[0].x0_ld = ws.obs_pred.data_ptr(), 11, 11
+        io[0].y, io[0].y_ld = ws.V1.data_ptr(), 1
+        io[0].acts = ws.acts_v1.data_ptr()
+        io[0].dy, io[0].dy_ld = ws.dV1.data_ptr(), 1
+        io[0].dx, io[0].dx_ld = ws.dobs1.data_ptr(), 11
+        P.n_pi = mlp_array([a.h_p.desc])
+        io = P.io_nx = io_array(1)                     # policy on the predicted next observation
+        io[0].x0, io[0].x0_dim, io[0].x0_ld = ws.obs_pred.data_ptr(), 11, 11
+        io[0].y, io[0].y_ld = ws.heads_nx.data_ptr(), 4
+        P.n_bar = mlp_array([a.h_extra[0].desc])
+        io = P.io_bn = io_array(1)                     # B(obs', a') forward + data backward
+        io[0].x0, io[0].x0_dim, io[0].x0_ld = ws.obs_pred.data_ptr(), 11, 11
+        io[0].x1, io[0].x1_dim, io[0].x1_ld = ws.pi_next.data_ptr(), 2, 2
+        io[0].y, io[0].y_ld = ws.Bn.data_ptr(), 1
+        io[0].acts = ws.acts_bn.data_ptr()
+        io[0].dy, io[0].dy_ld = ws.dBn.data_ptr(), 1
+        io[0].dx, io[0].dx_ld = ws.dxb.data_ptr(), 13
+
+    def rollout_begin(self, ws, P):
+        a, s = self.agent, stream_ptr()
+        _lib.call("nlbac_pvtol_state", ws.mb.data_ptr(), a.lay.LD, ws.B, ws.st6.data_ptr(), ws.op0.data_ptr(), s)
+        self.solver.forward_begin(ws.st6, ws.pi2, 1, ws.B, a.solver, float(self.env.dt), a.atol, a.rtol)
+
+    def loss_and_backward(self, ws, P, lam_upd, assume_single):
+        a, s, call = self.agent, stream_ptr(), _lib.call
+        B, sc, env = ws.B, a.sc.data_ptr(), self.env
+        pol = a.policy
+        follow, (gx, gy) = float(env.safety_operator_follow), self.GOAL
+        x1 = self.solver.forward_finish(assume_single_step=assume_single)
+        call("nlbac_pvtol_obs_fwd", x1.data_ptr(), ws.op0.data_ptr(), B, follow, gx, gy, B, ws.obs_pred.data_ptr(), 11,
+             None, s)
+        call("nlbac_mlp_fwd", P.n_l, P.io_v1, 1, B, s)
+        call("nlbac_mlp_fwd", P.n_pi, P.io_nx, 1, B, s)
+        call("nlbac_gauss_sample_fwd", ws.heads_nx.data_ptr(), 4, ws.eps[2].data_ptr(), pol.action_scale.data_ptr(),
+             pol.action_bias.data_ptr(), 2, B, ws.pi_next.data_ptr(), 2, ws.logp_nx.data_ptr(), s)
+        call("nlbac_mlp_fwd", P.n_bar, P.io_bn, 1, B, s)
+        call("nlbac_barrier_constraints_fwd", ws.Bv.data_ptr(), ws.Bn.data_ptr(), ws.V.data_ptr(), ws.V1.data_ptr(),
+             1.0, float(a.gamma_b), self.gamma_l, B, ws.matr.data_ptr(), ws.part_c.data_ptr(), s)
+        a.auglag(ws, 1, lam_upd)
+        call("nlbac_barrier_constraints_bwd", ws.matr.data_ptr(), 1.0, float(a.batch_size), B, sc, ws.dBn.data_ptr(),
+             ws.dV1.data_ptr(), s)
+        call("nlbac_mlp_bwd_data", P.n_l, P.io_v1, 1, B, s)          # dV' -> d obs'
+        call("nlbac_mlp_bwd_data", P.n_bar, P.io_bn, 1, B, s)        # dB' -> d [obs', a'] (a' is detached)
+        call("nlbac_pvtol_obs_bwd", x1.data_ptr(), ws.dobs1.data_ptr(), 11, follow, gx, gy, B, ws.dx_next.data_ptr(), 0, s)
+        call("nlbac_pvtol_obs_bwd", x1.data_ptr(), ws.dxb.data_ptr(), 13, follow, gx, gy, B, ws.dx_next.data_ptr(), 1, s)
+        du, _ = self.solver.backward(ws.dx_next, need_du=True)
+        return du, self.act_dim
+
+    def first_step_done(self):
+        return self.solver.first_step_done()
+
+
 TASKS = {"Unicycle": UnicycleTask, "SimulatedCars": CarsTask, "UnicycleBarrier": UnicycleBarrierTask,
-         "Pvtol": PvtolTask}
+         "Pvtol": PvtolTask, "PvtolBarrier": PvtolBarrierTask}

@@ -78,6 +78,17 @@ def unicycle_barrier_transitions(n, seed=1, env=None):
     return tr
 
 
+def pvtol_barrier_transitions(n, seed=1, env=None):
+    """Pvtol transitions plus the barrier signal of the learned-certificate copy (NP/envs/pvtol_env.py:144-220):
+    0, and -0.1 per hazard disc holding the next position."""
+    from .envspec import PvtolSpec
+    env = env or PvtolSpec()
+    tr = pvtol_transitions(n, seed, env)
+    d2 = ((tr["next_obs"][:, None, :2] - np.asarray(env.hazard_locations)[None]) ** 2).sum(2)
+    tr["barrier_signal"] = -0.1 * (d2 < env.hazards_radius ** 2).sum(1).astype(np.float64)
+    return tr
+
+
 def cars_transitions(n, seed=1, env=None):
     """Synthetic SimulatedCars transitions: states near the env's reset line-up
     (C/envs/simulated_cars_env.py:158-176) with random spreads, one true env step (``:66-99``),
@@ -262,13 +273,20 @@ def pvtol_agent_weights(hidden, seed=0):
     return dict(critic=critic, lyapunov=lya, policy=policy, backup_policy=backup, node=node)
 
 
+def pvtol_barrier_agent_weights(hidden, seed=0):
+    W = pvtol_agent_weights(hidden, seed)
+    del W["backup_policy"]
+    W["barrier"] = synth_state_dict(lya_shapes(11 + 2, hidden), seed * 10 + 6)
+    return W
+
+
 def agent_weights(env_name, hidden, seed=0):
-    return {"Unicycle": unicycle_agent_weights, "SimulatedCars": cars_agent_weights, "Pvtol": pvtol_agent_weights,
+    return {"PvtolBarrier": pvtol_barrier_agent_weights, "Unicycle": unicycle_agent_weights, "SimulatedCars": cars_agent_weights, "Pvtol": pvtol_agent_weights,
             "UnicycleBarrier": unicycle_barrier_agent_weights}[env_name](hidden, seed)
 
 
 def transitions(env_name, n, seed=1, env=None):
-    return {"Unicycle": unicycle_transitions, "SimulatedCars": cars_transitions, "Pvtol": pvtol_transitions,
+    return {"PvtolBarrier": pvtol_barrier_transitions, "Unicycle": unicycle_transitions, "SimulatedCars": cars_transitions, "Pvtol": pvtol_transitions,
             "UnicycleBarrier": unicycle_barrier_transitions}[env_name](n, seed, env)
 
 

@@ -19,7 +19,7 @@ What has to be faked to import the reference here:
   * ``sac_cbf_clf.model.device`` is hard-coded ``cuda`` -> rebound to CPU.
   * ``env`` is a plain object (gym is absent): ``nlbac_amd.envspec``.
 
-Usage:  python oracle/gen_golden.py [--env Unicycle|SimulatedCars|UnicycleBarrier|Pvtol]   (one env per process: the
+Usage:  python oracle/gen_golden.py [--env Unicycle|SimulatedCars|UnicycleBarrier|Pvtol|PvtolBarrier]   (one env per process: the
 reference's env copies all use the package name ``sac_cbf_clf``)
 """
 import os
@@ -42,6 +42,8 @@ REFS = {
     "Unicycle": "/root/reference/NLBAC_Unicycle_RL_training/Unicycle_RL_training",
     "SimulatedCars": "/root/reference/NLBAC_SimulatedCarsFollowing_RL_training/Simulated_Car_Following_RL_training",
     "Pvtol": "/root/reference/NLBAC_pvtol_RL_training/Pvtol_RL_training",
+    "PvtolBarrier": "/root/reference/neural_barrier_certificate/neural_barrier_certificate_NLBAC_pvtol_RL_training/"
+                    "Pvtol_RL_training",
     "UnicycleBarrier": "/root/reference/neural_barrier_certificate/neural_barrier_certificate_NLBAC_Unicycle_RL_training/"
                        "Unicycle_RL_training",
 }
@@ -51,6 +53,7 @@ CFG = {
     "Unicycle": dict(prefix="unicycle", obs=7, act=2, gamma_b=50.0, n_eps=3, n_ode=1),
     "SimulatedCars": dict(prefix="cars", obs=10, act=1, gamma_b=0.5, n_eps=5, n_ode=2),
     "UnicycleBarrier": dict(prefix="nbc_unicycle", obs=7, act=2, gamma_b=5.0, n_eps=3, n_ode=1),
+    "PvtolBarrier": dict(prefix="nbc_pvtol", obs=11, act=2, gamma_b=1.0, n_eps=3, n_ode=1),
     # Pvtol: backup controller every 20 updates -> call 20 exercises it without a lambda update
     "Pvtol": dict(prefix="pvtol", obs=11, act=2, gamma_b=0.8, n_eps=7, n_ode=3, calls=(0, 1, 8, 20)),
 }
@@ -188,7 +191,7 @@ def run_case(S, env_name, solver, B, hidden=256, seed=0, node_B=512, calls=None)
             eps_queue[:] = [torch.from_numpy(e) for e in eps]
             where_rec.clear(); node_out.clear(); rec.clear()
             torch.where = where
-            extra = (0,) if env_name == "Pvtol" else ()          # P: trailing i_episode argument
+            extra = (0,) if env_name.startswith("Pvtol") else ()          # P / NP: trailing i_episode argument
             ret = agent.update_parameters(FakeMemory(tr, idx, fields), B, updates, dyn,
                                           FakeMemory(tr, nidx, fields), 10, *extra)
             torch.where = orig_where

@@ -719,6 +719,7 @@ class OracleUnicycleBarrierAgent(OracleUnicycleAgent):
     (:404-420), CLF as in U, no ratio in the loss (:474-475)."""
     N_EPS = 3
     GOAL = (2.5, 2.5)
+    CLF_DT, GAMMA_L, RATIO_MIN = None, 1.0, None      # CLF divisor (None: env.dt), class-K coefficient, ratio clamp
 
     def __init__(self, env, args, weights, solver="euler"):
         self.env, self.args, self.solver = env, args, solver
@@ -751,6 +752,14 @@ class OracleUnicycleBarrierAgent(OracleUnicycleAgent):
         div = torch.sqrt(v0 * v0 + v1 * v1) + 0.001
         return torch.stack([st[:, 0], st[:, 1], c, s_, v0 / div, v1 / div, torch.exp(-dist)], 1)
 
+    def _predict(self, obs, pi):
+        """(x', get_obs(x') differentiable, input of V', solver info): one NODE step under ``pi``."""
+        x_next, info = self._rollout(self.get_state(obs), pi)
+        return x_next, self.get_obs(x_next), self._lookahead(x_next), info
+
+    def _lya_inputs(self, batch):
+        return batch["center"], batch["next_center"]
+
     def update(self, batch, eps, updates, node_batch=None):
         """NU/sac_cbf_clf/sac_cbf_clf.py:155-280; ``eps``: (next_obs sample, obs sample, sample on the predicted
         next observation inside the loss)."""
@@ -759,8 +768,8 @@ class OracleUnicycleBarrierAgent(OracleUnicycleAgent):
             R["node_loss"], R["g_node"] = self.train_step(*node_batch)
         obs, nobs, act = batch["obs"], batch["next_obs"], batch["action"]
         rew, con, sig = (batch[k].unsqueeze(1) for k in ("reward", "constraint", "barrier_signal"))
-        cen, ncen, mask = batch["center"], batch["next_center"], batch["mask"].unsqueeze(1)
-        dt = self.env.dt
+        (cen, ncen), mask = self._lya_inputs(batch), batch["mask"].unsqueeze(1)
+        dt = self.CLF_DT or self.env.dt
         with torch.no_grad():
             na, nlogp, _ = policy_sample(self.policy, nobs, eps[0], self.scale, self.bias)
             q1t, q2t = qnet(self.critic_target, nobs, na)
@@ -782,13 +791,11 @@ class OracleUnicycleBarrierAgent(OracleUnicycleAgent):
         pi, log_pi, _ = policy_sample(self.policy, obs, eps[1], self.scale, self.bias)
         policy_loss_1 = ((self.alpha * log_pi) - torch.min(*qnet(self.critic, obs, pi))).mean()
         # get_cbf_clf_part / get_policy_loss_2 (:339-477)
-        state = self.get_state(obs)
-        V = lyanet(self.lya, cen).detach()
-        x_next, info = self._rollout(state, pi)
-        V_next = lyanet(self.lya, self._lookahead(x_next))
-        lya_term = ((V_next - V) / dt) + 1.0 * V
+        V = lyanet(self.lya, batch["center"]).detach()
+        x_next, obs_pred, v_in, info = self._predict(obs, pi)
+        V_next = lyanet(self.lya, v_in)
+        lya_term = ((V_next - V) / dt) + self.GAMMA_L * V
         Bv = lyanet(self.barrier, torch.cat([obs, pi], 1)).detach()
-        obs_pred = self.get_obs(x_next)
         pi_next, _, _ = policy_sample(self.policy, obs_pred.detach(), eps[2], self.scale, self.bias)
         B_next = lyanet(self.barrier, torch.cat([obs_pred, pi_next.detach()], 1))
         barrier_term = -(B_next - Bv) - self.gamma_b * Bv
@@ -801,10 +808,13 @@ class OracleUnicycleBarrierAgent(OracleUnicycleAgent):
                 self.lambda_values[i] = float(torch.clamp(new, 0.01, 400.0))
         self.augmented_term = min(self.augmented_term * self.augmented_ratio, 200)
         rho = self.augmented_term
-        loss2 = 0.0
-        for i in (0, 1):
-            g = required[i] - self.cost_limit
-            loss2 = loss2 + float(self.lambda_values[i]) * g + rho / 2.0 * g * g
+        ratio = 1.0
+        if self.RATIO_MIN is not None:          # NP:440-447; NU has no ratio
+            ratio = max(float(torch.abs(torch.mean(required[:-1] - self.cost_limit)) /
+                              torch.abs(required[-1] - self.cost_limit)), self.RATIO_MIN)
+        g0, g1 = required[0] - self.cost_limit, required[1] - self.cost_limit
+        loss2 = float(self.lambda_values[0]) * g0 + rho / 2.0 * g0 * g0
+        loss2 = loss2 + float(self.lambda_values[1]) * ratio * g1 + ratio * ratio * rho / 2.0 * g1 * g1
         gp = torch.autograd.grad(policy_loss_1 + loss2, list(self.policy.values()))
         self._set_grads(self.policy.values(), gp)
         self.opt["policy"].step()
@@ -827,7 +837,33 @@ class OracleUnicycleBarrierAgent(OracleUnicycleAgent):
         return R
 
 
+class OraclePvtolBarrierAgent(OracleUnicycleBarrierAgent):
+    """Learned-barrier-certificate Pvtol copy (NP = neural_barrier_certificate/
+    neural_barrier_certificate_NLBAC_pvtol_RL_training/Pvtol_RL_training/sac_cbf_clf/sac_cbf_clf.py:150-480): the NU
+    update on Pvtol's state / observation maps, one NODE step, CLF (V' - V)/1 + 0.1 V on the predicted observation,
+    ratio clamped at 0.002; the Lyapunov critic is regressed on observations (:206-217)."""
+    GOAL = (4.5, 4.5)
+    CLF_DT, GAMMA_L, RATIO_MIN = 1.0, 0.1, 0.002
+    get_state = staticmethod(OraclePvtolAgent.get_state)
+    get_obs = OraclePvtolAgent.get_obs
+    _rollout = OraclePvtolAgent._rollout
+    _step7 = OraclePvtolAgent._step7
+    train_step = OraclePvtolAgent.train_step
+
+    def _setup_task(self, env):
+        self.node_fn = AffineNode(self.node, n_s=6, n_u=2)
+
+    def _lya_inputs(self, batch):
+        return batch["obs"], batch["next_obs"]
+
+    def _predict(self, obs, pi):
+        st7, st6 = self.get_state(obs)
+        x_next, info = self._rollout(st6, pi)
+        obs_pred = self.get_obs(self._step7(st7, x_next))
+        return x_next, obs_pred, obs_pred, info
+
+
 def make_oracle(env, args, weights, solver="euler"):
     kind = env.dynamics_mode + ("Barrier" if "barrier" in weights else "")
     return {"Unicycle": OracleUnicycleAgent, "SimulatedCars": OracleCarsAgent, "Pvtol": OraclePvtolAgent,
-            "UnicycleBarrier": OracleUnicycleBarrierAgent}[kind](env, args, weights, solver)
+            "PvtolBarrier": OraclePvtolBarrierAgent, "UnicycleBarrier": OracleUnicycleBarrierAgent}[kind](env, args, weights, solver)

@@ -70,9 +70,9 @@ def flat_grad(agent, arena, module, n_slabs=None):
 
 
 CASES = [("Unicycle", False), ("Unicycle", True), ("SimulatedCars", False), ("UnicycleBarrier", False),
-         ("UnicycleBarrier", True), ("Pvtol", False)]
+         ("UnicycleBarrier", True), ("Pvtol", False), ("PvtolBarrier", False)]
 IDS = ["unicycle-eager", "unicycle-hipgraph", "cars-eager", "nbc-unicycle-eager", "nbc-unicycle-hipgraph",
-       "pvtol-eager"]
+       "pvtol-eager", "nbc-pvtol-eager"]
 
 
 @pytest.mark.parametrize("env_name,graphs", CASES, ids=IDS)

@@ -22,7 +22,7 @@ def flat_sd(sd):
     return torch.cat([v.detach().reshape(-1) for v in sd.values()])
 
 
-@pytest.mark.parametrize("env_name", ["Unicycle", "SimulatedCars", "UnicycleBarrier", "Pvtol"])
+@pytest.mark.parametrize("env_name", ["Unicycle", "SimulatedCars", "UnicycleBarrier", "Pvtol", "PvtolBarrier"])
 @pytest.mark.parametrize("solver", ["euler", "rk4", "dopri5"])
 @pytest.mark.parametrize("B", [8, 128])
 def test_oracle_matches_reference_fixture(solver, B, env_name):
