@@ -27,6 +27,17 @@ class DynamicsModel:
             state = o.astype(np.float64).copy()
             state[:, ::2] *= 100.0
             state[:, 1::2] *= 30.0
+        elif self.env.dynamics_mode == 'Pvtol':
+            # P/sac_cbf_clf/dynamics.py:50-73: (state with the safety operator, the six dynamic states)
+            state = np.stack([o[:, 0], o[:, 1], np.arctan2(o[:, 3], o[:, 2]), o[:, 4], o[:, 5], o[:, 6], o[:, 7]],
+                             axis=1).astype(np.float64)
+            dyn = state[:, :6]
+            if single:
+                state, dyn = state[0], dyn[0]
+            if is_tensor:
+                return (torch.from_numpy(state).type(dtype).to(device),
+                        torch.from_numpy(np.ascontiguousarray(dyn)).type(dtype).to(device))
+            return state, dyn
         else:
             raise Exception('Unknown dynamics')
         if single:

@@ -190,3 +190,38 @@ def test_oracle_dopri5_agrees_with_scipy_rk45():
         np.testing.assert_allclose(y[i].numpy(), sol.y[:, -1], rtol=2e-5, atol=2e-6)
         np.testing.assert_allclose(yr[i].numpy(), sol.y[:, -1], rtol=2e-5, atol=2e-6)
     assert all(s[2] for s in info["steps"][-1:])
+
+
+def test_reference_import_lines_resolve_to_this_build():
+    """U/main.py:6-10 (and the same lines of the other drivers) after ``install_reference_names``."""
+    import subprocess
+    import sys
+    code = (
+        "import sys; sys.path.insert(0, %r)\n"
+        "import nlbac_amd\n"
+        "nlbac_amd.install_reference_names(barrier=%s)\n"
+        "from sac_cbf_clf.sac_cbf_clf import SAC_CBF_CLF\n"
+        "from sac_cbf_clf.replay_memory import ReplayMemory\n"
+        "from sac_cbf_clf.dynamics import DynamicsModel\n"
+        "from sac_cbf_clf.utils import prGreen, get_output_folder, prYellow\n"
+        "from sac_cbf_clf.model import BarrierNetwork, NeuralODEModel\n"
+        "import inspect\n"
+        "print(SAC_CBF_CLF.variant or 'base', len(inspect.signature(ReplayMemory.push).parameters))\n")
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    for barrier, expect in ((False, "base 11"), (True, "Barrier 12")):
+        out = subprocess.run([sys.executable, "-c", code % (root, barrier)], capture_output=True, text=True)
+        assert out.returncode == 0, out.stderr[-2000:]
+        assert out.stdout.strip() == expect
+
+
+def test_dynamics_model_pvtol_returns_state_pair():
+    from nlbac_amd.sac_cbf_clf.dynamics import DynamicsModel
+    env = make_env("Pvtol", 0)
+    dm = DynamicsModel(env, type("A", (), {"cuda": False})())
+    tr = synth.transitions("Pvtol", 5, seed=2, env=env)
+    st, dyn = dm.get_state(tr["obs"])
+    assert st.shape == (5, 7) and dyn.shape == (5, 6)
+    np.testing.assert_allclose(st[:, 6], tr["obs"][:, 7])
+    np.testing.assert_allclose(np.cos(st[:, 2]), tr["obs"][:, 2], atol=1e-12)
+    st_t, dyn_t = dm.get_state(torch.tensor(tr["obs"][0], dtype=torch.float32))
+    assert st_t.shape == (7,) and dyn_t.shape == (6,) and st_t.dtype == torch.float32
