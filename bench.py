@@ -222,19 +222,17 @@ def main():
     if world > 1:
         agent.enable_data_parallel(dist)
     dev = agent.device
-    replay = replay_rows(agent, synth.transitions(a.env, REPLAY_ROWS, seed=1 + rank, env=env)).to(dev)
+    from nlbac_amd.sac_cbf_clf.replay_memory import DeviceReplayMemory
+    # the replay lives in HBM in the agent's row layout; minibatches are drawn and gathered on the device
+    replay = DeviceReplayMemory(REPLAY_ROWS, 1234 + rank, agent, device_rng=True)
+    replay.push_rows(replay_rows(agent, synth.transitions(a.env, REPLAY_ROWS, seed=1 + rank, env=env)))
     ws = agent._workspace(B)
     fit_rows = torch.empty(NODE_FIT_ROWS, agent.lay.LD, device=dev)
-    gen = torch.Generator(device=dev)
-    gen.manual_seed(1234 + rank)
 
     def step(i):
-        idx = torch.randint(0, REPLAY_ROWS, (B,), device=dev, generator=gen)
-        torch.index_select(replay, 0, idx, out=ws.mb)
+        replay.sample_rows(B, out=ws.mb)
         if i % NODE_FIT_INTERVAL == 0:
-            nidx = torch.randint(0, REPLAY_ROWS, (NODE_FIT_ROWS,), device=dev, generator=gen)
-            torch.index_select(replay, 0, nidx, out=fit_rows)
-            agent.fit_node_rows(fit_rows)
+            agent.fit_node_rows(replay.sample_rows(NODE_FIT_ROWS, out=fit_rows))
         return agent.update_on_device(ws, i)
 
     def fence():

@@ -313,6 +313,11 @@ int nlbac_dopri_interp_bwd(const float *dout, const float *h_host, const float *
                            int P, int rows_per_problem, int n_s, float *dy0, float *dy1, float *dK,
                            nlbac_stream_t s);
 
+/* Replay minibatch gather on the device (replay_memory.py:21-25): dst[r] = src[idx[r]] for n_rows rows of ld floats
+ * (ld % 4 == 0; idx are int64 row numbers in [0, src_rows)). */
+int nlbac_gather_rows(const float *src, long src_rows, int ld, const long *idx, long n_rows, float *dst,
+                      nlbac_stream_t s);
+
 /* small utilities */
 int nlbac_axpby(float a, const float *x, float b, const float *y /*or NULL*/, long n, float *out, nlbac_stream_t s);
 int nlbac_fill(float *p, float v, long n, nlbac_stream_t s);

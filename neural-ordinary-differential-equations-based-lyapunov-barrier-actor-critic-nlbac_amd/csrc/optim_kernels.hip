@@ -4,6 +4,7 @@
 // soft_update at U/sac_cbf_clf/utils.py:75-79.
 //
 // HBM-bound streaming kernels: one float4 per lane, grid capped at 2048 blocks.
+#include <cstdint>
 #include "common.h"
 
 thread_local char nlbac_err_buf[512] = "";
@@ -177,5 +178,34 @@ extern "C" int nlbac_sum_partials(const float* partials, int n_blk, int n_cols, 
     NLBAC_REQUIRE(partials && out && n_blk >= 1 && n_cols >= 1, "nlbac_sum_partials: bad arguments");
     hipLaunchKernelGGL(sum_partials_kernel, dim3(nlbac_ceil_div(n_cols, 64)), dim3(64), 0, (hipStream_t)s, partials, n_blk, n_cols, mul, out);
     NLBAC_CHECK_LAUNCH("nlbac_sum_partials");
+    return 0;
+}
+
+
+// ---------------------------------------------------------------------------
+// Replay minibatch gather (replay_memory.py:21-25 on the device): dst[r] = src[idx[r]] for rows of ld floats
+// (ld % 4 == 0, 16-byte aligned rows): one lane per float4, consecutive lanes on consecutive 16-byte pieces of a row.
+// ---------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void gather_rows_kernel(const float4* __restrict__ src, int ld4,
+                                                          const long* __restrict__ idx, long n_rows, long src_rows,
+                                                          float4* __restrict__ dst) {
+    const long t = (long)blockIdx.x * 256 + threadIdx.x;
+    if (t >= n_rows * ld4) return;
+    const long r = t / ld4;
+    const int c = (int)(t - r * ld4);
+    long j = idx[r];
+    j = j < 0 ? 0 : (j >= src_rows ? src_rows - 1 : j);       // never read outside the buffer
+    dst[r * ld4 + c] = src[j * ld4 + c];
+}
+
+extern "C" int nlbac_gather_rows(const float* src, long src_rows, int ld, const long* idx, long n_rows, float* dst,
+                                 nlbac_stream_t s) {
+    NLBAC_REQUIRE(src && idx && dst && src_rows >= 1 && n_rows >= 1, "nlbac_gather_rows: bad arguments");
+    NLBAC_REQUIRE(ld >= 4 && ld % 4 == 0 && ((uintptr_t)src % 16) == 0 && ((uintptr_t)dst % 16) == 0,
+                  "nlbac_gather_rows: rows must be whole float4s (ld %d)", ld);
+    const long total = n_rows * (ld / 4);
+    hipLaunchKernelGGL(gather_rows_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, (hipStream_t)s,
+                       (const float4*)src, ld / 4, idx, n_rows, src_rows, (float4*)dst);
+    NLBAC_CHECK_LAUNCH("nlbac_gather_rows");
     return 0;
 }

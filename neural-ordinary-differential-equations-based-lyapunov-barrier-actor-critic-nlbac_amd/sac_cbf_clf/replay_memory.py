@@ -54,3 +54,109 @@ class ReplayMemory:
 
     def __len__(self):
         return self._len
+
+
+
+class DeviceReplayMemory:
+    """Replay buffer resident in HBM in the agent's minibatch row layout.
+
+    Same ``push`` / ``sample`` / ``len`` / ``position`` API as ``ReplayMemory``; rows are staged in a pinned host
+    block and uploaded in chunks, and ``sample_rows`` gathers a minibatch on the device straight into the agent's
+    workspace (one ``nlbac_gather_rows`` launch) — ``SAC_CBF_CLF.update_parameters`` takes that path, so an update
+    moves ``8 * batch`` index bytes over PCIe instead of the whole minibatch.  Index draws use ``random.sample`` on
+    the host exactly like the reference (``replay_memory.py:22``), so the same seed selects the same transitions;
+    ``device_rng=True`` draws them with the device generator instead (with replacement, no host involvement).
+    """
+
+    def __init__(self, capacity, seed, agent, chunk=4096, device_rng=False):
+        import torch
+        random.seed(seed)
+        self.capacity, self.agent, self.device_rng = int(capacity), agent, device_rng
+        self.lay, self.device = agent.lay, agent.device
+        self.n_fields = 11 if self.lay.sig is not None else 10
+        self.rows = torch.zeros(self.capacity, self.lay.LD, dtype=torch.float32, device=self.device)
+        self._stage = torch.zeros(min(chunk, self.capacity), self.lay.LD, dtype=torch.float32).pin_memory() \
+            if torch.cuda.is_available() else torch.zeros(min(chunk, self.capacity), self.lay.LD)
+        self._stage_np = self._stage.numpy()
+        self._n_staged, self._stage_start = 0, 0
+        self._len = 0
+        self.position = 0
+        self._gen = torch.Generator(device=self.device)
+        self._gen.manual_seed(int(seed) & 0x7FFFFFFF)
+
+    def push(self, *fields, t=None, next_t=None):
+        """Positional fields in the order of the reference's ``push`` (10, or 11 with the barrier signal)."""
+        fields = tuple(fields)
+        if len(fields) == self.n_fields - 2:
+            fields = fields + (t, next_t)
+        assert len(fields) == self.n_fields, "push takes %d fields" % self.n_fields
+        if self._n_staged == self._stage_np.shape[0] or \
+                (self._n_staged and self._stage_start + self._n_staged != self.position):
+            self.flush()
+        if self._n_staged == 0:
+            self._stage_start = self.position
+        batch1 = tuple(np.asarray(0.0 if f is None else f, dtype=np.float64)[None] for f in fields)
+        self._stage_np[self._n_staged] = self.agent._rows_from_host(batch1).numpy()[0]
+        self._n_staged += 1
+        self._len = max(self._len, self.position + 1)
+        self.position = (self.position + 1) % self.capacity
+        if self.position == 0:
+            self.flush()                       # keep a staged run contiguous in the ring
+
+    def push_rows(self, rows):
+        """Bulk insert of minibatch-layout rows (host or device tensor, (n, LD))."""
+        import torch
+        self.flush()
+        rows = torch.as_tensor(rows, dtype=torch.float32)
+        n = rows.shape[0]
+        assert rows.shape[1] == self.lay.LD and n <= self.capacity
+        first = min(n, self.capacity - self.position)
+        self.rows[self.position:self.position + first].copy_(rows[:first])
+        if n > first:
+            self.rows[:n - first].copy_(rows[first:])
+        self._len = min(self.capacity, max(self._len, self.position + n))
+        self.position = (self.position + n) % self.capacity
+
+    def flush(self):
+        if self._n_staged:
+            self.rows[self._stage_start:self._stage_start + self._n_staged].copy_(self._stage[:self._n_staged],
+                                                                                 non_blocking=False)
+            self._n_staged = 0
+
+    def _indices(self, batch_size):
+        import torch
+        if self.device_rng:
+            return torch.randint(0, self._len, (batch_size,), device=self.device, generator=self._gen)
+        idx = torch.tensor(random.sample(range(self._len), batch_size), dtype=torch.int64)
+        return idx.to(self.device)
+
+    def sample_rows(self, batch_size, out=None):
+        """Minibatch-layout rows (batch_size, LD) on the device."""
+        import torch
+        from .. import _lib
+        from ..arena import stream_ptr
+        self.flush()
+        idx = self._indices(batch_size)
+        if out is None:
+            out = torch.empty(batch_size, self.lay.LD, dtype=torch.float32, device=self.device)
+        _lib.call("nlbac_gather_rows", self.rows.data_ptr(), self._len, self.lay.LD, idx.data_ptr(), batch_size,
+                  out.data_ptr(), stream_ptr())
+        return out
+
+    def sample(self, batch_size):
+        """Reference-shaped ``sample``: the 10 (11) stacked numpy arrays (device -> host; use ``sample_rows`` on the
+        update path)."""
+        rows = self.sample_rows(batch_size).cpu().numpy().astype(np.float64)
+        lay = self.lay
+        cols = [("obs", lay.obs_dim), ("act", lay.act_dim), ("rew", 0), ("con", 0)]
+        if lay.sig is not None:
+            cols.append(("sig", 0))
+        cols += [("lya", lay.lya_dim), ("nlya", lay.lya_dim), ("nobs", lay.obs_dim), ("mask", 0), ("t", 0), ("nt", 0)]
+        out = []
+        for name, w in cols:
+            c = getattr(lay, name)
+            out.append(rows[:, c] if w == 0 else rows[:, c:c + w])
+        return tuple(out)
+
+    def __len__(self):
+        return self._len

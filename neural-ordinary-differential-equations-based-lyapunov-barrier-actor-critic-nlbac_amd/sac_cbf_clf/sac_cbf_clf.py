@@ -358,11 +358,17 @@ class SAC_CBF_CLF(object):
         minibatch -> 6 floats.  ``dynamics_model`` is accepted for signature
         parity; obs->state runs on the device.  ``i_episode`` is the Pvtol copy's trailing argument (P:181):
         its NODE fit stops after episode 100 (P:205)."""
+        fit = updates % NODE_model_update_interval == 0 and self.task.fit_due(i_episode)
+        nb = min(NODE_memory.position, 32768) if fit else 0
+        if hasattr(memory, "sample_rows"):           # replay resident in HBM: gather on the device
+            ws = self._workspace(batch_size)
+            memory.sample_rows(batch_size, out=ws.mb)
+            if fit:                                  # same draw order as the reference: minibatch, then NODE rows
+                self.fit_node_rows(NODE_memory.sample_rows(nb) if hasattr(NODE_memory, "sample_rows") else
+                                   self._rows_from_host(NODE_memory.sample(batch_size=nb)).to(self.device))
+            return self.update_on_device(ws, updates)
         batch = memory.sample(batch_size=batch_size)
-        node_rows = None
-        if updates % NODE_model_update_interval == 0 and self.task.fit_due(i_episode):
-            nb = min(NODE_memory.position, 32768)
-            node_rows = NODE_memory.sample(batch_size=nb)
+        node_rows = NODE_memory.sample(batch_size=nb) if fit else None
         return self.update_from_host(batch, updates, node_rows)
 
     def _rows_from_host(self, batch):
