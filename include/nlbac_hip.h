@@ -274,13 +274,16 @@ int nlbac_rk_stage_bwd(const float *dYup, const float *dXf, const float *dXg, in
  * Y_s = y0 + h_p sum_{j<s} beta[s][j] K_j, f_net and g_net (two wave groups of one workgroup),
  * K_s = f + g u, and optionally out = y0 + h sum c_out[j] K_j and err = h sum c_err[j] K_j.
  * K / Y / G are [n_stages_total][n][.] stage-major; stages < stage_begin are read from K (FSAL, f0).
- * acts_* ([layer][n_stages_total*n][hid], layer stride *_ls) may be NULL when no backward follows. */
+ * acts_* ([layer][n_stages_total*n][hid], layer stride *_ls) may be NULL when no backward follows.
+ * acts_bits != 0: the acts_* buffers receive bit-packed ReLU masks instead — uint32 words
+ * [layer][n_stages_total*n][ceil(hid/32)] (bit c of word t = unit 32 t + c is active), layer stride in words: all a
+ * backward without weight gradients needs, at 1/32 of the HBM traffic. */
 int nlbac_node_rk_fwd(const nlbac_mlp *f, const nlbac_mlp *g, const float *y0, const float *u, int P,
                       int rows_per_problem, int stage_begin, int stage_end, int n_stages_total,
                       const float *beta, const float *c_out, int n_out, const float *c_err, int n_err,
                       const float *h_host, const double *h_dev, int h_dev_stride, float *K, float *Y,
-                      float *G, float *acts_f, long acts_f_ls, float *acts_g, long acts_g_ls, float *out,
-                      float *err, nlbac_stream_t s);
+                      float *G, float *acts_f, long acts_f_ls, float *acts_g, long acts_g_ls, int acts_bits,
+                      float *out, float *err, nlbac_stream_t s);
 /* Fused backward of the same step (exact gradient of the discrete step): processes stages st_hi-1 .. st_lo.
  * In/out dK [n_stages_total][n][n_s] holds dL/dK_j (initialised by the caller from the step's output
  * combination / interpolant); dYup (may be NULL) is dL/d(stage input) of the last stage (FSAL y1);
@@ -291,6 +294,7 @@ int nlbac_node_rk_bwd(const nlbac_mlp *f, const nlbac_mlp *g, const float *u, co
                       int rows_per_problem, int n_stages_total, int st_lo, int st_hi, int dx_stage0,
                       const float *beta, const float *h_host, const double *h_dev, int h_dev_stride,
                       const float *acts_f, long acts_f_ls, const float *acts_g, long acts_g_ls,
+                      int acts_bits /* as written by nlbac_node_rk_fwd; excludes dz_f/dz_g/dG */,
                       float *dz_f, float *dz_g, float *dG, float *dK, const float *dYup, float *dy0,
                       int dy0_in, float *du, int du_acc, nlbac_stream_t s);
 /* dopri5 step control on the device.  ctl: per problem NLBAC_DOPRI_CTL doubles

@@ -153,10 +153,12 @@ __device__ __forceinline__ void fwd_prime(WaveGemm<NTW>& wg, const nlbac_mlp& ne
              fwd_next<NTW>(net, 0, inp, wrap, wave, lane));
 }
 
-template <int NTW>
+template <int NTW, int BITS = 0>
 __device__ __forceinline__ void fwd_wide_layers(WaveGemm<NTW>& wg, const nlbac_mlp& net, bool active, int wave, int lane,
                                                 int LD, int inp, float*& in, float*& out, float* acts_tile,
                                                 long acts_ls, int n_rows, int nwide_run, bool wrap) {
+    // BITS: acts_tile holds bit-packed ReLU masks instead of activations: uint32 word [layer][row][col tile]
+    // (bit = column within the 32-wide tile), enough for a backward that needs no weight gradients
     const int hid = net.hid, hidp8 = pad8(hid), nwide = net.n_layers - 1, half = lane >> 5;
     for (int l = 0; l < nwide_run; ++l) {
         if (l < nwide && active) {
@@ -185,15 +187,24 @@ __device__ __forceinline__ void fwd_wide_layers(WaveGemm<NTW>& wg, const nlbac_m
                     v[r] = colok ? fmaxf(acc[t][r] + bv[t], 0.f) : 0.f;
                     out[acc_row(r, half) * LD + col] = v[r];
                 }
-                if (acts && colok) {
+                if (BITS && acts) {
+                    unsigned* mp = reinterpret_cast<unsigned*>(acts) + (wave + 4 * t);
+                    const int NTm = (hid + 31) >> 5;
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) {
+                        const unsigned long long b = __ballot(v[r] > 0.f);
+                        const int m = acc_row(r, half);
+                        if ((lane & 31) == 0 && m < n_rows) mp[m * NTm] = (unsigned)(b >> (32 * half));
+                    }
+                } else if (!BITS && acts && colok) {
                     float* ap = acts + col;
                     if (n_rows == NLBAC_MLP_TILE) {
 #pragma unroll
-                        for (int r = 0; r < 16; ++r) ap[(long)acc_row(r, half) * hid] = v[r];
+                        for (int r = 0; r < 16; ++r) ap[acc_row(r, half) * hid] = v[r];
                     } else {
 #pragma unroll
                         for (int r = 0; r < 16; ++r)
-                            if (acc_row(r, half) < n_rows) ap[(long)acc_row(r, half) * hid] = v[r];
+                            if (acc_row(r, half) < n_rows) ap[acc_row(r, half) * hid] = v[r];
                     }
                 }
             }
@@ -241,7 +252,7 @@ __device__ __forceinline__ void bwd_prime(WaveGemm<NTW>& wg, const nlbac_mlp& ne
              bwd_next<NTW>(net, j, wave, lane, wrap));
 }
 
-template <int NTW>
+template <int NTW, int BITS = 0>
 __device__ __forceinline__ void bwd_wide_layers(WaveGemm<NTW>& wg, const nlbac_mlp& net, bool active, int wave, int lane,
                                                 int LD, float*& in, float*& out, const float* acts_tile,
                                                 float* dz_tile, long ls, int n_rows, int row_clamp,
@@ -257,16 +268,31 @@ __device__ __forceinline__ void bwd_wide_layers(WaveGemm<NTW>& wg, const nlbac_m
             // ReLU masks of this wave's output fragment, requested before the GEMM so they land under it
             const float* acts = acts_tile + (long)(j - 1) * ls;
             float av[2][16];
+            if constexpr (BITS != 0) {          // one mask word per (row, column tile): a broadcast load per half-wave
+                const unsigned* mk = reinterpret_cast<const unsigned*>(acts_tile) + (long)(j - 1) * ls;
+                const int NTm = (hid + 31) >> 5;
 #pragma unroll
-            for (int t = 0; t < NTW; ++t) {
-                const int colc = min((wave + 4 * t) * 32 + (lane & 31), hid - 1);
+                for (int t = 0; t < NTW; ++t) {
 #pragma unroll
-                for (int r = 0; r < 16; ++r) av[t][r] = acts[(long)min(acc_row(r, half), row_clamp) * hid + colc];
+                    for (int r = 0; r < 16; ++r) {
+                        const unsigned w = mk[min(acc_row(r, half), row_clamp) * NTm + (wave + 4 * t)];
+                        av[t][r] = ((w >> (lane & 31)) & 1u) ? 1.f : 0.f;
+                    }
+                }
+            } else {
+#pragma unroll
+                for (int t = 0; t < NTW; ++t) {
+                    const int colc = min((wave + 4 * t) * 32 + (lane & 31), hid - 1);
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) av[t][r] = acts[min(acc_row(r, half), row_clamp) * hid + colc];
+                }
             }
             f32x16 acc[2];
 #pragma unroll
             for (int r = 0; r < 16; ++r) { acc[0][r] = 0.f; acc[1][r] = 0.f; }
+#ifndef EXP_BWD_NO_GEMM
             wg.run(in + (lane & 31) * LD + half * 4, p0, p1, KC, nx, acc);
+#endif
             float* dz = dz_tile ? dz_tile + (long)(j - 1) * ls : nullptr;
 #pragma unroll
             for (int t = 0; t < NTW; ++t) {
@@ -277,7 +303,7 @@ __device__ __forceinline__ void bwd_wide_layers(WaveGemm<NTW>& wg, const nlbac_m
                     const int m = acc_row(r, half);
                     const bool ok = colok && (m < n_rows);
                     const float v = (ok && av[t][r] > 0.f) ? acc[t][r] : 0.f;
-                    if (dz && ok) dz[(long)m * hid + col] = v;
+                    if constexpr (BITS == 0) { if (dz && ok) dz[m * hid + col] = v; }   // mask mode keeps no dz
                     out[m * LD + col] = v;
                 }
             }

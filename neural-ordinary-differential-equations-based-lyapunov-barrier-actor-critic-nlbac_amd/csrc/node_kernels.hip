@@ -36,12 +36,14 @@ struct NodeRkLaunch {
     const double* h_dev; int h_stride; float h_val[8];
     float* K; float* Y; float* G;
     float* acts[2]; long acts_ls[2];
+    int acts_bits;                    // acts hold bit-packed ReLU masks [layer][stage*n + row][col tile] (uint32)
     float* out; float* err;
     int ld;
     int sw_off1;                      // float offset of g_net's output-layer block behind f_net's in LDS
 };
 
-template <int MODE>   // 1: both nets <= 4 column tiles, 2: both 8, 0: mixed (see mlp_kernels.hip)
+// MODE 1: both nets <= 4 column tiles, 2: both 8, 0: mixed (see mlp_kernels.hip); BITS: save ReLU bit masks
+template <int MODE, int BITS>
 __global__ __launch_bounds__(512) void node_rk_fwd_kernel(const NodeRkLaunch L) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     const int tid = threadIdx.x, t = tid & 255;
@@ -123,15 +125,15 @@ __global__ __launch_bounds__(512) void node_rk_fwd_kernel(const NodeRkLaunch L) 
         // ---- wide layers of f_net (group 0) and g_net (group 1), in lock step; the weight stream of each
         //      wave runs on across layers and stages (WaveGemm), only the LDS operands wait for the barriers
         {
-            float* acts_tile = L.acts[grp] ? L.acts[grp] + ((long)st * n + row0) * hid : nullptr;
+            float* acts_tile = L.acts[grp] ? L.acts[grp] + ((long)st * n + row0) * (BITS ? NT : hid) : nullptr;
             const bool wrap = st + 1 < L.stage_end;
             if constexpr (MODE == 2)
-                fwd_wide_layers<2>(wg2, net, active, wave, lane, LD, inp, in, out, acts_tile, L.acts_ls[grp], n_rows, nwide_max, wrap);
+                fwd_wide_layers<2, BITS>(wg2, net, active, wave, lane, LD, inp, in, out, acts_tile, L.acts_ls[grp], n_rows, nwide_max, wrap);
             else if constexpr (MODE == 1)
-                fwd_wide_layers<1>(wg1, net, active, wave, lane, LD, inp, in, out, acts_tile, L.acts_ls[grp], n_rows, nwide_max, wrap);
+                fwd_wide_layers<1, BITS>(wg1, net, active, wave, lane, LD, inp, in, out, acts_tile, L.acts_ls[grp], n_rows, nwide_max, wrap);
             else {
-                if (two) fwd_wide_layers<2>(wg2, net, active, wave, lane, LD, inp, in, out, acts_tile, L.acts_ls[grp], n_rows, nwide_max, wrap);
-                else fwd_wide_layers<1>(wg1, net, active, wave, lane, LD, inp, in, out, acts_tile, L.acts_ls[grp], n_rows, nwide_max, wrap);
+                if (two) fwd_wide_layers<2, BITS>(wg2, net, active, wave, lane, LD, inp, in, out, acts_tile, L.acts_ls[grp], n_rows, nwide_max, wrap);
+                else fwd_wide_layers<1, BITS>(wg1, net, active, wave, lane, LD, inp, in, out, acts_tile, L.acts_ls[grp], n_rows, nwide_max, wrap);
             }
         }
 
@@ -190,6 +192,7 @@ struct NodeRkBwdLaunch {
     nlbac_mlp net[2];
     const float* u; const float* G;
     const float* acts[2]; long acts_ls[2];
+    int acts_bits;                    // acts hold bit-packed ReLU masks (see NodeRkLaunch)
     float* dz[2]; float* dG;
     float* dK; const float* dYup;
     float* dy0; int dy0_in;
@@ -200,7 +203,55 @@ struct NodeRkBwdLaunch {
     int ld, sw_off1;
 };
 
-template <int MODE>
+// Top (skinny) layer of the backward for one 32-row tile: dz_top[m][k] = [act_top[m][k] > 0] sum_o dy[m][o] W_last[o][k].
+// RPT rows per thread: the 256 threads of a group cover (32 / RPT) row groups x (256 * RPT / 32) columns.
+template <int RPT, int BITS>
+__device__ __forceinline__ void node_top_layer(const float* __restrict__ sdy, const float* __restrict__ sW, int out_dim,
+                                               int hid, int hidp32, int NT, int t, int n_rows,
+                                               const float* __restrict__ atop, float* __restrict__ dz,
+                                               float* __restrict__ in, int LD) {
+    constexpr int CPG = 256 * RPT / 32;            // columns per row group
+    const int k = t % CPG, m0 = (t / CPG) * RPT, kc = min(k, hid - 1);
+    float av[RPT];
+    if constexpr (BITS != 0) {
+        const unsigned* mtop = reinterpret_cast<const unsigned*>(atop) + (kc >> 5);
+#pragma unroll
+        for (int i = 0; i < RPT; ++i)
+            av[i] = ((mtop[min(m0 + i, n_rows - 1) * NT] >> (kc & 31)) & 1u) ? 1.f : 0.f;
+    } else {
+#pragma unroll
+        for (int i = 0; i < RPT; ++i) av[i] = atop[min(m0 + i, n_rows - 1) * hid + kc];
+    }
+    float s[RPT];
+#pragma unroll
+    for (int i = 0; i < RPT; ++i) s[i] = 0.f;
+#ifndef EXP_BWD_NO_TOP
+    for (int o0 = 0; o0 < out_dim; o0 += 4) {
+        const int no = min(4, out_dim - o0);
+        float w[4];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) w[q] = (q < no) ? sW[(o0 + min(q, no - 1)) * hid + kc] : 0.f;
+#pragma unroll
+        for (int i = 0; i < RPT; ++i) {
+            const float4 d = *reinterpret_cast<const float4*>(sdy + (m0 + i) * 16 + o0);
+            s[i] += d.x * w[0] + d.y * w[1] + d.z * w[2] + d.w * w[3];
+        }
+    }
+#endif
+    if (k < hidp32) {
+        const bool colok = k < hid;
+#pragma unroll
+        for (int i = 0; i < RPT; ++i) {
+            const int m = m0 + i;
+            const bool ok = colok && (m < n_rows);
+            const float v = (ok && av[i] > 0.f) ? s[i] : 0.f;
+            if constexpr (BITS == 0) { if (dz && ok) dz[m * hid + k] = v; }   // (mask mode never keeps dz)
+            in[m * LD + k] = v;
+        }
+    }
+}
+
+template <int MODE, int BITS>
 __global__ __launch_bounds__(512) void node_rk_bwd_kernel(const NodeRkBwdLaunch L) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     const int tid = threadIdx.x, t = tid & 255;
@@ -272,8 +323,7 @@ __global__ __launch_bounds__(512) void node_rk_bwd_kernel(const NodeRkBwdLaunch 
     for (int st = L.st_hi - 1; st >= L.st_lo; --st) {
         const bool data = has_data(st);
         // ---- output-layer gradients of both nets, du
-        const int k = t, kc = min(k, hid - 1);
-        const float* acts_tile = L.acts[grp] + ((long)st * n + row0) * hid;
+        const float* acts_tile = L.acts[grp] + ((long)st * n + row0) * (BITS ? NT : hid);
         for (int idx = tid; idx < 2 * NLBAC_MLP_TILE * 16; idx += 512) {
             const int gsel = idx >> 9, rem = idx & 511, m = rem >> 4, o = rem & 15, row = row0 + m;
             float v = 0.f;
@@ -298,33 +348,12 @@ __global__ __launch_bounds__(512) void node_rk_bwd_kernel(const NodeRkBwdLaunch 
 
         float* in = buf;
         float* out = buf + NLBAC_MLP_TILE * LD;
-        {   // top (skinny) layer: thread = hidden column (ReLU masks requested first, they land under the dots)
-            float av[NLBAC_MLP_TILE];
-            const float* atop = acts_tile + (long)(nwide - 1) * L.acts_ls[grp] + kc;
-#pragma unroll
-            for (int m = 0; m < NLBAC_MLP_TILE; ++m) av[m] = atop[(long)min(m, n_rows - 1) * hid];
-            float s[NLBAC_MLP_TILE];
-#pragma unroll
-            for (int m = 0; m < NLBAC_MLP_TILE; ++m) s[m] = 0.f;
-            for (int o0 = 0; o0 < net.out_dim; o0 += 4) {
-                const int no = min(4, net.out_dim - o0);
-                const float* Wo = sW + o0 * hid + kc;
-                if (no == 1) top_layer_bwd<1>(sdy + o0, Wo, hid, 0, s);
-                else if (no == 2) top_layer_bwd<2>(sdy + o0, Wo, hid, 0, s);
-                else if (no == 3) top_layer_bwd<3>(sdy + o0, Wo, hid, 0, s);
-                else top_layer_bwd<4>(sdy + o0, Wo, hid, 0, s);
-            }
+        {   // top (skinny) layer: thread = (row group, hidden column); narrow nets split the 32 rows over the
+            // threads that would otherwise idle (hid <= 128: 2 groups of 16 rows)
+            const float* atop = acts_tile + (long)(nwide - 1) * L.acts_ls[grp];
             float* dz = keep_dz ? L.dz[grp] + (long)(nwide - 1) * L.acts_ls[grp] + ((long)st * n + row0) * hid : nullptr;
-            if (k < hidp32) {
-                const bool colok = k < hid;
-#pragma unroll
-                for (int m = 0; m < NLBAC_MLP_TILE; ++m) {
-                    const bool ok = colok && (m < n_rows);
-                    const float v = (ok && av[m] > 0.f) ? s[m] : 0.f;
-                    if (dz && ok) dz[(long)m * hid + k] = v;
-                    in[m * LD + k] = v;
-                }
-            }
+            // MODE 1: both nets have <= 128 padded columns -> two row groups of 16 rows; otherwise one thread per column
+            node_top_layer<(MODE == 1) ? 16 : 32, BITS>(sdy, sW, net.out_dim, hid, hidp32, NT, t, n_rows, atop, dz, in, LD);
         }
         __syncthreads();
 
@@ -332,12 +361,12 @@ __global__ __launch_bounds__(512) void node_rk_bwd_kernel(const NodeRkBwdLaunch 
             float* dz_tile = keep_dz ? L.dz[grp] + ((long)st * n + row0) * hid : nullptr;
             const bool wrap = has_data(st - 1);
             if constexpr (MODE == 2)
-                bwd_wide_layers<2>(wg2, net, active, wave, lane, LD, in, out, acts_tile, dz_tile, L.acts_ls[grp], n_rows, n_rows - 1, n_run, wrap);
+                bwd_wide_layers<2, BITS>(wg2, net, active, wave, lane, LD, in, out, acts_tile, dz_tile, L.acts_ls[grp], n_rows, n_rows - 1, n_run, wrap);
             else if constexpr (MODE == 1)
-                bwd_wide_layers<1>(wg1, net, active, wave, lane, LD, in, out, acts_tile, dz_tile, L.acts_ls[grp], n_rows, n_rows - 1, n_run, wrap);
+                bwd_wide_layers<1, BITS>(wg1, net, active, wave, lane, LD, in, out, acts_tile, dz_tile, L.acts_ls[grp], n_rows, n_rows - 1, n_run, wrap);
             else {
-                if (two) bwd_wide_layers<2>(wg2, net, active, wave, lane, LD, in, out, acts_tile, dz_tile, L.acts_ls[grp], n_rows, n_rows - 1, n_run, wrap);
-                else bwd_wide_layers<1>(wg1, net, active, wave, lane, LD, in, out, acts_tile, dz_tile, L.acts_ls[grp], n_rows, n_rows - 1, n_run, wrap);
+                if (two) bwd_wide_layers<2, BITS>(wg2, net, active, wave, lane, LD, in, out, acts_tile, dz_tile, L.acts_ls[grp], n_rows, n_rows - 1, n_run, wrap);
+                else bwd_wide_layers<1, BITS>(wg1, net, active, wave, lane, LD, in, out, acts_tile, dz_tile, L.acts_ls[grp], n_rows, n_rows - 1, n_run, wrap);
             }
         }
         if (st == 0 && !L.dx_stage0) continue;       // only the dz of stage 0 were wanted
@@ -384,9 +413,10 @@ extern "C" int nlbac_node_rk_bwd(const nlbac_mlp* f, const nlbac_mlp* g, const f
                                  int rows_per_problem, int n_stages_total, int st_lo, int st_hi, int dx_stage0,
                                  const float* beta, const float* h_host, const double* h_dev, int h_dev_stride,
                                  const float* acts_f, long acts_f_ls, const float* acts_g, long acts_g_ls,
-                                 float* dz_f, float* dz_g, float* dG, float* dK, const float* dYup, float* dy0,
-                                 int dy0_in, float* du, int du_acc, nlbac_stream_t s) {
+                                 int acts_bits, float* dz_f, float* dz_g, float* dG, float* dK, const float* dYup,
+                                 float* dy0, int dy0_in, float* du, int du_acc, nlbac_stream_t s) {
     NLBAC_REQUIRE(f && g && u && G && acts_f && acts_g && dK, "nlbac_node_rk_bwd: null pointer");
+    NLBAC_REQUIRE(!(acts_bits && dz_f), "nlbac_node_rk_bwd: weight gradients need the activations, not bit masks");
     NLBAC_REQUIRE(P >= 1 && P <= 8 && rows_per_problem >= 1, "nlbac_node_rk_bwd: bad problem sizes");
     NLBAC_REQUIRE(n_stages_total >= 1 && n_stages_total <= RK_MAX_STAGES && st_lo >= 0 && st_lo < st_hi &&
                       st_hi <= n_stages_total, "nlbac_node_rk_bwd: bad stage range");
@@ -402,6 +432,7 @@ extern "C" int nlbac_node_rk_bwd(const nlbac_mlp* f, const nlbac_mlp* g, const f
     L.net[0] = *f; L.net[1] = *g;
     L.u = u; L.G = G;
     L.acts[0] = acts_f; L.acts[1] = acts_g; L.acts_ls[0] = acts_f_ls; L.acts_ls[1] = acts_g_ls;
+    L.acts_bits = acts_bits;
     L.dz[0] = dz_f; L.dz[1] = dz_g; L.dG = dG;
     L.dK = dK; L.dYup = dYup; L.dy0 = dy0; L.dy0_in = dy0_in; L.du = du; L.du_acc = du_acc;
     L.n = P * rows_per_problem; L.rpp = rows_per_problem;
@@ -420,21 +451,20 @@ extern "C" int nlbac_node_rk_bwd(const nlbac_mlp* f, const nlbac_mlp* g, const f
                         NLBAC_MLP_TILE * (RK_MAX_NU + 1 + RK_MAX_NS + RK_MAX_NU + 2 * RK_MAX_NS + 2 * 16) + sw_total) *
                        sizeof(float);
     NLBAC_REQUIRE(lds <= 160 * 1024, "nlbac_node_rk_bwd: LDS budget exceeded (%zu B)", lds);
+    using KernelB = void (*)(const NodeRkBwdLaunch);
+    static const KernelB kb[2][3] = {{node_rk_bwd_kernel<0, 0>, node_rk_bwd_kernel<1, 0>, node_rk_bwd_kernel<2, 0>},
+                                     {node_rk_bwd_kernel<0, 1>, node_rk_bwd_kernel<1, 1>, node_rk_bwd_kernel<2, 1>}};
     static bool attr_set = false;
     if (!attr_set) {
-        (void)hipFuncSetAttribute((const void*)node_rk_bwd_kernel<0>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-        (void)hipFuncSetAttribute((const void*)node_rk_bwd_kernel<1>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-        (void)hipFuncSetAttribute((const void*)node_rk_bwd_kernel<2>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        for (int b = 0; b < 2; ++b)
+            for (int m = 0; m < 3; ++m)
+                (void)hipFuncSetAttribute((const void*)kb[b][m], hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         attr_set = true;
     }
     const int ntf = (f->hid + 31) >> 5, ntg = (g->hid + 31) >> 5;
     const int mode = (ntf <= 4 && ntg <= 4) ? 1 : ((ntf == 8 && ntg == 8) ? 2 : 0);
     const dim3 grid(nlbac_ceil_div(L.n, NLBAC_MLP_TILE));
-    switch (mode) {
-        case 1: hipLaunchKernelGGL(node_rk_bwd_kernel<1>, grid, dim3(512), lds, (hipStream_t)s, L); break;
-        case 2: hipLaunchKernelGGL(node_rk_bwd_kernel<2>, grid, dim3(512), lds, (hipStream_t)s, L); break;
-        default: hipLaunchKernelGGL(node_rk_bwd_kernel<0>, grid, dim3(512), lds, (hipStream_t)s, L);
-    }
+    hipLaunchKernelGGL(kb[acts_bits ? 1 : 0][mode], grid, dim3(512), lds, (hipStream_t)s, L);
     NLBAC_CHECK_LAUNCH("nlbac_node_rk_bwd");
     return 0;
 }
@@ -445,8 +475,8 @@ extern "C" int nlbac_node_rk_fwd(const nlbac_mlp* f, const nlbac_mlp* g, const f
                                  const float* beta /* [n_stages_total][n_stages_total] row-major */,
                                  const float* c_out, int n_out, const float* c_err, int n_err,
                                  const float* h_host, const double* h_dev, int h_dev_stride, float* K, float* Y,
-                                 float* G, float* acts_f, long acts_f_ls, float* acts_g, long acts_g_ls, float* out,
-                                 float* err, nlbac_stream_t s) {
+                                 float* G, float* acts_f, long acts_f_ls, float* acts_g, long acts_g_ls,
+                                 int acts_bits, float* out, float* err, nlbac_stream_t s) {
     NLBAC_REQUIRE(f && g && y0 && u && K && Y && G, "nlbac_node_rk_fwd: null pointer");
     NLBAC_REQUIRE(P >= 1 && P <= 8 && rows_per_problem >= 1, "nlbac_node_rk_fwd: bad problem sizes");
     NLBAC_REQUIRE(n_stages_total >= 1 && n_stages_total <= RK_MAX_STAGES && stage_begin >= 0 &&
@@ -474,6 +504,7 @@ extern "C" int nlbac_node_rk_fwd(const nlbac_mlp* f, const nlbac_mlp* g, const f
     for (int p = 0; p < P; ++p) L.h_val[p] = h_host ? h_host[p] : 0.f;
     L.K = K; L.Y = Y; L.G = G;
     L.acts[0] = acts_f; L.acts[1] = acts_g; L.acts_ls[0] = acts_f_ls; L.acts_ls[1] = acts_g_ls;
+    L.acts_bits = acts_bits;
     L.out = out; L.err = err;
     int w = ((f->hid > g->hid ? f->hid : g->hid) + 31) & ~31;
     L.ld = w + 4;
@@ -483,21 +514,20 @@ extern "C" int nlbac_node_rk_fwd(const nlbac_mlp* f, const nlbac_mlp* g, const f
                         NLBAC_MLP_TILE * (RK_MAX_NS + RK_MAX_NU + 1 + RK_MAX_NS + RK_MAX_GOUT) + sw_total) *
                        sizeof(float);
     NLBAC_REQUIRE(lds <= 160 * 1024, "nlbac_node_rk_fwd: LDS budget exceeded (%zu B)", lds);
+    using KernelF = void (*)(const NodeRkLaunch);
+    static const KernelF kf[2][3] = {{node_rk_fwd_kernel<0, 0>, node_rk_fwd_kernel<1, 0>, node_rk_fwd_kernel<2, 0>},
+                                     {node_rk_fwd_kernel<0, 1>, node_rk_fwd_kernel<1, 1>, node_rk_fwd_kernel<2, 1>}};
     static bool attr_set = false;
     if (!attr_set) {
-        (void)hipFuncSetAttribute((const void*)node_rk_fwd_kernel<0>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-        (void)hipFuncSetAttribute((const void*)node_rk_fwd_kernel<1>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-        (void)hipFuncSetAttribute((const void*)node_rk_fwd_kernel<2>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        for (int b = 0; b < 2; ++b)
+            for (int m = 0; m < 3; ++m)
+                (void)hipFuncSetAttribute((const void*)kf[b][m], hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         attr_set = true;
     }
     const int ntf = (f->hid + 31) >> 5, ntg = (g->hid + 31) >> 5;
     const int mode = (ntf <= 4 && ntg <= 4) ? 1 : ((ntf == 8 && ntg == 8) ? 2 : 0);
     const dim3 grid(nlbac_ceil_div(L.n, NLBAC_MLP_TILE));
-    switch (mode) {
-        case 1: hipLaunchKernelGGL(node_rk_fwd_kernel<1>, grid, dim3(512), lds, (hipStream_t)s, L); break;
-        case 2: hipLaunchKernelGGL(node_rk_fwd_kernel<2>, grid, dim3(512), lds, (hipStream_t)s, L); break;
-        default: hipLaunchKernelGGL(node_rk_fwd_kernel<0>, grid, dim3(512), lds, (hipStream_t)s, L);
-    }
+    hipLaunchKernelGGL(kf[acts_bits ? 1 : 0][mode], grid, dim3(512), lds, (hipStream_t)s, L);
     NLBAC_CHECK_LAUNCH("nlbac_node_rk_fwd");
     return 0;
 }

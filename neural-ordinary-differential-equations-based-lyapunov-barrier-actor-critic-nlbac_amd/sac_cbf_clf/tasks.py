@@ -81,6 +81,7 @@ class UnicycleTask(_Task):
         self.hazards = torch.tensor(np.asarray(self.env.hazards_locations), dtype=torch.float32,
                                     device=a.device).contiguous()
         self.solver = AffineNodeSolver(a.neural_ode_model, a.device)      # policy-loss rollouts (2B rows)
+        self.solver.keep_acts = False                                     # differentiated w.r.t. the actions only
         self.fit_solver = AffineNodeSolver(a.neural_ode_model, a.device)  # NODE fit rollouts
         self.solvers = [self.solver, self.fit_solver]
 
@@ -424,6 +425,8 @@ class PvtolTask(_Task):
         self.hazards = torch.tensor(np.asarray(self.env.hazard_locations), dtype=torch.float32,
                                     device=a.device).contiguous()
         self.steps = [AffineNodeSolver(a.neural_ode_model, a.device) for _ in range(3)]
+        for sv in self.steps:
+            sv.keep_acts = False                                          # differentiated w.r.t. state / actions only
         self.fit_solver = AffineNodeSolver(a.neural_ode_model, a.device)
         self.solvers = self.steps + [self.fit_solver]
 
@@ -565,6 +568,7 @@ class PvtolBarrierTask(PvtolTask):
     def setup(self):
         a = self.agent
         self.solver = AffineNodeSolver(a.neural_ode_model, a.device)
+        self.solver.keep_acts = False
         self.fit_solver = AffineNodeSolver(a.neural_ode_model, a.device)
         self.solvers = [self.solver, self.fit_solver]
 

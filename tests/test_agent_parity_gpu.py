@@ -239,3 +239,11 @@ def test_fused_rk_step_kernel_matches_per_stage_launches(solver, rows):
         res.append((out, du.clone(), dy0.clone(), ws.K.clone(), ws.Y.clone(), ws.gout.clone(), ws.acts_f.clone()))
     for a, b, name in zip(res[0], res[1], ("out", "du", "dy0", "K", "Y", "g(x)", "acts_f")):
         vec_close(b.cpu().numpy(), a.cpu().numpy(), 2e-6, "fused vs staged: " + name)
+    # bit-packed ReLU masks instead of saved activations (rollouts that need no weight gradients): same arithmetic
+    sol = AffineNodeSolver(node, "cuda")
+    sol.keep_acts = False
+    out = sol.forward(y0, u, 2, rows, solver, 0.02).clone()
+    du, dy0 = sol.backward(dout, need_du=True, need_dy0=True)
+    assert sol.ctx["steps"][-1]["ws"].bits and sol.ctx["steps"][-1]["ws"].acts_f.dtype == torch.int32
+    for a, b, name in zip(res[1][:3], (out, du, dy0), ("out", "du", "dy0")):
+        assert torch.equal(a, b), "mask mode differs from activation mode: " + name
