@@ -431,16 +431,16 @@ __global__ __launch_bounds__(256) void mlp_bwd_skinny_partial_kernel(const MlpLa
     for (int r0 = rb; r0 < re; r0 += SK_ROWS_LDS) {
         const int nr = min(SK_ROWS_LDS, re - r0);
         __syncthreads();
-        for (int idx = col; idx < SK_ROWS_LDS * SK_MAX_IN; idx += 256) {
+        for (int idx = col; idx < nr * SK_MAX_IN; idx += 256) {
             const int r = idx / SK_MAX_IN, i = idx - r * SK_MAX_IN;
             float v = 0.f;
-            if (r < nr && i < idim)
+            if (i < idim)
                 v = (i < x0d) ? io.x0[(long)(r0 + r) * io.x0_ld + i] : io.x1[(long)(r0 + r) * io.x1_ld + (i - x0d)];
             sx[r][i] = v;
         }
-        for (int idx = col; idx < SK_ROWS_LDS * SK_MAX_OUT; idx += 256) {
+        for (int idx = col; idx < nr * SK_MAX_OUT; idx += 256) {
             const int r = idx / SK_MAX_OUT, o = idx - r * SK_MAX_OUT;
-            sdy[r][o] = (r < nr && o < odim) ? io.dy[(long)(r0 + r) * io.dy_ld + o] : 0.f;
+            sdy[r][o] = (o < odim) ? io.dy[(long)(r0 + r) * io.dy_ld + o] : 0.f;
         }
         __syncthreads();
 #pragma unroll 4
@@ -486,19 +486,25 @@ __global__ __launch_bounds__(256) void mlp_bwd_skinny_reduce_kernel(const MlpLau
     const nlbac_mlp_io& io = L.io[blockIdx.y];
     const int hid = net.hid, nwide = net.n_layers - 1, idim = net.in_dim, odim = net.out_dim;
     const int nq = skinny_nq(net);
-    const int q = blockIdx.x, col = threadIdx.x;
+    // block = (quantity q, 64-column quarter); thread = (chunk group cg, column): the four chunk groups of a block sum
+    // interleaved quarters of the chunk list, combined through LDS in a fixed order (deterministic)
+    __shared__ float part[4][64];
+    const int q = blockIdx.x >> 2, col = (blockIdx.x & 3) * 64 + (threadIdx.x & 63), cg = threadIdx.x >> 6;
     if (q >= nq) return;
     const float* w = ws + (long)blockIdx.y * S.net_stride + (long)q * 256 + col;
     float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
-    int ch = 0;
-    for (; ch + 4 <= S.n_chunks; ch += 4) {       // four fixed interleaved chains (deterministic)
+    int ch = cg;
+    for (; ch + 12 < S.n_chunks; ch += 16) {       // four fixed interleaved chains per chunk group
         s0 += w[(long)(ch + 0) * nq * 256];
-        s1 += w[(long)(ch + 1) * nq * 256];
-        s2 += w[(long)(ch + 2) * nq * 256];
-        s3 += w[(long)(ch + 3) * nq * 256];
+        s1 += w[(long)(ch + 4) * nq * 256];
+        s2 += w[(long)(ch + 8) * nq * 256];
+        s3 += w[(long)(ch + 12) * nq * 256];
     }
-    for (; ch < S.n_chunks; ++ch) s0 += w[(long)ch * nq * 256];
-    const float v = (s0 + s1) + (s2 + s3);
+    for (; ch < S.n_chunks; ch += 4) s0 += w[(long)ch * nq * 256];
+    part[cg][threadIdx.x & 63] = (s0 + s1) + (s2 + s3);
+    __syncthreads();
+    if (cg != 0) return;
+    const float v = (part[0][threadIdx.x] + part[1][threadIdx.x]) + (part[2][threadIdx.x] + part[3][threadIdx.x]);
     float* g = io.grad;
     if (q < nwide) { if (col < hid) g[net.b_off[q] + col] = v; }
     else if (q < nwide + idim) { if (col < hid) g[net.w_off[0] + (long)col * idim + (q - nwide)] = v; }
@@ -608,9 +614,13 @@ extern "C" int nlbac_mlp_bwd_data(const nlbac_mlp* nets, const nlbac_mlp_io* io,
     return 0;
 }
 
+// rows per partial-sum chunk of the skinny-gradient reduction: short chunks so that >= 1 workgroup per CU streams
+// rows concurrently (the loop is latency bound), capped at 1024 chunks
+static inline int skinny_rows_per_chunk(int B) { return (B + 1023) / 1024 > 32 ? (B + 1023) / 1024 : 32; }
+
 extern "C" long nlbac_mlp_bwd_weights_ws_floats(const nlbac_mlp* nets, int n_nets, int B) {
     long per_net = 0;
-    const int rpc = (B + 1023) / 1024 > 128 ? (B + 1023) / 1024 : 128;
+    const int rpc = skinny_rows_per_chunk(B);
     const int n_chunks = (B + rpc - 1) / rpc;
     for (int i = 0; i < n_nets; ++i) {
         const long nq = (nets[i].n_layers - 1) + nets[i].in_dim + nets[i].out_dim + 1;
@@ -644,12 +654,12 @@ extern "C" int nlbac_mlp_bwd_weights(const nlbac_mlp* nets, const nlbac_mlp_io* 
         NLBAC_CHECK_LAUNCH("nlbac_mlp_bwd_weights(wide)");
     }
     SkinnyLaunch S;
-    S.rows_per_chunk = (B + 1023) / 1024 > 128 ? (B + 1023) / 1024 : 128;
+    S.rows_per_chunk = skinny_rows_per_chunk(B);
     S.n_chunks = (B + S.rows_per_chunk - 1) / S.rows_per_chunk;
     S.net_stride = need / n_nets;
     hipLaunchKernelGGL(mlp_bwd_skinny_partial_kernel, dim3(S.n_chunks, n_nets), dim3(256), 0, (hipStream_t)s, L, S, ws);
     NLBAC_CHECK_LAUNCH("nlbac_mlp_bwd_weights(skinny partial)");
-    hipLaunchKernelGGL(mlp_bwd_skinny_reduce_kernel, dim3(max_q, n_nets), dim3(256), 0, (hipStream_t)s, L, S, ws);
+    hipLaunchKernelGGL(mlp_bwd_skinny_reduce_kernel, dim3(max_q * 4, n_nets), dim3(256), 0, (hipStream_t)s, L, S, ws);
     NLBAC_CHECK_LAUNCH("nlbac_mlp_bwd_weights(skinny reduce)");
     return 0;
 }

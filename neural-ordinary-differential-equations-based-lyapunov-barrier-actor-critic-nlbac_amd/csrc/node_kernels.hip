@@ -240,12 +240,14 @@ __device__ __forceinline__ void node_top_layer(const float* __restrict__ sdy, co
 #endif
     if (k < hidp32) {
         const bool colok = k < hid;
+        float* dzr = dz;
+        if constexpr (BITS == 0) asm volatile("" : "+v"(dzr));   // address math here, not hoisted above the dots (spills)
 #pragma unroll
         for (int i = 0; i < RPT; ++i) {
             const int m = m0 + i;
             const bool ok = colok && (m < n_rows);
             const float v = (ok && av[i] > 0.f) ? s[i] : 0.f;
-            if constexpr (BITS == 0) { if (dz && ok) dz[m * hid + k] = v; }   // (mask mode never keeps dz)
+            if constexpr (BITS == 0) { if (dzr && ok) dzr[m * hid + k] = v; }   // (mask mode never keeps dz)
             in[m * LD + k] = v;
         }
     }
