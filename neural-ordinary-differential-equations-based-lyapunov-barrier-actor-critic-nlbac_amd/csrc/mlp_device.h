@@ -67,9 +67,11 @@ struct WaveGemm {
             for (int i = 0; i < 4; ++i) {
                 MFMA4(a[i], b0[i], b1[i])
                 const int c = kc + i + 4;
+#ifndef EXP_NO_BLOAD          // (ablation: MFMAs run on stale weight registers, no L2 traffic)
                 const bool here = c <= last;
                 b0[i] = *(here ? p0 + (long)c * 64 : nx.at0(i));
                 if (NTW == 2) b1[i] = *(here ? p1 + (long)c * 64 : nx.at1(i));
+#endif
                 a[i] = *reinterpret_cast<const float4*>(arow + min(c, last) * 8);
                 __builtin_amdgcn_sched_barrier(0);   // keep each slot's refill right behind its MFMAs
             }

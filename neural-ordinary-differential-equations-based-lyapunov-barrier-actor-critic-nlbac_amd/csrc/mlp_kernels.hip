@@ -20,6 +20,7 @@
 //     flight, no LDS round trip (each wave owns its own output columns);
 //   * the skinny first-input / last-output contractions (K or N <= 16) stay
 //     on the VALU.
+#include <cstdlib>
 #include "common.h"
 #include "mlp_device.h"
 
@@ -79,8 +80,12 @@ __global__ __launch_bounds__(256) void mlp_pack_kernel(const MlpLaunch L) {
 // ---------------------------------------------------------------------------
 // MODE 1: every net has <= 4 column tiles (one per wave); MODE 2: every net has 8 (two per wave);
 // MODE 0: mixed / other widths (both register sets live).
+// MODE 3: every net has 8 column tiles and the workgroup has 8 waves, one tile each (same code path as MODE 1):
+// half the per-tile latency of MODE 2 and twice the waves per CU.
 template <int MODE>
-__global__ __launch_bounds__(256, 2) void mlp_fwd_kernel(const MlpLaunch L) {
+__global__ __launch_bounds__(MODE == 3 ? 512 : 256, 2) void mlp_fwd_kernel(const MlpLaunch L) {
+    constexpr int NTHR = (MODE == 3) ? 512 : 256;
+    constexpr bool ONE = (MODE == 1 || MODE == 3);      // one column tile per wave
     extern __shared__ __attribute__((aligned(16))) float smem[];
     const nlbac_mlp& net = L.net[blockIdx.y];
     const nlbac_mlp_io& io = L.io[blockIdx.y];
@@ -94,13 +99,13 @@ __global__ __launch_bounds__(256, 2) void mlp_fwd_kernel(const MlpLaunch L) {
     float* out = smem + NLBAC_MLP_TILE * LD;
 
     const bool active = wave < NT, two = (MODE == 2) || (MODE == 0 && (wave + 4) < NT);
-    WaveGemm<(MODE == 1) ? 1 : 2> wg2;      // MODE 1 never touches wg2 / MODE 2 never touches wg1:
+    WaveGemm<ONE ? 1 : 2> wg2;              // MODE 1/3 never touch wg2 / MODE 2 never touches wg1:
     WaveGemm<1> wg1;                        // the unused one is dead code
     if (active) {          // weights do not depend on the input: start streaming them before staging it
-        if constexpr (MODE != 1) { if (two) fwd_prime<2>(wg2, net, inp, false, wave, lane); }
+        if constexpr (!ONE) { if (two) fwd_prime<2>(wg2, net, inp, false, wave, lane); }
         if constexpr (MODE != 2) { if (!two) fwd_prime<1>(wg1, net, inp, false, wave, lane); }
     }
-    for (int idx = tid; idx < NLBAC_MLP_TILE * inp; idx += 256) {
+    for (int idx = tid; idx < NLBAC_MLP_TILE * inp; idx += NTHR) {
         const int r = idx / inp, c = idx - r * inp, row = row0 + r;
         float v = 0.f;
         if (row < B) {
@@ -116,7 +121,7 @@ __global__ __launch_bounds__(256, 2) void mlp_fwd_kernel(const MlpLaunch L) {
         float* acts_tile = io.acts ? io.acts + (long)row0 * hid : nullptr;
         const int n_rows = min(NLBAC_MLP_TILE, B - row0);
         if constexpr (MODE == 2) fwd_wide_layers<2>(wg2, net, active, wave, lane, LD, inp, in, out, acts_tile, ls, n_rows, nwide, false);
-        else if constexpr (MODE == 1) fwd_wide_layers<1>(wg1, net, active, wave, lane, LD, inp, in, out, acts_tile, ls, n_rows, nwide, false);
+        else if constexpr (ONE) fwd_wide_layers<1>(wg1, net, active, wave, lane, LD, inp, in, out, acts_tile, ls, n_rows, nwide, false);
         else {
             if (two) fwd_wide_layers<2>(wg2, net, active, wave, lane, LD, inp, in, out, acts_tile, ls, n_rows, nwide, false);
             else fwd_wide_layers<1>(wg1, net, active, wave, lane, LD, inp, in, out, acts_tile, ls, n_rows, nwide, false);
@@ -126,7 +131,7 @@ __global__ __launch_bounds__(256, 2) void mlp_fwd_kernel(const MlpLaunch L) {
     // skinny output layer on the VALU: 8 lanes per sample row + shuffle reduction.  (With 1-4 outputs and
     // hid = 256 this keeps all 256 threads busy; the one-dot-per-thread form used by the fused RK kernel
     // measured 20 % slower here.)
-    {
+    if (tid < 256) {       // (waves 4-7 of MODE 3 are done)
         const float* W = net.params + net.w_off[nwide];
         const float* bias = net.params + net.b_off[nwide];
         const int m = tid >> 3, part = tid & 7, row = row0 + m;
@@ -535,6 +540,12 @@ static int tile_mode(const nlbac_mlp* nets, int n_nets) {
     return all_le4 ? 1 : (all_8 ? 2 : 0);
 }
 
+// 256-wide nets: 8 waves x one column tile (default) or 4 waves x two tiles (NLBAC_MLP_WAVES8=0, kept for A/B runs)
+static bool waves8() {
+    static const bool on = [] { const char* e = getenv("NLBAC_MLP_WAVES8"); return !(e && e[0] == '0'); }();
+    return on;
+}
+
 static int fill_launch(MlpLaunch& L, const nlbac_mlp* nets, const nlbac_mlp_io* io, int n_nets, int B, const char* who) {
     NLBAC_REQUIRE(n_nets >= 1 && n_nets <= NLBAC_MAX_NETS, "%s: n_nets %d out of [1,%d]", who, n_nets, NLBAC_MAX_NETS);
     NLBAC_REQUIRE(B >= 1, "%s: B must be >= 1", who);
@@ -591,7 +602,10 @@ extern "C" int nlbac_mlp_fwd(const nlbac_mlp* nets, const nlbac_mlp_io* io, int 
     const dim3 grid(nlbac_ceil_div(B, NLBAC_MLP_TILE), n_nets);
     switch (tile_mode(nets, n_nets)) {
         case 1: hipLaunchKernelGGL(mlp_fwd_kernel<1>, grid, dim3(256), lds, (hipStream_t)s, L); break;
-        case 2: hipLaunchKernelGGL(mlp_fwd_kernel<2>, grid, dim3(256), lds, (hipStream_t)s, L); break;
+        case 2:
+            if (waves8()) hipLaunchKernelGGL(mlp_fwd_kernel<3>, grid, dim3(512), lds, (hipStream_t)s, L);
+            else hipLaunchKernelGGL(mlp_fwd_kernel<2>, grid, dim3(256), lds, (hipStream_t)s, L);
+            break;
         default: hipLaunchKernelGGL(mlp_fwd_kernel<0>, grid, dim3(256), lds, (hipStream_t)s, L);
     }
     NLBAC_CHECK_LAUNCH("nlbac_mlp_fwd");

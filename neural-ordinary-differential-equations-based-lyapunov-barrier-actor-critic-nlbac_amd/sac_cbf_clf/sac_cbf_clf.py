@@ -72,7 +72,10 @@ class _Workspace:
         self.B = B
         self.mb = z(B, lay.LD)                   # minibatch rows (see _Layout)
         self.eps = z(task.n_eps, B, A)
-        self.heads_n, self.na, self.nlogp = z(B, 2 * A), z(B, A), z(B)
+        # policy samples of one update live side by side: rows [0,B) pi(s'), then pi(s) (and pi_backup(s)), so that
+        # one forward launch and one sampling launch serve all of them
+        self.heads3, self.act3, self.logp3 = z((1 + NP) * B, 2 * A), z((1 + NP) * B, A), z((1 + NP) * B)
+        self.heads_n, self.na, self.nlogp = self.heads3[:B], self.act3[:B], self.logp3[:B]
         self.q6 = z(6 + 2 * NX, B)               # q1t q2t lt q1 q2 lf [xt x]...
         self.dq3 = z(3 + NX, B)
         self.next_q, self.next_l = z(B), z(B)
@@ -81,7 +84,7 @@ class _Workspace:
         self.nblk = (B + 255) // 256
         self.part_td = z(self.nblk, 3)
         self.part_tdx = z(max(NX, 1), self.nblk)
-        self.heads2, self.pi2, self.logp2 = z(NP * B, 2 * A), z(NP * B, A), z(NP * B)
+        self.heads2, self.pi2, self.logp2 = self.heads3[B:], self.act3[B:], self.logp3[B:]
         self.acts_p = z(NP, 2, B, H)
         self.dz_p = z(NP, 2, B, H)
         self.plan = None
@@ -542,6 +545,12 @@ class SAC_CBF_CLF(object):
         io = P.io_act = io_array(NP)
         for i in range(NP):
             act_io(io, i, i)
+        P.n_pol3 = mlp_array([pi.desc] + [h.desc for h in self.h_pols[:NP]])     # pi(s') + the actors on s
+        io3 = P.io_pol3 = io_array(1 + NP)
+        x(io3, 0, p_nobs, Do, LD)
+        io3[0].y, io3[0].y_ld = ws.heads_n.data_ptr(), 2 * Da
+        for i in range(NP):
+            act_io(io3, 1 + i, i)
         P.act_groups = []                # per Adam group: the nets whose weight gradients land in its arena
         for g in self.actor_groups:
             cnt = min(g.count, NP - g.first)
@@ -644,9 +653,11 @@ class SAC_CBF_CLF(object):
         p_scale, p_bias = pol.action_scale.data_ptr(), pol.action_bias.data_ptr()
 
         # ---- A. targets (no grad): pi(s'), Q_target(s', a'), L_target(c') ; critic / Lyapunov forward
-        call("nlbac_mlp_fwd", P.n_pol, P.io_pol_next, 1, B, s)
-        call("nlbac_gauss_sample_fwd", ws.heads_n.data_ptr(), 2 * A, ws.eps[0].data_ptr(), p_scale, p_bias, A, B,
-             ws.na.data_ptr(), A, ws.nlogp.data_ptr(), s)
+        # (the actors' forward on s does not depend on the critic step below: it shares pi(s')'s launch, and all
+        #  (1+NP)*B samples are drawn by one launch - eps[0 .. NP] are contiguous)
+        call("nlbac_mlp_fwd", P.n_pol3, P.io_pol3, 1 + NP, B, s)
+        call("nlbac_gauss_sample_fwd", ws.heads3.data_ptr(), 2 * A, ws.eps.data_ptr(), p_scale, p_bias, A, (1 + NP) * B,
+             ws.act3.data_ptr(), A, ws.logp3.data_ptr(), s)
         call("nlbac_mlp_fwd", P.n_six, P.io_six, P.n_six_count, B, s)
         q = ws.q6
         call("nlbac_td_targets", q[0].data_ptr(), q[1].data_ptr(), q[2].data_ptr(), ws.nlogp.data_ptr(),
@@ -671,10 +682,6 @@ class SAC_CBF_CLF(object):
             pack(self.h_crit, target=True)
 
         # ---- C. actors: sample, Q(s, pi), then the rollout of the learned dynamics -----
-        call("nlbac_mlp_fwd", P.n_act, P.io_act, NP, B, s)
-        eps2 = ws.eps[1:1 + NP]                                # (NP,B,A) == (NP*B,A)
-        call("nlbac_gauss_sample_fwd", ws.heads2.data_ptr(), 2 * A, eps2.data_ptr(), p_scale, p_bias, A, NP * B,
-             ws.pi2.data_ptr(), A, ws.logp2.data_ptr(), s)
         call("nlbac_mlp_fwd", P.n_q5, P.io_q5, P.n_q5_count, B, s)
         call("nlbac_actor_q_terms", ws.qpi[0].data_ptr(), ws.qpi[1].data_ptr(), ws.logp2.data_ptr(),
              sc + 4 * SC.SC_ALPHA, B, G, NP, ws.dq_pi[0].data_ptr(), ws.dq_pi[1].data_ptr(), ws.part_q.data_ptr(), s)
