@@ -462,7 +462,9 @@ class SAC_CBF_CLF(object):
         _lib.call("nlbac_sum_partials", w["part"].data_ptr(), nblk, 1, 1.0 / (NG * ns),
                   self.sc.data_ptr() + 4 * SC.SC_NODE_LOSS, s)
         self.task.fit_solver.backward(w["dpred"], need_du=False, need_params=True)
-        used = self.task.fit_solver.accumulate_param_grads(self.ar_n, self.n_fit_slabs)
+        # every accepted RK step writes its own gradient slabs; a solve with many steps takes narrower ones
+        n_steps = max(1, len(self.task.fit_solver.ctx.get("steps") or [None]))
+        used = self.task.fit_solver.accumulate_param_grads(self.ar_n, max(1, min(self.n_fit_slabs, self.ar_n.n_slabs // n_steps)))
         self._adam(self.ar_n, 1e-3, used, extra=self.sc[SC.SC_NODE_LOSS:SC.SC_NODE_LOSS + 1])
         pack(self.h_node)
 

@@ -1,0 +1,95 @@
+"""GPU: the dopri5 driver beyond the one-step case — several accepted steps, rejected attempts, and the per-problem
+fallback when the problems of one batch take different decisions — against the oracle's odeint + autograd
+(forward value, gradients w.r.t. the initial state, the actions and the NODE parameters)."""
+import numpy as np
+import pytest
+import torch
+
+from common import vec_close
+from nlbac_amd import synth
+from test_agent_parity_gpu import make_agent
+
+pytestmark = pytest.mark.gpu
+TOL = 1e-4
+
+
+def rows_close(a, b, name, frac=0.05, loose=2e-2):
+    """Row-wise gradient comparison for a ReLU field: the discrete gradient is discontinuous where a stage point sits on
+    a ReLU kink, and over a multi-step solve (35+ field evaluations per row) fp32 rounding flips a mask in a few rows.
+    Bar: every row within ``loose`` of the tensor's scale, at most ``frac`` of the rows beyond TOL, median row error
+    below TOL / 10."""
+    a, b = np.asarray(a, dtype=np.float64), np.asarray(b, dtype=np.float64)
+    e = np.abs(a - b).max(1) / np.abs(b).max()
+    assert e.max() <= loose, "%s: worst row off by %.3e" % (name, e.max())
+    assert (e > TOL).mean() <= frac, "%s: %.1f %% of the rows beyond %.0e" % (name, 100 * (e > TOL).mean(), TOL)
+    assert np.median(e) <= TOL / 10, "%s: median row error %.3e" % (name, np.median(e))
+
+
+def oracle_solve(sd_np, y0, u, T, dout, n_s=3, n_u=2):
+    from oracle import nlbac_oracle as O
+    sd = {k: torch.tensor(v, requires_grad=True) for k, v in sd_np.items()}
+    y0 = y0.clone().requires_grad_(True)
+    u = u.clone().requires_grad_(True)
+    info = {}
+    out = O.odeint(O.AffineNode(sd, n_s=n_s, n_u=n_u), torch.cat((y0, u), 1), torch.tensor([0.0, T]), method="dopri5",
+                   atol=1e-7, rtol=1e-5, info=info)[-1][:, :n_s]
+    g = torch.autograd.grad((out * dout).sum(), [y0, u] + list(sd.values()))
+    return out.detach(), g[0], g[1], torch.cat([t.reshape(-1) for t in g[2:]]), info
+
+
+@pytest.mark.parametrize("T", [0.3, 0.6])
+def test_multi_step_dopri5_with_parameter_gradients(T):
+    from nlbac_amd.odeint import AffineNodeSolver
+    agent, env = make_agent(64, 64, 0, "dopri5")
+    W = synth.agent_weights("Unicycle", 64, 0)["node"]
+    gen = torch.Generator().manual_seed(int(T * 10))
+    n = 200
+    y0 = torch.cat([torch.rand(n, 2, generator=gen) * 4 - 2, torch.rand(n, 1, generator=gen) * 6 - 3], 1)
+    u = (torch.rand(n, 2, generator=gen) * 2 - 1) * torch.tensor([3.5, 12.0])
+    dout = torch.randn(n, 3, generator=gen)
+    out_o, dy0_o, du_o, gp_o, info = oracle_solve(W, y0, u, T, dout)
+    n_acc = sum(1 for s_ in info["steps"] if s_[2])
+    assert n_acc >= 2, "the case must need several accepted steps (got %r)" % (info["steps"],)
+
+    sol = AffineNodeSolver(agent.neural_ode_model, "cuda")
+    out = sol.forward(y0.cuda(), u.cuda(), 1, n, "dopri5", T)
+    assert len(sol.ctx["steps"]) == n_acc
+    vec_close(out.cpu().numpy(), out_o.numpy(), TOL, "x(T)")
+    du, dy0 = sol.backward(dout.cuda(), need_du=True, need_params=True, need_dy0=True)
+    rows_close(dy0.cpu().numpy(), dy0_o.numpy(), "d/dy0")
+    rows_close(du.cpu().numpy(), du_o.numpy(), "d/du")
+    ar = agent.ar_n
+    ar.grad.zero_()
+    per = ar.n_slabs // len(sol.ctx["steps"])
+    used = sol.accumulate_param_grads(ar, per)
+    g = ar.grad[:used].sum(0)
+    gp = torch.cat([g[ar.offset_of[id(p)]:ar.offset_of[id(p)] + p.numel()] for p in agent.neural_ode_model.parameters()])
+    # parameter gradients are sums over rows: a flipped mask in a few rows moves single entries by up to one row's
+    # contribution, so the bar is on the vector as a whole
+    a, b = gp.cpu().numpy().astype(np.float64), gp_o.numpy().astype(np.float64)
+    assert np.linalg.norm(a - b) / np.linalg.norm(b) <= 5e-3, "d/d theta: relative L2 error %.3e" % (
+        np.linalg.norm(a - b) / np.linalg.norm(b))
+    assert (np.abs(a - b) > 1e-3 * np.abs(b).max()).mean() <= 0.01
+
+
+def test_problems_that_diverge_fall_back_to_per_problem_solves():
+    from nlbac_amd.odeint import AffineNodeSolver
+    agent, env = make_agent(64, 64, 0, "dopri5")
+    W = synth.agent_weights("Unicycle", 64, 0)["node"]
+    gen = torch.Generator().manual_seed(3)
+    rpp, T = 96, 0.3
+    y0 = torch.cat([torch.rand(2 * rpp, 2, generator=gen) * 4 - 2, torch.rand(2 * rpp, 1, generator=gen) * 6 - 3], 1)
+    u = (torch.rand(2 * rpp, 2, generator=gen) * 2 - 1) * torch.tensor([3.5, 12.0])
+    u[rpp:] *= 5.0                                     # the second problem is stiffer: other step sizes
+    dout = torch.randn(2 * rpp, 3, generator=gen)
+    sol = AffineNodeSolver(agent.neural_ode_model, "cuda")
+    sol.keep_acts = False
+    out = sol.forward(y0.cuda(), u.cuda(), 2, rpp, "dopri5", T)
+    du, dy0 = sol.backward(dout.cuda(), need_du=True, need_dy0=True)
+    assert sol.stats["split"] >= 1, "the case must make the two problems diverge (stats %r)" % (sol.stats,)
+    for p in range(2):
+        rows = slice(p * rpp, (p + 1) * rpp)
+        out_o, dy0_o, du_o, _, info = oracle_solve(W, y0[rows], u[rows], T, dout[rows])
+        vec_close(out[rows].cpu().numpy(), out_o.numpy(), TOL, "x(T) problem %d" % p)
+        rows_close(dy0[rows].cpu().numpy(), dy0_o.numpy(), "d/dy0 problem %d" % p)
+        rows_close(du[rows].cpu().numpy(), du_o.numpy(), "d/du problem %d" % p)
