@@ -230,6 +230,18 @@ __device__ __forceinline__ void top_layer_bwd(const float* __restrict__ sdy, con
     }
 }
 
+// A finished 32 x hid tile in LDS -> its rows in global memory (hid % 4 == 0): float4 per lane, coalesced.  Keeping the
+// global dz stores out of the MFMA epilogues (which would hold 16 row addresses per lane) is what keeps those
+// epilogues free of register spills; the copy of layer j's tile overlaps layer j-1's GEMM.
+__device__ __forceinline__ void tile_to_global(const float* __restrict__ tile, int LD, float* __restrict__ g, int hid,
+                                               int n_rows, int t, int nthr) {
+    const int q = hid >> 2;
+    for (int idx = t; idx < n_rows * q; idx += nthr) {
+        const int r = idx / q, c = (idx - r * q) << 2;
+        *reinterpret_cast<float4*>(g + r * hid + c) = *reinterpret_cast<const float4*>(tile + r * LD + c);
+    }
+}
+
 // backward wide layers: dz[j-1] = (dz[j] W_j) * [acts[j-1] > 0] for j = nwide-1 .. 1 (backward packs)
 // (wrap: after layer 1 the stream restarts at layer nwide-1 — the next RK stage of a fused backward)
 template <int NTW>
@@ -258,7 +270,7 @@ template <int NTW, int BITS = 0>
 __device__ __forceinline__ void bwd_wide_layers(WaveGemm<NTW>& wg, const nlbac_mlp& net, bool active, int wave, int lane,
                                                 int LD, float*& in, float*& out, const float* acts_tile,
                                                 float* dz_tile, long ls, int n_rows, int row_clamp,
-                                                int n_run = -1, bool wrap = false) {
+                                                int n_run = -1, bool wrap = false, int nthr = 256) {
     const int hid = net.hid, KC = pad8(hid) >> 3, nwide = net.n_layers - 1, half = lane >> 5;
     if (n_run < 0) n_run = nwide - 1;          // lock-step iterations (>= nwide-1 when groups differ in depth)
     for (int it = 0; it < n_run; ++it) {
@@ -295,7 +307,6 @@ __device__ __forceinline__ void bwd_wide_layers(WaveGemm<NTW>& wg, const nlbac_m
 #ifndef EXP_BWD_NO_GEMM
             wg.run(in + (lane & 31) * LD + half * 4, p0, p1, KC, nx, acc);
 #endif
-            float* dz = dz_tile ? dz_tile + (long)(j - 1) * ls : nullptr;
 #pragma unroll
             for (int t = 0; t < NTW; ++t) {
                 const int col = (wave + 4 * t) * 32 + (lane & 31);
@@ -304,13 +315,17 @@ __device__ __forceinline__ void bwd_wide_layers(WaveGemm<NTW>& wg, const nlbac_m
                 for (int r = 0; r < 16; ++r) {
                     const int m = acc_row(r, half);
                     const bool ok = colok && (m < n_rows);
-                    const float v = (ok && av[t][r] > 0.f) ? acc[t][r] : 0.f;
-                    if constexpr (BITS == 0) { if (dz && ok) dz[m * hid + col] = v; }   // mask mode keeps no dz
-                    out[m * LD + col] = v;
+                    out[m * LD + col] = (ok && av[t][r] > 0.f) ? acc[t][r] : 0.f;
                 }
             }
         }
         __syncthreads();
-        if (j >= 1) { float* tmp = in; in = out; out = tmp; }
+        if (j >= 1) {
+            float* tmp = in; in = out; out = tmp;
+            // dz[j-1] now sits complete in `in`: stream it out while the next layer's GEMM runs (mask mode keeps no dz)
+            if constexpr (BITS == 0) {
+                if (dz_tile) tile_to_global(in, LD, dz_tile + (long)(j - 1) * ls, hid, n_rows, wave * 64 + lane, nthr);
+            }
+        }
     }
 }

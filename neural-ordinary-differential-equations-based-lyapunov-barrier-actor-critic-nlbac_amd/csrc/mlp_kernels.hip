@@ -230,19 +230,18 @@ __global__ __launch_bounds__(256, 2) void mlp_bwd_data_kernel(const MlpLaunch L)
             else if (no == 3) top_layer_bwd<3>(sdy + o0, Wo, hid, 0, s);
             else top_layer_bwd<4>(sdy + o0, Wo, hid, 0, s);
         }
-        float* dz = io.dz ? io.dz + (long)(nwide - 1) * ls : nullptr;
         if (k < hidp32) {
             const bool colok = k < hid;
 #pragma unroll
             for (int m = 0; m < NLBAC_MLP_TILE; ++m) {
                 const bool ok = colok && (row0 + m < B);
-                const float v = (ok && av[m] > 0.f) ? s[m] : 0.f;
-                if (dz && ok) dz[(long)(row0 + m) * hid + k] = v;
-                in[m * LD + k] = v;
+                in[m * LD + k] = (ok && av[m] > 0.f) ? s[m] : 0.f;
             }
         }
     }
     __syncthreads();
+    if (io.dz)       // the top layer's dz leaves from the finished LDS tile (coalesced, overlaps the first GEMM)
+        tile_to_global(in, LD, io.dz + (long)(nwide - 1) * ls + (long)row0 * hid, hid, min(NLBAC_MLP_TILE, B - row0), tid, 256);
 
     {
         const int n_rows = min(NLBAC_MLP_TILE, B - row0);

@@ -208,8 +208,7 @@ struct NodeRkBwdLaunch {
 template <int RPT, int BITS>
 __device__ __forceinline__ void node_top_layer(const float* __restrict__ sdy, const float* __restrict__ sW, int out_dim,
                                                int hid, int hidp32, int NT, int t, int n_rows,
-                                               const float* __restrict__ atop, float* __restrict__ dz,
-                                               float* __restrict__ in, int LD) {
+                                               const float* __restrict__ atop, float* __restrict__ in, int LD) {
     constexpr int CPG = 256 * RPT / 32;            // columns per row group
     const int k = t % CPG, m0 = (t / CPG) * RPT, kc = min(k, hid - 1);
     float av[RPT];
@@ -240,15 +239,12 @@ __device__ __forceinline__ void node_top_layer(const float* __restrict__ sdy, co
 #endif
     if (k < hidp32) {
         const bool colok = k < hid;
-        float* dzr = dz;
-        if constexpr (BITS == 0) asm volatile("" : "+v"(dzr));   // address math here, not hoisted above the dots (spills)
 #pragma unroll
         for (int i = 0; i < RPT; ++i) {
             const int m = m0 + i;
             const bool ok = colok && (m < n_rows);
             const float v = (ok && av[i] > 0.f) ? s[i] : 0.f;
-            if constexpr (BITS == 0) { if (dzr && ok) dzr[m * hid + k] = v; }   // (mask mode never keeps dz)
-            in[m * LD + k] = v;
+            in[m * LD + k] = v;        // (dz goes out from this LDS tile afterwards: tile_to_global)
         }
     }
 }
@@ -353,11 +349,14 @@ __global__ __launch_bounds__(512) void node_rk_bwd_kernel(const NodeRkBwdLaunch 
         {   // top (skinny) layer: thread = (row group, hidden column); narrow nets split the 32 rows over the
             // threads that would otherwise idle (hid <= 128: 2 groups of 16 rows)
             const float* atop = acts_tile + (long)(nwide - 1) * L.acts_ls[grp];
-            float* dz = keep_dz ? L.dz[grp] + (long)(nwide - 1) * L.acts_ls[grp] + ((long)st * n + row0) * hid : nullptr;
             // MODE 1: both nets have <= 128 padded columns -> two row groups of 16 rows; otherwise one thread per column
-            node_top_layer<(MODE == 1) ? 16 : 32, BITS>(sdy, sW, net.out_dim, hid, hidp32, NT, t, n_rows, atop, dz, in, LD);
+            node_top_layer<(MODE == 1) ? 16 : 32, BITS>(sdy, sW, net.out_dim, hid, hidp32, NT, t, n_rows, atop, in, LD);
         }
         __syncthreads();
+        if constexpr (BITS == 0) {
+            if (keep_dz) tile_to_global(in, LD, L.dz[grp] + (long)(nwide - 1) * L.acts_ls[grp] + ((long)st * n + row0) * hid,
+                                        hid, n_rows, t, 256);
+        }
 
         {
             float* dz_tile = keep_dz ? L.dz[grp] + ((long)st * n + row0) * hid : nullptr;
