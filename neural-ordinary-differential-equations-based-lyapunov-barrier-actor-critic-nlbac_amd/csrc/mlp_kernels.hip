@@ -341,29 +341,40 @@ __global__ __launch_bounds__(256) void mlp_bwd_wide_kernel(const MlpLaunch L) {
         *reinterpret_cast<float4*>(&sB[buf_][lr][lc]) = sel4(b_ok && lo_, B0);              \
         *reinterpret_cast<float4*>(&sB[buf_][lr + 16][lc]) = sel4(b_ok && hi_, B1);         \
     }
+    // Register double buffering without copies: the loop is unrolled by two and the two operand register sets swap
+    // roles (X: loaded last step, staged this step; Y: in flight) - a "c = n" copy at the end of each step would make
+    // the compiler wait for the in-flight loads there and serialise the stream.
+#define DW_MFMA(buf_)                                                                       \
+    {                                                                                       \
+        float av[DW_CHUNK / 2], bv[DW_CHUNK / 2];                                           \
+        _Pragma("unroll") for (int bb = 0; bb < DW_CHUNK / 2; ++bb) {                       \
+            av[bb] = sA[buf_][2 * bb + half][wn * 32 + (lane & 31)];                        \
+            bv[bb] = sB[buf_][2 * bb + half][wk * 32 + (lane & 31)];                        \
+        }                                                                                   \
+        __builtin_amdgcn_sched_barrier(0);                                                  \
+        _Pragma("unroll") for (int bb = 0; bb < DW_CHUNK / 2; ++bb)                         \
+            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av[bb], bv[bb], acc, 0, 0, 0);       \
+    }
     if (rb < re) {
-        float4 c_a0, c_a1, c_b0, c_b1;      // chunk +1 (to be staged next)
-        float4 n_a0, n_a1, n_b0, n_b1;      // chunk +2 (in flight)
-        DW_LOAD(rb, c_a0, c_a1, c_b0, c_b1)
-        DW_STAGE(rb, c_a0, c_a1, c_b0, c_b1, 0)
-        DW_LOAD(rb + DW_CHUNK, c_a0, c_a1, c_b0, c_b1)
+        float4 x_a0, x_a1, x_b0, x_b1, y_a0, y_a1, y_b0, y_b1;
+        DW_LOAD(rb, x_a0, x_a1, x_b0, x_b1)
+        DW_STAGE(rb, x_a0, x_a1, x_b0, x_b1, 0)
+        DW_LOAD(rb + DW_CHUNK, x_a0, x_a1, x_b0, x_b1)
         __syncthreads();
-        int buf = 0;
-        for (int r0 = rb; r0 < re; r0 += DW_CHUNK) {
-            const bool more = (r0 + DW_CHUNK) < re;
-            if (more) DW_LOAD(r0 + 2 * DW_CHUNK, n_a0, n_a1, n_b0, n_b1)
-#pragma unroll
-            for (int bb = 0; bb < DW_CHUNK / 2; ++bb) {
-                const float a = sA[buf][2 * bb + half][wn * 32 + (lane & 31)];
-                const float b = sB[buf][2 * bb + half][wk * 32 + (lane & 31)];
-                acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, acc, 0, 0, 0);
-            }
-            if (more) {
-                DW_STAGE(r0 + DW_CHUNK, c_a0, c_a1, c_b0, c_b1, buf ^ 1)
-                c_a0 = n_a0; c_a1 = n_a1; c_b0 = n_b0; c_b1 = n_b1;
-            }
+        for (int r0 = rb; r0 < re; r0 += 2 * DW_CHUNK) {
+            if (r0 + 2 * DW_CHUNK < re) DW_LOAD(r0 + 2 * DW_CHUNK, y_a0, y_a1, y_b0, y_b1)
+            __builtin_amdgcn_sched_barrier(0);     // the loads are issued HERE (the scheduler would sink them to their use)
+            DW_MFMA(0)
+            __builtin_amdgcn_sched_barrier(0);
+            if (r0 + DW_CHUNK < re) DW_STAGE(r0 + DW_CHUNK, x_a0, x_a1, x_b0, x_b1, 1)
             __syncthreads();
-            buf ^= 1;
+            if (r0 + DW_CHUNK >= re) break;
+            if (r0 + 3 * DW_CHUNK < re) DW_LOAD(r0 + 3 * DW_CHUNK, x_a0, x_a1, x_b0, x_b1)
+            __builtin_amdgcn_sched_barrier(0);
+            DW_MFMA(1)
+            __builtin_amdgcn_sched_barrier(0);
+            if (r0 + 2 * DW_CHUNK < re) DW_STAGE(r0 + 2 * DW_CHUNK, y_a0, y_a1, y_b0, y_b1, 0)
+            __syncthreads();
         }
     }
     float* g = io.grad + (long)slab * L.slab_stride + net.w_off[j];
@@ -372,6 +383,104 @@ __global__ __launch_bounds__(256) void mlp_bwd_wide_kernel(const MlpLaunch L) {
     for (int r = 0; r < 16; ++r) {
         const int n = n0 + wn * 32 + acc_row(r, half);
         if (n < hid && k < hid) g[(long)n * hid + k] = acc[r];
+    }
+}
+
+// Narrow nets (hid <= 128, the NODE fit): one workgroup owns the whole (padded 128x128) dW_j of a layer for its row
+// slab, so dz and acts are read from HBM once per layer instead of once per 64-column tile pair (the fit streams
+// ~1.3 GB of them per RK step - the one HBM-bound place of the update).  Each wave accumulates a 64x64 quadrant
+// (2x2 MFMA tiles): four MFMAs per pair of LDS operand reads.  grid.x = layer, grid.y = row slab, grid.z = net.
+#define DW128_LD 132
+__global__ __launch_bounds__(256) void mlp_bwd_wide128_kernel(const MlpLaunch L) {
+    extern __shared__ __attribute__((aligned(16))) float dw_smem[];
+    float (*sA)[DW_CHUNK][DW128_LD] = reinterpret_cast<float (*)[DW_CHUNK][DW128_LD]>(dw_smem);
+    float (*sB)[DW_CHUNK][DW128_LD] = reinterpret_cast<float (*)[DW_CHUNK][DW128_LD]>(dw_smem + 2 * DW_CHUNK * DW128_LD);
+    const nlbac_mlp& net = L.net[blockIdx.z];
+    const nlbac_mlp_io& io = L.io[blockIdx.z];
+    const int B = L.B, hid = net.hid, nwide = net.n_layers - 1;
+    if ((int)blockIdx.x >= nwide - 1) return;
+    const int j = 1 + blockIdx.x;
+    const int slab = blockIdx.y;
+    const int rb = slab * L.rows_per_slab, re = min(B, rb + L.rows_per_slab);
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, half = lane >> 5;
+    const int wn = wave >> 1, wk = wave & 1;
+    const long ls = io.acts_ls ? io.acts_ls : (long)B * hid;
+    const float* dz = io.dz + (long)j * ls;
+    const float* at = io.acts + (long)(j - 1) * ls;
+    const int lr = tid >> 5, lc = (tid & 31) * 4;        // this thread stages rows lr, lr+8, lr+16, lr+24 of a chunk
+    const bool c_ok = lc < hid;
+    const float* pa = dz + (c_ok ? lc : 0);
+    const float* pb = at + (c_ok ? lc : 0);
+
+    f32x16 acc[4];
+#pragma unroll
+    for (int q = 0; q < 4; ++q)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[q][r] = 0.f;
+
+#define DW128_LOAD(r0_, A, Bv)                                                              \
+    {                                                                                       \
+        _Pragma("unroll") for (int q = 0; q < 4; ++q) {                                     \
+            const int rr_ = min((r0_) + lr + 8 * q, re - 1);                                \
+            A[q] = *reinterpret_cast<const float4*>(pa + (long)rr_ * hid);                  \
+            Bv[q] = *reinterpret_cast<const float4*>(pb + (long)rr_ * hid);                 \
+        }                                                                                   \
+    }
+#define DW128_STAGE(r0_, A, Bv, buf_)                                                       \
+    {                                                                                       \
+        _Pragma("unroll") for (int q = 0; q < 4; ++q) {                                     \
+            const bool ok_ = c_ok && ((r0_) + lr + 8 * q < re);                             \
+            *reinterpret_cast<float4*>(&sA[buf_][lr + 8 * q][lc]) = sel4(ok_, A[q]);        \
+            *reinterpret_cast<float4*>(&sB[buf_][lr + 8 * q][lc]) = sel4(ok_, Bv[q]);       \
+        }                                                                                   \
+    }
+#define DW128_MFMA(buf_)                                                                    \
+    {                                                                                       \
+        float a0[DW_CHUNK / 2], a1[DW_CHUNK / 2], b0[DW_CHUNK / 2], b1[DW_CHUNK / 2];       \
+        _Pragma("unroll") for (int bb = 0; bb < DW_CHUNK / 2; ++bb) {                       \
+            const float* ra = &sA[buf_][2 * bb + half][wn * 64 + (lane & 31)];              \
+            const float* rbp = &sB[buf_][2 * bb + half][wk * 64 + (lane & 31)];             \
+            a0[bb] = ra[0]; a1[bb] = ra[32]; b0[bb] = rbp[0]; b1[bb] = rbp[32];             \
+        }                                                                                   \
+        __builtin_amdgcn_sched_barrier(0);                                                  \
+        _Pragma("unroll") for (int bb = 0; bb < DW_CHUNK / 2; ++bb) {                       \
+            acc[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0[bb], b0[bb], acc[0], 0, 0, 0); \
+            acc[1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0[bb], b1[bb], acc[1], 0, 0, 0); \
+            acc[2] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1[bb], b0[bb], acc[2], 0, 0, 0); \
+            acc[3] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1[bb], b1[bb], acc[3], 0, 0, 0); \
+        }                                                                                   \
+    }
+    if (rb < re) {      // (two register sets swapping roles, loop unrolled by two: see mlp_bwd_wide_kernel)
+        float4 xa[4], xb[4], ya[4], yb[4];
+        DW128_LOAD(rb, xa, xb)
+        DW128_STAGE(rb, xa, xb, 0)
+        DW128_LOAD(rb + DW_CHUNK, xa, xb)
+        __syncthreads();
+        for (int r0 = rb; r0 < re; r0 += 2 * DW_CHUNK) {
+            if (r0 + 2 * DW_CHUNK < re) DW128_LOAD(r0 + 2 * DW_CHUNK, ya, yb)
+            __builtin_amdgcn_sched_barrier(0);     // the loads are issued HERE (the scheduler would sink them to their use)
+            DW128_MFMA(0)
+            __builtin_amdgcn_sched_barrier(0);
+            if (r0 + DW_CHUNK < re) DW128_STAGE(r0 + DW_CHUNK, xa, xb, 1)
+            __syncthreads();
+            if (r0 + DW_CHUNK >= re) break;
+            if (r0 + 3 * DW_CHUNK < re) DW128_LOAD(r0 + 3 * DW_CHUNK, xa, xb)
+            __builtin_amdgcn_sched_barrier(0);
+            DW128_MFMA(1)
+            __builtin_amdgcn_sched_barrier(0);
+            if (r0 + 2 * DW_CHUNK < re) DW128_STAGE(r0 + 2 * DW_CHUNK, ya, yb, 0)
+            __syncthreads();
+        }
+    }
+    float* g = io.grad + (long)slab * L.slab_stride + net.w_off[j];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        const int k = wk * 64 + (q & 1) * 32 + (lane & 31);
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int n = wn * 64 + (q >> 1) * 32 + acc_row(r, half);
+            if (n < hid && k < hid) g[n * hid + k] = acc[q][r];
+        }
     }
 }
 
@@ -663,7 +772,23 @@ extern "C" int nlbac_mlp_bwd_weights(const nlbac_mlp* nets, const nlbac_mlp_io* 
     rps = (rps + DW_CHUNK - 1) / DW_CHUNK * DW_CHUNK;
     L.n_slabs = n_slabs; L.rows_per_slab = rps; L.slab_stride = slab_stride;
     if (max_blocks > 0) {
-        hipLaunchKernelGGL(mlp_bwd_wide_kernel, dim3(max_blocks, n_slabs, n_nets), dim3(256), 0, (hipStream_t)s, L);
+        bool narrow = true;
+        int max_layers = 0;
+        for (int i = 0; i < n_nets; ++i) {
+            narrow = narrow && nets[i].hid <= 128;
+            if (nets[i].n_layers - 2 > max_layers) max_layers = nets[i].n_layers - 2;
+        }
+        if (narrow) {
+            static bool attr_set = false;
+            const size_t lds = (size_t)4 * DW_CHUNK * DW128_LD * sizeof(float);
+            if (!attr_set) {
+                (void)hipFuncSetAttribute((const void*)mlp_bwd_wide128_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+                attr_set = true;
+            }
+            hipLaunchKernelGGL(mlp_bwd_wide128_kernel, dim3(max_layers, n_slabs, n_nets), dim3(256), lds, (hipStream_t)s, L);
+        } else {
+            hipLaunchKernelGGL(mlp_bwd_wide_kernel, dim3(max_blocks, n_slabs, n_nets), dim3(256), 0, (hipStream_t)s, L);
+        }
         NLBAC_CHECK_LAUNCH("nlbac_mlp_bwd_weights(wide)");
     }
     SkinnyLaunch S;
