@@ -510,6 +510,46 @@ __device__ __forceinline__ int skinny_nq(const nlbac_mlp& net) {
 }
 
 #define SK_ROWS_LDS 128
+// The row loop of one chunk for a net with NW wide layers: thread = hidden column.  Eight rows are in flight per
+// thread (8 x (NW + 1) independent loads: the loop is latency bound), none of them redundant.
+template <int NW>
+__device__ __forceinline__ void skinny_rows(const float* __restrict__ aL, const float* __restrict__ dz0, long ls, int hid,
+                                            int r0, int nr, const float (*sx)[SK_MAX_IN], const float (*sdy)[SK_MAX_OUT],
+                                            int col, float (&dW0)[SK_MAX_IN], float (&dWL)[SK_MAX_OUT],
+                                            float (&db)[NLBAC_MAX_LAYERS - 1], float& dbL) {
+    constexpr int U = 8;
+    for (int rr = 0; rr < nr; rr += U) {
+        float a[U], z[U][NW];
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const long ro = (long)(r0 + min(rr + u, nr - 1)) * hid;       // clamped: every load unconditional
+            a[u] = aL[ro];
+#pragma unroll
+            for (int j = 0; j < NW; ++j) z[u][j] = dz0[(long)j * ls + ro];
+        }
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            if (rr + u < nr) {                                            // (uniform)
+                const int r = rr + u;
+#pragma unroll
+                for (int j = 0; j < NW; ++j) db[j] += z[u][j];
+#pragma unroll
+                for (int i = 0; i < SK_MAX_IN; i += 4) {
+                    const float4 xv = *reinterpret_cast<const float4*>(&sx[r][i]);
+                    dW0[i] += z[u][0] * xv.x; dW0[i + 1] += z[u][0] * xv.y; dW0[i + 2] += z[u][0] * xv.z; dW0[i + 3] += z[u][0] * xv.w;
+                }
+#pragma unroll
+                for (int o = 0; o < SK_MAX_OUT; o += 4) {
+                    const float4 dv = *reinterpret_cast<const float4*>(&sdy[r][o]);
+                    dWL[o] += dv.x * a[u]; dWL[o + 1] += dv.y * a[u]; dWL[o + 2] += dv.z * a[u]; dWL[o + 3] += dv.w * a[u];
+                }
+                if (col < SK_MAX_OUT) dbL += sdy[r][col];
+            }
+        }
+    }
+}
+
 __global__ __launch_bounds__(256) void mlp_bwd_skinny_partial_kernel(const MlpLaunch L, const SkinnyLaunch S,
                                                                      float* __restrict__ ws) {
     // x / dy rows of the current 128-row block, zero-padded to fixed widths so the
@@ -536,9 +576,7 @@ __global__ __launch_bounds__(256) void mlp_bwd_skinny_partial_kernel(const MlpLa
     for (int j = 0; j < NLBAC_MAX_LAYERS - 1; ++j) db[j] = 0.f;
     float dbL = 0.f;
     const float* aL = io.acts + (long)(nwide - 1) * ls + c;
-    const float* dzp[NLBAC_MAX_LAYERS - 1];
-#pragma unroll
-    for (int j = 0; j < NLBAC_MAX_LAYERS - 1; ++j) dzp[j] = io.dz + (long)min(j, nwide - 1) * ls + c;
+    const float* dz0 = io.dz + c;
     const int x0d = io.x0_dim;
 
     for (int r0 = rb; r0 < re; r0 += SK_ROWS_LDS) {
@@ -556,26 +594,12 @@ __global__ __launch_bounds__(256) void mlp_bwd_skinny_partial_kernel(const MlpLa
             sdy[r][o] = (o < odim) ? io.dy[(long)(r0 + r) * io.dy_ld + o] : 0.f;
         }
         __syncthreads();
-#pragma unroll 4
-        for (int r = 0; r < nr; ++r) {
-            const long ro = (long)(r0 + r) * hid;
-            const float a = aL[ro];
-            float z[NLBAC_MAX_LAYERS - 1];
-#pragma unroll
-            for (int j = 0; j < NLBAC_MAX_LAYERS - 1; ++j) z[j] = dzp[j][ro];
-#pragma unroll
-            for (int j = 0; j < NLBAC_MAX_LAYERS - 1; ++j) db[j] += z[j];
-#pragma unroll
-            for (int i = 0; i < SK_MAX_IN; i += 4) {
-                const float4 xv = *reinterpret_cast<const float4*>(&sx[r][i]);
-                dW0[i] += z[0] * xv.x; dW0[i + 1] += z[0] * xv.y; dW0[i + 2] += z[0] * xv.z; dW0[i + 3] += z[0] * xv.w;
-            }
-#pragma unroll
-            for (int o = 0; o < SK_MAX_OUT; o += 4) {
-                const float4 dv = *reinterpret_cast<const float4*>(&sdy[r][o]);
-                dWL[o] += dv.x * a; dWL[o + 1] += dv.y * a; dWL[o + 2] += dv.z * a; dWL[o + 3] += dv.w * a;
-            }
-            if (col < SK_MAX_OUT) dbL += sdy[r][col];
+        switch (nwide) {       // (uniform per block)
+            case 1: skinny_rows<1>(aL, dz0, ls, hid, r0, nr, sx, sdy, col, dW0, dWL, db, dbL); break;
+            case 2: skinny_rows<2>(aL, dz0, ls, hid, r0, nr, sx, sdy, col, dW0, dWL, db, dbL); break;
+            case 3: skinny_rows<3>(aL, dz0, ls, hid, r0, nr, sx, sdy, col, dW0, dWL, db, dbL); break;
+            case 4: skinny_rows<4>(aL, dz0, ls, hid, r0, nr, sx, sdy, col, dW0, dWL, db, dbL); break;
+            default: skinny_rows<5>(aL, dz0, ls, hid, r0, nr, sx, sdy, col, dW0, dWL, db, dbL);
         }
     }
 
