@@ -763,6 +763,32 @@ class SAC_CBF_CLF(object):
         self.repack_all()
 
 
+    # Full training state (row f4: what the reference's save_model omits — targets, optimiser moments and step counts,
+    # multipliers, augmented terms, temperatures, the NODE): resume continues bit for bit.
+    def save_checkpoint(self, path):
+        names = ("ar_c", "ar_a", "ar_b", "ar_n")
+        state = {"solver": self.solver, "sc": self.sc.cpu()}
+        for n in names:
+            a = getattr(self, n, None)
+            if a is not None:
+                state[n] = {k: getattr(a, k).cpu() for k in ("theta", "m", "v", "state")}
+                if a.target is not None:
+                    state[n]["target"] = a.target.cpu()
+        torch.save(state, path)
+
+    def load_checkpoint(self, path):
+        state = torch.load(path, map_location="cpu", weights_only=True)
+        for n, a_state in state.items():
+            if n in ("solver", "sc"):
+                continue
+            a = getattr(self, n)
+            for k, v in a_state.items():
+                getattr(a, k).copy_(v)
+        self.sc.copy_(state["sc"])
+        self.solver = state["solver"]
+        self.repack_all()
+
+
 class _TargetView:
     """state_dict-style access to a target network stored in ``arena.target``."""
 

@@ -63,3 +63,40 @@ def test_device_replay_ring_wraps_and_bulk_insert():
     torch.testing.assert_close(mem2.rows.cpu(), mem.rows.cpu())
     out = mem.sample_rows(8)
     assert out.shape == (8, agent.lay.LD)
+
+
+def test_checkpoint_resume_is_bit_identical(tmp_path):
+    """save_model / load_weights round trip (reference files) and the full-state checkpoint: resuming continues bit
+    for bit."""
+    B = 64
+    tr = synth.transitions("Unicycle", 512, seed=9)
+
+    def run(agent, env, updates):
+        rs = np.random.RandomState(updates[0])
+        rets = []
+        for u in updates:
+            idx = rs.choice(512, B, replace=False)
+            agent.set_noise(synth.normal_eps(3, B, 2, seed=u))
+            host = tuple(tr[f][idx] for f in synth.FIELDS)
+            node = tuple(tr[f][:256] for f in ("obs", "action", "next_obs")) if u % 10 == 0 else None
+            rets.append(agent.update_from_host(host, u, node))
+        return rets
+    a0, env = make_agent(B, 64, 0, "rk4")
+    run(a0, env, [0, 1, 2])
+    a0.save_checkpoint(str(tmp_path / "full.pt"))
+    a0.save_model(str(tmp_path))
+    tail0 = run(a0, env, [10, 11])
+    a1, _ = make_agent(B, 64, 1, "euler")          # different seed / solver: everything must come from the file
+    a1.load_checkpoint(str(tmp_path / "full.pt"))
+    tail1 = run(a1, env, [10, 11])
+    np.testing.assert_array_equal(np.array(tail0), np.array(tail1))
+    for x, y in ((a0.ar_c, a1.ar_c), (a0.ar_a, a1.ar_a), (a0.ar_n, a1.ar_n)):
+        assert torch.equal(x.theta, y.theta) and torch.equal(x.m, y.m)
+    assert torch.equal(a0.ar_c.target, a1.ar_c.target) and torch.equal(a0.sc, a1.sc)
+    # reference-format files: policy / critic / Lyapunov / NODE weights round-trip through the .pkl files
+    a2, _ = make_agent(B, 64, 2, "rk4")
+    a2.load_weights(str(tmp_path))
+    obs = tr["obs"][:5]
+    a3, _ = make_agent(B, 64, 3, "rk4")
+    a3.load_checkpoint(str(tmp_path / "full.pt"))
+    np.testing.assert_array_equal(a2.select_action(obs, evaluate=True), a3.select_action(obs, evaluate=True))
