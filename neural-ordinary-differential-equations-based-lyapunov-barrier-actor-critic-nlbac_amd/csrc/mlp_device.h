@@ -187,7 +187,7 @@ __device__ __forceinline__ void fwd_wide_layers(WaveGemm<NTW>& wg, const nlbac_m
 #pragma unroll
                 for (int r = 0; r < 16; ++r) {
                     v[r] = colok ? fmaxf(acc[t][r] + bv[t], 0.f) : 0.f;
-                    out[acc_row(r, half) * LD + col] = v[r];
+                    if (col < LD - 4) out[acc_row(r, half) * LD + col] = v[r];   // (a narrow LD holds pad8(hid) columns)
                 }
                 if (BITS && acts) {
                     unsigned* mp = reinterpret_cast<unsigned*>(acts) + (wave + 4 * t);

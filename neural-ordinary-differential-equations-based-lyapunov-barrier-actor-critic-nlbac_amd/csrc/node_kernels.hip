@@ -42,9 +42,12 @@ struct NodeRkLaunch {
     int sw_off1;                      // float offset of g_net's output-layer block behind f_net's in LDS
 };
 
+// OCC 1: compiled for 4 waves per SIMD (128 VGPRs, a few spills) so that two workgroups share a CU and overlap their
+// per-tile latency chains - pays off only for launches with well over one tile per CU (measured: 32768 rows, mask mode,
+// 390 -> 329 us; 8192 rows 99 -> 104 us), so the launcher picks it by tile count.
 // MODE 1: both nets <= 4 column tiles, 2: both 8, 0: mixed (see mlp_kernels.hip); BITS: save ReLU bit masks
-template <int MODE, int BITS>
-__global__ __launch_bounds__(512) void node_rk_fwd_kernel(const NodeRkLaunch L) {
+template <int MODE, int BITS, int OCC>
+__global__ __launch_bounds__(512, OCC ? 4 : 2) void node_rk_fwd_kernel(const NodeRkLaunch L) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     const int tid = threadIdx.x, t = tid & 255;
     const int grp = __builtin_amdgcn_readfirstlane(tid >> 8);   // wave-uniform: lets L.net[grp] etc. be scalar loads
@@ -507,7 +510,8 @@ extern "C" int nlbac_node_rk_fwd(const nlbac_mlp* f, const nlbac_mlp* g, const f
     L.acts[0] = acts_f; L.acts[1] = acts_g; L.acts_ls[0] = acts_f_ls; L.acts_ls[1] = acts_g_ls;
     L.acts_bits = acts_bits;
     L.out = out; L.err = err;
-    int w = ((f->hid > g->hid ? f->hid : g->hid) + 31) & ~31;
+    // LDS tiles hold pad8(hid) columns (the next layer's K extent), row stride = 4 mod 8 dwords: two workgroups fit per CU
+    int w = ((f->hid > g->hid ? f->hid : g->hid) + 7) & ~7;
     L.ld = w + 4;
     L.sw_off1 = ((f->out_dim * (f->hid + 1)) + 3) & ~3;
     const int sw_total = L.sw_off1 + (((g->out_dim * (g->hid + 1)) + 3) & ~3);
@@ -516,19 +520,27 @@ extern "C" int nlbac_node_rk_fwd(const nlbac_mlp* f, const nlbac_mlp* g, const f
                        sizeof(float);
     NLBAC_REQUIRE(lds <= 160 * 1024, "nlbac_node_rk_fwd: LDS budget exceeded (%zu B)", lds);
     using KernelF = void (*)(const NodeRkLaunch);
-    static const KernelF kf[2][3] = {{node_rk_fwd_kernel<0, 0>, node_rk_fwd_kernel<1, 0>, node_rk_fwd_kernel<2, 0>},
-                                     {node_rk_fwd_kernel<0, 1>, node_rk_fwd_kernel<1, 1>, node_rk_fwd_kernel<2, 1>}};
+    static const KernelF kf[2][2][3] = {
+        {{node_rk_fwd_kernel<0, 0, 0>, node_rk_fwd_kernel<1, 0, 0>, node_rk_fwd_kernel<2, 0, 0>},
+         {node_rk_fwd_kernel<0, 1, 0>, node_rk_fwd_kernel<1, 1, 0>, node_rk_fwd_kernel<2, 1, 0>}},
+        {{node_rk_fwd_kernel<0, 0, 1>, node_rk_fwd_kernel<1, 0, 1>, node_rk_fwd_kernel<2, 0, 1>},
+         {node_rk_fwd_kernel<0, 1, 1>, node_rk_fwd_kernel<1, 1, 1>, node_rk_fwd_kernel<2, 1, 1>}}};
     static bool attr_set = false;
     if (!attr_set) {
-        for (int b = 0; b < 2; ++b)
-            for (int m = 0; m < 3; ++m)
-                (void)hipFuncSetAttribute((const void*)kf[b][m], hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        for (int o = 0; o < 2; ++o)
+            for (int b = 0; b < 2; ++b)
+                for (int m = 0; m < 3; ++m)
+                    (void)hipFuncSetAttribute((const void*)kf[o][b][m], hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         attr_set = true;
     }
     const int ntf = (f->hid + 31) >> 5, ntg = (g->hid + 31) >> 5;
     const int mode = (ntf <= 4 && ntg <= 4) ? 1 : ((ntf == 8 && ntg == 8) ? 2 : 0);
-    const dim3 grid(nlbac_ceil_div(L.n, NLBAC_MLP_TILE));
-    hipLaunchKernelGGL(kf[acts_bits ? 1 : 0][mode], grid, dim3(512), lds, (hipStream_t)s, L);
+    const int n_tiles = nlbac_ceil_div(L.n, NLBAC_MLP_TILE);
+    // two workgroups per CU when there is more than ~1.5 tiles per CU, the tiles fit twice into LDS and no
+    // activations are streamed out (mask mode / no save)
+    const int occ = (n_tiles > 384 && lds <= 80 * 1024 && (acts_bits || !acts_f)) ? 1 : 0;
+    const dim3 grid(n_tiles);
+    hipLaunchKernelGGL(kf[occ][acts_bits ? 1 : 0][mode], grid, dim3(512), lds, (hipStream_t)s, L);
     NLBAC_CHECK_LAUNCH("nlbac_node_rk_fwd");
     return 0;
 }
