@@ -77,9 +77,10 @@ class _StepWS:
             f, g = solver.f, solver.g
             z = lambda *s: torch.zeros(*s, dtype=torch.float32, device=dev)
             self.dK = z(S, n, ns)
-            self.dG = z(S, n, ns * nu)
-            self.dz_f = z(f.n_layers - 1, S * n, f.hid)
-            self.dz_g = z(g.n_layers - 1, S * n, g.hid)
+            keep = solver.keep_acts or not solver.fused      # weight gradients / the stage-by-stage path need dz
+            self.dG = z(S, n, ns * nu) if keep else None
+            self.dz_f = z(f.n_layers - 1, S * n, f.hid) if keep else None
+            self.dz_g = z(g.n_layers - 1, S * n, g.hid) if keep else None
             self.dXf = z(n, f.in_dim)
             self.dXg = z(n, g.in_dim)
             self.dy0 = z(n, ns)
@@ -113,6 +114,26 @@ class AffineNodeSolver:
         if key not in self._ws:
             self._ws[key] = self.STEP_WS(self, n, S)
         return self._ws[key]
+
+    def reserve(self, n, P, method, steps=2):
+        """Allocate the buffers of a solve on n rows / P problems ahead of time: the step workspaces of the first
+        ``steps`` accepted dopri5 steps (forward and backward halves) and, for P > 1, those of the per-problem fallback
+        solvers — so that the first multi-step or diverging solve of a run does not pay tens of milliseconds of
+        allocation in the middle of training."""
+        if method != "dopri5":
+            S = len(TABLEAU[method]["c_sol"])
+            self._step_ws(n, S, 0).bwd(self)
+            return
+        for idx in range(steps):
+            self._step_ws(n, 7, idx).bwd(self)
+        self._step_ws(n, 1, "tmp")
+        if P > 1:
+            for p in range(P):
+                if p not in self._children:
+                    self._children[p] = type(self)(self.node, self.device)
+                k = self._children[p]
+                k.comm, k.fused, k.keep_acts = self.comm, self.fused, self.keep_acts
+                k.reserve(n // P, 1, method, steps)
 
     def _buf(self, name, *shape, dtype=torch.float32):
         key = (name, shape, dtype)
@@ -466,7 +487,9 @@ class AffineNodeSolver:
                 else:
                     ws.dy0.zero_()
                     ws.dy1.copy_(dy_carry)
-                    ws.dK[6].add_(dk_carry)
+                    # (own kernel: the first use of an ATen op lazily loads its code object - ~60 ms in the middle of training)
+                    _lib.call("nlbac_axpby", 1.0, ws.dK[6].data_ptr(), 1.0, dk_carry.data_ptr(), ws.dK[6].numel(),
+                              ws.dK[6].data_ptr(), s)
                 top_up = ws.dy1           # y1 == stage-6 input
             else:
                 tab = TABLEAU[method]

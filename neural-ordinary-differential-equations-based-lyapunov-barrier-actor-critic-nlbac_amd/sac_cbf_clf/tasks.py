@@ -40,6 +40,14 @@ class _Task:
     def z(self, *shape):
         return torch.zeros(*shape, dtype=torch.float32, device=self.agent.device)
 
+    def reserve(self, solver, n, P):
+        """Pre-allocate a solver's buffers for (n rows, P problems, the agent's current method) once."""
+        key = (id(solver), n, P, self.agent.solver)
+        seen = self.__dict__.setdefault("_reserved", set())
+        if key not in seen:
+            seen.add(key)
+            solver.reserve(n, P, self.agent.solver)
+
     def n_pol_now(self, updates):
         return self.n_pol
 
@@ -123,6 +131,7 @@ class UnicycleTask(_Task):
         # state (twice: primary and backup rows of the rollout) and look-ahead point
         _lib.call("nlbac_unicycle_state", p_obs, LD, B, self.l_p, ws.y0_2.data_ptr(), ws.ps.data_ptr(), s)
         _lib.call("nlbac_unicycle_state", p_obs, LD, B, self.l_p, ws.y0_2[B:].data_ptr(), None, s)
+        self.reserve(self.solver, 2 * B, 2)
         self.solver.forward_begin(ws.y0_2, ws.pi2, 2, B, a.solver, float(self.env.dt), a.atol, a.rtol)
 
     def loss_and_backward(self, ws, P, lam_upd, assume_single):
@@ -164,6 +173,8 @@ class UnicycleTask(_Task):
         a, s = self.agent, stream_ptr()
         _lib.call("nlbac_unicycle_state", p_obs, obs_ld, N, self.l_p, w["st"].data_ptr(), None, s)
         _lib.call("nlbac_unicycle_state", p_nobs, nobs_ld, N, self.l_p, w["nst"].data_ptr(), None, s)
+        if isinstance(self.fit_solver, AffineNodeSolver) and not isinstance(self.fit_solver, ConcatNodeSolver):
+            self.reserve(self.fit_solver, N, 1)
         self.fit_solver.forward_begin(w["st"], w["u"], 1, N, a.solver, self.env.dt, a.atol, a.rtol)
 
 
@@ -231,6 +242,7 @@ class UnicycleBarrierTask(UnicycleTask):
     def rollout_begin(self, ws, P):
         a, s = self.agent, stream_ptr()
         _lib.call("nlbac_unicycle_state", ws.mb.data_ptr(), a.lay.LD, ws.B, self.l_p, ws.y0.data_ptr(), None, s)
+        self.reserve(self.solver, ws.B, 1)
         self.solver.forward_begin(ws.y0, ws.pi2, 1, ws.B, a.solver, float(self.env.dt), a.atol, a.rtol)
 
     def loss_and_backward(self, ws, P, lam_upd, assume_single):
@@ -379,6 +391,8 @@ class CarsTask(_Task):
         a, s = self.agent, stream_ptr()
         _lib.call("nlbac_cars_state", p_obs, obs_ld, N, w["st"].data_ptr(), s)
         _lib.call("nlbac_cars_state", p_nobs, nobs_ld, N, w["nst"].data_ptr(), s)
+        if isinstance(self.fit_solver, AffineNodeSolver) and not isinstance(self.fit_solver, ConcatNodeSolver):
+            self.reserve(self.fit_solver, N, 1)
         self.fit_solver.forward_begin(w["st"], w["u"], 1, N, a.solver, self.env.dt, a.atol, a.rtol)
 
 
@@ -475,6 +489,8 @@ class PvtolTask(_Task):
         _lib.call("nlbac_pvtol_state", ws.mb.data_ptr(), a.lay.LD, B, ws.st6.data_ptr(), ws.op0.data_ptr(), s)
         for p in range(NP):
             ws.y0[p * B:(p + 1) * B].copy_(ws.st6)
+        for sv in self.steps:
+            self.reserve(sv, NP * B, NP)
         self.steps[0].forward_begin(ws.y0[:NP * B], ws.pi2[:NP * B], NP, B, a.solver, float(self.env.dt), a.atol,
                                     a.rtol)
 
@@ -540,6 +556,8 @@ class PvtolTask(_Task):
         a, s = self.agent, stream_ptr()
         _lib.call("nlbac_pvtol_state", p_obs, obs_ld, N, w["st"].data_ptr(), None, s)
         _lib.call("nlbac_pvtol_state", p_nobs, nobs_ld, N, w["nst"].data_ptr(), None, s)
+        if isinstance(self.fit_solver, AffineNodeSolver) and not isinstance(self.fit_solver, ConcatNodeSolver):
+            self.reserve(self.fit_solver, N, 1)
         self.fit_solver.forward_begin(w["st"], w["u"], 1, N, a.solver, self.env.dt, a.atol, a.rtol)
 
 
@@ -620,6 +638,7 @@ class PvtolBarrierTask(PvtolTask):
     def rollout_begin(self, ws, P):
         a, s = self.agent, stream_ptr()
         _lib.call("nlbac_pvtol_state", ws.mb.data_ptr(), a.lay.LD, ws.B, ws.st6.data_ptr(), ws.op0.data_ptr(), s)
+        self.reserve(self.solver, ws.B, 1)
         self.solver.forward_begin(ws.st6, ws.pi2, 1, ws.B, a.solver, float(self.env.dt), a.atol, a.rtol)
 
     def loss_and_backward(self, ws, P, lam_upd, assume_single):
