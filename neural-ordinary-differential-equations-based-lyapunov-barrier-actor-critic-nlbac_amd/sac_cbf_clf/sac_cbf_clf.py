@@ -1,21 +1,23 @@
-"""``SAC_CBF_CLF`` — drop-in for the reference agent class
-(``U/sac_cbf_clf/sac_cbf_clf.py:26-656``) whose ``update_parameters`` runs
-entirely on one MI355X through the C ABI in ``include/nlbac_hip.h``.
+"""``SAC_CBF_CLF`` — drop-in for the reference agent class (``U/sac_cbf_clf/sac_cbf_clf.py:26-656`` and its
+per-environment copies ``C/``, ``P/``; the learned-barrier copies ``NU/``, ``NP/`` are the subclass in
+``nlbac_amd/neural_barrier_certificate/``) whose ``update_parameters`` runs entirely on one MI355X through the C ABI
+in ``include/nlbac_hip.h``.
 
-Same constructor arguments, public methods, return values, checkpoint files
-and ``state_dict`` key names as the reference.  Differences that are visible
-to a caller:
+Same constructor arguments, public methods, return values, checkpoint files and ``state_dict`` key names as the
+reference.  Differences that are visible to a caller:
   * CUDA(HIP)-only: ``args.cuda`` must be true (no CPU fallback);
-  * ``self.solver`` may be ``'euler'`` (reference default), ``'rk4'`` or
-    ``'dopri5'``; the NODE-fit and CBF/CLF rollouts use it;
-  * Lagrange multipliers / augmented term / alpha live on the device
-    (``lambda_values`` etc. are read-back properties);
-  * policy noise comes from the device generator unless ``set_noise`` is
-    given pre-drawn N(0,1) samples (parity tests).
+  * ``self.solver`` may be ``'euler'`` (reference default), ``'rk4'`` or ``'dopri5'``; the NODE-fit and CBF/CLF
+    rollouts use it;
+  * Lagrange multipliers / augmented terms / temperatures live on the device (``lambda_values`` etc. are read-back
+    properties);
+  * policy noise comes from the device generator unless ``set_noise`` is given pre-drawn N(0,1) samples (parity tests);
+  * a replay object with ``sample_rows`` (``DeviceReplayMemory``) is gathered on the device.
 
-One update = the launch sequence in ``_update_device``: every
-per-sample quantity is computed in fused HIP kernels, the only host<->device
-traffic is the minibatch upload and one 512-byte scalars read-back.
+The environment-specific half of an update (row layout, NODE form, rollout, CBF / CLF terms, NODE fit) is a task
+object (``tasks.py``) chosen from ``env.dynamics_mode``; this file holds the shared SAC / Lyapunov machinery:
+``_upd_part1`` (targets, critic step, actor forward, rollout start) and ``_upd_part2`` (constraints, actor backward,
+actor step), see DESIGN.md §3.  Host<->device traffic per update: the minibatch upload (or 8 bytes per row of
+indices), one 512-byte scalars read-back and, for dopri5, one 256-byte control block per attempted step.
 """
 import random
 import types
