@@ -159,8 +159,9 @@ int nlbac_alpha_refresh(const float *log_alpha, int log_alpha_stride, int first_
 
 /* Unicycle geometry: obs -> state (atan2 in fp64 then cast, dynamics.py:53-58) and look-ahead
  * p(x) = xy + l_p (cos th, sin th) (sac_cbf_clf.py:429-437, 455-469). */
-int nlbac_unicycle_state(const float *obs, int obs_ld, int B, float l_p, float *state /*(B,3)*/,
-                         float *ps /*(B,2) or NULL*/, nlbac_stream_t s);
+int nlbac_unicycle_state(const float *obs, int obs_ld, int B, float l_p,
+                         float *state /*(n_copies*B,3): the B states repeated n_copies times (one per controller)*/,
+                         int n_copies, float *ps /*(B,2) or NULL*/, nlbac_stream_t s);
 int nlbac_unicycle_lookahead(const float *x /*(n,3)*/, int n, float l_p, float *ps /*(n,2)*/, nlbac_stream_t s);
 int nlbac_unicycle_lookahead_bwd(const float *x, const float *dps, const float *dps2 /*or NULL*/, int n,
                                  float l_p, float *dx /*(n,3)*/, nlbac_stream_t s);

@@ -66,7 +66,7 @@ _PROTOS = {
     "nlbac_actor_q_terms": [_P, _P, _P, _P, _I, _I, _I, _P, _P, _P, _P],
     "nlbac_actor_scalars": [_P, _I, _I, _I, _I, _F, _P, _I, _P, _P, _P],
     "nlbac_alpha_refresh": [_P, _I, _I, _I, _P, _P],
-    "nlbac_unicycle_state": [_P, _I, _I, _F, _P, _P, _P],
+    "nlbac_unicycle_state": [_P, _I, _I, _F, _P, _I, _P, _P],
     "nlbac_unicycle_lookahead": [_P, _I, _F, _P, _P],
     "nlbac_unicycle_lookahead_bwd": [_P, _P, _P, _I, _F, _P, _P],
     "nlbac_unicycle_constraints_fwd": [_P, _P, _P, _P, _P, _I, _F, _F, _F, _F, _I, _P, _P, _P, _P],

@@ -151,13 +151,18 @@ def stream_ptr():
 
 
 def pack(handles, target=False):
+    """Rewrite the MFMA-fragment copies of the nets' weights.  ``target``: False the trained nets, True their Polyak
+    targets, "both" the two sets in one launch (up to NLBAC_MAX_NETS descriptors per launch)."""
     # descriptor arrays are cached on the first handle (they die with it; a global cache keyed by id()
     # would hand stale pointers to a new net that happens to reuse a freed object's id)
     cache = handles[0].__dict__.setdefault("_pack_cache", {})
     key = (tuple(id(h) for h in handles), target)
     arrs = cache.get(key)
     if arrs is None:
-        descs = [h.desc_target if target else h.desc for h in handles]
+        if target == "both":
+            descs = [h.desc for h in handles] + [h.desc_target for h in handles]
+        else:
+            descs = [h.desc_target if target else h.desc for h in handles]
         arrs = [(mlp_array(descs[i:i + _lib.MAX_NETS]), len(descs[i:i + _lib.MAX_NETS]))
                 for i in range(0, len(descs), _lib.MAX_NETS)]
         cache[key] = (arrs, list(handles))       # keep the other handles alive as long as the entry exists

@@ -173,13 +173,16 @@ __global__ void alpha_refresh_kernel(const float* log_alpha, int log_alpha_strid
 // Unicycle geometry
 // ---------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void unicycle_state_kernel(const float* obs, int obs_ld, int B, float l_p,
-                                                             float* state, float* ps) {
+                                                             float* state, int n_copies, float* ps) {
     const int i = blockIdx.x * 256 + threadIdx.x;
     if (i >= B) return;
     const float* o = obs + (long)i * obs_ld;
     // the reference computes arctan2 on the host in float64 and casts back
     const float th = (float)atan2((double)o[3], (double)o[2]);
-    state[i * 3 + 0] = o[0]; state[i * 3 + 1] = o[1]; state[i * 3 + 2] = th;
+    for (int c = 0; c < n_copies; ++c) {       // one copy per controller whose rollout starts from this state
+        float* st = state + ((long)c * B + i) * 3;
+        st[0] = o[0]; st[1] = o[1]; st[2] = th;
+    }
     if (ps) {
         ps[i * 2 + 0] = o[0] + l_p * cosf(th);
         ps[i * 2 + 1] = o[1] + l_p * sinf(th);
@@ -543,10 +546,10 @@ extern "C" int nlbac_alpha_refresh(const float* log_alpha, int log_alpha_stride,
     return 0;
 }
 
-extern "C" int nlbac_unicycle_state(const float* obs, int obs_ld, int B, float l_p, float* state, float* ps,
-                                    nlbac_stream_t s) {
-    NLBAC_REQUIRE(obs && state, "nlbac_unicycle_state: null pointer");
-    hipLaunchKernelGGL(unicycle_state_kernel, GRID1(B), obs, obs_ld, B, l_p, state, ps);
+extern "C" int nlbac_unicycle_state(const float* obs, int obs_ld, int B, float l_p, float* state, int n_copies,
+                                    float* ps, nlbac_stream_t s) {
+    NLBAC_REQUIRE(obs && state && n_copies >= 1, "nlbac_unicycle_state: bad arguments");
+    hipLaunchKernelGGL(unicycle_state_kernel, GRID1(B), obs, obs_ld, B, l_p, state, n_copies, ps);
     NLBAC_CHECK_LAUNCH("nlbac_unicycle_state");
     return 0;
 }

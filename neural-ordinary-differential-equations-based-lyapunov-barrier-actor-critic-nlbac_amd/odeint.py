@@ -463,8 +463,8 @@ class AffineNodeSolver:
         s = stream_ptr()
         assert not (need_params and not self.keep_acts), "this solver keeps ReLU masks only (keep_acts=False)"
         du = self._buf("du", n, nu) if need_du else None
-        if du is not None:
-            du.zero_()
+        if du is not None and not self.fused:
+            du.zero_()           # (the fused kernel overwrites du on the first step it processes)
         steps = ctx["steps"]
         dy_carry = None          # grad wrt the y1 of the step being processed
         dk_carry = None          # grad wrt f1 (=K[6]) of that step, from the next step's FSAL stage 0
@@ -507,7 +507,7 @@ class AffineNodeSolver:
                           1 if ws.bits else 0, ws.dz_f.data_ptr() if need_params else None, ws.dz_g.data_ptr() if need_params else None,
                           ws.dG.data_ptr() if need_params else None, ws.dK.data_ptr(),
                           top_up.data_ptr() if top_up is not None else None, ws.dy0.data_ptr(), 1,
-                          du.data_ptr() if du is not None else None, 1, s)
+                          du.data_ptr() if du is not None else None, 0 if last else 1, s)
                 dy_carry = ws.dy0
                 dk_carry = ws.dK[0]
                 continue

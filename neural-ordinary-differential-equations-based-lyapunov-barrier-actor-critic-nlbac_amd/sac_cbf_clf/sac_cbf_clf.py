@@ -681,9 +681,7 @@ class SAC_CBF_CLF(object):
         bwd_weights(P.n_crit, P.io_crit, n_crit, B, a.n_slabs, a.n, self.device)
         self._adam(a, self.critic_lyapunov_lr, a.n_slabs, extra=self.sc[SC.SC_QF1:SC.SC_QF1 + 3],
                    target=a.target.data_ptr(), tau=self.tau if soft else -1.0)
-        pack(self.h_crit)
-        if soft:
-            pack(self.h_crit, target=True)
+        pack(self.h_crit, target="both" if soft else False)
 
         # ---- C. actors: sample, Q(s, pi), then the rollout of the learned dynamics -----
         call("nlbac_mlp_fwd", P.n_q5, P.io_q5, P.n_q5_count, B, s)

@@ -129,8 +129,7 @@ class UnicycleTask(_Task):
         B, LD = ws.B, a.lay.LD
         p_obs = ws.mb.data_ptr()
         # state (twice: primary and backup rows of the rollout) and look-ahead point
-        _lib.call("nlbac_unicycle_state", p_obs, LD, B, self.l_p, ws.y0_2.data_ptr(), ws.ps.data_ptr(), s)
-        _lib.call("nlbac_unicycle_state", p_obs, LD, B, self.l_p, ws.y0_2[B:].data_ptr(), None, s)
+        _lib.call("nlbac_unicycle_state", p_obs, LD, B, self.l_p, ws.y0_2.data_ptr(), 2, ws.ps.data_ptr(), s)
         self.reserve(self.solver, 2 * B, 2)
         self.solver.forward_begin(ws.y0_2, ws.pi2, 2, B, a.solver, float(self.env.dt), a.atol, a.rtol)
 
@@ -171,8 +170,8 @@ class UnicycleTask(_Task):
 
     def fit_part1(self, w, p_obs, obs_ld, p_nobs, nobs_ld, N):
         a, s = self.agent, stream_ptr()
-        _lib.call("nlbac_unicycle_state", p_obs, obs_ld, N, self.l_p, w["st"].data_ptr(), None, s)
-        _lib.call("nlbac_unicycle_state", p_nobs, nobs_ld, N, self.l_p, w["nst"].data_ptr(), None, s)
+        _lib.call("nlbac_unicycle_state", p_obs, obs_ld, N, self.l_p, w["st"].data_ptr(), 1, None, s)
+        _lib.call("nlbac_unicycle_state", p_nobs, nobs_ld, N, self.l_p, w["nst"].data_ptr(), 1, None, s)
         if isinstance(self.fit_solver, AffineNodeSolver) and not isinstance(self.fit_solver, ConcatNodeSolver):
             self.reserve(self.fit_solver, N, 1)
         self.fit_solver.forward_begin(w["st"], w["u"], 1, N, a.solver, self.env.dt, a.atol, a.rtol)
@@ -241,7 +240,7 @@ class UnicycleBarrierTask(UnicycleTask):
 
     def rollout_begin(self, ws, P):
         a, s = self.agent, stream_ptr()
-        _lib.call("nlbac_unicycle_state", ws.mb.data_ptr(), a.lay.LD, ws.B, self.l_p, ws.y0.data_ptr(), None, s)
+        _lib.call("nlbac_unicycle_state", ws.mb.data_ptr(), a.lay.LD, ws.B, self.l_p, ws.y0.data_ptr(), 1, None, s)
         self.reserve(self.solver, ws.B, 1)
         self.solver.forward_begin(ws.y0, ws.pi2, 1, ws.B, a.solver, float(self.env.dt), a.atol, a.rtol)
 
