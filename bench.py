@@ -202,11 +202,18 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     assert world == a.gpus, "launch with torch.distributed.run --nproc-per-node %d" % a.gpus
-    torch.cuda.set_device(local_rank)
+    # one rank per GPU; NLBAC_BENCH_BACKEND=gloo lets several ranks share one card for a rehearsal of the N>1 path
+    backend = os.environ.get("NLBAC_BENCH_BACKEND", "nccl")
+    n_dev = max(1, torch.cuda.device_count())
+    assert backend != "nccl" or local_rank < n_dev, "rank %d has no GPU of its own (%d visible)" % (local_rank, n_dev)
+    torch.cuda.set_device(local_rank % n_dev)
     dist = None
     if world > 1:
         import torch.distributed as dist
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        else:
+            dist.init_process_group(backend)
 
     if a.env.endswith("Barrier"):
         from nlbac_amd.neural_barrier_certificate.sac_cbf_clf.sac_cbf_clf import SAC_CBF_CLF
