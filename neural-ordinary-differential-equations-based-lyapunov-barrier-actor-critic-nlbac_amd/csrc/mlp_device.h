@@ -115,8 +115,24 @@ __device__ __forceinline__ void skinny_dot(const float* __restrict__ lds_row, co
 // output t>>5.  The 32 lanes of a half-wave read 32 different rows at the same k (ds_read_b128, row
 // stride = 4 mod 8 dwords: conflict-free) and broadcast-read the weight row; no cross-lane reduction.
 __device__ __forceinline__ float skinny_row_dot(const float* __restrict__ hrow, const float* __restrict__ w, int hid) {
+    // 16 k per step: the eight ds_read_b128 are issued together (one LDS latency per step instead of one per float4;
+    // the output layers of the fused RK kernel were latency bound at ~145 cycles per float4), same summation order
     float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
-    for (int k = 0; k < hid; k += 4) {
+    int k = 0;
+    for (; k + 16 <= hid; k += 16) {
+        float4 h[4], ww[4];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            h[q] = *reinterpret_cast<const float4*>(hrow + k + 4 * q);
+            ww[q] = *reinterpret_cast<const float4*>(w + k + 4 * q);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            a0 += h[q].x * ww[q].x; a1 += h[q].y * ww[q].y; a2 += h[q].z * ww[q].z; a3 += h[q].w * ww[q].w;
+        }
+    }
+    for (; k < hid; k += 4) {
         const float4 h = *reinterpret_cast<const float4*>(hrow + k);
         const float4 ww = *reinterpret_cast<const float4*>(w + k);
         a0 += h.x * ww.x; a1 += h.y * ww.y; a2 += h.z * ww.z; a3 += h.w * ww.w;
@@ -158,7 +174,8 @@ __device__ __forceinline__ void fwd_prime(WaveGemm<NTW>& wg, const nlbac_mlp& ne
 template <int NTW, int BITS = 0>
 __device__ __forceinline__ void fwd_wide_layers(WaveGemm<NTW>& wg, const nlbac_mlp& net, bool active, int wave, int lane,
                                                 int LD, int inp, float*& in, float*& out, float* acts_tile,
-                                                long acts_ls, int n_rows, int nwide_run, bool wrap) {
+                                                long acts_ls, int n_rows, int nwide_run, bool wrap,
+                                                long long* dbg = nullptr /* ablation builds: per-layer clock stamps */) {
     // BITS: acts_tile holds bit-packed ReLU masks instead of activations: uint32 word [layer][row][col tile]
     // (bit = column within the 32-wide tile), enough for a backward that needs no weight gradients
     const int hid = net.hid, hidp8 = pad8(hid), nwide = net.n_layers - 1, half = lane >> 5;
@@ -175,9 +192,11 @@ __device__ __forceinline__ void fwd_wide_layers(WaveGemm<NTW>& wg, const nlbac_m
             f32x16 acc[2];
 #pragma unroll
             for (int r = 0; r < 16; ++r) { acc[0][r] = 0.f; acc[1][r] = 0.f; }
+            if (dbg) dbg[4 * l + 0] = (long long)__builtin_readcyclecounter();
 #ifndef EXP_NO_GEMM
             wg.run(in + (lane & 31) * LD + half * 4, p0, p1, KC, nx, acc);
 #endif
+            if (dbg) dbg[4 * l + 1] = (long long)__builtin_readcyclecounter();
             float* acts = acts_tile ? acts_tile + (long)l * acts_ls : nullptr;
 #pragma unroll
             for (int t = 0; t < NTW; ++t) {
@@ -190,14 +209,20 @@ __device__ __forceinline__ void fwd_wide_layers(WaveGemm<NTW>& wg, const nlbac_m
                     if (col < LD - 4) out[acc_row(r, half) * LD + col] = v[r];   // (a narrow LD holds pad8(hid) columns)
                 }
                 if (BITS && acts) {
+                    // 16 wave-uniform ballots hold the 32 row words of this tile (low half: row 8i+j, high half: row
+                    // 8i+4+j for r = 4i+j); lane m < 32 picks row m's word and the wave writes them with ONE store
+                    // (16 predicated single-lane stores cost ~1000 cycles of exec-mask juggling per layer)
                     unsigned* mp = reinterpret_cast<unsigned*>(acts) + (wave + 4 * t);
                     const int NTm = (hid + 31) >> 5;
+                    const int m = lane & 31, want = ((m >> 3) << 2) | (m & 3), hi = (m >> 2) & 1;
+                    unsigned word = 0u;
 #pragma unroll
                     for (int r = 0; r < 16; ++r) {
                         const unsigned long long b = __ballot(v[r] > 0.f);
-                        const int m = acc_row(r, half);
-                        if ((lane & 31) == 0 && m < n_rows) mp[m * NTm] = (unsigned)(b >> (32 * half));
+                        const unsigned w = hi ? (unsigned)(b >> 32) : (unsigned)b;
+                        word = (r == want) ? w : word;
                     }
+                    if (lane < 32 && m < n_rows) mp[m * NTm] = word;
                 } else if (!BITS && acts && colok) {
                     float* ap = acts + col;
                     if (n_rows == NLBAC_MLP_TILE) {
@@ -211,7 +236,9 @@ __device__ __forceinline__ void fwd_wide_layers(WaveGemm<NTW>& wg, const nlbac_m
                 }
             }
         }
+        if (dbg) dbg[4 * l + 2] = (long long)__builtin_readcyclecounter();
         __syncthreads();
+        if (dbg) dbg[4 * l + 3] = (long long)__builtin_readcyclecounter();
         if (l < nwide) { float* tmp = in; in = out; out = tmp; }
     }
 }

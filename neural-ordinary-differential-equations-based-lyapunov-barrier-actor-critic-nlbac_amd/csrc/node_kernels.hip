@@ -46,6 +46,11 @@ struct NodeRkLaunch {
 // per-tile latency chains - pays off only for launches with well over one tile per CU (measured: 32768 rows, mask mode,
 // 390 -> 329 us; 8192 rows 99 -> 104 us), so the launcher picks it by tile count.
 // MODE 1: both nets <= 4 column tiles, 2: both 8, 0: mixed (see mlp_kernels.hip); BITS: save ReLU bit masks
+#ifdef EXP_TIMING     // ablation build only: workgroup 0 stamps the shader clock at phase boundaries into L.err (as int64)
+#define TSTAMP(slot_) if (L.err && blockIdx.x == 0 && tid == 0) reinterpret_cast<long long*>(L.err)[slot_] = (long long)__builtin_readcyclecounter();
+#else
+#define TSTAMP(slot_)
+#endif
 template <int MODE, int BITS, int OCC>
 __global__ __launch_bounds__(512, OCC ? 4 : 2) void node_rk_fwd_kernel(const NodeRkLaunch L) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
@@ -107,8 +112,10 @@ __global__ __launch_bounds__(512, OCC ? 4 : 2) void node_rk_fwd_kernel(const Nod
     }
     __syncthreads();
 
+    TSTAMP(0)
     for (int st = L.stage_begin; st < L.stage_end; ++st) {
         // ---- stage input  Y_st = y0 + h sum_j beta[st][j] K_j   (same op order as rk_combine_kernel)
+        TSTAMP(1 + 8 * (st - L.stage_begin) + 0)
         float* in = buf;
         float* out = buf + NLBAC_MLP_TILE * LD;
         for (int idx = t; idx < NLBAC_MLP_TILE * inp; idx += 256) {
@@ -124,6 +131,7 @@ __global__ __launch_bounds__(512, OCC ? 4 : 2) void node_rk_fwd_kernel(const Nod
             in[m * LD + c] = a;
         }
         __syncthreads();
+        TSTAMP(1 + 8 * (st - L.stage_begin) + 1)
 
         // ---- wide layers of f_net (group 0) and g_net (group 1), in lock step; the weight stream of each
         //      wave runs on across layers and stages (WaveGemm), only the LDS operands wait for the barriers
@@ -132,14 +140,22 @@ __global__ __launch_bounds__(512, OCC ? 4 : 2) void node_rk_fwd_kernel(const Nod
             const bool wrap = st + 1 < L.stage_end;
             if constexpr (MODE == 2)
                 fwd_wide_layers<2, BITS>(wg2, net, active, wave, lane, LD, inp, in, out, acts_tile, L.acts_ls[grp], n_rows, nwide_max, wrap);
-            else if constexpr (MODE == 1)
+            else if constexpr (MODE == 1) {
+#ifdef EXP_TIMING       // per-layer stamps of wave 0 of workgroup 0, stage index 1 of the launch
+                long long* dbg = (L.err && blockIdx.x == 0 && tid == 0 && st == L.stage_begin + 1)
+                                     ? reinterpret_cast<long long*>(L.err) + 64 : nullptr;
+                fwd_wide_layers<1, BITS>(wg1, net, active, wave, lane, LD, inp, in, out, acts_tile, L.acts_ls[grp], n_rows, nwide_max, wrap, dbg);
+#else
                 fwd_wide_layers<1, BITS>(wg1, net, active, wave, lane, LD, inp, in, out, acts_tile, L.acts_ls[grp], n_rows, nwide_max, wrap);
+#endif
+            }
             else {
                 if (two) fwd_wide_layers<2, BITS>(wg2, net, active, wave, lane, LD, inp, in, out, acts_tile, L.acts_ls[grp], n_rows, nwide_max, wrap);
                 else fwd_wide_layers<1, BITS>(wg1, net, active, wave, lane, LD, inp, in, out, acts_tile, L.acts_ls[grp], n_rows, nwide_max, wrap);
             }
         }
 
+        TSTAMP(1 + 8 * (st - L.stage_begin) + 2)
         // ---- skinny output layers -> sF / sG (and g(x) to global for the backward)
 #ifndef EXP_NO_SKINNY
         for (int idx = t; idx < NLBAC_MLP_TILE * net.out_dim; idx += 256) {
@@ -150,6 +166,7 @@ __global__ __launch_bounds__(512, OCC ? 4 : 2) void node_rk_fwd_kernel(const Nod
         }
 #endif
         __syncthreads();
+        TSTAMP(1 + 8 * (st - L.stage_begin) + 3)
 
         // ---- k = f + g u   (same op order as affine_fwd_kernel)
         for (int idx = tid; idx < NLBAC_MLP_TILE * ns; idx += 512) {
@@ -160,9 +177,13 @@ __global__ __launch_bounds__(512, OCC ? 4 : 2) void node_rk_fwd_kernel(const Nod
             if (row0 + m < n) L.K[((long)st * n + row0 + m) * ns + r] = a;
         }
         __syncthreads();
+        TSTAMP(1 + 8 * (st - L.stage_begin) + 4)
     }
 
     // ---- step outputs
+#ifdef EXP_TIMING
+    return;
+#endif
     for (int idx = tid; idx < NLBAC_MLP_TILE * ns; idx += 512) {
         const int m = idx / ns, r = idx - m * ns, row = row0 + m;
         if (row >= n) continue;
@@ -208,13 +229,13 @@ struct NodeRkBwdLaunch {
 
 // Top (skinny) layer of the backward for one 32-row tile: dz_top[m][k] = [act_top[m][k] > 0] sum_o dy[m][o] W_last[o][k].
 // RPT rows per thread: the 256 threads of a group cover (32 / RPT) row groups x (256 * RPT / 32) columns.
+// ReLU masks of the top hidden layer for this thread's (row group, column): issued at the start of a stage so that their
+// global latency (~2k cycles) hides under the output-gradient fill and the first barrier.
 template <int RPT, int BITS>
-__device__ __forceinline__ void node_top_layer(const float* __restrict__ sdy, const float* __restrict__ sW, int out_dim,
-                                               int hid, int hidp32, int NT, int t, int n_rows,
-                                               const float* __restrict__ atop, float* __restrict__ in, int LD) {
-    constexpr int CPG = 256 * RPT / 32;            // columns per row group
+__device__ __forceinline__ void node_top_masks(const float* __restrict__ atop, int hid, int NT, int t, int n_rows,
+                                               float (&av)[RPT]) {
+    constexpr int CPG = 256 * RPT / 32;
     const int k = t % CPG, m0 = (t / CPG) * RPT, kc = min(k, hid - 1);
-    float av[RPT];
     if constexpr (BITS != 0) {
         const unsigned* mtop = reinterpret_cast<const unsigned*>(atop) + (kc >> 5);
 #pragma unroll
@@ -224,6 +245,14 @@ __device__ __forceinline__ void node_top_layer(const float* __restrict__ sdy, co
 #pragma unroll
         for (int i = 0; i < RPT; ++i) av[i] = atop[min(m0 + i, n_rows - 1) * hid + kc];
     }
+}
+
+template <int RPT, int BITS>
+__device__ __forceinline__ void node_top_layer(const float* __restrict__ sdy, const float* __restrict__ sW, int out_dim,
+                                               int hid, int hidp32, int NT, int t, int n_rows,
+                                               const float (&av)[RPT], float* __restrict__ in, int LD) {
+    constexpr int CPG = 256 * RPT / 32;            // columns per row group
+    const int k = t % CPG, m0 = (t / CPG) * RPT, kc = min(k, hid - 1);
     float s[RPT];
 #pragma unroll
     for (int i = 0; i < RPT; ++i) s[i] = 0.f;
@@ -321,10 +350,20 @@ __global__ __launch_bounds__(512) void node_rk_bwd_kernel(const NodeRkBwdLaunch 
     }
     __syncthreads();
 
+#ifdef EXP_TIMING      // stamps of workgroup 0 go to the (otherwise unused in mask mode) dz[1] pointer
+#define BSTAMP(slot_) if (L.dz[1] && blockIdx.x == 0 && tid == 0) reinterpret_cast<long long*>(L.dz[1])[slot_] = (long long)__builtin_readcyclecounter();
+#else
+#define BSTAMP(slot_)
+#endif
     for (int st = L.st_hi - 1; st >= L.st_lo; --st) {
         const bool data = has_data(st);
+        BSTAMP(8 * st + 0)
         // ---- output-layer gradients of both nets, du
         const float* acts_tile = L.acts[grp] + ((long)st * n + row0) * (BITS ? NT : hid);
+        constexpr int TOP_RPT = (MODE == 1) ? 16 : 32;   // MODE 1: <= 128 padded columns -> two row groups of 16 rows
+        float av_top[TOP_RPT];
+        if (data) node_top_masks<TOP_RPT, BITS>(acts_tile + (long)(nwide - 1) * L.acts_ls[grp], hid, NT, t, n_rows, av_top);
+        __builtin_amdgcn_sched_barrier(0);       // (issued here, not sunk to their use behind the barrier)
         for (int idx = tid; idx < 2 * NLBAC_MLP_TILE * 16; idx += 512) {
             const int gsel = idx >> 9, rem = idx & 511, m = rem >> 4, o = rem & 15, row = row0 + m;
             float v = 0.f;
@@ -346,16 +385,15 @@ __global__ __launch_bounds__(512) void node_rk_bwd_kernel(const NodeRkBwdLaunch 
             }
         if (!data) continue;              // uniform: nothing below is needed for this stage
         __syncthreads();
+        BSTAMP(8 * st + 1)
 
         float* in = buf;
         float* out = buf + NLBAC_MLP_TILE * LD;
-        {   // top (skinny) layer: thread = (row group, hidden column); narrow nets split the 32 rows over the
-            // threads that would otherwise idle (hid <= 128: 2 groups of 16 rows)
-            const float* atop = acts_tile + (long)(nwide - 1) * L.acts_ls[grp];
-            // MODE 1: both nets have <= 128 padded columns -> two row groups of 16 rows; otherwise one thread per column
-            node_top_layer<(MODE == 1) ? 16 : 32, BITS>(sdy, sW, net.out_dim, hid, hidp32, NT, t, n_rows, atop, in, LD);
-        }
+        // top (skinny) layer: thread = (row group, hidden column); narrow nets split the 32 rows over the threads that
+        // would otherwise idle (hid <= 128: 2 groups of 16 rows)
+        node_top_layer<TOP_RPT, BITS>(sdy, sW, net.out_dim, hid, hidp32, NT, t, n_rows, av_top, in, LD);
         __syncthreads();
+        BSTAMP(8 * st + 2)
         if constexpr (BITS == 0) {
             if (keep_dz) tile_to_global(in, LD, L.dz[grp] + (long)(nwide - 1) * L.acts_ls[grp] + ((long)st * n + row0) * hid,
                                         hid, n_rows, t, 256);
@@ -373,6 +411,7 @@ __global__ __launch_bounds__(512) void node_rk_bwd_kernel(const NodeRkBwdLaunch 
                 else bwd_wide_layers<1, BITS>(wg1, net, active, wave, lane, LD, in, out, acts_tile, dz_tile, L.acts_ls[grp], n_rows, n_rows - 1, n_run, wrap);
             }
         }
+        BSTAMP(8 * st + 3)
         if (st == 0 && !L.dx_stage0) continue;       // only the dz of stage 0 were wanted
 
         // ---- dX = dz0 W_0 (one dot product per thread), then the stage algebra
@@ -381,6 +420,7 @@ __global__ __launch_bounds__(512) void node_rk_bwd_kernel(const NodeRkBwdLaunch 
             sDX[(grp * NLBAC_MLP_TILE + m) * RK_MAX_NS + i] = skinny_row_dot(in + m * LD, sW0t + i * hid, hid);
         }
         __syncthreads();
+        BSTAMP(8 * st + 4)
         for (int idx = tid; idx < NLBAC_MLP_TILE * ns; idx += 512) {
             const int m = idx / ns, c = idx - m * ns, row = row0 + m;
             float d = (L.dYup && st == L.S_total - 1 && row < n) ? L.dYup[(long)row * ns + c] : 0.f;
@@ -392,6 +432,7 @@ __global__ __launch_bounds__(512) void node_rk_bwd_kernel(const NodeRkBwdLaunch 
                 if (L.beta[st][j] != 0.f) sDK[(j * NLBAC_MLP_TILE + m) * RK_MAX_NS + c] += (L.beta[st][j] * h) * d;
         }
         __syncthreads();
+        BSTAMP(8 * st + 5)
     }
     __syncthreads();
 
@@ -428,8 +469,10 @@ extern "C" int nlbac_node_rk_bwd(const nlbac_mlp* f, const nlbac_mlp* g, const f
                       g->out_dim % f->in_dim == 0 && g->out_dim / f->in_dim <= RK_MAX_NU && g->out_dim <= 16,
                   "nlbac_node_rk_bwd: f/g shapes are not a supported control-affine field");
     NLBAC_REQUIRE(f->hid % 4 == 0 && g->hid % 4 == 0 && f->hid <= 256 && g->hid <= 256, "nlbac_node_rk_bwd: bad hid");
+#ifndef EXP_TIMING
     NLBAC_REQUIRE((dz_f == nullptr) == (dz_g == nullptr) && (dz_f == nullptr) == (dG == nullptr),
                   "nlbac_node_rk_bwd: dz_f, dz_g and dG go together");
+#endif
     NLBAC_REQUIRE(h_dev || h_host, "nlbac_node_rk_bwd: no step size");
     NodeRkBwdLaunch L;
     memset(&L, 0, sizeof(L));
