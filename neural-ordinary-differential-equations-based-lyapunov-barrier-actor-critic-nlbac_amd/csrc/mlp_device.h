@@ -171,11 +171,32 @@ __device__ __forceinline__ void fwd_prime(WaveGemm<NTW>& wg, const nlbac_mlp& ne
              fwd_next<NTW>(net, 0, inp, wrap, wave, lane));
 }
 
+// A barrier over ONE wave group of a workgroup (the fused NODE kernels run f_net and g_net in two groups of four waves
+// with separate LDS tiles): an LDS arrival counter that only the group's own waves bump and poll, so the other group
+// is free to run ahead between the stage boundaries (__syncthreads() there).  Every wave of the group must call it the
+// same number of times; gb == nullptr is the plain workgroup barrier.
+struct GroupBar {
+    unsigned* cnt;       // LDS word, zeroed before the first use
+    unsigned target;     // arrivals expected after the next sync (wave-uniform)
+    unsigned n_waves;
+};
+__device__ __forceinline__ void tile_sync(GroupBar* gb, int lane) {
+    if (!gb) { __syncthreads(); return; }
+    gb->target += gb->n_waves;
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");       // this wave's LDS writes have landed
+    if (lane == 0) __hip_atomic_fetch_add(gb->cnt, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+    while ((int)(__builtin_amdgcn_readfirstlane(
+                     __hip_atomic_load(gb->cnt, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP)) - gb->target) < 0)
+        __builtin_amdgcn_s_sleep(1);
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+}
+
 template <int NTW, int BITS = 0>
 __device__ __forceinline__ void fwd_wide_layers(WaveGemm<NTW>& wg, const nlbac_mlp& net, bool active, int wave, int lane,
                                                 int LD, int inp, float*& in, float*& out, float* acts_tile,
                                                 long acts_ls, int n_rows, int nwide_run, bool wrap,
-                                                long long* dbg = nullptr /* ablation builds: per-layer clock stamps */) {
+                                                long long* dbg = nullptr /* ablation builds: per-layer clock stamps */,
+                                                GroupBar* gb = nullptr) {
     // BITS: acts_tile holds bit-packed ReLU masks instead of activations: uint32 word [layer][row][col tile]
     // (bit = column within the 32-wide tile), enough for a backward that needs no weight gradients
     const int hid = net.hid, hidp8 = pad8(hid), nwide = net.n_layers - 1, half = lane >> 5;
@@ -237,7 +258,7 @@ __device__ __forceinline__ void fwd_wide_layers(WaveGemm<NTW>& wg, const nlbac_m
             }
         }
         if (dbg) dbg[4 * l + 2] = (long long)__builtin_readcyclecounter();
-        __syncthreads();
+        tile_sync(gb, lane);
         if (dbg) dbg[4 * l + 3] = (long long)__builtin_readcyclecounter();
         if (l < nwide) { float* tmp = in; in = out; out = tmp; }
     }
@@ -297,7 +318,8 @@ template <int NTW, int BITS = 0>
 __device__ __forceinline__ void bwd_wide_layers(WaveGemm<NTW>& wg, const nlbac_mlp& net, bool active, int wave, int lane,
                                                 int LD, float*& in, float*& out, const float* acts_tile,
                                                 float* dz_tile, long ls, int n_rows, int row_clamp,
-                                                int n_run = -1, bool wrap = false, int nthr = 256) {
+                                                int n_run = -1, bool wrap = false, int nthr = 256,
+                                                GroupBar* gb = nullptr) {
     const int hid = net.hid, KC = pad8(hid) >> 3, nwide = net.n_layers - 1, half = lane >> 5;
     if (n_run < 0) n_run = nwide - 1;          // lock-step iterations (>= nwide-1 when groups differ in depth)
     for (int it = 0; it < n_run; ++it) {
@@ -346,7 +368,7 @@ __device__ __forceinline__ void bwd_wide_layers(WaveGemm<NTW>& wg, const nlbac_m
                 }
             }
         }
-        __syncthreads();
+        tile_sync(gb, lane);
         if (j >= 1) {
             float* tmp = in; in = out; out = tmp;
             // dz[j-1] now sits complete in `in`: stream it out while the next layer's GEMM runs (mask mode keeps no dz)

@@ -20,6 +20,7 @@
 // backward needs (Y, K, g(x), post-ReLU activations) is written once, coalesced.
 #include "mlp_device.h"
 
+#define NODE_LDS_MAX (160 * 1024 - 64)   /* dynamic LDS per workgroup; the rest holds the static group-barrier counters */
 #define RK_MAX_STAGES 8
 #define RK_MAX_NS 8
 #define RK_MAX_NU 4
@@ -57,13 +58,15 @@ __global__ __launch_bounds__(512, OCC ? 4 : 2) void node_rk_fwd_kernel(const Nod
     const int tid = threadIdx.x, t = tid & 255;
     const int grp = __builtin_amdgcn_readfirstlane(tid >> 8);   // wave-uniform: lets L.net[grp] etc. be scalar loads
     const int lane = t & 63, wave = t >> 6;
+    __shared__ unsigned s_gcnt[2];            // per-group barrier counters (GroupBar): f_net / g_net run decoupled
+    if (tid < 2) s_gcnt[tid] = 0u;            // between the stage boundaries (visible after the prologue barrier)
+    GroupBar gbar{&s_gcnt[grp], 0u, 4u};
     const int n = L.n, ns = L.n_s, nu = L.n_u, LD = L.ld;
     const int row0 = blockIdx.x * NLBAC_MLP_TILE;
     const nlbac_mlp& net = L.net[grp];
     const int hid = net.hid, NT = pad32(hid) >> 5, hidp8 = pad8(hid);
     const int nwide_own = net.n_layers - 1;
     (void)hidp8;
-    const int nwide_max = max(L.net[0].n_layers, L.net[1].n_layers) - 1;
     const int inp = pad8(ns);
     const int n_rows = min(NLBAC_MLP_TILE, n - row0);
     const bool active = wave < NT, two = (MODE == 2) || (MODE == 0 && (wave + 4) < NT);
@@ -130,28 +133,29 @@ __global__ __launch_bounds__(512, OCC ? 4 : 2) void node_rk_fwd_kernel(const Nod
             }
             in[m * LD + c] = a;
         }
-        __syncthreads();
+        tile_sync(&gbar, lane);               // (the tile is written and read by this group only)
         TSTAMP(1 + 8 * (st - L.stage_begin) + 1)
 
-        // ---- wide layers of f_net (group 0) and g_net (group 1), in lock step; the weight stream of each
-        //      wave runs on across layers and stages (WaveGemm), only the LDS operands wait for the barriers
+        // ---- wide layers of f_net (group 0) and g_net (group 1), each behind its own group barrier so that one
+        //      group's GEMM can overlap the other's epilogue; the weight stream of each wave runs on across layers and
+        //      stages (WaveGemm), only the LDS operands wait for the barriers
         {
             float* acts_tile = L.acts[grp] ? L.acts[grp] + ((long)st * n + row0) * (BITS ? NT : hid) : nullptr;
             const bool wrap = st + 1 < L.stage_end;
             if constexpr (MODE == 2)
-                fwd_wide_layers<2, BITS>(wg2, net, active, wave, lane, LD, inp, in, out, acts_tile, L.acts_ls[grp], n_rows, nwide_max, wrap);
+                fwd_wide_layers<2, BITS>(wg2, net, active, wave, lane, LD, inp, in, out, acts_tile, L.acts_ls[grp], n_rows, nwide_own, wrap, nullptr, &gbar);
             else if constexpr (MODE == 1) {
 #ifdef EXP_TIMING       // per-layer stamps of wave 0 of workgroup 0, stage index 1 of the launch
                 long long* dbg = (L.err && blockIdx.x == 0 && tid == 0 && st == L.stage_begin + 1)
                                      ? reinterpret_cast<long long*>(L.err) + 64 : nullptr;
-                fwd_wide_layers<1, BITS>(wg1, net, active, wave, lane, LD, inp, in, out, acts_tile, L.acts_ls[grp], n_rows, nwide_max, wrap, dbg);
+                fwd_wide_layers<1, BITS>(wg1, net, active, wave, lane, LD, inp, in, out, acts_tile, L.acts_ls[grp], n_rows, nwide_own, wrap, dbg, &gbar);
 #else
-                fwd_wide_layers<1, BITS>(wg1, net, active, wave, lane, LD, inp, in, out, acts_tile, L.acts_ls[grp], n_rows, nwide_max, wrap);
+                fwd_wide_layers<1, BITS>(wg1, net, active, wave, lane, LD, inp, in, out, acts_tile, L.acts_ls[grp], n_rows, nwide_own, wrap, nullptr, &gbar);
 #endif
             }
             else {
-                if (two) fwd_wide_layers<2, BITS>(wg2, net, active, wave, lane, LD, inp, in, out, acts_tile, L.acts_ls[grp], n_rows, nwide_max, wrap);
-                else fwd_wide_layers<1, BITS>(wg1, net, active, wave, lane, LD, inp, in, out, acts_tile, L.acts_ls[grp], n_rows, nwide_max, wrap);
+                if (two) fwd_wide_layers<2, BITS>(wg2, net, active, wave, lane, LD, inp, in, out, acts_tile, L.acts_ls[grp], n_rows, nwide_own, wrap, nullptr, &gbar);
+                else fwd_wide_layers<1, BITS>(wg1, net, active, wave, lane, LD, inp, in, out, acts_tile, L.acts_ls[grp], n_rows, nwide_own, wrap, nullptr, &gbar);
             }
         }
 
@@ -287,12 +291,14 @@ __global__ __launch_bounds__(512) void node_rk_bwd_kernel(const NodeRkBwdLaunch 
     const int tid = threadIdx.x, t = tid & 255;
     const int grp = __builtin_amdgcn_readfirstlane(tid >> 8);   // wave-uniform: lets L.net[grp] etc. be scalar loads
     const int lane = t & 63, wave = t >> 6;
+    __shared__ unsigned s_gcnt[2];            // per-group barrier counters, as in the forward kernel
+    if (tid < 2) s_gcnt[tid] = 0u;
+    GroupBar gbar{&s_gcnt[grp], 0u, 4u};
     const int n = L.n, ns = L.n_s, nu = L.n_u, LD = L.ld, gout = ns * nu;
     const int row0 = blockIdx.x * NLBAC_MLP_TILE;
     const nlbac_mlp& net = L.net[grp];
     const int hid = net.hid, NT = pad32(hid) >> 5, hidp32 = NT * 32;
     const int nwide = net.n_layers - 1;
-    const int n_run = max(L.net[0].n_layers, L.net[1].n_layers) - 2;
     const int n_rows = min(NLBAC_MLP_TILE, n - row0);
     const bool keep_dz = L.dz[0] != nullptr;
     const bool active = wave < NT, two = (MODE == 2) || (MODE == 0 && (wave + 4) < NT);
@@ -364,16 +370,16 @@ __global__ __launch_bounds__(512) void node_rk_bwd_kernel(const NodeRkBwdLaunch 
         float av_top[TOP_RPT];
         if (data) node_top_masks<TOP_RPT, BITS>(acts_tile + (long)(nwide - 1) * L.acts_ls[grp], hid, NT, t, n_rows, av_top);
         __builtin_amdgcn_sched_barrier(0);       // (issued here, not sunk to their use behind the barrier)
-        for (int idx = tid; idx < 2 * NLBAC_MLP_TILE * 16; idx += 512) {
-            const int gsel = idx >> 9, rem = idx & 511, m = rem >> 4, o = rem & 15, row = row0 + m;
+        for (int rem = t; rem < NLBAC_MLP_TILE * 16; rem += 256) {       // each group fills its own net's rows
+            const int m = rem >> 4, o = rem & 15, row = row0 + m;
             float v = 0.f;
-            if (gsel == 0) {
+            if (grp == 0) {
                 if (o < ns) v = sDK[(st * NLBAC_MLP_TILE + m) * RK_MAX_NS + o];
             } else if (o < gout) {
                 v = sDK[(st * NLBAC_MLP_TILE + m) * RK_MAX_NS + o / nu] * sU[m * RK_MAX_NU + o % nu];
                 if (L.dG && row < n) L.dG[((long)st * n + row) * gout + o] = v;
             }
-            sdy_all[idx] = v;
+            sdy[rem] = v;
         }
         if (L.du)
             for (int idx = tid; idx < NLBAC_MLP_TILE * nu; idx += 512) {
@@ -384,7 +390,7 @@ __global__ __launch_bounds__(512) void node_rk_bwd_kernel(const NodeRkBwdLaunch 
                 sDU[m * RK_MAX_NU + c] = sDU[m * RK_MAX_NU + c] + 1.0f * a;
             }
         if (!data) continue;              // uniform: nothing below is needed for this stage
-        __syncthreads();
+        tile_sync(&gbar, lane);
         BSTAMP(8 * st + 1)
 
         float* in = buf;
@@ -392,7 +398,7 @@ __global__ __launch_bounds__(512) void node_rk_bwd_kernel(const NodeRkBwdLaunch 
         // top (skinny) layer: thread = (row group, hidden column); narrow nets split the 32 rows over the threads that
         // would otherwise idle (hid <= 128: 2 groups of 16 rows)
         node_top_layer<TOP_RPT, BITS>(sdy, sW, net.out_dim, hid, hidp32, NT, t, n_rows, av_top, in, LD);
-        __syncthreads();
+        tile_sync(&gbar, lane);
         BSTAMP(8 * st + 2)
         if constexpr (BITS == 0) {
             if (keep_dz) tile_to_global(in, LD, L.dz[grp] + (long)(nwide - 1) * L.acts_ls[grp] + ((long)st * n + row0) * hid,
@@ -403,12 +409,12 @@ __global__ __launch_bounds__(512) void node_rk_bwd_kernel(const NodeRkBwdLaunch 
             float* dz_tile = keep_dz ? L.dz[grp] + ((long)st * n + row0) * hid : nullptr;
             const bool wrap = has_data(st - 1);
             if constexpr (MODE == 2)
-                bwd_wide_layers<2, BITS>(wg2, net, active, wave, lane, LD, in, out, acts_tile, dz_tile, L.acts_ls[grp], n_rows, n_rows - 1, n_run, wrap);
+                bwd_wide_layers<2, BITS>(wg2, net, active, wave, lane, LD, in, out, acts_tile, dz_tile, L.acts_ls[grp], n_rows, n_rows - 1, nwide - 1, wrap, 256, &gbar);
             else if constexpr (MODE == 1)
-                bwd_wide_layers<1, BITS>(wg1, net, active, wave, lane, LD, in, out, acts_tile, dz_tile, L.acts_ls[grp], n_rows, n_rows - 1, n_run, wrap);
+                bwd_wide_layers<1, BITS>(wg1, net, active, wave, lane, LD, in, out, acts_tile, dz_tile, L.acts_ls[grp], n_rows, n_rows - 1, nwide - 1, wrap, 256, &gbar);
             else {
-                if (two) bwd_wide_layers<2, BITS>(wg2, net, active, wave, lane, LD, in, out, acts_tile, dz_tile, L.acts_ls[grp], n_rows, n_rows - 1, n_run, wrap);
-                else bwd_wide_layers<1, BITS>(wg1, net, active, wave, lane, LD, in, out, acts_tile, dz_tile, L.acts_ls[grp], n_rows, n_rows - 1, n_run, wrap);
+                if (two) bwd_wide_layers<2, BITS>(wg2, net, active, wave, lane, LD, in, out, acts_tile, dz_tile, L.acts_ls[grp], n_rows, n_rows - 1, nwide - 1, wrap, 256, &gbar);
+                else bwd_wide_layers<1, BITS>(wg1, net, active, wave, lane, LD, in, out, acts_tile, dz_tile, L.acts_ls[grp], n_rows, n_rows - 1, nwide - 1, wrap, 256, &gbar);
             }
         }
         BSTAMP(8 * st + 3)
@@ -497,7 +503,7 @@ extern "C" int nlbac_node_rk_bwd(const nlbac_mlp* f, const nlbac_mlp* g, const f
     const size_t lds = ((size_t)4 * NLBAC_MLP_TILE * L.ld + RK_MAX_STAGES * NLBAC_MLP_TILE * RK_MAX_NS +
                         NLBAC_MLP_TILE * (RK_MAX_NU + 1 + RK_MAX_NS + RK_MAX_NU + 2 * RK_MAX_NS + 2 * 16) + sw_total) *
                        sizeof(float);
-    NLBAC_REQUIRE(lds <= 160 * 1024, "nlbac_node_rk_bwd: LDS budget exceeded (%zu B)", lds);
+    NLBAC_REQUIRE(lds <= NODE_LDS_MAX, "nlbac_node_rk_bwd: LDS budget exceeded (%zu B)", lds);
     using KernelB = void (*)(const NodeRkBwdLaunch);
     static const KernelB kb[2][3] = {{node_rk_bwd_kernel<0, 0>, node_rk_bwd_kernel<1, 0>, node_rk_bwd_kernel<2, 0>},
                                      {node_rk_bwd_kernel<0, 1>, node_rk_bwd_kernel<1, 1>, node_rk_bwd_kernel<2, 1>}};
@@ -505,7 +511,7 @@ extern "C" int nlbac_node_rk_bwd(const nlbac_mlp* f, const nlbac_mlp* g, const f
     if (!attr_set) {
         for (int b = 0; b < 2; ++b)
             for (int m = 0; m < 3; ++m)
-                (void)hipFuncSetAttribute((const void*)kb[b][m], hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+                (void)hipFuncSetAttribute((const void*)kb[b][m], hipFuncAttributeMaxDynamicSharedMemorySize, NODE_LDS_MAX);
         attr_set = true;
     }
     const int ntf = (f->hid + 31) >> 5, ntg = (g->hid + 31) >> 5;
@@ -561,7 +567,7 @@ extern "C" int nlbac_node_rk_fwd(const nlbac_mlp* f, const nlbac_mlp* g, const f
     const size_t lds = ((size_t)4 * NLBAC_MLP_TILE * L.ld + RK_MAX_STAGES * NLBAC_MLP_TILE * RK_MAX_NS +
                         NLBAC_MLP_TILE * (RK_MAX_NS + RK_MAX_NU + 1 + RK_MAX_NS + RK_MAX_GOUT) + sw_total) *
                        sizeof(float);
-    NLBAC_REQUIRE(lds <= 160 * 1024, "nlbac_node_rk_fwd: LDS budget exceeded (%zu B)", lds);
+    NLBAC_REQUIRE(lds <= NODE_LDS_MAX, "nlbac_node_rk_fwd: LDS budget exceeded (%zu B)", lds);
     using KernelF = void (*)(const NodeRkLaunch);
     static const KernelF kf[2][2][3] = {
         {{node_rk_fwd_kernel<0, 0, 0>, node_rk_fwd_kernel<1, 0, 0>, node_rk_fwd_kernel<2, 0, 0>},
@@ -573,7 +579,7 @@ extern "C" int nlbac_node_rk_fwd(const nlbac_mlp* f, const nlbac_mlp* g, const f
         for (int o = 0; o < 2; ++o)
             for (int b = 0; b < 2; ++b)
                 for (int m = 0; m < 3; ++m)
-                    (void)hipFuncSetAttribute((const void*)kf[o][b][m], hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+                    (void)hipFuncSetAttribute((const void*)kf[o][b][m], hipFuncAttributeMaxDynamicSharedMemorySize, NODE_LDS_MAX);
         attr_set = true;
     }
     const int ntf = (f->hid + 31) >> 5, ntg = (g->hid + 31) >> 5;
