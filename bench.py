@@ -184,6 +184,36 @@ def cpu_baseline(B, solver, env_name="Unicycle", seed=0):
                                                                 NODE_FIT_INTERVAL, solver))
 
 
+def node_odeint_submetric(agent, env, B, solver, iters=50):
+    """Isolated NODE solve over [0, dt] + its backward (gradient to the controls), P = 2 problems of B rows — the two
+    rollouts (policy / backup policy) one update performs.  Times whole solves with HIP events on the launch stream."""
+    sol = agent.node_solver
+    P = 2
+    n = P * B
+    g = torch.Generator(device="cpu").manual_seed(7)
+    y0 = ((torch.rand(n, sol.n_s, generator=g) * 2 - 1)).to(agent.device)
+    u = ((torch.rand(n, sol.n_u, generator=g) * 2 - 1)).to(agent.device)
+    dout = torch.randn(n, sol.n_s, generator=g).to(agent.device)
+    dt = float(env.dt)
+
+    def once():
+        sol.forward(y0, u, P, B, solver, dt, agent.atol, agent.rtol)
+        sol.backward(dout, need_du=True)
+
+    for _ in range(5):
+        once()
+    torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(iters):
+        once()
+    e1.record()
+    torch.cuda.synchronize()
+    ms = e0.elapsed_time(e1) / iters
+    return {"value": n / (ms * 1e-3), "unit": "rows/s", "ms_per_solve_fwd_bwd": ms, "rows": n, "problems": P,
+            "solver": solver}
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -291,6 +321,13 @@ def main():
             step(a.warmup + a.steps + i)
     fence()
 
+    # ---- sub-metric: the NODE odeint alone, forward + backward to the controls, on the rollout
+    #      shape of the update (one problem per controller, B rows each)
+    ode_sub = None
+    solver_stats = dict(agent.node_solver.stats)
+    if rank == 0 and world == 1:
+        ode_sub = node_odeint_submetric(agent, env, B, a.solver)
+
     cpu = None
     if rank == 0 and world == 1 and not a.no_cpu_baseline:
         cpu = cpu_baseline(B, a.solver, a.env)
@@ -307,8 +344,8 @@ def main():
                                    % (a.env, B, a.solver, {"Unicycle": 1, "SimulatedCars": 2, "Pvtol": 3, "UnicycleBarrier": 4, "PvtolBarrier": 4}[a.env], NODE_FIT_ROWS, NODE_FIT_INTERVAL, REPLAY_ROWS),
                        "solver": a.solver, "batch_per_gpu": B, "global_batch": B * world,
                        "parallelism": "dp%d" % world, "hipgraph": bool(agent.use_graphs),
-                       "rollout_solver_stats": dict(agent.node_solver.stats), "last_losses": [float(x) for x in ret]},
-            "roofline": roofline, "cpu_baseline": cpu,
+                       "rollout_solver_stats": solver_stats, "last_losses": [float(x) for x in ret]},
+            "roofline": roofline, "cpu_baseline": cpu, "node_odeint_fwd_bwd": ode_sub,
         }
         if cpu:
             out["speedup_vs_cpu_baseline"] = value / cpu["value"]

@@ -99,13 +99,19 @@ int nlbac_mlp_bwd_weights(const nlbac_mlp *nets, const nlbac_mlp_io *io, int n_n
 
 /* ------------------------------------------------------------------------
  * Optimiser (torch.optim.Adam defaults: betas .9/.999, eps 1e-8, no decay).
- * `state` = {int step; float step_size; float bc2_sqrt; float pad} on device.
+ * `state` = {int step; float step_size; float bc2_sqrt; uint32 ticket (zero)} on device.
  * ---------------------------------------------------------------------- */
 int nlbac_adam_prepare(void *state, double lr, nlbac_stream_t s); /* ++step, bias corrections */
 /* p,m,v: n floats; grad: n_slabs slabs (summed in slab order); if target!=NULL:
  * target = (1-tau) target + tau p_new  (soft_update fused; tau<0 disables). */
 int nlbac_adam_step(float *p, float *m, float *v, const float *grad, int n_slabs, long slab_stride,
                     long n, const void *state, float *target, float tau, nlbac_stream_t s);
+/* nlbac_adam_prepare + nlbac_adam_step + nlbac_mlp_pack of the stepped nets in one launch.  scatter /
+ * scatter_target (or NULL): 2n uint64 device addresses, [2i], [2i+1] = the forward / backward MFMA-fragment
+ * slot of parameter i inside the nets' `packed` buffers (0 = none), for the trained and the target copy. */
+int nlbac_adam_fused(float *p, float *m, float *v, const float *grad, int n_slabs, long slab_stride, long n,
+                     void *state, double lr, float *target, float tau, const void *scatter,
+                     const void *scatter_target, nlbac_stream_t s);
 int nlbac_reduce_slabs(float *out, const float *grad, int n_slabs, long slab_stride, long n, nlbac_stream_t s);
 int nlbac_soft_update(float *target, const float *src, long n, float tau, nlbac_stream_t s);
 
@@ -306,6 +312,11 @@ int nlbac_node_rk_bwd(const nlbac_mlp *f, const nlbac_mlp *g, const float *u, co
 int nlbac_dopri_norm_partials(const float *a, const float *b, const float *y0, const float *y1,
                               const float *u, int mode, float rtol, float atol, int n_s, int n_u,
                               int rows_per_problem, int P, float *partials, nlbac_stream_t s);
+/* nlbac_dopri_norm_partials + nlbac_dopri_control in one launch (single-GPU path: no all-reduce between them).  tickets: P zeroed
+ * uint32 words, left zeroed by the launch. */
+int nlbac_dopri_norm_control(const float *a, const float *b, const float *y0, const float *y1, const float *u,
+                             int mode, float rtol, float atol, int n_s, int n_u, int rows_per_problem, int P,
+                             double t_end, float *partials, unsigned *tickets, double *ctl, nlbac_stream_t s);
 int nlbac_dopri_control(const float *partials, int n_blk_per_problem, int mode, int n_s, int n_u,
                         int rows_per_problem, int P, double t_end, double *ctl, nlbac_stream_t s);
 /* y(t_end) from the accepted step's stages (4th-order interpolant, x=(t_end-t)/h) and its backward

@@ -58,6 +58,7 @@ _PROTOS = {
     "nlbac_mlp_bwd_weights": [C.POINTER(Mlp), C.POINTER(MlpIO), _I, _I, _I, _L, _P, _L, _P],
     "nlbac_adam_prepare": [_P, _D, _P],
     "nlbac_adam_step": [_P, _P, _P, _P, _I, _L, _L, _P, _P, _F, _P],
+    "nlbac_adam_fused": [_P, _P, _P, _P, _I, _L, _L, _P, _D, _P, _F, _P, _P, _P],
     "nlbac_reduce_slabs": [_P, _P, _I, _L, _L, _P],
     "nlbac_soft_update": [_P, _P, _L, _F, _P],
     "nlbac_gauss_sample_fwd": [_P, _I, _P, _P, _P, _I, _I, _P, _I, _P, _P],
@@ -98,6 +99,7 @@ _PROTOS = {
     "nlbac_node_rk_bwd": [C.POINTER(Mlp), C.POINTER(Mlp), _P, _P, _I, _I, _I, _I, _I, _I, c_float_p, c_float_p, _P, _I,
                           _P, _L, _P, _L, _I, _P, _P, _P, _P, _P, _P, _I, _P, _I, _P],
     "nlbac_dopri_norm_partials": [_P, _P, _P, _P, _P, _I, _F, _F, _I, _I, _I, _I, _P, _P],
+    "nlbac_dopri_norm_control": [_P, _P, _P, _P, _P, _I, _F, _F, _I, _I, _I, _I, _D, _P, _P, _P, _P],
     "nlbac_dopri_control": [_P, _I, _I, _I, _I, _I, _I, _D, _P, _P],
     "nlbac_dopri_interp_fwd": [_P, _P, _P, c_float_p, c_float_p, _P, _I, _I, _I, _P, _P],
     "nlbac_dopri_interp_bwd": [_P, c_float_p, c_float_p, _P, _I, _I, _I, _P, _P, _P, _P],

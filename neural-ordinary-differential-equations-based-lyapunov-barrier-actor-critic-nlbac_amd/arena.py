@@ -36,6 +36,8 @@ class Arena:
         self._pending = []      # (param, offset)
         self.size = 0
         self.theta = None
+        self.handles = []       # the MlpHandles whose parameters live here
+        self._scatter = None
 
     def add_group(self, params):
         """Reserve contiguous space for a list of nn.Parameters (no padding
@@ -70,6 +72,65 @@ class Arena:
     def hard_update_target(self):
         self.target.copy_(self.theta)
 
+    def scatter_tables(self):
+        """(scatter, scatter_target) for ``nlbac_adam_fused``: per parameter the device addresses of its forward /
+        backward MFMA-fragment slots in the nets' ``packed`` (``packed_target``) buffers, so the optimiser step
+        refreshes those copies itself.  Found by packing an index ramp once (the fragment layout stays the business
+        of ``nlbac_mlp_pack`` alone) and checked against a real pack."""
+        if self._scatter is not None:
+            return self._scatter
+        import numpy as np
+        hs = [h for h in self.handles if h.desc is not None]
+        n = self.n
+        assert hs and n < (1 << 24), "index ramp must stay exact in fp32"
+        keep = self.theta.clone()
+        self.theta.copy_(torch.arange(1, n + 1, dtype=torch.float32))
+        pack(hs)
+        torch.cuda.synchronize()
+        src_all, addr_all, addr_t_all = [], [], []
+        for h in hs:
+            pk = h.packed.cpu().numpy()
+            slots = np.nonzero(pk)[0]
+            src_all.append(pk[slots].astype(np.int64) - 1)
+            addr_all.append(np.uint64(h.packed.data_ptr()) + slots.astype(np.uint64) * np.uint64(4))
+            if self.with_target:
+                addr_t_all.append(np.uint64(h.packed_target.data_ptr()) + slots.astype(np.uint64) * np.uint64(4))
+        src = np.concatenate(src_all)
+        order = np.argsort(src, kind="stable")
+        src = src[order]
+        first = np.ones(len(src), dtype=bool)
+        first[1:] = src[1:] != src[:-1]
+        second = ~first
+        assert not (second[1:] & second[:-1]).any(), "a parameter has more than two fragment slots"
+
+        def table(addrs):
+            a = np.concatenate(addrs)[order]
+            t = np.zeros((n, 2), dtype=np.uint64)
+            t[src[first], 0] = a[first]
+            t[src[second], 1] = a[second]
+            return torch.from_numpy(t.view(np.int64).reshape(-1)).to(self.device)
+
+        tab = table(addr_all)
+        tab_t = table(addr_t_all) if self.with_target else None
+        self.theta.copy_(keep)
+        pack(hs)
+        if self.with_target:
+            pack(hs, target=True)
+        # check: scattering theta through the table reproduces the packed buffers
+        th = self.theta.cpu().numpy()
+        t_np = tab.cpu().numpy().view(np.uint64).reshape(n, 2)
+        for h in hs:
+            pk = h.packed.cpu().numpy()
+            base = np.uint64(h.packed.data_ptr())
+            chk = np.zeros_like(pk)
+            for c in range(2):
+                a = t_np[:, c]
+                sel = (a >= base) & (a < base + np.uint64(4 * pk.size))
+                chk[((a[sel] - base) // np.uint64(4)).astype(np.int64)] = th[sel]
+            assert np.array_equal(chk, pk), "scatter table does not reproduce nlbac_mlp_pack for %s" % h.name
+        self._scatter = (tab, tab_t)
+        return self._scatter
+
     def grad_view(self, p, slab=None):
         off = self.offset_of[id(p)]
         g = self.grad[:, off:off + p.numel()]
@@ -99,6 +160,7 @@ class MlpHandle:
         for Ws, bs in flat:               # contiguous groups: W's then b's
             arena.add_group(Ws)
             arena.add_group(bs)
+        arena.handles.append(self)
         self.desc = None
         self.desc_target = None
 
@@ -109,6 +171,7 @@ class MlpHandle:
         for l, (Ws, bs) in enumerate(self._flat):
             d.w_off[l] = a.offset_of[id(Ws[0])]
             d.b_off[l] = a.offset_of[id(bs[0])]
+        a._scatter = None                 # (new packed buffers: the slot addresses change)
         lib = _lib.load()
         n_packed = lib.nlbac_mlp_pack_layout(C.byref(d))
         self.packed = torch.zeros(max(n_packed, 4), dtype=torch.float32, device=a.device)

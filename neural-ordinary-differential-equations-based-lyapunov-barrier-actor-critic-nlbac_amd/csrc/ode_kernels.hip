@@ -98,9 +98,9 @@ enum { C_H = 0, C_T = 1, C_RATIO = 2, C_ACCEPT = 3, C_DONE = 4, C_X = 5, C_H0 = 
 //  mode 0: col0 = sum (y0/scale)^2 (+ (u/scale_u)^2), col1 = sum (a/scale)^2          a = f0
 //  mode 1: col0 = sum ((a-b)/scale)^2                                                  a = f1, b = f0
 //  mode 2: col0 = sum (a/tol)^2, tol = atol + rtol*max(|y0|,|y1|)                      a = err
-__global__ __launch_bounds__(256) void dopri_norm_kernel(const float* a, const float* b, const float* y0,
-                                                         const float* y1, const float* u, int mode, float rtol,
-                                                         float atol, int n_s, int n_u, int rpp, float* partials) {
+__device__ __forceinline__ void dopri_norm_block(const float* a, const float* b, const float* y0, const float* y1,
+                                                 const float* u, int mode, float rtol, float atol, int n_s, int n_u,
+                                                 int rpp, float* partials) {
     __shared__ float red[8];
     const int p = blockIdx.y;
     const int i = blockIdx.x * 256 + threadIdx.x;
@@ -138,15 +138,28 @@ __global__ __launch_bounds__(256) void dopri_norm_kernel(const float* a, const f
     }
 }
 
-__global__ void dopri_control_kernel(const float* partials, int nblk, int mode, int n_s, int n_u, int rpp,
-                                     double t_end, double* ctl) {
-    const int p = blockIdx.x;
-    if (threadIdx.x != 0) return;
+__global__ __launch_bounds__(256) void dopri_norm_kernel(const float* a, const float* b, const float* y0,
+                                                         const float* y1, const float* u, int mode, float rtol,
+                                                         float atol, int n_s, int n_u, int rpp, float* partials) {
+    dopri_norm_block(a, b, y0, y1, u, mode, rtol, atol, n_s, n_u, rpp, partials);
+}
+
+// the controller of problem p on the finished block sums (fixed summation order: deterministic); COHERENT: the sums
+// were written by other workgroups of the same launch (read them past the non-coherent caches)
+template <bool COHERENT>
+__device__ __forceinline__ void dopri_control_one(const float* partials, int p, int nblk, int mode, int n_s, int n_u,
+                                                  int rpp, double t_end, double* ctl) {
     double* c = ctl + (long)p * NLBAC_DOPRI_CTL;
     double s0 = 0.0, s1 = 0.0;
     for (int b = 0; b < nblk; ++b) {
-        s0 += (double)partials[((long)p * nblk + b) * 2 + 0];
-        s1 += (double)partials[((long)p * nblk + b) * 2 + 1];
+        const float* q = partials + ((long)p * nblk + b) * 2;
+        if constexpr (COHERENT) {
+            s0 += (double)__hip_atomic_load(q + 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            s1 += (double)__hip_atomic_load(q + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        } else {
+            s0 += (double)q[0];
+            s1 += (double)q[1];
+        }
     }
     const double cnt = (double)rpp * (double)(n_s + n_u);
     if (mode == 0) {
@@ -182,6 +195,29 @@ __global__ void dopri_control_kernel(const float* partials, int nblk, int mode, 
             c[C_H] = h * fac;
         }
     }
+}
+
+__global__ void dopri_control_kernel(const float* partials, int nblk, int mode, int n_s, int n_u, int rpp,
+                                     double t_end, double* ctl) {
+    if (threadIdx.x != 0) return;
+    dopri_control_one<false>(partials, blockIdx.x, nblk, mode, n_s, n_u, rpp, t_end, ctl);
+}
+
+// norm + controller in one launch: the workgroup that finishes a problem's sums last (a ticket counter per problem,
+// left at zero again for the next launch) runs that problem's controller
+__global__ __launch_bounds__(256) void dopri_norm_control_kernel(const float* a, const float* b, const float* y0,
+                                                                 const float* y1, const float* u, int mode, float rtol,
+                                                                 float atol, int n_s, int n_u, int rpp, double t_end,
+                                                                 float* partials, unsigned* tickets, double* ctl) {
+    dopri_norm_block(a, b, y0, y1, u, mode, rtol, atol, n_s, n_u, rpp, partials);
+    if (threadIdx.x != 0) return;
+    const int p = blockIdx.y;
+    __threadfence();                                   // this block's sums are visible device-wide before its ticket
+    const unsigned ticket = __hip_atomic_fetch_add(tickets + p, 1u, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT);
+    if (ticket != gridDim.x - 1) return;
+    __hip_atomic_store(tickets + p, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    __threadfence();
+    dopri_control_one<true>(partials, p, (int)gridDim.x, mode, n_s, n_u, rpp, t_end, ctl);
 }
 
 #define DPM0 (6025192743.0 / 30085553152.0 / 2.0)
@@ -318,6 +354,21 @@ extern "C" int nlbac_dopri_norm_partials(const float* a, const float* b, const f
     hipLaunchKernelGGL(dopri_norm_kernel, dim3(nlbac_ceil_div(rows_per_problem, 256), P), dim3(256), 0,
                        (hipStream_t)s, a, b, y0, y1, u, mode, rtol, atol, n_s, n_u, rows_per_problem, partials);
     NLBAC_CHECK_LAUNCH("nlbac_dopri_norm_partials");
+    return 0;
+}
+
+extern "C" int nlbac_dopri_norm_control(const float* a, const float* b, const float* y0, const float* y1, const float* u,
+                                        int mode, float rtol, float atol, int n_s, int n_u, int rows_per_problem, int P,
+                                        double t_end, float* partials, unsigned* tickets, double* ctl,
+                                        nlbac_stream_t s) {
+    NLBAC_REQUIRE(a && y0 && partials && tickets && ctl && mode >= 0 && mode <= 2,
+                  "nlbac_dopri_norm_control: bad arguments");
+    NLBAC_REQUIRE((mode != 0 || u) && (mode != 1 || b) && (mode != 2 || y1), "nlbac_dopri_norm_control: missing operand");
+    NLBAC_REQUIRE(P >= 1 && P <= MAX_PROBLEMS, "nlbac_dopri_norm_control: P %d out of range", P);
+    hipLaunchKernelGGL(dopri_norm_control_kernel, dim3(nlbac_ceil_div(rows_per_problem, 256), P), dim3(256), 0,
+                       (hipStream_t)s, a, b, y0, y1, u, mode, rtol, atol, n_s, n_u, rows_per_problem, t_end, partials,
+                       tickets, ctl);
+    NLBAC_CHECK_LAUNCH("nlbac_dopri_norm_control");
     return 0;
 }
 

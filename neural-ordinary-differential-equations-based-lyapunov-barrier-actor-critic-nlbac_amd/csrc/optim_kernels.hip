@@ -16,7 +16,7 @@ struct AdamState {
     int step;
     float step_size;   // lr / (1 - beta1^t)
     float bc2_sqrt;    // sqrt(1 - beta2^t)
-    float pad;
+    unsigned ticket;   // nlbac_adam_fused: workgroups that have finished (zero between launches)
 };
 
 __global__ void adam_prepare_kernel(AdamState* st, double lr) {
@@ -82,6 +82,93 @@ __global__ __launch_bounds__(256) void adam_step_kernel(float* __restrict__ p, f
     }
 }
 
+// One launch per optimiser step: ++step and its bias corrections (adam_prepare), the slab sum + Adam + Polyak update
+// (adam_step), and the refresh of the MFMA-fragment copies of the weights (mlp_pack) through a scatter table: for
+// parameter i, scat[2i], scat[2i+1] are the device addresses of its forward / backward fragment slots (0 = none;
+// biases and skinny layers are read from the flat parameters).  Every workgroup derives the step constants from the
+// still un-incremented counter; the workgroup that finishes last publishes the new counter.
+__device__ __forceinline__ void scatter2(const unsigned long long* __restrict__ scat, long i, float val) {
+    const unsigned long long a = scat[2 * i], b = scat[2 * i + 1];
+    if (a) *reinterpret_cast<float*>(a) = val;
+    if (b) *reinterpret_cast<float*>(b) = val;
+}
+
+__global__ __launch_bounds__(256) void adam_fused_kernel(float* __restrict__ p, float* __restrict__ m,
+                                                         float* __restrict__ v, const float* __restrict__ grad,
+                                                         int n_slabs, long slab_stride, long n, AdamState* st, double lr,
+                                                         float* __restrict__ target, float tau,
+                                                         const unsigned long long* __restrict__ scat,
+                                                         const unsigned long long* __restrict__ scat_t) {
+    __shared__ float s_const[2];
+    __shared__ int s_step;
+    if (threadIdx.x == 0) {
+        const int t = __hip_atomic_load(&st->step, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) + 1;
+        const double bc1 = 1.0 - pow(0.9, (double)t);
+        const double bc2 = 1.0 - pow(0.999, (double)t);
+        s_const[0] = (float)(lr / bc1);
+        s_const[1] = (float)sqrt(bc2);
+        s_step = t;
+    }
+    __syncthreads();
+    const float step_size = s_const[0], bc2_sqrt = s_const[1];
+    const long n4 = n >> 2;
+    const long stride = (long)gridDim.x * blockDim.x;
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += stride) {
+        float4 g = reinterpret_cast<const float4*>(grad)[i];
+        for (int s = 1; s < n_slabs; ++s) {
+            const float4 gs = reinterpret_cast<const float4*>(grad + s * slab_stride)[i];
+            g.x += gs.x; g.y += gs.y; g.z += gs.z; g.w += gs.w;
+        }
+        float4 pp = reinterpret_cast<float4*>(p)[i];
+        float4 mm = reinterpret_cast<float4*>(m)[i];
+        float4 vv = reinterpret_cast<float4*>(v)[i];
+        adam_one(pp.x, mm.x, vv.x, g.x, step_size, bc2_sqrt);
+        adam_one(pp.y, mm.y, vv.y, g.y, step_size, bc2_sqrt);
+        adam_one(pp.z, mm.z, vv.z, g.z, step_size, bc2_sqrt);
+        adam_one(pp.w, mm.w, vv.w, g.w, step_size, bc2_sqrt);
+        reinterpret_cast<float4*>(p)[i] = pp;
+        reinterpret_cast<float4*>(m)[i] = mm;
+        reinterpret_cast<float4*>(v)[i] = vv;
+        if (scat) {
+            scatter2(scat, 4 * i + 0, pp.x); scatter2(scat, 4 * i + 1, pp.y);
+            scatter2(scat, 4 * i + 2, pp.z); scatter2(scat, 4 * i + 3, pp.w);
+        }
+        if (target) {
+            float4 t = reinterpret_cast<float4*>(target)[i];
+            t.x = t.x * (1.0f - tau) + pp.x * tau; t.y = t.y * (1.0f - tau) + pp.y * tau;
+            t.z = t.z * (1.0f - tau) + pp.z * tau; t.w = t.w * (1.0f - tau) + pp.w * tau;
+            reinterpret_cast<float4*>(target)[i] = t;
+            if (scat_t) {
+                scatter2(scat_t, 4 * i + 0, t.x); scatter2(scat_t, 4 * i + 1, t.y);
+                scatter2(scat_t, 4 * i + 2, t.z); scatter2(scat_t, 4 * i + 3, t.w);
+            }
+        }
+    }
+    for (long i = (n4 << 2) + (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
+        float g = grad[i];
+        for (int s = 1; s < n_slabs; ++s) g += grad[s * slab_stride + i];
+        float pp = p[i], mm = m[i], vv = v[i];
+        adam_one(pp, mm, vv, g, step_size, bc2_sqrt);
+        p[i] = pp; m[i] = mm; v[i] = vv;
+        if (scat) scatter2(scat, i, pp);
+        if (target) {
+            const float t = target[i] * (1.0f - tau) + pp * tau;
+            target[i] = t;
+            if (scat_t) scatter2(scat_t, i, t);
+        }
+    }
+    __syncthreads();                                   // every wave of this block has read the constants
+    if (threadIdx.x == 0) {
+        const unsigned ticket = __hip_atomic_fetch_add(&st->ticket, 1u, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT);
+        if (ticket == gridDim.x - 1) {                 // all workgroups have read st->step by now
+            __hip_atomic_store(&st->ticket, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            st->step_size = step_size;
+            st->bc2_sqrt = bc2_sqrt;
+            __hip_atomic_store(&st->step, s_step, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+        }
+    }
+}
+
 __global__ __launch_bounds__(256) void reduce_slabs_kernel(float* __restrict__ out, const float* __restrict__ grad,
                                                            int n_slabs, long slab_stride, long n) {
     const long stride = (long)gridDim.x * blockDim.x;
@@ -143,6 +230,22 @@ extern "C" int nlbac_adam_step(float* p, float* m, float* v, const float* grad, 
     hipLaunchKernelGGL(adam_step_kernel, dim3(stream_grid(n, 4)), dim3(256), 0, (hipStream_t)s, p, m, v, grad,
                        n_slabs, slab_stride, n, (const AdamState*)state, (tau >= 0.f) ? target : nullptr, tau);
     NLBAC_CHECK_LAUNCH("nlbac_adam_step");
+    return 0;
+}
+
+extern "C" int nlbac_adam_fused(float* p, float* m, float* v, const float* grad, int n_slabs, long slab_stride, long n,
+                                void* state, double lr, float* target, float tau, const void* scatter,
+                                const void* scatter_target, nlbac_stream_t s) {
+    NLBAC_REQUIRE(p && m && v && grad && state, "nlbac_adam_fused: null pointer");
+    NLBAC_REQUIRE(n_slabs >= 1 && n >= 1 && lr > 0.0, "nlbac_adam_fused: bad sizes");
+    NLBAC_REQUIRE(((uintptr_t)p | (uintptr_t)m | (uintptr_t)v | (uintptr_t)grad | (uintptr_t)target) % 16 == 0 &&
+                      slab_stride % 4 == 0 && ((uintptr_t)scatter | (uintptr_t)scatter_target) % 8 == 0,
+                  "nlbac_adam_fused: buffers must be 16-byte aligned");
+    NLBAC_REQUIRE(!scatter_target || (target && tau >= 0.f), "nlbac_adam_fused: scatter_target without a target");
+    hipLaunchKernelGGL(adam_fused_kernel, dim3(stream_grid(n, 4)), dim3(256), 0, (hipStream_t)s, p, m, v, grad, n_slabs,
+                       slab_stride, n, (AdamState*)state, lr, (tau >= 0.f) ? target : nullptr, tau,
+                       (const unsigned long long*)scatter, (const unsigned long long*)scatter_target);
+    NLBAC_CHECK_LAUNCH("nlbac_adam_fused");
     return 0;
 }
 

@@ -271,12 +271,60 @@ class AffineNodeSolver:
         """dopri5, after forward_begin: True iff every problem accepted its first step and reached dt
         (the overwhelmingly common case at dt=0.02).  One small D2H read."""
         P = self.ctx["P"]
-        c = self._ctl(P).cpu()
+        c = self._ctl_read(P)
         self.ctx["ctl_host"] = c
         return all(bool(c[p, 3] > 0) and bool(c[p, 4] > 0) for p in range(P))
 
     def _ctl(self, P):
         return self._buf("ctl", P, _lib.DOPRI_CTL, dtype=torch.float64)
+
+    def _ctl_post(self, P):
+        """After an attempted step: send the control block to pinned host memory on a side stream, so that the
+        host can read the accept decision as soon as the controller has run — without draining the launch
+        stream, on which the caller may have queued independent work behind the attempt (the agent queues its
+        whole critic phase there).  Not inside a hipGraph capture (the replay path reads with ``_ctl(P).cpu()``)."""
+        if torch.cuda.is_current_stream_capturing():
+            return
+        side = self.__dict__.get("_side")
+        if side is None:
+            side = self._side = torch.cuda.Stream(device=self.device)
+            self._ev_ctl = (torch.cuda.Event(), torch.cuda.Event())
+            self._ctl_pin = {}
+        pin = self._ctl_pin.get(P)
+        if pin is None:
+            pin = self._ctl_pin[P] = torch.zeros(P, _lib.DOPRI_CTL, dtype=torch.float64).pin_memory()
+        ev_a, ev_b = self._ev_ctl
+        ev_a.record()
+        side.wait_event(ev_a)
+        with torch.cuda.stream(side):
+            pin.copy_(self._ctl(P), non_blocking=True)
+            ev_b.record()
+        self.ctx["ctl_pending"] = P
+
+    def _ctl_read(self, P):
+        """Host copy of the control block of the last attempted step."""
+        if self.ctx.pop("ctl_pending", None) == P:
+            self._ev_ctl[1].synchronize()
+            return self._ctl_pin[P].clone()
+        return self._ctl(P).cpu()
+
+    def _norm_control(self, a, b, y0, y1, u, mode, P, rpp):
+        """Scaled RMS norm(s) of mode 0/1/2 (include/nlbac_hip.h) over each problem's rows, then the step-size
+        controller: one launch on a single GPU, norm -> all-reduce -> controller under data parallelism."""
+        ctx = self.ctx
+        ns, nu, s = self.n_s, self.n_u, stream_ptr()
+        nblk = (rpp + 255) // 256
+        part = self._buf("part", P, nblk, 2)
+        ctl = self._ctl(P)
+        dp = lambda t: t.data_ptr() if t is not None else None
+        if self.comm is not None and self.comm.world > 1:
+            _lib.call("nlbac_dopri_norm_partials", dp(a), dp(b), dp(y0), dp(y1), dp(u), mode, ctx["rtol"], ctx["atol"],
+                      ns, nu, rpp, P, part.data_ptr(), s)
+            self._control(part, nblk, mode, P, rpp, ctx["t_end"], ctl)
+            return
+        tickets = self._buf("tickets", P, dtype=torch.int32)
+        _lib.call("nlbac_dopri_norm_control", dp(a), dp(b), dp(y0), dp(y1), dp(u), mode, ctx["rtol"], ctx["atol"],
+                  ns, nu, rpp, P, ctx["t_end"], part.data_ptr(), tickets.data_ptr(), ctl.data_ptr(), s)
 
     def _control(self, part, nblk, mode, P, rpp, t_end, ctl):
         """Step-size controller; under data parallelism the squared-norm sums are all-reduced first so every
@@ -310,9 +358,8 @@ class AffineNodeSolver:
                 self._stage_eval(ws, st, u)
             _lib.call("nlbac_rk_combine", None, ws.K.data_ptr(), S, self._coef("err"), None, h_dev, _lib.DOPRI_CTL,
                       P, rpp, ns, ws.err.data_ptr(), s)
-        _lib.call("nlbac_dopri_norm_partials", ws.err.data_ptr(), None, cur_y0.data_ptr(), ws.Y[6].data_ptr(), None,
-                  2, ctx["rtol"], ctx["atol"], ns, nu, rpp, P, part.data_ptr(), s)
-        self._control(part, nblk, 2, P, rpp, ctx["t_end"], ctl)
+        self._norm_control(ws.err, None, cur_y0, ws.Y[6], None, 2, P, rpp)
+        self._ctl_post(P)
 
     def _coef(self, key):
         c = self._coefs.get(key)
@@ -336,9 +383,7 @@ class AffineNodeSolver:
         else:
             ws.Y[0].copy_(y0)
             self._stage_eval(ws, 0, u)
-        _lib.call("nlbac_dopri_norm_partials", ws.K[0].data_ptr(), None, y0.data_ptr(), None, u.data_ptr(), 0,
-                  rtol, atol, ns, nu, rpp, P, part.data_ptr(), s)
-        self._control(part, nblk, 0, P, rpp, t_end, ctl)
+        self._norm_control(ws.K[0], None, y0, None, u, 0, P, rpp)
         ytmp, ktmp, gtmp = self._buf("ytmp", n, ns), self._buf("ktmp", n, ns), self._buf("gtmp", n, ns * nu)
         h0_dev = ctl.data_ptr() + 6 * 8           # C_H0
         _lib.call("nlbac_rk_combine", y0.data_ptr(), ws.K.data_ptr(), 1, self._coef("one"), None, h0_dev,
@@ -349,9 +394,7 @@ class AffineNodeSolver:
             ktmp = tws.K[0]
         else:
             self._probe_eval(ytmp, u, n, ktmp, gtmp)
-        _lib.call("nlbac_dopri_norm_partials", ktmp.data_ptr(), ws.K[0].data_ptr(), y0.data_ptr(), None, None, 1,
-                  rtol, atol, ns, nu, rpp, P, part.data_ptr(), s)
-        self._control(part, nblk, 1, P, rpp, t_end, ctl)
+        self._norm_control(ktmp, ws.K[0], y0, None, None, 1, P, rpp)
         self._dopri_attempt(ws, y0, u, P, rpp)
 
     def _dopri_accept_first(self, c):
@@ -362,9 +405,8 @@ class AffineNodeSolver:
         P, rpp, n, ns = ctx["P"], ctx["rpp"], ctx["n"], self.n_s
         ws = self._step_ws(n, 7, 0)
         ctl = self._ctl(P)
-        ws.y1.copy_(ws.Y[6])
-        out = self._buf("dopri_out", n, ns)
-        _lib.call("nlbac_dopri_interp_fwd", ctx["y0"].data_ptr(), ws.y1.data_ptr(), ws.K.data_ptr(), None, None,
+        out = self._buf("dopri_out", n, ns)       # (y1 is the input of stage 6: read in place, no copy)
+        _lib.call("nlbac_dopri_interp_fwd", ctx["y0"].data_ptr(), ws.Y[6].data_ptr(), ws.K.data_ptr(), None, None,
                   ctl.data_ptr(), P, rpp, ns, out.data_ptr(), stream_ptr())
         step = dict(ws=ws, first=True, dev=True)
         if c is not None:
@@ -386,7 +428,7 @@ class AffineNodeSolver:
         for attempt in range(1000):
             c = ctx.pop("ctl_host", None)
             if c is None:
-                c = ctl.cpu()                     # the one host sync per attempted step
+                c = self._ctl_read(P)             # the one host wait per attempted step
             acc = [bool(c[p, 3] > 0) for p in range(P)]
             done = [bool(c[p, 4] > 0) for p in range(P)]
             if any(a != acc[0] for a in acc) or any(d != done[0] for d in done):
@@ -397,21 +439,20 @@ class AffineNodeSolver:
             if attempt == 0:
                 self.stats["multi_attempt"] += 1
             if acc[0]:
-                ws.y1.copy_(ws.Y[6])
                 steps.append(dict(ws=ws, h=[float(c[p, 11]) for p in range(P)], first=(idx == 0)))
                 if done[0]:
                     x = [float(c[p, 5]) for p in range(P)]
                     steps[-1]["x"] = x
                     out = self._buf("dopri_out", n, ns)
-                    _lib.call("nlbac_dopri_interp_fwd", cur_y0.data_ptr(), ws.y1.data_ptr(), ws.K.data_ptr(),
+                    _lib.call("nlbac_dopri_interp_fwd", cur_y0.data_ptr(), ws.Y[6].data_ptr(), ws.K.data_ptr(),
                               fptr(*steps[-1]["h"]), fptr(*x), None, P, rpp, ns, out.data_ptr(), s)
                     ctx.update(steps=steps, out=out, info=info)
                     return out
-                cur_y0 = ws.y1
+                cur_y0 = ws.Y[6]                  # y1 of an accepted step = its stage-6 input (ws is not reused)
                 idx += 1
                 prev = ws
                 ws = self._step_ws(n, S, idx)
-                ws.Y[0].copy_(prev.y1)
+                ws.Y[0].copy_(prev.Y[6])
                 ws.K[0].copy_(prev.K[6])          # FSAL
             self._dopri_attempt(ws, cur_y0, u, P, rpp)
         raise _lib.NlbacError("dopri5: max_num_steps exceeded")
@@ -477,7 +518,8 @@ class AffineNodeSolver:
             h_dev = self._ctl(P).data_ptr() + 8 * 11 if dev else None      # C_HUSED
             h_stride = _lib.DOPRI_CTL if dev else 0
             last = si == len(steps) - 1
-            ws.dK.zero_()
+            if not (method == "dopri5" and last):
+                ws.dK.zero_()              # (the interpolant's backward assigns every stage of dK itself)
             if method == "dopri5":
                 beta, first_eval = DP_BETA, step["first"]
                 if last:

@@ -216,6 +216,8 @@ class SAC_CBF_CLF(object):
         if task.has_signal:
             self.BarrierNet_target = _TargetView(self.BarrierNet, self.ar_c)
         self.repack_all()
+        for ar in self.arenas:          # (built here, not inside a captured update)
+            ar.scatter_tables()
 
         # --- device scalars: alpha, lambdas, augmented term --------------------
         self.sc = torch.zeros(SC.SC_SIZE, dtype=torch.float32, device=dev)
@@ -270,12 +272,14 @@ class SAC_CBF_CLF(object):
         flat buffer (+ ``extra`` scalars riding along) -> all-reduce -> step on the reduced gradient."""
         s = stream_ptr()
         a = arena
-        _lib.call("nlbac_adam_prepare", a.state.data_ptr(), lr, s)
+        # one launch: ++step, slab sum, Adam, Polyak targets and the refresh of the nets' MFMA-fragment weight copies
+        scat, scat_t = a.scatter_tables()
+        scat_t = scat_t.data_ptr() if (scat_t is not None and target is not None and tau >= 0) else None
         if self.world == 1:
             if before_step is not None:
                 before_step(a.grad.data_ptr())
-            _lib.call("nlbac_adam_step", a.theta.data_ptr(), a.m.data_ptr(), a.v.data_ptr(), a.grad.data_ptr(),
-                      n_slabs, a.n, a.n, a.state.data_ptr(), target, tau, s)
+            _lib.call("nlbac_adam_fused", a.theta.data_ptr(), a.m.data_ptr(), a.v.data_ptr(), a.grad.data_ptr(),
+                      n_slabs, a.n, a.n, a.state.data_ptr(), lr, target, tau, scat.data_ptr(), scat_t, s)
             return
         n_extra = 0 if extra is None else extra.numel()
         xb = self._exchange_buf("g%d" % id(a), a.n + 4)
@@ -287,8 +291,8 @@ class SAC_CBF_CLF(object):
             extra.copy_(xb[a.n:a.n + n_extra])
         if before_step is not None:
             before_step(xb.data_ptr())
-        _lib.call("nlbac_adam_step", a.theta.data_ptr(), a.m.data_ptr(), a.v.data_ptr(), xb.data_ptr(), 1, a.n, a.n,
-                  a.state.data_ptr(), target, tau, s)
+        _lib.call("nlbac_adam_fused", a.theta.data_ptr(), a.m.data_ptr(), a.v.data_ptr(), xb.data_ptr(), 1, a.n, a.n,
+                  a.state.data_ptr(), lr, target, tau, scat.data_ptr(), scat_t, s)
 
     # ------------------------------------------------------------------ utils
     def repack_all(self):
@@ -468,7 +472,6 @@ class SAC_CBF_CLF(object):
         n_steps = max(1, len(self.task.fit_solver.ctx.get("steps") or [None]))
         used = self.task.fit_solver.accumulate_param_grads(self.ar_n, max(1, min(self.n_fit_slabs, self.ar_n.n_slabs // n_steps)))
         self._adam(self.ar_n, 1e-3, used, extra=self.sc[SC.SC_NODE_LOSS:SC.SC_NODE_LOSS + 1])
-        pack(self.h_node)
 
     def _capture(self, fn):
         """Record the launches of ``fn`` into a hipGraph (all kernel arguments are static device pointers /
@@ -662,6 +665,9 @@ class SAC_CBF_CLF(object):
         call("nlbac_mlp_fwd", P.n_pol3, P.io_pol3, 1 + NP, B, s)
         call("nlbac_gauss_sample_fwd", ws.heads3.data_ptr(), 2 * A, ws.eps.data_ptr(), p_scale, p_bias, A, (1 + NP) * B,
              ws.act3.data_ptr(), A, ws.logp3.data_ptr(), s)
+        # the rollout of the learned dynamics needs only pi(s) and the NODE: its first attempted step goes in here,
+        # so that the critic phase below is queued behind it while the host waits for the accept decision
+        self.task.rollout_begin(ws, P)
         call("nlbac_mlp_fwd", P.n_six, P.io_six, P.n_six_count, B, s)
         q = ws.q6
         call("nlbac_td_targets", q[0].data_ptr(), q[1].data_ptr(), q[2].data_ptr(), ws.nlogp.data_ptr(),
@@ -681,13 +687,11 @@ class SAC_CBF_CLF(object):
         bwd_weights(P.n_crit, P.io_crit, n_crit, B, a.n_slabs, a.n, self.device)
         self._adam(a, self.critic_lyapunov_lr, a.n_slabs, extra=self.sc[SC.SC_QF1:SC.SC_QF1 + 3],
                    target=a.target.data_ptr(), tau=self.tau if soft else -1.0)
-        pack(self.h_crit, target="both" if soft else False)
 
-        # ---- C. actors: sample, Q(s, pi), then the rollout of the learned dynamics -----
+        # ---- C. actors: Q(s, pi) with the stepped critics (the rollout was started in phase A) -----
         call("nlbac_mlp_fwd", P.n_q5, P.io_q5, P.n_q5_count, B, s)
         call("nlbac_actor_q_terms", ws.qpi[0].data_ptr(), ws.qpi[1].data_ptr(), ws.logp2.data_ptr(),
              sc + 4 * SC.SC_ALPHA, B, G, NP, ws.dq_pi[0].data_ptr(), ws.dq_pi[1].data_ptr(), ws.part_q.data_ptr(), s)
-        self.task.rollout_begin(ws, P)
 
     def _upd_part2(self, ws, lam_upd, assume_single):
         """Constraints, augmented-Lagrangian scalars, the whole actor backward and the actor Adam step."""
@@ -727,7 +731,6 @@ class SAC_CBF_CLF(object):
             self._adam(a, self.lr, a.n_slabs, before_step=alpha_grads)
             if tune:
                 call("nlbac_alpha_refresh", la, g.la_stride, g.first, cnt, sc, s)
-        pack(self.h_pols[:NP])
 
     # ------------------------------------------------------------ checkpoints
     def save_model(self, output):

@@ -109,9 +109,11 @@ def test_mlp_fwd_bwd_matches_torch(in_dim, hid, out_dim, n_layers, B, split):
         vec_close(gb, grads_ref[l][1], TOL, "db%d" % l)
 
 
-def test_multi_net_launch_and_adam_soft_update():
+@pytest.mark.parametrize("fused", [False, True], ids=["prepare+step+pack", "adam_fused"])
+def test_multi_net_launch_and_adam_soft_update(fused):
     """Three nets in one launch (grid.y) + Adam with slab reduction + fused Polyak update
-    vs torch.optim.Adam / the reference's soft_update arithmetic."""
+    vs torch.optim.Adam / the reference's soft_update arithmetic.  ``fused``: the one-launch optimiser step that
+    also refreshes the MFMA-fragment weight copies through the arena's scatter tables."""
     from nlbac_amd import _lib, arena as A
     torch.manual_seed(0)
     B, hid = 96, 256
@@ -153,10 +155,16 @@ def test_multi_net_launch_and_adam_soft_update():
         _lib.call("nlbac_mlp_fwd", nets, io, 3, B, s)
         _lib.call("nlbac_mlp_bwd_data", nets, io, 3, B, s)
         A.bwd_weights(nets, io, 3, B, ar.n_slabs, ar.n, "cuda")
-        _lib.call("nlbac_adam_prepare", ar.state.data_ptr(), lr, s)
-        _lib.call("nlbac_adam_step", ar.theta.data_ptr(), ar.m.data_ptr(), ar.v.data_ptr(), ar.grad.data_ptr(),
-                  ar.n_slabs, ar.n, ar.n, ar.state.data_ptr(), ar.target.data_ptr(), tau, s)
-        A.pack(hs)
+        if fused:
+            scat, scat_t = ar.scatter_tables()
+            _lib.call("nlbac_adam_fused", ar.theta.data_ptr(), ar.m.data_ptr(), ar.v.data_ptr(), ar.grad.data_ptr(),
+                      ar.n_slabs, ar.n, ar.n, ar.state.data_ptr(), lr, ar.target.data_ptr(), tau, scat.data_ptr(),
+                      scat_t.data_ptr(), s)
+        else:
+            _lib.call("nlbac_adam_prepare", ar.state.data_ptr(), lr, s)
+            _lib.call("nlbac_adam_step", ar.theta.data_ptr(), ar.m.data_ptr(), ar.v.data_ptr(), ar.grad.data_ptr(),
+                      ar.n_slabs, ar.n, ar.n, ar.state.data_ptr(), ar.target.data_ptr(), tau, s)
+            A.pack(hs)
         opt.zero_grad()
         for i in range(3):
             h = xs[i]
@@ -170,6 +178,15 @@ def test_multi_net_launch_and_adam_soft_update():
             for t, p in zip(targ, flat):
                 t.copy_(t * (1.0 - tau) + p * tau)
     torch.cuda.synchronize()
+    st = ar.state.cpu()
+    assert int(st[0]) == 2 and int(st[3]) == 0, "step counter / ticket after two optimiser steps: %s" % st
+    if fused:       # the scattered fragment copies are bit-identical to a fresh pack of the stepped parameters
+        got = [(h.packed.clone(), h.packed_target.clone()) for h in hs]
+        A.pack(hs)
+        A.pack(hs, target=True)
+        torch.cuda.synchronize()
+        for h, (pk, pkt) in zip(hs, got):
+            assert torch.equal(pk, h.packed) and torch.equal(pkt, h.packed_target)
     k = 0
     for i, m in enumerate(mods):
         for l in m:
