@@ -333,6 +333,12 @@ int nlbac_dopri_interp_bwd(const float *dout, const float *h_host, const float *
  * (ld % 4 == 0; idx are int64 row numbers in [0, src_rows)). */
 int nlbac_gather_rows(const float *src, long src_rows, int ld, const long *idx, long n_rows, float *dst,
                       nlbac_stream_t s);
+/* Device-drawn minibatch: n_rows indices uniform on [0, src_rows) with replacement (Philox4x32-10 keyed by
+ * `seed`, counter = `draw`, the caller's draw number), gathered like nlbac_gather_rows, plus n_eps N(0,1)
+ * floats (the update's policy noise; eps may be NULL with n_eps 0) — one launch.  Replaces the host
+ * random.sample + np.stack of replay_memory.py:21-25 when the caller does not need the host's index stream. */
+int nlbac_sample_rows(const float *src, long src_rows, int ld, long n_rows, float *dst, float *eps, long n_eps,
+                      unsigned long long seed, unsigned long long draw, nlbac_stream_t s);
 
 /* small utilities */
 int nlbac_axpby(float a, const float *x, float b, const float *y /*or NULL*/, long n, float *out, nlbac_stream_t s);

@@ -301,6 +301,67 @@ __global__ __launch_bounds__(256) void gather_rows_kernel(const float4* __restri
     dst[r * ld4 + c] = src[j * ld4 + c];
 }
 
+// ---------------------------------------------------------------------------
+// Device-side draw of a minibatch (device_rng mode): row indices uniform on [0, src_rows) with
+// replacement, the gather into minibatch layout and the N(0,1) policy noise of the update, in ONE launch (the update
+// boundary is where the host is the bottleneck).  Philox4x32-10, counter = (draw number, row | lane); Box-Muller.
+// ---------------------------------------------------------------------------
+__device__ __forceinline__ uint4 philox4x32_10(uint4 ctr, uint2 key) {
+#pragma unroll
+    for (int r = 0; r < 10; ++r) {
+        const unsigned long long p0 = (unsigned long long)0xD2511F53u * ctr.x;
+        const unsigned long long p1 = (unsigned long long)0xCD9E8D57u * ctr.z;
+        ctr = make_uint4((unsigned)(p1 >> 32) ^ ctr.y ^ key.x, (unsigned)p1, (unsigned)(p0 >> 32) ^ ctr.w ^ key.y,
+                         (unsigned)p0);
+        key.x += 0x9E3779B9u;
+        key.y += 0xBB67AE85u;
+    }
+    return ctr;
+}
+
+__device__ __forceinline__ float u01(unsigned x) { return (float)(x >> 8) * 0x1p-24f + 0x1p-25f; }   // (0, 1)
+
+__global__ __launch_bounds__(256) void sample_rows_kernel(const float4* __restrict__ src, int ld4, long n_rows,
+                                                          long src_rows, float4* __restrict__ dst,
+                                                          float* __restrict__ eps, long n_eps,
+                                                          unsigned long long seed, unsigned long long draw) {
+    const long t = (long)blockIdx.x * 256 + threadIdx.x;
+    const uint2 key = make_uint2((unsigned)seed, (unsigned)(seed >> 32));
+    if (t < n_rows * ld4) {
+        const long r = t / ld4;
+        const int c = (int)(t - r * ld4);
+        const uint4 x = philox4x32_10(make_uint4((unsigned)draw, (unsigned)(draw >> 32), (unsigned)r, 0u), key);
+        const long j = (long)(((unsigned long long)x.x * (unsigned long long)src_rows) >> 32);
+        dst[r * ld4 + c] = src[j * ld4 + c];
+    }
+    const long q = (n_eps + 3) >> 2;
+    if (eps && t < q) {
+        const uint4 x = philox4x32_10(make_uint4((unsigned)draw, (unsigned)(draw >> 32), (unsigned)t, 1u), key);
+        const float r0 = sqrtf(-2.f * logf(u01(x.x))), r1 = sqrtf(-2.f * logf(u01(x.z)));
+        float s0, c0, s1, c1;
+        sincosf(6.283185307179586f * u01(x.y), &s0, &c0);
+        sincosf(6.283185307179586f * u01(x.w), &s1, &c1);
+        const float v[4] = {r0 * c0, r0 * s0, r1 * c1, r1 * s1};
+        for (int k = 0; k < 4; ++k)
+            if (4 * t + k < n_eps) eps[4 * t + k] = v[k];
+    }
+}
+
+extern "C" int nlbac_sample_rows(const float* src, long src_rows, int ld, long n_rows, float* dst, float* eps,
+                                 long n_eps, unsigned long long seed, unsigned long long draw, nlbac_stream_t s) {
+    NLBAC_REQUIRE(src && dst && src_rows >= 1 && src_rows < (1L << 32) && n_rows >= 1 && n_eps >= 0,
+                  "nlbac_sample_rows: bad arguments");
+    NLBAC_REQUIRE(ld >= 4 && ld % 4 == 0 && ((uintptr_t)src % 16) == 0 && ((uintptr_t)dst % 16) == 0,
+                  "nlbac_sample_rows: rows must be whole float4s (ld %d)", ld);
+    NLBAC_REQUIRE(eps || n_eps == 0, "nlbac_sample_rows: n_eps without a buffer");
+    const long total = n_rows * (ld / 4), q = (n_eps + 3) / 4;
+    const long threads = total > q ? total : q;
+    hipLaunchKernelGGL(sample_rows_kernel, dim3((unsigned)((threads + 255) / 256)), dim3(256), 0, (hipStream_t)s,
+                       (const float4*)src, ld / 4, n_rows, src_rows, (float4*)dst, eps, n_eps, seed, draw);
+    NLBAC_CHECK_LAUNCH("nlbac_sample_rows");
+    return 0;
+}
+
 extern "C" int nlbac_gather_rows(const float* src, long src_rows, int ld, const long* idx, long n_rows, float* dst,
                                  nlbac_stream_t s) {
     NLBAC_REQUIRE(src && idx && dst && src_rows >= 1 && n_rows >= 1, "nlbac_gather_rows: bad arguments");

@@ -127,12 +127,17 @@ class AffineNodeSolver:
         for idx in range(steps):
             self._step_ws(n, 7, idx).bwd(self)
         self._step_ws(n, 1, "tmp")
+        self._ctl_io(P)
         if P > 1:
             for p in range(P):
                 if p not in self._children:
                     self._children[p] = type(self)(self.node, self.device)
                 k = self._children[p]
                 k.comm, k.fused, k.keep_acts = self.comm, self.fused, self.keep_acts
+                # the per-problem solvers run one after the other inside this solver's solve: they share its read-back
+                # stream and pinned blocks (a pinned allocation costs milliseconds)
+                self._ctl_io(1)
+                k._side, k._ev_ctl, k._ctl_pin = self._side, self._ev_ctl, self._ctl_pin
                 k.reserve(n // P, 1, method, steps)
 
     def _buf(self, name, *shape, dtype=torch.float32):
@@ -285,14 +290,7 @@ class AffineNodeSolver:
         whole critic phase there).  Not inside a hipGraph capture (the replay path reads with ``_ctl(P).cpu()``)."""
         if torch.cuda.is_current_stream_capturing():
             return
-        side = self.__dict__.get("_side")
-        if side is None:
-            side = self._side = torch.cuda.Stream(device=self.device)
-            self._ev_ctl = (torch.cuda.Event(), torch.cuda.Event())
-            self._ctl_pin = {}
-        pin = self._ctl_pin.get(P)
-        if pin is None:
-            pin = self._ctl_pin[P] = torch.zeros(P, _lib.DOPRI_CTL, dtype=torch.float64).pin_memory()
+        side, pin = self._ctl_io(P)
         ev_a, ev_b = self._ev_ctl
         ev_a.record()
         side.wait_event(ev_a)
@@ -300,6 +298,17 @@ class AffineNodeSolver:
             pin.copy_(self._ctl(P), non_blocking=True)
             ev_b.record()
         self.ctx["ctl_pending"] = P
+
+    def _ctl_io(self, P):
+        """(side stream, pinned block for P problems) of the control-block read-back, created on first use."""
+        if self.__dict__.get("_side") is None:
+            self._side = torch.cuda.Stream(device=self.device)
+            self._ev_ctl = (torch.cuda.Event(), torch.cuda.Event())
+            self._ctl_pin = {}
+        pin = self._ctl_pin.get(P)
+        if pin is None:
+            pin = self._ctl_pin[P] = torch.zeros(P, _lib.DOPRI_CTL, dtype=torch.float64).pin_memory()
+        return self._side, pin
 
     def _ctl_read(self, P):
         """Host copy of the control block of the last attempted step."""
@@ -471,6 +480,8 @@ class AffineNodeSolver:
                 self._children[p] = type(self)(self.node, self.device)
             k = self._children[p]
             k.comm, k.fused, k.keep_acts = self.comm, self.fused, self.keep_acts
+            self._ctl_io(1)
+            k._side, k._ev_ctl, k._ctl_pin = self._side, self._ev_ctl, self._ctl_pin
             rows = slice(p * rpp, (p + 1) * rpp)
             o = k.forward(ctx["y0"][rows], ctx["u"][rows], 1, rpp, "dopri5", ctx["t_end"], ctx["atol"], ctx["rtol"])
             out[rows].copy_(o)

@@ -65,7 +65,9 @@ class DeviceReplayMemory:
     workspace (one ``nlbac_gather_rows`` launch) — ``SAC_CBF_CLF.update_parameters`` takes that path, so an update
     moves ``8 * batch`` index bytes over PCIe instead of the whole minibatch.  Index draws use ``random.sample`` on
     the host exactly like the reference (``replay_memory.py:22``), so the same seed selects the same transitions;
-    ``device_rng=True`` draws them with the device generator instead (with replacement, no host involvement).
+    ``device_rng=True`` draws them on the device instead (with replacement, no host involvement): index draw, gather
+    and — when the caller hands in the agent's noise buffer (``eps_out``) — the update's N(0,1) policy noise are one
+    ``nlbac_sample_rows`` launch.
     """
 
     def __init__(self, capacity, seed, agent, chunk=4096, device_rng=False):
@@ -81,8 +83,8 @@ class DeviceReplayMemory:
         self._n_staged, self._stage_start = 0, 0
         self._len = 0
         self.position = 0
-        self._gen = torch.Generator(device=self.device)
-        self._gen.manual_seed(int(seed) & 0x7FFFFFFF)
+        self._seed = (int(seed) * 0x9E3779B97F4A7C15 + 0x632BE59BD9B4E019) & 0xFFFFFFFFFFFFFFFF   # Philox key
+        self._draws = 0                                                                           # Philox counter
 
     def push(self, *fields, t=None, next_t=None):
         """Positional fields in the order of the reference's ``push`` (10, or 11 with the barrier signal)."""
@@ -123,24 +125,26 @@ class DeviceReplayMemory:
                                                                                  non_blocking=False)
             self._n_staged = 0
 
-    def _indices(self, batch_size):
-        import torch
-        if self.device_rng:
-            return torch.randint(0, self._len, (batch_size,), device=self.device, generator=self._gen)
-        idx = torch.tensor(random.sample(range(self._len), batch_size), dtype=torch.int64)
-        return idx.to(self.device)
-
-    def sample_rows(self, batch_size, out=None):
-        """Minibatch-layout rows (batch_size, LD) on the device."""
+    def sample_rows(self, batch_size, out=None, eps_out=None):
+        """Minibatch-layout rows (batch_size, LD) on the device.  ``eps_out``: a contiguous fp32 device buffer to fill
+        with N(0,1) draws alongside (``SAC_CBF_CLF.update_on_device(..., eps_ready=True)`` then skips its own draw)."""
         import torch
         from .. import _lib
         from ..arena import stream_ptr
         self.flush()
-        idx = self._indices(batch_size)
         if out is None:
             out = torch.empty(batch_size, self.lay.LD, dtype=torch.float32, device=self.device)
+        if self.device_rng:
+            self._draws += 1
+            _lib.call("nlbac_sample_rows", self.rows.data_ptr(), self._len, self.lay.LD, batch_size, out.data_ptr(),
+                      eps_out.data_ptr() if eps_out is not None else None,
+                      eps_out.numel() if eps_out is not None else 0, self._seed, self._draws, stream_ptr())
+            return out
+        idx = torch.tensor(random.sample(range(self._len), batch_size), dtype=torch.int64).to(self.device)
         _lib.call("nlbac_gather_rows", self.rows.data_ptr(), self._len, self.lay.LD, idx.data_ptr(), batch_size,
                   out.data_ptr(), stream_ptr())
+        if eps_out is not None:
+            eps_out.normal_()
         return out
 
     def sample(self, batch_size):

@@ -306,7 +306,16 @@ class SAC_CBF_CLF(object):
         self._noise = [torch.as_tensor(e, dtype=torch.float32) for e in eps_list]
 
     def _scalars(self):
-        return self.sc.cpu().numpy()
+        """Host copy of the device scalars (one 512-byte read through a pinned buffer; waits for the launch stream)."""
+        pin = self.__dict__.get("_sc_pin")
+        if pin is None:
+            pin = self._sc_pin = [torch.zeros(SC.SC_SIZE, dtype=torch.float32).pin_memory() for _ in range(3)]
+            self._sc_ev = [torch.cuda.Event() for _ in range(3)]
+            self._sc_lag = None
+        pin[0].copy_(self.sc, non_blocking=True)
+        self._sc_ev[0].record()
+        self._sc_ev[0].synchronize()
+        return pin[0].numpy().copy()
 
     @property
     def alpha(self):
@@ -371,11 +380,12 @@ class SAC_CBF_CLF(object):
         nb = min(NODE_memory.position, 32768) if fit else 0
         if hasattr(memory, "sample_rows"):           # replay resident in HBM: gather on the device
             ws = self._workspace(batch_size)
-            memory.sample_rows(batch_size, out=ws.mb)
+            eps_ready = self._noise is None and getattr(memory, "device_rng", False)
+            memory.sample_rows(batch_size, out=ws.mb, **({"eps_out": ws.eps} if eps_ready else {}))
             if fit:                                  # same draw order as the reference: minibatch, then NODE rows
                 self.fit_node_rows(NODE_memory.sample_rows(nb) if hasattr(NODE_memory, "sample_rows") else
                                    self._rows_from_host(NODE_memory.sample(batch_size=nb)).to(self.device))
-            return self.update_on_device(ws, updates)
+            return self.update_on_device(ws, updates, eps_ready=eps_ready)
         batch = memory.sample(batch_size=batch_size)
         node_rows = NODE_memory.sample(batch_size=nb) if fit else None
         return self.update_from_host(batch, updates, node_rows)
@@ -605,15 +615,16 @@ class SAC_CBF_CLF(object):
              self.task.ratio_mode, self.task.backup_mode if NP == 2 else 0, 0.01, self.task.lam_hi,
              self.sc.data_ptr(), s)
 
-    def update_on_device(self, ws, updates, sync=True):
-        """Minibatch already in ``ws.mb``; returns the reference's 6 floats."""
+    def update_on_device(self, ws, updates, sync=True, eps_ready=False):
+        """Minibatch already in ``ws.mb``; returns the reference's 6 floats.  ``eps_ready``: ``ws.eps`` already holds
+        this update's N(0,1) draws (``DeviceReplayMemory.sample_rows(..., eps_out=ws.eps)``)."""
         if self._noise is not None:
             assert len(self._noise) == self.task.n_eps, "set_noise needs %d draws" % self.task.n_eps
             order = self.task.eps_order or range(self.task.n_eps)     # device slot -> reference draw index
             for i, j in enumerate(order):
                 ws.eps[i].copy_(self._noise[j].to(self.device).reshape(ws.eps[i].shape))
             self._noise = None
-        else:
+        elif not eps_ready:
             ws.eps.normal_()
         soft = (updates % self.target_update_interval == 0)
         lam_upd = 1 if updates % self.Lagrangian_multiplier_update_interval == 0 else 0
@@ -639,9 +650,26 @@ class SAC_CBF_CLF(object):
         return self._returns(sync)
 
     def _returns(self, sync):
+        """The reference's 6 floats.  ``sync``: True — of this update (the host waits for it, as the reference's
+        ``.item()`` calls do); "lagged" — of the previous ``"lagged"`` call (None on the first), while this update's
+        are on their way to pinned memory: the launch stream never drains, for drivers that only log the values;
+        False — nothing."""
         if not sync:
             return None
-        h = self._scalars()
+        if sync == "lagged":
+            if self.__dict__.get("_sc_pin") is None:
+                self._scalars()
+            k = 1 + (self.__dict__.get("_sc_flip", 0) & 1)
+            self._sc_flip = k
+            prev, self._sc_lag = self._sc_lag, k
+            self._sc_pin[k].copy_(self.sc, non_blocking=True)
+            self._sc_ev[k].record()
+            if prev is None:
+                return None
+            self._sc_ev[prev].synchronize()
+            h = self._sc_pin[prev].numpy().copy()
+        else:
+            h = self._scalars()
         alpha_loss = float(h[SC.SC_ALOSS]) if self.automatic_entropy_tuning else 0.0
         return (float(h[SC.SC_QF1]), float(h[SC.SC_QF2]), float(h[SC.SC_LF]), float(h[SC.SC_PL1]),
                 alpha_loss, float(h[SC.SC_ALPHA]))

@@ -100,3 +100,60 @@ def test_checkpoint_resume_is_bit_identical(tmp_path):
     a3, _ = make_agent(B, 64, 3, "rk4")
     a3.load_checkpoint(str(tmp_path / "full.pt"))
     np.testing.assert_array_equal(a2.select_action(obs, evaluate=True), a3.select_action(obs, evaluate=True))
+
+
+def test_device_drawn_minibatch_and_noise():
+    """``device_rng`` mode: one launch draws the row indices (uniform, with replacement), gathers the rows and fills the
+    update's N(0,1) noise.  Checked: every output row is a whole source row with an index in range, the draw is a
+    deterministic function of (seed, draw number), indices and noise have the right first moments."""
+    from nlbac_amd.sac_cbf_clf.replay_memory import DeviceReplayMemory
+    agent, env = make_agent(8, 64, 0, "euler")
+    LD, n_src, B = agent.lay.LD, 3000, 4096
+    src = torch.randn(n_src, LD)
+    src[:, 0] = torch.arange(n_src, dtype=torch.float32)          # column 0 = the row's own index
+    outs = []
+    for seed in (5, 5, 6):
+        mem = DeviceReplayMemory(n_src + 10, seed, agent, device_rng=True)      # (capacity > rows held: len matters)
+        mem.push_rows(src)
+        eps = torch.full((3, B, 2), float("nan"), device="cuda")
+        a = mem.sample_rows(B, eps_out=eps).cpu()
+        b = mem.sample_rows(B).cpu()
+        outs.append((a, b, eps.cpu()))
+        idx = a[:, 0].long()
+        assert int(idx.min()) >= 0 and int(idx.max()) < n_src
+        assert torch.equal(a, src[idx])                           # whole rows, bit-exact
+        assert not torch.equal(a[:, 0], b[:, 0])                  # the next draw differs
+    (a0, b0, e0), (a1, b1, e1), (a2, b2, e2) = outs
+    assert torch.equal(a0, a1) and torch.equal(b0, b1) and torch.equal(e0, e1)      # same seed: same stream
+    assert not torch.equal(a0[:, 0], a2[:, 0]) and not torch.equal(e0, e2)          # another seed: another stream
+    # first moments: indices uniform on [0, n_src) (mean n/2, sd n/sqrt(12), 4096 draws), noise standard normal
+    idx = a0[:, 0].double()
+    assert abs(float(idx.mean()) - (n_src - 1) / 2) < 5 * n_src / np.sqrt(12 * B)
+    assert len(torch.unique(idx)) > 0.6 * min(n_src, B)
+    e = e0.double().flatten()
+    assert torch.isfinite(e).all() and len(torch.unique(e)) > 0.999 * e.numel()
+    assert abs(float(e.mean())) < 5 / np.sqrt(e.numel()) and abs(float(e.std()) - 1) < 0.03
+    assert abs(float((e ** 3).mean())) < 0.1 and abs(float((e ** 4).mean()) - 3) < 0.25
+
+
+def test_lagged_loss_readback_returns_the_previous_update():
+    """``update_on_device(..., sync="lagged")`` hands back the 6 floats of the previous call (None first) and leaves
+    the updates themselves untouched."""
+    from nlbac_amd.sac_cbf_clf.replay_memory import DeviceReplayMemory
+    B = 64
+    got = []
+    for mode in (True, "lagged"):
+        agent, env = make_agent(B, 64, 0, "dopri5")
+        mem = DeviceReplayMemory(512, 3, agent, device_rng=True)
+        mem.push_rows(agent._rows_from_host(tuple(synth.transitions("Unicycle", 512, seed=9)[f] for f in synth.FIELDS)))
+        ws = agent._workspace(B)
+        rets = []
+        for i in range(4):
+            mem.sample_rows(B, out=ws.mb, eps_out=ws.eps)
+            rets.append(agent.update_on_device(ws, i, sync=mode, eps_ready=True))
+        torch.cuda.synchronize()
+        got.append((rets, agent.ar_c.theta.clone(), agent.ar_a.theta.clone()))
+    (r_sync, c0, a0), (r_lag, c1, a1) = got
+    assert r_lag[0] is None
+    assert r_lag[1:] == r_sync[:3]
+    assert torch.equal(c0, c1) and torch.equal(a0, a1)

@@ -1,6 +1,6 @@
 #!/bin/bash
 # Run on the GPU box via:  gpurun -- 'bash tools/gpu_tests.sh [pytest args]'
-set -e
+set -eo pipefail
 cd "${GRAFT_REPO_ROOT:-.}"
 mkdir -p gpurun_out
 timeout -k 10 900 python -m pytest tests -x -q -m gpu "$@" 2>&1 | tee gpurun_out/pytest_gpu.log | tail -40

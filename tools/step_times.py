@@ -19,14 +19,14 @@ fit_rows = torch.empty(32768, agent.lay.LD, device=agent.device)
 st = agent.node_solver.stats
 kinds = {}
 for i in range(260):
-    replay.sample_rows(B, out=ws.mb)
+    replay.sample_rows(B, out=ws.mb, eps_out=ws.eps)
     fit = i % 10 == 0
     before = dict(st)
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     if fit:
         agent.fit_node_rows(replay.sample_rows(32768, out=fit_rows))
-    agent.update_on_device(ws, i)
+    agent.update_on_device(ws, i, eps_ready=True)
     torch.cuda.synchronize()
     dt = (time.perf_counter() - t0) * 1e3
     kind = ("fit+" if fit else "") + ("split" if st["split"] > before["split"] else "multi" if st["multi_attempt"] > before["multi_attempt"] else "single")
