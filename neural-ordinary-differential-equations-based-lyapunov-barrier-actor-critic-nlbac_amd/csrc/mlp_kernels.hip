@@ -82,8 +82,10 @@ __global__ __launch_bounds__(256) void mlp_pack_kernel(const MlpLaunch L) {
 // MODE 0: mixed / other widths (both register sets live).
 // MODE 3: every net has 8 column tiles and the workgroup has 8 waves, one tile each (same code path as MODE 1):
 // half the per-tile latency of MODE 2 and twice the waves per CU.
-template <int MODE>
-__global__ __launch_bounds__(MODE == 3 ? 512 : 256, 2) void mlp_fwd_kernel(const MlpLaunch L) {
+// OCC (MODE 3): cap the kernel at 128 VGPRs so that two workgroups share a CU (a few spills): pays once the grid has
+// more tiles than CUs (6 nets x 128 tiles: 45 -> 43 us), costs ~1 us on the one- and two-net launches.
+template <int MODE, int OCC = 0>
+__global__ __launch_bounds__(MODE == 3 ? 512 : 256, OCC ? 4 : 2) void mlp_fwd_kernel(const MlpLaunch L) {
     constexpr int NTHR = (MODE == 3) ? 512 : 256;
     constexpr bool ONE = (MODE == 1 || MODE == 3);      // one column tile per wave
     extern __shared__ __attribute__((aligned(16))) float smem[];
@@ -550,8 +552,11 @@ __device__ __forceinline__ void skinny_rows(const float* __restrict__ aL, const 
     }
 }
 
-__global__ __launch_bounds__(256) void mlp_bwd_skinny_partial_kernel(const MlpLaunch L, const SkinnyLaunch S,
-                                                                     float* __restrict__ ws) {
+// NTHR: threads per block = columns covered; nets of <= 128 hidden units run 128-thread blocks (with 256, half the
+// waves of every block would hold no column and still take the wave slots the kernel's register budget allows)
+template <int NTHR>
+__global__ __launch_bounds__(NTHR) void mlp_bwd_skinny_partial_kernel(const MlpLaunch L, const SkinnyLaunch S,
+                                                                      float* __restrict__ ws) {
     // x / dy rows of the current 128-row block, zero-padded to fixed widths so the
     // inner loop has no data-dependent branches (every load is unconditional and
     // can be issued ahead; a guarded load would serialise on s_waitcnt per element)
@@ -582,14 +587,14 @@ __global__ __launch_bounds__(256) void mlp_bwd_skinny_partial_kernel(const MlpLa
     for (int r0 = rb; r0 < re; r0 += SK_ROWS_LDS) {
         const int nr = min(SK_ROWS_LDS, re - r0);
         __syncthreads();
-        for (int idx = col; idx < nr * SK_MAX_IN; idx += 256) {
+        for (int idx = col; idx < nr * SK_MAX_IN; idx += NTHR) {
             const int r = idx / SK_MAX_IN, i = idx - r * SK_MAX_IN;
             float v = 0.f;
             if (i < idim)
                 v = (i < x0d) ? io.x0[(long)(r0 + r) * io.x0_ld + i] : io.x1[(long)(r0 + r) * io.x1_ld + (i - x0d)];
             sx[r][i] = v;
         }
-        for (int idx = col; idx < nr * SK_MAX_OUT; idx += 256) {
+        for (int idx = col; idx < nr * SK_MAX_OUT; idx += NTHR) {
             const int r = idx / SK_MAX_OUT, o = idx - r * SK_MAX_OUT;
             sdy[r][o] = (o < odim) ? io.dy[(long)(r0 + r) * io.dy_ld + o] : 0.f;
         }
@@ -735,7 +740,9 @@ extern "C" int nlbac_mlp_fwd(const nlbac_mlp* nets, const nlbac_mlp_io* io, int 
     switch (tile_mode(nets, n_nets)) {
         case 1: hipLaunchKernelGGL(mlp_fwd_kernel<1>, grid, dim3(256), lds, (hipStream_t)s, L); break;
         case 2:
-            if (waves8()) hipLaunchKernelGGL(mlp_fwd_kernel<3>, grid, dim3(512), lds, (hipStream_t)s, L);
+            if (waves8() && (long)grid.x * grid.y > 256 && lds <= 80 * 1024)
+                hipLaunchKernelGGL((mlp_fwd_kernel<3, 1>), grid, dim3(512), lds, (hipStream_t)s, L);
+            else if (waves8()) hipLaunchKernelGGL(mlp_fwd_kernel<3>, grid, dim3(512), lds, (hipStream_t)s, L);
             else hipLaunchKernelGGL(mlp_fwd_kernel<2>, grid, dim3(256), lds, (hipStream_t)s, L);
             break;
         default: hipLaunchKernelGGL(mlp_fwd_kernel<0>, grid, dim3(256), lds, (hipStream_t)s, L);
@@ -819,7 +826,12 @@ extern "C" int nlbac_mlp_bwd_weights(const nlbac_mlp* nets, const nlbac_mlp_io* 
     S.rows_per_chunk = skinny_rows_per_chunk(B);
     S.n_chunks = (B + S.rows_per_chunk - 1) / S.rows_per_chunk;
     S.net_stride = need / n_nets;
-    hipLaunchKernelGGL(mlp_bwd_skinny_partial_kernel, dim3(S.n_chunks, n_nets), dim3(256), 0, (hipStream_t)s, L, S, ws);
+    bool all_narrow = true;
+    for (int i = 0; i < n_nets; ++i) all_narrow = all_narrow && nets[i].hid <= 128;
+    if (all_narrow)
+        hipLaunchKernelGGL(mlp_bwd_skinny_partial_kernel<128>, dim3(S.n_chunks, n_nets), dim3(128), 0, (hipStream_t)s, L, S, ws);
+    else
+        hipLaunchKernelGGL(mlp_bwd_skinny_partial_kernel<256>, dim3(S.n_chunks, n_nets), dim3(256), 0, (hipStream_t)s, L, S, ws);
     NLBAC_CHECK_LAUNCH("nlbac_mlp_bwd_weights(skinny partial)");
     hipLaunchKernelGGL(mlp_bwd_skinny_reduce_kernel, dim3(max_q * 4, n_nets), dim3(256), 0, (hipStream_t)s, L, S, ws);
     NLBAC_CHECK_LAUNCH("nlbac_mlp_bwd_weights(skinny reduce)");

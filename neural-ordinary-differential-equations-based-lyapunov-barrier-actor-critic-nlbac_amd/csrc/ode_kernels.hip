@@ -144,23 +144,10 @@ __global__ __launch_bounds__(256) void dopri_norm_kernel(const float* a, const f
     dopri_norm_block(a, b, y0, y1, u, mode, rtol, atol, n_s, n_u, rpp, partials);
 }
 
-// the controller of problem p on the finished block sums (fixed summation order: deterministic); COHERENT: the sums
-// were written by other workgroups of the same launch (read them past the non-coherent caches)
-template <bool COHERENT>
-__device__ __forceinline__ void dopri_control_one(const float* partials, int p, int nblk, int mode, int n_s, int n_u,
+// the controller of problem p on its finished squared-norm sums
+__device__ __forceinline__ void dopri_control_one(double s0, double s1, int p, int mode, int n_s, int n_u,
                                                   int rpp, double t_end, double* ctl) {
     double* c = ctl + (long)p * NLBAC_DOPRI_CTL;
-    double s0 = 0.0, s1 = 0.0;
-    for (int b = 0; b < nblk; ++b) {
-        const float* q = partials + ((long)p * nblk + b) * 2;
-        if constexpr (COHERENT) {
-            s0 += (double)__hip_atomic_load(q + 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            s1 += (double)__hip_atomic_load(q + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        } else {
-            s0 += (double)q[0];
-            s1 += (double)q[1];
-        }
-    }
     const double cnt = (double)rpp * (double)(n_s + n_u);
     if (mode == 0) {
         const double d0 = sqrt(s0 / cnt), d1 = sqrt(s1 / cnt);
@@ -200,7 +187,13 @@ __device__ __forceinline__ void dopri_control_one(const float* partials, int p, 
 __global__ void dopri_control_kernel(const float* partials, int nblk, int mode, int n_s, int n_u, int rpp,
                                      double t_end, double* ctl) {
     if (threadIdx.x != 0) return;
-    dopri_control_one<false>(partials, blockIdx.x, nblk, mode, n_s, n_u, rpp, t_end, ctl);
+    const int p = blockIdx.x;
+    double s0 = 0.0, s1 = 0.0;
+    for (int b = 0; b < nblk; ++b) {
+        s0 += (double)partials[((long)p * nblk + b) * 2 + 0];
+        s1 += (double)partials[((long)p * nblk + b) * 2 + 1];
+    }
+    dopri_control_one(s0, s1, p, mode, n_s, n_u, rpp, t_end, ctl);
 }
 
 // norm + controller in one launch: the workgroup that finishes a problem's sums last (a ticket counter per problem,
@@ -210,14 +203,37 @@ __global__ __launch_bounds__(256) void dopri_norm_control_kernel(const float* a,
                                                                  float atol, int n_s, int n_u, int rpp, double t_end,
                                                                  float* partials, unsigned* tickets, double* ctl) {
     dopri_norm_block(a, b, y0, y1, u, mode, rtol, atol, n_s, n_u, rpp, partials);
-    if (threadIdx.x != 0) return;
-    const int p = blockIdx.y;
-    __threadfence();                                   // this block's sums are visible device-wide before its ticket
-    const unsigned ticket = __hip_atomic_fetch_add(tickets + p, 1u, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT);
-    if (ticket != gridDim.x - 1) return;
-    __hip_atomic_store(tickets + p, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    __shared__ unsigned s_last;
+    __shared__ double s_red[2][256];
+    const int p = blockIdx.y, nblk = (int)gridDim.x;
+    if (threadIdx.x == 0) {
+        __threadfence();                               // this block's sums are visible device-wide before its ticket
+        const unsigned ticket = __hip_atomic_fetch_add(tickets + p, 1u, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT);
+        s_last = (ticket == gridDim.x - 1) ? 1u : 0u;
+        if (s_last) __hip_atomic_store(tickets + p, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+    __syncthreads();
+    if (!s_last) return;                               // (uniform per block)
     __threadfence();
-    dopri_control_one<true>(partials, p, (int)gridDim.x, mode, n_s, n_u, rpp, t_end, ctl);
+    // the sums were written by other workgroups of this launch: read them past the non-coherent caches; fixed
+    // assignment of blocks to lanes and a fixed tree, so the result does not depend on which block came last
+    double v0 = 0.0, v1 = 0.0;
+    for (int b = threadIdx.x; b < nblk; b += 256) {
+        const float* q = partials + ((long)p * nblk + b) * 2;
+        v0 += (double)__hip_atomic_load(q + 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        v1 += (double)__hip_atomic_load(q + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+    s_red[0][threadIdx.x] = v0;
+    s_red[1][threadIdx.x] = v1;
+    __syncthreads();
+    for (int w = 128; w >= 1; w >>= 1) {
+        if ((int)threadIdx.x < w) {
+            s_red[0][threadIdx.x] += s_red[0][threadIdx.x + w];
+            s_red[1][threadIdx.x] += s_red[1][threadIdx.x + w];
+        }
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) dopri_control_one(s_red[0][0], s_red[1][0], p, mode, n_s, n_u, rpp, t_end, ctl);
 }
 
 #define DPM0 (6025192743.0 / 30085553152.0 / 2.0)

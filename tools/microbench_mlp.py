@@ -16,6 +16,7 @@ P = agent._plan(ws, 2)
 s = stream_ptr()
 cases = {
     "fwd 1 net  pi(s')": lambda: _lib.call("nlbac_mlp_fwd", P.n_pol, P.io_pol_next, 1, B, s),
+    "fwd 3 nets pi(s'),pi(s)x2": lambda: _lib.call("nlbac_mlp_fwd", P.n_pol3, P.io_pol3, 3, B, s),
     "fwd 6 nets critics": lambda: _lib.call("nlbac_mlp_fwd", P.n_six, P.io_six, 6, B, s),
     "fwd 2 nets actors": lambda: _lib.call("nlbac_mlp_fwd", P.n_act, P.io_act, 2, B, s),
     "fwd 5 nets Q(s,pi)": lambda: _lib.call("nlbac_mlp_fwd", P.n_q5, P.io_q5, 5, B, s),
