@@ -39,6 +39,8 @@ TABLEAU = {
     "euler": dict(beta=[], c_sol=[1.0]),
     "rk4": dict(beta=[[1 / 3], [-1 / 3, 1.0], [1.0, -1.0, 1.0]], c_sol=[1 / 8, 3 / 8, 3 / 8, 1 / 8]),
     "dopri5": dict(beta=DP_BETA, c_sol=None),
+    # the initial-step probe of dopri5: f(y0 + h0 f0) as "stage 1" of a two-stage table (f0 = stage 0 is in place)
+    "probe": dict(beta=[[1.0]], c_sol=None),
 }
 
 
@@ -126,7 +128,6 @@ class AffineNodeSolver:
             return
         for idx in range(steps):
             self._step_ws(n, 7, idx).bwd(self)
-        self._step_ws(n, 1, "tmp")
         self._ctl_io(P)
         if P > 1:
             for p in range(P):
@@ -393,15 +394,16 @@ class AffineNodeSolver:
             ws.Y[0].copy_(y0)
             self._stage_eval(ws, 0, u)
         self._norm_control(ws.K[0], None, y0, None, u, 0, P, rpp)
-        ytmp, ktmp, gtmp = self._buf("ytmp", n, ns), self._buf("ktmp", n, ns), self._buf("gtmp", n, ns * nu)
         h0_dev = ctl.data_ptr() + 6 * 8           # C_H0
-        _lib.call("nlbac_rk_combine", y0.data_ptr(), ws.K.data_ptr(), 1, self._coef("one"), None, h0_dev,
-                  _lib.DOPRI_CTL, P, rpp, ns, ytmp.data_ptr(), s)
         if self.fused:
-            tws = self._step_ws(n, 1, "tmp")
-            self._rk_fused(tws, ytmp, u, P, rpp, "euler", 0, 1, h_host=[0.0] * P, save_acts=False)
-            ktmp = tws.K[0]
+            # probe f(y0 + h0 f0): the fused kernel forms the stage input itself (same arithmetic as nlbac_rk_combine);
+            # K[1] / Y[1] / gout[1] of the step workspace are scratch until the real stage 1 overwrites them
+            self._rk_fused(ws, y0, u, P, rpp, "probe", 1, 2, h_dev=h0_dev, save_acts=False)
+            ktmp = ws.K[1]
         else:
+            ytmp, ktmp, gtmp = self._buf("ytmp", n, ns), self._buf("ktmp", n, ns), self._buf("gtmp", n, ns * nu)
+            _lib.call("nlbac_rk_combine", y0.data_ptr(), ws.K.data_ptr(), 1, self._coef("one"), None, h0_dev,
+                      _lib.DOPRI_CTL, P, rpp, ns, ytmp.data_ptr(), s)
             self._probe_eval(ytmp, u, n, ktmp, gtmp)
         self._norm_control(ktmp, ws.K[0], y0, None, None, 1, P, rpp)
         self._dopri_attempt(ws, y0, u, P, rpp)
