@@ -683,6 +683,12 @@ static bool waves8() {
     return on;
 }
 
+// two-workgroups-per-CU forward variant: -1 = by grid size (default), 0 / 1 = forced (NLBAC_MLP_OCC, for A/B runs)
+static int occ_mode() {
+    static const int m = [] { const char* e = getenv("NLBAC_MLP_OCC"); return e ? (e[0] == '1' ? 1 : (e[0] == '0' ? 0 : -1)) : -1; }();
+    return m;
+}
+
 static int fill_launch(MlpLaunch& L, const nlbac_mlp* nets, const nlbac_mlp_io* io, int n_nets, int B, const char* who) {
     NLBAC_REQUIRE(n_nets >= 1 && n_nets <= NLBAC_MAX_NETS, "%s: n_nets %d out of [1,%d]", who, n_nets, NLBAC_MAX_NETS);
     NLBAC_REQUIRE(B >= 1, "%s: B must be >= 1", who);
@@ -740,7 +746,8 @@ extern "C" int nlbac_mlp_fwd(const nlbac_mlp* nets, const nlbac_mlp_io* io, int 
     switch (tile_mode(nets, n_nets)) {
         case 1: hipLaunchKernelGGL(mlp_fwd_kernel<1>, grid, dim3(256), lds, (hipStream_t)s, L); break;
         case 2:
-            if (waves8() && (long)grid.x * grid.y > 256 && lds <= 80 * 1024)
+            if (waves8() && lds <= 80 * 1024 &&
+                (occ_mode() == 1 || (occ_mode() < 0 && (long)grid.x * grid.y > 256)))
                 hipLaunchKernelGGL((mlp_fwd_kernel<3, 1>), grid, dim3(512), lds, (hipStream_t)s, L);
             else if (waves8()) hipLaunchKernelGGL(mlp_fwd_kernel<3>, grid, dim3(512), lds, (hipStream_t)s, L);
             else hipLaunchKernelGGL(mlp_fwd_kernel<2>, grid, dim3(256), lds, (hipStream_t)s, L);
