@@ -759,3 +759,87 @@ class ConcatNodeSolver(AffineNodeSolver):
             bwd_weights(self._nets(), io, 1, rows, slabs_per_step, arena.n, self.device)
             n_used += slabs_per_step
         return n_used
+
+
+# ---------------------------------------------------------------------------
+# torchdiffeq-shaped entry (SURVEY.md §8b "Solver entry"): the call the reference makes at
+# U/sac_cbf_clf/sac_cbf_clf.py:453,577 and U/sac_cbf_clf/model.py:252 —
+#     odeint(model, cat(state, action), tensor([0, dt]), method=..., atol=1e-7, rtol=1e-5)[-1][:, :n_s]
+# — on the device kernels, differentiable w.r.t. y0 and the model's parameters through torch.autograd.
+# The agent itself drives the solvers directly (no autograd graph); this entry is for reference-shaped code.
+# ---------------------------------------------------------------------------
+def _solver_of(func):
+    """The (cached) solver of a ``NeuralODEModel`` of this build; a model that is not part of an agent gets its own
+    parameter arena on the current device."""
+    from .sac_cbf_clf.model import NeuralODEModel
+    if not isinstance(func, NeuralODEModel):
+        raise TypeError("nlbac_amd.odeint integrates this build's NeuralODEModel (its field runs as HIP kernels); "
+                        "got %s" % type(func).__name__)
+    sv = func.__dict__.get("_odeint_solver")
+    if sv is None:
+        handles = func.device_handles()
+        sv = (AffineNodeSolver if func.affine else ConcatNodeSolver)(func, handles[0].arena.device)
+        sv.keep_acts = True                  # parameter gradients need the pre-activation gradients of every stage
+        func.__dict__["_odeint_solver"] = sv
+    return sv
+
+
+class _OdeintFunction(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, func, method, dt, atol, rtol, y0, *params):
+        sv = _solver_of(func)
+        ns, nu = sv.n_s, sv.n_u
+        assert y0.dim() == 2 and y0.shape[1] == ns + nu, "y0 must be (batch, %d)" % (ns + nu)
+        y0 = y0.detach().float().contiguous()
+        x0, u = y0[:, :ns].contiguous(), y0[:, ns:].contiguous()
+        x1 = sv.forward(x0, u, 1, y0.shape[0], method, dt, atol, rtol)
+        ctx.func, ctx.sv, ctx.n_params = func, sv, len(params)
+        ctx.solve_id = sv.stats["solves"]
+        return torch.stack([y0, torch.cat([x1, u], dim=1)])
+
+    @staticmethod
+    def backward(ctx, g):
+        sv, func = ctx.sv, ctx.func
+        assert sv.stats["solves"] == ctx.solve_id, \
+            "odeint: backward must run before the next solve with the same model (the solver keeps one solve's state)"
+        ns = sv.n_s
+        g = g.float()
+        need_p = any(ctx.needs_input_grad[6:])
+        du, dy0 = sv.backward(g[1][:, :ns].contiguous(), need_du=True, need_params=need_p, need_dy0=True)
+        gy0 = g[0] + torch.cat([dy0, du + g[1][:, ns:]], dim=1) if ctx.needs_input_grad[5] else None
+        gp = [None] * ctx.n_params
+        if need_p:
+            arena = func.device_handles()[0].arena
+            n_steps = max(1, len(sv.ctx.get("steps") or [None]))
+            used = sv.accumulate_param_grads(arena, max(1, arena.n_slabs // n_steps))
+            flat = torch.empty(arena.n, dtype=torch.float32, device=arena.device)
+            _lib.call("nlbac_reduce_slabs", flat.data_ptr(), arena.grad.data_ptr(), used, arena.n, arena.n, stream_ptr())
+            gp = []
+            for p in func.parameters():
+                off = arena.offset_of[id(p)]
+                gp.append(flat[off:off + p.numel()].view(p.shape))
+        return (None, None, None, None, None, gy0, *gp)
+
+
+def odeint(func, y0, t, *, method="dopri5", atol=1e-7, rtol=1e-5, **options):
+    """``torchdiffeq.odeint`` for this build's NODE models on ``t = [t0, t1]``: returns ``stack([y0, y(t1)])`` with the
+    carried control columns passed through, differentiable w.r.t. ``y0`` and ``func.parameters()``.  ``method`` is
+    ``'euler'`` / ``'rk4'`` (one step over the interval, torchdiffeq's fixed-grid semantics) or ``'dopri5'``.
+    The packed MFMA copies of the weights are refreshed first, so a ``torch.optim`` step on ``func.parameters()``
+    between calls is picked up."""
+    if options:
+        raise TypeError("odeint: unsupported options %s" % sorted(options))
+    from .sac_cbf_clf.model import NeuralODEModel
+    if not isinstance(func, NeuralODEModel):
+        raise TypeError("nlbac_amd.odeint integrates this build's NeuralODEModel (its field runs as HIP kernels); "
+                        "got %s" % type(func).__name__)
+    t = torch.as_tensor(t)
+    if t.numel() != 2:
+        raise NotImplementedError("odeint: the reference only ever integrates over t = [0, dt]; got %d time points"
+                                  % t.numel())
+    dt = float(t[1]) - float(t[0])
+    func.refresh_device_weights()
+    return _OdeintFunction.apply(func, method, dt, float(atol), float(rtol), y0, *func.parameters())
+
+
+odeint_adjoint = odeint        # same gradient by direct backpropagation through the steps (no reference call site)

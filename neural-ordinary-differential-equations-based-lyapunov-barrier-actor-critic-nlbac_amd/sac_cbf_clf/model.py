@@ -12,7 +12,7 @@ import torch
 import torch.nn as nn
 
 from .. import _lib
-from ..arena import MlpHandle, io_array, mlp_array, stream_ptr
+from ..arena import MlpHandle, io_array, mlp_array, pack, stream_ptr
 
 LOG_SIG_MAX = 2
 LOG_SIG_MIN = -20
@@ -156,6 +156,40 @@ class NeuralODEModel(nn.Module):
             self.n_s, self.n_carry = output_dim1, input_dim - output_dim1
             self.net = seq(input_dim, depth, output_dim1, hid)
 
+    def device_handles(self):
+        """The model's ``MlpHandle``s; a model built outside an agent attaches itself to an arena of its own here."""
+        hs = [self.f, self.g] if (self.affine and hasattr(self, "f")) else \
+            ([self.net_handle] if hasattr(self, "net_handle") else None)
+        if hs is None:
+            from ..arena import Arena
+            arena = Arena("cuda", n_slabs=16)
+            hs = self.attach(arena)
+            arena.finalize()
+        if hs[0].desc is None:
+            for h in hs:
+                h.bind()
+            pack(hs)
+        return hs
+
+    def refresh_device_weights(self):
+        """Re-pack the MFMA-fragment copies of the weights (after anything but this build's own optimiser kernel
+        has written the parameters, e.g. a ``torch.optim`` step or ``load_state_dict``)."""
+        pack(self.device_handles())
+
+    def forward(self, t, s):
+        """The reference's field evaluation (U/model.py:208-217, C/model.py:196-203): ``s = [x | carried inputs]``
+        -> ``[dx/dt | 0]``, on the device kernels.  Not recorded by autograd — gradients flow through
+        ``nlbac_amd.odeint.odeint``, which differentiates whole solves."""
+        from ..odeint import _solver_of
+        sv = _solver_of(self)
+        ns = sv.n_s
+        s = s.detach().float().contiguous()
+        n = s.shape[0]
+        x, c = s[:, :ns].contiguous(), s[:, ns:].contiguous()
+        k, g = torch.empty(n, ns, device=s.device), torch.empty(n, ns * max(1, sv.n_u), device=s.device)
+        sv._eval(x, c, n, k, g)               # (fresh launch descriptors: the inputs are the caller's tensors)
+        return torch.cat([k, torch.zeros_like(c)], dim=1)
+
     def attach(self, arena):
         if self.affine:
             self.f = MlpHandle(arena, [(m.weight, m.bias) for m in self.f_net if isinstance(m, nn.Linear)], "f_net")
@@ -163,3 +197,31 @@ class NeuralODEModel(nn.Module):
             return [self.f, self.g]
         self.net_handle = MlpHandle(arena, [(m.weight, m.bias) for m in self.net if isinstance(m, nn.Linear)], "net")
         return [self.net_handle]
+
+
+def train_step(model, state, action, next_state, *rest) -> float:
+    """The reference's NODE regression step, same positional signature (U/model.py:221-260; the SimulatedCars copy
+    passes ``time_batch`` before the optimizer, C/model.py:208-252):
+
+        train_step(model, state, action, next_state[, time_batch], optimizer, loss_func, horizon, solver, time_interval)
+
+    one solve over ``[0, time_interval]`` from ``[state | action (| time)]``, ``loss_func`` on the predicted state,
+    backward through the solve, ``optimizer.step()``; returns ``loss / horizon``.  (``SAC_CBF_CLF.update_parameters``
+    does not come through here: its NODE fit is the fused device path, ``fit_node_rows``.)"""
+    from ..odeint import odeint
+    if len(rest) == 6:
+        time_batch, optimizer, loss_func, horizon, solver, time_interval = rest
+    else:
+        (optimizer, loss_func, horizon, solver, time_interval), time_batch = rest, None
+    assert state.dim() == 2 and action.dim() == 2 and next_state.dim() == 2, (state.shape, action.shape, next_state.shape)
+    dev = model.device_handles()[0].arena.device
+    cols = [state, action] + ([time_batch] if time_batch is not None else [])
+    y0 = torch.cat([torch.as_tensor(c, dtype=torch.float32).to(dev) for c in cols], dim=-1)
+    model.train()
+    optimizer.zero_grad()
+    pred = odeint(model, y0, torch.tensor([0.0, float(time_interval)]), method=solver, atol=1e-7, rtol=1e-5)[-1]
+    loss = loss_func(pred[:, :state.shape[1]], torch.as_tensor(next_state, dtype=torch.float32).to(dev))
+    loss.backward()
+    optimizer.step()
+    model.refresh_device_weights()
+    return float(loss.item()) / horizon
