@@ -1,0 +1,51 @@
+"""GPU: the BASELINE.json configurations at their FULL sizes (batch, hidden width, solver): two updates — the first with
+a NODE fit on 32768 rows, the second on the λ-update branch's neighbour — must return the CPU oracle's six floats to
+1e-4, and a second agent fed the same inputs must land on bit-identical parameters (the update has no atomics and no
+order-dependent reductions).  The oracle needs ~0.1-3 s per update at these sizes on the box's host cores."""
+import numpy as np
+import pytest
+import torch
+
+from nlbac_amd import synth
+from test_agent_parity_gpu import make_agent
+
+pytestmark = pytest.mark.gpu
+GAMMA_B = {"Unicycle": 50.0, "Pvtol": 0.8, "SimulatedCars": 0.5, "UnicycleBarrier": 5.0}
+FIT_ROWS = 32768
+
+
+@pytest.mark.parametrize("env_name,B,solver", [("Unicycle", 4096, "dopri5"),          # configs[1], the headline
+                                               ("SimulatedCars", 8192, "rk4"),        # configs[2]
+                                               ("Pvtol", 16384, "dopri5"),            # configs[3]
+                                               ("UnicycleBarrier", 32768, "dopri5")])  # the agent pattern of configs[4]
+def test_baseline_configurations_at_full_size(env_name, B, solver):
+    from oracle import nlbac_oracle as O
+    H = 256
+    torch.set_num_threads(max(1, min(16, torch.get_num_threads())))
+    oargs = O.Args(batch_size=B, hidden_size=H, seed=0)
+    oargs.gamma_b = GAMMA_B[env_name]
+    oracle = O.make_oracle(synth.fixture_env(env_name, 0), oargs, synth.agent_weights(env_name, H, 0), solver=solver)
+    agents = [make_agent(B, H, 0, solver, env_name, GAMMA_B[env_name]) for _ in range(2)]
+    env = agents[0][1]
+    n_rows = max(B, FIT_ROWS)
+    tr = synth.transitions(env_name, n_rows, seed=3, env=env)
+    fields = synth.fields(env_name)
+    node_fields = ("obs", "action", "next_obs", "t") if env_name == "SimulatedCars" else ("obs", "action", "next_obs")
+    for u in (0, 1):
+        idx = np.random.RandomState(u).choice(n_rows, B, replace=False)
+        batch = {f: torch.tensor(tr[f][idx], dtype=torch.float32) for f in fields}
+        eps = [torch.from_numpy(e) for e in synth.normal_eps(agents[0][0].task.n_eps, B, env.n_u, seed=u)]
+        node = tuple(torch.tensor(tr[f][:FIT_ROWS], dtype=torch.float32) for f in node_fields) if u == 0 else None
+        R = oracle.update(batch, eps, u, node_batch=node)
+        rets = []
+        for agent, _ in agents:
+            agent.set_noise(eps)
+            rets.append(agent.update_from_host(tuple(batch[f].numpy() for f in fields), u,
+                                               tuple(x.numpy() for x in node) if node else None))
+        worst = max(abs(a - b) / (abs(b) + 1e-3) for a, b in zip(rets[0], R["ret"]))
+        assert worst < 1e-4, "%s B=%d update %d: max rel err vs oracle %.2e" % (env_name, B, u, worst)
+        assert rets[0] == rets[1], "two runs of the same update differ: %s vs %s" % (rets[0], rets[1])
+    torch.cuda.synchronize()
+    a, b = agents[0][0], agents[1][0]
+    for x, y in zip(a.arenas, b.arenas):
+        assert torch.equal(x.theta, y.theta), "parameters after two identical updates are not bit-identical"
