@@ -109,3 +109,45 @@ def test_odeint_rejects_foreign_modules_and_grids():
     m = NeuralODEModel(3, 3, 6)
     with pytest.raises(NotImplementedError):
         odeint(m, torch.zeros(4, 5).cuda(), torch.tensor([0.0, 0.1, 0.2]), method="euler")
+
+
+@pytest.mark.parametrize("hid", [64, 160, 232])
+@pytest.mark.parametrize("masks", [False, True], ids=["acts", "relu-bit-masks"])
+def test_other_node_widths_run_the_other_kernel_modes(hid, masks):
+    """The fused RK kernels pick a tiling mode by hidden width (<= 128: one column tile per wave; 225-256: two; anything
+    else: mixed).  The reference's NODE is 100 wide; 64 / 160 / 232 put the other instantiations — and their
+    per-group barriers — under the same oracle check, with activations kept (parameter gradients) and with bit masks
+    (gradient to the controls only)."""
+    from nlbac_amd.odeint import odeint, _solver_of
+    from nlbac_amd.sac_cbf_clf.model import NeuralODEModel
+    torch.manual_seed(hid)
+    m = NeuralODEModel(3, 3, 6, hidden_dim=hid)
+    sd = {k: v.detach().clone().requires_grad_() for k, v in m.state_dict().items()}
+    ref = O.AffineNode(sd)
+    g = torch.Generator().manual_seed(4)
+    B = 200
+    y0 = torch.cat([torch.rand(B, 3, generator=g) * 2 - 1, torch.rand(B, 2, generator=g) * 2 - 1], 1)
+    w = torch.randn(B, 3, generator=g)
+    t = torch.tensor([0.0, 0.05])
+    y0r = y0.clone().requires_grad_()
+    out_r = O.odeint(ref, y0r, t, method="dopri5")[-1][:, :3]
+    (out_r * w).sum().backward()
+    if not masks:
+        y0d = y0.cuda().requires_grad_()
+        out_d = odeint(m, y0d, t, method="dopri5")[-1][:, :3]
+        (out_d * w.cuda()).sum().backward()
+        close(out_d, out_r, "x(dt)")
+        close(y0d.grad, y0r.grad, "d/dy0")
+        for k, p in m.named_parameters():
+            a, b = p.grad.detach().cpu().double(), sd[k].grad.double()
+            assert float((a - b).norm()) / max(1e-9, float(b.norm())) < 1e-3, k
+    else:
+        sv = _solver_of(m)
+        sv.keep_acts = False
+        sv._ws.clear()                       # (workspaces are laid out for the mode they were created in)
+        m.refresh_device_weights()
+        yd = y0.cuda()
+        x1 = sv.forward(yd[:, :3].contiguous(), yd[:, 3:].contiguous(), 1, B, "dopri5", 0.05, 1e-7, 1e-5)
+        close(x1, out_r, "x(dt)")
+        du, dy0 = sv.backward(w.cuda(), need_du=True, need_dy0=True)
+        close(torch.cat([dy0, du], 1), y0r.grad, "d/dy0")
