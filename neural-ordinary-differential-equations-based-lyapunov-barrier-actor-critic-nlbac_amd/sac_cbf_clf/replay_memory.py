@@ -49,7 +49,7 @@ class ReplayMemory:
         self.position = (self.position + 1) % self.capacity
 
     def sample(self, batch_size):
-        idx = np.asarray(random.sample(range(self._len), batch_size))
+        idx = np.asarray(random.sample(range(self._len), batch_size), dtype=np.int64)
         return tuple(c[idx] for c in self._cols)
 
     def __len__(self):
