@@ -10,6 +10,7 @@ line per episode (the reference's wandb / spinup loggers are host tooling and ou
 ``--device_replay`` keeps both replays in HBM (same index stream, gather on the device).
 """
 import argparse
+import os
 import time
 
 import numpy as np
@@ -41,6 +42,9 @@ def get_args(argv=None):
     p.add_argument('--solver', default="euler", choices=["euler", "rk4", "dopri5"])
     p.add_argument('--output', default=None, help="directory for save_model at the reference's cadence")
     p.add_argument('--device_replay', action="store_true")
+    p.add_argument('--hipgraphs', action="store_true",
+                   help="replay each update as hipGraphs (pays at the reference's small batch sizes, where the host's "
+                        "launch rate bounds an update)")
     p.add_argument('--max_steps', type=int, default=0, help="stop after this many env steps (0: run all episodes)")
     return p.parse_args(argv)
 
@@ -112,6 +116,11 @@ def train(agent, env, dynamics_model, args, memory, node_memory, log=print):
                         if dx * dx + dy * dy >= 0.6:
                             use_backup, backup_time = False, 0
             obs = next_obs
+            if os.environ.get("NLBAC_TRAIN_CHECKSUM") == "2" and total_numsteps % 100 == 0:
+                import torch
+                torch.cuda.synchronize()
+                log("  step %d updates %d r %.9g a %.9g checksum %s" % (total_numsteps, updates, episode_reward, float(np.sum(action)),
+                    " ".join("%.17g" % float(a.theta.double().sum()) for a in agent.arenas)))
             if args.max_steps and total_numsteps >= args.max_steps:
                 done = True
         if args.output and ((i_episode % max(1, int(args.max_episodes / 2)) == 0) or i_episode == args.max_episodes - 1):
@@ -121,6 +130,10 @@ def train(agent, env, dynamics_model, args, memory, node_memory, log=print):
         history.append(rec)
         log("episode %(episode)d  reward %(reward).2f  length %(length)d  safety violations %(violations)d  "
             "steps %(total_steps)d  updates %(updates)d  %(seconds).1f s" % rec)
+        if os.environ.get("NLBAC_TRAIN_CHECKSUM"):      # run-to-run determinism check: parameter sums to the last bit
+            import torch
+            torch.cuda.synchronize()
+            log("  checksum " + " ".join("%.17g" % float(a.theta.double().sum()) for a in agent.arenas))
         if args.max_steps and total_numsteps >= args.max_steps:
             break
     return history
@@ -139,7 +152,16 @@ def main(argv=None):
         from .sac_cbf_clf.replay_memory import DeviceReplayMemory, ReplayMemory
     from .sac_cbf_clf.dynamics import DynamicsModel
     env = envs.make(args.env, args.seed)
+    if args.seed >= 0:       # U/main.py:253-258: every generator is seeded before the agent (and its networks) exist
+        import random
+        import torch
+        env.seed(args.seed)
+        random.seed(args.seed)
+        env.action_space.seed(args.seed)
+        torch.manual_seed(args.seed)
+        np.random.seed(args.seed)
     agent = SAC_CBF_CLF(env.observation_space.shape[0], env.action_space, env, args)
+    agent.use_graphs = bool(args.hipgraphs)
     agent.solver = args.solver
     dynamics_model = DynamicsModel(env, args)
     if args.device_replay:

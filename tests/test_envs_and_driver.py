@@ -49,3 +49,32 @@ def test_training_driver_runs_end_to_end(name, device_replay):
     hist = train.main(argv)
     assert hist and hist[-1]["total_steps"] >= 260 and hist[-1]["updates"] >= 150
     assert all(np.isfinite(h["reward"]) for h in hist)
+
+
+@pytest.mark.gpu
+def test_training_driver_is_reproducible_and_graph_replay_changes_nothing():
+    """Same seed, same run: the driver seeds every generator before the agent builds its networks (U/main.py:253-258),
+    the update has no order-dependent reductions, so two runs agree to the last bit — and a third run that replays
+    each update as hipGraphs does too."""
+    import torch
+    from nlbac_amd import train
+    argv = ["--env", "Unicycle", "--cuda", "--batch_size", "64", "--start_steps", "120", "--max_episodes", "2",
+            "--max_steps", "320", "--seed", "3", "--updates_per_step", "2", "--solver", "dopri5", "--device_replay"]
+    runs = []
+    for extra in ([], [], ["--hipgraphs"]):
+        agents = []
+        orig = train.train
+
+        def spy(agent, *a, **k):
+            agents.append(agent)
+            return orig(agent, *a, **k)
+        train.train = spy
+        try:
+            hist = train.main(argv + extra)
+        finally:
+            train.train = orig
+        torch.cuda.synchronize()
+        runs.append(([h["reward"] for h in hist], [a.theta.clone() for a in agents[0].arenas]))
+    for rewards, thetas in runs[1:]:
+        assert rewards == runs[0][0]
+        assert all(torch.equal(x, y) for x, y in zip(thetas, runs[0][1]))
