@@ -209,7 +209,14 @@ def ptr(t):
     return t.data_ptr() if t is not None else None
 
 
+_raw_stream = getattr(torch._C, "_cuda_getCurrentRawStream", None)
+
+
 def stream_ptr():
+    """hipStream_t of torch's current stream on the current device, as an int for the C ABI.  (The raw accessor skips
+    building a ``torch.cuda.Stream`` object per call — ~9 us each, a dozen calls per update.)"""
+    if _raw_stream is not None:
+        return _raw_stream(torch.cuda.current_device())
     return torch.cuda.current_stream().cuda_stream
 
 

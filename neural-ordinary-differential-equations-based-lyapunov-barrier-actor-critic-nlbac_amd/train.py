@@ -42,6 +42,9 @@ def get_args(argv=None):
     p.add_argument('--solver', default="euler", choices=["euler", "rk4", "dopri5"])
     p.add_argument('--output', default=None, help="directory for save_model at the reference's cadence")
     p.add_argument('--device_replay', action="store_true")
+    p.add_argument('--device_rng', action="store_true",
+                   help="with --device_replay: draw minibatch indices (and the policy noise) on the device instead of "
+                        "replaying the reference's host random.sample stream")
     p.add_argument('--hipgraphs', action="store_true",
                    help="replay each update as hipGraphs (pays at the reference's small batch sizes, where the host's "
                         "launch rate bounds an update)")
@@ -166,7 +169,9 @@ def main(argv=None):
     dynamics_model = DynamicsModel(env, args)
     if args.device_replay:
         cap = min(args.replay_size, 1 << 20)
-        memory, node_memory = DeviceReplayMemory(cap, args.seed, agent), DeviceReplayMemory(cap, args.seed, agent)
+        memory = DeviceReplayMemory(cap, args.seed, agent, device_rng=args.device_rng)
+        node_memory = DeviceReplayMemory(cap, args.seed + 1 if args.device_rng else args.seed, agent,
+                                         device_rng=args.device_rng)
     else:
         memory, node_memory = ReplayMemory(args.replay_size, args.seed), ReplayMemory(args.replay_size, args.seed)
     return train(agent, env, dynamics_model, args, memory, node_memory)
