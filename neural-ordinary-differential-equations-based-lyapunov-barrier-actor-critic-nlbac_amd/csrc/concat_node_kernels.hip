@@ -1,0 +1,348 @@
+// Fused Runge-Kutta step of the single-net NODE  dx/dt = net([x, c])  with carried inputs c = (u, t) constant over
+// the step (SimulatedCars: C/sac_cbf_clf/model.py:179-205, called through torchdiffeq.odeint at
+// C/sac_cbf_clf/sac_cbf_clf.py:437,458,581,603 and C/model.py:245).  ONE launch evaluates all requested stages of an
+// explicit RK step for a tile of 32 rows and ONE launch differentiates them — the same scheme as node_kernels.hip for
+// the control-affine field, with one net and therefore one 4-wave group per workgroup; they replace the per-stage
+// launch pairs  rk_combine -> mlp_fwd  and  mlp_bwd_data -> rk_stage_bwd  (kept as the cross-check and as the path for
+// nets wider than 128 units).
+//
+// CDNA4 mapping: 256-thread workgroup = 4 waves, one 32-column tile of the hidden layer per wave (the reference's net is
+// 64 wide: two waves carry the MFMAs, all four share the VALU phases); several workgroups share a CU (LDS ~25 KB,
+// < 128 VGPRs), which is what hides the per-tile layer chain here.  Weights stream from their fragment-packed,
+// L2-resident copy straight into registers (WaveGemm), stage derivatives stay in LDS across stages.
+#include "mlp_device.h"
+
+#define CK_MAX_STAGES 8
+#define CK_NS 16          // LDS row stride of state-sized rows (n_s <= 16)
+#define CK_NC 4           // carried inputs per row (n_c <= 4)
+
+struct ConcatRkLaunch {
+    nlbac_mlp net;
+    const float* y0; const float* c;
+    int n, rpp, n_s, n_c;
+    int stage_begin, stage_end;
+    float beta[CK_MAX_STAGES][CK_MAX_STAGES];
+    float c_out[CK_MAX_STAGES]; int n_out;
+    float c_err[CK_MAX_STAGES]; int n_err;
+    const double* h_dev; int h_stride; float h_val[8];
+    float* K; float* Y;
+    float* acts; long acts_ls;
+    float* out; float* err;
+    int ld;
+};
+
+__global__ __launch_bounds__(256) void concat_rk_fwd_kernel(const ConcatRkLaunch L) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int n = L.n, ns = L.n_s, nc = L.n_c, LD = L.ld;
+    const int row0 = blockIdx.x * NLBAC_MLP_TILE;
+    const nlbac_mlp& net = L.net;
+    const int hid = net.hid, NT = pad32(hid) >> 5, nwide = net.n_layers - 1;
+    const int inp = pad8(net.in_dim);
+    const int n_rows = min(NLBAC_MLP_TILE, n - row0);
+    const bool active = wave < NT;
+    const bool multi = L.stage_end - L.stage_begin > 1;
+    WaveGemm<1> wg;
+    if (active) fwd_prime<1>(wg, net, inp, multi, wave, lane);
+
+    float* buf = smem;                                              // ping-pong activation tiles
+    float* sK = smem + 2 * NLBAC_MLP_TILE * LD;                     // [stage][32][CK_NS]
+    float* sY0 = sK + CK_MAX_STAGES * NLBAC_MLP_TILE * CK_NS;       // [32][CK_NS]
+    float* sC = sY0 + NLBAC_MLP_TILE * CK_NS;                       // [32][CK_NC]
+    float* sH = sC + NLBAC_MLP_TILE * CK_NC;                        // [32]
+    float* sW = sH + NLBAC_MLP_TILE;                                // output layer [out][hid], then its bias
+    {
+        const float* W = net.params + net.w_off[nwide];
+        const float* bsrc = net.params + net.b_off[nwide];
+        const int nw = net.out_dim * hid;
+        for (int idx = tid; idx < nw; idx += 256) sW[idx] = W[idx];
+        for (int idx = tid; idx < net.out_dim; idx += 256) sW[nw + idx] = bsrc[idx];
+    }
+    for (int idx = tid; idx < NLBAC_MLP_TILE * CK_NS; idx += 256) {
+        const int m = idx / CK_NS, c = idx - m * CK_NS, row = row0 + m;
+        sY0[idx] = (row < n && c < ns) ? L.y0[(long)row * ns + c] : 0.f;
+    }
+    if (tid < NLBAC_MLP_TILE * CK_NC) {
+        const int m = tid / CK_NC, c = tid - m * CK_NC, row = row0 + m;
+        sC[tid] = (row < n && c < nc) ? L.c[(long)row * nc + c] : 0.f;
+    }
+    if (tid < NLBAC_MLP_TILE) {
+        const int p = min(row0 + tid, n - 1) / L.rpp;
+        sH[tid] = L.h_dev ? (float)L.h_dev[(long)p * L.h_stride] : L.h_val[p];
+    }
+    for (int idx = tid; idx < L.stage_begin * NLBAC_MLP_TILE * CK_NS; idx += 256) {      // stages of an earlier launch
+        const int j = idx / (NLBAC_MLP_TILE * CK_NS), rem = idx - j * NLBAC_MLP_TILE * CK_NS;
+        const int m = rem / CK_NS, c = rem - m * CK_NS, row = row0 + m;
+        sK[idx] = (row < n && c < ns) ? L.K[((long)j * n + row) * ns + c] : 0.f;
+    }
+    __syncthreads();
+
+    for (int st = L.stage_begin; st < L.stage_end; ++st) {
+        // ---- stage input [Y_st | c],  Y_st = y0 + h sum_j beta[st][j] K_j   (same op order as rk_combine_kernel)
+        float* in = buf;
+        float* out = buf + NLBAC_MLP_TILE * LD;
+        for (int idx = tid; idx < NLBAC_MLP_TILE * inp; idx += 256) {
+            const int m = idx / inp, c = idx - m * inp;
+            float a = 0.f;
+            if (c < ns) {
+                a = sY0[m * CK_NS + c];
+                const float h = sH[m];
+                for (int j = 0; j < st; ++j)
+                    if (L.beta[st][j] != 0.f) a = a + sK[(j * NLBAC_MLP_TILE + m) * CK_NS + c] * (L.beta[st][j] * h);
+                if (row0 + m < n) L.Y[((long)st * n + row0 + m) * ns + c] = a;
+            } else if (c < ns + nc) {
+                a = sC[m * CK_NC + (c - ns)];
+            }
+            in[m * LD + c] = a;
+        }
+        __syncthreads();
+        // ---- hidden layers (MFMA), activations saved for the backward
+        float* acts_tile = L.acts ? L.acts + ((long)st * n + row0) * hid : nullptr;
+        fwd_wide_layers<1, 0>(wg, net, active, wave, lane, LD, inp, in, out, acts_tile, L.acts_ls, n_rows, nwide,
+                              st + 1 < L.stage_end);
+        // ---- output layer: k_st
+        for (int idx = tid; idx < NLBAC_MLP_TILE * net.out_dim; idx += 256) {
+            const int m = idx & 31, o = idx >> 5, row = row0 + m;
+            const float val = skinny_row_dot(in + m * LD, sW + o * hid, hid) + sW[net.out_dim * hid + o];
+            sK[(st * NLBAC_MLP_TILE + m) * CK_NS + o] = val;
+            if (row < n) L.K[((long)st * n + row) * ns + o] = val;
+        }
+        __syncthreads();
+    }
+
+    // ---- step outputs
+    for (int idx = tid; idx < NLBAC_MLP_TILE * ns; idx += 256) {
+        const int m = idx / ns, r = idx - m * ns, row = row0 + m;
+        if (row >= n) continue;
+        const float h = sH[m];
+        if (L.out) {
+            float a = sY0[m * CK_NS + r];
+            for (int j = 0; j < L.n_out; ++j)
+                if (L.c_out[j] != 0.f) a = a + sK[(j * NLBAC_MLP_TILE + m) * CK_NS + r] * (L.c_out[j] * h);
+            L.out[(long)row * ns + r] = a;
+        }
+        if (L.err) {
+            float a = 0.f;
+            for (int j = 0; j < L.n_err; ++j)
+                if (L.c_err[j] != 0.f) a = a + sK[(j * NLBAC_MLP_TILE + m) * CK_NS + r] * (L.c_err[j] * h);
+            L.err[(long)row * ns + r] = a;
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------
+// Backward of one RK step: for st = st_hi-1 .. st_lo
+//     dz = J_net^T dK[st]  (data backward of the net);  dX = dz0 W_0
+//     dY = [dYup at the last stage] + dX[:, :n_s];  dy0 += dY;  dK[j] += beta[st][j] h dY;  dc += dX[:, n_s:]
+// With dz given it also leaves every stage's pre-activation gradients for nlbac_mlp_bwd_weights (NODE fit).
+// ---------------------------------------------------------------------------
+struct ConcatRkBwdLaunch {
+    nlbac_mlp net;
+    const float* acts; long acts_ls;
+    float* dz;
+    float* dK; const float* dYup;
+    float* dy0; int dy0_in;
+    float* dc; int dc_acc;
+    int n, rpp, n_s, n_c, S_total, st_lo, st_hi, dx_stage0;
+    float beta[CK_MAX_STAGES][CK_MAX_STAGES];
+    const double* h_dev; int h_stride; float h_val[8];
+    int ld;
+};
+
+__global__ __launch_bounds__(256) void concat_rk_bwd_kernel(const ConcatRkBwdLaunch L) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int n = L.n, ns = L.n_s, nc = L.n_c, LD = L.ld;
+    const int row0 = blockIdx.x * NLBAC_MLP_TILE;
+    const nlbac_mlp& net = L.net;
+    const int hid = net.hid, NT = pad32(hid) >> 5, hidp32 = NT * 32, nwide = net.n_layers - 1;
+    const int n_rows = min(NLBAC_MLP_TILE, n - row0);
+    const bool keep_dz = L.dz != nullptr;
+    const bool active = wave < NT;
+    const long ls = L.acts_ls;
+
+    float* buf = smem;
+    float* sDK = smem + 2 * NLBAC_MLP_TILE * LD;                    // [stage][32][CK_NS]
+    float* sH = sDK + CK_MAX_STAGES * NLBAC_MLP_TILE * CK_NS;       // [32]
+    float* sDY0 = sH + NLBAC_MLP_TILE;                              // [32][CK_NS] running dy0
+    float* sDC = sDY0 + NLBAC_MLP_TILE * CK_NS;                     // [32][CK_NC] running d carried
+    float* sDX = sDC + NLBAC_MLP_TILE * CK_NC;                      // [32][CK_NS]
+    float* sdy = sDX + NLBAC_MLP_TILE * CK_NS;                      // [32][16] output-layer gradient
+    float* sW = sdy + NLBAC_MLP_TILE * 16;                          // W_last [out][hid], then W_0^T [in][hid]
+    float* sW0t = sW + net.out_dim * hid;
+
+    const int st_lo = L.st_lo;
+    const bool stage0_data = L.dx_stage0 || keep_dz;
+#define ck_has_data(st_) ((st_) >= st_lo && ((st_) > 0 || stage0_data))
+    WaveGemm<1> wg;
+    if (active && nwide >= 2 && ck_has_data(L.st_hi - 1)) bwd_prime<1>(wg, net, wave, lane, ck_has_data(L.st_hi - 2));
+    {
+        const float* Wl = net.params + net.w_off[nwide];
+        const float* W0 = net.params + net.w_off[0];
+        for (int idx = tid; idx < net.out_dim * hid; idx += 256) sW[idx] = Wl[idx];
+        for (int idx = tid; idx < net.in_dim * hid; idx += 256) {
+            const int i = idx / hid, k = idx - i * hid;
+            sW0t[idx] = W0[(long)k * net.in_dim + i];
+        }
+    }
+    if (tid < NLBAC_MLP_TILE * CK_NC) {
+        const int m = tid / CK_NC, c = tid - m * CK_NC, row = row0 + m;
+        sDC[tid] = (row < n && c < nc && L.dc && L.dc_acc) ? L.dc[(long)row * nc + c] : 0.f;
+    }
+    for (int idx = tid; idx < NLBAC_MLP_TILE * CK_NS; idx += 256) {
+        const int m = idx / CK_NS, c = idx - m * CK_NS, row = row0 + m;
+        sDY0[idx] = (row < n && c < ns && L.dy0 && L.dy0_in) ? L.dy0[(long)row * ns + c] : 0.f;
+    }
+    if (tid < NLBAC_MLP_TILE) {
+        const int p = min(row0 + tid, n - 1) / L.rpp;
+        sH[tid] = L.h_dev ? (float)L.h_dev[(long)p * L.h_stride] : L.h_val[p];
+    }
+    for (int idx = tid; idx < L.st_hi * NLBAC_MLP_TILE * CK_NS; idx += 256) {
+        const int j = idx / (NLBAC_MLP_TILE * CK_NS), rem = idx - j * NLBAC_MLP_TILE * CK_NS;
+        const int m = rem / CK_NS, c = rem - m * CK_NS, row = row0 + m;
+        sDK[idx] = (row < n && c < ns) ? L.dK[((long)j * n + row) * ns + c] : 0.f;
+    }
+    __syncthreads();
+
+    for (int st = L.st_hi - 1; st >= L.st_lo; --st) {
+        const bool data = ck_has_data(st);
+        const float* acts_tile = L.acts + ((long)st * n + row0) * hid;
+        float av_top[16];            // <= 128 padded columns: two row groups of 16 rows cover the tile
+        if (data) node_top_masks<16, 0>(acts_tile + (long)(nwide - 1) * ls, hid, NT, tid, n_rows, av_top);
+        __builtin_amdgcn_sched_barrier(0);
+        for (int rem = tid; rem < NLBAC_MLP_TILE * 16; rem += 256) {
+            const int m = rem >> 4, o = rem & 15;
+            sdy[rem] = (o < ns) ? sDK[(st * NLBAC_MLP_TILE + m) * CK_NS + o] : 0.f;
+        }
+        if (!data) continue;             // uniform
+        __syncthreads();
+        float* in = buf;
+        float* out = buf + NLBAC_MLP_TILE * LD;
+        node_top_layer<16, 0>(sdy, sW, net.out_dim, hid, hidp32, NT, tid, n_rows, av_top, in, LD);
+        __syncthreads();
+        if (keep_dz) tile_to_global(in, LD, L.dz + (long)(nwide - 1) * ls + ((long)st * n + row0) * hid, hid, n_rows, tid, 256);
+        {
+            float* dz_tile = keep_dz ? L.dz + ((long)st * n + row0) * hid : nullptr;
+            bwd_wide_layers<1, 0>(wg, net, active, wave, lane, LD, in, out, acts_tile, dz_tile, ls, n_rows, n_rows - 1,
+                                  nwide - 1, ck_has_data(st - 1), 256);
+        }
+        if (st == 0 && !L.dx_stage0) continue;       // only the dz of stage 0 were wanted (uniform)
+
+        // ---- dX = dz0 W_0: state columns -> sDX, carried columns accumulate (always the same thread per entry)
+        for (int idx = tid; idx < NLBAC_MLP_TILE * net.in_dim; idx += 256) {
+            const int m = idx & 31, i = idx >> 5;
+            const float v = skinny_row_dot(in + m * LD, sW0t + i * hid, hid);
+            if (i < ns) sDX[m * CK_NS + i] = v;
+            else sDC[m * CK_NC + (i - ns)] += v;
+        }
+        __syncthreads();
+        for (int idx = tid; idx < NLBAC_MLP_TILE * ns; idx += 256) {
+            const int m = idx / ns, c = idx - m * ns, row = row0 + m;
+            float d = (L.dYup && st == L.S_total - 1 && row < n) ? L.dYup[(long)row * ns + c] : 0.f;
+            d += sDX[m * CK_NS + c];
+            sDY0[m * CK_NS + c] = sDY0[m * CK_NS + c] + d;
+            const float h = sH[m];
+            for (int j = 0; j < st; ++j)
+                if (L.beta[st][j] != 0.f) sDK[(j * NLBAC_MLP_TILE + m) * CK_NS + c] += (L.beta[st][j] * h) * d;
+        }
+        __syncthreads();
+    }
+    __syncthreads();
+    for (int idx = tid; idx < L.st_hi * NLBAC_MLP_TILE * ns; idx += 256) {
+        const int j = idx / (NLBAC_MLP_TILE * ns), rem = idx - j * NLBAC_MLP_TILE * ns;
+        const int m = rem / ns, c = rem - m * ns, row = row0 + m;
+        if (row < n) L.dK[((long)j * n + row) * ns + c] = sDK[(j * NLBAC_MLP_TILE + m) * CK_NS + c];
+    }
+    if (L.dy0)
+        for (int idx = tid; idx < NLBAC_MLP_TILE * ns; idx += 256) {
+            const int m = idx / ns, c = idx - m * ns, row = row0 + m;
+            if (row < n) L.dy0[(long)row * ns + c] = sDY0[m * CK_NS + c];
+        }
+    if (L.dc)
+        for (int idx = tid; idx < NLBAC_MLP_TILE * nc; idx += 256) {
+            const int m = idx / nc, c = idx - m * nc, row = row0 + m;
+            if (row < n) L.dc[(long)row * nc + c] = sDC[m * CK_NC + c];
+        }
+#undef ck_has_data
+}
+
+// ---------------------------------------------------------------------------
+static int concat_check(const nlbac_mlp* net, int P, int rpp, int S, const char* who) {
+    NLBAC_REQUIRE(net && P >= 1 && P <= 8 && rpp >= 1, "%s: bad problem sizes", who);
+    NLBAC_REQUIRE(S >= 1 && S <= CK_MAX_STAGES, "%s: bad stage count %d", who, S);
+    NLBAC_REQUIRE(net->n_layers >= 2 && net->hid % 4 == 0 && net->hid <= 128, "%s: hidden width %d (fused path: <= 128)",
+                  who, net->hid);
+    NLBAC_REQUIRE(net->out_dim >= 1 && net->out_dim <= CK_NS && net->in_dim > net->out_dim &&
+                      net->in_dim - net->out_dim <= CK_NC, "%s: net is not [x (<=16) | carried (<=4)] -> dx", who);
+    return 0;
+}
+
+extern "C" int nlbac_concat_rk_fwd(const nlbac_mlp* net, const float* y0, const float* c, int P, int rows_per_problem,
+                                   int stage_begin, int stage_end, int n_stages_total, const float* beta,
+                                   const float* c_out, int n_out, const float* c_err, int n_err, const float* h_host,
+                                   const double* h_dev, int h_dev_stride, float* K, float* Y, float* acts, long acts_ls,
+                                   float* out, float* err, nlbac_stream_t s) {
+    if (concat_check(net, P, rows_per_problem, n_stages_total, "nlbac_concat_rk_fwd")) return -1;
+    NLBAC_REQUIRE(y0 && c && K && Y, "nlbac_concat_rk_fwd: null pointer");
+    NLBAC_REQUIRE(stage_begin >= 0 && stage_begin < stage_end && stage_end <= n_stages_total,
+                  "nlbac_concat_rk_fwd: bad stage range");
+    NLBAC_REQUIRE(h_dev || h_host, "nlbac_concat_rk_fwd: no step size");
+    NLBAC_REQUIRE(n_out <= n_stages_total && n_err <= n_stages_total, "nlbac_concat_rk_fwd: bad coefficient counts");
+    ConcatRkLaunch L;
+    memset(&L, 0, sizeof(L));
+    L.net = *net;
+    L.y0 = y0; L.c = c;
+    L.n = P * rows_per_problem; L.rpp = rows_per_problem;
+    L.n_s = net->out_dim; L.n_c = net->in_dim - net->out_dim;
+    L.stage_begin = stage_begin; L.stage_end = stage_end;
+    if (beta)
+        for (int i = 0; i < n_stages_total; ++i)
+            for (int j = 0; j < n_stages_total; ++j) L.beta[i][j] = beta[i * n_stages_total + j];
+    for (int j = 0; j < n_out; ++j) L.c_out[j] = c_out[j];
+    for (int j = 0; j < n_err; ++j) L.c_err[j] = c_err[j];
+    L.n_out = out ? n_out : 0; L.n_err = err ? n_err : 0;
+    L.h_dev = h_dev; L.h_stride = h_dev_stride;
+    for (int p = 0; p < P; ++p) L.h_val[p] = h_host ? h_host[p] : 0.f;
+    L.K = K; L.Y = Y; L.acts = acts; L.acts_ls = acts_ls;
+    L.out = out; L.err = err;
+    const int in_p = (net->in_dim + 7) & ~7, hid_p = (net->hid + 7) & ~7;
+    L.ld = (hid_p > in_p ? hid_p : in_p) + 4;
+    const size_t lds = ((size_t)2 * NLBAC_MLP_TILE * L.ld + CK_MAX_STAGES * NLBAC_MLP_TILE * CK_NS +
+                        NLBAC_MLP_TILE * (CK_NS + CK_NC + 1) + ((net->out_dim * (net->hid + 1) + 3) & ~3)) * sizeof(float);
+    NLBAC_REQUIRE(lds <= 64 * 1024, "nlbac_concat_rk_fwd: LDS budget exceeded (%zu B)", lds);
+    hipLaunchKernelGGL(concat_rk_fwd_kernel, dim3(nlbac_ceil_div(L.n, NLBAC_MLP_TILE)), dim3(256), lds, (hipStream_t)s, L);
+    NLBAC_CHECK_LAUNCH("nlbac_concat_rk_fwd");
+    return 0;
+}
+
+extern "C" int nlbac_concat_rk_bwd(const nlbac_mlp* net, int P, int rows_per_problem, int n_stages_total, int st_lo,
+                                   int st_hi, int dx_stage0, const float* beta, const float* h_host,
+                                   const double* h_dev, int h_dev_stride, const float* acts, long acts_ls, float* dz,
+                                   float* dK, const float* dYup, float* dy0, int dy0_in, float* dc, int dc_acc,
+                                   nlbac_stream_t s) {
+    if (concat_check(net, P, rows_per_problem, n_stages_total, "nlbac_concat_rk_bwd")) return -1;
+    NLBAC_REQUIRE(acts && dK, "nlbac_concat_rk_bwd: null pointer");
+    NLBAC_REQUIRE(st_lo >= 0 && st_lo < st_hi && st_hi <= n_stages_total, "nlbac_concat_rk_bwd: bad stage range");
+    NLBAC_REQUIRE(h_dev || h_host, "nlbac_concat_rk_bwd: no step size");
+    ConcatRkBwdLaunch L;
+    memset(&L, 0, sizeof(L));
+    L.net = *net;
+    L.acts = acts; L.acts_ls = acts_ls; L.dz = dz;
+    L.dK = dK; L.dYup = dYup; L.dy0 = dy0; L.dy0_in = dy0_in; L.dc = dc; L.dc_acc = dc_acc;
+    L.n = P * rows_per_problem; L.rpp = rows_per_problem;
+    L.n_s = net->out_dim; L.n_c = net->in_dim - net->out_dim;
+    L.S_total = n_stages_total; L.st_lo = st_lo; L.st_hi = st_hi; L.dx_stage0 = dx_stage0;
+    if (beta)
+        for (int i = 0; i < n_stages_total; ++i)
+            for (int j = 0; j < n_stages_total; ++j) L.beta[i][j] = beta[i * n_stages_total + j];
+    L.h_dev = h_dev; L.h_stride = h_dev_stride;
+    for (int p = 0; p < P; ++p) L.h_val[p] = h_host ? h_host[p] : 0.f;
+    L.ld = ((net->hid + 31) & ~31) + 4;
+    const size_t lds = ((size_t)2 * NLBAC_MLP_TILE * L.ld + CK_MAX_STAGES * NLBAC_MLP_TILE * CK_NS +
+                        NLBAC_MLP_TILE * (1 + CK_NS + CK_NC + CK_NS + 16) +
+                        (((net->out_dim + net->in_dim) * net->hid + 3) & ~3)) * sizeof(float);
+    NLBAC_REQUIRE(lds <= 64 * 1024, "nlbac_concat_rk_bwd: LDS budget exceeded (%zu B)", lds);
+    hipLaunchKernelGGL(concat_rk_bwd_kernel, dim3(nlbac_ceil_div(L.n, NLBAC_MLP_TILE)), dim3(256), lds, (hipStream_t)s, L);
+    NLBAC_CHECK_LAUNCH("nlbac_concat_rk_bwd");
+    return 0;
+}

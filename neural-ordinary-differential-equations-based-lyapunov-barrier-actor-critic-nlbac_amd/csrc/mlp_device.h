@@ -378,3 +378,58 @@ __device__ __forceinline__ void bwd_wide_layers(WaveGemm<NTW>& wg, const nlbac_m
         }
     }
 }
+
+// Top (skinny) layer of the backward for one 32-row tile: dz_top[m][k] = [act_top[m][k] > 0] sum_o dy[m][o] W_last[o][k].
+// RPT rows per thread: the 256 threads of a group cover (32 / RPT) row groups x (256 * RPT / 32) columns.
+// ReLU masks of the top hidden layer for this thread's (row group, column): issued at the start of a stage so that their
+// global latency (~2k cycles) hides under the output-gradient fill and the first barrier.
+template <int RPT, int BITS>
+__device__ __forceinline__ void node_top_masks(const float* __restrict__ atop, int hid, int NT, int t, int n_rows,
+                                               float (&av)[RPT]) {
+    constexpr int CPG = 256 * RPT / 32;
+    const int k = t % CPG, m0 = (t / CPG) * RPT, kc = min(k, hid - 1);
+    if constexpr (BITS != 0) {
+        const unsigned* mtop = reinterpret_cast<const unsigned*>(atop) + (kc >> 5);
+#pragma unroll
+        for (int i = 0; i < RPT; ++i)
+            av[i] = ((mtop[min(m0 + i, n_rows - 1) * NT] >> (kc & 31)) & 1u) ? 1.f : 0.f;
+    } else {
+#pragma unroll
+        for (int i = 0; i < RPT; ++i) av[i] = atop[min(m0 + i, n_rows - 1) * hid + kc];
+    }
+}
+
+template <int RPT, int BITS>
+__device__ __forceinline__ void node_top_layer(const float* __restrict__ sdy, const float* __restrict__ sW, int out_dim,
+                                               int hid, int hidp32, int NT, int t, int n_rows,
+                                               const float (&av)[RPT], float* __restrict__ in, int LD) {
+    constexpr int CPG = 256 * RPT / 32;            // columns per row group
+    const int k = t % CPG, m0 = (t / CPG) * RPT, kc = min(k, hid - 1);
+    float s[RPT];
+#pragma unroll
+    for (int i = 0; i < RPT; ++i) s[i] = 0.f;
+#ifndef EXP_BWD_NO_TOP
+    for (int o0 = 0; o0 < out_dim; o0 += 4) {
+        const int no = min(4, out_dim - o0);
+        float w[4];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) w[q] = (q < no) ? sW[(o0 + min(q, no - 1)) * hid + kc] : 0.f;
+#pragma unroll
+        for (int i = 0; i < RPT; ++i) {
+            const float4 d = *reinterpret_cast<const float4*>(sdy + (m0 + i) * 16 + o0);
+            s[i] += d.x * w[0] + d.y * w[1] + d.z * w[2] + d.w * w[3];
+        }
+    }
+#endif
+    if (k < hidp32) {
+        const bool colok = k < hid;
+#pragma unroll
+        for (int i = 0; i < RPT; ++i) {
+            const int m = m0 + i;
+            const bool ok = colok && (m < n_rows);
+            const float v = (ok && av[i] > 0.f) ? s[i] : 0.f;
+            in[m * LD + k] = v;        // (dz goes out from this LDS tile afterwards: tile_to_global)
+        }
+    }
+}
+

@@ -220,6 +220,19 @@ class AffineNodeSolver:
                   stream_ptr())
         self.nfe += st1 - st0
 
+    def _rk_fused_bwd(self, ws, u, P, rpp, method, first_eval, need_dy0, need_params, h_host, h_dev, h_stride, top_up,
+                      du, last):
+        """One launch for the backward of every evaluated stage of the step in ``ws`` (nlbac_node_rk_bwd)."""
+        beta_arr, _ = self._beta(method)
+        f, g, S = self.f, self.g, ws.S
+        _lib.call("nlbac_node_rk_bwd", C.byref(f.desc), C.byref(g.desc), u.data_ptr(), ws.gout.data_ptr(), P, rpp,
+                  S, 0 if first_eval else 1, S, 1 if need_dy0 else 0, beta_arr, h_host, h_dev, h_stride,
+                  ws.acts_f.data_ptr(), S * ws.n * ws.wf, ws.acts_g.data_ptr(), S * ws.n * ws.wg,
+                  1 if ws.bits else 0, ws.dz_f.data_ptr() if need_params else None,
+                  ws.dz_g.data_ptr() if need_params else None, ws.dG.data_ptr() if need_params else None,
+                  ws.dK.data_ptr(), top_up.data_ptr() if top_up is not None else None, ws.dy0.data_ptr(), 1,
+                  du.data_ptr() if du is not None else None, 0 if last else 1, stream_ptr())
+
     def _combine(self, y0, K, n_k, coef, h, P, rpp, out):
         _lib.call("nlbac_rk_combine", y0.data_ptr() if y0 is not None else None, K.data_ptr(), n_k,
                   fptr(*coef), fptr(*h), None, 0, P, rpp, self.n_s, out.data_ptr(), stream_ptr())
@@ -554,15 +567,8 @@ class AffineNodeSolver:
                           None, 0, P, rpp, ns, ws.dK.data_ptr(), ws.dy0.data_ptr(), 0, None, 0, s)
                 top_up = None
             if self.fused:
-                beta_arr, S_tab = self._beta(method)
-                f, g = self.f, self.g
-                _lib.call("nlbac_node_rk_bwd", C.byref(f.desc), C.byref(g.desc), u.data_ptr(), ws.gout.data_ptr(), P, rpp,
-                          S, 0 if first_eval else 1, S, 1 if need_dy0 else 0, beta_arr, h_host, h_dev, h_stride,
-                          ws.acts_f.data_ptr(), S * ws.n * ws.wf, ws.acts_g.data_ptr(), S * ws.n * ws.wg,
-                          1 if ws.bits else 0, ws.dz_f.data_ptr() if need_params else None, ws.dz_g.data_ptr() if need_params else None,
-                          ws.dG.data_ptr() if need_params else None, ws.dK.data_ptr(),
-                          top_up.data_ptr() if top_up is not None else None, ws.dy0.data_ptr(), 1,
-                          du.data_ptr() if du is not None else None, 0 if last else 1, s)
+                self._rk_fused_bwd(ws, u, P, rpp, method, first_eval, need_dy0, need_params, h_host, h_dev, h_stride,
+                                   top_up, du, last)
                 dy_carry = ws.dy0
                 dk_carry = ws.dK[0]
                 continue
@@ -683,7 +689,8 @@ class ConcatNodeSolver(AffineNodeSolver):
         self._ws, self._scratch = {}, {}
         self.nfe = 0
         self._net_arr, self._coefs, self._children = None, {}, {}
-        self.fused = False
+        # one nlbac_concat_rk_fwd / _bwd launch per RK step (nets of <= 128 hidden units; wider ones run stage by stage)
+        self.fused = self.net.hid <= 128
         self.keep_acts = True
         self.stats = dict(solves=0, single_step=0, multi_attempt=0, split=0)
         self.comm = None
@@ -692,6 +699,27 @@ class ConcatNodeSolver(AffineNodeSolver):
         if self._net_arr is None:
             self._net_arr = mlp_array([self.net.desc])
         return self._net_arr
+
+    def _rk_fused(self, ws, y0, u, P, rpp, method, st0, st1, h_host=None, h_dev=None, c_out=None, out=None,
+                  c_err=None, err=None, save_acts=True):
+        beta, S = self._beta(method)
+        _lib.call("nlbac_concat_rk_fwd", C.byref(self.net.desc), y0.data_ptr(), u.data_ptr(), P, rpp, st0, st1, S, beta,
+                  c_out, len(c_out) if c_out is not None else 0, c_err, len(c_err) if c_err is not None else 0,
+                  fptr(*h_host) if h_host is not None else None, h_dev, _lib.DOPRI_CTL if h_dev else 0,
+                  ws.K.data_ptr(), ws.Y.data_ptr(), ws.acts.data_ptr() if save_acts else None,
+                  ws.S * P * rpp * self.net.hid, out.data_ptr() if out is not None else None,
+                  err.data_ptr() if err is not None else None, stream_ptr())
+        self.nfe += st1 - st0
+
+    def _rk_fused_bwd(self, ws, u, P, rpp, method, first_eval, need_dy0, need_params, h_host, h_dev, h_stride, top_up,
+                      du, last):
+        beta_arr, _ = self._beta(method)
+        S = ws.S
+        _lib.call("nlbac_concat_rk_bwd", C.byref(self.net.desc), P, rpp, S, 0 if first_eval else 1, S,
+                  1 if need_dy0 else 0, beta_arr, h_host, h_dev, h_stride, ws.acts.data_ptr(),
+                  S * ws.n * self.net.hid, ws.dz.data_ptr() if need_params else None, ws.dK.data_ptr(),
+                  top_up.data_ptr() if top_up is not None else None, ws.dy0.data_ptr(), 1,
+                  du.data_ptr() if du is not None else None, 0 if last else 1, stream_ptr())
 
     def _eval_io(self, x, k_out, c, acts=None, ls=0):
         io = io_array(1)
