@@ -65,6 +65,14 @@ def launch_flops(name, args):
             per += m[-1] + sum(m[1:-1]) + m[0]
         stages = (st_hi - st_lo) - (0 if (dx0 or st_lo > 0) else 1)
         return 2 * P * rpp * stages * (per + 2 * g.out_dim)
+    if name == "nlbac_concat_rk_fwd":     # (net, y0, c, P, rpp, st0, st1, ...): stages x rows x NODE eval
+        net, P, rpp, st0, st1 = args[0]._obj, args[3], args[4], args[5], args[6]
+        return 2 * P * rpp * (st1 - st0) * sum(_layer_macs(net))
+    if name == "nlbac_concat_rk_bwd":     # (net, P, rpp, S, st_lo, st_hi, dx0, ...): data backward
+        net, P, rpp, st_lo, st_hi, dx0 = args[0]._obj, args[1], args[2], args[4], args[5], args[6]
+        m = _layer_macs(net)
+        stages = (st_hi - st_lo) - (0 if (dx0 or st_lo > 0) else 1)
+        return 2 * P * rpp * stages * (m[-1] + sum(m[1:-1]) + m[0])
     nets, io, n_nets, B = args[0], args[1], args[2], args[3]
     total = 0
     for i in range(n_nets):
@@ -79,7 +87,8 @@ def launch_flops(name, args):
 
 class KernelTimer:
     """HIP events (torch.cuda.Event on the launch stream) around every launch of the MLP kernels."""
-    NAMES = ("nlbac_mlp_fwd", "nlbac_mlp_bwd_data", "nlbac_mlp_bwd_weights", "nlbac_node_rk_fwd", "nlbac_node_rk_bwd")
+    NAMES = ("nlbac_mlp_fwd", "nlbac_mlp_bwd_data", "nlbac_mlp_bwd_weights", "nlbac_node_rk_fwd", "nlbac_node_rk_bwd",
+             "nlbac_concat_rk_fwd", "nlbac_concat_rk_bwd")
 
     def __init__(self):
         self.records = {n: [] for n in self.NAMES}
@@ -338,7 +347,8 @@ def main():
         dom = max(ks, key=lambda k: ks[k]["ms"])
         kname = {"nlbac_mlp_fwd": "mlp_fwd_kernel", "nlbac_mlp_bwd_data": "mlp_bwd_data_kernel",
                  "nlbac_mlp_bwd_weights": "mlp_bwd_wide_kernel+mlp_bwd_skinny_partial/reduce_kernel",
-                 "nlbac_node_rk_fwd": "node_rk_fwd_kernel", "nlbac_node_rk_bwd": "node_rk_bwd_kernel"}[dom]
+                 "nlbac_node_rk_fwd": "node_rk_fwd_kernel", "nlbac_node_rk_bwd": "node_rk_bwd_kernel",
+                 "nlbac_concat_rk_fwd": "concat_rk_fwd_kernel", "nlbac_concat_rk_bwd": "concat_rk_bwd_kernel"}[dom]
         roofline = dict(bound="mfma", kernel=kname, achieved=ks[dom]["tflops"], peak=PEAK_F32_MFMA_TFLOPS,
                         unit="TFLOP/s", frac=ks[dom]["tflops"] / PEAK_F32_MFMA_TFLOPS,
                         traffic=pmc_traffic(kname, a.env, a.solver, B),

@@ -197,6 +197,11 @@ int nlbac_unicycle_constraints_bwd(const float *ps_next, const float *matr, cons
  * state (B,10); x1/x2 (2B,10) = rollout after one / two steps, primary rows then backup rows.
  * matr (B,3) = [cbf23, cbf34, clf], bmatr (B,2); partials [ceil(B/256)][5]; use nlbac_auglag(n_cbf=2). */
 int nlbac_cars_state(const float *obs, int obs_ld, int n, float *state, nlbac_stream_t s);
+/* nlbac_cars_state plus the inputs of the two-step rollout in one launch: y0_2 (2B,10) = state twice (primary /
+ * backup rows), c1 (2B,2) = [pi2 (the two controllers' actions), t], c2[:, 1] = next_t (c2[:, 0] is the re-sampled
+ * second action, written later) — C/sac_cbf_clf/sac_cbf_clf.py:424-437, 568-581. */
+int nlbac_cars_rollout_inputs(const float *mb, int ld, int t_col, int nt_col, const float *pi2, int B,
+                              float *state, float *y0_2, float *c1, float *c2, nlbac_stream_t s);
 int nlbac_cars_obs(const float *state, int n, float *obs, nlbac_stream_t s);
 int nlbac_cars_constraints_fwd(const float *state, const float *x1, const float *x2, const float *V,
                                const float *V1, float gamma_b, float gamma_l, float radius, int B,

@@ -79,6 +79,7 @@ _PROTOS = {
     "nlbac_rk_combine": [_P, _P, _I, c_float_p, c_float_p, _P, _I, _I, _I, _I, _P, _P],
     "nlbac_rk_stage_bwd": [_P, _P, _P, _I, _I, c_float_p, c_float_p, _P, _I, _I, _I, _I, _P, _P, _I, _P, _I, _P],
     "nlbac_cars_state": [_P, _I, _I, _P, _P],
+    "nlbac_cars_rollout_inputs": [_P, _I, _I, _I, _P, _I, _P, _P, _P, _P, _P],
     "nlbac_cars_obs": [_P, _I, _P, _P],
     "nlbac_cars_constraints_fwd": [_P, _P, _P, _P, _P, _F, _F, _F, _I, _P, _P, _P, _P],
     "nlbac_cars_constraints_bwd": [_P, _P, _F, _F, _I, _P, _P, _P, _P, _P],

@@ -374,6 +374,27 @@ __global__ __launch_bounds__(256) void cars_state_kernel(const float* obs, int o
         state[(long)i * 10 + c] = (float)((double)obs[(long)i * obs_ld + c] * ((c & 1) ? 30.0 : 100.0));
 }
 
+// Everything the two-step rollout starts from, in one launch: state, its two copies (primary / backup rows of the
+// first solve) and the carried inputs [action, time] of both steps (the second step's action column is filled later).
+__global__ __launch_bounds__(256) void cars_rollout_inputs_kernel(const float* mb, int ld, int t_col, int nt_col,
+                                                                  const float* pi2, int B, float* state, float* y0_2,
+                                                                  float* c1, float* c2) {
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= B) return;
+#pragma unroll
+    for (int c = 0; c < 10; ++c) {
+        const float v = (float)((double)mb[(long)i * ld + c] * ((c & 1) ? 30.0 : 100.0));
+        state[(long)i * 10 + c] = v;
+        y0_2[(long)i * 10 + c] = v;
+        y0_2[(long)(B + i) * 10 + c] = v;
+    }
+    const float t = mb[(long)i * ld + t_col], nt = mb[(long)i * ld + nt_col];
+    c1[2 * i + 0] = pi2[i];            c1[2 * i + 1] = t;
+    c1[2 * (B + i) + 0] = pi2[B + i];  c1[2 * (B + i) + 1] = t;
+    c2[2 * i + 1] = nt;
+    c2[2 * (B + i) + 1] = nt;
+}
+
 __global__ __launch_bounds__(256) void cars_obs_kernel(const float* state, int n, float* obs) {
     const int i = blockIdx.x * 256 + threadIdx.x;
     if (i >= n) return;
@@ -619,6 +640,15 @@ extern "C" int nlbac_cars_state(const float* obs, int obs_ld, int n, float* stat
     NLBAC_REQUIRE(obs && state, "nlbac_cars_state: null pointer");
     hipLaunchKernelGGL(cars_state_kernel, GRID1(n), obs, obs_ld, n, state);
     NLBAC_CHECK_LAUNCH("nlbac_cars_state");
+    return 0;
+}
+
+extern "C" int nlbac_cars_rollout_inputs(const float* mb, int ld, int t_col, int nt_col, const float* pi2, int B,
+                                         float* state, float* y0_2, float* c1, float* c2, nlbac_stream_t s) {
+    NLBAC_REQUIRE(mb && pi2 && state && y0_2 && c1 && c2 && B >= 1 && t_col >= 0 && nt_col >= 0 && t_col < ld &&
+                      nt_col < ld && ld >= 10, "nlbac_cars_rollout_inputs: bad arguments");
+    hipLaunchKernelGGL(cars_rollout_inputs_kernel, GRID1(B), mb, ld, t_col, nt_col, pi2, B, state, y0_2, c1, c2);
+    NLBAC_CHECK_LAUNCH("nlbac_cars_rollout_inputs");
     return 0;
 }
 

@@ -335,15 +335,9 @@ class CarsTask(_Task):
     def rollout_begin(self, ws, P):
         a, s = self.agent, stream_ptr()
         B, lay = ws.B, a.lay
-        _lib.call("nlbac_cars_state", ws.mb.data_ptr(), lay.LD, B, ws.state.data_ptr(), s)
-        ws.y0_2[:B].copy_(ws.state)
-        ws.y0_2[B:].copy_(ws.state)
-        t, nt = ws.mb[:, lay.t], ws.mb[:, lay.nt]
-        ws.c1[:, 0].copy_(ws.pi2[:, 0])
-        ws.c1[:B, 1].copy_(t)
-        ws.c1[B:, 1].copy_(t)
-        ws.c2[:B, 1].copy_(nt)
-        ws.c2[B:, 1].copy_(nt)
+        # state, its primary / backup copies and the carried [action, time] inputs of both steps: one launch
+        _lib.call("nlbac_cars_rollout_inputs", ws.mb.data_ptr(), lay.LD, lay.t, lay.nt, ws.pi2.data_ptr(), B,
+                  ws.state.data_ptr(), ws.y0_2.data_ptr(), ws.c1.data_ptr(), ws.c2.data_ptr(), s)
         self.solver1.forward_begin(ws.y0_2, ws.c1, 2, B, a.solver, float(self.env.dt), a.atol, a.rtol)
 
     def loss_and_backward(self, ws, P, lam_upd, assume_single):
