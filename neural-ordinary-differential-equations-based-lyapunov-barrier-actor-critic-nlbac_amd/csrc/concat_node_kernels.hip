@@ -31,7 +31,11 @@ struct ConcatRkLaunch {
     int ld;
 };
 
-__global__ __launch_bounds__(256) void concat_rk_fwd_kernel(const ConcatRkLaunch L) {
+// NTHR = threads per workgroup.  Measured on the 64-wide reference net (two column tiles): 128-thread workgroups — only
+// the two MFMA-carrying waves, twice as many workgroups per CU — are 7-12 % SLOWER than 256: the VALU phases (stage
+// input, output layer, top layer, dX, stage algebra) take as long as the MFMA chain and want all four waves.
+template <int NTHR>
+__global__ __launch_bounds__(NTHR) void concat_rk_fwd_kernel(const ConcatRkLaunch L) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int n = L.n, ns = L.n_s, nc = L.n_c, LD = L.ld;
@@ -55,10 +59,10 @@ __global__ __launch_bounds__(256) void concat_rk_fwd_kernel(const ConcatRkLaunch
         const float* W = net.params + net.w_off[nwide];
         const float* bsrc = net.params + net.b_off[nwide];
         const int nw = net.out_dim * hid;
-        for (int idx = tid; idx < nw; idx += 256) sW[idx] = W[idx];
-        for (int idx = tid; idx < net.out_dim; idx += 256) sW[nw + idx] = bsrc[idx];
+        for (int idx = tid; idx < nw; idx += NTHR) sW[idx] = W[idx];
+        for (int idx = tid; idx < net.out_dim; idx += NTHR) sW[nw + idx] = bsrc[idx];
     }
-    for (int idx = tid; idx < NLBAC_MLP_TILE * CK_NS; idx += 256) {
+    for (int idx = tid; idx < NLBAC_MLP_TILE * CK_NS; idx += NTHR) {
         const int m = idx / CK_NS, c = idx - m * CK_NS, row = row0 + m;
         sY0[idx] = (row < n && c < ns) ? L.y0[(long)row * ns + c] : 0.f;
     }
@@ -70,7 +74,7 @@ __global__ __launch_bounds__(256) void concat_rk_fwd_kernel(const ConcatRkLaunch
         const int p = min(row0 + tid, n - 1) / L.rpp;
         sH[tid] = L.h_dev ? (float)L.h_dev[(long)p * L.h_stride] : L.h_val[p];
     }
-    for (int idx = tid; idx < L.stage_begin * NLBAC_MLP_TILE * CK_NS; idx += 256) {      // stages of an earlier launch
+    for (int idx = tid; idx < L.stage_begin * NLBAC_MLP_TILE * CK_NS; idx += NTHR) {      // stages of an earlier launch
         const int j = idx / (NLBAC_MLP_TILE * CK_NS), rem = idx - j * NLBAC_MLP_TILE * CK_NS;
         const int m = rem / CK_NS, c = rem - m * CK_NS, row = row0 + m;
         sK[idx] = (row < n && c < ns) ? L.K[((long)j * n + row) * ns + c] : 0.f;
@@ -81,7 +85,7 @@ __global__ __launch_bounds__(256) void concat_rk_fwd_kernel(const ConcatRkLaunch
         // ---- stage input [Y_st | c],  Y_st = y0 + h sum_j beta[st][j] K_j   (same op order as rk_combine_kernel)
         float* in = buf;
         float* out = buf + NLBAC_MLP_TILE * LD;
-        for (int idx = tid; idx < NLBAC_MLP_TILE * inp; idx += 256) {
+        for (int idx = tid; idx < NLBAC_MLP_TILE * inp; idx += NTHR) {
             const int m = idx / inp, c = idx - m * inp;
             float a = 0.f;
             if (c < ns) {
@@ -101,7 +105,7 @@ __global__ __launch_bounds__(256) void concat_rk_fwd_kernel(const ConcatRkLaunch
         fwd_wide_layers<1, 0>(wg, net, active, wave, lane, LD, inp, in, out, acts_tile, L.acts_ls, n_rows, nwide,
                               st + 1 < L.stage_end);
         // ---- output layer: k_st
-        for (int idx = tid; idx < NLBAC_MLP_TILE * net.out_dim; idx += 256) {
+        for (int idx = tid; idx < NLBAC_MLP_TILE * net.out_dim; idx += NTHR) {
             const int m = idx & 31, o = idx >> 5, row = row0 + m;
             const float val = skinny_row_dot(in + m * LD, sW + o * hid, hid) + sW[net.out_dim * hid + o];
             sK[(st * NLBAC_MLP_TILE + m) * CK_NS + o] = val;
@@ -111,7 +115,7 @@ __global__ __launch_bounds__(256) void concat_rk_fwd_kernel(const ConcatRkLaunch
     }
 
     // ---- step outputs
-    for (int idx = tid; idx < NLBAC_MLP_TILE * ns; idx += 256) {
+    for (int idx = tid; idx < NLBAC_MLP_TILE * ns; idx += NTHR) {
         const int m = idx / ns, r = idx - m * ns, row = row0 + m;
         if (row >= n) continue;
         const float h = sH[m];
@@ -149,7 +153,8 @@ struct ConcatRkBwdLaunch {
     int ld;
 };
 
-__global__ __launch_bounds__(256) void concat_rk_bwd_kernel(const ConcatRkBwdLaunch L) {
+template <int NTHR>
+__global__ __launch_bounds__(NTHR) void concat_rk_bwd_kernel(const ConcatRkBwdLaunch L) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int n = L.n, ns = L.n_s, nc = L.n_c, LD = L.ld;
@@ -179,8 +184,8 @@ __global__ __launch_bounds__(256) void concat_rk_bwd_kernel(const ConcatRkBwdLau
     {
         const float* Wl = net.params + net.w_off[nwide];
         const float* W0 = net.params + net.w_off[0];
-        for (int idx = tid; idx < net.out_dim * hid; idx += 256) sW[idx] = Wl[idx];
-        for (int idx = tid; idx < net.in_dim * hid; idx += 256) {
+        for (int idx = tid; idx < net.out_dim * hid; idx += NTHR) sW[idx] = Wl[idx];
+        for (int idx = tid; idx < net.in_dim * hid; idx += NTHR) {
             const int i = idx / hid, k = idx - i * hid;
             sW0t[idx] = W0[(long)k * net.in_dim + i];
         }
@@ -189,7 +194,7 @@ __global__ __launch_bounds__(256) void concat_rk_bwd_kernel(const ConcatRkBwdLau
         const int m = tid / CK_NC, c = tid - m * CK_NC, row = row0 + m;
         sDC[tid] = (row < n && c < nc && L.dc && L.dc_acc) ? L.dc[(long)row * nc + c] : 0.f;
     }
-    for (int idx = tid; idx < NLBAC_MLP_TILE * CK_NS; idx += 256) {
+    for (int idx = tid; idx < NLBAC_MLP_TILE * CK_NS; idx += NTHR) {
         const int m = idx / CK_NS, c = idx - m * CK_NS, row = row0 + m;
         sDY0[idx] = (row < n && c < ns && L.dy0 && L.dy0_in) ? L.dy0[(long)row * ns + c] : 0.f;
     }
@@ -197,7 +202,7 @@ __global__ __launch_bounds__(256) void concat_rk_bwd_kernel(const ConcatRkBwdLau
         const int p = min(row0 + tid, n - 1) / L.rpp;
         sH[tid] = L.h_dev ? (float)L.h_dev[(long)p * L.h_stride] : L.h_val[p];
     }
-    for (int idx = tid; idx < L.st_hi * NLBAC_MLP_TILE * CK_NS; idx += 256) {
+    for (int idx = tid; idx < L.st_hi * NLBAC_MLP_TILE * CK_NS; idx += NTHR) {
         const int j = idx / (NLBAC_MLP_TILE * CK_NS), rem = idx - j * NLBAC_MLP_TILE * CK_NS;
         const int m = rem / CK_NS, c = rem - m * CK_NS, row = row0 + m;
         sDK[idx] = (row < n && c < ns) ? L.dK[((long)j * n + row) * ns + c] : 0.f;
@@ -207,10 +212,10 @@ __global__ __launch_bounds__(256) void concat_rk_bwd_kernel(const ConcatRkBwdLau
     for (int st = L.st_hi - 1; st >= L.st_lo; --st) {
         const bool data = ck_has_data(st);
         const float* acts_tile = L.acts + ((long)st * n + row0) * hid;
-        float av_top[16];            // <= 128 padded columns: two row groups of 16 rows cover the tile
-        if (data) node_top_masks<16, 0>(acts_tile + (long)(nwide - 1) * ls, hid, NT, tid, n_rows, av_top);
+        float av_top[16];            // NTHR / 2 padded columns x two row groups of 16 rows cover the tile
+        if (data) node_top_masks<16, 0, NTHR>(acts_tile + (long)(nwide - 1) * ls, hid, NT, tid, n_rows, av_top);
         __builtin_amdgcn_sched_barrier(0);
-        for (int rem = tid; rem < NLBAC_MLP_TILE * 16; rem += 256) {
+        for (int rem = tid; rem < NLBAC_MLP_TILE * 16; rem += NTHR) {
             const int m = rem >> 4, o = rem & 15;
             sdy[rem] = (o < ns) ? sDK[(st * NLBAC_MLP_TILE + m) * CK_NS + o] : 0.f;
         }
@@ -218,25 +223,25 @@ __global__ __launch_bounds__(256) void concat_rk_bwd_kernel(const ConcatRkBwdLau
         __syncthreads();
         float* in = buf;
         float* out = buf + NLBAC_MLP_TILE * LD;
-        node_top_layer<16, 0>(sdy, sW, net.out_dim, hid, hidp32, NT, tid, n_rows, av_top, in, LD);
+        node_top_layer<16, 0, NTHR>(sdy, sW, net.out_dim, hid, hidp32, NT, tid, n_rows, av_top, in, LD);
         __syncthreads();
-        if (keep_dz) tile_to_global(in, LD, L.dz + (long)(nwide - 1) * ls + ((long)st * n + row0) * hid, hid, n_rows, tid, 256);
+        if (keep_dz) tile_to_global(in, LD, L.dz + (long)(nwide - 1) * ls + ((long)st * n + row0) * hid, hid, n_rows, tid, NTHR);
         {
             float* dz_tile = keep_dz ? L.dz + ((long)st * n + row0) * hid : nullptr;
             bwd_wide_layers<1, 0>(wg, net, active, wave, lane, LD, in, out, acts_tile, dz_tile, ls, n_rows, n_rows - 1,
-                                  nwide - 1, ck_has_data(st - 1), 256);
+                                  nwide - 1, ck_has_data(st - 1), NTHR);
         }
         if (st == 0 && !L.dx_stage0) continue;       // only the dz of stage 0 were wanted (uniform)
 
         // ---- dX = dz0 W_0: state columns -> sDX, carried columns accumulate (always the same thread per entry)
-        for (int idx = tid; idx < NLBAC_MLP_TILE * net.in_dim; idx += 256) {
+        for (int idx = tid; idx < NLBAC_MLP_TILE * net.in_dim; idx += NTHR) {
             const int m = idx & 31, i = idx >> 5;
             const float v = skinny_row_dot(in + m * LD, sW0t + i * hid, hid);
             if (i < ns) sDX[m * CK_NS + i] = v;
             else sDC[m * CK_NC + (i - ns)] += v;
         }
         __syncthreads();
-        for (int idx = tid; idx < NLBAC_MLP_TILE * ns; idx += 256) {
+        for (int idx = tid; idx < NLBAC_MLP_TILE * ns; idx += NTHR) {
             const int m = idx / ns, c = idx - m * ns, row = row0 + m;
             float d = (L.dYup && st == L.S_total - 1 && row < n) ? L.dYup[(long)row * ns + c] : 0.f;
             d += sDX[m * CK_NS + c];
@@ -248,18 +253,18 @@ __global__ __launch_bounds__(256) void concat_rk_bwd_kernel(const ConcatRkBwdLau
         __syncthreads();
     }
     __syncthreads();
-    for (int idx = tid; idx < L.st_hi * NLBAC_MLP_TILE * ns; idx += 256) {
+    for (int idx = tid; idx < L.st_hi * NLBAC_MLP_TILE * ns; idx += NTHR) {
         const int j = idx / (NLBAC_MLP_TILE * ns), rem = idx - j * NLBAC_MLP_TILE * ns;
         const int m = rem / ns, c = rem - m * ns, row = row0 + m;
         if (row < n) L.dK[((long)j * n + row) * ns + c] = sDK[(j * NLBAC_MLP_TILE + m) * CK_NS + c];
     }
     if (L.dy0)
-        for (int idx = tid; idx < NLBAC_MLP_TILE * ns; idx += 256) {
+        for (int idx = tid; idx < NLBAC_MLP_TILE * ns; idx += NTHR) {
             const int m = idx / ns, c = idx - m * ns, row = row0 + m;
             if (row < n) L.dy0[(long)row * ns + c] = sDY0[m * CK_NS + c];
         }
     if (L.dc)
-        for (int idx = tid; idx < NLBAC_MLP_TILE * nc; idx += 256) {
+        for (int idx = tid; idx < NLBAC_MLP_TILE * nc; idx += NTHR) {
             const int m = idx / nc, c = idx - m * nc, row = row0 + m;
             if (row < n) L.dc[(long)row * nc + c] = sDC[m * CK_NC + c];
         }
@@ -310,7 +315,7 @@ extern "C" int nlbac_concat_rk_fwd(const nlbac_mlp* net, const float* y0, const 
     const size_t lds = ((size_t)2 * NLBAC_MLP_TILE * L.ld + CK_MAX_STAGES * NLBAC_MLP_TILE * CK_NS +
                         NLBAC_MLP_TILE * (CK_NS + CK_NC + 1) + ((net->out_dim * (net->hid + 1) + 3) & ~3)) * sizeof(float);
     NLBAC_REQUIRE(lds <= 64 * 1024, "nlbac_concat_rk_fwd: LDS budget exceeded (%zu B)", lds);
-    hipLaunchKernelGGL(concat_rk_fwd_kernel, dim3(nlbac_ceil_div(L.n, NLBAC_MLP_TILE)), dim3(256), lds, (hipStream_t)s, L);
+    hipLaunchKernelGGL(concat_rk_fwd_kernel<256>, dim3(nlbac_ceil_div(L.n, NLBAC_MLP_TILE)), dim3(256), lds, (hipStream_t)s, L);
     NLBAC_CHECK_LAUNCH("nlbac_concat_rk_fwd");
     return 0;
 }
@@ -342,7 +347,7 @@ extern "C" int nlbac_concat_rk_bwd(const nlbac_mlp* net, int P, int rows_per_pro
                         NLBAC_MLP_TILE * (1 + CK_NS + CK_NC + CK_NS + 16) +
                         (((net->out_dim + net->in_dim) * net->hid + 3) & ~3)) * sizeof(float);
     NLBAC_REQUIRE(lds <= 64 * 1024, "nlbac_concat_rk_bwd: LDS budget exceeded (%zu B)", lds);
-    hipLaunchKernelGGL(concat_rk_bwd_kernel, dim3(nlbac_ceil_div(L.n, NLBAC_MLP_TILE)), dim3(256), lds, (hipStream_t)s, L);
+    hipLaunchKernelGGL(concat_rk_bwd_kernel<256>, dim3(nlbac_ceil_div(L.n, NLBAC_MLP_TILE)), dim3(256), lds, (hipStream_t)s, L);
     NLBAC_CHECK_LAUNCH("nlbac_concat_rk_bwd");
     return 0;
 }

@@ -383,10 +383,10 @@ __device__ __forceinline__ void bwd_wide_layers(WaveGemm<NTW>& wg, const nlbac_m
 // RPT rows per thread: the 256 threads of a group cover (32 / RPT) row groups x (256 * RPT / 32) columns.
 // ReLU masks of the top hidden layer for this thread's (row group, column): issued at the start of a stage so that their
 // global latency (~2k cycles) hides under the output-gradient fill and the first barrier.
-template <int RPT, int BITS>
+template <int RPT, int BITS, int NTHR = 256>
 __device__ __forceinline__ void node_top_masks(const float* __restrict__ atop, int hid, int NT, int t, int n_rows,
                                                float (&av)[RPT]) {
-    constexpr int CPG = 256 * RPT / 32;
+    constexpr int CPG = NTHR * RPT / 32;
     const int k = t % CPG, m0 = (t / CPG) * RPT, kc = min(k, hid - 1);
     if constexpr (BITS != 0) {
         const unsigned* mtop = reinterpret_cast<const unsigned*>(atop) + (kc >> 5);
@@ -399,11 +399,11 @@ __device__ __forceinline__ void node_top_masks(const float* __restrict__ atop, i
     }
 }
 
-template <int RPT, int BITS>
+template <int RPT, int BITS, int NTHR = 256>
 __device__ __forceinline__ void node_top_layer(const float* __restrict__ sdy, const float* __restrict__ sW, int out_dim,
                                                int hid, int hidp32, int NT, int t, int n_rows,
                                                const float (&av)[RPT], float* __restrict__ in, int LD) {
-    constexpr int CPG = 256 * RPT / 32;            // columns per row group
+    constexpr int CPG = NTHR * RPT / 32;           // columns per row group
     const int k = t % CPG, m0 = (t / CPG) * RPT, kc = min(k, hid - 1);
     float s[RPT];
 #pragma unroll
