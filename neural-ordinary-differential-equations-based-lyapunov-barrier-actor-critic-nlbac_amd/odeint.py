@@ -44,14 +44,45 @@ TABLEAU = {
 }
 
 
+class _Store:
+    """Backing storage of one step workspace, sized for ``cap >= n`` rows.  The buffers of a workspace are laid out for
+    an exact row count n (stage-major, the kernels index them with n), so a workspace for another n of the same
+    capacity bucket is a fresh set of VIEWS over the same allocations: the k-th buffer a workspace asks for is the
+    k-th allocation of the store.  A NODE fit whose batch grows by a few rows every time (the replay filling up) then
+    costs no allocation and no fill."""
+
+    def __init__(self, device, n, cap):
+        self.device, self.n, self.cap = device, n, cap
+        self.flat, self.k = [], 0
+
+    def rebind(self, n):
+        assert n <= self.cap
+        self.n, self.k = n, 0
+        return self
+
+    def zeros(self, *shape, dtype=torch.float32):
+        numel = 1
+        for d in shape:
+            numel *= d
+        need = -(-numel * self.cap // self.n)          # every buffer is linear in the row count
+        if self.k == len(self.flat):
+            self.flat.append(torch.zeros(need, dtype=dtype, device=self.device))
+        t = self.flat[self.k]
+        if t.numel() < need or t.dtype != dtype:        # (another solver mode asked for a different buffer here)
+            t = self.flat[self.k] = torch.zeros(need, dtype=dtype, device=self.device)
+        self.k += 1
+        return t[:numel].view(*shape)
+
+
 class _StepWS:
     """Device buffers of one RK step for n rows (stage-major)."""
 
-    def __init__(self, solver, n, S):
+    def __init__(self, solver, n, S, store=None):
         dev, ns, nu = solver.device, solver.n_s, solver.n_u
         f, g = solver.f, solver.g
         self.n, self.S = n, S
-        z = lambda *s: torch.zeros(*s, dtype=torch.float32, device=dev)
+        self._store = store if store is not None else _Store(dev, n, n)
+        z = self._store.zeros
         self.K = z(S, n, ns)
         self.Y = z(S, n, ns)
         self.fout = z(n, ns)
@@ -60,7 +91,7 @@ class _StepWS:
         # hidden units) instead of the activations: 1/32 of the HBM traffic of the fused step kernels
         self.bits = bool(solver.fused and not solver.keep_acts)
         if self.bits:
-            zi = lambda *s: torch.zeros(*s, dtype=torch.int32, device=dev)
+            zi = lambda *s: self._store.zeros(*s, dtype=torch.int32)
             self.wf, self.wg = (f.hid + 31) // 32, (g.hid + 31) // 32
             self.acts_f = zi(f.n_layers - 1, S * n, self.wf)
             self.acts_g = zi(g.n_layers - 1, S * n, self.wg)
@@ -77,7 +108,7 @@ class _StepWS:
         if self._bwd is None:
             dev, ns, nu, n, S = solver.device, solver.n_s, solver.n_u, self.n, self.S
             f, g = solver.f, solver.g
-            z = lambda *s: torch.zeros(*s, dtype=torch.float32, device=dev)
+            z = self._store.zeros
             self.dK = z(S, n, ns)
             keep = solver.keep_acts or not solver.fused      # weight gradients / the stage-by-stage path need dz
             self.dG = z(S, n, ns * nu) if keep else None
@@ -111,17 +142,52 @@ class AffineNodeSolver:
         self.comm = None       # nlbac_amd.parallel.DataParallel: global dopri5 error norms
 
     # -- workspace -----------------------------------------------------------
+    MAX_SIZES = 2      # distinct row counts whose buffers are kept (the NODE fit's batch grows with the replay)
+
+    def _touch(self, n):
+        """Start of a solve on n rows: make n the current size and drop the buffers of the least recently used sizes
+        beyond ``MAX_SIZES`` — workspaces are laid out for an exact row count, and a training run feeds the NODE fit
+        min(replay size, 32768) rows, a new count at every fit while the replay fills."""
+        order = self.__dict__.setdefault("_n_order", [])
+        if n in order:
+            order.remove(n)
+        order.append(n)
+        while len(order) > self.MAX_SIZES:
+            old = order.pop(0)
+            for k in [k for k in self._ws if k[0] == old]:
+                del self._ws[k]
+            self._scratch.pop(old, None)
+        self._cur_n = n
+
+    @staticmethod
+    def _bucket(n):
+        return n if n <= 4096 else -(-n // 4096) * 4096
+
     def _step_ws(self, n, S, idx):
         key = (n, S, idx)
-        if key not in self._ws:
-            self._ws[key] = self.STEP_WS(self, n, S)
-        return self._ws[key]
+        ws = self._ws.get(key)
+        if ws is None:
+            # one live workspace per (capacity bucket, S, idx): the views of the previous row count go, storage stays
+            skey = (self._bucket(n), S, idx, self.fused, self.keep_acts)
+            stores = self.__dict__.setdefault("_stores", {})
+            st = stores.get(skey)
+            if st is None:
+                buckets = list(dict.fromkeys(k[0] for k in stores))          # in order of first use
+                if skey[0] not in buckets and len(buckets) >= self.MAX_SIZES:
+                    for k in [k for k in stores if k[0] == buckets[0]]:      # the oldest bucket goes, whole
+                        del stores[k]
+                st = stores[skey] = _Store(self.device, n, skey[0])
+            for k in [k for k, w in self._ws.items() if w._store is st]:
+                del self._ws[k]
+            ws = self._ws[key] = self.STEP_WS(self, n, S, st.rebind(n))
+        return ws
 
     def reserve(self, n, P, method, steps=2):
         """Allocate the buffers of a solve on n rows / P problems ahead of time: the step workspaces of the first
         ``steps`` accepted dopri5 steps (forward and backward halves) and, for P > 1, those of the per-problem fallback
         solvers — so that the first multi-step or diverging solve of a run does not pay tens of milliseconds of
         allocation in the middle of training."""
+        self._touch(n)
         if method != "dopri5":
             S = len(TABLEAU[method]["c_sol"])
             self._step_ws(n, S, 0).bwd(self)
@@ -142,10 +208,12 @@ class AffineNodeSolver:
                 k.reserve(n // P, 1, method, steps)
 
     def _buf(self, name, *shape, dtype=torch.float32):
+        """Named scratch buffer of the current solve size (dropped with that size's workspaces, see ``_touch``)."""
+        pool = self._scratch.setdefault(self.__dict__.get("_cur_n", 0), {})
         key = (name, shape, dtype)
-        if key not in self._scratch:
-            self._scratch[key] = torch.zeros(*shape, dtype=dtype, device=self.device)
-        return self._scratch[key]
+        if key not in pool:
+            pool[key] = torch.zeros(*shape, dtype=dtype, device=self.device)
+        return pool[key]
 
     # -- one field evaluation k = f(x) + g(x) u -----------------------------------
     def _nets(self):
@@ -176,9 +244,10 @@ class AffineNodeSolver:
 
     def _probe_eval(self, ytmp, u, n, ktmp, gtmp):
         """field evaluation outside the step workspaces (dopri5 initial-step probe), nothing saved"""
-        tio = self._scratch.setdefault("tmp_io", {}).get(n)
+        pool = self._scratch.setdefault(self.__dict__.get("_cur_n", 0), {})
+        tio = pool.get(("tmp_io", n))
         if tio is None:
-            tio = self._scratch["tmp_io"][n] = self._eval_io(ytmp, gtmp)
+            tio = pool[("tmp_io", n)] = self._eval_io(ytmp, gtmp)
         self._eval(ytmp, u, n, ktmp, gtmp, tio)
 
     def _stage_eval(self, ws, st, u):
@@ -249,6 +318,7 @@ class AffineNodeSolver:
         accept/reject decision of the first attempted step); euler/rk4 run to completion.  No host sync."""
         n = P * rpp
         assert y0.shape == (n, self.n_s) and u.shape == (n, self.n_u)
+        self._touch(n)
         self.stats["solves"] += 1
         self.ctx = dict(method=method, P=P, rpp=rpp, n=n, u=u, y0=y0, steps=[], t_end=float(dt), atol=atol,
                         rtol=rtol)
@@ -649,11 +719,12 @@ class AffineNodeSolver:
 # (SimulatedCars: C/sac_cbf_clf/model.py:179-205).  Same RK machinery, stage by stage on nlbac_mlp_*.
 # ---------------------------------------------------------------------------
 class _ConcatStepWS:
-    def __init__(self, solver, n, S):
+    def __init__(self, solver, n, S, store=None):
         dev, ns, nc = solver.device, solver.n_s, solver.n_u
         net = solver.net
         self.n, self.S = n, S
-        z = lambda *s: torch.zeros(*s, dtype=torch.float32, device=dev)
+        self._store = store if store is not None else _Store(dev, n, n)
+        z = self._store.zeros
         self.K = z(S, n, ns)
         self.Y = z(S, n, ns)
         self.acts = z(net.n_layers - 1, S * n, net.hid)
@@ -666,7 +737,7 @@ class _ConcatStepWS:
         if self._bwd is None:
             dev, ns, nc, n, S = solver.device, solver.n_s, solver.n_u, self.n, self.S
             net = solver.net
-            z = lambda *s: torch.zeros(*s, dtype=torch.float32, device=dev)
+            z = self._store.zeros
             self.dK = z(S, n, ns)
             self.dz = z(net.n_layers - 1, S * n, net.hid)
             self.dX = z(n, net.in_dim)

@@ -444,6 +444,8 @@ class SAC_CBF_CLF(object):
     def _fit(self, p_obs, obs_ld, action, p_nobs, nobs_ld, N):
         task = self.task
         if N not in self._fit_ws:
+            while len(self._fit_ws) >= 2:       # the fit batch grows with the replay: keep the two latest sizes only
+                self._fit_ws.pop(next(iter(self._fit_ws)))
             w = task.fit_ws(N)
             w.update(graphs={}, warm=0)
             self._fit_ws[N] = w

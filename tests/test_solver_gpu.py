@@ -93,3 +93,31 @@ def test_problems_that_diverge_fall_back_to_per_problem_solves():
         vec_close(out[rows].cpu().numpy(), out_o.numpy(), TOL, "x(T) problem %d" % p)
         rows_close(dy0[rows].cpu().numpy(), dy0_o.numpy(), "d/dy0 problem %d" % p)
         rows_close(du[rows].cpu().numpy(), du_o.numpy(), "d/du problem %d" % p)
+
+
+def test_workspaces_of_a_growing_node_fit_batch_stay_bounded():
+    """The driver fits the NODE on min(replay size, 32768) rows — a different row count at every fit while the replay
+    fills.  Step workspaces are laid out per row count: they are views over storage sized per 4096-row bucket, and only
+    the most recent sizes are kept, so device memory follows the CURRENT batch, not the number of sizes seen — and
+    the result of a fit does not depend on what the storage held before."""
+    agent, env = make_agent(64, 64, 0, "dopri5")
+    tr = synth.transitions("Unicycle", 12000, seed=2, env=env)
+    rows = agent._rows_from_host(tuple(tr[f] for f in synth.FIELDS)).to(agent.device)
+    sizes = [5000 + 173 * i for i in range(30)]
+    marks = []
+    for N in sizes:
+        agent.fit_node_rows(rows[:N])
+        torch.cuda.synchronize()
+        marks.append(torch.cuda.memory_allocated())
+    sv = agent.fit_solver
+    assert len({k[0] for k in sv._ws}) <= sv.MAX_SIZES and len(agent._fit_ws) <= 2
+    assert marks[-1] < 3.0 * marks[0], marks            # 30 sizes, 2x the rows: nowhere near 30x the memory
+    # same sequence of fits on a fresh agent that only ever sees the final size: identical parameters
+    fresh, _ = make_agent(64, 64, 0, "dopri5")
+    for N in sizes[:-1]:
+        pass
+    a2, _ = make_agent(64, 64, 0, "dopri5")
+    for N in sizes:
+        a2.fit_node_rows(rows[:N])
+    torch.cuda.synchronize()
+    assert torch.equal(a2.ar_n.theta, agent.ar_n.theta)
