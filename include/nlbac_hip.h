@@ -348,6 +348,11 @@ int nlbac_dopri_interp_bwd(const float *dout, const float *h_host, const float *
                            int P, int rows_per_problem, int n_s, float *dy0, float *dy1, float *dK,
                            nlbac_stream_t s);
 
+/* Strided block copy of 32-bit words: block b (block_len words) from src + b*src_stride to dst + b*dst_stride —
+ * a row range of a stage-major solver buffer in one launch (hands a problem's first attempted dopri5 step to its
+ * own solver when the problems of a joint solve stop agreeing on accept / done). */
+int nlbac_copy_blocks(const void *src, long src_stride, void *dst, long dst_stride, long block_len, long n_blocks,
+                      nlbac_stream_t s);
 /* Replay minibatch gather on the device (replay_memory.py:21-25): dst[r] = src[idx[r]] for n_rows rows of ld floats
  * (ld % 4 == 0; idx are int64 row numbers in [0, src_rows)). */
 int nlbac_gather_rows(const float *src, long src_rows, int ld, const long *idx, long n_rows, float *dst,

@@ -89,6 +89,7 @@ _PROTOS = {
     "nlbac_pvtol_obs_bwd": [_P, _P, _I, _F, _F, _F, _I, _P, _I, _P],
     "nlbac_pvtol_constraints_fwd": [_P, _P, _P, _P, _P, _P, _P, _P, _I, _F, _F, _F, _F, _F, _F, _F, _I, _I, _P, _P, _P, _P],
     "nlbac_pvtol_constraints_bwd": [_P, _P, _P, _P, _P, _P, _I, _F, _F, _F, _I, _I, _P, _P, _P, _P, _P, _P],
+    "nlbac_copy_blocks": [_P, _L, _P, _L, _L, _L, _P],
     "nlbac_gather_rows": [_P, _L, _I, _P, _L, _P, _P],
     "nlbac_sample_rows": [_P, _L, _I, _L, _P, _P, _L, C.c_uint64, C.c_uint64, _P],
     "nlbac_td_value": [_P, _P, _I, _P, _I, _P, _F, _I, _I, _P, _P, _P, _P],

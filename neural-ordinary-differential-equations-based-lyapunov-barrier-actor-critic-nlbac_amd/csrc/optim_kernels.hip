@@ -362,6 +362,28 @@ extern "C" int nlbac_sample_rows(const float* src, long src_rows, int ld, long n
     return 0;
 }
 
+// n_blocks blocks of block_len contiguous dwords each, block b at src + b * src_stride -> dst + b * dst_stride
+// (a row range of a stage-major buffer: one block per stage).  Moves bits: float and int32 buffers alike.
+__global__ __launch_bounds__(256) void copy_blocks_kernel(const float* __restrict__ src, long src_stride,
+                                                          float* __restrict__ dst, long dst_stride, long block_len,
+                                                          long n_blocks) {
+    const long total = block_len * n_blocks, stride = (long)gridDim.x * 256;
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < total; i += stride) {
+        const long b = i / block_len, j = i - b * block_len;
+        dst[b * dst_stride + j] = src[b * src_stride + j];
+    }
+}
+
+extern "C" int nlbac_copy_blocks(const void* src, long src_stride, void* dst, long dst_stride, long block_len,
+                                 long n_blocks, nlbac_stream_t s) {
+    NLBAC_REQUIRE(src && dst && block_len >= 1 && n_blocks >= 1 && src_stride >= block_len && dst_stride >= block_len,
+                  "nlbac_copy_blocks: bad arguments");
+    hipLaunchKernelGGL(copy_blocks_kernel, dim3(stream_grid(block_len * n_blocks)), dim3(256), 0, (hipStream_t)s,
+                       (const float*)src, src_stride, (float*)dst, dst_stride, block_len, n_blocks);
+    NLBAC_CHECK_LAUNCH("nlbac_copy_blocks");
+    return 0;
+}
+
 extern "C" int nlbac_gather_rows(const float* src, long src_rows, int ld, const long* idx, long n_rows, float* dst,
                                  nlbac_stream_t s) {
     NLBAC_REQUIRE(src && idx && dst && src_rows >= 1 && n_rows >= 1, "nlbac_gather_rows: bad arguments");

@@ -76,6 +76,8 @@ class _Store:
 
 class _StepWS:
     """Device buffers of one RK step for n rows (stage-major)."""
+    # what a per-problem solver takes over from a joint first attempt: (buffer, leading blocks per row range)
+    ADOPT = ("K", "Y", "gout", "err", "acts_f", "acts_g")
 
     def __init__(self, solver, n, S, store=None):
         dev, ns, nu = solver.device, solver.n_s, solver.n_u
@@ -526,7 +528,7 @@ class AffineNodeSolver:
             acc = [bool(c[p, 3] > 0) for p in range(P)]
             done = [bool(c[p, 4] > 0) for p in range(P)]
             if any(a != acc[0] for a in acc) or any(d != done[0] for d in done):
-                return self._solve_split()
+                return self._solve_split(c if attempt == 0 else None)
             if attempt == 0 and acc[0] and done[0]:
                 return self._dopri_accept_first(c)
             info.append([(float(c[p, 11]), float(c[p, 2]), acc[p]) for p in range(P)])
@@ -551,10 +553,35 @@ class AffineNodeSolver:
             self._dopri_attempt(ws, cur_y0, u, P, rpp)
         raise _lib.NlbacError("dopri5: max_num_steps exceeded")
 
-    def _solve_split(self):
+    def _adopt_first_attempt(self, k, p, c):
+        """Hand per-problem solver ``k`` the joint first attempted step of problem ``p``: its rows of the step
+        workspace (stage derivatives, stage inputs, g(x), error estimate, activations / ReLU masks) and its control
+        block, so that it continues from the accept decision ``c`` instead of redoing f0, the probe and the attempt."""
+        ctx = self.ctx
+        P, rpp, n, S = ctx["P"], ctx["rpp"], ctx["n"], 7
+        rows = slice(p * rpp, (p + 1) * rpp)
+        src = self._step_ws(n, S, 0)
+        k._touch(rpp)
+        k.stats["solves"] += 1
+        k.ctx = dict(method="dopri5", P=1, rpp=rpp, n=rpp, u=ctx["u"][rows], y0=ctx["y0"][rows], steps=[],
+                     t_end=ctx["t_end"], atol=ctx["atol"], rtol=ctx["rtol"])
+        dst = k._step_ws(rpp, S, 0)
+        s = stream_ptr()
+        for name in src.ADOPT:
+            a, b = getattr(src, name), getattr(dst, name)
+            w = a.shape[-1]                               # [.., rows, w] with rows = n or S*n (stage-major)
+            blocks = a.numel() // (n * w)
+            _lib.call("nlbac_copy_blocks", a.data_ptr() + 4 * p * rpp * w, n * w, b.data_ptr(), rpp * w, rpp * w,
+                      blocks, s)
+        _lib.call("nlbac_copy_blocks", self._ctl(P).data_ptr() + 8 * _lib.DOPRI_CTL * p, 2 * _lib.DOPRI_CTL,
+                  k._ctl(1).data_ptr(), 2 * _lib.DOPRI_CTL, 2 * _lib.DOPRI_CTL, 1, s)
+        k.ctx["ctl_host"] = c[p:p + 1].clone()
+
+    def _solve_split(self, c=None):
         """The problems of one batch want different step sequences (one accepted / finished, another not):
-        each has its own adaptive step size in the reference too (separate odeint calls), so redo the solve
-        problem by problem with child solvers on the row ranges."""
+        each has its own adaptive step size in the reference too (separate odeint calls), so finish the solve
+        problem by problem with child solvers on the row ranges.  ``c``: host copy of the control block when the
+        disagreement shows at the first attempt — the children then take that attempt over; later ones start over."""
         ctx = self.ctx
         self.stats["split"] += 1
         P, rpp, n = ctx["P"], ctx["rpp"], ctx["n"]
@@ -568,8 +595,14 @@ class AffineNodeSolver:
             self._ctl_io(1)
             k._side, k._ev_ctl, k._ctl_pin = self._side, self._ev_ctl, self._ctl_pin
             rows = slice(p * rpp, (p + 1) * rpp)
-            o = k.forward(ctx["y0"][rows], ctx["u"][rows], 1, rpp, "dopri5", ctx["t_end"], ctx["atol"], ctx["rtol"])
-            out[rows].copy_(o)
+            if c is not None:
+                self.stats["adopted"] = self.stats.get("adopted", 0) + (1 if p == 0 else 0)
+                self._adopt_first_attempt(k, p, c)
+                o = k._dopri_continue()
+            else:
+                o = k.forward(ctx["y0"][rows], ctx["u"][rows], 1, rpp, "dopri5", ctx["t_end"], ctx["atol"], ctx["rtol"])
+            _lib.call("nlbac_copy_blocks", o.data_ptr(), o.numel(), out.data_ptr() + 4 * p * rpp * self.n_s, o.numel(),
+                      o.numel(), 1, stream_ptr())
             kids.append(k)
             info.append(k.ctx.get("info"))
         ctx.update(split=kids, out=out, steps=[], info_split=info)
@@ -719,6 +752,8 @@ class AffineNodeSolver:
 # (SimulatedCars: C/sac_cbf_clf/model.py:179-205).  Same RK machinery, stage by stage on nlbac_mlp_*.
 # ---------------------------------------------------------------------------
 class _ConcatStepWS:
+    ADOPT = ("K", "Y", "err", "acts")
+
     def __init__(self, solver, n, S, store=None):
         dev, ns, nc = solver.device, solver.n_s, solver.n_u
         net = solver.net
