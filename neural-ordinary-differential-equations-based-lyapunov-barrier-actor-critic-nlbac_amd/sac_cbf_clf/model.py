@@ -107,6 +107,41 @@ class GaussianPolicy(nn.Module):
         self.action_bias = self.action_bias.to(device)
         return super().to(device)
 
+    def act(self, state, evaluate=False):
+        """One action for one observation — the driver's per-env-step call (``select_action``, U/main.py:106).  Latency
+        path: pinned staging in and out, persistent device buffers and launch descriptor, three launches (policy
+        forward, N(0,1) draw, squashed-Gaussian head) and one read-back.  ``evaluate``: the deterministic action
+        tanh(mean)·scale + bias, i.e. the same head with a zero draw."""
+        A = self.num_actions
+        w = self.__dict__.get("_act_ws")
+        if w is None:
+            import types
+            dev = self.net.arena.device
+            obs = self.linear1.in_features
+            w = types.SimpleNamespace(
+                pin_in=torch.zeros(1, obs).pin_memory(), d_in=torch.zeros(1, obs, device=dev),
+                heads=torch.zeros(1, 2 * A, device=dev), eps=torch.zeros(1, A, device=dev),
+                action=torch.zeros(1, A, device=dev), logp=torch.zeros(1, device=dev),
+                pin_out=torch.zeros(1, A).pin_memory(), io=io_array(1), ev=torch.cuda.Event())
+            w.io[0].x0, w.io[0].x0_dim, w.io[0].x0_ld = w.d_in.data_ptr(), obs, obs
+            w.io[0].y, w.io[0].y_ld = w.heads.data_ptr(), 2 * A
+            w.np_in, w.np_out = w.pin_in.numpy(), w.pin_out.numpy()
+            w.nets = mlp_array([self.net.desc])
+            self.__dict__["_act_ws"] = w
+        w.np_in[0, :] = state                     # (float64 -> float32, as the reference's FloatTensor cast)
+        w.d_in.copy_(w.pin_in, non_blocking=True)
+        _lib.call("nlbac_mlp_fwd", w.nets, w.io, 1, 1, stream_ptr())
+        if evaluate:
+            w.eps.zero_()
+        else:
+            w.eps.normal_()
+        _lib.call("nlbac_gauss_sample_fwd", w.heads.data_ptr(), 2 * A, w.eps.data_ptr(), self.action_scale.data_ptr(),
+                  self.action_bias.data_ptr(), A, 1, w.action.data_ptr(), A, w.logp.data_ptr(), stream_ptr())
+        w.pin_out.copy_(w.action, non_blocking=True)
+        w.ev.record()
+        w.ev.synchronize()
+        return w.np_out[0].copy()
+
     def sample(self, state, eps=None):
         """(action, log_prob, tanh(mean)*scale+bias) for a (n, obs) device tensor."""
         n, A = state.shape[0], self.num_actions

@@ -349,6 +349,8 @@ class SAC_CBF_CLF(object):
 
     # --------------------------------------------------------- action selection
     def _select(self, policy, state, evaluate, warmup):
+        if not warmup and np.ndim(state) == 1:
+            return policy.act(np.asarray(state, dtype=np.float64), evaluate)      # one observation: the latency path
         state = to_tensor(np.asarray(state, dtype=np.float64), torch.FloatTensor, self.device)
         expand_dim = len(state.shape) == 1
         if expand_dim:

@@ -157,3 +157,30 @@ def test_lagged_loss_readback_returns_the_previous_update():
     assert r_lag[0] is None
     assert r_lag[1:] == r_sync[:3]
     assert torch.equal(c0, c1) and torch.equal(a0, a1)
+
+
+def test_select_action_latency_path_matches_the_policy_formula():
+    """``select_action`` on one observation (pinned staging, persistent buffers) against the oracle's policy head:
+    the deterministic action is tanh(mean)·scale + bias, the stochastic one is the squashed Gaussian at the draw the
+    call made; a batch of observations takes the tensor path and agrees with the single-observation path."""
+    from oracle import nlbac_oracle as O
+    agent, env = make_agent(8, 256, 0, "euler")
+    sd = {k: v.detach().cpu().clone() for k, v in agent.policy.state_dict().items()}
+    scale, bias = agent.policy.action_scale.cpu(), agent.policy.action_bias.cpu()
+    tr = synth.transitions("Unicycle", 16, seed=5, env=env)
+    for i in range(4):
+        obs = tr["obs"][i]
+        o32 = torch.tensor(obs, dtype=torch.float32)[None]
+        a_det = agent.select_action(obs, evaluate=True)
+        ref_det = O.policy_sample(sd, o32, torch.zeros(1, 2), scale, bias)[2][0].numpy()
+        np.testing.assert_allclose(a_det, ref_det, rtol=1e-5, atol=1e-6)
+        a = agent.select_action(obs)
+        eps = agent.policy._act_ws.eps.cpu()
+        ref = O.policy_sample(sd, o32, eps, scale, bias)[0][0].numpy()
+        np.testing.assert_allclose(a, ref, rtol=1e-5, atol=1e-6)
+        assert a.shape == (2,) and a.dtype == np.float32
+    batch = agent.select_action(tr["obs"][:4], evaluate=True)
+    singles = np.stack([agent.select_action(tr["obs"][i], evaluate=True) for i in range(4)])
+    np.testing.assert_allclose(batch, singles, rtol=1e-6, atol=1e-7)
+    with pytest.raises(AttributeError):
+        make_agent(8, 64, 0, "euler", "UnicycleBarrier")[0].select_action_backup(tr["obs"][0])
