@@ -10,5 +10,7 @@ pr.enable()
 train.main(argv)
 pr.disable()
 s = io.StringIO()
-pstats.Stats(pr, stream=s).sort_stats("cumulative").print_stats(38)
-print(s.getvalue()[:6500])
+st = pstats.Stats(pr, stream=s)
+st.sort_stats("cumulative").print_stats(24)
+st.sort_stats("tottime").print_stats(18)
+print(s.getvalue()[:9000])
