@@ -207,6 +207,7 @@ class AffineNodeSolver:
                 # stream and pinned blocks (a pinned allocation costs milliseconds)
                 self._ctl_io(1)
                 k._side, k._ev_ctl, k._ctl_pin = self._side, self._ev_ctl, self._ctl_pin
+                k.before_wait = self.__dict__.get("before_wait")
                 k.reserve(n // P, 1, method, steps)
 
     def _buf(self, name, *shape, dtype=torch.float32):
@@ -399,6 +400,9 @@ class AffineNodeSolver:
     def _ctl_read(self, P):
         """Host copy of the control block of the last attempted step."""
         if self.ctx.pop("ctl_pending", None) == P:
+            hook = self.__dict__.get("before_wait")
+            if hook is not None:
+                hook()                   # (the owner queues independent work behind the attempt before the host blocks)
             self._ev_ctl[1].synchronize()
             return self._ctl_pin[P].clone()
         return self._ctl(P).cpu()
@@ -594,6 +598,7 @@ class AffineNodeSolver:
             k.comm, k.fused, k.keep_acts = self.comm, self.fused, self.keep_acts
             self._ctl_io(1)
             k._side, k._ev_ctl, k._ctl_pin = self._side, self._ev_ctl, self._ctl_pin
+            k.before_wait = self.__dict__.get("before_wait")
             rows = slice(p * rpp, (p + 1) * rpp)
             if c is not None:
                 self.stats["adopted"] = self.stats.get("adopted", 0) + (1 if p == 0 else 0)

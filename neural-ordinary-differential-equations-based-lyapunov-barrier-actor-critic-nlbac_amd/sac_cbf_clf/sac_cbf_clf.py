@@ -19,6 +19,7 @@ object (``tasks.py``) chosen from ``env.dynamics_mode``; this file holds the sha
 actor step), see DESIGN.md §3.  Host<->device traffic per update: the minibatch upload (or 8 bytes per row of
 indices), one 512-byte scalars read-back and, for dopri5, one 256-byte control block per attempted step.
 """
+import collections
 import random
 import types
 
@@ -230,6 +231,9 @@ class SAC_CBF_CLF(object):
         self._ws = {}
         self._noise = None
         self._fit_ws = {}
+        self._fill = collections.deque()
+        for sv in self.task.solvers:          # independent launches go in just before a solver waits for a decision
+            sv.before_wait = self._fill_one
         self.use_graphs = False  # replay the update as hipGraphs (single GPU; see update_on_device)
         self.dp = None          # nlbac_amd.parallel.DataParallel when sharded over GPUs
         self._xb = {}
@@ -700,6 +704,26 @@ class SAC_CBF_CLF(object):
         # the rollout of the learned dynamics needs only pi(s) and the NODE: its first attempted step goes in here,
         # so that the critic phase below is queued behind it while the host waits for the accept decision
         self.task.rollout_begin(ws, P)
+        # The rest of part 1 does not depend on the rollout.  It is cut into three pieces that the solvers pull in one
+        # at a time just before each wait for an accept decision (``before_wait``), so that every attempted step —
+        # the second of a two-step solve, the second and third solve of Pvtol's chain — has work queued behind it;
+        # whatever is left goes in when the rollout is finished (``drain_fill``, called by the task).
+        self._fill = collections.deque((lambda: self._part1_targets(ws, P, B, G, LD, s),
+                                        lambda: self._part1_critic_step(ws, P, B, soft),
+                                        lambda: self._part1_actor_q(ws, P, B, G, NP, s)))
+        if self.solver != "dopri5" or torch.cuda.is_current_stream_capturing():
+            self.drain_fill()                   # no waits on this path (fixed-step solver / graph capture)
+
+    def _fill_one(self):
+        if self._fill:
+            self._fill.popleft()()
+
+    def drain_fill(self):
+        while self._fill:
+            self._fill.popleft()()
+
+    def _part1_targets(self, ws, P, B, G, LD, s):
+        sc, call = self.sc.data_ptr(), _lib.call
         call("nlbac_mlp_fwd", P.n_six, P.io_six, P.n_six_count, B, s)
         q = ws.q6
         call("nlbac_td_targets", q[0].data_ptr(), q[1].data_ptr(), q[2].data_ptr(), ws.nlogp.data_ptr(),
@@ -713,14 +737,17 @@ class SAC_CBF_CLF(object):
             call("nlbac_sum_partials", ws.part_tdx[k].data_ptr(), ws.nblk, 1, 1.0 / G, sc + 4 * SC.SC_XLOSS, s)
 
         # ---- B. critic / Lyapunov backward + Adam (+ Polyak targets) ---------------
-        n_crit = len(self.h_crit)
-        call("nlbac_mlp_bwd_data", P.n_crit, P.io_crit, n_crit, B, s)
+        call("nlbac_mlp_bwd_data", P.n_crit, P.io_crit, len(self.h_crit), B, s)
+
+    def _part1_critic_step(self, ws, P, B, soft):
         a = self.ar_c
-        bwd_weights(P.n_crit, P.io_crit, n_crit, B, a.n_slabs, a.n, self.device)
+        bwd_weights(P.n_crit, P.io_crit, len(self.h_crit), B, a.n_slabs, a.n, self.device)
         self._adam(a, self.critic_lyapunov_lr, a.n_slabs, extra=self.sc[SC.SC_QF1:SC.SC_QF1 + 3],
                    target=a.target.data_ptr(), tau=self.tau if soft else -1.0)
 
+    def _part1_actor_q(self, ws, P, B, G, NP, s):
         # ---- C. actors: Q(s, pi) with the stepped critics (the rollout was started in phase A) -----
+        sc, call = self.sc.data_ptr(), _lib.call
         call("nlbac_mlp_fwd", P.n_q5, P.io_q5, P.n_q5_count, B, s)
         call("nlbac_actor_q_terms", ws.qpi[0].data_ptr(), ws.qpi[1].data_ptr(), ws.logp2.data_ptr(),
              sc + 4 * SC.SC_ALPHA, B, G, NP, ws.dq_pi[0].data_ptr(), ws.dq_pi[1].data_ptr(), ws.part_q.data_ptr(), s)

@@ -138,6 +138,7 @@ class UnicycleTask(_Task):
         a, s, call = self.agent, stream_ptr(), _lib.call
         B, sc, dt = ws.B, a.sc.data_ptr(), float(self.env.dt)
         x_next2 = self.solver.forward_finish(assume_single_step=assume_single)
+        a.drain_fill()           # what is left of part 1 (critic step, Q(s, pi)): everything below uses the stepped nets
         call("nlbac_unicycle_lookahead", x_next2.data_ptr(), 2 * B, self.l_p, ws.ps_next2.data_ptr(), s)
         call("nlbac_mlp_fwd", P.n_l, P.io_vn, 1, B, s)
         r_coll = 1.05 * float(self.env.hazards_radius)
@@ -250,6 +251,7 @@ class UnicycleBarrierTask(UnicycleTask):
         pol = a.policy
         gx, gy = self.GOAL
         x_next = self.solver.forward_finish(assume_single_step=assume_single)
+        a.drain_fill()
         call("nlbac_unicycle_lookahead", x_next.data_ptr(), B, self.l_p, ws.ps_next.data_ptr(), s)
         call("nlbac_mlp_fwd", P.n_l, P.io_vn, 1, B, s)
         call("nlbac_unicycle_obs_fwd", x_next.data_ptr(), B, gx, gy, ws.obs_pred.data_ptr(), 7, s)
@@ -352,6 +354,7 @@ class CarsTask(_Task):
         call("nlbac_gauss_sample_fwd", ws.heads_nx.data_ptr(), 2, ws.eps[3:5].data_ptr(), pol.action_scale.data_ptr(),
              pol.action_bias.data_ptr(), 1, 2 * B, ws.c2.data_ptr(), 2, ws.logp_nx.data_ptr(), s)
         x2 = self.solver2.forward(ws.x1_2, ws.c2, 2, B, a.solver, dt, a.atol, a.rtol)
+        a.drain_fill()
         call("nlbac_mlp_fwd", P.n_l, P.io_v1, 1, B, s)
         call("nlbac_cars_constraints_fwd", ws.state.data_ptr(), ws.x1_2.data_ptr(), x2.data_ptr(), ws.V.data_ptr(),
              ws.V1.data_ptr(), float(a.gamma_b), self.gamma_l, self.collision_radius, B, ws.matr.data_ptr(),
@@ -509,6 +512,7 @@ class PvtolTask(_Task):
         call("nlbac_gauss_sample_fwd", ws.heads_n2.data_ptr(), 4, ws.eps[5:5 + NP].data_ptr(), p_scale, p_bias, 2, n,
              ws.a2.data_ptr(), 2, ws.logp_nx.data_ptr(), s)
         ws.x3[:n].copy_(s3.forward(ws.x2[:n], ws.a2[:n], NP, B, a.solver, dt, a.atol, a.rtol))
+        a.drain_fill()
         call("nlbac_mlp_fwd", P.n_l, P.io_v1, 1, B, s)
         hz = self.hazards.data_ptr()
         call("nlbac_pvtol_constraints_fwd", ws.st6.data_ptr(), ws.op0.data_ptr(), ws.x1.data_ptr(), ws.x2.data_ptr(),
@@ -640,6 +644,7 @@ class PvtolBarrierTask(PvtolTask):
         pol = a.policy
         follow, (gx, gy) = float(env.safety_operator_follow), self.GOAL
         x1 = self.solver.forward_finish(assume_single_step=assume_single)
+        a.drain_fill()
         call("nlbac_pvtol_obs_fwd", x1.data_ptr(), ws.op0.data_ptr(), B, follow, gx, gy, B, ws.obs_pred.data_ptr(), 11,
              None, s)
         call("nlbac_mlp_fwd", P.n_l, P.io_v1, 1, B, s)
