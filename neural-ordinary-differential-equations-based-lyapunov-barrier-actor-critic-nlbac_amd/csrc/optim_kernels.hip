@@ -88,9 +88,31 @@ __global__ __launch_bounds__(256) void adam_step_kernel(float* __restrict__ p, f
 // biases and skinny layers are read from the flat parameters).  Every workgroup derives the step constants from the
 // still un-incremented counter; the workgroup that finishes last publishes the new counter.
 __device__ __forceinline__ void scatter2(const unsigned long long* __restrict__ scat, long i, float val) {
-    const unsigned long long a = scat[2 * i], b = scat[2 * i + 1];
-    if (a) *reinterpret_cast<float*>(a) = val;
-    if (b) *reinterpret_cast<float*>(b) = val;
+    const ulonglong2 ab = reinterpret_cast<const ulonglong2*>(scat)[i];          // both slots of parameter i: one load
+    if (ab.x) *reinterpret_cast<float*>(ab.x) = val;
+    if (ab.y) *reinterpret_cast<float*>(ab.y) = val;
+}
+
+// sum of the gradient slabs at float4 index i, in slab order (the additions are sequential as before; the loads of
+// four slabs are issued together instead of one per loop trip - the trips were a chain of exposed memory latencies)
+__device__ __forceinline__ float4 slab_sum4(const float* __restrict__ grad, int n_slabs, long slab_stride, long i) {
+    float4 g = reinterpret_cast<const float4*>(grad)[i];
+    int s = 1;
+    for (; s + 3 < n_slabs; s += 4) {
+        const float4 a = reinterpret_cast<const float4*>(grad + (long)s * slab_stride)[i];
+        const float4 b = reinterpret_cast<const float4*>(grad + (long)(s + 1) * slab_stride)[i];
+        const float4 c = reinterpret_cast<const float4*>(grad + (long)(s + 2) * slab_stride)[i];
+        const float4 d = reinterpret_cast<const float4*>(grad + (long)(s + 3) * slab_stride)[i];
+        g.x += a.x; g.y += a.y; g.z += a.z; g.w += a.w;
+        g.x += b.x; g.y += b.y; g.z += b.z; g.w += b.w;
+        g.x += c.x; g.y += c.y; g.z += c.z; g.w += c.w;
+        g.x += d.x; g.y += d.y; g.z += d.z; g.w += d.w;
+    }
+    for (; s < n_slabs; ++s) {
+        const float4 a = reinterpret_cast<const float4*>(grad + (long)s * slab_stride)[i];
+        g.x += a.x; g.y += a.y; g.z += a.z; g.w += a.w;
+    }
+    return g;
 }
 
 __global__ __launch_bounds__(256) void adam_fused_kernel(float* __restrict__ p, float* __restrict__ m,
@@ -114,11 +136,7 @@ __global__ __launch_bounds__(256) void adam_fused_kernel(float* __restrict__ p, 
     const long n4 = n >> 2;
     const long stride = (long)gridDim.x * blockDim.x;
     for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += stride) {
-        float4 g = reinterpret_cast<const float4*>(grad)[i];
-        for (int s = 1; s < n_slabs; ++s) {
-            const float4 gs = reinterpret_cast<const float4*>(grad + s * slab_stride)[i];
-            g.x += gs.x; g.y += gs.y; g.z += gs.z; g.w += gs.w;
-        }
+        float4 g = slab_sum4(grad, n_slabs, slab_stride, i);
         float4 pp = reinterpret_cast<float4*>(p)[i];
         float4 mm = reinterpret_cast<float4*>(m)[i];
         float4 vv = reinterpret_cast<float4*>(v)[i];
