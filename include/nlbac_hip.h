@@ -77,6 +77,10 @@ typedef struct nlbac_mlp_io {
     float *dz;                          /* [n_layers-1][B][hid] pre-activation grads (bwd_data out, bwd_weights in) */
     float *dx; int dx_ld;               /* bwd_data out: (B, in_dim) or NULL        */
     float *grad;                        /* bwd_weights out: slab 0 of the flat grad (same offsets as params) */
+    float *skinny_ws;                   /* or NULL.  This net's block of the nlbac_mlp_bwd_weights workspace (ws +
+                                           i * ws_floats / n_nets): nlbac_mlp_bwd_data then leaves the per-32-row partial
+                                           sums of the bias / first- / last-layer gradients there (it has every dz tile
+                                           in LDS anyway) and nlbac_mlp_bwd_weights only reduces them.  B <= 32768. */
 } nlbac_mlp_io;
 
 /* number of floats nlbac_mlp_pack needs in `packed`, and the offsets it will use */

@@ -41,7 +41,8 @@ class MlpIO(C.Structure):
                 ("dy", C.c_void_p), ("dy_ld", C.c_int),
                 ("dz", C.c_void_p),
                 ("dx", C.c_void_p), ("dx_ld", C.c_int),
-                ("grad", C.c_void_p)]
+                ("grad", C.c_void_p),
+                ("skinny_ws", C.c_void_p)]
 
 
 _P, _I, _F, _D, _L = C.c_void_p, C.c_int, C.c_float, C.c_double, C.c_long

@@ -246,12 +246,29 @@ def pack(handles, target=False):
 _BW_WS = {}
 
 
-def bwd_weights(nets, io, n_nets, B, n_slabs, slab_stride, device):
-    """nlbac_mlp_bwd_weights with a cached per-device workspace for the skinny-gradient partials."""
+def skinny_partials_ws(nets, io_sets, n_nets, B, device):
+    """A workspace of ``nlbac_mlp_bwd_weights`` of its own for these nets, with every net's block entered into the
+    launch descriptors of ``io_sets`` (the data-backward's and the weight-backward's): ``nlbac_mlp_bwd_data`` then
+    leaves the skinny-gradient partial sums there and ``nlbac_mlp_bwd_weights(..., ws=<this>)`` only reduces them.
+    Returns None (separate partial pass) for batches / widths the fused form does not cover."""
+    if B > 32768 or any(nets[i].hid > 256 for i in range(n_nets)):
+        return None
+    need = _lib.load().nlbac_mlp_bwd_weights_ws_floats(nets, n_nets, B)
+    ws = torch.empty(max(need, 4), dtype=torch.float32, device=device)
+    for i in range(n_nets):
+        for io in io_sets:
+            io[i].skinny_ws = ws.data_ptr() + 4 * i * (need // n_nets)
+    return ws
+
+
+def bwd_weights(nets, io, n_nets, B, n_slabs, slab_stride, device, ws=None):
+    """nlbac_mlp_bwd_weights with a cached per-device workspace for the skinny-gradient partials (or the caller's,
+    see ``skinny_partials_ws``)."""
     lib = _lib.load()
     need = lib.nlbac_mlp_bwd_weights_ws_floats(nets, n_nets, B)
     key = str(device)
-    ws = _BW_WS.get(key)
+    if ws is None:
+        ws = _BW_WS.get(key)
     if ws is None or ws.numel() < need:
         ws = torch.empty(max(need, 1 << 20), dtype=torch.float32, device=device)
         _BW_WS[key] = ws

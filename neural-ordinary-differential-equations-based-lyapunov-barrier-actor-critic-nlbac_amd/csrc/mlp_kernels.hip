@@ -200,6 +200,12 @@ __global__ __launch_bounds__(256, 2) void mlp_bwd_data_kernel(const MlpLaunch L)
     float* in = smem;
     float* out = smem + NLBAC_MLP_TILE * LD;
     float* sdy = smem + 2 * NLBAC_MLP_TILE * LD;   // [32][16]
+    float* sx = sdy + NLBAC_MLP_TILE * 16;         // [32][16] input rows (only for the skinny-gradient partials)
+    // skinny-gradient partials of this 32-row tile (= one chunk of mlp_bwd_skinny_partial_kernel, same sums in the same
+    // order): thread = hidden column, quantity q at w[q * 256]
+    const bool sk = io.skinny_ws != nullptr && io.dz != nullptr;
+    float* w = sk ? io.skinny_ws + (long)blockIdx.x * ((net.n_layers - 1) + net.in_dim + net.out_dim + 1) * 256 + tid
+                  : nullptr;
 
     const bool active = wave < NT, two = (MODE == 2) || (MODE == 0 && (wave + 4) < NT);
     WaveGemm<(MODE == 1) ? 1 : 2> wg2;      // MODE 1 never touches wg2 / MODE 2 never touches wg1:
@@ -212,6 +218,14 @@ __global__ __launch_bounds__(256, 2) void mlp_bwd_data_kernel(const MlpLaunch L)
         const int r = idx >> 4, c = idx & 15, row = row0 + r;
         sdy[idx] = (row < B && c < net.out_dim) ? io.dy[(long)row * io.dy_ld + c] : 0.f;
     }
+    if (sk)
+        for (int idx = tid; idx < NLBAC_MLP_TILE * 16; idx += 256) {
+            const int r = idx >> 4, i = idx & 15, row = row0 + r;
+            float v = 0.f;
+            if (row < B && i < net.in_dim)
+                v = (i < io.x0_dim) ? io.x0[(long)row * io.x0_ld + i] : io.x1[(long)row * io.x1_ld + (i - io.x0_dim)];
+            sx[idx] = v;
+        }
 
     {   // top (skinny) layer: thread = hidden column; ReLU masks are fetched up front (clamped, unconditional)
         const int k = tid, kc = min(k, hid - 1);
@@ -240,8 +254,29 @@ __global__ __launch_bounds__(256, 2) void mlp_bwd_data_kernel(const MlpLaunch L)
                 in[m * LD + k] = (ok && av[m] > 0.f) ? s[m] : 0.f;
             }
         }
+        if (sk) {      // last layer: dW_L[o][k] = sum_m dy[m][o] a_L[m][k] (av holds the activations), db_L[o] = sum_m dy[m][o]
+            const int idim = net.in_dim, odim = net.out_dim;
+            const bool live = k < hid;
+            for (int o = 0; o < odim; ++o) {
+                float a = 0.f;
+#pragma unroll
+                for (int m = 0; m < NLBAC_MLP_TILE; ++m) a = __builtin_fmaf(sdy[m * 16 + o], av[m], a);   // (fused, as
+                                                               // mlp_bwd_skinny_partial_kernel's contracted multiply-adds)
+                w[(long)(nwide + idim + o) * 256] = live ? a : 0.f;
+            }
+            float bl = 0.f;
+            if (k < 16)
+                for (int m = 0; m < NLBAC_MLP_TILE; ++m) bl += sdy[m * 16 + k];
+            w[(long)(nwide + idim + odim) * 256] = bl;
+        }
     }
     __syncthreads();
+    if (sk) {          // bias gradient of the top hidden layer: column sum of the finished dz tile
+        float a = 0.f;
+        if (tid < hid)
+            for (int m = 0; m < NLBAC_MLP_TILE; ++m) a += in[m * LD + tid];
+        w[(long)(nwide - 1) * 256] = a;
+    }
     if (io.dz)       // the top layer's dz leaves from the finished LDS tile (coalesced, overlaps the first GEMM)
         tile_to_global(in, LD, io.dz + (long)(nwide - 1) * ls + (long)row0 * hid, hid, min(NLBAC_MLP_TILE, B - row0), tid, 256);
 
@@ -249,14 +284,24 @@ __global__ __launch_bounds__(256, 2) void mlp_bwd_data_kernel(const MlpLaunch L)
         const int n_rows = min(NLBAC_MLP_TILE, B - row0);
         const float* acts_tile = io.acts + (long)row0 * hid;
         float* dz_tile = io.dz ? io.dz + (long)row0 * hid : nullptr;
-        if constexpr (MODE == 2) bwd_wide_layers<2>(wg2, net, active, wave, lane, LD, in, out, acts_tile, dz_tile, ls, n_rows, n_rows - 1);
-        else if constexpr (MODE == 1) bwd_wide_layers<1>(wg1, net, active, wave, lane, LD, in, out, acts_tile, dz_tile, ls, n_rows, n_rows - 1);
+        if constexpr (MODE == 2) bwd_wide_layers<2>(wg2, net, active, wave, lane, LD, in, out, acts_tile, dz_tile, ls, n_rows, n_rows - 1, -1, false, 256, nullptr, w);
+        else if constexpr (MODE == 1) bwd_wide_layers<1>(wg1, net, active, wave, lane, LD, in, out, acts_tile, dz_tile, ls, n_rows, n_rows - 1, -1, false, 256, nullptr, w);
         else {
-            if (two) bwd_wide_layers<2>(wg2, net, active, wave, lane, LD, in, out, acts_tile, dz_tile, ls, n_rows, n_rows - 1);
-            else bwd_wide_layers<1>(wg1, net, active, wave, lane, LD, in, out, acts_tile, dz_tile, ls, n_rows, n_rows - 1);
+            if (two) bwd_wide_layers<2>(wg2, net, active, wave, lane, LD, in, out, acts_tile, dz_tile, ls, n_rows, n_rows - 1, -1, false, 256, nullptr, w);
+            else bwd_wide_layers<1>(wg1, net, active, wave, lane, LD, in, out, acts_tile, dz_tile, ls, n_rows, n_rows - 1, -1, false, 256, nullptr, w);
         }
     }
 
+    if (sk) {      // first layer: dW_0[k][i] = sum_m dz0[m][k] x[m][i]
+        const int idim = net.in_dim;
+        const bool live = tid < hid;
+        for (int i = 0; i < idim; ++i) {
+            float a = 0.f;
+            if (live)
+                for (int m = 0; m < NLBAC_MLP_TILE; ++m) a = __builtin_fmaf(in[m * LD + tid], sx[m * 16 + i], a);
+            w[(long)(nwide + i) * 256] = a;
+        }
+    }
     if (io.dx) {   // dx[m][i] = sum_n dz0[m][n] W0[n][i]
         const float* W = net.params + net.w_off[0];
         const int idim = net.in_dim;
@@ -539,12 +584,14 @@ __device__ __forceinline__ void skinny_rows(const float* __restrict__ aL, const 
 #pragma unroll
                 for (int i = 0; i < SK_MAX_IN; i += 4) {
                     const float4 xv = *reinterpret_cast<const float4*>(&sx[r][i]);
-                    dW0[i] += z[u][0] * xv.x; dW0[i + 1] += z[u][0] * xv.y; dW0[i + 2] += z[u][0] * xv.z; dW0[i + 3] += z[u][0] * xv.w;
+                    dW0[i] = __builtin_fmaf(z[u][0], xv.x, dW0[i]);         dW0[i + 1] = __builtin_fmaf(z[u][0], xv.y, dW0[i + 1]);
+                    dW0[i + 2] = __builtin_fmaf(z[u][0], xv.z, dW0[i + 2]); dW0[i + 3] = __builtin_fmaf(z[u][0], xv.w, dW0[i + 3]);
                 }
 #pragma unroll
                 for (int o = 0; o < SK_MAX_OUT; o += 4) {
                     const float4 dv = *reinterpret_cast<const float4*>(&sdy[r][o]);
-                    dWL[o] += dv.x * a[u]; dWL[o + 1] += dv.y * a[u]; dWL[o + 2] += dv.z * a[u]; dWL[o + 3] += dv.w * a[u];
+                    dWL[o] = __builtin_fmaf(dv.x, a[u], dWL[o]);         dWL[o + 1] = __builtin_fmaf(dv.y, a[u], dWL[o + 1]);
+                    dWL[o + 2] = __builtin_fmaf(dv.z, a[u], dWL[o + 2]); dWL[o + 3] = __builtin_fmaf(dv.w, a[u], dWL[o + 3]);
                 }
                 if (col < SK_MAX_OUT) dbL += sdy[r][col];
             }
@@ -763,7 +810,10 @@ extern "C" int nlbac_mlp_bwd_data(const nlbac_mlp* nets, const nlbac_mlp_io* io,
     if (fill_launch(L, nets, io, n_nets, B, "nlbac_mlp_bwd_data")) return -1;
     for (int i = 0; i < n_nets; ++i)
         NLBAC_REQUIRE(io[i].dy && io[i].acts, "nlbac_mlp_bwd_data: net %d needs dy and acts", i);
-    const size_t lds = ((size_t)2 * NLBAC_MLP_TILE * L.ld + NLBAC_MLP_TILE * 16) * sizeof(float);
+    for (int i = 0; i < n_nets; ++i)
+        NLBAC_REQUIRE(!io[i].skinny_ws || (B <= 32768 && io[i].x0 && io[i].dz && nets[i].hid <= 256),
+                      "nlbac_mlp_bwd_data: net %d: skinny-gradient partials need x0, dz, hid <= 256 and B <= 32768", i);
+    const size_t lds = ((size_t)2 * NLBAC_MLP_TILE * L.ld + 2 * NLBAC_MLP_TILE * 16) * sizeof(float);
     const dim3 grid(nlbac_ceil_div(B, NLBAC_MLP_TILE), n_nets);
     switch (tile_mode(nets, n_nets)) {
         case 1: hipLaunchKernelGGL(mlp_bwd_data_kernel<1>, grid, dim3(256), lds, (hipStream_t)s, L); break;
@@ -833,9 +883,14 @@ extern "C" int nlbac_mlp_bwd_weights(const nlbac_mlp* nets, const nlbac_mlp_io* 
     S.rows_per_chunk = skinny_rows_per_chunk(B);
     S.n_chunks = (B + S.rows_per_chunk - 1) / S.rows_per_chunk;
     S.net_stride = need / n_nets;
-    bool all_narrow = true;
-    for (int i = 0; i < n_nets; ++i) all_narrow = all_narrow && nets[i].hid <= 128;
-    if (all_narrow)
+    bool all_narrow = true, partials_ready = S.rows_per_chunk == NLBAC_MLP_TILE;
+    for (int i = 0; i < n_nets; ++i) {
+        all_narrow = all_narrow && nets[i].hid <= 128;
+        // nlbac_mlp_bwd_data has already left this net's partial sums in its block of ws (nlbac_mlp_io::skinny_ws)
+        partials_ready = partials_ready && io[i].skinny_ws == ws + (long)i * S.net_stride;
+    }
+    if (partials_ready) {
+    } else if (all_narrow)
         hipLaunchKernelGGL(mlp_bwd_skinny_partial_kernel<128>, dim3(S.n_chunks, n_nets), dim3(128), 0, (hipStream_t)s, L, S, ws);
     else
         hipLaunchKernelGGL(mlp_bwd_skinny_partial_kernel<256>, dim3(S.n_chunks, n_nets), dim3(256), 0, (hipStream_t)s, L, S, ws);

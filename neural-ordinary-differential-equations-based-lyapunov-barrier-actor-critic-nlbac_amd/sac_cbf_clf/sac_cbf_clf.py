@@ -28,7 +28,7 @@ import torch
 import torch.nn as nn
 
 from .. import _lib
-from ..arena import Arena, bwd_weights, io_array, mlp_array, pack, stream_ptr
+from ..arena import Arena, bwd_weights, io_array, mlp_array, pack, skinny_partials_ws, stream_ptr
 from . import _layout as SC
 from .model import BarrierNetwork, GaussianPolicy, LyaNetwork, QNetwork
 from .tasks import TASKS
@@ -559,6 +559,8 @@ class SAC_CBF_CLF(object):
         for i in [0, 1] + list(range(3, 3 + NX)):
             x(io, i, p_obs, Do, LD, p_act, Da, LD)
         x(io, 2, p_cen, Dl, LD)
+        # (its data backward leaves the skinny-gradient partial sums for the weight backward: one launch less)
+        P.sk_crit = skinny_partials_ws(P.n_crit, (io,), 3 + NX, B, self.device)
         # C: both actors (forward and backward share one descriptor)
         def act_io(io, j, i):            # entry j of an io array describes controller i
             x(io, j, p_obs, Do, LD)
@@ -584,7 +586,11 @@ class SAC_CBF_CLF(object):
             gio = io_array(cnt)
             for j in range(cnt):
                 act_io(gio, j, g.first + j)
-            P.act_groups.append((g, cnt, mlp_array([h.desc for h in self.h_pols[g.first:g.first + cnt]]), gio))
+            nets_g = mlp_array([h.desc for h in self.h_pols[g.first:g.first + cnt]])
+            # the actors' data backward (P.io_act) leaves this group's skinny-gradient partials for its weight backward
+            io_act_g = [P.io_act[g.first + j] for j in range(cnt)]       # (views into the array, not copies)
+            sk = skinny_partials_ws(nets_g, (gio, io_act_g), cnt, B, self.device)
+            P.act_groups.append((g, cnt, nets_g, gio, sk))
         # C: Q(s, pi) for primary / backup + V(current Lyapunov input)
         extra = self.task.extra_value_nets()
         P.n_q5 = mlp_array([q1.desc, q2.desc] * NP + [l.desc] + [h.desc for h in extra])
@@ -741,7 +747,7 @@ class SAC_CBF_CLF(object):
 
     def _part1_critic_step(self, ws, P, B, soft):
         a = self.ar_c
-        bwd_weights(P.n_crit, P.io_crit, len(self.h_crit), B, a.n_slabs, a.n, self.device)
+        bwd_weights(P.n_crit, P.io_crit, len(self.h_crit), B, a.n_slabs, a.n, self.device, ws=P.sk_crit)
         self._adam(a, self.critic_lyapunov_lr, a.n_slabs, extra=self.sc[SC.SC_QF1:SC.SC_QF1 + 3],
                    target=a.target.data_ptr(), tau=self.tau if soft else -1.0)
 
@@ -773,9 +779,9 @@ class SAC_CBF_CLF(object):
         call("nlbac_mlp_bwd_data", P.n_act, P.io_act, NP, B, s)
         tune = self.automatic_entropy_tuning
         p_part_q, n_part = ws.p_part_q, ws.n_part_q
-        for g, cnt, nets, gio in P.act_groups:
+        for g, cnt, nets, gio, sk_ws in P.act_groups:
             a = g.arena
-            bwd_weights(nets, gio, cnt, B, a.n_slabs, a.n, self.device)
+            bwd_weights(nets, gio, cnt, B, a.n_slabs, a.n, self.device, ws=sk_ws)
             la = a.theta.data_ptr() + 4 * g.la_off
 
             def alpha_grads(p_grad, g=g, cnt=cnt, la=la):

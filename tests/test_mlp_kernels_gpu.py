@@ -195,3 +195,55 @@ def test_multi_net_launch_and_adam_soft_update(fused):
                 off = ar.offset_of[id(p)]
                 vec_close(ar.target[off:off + p.numel()].cpu().view(p.shape), targ[k], 2e-6, "target %d" % k)
                 k += 1
+
+
+@pytest.mark.parametrize("B,hid,dims", [(4096, 256, (9, 1)), (100, 256, (7, 4)), (1000, 100, (3, 6)), (77, 160, (13, 2))])
+def test_skinny_gradient_partials_from_the_data_backward_are_bit_identical(B, hid, dims):
+    """With ``nlbac_mlp_io::skinny_ws`` set, ``nlbac_mlp_bwd_data`` leaves the per-32-row partial sums of the bias,
+    first- and last-layer gradients (it holds every dz tile in LDS) and ``nlbac_mlp_bwd_weights`` only reduces them: the
+    same sums in the same order as the separate partial pass, so every gradient must match bit for bit."""
+    from nlbac_amd import _lib, arena as A
+    in_dim, out_dim = dims
+    torch.manual_seed(B + hid)
+    mods = [[nn.Linear(in_dim, hid), nn.Linear(hid, hid), nn.Linear(hid, hid), nn.Linear(hid, out_dim)] for _ in range(2)]
+    ar = A.Arena("cuda", n_slabs=4)
+    hs = [A.MlpHandle(ar, [(l.weight, l.bias) for l in m]) for m in mods]
+    ar.finalize()
+    for h in hs:
+        h.bind()
+    A.pack(hs)
+    g = torch.Generator().manual_seed(1)
+    keep, grads = [], []
+    nets = A.mlp_array([h.desc for h in hs])
+    s = A.stream_ptr()
+    for fused in (False, True):
+        io = A.io_array(2)
+        for i in range(2):
+            x, dy = torch.randn(B, in_dim, generator=torch.Generator().manual_seed(10 + i)).cuda(), \
+                torch.randn(B, out_dim, generator=torch.Generator().manual_seed(20 + i)).cuda()
+            y, acts, dz = torch.empty(B, out_dim, device="cuda"), torch.empty(3, B, hid, device="cuda"), \
+                torch.empty(3, B, hid, device="cuda")
+            keep += [x, dy, y, acts, dz]
+            io[i].x0, io[i].x0_dim, io[i].x0_ld = x.data_ptr(), in_dim, in_dim
+            io[i].y, io[i].y_ld = y.data_ptr(), out_dim
+            io[i].acts, io[i].dz = acts.data_ptr(), dz.data_ptr()
+            io[i].dy, io[i].dy_ld = dy.data_ptr(), out_dim
+            io[i].grad = ar.grad.data_ptr()
+        ws = A.skinny_partials_ws(nets, (io,), 2, B, "cuda") if fused else None
+        assert (ws is not None) == fused
+        ar.grad.fill_(float("nan"))
+        _lib.call("nlbac_mlp_fwd", nets, io, 2, B, s)
+        _lib.call("nlbac_mlp_bwd_data", nets, io, 2, B, s)
+        A.bwd_weights(nets, io, 2, B, ar.n_slabs, ar.n, "cuda", ws=ws)
+        torch.cuda.synchronize()
+        keep.append(ws)
+        grads.append(ar.grad.clone())
+    a, b = grads
+    for m in mods:
+        for l in m:
+            for p in (l.weight, l.bias):
+                off = ar.offset_of[id(p)]
+                ga, gb = a[:, off:off + p.numel()], b[:, off:off + p.numel()]
+                assert torch.equal(torch.nan_to_num(ga), torch.nan_to_num(gb)) and \
+                    torch.equal(torch.isnan(ga), torch.isnan(gb))
+                assert torch.isfinite(ga[0]).all()
