@@ -721,8 +721,13 @@ class SAC_CBF_CLF(object):
             self.drain_fill()                   # no waits on this path (fixed-step solver / graph capture)
 
     def _fill_one(self):
-        if self._fill:
+        """Called by a solver just before it waits for an accept decision: queue the next piece(s) of part 1 behind the
+        attempted step.  The first wait of an update gets two (the host needs ~100 us of queued work to read the
+        decision and launch what follows without the stream running dry), later ones one each."""
+        k = 2 if len(self._fill) == 3 else 1
+        while k and self._fill:
             self._fill.popleft()()
+            k -= 1
 
     def drain_fill(self):
         while self._fill:
