@@ -516,23 +516,28 @@ class AffineNodeSolver:
         ctx.update(steps=[step], out=out)
         return out
 
-    def _dopri_continue(self):
+    def _dopri_continue(self, resume=None):
+        """The attempt loop after the first attempted step has been queued.  ``resume``: state taken over from a joint
+        solve (accepted steps so far, index of the step being attempted, attempt number) — see ``_adopt``."""
         ctx = self.ctx
         P, rpp, n, u, y0 = ctx["P"], ctx["rpp"], ctx["n"], ctx["u"], ctx["y0"]
         ns, S = self.n_s, 7
         s = stream_ptr()
         ctl = self._ctl(P)
         steps, info = [], []
-        cur_y0, idx = y0, 0
-        ws = self._step_ws(n, S, 0)
-        for attempt in range(1000):
+        cur_y0, idx, start = y0, 0, 0
+        if resume is not None:
+            steps, info, cur_y0, idx, start = (resume["steps"], resume["info"], resume["cur_y0"], resume["idx"],
+                                               resume["attempt"])
+        ws = self._step_ws(n, S, idx)
+        for attempt in range(start, 1000):
             c = ctx.pop("ctl_host", None)
             if c is None:
                 c = self._ctl_read(P)             # the one host wait per attempted step
             acc = [bool(c[p, 3] > 0) for p in range(P)]
             done = [bool(c[p, 4] > 0) for p in range(P)]
             if any(a != acc[0] for a in acc) or any(d != done[0] for d in done):
-                return self._solve_split(c if attempt == 0 else None)
+                return self._solve_split(c, dict(steps=steps, info=info, idx=idx, attempt=attempt))
             if attempt == 0 and acc[0] and done[0]:
                 return self._dopri_accept_first(c)
             info.append([(float(c[p, 11]), float(c[p, 2]), acc[p]) for p in range(P)])
@@ -557,35 +562,40 @@ class AffineNodeSolver:
             self._dopri_attempt(ws, cur_y0, u, P, rpp)
         raise _lib.NlbacError("dopri5: max_num_steps exceeded")
 
-    def _adopt_first_attempt(self, k, p, c):
-        """Hand per-problem solver ``k`` the joint first attempted step of problem ``p``: its rows of the step
-        workspace (stage derivatives, stage inputs, g(x), error estimate, activations / ReLU masks) and its control
-        block, so that it continues from the accept decision ``c`` instead of redoing f0, the probe and the attempt."""
+    def _adopt(self, k, p, c, st):
+        """Hand per-problem solver ``k`` everything the joint solve has done for problem ``p``: its rows of every step
+        workspace so far (stage derivatives, stage inputs, g(x), error estimate, activations / ReLU masks — one
+        strided-copy launch per buffer) and its control block, so that it continues from the accept decision ``c``
+        instead of starting the solve again.  Returns the state ``k._dopri_continue`` resumes from."""
         ctx = self.ctx
         P, rpp, n, S = ctx["P"], ctx["rpp"], ctx["n"], 7
         rows = slice(p * rpp, (p + 1) * rpp)
-        src = self._step_ws(n, S, 0)
         k._touch(rpp)
         k.stats["solves"] += 1
         k.ctx = dict(method="dopri5", P=1, rpp=rpp, n=rpp, u=ctx["u"][rows], y0=ctx["y0"][rows], steps=[],
                      t_end=ctx["t_end"], atol=ctx["atol"], rtol=ctx["rtol"])
-        dst = k._step_ws(rpp, S, 0)
         s = stream_ptr()
-        for name in src.ADOPT:
-            a, b = getattr(src, name), getattr(dst, name)
-            w = a.shape[-1]                               # [.., rows, w] with rows = n or S*n (stage-major)
-            blocks = a.numel() // (n * w)
-            _lib.call("nlbac_copy_blocks", a.data_ptr() + 4 * p * rpp * w, n * w, b.data_ptr(), rpp * w, rpp * w,
-                      blocks, s)
+        kws = []
+        for j in range(st["idx"] + 1):                    # accepted steps 0 .. idx-1 and the step being attempted
+            src, dst = self._step_ws(n, S, j), k._step_ws(rpp, S, j)
+            for name in src.ADOPT:
+                a, b = getattr(src, name), getattr(dst, name)
+                w = a.shape[-1]                           # [.., rows, w] with rows = n or S*n (stage-major)
+                _lib.call("nlbac_copy_blocks", a.data_ptr() + 4 * p * rpp * w, n * w, b.data_ptr(), rpp * w, rpp * w,
+                          a.numel() // (n * w), s)
+            kws.append(dst)
         _lib.call("nlbac_copy_blocks", self._ctl(P).data_ptr() + 8 * _lib.DOPRI_CTL * p, 2 * _lib.DOPRI_CTL,
                   k._ctl(1).data_ptr(), 2 * _lib.DOPRI_CTL, 2 * _lib.DOPRI_CTL, 1, s)
         k.ctx["ctl_host"] = c[p:p + 1].clone()
+        steps = [dict(ws=kws[j], h=[step["h"][p]], first=step["first"]) for j, step in enumerate(st["steps"])]
+        return dict(steps=steps, info=[[e[p]] for e in st["info"]], idx=st["idx"], attempt=st["attempt"],
+                    cur_y0=kws[st["idx"] - 1].Y[6] if st["idx"] else k.ctx["y0"])
 
-    def _solve_split(self, c=None):
-        """The problems of one batch want different step sequences (one accepted / finished, another not):
-        each has its own adaptive step size in the reference too (separate odeint calls), so finish the solve
-        problem by problem with child solvers on the row ranges.  ``c``: host copy of the control block when the
-        disagreement shows at the first attempt — the children then take that attempt over; later ones start over."""
+    def _solve_split(self, c, st):
+        """The problems of one batch want different step sequences (one accepted / finished, another not): each has its
+        own adaptive step size in the reference too (separate odeint calls), so the solve is finished problem by
+        problem by child solvers on the row ranges, which take over what has been done jointly (``_adopt``; ``c``: host
+        copy of the control block, ``st``: accepted steps / attempt number at the point of disagreement)."""
         ctx = self.ctx
         self.stats["split"] += 1
         P, rpp, n = ctx["P"], ctx["rpp"], ctx["n"]
@@ -600,12 +610,10 @@ class AffineNodeSolver:
             k._side, k._ev_ctl, k._ctl_pin = self._side, self._ev_ctl, self._ctl_pin
             k.before_wait = self.__dict__.get("before_wait")
             rows = slice(p * rpp, (p + 1) * rpp)
-            if c is not None:
-                self.stats["adopted"] = self.stats.get("adopted", 0) + (1 if p == 0 else 0)
-                self._adopt_first_attempt(k, p, c)
-                o = k._dopri_continue()
-            else:
-                o = k.forward(ctx["y0"][rows], ctx["u"][rows], 1, rpp, "dopri5", ctx["t_end"], ctx["atol"], ctx["rtol"])
+            if p == 0:
+                key = "adopted" if st["attempt"] == 0 else "adopted_late"
+                self.stats[key] = self.stats.get(key, 0) + 1
+            o = k._dopri_continue(self._adopt(k, p, c, st))
             _lib.call("nlbac_copy_blocks", o.data_ptr(), o.numel(), out.data_ptr() + 4 * p * rpp * self.n_s, o.numel(),
                       o.numel(), 1, stream_ptr())
             kids.append(k)

@@ -75,9 +75,9 @@ def test_multi_step_dopri5_with_parameter_gradients(T):
 @pytest.mark.parametrize("masks", [True, False], ids=["relu-bit-masks", "acts"])
 def test_problems_that_diverge_fall_back_to_per_problem_solves(masks):
     """Two problems that stop agreeing on accept / done (the second is stiffer): each finishes on its own solver and
-    the results are the oracle's separate odeint calls.  Horizons are tried until both kinds of divergence have been
-    seen: at a later attempt (the per-problem solvers start over) and at the first one (they take the joint first
-    attempt over — their rows of the step workspace and their control block — instead of redoing it)."""
+    the results are the oracle's separate odeint calls.  The per-problem solvers take over what the joint solve has
+    done — their rows of every step workspace so far and their control block — instead of starting again; horizons are
+    tried until both kinds of divergence have been seen: at the first attempt and after some joint steps."""
     from nlbac_amd.odeint import AffineNodeSolver
     agent, env = make_agent(64, 64, 0, "dopri5")
     W = synth.agent_weights("Unicycle", 64, 0)["node"]
@@ -96,6 +96,7 @@ def test_problems_that_diverge_fall_back_to_per_problem_solves(masks):
         if not sol.stats["split"]:
             continue
         kind = "first attempt" if sol.stats.get("adopted", 0) else "later attempt"
+        assert sol.stats.get("adopted", 0) + sol.stats.get("adopted_late", 0) == sol.stats["split"]
         if kind in seen:
             continue
         seen.add(kind)
