@@ -352,6 +352,60 @@ int nlbac_dopri_interp_bwd(const float *dout, const float *h_host, const float *
                            int P, int rows_per_problem, int n_s, float *dy0, float *dy1, float *dK,
                            nlbac_stream_t s);
 
+/* ------------------------------------------------------------------------
+ * odeint_adjoint (torchdiffeq 0.2.3 OdeintAdjointMethod, torchdiffeq/_impl/adjoint.py; pinned by the reference at
+ * README.md:33, never called by it — would-be call sites P/sac_cbf_clf/sac_cbf_clf.py:459,499,534,774,812,852 and
+ * P/sac_cbf_clf/model.py:259, BASELINE configs[3]).  The augmented state is kept per row as
+ *     z = [ y (n_s) | a_x (n_s) | a_u (n_u) ],   W = 2 n_s + n_u floats,
+ * integrated in s = t1 - t:  dy/ds = -(f + g u),  da_x/ds = (d(f + g u)/dx)^T a_x,  da_u/ds = g^T a_x.
+ * nlbac_node_adj_step evaluates stages [st_lo, st_hi) of one explicit RK step of that system in ONE launch; every
+ * stage re-computes f_net / g_net on its stage input and back-propagates a_x through them at once (nothing of the
+ * forward solve is read).  KZ [n_stages_total][n][W] stage derivatives (stages < st_lo are read: FSAL / f0);
+ * Z1 = Z0 + h sum c_out[j] KZ_j and ERR = h sum c_err[j] KZ_j when given.  ctl (or NULL): the dopri control blocks —
+ * rows of problems whose `done` is set are left untouched, so a fixed chain of attempts can be enqueued without a
+ * host decision per attempt.  With ZS / dG / acts_* / dz_* (all or none; P = 1) the stage inputs, the output-layer
+ * gradient of g_net, the activations and the pre-activation gradients of every evaluated stage are written
+ * ([stage][n][.] resp. [layer][n_stages_total*n][hid]) for nlbac_mlp_bwd_weights with x0 = ZS (ld W),
+ * dy = ZS + n_s (ld W) for f_net and dy = dG for g_net: the parameter adjoint's stage derivative.  Without them the
+ * ReLU masks live in LDS and the launch moves 2 W floats per row.
+ * ---------------------------------------------------------------------- */
+int nlbac_node_adj_step(const nlbac_mlp *f, const nlbac_mlp *g, const float *u, int P, int rows_per_problem,
+                        int st_lo, int st_hi, int n_stages_total, const float *beta, const float *c_out, int n_out,
+                        const float *c_err, int n_err, const float *h_host, const double *h_dev, int h_dev_stride,
+                        const double *ctl, const float *Z0, float *KZ, float *Z1, float *ERR, float *ZS, float *dG,
+                        float *acts_f, long acts_f_ls, float *acts_g, long acts_g_ls, float *dz_f, float *dz_g,
+                        nlbac_stream_t s);
+/* Z[row] = [y | a_x | 0]  and  (dy0, du) = (Z[:, n_s:2n_s], Z[:, 2n_s:])  (either output may be NULL) */
+int nlbac_adj_pack(const float *y, const float *a_x, int n_s, int n_u, int n, float *Z, nlbac_stream_t s);
+int nlbac_adj_unpack(const float *Z, int n_s, int n_u, int n, float *dy0, float *du, nlbac_stream_t s);
+/* Step control of the adjoint solve: torchdiffeq's default adjoint norm (handle_adjoint_norm_) — the maximum of the
+ * RMS norms of the y part [x | u], the adj_y part [a_x | a_u] and, when pnorm is given, pnorm[0] (pnorm[1] for the
+ * second norm of mode 0): the largest per-tensor RMS of the parameter adjoint, from nlbac_adj_param_norm.
+ * Modes as nlbac_dopri_norm_control (a = KZ[0] / KZ[1] / ERR, b = KZ[0]); partials [P][ceil(rows/256)][4].
+ * tickets == NULL: partial sums only (data parallel: all-reduce, then nlbac_adj_control).  A problem whose solve is
+ * done is skipped in mode 2. */
+int nlbac_adj_norm_control(const float *a, const float *b, const float *Z0, const float *Z1, const float *u, int mode,
+                           float rtol, float atol, int n_s, int n_u, int rows_per_problem, int P, double t_end,
+                           const float *pnorm, float *partials, unsigned *tickets, double *ctl, nlbac_stream_t s);
+int nlbac_adj_control(const float *partials, int n_blk_per_problem, int mode, int n_s, int n_u, int rows_per_problem,
+                      int P, double t_end, const float *pnorm, double *ctl, nlbac_stream_t s);
+/* After an attempted step, on the device: rows (w floats each) of problems whose step was accepted and whose solve
+ * goes on take dst0 <- src0 (z0 <- z1) and dst1 <- src1 (first stage <- last stage, FSAL; dst1 may be NULL). */
+int nlbac_adj_commit(const double *ctl, int rows_per_problem, long n_rows, int w, float *dst0, const float *src0,
+                     float *dst1, const float *src1, nlbac_stream_t s);
+/* The parameter adjoint theta_bar (flat, the arena's layout) beside the per-row state.  K [n_stages][k_stride]: its
+ * stage derivatives (nlbac_mlp_bwd_weights on what nlbac_node_adj_step kept of each stage, reduced over the slabs).
+ * Forms, per PARAMETER TENSOR (segments seg_off / seg_len, device int arrays), what the step-size norm needs —
+ * torchdiffeq's _mixed_norm over adj_params: pnorm[0] (and pnorm[1] in mode 0) = max over tensors of the tensor's RMS:
+ *   mode 0: (th0 / scale, K[0] / scale), scale = atol + rtol |th0|;   mode 1: (K[1] - K[0]) / scale;
+ *   mode 2: th1 = th0 + h sum c_sol[j] K[j] is written, pnorm[0] from h sum c_err[j] K[j] / (atol + rtol max(|th0|,|th1|)).
+ * h = h_dev[0] when given else h_host[0].  pseg: 2 n_seg floats of scratch, ticket: a zeroed uint32 (left zeroed).
+ * Skipped in mode 2 when ctl (problem 0) says done. */
+int nlbac_adj_param_norm(int mode, const float *th0, const float *K, long k_stride, int n_stages, const float *c_sol,
+                         const float *c_err, const float *h_host, const double *h_dev, const int *seg_off,
+                         const int *seg_len, int n_seg, float rtol, float atol, const double *ctl, float *th1,
+                         float *pseg, unsigned *ticket, float *pnorm, nlbac_stream_t s);
+
 /* Strided block copy of 32-bit words: block b (block_len words) from src + b*src_stride to dst + b*dst_stride —
  * a row range of a stage-major solver buffer in one launch (hands a problem's first attempted dopri5 step to its
  * own solver when the problems of a joint solve stop agreeing on accept / done). */

@@ -106,6 +106,15 @@ _PROTOS = {
                             _P, _I, _P, _P, _P, _L, _P, _P, _P],
     "nlbac_concat_rk_bwd": [C.POINTER(Mlp), _I, _I, _I, _I, _I, _I, c_float_p, c_float_p, _P, _I, _P, _L, _P, _P, _P, _P,
                             _I, _P, _I, _P],
+    "nlbac_node_adj_step": [C.POINTER(Mlp), C.POINTER(Mlp), _P, _I, _I, _I, _I, _I, c_float_p, c_float_p, _I, c_float_p,
+                            _I, c_float_p, _P, _I, _P, _P, _P, _P, _P, _P, _P, _P, _L, _P, _L, _P, _P, _P],
+    "nlbac_adj_pack": [_P, _P, _I, _I, _I, _P, _P],
+    "nlbac_adj_unpack": [_P, _I, _I, _I, _P, _P, _P],
+    "nlbac_adj_norm_control": [_P, _P, _P, _P, _P, _I, _F, _F, _I, _I, _I, _I, _D, _P, _P, _P, _P, _P],
+    "nlbac_adj_control": [_P, _I, _I, _I, _I, _I, _I, _D, _P, _P, _P],
+    "nlbac_adj_param_norm": [_I, _P, _P, _L, _I, c_float_p, c_float_p, c_float_p, _P, _P, _P, _I, _F, _F, _P, _P, _P, _P, _P,
+                             _P],
+    "nlbac_adj_commit": [_P, _I, _L, _I, _P, _P, _P, _P, _P],
     "nlbac_dopri_norm_partials": [_P, _P, _P, _P, _P, _I, _F, _F, _I, _I, _I, _I, _P, _P],
     "nlbac_dopri_norm_control": [_P, _P, _P, _P, _P, _I, _F, _F, _I, _I, _I, _I, _D, _P, _P, _P, _P],
     "nlbac_dopri_control": [_P, _I, _I, _I, _I, _I, _I, _D, _P, _P],

@@ -10,6 +10,7 @@
 // state dimension n_s <= 8, action dimension n_u <= 4.  Stage derivatives are
 // kept stage-major: K[stage][row][n_s].
 #include "common.h"
+#include "ode_control.h"
 
 #define MAX_NS 8
 #define MAX_NUA 4
@@ -88,12 +89,6 @@ __global__ __launch_bounds__(256) void rk_stage_bwd_kernel(const float* dYup, co
     }
 }
 
-// ---------------------------------------------------------------------------
-// dopri5 step-size control.  ctl: per problem NLBAC_DOPRI_CTL doubles.
-// ---------------------------------------------------------------------------
-enum { C_H = 0, C_T = 1, C_RATIO = 2, C_ACCEPT = 3, C_DONE = 4, C_X = 5, C_H0 = 6, C_D0 = 7, C_D1 = 8, C_D2 = 9,
-       C_NSTEPS = 10, C_HUSED = 11 };
-
 // partial sums of squared scaled quantities; partials [P][nblk][2]
 //  mode 0: col0 = sum (y0/scale)^2 (+ (u/scale_u)^2), col1 = sum (a/scale)^2          a = f0
 //  mode 1: col0 = sum ((a-b)/scale)^2                                                  a = f1, b = f0
@@ -144,44 +139,11 @@ __global__ __launch_bounds__(256) void dopri_norm_kernel(const float* a, const f
     dopri_norm_block(a, b, y0, y1, u, mode, rtol, atol, n_s, n_u, rpp, partials);
 }
 
-// the controller of problem p on its finished squared-norm sums
+// the controller of problem p on its finished squared-norm sums (plain RMS norm over the problem's rows)
 __device__ __forceinline__ void dopri_control_one(double s0, double s1, int p, int mode, int n_s, int n_u,
                                                   int rpp, double t_end, double* ctl) {
-    double* c = ctl + (long)p * NLBAC_DOPRI_CTL;
     const double cnt = (double)rpp * (double)(n_s + n_u);
-    if (mode == 0) {
-        const double d0 = sqrt(s0 / cnt), d1 = sqrt(s1 / cnt);
-        c[C_D0] = d0; c[C_D1] = d1;
-        c[C_H0] = (d0 < 1e-5 || d1 < 1e-5) ? 1e-6 : 0.01 * d0 / d1;
-        c[C_T] = 0.0; c[C_NSTEPS] = 0.0; c[C_DONE] = 0.0;
-    } else if (mode == 1) {
-        const double h0 = c[C_H0], d1 = c[C_D1];
-        const double d2 = sqrt(s0 / cnt) / h0;
-        c[C_D2] = d2;
-        double h1;
-        if (d1 <= 1e-15 && d2 <= 1e-15) h1 = fmax(1e-6, h0 * 1e-3);
-        else h1 = pow(0.01 / fmax(d1, d2), 1.0 / 5.0);
-        c[C_H] = fmin(100.0 * h0, h1);
-    } else {
-        const double ratio = sqrt(s0 / cnt);
-        const double h = c[C_H], t = c[C_T];
-        const bool accept = ratio <= 1.0;
-        double fac;
-        if (ratio == 0.0) fac = 10.0;
-        else {
-            const double dfac = (ratio < 1.0) ? 1.0 : 0.2;
-            fac = fmin(10.0, fmax(0.9 / pow(ratio, 0.2), dfac));
-        }
-        c[C_RATIO] = ratio; c[C_ACCEPT] = accept ? 1.0 : 0.0; c[C_HUSED] = h;
-        c[C_NSTEPS] += 1.0;
-        if (accept && t + h >= t_end) {
-            c[C_DONE] = 1.0;
-            c[C_X] = (t_end - t) / h;
-        } else {
-            if (accept) c[C_T] = t + h;
-            c[C_H] = h * fac;
-        }
-    }
+    dopri_control_vals(sqrt(s0 / cnt), sqrt(s1 / cnt), p, mode, t_end, ctl);
 }
 
 __global__ void dopri_control_kernel(const float* partials, int nblk, int mode, int n_s, int n_u, int rpp,

@@ -142,6 +142,7 @@ class AffineNodeSolver:
         self._children = {}    # per-problem solvers for batches whose problems diverge (dopri5)
         self.stats = dict(solves=0, single_step=0, multi_attempt=0, split=0)
         self.comm = None       # nlbac_amd.parallel.DataParallel: global dopri5 error norms
+        self.adjoint = False   # True: ``backward`` is the continuous adjoint (odeint_adjoint); the forward keeps nothing
 
     # -- workspace -----------------------------------------------------------
     MAX_SIZES = 2      # distinct row counts whose buffers are kept (the NODE fit's batch grows with the replay)
@@ -281,6 +282,7 @@ class AffineNodeSolver:
         beta, S = self._beta(method)
         f, g = self.f, self.g
         n = P * rpp
+        save_acts = save_acts and not self.adjoint       # (the adjoint re-computes every stage it differentiates)
         _lib.call("nlbac_node_rk_fwd", C.byref(f.desc), C.byref(g.desc), y0.data_ptr(), u.data_ptr(), P, rpp,
                   st0, st1, S, beta, c_out, len(c_out) if c_out is not None else 0,
                   c_err, len(c_err) if c_err is not None else 0,
@@ -370,7 +372,7 @@ class AffineNodeSolver:
     def _ctl(self, P):
         return self._buf("ctl", P, _lib.DOPRI_CTL, dtype=torch.float64)
 
-    def _ctl_post(self, P):
+    def _ctl_post(self, P, src=None):
         """After an attempted step: send the control block to pinned host memory on a side stream, so that the
         host can read the accept decision as soon as the controller has run — without draining the launch
         stream, on which the caller may have queued independent work behind the attempt (the agent queues its
@@ -382,7 +384,7 @@ class AffineNodeSolver:
         ev_a.record()
         side.wait_event(ev_a)
         with torch.cuda.stream(side):
-            pin.copy_(self._ctl(P), non_blocking=True)
+            pin.copy_(self._ctl(P) if src is None else src, non_blocking=True)
             ev_b.record()
         self.ctx["ctl_pending"] = P
 
@@ -463,7 +465,8 @@ class AffineNodeSolver:
     def _coef(self, key):
         c = self._coefs.get(key)
         if c is None:
-            vals = DP_C_ERR if key == "err" else ([1.0] if key == "one" else DP_BETA[key[1] - 1])
+            vals = DP_C_ERR if key == "err" else ([1.0] if key == "one" else (DP_BETA[5] + [0.0] if key == "sol" else
+                                                                              DP_BETA[key[1] - 1]))
             c = self._coefs[key] = fptr(*vals)
         return c
 
@@ -628,6 +631,8 @@ class AffineNodeSolver:
         ``need_params`` the pre-activation grads of every stage are kept for
         ``accumulate_param_grads``."""
         ctx = self.ctx
+        if self.adjoint:
+            return self.backward_adjoint(dout, need_du, need_params, need_dy0)
         if ctx.get("split"):
             assert not need_params, "parameter gradients are only taken on single-problem solves"
             rpp = ctx["rpp"]
@@ -700,6 +705,216 @@ class AffineNodeSolver:
         dy0 = steps[0]["ws"].dy0 if need_dy0 else None
         return du, dy0
 
+    # -- continuous adjoint (odeint_adjoint) ---------------------------------------------------------
+    # torchdiffeq 0.2.3 OdeintAdjointMethod.backward restated on the device: the augmented state z = [y | a_x | a_u]
+    # (+ the parameter adjoint, a quadrature) is integrated from t1 back to t0 with the forward's method and
+    # tolerances and the mixed default adjoint norm; one nlbac_node_adj_step launch per RK step re-computes the nets on
+    # every stage input and back-propagates a_x through them, so nothing of the forward solve is kept.  The dopri5
+    # attempts are a device-driven chain (kernels skip problems whose solve is done, an accepted step is handed over
+    # by nlbac_adj_commit); the host looks at the control block once per chain, not once per attempt.
+    ADJ_MAX_ATTEMPTS = 1000
+
+    def _adj_ws(self, n, S):
+        key = ("adj", n, S)
+        pool = self._scratch.setdefault(n, {})
+        w = pool.get(key)
+        if w is None:
+            W = 2 * self.n_s + self.n_u
+            z = lambda *s: torch.zeros(*s, dtype=torch.float32, device=self.device)
+            w = pool[key] = dict(Z0=z(n, W), Z1=z(n, W), KZ=z(S, n, W), ERR=z(n, W), OUT=z(n, W), W=W)
+        return w
+
+    def _adj_step(self, w, u, P, rpp, method, st0, st1, h_host=None, h_dev=None, ctl=None, c_out=None, c_err=None,
+                  keep=None):
+        beta, S = self._beta(method)
+        f, g = self.f, self.g
+        k = keep or {}
+        dp = lambda t: t.data_ptr() if t is not None else None
+        _lib.call("nlbac_node_adj_step", C.byref(f.desc), C.byref(g.desc), u.data_ptr(), P, rpp, st0, st1, S, beta,
+                  c_out, len(c_out) if c_out is not None else 0, c_err, len(c_err) if c_err is not None else 0,
+                  fptr(*h_host) if h_host is not None else None, h_dev, _lib.DOPRI_CTL if h_dev else 0, ctl,
+                  w["Z0"].data_ptr(), w["KZ"].data_ptr(), w["Z1"].data_ptr() if c_out is not None else None,
+                  w["ERR"].data_ptr() if c_err is not None else None, dp(k.get("ZS")), dp(k.get("dG")),
+                  dp(k.get("acts_f")), k.get("ls_f", 0), dp(k.get("acts_g")), k.get("ls_g", 0), dp(k.get("dz_f")),
+                  dp(k.get("dz_g")), stream_ptr())
+        self.nfe += st1 - st0
+        if keep:
+            for st in range(st0, st1):
+                self._adj_stage_dw(self._adj_par_cur, st)
+
+    def _adj_norm_control(self, a, b, w, u, mode, P, rpp, ctl, pnorm=None):
+        ctx = self.ctx
+        ns, nu, s = self.n_s, self.n_u, stream_ptr()
+        nblk = (rpp + 255) // 256
+        part = self._buf("adj_part", P, nblk, 4)
+        dp = lambda t: t.data_ptr() if t is not None else None
+        if self.comm is not None and self.comm.world > 1:
+            _lib.call("nlbac_adj_norm_control", dp(a), dp(b), w["Z0"].data_ptr(), w["Z1"].data_ptr(), dp(u), mode,
+                      ctx["rtol"], ctx["atol"], ns, nu, rpp, P, ctx["t_end"], None, part.data_ptr(), None,
+                      ctl.data_ptr(), s)
+            sums = self._buf("adj_psum", P, 1, 4)
+            for p in range(P):
+                _lib.call("nlbac_sum_partials", part[p].data_ptr(), nblk, 4, 1.0, sums[p].data_ptr(), s)
+            self.comm.all_reduce_(sums)
+            _lib.call("nlbac_adj_control", sums.data_ptr(), 1, mode, ns, nu, rpp * self.comm.world, P, ctx["t_end"],
+                      dp(pnorm), ctl.data_ptr(), s)
+            return
+        tickets = self._buf("adj_tickets", P, dtype=torch.int32)
+        _lib.call("nlbac_adj_norm_control", dp(a), dp(b), w["Z0"].data_ptr(), w["Z1"].data_ptr(), dp(u), mode,
+                  ctx["rtol"], ctx["atol"], ns, nu, rpp, P, ctx["t_end"], dp(pnorm), part.data_ptr(),
+                  tickets.data_ptr(), ctl.data_ptr(), s)
+
+    # -- parameter adjoint (a quadrature beside the per-row state; single-problem solves) -----------------
+    ADJ_SUB_SLABS = 40       # row slabs of one stage's weight-gradient GEMM (workgroups: layers x slabs x nets)
+
+    def _adj_params_begin(self, w, n, S):
+        ctx = self.ctx
+        assert ctx["P"] == 1, "parameter gradients are only taken on single-problem solves"
+        key = ("adj_par", n, S)
+        pool = self._scratch.setdefault(n, {})
+        par = pool.get(key)
+        if par is None:
+            f, g, ns, nu, dev = self.f, self.g, self.n_s, self.n_u, self.device
+            z = lambda *s, dtype=torch.float32: torch.zeros(*s, dtype=dtype, device=dev)
+            arena = f.arena
+            NP = arena.n
+            keep = dict(ZS=z(S, n, w["W"]), dG=z(S, n, ns * nu), acts_f=z(f.n_layers - 1, S * n, f.hid),
+                        acts_g=z(g.n_layers - 1, S * n, g.hid), dz_f=z(f.n_layers - 1, S * n, f.hid),
+                        dz_g=z(g.n_layers - 1, S * n, g.hid), ls_f=S * n * f.hid, ls_g=S * n * g.hid)
+            segs = [(arena.offset_of[id(p)], p.numel()) for p in self.node.parameters()]
+            par = pool[key] = dict(
+                keep=keep, NP=NP, K=z(S, NP), th0=z(NP), th1=z(NP), out=z(NP), slabs=z(self.ADJ_SUB_SLABS, NP),
+                seg_off=torch.tensor([o for o, _ in segs], dtype=torch.int32, device=dev),
+                seg_len=torch.tensor([l for _, l in segs], dtype=torch.int32, device=dev), n_seg=len(segs),
+                pseg=z(2 * len(segs)), ticket=z(1, dtype=torch.int32), pnorm=z(2), io={}, n=n, S=S, w=w)
+        _lib.call("nlbac_fill", par["th0"].data_ptr(), 0.0, par["NP"], stream_ptr())
+        par["grad"] = None
+        return par
+
+    def _adj_stage_dw(self, par, st):
+        """K_theta[st] = sum over the rows of stage ``st`` of (dF/dtheta)^T a_x: nlbac_mlp_bwd_weights on what the
+        step kernel kept of that stage (row slabs), then the slab sum."""
+        k, n, S, w = par["keep"], par["n"], par["S"], par["w"]
+        W, ns, nu = w["W"], self.n_s, self.n_u
+        io = par["io"].get(st)
+        if io is None:
+            io = par["io"][st] = io_array(2)
+            ZS = k["ZS"][st]
+            for i, (net, acts, dz) in enumerate(((self.f, k["acts_f"], k["dz_f"]), (self.g, k["acts_g"], k["dz_g"]))):
+                io[i].x0, io[i].x0_dim, io[i].x0_ld = ZS.data_ptr(), ns, W
+                io[i].acts, io[i].dz = acts[:, st * n:].data_ptr(), dz[:, st * n:].data_ptr()
+                io[i].acts_ls = S * n * net.hid
+                io[i].grad = par["slabs"].data_ptr()
+            io[0].dy, io[0].dy_ld = ZS.data_ptr() + 4 * ns, W              # cotangent of f_net's output: a_x
+            io[1].dy, io[1].dy_ld = k["dG"][st].data_ptr(), ns * nu        # of g_net's: a_x u^T
+        bwd_weights(self._nets(), io, 2, n, self.ADJ_SUB_SLABS, par["NP"], self.device)
+        _lib.call("nlbac_reduce_slabs", par["K"][st].data_ptr(), par["slabs"].data_ptr(), self.ADJ_SUB_SLABS,
+                  par["NP"], par["NP"], stream_ptr())
+
+    def _adj_params_norm(self, par, mode, cp, h_host=None, c_sol=None):
+        ctx = self.ctx
+        _lib.call("nlbac_adj_param_norm", mode, par["th0"].data_ptr(), par["K"].data_ptr(), par["NP"], par["S"],
+                  c_sol if c_sol is not None else self._coef("sol"), self._coef("err") if c_sol is None else fptr(*([0.0] * par["S"])),
+                  fptr(h_host) if h_host is not None else None, cp if h_host is None else None,
+                  par["seg_off"].data_ptr(), par["seg_len"].data_ptr(), par["n_seg"], ctx["rtol"], ctx["atol"],
+                  cp if (mode == 2 and h_host is None) else None, par["th1"].data_ptr(), par["pseg"].data_ptr(),
+                  par["ticket"].data_ptr(), par["pnorm"].data_ptr(), stream_ptr())
+        return par["pnorm"]
+
+    def _adj_params_commit(self, par, cp):
+        NP = par["NP"]
+        _lib.call("nlbac_adj_commit", cp, NP // 4, NP // 4, 4, par["th0"].data_ptr(), par["th1"].data_ptr(),
+                  par["K"][0].data_ptr(), par["K"][6].data_ptr(), stream_ptr())
+
+    def _adj_params_finish(self, par, cp):
+        NP = par["NP"]
+        _lib.call("nlbac_dopri_interp_fwd", par["th0"].data_ptr(), par["th1"].data_ptr(), par["K"].data_ptr(), None,
+                  None, cp, 1, NP // 4, 4, par["out"].data_ptr(), stream_ptr())
+        par["grad"] = par["out"]
+        self.ctx["adj_par"] = par
+
+    def _adj_params_fixed(self, par, w, c_sol, h):
+        """fixed grid: theta_bar(t0) = h sum_j c_sol[j] K_theta[j]"""
+        self._adj_params_norm(par, 2, None, h_host=h, c_sol=fptr(*c_sol))
+        par["grad"] = par["th1"]
+        self.ctx["adj_par"] = par
+
+    def backward_adjoint(self, dout, need_du=True, need_params=False, need_dy0=False):
+        """dL/du, dL/dy0 (and, with ``need_params``, the parameter adjoint for ``accumulate_param_grads``) from
+        dL/dy(t1) = ``dout`` by solving the adjoint system backwards from the forward's y(t1)."""
+        ctx = self.ctx
+        P, rpp, n, u, method = ctx["P"], ctx["rpp"], ctx["n"], ctx["u"], ctx["method"]
+        ns, nu, s = self.n_s, self.n_u, stream_ptr()
+        assert dout.shape == (n, ns) and dout.is_contiguous()
+        self._cur_n = n
+        S = 7 if method == "dopri5" else len(TABLEAU[method]["c_sol"])
+        w = self._adj_ws(n, S)
+        par = self._adj_par_cur = self._adj_params_begin(w, n, S) if need_params else None
+        _lib.call("nlbac_adj_pack", ctx["out"].data_ptr(), dout.data_ptr(), ns, nu, n, w["Z0"].data_ptr(), s)
+        if method in ("euler", "rk4"):
+            tab = TABLEAU[method]
+            h = [ctx["t_end"]] * P
+            self._adj_step(w, u, P, rpp, method, 0, S, h_host=h, c_out=fptr(*tab["c_sol"]),
+                           keep=par and par["keep"])
+            if par:
+                self._adj_params_fixed(par, w, tab["c_sol"], h[0])
+            res = w["Z1"]
+            ctx["adjoint_info"] = None
+        else:
+            res = self._adj_dopri(w, u, P, rpp, par)
+        du = self._buf("du", n, nu) if need_du else None
+        dy0 = self._buf("dy0_adj", n, ns) if need_dy0 else None
+        if du is not None or dy0 is not None:
+            _lib.call("nlbac_adj_unpack", res.data_ptr(), ns, nu, n, dy0.data_ptr() if dy0 is not None else None,
+                      du.data_ptr() if du is not None else None, s)
+        return du, dy0
+
+    def _adj_dopri(self, w, u, P, rpp, par):
+        ctx = self.ctx
+        n, S, s = ctx["n"], 7, stream_ptr()
+        ctl = self._buf("adj_ctl", P, _lib.DOPRI_CTL, dtype=torch.float64)
+        cp = ctl.data_ptr()
+        KZ = w["KZ"]
+        keep = par and par["keep"]
+        # f0 = G(z(t1)) and Hairer's initial step
+        self._adj_step(w, u, P, rpp, "dopri5", 0, 1, h_host=[0.0] * P, keep=keep)
+        pn = self._adj_params_norm(par, 0, cp) if par else None
+        self._adj_norm_control(KZ[0], None, w, u, 0, P, rpp, ctl, pn)
+        self._adj_step(w, u, P, rpp, "probe", 1, 2, h_dev=cp + 8 * 6, keep=keep)             # C_H0
+        pn = self._adj_params_norm(par, 1, cp) if par else None
+        self._adj_norm_control(KZ[1], KZ[0], w, None, 1, P, rpp, ctl, pn)
+        c_sol, c_err = self._coef("sol"), self._coef("err")
+        chain = max(1, int(self.__dict__.get("_adj_chain", 1)))
+        attempts = 0
+        while True:
+            for i in range(chain):
+                if attempts:
+                    # accepted and not finished: z0 <- z1, first stage <- last stage (FSAL); decided on the device
+                    _lib.call("nlbac_adj_commit", cp, rpp, n, w["W"], w["Z0"].data_ptr(), w["Z1"].data_ptr(),
+                              KZ[0].data_ptr(), KZ[6].data_ptr(), s)
+                    if par:
+                        self._adj_params_commit(par, cp)
+                self._adj_step(w, u, P, rpp, "dopri5", 1, S, h_dev=cp, ctl=cp, c_out=c_sol, c_err=c_err, keep=keep)
+                pn = self._adj_params_norm(par, 2, cp) if par else None
+                self._adj_norm_control(w["ERR"], None, w, None, 2, P, rpp, ctl, pn)
+                attempts += 1
+            self._ctl_post(P, ctl)
+            c = self._ctl_read(P) if ctx.get("ctl_pending") == P else ctl.cpu()
+            if all(bool(c[p, 4] > 0) for p in range(P)):
+                break
+            if attempts >= self.ADJ_MAX_ATTEMPTS:
+                raise _lib.NlbacError("odeint_adjoint (dopri5): max_num_steps exceeded")
+            chain = 2
+        used = int(max(float(c[p, 10]) for p in range(P)))       # C_NSTEPS: attempts of the slowest problem
+        self._adj_chain = max(1, used)
+        ctx["adjoint_info"] = [[(float(c[p, 11]), float(c[p, 2]), int(c[p, 10])) for p in range(P)]]
+        # the interpolant of the last accepted step at t0 (steps are not clipped), all columns of z at once
+        _lib.call("nlbac_dopri_interp_fwd", w["Z0"].data_ptr(), w["Z1"].data_ptr(), KZ.data_ptr(), None, None, cp, P,
+                  rpp, w["W"], w["OUT"].data_ptr(), s)
+        if par:
+            self._adj_params_finish(par, cp)
+        return w["OUT"]
+
     def _stage_backward(self, ws, st, need_dx, need_params, du, up, coef, h_host, h_dev, h_stride):
         """Un-fused backward of one stage of the control-affine field: affine_bwd -> mlp_bwd_data[f,g] ->
         rk_stage_bwd (kept as the cross-check of nlbac_node_rk_bwd)."""
@@ -738,6 +953,10 @@ class AffineNodeSolver:
         Returns the number of slabs written."""
         ctx = self.ctx
         s = stream_ptr()
+        if self.adjoint:       # the adjoint solve has integrated the parameter adjoint already: one finished vector
+            par = ctx["adj_par"]
+            _lib.call("nlbac_axpby", 1.0, par["grad"].data_ptr(), 0.0, None, arena.n, arena.grad.data_ptr(), s)
+            return 1
         n_used = 0
         for si, step in enumerate(ctx["steps"]):
             ws = step["ws"]
@@ -813,11 +1032,16 @@ class ConcatNodeSolver(AffineNodeSolver):
         self.keep_acts = True
         self.stats = dict(solves=0, single_step=0, multi_attempt=0, split=0)
         self.comm = None
+        self.adjoint = False
 
     def _nets(self):
         if self._net_arr is None:
             self._net_arr = mlp_array([self.net.desc])
         return self._net_arr
+
+    def backward_adjoint(self, dout, need_du=True, need_params=False, need_dy0=False):
+        raise NotImplementedError("odeint_adjoint is built for the control-affine NODE (nlbac_node_adj_step); the "
+                                  "single-net NODE differentiates through the steps")
 
     def _rk_fused(self, ws, y0, u, P, rpp, method, st0, st1, h_host=None, h_dev=None, c_out=None, out=None,
                   c_err=None, err=None, save_acts=True):
@@ -915,26 +1139,28 @@ class ConcatNodeSolver(AffineNodeSolver):
 # — on the device kernels, differentiable w.r.t. y0 and the model's parameters through torch.autograd.
 # The agent itself drives the solvers directly (no autograd graph); this entry is for reference-shaped code.
 # ---------------------------------------------------------------------------
-def _solver_of(func):
+def _solver_of(func, adjoint=False):
     """The (cached) solver of a ``NeuralODEModel`` of this build; a model that is not part of an agent gets its own
-    parameter arena on the current device."""
+    parameter arena on the current device.  The adjoint entry keeps a solver of its own (it saves nothing in forward)."""
     from .sac_cbf_clf.model import NeuralODEModel
     if not isinstance(func, NeuralODEModel):
         raise TypeError("nlbac_amd.odeint integrates this build's NeuralODEModel (its field runs as HIP kernels); "
                         "got %s" % type(func).__name__)
-    sv = func.__dict__.get("_odeint_solver")
+    key = "_odeint_solver_adj" if adjoint else "_odeint_solver"
+    sv = func.__dict__.get(key)
     if sv is None:
         handles = func.device_handles()
         sv = (AffineNodeSolver if func.affine else ConcatNodeSolver)(func, handles[0].arena.device)
         sv.keep_acts = True                  # parameter gradients need the pre-activation gradients of every stage
-        func.__dict__["_odeint_solver"] = sv
+        sv.adjoint = bool(adjoint)
+        func.__dict__[key] = sv
     return sv
 
 
 class _OdeintFunction(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, func, method, dt, atol, rtol, y0, *params):
-        sv = _solver_of(func)
+    def forward(ctx, func, method, dt, atol, rtol, adjoint, y0, *params):
+        sv = _solver_of(func, bool(adjoint))
         ns, nu = sv.n_s, sv.n_u
         assert y0.dim() == 2 and y0.shape[1] == ns + nu, "y0 must be (batch, %d)" % (ns + nu)
         y0 = y0.detach().float().contiguous()
@@ -942,6 +1168,7 @@ class _OdeintFunction(torch.autograd.Function):
         x1 = sv.forward(x0, u, 1, y0.shape[0], method, dt, atol, rtol)
         ctx.func, ctx.sv, ctx.n_params = func, sv, len(params)
         ctx.solve_id = sv.stats["solves"]
+        ctx.with_params = adjoint != "no-params"
         return torch.stack([y0, torch.cat([x1, u], dim=1)])
 
     @staticmethod
@@ -951,9 +1178,9 @@ class _OdeintFunction(torch.autograd.Function):
             "odeint: backward must run before the next solve with the same model (the solver keeps one solve's state)"
         ns = sv.n_s
         g = g.float()
-        need_p = any(ctx.needs_input_grad[6:])
+        need_p = any(ctx.needs_input_grad[7:]) and ctx.with_params
         du, dy0 = sv.backward(g[1][:, :ns].contiguous(), need_du=True, need_params=need_p, need_dy0=True)
-        gy0 = g[0] + torch.cat([dy0, du + g[1][:, ns:]], dim=1) if ctx.needs_input_grad[5] else None
+        gy0 = g[0] + torch.cat([dy0, du + g[1][:, ns:]], dim=1) if ctx.needs_input_grad[6] else None
         gp = [None] * ctx.n_params
         if need_p:
             arena = func.device_handles()[0].arena
@@ -965,15 +1192,10 @@ class _OdeintFunction(torch.autograd.Function):
             for p in func.parameters():
                 off = arena.offset_of[id(p)]
                 gp.append(flat[off:off + p.numel()].view(p.shape))
-        return (None, None, None, None, None, gy0, *gp)
+        return (None, None, None, None, None, None, gy0, *gp)
 
 
-def odeint(func, y0, t, *, method="dopri5", atol=1e-7, rtol=1e-5, **options):
-    """``torchdiffeq.odeint`` for this build's NODE models on ``t = [t0, t1]``: returns ``stack([y0, y(t1)])`` with the
-    carried control columns passed through, differentiable w.r.t. ``y0`` and ``func.parameters()``.  ``method`` is
-    ``'euler'`` / ``'rk4'`` (one step over the interval, torchdiffeq's fixed-grid semantics) or ``'dopri5'``.
-    The packed MFMA copies of the weights are refreshed first, so a ``torch.optim`` step on ``func.parameters()``
-    between calls is picked up."""
+def _odeint(func, y0, t, method, atol, rtol, adjoint, options):
     if options:
         raise TypeError("odeint: unsupported options %s" % sorted(options))
     from .sac_cbf_clf.model import NeuralODEModel
@@ -986,7 +1208,27 @@ def odeint(func, y0, t, *, method="dopri5", atol=1e-7, rtol=1e-5, **options):
                                   % t.numel())
     dt = float(t[1]) - float(t[0])
     func.refresh_device_weights()
-    return _OdeintFunction.apply(func, method, dt, float(atol), float(rtol), y0, *func.parameters())
+    return _OdeintFunction.apply(func, method, dt, float(atol), float(rtol), adjoint, y0, *func.parameters())
 
 
-odeint_adjoint = odeint        # same gradient by direct backpropagation through the steps (no reference call site)
+def odeint(func, y0, t, *, method="dopri5", atol=1e-7, rtol=1e-5, **options):
+    """``torchdiffeq.odeint`` for this build's NODE models on ``t = [t0, t1]``: returns ``stack([y0, y(t1)])`` with the
+    carried control columns passed through, differentiable w.r.t. ``y0`` and ``func.parameters()``.  ``method`` is
+    ``'euler'`` / ``'rk4'`` (one step over the interval, torchdiffeq's fixed-grid semantics) or ``'dopri5'``.
+    The packed MFMA copies of the weights are refreshed first, so a ``torch.optim`` step on ``func.parameters()``
+    between calls is picked up."""
+    return _odeint(func, y0, t, method, atol, rtol, False, options)
+
+
+def odeint_adjoint(func, y0, t, *, method="dopri5", atol=1e-7, rtol=1e-5, adjoint_params=None, **options):
+    """``torchdiffeq.odeint_adjoint`` (0.2.3) on ``t = [t0, t1]``: the same forward solve, keeping only y(t1); the
+    backward integrates the augmented state [y, adj_y, adj_params] from t1 to t0 with the same method and tolerances
+    (``adjoint_rtol`` / ``adjoint_atol`` / ``adjoint_method`` default to the forward's in torchdiffeq; only those
+    defaults are offered) under torchdiffeq's default mixed adjoint norm.  Memory does not grow with the number of
+    steps, and the gradient equals direct back-propagation only to solver tolerance.  ``adjoint_params``: ``None`` —
+    every parameter of ``func`` (torchdiffeq's default, ``find_parameters``); ``()`` — no parameter adjoint (it then
+    also stays out of the step-size norm).  The reference never calls this; semantics follow the
+    published algorithm."""
+    if adjoint_params is not None and len(tuple(adjoint_params)) != 0:
+        raise NotImplementedError("odeint_adjoint: adjoint_params is None (all of func's parameters) or ()")
+    return _odeint(func, y0, t, method, atol, rtol, "no-params" if adjoint_params is not None else "params", options)

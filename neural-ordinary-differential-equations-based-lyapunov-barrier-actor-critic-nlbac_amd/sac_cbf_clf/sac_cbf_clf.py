@@ -235,8 +235,29 @@ class SAC_CBF_CLF(object):
         for sv in self.task.solvers:          # independent launches go in just before a solver waits for a decision
             sv.before_wait = self._fill_one
         self.use_graphs = False  # replay the update as hipGraphs (single GPU; see update_on_device)
+        self.adjoint = bool(getattr(args, "adjoint", False))
         self.dp = None          # nlbac_amd.parallel.DataParallel when sharded over GPUs
         self._xb = {}
+
+    @property
+    def adjoint(self):
+        """True: every NODE solve of the update is differentiated by the continuous adjoint (``odeint_adjoint``,
+        BASELINE configs[3]) — the rollouts without a parameter adjoint (the policy loss needs d/d action only), the
+        NODE fit with it — instead of back-propagating through the solver's steps."""
+        return self._adjoint
+
+    @adjoint.setter
+    def adjoint(self, on):
+        from ..odeint import ConcatNodeSolver
+        if on and any(isinstance(sv, ConcatNodeSolver) for sv in self.task.solvers):
+            raise NotImplementedError("odeint_adjoint is built for the control-affine NODE copies")
+        self._adjoint = bool(on)
+        for sv in self.task.solvers:
+            sv.adjoint = bool(on)
+
+    def _graphs_on(self):
+        # (a dopri5 adjoint solve reads its control block on the host: not capturable)
+        return self.use_graphs and self.world == 1 and self.task.graph_ok and not (self._adjoint and self.solver == "dopri5")
 
     @property
     def node_solver(self):
@@ -459,7 +480,7 @@ class SAC_CBF_CLF(object):
         w["u"].copy_(action)
         key = (p_obs, obs_ld, p_nobs, nobs_ld, self.solver)
         part1 = lambda: task.fit_part1(w, p_obs, obs_ld, p_nobs, nobs_ld, N)
-        if not (self.use_graphs and self.world == 1 and task.graph_ok) or w["warm"] < 1:
+        if not self._graphs_on() or w["warm"] < 1:
             w["warm"] += 1
             part1()
             self._fit_part2(w, N, task.fit_solver.forward_finish())
@@ -644,7 +665,7 @@ class SAC_CBF_CLF(object):
         lam_upd = 1 if updates % self.Lagrangian_multiplier_update_interval == 0 else 0
         NP = ws.np_now = self.task.n_pol_now(updates)
         ws.blam_upd = self.task.backup_lam_due(updates, self.Lagrangian_multiplier_update_interval)
-        if not (self.use_graphs and self.world == 1 and self.task.graph_ok) or ws.warm < 1:
+        if not self._graphs_on() or ws.warm < 1:
             ws.warm += 1
             self._upd_part1(ws, soft)
             self._upd_part2(ws, lam_upd, False)

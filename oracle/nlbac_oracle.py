@@ -247,6 +247,127 @@ def odeint(func, y0, t, method="euler", atol=1e-7, rtol=1e-5, info=None):
 
 
 # ---------------------------------------------------------------------------
+# odeint_adjoint restatement — torchdiffeq 0.2.3 ``OdeintAdjointMethod`` (torchdiffeq/_impl/adjoint.py) from the
+# published algorithm; the reference never calls it and the package is not in the container, so this is
+# SPEC FROM THE PUBLISHED ALGORITHM, PARITY UNPINNED.  What it restates:
+#   forward : ``odeint`` under no_grad, only y(t1) is kept
+#   backward: the augmented state (y, adj_y, adj_params) is integrated from t1 back to t0 with the same method and
+#             tolerances; d/dt (y, adj_y, adj_p) = (f, -adj_y^T df/dy, -adj_y^T df/dp); the decreasing time grid is
+#             handled the way ``_check_inputs`` does (t -> -t, f -> -f): in s = -t every right-hand side flips sign
+#   norm    : ``handle_adjoint_norm_`` default: max(rms(y part), rms(adj_y part), max_i rms(adj_param_i)) of the
+#             scaled quantity — a mixed norm over the tuple, every parameter tensor on its own
+#   result  : adaptive: the dopri5 interpolant at t0 for every component (steps are not clipped); fixed grid: one step
+# ---------------------------------------------------------------------------
+
+def _tuple_norm(parts):
+    return max([_rms(p) for p in parts] + [0.0])
+
+
+def _tuple_axpy(z0, ks, coefs, hf):
+    out = []
+    for i, z in enumerate(z0):
+        a = z
+        for c, k in zip(coefs, ks):
+            if c != 0:
+                a = a + k[i] * (np.float32(c) * hf)
+        out.append(a)
+    return out
+
+
+def odeint_tuple(G, z0, T, method, atol, rtol, info=None):
+    """Integrate dz/ds = G(z) over s in [0, T] for a list-of-tensors state with the mixed norm above.  Same solver
+    arithmetic as ``odeint`` (which is the one-tensor case with a plain RMS norm)."""
+    hT = np.float32(T)
+    if method == "euler":
+        return _tuple_axpy(z0, [G(z0)], [1.0], hT)
+    if method == "rk4":          # 3/8 rule in tableau form (the same numbers as ``odeint``'s rk4 up to rounding order)
+        ks = [G(z0)]
+        for beta in ([1 / 3], [-1 / 3, 1.0], [1.0, -1.0, 1.0]):
+            ks.append(G(_tuple_axpy(z0, ks, beta, hT)))
+        return _tuple_axpy(z0, ks, [1 / 8, 3 / 8, 3 / 8, 1 / 8], hT)
+    assert method == "dopri5", method
+    with torch.no_grad():
+        f0 = G(z0)
+        scale = [atol + z.abs() * rtol for z in z0]
+        d0 = _tuple_norm([z / s for z, s in zip(z0, scale)])
+        d1 = _tuple_norm([f / s for f, s in zip(f0, scale)])
+        h0 = 1e-6 if (d0 < 1e-5 or d1 < 1e-5) else 0.01 * d0 / d1
+        f1 = G(_tuple_axpy(z0, [f0], [1.0], np.float32(h0)))
+        d2 = _tuple_norm([(b - a) / s for a, b, s in zip(f0, f1, scale)]) / h0
+        h1 = max(1e-6, h0 * 1e-3) if (d1 <= 1e-15 and d2 <= 1e-15) else (0.01 / max(d1, d2)) ** (1.0 / 5.0)
+        h = min(100 * h0, h1)
+        tc, zc, fc, steps = 0.0, z0, f0, []
+        for n in range(1000):
+            hf = np.float32(h)
+            ks = [fc]
+            zi = zc
+            for beta in _DP_BETA:
+                zi = _tuple_axpy(zc, ks, beta, hf)
+                ks.append(G(zi))
+            zn, fn = zi, ks[-1]
+            err = [sum(k[i] * (np.float32(c) * hf) for c, k in zip(_DP_C_ERR, ks)) for i in range(len(zc))]
+            ratio = _tuple_norm([e / (atol + rtol * torch.max(a.abs(), b.abs())) for e, a, b in zip(err, zc, zn)])
+            accept = ratio <= 1
+            steps.append((h, ratio, accept))
+            fac = 10.0 if ratio == 0 else min(10.0, max(0.9 / ratio ** 0.2, 1.0 if ratio < 1 else 0.2))
+            if accept:
+                if tc + h >= T:
+                    x = (T - tc) / h
+                    out = [dopri5_interp(zc[i], zn[i], [k[i] for k in ks], h, x) for i in range(len(zc))]
+                    if info is not None:
+                        info["steps"] = steps
+                    return out
+                tc, zc, fc = tc + h, zn, fn
+            h = h * fac
+    raise AssertionError("max_num_steps exceeded")
+
+
+class _OdeintAdjoint(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, func, method, atol, rtol, info, n_params, y0, t, *params):
+        with torch.no_grad():
+            ans = odeint(func, y0, t, method=method, atol=atol, rtol=rtol, info=info)
+        ctx.func, ctx.method, ctx.atol, ctx.rtol, ctx.info = func, method, atol, rtol, info
+        ctx.save_for_backward(t, ans, *params)
+        return ans
+
+    @staticmethod
+    def backward(ctx, grad_y):
+        t, y, *params = ctx.saved_tensors
+        func = ctx.func
+        params = tuple(params)
+
+        def G(z):           # s-time right-hand side: minus the augmented dynamics of adjoint.py
+            yv, adj = z[0], z[1]
+            with torch.enable_grad():
+                yv = yv.detach().requires_grad_(True)
+                fe = func(t[0], yv)
+                vj = torch.autograd.grad(fe, (yv,) + params, -adj, allow_unused=True)
+            vj = [torch.zeros_like(x) if v is None else v for v, x in zip(vj, (yv,) + params)]
+            return [-fe.detach()] + [-v for v in vj]
+
+        z1 = [y[-1], grad_y[-1]] + [torch.zeros_like(p) for p in params]
+        binfo = {}
+        with torch.no_grad():
+            z0 = odeint_tuple(G, z1, float(t[1]) - float(t[0]), ctx.method, ctx.atol, ctx.rtol, binfo)
+        if ctx.info is not None:
+            ctx.info["adjoint_steps"] = binfo.get("steps")
+        adj_y = z0[1] + grad_y[0]
+        return (None, None, None, None, None, None, adj_y, None, *z0[2:])
+
+
+def odeint_adjoint(func, y0, t, method="euler", atol=1e-7, rtol=1e-5, adjoint_params=None, info=None):
+    """``torchdiffeq.odeint_adjoint`` on ``t = [t0, t1]`` (adjoint tolerances / method default to the forward ones,
+    as in torchdiffeq).  ``adjoint_params``: the tensors the parameter adjoint is integrated for — default: every
+    tensor of ``func.sd`` (torchdiffeq: ``find_parameters(func)``); ``()`` leaves the parameter adjoint out of the
+    augmented state and of the step-size norm."""
+    if adjoint_params is None:
+        adjoint_params = tuple(func.sd.values())
+    adjoint_params = tuple(p for p in adjoint_params if p.requires_grad)
+    return _OdeintAdjoint.apply(func, method, atol, rtol, info, len(adjoint_params), y0, t, *adjoint_params)
+
+
+# ---------------------------------------------------------------------------
 # the agent
 # ---------------------------------------------------------------------------
 
@@ -320,6 +441,16 @@ class OracleAgentBase:
         self.backup_augmented_term = 1.0
         self.cost_limit = 0.0
         self._setup_task(env)
+
+    adjoint = False           # True: every NODE solve is differentiated by ``odeint_adjoint`` (BASELINE configs[3])
+
+    def _ode(self, y0, t, info, fit=False):
+        """The solver call of the rollouts / the NODE fit.  With ``adjoint`` the rollouts integrate no parameter
+        adjoint (``adjoint_params=()``: the policy loss needs d/d action only), the fit integrates all of them."""
+        if self.adjoint:
+            return odeint_adjoint(self.node_fn, y0, t, method=self.solver, atol=1e-7, rtol=1e-5, info=info,
+                                  adjoint_params=None if fit else ())
+        return odeint(self.node_fn, y0, t, method=self.solver, atol=1e-7, rtol=1e-5, info=info)
 
     def _backup_due(self, updates):
         return True
@@ -466,11 +597,11 @@ class OracleUnicycleAgent(OracleAgentBase):
         st[:, 0], st[:, 1], st[:, 2] = o[:, 0], o[:, 1], np.arctan2(o[:, 3], o[:, 2])
         return torch.from_numpy(st).float()
 
-    def _rollout(self, state, action):
+    def _rollout(self, state, action, fit=False):
         y0 = torch.cat((state, action), -1)
         t = torch.tensor([0, self.env.dt])
         info = {}
-        y = odeint(self.node_fn, y0, t, method=self.solver, atol=1e-7, rtol=1e-5, info=info)[-1]
+        y = self._ode(y0, t, info, fit)[-1]
         return y[:, :3], info
 
     def _lookahead(self, st):
@@ -487,7 +618,7 @@ class OracleUnicycleAgent(OracleAgentBase):
         """model.py:221-260 via sac_cbf_clf.py:205-219."""
         st, nst = self.get_state(node_obs), self.get_state(node_next_obs)
         self.opt["node"].zero_grad()
-        pred, _ = self._rollout(st, node_action)
+        pred, _ = self._rollout(st, node_action, fit=True)
         loss = F.mse_loss(pred, nst)
         g = torch.autograd.grad(loss, list(self.node.values()))
         self._set_grads(self.node.values(), g)
@@ -542,17 +673,17 @@ class OracleCarsAgent(OracleAgentBase):
         o[:, 1::2] /= 30.0
         return o
 
-    def _rollout(self, state, action, t):
+    def _rollout(self, state, action, t, fit=False):
         y0 = torch.cat((state, action, t), -1)
         ts = torch.tensor([0, self.env.dt])
         info = {}
-        y = odeint(self.node_fn, y0, ts, method=self.solver, atol=1e-7, rtol=1e-5, info=info)[-1]
+        y = self._ode(y0, ts, info, fit)[-1]
         return y[:, :10], info
 
     def train_step(self, node_obs, node_action, node_next_obs, node_t):
         """C/model.py:208-252 via C/sac_cbf_clf.py:201-217."""
         st, nst = self.get_state(node_obs), self.get_state(node_next_obs)
-        pred, _ = self._rollout(st, node_action, node_t.reshape(-1, 1))
+        pred, _ = self._rollout(st, node_action, node_t.reshape(-1, 1), fit=True)
         loss = F.mse_loss(pred, nst)
         g = torch.autograd.grad(loss, list(self.node.values()))
         self._set_grads(self.node.values(), g)
@@ -641,17 +772,17 @@ class OraclePvtolAgent(OracleAgentBase):
         return torch.stack([st7[:, 0], st7[:, 1], c, s_, st7[:, 3], st7[:, 4], st7[:, 5], st7[:, 6], v0 / div,
                             v1 / div, torch.exp(-dist)], 1)
 
-    def _rollout(self, state6, action):
+    def _rollout(self, state6, action, fit=False):
         y0 = torch.cat((state6, action), -1)
         t = torch.tensor([0, self.env.dt])
         info = {}
-        y = odeint(self.node_fn, y0, t, method=self.solver, atol=1e-7, rtol=1e-5, info=info)[-1]
+        y = self._ode(y0, t, info, fit)[-1]
         return y[:, :6], info
 
     def train_step(self, node_obs, node_action, node_next_obs):
         """P/model.py:224-266 via P/sac_cbf_clf.py:205-219."""
         (_, st), (_, nst) = self.get_state(node_obs), self.get_state(node_next_obs)
-        pred, _ = self._rollout(st, node_action)
+        pred, _ = self._rollout(st, node_action, fit=True)
         loss = F.mse_loss(pred, nst)
         g = torch.autograd.grad(loss, list(self.node.values()))
         self._set_grads(self.node.values(), g)
@@ -863,7 +994,10 @@ class OraclePvtolBarrierAgent(OracleUnicycleBarrierAgent):
         return x_next, obs_pred, obs_pred, info
 
 
-def make_oracle(env, args, weights, solver="euler"):
+def make_oracle(env, args, weights, solver="euler", adjoint=False):
     kind = env.dynamics_mode + ("Barrier" if "barrier" in weights else "")
-    return {"Unicycle": OracleUnicycleAgent, "SimulatedCars": OracleCarsAgent, "Pvtol": OraclePvtolAgent,
-            "PvtolBarrier": OraclePvtolBarrierAgent, "UnicycleBarrier": OracleUnicycleBarrierAgent}[kind](env, args, weights, solver)
+    cls = {"Unicycle": OracleUnicycleAgent, "SimulatedCars": OracleCarsAgent, "Pvtol": OraclePvtolAgent,
+            "PvtolBarrier": OraclePvtolBarrierAgent, "UnicycleBarrier": OracleUnicycleBarrierAgent}[kind]
+    agent = cls(env, args, weights, solver)
+    agent.adjoint = bool(adjoint)
+    return agent

@@ -1,0 +1,233 @@
+"""GPU: ``odeint_adjoint`` (BASELINE configs[3], "dopri5 + adjoint backward") — the HIP adjoint solve
+(``nlbac_node_adj_step`` + the device-driven dopri5 chain) against the oracle's restatement of torchdiffeq 0.2.3's
+``OdeintAdjointMethod`` (same augmented system, same mixed norm, same step sequence: 1e-4) and against direct
+back-propagation through the solver's steps (equal only to solver tolerance).
+
+PARITY UNPINNED: the reference never calls ``odeint_adjoint`` and torchdiffeq is not in the container; the oracle
+follows the published algorithm (oracle/nlbac_oracle.py, ``odeint_adjoint``)."""
+import numpy as np
+import pytest
+import torch
+
+from common import vec_close
+from nlbac_amd import synth
+from test_agent_parity_gpu import make_agent, params_close, flat_params, flat_grad
+
+pytestmark = pytest.mark.gpu
+TOL = 1e-4
+DIMS = {"Unicycle": (3, 2, (3.5, 12.0)), "Pvtol": (6, 2, (3.5, 15.0))}
+
+
+def problem(env_name, n, seed, T_scale=1.0):
+    ns, nu, amax = DIMS[env_name]
+    g = torch.Generator().manual_seed(seed)
+    y0 = torch.rand(n, ns, generator=g) * 2 - 1
+    if env_name == "Unicycle":
+        y0 = y0 * torch.tensor([2.0, 2.0, 3.0])
+    u = (torch.rand(n, nu, generator=g) * 2 - 1) * torch.tensor(amax)
+    dout = torch.randn(n, ns, generator=g) / n          # cotangents of a batch-mean loss, as in the update
+    return y0, u, dout
+
+
+def oracle_adjoint(sd_np, y0, u, T, dout, method, ns, nu, with_params):
+    from oracle import nlbac_oracle as O
+    sd = {k: torch.tensor(v, requires_grad=True) for k, v in sd_np.items()}
+    y0 = y0.clone().requires_grad_(True)
+    u = u.clone().requires_grad_(True)
+    info = {}
+    out = O.odeint_adjoint(O.AffineNode(sd, n_s=ns, n_u=nu), torch.cat((y0, u), 1), torch.tensor([0.0, T]),
+                           method=method, atol=1e-7, rtol=1e-5, info=info,
+                           adjoint_params=None if with_params else ())[-1][:, :ns]
+    g = torch.autograd.grad((out * dout).sum(), [y0, u] + (list(sd.values()) if with_params else []))
+    gp = torch.cat([t.reshape(-1) for t in g[2:]]) if with_params else None
+    return out.detach(), g[0], g[1], gp, info
+
+
+def oracle_direct(sd_np, y0, u, T, dout, method, ns, nu):
+    from oracle import nlbac_oracle as O
+    sd = {k: torch.tensor(v, requires_grad=True) for k, v in sd_np.items()}
+    y0 = y0.clone().requires_grad_(True)
+    u = u.clone().requires_grad_(True)
+    out = O.odeint(O.AffineNode(sd, n_s=ns, n_u=nu), torch.cat((y0, u), 1), torch.tensor([0.0, T]), method=method,
+                   atol=1e-7, rtol=1e-5)[-1][:, :ns]
+    g = torch.autograd.grad((out * dout).sum(), [y0, u] + list(sd.values()))
+    return g[0], g[1], torch.cat([t.reshape(-1) for t in g[2:]])
+
+
+def same_sequence(n_attempts, steps):
+    """The device and the oracle took the same accept / reject decisions.  An adaptive solve of a ReLU field has
+    decisions with an error ratio within rounding of 1; where the oracle's own sequence holds such a marginal decision
+    the two may part ways there (both are valid dopri5 runs: they agree to solver tolerance, not to 1e-4)."""
+    if n_attempts == len(steps):
+        return True
+    assert any(abs(r - 1.0) < 0.05 for _, r, _ in steps), "step sequences differ without a marginal decision: %d vs %r" % (
+        n_attempts, steps)
+    return False
+
+
+def rel_l2(a, b):
+    a, b = np.asarray(a, dtype=np.float64), np.asarray(b, dtype=np.float64)
+    return float(np.linalg.norm(a - b) / max(np.linalg.norm(b), 1e-30))
+
+
+@pytest.mark.parametrize("env_name", ["Unicycle", "Pvtol"])
+@pytest.mark.parametrize("method", ["euler", "rk4", "dopri5"])
+@pytest.mark.parametrize("T", [0.02, 0.25])
+def test_adjoint_of_a_rollout_matches_the_oracle(env_name, method, T):
+    """Two problems (the primary / backup rows of a policy-loss rollout), ragged last tile, no parameter adjoint:
+    d/dy0 and d/du against the oracle's adjoint per problem, and against direct back-propagation."""
+    from nlbac_amd.odeint import AffineNodeSolver
+    ns, nu, _ = DIMS[env_name]
+    agent, env = make_agent(64, 64, 0, method, env_name)
+    W = synth.agent_weights(env_name, 64, 0)["node"]
+    rpp = 77
+    y0, u, dout = problem(env_name, 2 * rpp, 5)
+    u[rpp:] *= 3.0                                   # the second problem is stiffer: its own step sequence
+    sol = AffineNodeSolver(agent.neural_ode_model, "cuda")
+    sol.adjoint, sol.keep_acts = True, False
+    out = sol.forward(y0.cuda(), u.cuda(), 2, rpp, method, T).clone()
+    du, dy0 = sol.backward(dout.cuda(), need_du=True, need_dy0=True)
+    du, dy0 = du.cpu().numpy(), dy0.cpu().numpy()
+    for p in range(2):
+        rows = slice(p * rpp, (p + 1) * rpp)
+        out_o, dy0_o, du_o, _, info = oracle_adjoint(W, y0[rows], u[rows], T, dout[rows], method, ns, nu, False)
+        vec_close(out[rows].cpu().numpy(), out_o.numpy(), TOL, "x(T) problem %d" % p)
+        tol = TOL
+        if method == "dopri5":      # the device took the oracle's step sequence
+            st = info["adjoint_steps"]
+            h_used, ratio, n_att = sol.ctx["adjoint_info"][0][p]
+            if same_sequence(n_att, st):
+                assert abs(h_used - st[-1][0]) <= 1e-4 * st[-1][0]
+            else:
+                tol = 5e-3
+        vec_close(dy0[rows], dy0_o.numpy(), tol, "adjoint d/dy0 problem %d (%s)" % (p, info.get("adjoint_steps")))
+        vec_close(du[rows], du_o.numpy(), tol, "adjoint d/du problem %d" % p)
+        # continuous adjoint vs the exact gradient of the discrete solve: solver tolerance (one fixed step of
+        # h = T for euler / rk4: O(h) resp. O(h^4) apart)
+        gd = oracle_direct(W, y0[rows], u[rows], T, dout[rows], method, ns, nu)
+        bar = {"euler": 0.2, "rk4": 1e-3 if T < 0.1 else 0.1, "dopri5": 5e-3}[method]
+        assert rel_l2(dy0[rows], gd[0].numpy()) < bar and rel_l2(du[rows], gd[1].numpy()) < bar, (
+            rel_l2(dy0[rows], gd[0].numpy()), rel_l2(du[rows], gd[1].numpy()))
+
+
+@pytest.mark.parametrize("env_name", ["Unicycle", "Pvtol"])
+@pytest.mark.parametrize("method", ["euler", "rk4", "dopri5"])
+def test_odeint_adjoint_entry_with_parameter_adjoint(env_name, method):
+    """``odeint_adjoint(func, y0, t)`` under torch.autograd, torchdiffeq's defaults: every parameter of ``func`` is an
+    adjoint parameter and takes part in the step-size norm (per tensor).  Gradients w.r.t. y0 and the parameters
+    against the oracle's adjoint; the dopri5 adjoint solve takes several steps here."""
+    from nlbac_amd.odeint import odeint_adjoint
+    ns, nu, _ = DIMS[env_name]
+    agent, env = make_agent(64, 64, 0, method, env_name)
+    m = agent.neural_ode_model
+    W = synth.agent_weights(env_name, 64, 0)["node"]
+    n, T = 200, 0.02
+    y0, u, dout = problem(env_name, n, 11)
+    out_o, dy0_o, du_o, gp_o, info = oracle_adjoint(W, y0, u, T, dout, method, ns, nu, True)
+    y0d = torch.cat((y0, u), 1).cuda().requires_grad_()
+    out = odeint_adjoint(m, y0d, torch.tensor([0.0, T]), method=method, atol=1e-7, rtol=1e-5)
+    w = torch.zeros(2, n, ns + nu)
+    w[1, :, :ns] = dout
+    (out * w.cuda()).sum().backward()
+    vec_close(out[1, :, :ns].detach().cpu().numpy(), out_o.numpy(), TOL, "y(t1)")
+    gy = y0d.grad.cpu().numpy()
+    tol = TOL
+    if method == "dopri5":
+        from nlbac_amd.odeint import _solver_of
+        sv = _solver_of(m, True)
+        st = info["adjoint_steps"]
+        assert len(st) >= 3, "the parameter adjoint should make this solve take several steps: %r" % (st,)
+        if not same_sequence(sv.ctx["adjoint_info"][0][0][2], st):
+            tol = 5e-3
+    vec_close(gy[:, :ns], dy0_o.numpy(), tol, "adjoint d/dy0")
+    vec_close(gy[:, ns:], du_o.numpy(), tol, "adjoint d/du")
+    gp = torch.cat([p.grad.reshape(-1) for p in m.parameters()]).cpu().numpy()
+    assert rel_l2(gp, gp_o.numpy()) < max(1e-3, tol), "parameter adjoint: relative L2 error %.3e (%s)" % (
+        rel_l2(gp, gp_o.numpy()), info.get("adjoint_steps"))
+    # adjoint_params=(): no parameter gradient, same state gradient as the rollout form
+    for p in m.parameters():
+        p.grad = None
+    y0e = torch.cat((y0, u), 1).cuda().requires_grad_()
+    out = odeint_adjoint(m, y0e, torch.tensor([0.0, T]), method=method, atol=1e-7, rtol=1e-5, adjoint_params=())
+    (out * w.cuda()).sum().backward()
+    assert all(p.grad is None for p in m.parameters())
+    _, dy0_n, du_n, _, _ = oracle_adjoint(W, y0, u, T, dout, method, ns, nu, False)
+    vec_close(y0e.grad.cpu().numpy()[:, :ns], dy0_n.numpy(), TOL, "adjoint d/dy0 (no parameter adjoint)")
+
+
+@pytest.mark.parametrize("env_name,solver", [("Pvtol", "dopri5"), ("Pvtol", "euler"), ("Unicycle", "dopri5"),
+                                             ("PvtolBarrier", "rk4")])
+@pytest.mark.parametrize("B", [128])
+def test_update_with_adjoint_matches_the_oracle(env_name, solver, B):
+    """Whole updates with every NODE solve differentiated by the adjoint (three chained rollouts in Pvtol, the NODE
+    fit with the parameter adjoint) against the oracle agent doing the same."""
+    from oracle import nlbac_oracle as O
+    torch.set_num_threads(4)
+    seed, hidden = 0, 64
+    gamma_b = {"Pvtol": 0.8, "Unicycle": 50.0, "PvtolBarrier": 0.8}[env_name]
+    agent, env = make_agent(B, hidden, seed, solver, env_name, gamma_b)
+    agent.adjoint = True
+    oargs = O.Args(batch_size=B, hidden_size=hidden, seed=seed)
+    oargs.gamma_b = gamma_b
+    oracle = O.make_oracle(synth.fixture_env(env_name, seed), oargs, synth.agent_weights(env_name, hidden, seed),
+                           solver=solver, adjoint=True)
+    tr = synth.transitions(env_name, 4096, seed=seed + 1, env=env)
+    fields = synth.fields(env_name)
+    lr = dict(critic=4e-4, policy=3e-4, node=1e-3)
+    for ci, updates in enumerate((0, 1, 20)):
+        rs = np.random.RandomState(ci)
+        idx, nidx = rs.choice(4096, B, replace=False), rs.choice(4096, 512, replace=False)
+        batch = {f: torch.tensor(tr[f][idx], dtype=torch.float32) for f in fields}
+        eps = [torch.from_numpy(e) for e in synth.normal_eps(agent.task.n_eps, B, env.n_u, seed=ci)]
+        with_fit = updates % 10 == 0
+        node = tuple(torch.tensor(tr[f][nidx], dtype=torch.float32) for f in ("obs", "action", "next_obs"))
+        R = oracle.update(batch, eps, updates, node_batch=node if with_fit else None)
+        agent.set_noise(eps)
+        ret = agent.update_from_host(tuple(batch[f].numpy() for f in fields), updates,
+                                     tuple(t.numpy() for t in node) if with_fit else None)
+        torch.cuda.synchronize()
+        vec_close(ret, R["ret"], TOL, "ret (update %d)" % updates)
+        v = flat_grad(agent, agent.ar_a, agent.policy)
+        vec_close(v, R["g_policy"], 2e-4, "policy gradient through the adjoint (update %d)" % updates)
+        if with_fit:
+            gn = flat_grad(agent, agent.ar_n, agent.neural_ode_model)
+            assert rel_l2(gn.numpy(), R["g_node"].numpy()) < 1e-3, "NODE-fit gradient through the parameter adjoint"
+        for name, mod, osd in (("critic", agent.critic, oracle.critic), ("policy", agent.policy, oracle.policy),
+                               ("node", agent.neural_ode_model, oracle.node)):
+            ov = torch.cat([osd[k].detach().reshape(-1) for k in osd])
+            params_close(flat_params(mod), ov, lr[name] * (ci + 1), "params %s (update %d)" % (name, updates))
+
+
+def test_pvtol_full_size_dopri5_adjoint():
+    """BASELINE configs[3] at its full size: Pvtol dims, batch 16384, dopri5, adjoint backward; NODE fit on 32768
+    rows through the parameter adjoint.  The six returned floats against the oracle, and the adjoint's action
+    gradient against direct back-propagation of the same update at solver tolerance."""
+    from oracle import nlbac_oracle as O
+    B, H, env_name, solver = 16384, 256, "Pvtol", "dopri5"
+    torch.set_num_threads(max(1, min(16, torch.get_num_threads())))
+    oargs = O.Args(batch_size=B, hidden_size=H, seed=0)
+    oargs.gamma_b = 0.8
+    oracle = O.make_oracle(synth.fixture_env(env_name, 0), oargs, synth.agent_weights(env_name, H, 0), solver=solver,
+                           adjoint=True)
+    agent, env = make_agent(B, H, 0, solver, env_name, 0.8)
+    agent.adjoint = True
+    direct, _ = make_agent(B, H, 0, solver, env_name, 0.8)
+    tr = synth.transitions(env_name, 32768, seed=3, env=env)
+    fields = synth.fields(env_name)
+    for u in (0, 1):
+        idx = np.random.RandomState(u).choice(32768, B, replace=False)
+        batch = {f: torch.tensor(tr[f][idx], dtype=torch.float32) for f in fields}
+        eps = [torch.from_numpy(e) for e in synth.normal_eps(agent.task.n_eps, B, env.n_u, seed=u)]
+        node = tuple(torch.tensor(tr[f][:32768], dtype=torch.float32) for f in ("obs", "action", "next_obs")) if u == 0 else None
+        R = oracle.update(batch, eps, u, node_batch=node)
+        rets = []
+        for a in (agent, direct):
+            a.set_noise(eps)
+            rets.append(a.update_from_host(tuple(batch[f].numpy() for f in fields), u,
+                                           tuple(x.numpy() for x in node) if node else None))
+        worst = max(abs(a - b) / (abs(b) + 1e-3) for a, b in zip(rets[0], R["ret"]))
+        assert worst < 1e-4, "update %d: max rel err vs oracle %.2e" % (u, worst)
+        ga = flat_grad(agent, agent.ar_a, agent.policy).numpy()
+        vec_close(ga, R["g_policy"].numpy(), 2e-4, "policy gradient vs the oracle's adjoint (update %d)" % u)
+        gd = flat_grad(direct, direct.ar_a, direct.policy).numpy()
+        assert rel_l2(ga, gd) < 5e-3, "adjoint vs direct back-propagation: %.3e" % rel_l2(ga, gd)
