@@ -33,6 +33,14 @@ NODE_FIT_ROWS, NODE_FIT_INTERVAL, REPLAY_ROWS = 32768, 10, 65536
 GAMMA_B = {"Unicycle": 50.0, "SimulatedCars": 0.5, "UnicycleBarrier": 5.0, "Pvtol": 0.8, "PvtolBarrier": 1.0}       # the reference README's run commands
 
 
+# what each --env is in terms of BASELINE.json (the learned-barrier copies are the reference's NU / NP agents on a
+# control-affine NODE: NOT configs[4], whose Quadrotor-like task is --env QuadrotorLike)
+WORKLOAD_NOTE = {"Unicycle": "BASELINE.json configs[1] at B=4096 dopri5", "SimulatedCars": "BASELINE.json configs[2] at B=8192 rk4",
+                 "Pvtol": "BASELINE.json configs[3] at B=16384 dopri5 --adjoint",
+                 "UnicycleBarrier": "the reference's learned-barrier Unicycle copy NU; no BASELINE config",
+                 "PvtolBarrier": "the reference's learned-barrier Pvtol copy NP; no BASELINE config"}
+
+
 class Args:
     gamma, gamma_b, tau, alpha, lr = 0.99, 50.0, 0.005, 0.2, 3e-4
     hidden_size, target_update_interval, Lagrangian_multiplier_update_interval = 256, 1, 8
@@ -65,6 +73,13 @@ def launch_flops(name, args):
             per += m[-1] + sum(m[1:-1]) + m[0]
         stages = (st_hi - st_lo) - (0 if (dx0 or st_lo > 0) else 1)
         return 2 * P * rpp * stages * (per + 2 * g.out_dim)
+    if name == "nlbac_node_adj_step":     # (f, g, u, P, rpp, st_lo, st_hi, ...): every stage = field eval + its data backward
+        f, g, P, rpp, st_lo, st_hi = args[0]._obj, args[1]._obj, args[3], args[4], args[5], args[6]
+        per = 0
+        for net in (f, g):
+            m = _layer_macs(net)
+            per += sum(m) + m[-1] + sum(m[1:-1]) + m[0]
+        return 2 * P * rpp * (st_hi - st_lo) * (per + 3 * g.out_dim)
     if name == "nlbac_concat_rk_fwd":     # (net, y0, c, P, rpp, st0, st1, ...): stages x rows x NODE eval
         net, P, rpp, st0, st1 = args[0]._obj, args[3], args[4], args[5], args[6]
         return 2 * P * rpp * (st1 - st0) * sum(_layer_macs(net))
@@ -88,7 +103,7 @@ def launch_flops(name, args):
 class KernelTimer:
     """HIP events (torch.cuda.Event on the launch stream) around every launch of the MLP kernels."""
     NAMES = ("nlbac_mlp_fwd", "nlbac_mlp_bwd_data", "nlbac_mlp_bwd_weights", "nlbac_node_rk_fwd", "nlbac_node_rk_bwd",
-             "nlbac_concat_rk_fwd", "nlbac_concat_rk_bwd")
+             "nlbac_node_adj_step", "nlbac_concat_rk_fwd", "nlbac_concat_rk_bwd")
 
     def __init__(self):
         self.records = {n: [] for n in self.NAMES}
@@ -154,7 +169,7 @@ def host_cores():
     return max(1, min(n, 16))
 
 
-def cpu_baseline(B, solver, env_name="Unicycle", seed=0):
+def cpu_baseline(B, solver, env_name="Unicycle", seed=0, adjoint=False):
     """The oracle (CPU restatement pinned to the reference) timed on this box's host cores on a
     bounded sample of the same workload: 2 updates at batch B + 1 NODE fit on 32768 rows."""
     from oracle import nlbac_oracle as O
@@ -165,7 +180,7 @@ def cpu_baseline(B, solver, env_name="Unicycle", seed=0):
     W = synth.agent_weights(env_name, 256, seed)
     oargs = O.Args(batch_size=B, hidden_size=256, seed=seed)
     oargs.gamma_b = GAMMA_B[env_name]
-    agent = O.make_oracle(env, oargs, W, solver=solver)
+    agent = O.make_oracle(env, oargs, W, solver=solver, adjoint=adjoint)
     tr = synth.transitions(env_name, REPLAY_ROWS, seed=1, env=env)
     fields = synth.fields(env_name)
     rs = np.random.RandomState(0)
@@ -190,8 +205,9 @@ def cpu_baseline(B, solver, env_name="Unicycle", seed=0):
     per_update = t_upd + t_fit / NODE_FIT_INTERVAL
     return dict(value=B / per_update, unit="samples/s", cores=cores, kind="port",
                 sample="oracle (PyTorch-CPU restatement): %d updates at B=%d (%.2f s each) + 1 NODE fit on %d rows "
-                       "(%.2f s, amortised /%d), solver %s" % (n_upd, B, t_upd, NODE_FIT_ROWS, t_fit,
-                                                                NODE_FIT_INTERVAL, solver))
+                       "(%.2f s, amortised /%d), solver %s%s" % (n_upd, B, t_upd, NODE_FIT_ROWS, t_fit,
+                                                                  NODE_FIT_INTERVAL, solver,
+                                                                  " + odeint_adjoint" if adjoint else ""))
 
 
 def node_odeint_submetric(agent, env, B, solver, iters=50):
@@ -232,6 +248,8 @@ def main():
     ap.add_argument("--batch", type=int, default=4096)
     ap.add_argument("--solver", default="dopri5", choices=["euler", "rk4", "dopri5"])
     ap.add_argument("--env", default="Unicycle", choices=["Unicycle", "SimulatedCars", "UnicycleBarrier", "Pvtol", "PvtolBarrier"])
+    ap.add_argument("--adjoint", action="store_true",
+                    help="differentiate every NODE solve by the continuous adjoint (odeint_adjoint; BASELINE configs[3])")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--graphs", action="store_true",
                     help="replay the update as hipGraphs (measured equal to eager launches once descriptors are cached)")
@@ -265,6 +283,7 @@ def main():
     args.gamma_b = GAMMA_B[a.env]
     agent = SAC_CBF_CLF(env.obs_dim, env.action_space, env, args)
     agent.solver = a.solver
+    agent.adjoint = a.adjoint
     agent.use_graphs = (world == 1) and a.graphs
     if world > 1:
         agent.enable_data_parallel(dist)
@@ -348,6 +367,7 @@ def main():
         kname = {"nlbac_mlp_fwd": "mlp_fwd_kernel", "nlbac_mlp_bwd_data": "mlp_bwd_data_kernel",
                  "nlbac_mlp_bwd_weights": "mlp_bwd_wide_kernel+mlp_bwd_skinny_partial/reduce_kernel",
                  "nlbac_node_rk_fwd": "node_rk_fwd_kernel", "nlbac_node_rk_bwd": "node_rk_bwd_kernel",
+                 "nlbac_node_adj_step": "node_adj_kernel",
                  "nlbac_concat_rk_fwd": "concat_rk_fwd_kernel", "nlbac_concat_rk_bwd": "concat_rk_bwd_kernel"}[dom]
         roofline = dict(bound="mfma", kernel=kname, achieved=ks[dom]["tflops"], peak=PEAK_F32_MFMA_TFLOPS,
                         unit="TFLOP/s", frac=ks[dom]["tflops"] / PEAK_F32_MFMA_TFLOPS,
@@ -369,7 +389,7 @@ def main():
 
     cpu = None
     if rank == 0 and world == 1 and not a.no_cpu_baseline:
-        cpu = cpu_baseline(B, a.solver, a.env)
+        cpu = cpu_baseline(B, a.solver, a.env, adjoint=a.adjoint)
 
     if rank == 0:
         out = {
@@ -378,10 +398,11 @@ def main():
             "value": value, "unit": "samples/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
             "ms_per_step": 1e3 * elapsed / a.steps, "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-            "config": {"workload": "%s B=%d %s (BASELINE.json configs[%d]); NODE fit on %d rows every %d "
+            "config": {"workload": "%s B=%d %s%s (%s); NODE fit on %d rows every %d "
                                    "updates; replay of %d synthetic transitions resident in HBM"
-                                   % (a.env, B, a.solver, {"Unicycle": 1, "SimulatedCars": 2, "Pvtol": 3, "UnicycleBarrier": 4, "PvtolBarrier": 4}[a.env], NODE_FIT_ROWS, NODE_FIT_INTERVAL, REPLAY_ROWS),
-                       "solver": a.solver, "batch_per_gpu": B, "global_batch": B * world,
+                                   % (a.env, B, a.solver, " + odeint_adjoint" if a.adjoint else "", WORKLOAD_NOTE[a.env],
+                                      NODE_FIT_ROWS, NODE_FIT_INTERVAL, REPLAY_ROWS),
+                       "solver": a.solver, "adjoint": bool(a.adjoint), "batch_per_gpu": B, "global_batch": B * world,
                        "parallelism": "dp%d" % world, "hipgraph": bool(agent.use_graphs),
                        "rollout_solver_stats": solver_stats, "last_losses": [float(x) for x in ret]},
             "roofline": roofline, "cpu_baseline": cpu, "node_odeint_fwd_bwd": ode_sub,

