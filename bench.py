@@ -30,7 +30,7 @@ from nlbac_amd.envspec import make_env
 
 PEAK_F32_MFMA_TFLOPS = 157.3     # MI355X_MICROARCH.md, chip-level parameters
 NODE_FIT_ROWS, NODE_FIT_INTERVAL, REPLAY_ROWS = 32768, 10, 65536
-GAMMA_B = {"Unicycle": 50.0, "SimulatedCars": 0.5, "UnicycleBarrier": 5.0, "Pvtol": 0.8, "PvtolBarrier": 1.0}       # the reference README's run commands
+GAMMA_B = {"QuadrotorLike": 1.0, "Unicycle": 50.0, "SimulatedCars": 0.5, "UnicycleBarrier": 5.0, "Pvtol": 0.8, "PvtolBarrier": 1.0}       # the reference README's run commands
 
 
 # what each --env is in terms of BASELINE.json (the learned-barrier copies are the reference's NU / NP agents on a
@@ -38,7 +38,9 @@ GAMMA_B = {"Unicycle": 50.0, "SimulatedCars": 0.5, "UnicycleBarrier": 5.0, "Pvto
 WORKLOAD_NOTE = {"Unicycle": "BASELINE.json configs[1] at B=4096 dopri5", "SimulatedCars": "BASELINE.json configs[2] at B=8192 rk4",
                  "Pvtol": "BASELINE.json configs[3] at B=16384 dopri5 --adjoint",
                  "UnicycleBarrier": "the reference's learned-barrier Unicycle copy NU; no BASELINE config",
-                 "PvtolBarrier": "the reference's learned-barrier Pvtol copy NP; no BASELINE config"}
+                 "PvtolBarrier": "the reference's learned-barrier Pvtol copy NP; no BASELINE config",
+                 "QuadrotorLike": "BASELINE.json configs[4] at B=32768: Quadrotor-like SYNTHETIC task — the reference has "
+                                  "no code for it (empty submodule), parity vs the oracle's reading of README.md:190-192 only"}
 
 
 class Args:
@@ -247,7 +249,7 @@ def main():
     ap.add_argument("--warmup", type=int, default=20)
     ap.add_argument("--batch", type=int, default=4096)
     ap.add_argument("--solver", default="dopri5", choices=["euler", "rk4", "dopri5"])
-    ap.add_argument("--env", default="Unicycle", choices=["Unicycle", "SimulatedCars", "UnicycleBarrier", "Pvtol", "PvtolBarrier"])
+    ap.add_argument("--env", default="Unicycle", choices=["Unicycle", "SimulatedCars", "UnicycleBarrier", "Pvtol", "PvtolBarrier", "QuadrotorLike"])
     ap.add_argument("--adjoint", action="store_true",
                     help="differentiate every NODE solve by the continuous adjoint (odeint_adjoint; BASELINE configs[3])")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -273,7 +275,7 @@ def main():
         else:
             dist.init_process_group(backend)
 
-    if a.env.endswith("Barrier"):
+    if a.env.endswith("Barrier") or a.env == "QuadrotorLike":
         from nlbac_amd.neural_barrier_certificate.sac_cbf_clf.sac_cbf_clf import SAC_CBF_CLF
     else:
         from nlbac_amd.sac_cbf_clf.sac_cbf_clf import SAC_CBF_CLF

@@ -317,16 +317,22 @@ int nlbac_node_rk_bwd(const nlbac_mlp *f, const nlbac_mlp *g, const float *u, co
  * (SimulatedCars, C/sac_cbf_clf/model.py:179-205; odeint call sites C/sac_cbf_clf/sac_cbf_clf.py:437,458,581,603,
  * C/model.py:245): n_s = net->out_dim state columns, n_c = net->in_dim - n_s carried columns (c: (rows, n_c)),
  * hidden width <= 128.  Arguments as in nlbac_node_rk_fwd / _bwd; acts hold activations (floats); dc = gradient
- * w.r.t. the carried inputs (dc_acc: 0 overwrite, 1 add to the buffer's contents). */
+ * w.r.t. the carried inputs (dc_acc: 0 overwrite, 1 add to the buffer's contents).
+ * norm (or NULL): the field is  dx/dt = out_mu + out_sig * net(([x | c] - in_mu) * in_isig)  — inputs normalised,
+ * outputs de-normalised inside the kernels (the Quadrotor NODE of /root/reference/README.md:192; BASELINE configs[4]);
+ * norm = [in_mu (in_dim) | in_isig (in_dim) | out_mu (n_s) | out_sig (n_s)] on the device.  What the weight gradients
+ * then need is kept on request: Xn [stage][n][in_dim] the normalised net inputs (forward), dyn [stage][n][n_s] the
+ * gradient w.r.t. the net's own output (backward, with dz). */
 int nlbac_concat_rk_fwd(const nlbac_mlp *net, const float *y0, const float *c, int P, int rows_per_problem,
                         int stage_begin, int stage_end, int n_stages_total, const float *beta,
                         const float *c_out, int n_out, const float *c_err, int n_err, const float *h_host,
                         const double *h_dev, int h_dev_stride, float *K, float *Y, float *acts, long acts_ls,
-                        float *out, float *err, nlbac_stream_t s);
+                        float *out, float *err, const float *norm, float *Xn, nlbac_stream_t s);
 int nlbac_concat_rk_bwd(const nlbac_mlp *net, int P, int rows_per_problem, int n_stages_total, int st_lo,
                         int st_hi, int dx_stage0, const float *beta, const float *h_host, const double *h_dev,
                         int h_dev_stride, const float *acts, long acts_ls, float *dz, float *dK, const float *dYup,
-                        float *dy0, int dy0_in, float *dc, int dc_acc, nlbac_stream_t s);
+                        float *dy0, int dy0_in, float *dc, int dc_acc, const float *norm, float *dyn,
+                        nlbac_stream_t s);
 /* dopri5 step control on the device.  ctl: per problem NLBAC_DOPRI_CTL doubles
  * {h, t, ratio, accept, done, x, h0, d0, d1, d2, n_steps, h_used}.
  * norm partials [P][ceil(rows/256)][2]; mode 0: (y0/scale, f0/scale) with a=f0;

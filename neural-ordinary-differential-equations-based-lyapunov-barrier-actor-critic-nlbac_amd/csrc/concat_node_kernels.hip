@@ -28,6 +28,11 @@ struct ConcatRkLaunch {
     float* K; float* Y;
     float* acts; long acts_ls;
     float* out; float* err;
+    // input normalisation / output de-normalisation of the field (the Quadrotor NODE, /root/reference/README.md:192):
+    // dx/dt = out_mu + out_sig * net(([x | c] - in_mu) * in_isig); norm = [in_mu | in_isig] (in_dim each) then
+    // [out_mu | out_sig] (n_s each), or null.  Xn: [stage][n][in_dim] normalised net inputs kept for the first layer's
+    // weight gradient (or null).
+    const float* norm; float* Xn;
     int ld;
 };
 
@@ -55,13 +60,17 @@ __global__ __launch_bounds__(NTHR) void concat_rk_fwd_kernel(const ConcatRkLaunc
     float* sC = sY0 + NLBAC_MLP_TILE * CK_NS;                       // [32][CK_NC]
     float* sH = sC + NLBAC_MLP_TILE * CK_NC;                        // [32]
     float* sW = sH + NLBAC_MLP_TILE;                                // output layer [out][hid], then its bias
+    float* sN = sW + ((net.out_dim * (hid + 1) + 3) & ~3);          // [in_mu | in_isig | out_mu | out_sig] (norm only)
     {
         const float* W = net.params + net.w_off[nwide];
         const float* bsrc = net.params + net.b_off[nwide];
         const int nw = net.out_dim * hid;
         for (int idx = tid; idx < nw; idx += NTHR) sW[idx] = W[idx];
         for (int idx = tid; idx < net.out_dim; idx += NTHR) sW[nw + idx] = bsrc[idx];
+        if (L.norm)
+            for (int idx = tid; idx < 2 * net.in_dim + 2 * ns; idx += NTHR) sN[idx] = L.norm[idx];
     }
+    const int idim = net.in_dim;
     for (int idx = tid; idx < NLBAC_MLP_TILE * CK_NS; idx += NTHR) {
         const int m = idx / CK_NS, c = idx - m * CK_NS, row = row0 + m;
         sY0[idx] = (row < n && c < ns) ? L.y0[(long)row * ns + c] : 0.f;
@@ -97,6 +106,10 @@ __global__ __launch_bounds__(NTHR) void concat_rk_fwd_kernel(const ConcatRkLaunc
             } else if (c < ns + nc) {
                 a = sC[m * CK_NC + (c - ns)];
             }
+            if (L.norm && c < idim) {
+                a = (a - sN[c]) * sN[idim + c];
+                if (L.Xn && row0 + m < n) L.Xn[((long)st * n + row0 + m) * idim + c] = a;
+            }
             in[m * LD + c] = a;
         }
         __syncthreads();
@@ -107,7 +120,8 @@ __global__ __launch_bounds__(NTHR) void concat_rk_fwd_kernel(const ConcatRkLaunc
         // ---- output layer: k_st
         for (int idx = tid; idx < NLBAC_MLP_TILE * net.out_dim; idx += NTHR) {
             const int m = idx & 31, o = idx >> 5, row = row0 + m;
-            const float val = skinny_row_dot(in + m * LD, sW + o * hid, hid) + sW[net.out_dim * hid + o];
+            float val = skinny_row_dot(in + m * LD, sW + o * hid, hid) + sW[net.out_dim * hid + o];
+            if (L.norm) val = val * sN[2 * idim + ns + o] + sN[2 * idim + o];
             sK[(st * NLBAC_MLP_TILE + m) * CK_NS + o] = val;
             if (row < n) L.K[((long)st * n + row) * ns + o] = val;
         }
@@ -150,6 +164,8 @@ struct ConcatRkBwdLaunch {
     int n, rpp, n_s, n_c, S_total, st_lo, st_hi, dx_stage0;
     float beta[CK_MAX_STAGES][CK_MAX_STAGES];
     const double* h_dev; int h_stride; float h_val[8];
+    const float* norm;                // as ConcatRkLaunch::norm
+    float* dyn;                       // [stage][n][n_s] gradient w.r.t. the net's own output (dK * out_sig), kept with dz
     int ld;
 };
 
@@ -175,6 +191,10 @@ __global__ __launch_bounds__(NTHR) void concat_rk_bwd_kernel(const ConcatRkBwdLa
     float* sdy = sDX + NLBAC_MLP_TILE * CK_NS;                      // [32][16] output-layer gradient
     float* sW = sdy + NLBAC_MLP_TILE * 16;                          // W_last [out][hid], then W_0^T [in][hid]
     float* sW0t = sW + net.out_dim * hid;
+    float* sN = sW + (((net.out_dim + net.in_dim) * hid + 3) & ~3);   // [in_mu | in_isig | out_mu | out_sig] (norm only)
+    const int idim = net.in_dim;
+    if (L.norm)
+        for (int idx = tid; idx < 2 * idim + 2 * ns; idx += NTHR) sN[idx] = L.norm[idx];
 
     const int st_lo = L.st_lo;
     const bool stage0_data = L.dx_stage0 || keep_dz;
@@ -217,7 +237,12 @@ __global__ __launch_bounds__(NTHR) void concat_rk_bwd_kernel(const ConcatRkBwdLa
         __builtin_amdgcn_sched_barrier(0);
         for (int rem = tid; rem < NLBAC_MLP_TILE * 16; rem += NTHR) {
             const int m = rem >> 4, o = rem & 15;
-            sdy[rem] = (o < ns) ? sDK[(st * NLBAC_MLP_TILE + m) * CK_NS + o] : 0.f;
+            float v = (o < ns) ? sDK[(st * NLBAC_MLP_TILE + m) * CK_NS + o] : 0.f;
+            if (L.norm && o < ns) {
+                v *= sN[2 * idim + ns + o];
+                if (L.dyn && data && row0 + m < n) L.dyn[((long)st * n + row0 + m) * ns + o] = v;
+            }
+            sdy[rem] = v;
         }
         if (!data) continue;             // uniform
         __syncthreads();
@@ -236,7 +261,8 @@ __global__ __launch_bounds__(NTHR) void concat_rk_bwd_kernel(const ConcatRkBwdLa
         // ---- dX = dz0 W_0: state columns -> sDX, carried columns accumulate (always the same thread per entry)
         for (int idx = tid; idx < NLBAC_MLP_TILE * net.in_dim; idx += NTHR) {
             const int m = idx & 31, i = idx >> 5;
-            const float v = skinny_row_dot(in + m * LD, sW0t + i * hid, hid);
+            float v = skinny_row_dot(in + m * LD, sW0t + i * hid, hid);
+            if (L.norm) v *= sN[idim + i];
             if (i < ns) sDX[m * CK_NS + i] = v;
             else sDC[m * CK_NC + (i - ns)] += v;
         }
@@ -286,7 +312,7 @@ extern "C" int nlbac_concat_rk_fwd(const nlbac_mlp* net, const float* y0, const 
                                    int stage_begin, int stage_end, int n_stages_total, const float* beta,
                                    const float* c_out, int n_out, const float* c_err, int n_err, const float* h_host,
                                    const double* h_dev, int h_dev_stride, float* K, float* Y, float* acts, long acts_ls,
-                                   float* out, float* err, nlbac_stream_t s) {
+                                   float* out, float* err, const float* norm, float* Xn, nlbac_stream_t s) {
     if (concat_check(net, P, rows_per_problem, n_stages_total, "nlbac_concat_rk_fwd")) return -1;
     NLBAC_REQUIRE(y0 && c && K && Y, "nlbac_concat_rk_fwd: null pointer");
     NLBAC_REQUIRE(stage_begin >= 0 && stage_begin < stage_end && stage_end <= n_stages_total,
@@ -310,10 +336,13 @@ extern "C" int nlbac_concat_rk_fwd(const nlbac_mlp* net, const float* y0, const 
     for (int p = 0; p < P; ++p) L.h_val[p] = h_host ? h_host[p] : 0.f;
     L.K = K; L.Y = Y; L.acts = acts; L.acts_ls = acts_ls;
     L.out = out; L.err = err;
+    NLBAC_REQUIRE(norm || !Xn, "nlbac_concat_rk_fwd: Xn goes with norm");
+    L.norm = norm; L.Xn = Xn;
     const int in_p = (net->in_dim + 7) & ~7, hid_p = (net->hid + 7) & ~7;
     L.ld = (hid_p > in_p ? hid_p : in_p) + 4;
     const size_t lds = ((size_t)2 * NLBAC_MLP_TILE * L.ld + CK_MAX_STAGES * NLBAC_MLP_TILE * CK_NS +
-                        NLBAC_MLP_TILE * (CK_NS + CK_NC + 1) + ((net->out_dim * (net->hid + 1) + 3) & ~3)) * sizeof(float);
+                        NLBAC_MLP_TILE * (CK_NS + CK_NC + 1) + ((net->out_dim * (net->hid + 1) + 3) & ~3) +
+                        2 * (CK_NS + CK_NC) + 2 * CK_NS) * sizeof(float);
     NLBAC_REQUIRE(lds <= 64 * 1024, "nlbac_concat_rk_fwd: LDS budget exceeded (%zu B)", lds);
     hipLaunchKernelGGL(concat_rk_fwd_kernel<256>, dim3(nlbac_ceil_div(L.n, NLBAC_MLP_TILE)), dim3(256), lds, (hipStream_t)s, L);
     NLBAC_CHECK_LAUNCH("nlbac_concat_rk_fwd");
@@ -324,7 +353,7 @@ extern "C" int nlbac_concat_rk_bwd(const nlbac_mlp* net, int P, int rows_per_pro
                                    int st_hi, int dx_stage0, const float* beta, const float* h_host,
                                    const double* h_dev, int h_dev_stride, const float* acts, long acts_ls, float* dz,
                                    float* dK, const float* dYup, float* dy0, int dy0_in, float* dc, int dc_acc,
-                                   nlbac_stream_t s) {
+                                   const float* norm, float* dyn, nlbac_stream_t s) {
     if (concat_check(net, P, rows_per_problem, n_stages_total, "nlbac_concat_rk_bwd")) return -1;
     NLBAC_REQUIRE(acts && dK, "nlbac_concat_rk_bwd: null pointer");
     NLBAC_REQUIRE(st_lo >= 0 && st_lo < st_hi && st_hi <= n_stages_total, "nlbac_concat_rk_bwd: bad stage range");
@@ -342,10 +371,13 @@ extern "C" int nlbac_concat_rk_bwd(const nlbac_mlp* net, int P, int rows_per_pro
             for (int j = 0; j < n_stages_total; ++j) L.beta[i][j] = beta[i * n_stages_total + j];
     L.h_dev = h_dev; L.h_stride = h_dev_stride;
     for (int p = 0; p < P; ++p) L.h_val[p] = h_host ? h_host[p] : 0.f;
+    NLBAC_REQUIRE(norm || !dyn, "nlbac_concat_rk_bwd: dyn goes with norm");
+    NLBAC_REQUIRE(!norm || !dz || dyn, "nlbac_concat_rk_bwd: weight gradients of a normalised field need dyn");
+    L.norm = norm; L.dyn = dyn;
     L.ld = ((net->hid + 31) & ~31) + 4;
     const size_t lds = ((size_t)2 * NLBAC_MLP_TILE * L.ld + CK_MAX_STAGES * NLBAC_MLP_TILE * CK_NS +
                         NLBAC_MLP_TILE * (1 + CK_NS + CK_NC + CK_NS + 16) +
-                        (((net->out_dim + net->in_dim) * net->hid + 3) & ~3)) * sizeof(float);
+                        (((net->out_dim + net->in_dim) * net->hid + 3) & ~3) + 2 * (CK_NS + CK_NC) + 2 * CK_NS) * sizeof(float);
     NLBAC_REQUIRE(lds <= 64 * 1024, "nlbac_concat_rk_bwd: LDS budget exceeded (%zu B)", lds);
     hipLaunchKernelGGL(concat_rk_bwd_kernel<256>, dim3(nlbac_ceil_div(L.n, NLBAC_MLP_TILE)), dim3(256), lds, (hipStream_t)s, L);
     NLBAC_CHECK_LAUNCH("nlbac_concat_rk_bwd");

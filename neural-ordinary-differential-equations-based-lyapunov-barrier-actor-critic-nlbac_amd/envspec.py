@@ -110,6 +110,47 @@ class PvtolSpec:
         return [s]
 
 
+class QuadrotorLikeSpec:
+    """BASELINE configs[4] "Quadrotor (safe-control-gym) + neural barrier certificate".  The reference's Quadrotor code
+    is an EMPTY submodule (neural_barrier_certificate/safe-control-gym/); only prose exists
+    (/root/reference/README.md:66-72, 190-192): a 2D quadrotor, no pre-defined CBFs, barrier signals D1 = -1.0 outside
+    the allowed range and D2 = -10.0 on collision, a NODE on normalised [state (6) | action (2)] -> 6 with
+    de-normalised outputs.  This is a SYNTHETIC stand-in of that shape — NO REFERENCE PARITY EXISTS for it: planar
+    quadrotor state [x, x', z, z', theta, theta'] (the 2D quadrotor of safe-control-gym's paper), observation = state,
+    two rotor thrusts as the action, dt 0.02; every constant below is this build's choice."""
+
+    dynamics_mode = "Quadrotor"
+    n_s, n_u, obs_dim, lya_in = 6, 2, 6, 6
+    MASS, IYY, ARM, G = 0.027, 1.4e-5, 0.0397, 9.8
+
+    def __init__(self, seed=0):
+        hover = self.MASS * self.G / 2.0
+        lo, hi = np.array([0.5 * hover] * 2), np.array([1.5 * hover] * 2)
+        self.action_space = Box(lo, hi)
+        self.safe_action_space = Box(lo, hi)
+        self.observation_space = Box(-1e10, 1e10, shape=(6,))
+        self.dt = 0.02
+        self.max_episode_steps = 500
+        self.goal_pos = np.array([0.0, 1.0])                 # (x, z)
+        self.x_range, self.z_range = (-2.0, 2.0), (0.0, 2.0)
+        self.obstacle, self.obstacle_radius = np.array([0.6, 0.6]), 0.25
+        self.D1, self.D2 = -1.0, -10.0                       # README.md:190
+        # normalisation of the NODE's inputs [state | action] and de-normalisation of its outputs (d state / dt)
+        self.node_in_mean = np.array([0.0, 0.0, 1.0, 0.0, 0.0, 0.0, hover, hover])
+        self.node_in_std = np.array([1.0, 1.0, 0.5, 1.0, 0.3, 2.0, 0.3 * hover, 0.3 * hover])
+        self.node_out_mean = np.zeros(6)
+        self.node_out_std = np.array([1.0, 4.0, 1.0, 4.0, 2.0, 60.0])
+        self.seed(seed)
+
+    @property
+    def node_normalizer(self):
+        return (self.node_in_mean, self.node_in_std, self.node_out_mean, self.node_out_std)
+
+    def seed(self, s=None):
+        self.action_space.seed(s)
+        return [s]
+
+
 def make_env(name, seed=0, **overrides):
     """``UnicycleBarrier`` is the learned-barrier-certificate copy (``neural_barrier_certificate/``): the same
     Unicycle constants (its ``dynamics_mode`` is still ``'Unicycle'``); the agent class differs, not the env."""
@@ -119,4 +160,6 @@ def make_env(name, seed=0, **overrides):
         return SimulatedCarsSpec(seed)
     if name in ("Pvtol", "PvtolBarrier"):
         return PvtolSpec(seed, **overrides)
+    if name == "QuadrotorLike":
+        return QuadrotorLikeSpec(seed)
     raise Exception("Dynamics mode not supported.")

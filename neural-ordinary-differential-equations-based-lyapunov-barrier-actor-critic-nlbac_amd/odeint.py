@@ -999,6 +999,8 @@ class _ConcatStepWS:
         self.err = z(n, ns)
         self.io_fwd, self.io_bwd = {}, {}
         self._bwd = None
+        # a normalised field keeps the normalised net inputs of every stage for the first layer's weight gradient
+        self.Xn = z(S, n, net.in_dim) if solver.norm is not None else None
 
     def bwd(self, solver):
         if self._bwd is None:
@@ -1011,6 +1013,7 @@ class _ConcatStepWS:
             self.dy0 = z(n, ns)
             self.dy1 = z(n, ns)
             self.c_rep = z(S * n, nc)      # carried inputs repeated per stage (first-layer weight gradients)
+            self.dyn = z(S, n, ns) if solver.norm is not None else None      # d/d(net output) = dK * out_std
             self._bwd = True
         return self
 
@@ -1033,6 +1036,10 @@ class ConcatNodeSolver(AffineNodeSolver):
         self.stats = dict(solves=0, single_step=0, multi_attempt=0, split=0)
         self.comm = None
         self.adjoint = False
+        # input normalisation / output de-normalisation lives inside the fused step kernels only
+        self.norm = node.norm_device() if getattr(node, "normalized", False) else None
+        if self.norm is not None and not self.fused:
+            raise _lib.NlbacError("a normalised NODE needs the fused step kernels (hidden width <= 128)")
 
     def _nets(self):
         if self._net_arr is None:
@@ -1051,7 +1058,9 @@ class ConcatNodeSolver(AffineNodeSolver):
                   fptr(*h_host) if h_host is not None else None, h_dev, _lib.DOPRI_CTL if h_dev else 0,
                   ws.K.data_ptr(), ws.Y.data_ptr(), ws.acts.data_ptr() if save_acts else None,
                   ws.S * P * rpp * self.net.hid, out.data_ptr() if out is not None else None,
-                  err.data_ptr() if err is not None else None, stream_ptr())
+                  err.data_ptr() if err is not None else None,
+                  self.norm.data_ptr() if self.norm is not None else None,
+                  ws.Xn.data_ptr() if (self.norm is not None and save_acts) else None, stream_ptr())
         self.nfe += st1 - st0
 
     def _rk_fused_bwd(self, ws, u, P, rpp, method, first_eval, need_dy0, need_params, h_host, h_dev, h_stride, top_up,
@@ -1062,7 +1071,9 @@ class ConcatNodeSolver(AffineNodeSolver):
                   1 if need_dy0 else 0, beta_arr, h_host, h_dev, h_stride, ws.acts.data_ptr(),
                   S * ws.n * self.net.hid, ws.dz.data_ptr() if need_params else None, ws.dK.data_ptr(),
                   top_up.data_ptr() if top_up is not None else None, ws.dy0.data_ptr(), 1,
-                  du.data_ptr() if du is not None else None, 0 if last else 1, stream_ptr())
+                  du.data_ptr() if du is not None else None, 0 if last else 1,
+                  self.norm.data_ptr() if self.norm is not None else None,
+                  ws.dyn.data_ptr() if (self.norm is not None and need_params) else None, stream_ptr())
 
     def _eval_io(self, x, k_out, c, acts=None, ls=0):
         io = io_array(1)
@@ -1117,11 +1128,15 @@ class ConcatNodeSolver(AffineNodeSolver):
             S, n = ws.S, ws.n
             st0 = 0 if step["first"] or ctx["method"] != "dopri5" else 1
             rows = (S - st0) * n
-            ws.c_rep.view(S, n, self.n_u).copy_(ctx["u"].unsqueeze(0).expand(S, n, self.n_u))
             io = io_array(1)
-            io[0].x0, io[0].x0_dim, io[0].x0_ld = ws.Y[st0:].data_ptr(), self.n_s, self.n_s
-            io[0].x1, io[0].x1_dim, io[0].x1_ld = ws.c_rep[st0 * n:].data_ptr(), self.n_u, self.n_u
-            io[0].dy, io[0].dy_ld = ws.dK[st0:].data_ptr(), self.n_s
+            if self.norm is not None:      # the net saw normalised inputs and its output is scaled: use what the kernels kept
+                io[0].x0, io[0].x0_dim, io[0].x0_ld = ws.Xn[st0:].data_ptr(), self.net.in_dim, self.net.in_dim
+                io[0].dy, io[0].dy_ld = ws.dyn[st0:].data_ptr(), self.n_s
+            else:
+                ws.c_rep.view(S, n, self.n_u).copy_(ctx["u"].unsqueeze(0).expand(S, n, self.n_u))
+                io[0].x0, io[0].x0_dim, io[0].x0_ld = ws.Y[st0:].data_ptr(), self.n_s, self.n_s
+                io[0].x1, io[0].x1_dim, io[0].x1_ld = ws.c_rep[st0 * n:].data_ptr(), self.n_u, self.n_u
+                io[0].dy, io[0].dy_ld = ws.dK[st0:].data_ptr(), self.n_s
             io[0].acts = ws.acts[:, st0 * n:].data_ptr()
             io[0].dz = ws.dz[:, st0 * n:].data_ptr()
             io[0].acts_ls = S * n * self.net.hid

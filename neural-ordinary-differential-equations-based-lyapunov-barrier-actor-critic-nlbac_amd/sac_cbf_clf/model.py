@@ -8,6 +8,7 @@ bias, the NODE keeps PyTorch's default ``nn.Linear`` init.  The modules only
 all arithmetic runs in the HIP kernels — ``forward`` here is the thin
 inference path used by ``select_action``.
 """
+import numpy as np
 import torch
 import torch.nn as nn
 
@@ -169,10 +170,22 @@ class NeuralODEModel(nn.Module):
     ``NeuralODEModel(input_dim, output_dim)`` — one net of 4 Linear layers of width 64 on [x, u, t]
     (C/sac_cbf_clf/model.py:179-194); the trailing ``input_dim - output_dim`` inputs are carried unchanged."""
 
-    def __init__(self, input_dim, output_dim1, output_dim2=None, hidden_dim=None, f_depth=5, g_depth=4, depth=4):
+    def __init__(self, input_dim, output_dim1, output_dim2=None, hidden_dim=None, f_depth=5, g_depth=4, depth=4,
+                 normalizer=None):
+        """``normalizer`` (single-net form only): ``(in_mean, in_std, out_mean, out_std)`` — states and actions are
+        normalised before they enter the net and its outputs de-normalised before they are used as the prediction
+        (the Quadrotor NODE, /root/reference/README.md:192; no reference code exists for it):
+        ``dx/dt = out_mean + out_std * net(([x, u] - in_mean) / in_std)``.  Fixed constants, kept as buffers."""
         super().__init__()
         self.input_dim, self.output_dim1, self.output_dim2 = input_dim, output_dim1, output_dim2
         self.affine = output_dim2 is not None
+        self.normalized = normalizer is not None
+        if self.normalized:
+            assert not self.affine, "normalisation is built for the single-net form"
+            im, isd, om, osd = (torch.as_tensor(np.asarray(v), dtype=torch.float32).reshape(-1) for v in normalizer)
+            assert im.numel() == isd.numel() == input_dim and om.numel() == osd.numel() == output_dim1
+            for name, v in (("in_mean", im), ("in_std", isd), ("out_mean", om), ("out_std", osd)):
+                self.register_buffer(name, v.clone(), persistent=False)   # env constants, not checkpoint state
 
         def seq(in_dim, depth, out, hid):
             layers = [nn.Linear(in_dim, hid), nn.ReLU()]
@@ -206,6 +219,18 @@ class NeuralODEModel(nn.Module):
             pack(hs)
         return hs
 
+    def norm_device(self):
+        """[in_mean | 1/in_std | out_mean | out_std] on the model's device (what the fused kernels read), or None."""
+        if not self.normalized:
+            return None
+        t = self.__dict__.get("_norm_dev")
+        if t is None:
+            dev = self.device_handles()[0].arena.device
+            isig = (1.0 / self.in_std.float())          # fp32 reciprocal, as the oracle forms it
+            t = torch.cat([self.in_mean.float(), isig, self.out_mean.float(), self.out_std.float()]).to(dev).contiguous()
+            self.__dict__["_norm_dev"] = t
+        return t
+
     def refresh_device_weights(self):
         """Re-pack the MFMA-fragment copies of the weights (after anything but this build's own optimiser kernel
         has written the parameters, e.g. a ``torch.optim`` step or ``load_state_dict``)."""
@@ -220,10 +245,17 @@ class NeuralODEModel(nn.Module):
         ns = sv.n_s
         s = s.detach().float().contiguous()
         n = s.shape[0]
-        x, c = s[:, :ns].contiguous(), s[:, ns:].contiguous()
+        s_in = s
+        if self.normalized:                   # (inference path: normalise / de-normalise around the net launch)
+            nd = self.norm_device()
+            d = self.input_dim
+            s_in = (s - nd[:d]) * nd[d:2 * d]
+        x, c = s_in[:, :ns].contiguous(), s_in[:, ns:].contiguous()
         k, g = torch.empty(n, ns, device=s.device), torch.empty(n, ns * max(1, sv.n_u), device=s.device)
         sv._eval(x, c, n, k, g)               # (fresh launch descriptors: the inputs are the caller's tensors)
-        return torch.cat([k, torch.zeros_like(c)], dim=1)
+        if self.normalized:
+            k = k * nd[2 * d + ns:2 * d + 2 * ns] + nd[2 * d:2 * d + ns]
+        return torch.cat([k, torch.zeros_like(s[:, ns:])], dim=1)
 
     def attach(self, arena):
         if self.affine:

@@ -35,7 +35,7 @@ from .tasks import TASKS
 from .utils import to_tensor
 
 DYNAMICS_MODE = {'Unicycle': {'n_s': 3, 'n_u': 2}, 'SimulatedCars': {'n_s': 10, 'n_u': 1},
-                 'Pvtol': {'n_s': 6, 'n_u': 2}}
+                 'Pvtol': {'n_s': 6, 'n_u': 2}, 'Quadrotor': {'n_s': 6, 'n_u': 2}}
 l_p = 0.03
 
 

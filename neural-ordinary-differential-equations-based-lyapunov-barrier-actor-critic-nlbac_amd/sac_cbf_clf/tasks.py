@@ -667,6 +667,113 @@ class PvtolBarrierTask(PvtolTask):
     def first_step_done(self):
         return self.solver.first_step_done()
 
+# =====================================================================================
+class QuadrotorBarrierTask(PvtolBarrierTask):
+    """BASELINE configs[4] "Quadrotor + neural barrier certificate" as far as the reference describes it
+    (/root/reference/README.md:66-72, 190-192; its code is an empty submodule — NO REFERENCE PARITY, checked against
+    the oracle only): the learned-barrier agent pattern of NP (one controller, BarrierNetwork trained on the barrier
+    signal D1 = -1 / D2 = -10, one NODE step, CLF (V' - V)/1 + 0.1 V, ratio clamped at 0.002) on a NON-affine
+    single-net NODE  dx/dt = out_mu + out_sig * net(([x | u] - in_mu) / in_sig)  (8 -> 6, inputs normalised, outputs
+    de-normalised inside the fused RK kernels).  The observation is the state, so get_state / get_obs are identities."""
+    name = "QuadrotorBarrier"
+    obs_dim, act_dim, lya_dim, n_s = 6, 2, 6, 6
+    NODE_HIDDEN = 128
+
+    def build_node(self):
+        return NeuralODEModel(8, 6, hidden_dim=self.NODE_HIDDEN, normalizer=self.env.node_normalizer)
+
+    def setup(self):
+        a = self.agent
+        self.solver = ConcatNodeSolver(a.neural_ode_model, a.device)       # carried inputs = the action
+        self.fit_solver = ConcatNodeSolver(a.neural_ode_model, a.device)
+        self.solvers = [self.solver, self.fit_solver]
+
+    def alloc(self, ws):
+        B, z, H = ws.B, self.z, self.agent.hidden
+        ws.st6 = z(B, 6)
+        ws.V, ws.V1, ws.dV1 = z(B), z(B), z(B)
+        ws.acts_v1 = z(2, B, H)
+        ws.obs_pred = z(B, 6)
+        ws.heads_nx, ws.pi_next, ws.logp_nx = z(B, 4), z(B, 2), z(B)
+        ws.Bv, ws.Bn, ws.dBn = z(B), z(B), z(B)
+        ws.acts_bn = z(2, B, H)
+        ws.dxb = z(B, 8)                               # d B(obs', a') / d [obs', a']
+        ws.matr = z(B, 2)
+        ws.part_c = z(ws.nblk, 2)
+        ws.dx_next = z(B, 6)
+
+    def extra_value_io(self, ws, io, i):               # B(obs, pi), value only
+        lay = self.agent.lay
+        io[i].x0, io[i].x0_dim, io[i].x0_ld = ws.mb.data_ptr() + 4 * lay.obs, 6, lay.LD
+        io[i].x1, io[i].x1_dim, io[i].x1_ld = ws.pi2.data_ptr(), 2, 2
+        io[i].y, io[i].y_ld = ws.Bv.data_ptr(), 1
+
+    def plan(self, ws, P):
+        a = self.agent
+        P.n_l = mlp_array([a.h_l.desc])
+        io = P.io_v1 = io_array(1)                     # V(obs') forward + data backward, d obs' lands in dx_next
+        io[0].x0, io[0].x0_dim, io[0].x0_ld = ws.obs_pred.data_ptr(), 6, 6
+        io[0].y, io[0].y_ld = ws.V1.data_ptr(), 1
+        io[0].acts = ws.acts_v1.data_ptr()
+        io[0].dy, io[0].dy_ld = ws.dV1.data_ptr(), 1
+        io[0].dx, io[0].dx_ld = ws.dx_next.data_ptr(), 6
+        P.n_pi = mlp_array([a.h_p.desc])
+        io = P.io_nx = io_array(1)                     # policy on the predicted next observation
+        io[0].x0, io[0].x0_dim, io[0].x0_ld = ws.obs_pred.data_ptr(), 6, 6
+        io[0].y, io[0].y_ld = ws.heads_nx.data_ptr(), 4
+        P.n_bar = mlp_array([a.h_extra[0].desc])
+        io = P.io_bn = io_array(1)                     # B(obs', a') forward + data backward
+        io[0].x0, io[0].x0_dim, io[0].x0_ld = ws.obs_pred.data_ptr(), 6, 6
+        io[0].x1, io[0].x1_dim, io[0].x1_ld = ws.pi_next.data_ptr(), 2, 2
+        io[0].y, io[0].y_ld = ws.Bn.data_ptr(), 1
+        io[0].acts = ws.acts_bn.data_ptr()
+        io[0].dy, io[0].dy_ld = ws.dBn.data_ptr(), 1
+        io[0].dx, io[0].dx_ld = ws.dxb.data_ptr(), 8
+
+    def _obs_cols(self, src, src_ld, n, dst):
+        """the state IS the observation: its six columns of a minibatch-layout row block, made contiguous"""
+        _lib.call("nlbac_copy_blocks", src, src_ld, dst.data_ptr(), 6, 6, n, stream_ptr())
+
+    def rollout_begin(self, ws, P):
+        a = self.agent
+        self._obs_cols(ws.mb.data_ptr() + 4 * a.lay.obs, a.lay.LD, ws.B, ws.st6)
+        self.solver.forward_begin(ws.st6, ws.pi2, 1, ws.B, a.solver, float(self.env.dt), a.atol, a.rtol)
+
+    def loss_and_backward(self, ws, P, lam_upd, assume_single):
+        a, s, call = self.agent, stream_ptr(), _lib.call
+        B, sc = ws.B, a.sc.data_ptr()
+        pol = a.policy
+        x1 = self.solver.forward_finish(assume_single_step=assume_single)
+        a.drain_fill()
+        call("nlbac_copy_blocks", x1.data_ptr(), 6 * B, ws.obs_pred.data_ptr(), 6 * B, 6 * B, 1, s)   # obs' = x'
+        call("nlbac_mlp_fwd", P.n_l, P.io_v1, 1, B, s)
+        call("nlbac_mlp_fwd", P.n_pi, P.io_nx, 1, B, s)
+        call("nlbac_gauss_sample_fwd", ws.heads_nx.data_ptr(), 4, ws.eps[2].data_ptr(), pol.action_scale.data_ptr(),
+             pol.action_bias.data_ptr(), 2, B, ws.pi_next.data_ptr(), 2, ws.logp_nx.data_ptr(), s)
+        call("nlbac_mlp_fwd", P.n_bar, P.io_bn, 1, B, s)
+        call("nlbac_barrier_constraints_fwd", ws.Bv.data_ptr(), ws.Bn.data_ptr(), ws.V.data_ptr(), ws.V1.data_ptr(),
+             1.0, float(a.gamma_b), self.gamma_l, B, ws.matr.data_ptr(), ws.part_c.data_ptr(), s)
+        a.auglag(ws, 1, lam_upd)
+        call("nlbac_barrier_constraints_bwd", ws.matr.data_ptr(), 1.0, float(a.batch_size), B, sc, ws.dBn.data_ptr(),
+             ws.dV1.data_ptr(), s)
+        call("nlbac_mlp_bwd_data", P.n_l, P.io_v1, 1, B, s)          # dV' -> d obs' (written to dx_next)
+        call("nlbac_mlp_bwd_data", P.n_bar, P.io_bn, 1, B, s)        # dB' -> d [obs', a'] (a' is detached)
+        call("nlbac_add_cols", ws.dx_next.data_ptr(), 6, 0, ws.dxb.data_ptr(), 8, 6, B, s)
+        dc, _ = self.solver.backward(ws.dx_next, need_du=True)       # (B, 2): d / d action (the carried inputs)
+        return dc, self.act_dim
+
+    # -- NODE fit: one solve from (obs, action) against next_obs ---------------------------------------
+    def fit_inputs(self, rows):
+        lay = self.agent.lay
+        return (rows.data_ptr() + 4 * lay.obs, rows.shape[1], rows[:, lay.act:lay.act + 2],
+                rows.data_ptr() + 4 * lay.nobs, rows.shape[1], rows.shape[0])
+
+    def fit_part1(self, w, p_obs, obs_ld, p_nobs, nobs_ld, N):
+        a = self.agent
+        self._obs_cols(p_obs, obs_ld, N, w["st"])
+        self._obs_cols(p_nobs, nobs_ld, N, w["nst"])
+        self.fit_solver.forward_begin(w["st"], w["u"], 1, N, a.solver, self.env.dt, a.atol, a.rtol)
+
 
 TASKS = {"Unicycle": UnicycleTask, "SimulatedCars": CarsTask, "UnicycleBarrier": UnicycleBarrierTask,
-         "Pvtol": PvtolTask, "PvtolBarrier": PvtolBarrierTask}
+         "Pvtol": PvtolTask, "PvtolBarrier": PvtolBarrierTask, "QuadrotorBarrier": QuadrotorBarrierTask}

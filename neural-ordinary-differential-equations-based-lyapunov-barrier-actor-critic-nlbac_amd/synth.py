@@ -181,6 +181,35 @@ def pvtol_transitions(n, seed=1, env=None):
                 next_center=next_obs.copy(), next_obs=next_obs, mask=np.ones(n), t=t, next_t=t + dt)
 
 
+def quadrotor_transitions(n, seed=1, env=None):
+    """Synthetic transitions of the Quadrotor-like task (``envspec.QuadrotorLikeSpec``; no reference code exists):
+    random planar-quadrotor states, one Euler step of the rigid-body model, reward / cost = (minus) the distance to
+    the goal, barrier signal D1 outside the allowed x / z range and D2 inside the obstacle (README.md:190); the
+    observation is the state and the Lyapunov inputs are the observations (the NP pattern)."""
+    from .envspec import QuadrotorLikeSpec
+    env = env or QuadrotorLikeSpec()
+    rs = np.random.RandomState(seed)
+    dt = env.dt
+    st = np.stack([rs.uniform(-2.2, 2.2, n), rs.normal(0, 0.8, n), rs.uniform(-0.1, 2.2, n), rs.normal(0, 0.8, n),
+                   rs.uniform(-0.4, 0.4, n), rs.normal(0, 1.5, n)], axis=1)
+    near = rs.uniform(0, 1, n) < 0.2          # a fifth of the rows sit around the obstacle
+    st[near, 0] = env.obstacle[0] + rs.uniform(-0.4, 0.4, n)[near]
+    st[near, 2] = env.obstacle[1] + rs.uniform(-0.4, 0.4, n)[near]
+    lo, hi = env.action_space.low.astype(np.float64), env.action_space.high.astype(np.float64)
+    action = rs.uniform(lo, hi, size=(n, 2))
+    T = action.sum(1)
+    f = np.stack([st[:, 1], np.sin(st[:, 4]) * T / env.MASS, st[:, 3], np.cos(st[:, 4]) * T / env.MASS - env.G,
+                  st[:, 5], (action[:, 1] - action[:, 0]) * env.ARM / np.sqrt(2.0) / env.IYY], axis=1)
+    nxt = st + dt * f
+    dist = np.sqrt((nxt[:, 0] - env.goal_pos[0]) ** 2 + (nxt[:, 2] - env.goal_pos[1]) ** 2)
+    out = (nxt[:, 0] < env.x_range[0]) | (nxt[:, 0] > env.x_range[1]) | (nxt[:, 2] < env.z_range[0]) | (nxt[:, 2] > env.z_range[1])
+    hit = (nxt[:, 0] - env.obstacle[0]) ** 2 + (nxt[:, 2] - env.obstacle[1]) ** 2 < env.obstacle_radius ** 2
+    sig = env.D1 * out.astype(np.float64) + env.D2 * hit.astype(np.float64)
+    t = rs.randint(0, 500, n).astype(np.float64) * dt
+    return dict(obs=st, action=action, reward=-dist + 250.0 * (dist < 0.05), constraint=dist, barrier_signal=sig,
+                center=st.copy(), next_center=nxt.copy(), next_obs=nxt, mask=np.ones(n), t=t, next_t=t + dt)
+
+
 # ---------------------------------------------------------------------------
 # network shapes (reference key names; U/sac_cbf_clf/model.py:37-133,177-206)
 # ---------------------------------------------------------------------------
@@ -280,13 +309,26 @@ def pvtol_barrier_agent_weights(hidden, seed=0):
     return W
 
 
+QUADROTOR_NODE_HIDDEN = 128
+
+
+def quadrotor_agent_weights(hidden, seed=0):
+    """One controller, a BarrierNetwork on (obs, action), a single-net NODE 8 -> 128 -> 128 -> 128 -> 6."""
+    critic = synth_state_dict(qnet_shapes(6, 2, hidden), seed * 10 + 1)
+    lya = synth_state_dict(lya_shapes(6, hidden), seed * 10 + 2)
+    policy = synth_state_dict(policy_shapes(6, 2, hidden), seed * 10 + 3)
+    node = synth_state_dict(node_single_shapes(8, 6, hidden=QUADROTOR_NODE_HIDDEN), seed * 10 + 5, kind="default")
+    barrier = synth_state_dict(lya_shapes(6 + 2, hidden), seed * 10 + 6)
+    return dict(critic=critic, lyapunov=lya, policy=policy, node=node, barrier=barrier)
+
+
 def agent_weights(env_name, hidden, seed=0):
-    return {"PvtolBarrier": pvtol_barrier_agent_weights, "Unicycle": unicycle_agent_weights, "SimulatedCars": cars_agent_weights, "Pvtol": pvtol_agent_weights,
+    return {"QuadrotorLike": quadrotor_agent_weights, "PvtolBarrier": pvtol_barrier_agent_weights, "Unicycle": unicycle_agent_weights, "SimulatedCars": cars_agent_weights, "Pvtol": pvtol_agent_weights,
             "UnicycleBarrier": unicycle_barrier_agent_weights}[env_name](hidden, seed)
 
 
 def transitions(env_name, n, seed=1, env=None):
-    return {"PvtolBarrier": pvtol_barrier_transitions, "Unicycle": unicycle_transitions, "SimulatedCars": cars_transitions, "Pvtol": pvtol_transitions,
+    return {"QuadrotorLike": quadrotor_transitions, "PvtolBarrier": pvtol_barrier_transitions, "Unicycle": unicycle_transitions, "SimulatedCars": cars_transitions, "Pvtol": pvtol_transitions,
             "UnicycleBarrier": unicycle_barrier_transitions}[env_name](n, seed, env)
 
 
@@ -306,7 +348,7 @@ def fixture_env(env_name, seed=0):
 
 
 def fields(env_name):
-    return FIELDS_BARRIER if env_name.endswith("Barrier") else FIELDS
+    return FIELDS_BARRIER if (env_name.endswith("Barrier") or env_name == "QuadrotorLike") else FIELDS
 
 
 def normal_eps(n_draws, batch, n_u, seed):

@@ -103,17 +103,28 @@ class AffineNode:
 class ConcatNode:
     """C/sac_cbf_clf/model.py:179-205: ds/dt = net([x, u, t]); the action and time columns are carried."""
 
-    def __init__(self, sd, n_s=10, n_carry=2, depth=4):
+    def __init__(self, sd, n_s=10, n_carry=2, depth=4, norm=None):
+        """``norm`` = (in_mean, in_std, out_mean, out_std): the Quadrotor form (/root/reference/README.md:192, prose
+        only — no reference code): states and actions are normalised before they enter the net, its outputs are
+        de-normalised before they are used as the prediction."""
         self.sd, self.n_s, self.n_carry = sd, n_s, n_carry
         self.names = ["net.%d" % (2 * i) for i in range(depth)]
         self.nfe = 0
+        self.norm = None
+        if norm is not None:
+            im, isd, om, osd = (torch.as_tensor(np.asarray(v), dtype=torch.float32) for v in norm)
+            self.norm = (im, 1.0 / isd, om, osd)
 
     def __call__(self, t, s):
         self.nfe += 1
         x = s
+        if self.norm is not None:
+            x = (s - self.norm[0]) * self.norm[1]
         for n in self.names[:-1]:
             x = F.relu(_lin(self.sd, n, x))
         ds = _lin(self.sd, self.names[-1], x)
+        if self.norm is not None:
+            ds = ds * self.norm[3] + self.norm[2]
         return torch.cat((ds, torch.zeros_like(s[:, self.n_s:])), -1)
 
 
@@ -994,9 +1005,51 @@ class OraclePvtolBarrierAgent(OracleUnicycleBarrierAgent):
         return x_next, obs_pred, obs_pred, info
 
 
+class OracleQuadrotorLikeAgent(OracleUnicycleBarrierAgent):
+    """BASELINE configs[4] as far as the reference's prose goes (/root/reference/README.md:66-72, 190-192; the code is
+    an empty submodule, so there is NOTHING to pin this against — PARITY UNPINNED): the NP update (one controller,
+    learned barrier on the signals D1 / D2, CLF (V' - V)/1 + 0.1 V, ratio clamped at 0.002, Lyapunov critic on
+    observations) over a single-net NODE on normalised [state (6) | action (2)] with de-normalised outputs; the
+    observation is the state."""
+    CLF_DT, GAMMA_L, RATIO_MIN = 1.0, 0.1, 0.002
+
+    def _setup_task(self, env):
+        self.node_fn = ConcatNode(self.node, n_s=6, n_carry=2, depth=4, norm=env.node_normalizer)
+
+    @staticmethod
+    def get_state(obs):
+        return obs.detach().double().float()
+
+    def get_obs(self, st):
+        return st
+
+    def _rollout(self, state, action, fit=False):
+        y0 = torch.cat((state, action), -1)
+        t = torch.tensor([0, self.env.dt])
+        info = {}
+        y = self._ode(y0, t, info, fit)[-1]
+        return y[:, :6], info
+
+    def train_step(self, node_obs, node_action, node_next_obs):
+        st, nst = self.get_state(node_obs), self.get_state(node_next_obs)
+        pred, _ = self._rollout(st, node_action, fit=True)
+        loss = F.mse_loss(pred, nst)
+        g = torch.autograd.grad(loss, list(self.node.values()))
+        self._set_grads(self.node.values(), g)
+        self.opt["node"].step()
+        return float(loss), _flat(g)
+
+    def _lya_inputs(self, batch):
+        return batch["obs"], batch["next_obs"]
+
+    def _predict(self, obs, pi):
+        x_next, info = self._rollout(self.get_state(obs), pi)
+        return x_next, x_next, x_next, info
+
+
 def make_oracle(env, args, weights, solver="euler", adjoint=False):
     kind = env.dynamics_mode + ("Barrier" if "barrier" in weights else "")
-    cls = {"Unicycle": OracleUnicycleAgent, "SimulatedCars": OracleCarsAgent, "Pvtol": OraclePvtolAgent,
+    cls = {"QuadrotorBarrier": OracleQuadrotorLikeAgent, "Unicycle": OracleUnicycleAgent, "SimulatedCars": OracleCarsAgent, "Pvtol": OraclePvtolAgent,
             "PvtolBarrier": OraclePvtolBarrierAgent, "UnicycleBarrier": OracleUnicycleBarrierAgent}[kind]
     agent = cls(env, args, weights, solver)
     agent.adjoint = bool(adjoint)

@@ -10,10 +10,10 @@ from nlbac_amd.envspec import make_env
 
 GOLD = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
 BATCH_FIELDS = ("obs", "action", "reward", "constraint", "center", "next_center", "next_obs", "mask", "t", "next_t")
-PREFIX = {"Unicycle": "unicycle", "SimulatedCars": "cars", "UnicycleBarrier": "nbc_unicycle", "Pvtol": "pvtol",
+PREFIX = {"QuadrotorLike": "quadrotor_like", "Unicycle": "unicycle", "SimulatedCars": "cars", "UnicycleBarrier": "nbc_unicycle", "Pvtol": "pvtol",
           "PvtolBarrier": "nbc_pvtol"}
-N_EPS = {"Unicycle": 3, "SimulatedCars": 5, "UnicycleBarrier": 3, "Pvtol": 7, "PvtolBarrier": 3}
-NODE_FIELDS = {"Unicycle": ("obs", "action", "next_obs"), "SimulatedCars": ("obs", "action", "next_obs", "t"),
+N_EPS = {"QuadrotorLike": 3, "Unicycle": 3, "SimulatedCars": 5, "UnicycleBarrier": 3, "Pvtol": 7, "PvtolBarrier": 3}
+NODE_FIELDS = {"QuadrotorLike": ("obs", "action", "next_obs"), "Unicycle": ("obs", "action", "next_obs"), "SimulatedCars": ("obs", "action", "next_obs", "t"),
                "UnicycleBarrier": ("obs", "action", "next_obs"), "Pvtol": ("obs", "action", "next_obs"),
                "PvtolBarrier": ("obs", "action", "next_obs")}
 

@@ -17,7 +17,7 @@ TOL = 1e-4
 
 def make_agent(B, hidden, seed, solver, env_name="Unicycle", gamma_b=None):
     from oracle.nlbac_oracle import Args
-    if env_name.endswith("Barrier"):
+    if env_name.endswith("Barrier") or env_name == "QuadrotorLike":
         from nlbac_amd.neural_barrier_certificate.sac_cbf_clf.sac_cbf_clf import SAC_CBF_CLF
     else:
         from nlbac_amd.sac_cbf_clf.sac_cbf_clf import SAC_CBF_CLF
