@@ -137,12 +137,22 @@ class AffineNodeSolver:
         self.nfe = 0
         self._net_arr = None
         self._coefs = {}
-        self.fused = True      # one nlbac_node_rk_fwd launch per RK step instead of 3 launches per stage
+        # one nlbac_node_rk_fwd / _bwd launch per RK step instead of 3 launches per stage — when the fused backward's
+        # LDS carve fits (4 tiles + both nets' first / last layers: up to 232-wide nets); wider ones run stage by stage
+        self.fused = self._fused_fits(node.f, node.g)
         self.keep_acts = True  # False: backward never asks for weight gradients -> ReLU bit masks suffice
         self._children = {}    # per-problem solvers for batches whose problems diverge (dopri5)
         self.stats = dict(solves=0, single_step=0, multi_attempt=0, split=0)
         self.comm = None       # nlbac_amd.parallel.DataParallel: global dopri5 error norms
         self.adjoint = False   # True: ``backward`` is the continuous adjoint (odeint_adjoint); the forward keeps nothing
+
+    @staticmethod
+    def _fused_fits(f, g):
+        pad = lambda x, m: (x + m - 1) // m * m
+        ld = pad(max(f.hid, g.hid), 32) + 4
+        sw = pad((f.out_dim + f.in_dim) * f.hid, 4) + pad((g.out_dim + g.in_dim) * g.hid, 4)
+        lds = 4 * (4 * 32 * ld + 8 * 32 * 8 + 32 * (4 + 1 + 8 + 4 + 2 * 8 + 2 * 16) + sw)      # nlbac_node_rk_bwd's carve
+        return lds <= 160 * 1024 - 64
 
     # -- workspace -----------------------------------------------------------
     MAX_SIZES = 2      # distinct row counts whose buffers are kept (the NODE fit's batch grows with the replay)
@@ -972,11 +982,26 @@ class AffineNodeSolver:
                 io[i].acts = acts[:, st0 * n:].data_ptr()
                 io[i].dz = dz[:, st0 * n:].data_ptr()
                 io[i].acts_ls = S * n * net.hid
+            if n_used + slabs_per_step > arena.n_slabs:
+                n_used = self._fold_slabs(arena, n_used)
+            for i in range(2):
                 io[i].grad = arena.grad[n_used:].data_ptr()
-            assert n_used + slabs_per_step <= arena.n_slabs, "arena has too few gradient slabs"
             bwd_weights(self._nets(), io, 2, rows, slabs_per_step, arena.n, self.device)
             n_used += slabs_per_step
         return n_used
+
+    def _fold_slabs(self, arena, n_used):
+        """A solve with more accepted steps than the arena has gradient slabs: sum what has been written into slab 0,
+        clear the rest (the skinny-layer gradients of a step sit in its first slab only) and carry on behind it — the
+        one place where the order of the final slab sum differs from one slab set per step."""
+        if arena.n_slabs < 2:
+            raise _lib.NlbacError("arena has too few gradient slabs (%d) for this solve" % arena.n_slabs)
+        tmp = self._buf("grad_fold", arena.n)
+        s = stream_ptr()
+        _lib.call("nlbac_reduce_slabs", tmp.data_ptr(), arena.grad.data_ptr(), n_used, arena.n, arena.n, s)
+        _lib.call("nlbac_axpby", 1.0, tmp.data_ptr(), 0.0, None, arena.n, arena.grad.data_ptr(), s)
+        _lib.call("nlbac_fill", arena.grad[1:].data_ptr(), 0.0, (arena.n_slabs - 1) * arena.n, s)
+        return 1
 
 
 # ---------------------------------------------------------------------------
@@ -1140,8 +1165,9 @@ class ConcatNodeSolver(AffineNodeSolver):
             io[0].acts = ws.acts[:, st0 * n:].data_ptr()
             io[0].dz = ws.dz[:, st0 * n:].data_ptr()
             io[0].acts_ls = S * n * self.net.hid
+            if n_used + slabs_per_step > arena.n_slabs:
+                n_used = self._fold_slabs(arena, n_used)
             io[0].grad = arena.grad[n_used:].data_ptr()
-            assert n_used + slabs_per_step <= arena.n_slabs, "arena has too few gradient slabs"
             bwd_weights(self._nets(), io, 1, rows, slabs_per_step, arena.n, self.device)
             n_used += slabs_per_step
         return n_used

@@ -470,6 +470,7 @@ class SAC_CBF_CLF(object):
 
     def _fit(self, p_obs, obs_ld, action, p_nobs, nobs_ld, N):
         task = self.task
+        self._fill.clear()      # (pieces of an update that raised half-way must not run behind this fit's solves)
         if N not in self._fit_ws:
             while len(self._fit_ws) >= 2:       # the fit batch grows with the replay: keep the two latest sizes only
                 self._fit_ws.pop(next(iter(self._fit_ws)))
@@ -509,7 +510,8 @@ class SAC_CBF_CLF(object):
         self.task.fit_solver.backward(w["dpred"], need_du=False, need_params=True)
         # every accepted RK step writes its own gradient slabs; a solve with many steps takes narrower ones
         n_steps = max(1, len(self.task.fit_solver.ctx.get("steps") or [None]))
-        used = self.task.fit_solver.accumulate_param_grads(self.ar_n, max(1, min(self.n_fit_slabs, self.ar_n.n_slabs // n_steps)))
+        used = self.task.fit_solver.accumulate_param_grads(
+            self.ar_n, max(1, min(self.n_fit_slabs, self.ar_n.n_slabs // min(n_steps, self.ar_n.n_slabs))))
         self._adam(self.ar_n, 1e-3, used, extra=self.sc[SC.SC_NODE_LOSS:SC.SC_NODE_LOSS + 1])
 
     def _capture(self, fn):

@@ -51,6 +51,29 @@ def test_ctypes_structs_match_header_sizes(lib):
     assert net.pf_off[0] == 0 and net.pb_off[0] == -1 and net.pb_off[1] > net.pf_off[1] > 0
 
 
+def test_integration_snippet_structs_match_the_compiled_header(tmp_path):
+    """INTEGRATION.md shows a maintainer the ctypes structs to bind: their sizes must equal sizeof() of the C structs
+    of include/nlbac_hip.h as gcc lays them out (a snippet one member short makes the library read past its end), and
+    so must the build's own ctypes structs."""
+    import ctypes as C
+    import subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    src = tmp_path / "sz.c"
+    src.write_text('#include <stdio.h>\n#include "nlbac_hip.h"\n'
+                   'int main(void){printf("%zu %zu\\n", sizeof(nlbac_mlp), sizeof(nlbac_mlp_io));return 0;}\n')
+    exe = tmp_path / "sz"
+    subprocess.run(["gcc", "-I", os.path.join(root, "include"), str(src), "-o", str(exe)], check=True)
+    sz_mlp, sz_io = (int(x) for x in subprocess.run([str(exe)], capture_output=True, text=True, check=True).stdout.split())
+    assert (C.sizeof(_lib.Mlp), C.sizeof(_lib.MlpIO)) == (sz_mlp, sz_io)
+    doc = open(os.path.join(root, "INTEGRATION.md")).read()
+    classes = re.findall(r"^class (Mlp|MlpIO)\(C\.Structure\):.*?(?=^\S)", doc, flags=re.S | re.M)
+    code = "".join(m.group(0) for m in re.finditer(r"^class (?:Mlp|MlpIO)\(C\.Structure\):.*?(?=^\S)", doc, flags=re.S | re.M))
+    assert len(classes) == 2, "INTEGRATION.md no longer shows the two ctypes structs"
+    ns = {"C": C}
+    exec(code, ns)
+    assert (C.sizeof(ns["Mlp"]), C.sizeof(ns["MlpIO"])) == (sz_mlp, sz_io), "INTEGRATION.md's structs drifted from the header"
+
+
 def test_error_reporting_is_loud(lib):
     net = _lib.Mlp()
     net.n_layers, net.in_dim, net.hid, net.out_dim = 3, 99, 256, 1     # in_dim too large
