@@ -1,7 +1,8 @@
 """Reference-shaped training driver: the loop of ``U/main.py:20-165`` — warm-up with random
 actions, one ``update_parameters`` per ``updates_per_step`` once the replay holds a batch, transitions pushed to the
-controller replay and the NODE replay, the stuck-detection heuristic that hands control to the backup controller
-(``U/main.py:108-142``) — on the gym-free simulators of ``nlbac_amd.envs`` and the MI355X agent.  Logging is one
+controller replay and the NODE replay, and each copy's rules for handing control to the backup controller
+(``U/main.py:108-142``, ``C/main.py:100-112``, ``P/main.py:128-200``; the learned-barrier copies have none) — on the
+gym-free simulators of ``nlbac_amd.envs`` and the MI355X agent.  Logging is one
 line per episode (the reference's wandb / spinup loggers are host tooling and out of scope).
 
     python -m nlbac_amd.train --env Unicycle --gamma_b 50 --max_episodes 200 --cuda --updates_per_step 2 \\
@@ -52,23 +53,185 @@ def get_args(argv=None):
     return p.parse_args(argv)
 
 
-def train(agent, env, dynamics_model, args, memory, node_memory, log=print):
-    """Returns a list of per-episode dicts (reward, length, safety violations, updates)."""
+class _Handover:
+    """Which controller acts and which transitions reach the controller replay — the hand-over logic of the reference
+    drivers, one subclass per ``main.py`` copy.  ``use_backup``: the backup controller acts this step (and the
+    transition is kept out of ``memory``)."""
+    first_backup_episode = None        # hand-over is allowed from this episode on (None: this copy has no backup)
+    memory_t_shift = 0                 # SimulatedCars stamps the controller replay one step earlier (C/main.py:97-99)
+
+    def __init__(self, env):
+        self.env = env
+        self.allowed = False
+
+    def begin_episode(self, i_episode):
+        if self.first_backup_episode is not None and i_episode >= self.first_backup_episode:
+            self.allowed = True
+
+    @property
+    def use_backup(self):
+        return False
+
+    def on_backup_action(self):
+        pass
+
+    def after_step(self, episode_steps, lya_in, next_lya_in, next_obs, info):
+        pass
+
+
+class _UnicycleHandover(_Handover):
+    """U/main.py:39-142: stuck for 8 checks (the look-ahead point moved less than 0.1 in 40 steps) -> the backup
+    controller for at most 30 steps or until it has moved sqrt(0.6) away; allowed after episode 3."""
+    first_backup_episode = 4
+    STUCK2, CHECKS, MAX_BACKUP, AWAY2 = 0.01, 8, 30, 0.6
+
+    def begin_episode(self, i_episode):
+        super().begin_episode(i_episode)
+        self.backup = False
+        self.positions, self.backup_time, self.violation_time = [], 0, 0
+        self.x0 = self.y0 = 0.0
+
+    @property
+    def use_backup(self):
+        return self.backup and self.allowed
+
+    def on_backup_action(self):
+        self.backup_time += 1
+
+    def after_step(self, episode_steps, lya_in, next_lya_in, next_obs, info):
+        self.positions.append(np.asarray(next_lya_in))
+        if episode_steps < 50:
+            return
+        diff = self.positions[-1] - self.positions[-40]
+        moved = diff[0] * diff[0] + diff[1] * diff[1]
+        if self.allowed and not self.backup:
+            if moved <= self.STUCK2:
+                self.violation_time += 1
+                if self.violation_time >= self.CHECKS:
+                    self.backup, self.violation_time = True, 0
+                    self.x0, self.y0 = next_lya_in[0], next_lya_in[1]
+            if moved > self.STUCK2 and self.violation_time > 0:
+                self.violation_time = 0
+        if self.backup and self.allowed:
+            if self.backup_time >= self.MAX_BACKUP:
+                self.backup, self.backup_time = False, 0
+            dx, dy = next_lya_in[0] - self.x0, next_lya_in[1] - self.y0
+            if dx * dx + dy * dy >= self.AWAY2:
+                self.backup, self.backup_time = False, 0
+
+
+class _CarsHandover(_Handover):
+    """C/main.py:41-112: from episode 0 on; the 4th car closer than 2.5 to the 5th while the following distance is met
+    -> the backup controller, for at most 15 steps, or from 5 steps on once both gaps exceed 2.5."""
+    first_backup_episode = 0
+    memory_t_shift = -1
+
+    def begin_episode(self, i_episode):
+        super().begin_episode(i_episode)
+        self.backup, self.backup_time = False, 0
+
+    @property
+    def use_backup(self):
+        return self.backup and self.allowed
+
+    def on_backup_action(self):
+        self.backup_time += 1
+
+    def after_step(self, episode_steps, lya_in, next_lya_in, next_obs, info):
+        d34 = next_obs[4] * 100.0 - next_obs[6] * 100.0
+        d45 = next_obs[6] * 100.0 - next_obs[8] * 100.0
+        if self.allowed and not self.backup:
+            if d45 < 2.5 and info.get('reached', 0) != 0:
+                self.backup = True
+        if self.backup and self.allowed:
+            if self.backup_time >= 15:
+                self.backup, self.backup_time = False, 0
+            if self.backup_time >= 5 and d34 > 2.5 and d45 > 2.5:
+                self.backup, self.backup_time = False, 0
+
+
+class _PvtolHandover(_Handover):
+    """P/main.py:40-200: two reasons to hand over, each with its own timers — trapped (moved^2 <= 0.015 in 40 steps,
+    8 checks; back after 30 steps or 1.0 away) and running away from the safety operator towards the goal (back after
+    15 steps or once within 0.9 operator_dist); allowed from episode 3 on."""
+    first_backup_episode = 3
+
+    def begin_episode(self, i_episode):
+        super().begin_episode(i_episode)
+        self.obs_b = self.y_b = False
+        self.positions = []
+        self.obs_time = self.y_time = self.viol_obs = self.viol_y = 0
+        self.x0 = self.y0 = 0.0
+
+    @property
+    def use_backup(self):
+        return (self.obs_b and self.allowed) or (self.y_b and self.allowed)
+
+    def on_backup_action(self):
+        if self.obs_b and self.y_b:
+            self.obs_time += 1
+            self.y_time += 1
+        elif self.obs_b and not self.y_b:
+            self.obs_time += 1
+        else:
+            self.y_time += 1
+
+    def after_step(self, episode_steps, lya_in, next_lya_in, next_obs, info):
+        self.positions.append(np.asarray(next_lya_in))
+        if episode_steps < 50:
+            return
+        env, nx, pv = self.env, next_lya_in, lya_in
+        diff = self.positions[-1] - self.positions[-40]
+        moved = diff[0] * diff[0] + diff[1] * diff[1]
+        if self.allowed and not self.obs_b:
+            if moved <= 0.015:
+                self.viol_obs += 1
+                if self.viol_obs >= 8:
+                    self.obs_b, self.viol_obs = True, 0
+                    self.x0, self.y0 = nx[0], nx[1]
+            if moved > 0.015 and self.viol_obs > 0:
+                self.viol_obs = 0
+        if self.obs_b and self.allowed:
+            if self.obs_time >= 30:
+                self.obs_b, self.obs_time = False, 0
+            dx, dy = nx[0] - self.x0, nx[1] - self.y0
+            if dx * dx + dy * dy >= 1.0:
+                self.obs_b, self.obs_time = False, 0
+        running = ((nx[0] <= 4.5 and nx[0] - pv[0] > 0 and nx[0] - nx[7] > env.operator_dist) or
+                   (nx[0] > 4.5 and nx[0] - pv[0] < 0 and nx[7] - nx[0] > env.operator_dist))
+        if self.allowed and not self.y_b:
+            if running:
+                self.viol_y += 1
+                if self.viol_y >= 1:
+                    self.y_b, self.viol_y = True, 0
+            if (not running) and self.viol_y > 0:
+                self.viol_y = 0
+        if self.y_b and self.allowed:
+            if self.y_time >= 15:
+                self.y_b, self.y_time = False, 0
+            if ((nx[0] <= 4.5 and nx[0] - nx[7] <= 0.9 * env.operator_dist) or
+                    (nx[0] > 4.5 and nx[7] - nx[0] <= 0.9 * env.operator_dist)):
+                self.y_b, self.y_time = False, 0
+
+
+def make_handover(env_name, env, has_backup):
+    if not has_backup:
+        return _Handover(env)          # NU / NP: one controller, every transition is kept (NU/main.py:36-90)
+    return {"Unicycle": _UnicycleHandover, "SimulatedCars": _CarsHandover, "Pvtol": _PvtolHandover}[env_name](env)
+
+
+def train(agent, env, dynamics_model, args, memory, node_memory, log=print, trace=None):
+    """Returns a list of per-episode dicts (reward, length, safety violations, updates).  ``trace``: a list that
+    receives one (use_backup, pushed_to_memory) pair per env step (driver tests)."""
     barrier = args.env.endswith("Barrier")
     pvtol = args.env.startswith("Pvtol")
-    unicycle = args.env.startswith("Unicycle")
     has_backup = getattr(agent, "backup_policy", None) is not None
+    ho = make_handover(args.env, env, has_backup and not barrier)
     total_numsteps = updates = 0
-    start_using_backup = False
     history = []
     for i_episode in range(args.max_episodes):
-        use_backup = False
-        if i_episode > 3:
-            start_using_backup = has_backup and unicycle      # the stuck heuristic below is the Unicycle driver's
-        positions_record = []
-        backup_time = violation_time = 0
+        ho.begin_episode(i_episode)
         episode_reward = episode_cost = episode_steps = 0
-        x_init_diff = y_init_diff = 0.0
         done = False
         obs = env.reset()
         t0 = time.perf_counter()
@@ -80,9 +243,10 @@ def train(agent, env, dynamics_model, args, memory, node_memory, log=print):
                                             args.NODE_model_update_interval, *extra)
                     updates += 1
             warm = args.start_steps > total_numsteps
-            if use_backup and start_using_backup:
+            acting_backup = ho.use_backup
+            if acting_backup:
                 action = agent.select_action_backup(obs, warmup=warm)
-                backup_time += 1
+                ho.on_backup_action()
             else:
                 action = agent.select_action(obs, warmup=warm)
             out = env.step(action)
@@ -92,32 +256,19 @@ def train(agent, env, dynamics_model, args, memory, node_memory, log=print):
             episode_steps += 1
             total_numsteps += 1
             episode_reward += reward
-            episode_cost += info.get('num_safety_violation', 0) + info.get('num_safety_violation_obstacles', 0)
+            episode_cost += (info.get('num_safety_violation', 0) + info.get('num_safety_violation_obstacles', 0) +
+                             info.get('num_safety_violation_safety_operator', 0) +
+                             info.get('num_safety_violation_y_min', 0) + info.get('num_safety_violation_y_max', 0))
             mask = 1 if episode_steps == env.max_episode_steps else float(not done)
             row = (obs, action, reward, constraint) + sig + (lya_in, next_lya_in, next_obs, mask)
-            tt = dict(t=episode_steps * env.dt, next_t=(episode_steps + 1) * env.dt)
-            if not (start_using_backup and use_backup):
-                memory.push(*row, **tt)
-            node_memory.push(*row, **tt)
-            if unicycle:          # U/main.py:108-142: stuck for 8 checks -> backup controller for up to 30 steps
-                positions_record.append(np.asarray(next_lya_in))
-                if episode_steps >= 50:
-                    diff = positions_record[-1] - positions_record[-40]
-                    moved = float(diff[0] * diff[0] + diff[1] * diff[1])
-                    if start_using_backup and not use_backup:
-                        if moved <= 0.01:
-                            violation_time += 1
-                            if violation_time >= 8:
-                                use_backup, violation_time = True, 0
-                                x_init_diff, y_init_diff = next_lya_in[0], next_lya_in[1]
-                        elif violation_time > 0:
-                            violation_time = 0
-                    if use_backup and start_using_backup:
-                        if backup_time >= 30:
-                            use_backup, backup_time = False, 0
-                        dx, dy = next_lya_in[0] - x_init_diff, next_lya_in[1] - y_init_diff
-                        if dx * dx + dy * dy >= 0.6:
-                            use_backup, backup_time = False, 0
+            pushed = not acting_backup
+            if pushed:
+                k = episode_steps + ho.memory_t_shift
+                memory.push(*row, t=k * env.dt, next_t=(k + 1) * env.dt)
+            node_memory.push(*row, t=episode_steps * env.dt, next_t=(episode_steps + 1) * env.dt)
+            ho.after_step(episode_steps, lya_in, next_lya_in, next_obs, info)
+            if trace is not None:
+                trace.append((bool(acting_backup), bool(pushed)))
             obs = next_obs
             if os.environ.get("NLBAC_TRAIN_CHECKSUM") == "2" and total_numsteps % 100 == 0:
                 import torch
