@@ -8,8 +8,11 @@ synthetic minibatch already resident in HBM: NODE rollouts (primary + backup
 controller), actor / twin-Q / Lyapunov forward+backward, CBF/CLF augmented-
 Lagrangian loss, Adam steps, Polyak update, and — every 10th step — the NODE
 regression step on 32768 transitions.  Workload at N=1:
-BASELINE.json configs[1] (Unicycle, batch 4096, dopri5).  Weak scaling: every
-rank runs its own 4096-row shard of a 4096*N global batch.
+BASELINE.json configs[1] (Unicycle, batch 4096, dopri5).  N > 1: weak scaling by
+default (every rank runs its own 4096-row shard of a 4096*N global batch; the
+headline ``value``), and the same line carries ``strong`` — the metric's literal
+split, ONE 4096-row global batch sharded over the N ranks — measured right after.
+``--global-batch G`` makes the strong split the headline instead.
 """
 import argparse
 import io
@@ -144,12 +147,42 @@ def pmc_traffic(kernel, env_name, solver, B):
     (tools/gpu_pmc.sh: FETCH_SIZE and WRITE_SIZE in separate passes, gfx950 read-side x2 correction applied in
     tools/pmc_summary.py).  Counters cannot be collected from inside the timed process, so this is read from
     profiles/; None when no pass exists for the workload."""
-    path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles",
-                        "r01_pmc_hbm_traffic_%s_%s_B%d.json" % (env_name.lower(), solver, B))
-    if not os.path.exists(path):
-        return None
-    k = json.load(open(path))["kernels"].get(kernel.split("+")[0])
-    return None if k is None else k["hbm_bytes_per_launch"]
+    here = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles")
+    for r in ("r02", "r01"):
+        path = os.path.join(here, "%s_pmc_hbm_traffic_%s_%s_B%d.json" % (r, env_name.lower(), solver, B))
+        if os.path.exists(path):
+            k = json.load(open(path))["kernels"].get(kernel.split("+")[0])
+            return None if k is None else k["hbm_bytes_per_launch"]
+    return None
+
+
+PEAK_HBM_BYTES_PER_S = 8.0e12      # MI355X_MICROARCH.md: HBM3E ~8 TB/s
+
+
+def algorithmic_bytes_per_update(agent, B):
+    """SURVEY.md §8(d) "Algorithmic bytes per sample-update", from the agent's real sizes: the minibatch rows read
+    once; every trained parameter read with its gradient and Adam moments and written back with them (28 B), every
+    target parameter read and written plus the live one read (12 B), the NODE's weights read once by the rollouts
+    (4 B); plus, amortised over the fit interval, the NODE-fit rows and the NODE's own optimiser step."""
+    row = 4 * agent.lay.width
+    trained = sum(a.n for a in agent.arenas if a is not agent.ar_n)
+    target = agent.ar_c.n
+    node = agent.ar_n.n
+    fit_row = 4 * (2 * agent.lay.obs_dim + agent.lay.act_dim)
+    per_update = B * row + 28 * trained + 12 * target + 4 * node
+    fit = (NODE_FIT_ROWS * fit_row + 28 * node) / NODE_FIT_INTERVAL
+    return dict(total=per_update + fit, minibatch=B * row, optimiser=28 * trained + 12 * target + 4 * node, node_fit=fit)
+
+
+def pmc_update_traffic(env_name, solver, B, adjoint=False):
+    """HBM bytes per update (all kernels) from the committed counter passes of this workload (tools/gpu_pmc.sh writes
+    ``per_update_bytes`` from a lean run of exactly warmup + steps updates), or None."""
+    tag = "%s_%s_B%d%s" % (env_name.lower(), solver, B, "_adjoint" if adjoint else "")
+    for r in ("r02",):
+        path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "%s_pmc_hbm_traffic_%s.json" % (r, tag))
+        if os.path.exists(path):
+            return json.load(open(path)).get("per_update_bytes")
+    return None
 
 
 def log(msg):
@@ -256,7 +289,15 @@ def main():
     ap.add_argument("--graphs", action="store_true",
                     help="replay the update as hipGraphs (measured equal to eager launches once descriptors are cached)")
     ap.add_argument("--profile-steps", type=int, default=20)
+    ap.add_argument("--global-batch", type=int, default=0,
+                    help="strong scaling: ONE global batch of this many rows sharded over the ranks (default 0: weak "
+                         "scaling, --batch rows per rank)")
+    ap.add_argument("--lean", action="store_true",
+                    help="warm-up + timed region only (no pipelined replay, event-timed pass, sub-metric, CPU baseline): "
+                         "the process runs exactly warmup + steps updates — what the counter passes profile")
     a = ap.parse_args()
+    if a.lean:
+        a.profile_steps, a.no_cpu_baseline = 0, True
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
@@ -279,29 +320,8 @@ def main():
         from nlbac_amd.neural_barrier_certificate.sac_cbf_clf.sac_cbf_clf import SAC_CBF_CLF
     else:
         from nlbac_amd.sac_cbf_clf.sac_cbf_clf import SAC_CBF_CLF
-    B = a.batch
-    env = make_env(a.env, 0)
-    args = Args(B * world)                                            # global batch in the loss normalisation
-    args.gamma_b = GAMMA_B[a.env]
-    agent = SAC_CBF_CLF(env.obs_dim, env.action_space, env, args)
-    agent.solver = a.solver
-    agent.adjoint = a.adjoint
-    agent.use_graphs = (world == 1) and a.graphs
-    if world > 1:
-        agent.enable_data_parallel(dist)
-    dev = agent.device
     from nlbac_amd.sac_cbf_clf.replay_memory import DeviceReplayMemory
-    # the replay lives in HBM in the agent's row layout; minibatches are drawn and gathered on the device
-    replay = DeviceReplayMemory(REPLAY_ROWS, 1234 + rank, agent, device_rng=True)
-    replay.push_rows(replay_rows(agent, synth.transitions(a.env, REPLAY_ROWS, seed=1 + rank, env=env)))
-    ws = agent._workspace(B)
-    fit_rows = torch.empty(NODE_FIT_ROWS, agent.lay.LD, device=dev)
-
-    def step(i, sync=True):
-        replay.sample_rows(B, out=ws.mb, eps_out=ws.eps)       # index draw + gather + policy noise: one launch
-        if i % NODE_FIT_INTERVAL == 0:
-            agent.fit_node_rows(replay.sample_rows(NODE_FIT_ROWS, out=fit_rows))
-        return agent.update_on_device(ws, i, sync=sync, eps_ready=True)
+    env = make_env(a.env, 0)
 
     def fence():
         torch.cuda.synchronize()
@@ -309,51 +329,100 @@ def main():
             dist.barrier()
             torch.cuda.synchronize()
 
-    log("setup done; warm-up")
-    for i in range(a.warmup):
-        step(i)
-    fence()
-    snap = io.BytesIO()                # agent + replay-draw state at the start of the timed region (replayed below)
-    agent.save_checkpoint(snap)
-    draws0 = replay._draws
-    fence()
-    log("timed region: %d steps" % a.steps)
-    t0 = time.perf_counter()
-    for i in range(a.steps):
-        ret = step(a.warmup + i)
-    fence()
-    elapsed = time.perf_counter() - t0
-    if dist is not None:
-        t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
+    def max_over_ranks(x):
+        if dist is None:
+            return x
+        t = torch.tensor([x], device="cuda", dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t)
-    value = B * world * a.steps / elapsed
-    log("timed region done: %.3f ms/step, %.0f samples/s" % (1e3 * elapsed / a.steps, value))
+        return float(t)
 
-    solver_stats = dict(agent.node_solver.stats)
+    def measure(B, global_B, steps, warmup, extras, strong=False):
+        """One agent at ``B`` rows per rank (losses normalised by ``global_B``): warm-up, the timed region bracketed by
+        barrier + synchronize, max over ranks.  ``extras``: also the pipelined replay / event-timed pass / sub-metric."""
+        args = Args(global_B)                                         # global batch in the loss normalisation
+        args.gamma_b = GAMMA_B[a.env]
+        agent = SAC_CBF_CLF(env.obs_dim, env.action_space, env, args)
+        agent.solver = a.solver
+        agent.adjoint = a.adjoint
+        agent.use_graphs = (world == 1) and a.graphs
+        if world > 1:
+            agent.enable_data_parallel(dist)
+        dev = agent.device
+        # the replay lives in HBM in the agent's row layout; minibatches are drawn and gathered on the device
+        replay = DeviceReplayMemory(REPLAY_ROWS, 1234 + rank, agent, device_rng=True)
+        replay.push_rows(replay_rows(agent, synth.transitions(a.env, REPLAY_ROWS, seed=1 + rank, env=env)))
+        ws = agent._workspace(B)
+        fit_local = max(1, NODE_FIT_ROWS // world) if strong else NODE_FIT_ROWS     # (strong: the fit batch is sharded too)
+        fit_rows = torch.empty(fit_local, agent.lay.LD, device=dev)
 
-    # ---- secondary figure: the SAME updates again (state and replay draws rewound to the start of the timed region)
-    #      with the 6 returned floats read one call late (sync="lagged"), the way a driver that only logs them can
-    #      run; the headline above keeps the reference's blocking return
-    n_pipe = a.steps
-    base = a.warmup
-    snap.seek(0)
-    agent.load_checkpoint(snap)
-    replay._draws = draws0
-    fence()
-    t0 = time.perf_counter()
-    for i in range(n_pipe):
-        step(base + i, sync="lagged")
-    fence()
-    el2 = time.perf_counter() - t0
-    if dist is not None:
-        t = torch.tensor([el2], device=dev, dtype=torch.float64)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        el2 = float(t)
-    pipelined = {"value": B * world * n_pipe / el2, "unit": "samples/s", "ms_per_step": 1e3 * el2 / n_pipe,
-                 "steps": n_pipe, "note": "the timed region replayed from the same state with the returned losses read one update late "
-                         "(pinned memory): identical updates, launch stream never drains"}
-    base += n_pipe
+        def step(i, sync=True):
+            replay.sample_rows(B, out=ws.mb, eps_out=ws.eps)       # index draw + gather + policy noise: one launch
+            if i % NODE_FIT_INTERVAL == 0:
+                agent.fit_node_rows(replay.sample_rows(fit_local, out=fit_rows))
+            return agent.update_on_device(ws, i, sync=sync, eps_ready=True)
+
+        for i in range(warmup):
+            step(i)
+        fence()
+        snap = io.BytesIO()            # agent + replay-draw state at the start of the timed region (replayed below)
+        agent.save_checkpoint(snap)
+        draws0 = replay._draws
+        fence()
+        t0 = time.perf_counter()
+        for i in range(steps):
+            ret = step(warmup + i)
+        fence()
+        elapsed = max_over_ranks(time.perf_counter() - t0)
+        res = dict(agent=agent, B=B, global_B=global_B, elapsed=elapsed, value=global_B * steps / elapsed,
+                   ms=1e3 * elapsed / steps, ret=[float(x) for x in ret], stats=dict(agent.node_solver.stats),
+                   fit_rows_per_rank=fit_local, step=step, base=warmup + steps)
+        if not extras:
+            return res
+        # ---- secondary figure: the SAME updates again (state and replay draws rewound to the start of the timed
+        #      region) with the 6 returned floats read one call late (sync="lagged"), the way a driver that only logs
+        #      them can run; the headline above keeps the reference's blocking return
+        snap.seek(0)
+        agent.load_checkpoint(snap)
+        replay._draws = draws0
+        fence()
+        t0 = time.perf_counter()
+        for i in range(steps):
+            step(warmup + i, sync="lagged")
+        fence()
+        el2 = max_over_ranks(time.perf_counter() - t0)
+        res["pipelined"] = {"value": global_B * steps / el2, "unit": "samples/s", "ms_per_step": 1e3 * el2 / steps,
+                            "steps": steps,
+                            "note": "the timed region replayed from the same state with the returned losses read one "
+                                    "update late (pinned memory): identical updates, launch stream never drains"}
+        res["base"] = warmup + 2 * steps
+        return res
+
+    strong_first = a.global_batch > 0
+    if strong_first:
+        assert a.global_batch % world == 0, "--global-batch must divide over the ranks"
+        B, GB = a.global_batch // world, a.global_batch
+    else:
+        B, GB = a.batch, a.batch * world
+    log("setup; warm-up + timed region: %d steps, %d rows per rank, global batch %d" % (a.steps, B, GB))
+    main_run = measure(B, GB, a.steps, a.warmup, extras=not a.lean, strong=strong_first)
+    agent, value, elapsed, step, base = (main_run[k] for k in ("agent", "value", "elapsed", "step", "base"))
+    log("timed region done: %.3f ms/step, %.0f samples/s" % (main_run["ms"], value))
+    pipelined = main_run.get("pipelined")
+
+    # ---- N > 1: the other split of the same metric, measured right after (its own agent)
+    other = None
+    if world > 1 and not a.lean:
+        if strong_first:
+            o = measure(a.batch, a.batch * world, a.steps, a.warmup, extras=False)
+            kind = "weak"
+        else:
+            assert a.batch % world == 0
+            o = measure(a.batch // world, a.batch, a.steps, a.warmup, extras=False, strong=True)
+            kind = "strong"
+        other = {"scaling": kind, "value": o["value"], "unit": "samples/s", "ms_per_step": o["ms"],
+                 "batch_per_gpu": o["B"], "global_batch": o["global_B"], "node_fit_rows_per_gpu": o["fit_rows_per_rank"],
+                 "rollout_solver_stats": o["stats"]}
+        del o
 
     # ---- roofline of the dominant kernel: separate pass, HIP events around each MLP launch ----------
     roofline = None
@@ -378,15 +447,36 @@ def main():
                         flops_per_launch=ks[dom]["flops"] / ks[dom]["launches"],
                         all={k: dict(avg_us=round(v["avg_us"], 2), tflops=round(v["tflops"], 2),
                                      launches=v["launches"]) for k, v in ks.items()})
+        # the whole update against both roofs: executed MFMA-kernel FLOP of the event-timed pass per update over the
+        # headline time, and the HBM side north_star asks for (algorithmic bytes; counter bytes when a pass exists)
+        flop_upd = sum(v["flops"] for v in ks.values()) / a.profile_steps
+        roofline["update"] = dict(mfma_flop_per_update=flop_upd, achieved=flop_upd / (main_run["ms"] * 1e-3) / 1e12,
+                                  unit="TFLOP/s", frac=flop_upd / (main_run["ms"] * 1e-3) / 1e12 / PEAK_F32_MFMA_TFLOPS)
     elif a.profile_steps:
         for i in range(a.profile_steps):
             step(base + i)
     fence()
+    if rank == 0:
+        alg = algorithmic_bytes_per_update(agent, B)
+        cnt = pmc_update_traffic(a.env, a.solver, B, a.adjoint)
+        sec = main_run["ms"] * 1e-3
+        hbm = dict(algorithmic_bytes=alg["total"], algorithmic_split=alg, counter_bytes=cnt,
+                   achieved_bw=alg["total"] / sec / 1e9, unit="GB/s", peak=PEAK_HBM_BYTES_PER_S / 1e9,
+                   frac=alg["total"] / sec / PEAK_HBM_BYTES_PER_S,
+                   counter_bw=(cnt / sec / 1e9) if cnt else None,
+                   counter_frac=(cnt / sec / PEAK_HBM_BYTES_PER_S) if cnt else None,
+                   note="per update and GPU: algorithmic = minibatch rows + optimiser / target / NODE parameter traffic "
+                        "(SURVEY.md 8d) + the amortised NODE fit; counter = FETCH_SIZE x2 + WRITE_SIZE of all kernels "
+                        "from the committed rocprofv3 --pmc passes (includes Infinity-Cache hits)")
+        if roofline is None:
+            roofline = dict(bound="mfma", kernel=None, achieved=None, peak=PEAK_F32_MFMA_TFLOPS, unit="TFLOP/s",
+                            frac=None, traffic=None)
+        roofline["hbm"] = hbm
 
     # ---- sub-metric: the NODE odeint alone, forward + backward to the controls, on the rollout
     #      shape of the update (one problem per controller, B rows each)
     ode_sub = None
-    if rank == 0 and world == 1:
+    if rank == 0 and world == 1 and not a.lean:
         ode_sub = node_odeint_submetric(agent, env, B, a.solver)
 
     cpu = None
@@ -396,20 +486,23 @@ def main():
     if rank == 0:
         out = {
             "metric": "ODE-integrate+update samples/sec, Unicycle batch 4096" if a.env == "Unicycle" else
-                      "ODE-integrate+update samples/sec, %s batch %d" % (a.env, B),
+                      "ODE-integrate+update samples/sec, %s batch %d" % (a.env, GB if strong_first else B),
             "value": value, "unit": "samples/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
-            "ms_per_step": 1e3 * elapsed / a.steps, "higher_is_better": True, "scaling": "weak",
+            "ms_per_step": main_run["ms"], "higher_is_better": True, "scaling": "strong" if strong_first else "weak",
             "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {"workload": "%s B=%d %s%s (%s); NODE fit on %d rows every %d "
                                    "updates; replay of %d synthetic transitions resident in HBM"
-                                   % (a.env, B, a.solver, " + odeint_adjoint" if a.adjoint else "", WORKLOAD_NOTE[a.env],
-                                      NODE_FIT_ROWS, NODE_FIT_INTERVAL, REPLAY_ROWS),
-                       "solver": a.solver, "adjoint": bool(a.adjoint), "batch_per_gpu": B, "global_batch": B * world,
+                                   % (a.env, GB if strong_first else B, a.solver, " + odeint_adjoint" if a.adjoint else "",
+                                      WORKLOAD_NOTE[a.env], NODE_FIT_ROWS, NODE_FIT_INTERVAL, REPLAY_ROWS),
+                       "solver": a.solver, "adjoint": bool(a.adjoint), "batch_per_gpu": B, "global_batch": GB,
+                       "node_fit_rows_per_gpu": main_run["fit_rows_per_rank"],
                        "parallelism": "dp%d" % world, "hipgraph": bool(agent.use_graphs),
-                       "rollout_solver_stats": solver_stats, "last_losses": [float(x) for x in ret]},
+                       "rollout_solver_stats": main_run["stats"], "last_losses": main_run["ret"]},
             "roofline": roofline, "cpu_baseline": cpu, "node_odeint_fwd_bwd": ode_sub,
             "pipelined": pipelined,
         }
+        if other is not None:
+            out[other["scaling"]] = other
         if cpu:
             out["speedup_vs_cpu_baseline"] = value / cpu["value"]
         print(json.dumps(out))

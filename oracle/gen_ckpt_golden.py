@@ -39,6 +39,12 @@ def main():
     barrier = env_name.endswith("Barrier")
 
     def build(seed):
+        import random
+        # the reference driver seeds every generator BEFORE the agent exists (U/main.py:253-263): the critic, the
+        # Lyapunov net and their targets are created ahead of the constructor's own manual_seed (sac_cbf_clf.py:47-70)
+        random.seed(seed)
+        np.random.seed(seed)
+        torch.manual_seed(seed)
         env = synth.fixture_env(env_name, seed)
         args = O.Args(batch_size=B, hidden_size=HIDDEN, seed=seed)
         args.gamma_b = cfg["gamma_b"]

@@ -31,6 +31,10 @@ def test_reference_written_checkpoint_loads_and_reproduces_the_next_update(env_n
     env = synth.fixture_env(env_name, seed)
     args = Args(batch_size=B, hidden_size=hidden, seed=seed, cuda=True)
     args.gamma_b = float(g["gamma_b"])
+    import random
+    random.seed(seed)              # as the reference driver does before it builds the agent (U/main.py:253-263)
+    np.random.seed(seed)
+    torch.manual_seed(seed)
     agent = SAC_CBF_CLF(env.obs_dim, env.action_space, env, args)
     agent.load_weights(d)
     agent.neural_ode_model.load_state_dict(torch.load(os.path.join(d, "node_model.pkl"), map_location="cuda",

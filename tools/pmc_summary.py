@@ -31,6 +31,7 @@ def per_kernel(d, counter):
 
 def main():
     fd, wd = sys.argv[1], sys.argv[2]
+    n_updates = int(sys.argv[3]) if len(sys.argv) > 3 else 0      # updates the profiled (lean) process ran
     f_acc, f_cnt = per_kernel(fd, "FETCH_SIZE")
     w_acc, w_cnt = per_kernel(wd, "WRITE_SIZE")
     out = {}
@@ -40,8 +41,14 @@ def main():
         write = 1024.0 * w_acc.get(k, 0.0) / max(1, w_cnt.get(k, 0))
         out[k] = dict(launches=n, fetch_bytes_per_launch=fetch, write_bytes_per_launch=write,
                       hbm_bytes_per_launch=fetch + write)
-    json.dump(dict(note="FETCH_SIZE x2 (gfx950 tallies 128-B requests at 64 B) + WRITE_SIZE, KiB -> bytes, mean per launch",
-                   kernels=out), sys.stdout, indent=1)
+    total = sum(v["hbm_bytes_per_launch"] * v["launches"] for v in out.values())
+    res = dict(note="FETCH_SIZE x2 (gfx950 tallies 128-B requests at 64 B) + WRITE_SIZE, KiB -> bytes, mean per launch",
+               kernels=out)
+    if n_updates:
+        res.update(updates=n_updates, per_update_bytes=total / n_updates,
+                   per_update_note="all kernels of a lean bench process (bench.py --lean: exactly warm-up + timed updates, "
+                                   "NODE fits included) divided by its update count")
+    json.dump(res, sys.stdout, indent=1)
 
 
 if __name__ == "__main__":
