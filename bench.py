@@ -497,7 +497,8 @@ def main():
                        "solver": a.solver, "adjoint": bool(a.adjoint), "batch_per_gpu": B, "global_batch": GB,
                        "node_fit_rows_per_gpu": main_run["fit_rows_per_rank"],
                        "parallelism": "dp%d" % world, "hipgraph": bool(agent.use_graphs),
-                       "rollout_solver_stats": main_run["stats"], "last_losses": main_run["ret"]},
+                       "rollout_solver_stats": main_run["stats"], "last_losses": main_run["ret"],
+                       "hbm_peak_allocated_bytes": int(torch.cuda.max_memory_allocated())},
             "roofline": roofline, "cpu_baseline": cpu, "node_odeint_fwd_bwd": ode_sub,
             "pipelined": pipelined,
         }

@@ -6,7 +6,9 @@ import numpy as np
 import pytest
 import torch
 
+from common import vec_close
 from nlbac_amd import synth
+from nlbac_amd.sac_cbf_clf import _layout as SC
 from test_agent_parity_gpu import make_agent
 
 pytestmark = pytest.mark.gpu
@@ -45,6 +47,22 @@ def test_baseline_configurations_at_full_size(env_name, B, solver):
         worst = max(abs(a - b) / (abs(b) + 1e-3) for a, b in zip(rets[0], R["ret"]))
         assert worst < 1e-4, "%s B=%d update %d: max rel err vs oracle %.2e" % (env_name, B, u, worst)
         assert rets[0] == rets[1], "two runs of the same update differ: %s vs %s" % (rets[0], rets[1])
+        # beyond the six floats: the constraint sums the augmented-Lagrangian loss is built on, the first predicted
+        # state, and the gradients the optimisers consumed (as norms: the oracle's full vectors at these sizes)
+        a0 = agents[0][0]
+        sc = a0.sc.cpu().numpy()
+        vec_close(sc[SC.SC_REQ:SC.SC_REQ + len(R["required"])], R["required"].numpy(), 1e-4, "required (update %d)" % u)
+        if "brequired" in R:
+            vec_close(sc[SC.SC_BREQ:SC.SC_BREQ + len(R["brequired"])], R["brequired"].numpy(), 1e-4, "brequired")
+        vec_close(a0.node_solver.ctx["out"][:B].cpu().numpy(), R["x_next"].numpy(), 1e-4, "x_next (update %d)" % u)
+        for name, ar, mod in (("critic", a0.ar_c, a0.critic), ("policy", a0.ar_a, a0.policy),
+                              ("node", a0.ar_n, a0.neural_ode_model)):
+            if "g_" + name not in R or (name == "node" and u != 0):
+                continue
+            gd = torch.cat([ar.grad_view(p_).reshape(-1) for p_ in mod.parameters()]).cpu().double()
+            go = R["g_" + name].double()
+            rel = float((gd - go).norm() / go.norm())
+            assert rel < (2e-3 if name == "node" else 5e-4), "%s gradient (update %d): relative L2 error %.3e" % (name, u, rel)
     torch.cuda.synchronize()
     a, b = agents[0][0], agents[1][0]
     for x, y in zip(a.arenas, b.arenas):

@@ -13,27 +13,88 @@ pytestmark = pytest.mark.gpu
 TOL = 1e-4
 
 
-def rows_close(a, b, name, frac=0.05, loose=2e-2):
-    """Row-wise gradient comparison for a ReLU field: the discrete gradient is discontinuous where a stage point sits on
-    a ReLU kink, and over a multi-step solve (35+ field evaluations per row) fp32 rounding flips a mask in a few rows.
-    Bar: every row within ``loose`` of the tensor's scale, at most ``frac`` of the rows beyond TOL, median row error
-    below TOL / 10."""
+KINK = 2e-5
+
+
+def rows_close(a, b, name, margin):
+    """Row-wise gradient comparison for a ReLU field.  The discrete gradient is discontinuous where a stage point sits
+    on a ReLU kink; ``margin[r]`` is the smallest |pre-activation| / (layer scale) the oracle met for row r, in fp64,
+    over every unit, stage and step of the solve.  Bar: EVERY row whose margin exceeds ``KINK`` (no unit anywhere near
+    its kink, so fp32 rounding cannot flip a mask) is within TOL of the tensor's scale; a row beyond TOL must be one
+    of the near-kink rows, and even those stay within 5e-2 (one flipped unit moves a row by that unit's share)."""
     a, b = np.asarray(a, dtype=np.float64), np.asarray(b, dtype=np.float64)
     e = np.abs(a - b).max(1) / np.abs(b).max()
-    assert e.max() <= loose, "%s: worst row off by %.3e" % (name, e.max())
-    assert (e > TOL).mean() <= frac, "%s: %.1f %% of the rows beyond %.0e" % (name, 100 * (e > TOL).mean(), TOL)
+    near = np.asarray(margin) < KINK
+    assert (e[~near] <= TOL).all(), "%s: %d rows beyond %.0e that are NOT near a ReLU kink (worst %.3e, margin %.3e)" % (
+        name, int((e[~near] > TOL).sum()), TOL, e[~near].max(), np.asarray(margin)[~near][np.argmax(e[~near])])
+    assert e.max() <= 5e-2, "%s: worst near-kink row off by %.3e" % (name, e.max())
     assert np.median(e) <= TOL / 10, "%s: median row error %.3e" % (name, np.median(e))
+    return int(near.sum()), int((e > TOL).sum())
+
+
+def flipped_rows(sol, info, n):
+    """Rows for which the device took another branch of some ReLU than the oracle's fp32 run, anywhere in the solve:
+    the device's saved activations of every accepted step (stage 0 of the first step, stages 1-6 of each) against the
+    oracle's masks of the same field evaluations (call 0 = f0, call 1 = the initial-step probe, then six per attempt)."""
+    acc = [i for i, st in enumerate(info["steps"]) if st[2]]
+    assert len(acc) == len(sol.ctx["steps"])
+    flipped = np.zeros(n, dtype=bool)
+    for k, a in enumerate(acc):
+        ws = sol.ctx["steps"][k]["ws"]
+        for st in ([0] if k == 0 else []) + list(range(1, 7)):
+            call = 0 if st == 0 else 2 + 6 * a + (st - 1)
+            for net, acts in ((0, ws.acts_f), (1, ws.acts_g)):
+                for l, m in enumerate(info["masks"][call][net]):
+                    dev = (acts[l, st * n:(st + 1) * n] > 0).cpu().numpy()
+                    flipped |= (dev != m).any(1)
+    return flipped
 
 
 def oracle_solve(sd_np, y0, u, T, dout, n_s=3, n_u=2):
+    """The oracle's odeint + autograd in fp32, plus — from a second, fp64 run of the same step sequence — the per-row
+    kink margin of ``rows_close``."""
     from oracle import nlbac_oracle as O
     sd = {k: torch.tensor(v, requires_grad=True) for k, v in sd_np.items()}
     y0 = y0.clone().requires_grad_(True)
     u = u.clone().requires_grad_(True)
     info = {}
-    out = O.odeint(O.AffineNode(sd, n_s=n_s, n_u=n_u), torch.cat((y0, u), 1), torch.tensor([0.0, T]), method="dopri5",
+
+    class Masks(O.AffineNode):          # the fp32 run's ReLU masks, per field evaluation: [(f layers), (g layers)]
+        calls = []
+
+        def _mlp(self, names, x):
+            ms = []
+            for nm in names[:-1]:
+                x = torch.relu(O._lin(self.sd, nm, x))
+                ms.append((x > 0).detach().numpy())
+            if names is self.f_names:
+                self.calls.append([ms])
+            else:
+                self.calls[-1].append(ms)
+            return O._lin(self.sd, names[-1], x)
+    Masks.calls = []
+    out = O.odeint(Masks(sd, n_s=n_s, n_u=n_u), torch.cat((y0, u), 1), torch.tensor([0.0, T]), method="dopri5",
                    atol=1e-7, rtol=1e-5, info=info)[-1][:, :n_s]
     g = torch.autograd.grad((out * dout).sum(), [y0, u] + list(sd.values()))
+    info["masks"] = Masks.calls
+
+    class Margin(O.AffineNode):
+        def __init__(self, sd64):
+            super().__init__(sd64, n_s=n_s, n_u=n_u)
+            self.margin = None
+
+        def _mlp(self, names, x):
+            for nm in names[:-1]:
+                z = O._lin(self.sd, nm, x)
+                m = (z.abs() / z.abs().mean()).min(1).values
+                self.margin = m if self.margin is None else torch.minimum(self.margin, m)
+                x = torch.relu(z)
+            return O._lin(self.sd, names[-1], x)
+    with torch.no_grad():
+        node64 = Margin({k: torch.tensor(v, dtype=torch.float64) for k, v in sd_np.items()})
+        O.odeint(node64, torch.cat((y0.detach(), u.detach()), 1).double(), torch.tensor([0.0, T], dtype=torch.float64),
+                 method="dopri5", atol=1e-7, rtol=1e-5)
+    info["margin"] = node64.margin.numpy()
     return out.detach(), g[0], g[1], torch.cat([t.reshape(-1) for t in g[2:]]), info
 
 
@@ -56,8 +117,15 @@ def test_multi_step_dopri5_with_parameter_gradients(T):
     assert len(sol.ctx["steps"]) == n_acc
     vec_close(out.cpu().numpy(), out_o.numpy(), TOL, "x(T)")
     du, dy0 = sol.backward(dout.cuda(), need_du=True, need_params=True, need_dy0=True)
-    rows_close(dy0.cpu().numpy(), dy0_o.numpy(), "d/dy0")
-    rows_close(du.cpu().numpy(), du_o.numpy(), "d/du")
+    # exact statement: a row may leave the 1e-4 bar only if the device took another branch of some ReLU than the
+    # oracle somewhere in its solve (compared unit by unit on the saved activations); all other rows are within 1e-4
+    flip = flipped_rows(sol, info, n)
+    assert flip.sum() <= 0.1 * n, "%d of %d rows with a flipped ReLU" % (flip.sum(), n)
+    for name, dv, ov in (("d/dy0", dy0, dy0_o), ("d/du", du, du_o)):
+        e = np.abs(dv.cpu().numpy().astype(np.float64) - ov.numpy()).max(1) / np.abs(ov.numpy()).max()
+        assert (e[~flip] <= TOL).all(), "%s: row without a flipped mask off by %.3e" % (name, e[~flip].max())
+        assert e.max() <= 5e-2, "%s: worst flipped-mask row off by %.3e" % (name, e.max())
+    assert (np.asarray(info["margin"])[flip] < 1e-3).all(), "a mask flipped far from its kink"      # (|z| / mean|z| over 4 steps)
     ar = agent.ar_n
     ar.grad.zero_()
     per = ar.n_slabs // len(sol.ctx["steps"])
@@ -104,8 +172,8 @@ def test_problems_that_diverge_fall_back_to_per_problem_solves(masks):
             rows = slice(p * rpp, (p + 1) * rpp)
             out_o, dy0_o, du_o, _, info = oracle_solve(W, y0[rows], u[rows], T, dout[rows])
             vec_close(out[rows].cpu().numpy(), out_o.numpy(), TOL, "x(T) problem %d (T=%g, %s)" % (p, T, kind))
-            rows_close(dy0[rows].cpu().numpy(), dy0_o.numpy(), "d/dy0 problem %d (T=%g, %s)" % (p, T, kind))
-            rows_close(du[rows].cpu().numpy(), du_o.numpy(), "d/du problem %d (T=%g, %s)" % (p, T, kind))
+            rows_close(dy0[rows].cpu().numpy(), dy0_o.numpy(), "d/dy0 problem %d (T=%g, %s)" % (p, T, kind), info["margin"])
+            rows_close(du[rows].cpu().numpy(), du_o.numpy(), "d/du problem %d (T=%g, %s)" % (p, T, kind), info["margin"])
         if len(seen) == 2:
             break
     assert seen == {"first attempt", "later attempt"}, "horizons tried did not produce both kinds of divergence: %r" % seen
