@@ -294,12 +294,37 @@ int nlbac_rk_stage_bwd(const float *dYup, const float *dXf, const float *dXg, in
  * acts_bits != 0: the acts_* buffers receive bit-packed ReLU masks instead — uint32 words
  * [layer][n_stages_total*n][ceil(hid/32)] (bit c of word t = unit 32 t + c is active), layer stride in words: all a
  * backward without weight gradients needs, at 1/32 of the HBM traffic. */
+/* Device-driven dopri5 step chain (optional, NULL = one self-contained launch).  A solve's accepted steps live in
+ * STEP SLOTS — identical buffer layouts `slot_floats` floats apart; every K / Y / G / acts / err / dK / dG / dz /
+ * dy0 / dYup pointer a launch is given is slot 0's.  ctl (the NLBAC_DOPRI_CTL control blocks): a problem whose `done`
+ * is set is skipped, otherwise the launch works in slot ctl[12] (= accepted steps so far); a slot > 0 starts from its
+ * predecessor's last stage (y1 and, FSAL, its derivative).  norm_mode 0 / 1 / 2: the scaled norms of
+ * nlbac_dopri_norm_control and the step controller run in the launch's own epilogue (last workgroup per problem;
+ * partials: P * ceil(rows_per_problem / 32) * 2 floats, tickets: P zeroed uint32) — an attempted step is ONE launch
+ * and a fixed number of attempts can be enqueued without the host looking at any of them.  The controller records an
+ * accepted step's size in hslots[p * n_slots + slot]; it stops a solve that runs out of slots (ctl[13], with done).
+ * Needs rows_per_problem % 32 == 0 (or P == 1).  The backward walks the slots from each problem's last one:
+ * launch back_idx differentiates slot ctl[12] - back_idx. */
+typedef struct nlbac_rk_chain {
+    const double *ctl;
+    long slot_floats;
+    int norm_mode; /* -1: none */
+    int n_slots;
+    float rtol, atol;
+    double t_end;
+    float *partials;
+    unsigned *tickets;
+    double *ctl_w;  /* the control blocks the fused controller updates (normally == ctl) */
+    double *hslots; /* [P][n_slots] accepted step sizes */
+    double *alog;   /* or NULL: attempt log [P][alog_cap][3] = (step size tried, error ratio, accepted) */
+    int alog_cap;
+} nlbac_rk_chain;
 int nlbac_node_rk_fwd(const nlbac_mlp *f, const nlbac_mlp *g, const float *y0, const float *u, int P,
                       int rows_per_problem, int stage_begin, int stage_end, int n_stages_total,
                       const float *beta, const float *c_out, int n_out, const float *c_err, int n_err,
                       const float *h_host, const double *h_dev, int h_dev_stride, float *K, float *Y,
                       float *G, float *acts_f, long acts_f_ls, float *acts_g, long acts_g_ls, int acts_bits,
-                      float *out, float *err, nlbac_stream_t s);
+                      float *out, float *err, const nlbac_rk_chain *chain, nlbac_stream_t s);
 /* Fused backward of the same step (exact gradient of the discrete step): processes stages st_hi-1 .. st_lo.
  * In/out dK [n_stages_total][n][n_s] holds dL/dK_j (initialised by the caller from the step's output
  * combination / interpolant); dYup (may be NULL) is dL/d(stage input) of the last stage (FSAL y1);
@@ -312,7 +337,8 @@ int nlbac_node_rk_bwd(const nlbac_mlp *f, const nlbac_mlp *g, const float *u, co
                       const float *acts_f, long acts_f_ls, const float *acts_g, long acts_g_ls,
                       int acts_bits /* as written by nlbac_node_rk_fwd; excludes dz_f/dz_g/dG */,
                       float *dz_f, float *dz_g, float *dG, float *dK, const float *dYup, float *dy0,
-                      int dy0_in, float *du, int du_acc, nlbac_stream_t s);
+                      int dy0_in, float *du, int du_acc, const nlbac_rk_chain *chain, int back_idx,
+                      nlbac_stream_t s);
 /* The same one-launch RK step for the single-net NODE dx/dt = net([x | c]) with carried inputs c = (u, t)
  * (SimulatedCars, C/sac_cbf_clf/model.py:179-205; odeint call sites C/sac_cbf_clf/sac_cbf_clf.py:437,458,581,603,
  * C/model.py:245): n_s = net->out_dim state columns, n_c = net->in_dim - n_s carried columns (c: (rows, n_c)),
@@ -340,23 +366,31 @@ int nlbac_concat_rk_bwd(const nlbac_mlp *net, int P, int rows_per_problem, int n
 #define NLBAC_DOPRI_CTL 16
 int nlbac_dopri_norm_partials(const float *a, const float *b, const float *y0, const float *y1,
                               const float *u, int mode, float rtol, float atol, int n_s, int n_u,
-                              int rows_per_problem, int P, float *partials, nlbac_stream_t s);
+                              int rows_per_problem, int P, float *partials,
+                              const double *slot_ctl /* or NULL; mode 2 of a device-driven chain: a, y1 are slot 0's and
+                                                        the attempt's are those of slot ctl[12]; done problems are skipped */,
+                              long slot_floats, nlbac_stream_t s);
 /* nlbac_dopri_norm_partials + nlbac_dopri_control in one launch (single-GPU path: no all-reduce between them).  tickets: P zeroed
  * uint32 words, left zeroed by the launch. */
 int nlbac_dopri_norm_control(const float *a, const float *b, const float *y0, const float *y1, const float *u,
                              int mode, float rtol, float atol, int n_s, int n_u, int rows_per_problem, int P,
                              double t_end, float *partials, unsigned *tickets, double *ctl, nlbac_stream_t s);
 int nlbac_dopri_control(const float *partials, int n_blk_per_problem, int mode, int n_s, int n_u,
-                        int rows_per_problem, int P, double t_end, double *ctl, nlbac_stream_t s);
+                        int rows_per_problem, int P, double t_end, double *ctl,
+                        int n_slots /* 0: no step slots; > 0: chained (a finished solve is left alone in mode 2) */,
+                        double *hslots /* or NULL: [P][n_slots] accepted step sizes */,
+                        double *alog /* or NULL: attempt log, see nlbac_rk_chain */, int alog_cap, nlbac_stream_t s);
 /* y(t_end) from the accepted step's stages (4th-order interpolant, x=(t_end-t)/h) and its backward
  * (writes dy0, dy1, dK[0..6]).  h and x come from the device control block `ctl` (h_used, x) when it is
  * non-NULL — hipGraph-replay safe — else from the host arrays. */
 int nlbac_dopri_interp_fwd(const float *y0, const float *y1, const float *K, const float *h_host,
                            const float *x_host, const double *ctl, int P, int rows_per_problem, int n_s,
-                           float *out, nlbac_stream_t s);
+                           float *out, long slot_floats, nlbac_stream_t s);
 int nlbac_dopri_interp_bwd(const float *dout, const float *h_host, const float *x_host, const double *ctl,
                            int P, int rows_per_problem, int n_s, float *dy0, float *dy1, float *dK,
-                           nlbac_stream_t s);
+                           long slot_floats, nlbac_stream_t s);
+/* (slot_floats != 0: y1 / K resp. dy0 / dy1 / dK are slot 0's pointers of a device-driven chain and the step
+ * interpolated is the one in slot ctl[12]; its y0 is the predecessor slot's y1.) */
 
 /* ------------------------------------------------------------------------
  * odeint_adjoint (torchdiffeq 0.2.3 OdeintAdjointMethod, torchdiffeq/_impl/adjoint.py; pinned by the reference at

@@ -45,6 +45,14 @@ class MlpIO(C.Structure):
                 ("skinny_ws", C.c_void_p)]
 
 
+class RkChain(C.Structure):
+    """``struct nlbac_rk_chain``"""
+    _fields_ = [("ctl", C.c_void_p), ("slot_floats", C.c_long), ("norm_mode", C.c_int), ("n_slots", C.c_int),
+                ("rtol", C.c_float), ("atol", C.c_float), ("t_end", C.c_double), ("partials", C.c_void_p),
+                ("tickets", C.c_void_p), ("ctl_w", C.c_void_p), ("hslots", C.c_void_p), ("alog", C.c_void_p),
+                ("alog_cap", C.c_int)]
+
+
 _P, _I, _F, _D, _L = C.c_void_p, C.c_int, C.c_float, C.c_double, C.c_long
 
 # name -> argtypes (return type is always int unless listed in _RESTYPE)
@@ -99,9 +107,9 @@ _PROTOS = {
     "nlbac_barrier_constraints_fwd": [_P, _P, _P, _P, _F, _F, _F, _I, _P, _P, _P],
     "nlbac_barrier_constraints_bwd": [_P, _F, _F, _I, _P, _P, _P, _P],
     "nlbac_node_rk_fwd": [C.POINTER(Mlp), C.POINTER(Mlp), _P, _P, _I, _I, _I, _I, _I, c_float_p, c_float_p, _I,
-                          c_float_p, _I, c_float_p, _P, _I, _P, _P, _P, _P, _L, _P, _L, _I, _P, _P, _P],
+                          c_float_p, _I, c_float_p, _P, _I, _P, _P, _P, _P, _L, _P, _L, _I, _P, _P, C.POINTER(RkChain), _P],
     "nlbac_node_rk_bwd": [C.POINTER(Mlp), C.POINTER(Mlp), _P, _P, _I, _I, _I, _I, _I, _I, c_float_p, c_float_p, _P, _I,
-                          _P, _L, _P, _L, _I, _P, _P, _P, _P, _P, _P, _I, _P, _I, _P],
+                          _P, _L, _P, _L, _I, _P, _P, _P, _P, _P, _P, _I, _P, _I, C.POINTER(RkChain), _I, _P],
     "nlbac_concat_rk_fwd": [C.POINTER(Mlp), _P, _P, _I, _I, _I, _I, _I, c_float_p, c_float_p, _I, c_float_p, _I, c_float_p,
                             _P, _I, _P, _P, _P, _L, _P, _P, _P, _P, _P],
     "nlbac_concat_rk_bwd": [C.POINTER(Mlp), _I, _I, _I, _I, _I, _I, c_float_p, c_float_p, _P, _I, _P, _L, _P, _P, _P, _P,
@@ -115,11 +123,11 @@ _PROTOS = {
     "nlbac_adj_param_norm": [_I, _P, _P, _L, _I, c_float_p, c_float_p, c_float_p, _P, _P, _P, _I, _F, _F, _P, _P, _P, _P, _P,
                              _P],
     "nlbac_adj_commit": [_P, _I, _L, _I, _P, _P, _P, _P, _P],
-    "nlbac_dopri_norm_partials": [_P, _P, _P, _P, _P, _I, _F, _F, _I, _I, _I, _I, _P, _P],
+    "nlbac_dopri_norm_partials": [_P, _P, _P, _P, _P, _I, _F, _F, _I, _I, _I, _I, _P, _P, _L, _P],
     "nlbac_dopri_norm_control": [_P, _P, _P, _P, _P, _I, _F, _F, _I, _I, _I, _I, _D, _P, _P, _P, _P],
-    "nlbac_dopri_control": [_P, _I, _I, _I, _I, _I, _I, _D, _P, _P],
-    "nlbac_dopri_interp_fwd": [_P, _P, _P, c_float_p, c_float_p, _P, _I, _I, _I, _P, _P],
-    "nlbac_dopri_interp_bwd": [_P, c_float_p, c_float_p, _P, _I, _I, _I, _P, _P, _P, _P],
+    "nlbac_dopri_control": [_P, _I, _I, _I, _I, _I, _I, _D, _P, _I, _P, _P, _I, _P],
+    "nlbac_dopri_interp_fwd": [_P, _P, _P, c_float_p, c_float_p, _P, _I, _I, _I, _P, _L, _P],
+    "nlbac_dopri_interp_bwd": [_P, c_float_p, c_float_p, _P, _I, _I, _I, _P, _P, _P, _L, _P],
     "nlbac_axpby": [_F, _P, _F, _P, _L, _P, _P],
     "nlbac_fill": [_P, _F, _L, _P],
     "nlbac_sum_partials": [_P, _I, _I, _F, _P, _P],

@@ -19,6 +19,7 @@
 // Stage derivatives of the tile stay in LDS across stages (sK); everything the
 // backward needs (Y, K, g(x), post-ReLU activations) is written once, coalesced.
 #include "mlp_device.h"
+#include "ode_control.h"
 
 #define NODE_LDS_MAX (160 * 1024 - 64)   /* dynamic LDS per workgroup; the rest holds the static group-barrier counters */
 #define RK_MAX_STAGES 8
@@ -41,6 +42,14 @@ struct NodeRkLaunch {
     float* out; float* err;
     int ld;
     int sw_off1;                      // float offset of g_net's output-layer block behind f_net's in LDS
+    // device-driven dopri5 chain (nlbac_rk_chain): problems whose solve is done are skipped; the step's buffers (K, Y,
+    // G, acts, err) are those of step slot C_NACC, `slot_floats` floats apart; a slot > 0 starts from its predecessor's
+    // last stage (y1 = Y[6], FSAL K[6]).  norm_mode >= 0: the scaled norms of nlbac_dopri_norm_control and the step
+    // controller run in this launch's epilogue (last workgroup of each problem).
+    const double* ctl; long slot_floats;
+    int norm_mode, n_slots; float rtol, atol; double t_end;
+    float* partials; unsigned* tickets; double* ctl_w; double* hslots;
+    double* alog; int alog_cap;       // attempt log [P][alog_cap][3] = (h tried, error ratio, accepted) or null
 };
 
 // OCC 1: compiled for 4 waves per SIMD (128 VGPRs, a few spills) so that two workgroups share a CU and overlap their
@@ -63,6 +72,22 @@ __global__ __launch_bounds__(512, OCC ? 4 : 2) void node_rk_fwd_kernel(const Nod
     GroupBar gbar{&s_gcnt[grp], 0u, 4u};
     const int n = L.n, ns = L.n_s, nu = L.n_u, LD = L.ld;
     const int row0 = blockIdx.x * NLBAC_MLP_TILE;
+    // device-driven chain: this tile's problem (tiles do not straddle problems there), its step slot, FSAL source
+    const int p_tile = row0 / L.rpp;
+    long soff = 0;
+    bool fsal = false;
+    if (L.ctl) {
+        const double* c = L.ctl + (long)p_tile * NLBAC_DOPRI_CTL;
+        if (c[C_DONE] > 0.0) return;              // (uniform) this problem's solve has finished
+        const int slot = (int)c[C_NACC];
+        soff = (long)slot * L.slot_floats;
+        fsal = slot > 0;
+    }
+    float* const gK = L.K + soff;
+    float* const gY = L.Y + soff;
+    float* const gG = L.G + soff;
+    float* const gErr = L.err ? L.err + soff : nullptr;
+    const float* const gy0 = fsal ? (gY - L.slot_floats) + (long)(L.S_total - 1) * n * ns : L.y0;
     const nlbac_mlp& net = L.net[grp];
     const int hid = net.hid, NT = pad32(hid) >> 5, hidp8 = pad8(hid);
     const int nwide_own = net.n_layers - 1;
@@ -98,7 +123,7 @@ __global__ __launch_bounds__(512, OCC ? 4 : 2) void node_rk_fwd_kernel(const Nod
     // ---- tile constants: y0, u, h, already-known stages (FSAL / f0 from an earlier launch)
     for (int idx = tid; idx < NLBAC_MLP_TILE * RK_MAX_NS; idx += 512) {
         const int m = idx >> 3, c = idx & 7, row = row0 + m;
-        sY0[idx] = (row < n && c < ns) ? L.y0[(long)row * ns + c] : 0.f;
+        sY0[idx] = (row < n && c < ns) ? gy0[(long)row * ns + c] : 0.f;
     }
     for (int idx = tid; idx < NLBAC_MLP_TILE * RK_MAX_NU; idx += 512) {
         const int m = idx >> 2, c = idx & 3, row = row0 + m;
@@ -111,7 +136,16 @@ __global__ __launch_bounds__(512, OCC ? 4 : 2) void node_rk_fwd_kernel(const Nod
     for (int idx = tid; idx < L.stage_begin * NLBAC_MLP_TILE * RK_MAX_NS; idx += 512) {
         const int j = idx / (NLBAC_MLP_TILE * RK_MAX_NS), rem = idx - j * NLBAC_MLP_TILE * RK_MAX_NS;
         const int m = rem >> 3, c = rem & 7, row = row0 + m;
-        sK[idx] = (row < n && c < ns) ? L.K[((long)j * n + row) * ns + c] : 0.f;
+        float v = 0.f;
+        if (row < n && c < ns) {
+            if (fsal && j == 0) {       // first stage = the previous slot's last one; kept in this slot for the interpolant
+                v = (gK - L.slot_floats)[((long)(L.S_total - 1) * n + row) * ns + c];
+                gK[(long)row * ns + c] = v;
+            } else {
+                v = gK[((long)j * n + row) * ns + c];
+            }
+        }
+        sK[idx] = v;
     }
     __syncthreads();
 
@@ -129,7 +163,7 @@ __global__ __launch_bounds__(512, OCC ? 4 : 2) void node_rk_fwd_kernel(const Nod
                 const float h = sH[m];
                 for (int j = 0; j < st; ++j)
                     if (L.beta[st][j] != 0.f) a = a + sK[(j * NLBAC_MLP_TILE + m) * RK_MAX_NS + c] * (L.beta[st][j] * h);
-                if (grp == 0 && row0 + m < n) L.Y[((long)st * n + row0 + m) * ns + c] = a;
+                if (grp == 0 && row0 + m < n) gY[((long)st * n + row0 + m) * ns + c] = a;
             }
             in[m * LD + c] = a;
         }
@@ -140,7 +174,7 @@ __global__ __launch_bounds__(512, OCC ? 4 : 2) void node_rk_fwd_kernel(const Nod
         //      group's GEMM can overlap the other's epilogue; the weight stream of each wave runs on across layers and
         //      stages (WaveGemm), only the LDS operands wait for the barriers
         {
-            float* acts_tile = L.acts[grp] ? L.acts[grp] + ((long)st * n + row0) * (BITS ? NT : hid) : nullptr;
+            float* acts_tile = L.acts[grp] ? L.acts[grp] + soff + ((long)st * n + row0) * (BITS ? NT : hid) : nullptr;
             const bool wrap = st + 1 < L.stage_end;
             if constexpr (MODE == 2)
                 fwd_wide_layers<2, BITS>(wg2, net, active, wave, lane, LD, inp, in, out, acts_tile, L.acts_ls[grp], n_rows, nwide_own, wrap, nullptr, &gbar);
@@ -166,7 +200,7 @@ __global__ __launch_bounds__(512, OCC ? 4 : 2) void node_rk_fwd_kernel(const Nod
             const int m = idx & 31, o = idx >> 5, row = row0 + m;
             const float val = skinny_row_dot(in + m * LD, sW + o * hid, hid) + sW[net.out_dim * hid + o];
             (grp == 0 ? sF + m * RK_MAX_NS : sG + m * RK_MAX_GOUT)[o] = val;
-            if (grp == 1 && row < n) L.G[((long)st * n + row) * (ns * nu) + o] = val;
+            if (grp == 1 && row < n) gG[((long)st * n + row) * (ns * nu) + o] = val;
         }
 #endif
         __syncthreads();
@@ -178,7 +212,7 @@ __global__ __launch_bounds__(512, OCC ? 4 : 2) void node_rk_fwd_kernel(const Nod
             float a = sF[m * RK_MAX_NS + r];
             for (int c = 0; c < nu; ++c) a += sG[m * RK_MAX_GOUT + r * nu + c] * sU[m * RK_MAX_NU + c];
             sK[(st * NLBAC_MLP_TILE + m) * RK_MAX_NS + r] = a;
-            if (row0 + m < n) L.K[((long)st * n + row0 + m) * ns + r] = a;
+            if (row0 + m < n) gK[((long)st * n + row0 + m) * ns + r] = a;
         }
         __syncthreads();
         TSTAMP(1 + 8 * (st - L.stage_begin) + 4)
@@ -198,11 +232,95 @@ __global__ __launch_bounds__(512, OCC ? 4 : 2) void node_rk_fwd_kernel(const Nod
                 if (L.c_out[j] != 0.f) a = a + sK[(j * NLBAC_MLP_TILE + m) * RK_MAX_NS + r] * (L.c_out[j] * h);
             L.out[(long)row * ns + r] = a;
         }
-        if (L.err) {
+        if (gErr) {
             float a = 0.f;
             for (int j = 0; j < L.n_err; ++j)
                 if (L.c_err[j] != 0.f) a = a + sK[(j * NLBAC_MLP_TILE + m) * RK_MAX_NS + r] * (L.c_err[j] * h);
-            L.err[(long)row * ns + r] = a;
+            gErr[(long)row * ns + r] = a;
+        }
+    }
+
+    // ---- fused step control: this tile's partial sums of the scaled norms (same per-entry arithmetic as
+    //      dopri_norm_block), one ticket per problem; the last workgroup of a problem sums the tile partials in a fixed
+    //      order and runs the controller
+    if (L.norm_mode < 0) return;
+    __shared__ unsigned s_last;
+    if (tid < 64) {
+        const int m = tid;
+        float v0 = 0.f, v1 = 0.f;
+        if (m < n_rows) {
+            const float h = sH[m];
+            for (int r = 0; r < ns; ++r) {
+                const float y = sY0[m * RK_MAX_NS + r];
+                if (L.norm_mode == 2) {
+                    float e = 0.f, y1 = y;
+                    for (int j = 0; j < L.n_err; ++j)
+                        if (L.c_err[j] != 0.f) e = e + sK[(j * NLBAC_MLP_TILE + m) * RK_MAX_NS + r] * (L.c_err[j] * h);
+                    const int sl = L.S_total - 1;         // y1 = the last stage's input
+                    for (int j = 0; j < sl; ++j)
+                        if (L.beta[sl][j] != 0.f) y1 = y1 + sK[(j * NLBAC_MLP_TILE + m) * RK_MAX_NS + r] * (L.beta[sl][j] * h);
+                    const float tol = L.atol + L.rtol * fmaxf(fabsf(y), fabsf(y1));
+                    const float q = e / tol;
+                    v0 += q * q;
+                } else {
+                    const float sc = L.atol + fabsf(y) * L.rtol;
+                    if (L.norm_mode == 0) {
+                        const float q0 = y / sc, q1 = sK[m * RK_MAX_NS + r] / sc;
+                        v0 += q0 * q0; v1 += q1 * q1;
+                    } else {
+                        const float q = (sK[(NLBAC_MLP_TILE + m) * RK_MAX_NS + r] - sK[m * RK_MAX_NS + r]) / sc;
+                        v0 += q * q;
+                    }
+                }
+            }
+            if (L.norm_mode == 0)
+                for (int c = 0; c < nu; ++c) {
+                    const float y = sU[m * RK_MAX_NU + c];
+                    const float q = y / (L.atol + fabsf(y) * L.rtol);
+                    v0 += q * q;
+                }
+        }
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) { v0 += __shfl_down(v0, off, 64); v1 += __shfl_down(v1, off, 64); }
+        if (tid == 0) {
+            const int nblk = (L.rpp + NLBAC_MLP_TILE - 1) / NLBAC_MLP_TILE;
+            const int blk = (row0 - p_tile * L.rpp) / NLBAC_MLP_TILE;
+            float* q = L.partials + ((long)p_tile * nblk + blk) * 2;
+            q[0] = v0; q[1] = v1;
+            __threadfence();
+            const unsigned ticket = __hip_atomic_fetch_add(L.tickets + p_tile, 1u, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT);
+            s_last = (ticket == (unsigned)nblk - 1u) ? 1u : 0u;
+            if (s_last) __hip_atomic_store(L.tickets + p_tile, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+    }
+    __syncthreads();
+    if (!s_last || tid >= 64) return;
+    __threadfence();
+    {
+        const int nblk = (L.rpp + NLBAC_MLP_TILE - 1) / NLBAC_MLP_TILE;
+        double d0 = 0.0, d1 = 0.0;
+        for (int b = tid; b < nblk; b += 64) {
+            const float* q = L.partials + ((long)p_tile * nblk + b) * 2;
+            d0 += (double)__hip_atomic_load(q + 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            d1 += (double)__hip_atomic_load(q + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) { d0 += __shfl_down(d0, off, 64); d1 += __shfl_down(d1, off, 64); }
+        if (tid == 0) {
+            const double cnt = (double)L.rpp * (double)(ns + nu);
+            double* c = L.ctl_w + (long)p_tile * NLBAC_DOPRI_CTL;
+            const int slot_before = (int)c[C_NACC];
+            const double h_try = c[C_H];
+            dopri_control_vals(sqrt(d0 / cnt), sqrt(d1 / cnt), p_tile, L.norm_mode, L.t_end, L.ctl_w, L.n_slots);
+            if (L.norm_mode == 2 && L.hslots && c[C_ACCEPT] > 0.0)
+                L.hslots[(long)p_tile * L.n_slots + slot_before] = h_try;      // step size of the accepted step in its slot
+            if (L.norm_mode == 2 && L.alog) {
+                const int k = (int)c[C_NSTEPS] - 1;
+                if (k >= 0 && k < L.alog_cap) {
+                    double* a = L.alog + ((long)p_tile * L.alog_cap + k) * 3;
+                    a[0] = h_try; a[1] = c[C_RATIO]; a[2] = c[C_ACCEPT];
+                }
+            }
         }
     }
 }
@@ -229,6 +347,11 @@ struct NodeRkBwdLaunch {
     float beta[RK_MAX_STAGES][RK_MAX_STAGES];
     const double* h_dev; int h_stride; float h_val[8];
     int ld, sw_off1;
+    // device-driven chain: launch `back_idx` differentiates step slot C_NACC - back_idx of each problem (problems with
+    // fewer accepted steps are skipped); back_idx 0 is every problem's LAST step (dK / dy0 / dYup come from the
+    // interpolant's backward), the others start from the slot behind them: dK[6] = its dK[0] (FSAL), dYup = its dy0.
+    // Step sizes come from hslots[p][slot].
+    const double* ctl; long slot_floats; int back_idx, n_slots; const double* hslots;
 };
 
 template <int MODE, int BITS>
@@ -242,6 +365,21 @@ __global__ __launch_bounds__(512) void node_rk_bwd_kernel(const NodeRkBwdLaunch 
     GroupBar gbar{&s_gcnt[grp], 0u, 4u};
     const int n = L.n, ns = L.n_s, nu = L.n_u, LD = L.ld, gout = ns * nu;
     const int row0 = blockIdx.x * NLBAC_MLP_TILE;
+    long soff = 0;
+    int slot = 0;
+    const bool chained = L.ctl != nullptr;
+    if (chained) {
+        const int p_tile = row0 / L.rpp;
+        slot = (int)L.ctl[(long)p_tile * NLBAC_DOPRI_CTL + C_NACC] - L.back_idx;
+        if (slot < 0) return;                       // (uniform) this problem took fewer steps
+        soff = (long)slot * L.slot_floats;
+    }
+    const bool carry = chained && L.back_idx > 0;    // not the problem's last step: gradients arrive from the slot behind
+    const float* const gG = L.G + soff;
+    float* const gdG = L.dG ? L.dG + soff : nullptr;
+    float* const gdK = L.dK + soff;
+    float* const gdy0 = L.dy0 ? L.dy0 + soff : nullptr;
+    const float* const gdYup = carry ? gdy0 + L.slot_floats : (L.dYup ? L.dYup + soff : nullptr);
     const nlbac_mlp& net = L.net[grp];
     const int hid = net.hid, NT = pad32(hid) >> 5, hidp32 = NT * 32;
     const int nwide = net.n_layers - 1;
@@ -261,7 +399,7 @@ __global__ __launch_bounds__(512) void node_rk_bwd_kernel(const NodeRkBwdLaunch 
     float* sW = sdy_all + 2 * NLBAC_MLP_TILE * 16 + (grp ? L.sw_off1 : 0);   // W_last [out][hid], then W_0^T [in][hid]
     float* sW0t = sW + net.out_dim * hid;
 
-    const int st_lo = L.st_lo;
+    const int st_lo = chained ? (slot == 0 ? 0 : 1) : L.st_lo;    // (a later step's stage 0 is its predecessor's last stage)
     const bool stage0_data = L.dx_stage0 || keep_dz;
 #define has_data(st_) ((st_) >= st_lo && ((st_) > 0 || stage0_data))
 
@@ -289,16 +427,22 @@ __global__ __launch_bounds__(512) void node_rk_bwd_kernel(const NodeRkBwdLaunch 
     }
     for (int idx = tid; idx < NLBAC_MLP_TILE * RK_MAX_NS; idx += 512) {
         const int m = idx >> 3, c = idx & 7, row = row0 + m;
-        sDY0[idx] = (row < n && c < ns && L.dy0 && L.dy0_in) ? L.dy0[(long)row * ns + c] : 0.f;
+        sDY0[idx] = (row < n && c < ns && gdy0 && L.dy0_in && !carry) ? gdy0[(long)row * ns + c] : 0.f;
     }
     if (tid < NLBAC_MLP_TILE) {
         const int p = min(row0 + tid, n - 1) / L.rpp;
-        sH[tid] = L.h_dev ? (float)L.h_dev[(long)p * L.h_stride] : L.h_val[p];
+        sH[tid] = chained ? (float)L.hslots[(long)p * L.n_slots + slot]
+                          : (L.h_dev ? (float)L.h_dev[(long)p * L.h_stride] : L.h_val[p]);
     }
     for (int idx = tid; idx < L.st_hi * NLBAC_MLP_TILE * RK_MAX_NS; idx += 512) {
         const int j = idx / (NLBAC_MLP_TILE * RK_MAX_NS), rem = idx - j * NLBAC_MLP_TILE * RK_MAX_NS;
         const int m = rem >> 3, c = rem & 7, row = row0 + m;
-        sDK[idx] = (row < n && c < ns) ? L.dK[((long)j * n + row) * ns + c] : 0.f;
+        float v = 0.f;
+        if (row < n && c < ns) {
+            if (!carry) v = gdK[((long)j * n + row) * ns + c];
+            else if (j == L.S_total - 1) v = (gdK + L.slot_floats)[(long)row * ns + c];     // FSAL: next slot's dK[0]
+        }
+        sDK[idx] = v;
     }
     __syncthreads();
 
@@ -307,11 +451,11 @@ __global__ __launch_bounds__(512) void node_rk_bwd_kernel(const NodeRkBwdLaunch 
 #else
 #define BSTAMP(slot_)
 #endif
-    for (int st = L.st_hi - 1; st >= L.st_lo; --st) {
+    for (int st = L.st_hi - 1; st >= st_lo; --st) {
         const bool data = has_data(st);
         BSTAMP(8 * st + 0)
         // ---- output-layer gradients of both nets, du
-        const float* acts_tile = L.acts[grp] + ((long)st * n + row0) * (BITS ? NT : hid);
+        const float* acts_tile = L.acts[grp] + soff + ((long)st * n + row0) * (BITS ? NT : hid);
         constexpr int TOP_RPT = (MODE == 1) ? 16 : 32;   // MODE 1: <= 128 padded columns -> two row groups of 16 rows
         float av_top[TOP_RPT];
         if (data) node_top_masks<TOP_RPT, BITS>(acts_tile + (long)(nwide - 1) * L.acts_ls[grp], hid, NT, t, n_rows, av_top);
@@ -323,7 +467,7 @@ __global__ __launch_bounds__(512) void node_rk_bwd_kernel(const NodeRkBwdLaunch 
                 if (o < ns) v = sDK[(st * NLBAC_MLP_TILE + m) * RK_MAX_NS + o];
             } else if (o < gout) {
                 v = sDK[(st * NLBAC_MLP_TILE + m) * RK_MAX_NS + o / nu] * sU[m * RK_MAX_NU + o % nu];
-                if (L.dG && row < n) L.dG[((long)st * n + row) * gout + o] = v;
+                if (gdG && row < n) gdG[((long)st * n + row) * gout + o] = v;
             }
             sdy[rem] = v;
         }
@@ -332,7 +476,7 @@ __global__ __launch_bounds__(512) void node_rk_bwd_kernel(const NodeRkBwdLaunch 
                 const int m = idx / nu, c = idx - m * nu, row = min(row0 + m, n - 1);
                 float a = 0.f;
                 for (int r = 0; r < ns; ++r)
-                    a += L.G[((long)st * n + row) * gout + r * nu + c] * sDK[(st * NLBAC_MLP_TILE + m) * RK_MAX_NS + r];
+                    a += gG[((long)st * n + row) * gout + r * nu + c] * sDK[(st * NLBAC_MLP_TILE + m) * RK_MAX_NS + r];
                 sDU[m * RK_MAX_NU + c] = sDU[m * RK_MAX_NU + c] + 1.0f * a;
             }
         if (!data) continue;              // uniform: nothing below is needed for this stage
@@ -347,12 +491,12 @@ __global__ __launch_bounds__(512) void node_rk_bwd_kernel(const NodeRkBwdLaunch 
         tile_sync(&gbar, lane);
         BSTAMP(8 * st + 2)
         if constexpr (BITS == 0) {
-            if (keep_dz) tile_to_global(in, LD, L.dz[grp] + (long)(nwide - 1) * L.acts_ls[grp] + ((long)st * n + row0) * hid,
+            if (keep_dz) tile_to_global(in, LD, L.dz[grp] + soff + (long)(nwide - 1) * L.acts_ls[grp] + ((long)st * n + row0) * hid,
                                         hid, n_rows, t, 256);
         }
 
         {
-            float* dz_tile = keep_dz ? L.dz[grp] + ((long)st * n + row0) * hid : nullptr;
+            float* dz_tile = keep_dz ? L.dz[grp] + soff + ((long)st * n + row0) * hid : nullptr;
             const bool wrap = has_data(st - 1);
             if constexpr (MODE == 2)
                 bwd_wide_layers<2, BITS>(wg2, net, active, wave, lane, LD, in, out, acts_tile, dz_tile, L.acts_ls[grp], n_rows, n_rows - 1, nwide - 1, wrap, 256, &gbar);
@@ -375,7 +519,7 @@ __global__ __launch_bounds__(512) void node_rk_bwd_kernel(const NodeRkBwdLaunch 
         BSTAMP(8 * st + 4)
         for (int idx = tid; idx < NLBAC_MLP_TILE * ns; idx += 512) {
             const int m = idx / ns, c = idx - m * ns, row = row0 + m;
-            float d = (L.dYup && st == L.S_total - 1 && row < n) ? L.dYup[(long)row * ns + c] : 0.f;
+            float d = (gdYup && st == L.S_total - 1 && row < n) ? gdYup[(long)row * ns + c] : 0.f;
             d += sDX[m * RK_MAX_NS + c];
             d += sDX[(NLBAC_MLP_TILE + m) * RK_MAX_NS + c];
             sDY0[m * RK_MAX_NS + c] = sDY0[m * RK_MAX_NS + c] + d;
@@ -391,12 +535,12 @@ __global__ __launch_bounds__(512) void node_rk_bwd_kernel(const NodeRkBwdLaunch 
     for (int idx = tid; idx < L.st_hi * NLBAC_MLP_TILE * ns; idx += 512) {
         const int j = idx / (NLBAC_MLP_TILE * ns), rem = idx - j * NLBAC_MLP_TILE * ns;
         const int m = rem / ns, c = rem - m * ns, row = row0 + m;
-        if (row < n) L.dK[((long)j * n + row) * ns + c] = sDK[(j * NLBAC_MLP_TILE + m) * RK_MAX_NS + c];
+        if (row < n) gdK[((long)j * n + row) * ns + c] = sDK[(j * NLBAC_MLP_TILE + m) * RK_MAX_NS + c];
     }
-    if (L.dy0)
+    if (gdy0)
         for (int idx = tid; idx < NLBAC_MLP_TILE * ns; idx += 512) {
             const int m = idx / ns, c = idx - m * ns, row = row0 + m;
-            if (row < n) L.dy0[(long)row * ns + c] = sDY0[m * RK_MAX_NS + c];
+            if (row < n) gdy0[(long)row * ns + c] = sDY0[m * RK_MAX_NS + c];
         }
     if (L.du)
         for (int idx = tid; idx < NLBAC_MLP_TILE * nu; idx += 512) {
@@ -411,7 +555,8 @@ extern "C" int nlbac_node_rk_bwd(const nlbac_mlp* f, const nlbac_mlp* g, const f
                                  const float* beta, const float* h_host, const double* h_dev, int h_dev_stride,
                                  const float* acts_f, long acts_f_ls, const float* acts_g, long acts_g_ls,
                                  int acts_bits, float* dz_f, float* dz_g, float* dG, float* dK, const float* dYup,
-                                 float* dy0, int dy0_in, float* du, int du_acc, nlbac_stream_t s) {
+                                 float* dy0, int dy0_in, float* du, int du_acc, const nlbac_rk_chain* chain,
+                                 int back_idx, nlbac_stream_t s) {
     NLBAC_REQUIRE(f && g && u && G && acts_f && acts_g && dK, "nlbac_node_rk_bwd: null pointer");
     NLBAC_REQUIRE(!(acts_bits && dz_f), "nlbac_node_rk_bwd: weight gradients need the activations, not bit masks");
     NLBAC_REQUIRE(P >= 1 && P <= 8 && rows_per_problem >= 1, "nlbac_node_rk_bwd: bad problem sizes");
@@ -425,9 +570,17 @@ extern "C" int nlbac_node_rk_bwd(const nlbac_mlp* f, const nlbac_mlp* g, const f
     NLBAC_REQUIRE((dz_f == nullptr) == (dz_g == nullptr) && (dz_f == nullptr) == (dG == nullptr),
                   "nlbac_node_rk_bwd: dz_f, dz_g and dG go together");
 #endif
-    NLBAC_REQUIRE(h_dev || h_host, "nlbac_node_rk_bwd: no step size");
+    NLBAC_REQUIRE(h_dev || h_host || (chain && chain->hslots), "nlbac_node_rk_bwd: no step size");
     NodeRkBwdLaunch L;
     memset(&L, 0, sizeof(L));
+    if (chain && chain->ctl) {
+        NLBAC_REQUIRE(P == 1 || rows_per_problem % NLBAC_MLP_TILE == 0,
+                      "nlbac_node_rk_bwd: a chained launch needs rows_per_problem %% 32 == 0 (tiles must not straddle problems)");
+        NLBAC_REQUIRE(chain->hslots && chain->n_slots >= 1 && chain->slot_floats > 0 && back_idx >= 0 && dy0,
+                      "nlbac_node_rk_bwd: incomplete chain description");
+        L.ctl = chain->ctl; L.slot_floats = chain->slot_floats; L.back_idx = back_idx; L.n_slots = chain->n_slots;
+        L.hslots = chain->hslots;
+    }
     L.net[0] = *f; L.net[1] = *g;
     L.u = u; L.G = G;
     L.acts[0] = acts_f; L.acts[1] = acts_g; L.acts_ls[0] = acts_f_ls; L.acts_ls[1] = acts_g_ls;
@@ -475,7 +628,7 @@ extern "C" int nlbac_node_rk_fwd(const nlbac_mlp* f, const nlbac_mlp* g, const f
                                  const float* c_out, int n_out, const float* c_err, int n_err,
                                  const float* h_host, const double* h_dev, int h_dev_stride, float* K, float* Y,
                                  float* G, float* acts_f, long acts_f_ls, float* acts_g, long acts_g_ls,
-                                 int acts_bits, float* out, float* err, nlbac_stream_t s) {
+                                 int acts_bits, float* out, float* err, const nlbac_rk_chain* chain, nlbac_stream_t s) {
     NLBAC_REQUIRE(f && g && y0 && u && K && Y && G, "nlbac_node_rk_fwd: null pointer");
     NLBAC_REQUIRE(P >= 1 && P <= 8 && rows_per_problem >= 1, "nlbac_node_rk_fwd: bad problem sizes");
     NLBAC_REQUIRE(n_stages_total >= 1 && n_stages_total <= RK_MAX_STAGES && stage_begin >= 0 &&
@@ -505,6 +658,20 @@ extern "C" int nlbac_node_rk_fwd(const nlbac_mlp* f, const nlbac_mlp* g, const f
     L.acts[0] = acts_f; L.acts[1] = acts_g; L.acts_ls[0] = acts_f_ls; L.acts_ls[1] = acts_g_ls;
     L.acts_bits = acts_bits;
     L.out = out; L.err = err;
+    L.norm_mode = -1;
+    if (chain) {
+        NLBAC_REQUIRE(P == 1 || rows_per_problem % NLBAC_MLP_TILE == 0,
+                      "nlbac_node_rk_fwd: a chained launch needs rows_per_problem %% 32 == 0 (tiles must not straddle problems)");
+        NLBAC_REQUIRE(chain->norm_mode < 0 || (chain->norm_mode <= 2 && chain->partials && chain->tickets && chain->ctl_w),
+                      "nlbac_node_rk_fwd: fused step control needs partials, tickets and the control block");
+        NLBAC_REQUIRE(chain->norm_mode != 2 || (err && n_err > 0), "nlbac_node_rk_fwd: norm mode 2 needs the error coefficients");
+        NLBAC_REQUIRE(!chain->ctl || chain->slot_floats >= 0, "nlbac_node_rk_fwd: bad slot stride");
+        L.ctl = chain->ctl; L.slot_floats = chain->slot_floats;
+        L.norm_mode = chain->norm_mode; L.n_slots = chain->n_slots > 0 ? chain->n_slots : (1 << 30);
+        L.rtol = chain->rtol; L.atol = chain->atol; L.t_end = chain->t_end;
+        L.partials = chain->partials; L.tickets = chain->tickets; L.ctl_w = chain->ctl_w; L.hslots = chain->hslots;
+        L.alog = chain->alog; L.alog_cap = chain->alog_cap;
+    }
     // LDS tiles hold pad8(hid) columns (the next layer's K extent), row stride = 4 mod 8 dwords: two workgroups fit per CU
     int w = ((f->hid > g->hid ? f->hid : g->hid) + 7) & ~7;
     L.ld = w + 4;

@@ -95,9 +95,16 @@ __global__ __launch_bounds__(256) void rk_stage_bwd_kernel(const float* dYup, co
 //  mode 2: col0 = sum (a/tol)^2, tol = atol + rtol*max(|y0|,|y1|)                      a = err
 __device__ __forceinline__ void dopri_norm_block(const float* a, const float* b, const float* y0, const float* y1,
                                                  const float* u, int mode, float rtol, float atol, int n_s, int n_u,
-                                                 int rpp, float* partials) {
+                                                 int rpp, float* partials, const double* slot_ctl = nullptr,
+                                                 long slot_floats = 0) {
     __shared__ float red[8];
     const int p = blockIdx.y;
+    if (slot_ctl) {      // device-driven chain (mode 2): the attempt's buffers are those of step slot C_NACC
+        const int slot = (int)slot_ctl[(long)p * NLBAC_DOPRI_CTL + C_NACC];
+        a += (long)slot * slot_floats;
+        y1 += (long)slot * slot_floats;
+        if (slot > 0) y0 = y1 - slot_floats;          // the step starts from its predecessor's y1
+    }
     const int i = blockIdx.x * 256 + threadIdx.x;
     float v[2] = {0.f, 0.f};
     if (i < rpp) {
@@ -135,8 +142,10 @@ __device__ __forceinline__ void dopri_norm_block(const float* a, const float* b,
 
 __global__ __launch_bounds__(256) void dopri_norm_kernel(const float* a, const float* b, const float* y0,
                                                          const float* y1, const float* u, int mode, float rtol,
-                                                         float atol, int n_s, int n_u, int rpp, float* partials) {
-    dopri_norm_block(a, b, y0, y1, u, mode, rtol, atol, n_s, n_u, rpp, partials);
+                                                         float atol, int n_s, int n_u, int rpp, float* partials,
+                                                         const double* slot_ctl, long slot_floats) {
+    if (slot_ctl && mode == 2 && slot_ctl[(long)blockIdx.y * NLBAC_DOPRI_CTL + C_DONE] > 0.0) return;
+    dopri_norm_block(a, b, y0, y1, u, mode, rtol, atol, n_s, n_u, rpp, partials, slot_ctl, slot_floats);
 }
 
 // the controller of problem p on its finished squared-norm sums (plain RMS norm over the problem's rows)
@@ -147,15 +156,29 @@ __device__ __forceinline__ void dopri_control_one(double s0, double s1, int p, i
 }
 
 __global__ void dopri_control_kernel(const float* partials, int nblk, int mode, int n_s, int n_u, int rpp,
-                                     double t_end, double* ctl) {
+                                     double t_end, double* ctl, int n_slots, double* hslots, double* alog,
+                                     int alog_cap) {
     if (threadIdx.x != 0) return;
     const int p = blockIdx.x;
+    double* c = ctl + (long)p * NLBAC_DOPRI_CTL;
+    if (n_slots > 0 && mode == 2 && c[C_DONE] > 0.0) return;       // chained: a finished solve stays as it is
     double s0 = 0.0, s1 = 0.0;
     for (int b = 0; b < nblk; ++b) {
         s0 += (double)partials[((long)p * nblk + b) * 2 + 0];
         s1 += (double)partials[((long)p * nblk + b) * 2 + 1];
     }
-    dopri_control_one(s0, s1, p, mode, n_s, n_u, rpp, t_end, ctl);
+    const int slot_before = (int)c[C_NACC];
+    const double h_try = c[C_H];
+    const double cnt = (double)rpp * (double)(n_s + n_u);
+    dopri_control_vals(sqrt(s0 / cnt), sqrt(s1 / cnt), p, mode, t_end, ctl, n_slots > 0 ? n_slots : (1 << 30));
+    if (hslots && mode == 2 && c[C_ACCEPT] > 0.0) hslots[(long)p * n_slots + slot_before] = h_try;
+    if (alog && mode == 2) {
+        const int k = (int)c[C_NSTEPS] - 1;
+        if (k >= 0 && k < alog_cap) {
+            double* a = alog + ((long)p * alog_cap + k) * 3;
+            a[0] = h_try; a[1] = c[C_RATIO]; a[2] = c[C_ACCEPT];
+        }
+    }
 }
 
 // norm + controller in one launch: the workgroup that finishes a problem's sums last (a ticket counter per problem,
@@ -205,7 +228,12 @@ __global__ __launch_bounds__(256) void dopri_norm_control_kernel(const float* a,
 #define DPM5 (-1776094331.0 / 19743644256.0 / 2.0)
 #define DPM6 (11237099.0 / 235043384.0 / 2.0)
 
-struct InterpArg { float h[MAX_PROBLEMS]; float x[MAX_PROBLEMS]; const double* ctl; };
+struct InterpArg { float h[MAX_PROBLEMS]; float x[MAX_PROBLEMS]; const double* ctl; long slot_floats; };
+
+// device-driven chain: the last accepted step of problem p lives in step slot C_NACC (0 without slots)
+__device__ __forceinline__ int interp_slot(const InterpArg& ia, int p) {
+    return (ia.ctl && ia.slot_floats) ? (int)ia.ctl[(long)p * NLBAC_DOPRI_CTL + C_NACC] : 0;
+}
 
 // step size / interpolation abscissa of problem p: from the device control block when given
 // (so a captured hipGraph replays with the current values), else by value
@@ -226,6 +254,12 @@ __global__ __launch_bounds__(256) void dopri_interp_fwd_kernel(const float* y0, 
     if (i >= n) return;
     float h, x;
     interp_hx(ia, i / rpp, h, x);
+    {
+        const int slot = interp_slot(ia, i / rpp);
+        y1 += (long)slot * ia.slot_floats;
+        K += (long)slot * ia.slot_floats;
+        if (slot > 0) y0 = y1 - ia.slot_floats;       // (y1 points at the slot's last stage input: the predecessor's is its y0)
+    }
     const float cm[7] = {(float)DPM0, 0.f, (float)DPM2, (float)DPM3, (float)DPM4, (float)DPM5, (float)DPM6};
     for (int r = 0; r < n_s; ++r) {
         const float a0 = y0[(long)i * n_s + r], a1 = y1[(long)i * n_s + r];
@@ -249,6 +283,10 @@ __global__ __launch_bounds__(256) void dopri_interp_bwd_kernel(const float* dout
     if (i >= n) return;
     float h, x;
     interp_hx(ia, i / rpp, h, x);
+    {
+        const long off = (long)interp_slot(ia, i / rpp) * ia.slot_floats;
+        dy0 += off; dy1 += off; dK += off;
+    }
     const float cm[7] = {(float)DPM0, 0.f, (float)DPM2, (float)DPM3, (float)DPM4, (float)DPM5, (float)DPM6};
     const float x2 = x * x, x3 = x2 * x, x4 = x2 * x2;
     for (int r = 0; r < n_s; ++r) {
@@ -326,11 +364,14 @@ extern "C" int nlbac_rk_stage_bwd(const float* dYup, const float* dXf, const flo
 
 extern "C" int nlbac_dopri_norm_partials(const float* a, const float* b, const float* y0, const float* y1,
                                          const float* u, int mode, float rtol, float atol, int n_s, int n_u,
-                                         int rows_per_problem, int P, float* partials, nlbac_stream_t s) {
+                                         int rows_per_problem, int P, float* partials, const double* slot_ctl,
+                                         long slot_floats, nlbac_stream_t s) {
     NLBAC_REQUIRE(a && y0 && partials && mode >= 0 && mode <= 2, "nlbac_dopri_norm_partials: bad arguments");
     NLBAC_REQUIRE((mode != 0 || u) && (mode != 1 || b) && (mode != 2 || y1), "nlbac_dopri_norm_partials: missing operand");
+    NLBAC_REQUIRE(!slot_ctl || mode == 2, "nlbac_dopri_norm_partials: step slots apply to the error norm (mode 2)");
     hipLaunchKernelGGL(dopri_norm_kernel, dim3(nlbac_ceil_div(rows_per_problem, 256), P), dim3(256), 0,
-                       (hipStream_t)s, a, b, y0, y1, u, mode, rtol, atol, n_s, n_u, rows_per_problem, partials);
+                       (hipStream_t)s, a, b, y0, y1, u, mode, rtol, atol, n_s, n_u, rows_per_problem, partials,
+                       slot_ctl, slot_floats);
     NLBAC_CHECK_LAUNCH("nlbac_dopri_norm_partials");
     return 0;
 }
@@ -351,19 +392,23 @@ extern "C" int nlbac_dopri_norm_control(const float* a, const float* b, const fl
 }
 
 extern "C" int nlbac_dopri_control(const float* partials, int n_blk_per_problem, int mode, int n_s, int n_u,
-                                   int rows_per_problem, int P, double t_end, double* ctl, nlbac_stream_t s) {
+                                   int rows_per_problem, int P, double t_end, double* ctl, int n_slots, double* hslots,
+                                   double* alog, int alog_cap, nlbac_stream_t s) {
     NLBAC_REQUIRE(partials && ctl && mode >= 0 && mode <= 2, "nlbac_dopri_control: bad arguments");
+    NLBAC_REQUIRE(!hslots || n_slots >= 1, "nlbac_dopri_control: hslots needs n_slots");
     hipLaunchKernelGGL(dopri_control_kernel, dim3(P), dim3(64), 0, (hipStream_t)s, partials, n_blk_per_problem, mode,
-                       n_s, n_u, rows_per_problem, t_end, ctl);
+                       n_s, n_u, rows_per_problem, t_end, ctl, n_slots, hslots, alog, alog_cap);
     NLBAC_CHECK_LAUNCH("nlbac_dopri_control");
     return 0;
 }
 
 static int fill_ia(InterpArg& ia, const float* h_host, const float* x_host, const double* ctl, int P,
-                   const char* who) {
+                   const char* who, long slot_floats = 0) {
     NLBAC_REQUIRE(((h_host && x_host) || ctl) && P >= 1 && P <= MAX_PROBLEMS, "%s: bad arguments", who);
+    NLBAC_REQUIRE(slot_floats == 0 || ctl, "%s: step slots need the control block", who);
     memset(&ia, 0, sizeof(ia));
     ia.ctl = ctl;
+    ia.slot_floats = slot_floats;
     if (!ctl)
         for (int p = 0; p < P; ++p) { ia.h[p] = h_host[p]; ia.x[p] = x_host[p]; }
     return 0;
@@ -371,10 +416,10 @@ static int fill_ia(InterpArg& ia, const float* h_host, const float* x_host, cons
 
 extern "C" int nlbac_dopri_interp_fwd(const float* y0, const float* y1, const float* K, const float* h_host,
                                       const float* x_host, const double* ctl, int P, int rows_per_problem, int n_s,
-                                      float* out, nlbac_stream_t s) {
+                                      float* out, long slot_floats, nlbac_stream_t s) {
     InterpArg ia;
     NLBAC_REQUIRE(y0 && y1 && K && out, "nlbac_dopri_interp_fwd: null pointer");
-    if (fill_ia(ia, h_host, x_host, ctl, P, "nlbac_dopri_interp_fwd")) return -1;
+    if (fill_ia(ia, h_host, x_host, ctl, P, "nlbac_dopri_interp_fwd", slot_floats)) return -1;
     const int n = P * rows_per_problem;
     hipLaunchKernelGGL(dopri_interp_fwd_kernel, GRID1(n), y0, y1, K, ia, rows_per_problem, n_s, n, out);
     NLBAC_CHECK_LAUNCH("nlbac_dopri_interp_fwd");
@@ -383,10 +428,10 @@ extern "C" int nlbac_dopri_interp_fwd(const float* y0, const float* y1, const fl
 
 extern "C" int nlbac_dopri_interp_bwd(const float* dout, const float* h_host, const float* x_host,
                                       const double* ctl, int P, int rows_per_problem, int n_s, float* dy0,
-                                      float* dy1, float* dK, nlbac_stream_t s) {
+                                      float* dy1, float* dK, long slot_floats, nlbac_stream_t s) {
     InterpArg ia;
     NLBAC_REQUIRE(dout && dy0 && dy1 && dK, "nlbac_dopri_interp_bwd: null pointer");
-    if (fill_ia(ia, h_host, x_host, ctl, P, "nlbac_dopri_interp_bwd")) return -1;
+    if (fill_ia(ia, h_host, x_host, ctl, P, "nlbac_dopri_interp_bwd", slot_floats)) return -1;
     const int n = P * rows_per_problem;
     hipLaunchKernelGGL(dopri_interp_bwd_kernel, GRID1(n), dout, ia, rows_per_problem, n_s, n, dy0, dy1, dK);
     NLBAC_CHECK_LAUNCH("nlbac_dopri_interp_bwd");

@@ -44,34 +44,56 @@ TABLEAU = {
 }
 
 
-class _Store:
-    """Backing storage of one step workspace, sized for ``cap >= n`` rows.  The buffers of a workspace are laid out for
-    an exact row count n (stage-major, the kernels index them with n), so a workspace for another n of the same
-    capacity bucket is a fresh set of VIEWS over the same allocations: the k-th buffer a workspace asks for is the
-    k-th allocation of the store.  A NODE fit whose batch grows by a few rows every time (the replay filling up) then
-    costs no allocation and no fill."""
+class _Carver:
+    """Hands out the buffers of ONE step slot: consecutive 16-byte-aligned pieces of a flat float32 slice.  Every slot
+    of a pool is carved by the same sequence of requests, so a buffer sits at the same offset in every slot — which is
+    what lets the device-driven dopri5 chain address "the same buffer, k slots further" by pointer arithmetic
+    (``nlbac_rk_chain.slot_floats``).  ``flat is None``: dry run, only counts."""
 
-    def __init__(self, device, n, cap):
-        self.device, self.n, self.cap = device, n, cap
-        self.flat, self.k = [], 0
-
-    def rebind(self, n):
-        assert n <= self.cap
-        self.n, self.k = n, 0
-        return self
+    def __init__(self, flat, device):
+        self.flat, self.device, self.k = flat, device, 0
 
     def zeros(self, *shape, dtype=torch.float32):
         numel = 1
         for d in shape:
             numel *= d
-        need = -(-numel * self.cap // self.n)          # every buffer is linear in the row count
-        if self.k == len(self.flat):
-            self.flat.append(torch.zeros(need, dtype=dtype, device=self.device))
-        t = self.flat[self.k]
-        if t.numel() < need or t.dtype != dtype:        # (another solver mode asked for a different buffer here)
-            t = self.flat[self.k] = torch.zeros(need, dtype=dtype, device=self.device)
-        self.k += 1
-        return t[:numel].view(*shape)
+        take = (numel + 3) & ~3
+        off, self.k = self.k, self.k + take
+        if self.flat is None:
+            return torch.empty(0, dtype=dtype)
+        assert self.k <= self.flat.numel(), "step slot too small"
+        t = self.flat[off:off + numel]
+        if dtype != torch.float32:
+            t = t.view(dtype)
+        return t.view(*shape)
+
+
+class _SlotPool:
+    """Step slots of one capacity bucket: chunks of ``slots_per_chunk`` slots, each chunk ONE allocation
+    [slots][slot_floats].  The device-driven chain works inside chunk 0 (contiguous, ``n_slots`` = its size); the
+    host-driven path just asks for the next slot and may spill into further chunks."""
+
+    def __init__(self, solver, cap, S, n_slots):
+        self.solver, self.cap, self.S, self.n_slots = solver, cap, S, n_slots
+        dry = _Carver(None, solver.device)
+        solver.STEP_WS(solver, cap, S, dry).bwd(solver)
+        self.slot_floats = (dry.k + 63) & ~63
+        self.chunks = [torch.zeros(n_slots, self.slot_floats, dtype=torch.float32, device=solver.device)]
+        self.views = {}                  # (n, idx) -> step workspace
+
+    def ws(self, n, idx):
+        assert n <= self.cap
+        w = self.views.get((n, idx))
+        if w is None:
+            c, i = divmod(idx, self.n_slots)
+            while c >= len(self.chunks):
+                self.chunks.append(torch.zeros(self.n_slots, self.slot_floats, dtype=torch.float32,
+                                               device=self.solver.device))
+            for k in [k for k in self.views if k[0] != n]:      # views laid out for another row count go
+                del self.views[k]
+            w = self.views[(n, idx)] = self.solver.STEP_WS(self.solver, n, self.S, _Carver(self.chunks[c][i], self.solver.device))
+            w.slot, w.pool = idx, self
+        return w
 
 
 class _StepWS:
@@ -79,11 +101,11 @@ class _StepWS:
     # what a per-problem solver takes over from a joint first attempt: (buffer, leading blocks per row range)
     ADOPT = ("K", "Y", "gout", "err", "acts_f", "acts_g")
 
-    def __init__(self, solver, n, S, store=None):
+    def __init__(self, solver, n, S, store):
         dev, ns, nu = solver.device, solver.n_s, solver.n_u
         f, g = solver.f, solver.g
         self.n, self.S = n, S
-        self._store = store if store is not None else _Store(dev, n, n)
+        self._store = store
         z = self._store.zeros
         self.K = z(S, n, ns)
         self.Y = z(S, n, ns)
@@ -145,6 +167,8 @@ class AffineNodeSolver:
         self.stats = dict(solves=0, single_step=0, multi_attempt=0, split=0)
         self.comm = None       # nlbac_amd.parallel.DataParallel: global dopri5 error norms
         self.adjoint = False   # True: ``backward`` is the continuous adjoint (odeint_adjoint); the forward keeps nothing
+        self.generation = 0    # bumped whenever device buffers are freed or re-laid-out (owners of hipGraphs watch it)
+        self.device_loop = True   # dopri5 attempts as a device-driven chain (no host decision per attempt)
 
     @staticmethod
     def _fused_fits(f, g):
@@ -158,48 +182,58 @@ class AffineNodeSolver:
     MAX_SIZES = 2      # distinct row counts whose buffers are kept (the NODE fit's batch grows with the replay)
 
     def _touch(self, n):
-        """Start of a solve on n rows: make n the current size and drop the buffers of the least recently used sizes
-        beyond ``MAX_SIZES`` — workspaces are laid out for an exact row count, and a training run feeds the NODE fit
-        min(replay size, 32768) rows, a new count at every fit while the replay fills."""
+        """Start of a solve on n rows: make n the current size and drop the scratch of the least recently used sizes
+        beyond ``MAX_SIZES`` — a training run feeds the NODE fit min(replay size, 32768) rows, a new count at every fit
+        while the replay fills.  (Step slots live in per-capacity pools, see ``_pool``.)"""
         order = self.__dict__.setdefault("_n_order", [])
         if n in order:
             order.remove(n)
         order.append(n)
         while len(order) > self.MAX_SIZES:
             old = order.pop(0)
-            for k in [k for k in self._ws if k[0] == old]:
-                del self._ws[k]
             self._scratch.pop(old, None)
+            self.generation += 1
         self._cur_n = n
 
     @staticmethod
     def _bucket(n):
         return n if n <= 4096 else -(-n // 4096) * 4096
 
+    DEFAULT_SLOTS = 4      # step slots of a pool's first chunk = steps the device-driven chain can accept without a restart
+
+    def _pool(self, n, S, min_slots=1):
+        """The slot pool serving n rows / S stages (one per capacity bucket and solver mode; the two most recently
+        used buckets are kept).  ``generation`` counts every event that frees or re-lays-out device buffers — captured
+        hipGraphs bake their addresses in and are dropped by their owners when it moves."""
+        pools = self.__dict__.setdefault("_pools", {})
+        key = (self._bucket(n), S, self.fused, self.keep_acts)
+        pool = pools.get(key)
+        if pool is not None and pool.n_slots < min_slots:
+            del pools[key]
+            pool = None
+            self.generation += 1
+        if pool is None:
+            buckets = list(dict.fromkeys(k[0] for k in pools))              # in order of first use
+            if key[0] not in buckets and len(buckets) >= self.MAX_SIZES:
+                for k in [k for k in pools if k[0] == buckets[0]]:         # the oldest bucket goes, whole
+                    del pools[k]
+                self.generation += 1
+            n_slots = max(min_slots, self.DEFAULT_SLOTS if S == 7 else 1)
+            pool = pools[key] = _SlotPool(self, key[0], S, n_slots)
+        return pool
+
     def _step_ws(self, n, S, idx):
-        key = (n, S, idx)
-        ws = self._ws.get(key)
-        if ws is None:
-            # one live workspace per (capacity bucket, S, idx): the views of the previous row count go, storage stays
-            skey = (self._bucket(n), S, idx, self.fused, self.keep_acts)
-            stores = self.__dict__.setdefault("_stores", {})
-            st = stores.get(skey)
-            if st is None:
-                buckets = list(dict.fromkeys(k[0] for k in stores))          # in order of first use
-                if skey[0] not in buckets and len(buckets) >= self.MAX_SIZES:
-                    for k in [k for k in stores if k[0] == buckets[0]]:      # the oldest bucket goes, whole
-                        del stores[k]
-                st = stores[skey] = _Store(self.device, n, skey[0])
-            for k in [k for k, w in self._ws.items() if w._store is st]:
-                del self._ws[k]
-            ws = self._ws[key] = self.STEP_WS(self, n, S, st.rebind(n))
+        pool = self._pool(n, S)
+        had = (n, idx) in pool.views
+        ws = pool.ws(n, idx)
+        if not had and any(k[0] != n for k in pool.views):
+            self.generation += 1
         return ws
 
     def reserve(self, n, P, method, steps=2):
-        """Allocate the buffers of a solve on n rows / P problems ahead of time: the step workspaces of the first
-        ``steps`` accepted dopri5 steps (forward and backward halves) and, for P > 1, those of the per-problem fallback
-        solvers — so that the first multi-step or diverging solve of a run does not pay tens of milliseconds of
-        allocation in the middle of training."""
+        """Allocate the buffers of a solve on n rows / P problems ahead of time (the slot pool and, for a host-driven
+        multi-problem dopri5 solve, the per-problem fallback solvers), so that the first multi-step or diverging solve
+        of a run does not pay tens of milliseconds of allocation in the middle of training."""
         self._touch(n)
         if method != "dopri5":
             S = len(TABLEAU[method]["c_sol"])
@@ -208,7 +242,7 @@ class AffineNodeSolver:
         for idx in range(steps):
             self._step_ws(n, 7, idx).bwd(self)
         self._ctl_io(P)
-        if P > 1:
+        if P > 1 and not self._chain_ok(P, n // P):
             for p in range(P):
                 if p not in self._children:
                     self._children[p] = type(self)(self.node, self.device)
@@ -287,7 +321,7 @@ class AffineNodeSolver:
         return b
 
     def _rk_fused(self, ws, y0, u, P, rpp, method, st0, st1, h_host=None, h_dev=None, c_out=None, out=None,
-                  c_err=None, err=None, save_acts=True):
+                  c_err=None, err=None, save_acts=True, chain=None):
         """One launch for stages [st0, st1) of ``method`` on the step workspace ``ws`` (nlbac_node_rk_fwd)."""
         beta, S = self._beta(method)
         f, g = self.f, self.g
@@ -301,11 +335,11 @@ class AffineNodeSolver:
                   ws.acts_f.data_ptr() if save_acts else None, ws.S * n * ws.wf,
                   ws.acts_g.data_ptr() if save_acts else None, ws.S * n * ws.wg, 1 if ws.bits else 0,
                   out.data_ptr() if out is not None else None, err.data_ptr() if err is not None else None,
-                  stream_ptr())
+                  C.byref(chain) if chain is not None else None, stream_ptr())
         self.nfe += st1 - st0
 
     def _rk_fused_bwd(self, ws, u, P, rpp, method, first_eval, need_dy0, need_params, h_host, h_dev, h_stride, top_up,
-                      du, last):
+                      du, last, chain=None, back_idx=0):
         """One launch for the backward of every evaluated stage of the step in ``ws`` (nlbac_node_rk_bwd)."""
         beta_arr, _ = self._beta(method)
         f, g, S = self.f, self.g, ws.S
@@ -315,7 +349,8 @@ class AffineNodeSolver:
                   1 if ws.bits else 0, ws.dz_f.data_ptr() if need_params else None,
                   ws.dz_g.data_ptr() if need_params else None, ws.dG.data_ptr() if need_params else None,
                   ws.dK.data_ptr(), top_up.data_ptr() if top_up is not None else None, ws.dy0.data_ptr(), 1,
-                  du.data_ptr() if du is not None else None, 0 if last else 1, stream_ptr())
+                  du.data_ptr() if du is not None else None, 0 if last else 1,
+                  C.byref(chain) if chain is not None else None, back_idx, stream_ptr())
 
     def _combine(self, y0, K, n_k, coef, h, P, rpp, out):
         _lib.call("nlbac_rk_combine", y0.data_ptr() if y0 is not None else None, K.data_ptr(), n_k,
@@ -367,6 +402,8 @@ class AffineNodeSolver:
         variant enqueues only device work with device-resident step size, so it can be hipGraph-captured."""
         if self.ctx["method"] != "dopri5":
             return self.ctx["out"]
+        if self.ctx.get("chain"):
+            return self._dopri_finish_chain(assume_done=assume_single_step)
         if assume_single_step:
             return self._dopri_accept_first(None)
         return self._dopri_continue()
@@ -377,6 +414,12 @@ class AffineNodeSolver:
         P = self.ctx["P"]
         c = self._ctl_read(P)
         self.ctx["ctl_host"] = c
+        if self.ctx.get("chain"):       # device-driven chain: every problem finished within the attempts enqueued
+            ok = all(bool(c[p, 4] > 0) and not bool(c[p, 13] > 0) for p in range(P))
+            if not ok:                  # a captured chain that is too short: later captures enqueue more attempts
+                self._chain_len = int(max(float(c[p, 10]) for p in range(P))) + 1
+                self.generation += 1
+            return ok
         return all(bool(c[p, 3] > 0) and bool(c[p, 4] > 0) for p in range(P))
 
     def _ctl(self, P):
@@ -419,7 +462,7 @@ class AffineNodeSolver:
             return self._ctl_pin[P].clone()
         return self._ctl(P).cpu()
 
-    def _norm_control(self, a, b, y0, y1, u, mode, P, rpp):
+    def _norm_control(self, a, b, y0, y1, u, mode, P, rpp, slot_ctl=None, slot_floats=0, chain=None):
         """Scaled RMS norm(s) of mode 0/1/2 (include/nlbac_hip.h) over each problem's rows, then the step-size
         controller: one launch on a single GPU, norm -> all-reduce -> controller under data parallelism."""
         ctx = self.ctx
@@ -430,14 +473,14 @@ class AffineNodeSolver:
         dp = lambda t: t.data_ptr() if t is not None else None
         if self.comm is not None and self.comm.world > 1:
             _lib.call("nlbac_dopri_norm_partials", dp(a), dp(b), dp(y0), dp(y1), dp(u), mode, ctx["rtol"], ctx["atol"],
-                      ns, nu, rpp, P, part.data_ptr(), s)
-            self._control(part, nblk, mode, P, rpp, ctx["t_end"], ctl)
+                      ns, nu, rpp, P, part.data_ptr(), slot_ctl, slot_floats, s)
+            self._control(part, nblk, mode, P, rpp, ctx["t_end"], ctl, chain)
             return
         tickets = self._buf("tickets", P, dtype=torch.int32)
         _lib.call("nlbac_dopri_norm_control", dp(a), dp(b), dp(y0), dp(y1), dp(u), mode, ctx["rtol"], ctx["atol"],
                   ns, nu, rpp, P, ctx["t_end"], part.data_ptr(), tickets.data_ptr(), ctl.data_ptr(), s)
 
-    def _control(self, part, nblk, mode, P, rpp, t_end, ctl):
+    def _control(self, part, nblk, mode, P, rpp, t_end, ctl, chain=None):
         """Step-size controller; under data parallelism the squared-norm sums are all-reduced first so every
         rank takes the decision the single-device run over the global batch would take."""
         ns, nu, s = self.n_s, self.n_u, stream_ptr()
@@ -446,10 +489,12 @@ class AffineNodeSolver:
             for p in range(P):
                 _lib.call("nlbac_sum_partials", part[p].data_ptr(), nblk, 2, 1.0, sums[p].data_ptr(), s)
             self.comm.all_reduce_(sums)
+            tail = (chain.n_slots, chain.hslots, chain.alog, chain.alog_cap) if chain is not None else (0, None, None, 0)
             _lib.call("nlbac_dopri_control", sums.data_ptr(), 1, mode, ns, nu, rpp * self.comm.world, P, t_end,
-                      ctl.data_ptr(), s)
+                      ctl.data_ptr(), *tail, s)
         else:
-            _lib.call("nlbac_dopri_control", part.data_ptr(), nblk, mode, ns, nu, rpp, P, t_end, ctl.data_ptr(), s)
+            _lib.call("nlbac_dopri_control", part.data_ptr(), nblk, mode, ns, nu, rpp, P, t_end, ctl.data_ptr(), 0, None,
+                      None, 0, s)
 
     def _dopri_attempt(self, ws, cur_y0, u, P, rpp):
         """Stages 1..6 of one attempted step, error estimate, norm and controller (all on the device)."""
@@ -481,6 +526,8 @@ class AffineNodeSolver:
         return c
 
     def _dopri_begin(self, y0, u, P, rpp):
+        if self._chain_ok(P, rpp):
+            return self._dopri_begin_chain(y0, u, P, rpp)
         n, ns, nu, S = P * rpp, self.n_s, self.n_u, 7
         ctx = self.ctx
         s = stream_ptr()
@@ -510,6 +557,150 @@ class AffineNodeSolver:
         self._norm_control(ktmp, ws.K[0], y0, None, None, 1, P, rpp)
         self._dopri_attempt(ws, y0, u, P, rpp)
 
+    # -- dopri5 as a device-driven chain ------------------------------------------------------------------------
+    # An attempted step is ONE launch: nlbac_node_rk_fwd with an nlbac_rk_chain description evaluates stages 1-6 in
+    # the step slot the control block names, forms the error norm and runs the controller in its own epilogue.  The
+    # host enqueues a fixed number of attempts (kernels skip problems that have finished) and looks at the control
+    # block once per chain — not once per attempt; problems of one batch advance independently, so there is no
+    # per-problem fallback on this path.  The backward walks the slots the same way (``back_idx``).
+    ALOG_CAP = 64
+
+    def _chain_ok(self, P, rpp):
+        return bool(self.device_loop and self.fused and (P == 1 or rpp % _lib.MLP_TILE == 0))
+
+    def _chain(self, ws0, pool, P, rpp, norm_mode, read_ctl):
+        ctx = self.ctx
+        ctl = self._ctl(P)
+        nblk = (rpp + _lib.MLP_TILE - 1) // _lib.MLP_TILE
+        hs = self._buf("hslots%d" % pool.n_slots, P, pool.n_slots, dtype=torch.float64)
+        c = _lib.RkChain()
+        c.ctl = ctl.data_ptr() if read_ctl else None
+        c.slot_floats, c.n_slots = pool.slot_floats, pool.n_slots
+        c.rtol, c.atol, c.t_end = ctx["rtol"], ctx["atol"], ctx["t_end"]
+        c.ctl_w, c.hslots = ctl.data_ptr(), hs.data_ptr()
+        c.alog, c.alog_cap = self._buf("alog", P, self.ALOG_CAP, 3, dtype=torch.float64).data_ptr(), self.ALOG_CAP
+        if self.comm is not None and self.comm.world > 1:
+            c.norm_mode = -1                  # the norm is all-reduced between the launch and the controller
+        else:
+            c.norm_mode = norm_mode
+            c.partials = self._buf("cpart", P, nblk, 2).data_ptr()
+            c.tickets = self._buf("ctickets", P, dtype=torch.int32).data_ptr()
+        return c
+
+    def _chain_control(self, ws0, pool, chain, y0, u, mode, P, rpp):
+        """data parallel only: norm partial sums (slot-aware) -> all-reduce -> controller, as separate launches"""
+        if chain.norm_mode >= 0:
+            return
+        ctl = self._ctl(P)
+        if mode == 0:
+            self._norm_control(ws0.K[0], None, y0, None, u, 0, P, rpp)
+        elif mode == 1:
+            self._norm_control(ws0.K[1], ws0.K[0], y0, None, None, 1, P, rpp)
+        else:
+            self._norm_control(ws0.err, None, y0, ws0.Y[6], None, 2, P, rpp, slot_ctl=ctl.data_ptr(),
+                               slot_floats=pool.slot_floats, chain=chain)
+
+    def _dopri_begin_chain(self, y0, u, P, rpp, min_slots=1):
+        n, S = P * rpp, 7
+        ctx = self.ctx
+        pool = self._pool(n, S, min_slots)
+        ws0 = pool.ws(n, 0)
+        ctl = self._ctl(P)
+        cp = ctl.data_ptr()
+        ch = [self._chain(ws0, pool, P, rpp, m, read_ctl=(m == 2)) for m in (0, 1, 2)]
+        # f0 + Hairer's first guess, the probe f(y0 + h0 f0) + the initial step: one launch each (norms fused)
+        self._rk_fused(ws0, y0, u, P, rpp, "dopri5", 0, 1, h_dev=cp, chain=ch[0])
+        self._chain_control(ws0, pool, ch[0], y0, u, 0, P, rpp)
+        self._rk_fused(ws0, y0, u, P, rpp, "probe", 1, 2, h_dev=cp + 8 * 6, save_acts=False, chain=ch[1])
+        self._chain_control(ws0, pool, ch[1], y0, u, 1, P, rpp)
+        ctx["chain"] = dict(pool=pool, ws0=ws0, ch=ch[2], attempts=0, y0=y0)
+        self._chain_attempts(max(1, int(self.__dict__.get("_chain_len", 1))))
+
+    def _chain_attempts(self, k):
+        ctx = self.ctx
+        st = ctx["chain"]
+        P, rpp, u = ctx["P"], ctx["rpp"], ctx["u"]
+        ws0, pool, ch = st["ws0"], st["pool"], st["ch"]
+        cp = self._ctl(P).data_ptr()
+        for _ in range(k):
+            self._rk_fused(ws0, st["y0"], u, P, rpp, "dopri5", 1, 7, h_dev=cp, c_err=self._coef("err"), err=ws0.err,
+                           chain=ch)
+            self._chain_control(ws0, pool, ch, st["y0"], u, 2, P, rpp)
+        st["attempts"] += k
+        self._ctl_post(P)
+
+    def _dopri_finish_chain(self, assume_done=False):
+        ctx = self.ctx
+        st = ctx["chain"]
+        P, rpp, n, ns = ctx["P"], ctx["rpp"], ctx["n"], self.n_s
+        pool, ws0 = st["pool"], st["ws0"]
+        ctl = self._ctl(P)
+        c = None
+        while not assume_done:
+            c = ctx.pop("ctl_host", None)
+            if c is None:
+                c = self._ctl_read(P)               # the one host wait per CHAIN of attempts
+            if any(bool(c[p, 13] > 0) for p in range(P)):
+                # out of step slots: the solve was stopped; start it again in a pool with room for twice as many steps
+                self._dopri_begin_chain(ctx["y0"], ctx["u"], P, rpp, min_slots=2 * pool.n_slots)
+                st = ctx["chain"]
+                pool, ws0 = st["pool"], st["ws0"]
+                continue
+            if all(bool(c[p, 4] > 0) for p in range(P)):
+                break
+            if st["attempts"] >= 1000:
+                raise _lib.NlbacError("dopri5: max_num_steps exceeded")
+            self._chain_attempts(2)
+        out = self._buf("dopri_out", n, ns)
+        _lib.call("nlbac_dopri_interp_fwd", ctx["y0"].data_ptr(), ws0.Y[6].data_ptr(), ws0.K.data_ptr(), None, None,
+                  ctl.data_ptr(), P, rpp, ns, out.data_ptr(), pool.slot_floats, stream_ptr())
+        if c is not None:
+            nst = [int(c[p, 10]) for p in range(P)]
+            nacc = [int(c[p, 12]) for p in range(P)]
+            self._chain_len = max(1, max(nst))
+            key = "single_step" if max(nst) == 1 else "multi_attempt"
+            self.stats[key] += 1
+            alog = self._buf("alog", P, self.ALOG_CAP, 3, dtype=torch.float64).cpu() if max(nst) > 1 else None
+            info = []
+            for k in range(min(max(nst), self.ALOG_CAP)):
+                row = []
+                for p in range(P):
+                    if alog is None:
+                        row.append((float(c[p, 11]), float(c[p, 2]), True))
+                    elif k < nst[p]:
+                        row.append((float(alog[p, k, 0]), float(alog[p, k, 1]), bool(alog[p, k, 2] > 0)))
+                    else:
+                        row.append(None)
+                info.append(row)
+            ctx.update(nacc=nacc, info=info)
+            ctx["steps"] = [dict(ws=pool.ws(n, i), first=(i == 0)) for i in range(max(nacc) + 1)]
+        else:
+            ctx.update(nacc=None, steps=[dict(ws=ws0, first=True)])
+        ctx["out"] = out
+        return out
+
+    def _backward_chain(self, dout, need_du, need_params, need_dy0):
+        ctx = self.ctx
+        st = ctx["chain"]
+        P, rpp, n, u = ctx["P"], ctx["rpp"], ctx["n"], ctx["u"]
+        ns, nu, s = self.n_s, self.n_u, stream_ptr()
+        pool, ws0, ch = st["pool"], st["ws0"], st["ch"]
+        ctl = self._ctl(P)
+        # launches: one per accepted step of the slowest problem (unknown on the host inside a graph capture: then one
+        # per attempt that was enqueued — launches beyond a problem's first step return at once)
+        nb = (max(ctx["nacc"]) + 1) if ctx.get("nacc") is not None else st["attempts"]
+        for i in range(nb):
+            pool.ws(n, i).bwd(self)
+        du = self._buf("du", n, nu) if need_du else None
+        _lib.call("nlbac_dopri_interp_bwd", dout.data_ptr(), None, None, ctl.data_ptr(), P, rpp, ns, ws0.dy0.data_ptr(),
+                  ws0.dy1.data_ptr(), ws0.dK.data_ptr(), pool.slot_floats, s)
+        bch = _lib.RkChain()
+        bch.ctl, bch.slot_floats, bch.n_slots, bch.hslots, bch.norm_mode = ch.ctl_w, pool.slot_floats, pool.n_slots, ch.hslots, -1
+        for b in range(nb):
+            self._rk_fused_bwd(ws0, u, P, rpp, "dopri5", True, need_dy0, need_params, None, None, 0, ws0.dy1, du,
+                               b == 0, chain=bch, back_idx=b)
+        return du, (ws0.dy0 if need_dy0 else None)
+
     def _dopri_accept_first(self, c):
         """First step accepted and past dt: interpolate.  Step size and abscissa are read from the device
         control block by the kernels (identical arithmetic with or without a host copy of them)."""
@@ -520,7 +711,7 @@ class AffineNodeSolver:
         ctl = self._ctl(P)
         out = self._buf("dopri_out", n, ns)       # (y1 is the input of stage 6: read in place, no copy)
         _lib.call("nlbac_dopri_interp_fwd", ctx["y0"].data_ptr(), ws.Y[6].data_ptr(), ws.K.data_ptr(), None, None,
-                  ctl.data_ptr(), P, rpp, ns, out.data_ptr(), stream_ptr())
+                  ctl.data_ptr(), P, rpp, ns, out.data_ptr(), 0, stream_ptr())
         step = dict(ws=ws, first=True, dev=True)
         if c is not None:
             step["h"] = [float(c[p, 11]) for p in range(P)]
@@ -563,7 +754,7 @@ class AffineNodeSolver:
                     steps[-1]["x"] = x
                     out = self._buf("dopri_out", n, ns)
                     _lib.call("nlbac_dopri_interp_fwd", cur_y0.data_ptr(), ws.Y[6].data_ptr(), ws.K.data_ptr(),
-                              fptr(*steps[-1]["h"]), fptr(*x), None, P, rpp, ns, out.data_ptr(), s)
+                              fptr(*steps[-1]["h"]), fptr(*x), None, P, rpp, ns, out.data_ptr(), 0, s)
                     ctx.update(steps=steps, out=out, info=info)
                     return out
                 cur_y0 = ws.Y[6]                  # y1 of an accepted step = its stage-6 input (ws is not reused)
@@ -643,6 +834,8 @@ class AffineNodeSolver:
         ctx = self.ctx
         if self.adjoint:
             return self.backward_adjoint(dout, need_du, need_params, need_dy0)
+        if ctx.get("chain"):
+            return self._backward_chain(dout, need_du, need_params, need_dy0)
         if ctx.get("split"):
             assert not need_params, "parameter gradients are only taken on single-problem solves"
             rpp = ctx["rpp"]
@@ -682,7 +875,7 @@ class AffineNodeSolver:
                 if last:
                     _lib.call("nlbac_dopri_interp_bwd", dout.data_ptr(), h_host, None if dev else fptr(*step["x"]),
                               self._ctl(P).data_ptr() if dev else None, P, rpp, ns,
-                              ws.dy0.data_ptr(), ws.dy1.data_ptr(), ws.dK.data_ptr(), s)
+                              ws.dy0.data_ptr(), ws.dy1.data_ptr(), ws.dK.data_ptr(), 0, s)
                 else:
                     ws.dy0.zero_()
                     ws.dy1.copy_(dy_carry)
@@ -839,7 +1032,7 @@ class AffineNodeSolver:
     def _adj_params_finish(self, par, cp):
         NP = par["NP"]
         _lib.call("nlbac_dopri_interp_fwd", par["th0"].data_ptr(), par["th1"].data_ptr(), par["K"].data_ptr(), None,
-                  None, cp, 1, NP // 4, 4, par["out"].data_ptr(), stream_ptr())
+                  None, cp, 1, NP // 4, 4, par["out"].data_ptr(), 0, stream_ptr())
         par["grad"] = par["out"]
         self.ctx["adj_par"] = par
 
@@ -920,7 +1113,7 @@ class AffineNodeSolver:
         ctx["adjoint_info"] = [[(float(c[p, 11]), float(c[p, 2]), int(c[p, 10])) for p in range(P)]]
         # the interpolant of the last accepted step at t0 (steps are not clipped), all columns of z at once
         _lib.call("nlbac_dopri_interp_fwd", w["Z0"].data_ptr(), w["Z1"].data_ptr(), KZ.data_ptr(), None, None, cp, P,
-                  rpp, w["W"], w["OUT"].data_ptr(), s)
+                  rpp, w["W"], w["OUT"].data_ptr(), 0, s)
         if par:
             self._adj_params_finish(par, cp)
         return w["OUT"]
@@ -1011,11 +1204,11 @@ class AffineNodeSolver:
 class _ConcatStepWS:
     ADOPT = ("K", "Y", "err", "acts")
 
-    def __init__(self, solver, n, S, store=None):
+    def __init__(self, solver, n, S, store):
         dev, ns, nc = solver.device, solver.n_s, solver.n_u
         net = solver.net
         self.n, self.S = n, S
-        self._store = store if store is not None else _Store(dev, n, n)
+        self._store = store
         z = self._store.zeros
         self.K = z(S, n, ns)
         self.Y = z(S, n, ns)
@@ -1061,6 +1254,8 @@ class ConcatNodeSolver(AffineNodeSolver):
         self.stats = dict(solves=0, single_step=0, multi_attempt=0, split=0)
         self.comm = None
         self.adjoint = False
+        self.generation = 0
+        self.device_loop = False      # (the single-net kernels do not take the step-chain description yet)
         # input normalisation / output de-normalisation lives inside the fused step kernels only
         self.norm = node.norm_device() if getattr(node, "normalized", False) else None
         if self.norm is not None and not self.fused:

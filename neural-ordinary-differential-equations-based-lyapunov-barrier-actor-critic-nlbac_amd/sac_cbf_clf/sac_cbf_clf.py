@@ -473,7 +473,7 @@ class SAC_CBF_CLF(object):
         self._fill.clear()      # (pieces of an update that raised half-way must not run behind this fit's solves)
         if N not in self._fit_ws:
             while len(self._fit_ws) >= 2:       # the fit batch grows with the replay: keep the two latest sizes only
-                self._fit_ws.pop(next(iter(self._fit_ws)))
+                self._fit_ws.pop(next(iter(self._fit_ws)))      # (its graphs go with it)
             w = task.fit_ws(N)
             w.update(graphs={}, warm=0)
             self._fit_ws[N] = w
@@ -487,16 +487,12 @@ class SAC_CBF_CLF(object):
             self._fit_part2(w, N, task.fit_solver.forward_finish())
             return
         g = w["graphs"]
-        if ("p1",) + key not in g:
-            g[("p1",) + key] = self._capture(part1)
-        g[("p1",) + key].replay()
+        self._replay(self._graph(g, ("p1",) + key, part1))
         if self.solver == "dopri5" and not task.fit_solver.first_step_done():
             self._fit_part2(w, N, task.fit_solver.forward_finish())      # rare: finish this one eagerly
             return
-        if ("p2",) + key not in g:
-            g[("p2",) + key] = self._capture(
-                lambda: self._fit_part2(w, N, task.fit_solver.forward_finish(assume_single_step=True)))
-        g[("p2",) + key].replay()
+        self._replay(self._graph(g, ("p2",) + key,
+                                 lambda: self._fit_part2(w, N, task.fit_solver.forward_finish(assume_single_step=True))))
 
     def _fit_part2(self, w, N, pred):
         s = stream_ptr()
@@ -516,12 +512,33 @@ class SAC_CBF_CLF(object):
 
     def _capture(self, fn):
         """Record the launches of ``fn`` into a hipGraph (all kernel arguments are static device pointers /
-        constants; per-update scalars live in device memory)."""
+        constants; per-update scalars live in device memory).  The graph bakes in the addresses of the solvers'
+        buffers and belongs to the solves it recorded: the entry keeps the solvers' ``generation`` (any freed or
+        re-laid-out buffer invalidates it) and their solve contexts (restored before a replay, so that what the host
+        does around the replay — reading the control block, finishing a solve eagerly — talks about THIS graph's
+        solve and not about whichever batch size ran last)."""
         torch.cuda.synchronize()
         g = torch.cuda.CUDAGraph()
         with torch.cuda.graph(g):
             fn()
-        return g
+        svs = self.task.solvers
+        return types.SimpleNamespace(graph=g, gens=tuple(sv.generation for sv in svs),
+                                     ctxs=[(sv, sv.__dict__.get("ctx"), sv.__dict__.get("_cur_n")) for sv in svs])
+
+    def _graph(self, cache, key, fn):
+        """The captured graph for ``key``, re-captured if the solvers' buffers have moved since."""
+        e = cache.get(key)
+        if e is not None and e.gens != tuple(sv.generation for sv in self.task.solvers):
+            e = None
+        if e is None:
+            e = cache[key] = self._capture(fn)
+        return e
+
+    def _replay(self, e):
+        for sv, ctx, n in e.ctxs:
+            if ctx is not None:
+                sv.ctx, sv._cur_n = ctx, n
+        e.graph.replay()
 
     # -- the update proper --------------------------------------------------------
     def _plan(self, ws, NP=None):
@@ -675,15 +692,11 @@ class SAC_CBF_CLF(object):
             # hipGraph replay: part 1 up to the dopri5 accept decision, one 256-byte read, part 2
             g = ws.graphs
             k1, k2 = ("p1", soft, self.solver, NP), ("p2", lam_upd, ws.blam_upd, self.solver, NP)
-            if k1 not in g:
-                g[k1] = self._capture(lambda: self._upd_part1(ws, soft))
-            g[k1].replay()
+            self._replay(self._graph(g, k1, lambda: self._upd_part1(ws, soft)))
             if self.solver == "dopri5" and not self.task.first_step_done():
                 self._upd_part2(ws, lam_upd, False)          # rare: finish eagerly
             else:
-                if k2 not in g:
-                    g[k2] = self._capture(lambda: self._upd_part2(ws, lam_upd, True))
-                g[k2].replay()
+                self._replay(self._graph(g, k2, lambda: self._upd_part2(ws, lam_upd, True)))
         return self._returns(sync)
 
     def _returns(self, sync):

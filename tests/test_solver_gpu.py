@@ -13,7 +13,7 @@ pytestmark = pytest.mark.gpu
 TOL = 1e-4
 
 
-KINK = 2e-5
+KINK = 1e-4
 
 
 def rows_close(a, b, name, margin):
@@ -141,42 +141,47 @@ def test_multi_step_dopri5_with_parameter_gradients(T):
 
 
 @pytest.mark.parametrize("masks", [True, False], ids=["relu-bit-masks", "acts"])
-def test_problems_that_diverge_fall_back_to_per_problem_solves(masks):
-    """Two problems that stop agreeing on accept / done (the second is stiffer): each finishes on its own solver and
-    the results are the oracle's separate odeint calls.  The per-problem solvers take over what the joint solve has
-    done — their rows of every step workspace so far and their control block — instead of starting again; horizons are
-    tried until both kinds of divergence have been seen: at the first attempt and after some joint steps."""
+@pytest.mark.parametrize("rpp", [96, 77], ids=["device-chain", "ragged-host-fallback"])
+def test_problems_that_diverge_each_take_their_own_steps(masks, rpp):
+    """Two problems with different step sequences (the second is stiffer): each has its own adaptive step size in the
+    reference too (separate odeint calls), and the results must be the oracle's separate solves.  rows_per_problem a
+    multiple of 32: the device-driven chain — every problem advances through its own step slots, no host decision per
+    attempt, no fallback.  Ragged rows_per_problem (tiles straddle the problems): the host-driven loop, which finishes
+    diverging problems on per-problem solvers that take the joint work over."""
     from nlbac_amd.odeint import AffineNodeSolver
     agent, env = make_agent(64, 64, 0, "dopri5")
     W = synth.agent_weights("Unicycle", 64, 0)["node"]
     gen = torch.Generator().manual_seed(3)
-    rpp = 96
     y0 = torch.cat([torch.rand(2 * rpp, 2, generator=gen) * 4 - 2, torch.rand(2 * rpp, 1, generator=gen) * 6 - 3], 1)
     u = (torch.rand(2 * rpp, 2, generator=gen) * 2 - 1) * torch.tensor([3.5, 12.0])
     u[rpp:] *= 5.0                                     # the second problem is stiffer: other step sizes
     dout = torch.randn(2 * rpp, 3, generator=gen)
-    seen = set()
-    for T in (0.3, 0.02, 0.03, 0.045, 0.06, 0.08, 0.1, 0.13, 0.16, 0.2):
+    diverged = 0
+    for T in (0.3, 0.03, 0.06, 0.1, 0.16):
         sol = AffineNodeSolver(agent.neural_ode_model, "cuda")
         sol.keep_acts = not masks
         out = sol.forward(y0.cuda(), u.cuda(), 2, rpp, "dopri5", T)
         du, dy0 = sol.backward(dout.cuda(), need_du=True, need_dy0=True)
-        if not sol.stats["split"]:
-            continue
-        kind = "first attempt" if sol.stats.get("adopted", 0) else "later attempt"
-        assert sol.stats.get("adopted", 0) + sol.stats.get("adopted_late", 0) == sol.stats["split"]
-        if kind in seen:
-            continue
-        seen.add(kind)
+        chained = bool(sol.ctx.get("chain"))
+        assert chained == (rpp % 32 == 0)
+        n_att = []
         for p in range(2):
             rows = slice(p * rpp, (p + 1) * rpp)
             out_o, dy0_o, du_o, _, info = oracle_solve(W, y0[rows], u[rows], T, dout[rows])
-            vec_close(out[rows].cpu().numpy(), out_o.numpy(), TOL, "x(T) problem %d (T=%g, %s)" % (p, T, kind))
-            rows_close(dy0[rows].cpu().numpy(), dy0_o.numpy(), "d/dy0 problem %d (T=%g, %s)" % (p, T, kind), info["margin"])
-            rows_close(du[rows].cpu().numpy(), du_o.numpy(), "d/du problem %d (T=%g, %s)" % (p, T, kind), info["margin"])
-        if len(seen) == 2:
-            break
-    assert seen == {"first attempt", "later attempt"}, "horizons tried did not produce both kinds of divergence: %r" % seen
+            n_att.append(len(info["steps"]))
+            vec_close(out[rows].cpu().numpy(), out_o.numpy(), TOL, "x(T) problem %d (T=%g)" % (p, T))
+            rows_close(dy0[rows].cpu().numpy(), dy0_o.numpy(), "d/dy0 problem %d (T=%g)" % (p, T), info["margin"])
+            rows_close(du[rows].cpu().numpy(), du_o.numpy(), "d/du problem %d (T=%g)" % (p, T), info["margin"])
+            if chained:      # the device took the oracle's attempt sequence for this problem
+                dev = [a[p] for a in sol.ctx["info"] if a[p] is not None]
+                assert len(dev) == len(info["steps"]), (dev, info["steps"])
+                assert [d[2] for d in dev] == [s_[2] for s_ in info["steps"]]
+                # (later step sizes follow 0.9 ratio^-0.2 of an error ratio that is cancellation noise at the 1e-3 level)
+                np.testing.assert_allclose([d[0] for d in dev], [s_[0] for s_ in info["steps"]], rtol=2e-3)
+        diverged += n_att[0] != n_att[1]
+        if not chained and n_att[0] != n_att[1]:
+            assert sol.stats["split"] == 1
+    assert diverged >= 2, "the horizons tried did not make the two problems take different step sequences"
 
 
 def test_workspaces_of_a_growing_node_fit_batch_stay_bounded():
@@ -194,7 +199,7 @@ def test_workspaces_of_a_growing_node_fit_batch_stay_bounded():
         torch.cuda.synchronize()
         marks.append(torch.cuda.memory_allocated())
     sv = agent.fit_solver
-    assert len({k[0] for k in sv._ws}) <= sv.MAX_SIZES and len(agent._fit_ws) <= 2
+    assert len({k[0] for k in sv._pools}) <= sv.MAX_SIZES and len(agent._fit_ws) <= 2
     assert marks[-1] < 3.0 * marks[0], marks            # 30 sizes, 2x the rows: nowhere near 30x the memory
     # same sequence of fits on a fresh agent that only ever sees the final size: identical parameters
     fresh, _ = make_agent(64, 64, 0, "dopri5")
