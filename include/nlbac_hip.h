@@ -374,7 +374,11 @@ int nlbac_dopri_norm_partials(const float *a, const float *b, const float *y0, c
  * uint32 words, left zeroed by the launch. */
 int nlbac_dopri_norm_control(const float *a, const float *b, const float *y0, const float *y1, const float *u,
                              int mode, float rtol, float atol, int n_s, int n_u, int rows_per_problem, int P,
-                             double t_end, float *partials, unsigned *tickets, double *ctl, nlbac_stream_t s);
+                             double t_end, float *partials, unsigned *tickets, double *ctl,
+                             const struct nlbac_rk_chain *chain /* or NULL; device-driven chain, mode 2: a / y1 are
+                                 slot 0's, the attempt judged is the one in slot ctl[12], finished problems are skipped,
+                                 accepted step sizes / the attempt log are recorded as in nlbac_node_rk_fwd */,
+                             nlbac_stream_t s);
 int nlbac_dopri_control(const float *partials, int n_blk_per_problem, int mode, int n_s, int n_u,
                         int rows_per_problem, int P, double t_end, double *ctl,
                         int n_slots /* 0: no step slots; > 0: chained (a finished solve is left alone in mode 2) */,

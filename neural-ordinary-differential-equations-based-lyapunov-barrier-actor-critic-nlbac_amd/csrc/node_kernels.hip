@@ -286,16 +286,21 @@ __global__ __launch_bounds__(512, OCC ? 4 : 2) void node_rk_fwd_kernel(const Nod
             const int nblk = (L.rpp + NLBAC_MLP_TILE - 1) / NLBAC_MLP_TILE;
             const int blk = (row0 - p_tile * L.rpp) / NLBAC_MLP_TILE;
             float* q = L.partials + ((long)p_tile * nblk + blk) * 2;
-            q[0] = v0; q[1] = v1;
-            __threadfence();
-            const unsigned ticket = __hip_atomic_fetch_add(L.tickets + p_tile, 1u, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT);
+            // No agent-scope fence here: on gfx950 a release at agent scope writes the XCD's whole L2 back, and this
+            // workgroup has just written the step's K / Y / masks (measured: +15 us on a one-stage launch, +30 us on an
+            // attempt).  The two partial sums go out as device-scope atomic exchanges — performed at the level all
+            // XCDs see — and the ticket is only taken once both have RETURNED; the last workgroup reads them with
+            // device-scope atomic loads.  Everything else this kernel wrote is for later launches (kernel boundary).
+            const float o0 = __hip_atomic_exchange(q + 0, v0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            const float o1 = __hip_atomic_exchange(q + 1, v1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            asm volatile("" ::"v"(o0), "v"(o1) : "memory");
+            const unsigned ticket = __hip_atomic_fetch_add(L.tickets + p_tile, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             s_last = (ticket == (unsigned)nblk - 1u) ? 1u : 0u;
             if (s_last) __hip_atomic_store(L.tickets + p_tile, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         }
     }
     __syncthreads();
     if (!s_last || tid >= 64) return;
-    __threadfence();
     {
         const int nblk = (L.rpp + NLBAC_MLP_TILE - 1) / NLBAC_MLP_TILE;
         double d0 = 0.0, d1 = 0.0;

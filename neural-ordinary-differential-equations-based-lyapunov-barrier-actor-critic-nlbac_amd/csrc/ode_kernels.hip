@@ -186,8 +186,12 @@ __global__ void dopri_control_kernel(const float* partials, int nblk, int mode, 
 __global__ __launch_bounds__(256) void dopri_norm_control_kernel(const float* a, const float* b, const float* y0,
                                                                  const float* y1, const float* u, int mode, float rtol,
                                                                  float atol, int n_s, int n_u, int rpp, double t_end,
-                                                                 float* partials, unsigned* tickets, double* ctl) {
-    dopri_norm_block(a, b, y0, y1, u, mode, rtol, atol, n_s, n_u, rpp, partials);
+                                                                 float* partials, unsigned* tickets, double* ctl,
+                                                                 const double* slot_ctl, long slot_floats, int n_slots,
+                                                                 double* hslots, double* alog, int alog_cap) {
+    // device-driven chain (slot_ctl): a finished problem is left alone by all of its blocks
+    if (slot_ctl && mode == 2 && slot_ctl[(long)blockIdx.y * NLBAC_DOPRI_CTL + C_DONE] > 0.0) return;
+    dopri_norm_block(a, b, y0, y1, u, mode, rtol, atol, n_s, n_u, rpp, partials, slot_ctl, slot_floats);
     __shared__ unsigned s_last;
     __shared__ double s_red[2][256];
     const int p = blockIdx.y, nblk = (int)gridDim.x;
@@ -218,7 +222,22 @@ __global__ __launch_bounds__(256) void dopri_norm_control_kernel(const float* a,
         }
         __syncthreads();
     }
-    if (threadIdx.x == 0) dopri_control_one(s_red[0][0], s_red[1][0], p, mode, n_s, n_u, rpp, t_end, ctl);
+    if (threadIdx.x == 0) {
+        double* c = ctl + (long)p * NLBAC_DOPRI_CTL;
+        const int slot_before = (int)c[C_NACC];
+        const double h_try = c[C_H];
+        const double cnt = (double)rpp * (double)(n_s + n_u);
+        dopri_control_vals(sqrt(s_red[0][0] / cnt), sqrt(s_red[1][0] / cnt), p, mode, t_end, ctl,
+                           n_slots > 0 ? n_slots : (1 << 30));
+        if (hslots && mode == 2 && c[C_ACCEPT] > 0.0) hslots[(long)p * n_slots + slot_before] = h_try;
+        if (alog && mode == 2) {
+            const int k = (int)c[C_NSTEPS] - 1;
+            if (k >= 0 && k < alog_cap) {
+                double* al = alog + ((long)p * alog_cap + k) * 3;
+                al[0] = h_try; al[1] = c[C_RATIO]; al[2] = c[C_ACCEPT];
+            }
+        }
+    }
 }
 
 #define DPM0 (6025192743.0 / 30085553152.0 / 2.0)
@@ -379,14 +398,16 @@ extern "C" int nlbac_dopri_norm_partials(const float* a, const float* b, const f
 extern "C" int nlbac_dopri_norm_control(const float* a, const float* b, const float* y0, const float* y1, const float* u,
                                         int mode, float rtol, float atol, int n_s, int n_u, int rows_per_problem, int P,
                                         double t_end, float* partials, unsigned* tickets, double* ctl,
-                                        nlbac_stream_t s) {
+                                        const nlbac_rk_chain* chain, nlbac_stream_t s) {
     NLBAC_REQUIRE(a && y0 && partials && tickets && ctl && mode >= 0 && mode <= 2,
                   "nlbac_dopri_norm_control: bad arguments");
     NLBAC_REQUIRE((mode != 0 || u) && (mode != 1 || b) && (mode != 2 || y1), "nlbac_dopri_norm_control: missing operand");
     NLBAC_REQUIRE(P >= 1 && P <= MAX_PROBLEMS, "nlbac_dopri_norm_control: P %d out of range", P);
     hipLaunchKernelGGL(dopri_norm_control_kernel, dim3(nlbac_ceil_div(rows_per_problem, 256), P), dim3(256), 0,
                        (hipStream_t)s, a, b, y0, y1, u, mode, rtol, atol, n_s, n_u, rows_per_problem, t_end, partials,
-                       tickets, ctl);
+                       tickets, ctl, (chain && mode == 2) ? chain->ctl : nullptr, chain ? chain->slot_floats : 0,
+                       chain ? chain->n_slots : 0, chain ? chain->hslots : nullptr, chain ? chain->alog : nullptr,
+                       chain ? chain->alog_cap : 0);
     NLBAC_CHECK_LAUNCH("nlbac_dopri_norm_control");
     return 0;
 }

@@ -478,7 +478,8 @@ class AffineNodeSolver:
             return
         tickets = self._buf("tickets", P, dtype=torch.int32)
         _lib.call("nlbac_dopri_norm_control", dp(a), dp(b), dp(y0), dp(y1), dp(u), mode, ctx["rtol"], ctx["atol"],
-                  ns, nu, rpp, P, ctx["t_end"], part.data_ptr(), tickets.data_ptr(), ctl.data_ptr(), s)
+                  ns, nu, rpp, P, ctx["t_end"], part.data_ptr(), tickets.data_ptr(), ctl.data_ptr(),
+                  C.byref(chain) if chain is not None else None, s)
 
     def _control(self, part, nblk, mode, P, rpp, t_end, ctl, chain=None):
         """Step-size controller; under data parallelism the squared-norm sums are all-reduced first so every
@@ -564,6 +565,7 @@ class AffineNodeSolver:
     # block once per chain — not once per attempt; problems of one batch advance independently, so there is no
     # per-problem fallback on this path.  The backward walks the slots the same way (``back_idx``).
     ALOG_CAP = 64
+    FUSED_NORM_MODES = (0, 1)
 
     def _chain_ok(self, P, rpp):
         return bool(self.device_loop and self.fused and (P == 1 or rpp % _lib.MLP_TILE == 0))
@@ -579,8 +581,13 @@ class AffineNodeSolver:
         c.rtol, c.atol, c.t_end = ctx["rtol"], ctx["atol"], ctx["t_end"]
         c.ctl_w, c.hslots = ctl.data_ptr(), hs.data_ptr()
         c.alog, c.alog_cap = self._buf("alog", P, self.ALOG_CAP, 3, dtype=torch.float64).data_ptr(), self.ALOG_CAP
-        if self.comm is not None and self.comm.world > 1:
-            c.norm_mode = -1                  # the norm is all-reduced between the launch and the controller
+        # Where the norm + controller run.  Fused into the RK launch's epilogue (last workgroup of a problem) for the two
+        # one-stage launches of the initial-step selection: same GPU time as a launch of their own (26.7 us against
+        # 18 + 9), one launch less each.  NOT for an attempted step: the epilogue's device-scope atomics queue behind the
+        # six stages' stores (+18 us against a 9 us launch, MI355X) — it keeps the separate, slot-aware launch.  Data
+        # parallel: always separate (the sums are all-reduced between the norm and the controller).
+        if (self.comm is not None and self.comm.world > 1) or norm_mode not in self.FUSED_NORM_MODES:
+            c.norm_mode = -1
         else:
             c.norm_mode = norm_mode
             c.partials = self._buf("cpart", P, nblk, 2).data_ptr()
@@ -588,7 +595,8 @@ class AffineNodeSolver:
         return c
 
     def _chain_control(self, ws0, pool, chain, y0, u, mode, P, rpp):
-        """data parallel only: norm partial sums (slot-aware) -> all-reduce -> controller, as separate launches"""
+        """the scaled norm + step controller as launches of their own (slot-aware), where the RK launch did not run them
+        in its epilogue (see ``_chain``)"""
         if chain.norm_mode >= 0:
             return
         ctl = self._ctl(P)
