@@ -11,6 +11,7 @@
 // < 128 VGPRs), which is what hides the per-tile layer chain here.  Weights stream from their fragment-packed,
 // L2-resident copy straight into registers (WaveGemm), stage derivatives stay in LDS across stages.
 #include "mlp_device.h"
+#include "ode_control.h"
 
 #define CK_MAX_STAGES 8
 #define CK_NS 16          // LDS row stride of state-sized rows (n_s <= 16)
@@ -34,6 +35,12 @@ struct ConcatRkLaunch {
     // weight gradient (or null).
     const float* norm; float* Xn;
     int ld;
+    // device-driven dopri5 chain, as NodeRkLaunch (node_kernels.hip): step slots `slot_floats` apart, done problems
+    // skipped, FSAL from the previous slot, optional fused norm + controller epilogue
+    int S_total;
+    const double* ctl; long slot_floats;
+    int norm_mode, n_slots; float rtol, atol; double t_end;
+    float* partials; unsigned* tickets; double* ctl_w; double* hslots; double* alog; int alog_cap;
 };
 
 // NTHR = threads per workgroup.  Measured on the 64-wide reference net (two column tiles): 128-thread workgroups — only
@@ -45,6 +52,21 @@ __global__ __launch_bounds__(NTHR) void concat_rk_fwd_kernel(const ConcatRkLaunc
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int n = L.n, ns = L.n_s, nc = L.n_c, LD = L.ld;
     const int row0 = blockIdx.x * NLBAC_MLP_TILE;
+    const int p_tile = row0 / L.rpp;
+    long soff = 0;
+    bool fsal = false;
+    if (L.ctl) {
+        const double* c = L.ctl + (long)p_tile * NLBAC_DOPRI_CTL;
+        if (c[C_DONE] > 0.0) return;              // (uniform) this problem's solve has finished
+        const int slot = (int)c[C_NACC];
+        soff = (long)slot * L.slot_floats;
+        fsal = slot > 0;
+    }
+    float* const gK = L.K + soff;
+    float* const gY = L.Y + soff;
+    float* const gErr = L.err ? L.err + soff : nullptr;
+    float* const gXn = L.Xn ? L.Xn + soff : nullptr;
+    const float* const gy0 = fsal ? (gY - L.slot_floats) + (long)(L.S_total - 1) * n * ns : L.y0;
     const nlbac_mlp& net = L.net;
     const int hid = net.hid, NT = pad32(hid) >> 5, nwide = net.n_layers - 1;
     const int inp = pad8(net.in_dim);
@@ -73,7 +95,7 @@ __global__ __launch_bounds__(NTHR) void concat_rk_fwd_kernel(const ConcatRkLaunc
     const int idim = net.in_dim;
     for (int idx = tid; idx < NLBAC_MLP_TILE * CK_NS; idx += NTHR) {
         const int m = idx / CK_NS, c = idx - m * CK_NS, row = row0 + m;
-        sY0[idx] = (row < n && c < ns) ? L.y0[(long)row * ns + c] : 0.f;
+        sY0[idx] = (row < n && c < ns) ? gy0[(long)row * ns + c] : 0.f;
     }
     if (tid < NLBAC_MLP_TILE * CK_NC) {
         const int m = tid / CK_NC, c = tid - m * CK_NC, row = row0 + m;
@@ -86,7 +108,16 @@ __global__ __launch_bounds__(NTHR) void concat_rk_fwd_kernel(const ConcatRkLaunc
     for (int idx = tid; idx < L.stage_begin * NLBAC_MLP_TILE * CK_NS; idx += NTHR) {      // stages of an earlier launch
         const int j = idx / (NLBAC_MLP_TILE * CK_NS), rem = idx - j * NLBAC_MLP_TILE * CK_NS;
         const int m = rem / CK_NS, c = rem - m * CK_NS, row = row0 + m;
-        sK[idx] = (row < n && c < ns) ? L.K[((long)j * n + row) * ns + c] : 0.f;
+        float v = 0.f;
+        if (row < n && c < ns) {
+            if (fsal && j == 0) {       // first stage = the previous slot's last one; kept in this slot for the interpolant
+                v = (gK - L.slot_floats)[((long)(L.S_total - 1) * n + row) * ns + c];
+                gK[(long)row * ns + c] = v;
+            } else {
+                v = gK[((long)j * n + row) * ns + c];
+            }
+        }
+        sK[idx] = v;
     }
     __syncthreads();
 
@@ -102,19 +133,19 @@ __global__ __launch_bounds__(NTHR) void concat_rk_fwd_kernel(const ConcatRkLaunc
                 const float h = sH[m];
                 for (int j = 0; j < st; ++j)
                     if (L.beta[st][j] != 0.f) a = a + sK[(j * NLBAC_MLP_TILE + m) * CK_NS + c] * (L.beta[st][j] * h);
-                if (row0 + m < n) L.Y[((long)st * n + row0 + m) * ns + c] = a;
+                if (row0 + m < n) gY[((long)st * n + row0 + m) * ns + c] = a;
             } else if (c < ns + nc) {
                 a = sC[m * CK_NC + (c - ns)];
             }
             if (L.norm && c < idim) {
                 a = (a - sN[c]) * sN[idim + c];
-                if (L.Xn && row0 + m < n) L.Xn[((long)st * n + row0 + m) * idim + c] = a;
+                if (gXn && row0 + m < n) gXn[((long)st * n + row0 + m) * idim + c] = a;
             }
             in[m * LD + c] = a;
         }
         __syncthreads();
         // ---- hidden layers (MFMA), activations saved for the backward
-        float* acts_tile = L.acts ? L.acts + ((long)st * n + row0) * hid : nullptr;
+        float* acts_tile = L.acts ? L.acts + soff + ((long)st * n + row0) * hid : nullptr;
         fwd_wide_layers<1, 0>(wg, net, active, wave, lane, LD, inp, in, out, acts_tile, L.acts_ls, n_rows, nwide,
                               st + 1 < L.stage_end);
         // ---- output layer: k_st
@@ -123,7 +154,7 @@ __global__ __launch_bounds__(NTHR) void concat_rk_fwd_kernel(const ConcatRkLaunc
             float val = skinny_row_dot(in + m * LD, sW + o * hid, hid) + sW[net.out_dim * hid + o];
             if (L.norm) val = val * sN[2 * idim + ns + o] + sN[2 * idim + o];
             sK[(st * NLBAC_MLP_TILE + m) * CK_NS + o] = val;
-            if (row < n) L.K[((long)st * n + row) * ns + o] = val;
+            if (row < n) gK[((long)st * n + row) * ns + o] = val;
         }
         __syncthreads();
     }
@@ -139,11 +170,91 @@ __global__ __launch_bounds__(NTHR) void concat_rk_fwd_kernel(const ConcatRkLaunc
                 if (L.c_out[j] != 0.f) a = a + sK[(j * NLBAC_MLP_TILE + m) * CK_NS + r] * (L.c_out[j] * h);
             L.out[(long)row * ns + r] = a;
         }
-        if (L.err) {
+        if (gErr) {
             float a = 0.f;
             for (int j = 0; j < L.n_err; ++j)
                 if (L.c_err[j] != 0.f) a = a + sK[(j * NLBAC_MLP_TILE + m) * CK_NS + r] * (L.c_err[j] * h);
-            L.err[(long)row * ns + r] = a;
+            gErr[(long)row * ns + r] = a;
+        }
+    }
+
+    // ---- fused step control (see node_rk_fwd_kernel): tile partial sums, one ticket per problem, last workgroup = controller
+    if (L.norm_mode < 0) return;
+    __shared__ unsigned s_last;
+    if (tid < 64) {
+        const int m = tid;
+        float v0 = 0.f, v1 = 0.f;
+        if (m < n_rows) {
+            const float h = sH[m];
+            for (int r = 0; r < ns; ++r) {
+                const float y = sY0[m * CK_NS + r];
+                if (L.norm_mode == 2) {
+                    float e = 0.f, y1 = y;
+                    for (int j = 0; j < L.n_err; ++j)
+                        if (L.c_err[j] != 0.f) e = e + sK[(j * NLBAC_MLP_TILE + m) * CK_NS + r] * (L.c_err[j] * h);
+                    const int sl = L.S_total - 1;
+                    for (int j = 0; j < sl; ++j)
+                        if (L.beta[sl][j] != 0.f) y1 = y1 + sK[(j * NLBAC_MLP_TILE + m) * CK_NS + r] * (L.beta[sl][j] * h);
+                    const float q = e / (L.atol + L.rtol * fmaxf(fabsf(y), fabsf(y1)));
+                    v0 += q * q;
+                } else {
+                    const float sc = L.atol + fabsf(y) * L.rtol;
+                    if (L.norm_mode == 0) {
+                        const float q0 = y / sc, q1 = sK[m * CK_NS + r] / sc;
+                        v0 += q0 * q0; v1 += q1 * q1;
+                    } else {
+                        const float q = (sK[(NLBAC_MLP_TILE + m) * CK_NS + r] - sK[m * CK_NS + r]) / sc;
+                        v0 += q * q;
+                    }
+                }
+            }
+            if (L.norm_mode == 0)
+                for (int c = 0; c < nc; ++c) {
+                    const float y = sC[m * CK_NC + c];
+                    const float q = y / (L.atol + fabsf(y) * L.rtol);
+                    v0 += q * q;
+                }
+        }
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) { v0 += __shfl_down(v0, off, 64); v1 += __shfl_down(v1, off, 64); }
+        if (tid == 0) {
+            const int nblk = (L.rpp + NLBAC_MLP_TILE - 1) / NLBAC_MLP_TILE;
+            const int blk = (row0 - p_tile * L.rpp) / NLBAC_MLP_TILE;
+            float* q = L.partials + ((long)p_tile * nblk + blk) * 2;
+            const float o0 = __hip_atomic_exchange(q + 0, v0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            const float o1 = __hip_atomic_exchange(q + 1, v1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            asm volatile("" ::"v"(o0), "v"(o1) : "memory");
+            const unsigned ticket = __hip_atomic_fetch_add(L.tickets + p_tile, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            s_last = (ticket == (unsigned)nblk - 1u) ? 1u : 0u;
+            if (s_last) __hip_atomic_store(L.tickets + p_tile, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+    }
+    __syncthreads();
+    if (!s_last || tid >= 64) return;
+    {
+        const int nblk = (L.rpp + NLBAC_MLP_TILE - 1) / NLBAC_MLP_TILE;
+        double d0 = 0.0, d1 = 0.0;
+        for (int b = tid; b < nblk; b += 64) {
+            const float* q = L.partials + ((long)p_tile * nblk + b) * 2;
+            d0 += (double)__hip_atomic_load(q + 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            d1 += (double)__hip_atomic_load(q + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) { d0 += __shfl_down(d0, off, 64); d1 += __shfl_down(d1, off, 64); }
+        if (tid == 0) {
+            const double cnt = (double)L.rpp * (double)(ns + nc);
+            double* c = L.ctl_w + (long)p_tile * NLBAC_DOPRI_CTL;
+            const int slot_before = (int)c[C_NACC];
+            const double h_try = c[C_H];
+            dopri_control_vals(sqrt(d0 / cnt), sqrt(d1 / cnt), p_tile, L.norm_mode, L.t_end, L.ctl_w, L.n_slots);
+            if (L.norm_mode == 2 && L.hslots && c[C_ACCEPT] > 0.0) L.hslots[(long)p_tile * L.n_slots + slot_before] = h_try;
+            if (L.norm_mode == 2 && L.alog) {
+                const int k = (int)c[C_NSTEPS] - 1;
+                if (k >= 0 && k < L.alog_cap) {
+                    double* a = L.alog + ((long)p_tile * L.alog_cap + k) * 3;
+                    a[0] = h_try; a[1] = c[C_RATIO]; a[2] = c[C_ACCEPT];
+                }
+            }
         }
     }
 }
@@ -167,6 +278,8 @@ struct ConcatRkBwdLaunch {
     const float* norm;                // as ConcatRkLaunch::norm
     float* dyn;                       // [stage][n][n_s] gradient w.r.t. the net's own output (dK * out_sig), kept with dz
     int ld;
+    // device-driven chain, as NodeRkBwdLaunch: launch back_idx differentiates slot C_NACC - back_idx of each problem
+    const double* ctl; long slot_floats; int back_idx, n_slots; const double* hslots;
 };
 
 template <int NTHR>
@@ -175,6 +288,19 @@ __global__ __launch_bounds__(NTHR) void concat_rk_bwd_kernel(const ConcatRkBwdLa
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int n = L.n, ns = L.n_s, nc = L.n_c, LD = L.ld;
     const int row0 = blockIdx.x * NLBAC_MLP_TILE;
+    long soff = 0;
+    int slot = 0;
+    const bool chained = L.ctl != nullptr;
+    if (chained) {
+        slot = (int)L.ctl[(long)(row0 / L.rpp) * NLBAC_DOPRI_CTL + C_NACC] - L.back_idx;
+        if (slot < 0) return;                       // (uniform) this problem took fewer steps
+        soff = (long)slot * L.slot_floats;
+    }
+    const bool carry = chained && L.back_idx > 0;
+    float* const gdK = L.dK + soff;
+    float* const gdy0 = L.dy0 ? L.dy0 + soff : nullptr;
+    float* const gdyn = L.dyn ? L.dyn + soff : nullptr;
+    const float* const gdYup = carry ? gdy0 + L.slot_floats : (L.dYup ? L.dYup + soff : nullptr);
     const nlbac_mlp& net = L.net;
     const int hid = net.hid, NT = pad32(hid) >> 5, hidp32 = NT * 32, nwide = net.n_layers - 1;
     const int n_rows = min(NLBAC_MLP_TILE, n - row0);
@@ -196,7 +322,7 @@ __global__ __launch_bounds__(NTHR) void concat_rk_bwd_kernel(const ConcatRkBwdLa
     if (L.norm)
         for (int idx = tid; idx < 2 * idim + 2 * ns; idx += NTHR) sN[idx] = L.norm[idx];
 
-    const int st_lo = L.st_lo;
+    const int st_lo = chained ? (slot == 0 ? 0 : 1) : L.st_lo;
     const bool stage0_data = L.dx_stage0 || keep_dz;
 #define ck_has_data(st_) ((st_) >= st_lo && ((st_) > 0 || stage0_data))
     WaveGemm<1> wg;
@@ -216,22 +342,28 @@ __global__ __launch_bounds__(NTHR) void concat_rk_bwd_kernel(const ConcatRkBwdLa
     }
     for (int idx = tid; idx < NLBAC_MLP_TILE * CK_NS; idx += NTHR) {
         const int m = idx / CK_NS, c = idx - m * CK_NS, row = row0 + m;
-        sDY0[idx] = (row < n && c < ns && L.dy0 && L.dy0_in) ? L.dy0[(long)row * ns + c] : 0.f;
+        sDY0[idx] = (row < n && c < ns && gdy0 && L.dy0_in && !carry) ? gdy0[(long)row * ns + c] : 0.f;
     }
     if (tid < NLBAC_MLP_TILE) {
         const int p = min(row0 + tid, n - 1) / L.rpp;
-        sH[tid] = L.h_dev ? (float)L.h_dev[(long)p * L.h_stride] : L.h_val[p];
+        sH[tid] = chained ? (float)L.hslots[(long)p * L.n_slots + slot]
+                          : (L.h_dev ? (float)L.h_dev[(long)p * L.h_stride] : L.h_val[p]);
     }
     for (int idx = tid; idx < L.st_hi * NLBAC_MLP_TILE * CK_NS; idx += NTHR) {
         const int j = idx / (NLBAC_MLP_TILE * CK_NS), rem = idx - j * NLBAC_MLP_TILE * CK_NS;
         const int m = rem / CK_NS, c = rem - m * CK_NS, row = row0 + m;
-        sDK[idx] = (row < n && c < ns) ? L.dK[((long)j * n + row) * ns + c] : 0.f;
+        float v = 0.f;
+        if (row < n && c < ns) {
+            if (!carry) v = gdK[((long)j * n + row) * ns + c];
+            else if (j == L.S_total - 1) v = (gdK + L.slot_floats)[(long)row * ns + c];     // FSAL: next slot's dK[0]
+        }
+        sDK[idx] = v;
     }
     __syncthreads();
 
-    for (int st = L.st_hi - 1; st >= L.st_lo; --st) {
+    for (int st = L.st_hi - 1; st >= st_lo; --st) {
         const bool data = ck_has_data(st);
-        const float* acts_tile = L.acts + ((long)st * n + row0) * hid;
+        const float* acts_tile = L.acts + soff + ((long)st * n + row0) * hid;
         float av_top[16];            // NTHR / 2 padded columns x two row groups of 16 rows cover the tile
         if (data) node_top_masks<16, 0, NTHR>(acts_tile + (long)(nwide - 1) * ls, hid, NT, tid, n_rows, av_top);
         __builtin_amdgcn_sched_barrier(0);
@@ -240,7 +372,7 @@ __global__ __launch_bounds__(NTHR) void concat_rk_bwd_kernel(const ConcatRkBwdLa
             float v = (o < ns) ? sDK[(st * NLBAC_MLP_TILE + m) * CK_NS + o] : 0.f;
             if (L.norm && o < ns) {
                 v *= sN[2 * idim + ns + o];
-                if (L.dyn && data && row0 + m < n) L.dyn[((long)st * n + row0 + m) * ns + o] = v;
+                if (gdyn && data && row0 + m < n) gdyn[((long)st * n + row0 + m) * ns + o] = v;
             }
             sdy[rem] = v;
         }
@@ -250,9 +382,9 @@ __global__ __launch_bounds__(NTHR) void concat_rk_bwd_kernel(const ConcatRkBwdLa
         float* out = buf + NLBAC_MLP_TILE * LD;
         node_top_layer<16, 0, NTHR>(sdy, sW, net.out_dim, hid, hidp32, NT, tid, n_rows, av_top, in, LD);
         __syncthreads();
-        if (keep_dz) tile_to_global(in, LD, L.dz + (long)(nwide - 1) * ls + ((long)st * n + row0) * hid, hid, n_rows, tid, NTHR);
+        if (keep_dz) tile_to_global(in, LD, L.dz + soff + (long)(nwide - 1) * ls + ((long)st * n + row0) * hid, hid, n_rows, tid, NTHR);
         {
-            float* dz_tile = keep_dz ? L.dz + ((long)st * n + row0) * hid : nullptr;
+            float* dz_tile = keep_dz ? L.dz + soff + ((long)st * n + row0) * hid : nullptr;
             bwd_wide_layers<1, 0>(wg, net, active, wave, lane, LD, in, out, acts_tile, dz_tile, ls, n_rows, n_rows - 1,
                                   nwide - 1, ck_has_data(st - 1), NTHR);
         }
@@ -269,7 +401,7 @@ __global__ __launch_bounds__(NTHR) void concat_rk_bwd_kernel(const ConcatRkBwdLa
         __syncthreads();
         for (int idx = tid; idx < NLBAC_MLP_TILE * ns; idx += NTHR) {
             const int m = idx / ns, c = idx - m * ns, row = row0 + m;
-            float d = (L.dYup && st == L.S_total - 1 && row < n) ? L.dYup[(long)row * ns + c] : 0.f;
+            float d = (gdYup && st == L.S_total - 1 && row < n) ? gdYup[(long)row * ns + c] : 0.f;
             d += sDX[m * CK_NS + c];
             sDY0[m * CK_NS + c] = sDY0[m * CK_NS + c] + d;
             const float h = sH[m];
@@ -282,12 +414,12 @@ __global__ __launch_bounds__(NTHR) void concat_rk_bwd_kernel(const ConcatRkBwdLa
     for (int idx = tid; idx < L.st_hi * NLBAC_MLP_TILE * ns; idx += NTHR) {
         const int j = idx / (NLBAC_MLP_TILE * ns), rem = idx - j * NLBAC_MLP_TILE * ns;
         const int m = rem / ns, c = rem - m * ns, row = row0 + m;
-        if (row < n) L.dK[((long)j * n + row) * ns + c] = sDK[(j * NLBAC_MLP_TILE + m) * CK_NS + c];
+        if (row < n) gdK[((long)j * n + row) * ns + c] = sDK[(j * NLBAC_MLP_TILE + m) * CK_NS + c];
     }
-    if (L.dy0)
+    if (gdy0)
         for (int idx = tid; idx < NLBAC_MLP_TILE * ns; idx += NTHR) {
             const int m = idx / ns, c = idx - m * ns, row = row0 + m;
-            if (row < n) L.dy0[(long)row * ns + c] = sDY0[m * CK_NS + c];
+            if (row < n) gdy0[(long)row * ns + c] = sDY0[m * CK_NS + c];
         }
     if (L.dc)
         for (int idx = tid; idx < NLBAC_MLP_TILE * nc; idx += NTHR) {
@@ -312,7 +444,8 @@ extern "C" int nlbac_concat_rk_fwd(const nlbac_mlp* net, const float* y0, const 
                                    int stage_begin, int stage_end, int n_stages_total, const float* beta,
                                    const float* c_out, int n_out, const float* c_err, int n_err, const float* h_host,
                                    const double* h_dev, int h_dev_stride, float* K, float* Y, float* acts, long acts_ls,
-                                   float* out, float* err, const float* norm, float* Xn, nlbac_stream_t s) {
+                                   float* out, float* err, const float* norm, float* Xn, const nlbac_rk_chain* chain,
+                                   nlbac_stream_t s) {
     if (concat_check(net, P, rows_per_problem, n_stages_total, "nlbac_concat_rk_fwd")) return -1;
     NLBAC_REQUIRE(y0 && c && K && Y, "nlbac_concat_rk_fwd: null pointer");
     NLBAC_REQUIRE(stage_begin >= 0 && stage_begin < stage_end && stage_end <= n_stages_total,
@@ -338,6 +471,20 @@ extern "C" int nlbac_concat_rk_fwd(const nlbac_mlp* net, const float* y0, const 
     L.out = out; L.err = err;
     NLBAC_REQUIRE(norm || !Xn, "nlbac_concat_rk_fwd: Xn goes with norm");
     L.norm = norm; L.Xn = Xn;
+    L.S_total = n_stages_total;
+    L.norm_mode = -1;
+    if (chain) {
+        NLBAC_REQUIRE(P == 1 || rows_per_problem % NLBAC_MLP_TILE == 0,
+                      "nlbac_concat_rk_fwd: a chained launch needs rows_per_problem %% 32 == 0 (tiles must not straddle problems)");
+        NLBAC_REQUIRE(chain->norm_mode < 0 || (chain->norm_mode <= 2 && chain->partials && chain->tickets && chain->ctl_w),
+                      "nlbac_concat_rk_fwd: fused step control needs partials, tickets and the control block");
+        NLBAC_REQUIRE(chain->norm_mode != 2 || (err && n_err > 0), "nlbac_concat_rk_fwd: norm mode 2 needs the error coefficients");
+        L.ctl = chain->ctl; L.slot_floats = chain->slot_floats;
+        L.norm_mode = chain->norm_mode; L.n_slots = chain->n_slots > 0 ? chain->n_slots : (1 << 30);
+        L.rtol = chain->rtol; L.atol = chain->atol; L.t_end = chain->t_end;
+        L.partials = chain->partials; L.tickets = chain->tickets; L.ctl_w = chain->ctl_w; L.hslots = chain->hslots;
+        L.alog = chain->alog; L.alog_cap = chain->alog_cap;
+    }
     const int in_p = (net->in_dim + 7) & ~7, hid_p = (net->hid + 7) & ~7;
     L.ld = (hid_p > in_p ? hid_p : in_p) + 4;
     const size_t lds = ((size_t)2 * NLBAC_MLP_TILE * L.ld + CK_MAX_STAGES * NLBAC_MLP_TILE * CK_NS +
@@ -353,13 +500,22 @@ extern "C" int nlbac_concat_rk_bwd(const nlbac_mlp* net, int P, int rows_per_pro
                                    int st_hi, int dx_stage0, const float* beta, const float* h_host,
                                    const double* h_dev, int h_dev_stride, const float* acts, long acts_ls, float* dz,
                                    float* dK, const float* dYup, float* dy0, int dy0_in, float* dc, int dc_acc,
-                                   const float* norm, float* dyn, nlbac_stream_t s) {
+                                   const float* norm, float* dyn, const nlbac_rk_chain* chain, int back_idx,
+                                   nlbac_stream_t s) {
     if (concat_check(net, P, rows_per_problem, n_stages_total, "nlbac_concat_rk_bwd")) return -1;
     NLBAC_REQUIRE(acts && dK, "nlbac_concat_rk_bwd: null pointer");
     NLBAC_REQUIRE(st_lo >= 0 && st_lo < st_hi && st_hi <= n_stages_total, "nlbac_concat_rk_bwd: bad stage range");
-    NLBAC_REQUIRE(h_dev || h_host, "nlbac_concat_rk_bwd: no step size");
+    NLBAC_REQUIRE(h_dev || h_host || (chain && chain->hslots), "nlbac_concat_rk_bwd: no step size");
     ConcatRkBwdLaunch L;
     memset(&L, 0, sizeof(L));
+    if (chain && chain->ctl) {
+        NLBAC_REQUIRE(P == 1 || rows_per_problem % NLBAC_MLP_TILE == 0,
+                      "nlbac_concat_rk_bwd: a chained launch needs rows_per_problem %% 32 == 0");
+        NLBAC_REQUIRE(chain->hslots && chain->n_slots >= 1 && chain->slot_floats > 0 && back_idx >= 0 && dy0,
+                      "nlbac_concat_rk_bwd: incomplete chain description");
+        L.ctl = chain->ctl; L.slot_floats = chain->slot_floats; L.back_idx = back_idx; L.n_slots = chain->n_slots;
+        L.hslots = chain->hslots;
+    }
     L.net = *net;
     L.acts = acts; L.acts_ls = acts_ls; L.dz = dz;
     L.dK = dK; L.dYup = dYup; L.dy0 = dy0; L.dy0_in = dy0_in; L.dc = dc; L.dc_acc = dc_acc;

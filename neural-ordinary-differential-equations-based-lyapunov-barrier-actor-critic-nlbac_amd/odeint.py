@@ -1263,7 +1263,7 @@ class ConcatNodeSolver(AffineNodeSolver):
         self.comm = None
         self.adjoint = False
         self.generation = 0
-        self.device_loop = False      # (the single-net kernels do not take the step-chain description yet)
+        self.device_loop = True
         # input normalisation / output de-normalisation lives inside the fused step kernels only
         self.norm = node.norm_device() if getattr(node, "normalized", False) else None
         if self.norm is not None and not self.fused:
@@ -1279,7 +1279,7 @@ class ConcatNodeSolver(AffineNodeSolver):
                                   "single-net NODE differentiates through the steps")
 
     def _rk_fused(self, ws, y0, u, P, rpp, method, st0, st1, h_host=None, h_dev=None, c_out=None, out=None,
-                  c_err=None, err=None, save_acts=True):
+                  c_err=None, err=None, save_acts=True, chain=None):
         beta, S = self._beta(method)
         _lib.call("nlbac_concat_rk_fwd", C.byref(self.net.desc), y0.data_ptr(), u.data_ptr(), P, rpp, st0, st1, S, beta,
                   c_out, len(c_out) if c_out is not None else 0, c_err, len(c_err) if c_err is not None else 0,
@@ -1288,11 +1288,12 @@ class ConcatNodeSolver(AffineNodeSolver):
                   ws.S * P * rpp * self.net.hid, out.data_ptr() if out is not None else None,
                   err.data_ptr() if err is not None else None,
                   self.norm.data_ptr() if self.norm is not None else None,
-                  ws.Xn.data_ptr() if (self.norm is not None and save_acts) else None, stream_ptr())
+                  ws.Xn.data_ptr() if (self.norm is not None and save_acts) else None,
+                  C.byref(chain) if chain is not None else None, stream_ptr())
         self.nfe += st1 - st0
 
     def _rk_fused_bwd(self, ws, u, P, rpp, method, first_eval, need_dy0, need_params, h_host, h_dev, h_stride, top_up,
-                      du, last):
+                      du, last, chain=None, back_idx=0):
         beta_arr, _ = self._beta(method)
         S = ws.S
         _lib.call("nlbac_concat_rk_bwd", C.byref(self.net.desc), P, rpp, S, 0 if first_eval else 1, S,
@@ -1301,7 +1302,8 @@ class ConcatNodeSolver(AffineNodeSolver):
                   top_up.data_ptr() if top_up is not None else None, ws.dy0.data_ptr(), 1,
                   du.data_ptr() if du is not None else None, 0 if last else 1,
                   self.norm.data_ptr() if self.norm is not None else None,
-                  ws.dyn.data_ptr() if (self.norm is not None and need_params) else None, stream_ptr())
+                  ws.dyn.data_ptr() if (self.norm is not None and need_params) else None,
+                  C.byref(chain) if chain is not None else None, back_idx, stream_ptr())
 
     def _eval_io(self, x, k_out, c, acts=None, ls=0):
         io = io_array(1)

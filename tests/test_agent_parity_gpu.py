@@ -298,3 +298,43 @@ def test_fused_rk_step_kernel_matches_per_stage_launches(solver, rows):
     assert sol.ctx["steps"][-1]["ws"].bits and sol.ctx["steps"][-1]["ws"].acts_f.dtype == torch.int32
     for a, b, name in zip(res[1][:3], (out, du, dy0), ("out", "du", "dy0")):
         assert torch.equal(a, b), "mask mode differs from activation mode: " + name
+
+
+def test_hipgraphs_with_alternating_batch_sizes_stay_correct():
+    """Captured graphs bake in the addresses of the solvers' buffers and belong to the solve they recorded.  Updates that
+    alternate between three batch sizes (each with its own workspaces, graphs and dopri5 control blocks, and a NODE fit
+    whose row count changes) must each reproduce the oracle — a replay must neither write into buffers another size
+    has taken over nor read another size's accept decision."""
+    from oracle import nlbac_oracle as O
+    torch.set_num_threads(4)
+    hidden, seed, env_name, solver = 64, 0, "Unicycle", "dopri5"
+    agent, env = make_agent(128, hidden, seed, solver, env_name)
+    agent.use_graphs = True
+    oargs = O.Args(batch_size=128, hidden_size=hidden, seed=seed)
+    oracle = O.make_oracle(synth.fixture_env(env_name, seed), oargs, synth.agent_weights(env_name, hidden, seed), solver=solver)
+    tr = synth.transitions(env_name, 8192, seed=seed + 1, env=env)
+    fields = synth.fields(env_name)
+    sizes = [128, 256, 64, 128, 256, 64, 128, 256, 64, 256, 128]
+    fit_rows = {0: 512, 10: 5000}
+    for u, B in enumerate(sizes):
+        rs = np.random.RandomState(100 + u)
+        idx = rs.choice(8192, B, replace=False)
+        batch = {f: torch.tensor(tr[f][idx], dtype=torch.float32) for f in fields}
+        eps = [torch.from_numpy(e) for e in synth.normal_eps(3, B, 2, seed=u)]
+        node = None
+        if u in fit_rows:
+            nidx = rs.choice(8192, fit_rows[u], replace=False)
+            node = tuple(torch.tensor(tr[f][nidx], dtype=torch.float32) for f in ("obs", "action", "next_obs"))
+        R = oracle.update(batch, eps, u, node_batch=node)
+        agent.set_noise(eps)
+        ret = agent.update_from_host(tuple(batch[f].numpy() for f in fields), u,
+                                     tuple(t.numpy() for t in node) if node else None)
+        torch.cuda.synchronize()
+        vec_close(ret, R["ret"], TOL, "update %d (B=%d): returned floats" % (u, B))
+        vec_close(agent.node_solver.ctx["out"][:B].cpu().numpy(), R["x_next"].numpy(), TOL, "update %d: x_next" % u)
+        vec_close(flat_grad(agent, agent.ar_a, agent.policy), R["g_policy"], TOL, "update %d: policy gradient" % u)
+    assert sum(len(w.graphs) for w in agent._ws.values()) >= 6, "graphs were not captured for the three sizes"
+    for name, mod, osd in (("critic", agent.critic, oracle.critic), ("policy", agent.policy, oracle.policy),
+                           ("node", agent.neural_ode_model, oracle.node)):
+        ov = torch.cat([osd[k].detach().reshape(-1) for k in osd])
+        params_close(flat_params(mod), ov, 1e-3 * len(sizes), "params %s after %d updates" % (name, len(sizes)))
