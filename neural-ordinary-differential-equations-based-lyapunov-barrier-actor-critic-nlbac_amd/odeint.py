@@ -73,11 +73,13 @@ class _SlotPool:
     [slots][slot_floats].  The device-driven chain works inside chunk 0 (contiguous, ``n_slots`` = its size); the
     host-driven path just asks for the next slot and may spill into further chunks."""
 
-    def __init__(self, solver, cap, S, n_slots):
+    def __init__(self, solver, cap, S, n_slots, dry_only=False):
         self.solver, self.cap, self.S, self.n_slots = solver, cap, S, n_slots
         dry = _Carver(None, solver.device)
         solver.STEP_WS(solver, cap, S, dry).bwd(solver)
         self.slot_floats = (dry.k + 63) & ~63
+        if dry_only:
+            return
         self.chunks = [torch.zeros(n_slots, self.slot_floats, dtype=torch.float32, device=solver.device)]
         self.views = {}                  # (n, idx) -> step workspace
 
@@ -208,19 +210,35 @@ class AffineNodeSolver:
         pools = self.__dict__.setdefault("_pools", {})
         key = (self._bucket(n), S, self.fused, self.keep_acts)
         pool = pools.get(key)
+        dropped = False
         if pool is not None and pool.n_slots < min_slots:
             del pools[key]
-            pool = None
-            self.generation += 1
+            pool, dropped = None, True
         if pool is None:
             buckets = list(dict.fromkeys(k[0] for k in pools))              # in order of first use
             if key[0] not in buckets and len(buckets) >= self.MAX_SIZES:
                 for k in [k for k in pools if k[0] == buckets[0]]:         # the oldest bucket goes, whole
                     del pools[k]
+                dropped = True
+            if dropped:
                 self.generation += 1
+                # pools are GB-sized and each regrowth asks for a new size: hand the freed blocks back to the driver,
+                # or the caching allocator keeps every size it has ever seen (279 GiB reserved for 39 GiB in use in a
+                # long dopri5 training run before this)
+                if not torch.cuda.is_current_stream_capturing():
+                    torch.cuda.empty_cache()
             n_slots = max(min_slots, self.DEFAULT_SLOTS if S == 7 else 1)
+            pool = _SlotPool(self, key[0], S, n_slots, dry_only=True)
+            if pool.slot_floats * 4 * n_slots > self.MAX_POOL_BYTES:
+                raise _lib.NlbacError(
+                    "dopri5: %d accepted steps of %d rows need %.0f GiB of step slots (limit %.0f GiB): the field has "
+                    "become stiff for back-propagation through the steps — use the adjoint (agent.adjoint = True / "
+                    "odeint_adjoint), whose memory does not grow with the step count"
+                    % (n_slots, key[0], pool.slot_floats * 4 * n_slots / 2 ** 30, self.MAX_POOL_BYTES / 2 ** 30))
             pool = pools[key] = _SlotPool(self, key[0], S, n_slots)
         return pool
+
+    MAX_POOL_BYTES = 128 * 2 ** 30
 
     def _step_ws(self, n, S, idx):
         pool = self._pool(n, S)

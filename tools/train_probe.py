@@ -14,8 +14,9 @@ train.main(["--env", "Unicycle", "--gamma_b", "50", "--max_episodes", "40", "--c
             "--max_steps", steps])
 a = agents[0]
 for name, sv in (("rollout", a.node_solver), ("fit", a.fit_solver)):
-    print(name, sv.stats, "stores", len(sv.__dict__.get("_stores", {})), "ws", len(sv._ws),
-          "last solve steps", len(sv.ctx.get("steps") or []), "info", (sv.ctx.get("info") or [])[-3:])
+    print(name, sv.stats, "pools", {k[:2]: p.n_slots for k, p in sv.__dict__.get("_pools", {}).items()},
+          "chain length", sv.__dict__.get("_chain_len"), "last solve steps", len(sv.ctx.get("steps") or []),
+          "last attempts", (sv.ctx.get("info") or [])[-2:])
 ws = a._workspace(256)
 mem = agents[0]
 torch.cuda.synchronize()
