@@ -115,7 +115,10 @@ int nlbac_adam_step(float *p, float *m, float *v, const float *grad, int n_slabs
  * slot of parameter i inside the nets' `packed` buffers (0 = none), for the trained and the target copy. */
 int nlbac_adam_fused(float *p, float *m, float *v, const float *grad, int n_slabs, long slab_stride, long n,
                      void *state, double lr, float *target, float tau, const void *scatter,
-                     const void *scatter_target, nlbac_stream_t s);
+                     const void *scatter_target,
+                     int n_alpha /* 0..2 temperatures refreshed by the step itself: alpha_dst[k][0] = exp(p[alpha_off[k]])
+                                    after the step (sac_cbf_clf.py:297, 308) */,
+                     const long *alpha_off, float *const *alpha_dst, nlbac_stream_t s);
 int nlbac_reduce_slabs(float *out, const float *grad, int n_slabs, long slab_stride, long n, nlbac_stream_t s);
 int nlbac_soft_update(float *target, const float *src, long n, float tau, nlbac_stream_t s);
 
@@ -145,18 +148,31 @@ int nlbac_gauss_sample_bwd(const float *heads, int heads_ld, const float *eps, c
  * All q-like arguments are (B) vectors; reward/constraint/mask are read with stride rcm_ld (columns of
  * the minibatch rows); alpha = sc+SC_ALPHA.  Means are over B_norm rows
  * (= B on one GPU, the global batch under data parallelism; the same holds for every *_norm below).
- * partials: [ceil(B/256)][3] squared-error sums (qf1, qf2, lf). */
+ * partials: [ceil(B/256)][3] squared-error sums (qf1, qf2, lf).
+ * ticket (or NULL): a zeroed uint32 (left zeroed) — the launch then finishes the job itself: its last workgroup sums
+ * the partials in block order (exactly nlbac_sum_partials' arithmetic) and writes out[0..2] = sum * mul.  The same
+ * "(ticket, mul, out)" tail exists on nlbac_td_value; single GPU only (under data parallelism the sums are
+ * all-reduced first). */
 int nlbac_td_targets(const float *q1t, const float *q2t, const float *lt, const float *nlogp,
                      const float *reward, const float *constraint, const float *mask, int rcm_ld,
                      const float *q1, const float *q2, const float *lf, const float *alpha,
                      float gamma, int B, int B_norm, float *dq1, float *dq2, float *dlf, float *next_q,
-                     float *next_l, float *partials, nlbac_stream_t s);
+                     float *next_l, float *partials, unsigned *ticket, float mul, float *out, nlbac_stream_t s);
 
 /* policy_loss_1 pieces for P controllers (rows p*B..): d min(Q1,Q2)/dq * (-1/B) and
  * partials [P][ceil(B/256)][2] = sums of (alpha_p*logp - minq, logp)
  * (sac_cbf_clf.py:258-273). */
+typedef struct nlbac_actor_scalar_args { /* nlbac_actor_scalars' arguments, per problem (0 primary, 1 backup) */
+    float target_entropy;
+    const float *log_alpha[2];
+    float *g_log_alpha[2];
+    float *sc;
+} nlbac_actor_scalar_args;
+/* fused (or NULL) + ticket (a zeroed uint32, left zeroed): the launch's last workgroup also does nlbac_actor_scalars'
+ * job for all P problems (same sums in the same order) — single GPU only. */
 int nlbac_actor_q_terms(const float *q1, const float *q2, const float *logp, const float *alpha,
-                        int B, int B_norm, int P, float *dq1, float *dq2, float *partials, nlbac_stream_t s);
+                        int B, int B_norm, int P, float *dq1, float *dq2, float *partials,
+                        const nlbac_actor_scalar_args *fused, unsigned *ticket, nlbac_stream_t s);
 /* policy_loss_1, alpha_loss into sc; d alpha_loss / d log_alpha into g_log_alpha
  * (sac_cbf_clf.py:292-308) for problems first_problem .. first_problem+P-1 (0 primary, 1 backup);
  * partials is the base of all problems, log_alpha / g_log_alpha point at first_problem's entry (stride between). */
@@ -179,10 +195,20 @@ int nlbac_unicycle_lookahead_bwd(const float *x, const float *dps, const float *
 /* CBF/CLF terms, relu filter and column partial sums (sac_cbf_clf.py:471-504, 596-621).
  * ps (B,2); ps_next (2B,2): primary rows then backup rows.  matr (B,n_hz+1) and bmatr (B,n_hz)
  * are kept for the backward.  partials [ceil(B/256)][2*n_hz+1]. */
+typedef struct nlbac_auglag_args { /* nlbac_auglag's scalar arguments */
+    int n_cbf, n_clf;
+    float batch_size;
+    int do_lambda_update, do_backup_lambda_update, ratio_mode, backup_mode;
+    float lam_lo, lam_hi;
+} nlbac_auglag_args;
+/* Every *_constraints_fwd takes a trailing (fused, ticket, sc): with fused != NULL (single GPU) its last workgroup
+ * runs nlbac_auglag itself on the partial sums of this launch (ticket: a zeroed uint32, left zeroed) — one launch
+ * less per update, same arithmetic. */
 int nlbac_unicycle_constraints_fwd(const float *ps, const float *ps_next, const float *V,
                                    const float *V_next, const float *hazards, int n_hz, float r_coll,
                                    float dt, float gamma_b, float gamma_l, int B, float *matr,
-                                   float *bmatr, float *partials, nlbac_stream_t s);
+                                   float *bmatr, float *partials, const nlbac_auglag_args *fused,
+                                   unsigned *ticket, float *sc, nlbac_stream_t s);
 /* required_matrix, ratio, lambda update (clamp [lam_lo,lam_hi]), rho *= 1.0005 (cap 200), loss values and
  * loss coefficients, primary then backup (sac_cbf_clf.py:502-528, 619-638).
  * ratio_mode: 0 none (NU), 1 plain (U), 2 clamp at 0.002 (C/P/NP).
@@ -209,7 +235,8 @@ int nlbac_cars_rollout_inputs(const float *mb, int ld, int t_col, int nt_col, co
 int nlbac_cars_obs(const float *state, int n, float *obs, nlbac_stream_t s);
 int nlbac_cars_constraints_fwd(const float *state, const float *x1, const float *x2, const float *V,
                                const float *V1, float gamma_b, float gamma_l, float radius, int B,
-                               float *matr, float *bmatr, float *partials, nlbac_stream_t s);
+                               float *matr, float *bmatr, float *partials, const nlbac_auglag_args *fused,
+                               unsigned *ticket, float *sc, nlbac_stream_t s);
 int nlbac_cars_constraints_bwd(const float *matr, const float *bmatr, float gamma_b, float batch_size, int B,
                                const float *sc, float *dx1, float *dx2, float *dV1, nlbac_stream_t s);
 /* dst[row][col0+c] += src[row][c] */
@@ -225,14 +252,14 @@ int nlbac_add_cols(float *dst, int dst_ld, int col0, const float *src, int src_l
  *   partials [ceil(B/256)][2]; bwd gives dB(obs',a') and dV' from the coefficients in sc (:412-440). */
 int nlbac_td_value(const float *next_target, const float *signal, int sig_ld, const float *mask, int mask_ld,
                    const float *pred, float gamma, int B, int B_norm, float *dpred, float *next_out /*or NULL*/,
-                   float *partials, nlbac_stream_t s);
+                   float *partials, unsigned *ticket, float mul, float *out, nlbac_stream_t s);
 int nlbac_unicycle_obs_fwd(const float *x /*(n,3)*/, int n, float goal_x, float goal_y, float *obs, int obs_ld,
                            nlbac_stream_t s);
 int nlbac_unicycle_obs_bwd(const float *x, const float *dobs, int dobs_ld, int n, float goal_x, float goal_y,
                            float *dx /*(n,3)*/, int accumulate, nlbac_stream_t s);
 int nlbac_barrier_constraints_fwd(const float *Bv, const float *Bn, const float *V, const float *Vn, float dt,
                                   float gamma_b, float gamma_l, int B, float *matr, float *partials,
-                                  nlbac_stream_t s);
+                                  const nlbac_auglag_args *fused, unsigned *ticket, float *sc, nlbac_stream_t s);
 int nlbac_barrier_constraints_bwd(const float *matr, float dt, float batch_size, int B, const float *sc,
                                   float *dBn, float *dVn, nlbac_stream_t s);
 
@@ -252,7 +279,8 @@ int nlbac_pvtol_obs_bwd(const float *x6, const float *dobs, int dobs_ld, float f
 int nlbac_pvtol_constraints_fwd(const float *st6, const float *op0, const float *x1, const float *x2, const float *x3,
                                 const float *V, const float *V1, const float *hazards, int n_hz, float r_coll,
                                 float d_op, float y_max, float y_min, float follow, float gamma_b, float gamma_l,
-                                int B, int NP, float *matr, float *bmatr, float *partials, nlbac_stream_t s);
+                                int B, int NP, float *matr, float *bmatr, float *partials,
+                                const nlbac_auglag_args *fused, unsigned *ticket, float *sc, nlbac_stream_t s);
 int nlbac_pvtol_constraints_bwd(const float *matr, const float *bmatr, const float *x1, const float *x2,
                                 const float *x3, const float *hazards, int n_hz, float follow, float gamma_b,
                                 float batch_size, int B, int NP, const float *sc, float *dx1, float *dx2, float *dx3,

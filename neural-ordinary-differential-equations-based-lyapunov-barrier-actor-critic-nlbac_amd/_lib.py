@@ -45,6 +45,19 @@ class MlpIO(C.Structure):
                 ("skinny_ws", C.c_void_p)]
 
 
+class AuglagArgs(C.Structure):
+    """``struct nlbac_auglag_args``"""
+    _fields_ = [("n_cbf", C.c_int), ("n_clf", C.c_int), ("batch_size", C.c_float), ("do_lambda_update", C.c_int),
+                ("do_backup_lambda_update", C.c_int), ("ratio_mode", C.c_int), ("backup_mode", C.c_int),
+                ("lam_lo", C.c_float), ("lam_hi", C.c_float)]
+
+
+class ActorScalarArgs(C.Structure):
+    """``struct nlbac_actor_scalar_args``"""
+    _fields_ = [("target_entropy", C.c_float), ("log_alpha", C.c_void_p * 2), ("g_log_alpha", C.c_void_p * 2),
+                ("sc", C.c_void_p)]
+
+
 class RkChain(C.Structure):
     """``struct nlbac_rk_chain``"""
     _fields_ = [("ctl", C.c_void_p), ("slot_floats", C.c_long), ("norm_mode", C.c_int), ("n_slots", C.c_int),
@@ -67,19 +80,19 @@ _PROTOS = {
     "nlbac_mlp_bwd_weights": [C.POINTER(Mlp), C.POINTER(MlpIO), _I, _I, _I, _L, _P, _L, _P],
     "nlbac_adam_prepare": [_P, _D, _P],
     "nlbac_adam_step": [_P, _P, _P, _P, _I, _L, _L, _P, _P, _F, _P],
-    "nlbac_adam_fused": [_P, _P, _P, _P, _I, _L, _L, _P, _D, _P, _F, _P, _P, _P],
+    "nlbac_adam_fused": [_P, _P, _P, _P, _I, _L, _L, _P, _D, _P, _F, _P, _P, _I, C.POINTER(C.c_long), C.POINTER(C.c_void_p), _P],
     "nlbac_reduce_slabs": [_P, _P, _I, _L, _L, _P],
     "nlbac_soft_update": [_P, _P, _L, _F, _P],
     "nlbac_gauss_sample_fwd": [_P, _I, _P, _P, _P, _I, _I, _P, _I, _P, _P],
     "nlbac_gauss_sample_bwd": [_P, _I, _P, _P, _I, _I, _I, _P, _I, _P, _I, _P, _I, _P, _F, _P, _I, _P],
-    "nlbac_td_targets": [_P] * 7 + [_I] + [_P] * 4 + [_F, _I, _I] + [_P] * 6 + [_P],
-    "nlbac_actor_q_terms": [_P, _P, _P, _P, _I, _I, _I, _P, _P, _P, _P],
+    "nlbac_td_targets": [_P] * 7 + [_I] + [_P] * 4 + [_F, _I, _I] + [_P] * 6 + [_P, _F, _P, _P],
+    "nlbac_actor_q_terms": [_P, _P, _P, _P, _I, _I, _I, _P, _P, _P, C.POINTER(ActorScalarArgs), _P, _P],
     "nlbac_actor_scalars": [_P, _I, _I, _I, _I, _F, _P, _I, _P, _P, _P],
     "nlbac_alpha_refresh": [_P, _I, _I, _I, _P, _P],
     "nlbac_unicycle_state": [_P, _I, _I, _F, _P, _I, _P, _P],
     "nlbac_unicycle_lookahead": [_P, _I, _F, _P, _P],
     "nlbac_unicycle_lookahead_bwd": [_P, _P, _P, _I, _F, _P, _P],
-    "nlbac_unicycle_constraints_fwd": [_P, _P, _P, _P, _P, _I, _F, _F, _F, _F, _I, _P, _P, _P, _P],
+    "nlbac_unicycle_constraints_fwd": [_P, _P, _P, _P, _P, _I, _F, _F, _F, _F, _I, _P, _P, _P, C.POINTER(AuglagArgs), _P, _P, _P],
     "nlbac_auglag": [_P, _I, _I, _I, _F, _I, _I, _I, _I, _F, _F, _P, _P],
     "nlbac_unicycle_constraints_bwd": [_P, _P, _P, _P, _I, _F, _F, _I, _P, _P, _P, _P],
     "nlbac_mse_fwd_bwd": [_P, _I, _P, _I, _I, _I, _I, _P, _I, _P, _P],
@@ -90,21 +103,22 @@ _PROTOS = {
     "nlbac_cars_state": [_P, _I, _I, _P, _P],
     "nlbac_cars_rollout_inputs": [_P, _I, _I, _I, _P, _I, _P, _P, _P, _P, _P],
     "nlbac_cars_obs": [_P, _I, _P, _P],
-    "nlbac_cars_constraints_fwd": [_P, _P, _P, _P, _P, _F, _F, _F, _I, _P, _P, _P, _P],
+    "nlbac_cars_constraints_fwd": [_P, _P, _P, _P, _P, _F, _F, _F, _I, _P, _P, _P, C.POINTER(AuglagArgs), _P, _P, _P],
     "nlbac_cars_constraints_bwd": [_P, _P, _F, _F, _I, _P, _P, _P, _P, _P],
     "nlbac_add_cols": [_P, _I, _I, _P, _I, _I, _I, _P],
     "nlbac_pvtol_state": [_P, _I, _I, _P, _P, _P],
     "nlbac_pvtol_obs_fwd": [_P, _P, _I, _F, _F, _F, _I, _P, _I, _P, _P],
     "nlbac_pvtol_obs_bwd": [_P, _P, _I, _F, _F, _F, _I, _P, _I, _P],
-    "nlbac_pvtol_constraints_fwd": [_P, _P, _P, _P, _P, _P, _P, _P, _I, _F, _F, _F, _F, _F, _F, _F, _I, _I, _P, _P, _P, _P],
+    "nlbac_pvtol_constraints_fwd": [_P, _P, _P, _P, _P, _P, _P, _P, _I, _F, _F, _F, _F, _F, _F, _F, _I, _I, _P, _P, _P,
+                                    C.POINTER(AuglagArgs), _P, _P, _P],
     "nlbac_pvtol_constraints_bwd": [_P, _P, _P, _P, _P, _P, _I, _F, _F, _F, _I, _I, _P, _P, _P, _P, _P, _P],
     "nlbac_copy_blocks": [_P, _L, _P, _L, _L, _L, _P],
     "nlbac_gather_rows": [_P, _L, _I, _P, _L, _P, _P],
     "nlbac_sample_rows": [_P, _L, _I, _L, _P, _P, _L, C.c_uint64, C.c_uint64, _P],
-    "nlbac_td_value": [_P, _P, _I, _P, _I, _P, _F, _I, _I, _P, _P, _P, _P],
+    "nlbac_td_value": [_P, _P, _I, _P, _I, _P, _F, _I, _I, _P, _P, _P, _P, _F, _P, _P],
     "nlbac_unicycle_obs_fwd": [_P, _I, _F, _F, _P, _I, _P],
     "nlbac_unicycle_obs_bwd": [_P, _P, _I, _I, _F, _F, _P, _I, _P],
-    "nlbac_barrier_constraints_fwd": [_P, _P, _P, _P, _F, _F, _F, _I, _P, _P, _P],
+    "nlbac_barrier_constraints_fwd": [_P, _P, _P, _P, _F, _F, _F, _I, _P, _P, C.POINTER(AuglagArgs), _P, _P, _P],
     "nlbac_barrier_constraints_bwd": [_P, _F, _F, _I, _P, _P, _P, _P],
     "nlbac_node_rk_fwd": [C.POINTER(Mlp), C.POINTER(Mlp), _P, _P, _I, _I, _I, _I, _I, c_float_p, c_float_p, _I,
                           c_float_p, _I, c_float_p, _P, _I, _P, _P, _P, _P, _L, _P, _L, _I, _P, _P, C.POINTER(RkChain), _P],

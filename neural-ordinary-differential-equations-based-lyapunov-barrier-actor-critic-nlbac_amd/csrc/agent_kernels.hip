@@ -14,6 +14,38 @@
 #include "common.h"
 #include "scalars.h"
 
+struct AuglagArgs {        // nlbac_auglag's scalar arguments, by value (nlbac_auglag_args in the header)
+    int n_cbf, n_clf; float batch_size; int do_lambda_update, do_backup_lambda_update, ratio_mode, backup_mode;
+    float lam_lo, lam_hi;
+};
+
+template <bool COHERENT>
+__device__ __forceinline__ void auglag_body(const float* partials, int n_blk, const AuglagArgs A, float* sc);
+
+// runtime-width variant of publish_and_elect (common.h)
+__device__ __forceinline__ bool publish_and_elect_n(float* dst, const float* vals, int n, unsigned* ticket, unsigned n_blocks) {
+    __shared__ unsigned s_elect_n_;
+    if (threadIdx.x == 0) {
+        float acc = 0.f;
+        for (int k = 0; k < n; ++k) acc += __hip_atomic_exchange(dst + k, vals[k], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        asm volatile("" ::"v"(acc) : "memory");
+        const unsigned t = __hip_atomic_fetch_add(ticket, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        s_elect_n_ = (t == n_blocks - 1u) ? 1u : 0u;
+        if (s_elect_n_) __hip_atomic_store(ticket, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+    __syncthreads();
+    return s_elect_n_ != 0u;
+}
+// tail of a constraints_fwd kernel: plain partials, or (ticket) publish them and let the last workgroup run auglag
+#define CONSTRAINTS_TAIL(NCOLS_, V_)                                                              \
+    if (!ticket) {                                                                                \
+        if (threadIdx.x == 0)                                                                     \
+            for (int c_ = 0; c_ < (NCOLS_); ++c_) partials[(long)blockIdx.x * (NCOLS_) + c_] = (V_)[c_]; \
+        return;                                                                                   \
+    }                                                                                             \
+    if (!publish_and_elect_n(partials + (long)blockIdx.x * (NCOLS_), (V_), (NCOLS_), ticket, gridDim.x)) return; \
+    auglag_body<true>(partials, (int)gridDim.x, A, sc);
+
 #define LOG_SIG_MAX 2.0f
 #define LOG_SIG_MIN (-20.0f)
 #define SAMPLE_EPS 1e-6f
@@ -89,7 +121,8 @@ __global__ __launch_bounds__(256) void td_targets_kernel(const float* q1t, const
                                                          const float* q1, const float* q2, const float* lf,
                                                          const float* alpha, float gamma, int B, int B_norm,
                                                          float* dq1, float* dq2, float* dlf, float* next_q,
-                                                         float* next_l, float* partials) {
+                                                         float* next_l, float* partials, unsigned* ticket,
+                                                         float mul, float* out) {
     __shared__ float red[12];
     const int i = blockIdx.x * 256 + threadIdx.x;
     float v[3] = {0.f, 0.f, 0.f};
@@ -107,10 +140,20 @@ __global__ __launch_bounds__(256) void td_targets_kernel(const float* q1t, const
         v[0] = e1 * e1; v[1] = e2 * e2; v[2] = e3 * e3;
     }
     block_sum_256<3>(v, red);
-    if (threadIdx.x == 0) {
-        partials[blockIdx.x * 3 + 0] = v[0];
-        partials[blockIdx.x * 3 + 1] = v[1];
-        partials[blockIdx.x * 3 + 2] = v[2];
+    if (!ticket) {
+        if (threadIdx.x == 0) {
+            partials[blockIdx.x * 3 + 0] = v[0];
+            partials[blockIdx.x * 3 + 1] = v[1];
+            partials[blockIdx.x * 3 + 2] = v[2];
+        }
+        return;
+    }
+    // the three loss sums in this launch (same order as nlbac_sum_partials: block 0, 1, ...)
+    if (!publish_and_elect<3>(partials + blockIdx.x * 3, v, ticket, gridDim.x)) return;
+    if (threadIdx.x < 3) {
+        float s = 0.f;
+        for (unsigned b = 0; b < gridDim.x; ++b) s += coherent_load(partials + b * 3 + threadIdx.x);
+        out[threadIdx.x] = s * mul;
     }
 }
 
@@ -118,9 +161,25 @@ __global__ __launch_bounds__(256) void td_targets_kernel(const float* q1t, const
 // min(Q1,Q2)(s, pi) branch gradients and partial sums for policy_loss_1 / alpha loss.
 // Rows: P problems (primary, backup) x B.  partials: [P][nblk][2]
 // ---------------------------------------------------------------------------
+struct ActorScalarArgs {      // nlbac_actor_scalar_args: what nlbac_actor_scalars needs, per problem (0 primary, 1 backup)
+    float target_entropy; const float* log_alpha[2]; float* g_log_alpha[2]; float* sc;
+};
+__device__ __forceinline__ void actor_scalars_one(float s0, float s1, int p, int B, float target_entropy,
+                                                  const float* log_alpha, float* g_log_alpha, float* sc) {
+    const float pl1 = s0 / (float)B;
+    const float mean_lp = s1 / (float)B;
+    const float la = log_alpha[0];
+    const float aloss = -(la * (mean_lp + target_entropy));      // alpha_loss = -(log_alpha * (logp + H)).mean()
+    sc[(p == 0) ? SC_PL1 : SC_BPL1] = pl1;
+    sc[(p == 0) ? SC_ALOSS : SC_BALOSS] = aloss;
+    sc[(p == 0) ? SC_MEAN_LOGP : SC_MEAN_BLOGP] = mean_lp;
+    g_log_alpha[0] = -(mean_lp + target_entropy);
+}
+
 __global__ __launch_bounds__(256) void actor_q_terms_kernel(const float* q1, const float* q2, const float* logp,
                                                             const float* alpha, int B, int B_norm, float* dq1,
-                                                            float* dq2, float* partials) {
+                                                            float* dq2, float* partials, unsigned* ticket,
+                                                            const ActorScalarArgs F) {
     __shared__ float red[8];
     const int p = blockIdx.y;
     const int i = blockIdx.x * 256 + threadIdx.x;
@@ -135,9 +194,23 @@ __global__ __launch_bounds__(256) void actor_q_terms_kernel(const float* q1, con
         v[1] = logp[r];
     }
     block_sum_256<2>(v, red);
-    if (threadIdx.x == 0) {
-        partials[((long)p * gridDim.x + blockIdx.x) * 2 + 0] = v[0];
-        partials[((long)p * gridDim.x + blockIdx.x) * 2 + 1] = v[1];
+    if (!ticket) {
+        if (threadIdx.x == 0) {
+            partials[((long)p * gridDim.x + blockIdx.x) * 2 + 0] = v[0];
+            partials[((long)p * gridDim.x + blockIdx.x) * 2 + 1] = v[1];
+        }
+        return;
+    }
+    // policy_loss_1 / alpha loss / d log_alpha in this launch (same sums, same order as actor_scalars_kernel)
+    if (!publish_and_elect<2>(partials + ((long)p * gridDim.x + blockIdx.x) * 2, v, ticket, gridDim.x * gridDim.y)) return;
+    if (threadIdx.x < gridDim.y) {
+        const int pp = threadIdx.x, nblk = (int)gridDim.x;
+        float s0 = 0.f, s1 = 0.f;
+        for (int b = 0; b < nblk; ++b) {
+            s0 += coherent_load(partials + ((long)pp * nblk + b) * 2 + 0);
+            s1 += coherent_load(partials + ((long)pp * nblk + b) * 2 + 1);
+        }
+        actor_scalars_one(s0, s1, pp, B_norm, F.target_entropy, F.log_alpha[pp], F.g_log_alpha[pp], F.sc);
     }
 }
 
@@ -219,6 +292,7 @@ __global__ __launch_bounds__(256) void unicycle_constraints_fwd_kernel(const flo
                                                                        const float* V, const float* V_next,
                                                                        const float* hazards, float r2, float dt,
                                                                        float gamma_b, float gamma_l, int B,
+                                                                       unsigned* ticket, const AuglagArgs A, float* sc,
                                                                        float* matr, float* bmatr, float* partials) {
     __shared__ float red[4 * (2 * NH + 1)];
     const int i = blockIdx.x * 256 + threadIdx.x;
@@ -248,23 +322,24 @@ __global__ __launch_bounds__(256) void unicycle_constraints_fwd_kernel(const flo
         v[NH] = lya > 0.f ? lya : 0.f;
     }
     block_sum_256<2 * NH + 1>(v, red);
-    if (threadIdx.x == 0)
-#pragma unroll
-        for (int c = 0; c < 2 * NH + 1; ++c) partials[(long)blockIdx.x * (2 * NH + 1) + c] = v[c];
+    CONSTRAINTS_TAIL(2 * NH + 1, v)
 }
 
 // Augmented-Lagrangian scalars.  One wave: lanes sum the partial columns, lane 0 does the scalar bookkeeping.
 // backup_mode: 0 no backup controller (learned-barrier copies), 1 backup shares rho with the primary
 // (Unicycle / SimulatedCars), 2 backup keeps its own rho (Pvtol); lambda clamp [lam_lo, lam_hi].
-__global__ void auglag_kernel(const float* partials, int n_blk, int n_cbf, int n_clf, float batch_size,
-                              int do_lambda_update, int do_backup_lambda_update,
-                              int ratio_mode /*0 none,1 plain,2 clamp .002*/, int backup_mode, float lam_lo,
-                              float lam_hi, float* sc) {
+// required_matrix sums, ratio, lambda / rho updates and loss coefficients (sac_cbf_clf.py:502-528, 623-638) by ONE
+// workgroup: the stand-alone nlbac_auglag launch, or the last workgroup of a constraints_fwd launch (COHERENT: the
+// partials were published by other workgroups of the same launch).
+template <bool COHERENT>
+__device__ __forceinline__ void auglag_body(const float* partials, int n_blk, const AuglagArgs A, float* sc) {
+    const int n_cbf = A.n_cbf, n_clf = A.n_clf, ratio_mode = A.ratio_mode, backup_mode = A.backup_mode;
+    const int do_lambda_update = A.do_lambda_update, do_backup_lambda_update = A.do_backup_lambda_update;
+    const float batch_size = A.batch_size, lam_lo = A.lam_lo, lam_hi = A.lam_hi;
     const int nc = n_cbf + n_clf, ncol = nc + (backup_mode ? n_cbf : 0);
-    if (blockIdx.x != 0) return;
     for (int c = threadIdx.x; c < ncol; c += blockDim.x) {
         float s = 0.f;
-        for (int b = 0; b < n_blk; ++b) s += partials[(long)b * ncol + c];
+        for (int b = 0; b < n_blk; ++b) s += COHERENT ? coherent_load(partials + (long)b * ncol + c) : partials[(long)b * ncol + c];
         s = s / batch_size;
         if (c < nc) sc[SC_REQ + c] = s; else sc[SC_BREQ + (c - nc)] = s;
     }
@@ -329,6 +404,12 @@ __global__ void auglag_kernel(const float* partials, int n_blk, int n_cbf, int n
         sc[SC_BPL2] = loss;
     }
 }
+
+__global__ void auglag_kernel(const float* partials, int n_blk, const AuglagArgs A, float* sc) {
+    if (blockIdx.x != 0) return;
+    auglag_body<false>(partials, n_blk, A, sc);
+}
+
 
 // d ps_next (2B,2) from the CBF terms and dV_next (B) from the CLF term
 template <int NH>
@@ -411,8 +492,9 @@ __device__ __forceinline__ float cars_cbf(float h0, float h1, float h2, float gb
 // state (B,10); x1, x2 (2B,10): primary rows then backup rows.  matr (B,3) = [cbf23, cbf34, clf], bmatr (B,2).
 __global__ __launch_bounds__(256) void cars_constraints_fwd_kernel(const float* state, const float* x1, const float* x2,
                                                                    const float* V, const float* V1, float gamma_b,
-                                                                   float gamma_l, float radius, int B, float* matr,
-                                                                   float* bmatr, float* partials) {
+                                                                   float gamma_l, float radius, int B,
+                                                                   unsigned* ticket, const AuglagArgs A, float* sc,
+                                                                   float* matr, float* bmatr, float* partials) {
     __shared__ float red[20];
     const int i = blockIdx.x * 256 + threadIdx.x;
     float v[5] = {0.f, 0.f, 0.f, 0.f, 0.f};
@@ -439,9 +521,7 @@ __global__ __launch_bounds__(256) void cars_constraints_fwd_kernel(const float* 
         v[2] = lya > 0.f ? lya : 0.f;
     }
     block_sum_256<5>(v, red);
-    if (threadIdx.x == 0)
-#pragma unroll
-        for (int c = 0; c < 5; ++c) partials[(long)blockIdx.x * 5 + c] = v[c];
+    CONSTRAINTS_TAIL(5, v)
 }
 
 // dx1, dx2 (2B,10) and dV1 (B) from the loss coefficients in sc:  cbf = -h2 + 2(1-gb) h1 - (1-gb)^2 h0
@@ -498,6 +578,19 @@ __global__ __launch_bounds__(256) void mse_kernel(const float* pred, int pred_ld
 // ---------------------------------------------------------------------------
 // C ABI
 // ---------------------------------------------------------------------------
+static int fuse_args(AuglagArgs& A, const nlbac_auglag_args* fused, unsigned*& ticket, float* sc, const char* who) {
+    memset(&A, 0, sizeof(A));
+    if (!fused) { ticket = nullptr; return 0; }
+    NLBAC_REQUIRE(ticket && sc, "%s: the fused augmented-Lagrangian step needs a ticket word and the scalars block", who);
+    NLBAC_REQUIRE(fused->backup_mode >= 0 && fused->backup_mode <= 2 && fused->n_cbf >= 1 &&
+                      fused->n_cbf + fused->n_clf <= NLBAC_NC_MAX && fused->n_clf >= 0 && fused->n_clf <= 1,
+                  "%s: bad augmented-Lagrangian arguments", who);
+    A.n_cbf = fused->n_cbf; A.n_clf = fused->n_clf; A.batch_size = fused->batch_size;
+    A.do_lambda_update = fused->do_lambda_update; A.do_backup_lambda_update = fused->do_backup_lambda_update;
+    A.ratio_mode = fused->ratio_mode; A.backup_mode = fused->backup_mode; A.lam_lo = fused->lam_lo; A.lam_hi = fused->lam_hi;
+    return 0;
+}
+
 #define GRID1(n) dim3(nlbac_ceil_div((n), 256)), dim3(256), 0, (hipStream_t)s
 
 extern "C" int nlbac_gauss_sample_fwd(const float* heads, int heads_ld, const float* eps, const float* scale,
@@ -527,21 +620,35 @@ extern "C" int nlbac_td_targets(const float* q1t, const float* q2t, const float*
                                 const float* reward, const float* constraint, const float* mask, int rcm_ld,
                                 const float* q1, const float* q2, const float* lf, const float* alpha,
                                 float gamma, int B, int B_norm, float* dq1, float* dq2, float* dlf, float* next_q,
-                                float* next_l, float* partials, nlbac_stream_t s) {
+                                float* next_l, float* partials, unsigned* ticket, float mul, float* out,
+                                nlbac_stream_t s) {
     NLBAC_REQUIRE(q1t && q2t && lt && nlogp && reward && constraint && mask && q1 && q2 && lf && alpha && dq1 &&
                       dq2 && dlf && partials, "nlbac_td_targets: null pointer");
+    NLBAC_REQUIRE(!ticket || out, "nlbac_td_targets: the fused sums need an output");
     hipLaunchKernelGGL(td_targets_kernel, GRID1(B), q1t, q2t, lt, nlogp, reward, constraint, mask, rcm_ld, q1, q2, lf,
-                       alpha, gamma, B, B_norm, dq1, dq2, dlf, next_q, next_l, partials);
+                       alpha, gamma, B, B_norm, dq1, dq2, dlf, next_q, next_l, partials, ticket, mul, out);
     NLBAC_CHECK_LAUNCH("nlbac_td_targets");
     return 0;
 }
 
 extern "C" int nlbac_actor_q_terms(const float* q1, const float* q2, const float* logp, const float* alpha,
                                    int B, int B_norm, int P, float* dq1, float* dq2, float* partials,
-                                   nlbac_stream_t s) {
-    NLBAC_REQUIRE(q1 && q2 && logp && alpha && dq1 && dq2 && partials, "nlbac_actor_q_terms: null pointer");
+                                   const nlbac_actor_scalar_args* fused, unsigned* ticket, nlbac_stream_t s) {
+    NLBAC_REQUIRE(q1 && q2 && logp && alpha && dq1 && dq2 && partials && P >= 1 && P <= 2, "nlbac_actor_q_terms: bad arguments");
+    ActorScalarArgs F;
+    memset(&F, 0, sizeof(F));
+    if (fused) {
+        NLBAC_REQUIRE(ticket && fused->sc, "nlbac_actor_q_terms: the fused scalars need a ticket word and the scalars block");
+        F.target_entropy = fused->target_entropy; F.sc = fused->sc;
+        for (int p = 0; p < P; ++p) {
+            NLBAC_REQUIRE(fused->log_alpha[p] && fused->g_log_alpha[p], "nlbac_actor_q_terms: missing log_alpha pointers");
+            F.log_alpha[p] = fused->log_alpha[p]; F.g_log_alpha[p] = fused->g_log_alpha[p];
+        }
+    } else {
+        ticket = nullptr;
+    }
     hipLaunchKernelGGL(actor_q_terms_kernel, dim3(nlbac_ceil_div(B, 256), P), dim3(256), 0, (hipStream_t)s, q1, q2,
-                       logp, alpha, B, B_norm, dq1, dq2, partials);
+                       logp, alpha, B, B_norm, dq1, dq2, partials, ticket, F);
     NLBAC_CHECK_LAUNCH("nlbac_actor_q_terms");
     return 0;
 }
@@ -593,13 +700,16 @@ extern "C" int nlbac_unicycle_lookahead_bwd(const float* x, const float* dps, co
 extern "C" int nlbac_unicycle_constraints_fwd(const float* ps, const float* ps_next, const float* V,
                                               const float* V_next, const float* hazards, int n_hz, float r_coll,
                                               float dt, float gamma_b, float gamma_l, int B, float* matr,
-                                              float* bmatr, float* partials, nlbac_stream_t s) {
+                                              float* bmatr, float* partials, const nlbac_auglag_args* fused,
+                                              unsigned* ticket, float* sc, nlbac_stream_t s) {
     NLBAC_REQUIRE(ps && ps_next && V && V_next && hazards && matr && bmatr && partials,
                   "nlbac_unicycle_constraints_fwd: null pointer");
     NLBAC_REQUIRE(n_hz == 7, "nlbac_unicycle_constraints_fwd: built for n_hz == 7 (got %d)", n_hz);
     const float r2 = (float)((double)r_coll * (double)r_coll);
+    AuglagArgs A;
+    if (fuse_args(A, fused, ticket, sc, "nlbac_unicycle_constraints_fwd")) return -1;
     hipLaunchKernelGGL(unicycle_constraints_fwd_kernel<7>, GRID1(B), ps, ps_next, V, V_next, hazards, r2, dt,
-                       gamma_b, gamma_l, B, matr, bmatr, partials);
+                       gamma_b, gamma_l, B, ticket, A, sc, matr, bmatr, partials);
     NLBAC_CHECK_LAUNCH("nlbac_unicycle_constraints_fwd");
     return 0;
 }
@@ -610,8 +720,8 @@ extern "C" int nlbac_auglag(const float* partials, int n_blk, int n_cbf, int n_c
     NLBAC_REQUIRE(partials && sc, "nlbac_auglag: null pointer");
     NLBAC_REQUIRE(backup_mode >= 0 && backup_mode <= 2, "nlbac_auglag: backup_mode is 0, 1 or 2");
     NLBAC_REQUIRE(n_cbf >= 1 && n_cbf + n_clf <= NLBAC_NC_MAX && n_clf >= 0 && n_clf <= 1, "nlbac_auglag: bad constraint counts");
-    hipLaunchKernelGGL(auglag_kernel, dim3(1), dim3(64), 0, (hipStream_t)s, partials, n_blk, n_cbf, n_clf,
-                       batch_size, do_lambda_update, do_backup_lambda_update, ratio_mode, backup_mode, lam_lo, lam_hi, sc);
+    AuglagArgs A = {n_cbf, n_clf, batch_size, do_lambda_update, do_backup_lambda_update, ratio_mode, backup_mode, lam_lo, lam_hi};
+    hipLaunchKernelGGL(auglag_kernel, dim3(1), dim3(64), 0, (hipStream_t)s, partials, n_blk, A, sc);
     NLBAC_CHECK_LAUNCH("nlbac_auglag");
     return 0;
 }
@@ -661,10 +771,13 @@ extern "C" int nlbac_cars_obs(const float* state, int n, float* obs, nlbac_strea
 
 extern "C" int nlbac_cars_constraints_fwd(const float* state, const float* x1, const float* x2, const float* V,
                                           const float* V1, float gamma_b, float gamma_l, float radius, int B,
-                                          float* matr, float* bmatr, float* partials, nlbac_stream_t s) {
+                                          float* matr, float* bmatr, float* partials, const nlbac_auglag_args* fused,
+                                          unsigned* ticket, float* sc, nlbac_stream_t s) {
     NLBAC_REQUIRE(state && x1 && x2 && V && V1 && matr && bmatr && partials, "nlbac_cars_constraints_fwd: null pointer");
-    hipLaunchKernelGGL(cars_constraints_fwd_kernel, GRID1(B), state, x1, x2, V, V1, gamma_b, gamma_l, radius, B, matr,
-                       bmatr, partials);
+    AuglagArgs A;
+    if (fuse_args(A, fused, ticket, sc, "nlbac_cars_constraints_fwd")) return -1;
+    hipLaunchKernelGGL(cars_constraints_fwd_kernel, GRID1(B), state, x1, x2, V, V1, gamma_b, gamma_l, radius, B, ticket,
+                       A, sc, matr, bmatr, partials);
     NLBAC_CHECK_LAUNCH("nlbac_cars_constraints_fwd");
     return 0;
 }
@@ -696,7 +809,7 @@ extern "C" int nlbac_add_cols(float* dst, int dst_ld, int col0, const float* src
 __global__ __launch_bounds__(256) void td_value_kernel(const float* next_target, const float* signal, int sig_ld,
                                                        const float* mask, int mask_ld, const float* pred, float gamma,
                                                        int B, int B_norm, float* dpred, float* next_out,
-                                                       float* partials) {
+                                                       float* partials, unsigned* ticket, float mul, float* out) {
     __shared__ float red[4];
     const int i = blockIdx.x * 256 + threadIdx.x;
     float v[1] = {0.f};
@@ -708,7 +821,16 @@ __global__ __launch_bounds__(256) void td_value_kernel(const float* next_target,
         v[0] = e * e;
     }
     block_sum_256<1>(v, red);
-    if (threadIdx.x == 0) partials[blockIdx.x] = v[0];
+    if (!ticket) {
+        if (threadIdx.x == 0) partials[blockIdx.x] = v[0];
+        return;
+    }
+    if (!publish_and_elect<1>(partials + blockIdx.x, v, ticket, gridDim.x)) return;
+    if (threadIdx.x == 0) {
+        float s = 0.f;
+        for (unsigned b = 0; b < gridDim.x; ++b) s += coherent_load(partials + b);
+        out[0] = s * mul;
+    }
 }
 
 __global__ __launch_bounds__(256) void unicycle_obs_fwd_kernel(const float* x, int n, float gx, float gy, float* obs,
@@ -754,7 +876,8 @@ __global__ __launch_bounds__(256) void unicycle_obs_bwd_kernel(const float* x, c
 // matr (B,2) = [-(B' - B) - gamma_b B, (V' - V)/dt + gamma_l V]; partials [nblk][2]
 __global__ __launch_bounds__(256) void barrier_constraints_fwd_kernel(const float* Bv, const float* Bn, const float* V,
                                                                       const float* Vn, float dt, float gamma_b,
-                                                                      float gamma_l, int B, float* matr,
+                                                                      float gamma_l, int B, unsigned* ticket,
+                                                                      const AuglagArgs A, float* sc, float* matr,
                                                                       float* partials) {
     __shared__ float red[8];
     const int i = blockIdx.x * 256 + threadIdx.x;
@@ -768,7 +891,7 @@ __global__ __launch_bounds__(256) void barrier_constraints_fwd_kernel(const floa
         v[1] = lt > 0.f ? lt : 0.f;
     }
     block_sum_256<2>(v, red);
-    if (threadIdx.x == 0) { partials[blockIdx.x * 2] = v[0]; partials[blockIdx.x * 2 + 1] = v[1]; }
+    CONSTRAINTS_TAIL(2, v)
 }
 
 __global__ __launch_bounds__(256) void barrier_constraints_bwd_kernel(const float* matr, float dt, float batch_size,
@@ -781,10 +904,12 @@ __global__ __launch_bounds__(256) void barrier_constraints_bwd_kernel(const floa
 
 extern "C" int nlbac_td_value(const float* next_target, const float* signal, int sig_ld, const float* mask,
                               int mask_ld, const float* pred, float gamma, int B, int B_norm, float* dpred,
-                              float* next_out, float* partials, nlbac_stream_t s) {
+                              float* next_out, float* partials, unsigned* ticket, float mul, float* out,
+                              nlbac_stream_t s) {
     NLBAC_REQUIRE(next_target && signal && mask && pred && dpred && partials, "nlbac_td_value: null pointer");
+    NLBAC_REQUIRE(!ticket || out, "nlbac_td_value: the fused sum needs an output");
     hipLaunchKernelGGL(td_value_kernel, GRID1(B), next_target, signal, sig_ld, mask, mask_ld, pred, gamma, B, B_norm,
-                       dpred, next_out, partials);
+                       dpred, next_out, partials, ticket, mul, out);
     NLBAC_CHECK_LAUNCH("nlbac_td_value");
     return 0;
 }
@@ -807,9 +932,13 @@ extern "C" int nlbac_unicycle_obs_bwd(const float* x, const float* dobs, int dob
 
 extern "C" int nlbac_barrier_constraints_fwd(const float* Bv, const float* Bn, const float* V, const float* Vn,
                                              float dt, float gamma_b, float gamma_l, int B, float* matr,
-                                             float* partials, nlbac_stream_t s) {
+                                             float* partials, const nlbac_auglag_args* fused, unsigned* ticket,
+                                             float* sc, nlbac_stream_t s) {
     NLBAC_REQUIRE(Bv && Bn && V && Vn && matr && partials, "nlbac_barrier_constraints_fwd: null pointer");
-    hipLaunchKernelGGL(barrier_constraints_fwd_kernel, GRID1(B), Bv, Bn, V, Vn, dt, gamma_b, gamma_l, B, matr, partials);
+    AuglagArgs A;
+    if (fuse_args(A, fused, ticket, sc, "nlbac_barrier_constraints_fwd")) return -1;
+    hipLaunchKernelGGL(barrier_constraints_fwd_kernel, GRID1(B), Bv, Bn, V, Vn, dt, gamma_b, gamma_l, B, ticket, A, sc,
+                       matr, partials);
     NLBAC_CHECK_LAUNCH("nlbac_barrier_constraints_fwd");
     return 0;
 }
@@ -908,7 +1037,8 @@ __device__ __forceinline__ float pv_rd3(float h0, float h1, float h2, float h3, 
 __global__ __launch_bounds__(256) void pvtol_constraints_fwd_kernel(
     const float* st6, const float* op0, const float* x1, const float* x2, const float* x3, const float* V,
     const float* V1, const float* hazards, float r2, float d_op, float y_max, float y_min, float follow, float gb,
-    float gl, int B, int NP, float* matr, float* bmatr, float* partials) {
+    float gl, int B, int NP, unsigned* ticket, const AuglagArgs A, float* sc, float* matr, float* bmatr,
+    float* partials) {
     __shared__ float red[4 * (2 * PV_NC + 1)];
     const int i = blockIdx.x * 256 + threadIdx.x;
     float v[2 * PV_NC + 1];
@@ -954,10 +1084,8 @@ __global__ __launch_bounds__(256) void pvtol_constraints_fwd_kernel(
         }
     }
     block_sum_256<2 * PV_NC + 1>(v, red);
-    if (threadIdx.x == 0) {
-        const int ncol = PV_NC + 1 + (NP == 2 ? PV_NC : 0);
-        for (int k = 0; k < ncol; ++k) partials[(long)blockIdx.x * ncol + k] = v[k];
-    }
+    const int ncol = PV_NC + 1 + (NP == 2 ? PV_NC : 0);
+    CONSTRAINTS_TAIL(ncol, v)
 }
 
 __global__ __launch_bounds__(256) void pvtol_constraints_bwd_kernel(
@@ -1048,13 +1176,16 @@ extern "C" int nlbac_pvtol_constraints_fwd(const float* st6, const float* op0, c
                                            const float* x3, const float* V, const float* V1, const float* hazards,
                                            int n_hz, float r_coll, float d_op, float y_max, float y_min, float follow,
                                            float gamma_b, float gamma_l, int B, int NP, float* matr, float* bmatr,
-                                           float* partials, nlbac_stream_t s) {
+                                           float* partials, const nlbac_auglag_args* fused, unsigned* ticket,
+                                           float* sc, nlbac_stream_t s) {
     NLBAC_REQUIRE(st6 && op0 && x1 && x2 && x3 && V && V1 && hazards && matr && partials && (NP == 1 || bmatr),
                   "nlbac_pvtol_constraints_fwd: null pointer");
     NLBAC_REQUIRE(n_hz == PV_NH && (NP == 1 || NP == 2), "nlbac_pvtol_constraints_fwd: built for 5 hazards, 1-2 problems");
     const float r2 = (float)((double)r_coll * (double)r_coll);
+    AuglagArgs A;
+    if (fuse_args(A, fused, ticket, sc, "nlbac_pvtol_constraints_fwd")) return -1;
     hipLaunchKernelGGL(pvtol_constraints_fwd_kernel, GRID1(B), st6, op0, x1, x2, x3, V, V1, hazards, r2, d_op, y_max,
-                       y_min, follow, gamma_b, gamma_l, B, NP, matr, bmatr, partials);
+                       y_min, follow, gamma_b, gamma_l, B, NP, ticket, A, sc, matr, bmatr, partials);
     NLBAC_CHECK_LAUNCH("nlbac_pvtol_constraints_fwd");
     return 0;
 }

@@ -115,12 +115,21 @@ __device__ __forceinline__ float4 slab_sum4(const float* __restrict__ grad, int 
     return g;
 }
 
+// temperatures refreshed by the step itself: alpha = exp(log_alpha) for up to two log_alpha entries of this arena
+// (sac_cbf_clf.py:297, 308), written by the thread that has just stepped the entry
+struct AlphaRefresh { long off[2]; float* dst[2]; };
+__device__ __forceinline__ void alpha_refresh(const AlphaRefresh& AR, long e, float p_new) {
+    if (e == AR.off[0]) *AR.dst[0] = expf(p_new);
+    if (e == AR.off[1]) *AR.dst[1] = expf(p_new);
+}
+
 __global__ __launch_bounds__(256) void adam_fused_kernel(float* __restrict__ p, float* __restrict__ m,
                                                          float* __restrict__ v, const float* __restrict__ grad,
                                                          int n_slabs, long slab_stride, long n, AdamState* st, double lr,
                                                          float* __restrict__ target, float tau,
                                                          const unsigned long long* __restrict__ scat,
-                                                         const unsigned long long* __restrict__ scat_t) {
+                                                         const unsigned long long* __restrict__ scat_t,
+                                                         const AlphaRefresh AR) {
     __shared__ float s_const[2];
     __shared__ int s_step;
     if (threadIdx.x == 0) {
@@ -147,6 +156,10 @@ __global__ __launch_bounds__(256) void adam_fused_kernel(float* __restrict__ p, 
         reinterpret_cast<float4*>(p)[i] = pp;
         reinterpret_cast<float4*>(m)[i] = mm;
         reinterpret_cast<float4*>(v)[i] = vv;
+        if (AR.off[0] >= 0 || AR.off[1] >= 0) {
+            alpha_refresh(AR, 4 * i + 0, pp.x); alpha_refresh(AR, 4 * i + 1, pp.y);
+            alpha_refresh(AR, 4 * i + 2, pp.z); alpha_refresh(AR, 4 * i + 3, pp.w);
+        }
         if (scat) {
             scatter2(scat, 4 * i + 0, pp.x); scatter2(scat, 4 * i + 1, pp.y);
             scatter2(scat, 4 * i + 2, pp.z); scatter2(scat, 4 * i + 3, pp.w);
@@ -168,6 +181,7 @@ __global__ __launch_bounds__(256) void adam_fused_kernel(float* __restrict__ p, 
         float pp = p[i], mm = m[i], vv = v[i];
         adam_one(pp, mm, vv, g, step_size, bc2_sqrt);
         p[i] = pp; m[i] = mm; v[i] = vv;
+        alpha_refresh(AR, i, pp);
         if (scat) scatter2(scat, i, pp);
         if (target) {
             const float t = target[i] * (1.0f - tau) + pp * tau;
@@ -177,12 +191,15 @@ __global__ __launch_bounds__(256) void adam_fused_kernel(float* __restrict__ p, 
     }
     __syncthreads();                                   // every wave of this block has read the constants
     if (threadIdx.x == 0) {
-        const unsigned ticket = __hip_atomic_fetch_add(&st->ticket, 1u, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT);
+        // relaxed: every workgroup consumed st->step (it computed its constants from it) before the barrier above, so
+        // the counter may move once the last ticket is drawn; no agent-scope release per workgroup (that would write the
+        // XCD's L2 back behind every block's parameter stores)
+        const unsigned ticket = __hip_atomic_fetch_add(&st->ticket, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         if (ticket == gridDim.x - 1) {                 // all workgroups have read st->step by now
             __hip_atomic_store(&st->ticket, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             st->step_size = step_size;
             st->bc2_sqrt = bc2_sqrt;
-            __hip_atomic_store(&st->step, s_step, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+            __hip_atomic_store(&st->step, s_step, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         }
     }
 }
@@ -253,8 +270,16 @@ extern "C" int nlbac_adam_step(float* p, float* m, float* v, const float* grad, 
 
 extern "C" int nlbac_adam_fused(float* p, float* m, float* v, const float* grad, int n_slabs, long slab_stride, long n,
                                 void* state, double lr, float* target, float tau, const void* scatter,
-                                const void* scatter_target, nlbac_stream_t s) {
+                                const void* scatter_target, int n_alpha, const long* alpha_off, float* const* alpha_dst,
+                                nlbac_stream_t s) {
     NLBAC_REQUIRE(p && m && v && grad && state, "nlbac_adam_fused: null pointer");
+    NLBAC_REQUIRE(n_alpha >= 0 && n_alpha <= 2 && (n_alpha == 0 || (alpha_off && alpha_dst)), "nlbac_adam_fused: bad alpha refresh");
+    AlphaRefresh AR;
+    AR.off[0] = AR.off[1] = -1; AR.dst[0] = AR.dst[1] = nullptr;
+    for (int k = 0; k < n_alpha; ++k) {
+        NLBAC_REQUIRE(alpha_off[k] >= 0 && alpha_off[k] < n && alpha_dst[k], "nlbac_adam_fused: alpha entry out of range");
+        AR.off[k] = alpha_off[k]; AR.dst[k] = alpha_dst[k];
+    }
     NLBAC_REQUIRE(n_slabs >= 1 && n >= 1 && lr > 0.0, "nlbac_adam_fused: bad sizes");
     NLBAC_REQUIRE(((uintptr_t)p | (uintptr_t)m | (uintptr_t)v | (uintptr_t)grad | (uintptr_t)target) % 16 == 0 &&
                       slab_stride % 4 == 0 && ((uintptr_t)scatter | (uintptr_t)scatter_target) % 8 == 0,
@@ -262,7 +287,7 @@ extern "C" int nlbac_adam_fused(float* p, float* m, float* v, const float* grad,
     NLBAC_REQUIRE(!scatter_target || (target && tau >= 0.f), "nlbac_adam_fused: scatter_target without a target");
     hipLaunchKernelGGL(adam_fused_kernel, dim3(stream_grid(n, 4)), dim3(256), 0, (hipStream_t)s, p, m, v, grad, n_slabs,
                        slab_stride, n, (AdamState*)state, lr, (tau >= 0.f) ? target : nullptr, tau,
-                       (const unsigned long long*)scatter, (const unsigned long long*)scatter_target);
+                       (const unsigned long long*)scatter, (const unsigned long long*)scatter_target, AR);
     NLBAC_CHECK_LAUNCH("nlbac_adam_fused");
     return 0;
 }

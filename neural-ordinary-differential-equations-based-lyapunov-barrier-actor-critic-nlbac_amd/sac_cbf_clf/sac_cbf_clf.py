@@ -20,6 +20,7 @@ actor step), see DESIGN.md §3.  Host<->device traffic per update: the minibatch
 indices), one 512-byte scalars read-back and, for dopri5, one 256-byte control block per attempted step.
 """
 import collections
+import ctypes as C
 import random
 import types
 
@@ -228,6 +229,7 @@ class SAC_CBF_CLF(object):
         sc_host[SC.SC_BRHO_F64:SC.SC_BRHO_F64 + 2] = np.array([1.0], dtype=np.float64).view(np.float32)
         self.sc.copy_(torch.from_numpy(sc_host))
         task.setup()
+        self._tickets = torch.zeros(16, dtype=torch.int32, device=dev)     # last-workgroup tickets of the fused launches
         self._ws = {}
         self._noise = None
         self._fit_ws = {}
@@ -292,7 +294,7 @@ class SAC_CBF_CLF(object):
             self._xb[name] = torch.zeros(n, dtype=torch.float32, device=self.device)
         return self._xb[name]
 
-    def _adam(self, arena, lr, n_slabs, extra=None, target=None, tau=-1.0, before_step=None):
+    def _adam(self, arena, lr, n_slabs, extra=None, target=None, tau=-1.0, before_step=None, alpha=None):
         """Adam on a whole arena.  One GPU: slab sum fused into the step.  Data parallel: local slab sum ->
         flat buffer (+ ``extra`` scalars riding along) -> all-reduce -> step on the reduced gradient."""
         s = stream_ptr()
@@ -300,11 +302,16 @@ class SAC_CBF_CLF(object):
         # one launch: ++step, slab sum, Adam, Polyak targets and the refresh of the nets' MFMA-fragment weight copies
         scat, scat_t = a.scatter_tables()
         scat_t = scat_t.data_ptr() if (scat_t is not None and target is not None and tau >= 0) else None
+        # alpha = exp(log_alpha) refreshed by the step itself: (offsets of the log_alpha entries, where alpha goes)
+        n_al = len(alpha[0]) if alpha else 0
+        al_off = (C.c_long * 2)(*(list(alpha[0]) + [0, 0])[:2]) if alpha else None
+        al_dst = (C.c_void_p * 2)(*(list(alpha[1]) + [None, None])[:2]) if alpha else None
         if self.world == 1:
             if before_step is not None:
                 before_step(a.grad.data_ptr())
             _lib.call("nlbac_adam_fused", a.theta.data_ptr(), a.m.data_ptr(), a.v.data_ptr(), a.grad.data_ptr(),
-                      n_slabs, a.n, a.n, a.state.data_ptr(), lr, target, tau, scat.data_ptr(), scat_t, s)
+                      n_slabs, a.n, a.n, a.state.data_ptr(), lr, target, tau, scat.data_ptr(), scat_t, n_al, al_off,
+                      al_dst, s)
             return
         n_extra = 0 if extra is None else extra.numel()
         xb = self._exchange_buf("g%d" % id(a), a.n + 4)
@@ -317,7 +324,7 @@ class SAC_CBF_CLF(object):
         if before_step is not None:
             before_step(xb.data_ptr())
         _lib.call("nlbac_adam_fused", a.theta.data_ptr(), a.m.data_ptr(), a.v.data_ptr(), xb.data_ptr(), 1, a.n, a.n,
-                  a.state.data_ptr(), lr, target, tau, scat.data_ptr(), scat_t, s)
+                  a.state.data_ptr(), lr, target, tau, scat.data_ptr(), scat_t, n_al, al_off, al_dst, s)
 
     # ------------------------------------------------------------------ utils
     def repack_all(self):
@@ -649,11 +656,29 @@ class SAC_CBF_CLF(object):
         ws.plan[NP] = P
         return P
 
+    def auglag_fused(self, ws, n_cbf, lam_upd):
+        """The (fused, ticket, sc) tail of a ``*_constraints_fwd`` call: on one GPU the launch's last workgroup runs the
+        augmented-Lagrangian step (``nlbac_auglag``) itself; under data parallelism the sums are all-reduced first."""
+        if self.world > 1:
+            return None, None, None
+        A = _lib.AuglagArgs()
+        A.n_cbf, A.n_clf, A.batch_size = n_cbf, 1, float(self.batch_size)
+        A.do_lambda_update, A.do_backup_lambda_update = lam_upd, ws.blam_upd
+        A.ratio_mode = self.task.ratio_mode
+        A.backup_mode = self.task.backup_mode if ws.np_now == 2 else 0
+        A.lam_lo, A.lam_hi = 0.01, self.task.lam_hi
+        ws._auglag_args = A          # (kept alive until the call has been made)
+        return C.byref(A), self._tickets.data_ptr() + 4 * 12, self.sc.data_ptr()
+
     def auglag(self, ws, n_cbf, lam_upd):
         """required_matrix, ratio, lambda / rho updates and loss coefficients from the constraint partial sums
-        (all-reduced first under data parallelism: they enter the loss nonlinearly)."""
+        (all-reduced first under data parallelism: they enter the loss nonlinearly).  Single GPU: already done by the
+        constraints launch (``auglag_fused``)."""
         s, call = stream_ptr(), _lib.call
         NP = ws.np_now
+        if self.world == 1:
+            ws.p_part_q, ws.n_part_q = ws.part_q.data_ptr(), ws.nblk
+            return
         ncol = n_cbf + 1 + (n_cbf if NP == 2 else 0)
         p_part_c, n_part = ws.part_c.data_ptr(), ws.nblk
         ws.p_part_q, ws.n_part_q = ws.part_q.data_ptr(), ws.nblk
@@ -771,17 +796,22 @@ class SAC_CBF_CLF(object):
 
     def _part1_targets(self, ws, P, B, G, LD, s):
         sc, call = self.sc.data_ptr(), _lib.call
+        one = self.world == 1
         call("nlbac_mlp_fwd", P.n_six, P.io_six, P.n_six_count, B, s)
         q = ws.q6
         call("nlbac_td_targets", q[0].data_ptr(), q[1].data_ptr(), q[2].data_ptr(), ws.nlogp.data_ptr(),
              P.p_rew, P.p_con, P.p_mask, LD, q[3].data_ptr(), q[4].data_ptr(), q[5].data_ptr(),
              sc + 4 * SC.SC_ALPHA, self.gamma, B, G, ws.dq3[0].data_ptr(), ws.dq3[1].data_ptr(), ws.dq3[2].data_ptr(),
-             ws.next_q.data_ptr(), ws.next_l.data_ptr(), ws.part_td.data_ptr(), s)
-        call("nlbac_sum_partials", ws.part_td.data_ptr(), ws.nblk, 3, 1.0 / G, sc + 4 * SC.SC_QF1, s)
+             ws.next_q.data_ptr(), ws.next_l.data_ptr(), ws.part_td.data_ptr(),
+             *((self._tickets.data_ptr(), 1.0 / G, sc + 4 * SC.SC_QF1) if one else (None, 0.0, None)), s)
+        if not one:       # (single GPU: the launch's last workgroup has summed the three losses itself)
+            call("nlbac_sum_partials", ws.part_td.data_ptr(), ws.nblk, 3, 1.0 / G, sc + 4 * SC.SC_QF1, s)
         for k in range(len(self.h_extra)):      # barrier TD step (NU/sac_cbf_clf.py:224-233)
             call("nlbac_td_value", q[6 + 2 * k].data_ptr(), ws.mb.data_ptr() + 4 * self.lay.sig, LD, P.p_mask, LD,
-                 q[7 + 2 * k].data_ptr(), self.gamma, B, G, ws.dq3[3 + k].data_ptr(), None, ws.part_tdx[k].data_ptr(), s)
-            call("nlbac_sum_partials", ws.part_tdx[k].data_ptr(), ws.nblk, 1, 1.0 / G, sc + 4 * SC.SC_XLOSS, s)
+                 q[7 + 2 * k].data_ptr(), self.gamma, B, G, ws.dq3[3 + k].data_ptr(), None, ws.part_tdx[k].data_ptr(),
+                 *((self._tickets.data_ptr() + 4 * (1 + k), 1.0 / G, sc + 4 * SC.SC_XLOSS) if one else (None, 0.0, None)), s)
+            if not one:
+                call("nlbac_sum_partials", ws.part_tdx[k].data_ptr(), ws.nblk, 1, 1.0 / G, sc + 4 * SC.SC_XLOSS, s)
 
         # ---- B. critic / Lyapunov backward + Adam (+ Polyak targets) ---------------
         call("nlbac_mlp_bwd_data", P.n_crit, P.io_crit, len(self.h_crit), B, s)
@@ -796,8 +826,20 @@ class SAC_CBF_CLF(object):
         # ---- C. actors: Q(s, pi) with the stepped critics (the rollout was started in phase A) -----
         sc, call = self.sc.data_ptr(), _lib.call
         call("nlbac_mlp_fwd", P.n_q5, P.io_q5, P.n_q5_count, B, s)
+        fused = None
+        if self.world == 1:      # policy_loss_1 / alpha losses / d log_alpha by the launch's last workgroup (nlbac_actor_scalars)
+            fused = P.__dict__.get("actor_scalars")
+            if fused is None:
+                fused = P.actor_scalars = _lib.ActorScalarArgs()
+                fused.target_entropy, fused.sc = self.target_entropy, sc
+                for g in self.actor_groups:
+                    for k in range(min(g.count, NP - g.first)):
+                        off = g.la_off + k * g.la_stride
+                        fused.log_alpha[g.first + k] = g.arena.theta.data_ptr() + 4 * off
+                        fused.g_log_alpha[g.first + k] = g.arena.grad.data_ptr() + 4 * off
         call("nlbac_actor_q_terms", ws.qpi[0].data_ptr(), ws.qpi[1].data_ptr(), ws.logp2.data_ptr(),
-             sc + 4 * SC.SC_ALPHA, B, G, NP, ws.dq_pi[0].data_ptr(), ws.dq_pi[1].data_ptr(), ws.part_q.data_ptr(), s)
+             sc + 4 * SC.SC_ALPHA, B, G, NP, ws.dq_pi[0].data_ptr(), ws.dq_pi[1].data_ptr(), ws.part_q.data_ptr(),
+             C.byref(fused) if fused is not None else None, self._tickets.data_ptr() + 4 * 8 if fused is not None else None, s)
 
     def _upd_part2(self, ws, lam_upd, assume_single):
         """Constraints, augmented-Lagrangian scalars, the whole actor backward and the actor Adam step."""
@@ -827,16 +869,19 @@ class SAC_CBF_CLF(object):
 
             def alpha_grads(p_grad, g=g, cnt=cnt, la=la):
                 # policy_loss_1 / alpha losses from the (global) partial sums; d log_alpha goes straight into
-                # the gradient the Adam step reads (it is already a global mean: it must not be all-reduced)
-                call("nlbac_actor_scalars", p_part_q, n_part, G, g.first, cnt, self.target_entropy, la, g.la_stride,
-                     p_grad + 4 * g.la_off, sc, s)
+                # the gradient the Adam step reads (it is already a global mean: it must not be all-reduced).
+                # Single GPU: nlbac_actor_q_terms has done this in its own launch.
+                if self.world > 1:
+                    call("nlbac_actor_scalars", p_part_q, n_part, G, g.first, cnt, self.target_entropy, la, g.la_stride,
+                         p_grad + 4 * g.la_off, sc, s)
                 if not tune:
                     z = torch.zeros(1, device=self.device)
                     for off in [g.la_off + k * g.la_stride for k in range(cnt)]:
                         call("nlbac_axpby", 0.0, z.data_ptr(), 0.0, None, 1, p_grad + 4 * off, s)
-            self._adam(a, self.lr, a.n_slabs, before_step=alpha_grads)
-            if tune:
-                call("nlbac_alpha_refresh", la, g.la_stride, g.first, cnt, sc, s)
+            # (alpha = exp(log_alpha) is refreshed by the thread of the Adam step that moves log_alpha)
+            refresh = ([g.la_off + k * g.la_stride for k in range(cnt)],
+                       [sc + 4 * (SC.SC_ALPHA + g.first + k) for k in range(cnt)]) if tune else None
+            self._adam(a, self.lr, a.n_slabs, before_step=alpha_grads, alpha=refresh)
 
     # ------------------------------------------------------------ checkpoints
     def save_model(self, output):

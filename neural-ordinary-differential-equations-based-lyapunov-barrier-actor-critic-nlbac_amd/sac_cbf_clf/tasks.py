@@ -144,7 +144,7 @@ class UnicycleTask(_Task):
         r_coll = 1.05 * float(self.env.hazards_radius)
         call("nlbac_unicycle_constraints_fwd", ws.ps.data_ptr(), ws.ps_next2.data_ptr(), ws.V.data_ptr(),
              ws.Vn.data_ptr(), self.hazards.data_ptr(), self.num_cbfs, r_coll, dt, float(a.gamma_b), self.gamma_l, B,
-             ws.matr.data_ptr(), ws.bmatr.data_ptr(), ws.part_c.data_ptr(), s)
+             ws.matr.data_ptr(), ws.bmatr.data_ptr(), ws.part_c.data_ptr(), *a.auglag_fused(ws, self.num_cbfs, lam_upd), s)
         a.auglag(ws, self.num_cbfs, lam_upd)
         call("nlbac_unicycle_constraints_bwd", ws.ps_next2.data_ptr(), ws.matr.data_ptr(), ws.bmatr.data_ptr(),
              self.hazards.data_ptr(), self.num_cbfs, dt, float(a.batch_size), B, sc, ws.dps_next2.data_ptr(),
@@ -260,7 +260,8 @@ class UnicycleBarrierTask(UnicycleTask):
              pol.action_bias.data_ptr(), 2, B, ws.pi_next.data_ptr(), 2, ws.logp_nx.data_ptr(), s)
         call("nlbac_mlp_fwd", P.n_bar, P.io_bn, 1, B, s)
         call("nlbac_barrier_constraints_fwd", ws.Bv.data_ptr(), ws.Bn.data_ptr(), ws.V.data_ptr(), ws.Vn.data_ptr(),
-             dt, float(a.gamma_b), self.gamma_l, B, ws.matr.data_ptr(), ws.part_c.data_ptr(), s)
+             dt, float(a.gamma_b), self.gamma_l, B, ws.matr.data_ptr(), ws.part_c.data_ptr(),
+             *a.auglag_fused(ws, 1, lam_upd), s)
         a.auglag(ws, 1, lam_upd)
         call("nlbac_barrier_constraints_bwd", ws.matr.data_ptr(), dt, float(a.batch_size), B, sc, ws.dBn.data_ptr(),
              ws.dVn.data_ptr(), s)
@@ -358,7 +359,7 @@ class CarsTask(_Task):
         call("nlbac_mlp_fwd", P.n_l, P.io_v1, 1, B, s)
         call("nlbac_cars_constraints_fwd", ws.state.data_ptr(), ws.x1_2.data_ptr(), x2.data_ptr(), ws.V.data_ptr(),
              ws.V1.data_ptr(), float(a.gamma_b), self.gamma_l, self.collision_radius, B, ws.matr.data_ptr(),
-             ws.bmatr.data_ptr(), ws.part_c.data_ptr(), s)
+             ws.bmatr.data_ptr(), ws.part_c.data_ptr(), *a.auglag_fused(ws, self.num_cbfs, lam_upd), s)
         a.auglag(ws, self.num_cbfs, lam_upd)
         call("nlbac_cars_constraints_bwd", ws.matr.data_ptr(), ws.bmatr.data_ptr(), float(a.gamma_b),
              float(a.batch_size), B, sc, ws.dx1.data_ptr(), ws.dx2.data_ptr(), ws.dV1.data_ptr(), s)
@@ -519,7 +520,7 @@ class PvtolTask(_Task):
              ws.x3.data_ptr(), ws.V.data_ptr(), ws.V1.data_ptr(), hz, len(env.hazard_locations),
              1.2 * float(env.hazards_radius), 0.9 * float(env.operator_dist), float(env.y_max), float(env.y_min),
              follow, float(a.gamma_b), self.gamma_l, B, NP, ws.matr.data_ptr(), ws.bmatr.data_ptr(),
-             ws.part_c.data_ptr(), s)
+             ws.part_c.data_ptr(), *a.auglag_fused(ws, self.num_cbfs, lam_upd), s)
         a.auglag(ws, self.num_cbfs, lam_upd)
         call("nlbac_pvtol_constraints_bwd", ws.matr.data_ptr(), ws.bmatr.data_ptr(), ws.x1.data_ptr(),
              ws.x2.data_ptr(), ws.x3.data_ptr(), hz, len(env.hazard_locations), follow, float(a.gamma_b),
@@ -653,7 +654,8 @@ class PvtolBarrierTask(PvtolTask):
              pol.action_bias.data_ptr(), 2, B, ws.pi_next.data_ptr(), 2, ws.logp_nx.data_ptr(), s)
         call("nlbac_mlp_fwd", P.n_bar, P.io_bn, 1, B, s)
         call("nlbac_barrier_constraints_fwd", ws.Bv.data_ptr(), ws.Bn.data_ptr(), ws.V.data_ptr(), ws.V1.data_ptr(),
-             1.0, float(a.gamma_b), self.gamma_l, B, ws.matr.data_ptr(), ws.part_c.data_ptr(), s)
+             1.0, float(a.gamma_b), self.gamma_l, B, ws.matr.data_ptr(), ws.part_c.data_ptr(),
+             *a.auglag_fused(ws, 1, lam_upd), s)
         a.auglag(ws, 1, lam_upd)
         call("nlbac_barrier_constraints_bwd", ws.matr.data_ptr(), 1.0, float(a.batch_size), B, sc, ws.dBn.data_ptr(),
              ws.dV1.data_ptr(), s)
@@ -752,7 +754,8 @@ class QuadrotorBarrierTask(PvtolBarrierTask):
              pol.action_bias.data_ptr(), 2, B, ws.pi_next.data_ptr(), 2, ws.logp_nx.data_ptr(), s)
         call("nlbac_mlp_fwd", P.n_bar, P.io_bn, 1, B, s)
         call("nlbac_barrier_constraints_fwd", ws.Bv.data_ptr(), ws.Bn.data_ptr(), ws.V.data_ptr(), ws.V1.data_ptr(),
-             1.0, float(a.gamma_b), self.gamma_l, B, ws.matr.data_ptr(), ws.part_c.data_ptr(), s)
+             1.0, float(a.gamma_b), self.gamma_l, B, ws.matr.data_ptr(), ws.part_c.data_ptr(),
+             *a.auglag_fused(ws, 1, lam_upd), s)
         a.auglag(ws, 1, lam_upd)
         call("nlbac_barrier_constraints_bwd", ws.matr.data_ptr(), 1.0, float(a.batch_size), B, sc, ws.dBn.data_ptr(),
              ws.dV1.data_ptr(), s)

@@ -159,7 +159,7 @@ def test_multi_net_launch_and_adam_soft_update(fused):
             scat, scat_t = ar.scatter_tables()
             _lib.call("nlbac_adam_fused", ar.theta.data_ptr(), ar.m.data_ptr(), ar.v.data_ptr(), ar.grad.data_ptr(),
                       ar.n_slabs, ar.n, ar.n, ar.state.data_ptr(), lr, ar.target.data_ptr(), tau, scat.data_ptr(),
-                      scat_t.data_ptr(), s)
+                      scat_t.data_ptr(), 0, None, None, s)
         else:
             _lib.call("nlbac_adam_prepare", ar.state.data_ptr(), lr, s)
             _lib.call("nlbac_adam_step", ar.theta.data_ptr(), ar.m.data_ptr(), ar.v.data_ptr(), ar.grad.data_ptr(),
