@@ -495,6 +495,31 @@ int nlbac_gather_rows(const float *src, long src_rows, int ld, const long *idx, 
 int nlbac_sample_rows(const float *src, long src_rows, int ld, long n_rows, float *dst, float *eps, long n_eps,
                       unsigned long long seed, unsigned long long draw, nlbac_stream_t s);
 
+/* ------------------------------------------------------------------------
+ * Batched device simulators (row f3): n independent environments advanced by one launch, one lane each, float64 like
+ * the reference's numpy simulators — U/envs/unicycle_env.py:57-152 (+ barrier signal NU/envs/unicycle_env.py:116-144),
+ * P/envs/pvtol_env.py:85-216 (+ NP/envs/pvtol_env.py:144-220), C/envs/simulated_cars_env.py:66-146.  All arrays are
+ * float64 device arrays (ep_step / done: int32); `state`, `ep_step`, `last_dist` / `t` are advanced in place; every
+ * other array is an output of the step: obs, reward, constraint, barrier signal, the Lyapunov inputs before / after the
+ * step, done, info = [goal_met | reached, number of safety violations, safety cost] per environment.
+ * ---------------------------------------------------------------------- */
+int nlbac_unicycle_env_step(int n, const double *params /* dt, goal x, goal y, goal size, goal reward, hazard radius,
+                            l_p, barrier signal off, barrier signal on */, int max_steps, const double *hazards,
+                            int n_hz, const double *action /*(n,2)*/, double *state /*(n,3)*/, int *ep_step,
+                            double *last_dist, double *obs /*(n,7)*/, double *reward, double *constraint, double *signal,
+                            double *center /*(n,2)*/, double *next_center /*(n,2)*/, int *done, double *info /*(n,3)*/,
+                            nlbac_stream_t s);
+int nlbac_pvtol_env_step(int n, const double *params /* dt, goal x, goal y, goal size, goal reward, hazard radius,
+                         operator follow, barrier signal off, barrier signal on */, int max_steps,
+                         const double *hazards, int n_hz, const double *action /*(n,2)*/, double *state /*(n,7)*/,
+                         int *ep_step, double *obs /*(n,11)*/, double *reward, double *constraint, double *signal,
+                         double *lya_pre /*(n,11): the observation before the step*/, int *done, double *info,
+                         nlbac_stream_t s);
+int nlbac_cars_env_step(int n, const double *params /* dt, kp, k_brake, should_keep, keep threshold, goal reward */,
+                        int max_steps, const double *action /*(n)*/, double *state /*(n,10)*/, double *t, int *ep_step,
+                        double *obs /*(n,10)*/, double *reward, double *constraint, double *lya_pre /*(n,4)*/,
+                        double *lya_next /*(n,4)*/, int *done, double *info, nlbac_stream_t s);
+
 /* small utilities */
 int nlbac_axpby(float a, const float *x, float b, const float *y /*or NULL*/, long n, float *out, nlbac_stream_t s);
 int nlbac_fill(float *p, float v, long n, nlbac_stream_t s);

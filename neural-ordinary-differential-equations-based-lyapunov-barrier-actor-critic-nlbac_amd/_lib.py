@@ -142,6 +142,9 @@ _PROTOS = {
     "nlbac_dopri_control": [_P, _I, _I, _I, _I, _I, _I, _D, _P, _I, _P, _P, _I, _P],
     "nlbac_dopri_interp_fwd": [_P, _P, _P, c_float_p, c_float_p, _P, _I, _I, _I, _P, _L, _P],
     "nlbac_dopri_interp_bwd": [_P, c_float_p, c_float_p, _P, _I, _I, _I, _P, _P, _P, _L, _P],
+    "nlbac_unicycle_env_step": [_I, c_double_p, _I] + [_P, _I] + [_P] * 13,
+    "nlbac_pvtol_env_step": [_I, c_double_p, _I] + [_P, _I] + [_P] * 11,
+    "nlbac_cars_env_step": [_I, c_double_p, _I] + [_P] * 12,
     "nlbac_axpby": [_F, _P, _F, _P, _L, _P, _P],
     "nlbac_fill": [_P, _F, _L, _P],
     "nlbac_sum_partials": [_P, _I, _I, _F, _P, _P],
