@@ -70,6 +70,9 @@ __global__ __launch_bounds__(512, OCC ? 4 : 2) void node_rk_fwd_kernel(const Nod
     __shared__ unsigned s_gcnt[2];            // per-group barrier counters (GroupBar): f_net / g_net run decoupled
     if (tid < 2) s_gcnt[tid] = 0u;            // between the stage boundaries (visible after the prologue barrier)
     GroupBar gbar{&s_gcnt[grp], 0u, 4u};
+#ifdef EXP_PRIO
+    if (grp == 0) __builtin_amdgcn_s_setprio(EXP_PRIO);
+#endif
     const int n = L.n, ns = L.n_s, nu = L.n_u, LD = L.ld;
     const int row0 = blockIdx.x * NLBAC_MLP_TILE;
     // device-driven chain: this tile's problem (tiles do not straddle problems there), its step slot, FSAL source
@@ -368,6 +371,9 @@ __global__ __launch_bounds__(512) void node_rk_bwd_kernel(const NodeRkBwdLaunch 
     __shared__ unsigned s_gcnt[2];            // per-group barrier counters, as in the forward kernel
     if (tid < 2) s_gcnt[tid] = 0u;
     GroupBar gbar{&s_gcnt[grp], 0u, 4u};
+#ifdef EXP_PRIO
+    if (grp == 0) __builtin_amdgcn_s_setprio(EXP_PRIO);
+#endif
     const int n = L.n, ns = L.n_s, nu = L.n_u, LD = L.ld, gout = ns * nu;
     const int row0 = blockIdx.x * NLBAC_MLP_TILE;
     long soff = 0;

@@ -1,0 +1,17 @@
+#!/bin/bash
+# Build an experiment variant of the HIP library next to the product one (never loaded unless NLBAC_HIP_LIB names it):
+#   tools/build_variant.sh <name> "<extra hipcc flags, e.g. -DEXP_FOO>"   ->  <pkg>/lib/variants/libnlbac_hip_<name>.so
+set -e
+ROOT="$(cd "$(dirname "$0")/.." && pwd)"
+SRC=$(echo "$ROOT"/neural-*-nlbac_amd/csrc)
+OUT=$(echo "$ROOT"/neural-*-nlbac_amd/lib)/variants
+NAME=$1; shift
+TMP=$(mktemp -d)
+mkdir -p "$OUT"
+for f in mlp_kernels node_kernels node_adjoint_kernels concat_node_kernels optim_kernels agent_kernels ode_kernels env_kernels; do
+  /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -fPIC -std=c++17 -Wno-unused-function -I"$ROOT"/include -I"$SRC" "$@" -c "$SRC/$f.hip" -o "$TMP/$f.o" &
+done
+wait
+/opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC "$TMP"/*.o -o "$OUT/libnlbac_hip_$NAME.so"
+rm -rf "$TMP"
+echo "$OUT/libnlbac_hip_$NAME.so"

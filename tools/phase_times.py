@@ -40,6 +40,8 @@ for l in range(4):
     a = d[l]
     print("  layer %d: %6d | %6d | %6d   (layer total %6d)" % (l, a[1] - a[0], a[2] - a[1], a[3] - a[2], a[3] - a[0]))
 
+if os.environ.get("PHASE_FWD_ONLY"):
+    sys.exit(0)
 # ---- backward phases (mask mode): stamps come back through the dz_g pointer in the timing build
 import nlbac_amd.odeint as od
 dout = torch.randn(n, 3).cuda()
