@@ -118,7 +118,11 @@ int nlbac_adam_fused(float *p, float *m, float *v, const float *grad, int n_slab
                      const void *scatter_target,
                      int n_alpha /* 0..2 temperatures refreshed by the step itself: alpha_dst[k][0] = exp(p[alpha_off[k]])
                                     after the step (sac_cbf_clf.py:297, 308) */,
-                     const long *alpha_off, float *const *alpha_dst, nlbac_stream_t s);
+                     const long *alpha_off, float *const *alpha_dst,
+                     const float *mirror_src, float *mirror_dst /* or NULL: pinned HOST memory; the step's last workgroup
+                        writes mirror_src[0..n_mirror) there (the scalars block incl. the refreshed temperatures), so the
+                        update's last launch hands its results to the host itself (sac_cbf_clf.py:312-319 `.item()`s) */,
+                     int n_mirror, nlbac_stream_t s);
 int nlbac_reduce_slabs(float *out, const float *grad, int n_slabs, long slab_stride, long n, nlbac_stream_t s);
 int nlbac_soft_update(float *target, const float *src, long n, float tau, nlbac_stream_t s);
 
@@ -416,12 +420,22 @@ int nlbac_dopri_control(const float *partials, int n_blk_per_problem, int mode, 
 /* y(t_end) from the accepted step's stages (4th-order interpolant, x=(t_end-t)/h) and its backward
  * (writes dy0, dy1, dK[0..6]).  h and x come from the device control block `ctl` (h_used, x) when it is
  * non-NULL — hipGraph-replay safe — else from the host arrays. */
+/* Optional per-row map of the solve's output, evaluated inside the two interpolation launches instead of in launches
+ * of its own.  kind 1 = the Unicycle tasks' look-ahead point (sac_cbf_clf.py:439-447; same arithmetic as
+ * nlbac_unicycle_lookahead / nlbac_unicycle_lookahead_bwd): forward also writes p (n, 2); backward takes
+ * d loss / d p = dp (+ dp2) and the forward's output x instead of `dout` (which may then be NULL). */
+typedef struct nlbac_out_map {
+    int kind;            /* 0: none */
+    float l;             /* look-ahead distance */
+    float *p;            /* forward */
+    const float *dp, *dp2, *x;   /* backward (dp2 may be NULL) */
+} nlbac_out_map;
 int nlbac_dopri_interp_fwd(const float *y0, const float *y1, const float *K, const float *h_host,
                            const float *x_host, const double *ctl, int P, int rows_per_problem, int n_s,
-                           float *out, long slot_floats, nlbac_stream_t s);
+                           float *out, long slot_floats, const nlbac_out_map *map /* or NULL */, nlbac_stream_t s);
 int nlbac_dopri_interp_bwd(const float *dout, const float *h_host, const float *x_host, const double *ctl,
                            int P, int rows_per_problem, int n_s, float *dy0, float *dy1, float *dK,
-                           long slot_floats, nlbac_stream_t s);
+                           long slot_floats, const nlbac_out_map *map /* or NULL */, nlbac_stream_t s);
 /* (slot_floats != 0: y1 / K resp. dy0 / dy1 / dK are slot 0's pointers of a device-driven chain and the step
  * interpolated is the one in slot ctl[12]; its y0 is the predecessor slot's y1.) */
 

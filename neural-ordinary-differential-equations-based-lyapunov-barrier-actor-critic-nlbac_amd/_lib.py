@@ -66,6 +66,12 @@ class RkChain(C.Structure):
                 ("alog_cap", C.c_int)]
 
 
+class OutMap(C.Structure):
+    """``struct nlbac_out_map``"""
+    _fields_ = [("kind", C.c_int), ("l", C.c_float), ("p", C.c_void_p), ("dp", C.c_void_p), ("dp2", C.c_void_p),
+                ("x", C.c_void_p)]
+
+
 _P, _I, _F, _D, _L = C.c_void_p, C.c_int, C.c_float, C.c_double, C.c_long
 
 # name -> argtypes (return type is always int unless listed in _RESTYPE)
@@ -80,7 +86,8 @@ _PROTOS = {
     "nlbac_mlp_bwd_weights": [C.POINTER(Mlp), C.POINTER(MlpIO), _I, _I, _I, _L, _P, _L, _P],
     "nlbac_adam_prepare": [_P, _D, _P],
     "nlbac_adam_step": [_P, _P, _P, _P, _I, _L, _L, _P, _P, _F, _P],
-    "nlbac_adam_fused": [_P, _P, _P, _P, _I, _L, _L, _P, _D, _P, _F, _P, _P, _I, C.POINTER(C.c_long), C.POINTER(C.c_void_p), _P],
+    "nlbac_adam_fused": [_P, _P, _P, _P, _I, _L, _L, _P, _D, _P, _F, _P, _P, _I, C.POINTER(C.c_long), C.POINTER(C.c_void_p),
+                         _P, _P, _I, _P],
     "nlbac_reduce_slabs": [_P, _P, _I, _L, _L, _P],
     "nlbac_soft_update": [_P, _P, _L, _F, _P],
     "nlbac_gauss_sample_fwd": [_P, _I, _P, _P, _P, _I, _I, _P, _I, _P, _P],
@@ -140,8 +147,8 @@ _PROTOS = {
     "nlbac_dopri_norm_partials": [_P, _P, _P, _P, _P, _I, _F, _F, _I, _I, _I, _I, _P, _P, _L, _P],
     "nlbac_dopri_norm_control": [_P, _P, _P, _P, _P, _I, _F, _F, _I, _I, _I, _I, _D, _P, _P, _P, C.POINTER(RkChain), _P],
     "nlbac_dopri_control": [_P, _I, _I, _I, _I, _I, _I, _D, _P, _I, _P, _P, _I, _P],
-    "nlbac_dopri_interp_fwd": [_P, _P, _P, c_float_p, c_float_p, _P, _I, _I, _I, _P, _L, _P],
-    "nlbac_dopri_interp_bwd": [_P, c_float_p, c_float_p, _P, _I, _I, _I, _P, _P, _P, _L, _P],
+    "nlbac_dopri_interp_fwd": [_P, _P, _P, c_float_p, c_float_p, _P, _I, _I, _I, _P, _L, C.POINTER(OutMap), _P],
+    "nlbac_dopri_interp_bwd": [_P, c_float_p, c_float_p, _P, _I, _I, _I, _P, _P, _P, _L, C.POINTER(OutMap), _P],
     "nlbac_unicycle_env_step": [_I, c_double_p, _I] + [_P, _I] + [_P] * 13,
     "nlbac_pvtol_env_step": [_I, c_double_p, _I] + [_P, _I] + [_P] * 11,
     "nlbac_cars_env_step": [_I, c_double_p, _I] + [_P] * 12,

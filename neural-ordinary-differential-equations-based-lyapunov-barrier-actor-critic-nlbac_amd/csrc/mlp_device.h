@@ -35,7 +35,7 @@ __device__ __forceinline__ int acc_row(int r, int h) { return (r & 3) + 8 * (r >
     if (NTW == 2) acc[1] = MFMA1((A).w, (B1).w, acc[1]);
 
 // One wave's B-operand (weight) fragments form a stream that does not depend on the activations:
-// chunk 0..KC-1 of this layer, then chunk 0.. of the next layer.  WaveGemm keeps four chunks of it
+// chunk 0..KC-1 of this layer, then chunk 0.. of the next layer.  WaveGemm keeps B_DEPTH chunks of it
 // in statically indexed registers; while a layer's last chunks are being multiplied the freed slots
 // are refilled with the NEXT layer's first chunks, so after the inter-layer barrier the MFMAs start
 // on registers that are already loaded (only the LDS-resident A fragments are fetched then).
@@ -48,16 +48,24 @@ struct NextFrags {
     __device__ __forceinline__ const float4* at1(int i) const { return (i < KCn) ? n1 + (long)i * 64 : nn1 + (long)min(i, KCnn - 1) * 64; }
 };
 
-template <int NTW>
+// D: chunks of the weight stream in flight per column tile (a refill is issued behind its slot's MFMAs and needed D - 1
+// chunks later).  Four is enough: tools/micro/gemm_loop.hip (MI355X) — a lone one-tile wave runs a 100-wide layer's 52
+// MFMAs in 4.9k cycles (3.3k being the MFMA time, 3.8k with the weight loads compiled out) with four chunks in flight
+// and in 5.2k with eight, so the gap is the wave's own load / LDS instruction issue between its MFMAs, not latency;
+// two waves sharing a SIMD fill each other's gaps (6.5k for both GEMMs = the MFMA rate), which is how the kernels run.
+#ifndef NLBAC_B_DEPTH1
+#define NLBAC_B_DEPTH1 4
+#endif
+template <int NTW, int D = (NTW == 1) ? NLBAC_B_DEPTH1 : 4>
 struct WaveGemm {
-    float4 b0[4], b1[4];
+    float4 b0[D], b1[(NTW == 2) ? D : 1];
 
     // slot i <- chunk i of this layer, or the upcoming stream's slot-i fragment when this layer is shorter
     __device__ __forceinline__ void prime(const float4* p0, const float4* p1, int KC, const NextFrags& nx) {
 #pragma unroll
-        for (int i = 0; i < 4; ++i) {
+        for (int i = 0; i < D; ++i) {
             b0[i] = *((i < KC) ? p0 + (long)i * 64 : nx.at0(i));
-            b1[i] = (NTW == 2) ? *((i < KC) ? p1 + (long)i * 64 : nx.at1(i)) : make_float4(0, 0, 0, 0);
+            if (NTW == 2) b1[i] = *((i < KC) ? p1 + (long)i * 64 : nx.at1(i));
         }
     }
 
@@ -70,26 +78,27 @@ struct WaveGemm {
 #pragma unroll
         for (int i = 0; i < 4; ++i) a[i] = *reinterpret_cast<const float4*>(arow + min(i, last) * 8);
         int kc = 0;
-        for (; kc + 4 <= KC; kc += 4) {
+        for (; kc + D <= KC; kc += D) {
 #pragma unroll
-            for (int i = 0; i < 4; ++i) {
-                MFMA4(a[i], b0[i], b1[i])
-                const int c = kc + i + 4;
+            for (int i = 0; i < D; ++i) {
+                MFMA4(a[i & 3], b0[i], b1[(NTW == 2) ? i : 0])
 #ifndef EXP_NO_BLOAD          // (ablation: MFMAs run on stale weight registers, no L2 traffic)
+                const int c = kc + i + D;
                 const bool here = c <= last;
                 b0[i] = *(here ? p0 + (long)c * 64 : nx.at0(i));
                 if (NTW == 2) b1[i] = *(here ? p1 + (long)c * 64 : nx.at1(i));
 #endif
-                a[i] = *reinterpret_cast<const float4*>(arow + min(c, last) * 8);
+                a[i & 3] = *reinterpret_cast<const float4*>(arow + min(kc + i + 4, last) * 8);
                 __builtin_amdgcn_sched_barrier(0);   // keep each slot's refill right behind its MFMAs
             }
         }
 #pragma unroll
-        for (int i = 0; i < 3; ++i)
+        for (int i = 0; i < D - 1; ++i)
             if (kc + i < KC) {
-                MFMA4(a[i], b0[i], b1[i])
+                MFMA4(a[i & 3], b0[i], b1[(NTW == 2) ? i : 0])
                 b0[i] = *nx.at0(i);
                 if (NTW == 2) b1[i] = *nx.at1(i);
+                if (i + 4 < D - 1) a[i & 3] = *reinterpret_cast<const float4*>(arow + min(kc + i + 4, last) * 8);
             }
     }
 };
@@ -170,8 +179,8 @@ __device__ __forceinline__ NextFrags fwd_next(const nlbac_mlp& net, int l, int i
     return nx;
 }
 
-template <int NTW>
-__device__ __forceinline__ void fwd_prime(WaveGemm<NTW>& wg, const nlbac_mlp& net, int inp, bool wrap, int wave,
+template <int NTW, int D>
+__device__ __forceinline__ void fwd_prime(WaveGemm<NTW, D>& wg, const nlbac_mlp& net, int inp, bool wrap, int wave,
                                           int lane) {
     const int KC = inp >> 3;
     wg.prime(frag_ptr(net.packed, net.pf_off[0], KC, wave, lane),
@@ -195,12 +204,16 @@ __device__ __forceinline__ void tile_sync(GroupBar* gb, int lane) {
     if (lane == 0) __hip_atomic_fetch_add(gb->cnt, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
     while ((int)(__builtin_amdgcn_readfirstlane(
                      __hip_atomic_load(gb->cnt, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP)) - gb->target) < 0)
+#ifdef EXP_NOSLEEP
+        ;
+#else
         __builtin_amdgcn_s_sleep(1);
+#endif
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
 }
 
-template <int NTW, int BITS = 0>
-__device__ __forceinline__ void fwd_wide_layers(WaveGemm<NTW>& wg, const nlbac_mlp& net, bool active, int wave, int lane,
+template <int NTW, int BITS = 0, int D = 4>
+__device__ __forceinline__ void fwd_wide_layers(WaveGemm<NTW, D>& wg, const nlbac_mlp& net, bool active, int wave, int lane,
                                                 int LD, int inp, float*& in, float*& out, float* acts_tile,
                                                 long acts_ls, int n_rows, int nwide_run, bool wrap,
                                                 long long* dbg = nullptr /* ablation builds: per-layer clock stamps */,
@@ -310,8 +323,8 @@ __device__ __forceinline__ NextFrags bwd_next(const nlbac_mlp& net, int j, int w
     return nx;
 }
 
-template <int NTW>
-__device__ __forceinline__ void bwd_prime(WaveGemm<NTW>& wg, const nlbac_mlp& net, int wave, int lane,
+template <int NTW, int D>
+__device__ __forceinline__ void bwd_prime(WaveGemm<NTW, D>& wg, const nlbac_mlp& net, int wave, int lane,
                                           bool wrap = false) {
     const int nwide = net.n_layers - 1, KC = pad8(net.hid) >> 3;
     if (nwide < 2) return;
@@ -321,8 +334,8 @@ __device__ __forceinline__ void bwd_prime(WaveGemm<NTW>& wg, const nlbac_mlp& ne
              bwd_next<NTW>(net, j, wave, lane, wrap));
 }
 
-template <int NTW, int BITS = 0>
-__device__ __forceinline__ void bwd_wide_layers(WaveGemm<NTW>& wg, const nlbac_mlp& net, bool active, int wave, int lane,
+template <int NTW, int BITS = 0, int D = 4>
+__device__ __forceinline__ void bwd_wide_layers(WaveGemm<NTW, D>& wg, const nlbac_mlp& net, bool active, int wave, int lane,
                                                 int LD, float*& in, float*& out, const float* acts_tile,
                                                 float* dz_tile, long ls, int n_rows, int row_clamp,
                                                 int n_run = -1, bool wrap = false, int nthr = 256,

@@ -342,11 +342,37 @@ __global__ __launch_bounds__(256, 2) void mlp_bwd_data_kernel(const MlpLaunch L)
 __device__ __forceinline__ float4 sel4(bool c, const float4 v) {   // component selects stay in registers
     return make_float4(c ? v.x : 0.f, c ? v.y : 0.f, c ? v.z : 0.f, c ? v.w : 0.f);
 }
-__global__ __launch_bounds__(256) void mlp_bwd_wide_kernel(const MlpLaunch L) {
+struct SkinnyLaunch {
+    int rows_per_chunk, n_chunks;
+    long net_stride;      // floats between nets in ws
+};
+
+__device__ __forceinline__ int skinny_nq(const nlbac_mlp& net) {
+    return (net.n_layers - 1) + net.in_dim + net.out_dim + 1;
+}
+
+__device__ __forceinline__ void skinny_reduce_block(const MlpLaunch& L, const SkinnyLaunch& S, const float* __restrict__ ws,
+                                                    int blk, int inet, float (*part)[64]);
+
+// red_planes > 0: the first red_planes z-planes of the grid are not GEMM tiles but the blocks of the skinny-gradient
+// reduction (mlp_bwd_skinny_reduce_kernel's work: independent of the GEMM, both only read what the data backward left):
+// they are dispatched first and finish under the GEMM tiles instead of in a launch of their own.  Block index within the
+// planes -> (net, reduce block) with red_per_net blocks per net.
+__global__ __launch_bounds__(256) void mlp_bwd_wide_kernel(const MlpLaunch L, const SkinnyLaunch S,
+                                                           const float* __restrict__ ws, int red_planes, int red_per_net,
+                                                           int n_nets) {
     __shared__ __attribute__((aligned(16))) float sA[2][DW_CHUNK][DW_LDS_LD];
     __shared__ __attribute__((aligned(16))) float sB[2][DW_CHUNK][DW_LDS_LD];
-    const nlbac_mlp& net = L.net[blockIdx.z];
-    const nlbac_mlp_io& io = L.io[blockIdx.z];
+    if ((int)blockIdx.z < red_planes) {
+        const int idx = ((int)blockIdx.z * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x;
+        const int inet = idx / red_per_net;
+        if (inet < n_nets)
+            skinny_reduce_block(L, S, ws, idx - inet * red_per_net, inet, reinterpret_cast<float (*)[64]>(&sA[0][0][0]));
+        return;
+    }
+    const int znet = (int)blockIdx.z - red_planes;
+    const nlbac_mlp& net = L.net[znet];
+    const nlbac_mlp_io& io = L.io[znet];
     const int B = L.B, hid = net.hid, nwide = net.n_layers - 1;
     const int T = (hid + 63) >> 6;
     const int per_layer = T * T;
@@ -547,15 +573,6 @@ __global__ __launch_bounds__(256) void mlp_bwd_wide128_kernel(const MlpLaunch L)
 #define SK_MAX_OUT 16
 #define SK_MAX_Q (NLBAC_MAX_LAYERS + SK_MAX_IN + SK_MAX_OUT + 1)
 
-struct SkinnyLaunch {
-    int rows_per_chunk, n_chunks;
-    long net_stride;      // floats between nets in ws
-};
-
-__device__ __forceinline__ int skinny_nq(const nlbac_mlp& net) {
-    return (net.n_layers - 1) + net.in_dim + net.out_dim + 1;
-}
-
 #define SK_ROWS_LDS 128
 // The row loop of one chunk for a net with NW wide layers: thread = hidden column.  Eight rows are in flight per
 // thread (8 x (NW + 1) independent loads: the loop is latency bound), none of them redundant.
@@ -669,18 +686,17 @@ __global__ __launch_bounds__(NTHR) void mlp_bwd_skinny_partial_kernel(const MlpL
     w[(long)q * 256] = dbL;
 }
 
-__global__ __launch_bounds__(256) void mlp_bwd_skinny_reduce_kernel(const MlpLaunch L, const SkinnyLaunch S,
-                                                                    const float* __restrict__ ws) {
-    const nlbac_mlp& net = L.net[blockIdx.y];
-    const nlbac_mlp_io& io = L.io[blockIdx.y];
+// block `blk` = (quantity q, 64-column quarter) of net `inet`; thread = (chunk group cg, column): the four chunk groups
+// of a block sum interleaved quarters of the chunk list, combined through LDS (`part`, 4 x 64 floats) in a fixed order
+__device__ __forceinline__ void skinny_reduce_block(const MlpLaunch& L, const SkinnyLaunch& S, const float* __restrict__ ws,
+                                                    int blk, int inet, float (*part)[64]) {
+    const nlbac_mlp& net = L.net[inet];
+    const nlbac_mlp_io& io = L.io[inet];
     const int hid = net.hid, nwide = net.n_layers - 1, idim = net.in_dim, odim = net.out_dim;
     const int nq = skinny_nq(net);
-    // block = (quantity q, 64-column quarter); thread = (chunk group cg, column): the four chunk groups of a block sum
-    // interleaved quarters of the chunk list, combined through LDS in a fixed order (deterministic)
-    __shared__ float part[4][64];
-    const int q = blockIdx.x >> 2, col = (blockIdx.x & 3) * 64 + (threadIdx.x & 63), cg = threadIdx.x >> 6;
+    const int q = blk >> 2, col = (blk & 3) * 64 + (threadIdx.x & 63), cg = threadIdx.x >> 6;
     if (q >= nq) return;
-    const float* w = ws + (long)blockIdx.y * S.net_stride + (long)q * 256 + col;
+    const float* w = ws + (long)inet * S.net_stride + (long)q * 256 + col;
     float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
     int ch = cg;
     for (; ch + 12 < S.n_chunks; ch += 16) {       // four fixed interleaved chains per chunk group
@@ -699,6 +715,12 @@ __global__ __launch_bounds__(256) void mlp_bwd_skinny_reduce_kernel(const MlpLau
     else if (q < nwide + idim) { if (col < hid) g[net.w_off[0] + (long)col * idim + (q - nwide)] = v; }
     else if (q < nwide + idim + odim) { if (col < hid) g[net.w_off[nwide] + (long)(q - nwide - idim) * hid + col] = v; }
     else if (col < odim) g[net.b_off[nwide] + col] = v;
+}
+
+__global__ __launch_bounds__(256) void mlp_bwd_skinny_reduce_kernel(const MlpLaunch L, const SkinnyLaunch S,
+                                                                    const float* __restrict__ ws) {
+    __shared__ float part[4][64];
+    skinny_reduce_block(L, S, ws, blockIdx.x, blockIdx.y, part);
 }
 
 // ---------------------------------------------------------------------------
@@ -859,6 +881,16 @@ extern "C" int nlbac_mlp_bwd_weights(const nlbac_mlp* nets, const nlbac_mlp_io* 
     int rps = nlbac_ceil_div(B, n_slabs);
     rps = (rps + DW_CHUNK - 1) / DW_CHUNK * DW_CHUNK;
     L.n_slabs = n_slabs; L.rows_per_slab = rps; L.slab_stride = slab_stride;
+    SkinnyLaunch S;
+    S.rows_per_chunk = skinny_rows_per_chunk(B);
+    S.n_chunks = (B + S.rows_per_chunk - 1) / S.rows_per_chunk;
+    S.net_stride = need / n_nets;
+    bool all_narrow = true, partials_ready = S.rows_per_chunk == NLBAC_MLP_TILE, reduced = false;
+    for (int i = 0; i < n_nets; ++i) {
+        all_narrow = all_narrow && nets[i].hid <= 128;
+        // nlbac_mlp_bwd_data has already left this net's partial sums in its block of ws (nlbac_mlp_io::skinny_ws)
+        partials_ready = partials_ready && io[i].skinny_ws == ws + (long)i * S.net_stride;
+    }
     if (max_blocks > 0) {
         bool narrow = true;
         int max_layers = 0;
@@ -875,20 +907,16 @@ extern "C" int nlbac_mlp_bwd_weights(const nlbac_mlp* nets, const nlbac_mlp_io* 
             }
             hipLaunchKernelGGL(mlp_bwd_wide128_kernel, dim3(max_layers, n_slabs, n_nets), dim3(256), lds, (hipStream_t)s, L);
         } else {
-            hipLaunchKernelGGL(mlp_bwd_wide_kernel, dim3(max_blocks, n_slabs, n_nets), dim3(256), 0, (hipStream_t)s, L);
+            // (with the partial sums already there, the skinny reduction's blocks ride behind the GEMM tiles of slab 0)
+            const int per_plane = max_blocks * n_slabs, red_per_net = max_q * 4;
+            const int red_planes = partials_ready ? (red_per_net * n_nets + per_plane - 1) / per_plane : 0;
+            hipLaunchKernelGGL(mlp_bwd_wide_kernel, dim3(max_blocks, n_slabs, n_nets + red_planes), dim3(256), 0,
+                               (hipStream_t)s, L, S, ws, red_planes, red_per_net, n_nets);
+            reduced = partials_ready;
         }
         NLBAC_CHECK_LAUNCH("nlbac_mlp_bwd_weights(wide)");
     }
-    SkinnyLaunch S;
-    S.rows_per_chunk = skinny_rows_per_chunk(B);
-    S.n_chunks = (B + S.rows_per_chunk - 1) / S.rows_per_chunk;
-    S.net_stride = need / n_nets;
-    bool all_narrow = true, partials_ready = S.rows_per_chunk == NLBAC_MLP_TILE;
-    for (int i = 0; i < n_nets; ++i) {
-        all_narrow = all_narrow && nets[i].hid <= 128;
-        // nlbac_mlp_bwd_data has already left this net's partial sums in its block of ws (nlbac_mlp_io::skinny_ws)
-        partials_ready = partials_ready && io[i].skinny_ws == ws + (long)i * S.net_stride;
-    }
+    if (reduced) return 0;
     if (partials_ready) {
     } else if (all_narrow)
         hipLaunchKernelGGL(mlp_bwd_skinny_partial_kernel<128>, dim3(S.n_chunks, n_nets), dim3(128), 0, (hipStream_t)s, L, S, ws);

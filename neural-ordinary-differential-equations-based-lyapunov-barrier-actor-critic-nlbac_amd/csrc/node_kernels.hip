@@ -154,23 +154,27 @@ __global__ __launch_bounds__(512, OCC ? 4 : 2) void node_rk_fwd_kernel(const Nod
 
     TSTAMP(0)
     for (int st = L.stage_begin; st < L.stage_end; ++st) {
-        // ---- stage input  Y_st = y0 + h sum_j beta[st][j] K_j   (same op order as rk_combine_kernel)
+        // ---- stage input  Y_st = y0 + h sum_j beta[st][j] K_j   (same op order as rk_combine_kernel): formed here for
+        //      the launch's first stage only; every later stage's input is written by the threads that finish the
+        //      previous stage's k (below), into both groups' tiles
         TSTAMP(1 + 8 * (st - L.stage_begin) + 0)
         float* in = buf;
         float* out = buf + NLBAC_MLP_TILE * LD;
-        for (int idx = t; idx < NLBAC_MLP_TILE * inp; idx += 256) {
-            const int m = idx / inp, c = idx - m * inp;
-            float a = 0.f;
-            if (c < ns) {
-                a = sY0[m * RK_MAX_NS + c];
-                const float h = sH[m];
-                for (int j = 0; j < st; ++j)
-                    if (L.beta[st][j] != 0.f) a = a + sK[(j * NLBAC_MLP_TILE + m) * RK_MAX_NS + c] * (L.beta[st][j] * h);
-                if (grp == 0 && row0 + m < n) gY[((long)st * n + row0 + m) * ns + c] = a;
+        if (st == L.stage_begin) {
+            for (int idx = t; idx < NLBAC_MLP_TILE * inp; idx += 256) {
+                const int m = idx / inp, c = idx - m * inp;
+                float a = 0.f;
+                if (c < ns) {
+                    a = sY0[m * RK_MAX_NS + c];
+                    const float h = sH[m];
+                    for (int j = 0; j < st; ++j)
+                        if (L.beta[st][j] != 0.f) a = a + sK[(j * NLBAC_MLP_TILE + m) * RK_MAX_NS + c] * (L.beta[st][j] * h);
+                    if (grp == 0 && row0 + m < n) gY[((long)st * n + row0 + m) * ns + c] = a;
+                }
+                in[m * LD + c] = a;
             }
-            in[m * LD + c] = a;
+            tile_sync(&gbar, lane);               // (the tile is written and read by this group only)
         }
-        tile_sync(&gbar, lane);               // (the tile is written and read by this group only)
         TSTAMP(1 + 8 * (st - L.stage_begin) + 1)
 
         // ---- wide layers of f_net (group 0) and g_net (group 1), each behind its own group barrier so that one
@@ -209,13 +213,32 @@ __global__ __launch_bounds__(512, OCC ? 4 : 2) void node_rk_fwd_kernel(const Nod
         __syncthreads();
         TSTAMP(1 + 8 * (st - L.stage_begin) + 3)
 
-        // ---- k = f + g u   (same op order as affine_fwd_kernel)
-        for (int idx = tid; idx < NLBAC_MLP_TILE * ns; idx += 512) {
-            const int m = idx / ns, r = idx - m * ns;
-            float a = sF[m * RK_MAX_NS + r];
-            for (int c = 0; c < nu; ++c) a += sG[m * RK_MAX_GOUT + r * nu + c] * sU[m * RK_MAX_NU + c];
-            sK[(st * NLBAC_MLP_TILE + m) * RK_MAX_NS + r] = a;
-            if (row0 + m < n) gK[((long)st * n + row0 + m) * ns + r] = a;
+        // ---- k = f + g u   (same op order as affine_fwd_kernel), and — same thread, same (row, component) — the next
+        //      stage's input Y_{st+1} = y0 + h sum_j beta[st+1][j] K_j into the first tile of BOTH groups (nothing reads
+        //      the tiles between the barrier above and the one below); columns ns..inp-1 are zeroed again
+        {
+            const bool more = st + 1 < L.stage_end;
+            float* in_f = smem;
+            float* in_g = smem + 2 * NLBAC_MLP_TILE * LD;
+            for (int idx = tid; idx < NLBAC_MLP_TILE * inp; idx += 512) {
+                const int m = idx / inp, c = idx - m * inp;
+                float y = 0.f;
+                if (c < ns) {
+                    float a = sF[m * RK_MAX_NS + c];
+                    for (int q = 0; q < nu; ++q) a += sG[m * RK_MAX_GOUT + c * nu + q] * sU[m * RK_MAX_NU + q];
+                    sK[(st * NLBAC_MLP_TILE + m) * RK_MAX_NS + c] = a;
+                    if (row0 + m < n) gK[((long)st * n + row0 + m) * ns + c] = a;
+                    if (more) {
+                        y = sY0[m * RK_MAX_NS + c];
+                        const float h = sH[m];
+                        for (int j = 0; j < st; ++j)
+                            if (L.beta[st + 1][j] != 0.f) y = y + sK[(j * NLBAC_MLP_TILE + m) * RK_MAX_NS + c] * (L.beta[st + 1][j] * h);
+                        if (L.beta[st + 1][st] != 0.f) y = y + a * (L.beta[st + 1][st] * h);
+                        if (row0 + m < n) gY[((long)(st + 1) * n + row0 + m) * ns + c] = y;
+                    }
+                }
+                if (more) { in_f[m * LD + c] = y; in_g[m * LD + c] = y; }
+            }
         }
         __syncthreads();
         TSTAMP(1 + 8 * (st - L.stage_begin) + 4)

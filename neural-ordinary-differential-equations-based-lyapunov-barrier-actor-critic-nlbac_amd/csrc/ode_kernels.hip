@@ -266,9 +266,15 @@ __device__ __forceinline__ void interp_hx(const InterpArg& ia, int p, float& h, 
 }
 
 // y(t_end) = y0 + x(d + x(c + x(b + x a)))   (K: [7][n][n_s])
+// OutMap (nlbac_out_map): a per-row map of the solve's output evaluated by the interpolation launches themselves —
+// kind 1, the planar look-ahead point p = (x0 + l cos x2, x1 + l sin x2) of the Unicycle tasks (sac_cbf_clf.py:439-447:
+// `next_p_x = x_next[0] + l_p cos(theta)`): forward writes p next to x(t_end), backward takes d loss / d p (two
+// addends) instead of d loss / d x(t_end).  Same arithmetic as nlbac_unicycle_lookahead / _lookahead_bwd.
+struct OutMap { int kind; float l; float* p; const float* dp; const float* dp2; const float* x; };
+
 __global__ __launch_bounds__(256) void dopri_interp_fwd_kernel(const float* y0, const float* y1, const float* K,
                                                                const InterpArg ia, int rpp, int n_s, int n,
-                                                               float* out) {
+                                                               float* out, const OutMap om) {
     const int i = blockIdx.x * 256 + threadIdx.x;
     if (i >= n) return;
     float h, x;
@@ -293,11 +299,17 @@ __global__ __launch_bounds__(256) void dopri_interp_fwd_kernel(const float* y0, 
         const float d = h * f0;
         out[(long)i * n_s + r] = a0 + x * (d + x * (c + x * (b + x * a)));
     }
+    if (om.kind == 1) {
+        const float th = out[(long)i * n_s + 2];
+        om.p[i * 2 + 0] = out[(long)i * n_s + 0] + om.l * cosf(th);
+        om.p[i * 2 + 1] = out[(long)i * n_s + 1] + om.l * sinf(th);
+    }
 }
 
 // backward of the interpolant: writes dy0, dy1 and dK[0..6]
 __global__ __launch_bounds__(256) void dopri_interp_bwd_kernel(const float* dout, const InterpArg ia, int rpp,
-                                                               int n_s, int n, float* dy0, float* dy1, float* dK) {
+                                                               int n_s, int n, float* dy0, float* dy1, float* dK,
+                                                               const OutMap om) {
     const int i = blockIdx.x * 256 + threadIdx.x;
     if (i >= n) return;
     float h, x;
@@ -308,8 +320,15 @@ __global__ __launch_bounds__(256) void dopri_interp_bwd_kernel(const float* dout
     }
     const float cm[7] = {(float)DPM0, 0.f, (float)DPM2, (float)DPM3, (float)DPM4, (float)DPM5, (float)DPM6};
     const float x2 = x * x, x3 = x2 * x, x4 = x2 * x2;
+    float gm[3] = {0.f, 0.f, 0.f};
+    if (om.kind == 1) {
+        float d0 = om.dp[i * 2 + 0], d1 = om.dp[i * 2 + 1];
+        if (om.dp2) { d0 += om.dp2[i * 2 + 0]; d1 += om.dp2[i * 2 + 1]; }
+        const float th = om.x[(long)i * n_s + 2];
+        gm[0] = d0; gm[1] = d1; gm[2] = om.l * (-sinf(th) * d0 + cosf(th) * d1);
+    }
     for (int r = 0; r < n_s; ++r) {
-        const float g = dout[(long)i * n_s + r];
+        const float g = (om.kind == 1) ? gm[r] : dout[(long)i * n_s + r];
         const float A = x4 * g, Bc = x3 * g, C = x2 * g, D = x * g;
         const float ym = 16.f * A - 32.f * Bc + 16.f * C;
         dy0[(long)i * n_s + r] = g - 8.f * A + 18.f * Bc - 11.f * C + ym;
@@ -437,24 +456,36 @@ static int fill_ia(InterpArg& ia, const float* h_host, const float* x_host, cons
 
 extern "C" int nlbac_dopri_interp_fwd(const float* y0, const float* y1, const float* K, const float* h_host,
                                       const float* x_host, const double* ctl, int P, int rows_per_problem, int n_s,
-                                      float* out, long slot_floats, nlbac_stream_t s) {
+                                      float* out, long slot_floats,
+                                      const nlbac_out_map* map, nlbac_stream_t s) {
     InterpArg ia;
     NLBAC_REQUIRE(y0 && y1 && K && out, "nlbac_dopri_interp_fwd: null pointer");
     if (fill_ia(ia, h_host, x_host, ctl, P, "nlbac_dopri_interp_fwd", slot_floats)) return -1;
     const int n = P * rows_per_problem;
-    hipLaunchKernelGGL(dopri_interp_fwd_kernel, GRID1(n), y0, y1, K, ia, rows_per_problem, n_s, n, out);
+    OutMap om{0, 0.f, nullptr, nullptr, nullptr, nullptr};
+    if (map && map->kind) {
+        NLBAC_REQUIRE(map->kind == 1 && n_s == 3 && map->p, "nlbac_dopri_interp_fwd: out map 1 needs n_s == 3 and p");
+        om.kind = 1; om.l = map->l; om.p = map->p;
+    }
+    hipLaunchKernelGGL(dopri_interp_fwd_kernel, GRID1(n), y0, y1, K, ia, rows_per_problem, n_s, n, out, om);
     NLBAC_CHECK_LAUNCH("nlbac_dopri_interp_fwd");
     return 0;
 }
 
 extern "C" int nlbac_dopri_interp_bwd(const float* dout, const float* h_host, const float* x_host,
                                       const double* ctl, int P, int rows_per_problem, int n_s, float* dy0,
-                                      float* dy1, float* dK, long slot_floats, nlbac_stream_t s) {
+                                      float* dy1, float* dK, long slot_floats, const nlbac_out_map* map,
+                                      nlbac_stream_t s) {
     InterpArg ia;
-    NLBAC_REQUIRE(dout && dy0 && dy1 && dK, "nlbac_dopri_interp_bwd: null pointer");
+    NLBAC_REQUIRE((dout || (map && map->kind)) && dy0 && dy1 && dK, "nlbac_dopri_interp_bwd: null pointer");
     if (fill_ia(ia, h_host, x_host, ctl, P, "nlbac_dopri_interp_bwd", slot_floats)) return -1;
     const int n = P * rows_per_problem;
-    hipLaunchKernelGGL(dopri_interp_bwd_kernel, GRID1(n), dout, ia, rows_per_problem, n_s, n, dy0, dy1, dK);
+    OutMap om{0, 0.f, nullptr, nullptr, nullptr, nullptr};
+    if (map && map->kind) {
+        NLBAC_REQUIRE(map->kind == 1 && n_s == 3 && map->dp && map->x, "nlbac_dopri_interp_bwd: out map 1 needs n_s == 3, dp and x");
+        om.kind = 1; om.l = map->l; om.dp = map->dp; om.dp2 = map->dp2; om.x = map->x;
+    }
+    hipLaunchKernelGGL(dopri_interp_bwd_kernel, GRID1(n), dout, ia, rows_per_problem, n_s, n, dy0, dy1, dK, om);
     NLBAC_CHECK_LAUNCH("nlbac_dopri_interp_bwd");
     return 0;
 }

@@ -117,10 +117,22 @@ __device__ __forceinline__ float4 slab_sum4(const float* __restrict__ grad, int 
 
 // temperatures refreshed by the step itself: alpha = exp(log_alpha) for up to two log_alpha entries of this arena
 // (sac_cbf_clf.py:297, 308), written by the thread that has just stepped the entry
-struct AlphaRefresh { long off[2]; float* dst[2]; };
+// mirror: the last workgroup of the step also sends `n_mirror` floats at `mirror_src` (the agent's scalars block: the
+// losses this update returns) to `mirror_dst`, a pinned HOST buffer the device writes directly — the update's last
+// launch delivers its results itself instead of a copy launch behind it, on which the host would wait.  Entries the
+// step refreshes (the temperatures) go out from the thread that computes them.
+struct AlphaRefresh { long off[2]; float* dst[2]; const float* mirror_src; float* mirror_dst; int n_mirror; };
 __device__ __forceinline__ void alpha_refresh(const AlphaRefresh& AR, long e, float p_new) {
-    if (e == AR.off[0]) *AR.dst[0] = expf(p_new);
-    if (e == AR.off[1]) *AR.dst[1] = expf(p_new);
+#pragma unroll
+    for (int k = 0; k < 2; ++k)
+        if (e == AR.off[k]) {
+            const float a = expf(p_new);
+            *AR.dst[k] = a;
+            if (AR.mirror_dst) {
+                const long i = AR.dst[k] - AR.mirror_src;
+                if (i >= 0 && i < AR.n_mirror) AR.mirror_dst[i] = a;
+            }
+        }
 }
 
 __global__ __launch_bounds__(256) void adam_fused_kernel(float* __restrict__ p, float* __restrict__ m,
@@ -190,7 +202,9 @@ __global__ __launch_bounds__(256) void adam_fused_kernel(float* __restrict__ p, 
         }
     }
     __syncthreads();                                   // every wave of this block has read the constants
+    __shared__ int s_is_last;
     if (threadIdx.x == 0) {
+        s_is_last = 0;
         // relaxed: every workgroup consumed st->step (it computed its constants from it) before the barrier above, so
         // the counter may move once the last ticket is drawn; no agent-scope release per workgroup (that would write the
         // XCD's L2 back behind every block's parameter stores)
@@ -200,8 +214,17 @@ __global__ __launch_bounds__(256) void adam_fused_kernel(float* __restrict__ p, 
             st->step_size = step_size;
             st->bc2_sqrt = bc2_sqrt;
             __hip_atomic_store(&st->step, s_step, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            s_is_last = 1;
         }
     }
+    if (!AR.mirror_dst) return;
+    __syncthreads();
+    if (s_is_last)                                     // (written by earlier launches, except the refreshed entries)
+        for (int i = threadIdx.x; i < AR.n_mirror; i += blockDim.x) {
+            const bool refreshed = (AR.off[0] >= 0 && AR.dst[0] == AR.mirror_src + i) ||
+                                   (AR.off[1] >= 0 && AR.dst[1] == AR.mirror_src + i);
+            if (!refreshed) AR.mirror_dst[i] = AR.mirror_src[i];
+        }
 }
 
 __global__ __launch_bounds__(256) void reduce_slabs_kernel(float* __restrict__ out, const float* __restrict__ grad,
@@ -271,11 +294,13 @@ extern "C" int nlbac_adam_step(float* p, float* m, float* v, const float* grad, 
 extern "C" int nlbac_adam_fused(float* p, float* m, float* v, const float* grad, int n_slabs, long slab_stride, long n,
                                 void* state, double lr, float* target, float tau, const void* scatter,
                                 const void* scatter_target, int n_alpha, const long* alpha_off, float* const* alpha_dst,
-                                nlbac_stream_t s) {
+                                const float* mirror_src, float* mirror_dst, int n_mirror, nlbac_stream_t s) {
     NLBAC_REQUIRE(p && m && v && grad && state, "nlbac_adam_fused: null pointer");
     NLBAC_REQUIRE(n_alpha >= 0 && n_alpha <= 2 && (n_alpha == 0 || (alpha_off && alpha_dst)), "nlbac_adam_fused: bad alpha refresh");
     AlphaRefresh AR;
     AR.off[0] = AR.off[1] = -1; AR.dst[0] = AR.dst[1] = nullptr;
+    NLBAC_REQUIRE((mirror_dst == nullptr) || (mirror_src && n_mirror > 0 && n_mirror <= 1024), "nlbac_adam_fused: bad mirror");
+    AR.mirror_src = mirror_src; AR.mirror_dst = mirror_dst; AR.n_mirror = mirror_dst ? n_mirror : 0;
     for (int k = 0; k < n_alpha; ++k) {
         NLBAC_REQUIRE(alpha_off[k] >= 0 && alpha_off[k] < n && alpha_dst[k], "nlbac_adam_fused: alpha entry out of range");
         AR.off[k] = alpha_off[k]; AR.dst[k] = alpha_dst[k];

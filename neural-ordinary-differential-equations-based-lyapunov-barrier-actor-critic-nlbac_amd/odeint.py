@@ -585,6 +585,36 @@ class AffineNodeSolver:
     ALOG_CAP = 64
     FUSED_NORM_MODES = (0, 1)
 
+    # -- output map (nlbac_out_map) ------------------------------------------------------------------------------
+    def set_out_map(self, kind, l, p, dp=None, dp2=None):
+        """The owner's per-row map of the solve's output (kind 1: planar look-ahead point, ``p`` (n, 2) receives it,
+        ``dp`` / ``dp2`` hold its gradient at backward time).  Evaluated inside the dopri5 interpolation launches of the
+        device-driven chain; ``out_mapped`` / ``backward(None)`` tell / let the owner skip its own launches.  Anywhere
+        else (fixed-step methods, host-driven steps, the adjoint) the map is not applied and the owner launches it."""
+        self._out_map = dict(kind=kind, l=float(l), p=p, dp=dp, dp2=dp2)
+
+    @property
+    def out_mapped(self):
+        return bool(self.ctx.get("out_mapped"))
+
+    def _out_map_fwd(self, n):
+        m = self.__dict__.get("_out_map")
+        if m is None or m["p"].shape[0] != n or self.adjoint:
+            return None
+        om = _lib.OutMap()
+        om.kind, om.l, om.p = m["kind"], m["l"], m["p"].data_ptr()
+        return om
+
+    def _out_map_bwd(self, n):
+        m = self.__dict__.get("_out_map")
+        if m is None or m["dp"] is None or not self.ctx.get("out_mapped"):
+            return None
+        om = _lib.OutMap()
+        om.kind, om.l, om.dp = m["kind"], m["l"], m["dp"].data_ptr()
+        om.dp2 = m["dp2"].data_ptr() if m["dp2"] is not None else None
+        om.x = self.ctx["out"].data_ptr()
+        return om
+
     def _chain_ok(self, P, rpp):
         return bool(self.device_loop and self.fused and (P == 1 or rpp % _lib.MLP_TILE == 0))
 
@@ -678,8 +708,12 @@ class AffineNodeSolver:
                 raise _lib.NlbacError("dopri5: max_num_steps exceeded")
             self._chain_attempts(2)
         out = self._buf("dopri_out", n, ns)
+        # (the owner's map of the output — the Unicycle tasks' look-ahead point — is evaluated by this launch)
+        om = self._out_map_fwd(n)
         _lib.call("nlbac_dopri_interp_fwd", ctx["y0"].data_ptr(), ws0.Y[6].data_ptr(), ws0.K.data_ptr(), None, None,
-                  ctl.data_ptr(), P, rpp, ns, out.data_ptr(), pool.slot_floats, stream_ptr())
+                  ctl.data_ptr(), P, rpp, ns, out.data_ptr(), pool.slot_floats, C.byref(om) if om is not None else None,
+                  stream_ptr())
+        ctx["out_mapped"] = om is not None
         if c is not None:
             nst = [int(c[p, 10]) for p in range(P)]
             nacc = [int(c[p, 12]) for p in range(P)]
@@ -718,8 +752,11 @@ class AffineNodeSolver:
         for i in range(nb):
             pool.ws(n, i).bwd(self)
         du = self._buf("du", n, nu) if need_du else None
-        _lib.call("nlbac_dopri_interp_bwd", dout.data_ptr(), None, None, ctl.data_ptr(), P, rpp, ns, ws0.dy0.data_ptr(),
-                  ws0.dy1.data_ptr(), ws0.dK.data_ptr(), pool.slot_floats, s)
+        om = self._out_map_bwd(n) if dout is None else None
+        assert dout is not None or om is not None, "backward(None) needs an output map (set_out_map) with its gradients"
+        _lib.call("nlbac_dopri_interp_bwd", dout.data_ptr() if dout is not None else None, None, None, ctl.data_ptr(), P,
+                  rpp, ns, ws0.dy0.data_ptr(), ws0.dy1.data_ptr(), ws0.dK.data_ptr(), pool.slot_floats,
+                  C.byref(om) if om is not None else None, s)
         bch = _lib.RkChain()
         bch.ctl, bch.slot_floats, bch.n_slots, bch.hslots, bch.norm_mode = ch.ctl_w, pool.slot_floats, pool.n_slots, ch.hslots, -1
         for b in range(nb):
@@ -737,7 +774,7 @@ class AffineNodeSolver:
         ctl = self._ctl(P)
         out = self._buf("dopri_out", n, ns)       # (y1 is the input of stage 6: read in place, no copy)
         _lib.call("nlbac_dopri_interp_fwd", ctx["y0"].data_ptr(), ws.Y[6].data_ptr(), ws.K.data_ptr(), None, None,
-                  ctl.data_ptr(), P, rpp, ns, out.data_ptr(), 0, stream_ptr())
+                  ctl.data_ptr(), P, rpp, ns, out.data_ptr(), 0, None, stream_ptr())
         step = dict(ws=ws, first=True, dev=True)
         if c is not None:
             step["h"] = [float(c[p, 11]) for p in range(P)]
@@ -780,7 +817,7 @@ class AffineNodeSolver:
                     steps[-1]["x"] = x
                     out = self._buf("dopri_out", n, ns)
                     _lib.call("nlbac_dopri_interp_fwd", cur_y0.data_ptr(), ws.Y[6].data_ptr(), ws.K.data_ptr(),
-                              fptr(*steps[-1]["h"]), fptr(*x), None, P, rpp, ns, out.data_ptr(), 0, s)
+                              fptr(*steps[-1]["h"]), fptr(*x), None, P, rpp, ns, out.data_ptr(), 0, None, s)
                     ctx.update(steps=steps, out=out, info=info)
                     return out
                 cur_y0 = ws.Y[6]                  # y1 of an accepted step = its stage-6 input (ws is not reused)
@@ -901,7 +938,7 @@ class AffineNodeSolver:
                 if last:
                     _lib.call("nlbac_dopri_interp_bwd", dout.data_ptr(), h_host, None if dev else fptr(*step["x"]),
                               self._ctl(P).data_ptr() if dev else None, P, rpp, ns,
-                              ws.dy0.data_ptr(), ws.dy1.data_ptr(), ws.dK.data_ptr(), 0, s)
+                              ws.dy0.data_ptr(), ws.dy1.data_ptr(), ws.dK.data_ptr(), 0, None, s)
                 else:
                     ws.dy0.zero_()
                     ws.dy1.copy_(dy_carry)
@@ -1058,7 +1095,7 @@ class AffineNodeSolver:
     def _adj_params_finish(self, par, cp):
         NP = par["NP"]
         _lib.call("nlbac_dopri_interp_fwd", par["th0"].data_ptr(), par["th1"].data_ptr(), par["K"].data_ptr(), None,
-                  None, cp, 1, NP // 4, 4, par["out"].data_ptr(), 0, stream_ptr())
+                  None, cp, 1, NP // 4, 4, par["out"].data_ptr(), 0, None, stream_ptr())
         par["grad"] = par["out"]
         self.ctx["adj_par"] = par
 
@@ -1139,7 +1176,7 @@ class AffineNodeSolver:
         ctx["adjoint_info"] = [[(float(c[p, 11]), float(c[p, 2]), int(c[p, 10])) for p in range(P)]]
         # the interpolant of the last accepted step at t0 (steps are not clipped), all columns of z at once
         _lib.call("nlbac_dopri_interp_fwd", w["Z0"].data_ptr(), w["Z1"].data_ptr(), KZ.data_ptr(), None, None, cp, P,
-                  rpp, w["W"], w["OUT"].data_ptr(), 0, s)
+                  rpp, w["W"], w["OUT"].data_ptr(), 0, None, s)
         if par:
             self._adj_params_finish(par, cp)
         return w["OUT"]

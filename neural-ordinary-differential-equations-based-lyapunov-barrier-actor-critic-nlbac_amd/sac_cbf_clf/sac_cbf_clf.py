@@ -294,7 +294,7 @@ class SAC_CBF_CLF(object):
             self._xb[name] = torch.zeros(n, dtype=torch.float32, device=self.device)
         return self._xb[name]
 
-    def _adam(self, arena, lr, n_slabs, extra=None, target=None, tau=-1.0, before_step=None, alpha=None):
+    def _adam(self, arena, lr, n_slabs, extra=None, target=None, tau=-1.0, before_step=None, alpha=None, mirror=None):
         """Adam on a whole arena.  One GPU: slab sum fused into the step.  Data parallel: local slab sum ->
         flat buffer (+ ``extra`` scalars riding along) -> all-reduce -> step on the reduced gradient."""
         s = stream_ptr()
@@ -309,9 +309,11 @@ class SAC_CBF_CLF(object):
         if self.world == 1:
             if before_step is not None:
                 before_step(a.grad.data_ptr())
+            # mirror: (pinned host block) the step's last workgroup writes the scalars block to (see _returns)
             _lib.call("nlbac_adam_fused", a.theta.data_ptr(), a.m.data_ptr(), a.v.data_ptr(), a.grad.data_ptr(),
                       n_slabs, a.n, a.n, a.state.data_ptr(), lr, target, tau, scat.data_ptr(), scat_t, n_al, al_off,
-                      al_dst, s)
+                      al_dst, self.sc.data_ptr() if mirror is not None else None,
+                      mirror.data_ptr() if mirror is not None else None, SC.SC_SIZE if mirror is not None else 0, s)
             return
         n_extra = 0 if extra is None else extra.numel()
         xb = self._exchange_buf("g%d" % id(a), a.n + 4)
@@ -324,7 +326,7 @@ class SAC_CBF_CLF(object):
         if before_step is not None:
             before_step(xb.data_ptr())
         _lib.call("nlbac_adam_fused", a.theta.data_ptr(), a.m.data_ptr(), a.v.data_ptr(), xb.data_ptr(), 1, a.n, a.n,
-                  a.state.data_ptr(), lr, target, tau, scat.data_ptr(), scat_t, n_al, al_off, al_dst, s)
+                  a.state.data_ptr(), lr, target, tau, scat.data_ptr(), scat_t, n_al, al_off, al_dst, None, None, 0, s)
 
     # ------------------------------------------------------------------ utils
     def repack_all(self):
@@ -337,13 +339,17 @@ class SAC_CBF_CLF(object):
         backup sample)], each (B, n_u)."""
         self._noise = [torch.as_tensor(e, dtype=torch.float32) for e in eps_list]
 
-    def _scalars(self):
-        """Host copy of the device scalars (one 512-byte read through a pinned buffer; waits for the launch stream)."""
+    def _sc_pins(self):
         pin = self.__dict__.get("_sc_pin")
         if pin is None:
             pin = self._sc_pin = [torch.zeros(SC.SC_SIZE, dtype=torch.float32).pin_memory() for _ in range(3)]
             self._sc_ev = [torch.cuda.Event() for _ in range(3)]
             self._sc_lag = None
+        return pin
+
+    def _scalars(self):
+        """Host copy of the device scalars (one 512-byte read through a pinned buffer; waits for the launch stream)."""
+        pin = self._sc_pins()
         pin[0].copy_(self.sc, non_blocking=True)
         self._sc_ev[0].record()
         self._sc_ev[0].synchronize()
@@ -709,6 +715,18 @@ class SAC_CBF_CLF(object):
         lam_upd = 1 if updates % self.Lagrangian_multiplier_update_interval == 0 else 0
         NP = ws.np_now = self.task.n_pol_now(updates)
         ws.blam_upd = self.task.backup_lam_due(updates, self.Lagrangian_multiplier_update_interval)
+        # where the update's last launch (the actors' optimiser step) leaves the scalars block for the host: straight
+        # in pinned memory, so that no copy launch sits between that step and the host's wait.  Not under hipGraph
+        # replay (the address would be baked in) or data parallelism (the step is not the last thing that happens).
+        self._mirror = None
+        if sync and self.world == 1 and not self._graphs_on():
+            pin = self._sc_pins()
+            if sync == "lagged":
+                k = 1 + (self.__dict__.get("_sc_flip", 0) & 1)
+                self._sc_flip = k
+            else:
+                k = 0
+            self._mirror = (k, pin[k])
         if not self._graphs_on() or ws.warm < 1:
             ws.warm += 1
             self._upd_part1(ws, soft)
@@ -731,18 +749,26 @@ class SAC_CBF_CLF(object):
         False — nothing."""
         if not sync:
             return None
+        mirrored = self.__dict__.get("_mirror_done")      # (buffer index the last optimiser step wrote to, or None)
+        self._mirror_done = None
         if sync == "lagged":
-            if self.__dict__.get("_sc_pin") is None:
-                self._scalars()
-            k = 1 + (self.__dict__.get("_sc_flip", 0) & 1)
-            self._sc_flip = k
+            if mirrored is not None:
+                k = mirrored
+            else:
+                self._sc_pins()
+                k = 1 + (self.__dict__.get("_sc_flip", 0) & 1)
+                self._sc_flip = k
+                self._sc_pin[k].copy_(self.sc, non_blocking=True)
             prev, self._sc_lag = self._sc_lag, k
-            self._sc_pin[k].copy_(self.sc, non_blocking=True)
             self._sc_ev[k].record()
             if prev is None:
                 return None
             self._sc_ev[prev].synchronize()
             h = self._sc_pin[prev].numpy().copy()
+        elif mirrored is not None:
+            self._sc_ev[mirrored].record()
+            self._sc_ev[mirrored].synchronize()
+            h = self._sc_pin[mirrored].numpy().copy()
         else:
             h = self._scalars()
         alpha_loss = float(h[SC.SC_ALOSS]) if self.automatic_entropy_tuning else 0.0
@@ -881,7 +907,11 @@ class SAC_CBF_CLF(object):
             # (alpha = exp(log_alpha) is refreshed by the thread of the Adam step that moves log_alpha)
             refresh = ([g.la_off + k * g.la_stride for k in range(cnt)],
                        [sc + 4 * (SC.SC_ALPHA + g.first + k) for k in range(cnt)]) if tune else None
-            self._adam(a, self.lr, a.n_slabs, before_step=alpha_grads, alpha=refresh)
+            last = g is P.act_groups[-1][0]
+            mir = self.__dict__.get("_mirror") if last else None
+            self._adam(a, self.lr, a.n_slabs, before_step=alpha_grads, alpha=refresh, mirror=mir[1] if mir else None)
+            if mir:
+                self._mirror_done = mir[0]
 
     # ------------------------------------------------------------ checkpoints
     def save_model(self, output):

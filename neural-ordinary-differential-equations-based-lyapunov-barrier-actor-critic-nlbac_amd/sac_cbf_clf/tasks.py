@@ -131,6 +131,9 @@ class UnicycleTask(_Task):
         # state (twice: primary and backup rows of the rollout) and look-ahead point
         _lib.call("nlbac_unicycle_state", p_obs, LD, B, self.l_p, ws.y0_2.data_ptr(), 2, ws.ps.data_ptr(), s)
         self.reserve(self.solver, 2 * B, 2)
+        # the look-ahead point of x(t + dt) and its backward ride in the solver's interpolation launches where those
+        # exist (device-driven dopri5); elsewhere this task launches them (loss_and_backward)
+        self.solver.set_out_map(1, self.l_p, ws.ps_next2, ws.dps_next2, ws.dps_v2)
         self.solver.forward_begin(ws.y0_2, ws.pi2, 2, B, a.solver, float(self.env.dt), a.atol, a.rtol)
 
     def loss_and_backward(self, ws, P, lam_upd, assume_single):
@@ -139,7 +142,9 @@ class UnicycleTask(_Task):
         B, sc, dt = ws.B, a.sc.data_ptr(), float(self.env.dt)
         x_next2 = self.solver.forward_finish(assume_single_step=assume_single)
         a.drain_fill()           # what is left of part 1 (critic step, Q(s, pi)): everything below uses the stepped nets
-        call("nlbac_unicycle_lookahead", x_next2.data_ptr(), 2 * B, self.l_p, ws.ps_next2.data_ptr(), s)
+        mapped = self.solver.out_mapped
+        if not mapped:
+            call("nlbac_unicycle_lookahead", x_next2.data_ptr(), 2 * B, self.l_p, ws.ps_next2.data_ptr(), s)
         call("nlbac_mlp_fwd", P.n_l, P.io_vn, 1, B, s)
         r_coll = 1.05 * float(self.env.hazards_radius)
         call("nlbac_unicycle_constraints_fwd", ws.ps.data_ptr(), ws.ps_next2.data_ptr(), ws.V.data_ptr(),
@@ -150,9 +155,12 @@ class UnicycleTask(_Task):
              self.hazards.data_ptr(), self.num_cbfs, dt, float(a.batch_size), B, sc, ws.dps_next2.data_ptr(),
              ws.dVn.data_ptr(), s)
         call("nlbac_mlp_bwd_data", P.n_l, P.io_vn, 1, B, s)    # dV_next -> d ps_next (rows [0,B))
-        call("nlbac_unicycle_lookahead_bwd", x_next2.data_ptr(), ws.dps_next2.data_ptr(), ws.dps_v2.data_ptr(), 2 * B,
-             self.l_p, ws.dx_next2.data_ptr(), s)
-        du2, _ = self.solver.backward(ws.dx_next2, need_du=True)
+        if mapped:
+            du2, _ = self.solver.backward(None, need_du=True)
+        else:
+            call("nlbac_unicycle_lookahead_bwd", x_next2.data_ptr(), ws.dps_next2.data_ptr(), ws.dps_v2.data_ptr(), 2 * B,
+                 self.l_p, ws.dx_next2.data_ptr(), s)
+            du2, _ = self.solver.backward(ws.dx_next2, need_du=True)
         return du2, self.act_dim
 
     def first_step_done(self):
