@@ -350,13 +350,26 @@ typedef struct nlbac_rk_chain {
     double *hslots; /* [P][n_slots] accepted step sizes */
     double *alog;   /* or NULL: attempt log [P][alog_cap][3] = (step size tried, error ratio, accepted) */
     int alog_cap;
+    double *ctl_host; /* or NULL: pinned HOST memory, [P][NLBAC_DOPRI_CTL]; nlbac_dopri_norm_control's controller leaves
+                         a copy of each block it updates there (no copy launch between the decision and the host) */
 } nlbac_rk_chain;
+/* Optional: the solve's initial state is FORMED by the launch that evaluates stage 0 (and written to y0 for the launches
+ * that follow) instead of by a launch of its own.  kind 1 = the Unicycle tasks' state map (sac_cbf_clf.py:400-408
+ * `get_state`: (x, y, arctan2(sin, cos)) of observation row `row % rows_per_problem`, float64 arctan2 as the reference's
+ * numpy call) and, when ps is given, the look-ahead point of that state (same arithmetic as nlbac_unicycle_state). */
+typedef struct nlbac_in_map {
+    int kind;            /* 0: none */
+    const float *obs; int obs_ld;
+    float l;             /* look-ahead distance */
+    float *ps;           /* or NULL: (rows_per_problem, 2) */
+} nlbac_in_map;
 int nlbac_node_rk_fwd(const nlbac_mlp *f, const nlbac_mlp *g, const float *y0, const float *u, int P,
                       int rows_per_problem, int stage_begin, int stage_end, int n_stages_total,
                       const float *beta, const float *c_out, int n_out, const float *c_err, int n_err,
                       const float *h_host, const double *h_dev, int h_dev_stride, float *K, float *Y,
                       float *G, float *acts_f, long acts_f_ls, float *acts_g, long acts_g_ls, int acts_bits,
-                      float *out, float *err, const nlbac_rk_chain *chain, nlbac_stream_t s);
+                      float *out, float *err, const nlbac_rk_chain *chain,
+                      const nlbac_in_map *in_map /* or NULL; y0 is then written, not read */, nlbac_stream_t s);
 /* Fused backward of the same step (exact gradient of the discrete step): processes stages st_hi-1 .. st_lo.
  * In/out dK [n_stages_total][n][n_s] holds dL/dK_j (initialised by the caller from the step's output
  * combination / interpolant); dYup (may be NULL) is dL/d(stage input) of the last stage (FSAL y1);

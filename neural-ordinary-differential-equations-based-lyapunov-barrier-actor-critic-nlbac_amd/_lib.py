@@ -63,7 +63,12 @@ class RkChain(C.Structure):
     _fields_ = [("ctl", C.c_void_p), ("slot_floats", C.c_long), ("norm_mode", C.c_int), ("n_slots", C.c_int),
                 ("rtol", C.c_float), ("atol", C.c_float), ("t_end", C.c_double), ("partials", C.c_void_p),
                 ("tickets", C.c_void_p), ("ctl_w", C.c_void_p), ("hslots", C.c_void_p), ("alog", C.c_void_p),
-                ("alog_cap", C.c_int)]
+                ("alog_cap", C.c_int), ("ctl_host", C.c_void_p)]
+
+
+class InMap(C.Structure):
+    """``struct nlbac_in_map``"""
+    _fields_ = [("kind", C.c_int), ("obs", C.c_void_p), ("obs_ld", C.c_int), ("l", C.c_float), ("ps", C.c_void_p)]
 
 
 class OutMap(C.Structure):
@@ -128,7 +133,8 @@ _PROTOS = {
     "nlbac_barrier_constraints_fwd": [_P, _P, _P, _P, _F, _F, _F, _I, _P, _P, C.POINTER(AuglagArgs), _P, _P, _P],
     "nlbac_barrier_constraints_bwd": [_P, _F, _F, _I, _P, _P, _P, _P],
     "nlbac_node_rk_fwd": [C.POINTER(Mlp), C.POINTER(Mlp), _P, _P, _I, _I, _I, _I, _I, c_float_p, c_float_p, _I,
-                          c_float_p, _I, c_float_p, _P, _I, _P, _P, _P, _P, _L, _P, _L, _I, _P, _P, C.POINTER(RkChain), _P],
+                          c_float_p, _I, c_float_p, _P, _I, _P, _P, _P, _P, _L, _P, _L, _I, _P, _P, C.POINTER(RkChain),
+                          C.POINTER(InMap), _P],
     "nlbac_node_rk_bwd": [C.POINTER(Mlp), C.POINTER(Mlp), _P, _P, _I, _I, _I, _I, _I, _I, c_float_p, c_float_p, _P, _I,
                           _P, _L, _P, _L, _I, _P, _P, _P, _P, _P, _P, _I, _P, _I, C.POINTER(RkChain), _I, _P],
     "nlbac_concat_rk_fwd": [C.POINTER(Mlp), _P, _P, _I, _I, _I, _I, _I, c_float_p, c_float_p, _I, c_float_p, _I, c_float_p,

@@ -50,6 +50,9 @@ struct NodeRkLaunch {
     int norm_mode, n_slots; float rtol, atol; double t_end;
     float* partials; unsigned* tickets; double* ctl_w; double* hslots;
     double* alog; int alog_cap;       // attempt log [P][alog_cap][3] = (h tried, error ratio, accepted) or null
+    // nlbac_in_map: the solve's initial state is formed by this launch (stage 0 of a fresh step) from observation rows
+    // and written to y0 for the launches that follow; kind 1 = the Unicycle tasks' state (+ its look-ahead point)
+    int in_kind; const float* in_obs; int in_obs_ld; float in_l; float* in_ps; float* y0_w;
 };
 
 // OCC 1: compiled for 4 waves per SIMD (128 VGPRs, a few spills) so that two workgroups share a CU and overlap their
@@ -124,6 +127,22 @@ __global__ __launch_bounds__(512, OCC ? 4 : 2) void node_rk_fwd_kernel(const Nod
     }
 
     // ---- tile constants: y0, u, h, already-known stages (FSAL / f0 from an earlier launch)
+    if (L.in_kind == 1 && !fsal) {
+        // same arithmetic as unicycle_state_kernel (the reference takes arctan2 on the host in float64 and casts back)
+        for (int idx = tid; idx < NLBAC_MLP_TILE * RK_MAX_NS; idx += 512) sY0[idx] = 0.f;
+        __syncthreads();
+        if (tid < NLBAC_MLP_TILE && row0 + tid < n) {
+            const int row = row0 + tid, i = row % L.rpp;
+            const float* o = L.in_obs + (long)i * L.in_obs_ld;
+            const float th = (float)atan2((double)o[3], (double)o[2]);
+            sY0[tid * RK_MAX_NS + 0] = o[0]; sY0[tid * RK_MAX_NS + 1] = o[1]; sY0[tid * RK_MAX_NS + 2] = th;
+            L.y0_w[(long)row * 3 + 0] = o[0]; L.y0_w[(long)row * 3 + 1] = o[1]; L.y0_w[(long)row * 3 + 2] = th;
+            if (L.in_ps && row < L.rpp) {
+                L.in_ps[i * 2 + 0] = o[0] + L.in_l * cosf(th);
+                L.in_ps[i * 2 + 1] = o[1] + L.in_l * sinf(th);
+            }
+        }
+    } else
     for (int idx = tid; idx < NLBAC_MLP_TILE * RK_MAX_NS; idx += 512) {
         const int m = idx >> 3, c = idx & 7, row = row0 + m;
         sY0[idx] = (row < n && c < ns) ? gy0[(long)row * ns + c] : 0.f;
@@ -662,7 +681,8 @@ extern "C" int nlbac_node_rk_fwd(const nlbac_mlp* f, const nlbac_mlp* g, const f
                                  const float* c_out, int n_out, const float* c_err, int n_err,
                                  const float* h_host, const double* h_dev, int h_dev_stride, float* K, float* Y,
                                  float* G, float* acts_f, long acts_f_ls, float* acts_g, long acts_g_ls,
-                                 int acts_bits, float* out, float* err, const nlbac_rk_chain* chain, nlbac_stream_t s) {
+                                 int acts_bits, float* out, float* err, const nlbac_rk_chain* chain,
+                                 const nlbac_in_map* in_map, nlbac_stream_t s) {
     NLBAC_REQUIRE(f && g && y0 && u && K && Y && G, "nlbac_node_rk_fwd: null pointer");
     NLBAC_REQUIRE(P >= 1 && P <= 8 && rows_per_problem >= 1, "nlbac_node_rk_fwd: bad problem sizes");
     NLBAC_REQUIRE(n_stages_total >= 1 && n_stages_total <= RK_MAX_STAGES && stage_begin >= 0 &&
@@ -677,6 +697,13 @@ extern "C" int nlbac_node_rk_fwd(const nlbac_mlp* f, const nlbac_mlp* g, const f
     memset(&L, 0, sizeof(L));
     L.net[0] = *f; L.net[1] = *g;
     L.y0 = y0; L.u = u;
+    L.in_kind = 0; L.in_obs = nullptr; L.in_obs_ld = 0; L.in_l = 0.f; L.in_ps = nullptr; L.y0_w = nullptr;
+    if (in_map && in_map->kind) {
+        NLBAC_REQUIRE(in_map->kind == 1 && f->in_dim == 3 && in_map->obs && in_map->obs_ld >= 4 && stage_begin == 0,
+                      "nlbac_node_rk_fwd: in map 1 needs n_s == 3, observation rows and a launch that starts at stage 0");
+        L.in_kind = 1; L.in_obs = in_map->obs; L.in_obs_ld = in_map->obs_ld; L.in_l = in_map->l; L.in_ps = in_map->ps;
+        L.y0_w = const_cast<float*>(y0);
+    }
     L.n = P * rows_per_problem; L.rpp = rows_per_problem;
     L.n_s = f->in_dim; L.n_u = g->out_dim / f->in_dim;
     L.stage_begin = stage_begin; L.stage_end = stage_end; L.S_total = n_stages_total;

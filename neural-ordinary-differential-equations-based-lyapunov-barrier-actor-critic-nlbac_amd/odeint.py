@@ -345,6 +345,12 @@ class AffineNodeSolver:
         f, g = self.f, self.g
         n = P * rpp
         save_acts = save_acts and not self.adjoint       # (the adjoint re-computes every stage it differentiates)
+        im = None
+        if st0 == 0 and self.ctx.pop("in_map_pending", None):
+            # first launch of the solve: it forms the initial state itself (set_in_map) and leaves it in y0
+            m, im = self._in_map, _lib.InMap()
+            im.kind, im.obs, im.obs_ld, im.l = m["kind"], m["obs"].data_ptr(), m["obs_ld"], m["l"]
+            im.ps = m["ps"].data_ptr() if m["ps"] is not None else None
         _lib.call("nlbac_node_rk_fwd", C.byref(f.desc), C.byref(g.desc), y0.data_ptr(), u.data_ptr(), P, rpp,
                   st0, st1, S, beta, c_out, len(c_out) if c_out is not None else 0,
                   c_err, len(c_err) if c_err is not None else 0,
@@ -353,7 +359,7 @@ class AffineNodeSolver:
                   ws.acts_f.data_ptr() if save_acts else None, ws.S * n * ws.wf,
                   ws.acts_g.data_ptr() if save_acts else None, ws.S * n * ws.wg, 1 if ws.bits else 0,
                   out.data_ptr() if out is not None else None, err.data_ptr() if err is not None else None,
-                  C.byref(chain) if chain is not None else None, stream_ptr())
+                  C.byref(chain) if chain is not None else None, C.byref(im) if im is not None else None, stream_ptr())
         self.nfe += st1 - st0
 
     def _rk_fused_bwd(self, ws, u, P, rpp, method, first_eval, need_dy0, need_params, h_host, h_dev, h_stride, top_up,
@@ -390,6 +396,8 @@ class AffineNodeSolver:
         self.stats["solves"] += 1
         self.ctx = dict(method=method, P=P, rpp=rpp, n=n, u=u, y0=y0, steps=[], t_end=float(dt), atol=atol,
                         rtol=rtol)
+        if self.__dict__.pop("_in_map_armed", False):
+            self.ctx["in_map_pending"] = True          # (consumed by the solve's first launch, _rk_fused)
         if method in ("euler", "rk4"):
             tab = TABLEAU[method]
             S = len(tab["c_sol"])
@@ -457,6 +465,15 @@ class AffineNodeSolver:
         with torch.cuda.stream(side):
             pin.copy_(self._ctl(P) if src is None else src, non_blocking=True)
             ev_b.record()
+        self.ctx["ctl_pending"] = P
+
+    def _ctl_posted(self, P):
+        """Device-driven chain: the controller launches have written the host's copy themselves (``ctl_host``); mark the
+        point on the launch stream behind which it is complete."""
+        if torch.cuda.is_current_stream_capturing():
+            return
+        self._ctl_io(P)
+        self._ev_ctl[1].record()
         self.ctx["ctl_pending"] = P
 
     def _ctl_io(self, P):
@@ -585,6 +602,15 @@ class AffineNodeSolver:
     ALOG_CAP = 64
     FUSED_NORM_MODES = (0, 1)
 
+    # -- input map (nlbac_in_map) --------------------------------------------------------------------------------
+    def set_in_map(self, kind, obs, obs_ld, l, ps=None):
+        """The NEXT ``forward_begin``'s ``y0`` is an output: the solve's first launch forms the initial state from the
+        owner's observation rows (kind 1: the Unicycle tasks' state map, ``ps`` receives the state's look-ahead point)
+        and leaves it there.  Fused control-affine solver only (``fused``)."""
+        assert self.fused, "set_in_map: the stage-by-stage path reads y0"
+        self._in_map = dict(kind=kind, obs=obs, obs_ld=int(obs_ld), l=float(l), ps=ps)
+        self._in_map_armed = True
+
     # -- output map (nlbac_out_map) ------------------------------------------------------------------------------
     def set_out_map(self, kind, l, p, dp=None, dp2=None):
         """The owner's per-row map of the solve's output (kind 1: planar look-ahead point, ``p`` (n, 2) receives it,
@@ -629,6 +655,8 @@ class AffineNodeSolver:
         c.rtol, c.atol, c.t_end = ctx["rtol"], ctx["atol"], ctx["t_end"]
         c.ctl_w, c.hslots = ctl.data_ptr(), hs.data_ptr()
         c.alog, c.alog_cap = self._buf("alog", P, self.ALOG_CAP, 3, dtype=torch.float64).data_ptr(), self.ALOG_CAP
+        # the controller leaves the host's copy of the control block in pinned memory itself (see _ctl_posted)
+        c.ctl_host = None if torch.cuda.is_current_stream_capturing() else self._ctl_io(P)[1].data_ptr()
         # Where the norm + controller run.  Fused into the RK launch's epilogue (last workgroup of a problem) for the two
         # one-stage launches of the initial-step selection: same GPU time as a launch of their own (26.7 us against
         # 18 + 9), one launch less each.  NOT for an attempted step: the epilogue's device-scope atomics queue behind the
@@ -683,7 +711,10 @@ class AffineNodeSolver:
                            chain=ch)
             self._chain_control(ws0, pool, ch, st["y0"], u, 2, P, rpp)
         st["attempts"] += k
-        self._ctl_post(P)
+        if self.comm is not None and self.comm.world > 1:
+            self._ctl_post(P)        # (the all-reduced controller is nlbac_dopri_control: it leaves no host copy)
+        else:
+            self._ctl_posted(P)
 
     def _dopri_finish_chain(self, assume_done=False):
         ctx = self.ctx

@@ -128,8 +128,12 @@ class UnicycleTask(_Task):
         a, s = self.agent, stream_ptr()
         B, LD = ws.B, a.lay.LD
         p_obs = ws.mb.data_ptr()
-        # state (twice: primary and backup rows of the rollout) and look-ahead point
-        _lib.call("nlbac_unicycle_state", p_obs, LD, B, self.l_p, ws.y0_2.data_ptr(), 2, ws.ps.data_ptr(), s)
+        # state (twice: primary and backup rows of the rollout) and look-ahead point: formed by the rollout's first
+        # launch (fused solver), else by a launch of their own
+        if self.solver.fused:
+            self.solver.set_in_map(1, ws.mb, LD, self.l_p, ws.ps)
+        else:
+            _lib.call("nlbac_unicycle_state", p_obs, LD, B, self.l_p, ws.y0_2.data_ptr(), 2, ws.ps.data_ptr(), s)
         self.reserve(self.solver, 2 * B, 2)
         # the look-ahead point of x(t + dt) and its backward ride in the solver's interpolation launches where those
         # exist (device-driven dopri5); elsewhere this task launches them (loss_and_backward)
