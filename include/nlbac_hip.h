@@ -89,8 +89,22 @@ int nlbac_mlp_pack(const nlbac_mlp *nets, int n_nets, nlbac_stream_t s);
 
 /* y = MLP(x) for n_nets independent nets over the same B rows (grid.y = net). */
 int nlbac_mlp_fwd(const nlbac_mlp *nets, const nlbac_mlp_io *io, int n_nets, int B, nlbac_stream_t s);
+/* The same for policy nets (out_dim = 2 n_u: mean | log_std) with GaussianPolicy.sample (model.py:116-128) applied to
+ * every output row by the launch itself — nlbac_gauss_sample_fwd's arithmetic and outputs, no launch of its own.  Net i's
+ * rows are rows i*B.. of the stacked eps (n_nets*B, n_u), action and logp arrays. */
+typedef struct nlbac_gauss_head {
+    const float *eps, *scale, *bias; int n_u;
+    float *action; int action_ld; float *logp;
+} nlbac_gauss_head;
+int nlbac_mlp_fwd_gauss(const nlbac_mlp *nets, const nlbac_mlp_io *io, int n_nets, int B,
+                        const nlbac_gauss_head *head, nlbac_stream_t s);
 /* dz (all wide layers) and optionally dx from dy and the saved activations. */
 int nlbac_mlp_bwd_data(const nlbac_mlp *nets, const nlbac_mlp_io *io, int n_nets, int B, nlbac_stream_t s);
+struct nlbac_dy_head;
+/* The same with dL/dy PRODUCED in the launch (io[i].dy is not read): see nlbac_dy_head below, after the per-row
+ * entry points it replaces. */
+int nlbac_mlp_bwd_data_head(const nlbac_mlp *nets, const nlbac_mlp_io *io, int n_nets, int B,
+                            const struct nlbac_dy_head *head, nlbac_stream_t s);
 /* Weight/bias gradients from x, dy, acts, dz.  The hidden->hidden matrices are
  * reduced per row range into n_slabs gradient slabs (slab s = rows
  * [s*rows_per_slab, ...), fully overwritten, deterministic); the skinny first/last
@@ -177,6 +191,31 @@ typedef struct nlbac_actor_scalar_args { /* nlbac_actor_scalars' arguments, per 
 int nlbac_actor_q_terms(const float *q1, const float *q2, const float *logp, const float *alpha,
                         int B, int B_norm, int P, float *dq1, float *dq2, float *partials,
                         const nlbac_actor_scalar_args *fused, unsigned *ticket, nlbac_stream_t s);
+/* nlbac_mlp_bwd_data_head: the per-row step between a forward and the data backward that consumes its result runs in
+ * that backward's prologue (each workgroup for its 32 rows), its batch sums are finished by the launch's last
+ * designated workgroup; single GPU (the sums are not all-reduced).  Same row arithmetic, and the same outputs left in
+ * memory, as the entry point it replaces:
+ *   kind 1  nlbac_gauss_sample_bwd  net i = controller i (rows i*B.. of the stacked arrays); out_dim = 2 n_u
+ *   kind 2  nlbac_td_targets        nets 0, 1, 2 = Q1, Q2, Lyapunov critic; out[0..2] = the three losses * mul
+ *   kind 3  nlbac_actor_q_terms     net i = (controller i / 2, Q1 / Q2 = i % 2); + nlbac_actor_scalars via `actor`
+ * partials: 3 * n_tiles (kind 2) / 2 * n_prob * n_tiles (kind 3) floats, n_tiles = ceil(B / 32); ticket: a zeroed
+ * uint32, left zeroed. */
+typedef struct nlbac_dy_head {
+    int kind, B_norm;
+    /* 1 */
+    const float *heads; int heads_ld; const float *eps; const float *scale; int n_u;
+    const float *da[3]; int da_ld[3];
+    const float *alpha; /* kinds 1-3: temperatures (per controller) */
+    float dlogp_mul; float *dheads; int dheads_ld;
+    /* 2 */
+    const float *q1t, *q2t, *lt, *nlogp, *reward, *constraint, *mask; int rcm_ld;
+    const float *q[3]; float gamma; float *dq[3]; float *next_q, *next_l;
+    /* 3 */
+    const float *qa, *qb, *logp; float *dqa, *dqb; int n_prob;
+    nlbac_actor_scalar_args actor;
+    /* 2, 3 */
+    float *partials; unsigned *ticket; float mul; float *out;
+} nlbac_dy_head;
 /* policy_loss_1, alpha_loss into sc; d alpha_loss / d log_alpha into g_log_alpha
  * (sac_cbf_clf.py:292-308) for problems first_problem .. first_problem+P-1 (0 primary, 1 backup);
  * partials is the base of all problems, log_alpha / g_log_alpha point at first_problem's entry (stride between). */

@@ -58,6 +58,27 @@ class ActorScalarArgs(C.Structure):
                 ("sc", C.c_void_p)]
 
 
+class GaussHead(C.Structure):
+    """``struct nlbac_gauss_head``"""
+    _fields_ = [("eps", C.c_void_p), ("scale", C.c_void_p), ("bias", C.c_void_p), ("n_u", C.c_int),
+                ("action", C.c_void_p), ("action_ld", C.c_int), ("logp", C.c_void_p)]
+
+
+class DyHead(C.Structure):
+    """``struct nlbac_dy_head``"""
+    _fields_ = [("kind", C.c_int), ("B_norm", C.c_int),
+                ("heads", C.c_void_p), ("heads_ld", C.c_int), ("eps", C.c_void_p), ("scale", C.c_void_p), ("n_u", C.c_int),
+                ("da", C.c_void_p * 3), ("da_ld", C.c_int * 3),
+                ("alpha", C.c_void_p), ("dlogp_mul", C.c_float), ("dheads", C.c_void_p), ("dheads_ld", C.c_int),
+                ("q1t", C.c_void_p), ("q2t", C.c_void_p), ("lt", C.c_void_p), ("nlogp", C.c_void_p), ("reward", C.c_void_p),
+                ("constraint", C.c_void_p), ("mask", C.c_void_p), ("rcm_ld", C.c_int),
+                ("q", C.c_void_p * 3), ("gamma", C.c_float), ("dq", C.c_void_p * 3), ("next_q", C.c_void_p),
+                ("next_l", C.c_void_p),
+                ("qa", C.c_void_p), ("qb", C.c_void_p), ("logp", C.c_void_p), ("dqa", C.c_void_p), ("dqb", C.c_void_p),
+                ("n_prob", C.c_int), ("actor", ActorScalarArgs),
+                ("partials", C.c_void_p), ("ticket", C.c_void_p), ("mul", C.c_float), ("out", C.c_void_p)]
+
+
 class RkChain(C.Structure):
     """``struct nlbac_rk_chain``"""
     _fields_ = [("ctl", C.c_void_p), ("slot_floats", C.c_long), ("norm_mode", C.c_int), ("n_slots", C.c_int),
@@ -86,7 +107,9 @@ _PROTOS = {
     "nlbac_mlp_pack_layout": [C.POINTER(Mlp)],
     "nlbac_mlp_pack": [C.POINTER(Mlp), _I, _P],
     "nlbac_mlp_fwd": [C.POINTER(Mlp), C.POINTER(MlpIO), _I, _I, _P],
+    "nlbac_mlp_fwd_gauss": [C.POINTER(Mlp), C.POINTER(MlpIO), _I, _I, C.POINTER(GaussHead), _P],
     "nlbac_mlp_bwd_data": [C.POINTER(Mlp), C.POINTER(MlpIO), _I, _I, _P],
+    "nlbac_mlp_bwd_data_head": [C.POINTER(Mlp), C.POINTER(MlpIO), _I, _I, C.POINTER(DyHead), _P],
     "nlbac_mlp_bwd_weights_ws_floats": [C.POINTER(Mlp), _I, _I],
     "nlbac_mlp_bwd_weights": [C.POINTER(Mlp), C.POINTER(MlpIO), _I, _I, _I, _L, _P, _L, _P],
     "nlbac_adam_prepare": [_P, _D, _P],

@@ -13,6 +13,7 @@
 //   backup_get_policy_loss_2         U/sac_cbf_clf/sac_cbf_clf.py:532-640
 #include "common.h"
 #include "scalars.h"
+#include "dy_heads.h"
 
 struct AuglagArgs {        // nlbac_auglag's scalar arguments, by value (nlbac_auglag_args in the header)
     int n_cbf, n_clf; float batch_size; int do_lambda_update, do_backup_lambda_update, ratio_mode, backup_mode;
@@ -46,10 +47,6 @@ __device__ __forceinline__ bool publish_and_elect_n(float* dst, const float* val
     if (!publish_and_elect_n(partials + (long)blockIdx.x * (NCOLS_), (V_), (NCOLS_), ticket, gridDim.x)) return; \
     auglag_body<true>(partials, (int)gridDim.x, A, sc);
 
-#define LOG_SIG_MAX 2.0f
-#define LOG_SIG_MIN (-20.0f)
-#define SAMPLE_EPS 1e-6f
-#define MAX_NU 4
 
 // ---------------------------------------------------------------------------
 // GaussianPolicy.sample forward
@@ -59,23 +56,7 @@ __global__ __launch_bounds__(256) void gauss_fwd_kernel(const float* heads, int 
                                                         float* action, int action_ld, float* logp) {
     const int i = blockIdx.x * 256 + threadIdx.x;
     if (i >= n) return;
-    float lp = 0.f;
-    for (int c = 0; c < n_u; ++c) {
-        const float mean = heads[(long)i * heads_ld + c];
-        float ls = heads[(long)i * heads_ld + n_u + c];
-        ls = fminf(fmaxf(ls, LOG_SIG_MIN), LOG_SIG_MAX);
-        const float std = expf(ls);
-        const float e = eps[(long)i * n_u + c];
-        const float x = mean + e * std;
-        const float y = tanhf(x);
-        action[(long)i * action_ld + c] = y * scale[c] + bias[c];
-        const float var = std * std;
-        const float d = x - mean;
-        float l = -(d * d) / (2.0f * var) - ls - 0.91893853320467274178f;   // log(sqrt(2 pi))
-        l -= logf(scale[c] * (1.0f - y * y) + SAMPLE_EPS);
-        lp += l;
-    }
-    logp[i] = lp;
+    gauss_fwd_row(heads + (long)i * heads_ld, eps, scale, bias, n_u, i, action, action_ld, logp);
 }
 
 // backward: d heads from d action (sum of up to three sources) and d logp = alpha[p] * dlogp_mul
@@ -88,25 +69,8 @@ __global__ __launch_bounds__(256) void gauss_bwd_kernel(const float* heads, int 
     if (i >= n) return;
     const float dlp = alpha[i / rows_per_problem] * dlogp_mul;
     for (int c = 0; c < n_u; ++c) {
-        const float mean = heads[(long)i * heads_ld + c];
-        const float ls_raw = heads[(long)i * heads_ld + n_u + c];
-        const float ls = fminf(fmaxf(ls_raw, LOG_SIG_MIN), LOG_SIG_MAX);
-        const float std = expf(ls);
-        const float e = eps[(long)i * n_u + c];
-        const float y = tanhf(mean + e * std);
-        float da = 0.f;
-        if (da0) da += da0[(long)i * da0_ld + c];
-        if (da1) da += da1[(long)i * da1_ld + c];
-        if (da2) da += da2[(long)i * da2_ld + c];
-        const float one_m = 1.0f - y * y;
-        const float s1 = scale[c] * one_m;
-        // dx through a = scale*tanh(x)+bias and through -log(scale(1-y^2)+eps)
-        const float gx = da * s1 + dlp * (2.0f * y * s1 / (s1 + SAMPLE_EPS));
-        // the -(x-mean)^2/(2 var) term is constant (-eps^2/2) under reparameterisation
-        const float dmean = gx;
-        const float dstd = gx * e;
-        const bool in_range = (ls_raw >= LOG_SIG_MIN) && (ls_raw <= LOG_SIG_MAX);
-        const float dls = in_range ? (dstd * std - dlp) : 0.f;
+        float dmean, dls;
+        gauss_bwd_one(heads, heads_ld, eps, scale, n_u, i, c, da0, da0_ld, da1, da1_ld, da2, da2_ld, dlp, dmean, dls);
         dheads[(long)i * dheads_ld + c] = dmean;
         dheads[(long)i * dheads_ld + n_u + c] = dls;
     }
@@ -161,21 +125,6 @@ __global__ __launch_bounds__(256) void td_targets_kernel(const float* q1t, const
 // min(Q1,Q2)(s, pi) branch gradients and partial sums for policy_loss_1 / alpha loss.
 // Rows: P problems (primary, backup) x B.  partials: [P][nblk][2]
 // ---------------------------------------------------------------------------
-struct ActorScalarArgs {      // nlbac_actor_scalar_args: what nlbac_actor_scalars needs, per problem (0 primary, 1 backup)
-    float target_entropy; const float* log_alpha[2]; float* g_log_alpha[2]; float* sc;
-};
-__device__ __forceinline__ void actor_scalars_one(float s0, float s1, int p, int B, float target_entropy,
-                                                  const float* log_alpha, float* g_log_alpha, float* sc) {
-    const float pl1 = s0 / (float)B;
-    const float mean_lp = s1 / (float)B;
-    const float la = log_alpha[0];
-    const float aloss = -(la * (mean_lp + target_entropy));      // alpha_loss = -(log_alpha * (logp + H)).mean()
-    sc[(p == 0) ? SC_PL1 : SC_BPL1] = pl1;
-    sc[(p == 0) ? SC_ALOSS : SC_BALOSS] = aloss;
-    sc[(p == 0) ? SC_MEAN_LOGP : SC_MEAN_BLOGP] = mean_lp;
-    g_log_alpha[0] = -(mean_lp + target_entropy);
-}
-
 __global__ __launch_bounds__(256) void actor_q_terms_kernel(const float* q1, const float* q2, const float* logp,
                                                             const float* alpha, int B, int B_norm, float* dq1,
                                                             float* dq2, float* partials, unsigned* ticket,

@@ -1,0 +1,193 @@
+// "dy heads": where nlbac_mlp_bwd_data_head takes dL/dy of its nets from.  The per-row operations that sat in launches of
+// their own between a forward and the data backward that consumes their result — the squashed-Gaussian sample backward,
+// the TD / Lyapunov targets, the min(Q1, Q2)(s, pi) branch terms — run in the backward's prologue instead, for the 32
+// rows of the workgroup's tile, with their batch sums finished by the launch's last designated workgroup
+// (publish_and_elect, common.h).  The row arithmetic is the one of gauss_bwd_kernel / td_targets_kernel /
+// actor_q_terms_kernel (agent_kernels.hip), which stay for the data-parallel path and the other callers.
+//
+// Reference lines (U = NLBAC_Unicycle_RL_training/Unicycle_RL_training):
+//   GaussianPolicy.sample            U/sac_cbf_clf/model.py:116-128
+//   targets + MSE                    U/sac_cbf_clf/sac_cbf_clf.py:231-246
+//   policy_loss_1 / alpha loss       U/sac_cbf_clf/sac_cbf_clf.py:258-273, 292-308
+#pragma once
+#include "common.h"
+#include "scalars.h"
+
+#define LOG_SIG_MAX 2.0f
+#define LOG_SIG_MIN (-20.0f)
+#define SAMPLE_EPS 1e-6f
+#define MAX_NU 4
+
+struct ActorScalarArgs {      // nlbac_actor_scalar_args: what nlbac_actor_scalars needs, per problem (0 primary, 1 backup)
+    float target_entropy; const float* log_alpha[2]; float* g_log_alpha[2]; float* sc;
+};
+__device__ __forceinline__ void actor_scalars_one(float s0, float s1, int p, int B, float target_entropy,
+                                                  const float* log_alpha, float* g_log_alpha, float* sc) {
+    const float pl1 = s0 / (float)B;
+    const float mean_lp = s1 / (float)B;
+    const float la = log_alpha[0];
+    const float aloss = -(la * (mean_lp + target_entropy));      // alpha_loss = -(log_alpha * (logp + H)).mean()
+    sc[(p == 0) ? SC_PL1 : SC_BPL1] = pl1;
+    sc[(p == 0) ? SC_ALOSS : SC_BALOSS] = aloss;
+    sc[(p == 0) ? SC_MEAN_LOGP : SC_MEAN_BLOGP] = mean_lp;
+    g_log_alpha[0] = -(mean_lp + target_entropy);
+}
+
+// GaussianPolicy.sample of one row: heads = the row's (mean | log_std), i = the row's index in the stacked eps / action /
+// logp arrays
+__device__ __forceinline__ void gauss_fwd_row(const float* heads, const float* eps, const float* scale, const float* bias,
+                                              int n_u, long i, float* action, int action_ld, float* logp) {
+    float lp = 0.f;
+    for (int c = 0; c < n_u; ++c) {
+        const float mean = heads[c];
+        float ls = heads[n_u + c];
+        ls = fminf(fmaxf(ls, LOG_SIG_MIN), LOG_SIG_MAX);
+        const float std = expf(ls);
+        const float e = eps[i * n_u + c];
+        const float x = mean + e * std;
+        const float y = tanhf(x);
+        action[i * action_ld + c] = y * scale[c] + bias[c];
+        const float var = std * std;
+        const float d = x - mean;
+        float l = -(d * d) / (2.0f * var) - ls - 0.91893853320467274178f;   // log(sqrt(2 pi))
+        l -= logf(scale[c] * (1.0f - y * y) + SAMPLE_EPS);
+        lp += l;
+    }
+    logp[i] = lp;
+}
+
+// d heads of one (row, action component) from d action (up to three sources) and d logp = alpha * dlogp_mul
+__device__ __forceinline__ void gauss_bwd_one(const float* heads, int heads_ld, const float* eps, const float* scale,
+                                              int n_u, long i, int c, const float* da0, int da0_ld, const float* da1,
+                                              int da1_ld, const float* da2, int da2_ld, float dlp, float& dmean,
+                                              float& dls) {
+    const float mean = heads[i * heads_ld + c];
+    const float ls_raw = heads[i * heads_ld + n_u + c];
+    const float ls = fminf(fmaxf(ls_raw, LOG_SIG_MIN), LOG_SIG_MAX);
+    const float std = expf(ls);
+    const float e = eps[i * n_u + c];
+    const float y = tanhf(mean + e * std);
+    float da = 0.f;
+    if (da0) da += da0[i * da0_ld + c];
+    if (da1) da += da1[i * da1_ld + c];
+    if (da2) da += da2[i * da2_ld + c];
+    const float one_m = 1.0f - y * y;
+    const float s1 = scale[c] * one_m;
+    // dx through a = scale*tanh(x)+bias and through -log(scale(1-y^2)+eps)
+    const float gx = da * s1 + dlp * (2.0f * y * s1 / (s1 + SAMPLE_EPS));
+    // the -(x-mean)^2/(2 var) term is constant (-eps^2/2) under reparameterisation
+    dmean = gx;
+    const float dstd = gx * e;
+    const bool in_range = (ls_raw >= LOG_SIG_MIN) && (ls_raw <= LOG_SIG_MAX);
+    dls = in_range ? (dstd * std - dlp) : 0.f;
+}
+
+// Sum of n_tiles partials (stride floats apart) read past the non-coherent caches: thread t takes tiles t, t + 256, ...
+// in order, then the fixed tree of block_sum_256 — the result does not depend on which workgroup was elected.
+template <int NV>
+__device__ __forceinline__ void elected_tile_sums(const float* partials, int n_tiles, int stride, float (&v)[NV], float* red) {
+#pragma unroll
+    for (int k = 0; k < NV; ++k) v[k] = 0.f;
+    for (int b = threadIdx.x; b < n_tiles; b += 256)
+#pragma unroll
+        for (int k = 0; k < NV; ++k) v[k] += coherent_load(partials + (long)b * stride + k);
+    block_sum_256<NV>(v, red);
+}
+
+// Fills sdy[32][16] (dL/dy of the tile's rows, zero padded) of net `inet` of the launch.  Called by all 256 threads of an
+// mlp_bwd_data workgroup before anything reads sdy; `red`: >= 16 floats of LDS scratch.
+__device__ __forceinline__ void dy_head_fill(const nlbac_dy_head& H, int inet, int row0, int B, int n_tiles, float* sdy,
+                                             float* red) {
+    const int tid = threadIdx.x;
+    if (H.kind == 1) {
+        // GaussianPolicy.sample backward; net inet = controller inet, its rows are inet*B.. of the stacked arrays
+        const float dlp = H.alpha[inet] * H.dlogp_mul;
+        for (int idx = tid; idx < NLBAC_MLP_TILE * 16; idx += 256) {
+            const int r = idx >> 4, c = idx & 15, row = row0 + r;
+            float v = 0.f;
+            if (row < B && c < 2 * H.n_u) {
+                const long i = (long)inet * B + row;
+                const int cu = (c < H.n_u) ? c : c - H.n_u;
+                float dmean, dls;
+                gauss_bwd_one(H.heads, H.heads_ld, H.eps, H.scale, H.n_u, i, cu, H.da[0], H.da_ld[0], H.da[1], H.da_ld[1],
+                              H.da[2], H.da_ld[2], dlp, dmean, dls);
+                v = (c < H.n_u) ? dmean : dls;
+                if (H.dheads) H.dheads[i * H.dheads_ld + c] = v;
+            }
+            sdy[idx] = v;
+        }
+    } else if (H.kind == 2) {
+        // TD / Lyapunov targets; net 0 = Q1, 1 = Q2, 2 = Lyapunov critic.  Every net's workgroup publishes its own
+        // squared-error sum of the tile; the last of the 3 * n_tiles workgroups finishes the three losses.
+        float e2 = 0.f;
+        for (int idx = tid; idx < NLBAC_MLP_TILE * 16; idx += 256) sdy[idx] = 0.f;
+        __syncthreads();
+        if (tid < NLBAC_MLP_TILE && row0 + tid < B) {
+            const int i = row0 + tid;
+            const float mk = H.mask[(long)i * H.rcm_ld];
+            float y;
+            if (inet < 2) {
+                const float mq = fminf(H.q1t[i], H.q2t[i]) - H.alpha[0] * H.nlogp[i];
+                y = H.reward[(long)i * H.rcm_ld] + mk * H.gamma * mq;
+                if (inet == 0 && H.next_q) H.next_q[i] = y;
+            } else {
+                y = H.constraint[(long)i * H.rcm_ld] + mk * H.gamma * H.lt[i];
+                if (H.next_l) H.next_l[i] = y;
+            }
+            const float norm = (float)(2.0 / (double)H.B_norm);
+            const float e = H.q[inet][i] - y;
+            const float d = norm * e;
+            H.dq[inet][i] = d;
+            sdy[tid * 16] = d;
+            e2 = e * e;
+        }
+        if (tid < 64) {
+#pragma unroll
+            for (int off = 16; off > 0; off >>= 1) e2 += __shfl_down(e2, off, 64);
+        }
+        const float v1[1] = {e2};
+        const int tile = row0 / NLBAC_MLP_TILE;
+        if (publish_and_elect<1>(H.partials + (long)tile * 3 + inet, v1, H.ticket, 3u * (unsigned)n_tiles)) {
+            float s[3];
+            elected_tile_sums<3>(H.partials, n_tiles, 3, s, red);
+            if (tid < 3) H.out[tid] = s[tid] * H.mul;
+        }
+    } else if (H.kind == 3) {
+        // min(Q1, Q2)(s, pi) branch gradients; net inet = (controller inet / 2, Q1 / Q2 = inet % 2); the Q1 workgroups
+        // publish the tile's sums of (alpha logp - min q, logp); the last of them finishes policy_loss_1 / alpha loss /
+        // d log_alpha of every controller (actor_scalars_one)
+        const int p = inet >> 1, which = inet & 1, n_prob = H.n_prob;
+        float v0 = 0.f, v1 = 0.f;
+        for (int idx = tid; idx < NLBAC_MLP_TILE * 16; idx += 256) sdy[idx] = 0.f;
+        __syncthreads();
+        if (tid < NLBAC_MLP_TILE && row0 + tid < B) {
+            const long r = (long)p * B + row0 + tid;
+            const float a = H.qa[r], b = H.qb[r];
+            const float g = -(1.0f / (float)H.B_norm);
+            const float da = (a < b) ? g : ((a == b) ? 0.5f * g : 0.f);
+            const float db = (b < a) ? g : ((a == b) ? 0.5f * g : 0.f);
+            const float d = which ? db : da;
+            (which ? H.dqb : H.dqa)[r] = d;
+            sdy[tid * 16] = d;
+            v0 = H.alpha[p] * H.logp[r] - fminf(a, b);
+            v1 = H.logp[r];
+        }
+        if (which == 0) {
+            if (tid < 64) {
+#pragma unroll
+                for (int off = 16; off > 0; off >>= 1) { v0 += __shfl_down(v0, off, 64); v1 += __shfl_down(v1, off, 64); }
+            }
+            const float v2[2] = {v0, v1};
+            const int tile = row0 / NLBAC_MLP_TILE;
+            if (publish_and_elect<2>(H.partials + ((long)p * n_tiles + tile) * 2, v2, H.ticket, (unsigned)(n_prob * n_tiles))) {
+                for (int pp = 0; pp < n_prob; ++pp) {
+                    float s[2];
+                    elected_tile_sums<2>(H.partials + (long)pp * n_tiles * 2, n_tiles, 2, s, red);
+                    if (tid == 0)
+                        actor_scalars_one(s[0], s[1], pp, H.B_norm, H.actor.target_entropy, H.actor.log_alpha[pp],
+                                          H.actor.g_log_alpha[pp], H.actor.sc);
+                }
+            }
+        }
+    }
+}

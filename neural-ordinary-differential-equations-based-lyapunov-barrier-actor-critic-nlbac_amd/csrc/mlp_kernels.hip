@@ -23,6 +23,7 @@
 #include <cstdlib>
 #include "common.h"
 #include "mlp_device.h"
+#include "dy_heads.h"
 
 struct MlpLaunch {
     nlbac_mlp net[NLBAC_MAX_NETS];
@@ -85,7 +86,8 @@ __global__ __launch_bounds__(256) void mlp_pack_kernel(const MlpLaunch L) {
 // OCC (MODE 3): cap the kernel at 128 VGPRs so that two workgroups share a CU (a few spills): pays once the grid has
 // more tiles than CUs (6 nets x 128 tiles: 45 -> 43 us), costs ~1 us on the one- and two-net launches.
 template <int MODE, int OCC = 0>
-__global__ __launch_bounds__(MODE == 3 ? 512 : 256, OCC ? 4 : 2) void mlp_fwd_kernel(const MlpLaunch L) {
+__global__ __launch_bounds__(MODE == 3 ? 512 : 256, OCC ? 4 : 2) void mlp_fwd_kernel(const MlpLaunch L,
+                                                                                        const nlbac_gauss_head G) {
     constexpr int NTHR = (MODE == 3) ? 512 : 256;
     constexpr bool ONE = (MODE == 1 || MODE == 3);      // one column tile per wave
     extern __shared__ __attribute__((aligned(16))) float smem[];
@@ -159,6 +161,11 @@ __global__ __launch_bounds__(MODE == 3 ? 512 : 256, OCC ? 4 : 2) void mlp_fwd_ke
                 if (no > 3) y[3] = a[3] + bias[o0 + 3];
             }
         }
+        // squashed-Gaussian head (nlbac_gauss_head): the thread that has just written a row's (mean | log_std) draws
+        // the row's action and log-probability from it — gauss_fwd_kernel's arithmetic, no launch of its own
+        if (G.eps && part == 0 && row < B)
+            gauss_fwd_row(io.y + (long)row * io.y_ld, G.eps, G.scale, G.bias, G.n_u, (long)blockIdx.y * B + row, G.action,
+                          G.action_ld, G.logp);
     }
 }
 
@@ -187,7 +194,7 @@ __device__ __forceinline__ void dx_dot(const float* __restrict__ lds_row, const 
 }
 
 template <int MODE>
-__global__ __launch_bounds__(256, 2) void mlp_bwd_data_kernel(const MlpLaunch L) {
+__global__ __launch_bounds__(256, 2) void mlp_bwd_data_kernel(const MlpLaunch L, const nlbac_dy_head H) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     const nlbac_mlp& net = L.net[blockIdx.y];
     const nlbac_mlp_io& io = L.io[blockIdx.y];
@@ -214,9 +221,13 @@ __global__ __launch_bounds__(256, 2) void mlp_bwd_data_kernel(const MlpLaunch L)
         if constexpr (MODE != 1) { if (two) bwd_prime<2>(wg2, net, wave, lane); }
         if constexpr (MODE != 2) { if (!two) bwd_prime<1>(wg1, net, wave, lane); }
     }
-    for (int idx = tid; idx < NLBAC_MLP_TILE * 16; idx += 256) {
-        const int r = idx >> 4, c = idx & 15, row = row0 + r;
-        sdy[idx] = (row < B && c < net.out_dim) ? io.dy[(long)row * io.dy_ld + c] : 0.f;
+    if (H.kind == 0) {
+        for (int idx = tid; idx < NLBAC_MLP_TILE * 16; idx += 256) {
+            const int r = idx >> 4, c = idx & 15, row = row0 + r;
+            sdy[idx] = (row < B && c < net.out_dim) ? io.dy[(long)row * io.dy_ld + c] : 0.f;
+        }
+    } else {
+        dy_head_fill(H, blockIdx.y, row0, B, gridDim.x, sdy, sx);     // (dy heads: dL/dy is produced here, dy_heads.h)
     }
     if (sk)
         for (int idx = tid; idx < NLBAC_MLP_TILE * 16; idx += 256) {
@@ -802,48 +813,96 @@ extern "C" int nlbac_mlp_pack(const nlbac_mlp* nets, int n_nets, nlbac_stream_t 
     return 0;
 }
 
-extern "C" int nlbac_mlp_fwd(const nlbac_mlp* nets, const nlbac_mlp_io* io, int n_nets, int B, nlbac_stream_t s) {
+static int mlp_fwd_launch(const nlbac_mlp* nets, const nlbac_mlp_io* io, int n_nets, int B, const nlbac_gauss_head& G,
+                          const char* who, nlbac_stream_t s) {
     MlpLaunch L;
-    if (fill_launch(L, nets, io, n_nets, B, "nlbac_mlp_fwd")) return -1;
+    if (fill_launch(L, nets, io, n_nets, B, who)) return -1;
     for (int i = 0; i < n_nets; ++i) {
-        NLBAC_REQUIRE(io[i].x0 && io[i].y, "nlbac_mlp_fwd: net %d needs x0 and y", i);
+        NLBAC_REQUIRE(io[i].x0 && io[i].y, "%s: net %d needs x0 and y", who, i);
         NLBAC_REQUIRE(io[i].x0_dim == nets[i].in_dim || (io[i].x1 && io[i].x0_dim + io[i].x1_dim == nets[i].in_dim),
-                      "nlbac_mlp_fwd: net %d input dims %d+%d != in_dim %d", i, io[i].x0_dim, io[i].x1_dim, nets[i].in_dim);
+                      "%s: net %d input dims %d+%d != in_dim %d", who, i, io[i].x0_dim, io[i].x1_dim, nets[i].in_dim);
     }
     const size_t lds = (size_t)2 * NLBAC_MLP_TILE * L.ld * sizeof(float);
     const dim3 grid(nlbac_ceil_div(B, NLBAC_MLP_TILE), n_nets);
     switch (tile_mode(nets, n_nets)) {
-        case 1: hipLaunchKernelGGL(mlp_fwd_kernel<1>, grid, dim3(256), lds, (hipStream_t)s, L); break;
+        case 1: hipLaunchKernelGGL(mlp_fwd_kernel<1>, grid, dim3(256), lds, (hipStream_t)s, L, G); break;
         case 2:
             if (waves8() && lds <= 80 * 1024 &&
                 (occ_mode() == 1 || (occ_mode() < 0 && (long)grid.x * grid.y > 256)))
-                hipLaunchKernelGGL((mlp_fwd_kernel<3, 1>), grid, dim3(512), lds, (hipStream_t)s, L);
-            else if (waves8()) hipLaunchKernelGGL(mlp_fwd_kernel<3>, grid, dim3(512), lds, (hipStream_t)s, L);
-            else hipLaunchKernelGGL(mlp_fwd_kernel<2>, grid, dim3(256), lds, (hipStream_t)s, L);
+                hipLaunchKernelGGL((mlp_fwd_kernel<3, 1>), grid, dim3(512), lds, (hipStream_t)s, L, G);
+            else if (waves8()) hipLaunchKernelGGL(mlp_fwd_kernel<3>, grid, dim3(512), lds, (hipStream_t)s, L, G);
+            else hipLaunchKernelGGL(mlp_fwd_kernel<2>, grid, dim3(256), lds, (hipStream_t)s, L, G);
             break;
-        default: hipLaunchKernelGGL(mlp_fwd_kernel<0>, grid, dim3(256), lds, (hipStream_t)s, L);
+        default: hipLaunchKernelGGL(mlp_fwd_kernel<0>, grid, dim3(256), lds, (hipStream_t)s, L, G);
     }
-    NLBAC_CHECK_LAUNCH("nlbac_mlp_fwd");
+    NLBAC_CHECK_LAUNCH(who);
+    return 0;
+}
+
+extern "C" int nlbac_mlp_fwd(const nlbac_mlp* nets, const nlbac_mlp_io* io, int n_nets, int B, nlbac_stream_t s) {
+    nlbac_gauss_head G;
+    memset(&G, 0, sizeof(G));
+    return mlp_fwd_launch(nets, io, n_nets, B, G, "nlbac_mlp_fwd", s);
+}
+
+extern "C" int nlbac_mlp_fwd_gauss(const nlbac_mlp* nets, const nlbac_mlp_io* io, int n_nets, int B,
+                                   const nlbac_gauss_head* head, nlbac_stream_t s) {
+    const char* who = "nlbac_mlp_fwd_gauss";
+    NLBAC_REQUIRE(head && head->eps && head->scale && head->bias && head->action && head->logp && head->n_u >= 1 &&
+                      head->n_u <= MAX_NU, "%s: bad head", who);
+    for (int i = 0; i < n_nets; ++i)
+        NLBAC_REQUIRE(nets[i].out_dim == 2 * head->n_u && io[i].y_ld >= 2 * head->n_u, "%s: net %d must have 2 n_u outputs", who, i);
+    return mlp_fwd_launch(nets, io, n_nets, B, *head, who, s);
+}
+
+static int mlp_bwd_data_launch(const nlbac_mlp* nets, const nlbac_mlp_io* io, int n_nets, int B, const nlbac_dy_head& H,
+                               const char* who, nlbac_stream_t s) {
+    MlpLaunch L;
+    if (fill_launch(L, nets, io, n_nets, B, who)) return -1;
+    for (int i = 0; i < n_nets; ++i)
+        NLBAC_REQUIRE((io[i].dy || H.kind) && io[i].acts, "%s: net %d needs dy and acts", who, i);
+    for (int i = 0; i < n_nets; ++i)
+        NLBAC_REQUIRE(!io[i].skinny_ws || (B <= 32768 && io[i].x0 && io[i].dz && nets[i].hid <= 256),
+                      "%s: net %d: skinny-gradient partials need x0, dz, hid <= 256 and B <= 32768", who, i);
+    const size_t lds = ((size_t)2 * NLBAC_MLP_TILE * L.ld + 2 * NLBAC_MLP_TILE * 16) * sizeof(float);
+    const dim3 grid(nlbac_ceil_div(B, NLBAC_MLP_TILE), n_nets);
+    switch (tile_mode(nets, n_nets)) {
+        case 1: hipLaunchKernelGGL(mlp_bwd_data_kernel<1>, grid, dim3(256), lds, (hipStream_t)s, L, H); break;
+        case 2: hipLaunchKernelGGL(mlp_bwd_data_kernel<2>, grid, dim3(256), lds, (hipStream_t)s, L, H); break;
+        default: hipLaunchKernelGGL(mlp_bwd_data_kernel<0>, grid, dim3(256), lds, (hipStream_t)s, L, H);
+    }
+    NLBAC_CHECK_LAUNCH(who);
     return 0;
 }
 
 extern "C" int nlbac_mlp_bwd_data(const nlbac_mlp* nets, const nlbac_mlp_io* io, int n_nets, int B, nlbac_stream_t s) {
-    MlpLaunch L;
-    if (fill_launch(L, nets, io, n_nets, B, "nlbac_mlp_bwd_data")) return -1;
-    for (int i = 0; i < n_nets; ++i)
-        NLBAC_REQUIRE(io[i].dy && io[i].acts, "nlbac_mlp_bwd_data: net %d needs dy and acts", i);
-    for (int i = 0; i < n_nets; ++i)
-        NLBAC_REQUIRE(!io[i].skinny_ws || (B <= 32768 && io[i].x0 && io[i].dz && nets[i].hid <= 256),
-                      "nlbac_mlp_bwd_data: net %d: skinny-gradient partials need x0, dz, hid <= 256 and B <= 32768", i);
-    const size_t lds = ((size_t)2 * NLBAC_MLP_TILE * L.ld + 2 * NLBAC_MLP_TILE * 16) * sizeof(float);
-    const dim3 grid(nlbac_ceil_div(B, NLBAC_MLP_TILE), n_nets);
-    switch (tile_mode(nets, n_nets)) {
-        case 1: hipLaunchKernelGGL(mlp_bwd_data_kernel<1>, grid, dim3(256), lds, (hipStream_t)s, L); break;
-        case 2: hipLaunchKernelGGL(mlp_bwd_data_kernel<2>, grid, dim3(256), lds, (hipStream_t)s, L); break;
-        default: hipLaunchKernelGGL(mlp_bwd_data_kernel<0>, grid, dim3(256), lds, (hipStream_t)s, L);
+    nlbac_dy_head H;
+    memset(&H, 0, sizeof(H));
+    return mlp_bwd_data_launch(nets, io, n_nets, B, H, "nlbac_mlp_bwd_data", s);
+}
+
+extern "C" int nlbac_mlp_bwd_data_head(const nlbac_mlp* nets, const nlbac_mlp_io* io, int n_nets, int B,
+                                       const nlbac_dy_head* head, nlbac_stream_t s) {
+    const char* who = "nlbac_mlp_bwd_data_head";
+    NLBAC_REQUIRE(head && head->kind >= 1 && head->kind <= 3 && head->B_norm >= 1, "%s: bad head", who);
+    const nlbac_dy_head& H = *head;
+    if (H.kind == 1) {
+        NLBAC_REQUIRE(H.heads && H.eps && H.scale && H.alpha && H.n_u >= 1 && H.n_u <= MAX_NU, "%s: gauss head: null pointer / bad n_u", who);
+        for (int i = 0; i < n_nets; ++i) NLBAC_REQUIRE(nets[i].out_dim == 2 * H.n_u, "%s: gauss head: net %d must have 2 n_u outputs", who, i);
+    } else if (H.kind == 2) {
+        NLBAC_REQUIRE(n_nets == 3 && H.q1t && H.q2t && H.lt && H.nlogp && H.reward && H.constraint && H.mask && H.alpha &&
+                          H.q[0] && H.q[1] && H.q[2] && H.dq[0] && H.dq[1] && H.dq[2] && H.partials && H.ticket && H.out,
+                      "%s: td head: 3 nets (Q1, Q2, Lyapunov) and all pointers", who);
+        for (int i = 0; i < 3; ++i) NLBAC_REQUIRE(nets[i].out_dim == 1, "%s: td head: scalar nets", who);
+    } else {
+        NLBAC_REQUIRE(H.n_prob >= 1 && H.n_prob <= 2 && n_nets == 2 * H.n_prob && H.qa && H.qb && H.logp && H.alpha && H.dqa &&
+                          H.dqb && H.partials && H.ticket && H.actor.sc,
+                      "%s: actor head: 2 nets per controller and all pointers", who);
+        for (int p = 0; p < H.n_prob; ++p)
+            NLBAC_REQUIRE(H.actor.log_alpha[p] && H.actor.g_log_alpha[p], "%s: actor head: missing log_alpha pointers", who);
+        for (int i = 0; i < n_nets; ++i) NLBAC_REQUIRE(nets[i].out_dim == 1, "%s: actor head: scalar nets", who);
     }
-    NLBAC_CHECK_LAUNCH("nlbac_mlp_bwd_data");
-    return 0;
+    return mlp_bwd_data_launch(nets, io, n_nets, B, H, who, s);
 }
 
 // rows per partial-sum chunk of the skinny-gradient reduction: short chunks so that >= 1 workgroup per CU streams

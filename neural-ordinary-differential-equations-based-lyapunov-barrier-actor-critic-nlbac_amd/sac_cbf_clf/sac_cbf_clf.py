@@ -87,6 +87,8 @@ class _Workspace:
         self.dz_c = z(3 + NX, 2, B, H)
         self.nblk = (B + 255) // 256
         self.part_td = z(self.nblk, 3)
+        self.n_tiles = (B + _lib.MLP_TILE - 1) // _lib.MLP_TILE
+        self.part_td32 = z(self.n_tiles, 3)            # per-32-row-tile sums of the fused dy heads (nlbac_dy_head)
         self.part_tdx = z(max(NX, 1), self.nblk)
         self.heads2, self.pi2, self.logp2 = self.heads3[B:], self.act3[B:], self.logp3[B:]
         self.acts_p = z(NP, 2, B, H)
@@ -97,6 +99,7 @@ class _Workspace:
         self.acts_q = z(2 * NP, 2, B, H)
         self.dq_pi = z(2, NP * B)
         self.part_q = z(NP, self.nblk, 2)
+        self.part_q32 = z(NP, self.n_tiles, 2)
         self.dxq = z(2, NP * B, Do + A)
         self.dheads2 = z(NP * B, 2 * A)
         task.alloc(self)
@@ -791,9 +794,13 @@ class SAC_CBF_CLF(object):
         # ---- A. targets (no grad): pi(s'), Q_target(s', a'), L_target(c') ; critic / Lyapunov forward
         # (the actors' forward on s does not depend on the critic step below: it shares pi(s')'s launch, and all
         #  (1+NP)*B samples are drawn by one launch - eps[0 .. NP] are contiguous)
-        call("nlbac_mlp_fwd", P.n_pol3, P.io_pol3, 1 + NP, B, s)
-        call("nlbac_gauss_sample_fwd", ws.heads3.data_ptr(), 2 * A, ws.eps.data_ptr(), p_scale, p_bias, A, (1 + NP) * B,
-             ws.act3.data_ptr(), A, ws.logp3.data_ptr(), s)
+        # (the samples are drawn by the policy launch itself: nlbac_gauss_head)
+        gh = P.__dict__.get("head_pol3")
+        if gh is None:
+            gh = P.head_pol3 = _lib.GaussHead()
+            gh.eps, gh.scale, gh.bias, gh.n_u = ws.eps.data_ptr(), p_scale, p_bias, A
+            gh.action, gh.action_ld, gh.logp = ws.act3.data_ptr(), A, ws.logp3.data_ptr()
+        call("nlbac_mlp_fwd_gauss", P.n_pol3, P.io_pol3, 1 + NP, B, C.byref(gh), s)
         # the rollout of the learned dynamics needs only pi(s) and the NODE: its first attempted step goes in here,
         # so that the critic phase below is queued behind it while the host waits for the accept decision
         self.task.rollout_begin(ws, P)
@@ -825,6 +832,23 @@ class SAC_CBF_CLF(object):
         one = self.world == 1
         call("nlbac_mlp_fwd", P.n_six, P.io_six, P.n_six_count, B, s)
         q = ws.q6
+        if one and not self.h_extra:
+            # single GPU, no extra critic: targets, dL/dq and the three losses are produced by the critics' data backward
+            # itself (nlbac_dy_head kind 2) — no launch between the six-net forward and the backward
+            H = P.__dict__.get("head_td")
+            if H is None:
+                H = P.head_td = _lib.DyHead()
+                H.kind, H.B_norm = 2, G
+                H.q1t, H.q2t, H.lt, H.nlogp = q[0].data_ptr(), q[1].data_ptr(), q[2].data_ptr(), ws.nlogp.data_ptr()
+                H.reward, H.constraint, H.mask, H.rcm_ld = P.p_rew, P.p_con, P.p_mask, LD
+                H.alpha, H.gamma = sc + 4 * SC.SC_ALPHA, self.gamma
+                for k in range(3):
+                    H.q[k], H.dq[k] = q[3 + k].data_ptr(), ws.dq3[k].data_ptr()
+                H.next_q, H.next_l = ws.next_q.data_ptr(), ws.next_l.data_ptr()
+                H.partials, H.ticket = ws.part_td32.data_ptr(), self._tickets.data_ptr()
+                H.mul, H.out = 1.0 / G, sc + 4 * SC.SC_QF1
+            call("nlbac_mlp_bwd_data_head", P.n_crit, P.io_crit, len(self.h_crit), B, C.byref(H), s)
+            return
         call("nlbac_td_targets", q[0].data_ptr(), q[1].data_ptr(), q[2].data_ptr(), ws.nlogp.data_ptr(),
              P.p_rew, P.p_con, P.p_mask, LD, q[3].data_ptr(), q[4].data_ptr(), q[5].data_ptr(),
              sc + 4 * SC.SC_ALPHA, self.gamma, B, G, ws.dq3[0].data_ptr(), ws.dq3[1].data_ptr(), ws.dq3[2].data_ptr(),
@@ -852,6 +876,8 @@ class SAC_CBF_CLF(object):
         # ---- C. actors: Q(s, pi) with the stepped critics (the rollout was started in phase A) -----
         sc, call = self.sc.data_ptr(), _lib.call
         call("nlbac_mlp_fwd", P.n_q5, P.io_q5, P.n_q5_count, B, s)
+        if self.world == 1:
+            return               # (the branch terms and their sums come out of the Q(s, pi) data backward: _actor_q_head)
         fused = None
         if self.world == 1:      # policy_loss_1 / alpha losses / d log_alpha by the launch's last workgroup (nlbac_actor_scalars)
             fused = P.__dict__.get("actor_scalars")
@@ -867,6 +893,24 @@ class SAC_CBF_CLF(object):
              sc + 4 * SC.SC_ALPHA, B, G, NP, ws.dq_pi[0].data_ptr(), ws.dq_pi[1].data_ptr(), ws.part_q.data_ptr(),
              C.byref(fused) if fused is not None else None, self._tickets.data_ptr() + 4 * 8 if fused is not None else None, s)
 
+    def _actor_q_head(self, ws, P, NP, G):
+        H = P.__dict__.get("head_actor_q")
+        if H is None:
+            sc = self.sc.data_ptr()
+            H = P.head_actor_q = _lib.DyHead()
+            H.kind, H.B_norm, H.n_prob = 3, G, NP
+            H.qa, H.qb, H.logp = ws.qpi[0].data_ptr(), ws.qpi[1].data_ptr(), ws.logp2.data_ptr()
+            H.dqa, H.dqb = ws.dq_pi[0].data_ptr(), ws.dq_pi[1].data_ptr()
+            H.alpha = sc + 4 * SC.SC_ALPHA
+            H.actor.target_entropy, H.actor.sc = self.target_entropy, sc
+            for g in self.actor_groups:
+                for k in range(min(g.count, NP - g.first)):
+                    off = g.la_off + k * g.la_stride
+                    H.actor.log_alpha[g.first + k] = g.arena.theta.data_ptr() + 4 * off
+                    H.actor.g_log_alpha[g.first + k] = g.arena.grad.data_ptr() + 4 * off
+            H.partials, H.ticket = ws.part_q32.data_ptr(), self._tickets.data_ptr() + 4 * 8
+        return H
+
     def _upd_part2(self, ws, lam_upd, assume_single):
         """Constraints, augmented-Lagrangian scalars, the whole actor backward and the actor Adam step."""
         B, A, Do = ws.B, self.lay.act_dim, self.lay.obs_dim
@@ -880,12 +924,25 @@ class SAC_CBF_CLF(object):
         eps2 = ws.eps[1:1 + NP]
         du2, du_ld = self.task.loss_and_backward(ws, P, lam_upd, assume_single)
 
-        call("nlbac_mlp_bwd_data", P.n_q5, P.io_q5, 2 * NP, B, s)   # the Q(s, pi) nets: dx only
+        # the Q(s, pi) nets (dx only): single GPU — d min(Q1, Q2), policy_loss_1, the alpha losses and d log_alpha are
+        # produced by this launch (nlbac_dy_head kind 3); data parallel — nlbac_actor_q_terms ran in part 1
+        if self.world == 1:
+            call("nlbac_mlp_bwd_data_head", P.n_q5, P.io_q5, 2 * NP, B, C.byref(self._actor_q_head(ws, P, NP, G)), s)
+        else:
+            call("nlbac_mlp_bwd_data", P.n_q5, P.io_q5, 2 * NP, B, s)
+        # the actors: d heads from d action (two Q nets + the rollout) and d logp, inside their data backward (kind 1)
         D = Do + A
-        call("nlbac_gauss_sample_bwd", ws.heads2.data_ptr(), 2 * A, eps2.data_ptr(), p_scale, A,
-             NP * B, B, ws.dxq[0].data_ptr() + 4 * Do, D, ws.dxq[1].data_ptr() + 4 * Do, D, du2.data_ptr(), du_ld,
-             sc + 4 * SC.SC_ALPHA, 1.0 / G, ws.dheads2.data_ptr(), 2 * A, s)
-        call("nlbac_mlp_bwd_data", P.n_act, P.io_act, NP, B, s)
+        H = P.__dict__.get("head_gauss")
+        if H is None:
+            H = P.head_gauss = _lib.DyHead()
+            H.kind, H.B_norm = 1, G
+            H.heads, H.heads_ld, H.eps, H.scale, H.n_u = ws.heads2.data_ptr(), 2 * A, eps2.data_ptr(), p_scale, A
+            H.da[0], H.da_ld[0] = ws.dxq[0].data_ptr() + 4 * Do, D
+            H.da[1], H.da_ld[1] = ws.dxq[1].data_ptr() + 4 * Do, D
+            H.alpha, H.dlogp_mul = sc + 4 * SC.SC_ALPHA, 1.0 / G
+            H.dheads, H.dheads_ld = ws.dheads2.data_ptr(), 2 * A
+        H.da[2], H.da_ld[2] = du2.data_ptr(), du_ld
+        call("nlbac_mlp_bwd_data_head", P.n_act, P.io_act, NP, B, C.byref(H), s)
         tune = self.automatic_entropy_tuning
         p_part_q, n_part = ws.p_part_q, ws.n_part_q
         for g, cnt, nets, gio, sk_ws in P.act_groups:
