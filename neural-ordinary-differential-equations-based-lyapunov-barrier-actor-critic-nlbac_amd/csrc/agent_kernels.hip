@@ -23,16 +23,25 @@ struct AuglagArgs {        // nlbac_auglag's scalar arguments, by value (nlbac_a
 template <bool COHERENT>
 __device__ __forceinline__ void auglag_body(const float* partials, int n_blk, const AuglagArgs A, float* sc);
 
-// runtime-width variant of publish_and_elect (common.h)
+// runtime-width variant of publish_and_elect (common.h), n <= 64: the n exchanges are ONE wave instruction (lane k
+// publishes value k) — issued by thread 0 alone they were n dependent round trips to the memory side, ~0.6 us each
+// (15 columns: unicycle_constraints_fwd 14.6 -> ~6 us)
 __device__ __forceinline__ bool publish_and_elect_n(float* dst, const float* vals, int n, unsigned* ticket, unsigned n_blocks) {
     __shared__ unsigned s_elect_n_;
-    if (threadIdx.x == 0) {
-        float acc = 0.f;
-        for (int k = 0; k < n; ++k) acc += __hip_atomic_exchange(dst + k, vals[k], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        asm volatile("" ::"v"(acc) : "memory");
-        const unsigned t = __hip_atomic_fetch_add(ticket, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        s_elect_n_ = (t == n_blocks - 1u) ? 1u : 0u;
-        if (s_elect_n_) __hip_atomic_store(ticket, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    __shared__ float s_vals_n_[64];
+    if (threadIdx.x == 0)
+        for (int k = 0; k < n; ++k) s_vals_n_[k] = vals[k];
+    __syncthreads();
+    if (threadIdx.x < 64) {
+        float old = 0.f;
+        if ((int)threadIdx.x < n)
+            old = __hip_atomic_exchange(dst + threadIdx.x, s_vals_n_[threadIdx.x], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        asm volatile("" ::"v"(old) : "memory");        // every lane's exchange has returned before the ticket is taken
+        if (threadIdx.x == 0) {
+            const unsigned t = __hip_atomic_fetch_add(ticket, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            s_elect_n_ = (t == n_blocks - 1u) ? 1u : 0u;
+            if (s_elect_n_) __hip_atomic_store(ticket, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
     }
     __syncthreads();
     return s_elect_n_ != 0u;

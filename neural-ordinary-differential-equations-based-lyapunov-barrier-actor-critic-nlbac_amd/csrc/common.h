@@ -48,20 +48,29 @@ __device__ __forceinline__ void block_sum_256(float (&v)[NV], float* lds /* >= 4
 
 // Last-workgroup election for "partials -> final value in the same launch", WITHOUT an agent-scope fence: on gfx950 a
 // release at agent scope writes the XCD's whole L2 back (node_kernels.hip measured +15..30 us for it behind a kernel's
-// own stores).  Thread 0 publishes the block's N partial results with device-scope atomic exchanges (performed at the
-// level every XCD sees), waits for them to return, then takes a ticket; the block that draws the last ticket reads the
+// own stores).  Wave 0 publishes thread 0's N partial results with device-scope atomic exchanges (performed at the
+// level every XCD sees), waits for them to return, then thread 0 takes a ticket; the block that draws the last ticket reads the
 // others' results with ``coherent_load``.  Returns the verdict in every thread of the block (contains a barrier).
 template <int N>
 __device__ __forceinline__ bool publish_and_elect(float* dst, const float (&vals)[N], unsigned* ticket, unsigned n_blocks) {
     __shared__ unsigned s_elect_;
-    if (threadIdx.x == 0) {
-        float acc = 0.f;
+    if (threadIdx.x < 64) {
+        // thread 0's N values go out as ONE wave instruction (lane k sends value k): N dependent round trips to the
+        // memory side otherwise, ~0.6 us each
+        float mine = 0.f;
 #pragma unroll
-        for (int k = 0; k < N; ++k) acc += __hip_atomic_exchange(dst + k, vals[k], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        asm volatile("" ::"v"(acc) : "memory");        // every exchange has returned before the ticket is taken
-        const unsigned t = __hip_atomic_fetch_add(ticket, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        s_elect_ = (t == n_blocks - 1u) ? 1u : 0u;
-        if (s_elect_) __hip_atomic_store(ticket, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        for (int k = 0; k < N; ++k) {
+            const float bk = __shfl(vals[k], 0, 64);
+            if ((int)threadIdx.x == k) mine = bk;
+        }
+        float old = 0.f;
+        if ((int)threadIdx.x < N) old = __hip_atomic_exchange(dst + threadIdx.x, mine, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        asm volatile("" ::"v"(old) : "memory");        // every exchange has returned before the ticket is taken
+        if (threadIdx.x == 0) {
+            const unsigned t = __hip_atomic_fetch_add(ticket, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            s_elect_ = (t == n_blocks - 1u) ? 1u : 0u;
+            if (s_elect_) __hip_atomic_store(ticket, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
     }
     __syncthreads();
     return s_elect_ != 0u;

@@ -96,7 +96,7 @@ __global__ __launch_bounds__(256) void rk_stage_bwd_kernel(const float* dYup, co
 __device__ __forceinline__ void dopri_norm_block(const float* a, const float* b, const float* y0, const float* y1,
                                                  const float* u, int mode, float rtol, float atol, int n_s, int n_u,
                                                  int rpp, float* partials, const double* slot_ctl = nullptr,
-                                                 long slot_floats = 0) {
+                                                 long slot_floats = 0, bool publish = false) {
     __shared__ float red[8];
     const int p = blockIdx.y;
     if (slot_ctl) {      // device-driven chain (mode 2): the attempt's buffers are those of step slot C_NACC
@@ -134,9 +134,18 @@ __device__ __forceinline__ void dopri_norm_block(const float* a, const float* b,
             }
     }
     block_sum_256<2>(v, red);
-    if (threadIdx.x == 0) {
-        partials[((long)p * gridDim.x + blockIdx.x) * 2 + 0] = v[0];
-        partials[((long)p * gridDim.x + blockIdx.x) * 2 + 1] = v[1];
+    float* q = partials + ((long)p * gridDim.x + blockIdx.x) * 2;
+    if (!publish) {
+        if (threadIdx.x == 0) { q[0] = v[0]; q[1] = v[1]; }
+        return;
+    }
+    // for a reader in another workgroup of THIS launch (dopri_norm_control_kernel): both sums leave as device-scope
+    // atomic exchanges, one wave instruction, and have returned when this function does — no agent-scope fence, which on
+    // gfx950 writes the XCD's L2 back (common.h::publish_and_elect)
+    if (threadIdx.x < 64) {
+        float old = 0.f;
+        if (threadIdx.x < 2) old = __hip_atomic_exchange(q + threadIdx.x, threadIdx.x ? v[1] : v[0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        asm volatile("" ::"v"(old) : "memory");
     }
 }
 
@@ -192,19 +201,17 @@ __global__ __launch_bounds__(256) void dopri_norm_control_kernel(const float* a,
                                                                  double* ctl_host) {
     // device-driven chain (slot_ctl): a finished problem is left alone by all of its blocks
     if (slot_ctl && mode == 2 && slot_ctl[(long)blockIdx.y * NLBAC_DOPRI_CTL + C_DONE] > 0.0) return;
-    dopri_norm_block(a, b, y0, y1, u, mode, rtol, atol, n_s, n_u, rpp, partials, slot_ctl, slot_floats);
+    dopri_norm_block(a, b, y0, y1, u, mode, rtol, atol, n_s, n_u, rpp, partials, slot_ctl, slot_floats, true);
     __shared__ unsigned s_last;
     __shared__ double s_red[2][256];
     const int p = blockIdx.y, nblk = (int)gridDim.x;
-    if (threadIdx.x == 0) {
-        __threadfence();                               // this block's sums are visible device-wide before its ticket
-        const unsigned ticket = __hip_atomic_fetch_add(tickets + p, 1u, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT);
+    if (threadIdx.x == 0) {                            // (this block's sums have been performed device-wide: see above)
+        const unsigned ticket = __hip_atomic_fetch_add(tickets + p, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         s_last = (ticket == gridDim.x - 1) ? 1u : 0u;
         if (s_last) __hip_atomic_store(tickets + p, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
     __syncthreads();
     if (!s_last) return;                               // (uniform per block)
-    __threadfence();
     // the sums were written by other workgroups of this launch: read them past the non-coherent caches; fixed
     // assignment of blocks to lanes and a fixed tree, so the result does not depend on which block came last
     double v0 = 0.0, v1 = 0.0;
