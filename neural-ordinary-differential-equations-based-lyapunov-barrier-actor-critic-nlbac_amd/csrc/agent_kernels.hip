@@ -295,9 +295,20 @@ __device__ __forceinline__ void auglag_body(const float* partials, int n_blk, co
     const int do_lambda_update = A.do_lambda_update, do_backup_lambda_update = A.do_backup_lambda_update;
     const float batch_size = A.batch_size, lam_lo = A.lam_lo, lam_hi = A.lam_hi;
     const int nc = n_cbf + n_clf, ncol = nc + (backup_mode ? n_cbf : 0);
+    // the other workgroups' partial sums come in with ONE round of device-scope loads (every thread a few), staged in
+    // LDS, then column c is summed in block order by thread c — n_blk dependent loads per column took ~0.6 us each
+    // (16 blocks: unicycle_constraints_fwd 15 us, two thirds of it here)
+    __shared__ float s_stage[128 * 36];
+    const int n_all = n_blk * ncol;
+    const bool staged = COHERENT && n_all <= 128 * 36;
+    if (staged) {
+        for (int idx = threadIdx.x; idx < n_all; idx += blockDim.x) s_stage[idx] = coherent_load(partials + idx);
+        __syncthreads();
+    }
     for (int c = threadIdx.x; c < ncol; c += blockDim.x) {
         float s = 0.f;
-        for (int b = 0; b < n_blk; ++b) s += COHERENT ? coherent_load(partials + (long)b * ncol + c) : partials[(long)b * ncol + c];
+        for (int b = 0; b < n_blk; ++b)
+            s += staged ? s_stage[b * ncol + c] : (COHERENT ? coherent_load(partials + (long)b * ncol + c) : partials[(long)b * ncol + c]);
         s = s / batch_size;
         if (c < nc) sc[SC_REQ + c] = s; else sc[SC_BREQ + (c - nc)] = s;
     }

@@ -1,5 +1,6 @@
 """GPU idle time between consecutive kernels of a rocprofv3 kernel trace (``*_kernel_trace.csv``), per update
-(updates are delimited by the ``td_targets`` launch).  Usage: python tools/gap_report.py TRACE.csv [first last]"""
+(updates are delimited by the minibatch draw, ``sample_rows``; a NODE fit draws a second time, so pick a window
+between two fits — tools/update_table.py prints the kernel table of the same window).  Usage: python tools/gap_report.py TRACE.csv [first last]"""
 import collections
 import csv
 import sys
@@ -7,8 +8,9 @@ import sys
 
 def main():
     rows = list(csv.DictReader(open(sys.argv[1])))
-    ks = sorted((int(r["Start_Timestamp"]), int(r["End_Timestamp"]), r["Kernel_Name"].split("(")[0][:44]) for r in rows)
-    marks = [i for i, k in enumerate(ks) if k[2].startswith("td_targets")]
+    ks = sorted((int(r["Start_Timestamp"]), int(r["End_Timestamp"]), r["Kernel_Name"].split("(")[0].replace("void ", "")[:44])
+                for r in rows)
+    marks = [i for i, k in enumerate(ks) if k[2].startswith("sample_rows")]
     a = int(sys.argv[2]) if len(sys.argv) > 2 else 61
     b = int(sys.argv[3]) if len(sys.argv) > 3 else 69
     seg = ks[marks[a]:marks[b]]

@@ -20,9 +20,8 @@ echo "== 2 ranks sharing the card (gloo rehearsal of the N>1 line: weak + strong
 NLBAC_BENCH_BACKEND=gloo python -m torch.distributed.run --nnodes=1 --nproc-per-node 2 --master-addr 127.0.0.1 --master-port 29511 bench.py --gpus 2 --steps 40 --warmup 10 --no-cpu-baseline > $O/bench_2rank_gloo.json 2> $O/bench_2rank_gloo.err || tail -5 $O/bench_2rank_gloo.err
 echo "== kernel stats"
 bash tools/gpu_prof.sh r02_headline --steps 200 --warmup 20 > $O/prof_headline.log 2>&1
-echo "== counters"
-bash tools/gpu_pmc.sh unicycle_dopri5_B4096 > $O/pmc_u.log 2>&1
-bash tools/gpu_pmc.sh pvtol_dopri5_B16384_adjoint --env Pvtol --batch 16384 --adjoint > $O/pmc_pa.log 2>&1
-bash tools/gpu_pmc.sh pvtol_dopri5_B16384 --env Pvtol --batch 16384 > $O/pmc_pd.log 2>&1
-bash tools/gpu_pmc_mfma.sh unicycle_dopri5_B4096 --steps 30 --warmup 10 > $O/pmc_mfma.log 2>&1
+python tools/update_table.py gpurun_out/prof_r02_headline/run_kernel_trace.csv 68 77 > $O/update_table_single_step.txt 2>&1 || true
+python tools/gap_report.py gpurun_out/prof_r02_headline/run_kernel_trace.csv 68 77 > $O/gap_report.txt 2>&1 || true
+bash tools/gpu_prof.sh r02_pvtol --env Pvtol --batch 16384 --steps 40 --warmup 10 > $O/prof_pvtol.log 2>&1
+bash tools/gpu_prof.sh r02_pvtol_adjoint --env Pvtol --batch 16384 --adjoint --steps 40 --warmup 10 > $O/prof_pvtol_adjoint.log 2>&1
 echo done
