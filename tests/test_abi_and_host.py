@@ -74,6 +74,31 @@ def test_integration_snippet_structs_match_the_compiled_header(tmp_path):
     assert (C.sizeof(ns["Mlp"]), C.sizeof(ns["MlpIO"])) == (sz_mlp, sz_io), "INTEGRATION.md's structs drifted from the header"
 
 
+def test_every_ctypes_struct_of_the_binding_matches_the_header(tmp_path):
+    """The by-pointer argument structs of the C ABI, as ``_lib`` declares them to ctypes, against sizeof() and the offset
+    of the last member in include/nlbac_hip.h (a field missing or out of order shifts everything behind it)."""
+    import ctypes as C
+    import subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    pairs = [("nlbac_mlp", _lib.Mlp, None), ("nlbac_mlp_io", _lib.MlpIO, "skinny_ws"),
+             ("nlbac_auglag_args", _lib.AuglagArgs, "lam_hi"), ("nlbac_actor_scalar_args", _lib.ActorScalarArgs, "sc"),
+             ("nlbac_rk_chain", _lib.RkChain, "ctl_host"), ("nlbac_in_map", _lib.InMap, "ps"),
+             ("nlbac_out_map", _lib.OutMap, "x"), ("nlbac_gauss_head", _lib.GaussHead, "logp"),
+             ("nlbac_dy_head", _lib.DyHead, "out")]
+    body = "".join('printf("%%zu %%zu\\n", sizeof(%s), %s);' % (c, "offsetof(%s, %s)" % (c, last) if last else "(size_t)0")
+                   for c, _, last in pairs)
+    src = tmp_path / "sz.c"
+    src.write_text('#include <stdio.h>\n#include <stddef.h>\n#include "nlbac_hip.h"\nint main(void){%s return 0;}\n' % body)
+    exe = tmp_path / "sz"
+    subprocess.run(["gcc", "-I", os.path.join(root, "include"), str(src), "-o", str(exe)], check=True)
+    out = subprocess.run([str(exe)], capture_output=True, text=True, check=True).stdout.split()
+    for k, (cname, cls, last) in enumerate(pairs):
+        size, off = int(out[2 * k]), int(out[2 * k + 1])
+        assert C.sizeof(cls) == size, "%s: ctypes %d bytes, header %d" % (cname, C.sizeof(cls), size)
+        if last:
+            assert getattr(cls, last).offset == off, "%s.%s: ctypes offset %d, header %d" % (cname, last, getattr(cls, last).offset, off)
+
+
 def test_error_reporting_is_loud(lib):
     net = _lib.Mlp()
     net.n_layers, net.in_dim, net.hid, net.out_dim = 3, 99, 256, 1     # in_dim too large
