@@ -603,6 +603,20 @@ __global__ __launch_bounds__(512) void node_rk_bwd_kernel(const NodeRkBwdLaunch 
 #undef has_data
 }
 
+// A launch that differentiates stage 0 only, and that only w.r.t. the actions (Euler's backward when neither dy0 nor the
+// weight gradients are wanted): du = g(Y_0)^T dK_0 per row — no net is touched, so no tile kernel either (the fused
+// kernel spent 17.7 us on its prologue for it).
+__global__ __launch_bounds__(256) void node_du_only_kernel(const float* __restrict__ G, const float* __restrict__ dK,
+                                                           int n, int ns, int nu, float* __restrict__ du, int du_acc) {
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= n * nu) return;
+    const int row = i / nu, c = i - row * nu;
+    float a = 0.f;
+    for (int r = 0; r < ns; ++r) a += G[(long)row * ns * nu + r * nu + c] * dK[(long)row * ns + r];
+    const float old = du_acc ? du[i] : 0.f;
+    du[i] = old + 1.0f * a;
+}
+
 extern "C" int nlbac_node_rk_bwd(const nlbac_mlp* f, const nlbac_mlp* g, const float* u, const float* G, int P,
                                  int rows_per_problem, int n_stages_total, int st_lo, int st_hi, int dx_stage0,
                                  const float* beta, const float* h_host, const double* h_dev, int h_dev_stride,
@@ -624,6 +638,15 @@ extern "C" int nlbac_node_rk_bwd(const nlbac_mlp* f, const nlbac_mlp* g, const f
                   "nlbac_node_rk_bwd: dz_f, dz_g and dG go together");
 #endif
     NLBAC_REQUIRE(h_dev || h_host || (chain && chain->hslots), "nlbac_node_rk_bwd: no step size");
+    if (!(chain && chain->ctl) && st_lo == 0 && st_hi == 1 && !dx_stage0 && !dz_f) {
+        if (du) {
+            const int n = P * rows_per_problem, nu = g->out_dim / f->in_dim;
+            hipLaunchKernelGGL(node_du_only_kernel, dim3(nlbac_ceil_div((long)n * nu, 256)), dim3(256), 0, (hipStream_t)s, G, dK, n,
+                               f->in_dim, nu, du, du_acc);
+            NLBAC_CHECK_LAUNCH("nlbac_node_rk_bwd(du only)");
+        }
+        return 0;
+    }
     NodeRkBwdLaunch L;
     memset(&L, 0, sizeof(L));
     if (chain && chain->ctl) {
