@@ -21,6 +21,7 @@ indices), one 512-byte scalars read-back and, for dopri5, one 256-byte control b
 """
 import collections
 import ctypes as C
+import os
 import random
 import types
 
@@ -240,6 +241,10 @@ class SAC_CBF_CLF(object):
         for sv in self.task.solvers:          # independent launches go in just before a solver waits for a decision
             sv.before_wait = self._fill_one
         self.use_graphs = False  # replay the update as hipGraphs (single GPU; see update_on_device)
+        # per-row steps evaluated inside the MLP / solver launches that produce or consume them (nlbac_gauss_head,
+        # nlbac_dy_head, nlbac_in_map / nlbac_out_map, results written to pinned memory by the kernels): False (or
+        # NLBAC_FOLD=0) runs every step as the launch of its own it was — same numbers, for A/B runs and the tests
+        self.fold_launches = os.environ.get("NLBAC_FOLD", "1") != "0"
         self.adjoint = bool(getattr(args, "adjoint", False))
         self.dp = None          # nlbac_amd.parallel.DataParallel when sharded over GPUs
         self._xb = {}
@@ -722,7 +727,7 @@ class SAC_CBF_CLF(object):
         # in pinned memory, so that no copy launch sits between that step and the host's wait.  Not under hipGraph
         # replay (the address would be baked in) or data parallelism (the step is not the last thing that happens).
         self._mirror = None
-        if sync and self.world == 1 and not self._graphs_on():
+        if sync and self.world == 1 and not self._graphs_on() and self.fold_launches:
             pin = self._sc_pins()
             if sync == "lagged":
                 k = 1 + (self.__dict__.get("_sc_flip", 0) & 1)
@@ -794,13 +799,17 @@ class SAC_CBF_CLF(object):
         # ---- A. targets (no grad): pi(s'), Q_target(s', a'), L_target(c') ; critic / Lyapunov forward
         # (the actors' forward on s does not depend on the critic step below: it shares pi(s')'s launch, and all
         #  (1+NP)*B samples are drawn by one launch - eps[0 .. NP] are contiguous)
-        # (the samples are drawn by the policy launch itself: nlbac_gauss_head)
-        gh = P.__dict__.get("head_pol3")
-        if gh is None:
-            gh = P.head_pol3 = _lib.GaussHead()
-            gh.eps, gh.scale, gh.bias, gh.n_u = ws.eps.data_ptr(), p_scale, p_bias, A
-            gh.action, gh.action_ld, gh.logp = ws.act3.data_ptr(), A, ws.logp3.data_ptr()
-        call("nlbac_mlp_fwd_gauss", P.n_pol3, P.io_pol3, 1 + NP, B, C.byref(gh), s)
+        if self.fold_launches:      # (the samples are drawn by the policy launch itself: nlbac_gauss_head)
+            gh = P.__dict__.get("head_pol3")
+            if gh is None:
+                gh = P.head_pol3 = _lib.GaussHead()
+                gh.eps, gh.scale, gh.bias, gh.n_u = ws.eps.data_ptr(), p_scale, p_bias, A
+                gh.action, gh.action_ld, gh.logp = ws.act3.data_ptr(), A, ws.logp3.data_ptr()
+            call("nlbac_mlp_fwd_gauss", P.n_pol3, P.io_pol3, 1 + NP, B, C.byref(gh), s)
+        else:
+            call("nlbac_mlp_fwd", P.n_pol3, P.io_pol3, 1 + NP, B, s)
+            call("nlbac_gauss_sample_fwd", ws.heads3.data_ptr(), 2 * A, ws.eps.data_ptr(), p_scale, p_bias, A, (1 + NP) * B,
+                 ws.act3.data_ptr(), A, ws.logp3.data_ptr(), s)
         # the rollout of the learned dynamics needs only pi(s) and the NODE: its first attempted step goes in here,
         # so that the critic phase below is queued behind it while the host waits for the accept decision
         self.task.rollout_begin(ws, P)
@@ -832,7 +841,7 @@ class SAC_CBF_CLF(object):
         one = self.world == 1
         call("nlbac_mlp_fwd", P.n_six, P.io_six, P.n_six_count, B, s)
         q = ws.q6
-        if one and not self.h_extra:
+        if one and not self.h_extra and self.fold_launches:
             # single GPU, no extra critic: targets, dL/dq and the three losses are produced by the critics' data backward
             # itself (nlbac_dy_head kind 2) — no launch between the six-net forward and the backward
             H = P.__dict__.get("head_td")
@@ -876,7 +885,7 @@ class SAC_CBF_CLF(object):
         # ---- C. actors: Q(s, pi) with the stepped critics (the rollout was started in phase A) -----
         sc, call = self.sc.data_ptr(), _lib.call
         call("nlbac_mlp_fwd", P.n_q5, P.io_q5, P.n_q5_count, B, s)
-        if self.world == 1:
+        if self.world == 1 and self.fold_launches:
             return               # (the branch terms and their sums come out of the Q(s, pi) data backward: _actor_q_head)
         fused = None
         if self.world == 1:      # policy_loss_1 / alpha losses / d log_alpha by the launch's last workgroup (nlbac_actor_scalars)
@@ -926,13 +935,18 @@ class SAC_CBF_CLF(object):
 
         # the Q(s, pi) nets (dx only): single GPU — d min(Q1, Q2), policy_loss_1, the alpha losses and d log_alpha are
         # produced by this launch (nlbac_dy_head kind 3); data parallel — nlbac_actor_q_terms ran in part 1
-        if self.world == 1:
+        if self.world == 1 and self.fold_launches:
             call("nlbac_mlp_bwd_data_head", P.n_q5, P.io_q5, 2 * NP, B, C.byref(self._actor_q_head(ws, P, NP, G)), s)
         else:
             call("nlbac_mlp_bwd_data", P.n_q5, P.io_q5, 2 * NP, B, s)
         # the actors: d heads from d action (two Q nets + the rollout) and d logp, inside their data backward (kind 1)
         D = Do + A
-        H = P.__dict__.get("head_gauss")
+        if not self.fold_launches:
+            call("nlbac_gauss_sample_bwd", ws.heads2.data_ptr(), 2 * A, eps2.data_ptr(), p_scale, A,
+                 NP * B, B, ws.dxq[0].data_ptr() + 4 * Do, D, ws.dxq[1].data_ptr() + 4 * Do, D, du2.data_ptr(), du_ld,
+                 sc + 4 * SC.SC_ALPHA, 1.0 / G, ws.dheads2.data_ptr(), 2 * A, s)
+            call("nlbac_mlp_bwd_data", P.n_act, P.io_act, NP, B, s)
+        H = P.__dict__.get("head_gauss") if self.fold_launches else False
         if H is None:
             H = P.head_gauss = _lib.DyHead()
             H.kind, H.B_norm = 1, G
@@ -941,8 +955,9 @@ class SAC_CBF_CLF(object):
             H.da[1], H.da_ld[1] = ws.dxq[1].data_ptr() + 4 * Do, D
             H.alpha, H.dlogp_mul = sc + 4 * SC.SC_ALPHA, 1.0 / G
             H.dheads, H.dheads_ld = ws.dheads2.data_ptr(), 2 * A
-        H.da[2], H.da_ld[2] = du2.data_ptr(), du_ld
-        call("nlbac_mlp_bwd_data_head", P.n_act, P.io_act, NP, B, C.byref(H), s)
+        if H is not False:
+            H.da[2], H.da_ld[2] = du2.data_ptr(), du_ld
+            call("nlbac_mlp_bwd_data_head", P.n_act, P.io_act, NP, B, C.byref(H), s)
         tune = self.automatic_entropy_tuning
         p_part_q, n_part = ws.p_part_q, ws.n_part_q
         for g, cnt, nets, gio, sk_ws in P.act_groups:

@@ -130,14 +130,17 @@ class UnicycleTask(_Task):
         p_obs = ws.mb.data_ptr()
         # state (twice: primary and backup rows of the rollout) and look-ahead point: formed by the rollout's first
         # launch (fused solver), else by a launch of their own
-        if self.solver.fused:
+        if self.solver.fused and a.fold_launches:
             self.solver.set_in_map(1, ws.mb, LD, self.l_p, ws.ps)
         else:
             _lib.call("nlbac_unicycle_state", p_obs, LD, B, self.l_p, ws.y0_2.data_ptr(), 2, ws.ps.data_ptr(), s)
         self.reserve(self.solver, 2 * B, 2)
         # the look-ahead point of x(t + dt) and its backward ride in the solver's interpolation launches where those
         # exist (device-driven dopri5); elsewhere this task launches them (loss_and_backward)
-        self.solver.set_out_map(1, self.l_p, ws.ps_next2, ws.dps_next2, ws.dps_v2)
+        if a.fold_launches:
+            self.solver.set_out_map(1, self.l_p, ws.ps_next2, ws.dps_next2, ws.dps_v2)
+        else:
+            self.solver._out_map = None
         self.solver.forward_begin(ws.y0_2, ws.pi2, 2, B, a.solver, float(self.env.dt), a.atol, a.rtol)
 
     def loss_and_backward(self, ws, P, lam_upd, assume_single):

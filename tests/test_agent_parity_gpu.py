@@ -268,6 +268,48 @@ def test_hipgraph_replay_is_bit_identical_to_eager(solver):
     assert torch.equal(a0.sc, a1.sc)
 
 
+@pytest.mark.parametrize("env_name,solver", [("Unicycle", "dopri5"), ("Unicycle", "euler"), ("Pvtol", "dopri5")])
+def test_folded_launches_match_the_launches_they_replace(env_name, solver):
+    """The per-row steps evaluated inside the MLP / solver launches (Gaussian head, dy heads, in- / out-map, results
+    written to pinned memory by the kernels) against the same update with every step as the launch of its own
+    (``fold_launches = False``): identical row arithmetic, so the per-row outputs left in memory are bit-identical on the
+    first update (up to the contraction of the look-ahead map's multiply-adds); the batch sums are taken in a different order (per 32-row tile instead of per 256-row block), so the
+    losses, the temperatures' gradient and — through it — the parameters agree to rounding."""
+    B, hidden, seed = 256, 256, 0
+    gamma_b = {"Unicycle": 50.0, "Pvtol": 0.8}[env_name]
+    fields = synth.fields(env_name)
+    node_fields = ("obs", "action", "next_obs")
+    runs = []
+    for fold in (True, False):
+        agent, env = make_agent(B, hidden, seed, solver, env_name, gamma_b)
+        agent.fold_launches = fold
+        tr = synth.transitions(env_name, 4096, seed=3, env=env)
+        rs = np.random.RandomState(5)
+        rets, first = [], None
+        for updates in range(4):
+            idx = rs.choice(4096, B, replace=False)
+            nidx = rs.choice(4096, 1024, replace=False)
+            agent.set_noise(synth.normal_eps(agent.task.n_eps, B, env.n_u, seed=updates))
+            host = tuple(tr[f][idx] for f in fields)
+            node = tuple(tr[f][nidx] for f in node_fields) if updates == 0 else None
+            rets.append(agent.update_from_host(host, updates, node))
+            if updates == 0:
+                ws = agent._ws[B]
+                first = {k: getattr(ws, k).clone() for k in ("act3", "logp3", "dq3", "dq_pi", "dheads2", "next_q", "next_l")}
+        torch.cuda.synchronize()
+        runs.append((agent, rets, first))
+    (a0, r0, f0), (a1, r1, f1) = runs
+    for k in f0:
+        if k == "dheads2":      # (downstream of the rollout's backward, where the look-ahead map's multiply-adds are
+            #                      contracted differently inside the interpolation launch: rounding, not bit-identical)
+            assert float((f0[k] - f1[k]).abs().max()) <= 1e-5 * float(f1[k].abs().max()), k
+        else:
+            assert torch.equal(f0[k], f1[k]), "%s differs between the folded and the separate launches" % k
+    np.testing.assert_allclose(np.array(r0), np.array(r1), rtol=2e-6, atol=1e-7)
+    for i, (x, y) in enumerate(zip(a0.arenas, a1.arenas)):     # (Adam turns gradient rounding at |g| ~ 1e-8 into lr steps)
+        params_close(x.theta.cpu().numpy(), y.theta.cpu().numpy(), 4 * 1e-3, "arena %d" % i)
+
+
 @pytest.mark.parametrize("solver", ["euler", "rk4", "dopri5"])
 @pytest.mark.parametrize("rows", [96, 77])
 def test_fused_rk_step_kernel_matches_per_stage_launches(solver, rows):
