@@ -499,7 +499,7 @@ __global__ __launch_bounds__(512) void node_rk_bwd_kernel(const NodeRkBwdLaunch 
     }
     __syncthreads();
 
-#ifdef EXP_TIMING      // stamps of workgroup 0 go to the (otherwise unused in mask mode) dz[1] pointer
+#if defined(EXP_TIMING) || defined(EXP_TIMING_BWD)      // stamps of workgroup 0 go to the (otherwise unused in mask mode) dz[1] pointer
 #define BSTAMP(slot_) if (L.dz[1] && blockIdx.x == 0 && tid == 0) reinterpret_cast<long long*>(L.dz[1])[slot_] = (long long)__builtin_readcyclecounter();
 #else
 #define BSTAMP(slot_)
@@ -633,7 +633,7 @@ extern "C" int nlbac_node_rk_bwd(const nlbac_mlp* f, const nlbac_mlp* g, const f
                       g->out_dim % f->in_dim == 0 && g->out_dim / f->in_dim <= RK_MAX_NU && g->out_dim <= 16,
                   "nlbac_node_rk_bwd: f/g shapes are not a supported control-affine field");
     NLBAC_REQUIRE(f->hid % 4 == 0 && g->hid % 4 == 0 && f->hid <= 256 && g->hid <= 256, "nlbac_node_rk_bwd: bad hid");
-#ifndef EXP_TIMING
+#if !defined(EXP_TIMING) && !defined(EXP_TIMING_BWD)
     NLBAC_REQUIRE((dz_f == nullptr) == (dz_g == nullptr) && (dz_f == nullptr) == (dG == nullptr),
                   "nlbac_node_rk_bwd: dz_f, dz_g and dG go together");
 #endif

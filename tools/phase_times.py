@@ -16,29 +16,31 @@ sol.keep_acts = False
 ws = sol._step_ws(n, 7, 0)
 ctl = sol._ctl(2)
 ctl[:, 0] = 0.02
+FWD = not os.environ.get("PHASE_BWD_ONLY")       # (-DEXP_TIMING_BWD build: the forward runs normally, only the backward stamps)
 stamps = torch.zeros(4096, dtype=torch.int64, device="cuda")
 err = stamps.view(torch.float32)
 from nlbac_amd.odeint import fptr
-for it in range(3):
+for it in range(3 if FWD else 0):
     sol._rk_fused(ws, y0, u, 2, n // 2, "dopri5", 1, 7, h_dev=ctl.data_ptr(), c_err=fptr(0.0), err=err)
     torch.cuda.synchronize()
-# call with err pointing at the stamp buffer
-sol._rk_fused(ws, y0, u, 2, n // 2, "dopri5", 1, 7, h_dev=ctl.data_ptr(), c_err=fptr(0.0), err=err)
-torch.cuda.synchronize()
-t = stamps.cpu().numpy()
-base = t[0]
-names = ["stage input", "wide layers", "skinny out", "k = f + g u"]
-print("clock ticks (shader clock), workgroup 0; prologue ends at 0")
-for st in range(6):
-    row = t[1 + 8 * st: 1 + 8 * st + 5] - base
-    d = np.diff(row)
-    print("stage %d: start %7d  " % (st + 1, row[0]) + "  ".join("%s %6d" % (nm, x) for nm, x in zip(names, d)))
+if FWD:
+    # call with err pointing at the stamp buffer
+    sol._rk_fused(ws, y0, u, 2, n // 2, "dopri5", 1, 7, h_dev=ctl.data_ptr(), c_err=fptr(0.0), err=err)
+    torch.cuda.synchronize()
+    t = stamps.cpu().numpy()
+    base = t[0]
+    names = ["stage input", "wide layers", "skinny out", "k = f + g u"]
+    print("clock ticks (shader clock), workgroup 0; prologue ends at 0")
+    for st in range(6):
+        row = t[1 + 8 * st: 1 + 8 * st + 5] - base
+        d = np.diff(row)
+        print("stage %d: start %7d  " % (st + 1, row[0]) + "  ".join("%s %6d" % (nm, x) for nm, x in zip(names, d)))
 
-d = t[64:64 + 16].reshape(4, 4)
-print("wave 0, stage 2, per wide layer (ticks): GEMM issue+A reads | epilogue | barrier wait")
-for l in range(4):
-    a = d[l]
-    print("  layer %d: %6d | %6d | %6d   (layer total %6d)" % (l, a[1] - a[0], a[2] - a[1], a[3] - a[2], a[3] - a[0]))
+    d = t[64:64 + 16].reshape(4, 4)
+    print("wave 0, stage 2, per wide layer (ticks): GEMM issue+A reads | epilogue | barrier wait")
+    for l in range(4):
+        a = d[l]
+        print("  layer %d: %6d | %6d | %6d   (layer total %6d)" % (l, a[1] - a[0], a[2] - a[1], a[3] - a[2], a[3] - a[0]))
 
 if os.environ.get("PHASE_FWD_ONLY"):
     sys.exit(0)
