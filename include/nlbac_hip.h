@@ -196,9 +196,10 @@ int nlbac_actor_q_terms(const float *q1, const float *q2, const float *logp, con
  * designated workgroup; single GPU (the sums are not all-reduced).  Same row arithmetic, and the same outputs left in
  * memory, as the entry point it replaces:
  *   kind 1  nlbac_gauss_sample_bwd  net i = controller i (rows i*B.. of the stacked arrays); out_dim = 2 n_u
- *   kind 2  nlbac_td_targets        nets 0, 1, 2 = Q1, Q2, Lyapunov critic; out[0..2] = the three losses * mul
+ *   kind 2  nlbac_td_targets        nets 0, 1, 2 = Q1, Q2, Lyapunov critic [, 3 = BarrierNet: nlbac_td_value];
+ *                                   out[0..2] = the three losses * mul
  *   kind 3  nlbac_actor_q_terms     net i = (controller i / 2, Q1 / Q2 = i % 2); + nlbac_actor_scalars via `actor`
- * partials: 3 * n_tiles (kind 2) / 2 * n_prob * n_tiles (kind 3) floats, n_tiles = ceil(B / 32); ticket: a zeroed
+ * partials: n_nets * n_tiles (kind 2) / 2 * n_prob * n_tiles (kind 3) floats, n_tiles = ceil(B / 32); ticket: a zeroed
  * uint32, left zeroed. */
 typedef struct nlbac_dy_head {
     int kind, B_norm;
@@ -210,6 +211,9 @@ typedef struct nlbac_dy_head {
     /* 2 */
     const float *q1t, *q2t, *lt, *nlogp, *reward, *constraint, *mask; int rcm_ld;
     const float *q[3]; float gamma; float *dq[3]; float *next_q, *next_l;
+    /* 2, optional 4th net (the learned-barrier copies' BarrierNet, nlbac_td_value: NU/sac_cbf_clf/sac_cbf_clf.py:224-233):
+     * target xsig + mask * gamma * xt against xq; its loss * mul goes to out_x[0] */
+    const float *xt, *xsig; int xsig_ld; const float *xq; float *dxq; float *out_x;
     /* 3 */
     const float *qa, *qb, *logp; float *dqa, *dqb; int n_prob;
     nlbac_actor_scalar_args actor;

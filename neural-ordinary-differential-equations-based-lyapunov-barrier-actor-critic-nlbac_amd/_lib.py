@@ -74,6 +74,8 @@ class DyHead(C.Structure):
                 ("constraint", C.c_void_p), ("mask", C.c_void_p), ("rcm_ld", C.c_int),
                 ("q", C.c_void_p * 3), ("gamma", C.c_float), ("dq", C.c_void_p * 3), ("next_q", C.c_void_p),
                 ("next_l", C.c_void_p),
+                ("xt", C.c_void_p), ("xsig", C.c_void_p), ("xsig_ld", C.c_int), ("xq", C.c_void_p), ("dxq", C.c_void_p),
+                ("out_x", C.c_void_p),
                 ("qa", C.c_void_p), ("qb", C.c_void_p), ("logp", C.c_void_p), ("dqa", C.c_void_p), ("dqb", C.c_void_p),
                 ("n_prob", C.c_int), ("actor", ActorScalarArgs),
                 ("partials", C.c_void_p), ("ticket", C.c_void_p), ("mul", C.c_float), ("out", C.c_void_p)]

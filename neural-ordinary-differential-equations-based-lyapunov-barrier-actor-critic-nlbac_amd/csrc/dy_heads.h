@@ -97,7 +97,7 @@ __device__ __forceinline__ void elected_tile_sums(const float* partials, int n_t
 // Fills sdy[32][16] (dL/dy of the tile's rows, zero padded) of net `inet` of the launch.  Called by all 256 threads of an
 // mlp_bwd_data workgroup before anything reads sdy; `red`: >= 16 floats of LDS scratch.
 __device__ __forceinline__ void dy_head_fill(const nlbac_dy_head& H, int inet, int row0, int B, int n_tiles, float* sdy,
-                                             float* red) {
+                                             float* red, int n_nets) {
     const int tid = threadIdx.x;
     if (H.kind == 1) {
         // GaussianPolicy.sample backward; net inet = controller inet, its rows are inet*B.. of the stacked arrays
@@ -117,8 +117,9 @@ __device__ __forceinline__ void dy_head_fill(const nlbac_dy_head& H, int inet, i
             sdy[idx] = v;
         }
     } else if (H.kind == 2) {
-        // TD / Lyapunov targets; net 0 = Q1, 1 = Q2, 2 = Lyapunov critic.  Every net's workgroup publishes its own
-        // squared-error sum of the tile; the last of the 3 * n_tiles workgroups finishes the three losses.
+        // TD / Lyapunov targets; net 0 = Q1, 1 = Q2, 2 = Lyapunov critic (3 = the learned-barrier copies' BarrierNet).
+        // Every net's workgroup publishes its own squared-error sum of the tile; the last of the n_nets * n_tiles
+        // workgroups finishes the losses.
         float e2 = 0.f;
         for (int idx = tid; idx < NLBAC_MLP_TILE * 16; idx += 256) sdy[idx] = 0.f;
         __syncthreads();
@@ -130,14 +131,16 @@ __device__ __forceinline__ void dy_head_fill(const nlbac_dy_head& H, int inet, i
                 const float mq = fminf(H.q1t[i], H.q2t[i]) - H.alpha[0] * H.nlogp[i];
                 y = H.reward[(long)i * H.rcm_ld] + mk * H.gamma * mq;
                 if (inet == 0 && H.next_q) H.next_q[i] = y;
-            } else {
+            } else if (inet == 2) {
                 y = H.constraint[(long)i * H.rcm_ld] + mk * H.gamma * H.lt[i];
                 if (H.next_l) H.next_l[i] = y;
+            } else {
+                y = H.xsig[(long)i * H.xsig_ld] + mk * H.gamma * H.xt[i];
             }
             const float norm = (float)(2.0 / (double)H.B_norm);
-            const float e = H.q[inet][i] - y;
+            const float e = (inet < 3 ? H.q[inet][i] : H.xq[i]) - y;
             const float d = norm * e;
-            H.dq[inet][i] = d;
+            (inet < 3 ? H.dq[inet] : H.dxq)[i] = d;
             sdy[tid * 16] = d;
             e2 = e * e;
         }
@@ -147,10 +150,15 @@ __device__ __forceinline__ void dy_head_fill(const nlbac_dy_head& H, int inet, i
         }
         const float v1[1] = {e2};
         const int tile = row0 / NLBAC_MLP_TILE;
-        if (publish_and_elect<1>(H.partials + (long)tile * 3 + inet, v1, H.ticket, 3u * (unsigned)n_tiles)) {
+        if (publish_and_elect<1>(H.partials + (long)tile * n_nets + inet, v1, H.ticket, (unsigned)(n_nets * n_tiles))) {
             float s[3];
-            elected_tile_sums<3>(H.partials, n_tiles, 3, s, red);
+            elected_tile_sums<3>(H.partials, n_tiles, n_nets, s, red);
             if (tid < 3) H.out[tid] = s[tid] * H.mul;
+            if (n_nets == 4) {
+                float sx[1];
+                elected_tile_sums<1>(H.partials + 3, n_tiles, 4, sx, red);
+                if (tid == 0) H.out_x[0] = sx[0] * H.mul;
+            }
         }
     } else if (H.kind == 3) {
         // min(Q1, Q2)(s, pi) branch gradients; net inet = (controller inet / 2, Q1 / Q2 = inet % 2); the Q1 workgroups

@@ -227,7 +227,7 @@ __global__ __launch_bounds__(256, 2) void mlp_bwd_data_kernel(const MlpLaunch L,
             sdy[idx] = (row < B && c < net.out_dim) ? io.dy[(long)row * io.dy_ld + c] : 0.f;
         }
     } else {
-        dy_head_fill(H, blockIdx.y, row0, B, gridDim.x, sdy, sx);     // (dy heads: dL/dy is produced here, dy_heads.h)
+        dy_head_fill(H, blockIdx.y, row0, B, gridDim.x, sdy, sx, gridDim.y);     // (dy heads: dL/dy is produced here, dy_heads.h)
     }
     if (sk)
         for (int idx = tid; idx < NLBAC_MLP_TILE * 16; idx += 256) {
@@ -890,10 +890,11 @@ extern "C" int nlbac_mlp_bwd_data_head(const nlbac_mlp* nets, const nlbac_mlp_io
         NLBAC_REQUIRE(H.heads && H.eps && H.scale && H.alpha && H.n_u >= 1 && H.n_u <= MAX_NU, "%s: gauss head: null pointer / bad n_u", who);
         for (int i = 0; i < n_nets; ++i) NLBAC_REQUIRE(nets[i].out_dim == 2 * H.n_u, "%s: gauss head: net %d must have 2 n_u outputs", who, i);
     } else if (H.kind == 2) {
-        NLBAC_REQUIRE(n_nets == 3 && H.q1t && H.q2t && H.lt && H.nlogp && H.reward && H.constraint && H.mask && H.alpha &&
-                          H.q[0] && H.q[1] && H.q[2] && H.dq[0] && H.dq[1] && H.dq[2] && H.partials && H.ticket && H.out,
-                      "%s: td head: 3 nets (Q1, Q2, Lyapunov) and all pointers", who);
-        for (int i = 0; i < 3; ++i) NLBAC_REQUIRE(nets[i].out_dim == 1, "%s: td head: scalar nets", who);
+        NLBAC_REQUIRE((n_nets == 3 || n_nets == 4) && H.q1t && H.q2t && H.lt && H.nlogp && H.reward && H.constraint && H.mask &&
+                          H.alpha && H.q[0] && H.q[1] && H.q[2] && H.dq[0] && H.dq[1] && H.dq[2] && H.partials && H.ticket && H.out,
+                      "%s: td head: 3 nets (Q1, Q2, Lyapunov) or 4 (+ BarrierNet) and all pointers", who);
+        NLBAC_REQUIRE(n_nets == 3 || (H.xt && H.xsig && H.xq && H.dxq && H.out_x), "%s: td head: the 4th net's pointers", who);
+        for (int i = 0; i < n_nets; ++i) NLBAC_REQUIRE(nets[i].out_dim == 1, "%s: td head: scalar nets", who);
     } else {
         NLBAC_REQUIRE(H.n_prob >= 1 && H.n_prob <= 2 && n_nets == 2 * H.n_prob && H.qa && H.qb && H.logp && H.alpha && H.dqa &&
                           H.dqb && H.partials && H.ticket && H.actor.sc,

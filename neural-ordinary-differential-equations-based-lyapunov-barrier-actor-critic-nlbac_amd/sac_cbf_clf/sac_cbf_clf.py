@@ -89,7 +89,7 @@ class _Workspace:
         self.nblk = (B + 255) // 256
         self.part_td = z(self.nblk, 3)
         self.n_tiles = (B + _lib.MLP_TILE - 1) // _lib.MLP_TILE
-        self.part_td32 = z(self.n_tiles, 3)            # per-32-row-tile sums of the fused dy heads (nlbac_dy_head)
+        self.part_td32 = z(self.n_tiles, 4)            # per-32-row-tile sums of the fused dy heads (nlbac_dy_head)
         self.part_tdx = z(max(NX, 1), self.nblk)
         self.heads2, self.pi2, self.logp2 = self.heads3[B:], self.act3[B:], self.logp3[B:]
         self.acts_p = z(NP, 2, B, H)
@@ -841,7 +841,7 @@ class SAC_CBF_CLF(object):
         one = self.world == 1
         call("nlbac_mlp_fwd", P.n_six, P.io_six, P.n_six_count, B, s)
         q = ws.q6
-        if one and not self.h_extra and self.fold_launches:
+        if one and len(self.h_extra) <= 1 and self.fold_launches:
             # single GPU, no extra critic: targets, dL/dq and the three losses are produced by the critics' data backward
             # itself (nlbac_dy_head kind 2) — no launch between the six-net forward and the backward
             H = P.__dict__.get("head_td")
@@ -856,6 +856,10 @@ class SAC_CBF_CLF(object):
                 H.next_q, H.next_l = ws.next_q.data_ptr(), ws.next_l.data_ptr()
                 H.partials, H.ticket = ws.part_td32.data_ptr(), self._tickets.data_ptr()
                 H.mul, H.out = 1.0 / G, sc + 4 * SC.SC_QF1
+                if self.h_extra:        # BarrierNet TD step (NU/sac_cbf_clf.py:224-233): the launch's 4th net
+                    H.xt, H.xq, H.dxq = q[6].data_ptr(), q[7].data_ptr(), ws.dq3[3].data_ptr()
+                    H.xsig, H.xsig_ld = ws.mb.data_ptr() + 4 * self.lay.sig, LD
+                    H.out_x = sc + 4 * SC.SC_XLOSS
             call("nlbac_mlp_bwd_data_head", P.n_crit, P.io_crit, len(self.h_crit), B, C.byref(H), s)
             return
         call("nlbac_td_targets", q[0].data_ptr(), q[1].data_ptr(), q[2].data_ptr(), ws.nlogp.data_ptr(),

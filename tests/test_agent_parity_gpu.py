@@ -268,7 +268,8 @@ def test_hipgraph_replay_is_bit_identical_to_eager(solver):
     assert torch.equal(a0.sc, a1.sc)
 
 
-@pytest.mark.parametrize("env_name,solver", [("Unicycle", "dopri5"), ("Unicycle", "euler"), ("Pvtol", "dopri5")])
+@pytest.mark.parametrize("env_name,solver", [("Unicycle", "dopri5"), ("Unicycle", "euler"), ("Pvtol", "dopri5"),
+                                             ("UnicycleBarrier", "dopri5")])
 def test_folded_launches_match_the_launches_they_replace(env_name, solver):
     """The per-row steps evaluated inside the MLP / solver launches (Gaussian head, dy heads, in- / out-map, results
     written to pinned memory by the kernels) against the same update with every step as the launch of its own
@@ -276,7 +277,7 @@ def test_folded_launches_match_the_launches_they_replace(env_name, solver):
     first update (up to the contraction of the look-ahead map's multiply-adds); the batch sums are taken in a different order (per 32-row tile instead of per 256-row block), so the
     losses, the temperatures' gradient and — through it — the parameters agree to rounding."""
     B, hidden, seed = 256, 256, 0
-    gamma_b = {"Unicycle": 50.0, "Pvtol": 0.8}[env_name]
+    gamma_b = {"Unicycle": 50.0, "Pvtol": 0.8, "UnicycleBarrier": 5.0}[env_name]
     fields = synth.fields(env_name)
     node_fields = ("obs", "action", "next_obs")
     runs = []
