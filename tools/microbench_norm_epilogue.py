@@ -1,5 +1,9 @@
+"""GPU: the one-stage RK launches of dopri5's initial-step selection (f0, probe) with the scaled norm + step controller in
+their epilogue (nlbac_rk_chain.norm_mode 0 / 1), without them, and followed by the separate nlbac_dopri_norm_control
+launch — 8192 rollout rows."""
 import sys, os
-sys.path.insert(0, "/root/repo"); sys.path.insert(0, "/root/repo/tests")
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
 import torch
 import nlbac_amd
 from nlbac_amd import _lib
