@@ -50,6 +50,9 @@ def get_args(argv=None):
                    help="replay each update as hipGraphs (pays at the reference's small batch sizes, where the host's "
                         "launch rate bounds an update)")
     p.add_argument('--max_steps', type=int, default=0, help="stop after this many env steps (0: run all episodes)")
+    p.add_argument('--vector_envs', type=int, default=0,
+                   help="N > 0: N environments stepping on the device (train_vectorized: no transition touches the host, "
+                        "primary controller only); runs --max_steps env steps (default 100000)")
     return p.parse_args(argv)
 
 
@@ -293,6 +296,78 @@ def train(agent, env, dynamics_model, args, memory, node_memory, log=print, trac
     return history
 
 
+def train_vectorized(agent, env, args, n_steps, log=print, memory=None, check=None):
+    """Vectorised rollouts: ``env`` is one of ``nlbac_amd.envs.device`` — N environments stepping in
+    lock step on the device — and nothing of a transition touches the host: the policy acts on the (N, obs) device
+    tensor (one forward for all lanes), the simulator launch writes the next observations / rewards / constraints /
+    Lyapunov inputs, the transition rows are assembled in the agent's minibatch layout on the device and appended to a
+    ``DeviceReplayMemory`` (which serves both the controller updates and the NODE fit), ``updates_per_step`` updates
+    follow every vector step.  The reference's driver is one host environment at a time (``*/main.py::train``,
+    restated by ``train`` above and pinned against it); this is the same data flow widened to N lanes, WITHOUT the
+    backup-controller hand-over heuristics (which are per-episode host control flow): the primary controller acts in
+    every lane.  Time-limit terminations keep mask 1 (U/main.py:150), finished lanes are reset in place.
+    ``check``: a callable(step_index, rows) the tests use to look at the rows that were appended.
+    Returns dict(steps, updates, episodes, mean_return)."""
+    import torch
+    from .sac_cbf_clf.replay_memory import DeviceReplayMemory
+    dev, lay, N = agent.device, agent.lay, env.n
+    barrier = lay.sig is not None
+    if memory is None:
+        memory = DeviceReplayMemory(args.replay_size, args.seed, agent, device_rng=True)
+    lo = torch.as_tensor(np.asarray(env.action_space.low), dtype=torch.float32, device=dev)
+    hi = torch.as_tensor(np.asarray(env.action_space.high), dtype=torch.float32, device=dev)
+    gen = torch.Generator(device=dev)
+    gen.manual_seed(int(args.seed))
+    rows = torch.zeros(N, lay.LD, dtype=torch.float32, device=dev)
+    obs = env.reset().to(torch.float32).clone()
+    ep_ret = torch.zeros(N, dtype=torch.float64, device=dev)
+    ret_sum = torch.zeros((), dtype=torch.float64, device=dev)
+    n_done = torch.zeros((), dtype=torch.int64, device=dev)
+    steps = updates = it = 0
+    while steps < n_steps:
+        if steps < args.start_steps:
+            action = lo + (hi - lo) * torch.rand(N, lay.act_dim, generator=gen, device=dev)
+        else:
+            action = agent.policy.sample(obs)[0]
+        out = env.step(action)
+        nobs, reward, constraint = out[:3]
+        lya_in, next_lya_in, done = out[-4], out[-3], out[-2]
+        t = env.ep_step.to(torch.float32)                     # (already advanced by this step)
+        timeout = env.ep_step >= int(env.max_episode_steps)
+        rows.zero_()
+        rows[:, lay.obs:lay.obs + lay.obs_dim] = obs
+        rows[:, lay.act:lay.act + lay.act_dim] = action
+        rows[:, lay.rew], rows[:, lay.con] = reward.float(), constraint.float()
+        if barrier:
+            rows[:, lay.sig] = out[3].float()
+        rows[:, lay.lya:lay.lya + lay.lya_dim] = lya_in.float()
+        rows[:, lay.nlya:lay.nlya + lay.lya_dim] = next_lya_in.float()
+        rows[:, lay.nobs:lay.nobs + lay.obs_dim] = nobs.float()
+        rows[:, lay.mask] = torch.where(timeout, torch.ones_like(reward), 1.0 - done.to(reward.dtype)).float()
+        rows[:, lay.t], rows[:, lay.nt] = t * float(env.dt), (t + 1.0) * float(env.dt)
+        memory.push_rows(rows)
+        if check is not None:
+            check(it, rows)
+        ep_ret += reward
+        fin = done > 0
+        ret_sum += torch.where(fin, ep_ret, torch.zeros_like(ep_ret)).sum()
+        n_done += fin.sum()
+        ep_ret = torch.where(fin, torch.zeros_like(ep_ret), ep_ret)
+        steps += N
+        it += 1
+        if len(memory) > args.batch_size:
+            for _ in range(args.updates_per_step):
+                agent.update_parameters(memory, args.batch_size, updates, None, memory, args.NODE_model_update_interval)
+                updates += 1
+        env.reset(fin)                                         # (finished lanes start over; the others keep their state)
+        obs = env.obs.to(torch.float32).clone()
+    torch.cuda.synchronize()
+    eps = int(n_done)
+    res = dict(steps=steps, updates=updates, episodes=eps, mean_return=float(ret_sum) / max(eps, 1))
+    log("vectorised: %(steps)d env steps in %(episodes)d finished episodes, %(updates)d updates, mean return %(mean_return).2f" % res)
+    return res
+
+
 def main(argv=None):
     args = get_args(argv)
     import nlbac_amd  # noqa: F401
@@ -317,6 +392,12 @@ def main(argv=None):
     agent = SAC_CBF_CLF(env.observation_space.shape[0], env.action_space, env, args)
     agent.use_graphs = bool(args.hipgraphs)
     agent.solver = args.solver
+    if args.vector_envs > 0:
+        assert args.env != "SimulatedCars", "the vectorised driver covers the envs whose NODE takes no time input"
+        from .envs import device as device_envs
+        args.replay_size = min(args.replay_size, 1 << 20)
+        return train_vectorized(agent, device_envs.make(args.env, args.vector_envs, seed=max(args.seed, 0)), args,
+                                args.max_steps or 100000)
     dynamics_model = DynamicsModel(env, args)
     if args.device_replay:
         cap = min(args.replay_size, 1 << 20)
