@@ -198,7 +198,9 @@ int nlbac_actor_q_terms(const float *q1, const float *q2, const float *logp, con
  *   kind 1  nlbac_gauss_sample_bwd  net i = controller i (rows i*B.. of the stacked arrays); out_dim = 2 n_u
  *   kind 2  nlbac_td_targets        nets 0, 1, 2 = Q1, Q2, Lyapunov critic [, 3 = BarrierNet: nlbac_td_value];
  *                                   out[0..2] = the three losses * mul
- *   kind 3  nlbac_actor_q_terms     net i = (controller i / 2, Q1 / Q2 = i % 2); + nlbac_actor_scalars via `actor`
+ *   kind 3  nlbac_actor_q_terms     net i = (controller i / 2, Q1 / Q2 = i % 2) for i < 2 n_prob, nets behind them take
+ *                                   io[i].dy as in nlbac_mlp_bwd_data (an independent backward sharing the launch);
+ *                                   + nlbac_actor_scalars via `actor`
  * partials: n_nets * n_tiles (kind 2) / 2 * n_prob * n_tiles (kind 3) floats, n_tiles = ceil(B / 32); ticket: a zeroed
  * uint32, left zeroed. */
 typedef struct nlbac_dy_head {

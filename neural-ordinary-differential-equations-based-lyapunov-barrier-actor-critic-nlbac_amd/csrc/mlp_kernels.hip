@@ -221,7 +221,7 @@ __global__ __launch_bounds__(256, 2) void mlp_bwd_data_kernel(const MlpLaunch L,
         if constexpr (MODE != 1) { if (two) bwd_prime<2>(wg2, net, wave, lane); }
         if constexpr (MODE != 2) { if (!two) bwd_prime<1>(wg1, net, wave, lane); }
     }
-    if (H.kind == 0) {
+    if (H.kind == 0 || (H.kind == 3 && (int)blockIdx.y >= 2 * H.n_prob)) {     // (kind 3: nets behind the Q pairs read io.dy)
         for (int idx = tid; idx < NLBAC_MLP_TILE * 16; idx += 256) {
             const int r = idx >> 4, c = idx & 15, row = row0 + r;
             sdy[idx] = (row < B && c < net.out_dim) ? io.dy[(long)row * io.dy_ld + c] : 0.f;
@@ -896,12 +896,13 @@ extern "C" int nlbac_mlp_bwd_data_head(const nlbac_mlp* nets, const nlbac_mlp_io
         NLBAC_REQUIRE(n_nets == 3 || (H.xt && H.xsig && H.xq && H.dxq && H.out_x), "%s: td head: the 4th net's pointers", who);
         for (int i = 0; i < n_nets; ++i) NLBAC_REQUIRE(nets[i].out_dim == 1, "%s: td head: scalar nets", who);
     } else {
-        NLBAC_REQUIRE(H.n_prob >= 1 && H.n_prob <= 2 && n_nets == 2 * H.n_prob && H.qa && H.qb && H.logp && H.alpha && H.dqa &&
+        NLBAC_REQUIRE(H.n_prob >= 1 && H.n_prob <= 2 && n_nets >= 2 * H.n_prob && H.qa && H.qb && H.logp && H.alpha && H.dqa &&
                           H.dqb && H.partials && H.ticket && H.actor.sc,
-                      "%s: actor head: 2 nets per controller and all pointers", who);
+                      "%s: actor head: 2 nets per controller (further nets take io.dy) and all pointers", who);
         for (int p = 0; p < H.n_prob; ++p)
             NLBAC_REQUIRE(H.actor.log_alpha[p] && H.actor.g_log_alpha[p], "%s: actor head: missing log_alpha pointers", who);
-        for (int i = 0; i < n_nets; ++i) NLBAC_REQUIRE(nets[i].out_dim == 1, "%s: actor head: scalar nets", who);
+        for (int i = 0; i < 2 * H.n_prob; ++i) NLBAC_REQUIRE(nets[i].out_dim == 1, "%s: actor head: scalar nets", who);
+        for (int i = 2 * H.n_prob; i < n_nets; ++i) NLBAC_REQUIRE(io[i].dy, "%s: net %d needs dy", who, i);
     }
     return mlp_bwd_data_launch(nets, io, n_nets, B, H, who, s);
 }

@@ -935,11 +935,14 @@ class SAC_CBF_CLF(object):
         call = _lib.call
         p_scale = self.policy.action_scale.data_ptr()
         eps2 = ws.eps[1:1 + NP]
+        ws.q5_bwd_done = False       # (a task may run the Q(s, pi) data backward inside one of its own launches)
         du2, du_ld = self.task.loss_and_backward(ws, P, lam_upd, assume_single)
 
         # the Q(s, pi) nets (dx only): single GPU — d min(Q1, Q2), policy_loss_1, the alpha losses and d log_alpha are
         # produced by this launch (nlbac_dy_head kind 3); data parallel — nlbac_actor_q_terms ran in part 1
-        if self.world == 1 and self.fold_launches:
+        if ws.q5_bwd_done:
+            pass
+        elif self.world == 1 and self.fold_launches:
             call("nlbac_mlp_bwd_data_head", P.n_q5, P.io_q5, 2 * NP, B, C.byref(self._actor_q_head(ws, P, NP, G)), s)
         else:
             call("nlbac_mlp_bwd_data", P.n_q5, P.io_q5, 2 * NP, B, s)

@@ -10,6 +10,8 @@ lives in ``sac_cbf_clf.SAC_CBF_CLF`` and each environment contributes a task):
 ``UnicycleTask``   U/sac_cbf_clf/sac_cbf_clf.py:364-640, U/sac_cbf_clf/model.py:177-260
 ``CarsTask``       C/sac_cbf_clf/sac_cbf_clf.py:364-681, C/sac_cbf_clf/model.py:179-252
 """
+import ctypes as C
+
 import numpy as np
 import torch
 
@@ -116,6 +118,15 @@ class UnicycleTask(_Task):
         P.io_vc = io_array(1)                      # V(centre), value only
         P.io_vc[0].x0, P.io_vc[0].x0_dim, P.io_vc[0].x0_ld = ws.mb.data_ptr() + 4 * lay.lya, 2, lay.LD
         P.io_vc[0].y, P.io_vc[0].y_ld = ws.V.data_ptr(), 1
+        # the data backward of V(p(x')) and of the Q(s, pi) nets do not depend on each other and are both due when the
+        # constraints' gradients exist: one launch (the Q nets' dL/dq from the dy head, V's from io.dy) instead of a
+        # 128-tile launch on 256 CUs followed by a second one
+        n2 = 2 * P.NP
+        P.n_q5v = mlp_array([a.h_q1.desc, a.h_q2.desc] * P.NP + [a.h_l.desc])
+        P.io_q5v = io_array(n2 + 1)
+        for i in range(n2):
+            C.memmove(C.byref(P.io_q5v, i * C.sizeof(_lib.MlpIO)), C.byref(P.io_q5, i * C.sizeof(_lib.MlpIO)), C.sizeof(_lib.MlpIO))
+        C.memmove(C.byref(P.io_q5v, n2 * C.sizeof(_lib.MlpIO)), C.byref(P.io_vn, 0), C.sizeof(_lib.MlpIO))
 
     # V(centre) rides in the 5-net launch of the shared part: tell it where to write
     def value_now_io(self, ws, io, i):
@@ -161,7 +172,13 @@ class UnicycleTask(_Task):
         call("nlbac_unicycle_constraints_bwd", ws.ps_next2.data_ptr(), ws.matr.data_ptr(), ws.bmatr.data_ptr(),
              self.hazards.data_ptr(), self.num_cbfs, dt, float(a.batch_size), B, sc, ws.dps_next2.data_ptr(),
              ws.dVn.data_ptr(), s)
-        call("nlbac_mlp_bwd_data", P.n_l, P.io_vn, 1, B, s)    # dV_next -> d ps_next (rows [0,B))
+        if a.world == 1 and a.fold_launches:       # dV_next -> d ps_next (rows [0,B)), together with the Q(s, pi) nets' dx
+            NP = ws.np_now
+            call("nlbac_mlp_bwd_data_head", P.n_q5v, P.io_q5v, 2 * NP + 1, B,
+                 C.byref(a._actor_q_head(ws, P, NP, B * a.world)), s)
+            ws.q5_bwd_done = True
+        else:
+            call("nlbac_mlp_bwd_data", P.n_l, P.io_vn, 1, B, s)
         if mapped:
             du2, _ = self.solver.backward(None, need_du=True)
         else:
