@@ -127,6 +127,14 @@ class UnicycleTask(_Task):
         for i in range(n2):
             C.memmove(C.byref(P.io_q5v, i * C.sizeof(_lib.MlpIO)), C.byref(P.io_q5, i * C.sizeof(_lib.MlpIO)), C.sizeof(_lib.MlpIO))
         C.memmove(C.byref(P.io_q5v, n2 * C.sizeof(_lib.MlpIO)), C.byref(P.io_vn, 0), C.sizeof(_lib.MlpIO))
+        # likewise forward: Q(s, pi) [+ V(centre)] is the last piece of part 1 and V(p(x')) the first launch behind the
+        # rollout — when that piece is still pending at that point, both go out as one launch
+        nq = P.n_q5_count
+        P.n_q5f = mlp_array([a.h_q1.desc, a.h_q2.desc] * P.NP + [a.h_l.desc] * (nq - n2) + [a.h_l.desc])
+        P.io_q5f = io_array(nq + 1)
+        for i in range(nq):
+            C.memmove(C.byref(P.io_q5f, i * C.sizeof(_lib.MlpIO)), C.byref(P.io_q5, i * C.sizeof(_lib.MlpIO)), C.sizeof(_lib.MlpIO))
+        C.memmove(C.byref(P.io_q5f, nq * C.sizeof(_lib.MlpIO)), C.byref(P.io_vn, 0), C.sizeof(_lib.MlpIO))
 
     # V(centre) rides in the 5-net launch of the shared part: tell it where to write
     def value_now_io(self, ws, io, i):
@@ -159,11 +167,17 @@ class UnicycleTask(_Task):
         a, s, call = self.agent, stream_ptr(), _lib.call
         B, sc, dt = ws.B, a.sc.data_ptr(), float(self.env.dt)
         x_next2 = self.solver.forward_finish(assume_single_step=assume_single)
-        a.drain_fill()           # what is left of part 1 (critic step, Q(s, pi)): everything below uses the stepped nets
         mapped = self.solver.out_mapped
+        merged = mapped and a.world == 1 and a.fold_launches and not a.h_extra and len(a._fill) == 1
+        if merged:
+            a._fill.clear()      # (the pending piece is exactly the Q(s, pi) forward: it rides with V(p(x')) below)
+        a.drain_fill()           # what is left of part 1 (critic step, Q(s, pi)): everything below uses the stepped nets
         if not mapped:
             call("nlbac_unicycle_lookahead", x_next2.data_ptr(), 2 * B, self.l_p, ws.ps_next2.data_ptr(), s)
-        call("nlbac_mlp_fwd", P.n_l, P.io_vn, 1, B, s)
+        if merged:
+            call("nlbac_mlp_fwd", P.n_q5f, P.io_q5f, P.n_q5_count + 1, B, s)
+        else:
+            call("nlbac_mlp_fwd", P.n_l, P.io_vn, 1, B, s)
         r_coll = 1.05 * float(self.env.hazards_radius)
         call("nlbac_unicycle_constraints_fwd", ws.ps.data_ptr(), ws.ps_next2.data_ptr(), ws.V.data_ptr(),
              ws.Vn.data_ptr(), self.hazards.data_ptr(), self.num_cbfs, r_coll, dt, float(a.gamma_b), self.gamma_l, B,
