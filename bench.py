@@ -213,7 +213,7 @@ def host_cores():
 
 def cpu_baseline(B, solver, env_name="Unicycle", seed=0, adjoint=False):
     """The oracle (CPU restatement pinned to the reference) timed on this box's host cores on a
-    bounded sample of the same workload: 2 updates at batch B + 1 NODE fit on 32768 rows."""
+    bounded sample of the same workload (about 12 s of CPU work): updates at batch B and NODE fits on 32768 rows."""
     from oracle import nlbac_oracle as O
     cores = host_cores()
     torch.set_num_threads(cores)
@@ -233,23 +233,26 @@ def cpu_baseline(B, solver, env_name="Unicycle", seed=0, adjoint=False):
     eps = [torch.from_numpy(e) for e in synth.normal_eps(agent.N_EPS, B, env.n_u, seed=1)]
     agent.update(mk(B), eps, 1)                      # warm-up (allocator, thread pool)
     log("cpu_baseline: warm-up update done")
-    n_upd = 2
-    t0 = time.perf_counter()
-    for i in range(n_upd):
-        agent.update(mk(B), eps, 1 + i)
+    # a bounded sample of about 12 s of CPU work: updates for ~8 s (at least 4), NODE fits for ~4 s (at least 1)
+    n_upd, t0 = 0, time.perf_counter()
+    while n_upd < 4 or (time.perf_counter() - t0 < 8.0 and n_upd < 400):
+        agent.update(mk(B), eps, 1 + n_upd)
+        n_upd += 1
     t_upd = (time.perf_counter() - t0) / n_upd
-    log("cpu_baseline: %.2f s per update" % t_upd)
-    nb = mk(NODE_FIT_ROWS)
-    t0 = time.perf_counter()
-    agent.train_step(*[nb[f] for f in (("obs", "action", "next_obs", "t") if env_name == "SimulatedCars"
-                                       else ("obs", "action", "next_obs"))])
-    t_fit = time.perf_counter() - t0
+    log("cpu_baseline: %.3f s per update (%d updates)" % (t_upd, n_upd))
+    node_fields = ("obs", "action", "next_obs", "t") if env_name == "SimulatedCars" else ("obs", "action", "next_obs")
+    n_fit, t0 = 0, time.perf_counter()
+    while n_fit < 1 or (time.perf_counter() - t0 < 4.0 and n_fit < 40):
+        nb = mk(NODE_FIT_ROWS)
+        agent.train_step(*[nb[f] for f in node_fields])
+        n_fit += 1
+    t_fit = (time.perf_counter() - t0) / n_fit
     per_update = t_upd + t_fit / NODE_FIT_INTERVAL
     return dict(value=B / per_update, unit="samples/s", cores=cores, kind="port",
-                sample="oracle (PyTorch-CPU restatement): %d updates at B=%d (%.2f s each) + 1 NODE fit on %d rows "
-                       "(%.2f s, amortised /%d), solver %s%s" % (n_upd, B, t_upd, NODE_FIT_ROWS, t_fit,
-                                                                  NODE_FIT_INTERVAL, solver,
-                                                                  " + odeint_adjoint" if adjoint else ""))
+                sample="oracle (PyTorch-CPU restatement): %d updates at B=%d (%.3f s each) + %d NODE fits on %d rows "
+                       "(%.3f s each, amortised /%d), solver %s%s" % (n_upd, B, t_upd, n_fit, NODE_FIT_ROWS, t_fit,
+                                                                      NODE_FIT_INTERVAL, solver,
+                                                                      " + odeint_adjoint" if adjoint else ""))
 
 
 def node_odeint_submetric(agent, env, B, solver, iters=50):
