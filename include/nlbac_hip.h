@@ -32,7 +32,7 @@
 extern "C" {
 #endif
 
-#define NLBAC_ABI_VERSION 1
+#define NLBAC_ABI_VERSION 2 /* bumped whenever an exported signature or struct changes; nlbac_abi_version() returns it */
 #define NLBAC_MAX_LAYERS 6
 #define NLBAC_MAX_NETS 8
 #define NLBAC_MLP_TILE 32 /* samples per workgroup in the MLP kernels */
@@ -54,6 +54,13 @@ const char *nlbac_last_error(void);
  * nlbac_mlp_pack() after every optimiser step:
  *   pf_off[l]  forward pack of layer l      (B operand of  Y = X W^T)
  *   pb_off[l]  backward pack of layer l>=1  (B operand of dX = dY W ), -1 if none
+ * Nets of width 20..128 (hid % 4 == 0) with at least one hid x hid layer also get "RR packs" of those layers
+ * (layers 1 .. n_layers-2, contiguous, rr_layer_floats(hid) floats each): the A fragments of
+ * v_mfma_f32_16x16x4_f32 in the issue order of the register-resident layer chains (csrc/rr_device.h), which the
+ * fused RK kernels of the control-affine NODE stream:
+ *   rr_fwd_off  of W_l   (D[unit][row] = W_l X^T),        -1 if none
+ *   rr_bwd_off  of W_l^T (D[k][row]    = W_l^T dZ^T),     -1 if none
+ * packed_floats = size of `packed` as nlbac_mlp_pack_layout returned it.
  * ---------------------------------------------------------------------- */
 typedef struct nlbac_mlp {
     int n_layers, in_dim, hid, out_dim;
@@ -63,6 +70,7 @@ typedef struct nlbac_mlp {
     float *packed;
     int pf_off[NLBAC_MAX_LAYERS];
     int pb_off[NLBAC_MAX_LAYERS];
+    int rr_fwd_off, rr_bwd_off, packed_floats;
 } nlbac_mlp;
 
 /* Per-launch tensors of one net.  Unused pointers are NULL. */
@@ -125,11 +133,12 @@ int nlbac_adam_prepare(void *state, double lr, nlbac_stream_t s); /* ++step, bia
 int nlbac_adam_step(float *p, float *m, float *v, const float *grad, int n_slabs, long slab_stride,
                     long n, const void *state, float *target, float tau, nlbac_stream_t s);
 /* nlbac_adam_prepare + nlbac_adam_step + nlbac_mlp_pack of the stepped nets in one launch.  scatter /
- * scatter_target (or NULL): 2n uint64 device addresses, [2i], [2i+1] = the forward / backward MFMA-fragment
- * slot of parameter i inside the nets' `packed` buffers (0 = none), for the trained and the target copy. */
+ * scatter_target (or NULL): scatter_slots * n uint64 device addresses, [scatter_slots * i + k] = the k-th
+ * MFMA-fragment slot of parameter i inside the nets' `packed` buffers (0 = none; forward / backward pack: 2 slots,
+ * with RR packs: 4), for the trained and the target copy. */
 int nlbac_adam_fused(float *p, float *m, float *v, const float *grad, int n_slabs, long slab_stride, long n,
                      void *state, double lr, float *target, float tau, const void *scatter,
-                     const void *scatter_target,
+                     const void *scatter_target, int scatter_slots /* 2 or 4 */,
                      int n_alpha /* 0..2 temperatures refreshed by the step itself: alpha_dst[k][0] = exp(p[alpha_off[k]])
                                     after the step (sac_cbf_clf.py:297, 308) */,
                      const long *alpha_off, float *const *alpha_dst,
@@ -415,6 +424,10 @@ int nlbac_node_rk_fwd(const nlbac_mlp *f, const nlbac_mlp *g, const float *y0, c
                       float *G, float *acts_f, long acts_f_ls, float *acts_g, long acts_g_ls, int acts_bits,
                       float *out, float *err, const nlbac_rk_chain *chain,
                       const nlbac_in_map *in_map /* or NULL; y0 is then written, not read */, nlbac_stream_t s);
+/* uint32 words per row and layer of the bit-packed ReLU masks (acts_bits) that nlbac_node_rk_fwd writes and
+ * nlbac_node_rk_bwd reads for net `which` (0: f, 1: g) of this pair: ceil(hid / 32) for the LDS-tiled kernels, 4 (one
+ * word per lane quarter) when the pair runs on the register-resident kernels. */
+int nlbac_node_rk_mask_words(const nlbac_mlp *f, const nlbac_mlp *g, int which);
 /* Fused backward of the same step (exact gradient of the discrete step): processes stages st_hi-1 .. st_lo.
  * In/out dK [n_stages_total][n][n_s] holds dL/dK_j (initialised by the caller from the step's output
  * combination / interpolant); dYup (may be NULL) is dL/d(stage input) of the last stage (FSAL y1);

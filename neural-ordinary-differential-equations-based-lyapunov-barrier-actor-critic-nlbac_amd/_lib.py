@@ -29,7 +29,8 @@ class Mlp(C.Structure):
                 ("params", C.c_void_p),
                 ("w_off", C.c_int * MAX_LAYERS), ("b_off", C.c_int * MAX_LAYERS),
                 ("packed", C.c_void_p),
-                ("pf_off", C.c_int * MAX_LAYERS), ("pb_off", C.c_int * MAX_LAYERS)]
+                ("pf_off", C.c_int * MAX_LAYERS), ("pb_off", C.c_int * MAX_LAYERS),
+                ("rr_fwd_off", C.c_int), ("rr_bwd_off", C.c_int), ("packed_floats", C.c_int)]
 
 
 class MlpIO(C.Structure):
@@ -116,8 +117,9 @@ _PROTOS = {
     "nlbac_mlp_bwd_weights": [C.POINTER(Mlp), C.POINTER(MlpIO), _I, _I, _I, _L, _P, _L, _P],
     "nlbac_adam_prepare": [_P, _D, _P],
     "nlbac_adam_step": [_P, _P, _P, _P, _I, _L, _L, _P, _P, _F, _P],
-    "nlbac_adam_fused": [_P, _P, _P, _P, _I, _L, _L, _P, _D, _P, _F, _P, _P, _I, C.POINTER(C.c_long), C.POINTER(C.c_void_p),
-                         _P, _P, _I, _P],
+    "nlbac_adam_fused": [_P, _P, _P, _P, _I, _L, _L, _P, _D, _P, _F, _P, _P, _I, _I, C.POINTER(C.c_long),
+                         C.POINTER(C.c_void_p), _P, _P, _I, _P],
+    "nlbac_node_rk_mask_words": [C.POINTER(Mlp), C.POINTER(Mlp), _I],
     "nlbac_reduce_slabs": [_P, _P, _I, _L, _L, _P],
     "nlbac_soft_update": [_P, _P, _L, _F, _P],
     "nlbac_gauss_sample_fwd": [_P, _I, _P, _P, _P, _I, _I, _P, _I, _P, _P],
@@ -205,6 +207,20 @@ def build(verbose=False):
     return LIB_PATH
 
 
+ABI_VERSION = 2      # == NLBAC_ABI_VERSION of include/nlbac_hip.h (bumped with every signature / struct change)
+
+
+def _stale_sources():
+    """Sources / headers newer than the built library (only where the sources are present next to it)."""
+    try:
+        t_lib = os.path.getmtime(LIB_PATH)
+        header = os.path.join(os.path.dirname(_HERE), "include", "nlbac_hip.h")
+        srcs = [os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith((".hip", ".h"))] + [header]
+        return [os.path.basename(f) for f in srcs if os.path.exists(f) and os.path.getmtime(f) > t_lib + 1.0]
+    except OSError:
+        return []
+
+
 def load():
     """Load the shared library once and type every entry point."""
     global _lib
@@ -218,8 +234,13 @@ def load():
         fn = getattr(lib, name)   # AttributeError if the symbol is not exported
         fn.argtypes = argtypes
         fn.restype = _RESTYPE.get(name, C.c_int)
-    if lib.nlbac_abi_version() != 1:
-        raise NlbacError("ABI version mismatch")
+    if lib.nlbac_abi_version() != ABI_VERSION:
+        raise NlbacError("libnlbac_hip.so reports ABI version %d, this binding is written against %d: rebuild it "
+                         "(make -C %s)" % (lib.nlbac_abi_version(), ABI_VERSION, CSRC))
+    stale = _stale_sources()
+    if stale:      # (a warning, not an error: file times do not survive every way a tree is copied to another machine)
+        import warnings
+        warnings.warn("libnlbac_hip.so is older than %s: rebuild it (make -C %s)" % (", ".join(stale), CSRC))
     _lib = lib
     return lib
 

@@ -98,16 +98,18 @@ class Arena:
         src = np.concatenate(src_all)
         order = np.argsort(src, kind="stable")
         src = src[order]
-        first = np.ones(len(src), dtype=bool)
-        first[1:] = src[1:] != src[:-1]
-        second = ~first
-        assert not (second[1:] & second[:-1]).any(), "a parameter has more than two fragment slots"
+        # k-th occurrence of each parameter among its fragment slots (forward / backward pack: <= 2; with RR packs: 4)
+        start = np.ones(len(src), dtype=bool)
+        start[1:] = src[1:] != src[:-1]
+        first_idx = np.maximum.accumulate(np.where(start, np.arange(len(src)), 0))
+        occ = np.arange(len(src)) - first_idx
+        S = 2 if occ.max() < 2 else 4
+        assert occ.max() < S, "a parameter has more than four fragment slots"
 
         def table(addrs):
             a = np.concatenate(addrs)[order]
-            t = np.zeros((n, 2), dtype=np.uint64)
-            t[src[first], 0] = a[first]
-            t[src[second], 1] = a[second]
+            t = np.zeros((n, S), dtype=np.uint64)
+            t[src, occ] = a
             return torch.from_numpy(t.view(np.int64).reshape(-1)).to(self.device)
 
         tab = table(addr_all)
@@ -118,16 +120,17 @@ class Arena:
             pack(hs, target=True)
         # check: scattering theta through the table reproduces the packed buffers
         th = self.theta.cpu().numpy()
-        t_np = tab.cpu().numpy().view(np.uint64).reshape(n, 2)
+        t_np = tab.cpu().numpy().view(np.uint64).reshape(n, S)
         for h in hs:
             pk = h.packed.cpu().numpy()
             base = np.uint64(h.packed.data_ptr())
             chk = np.zeros_like(pk)
-            for c in range(2):
+            for c in range(S):
                 a = t_np[:, c]
                 sel = (a >= base) & (a < base + np.uint64(4 * pk.size))
                 chk[((a[sel] - base) // np.uint64(4)).astype(np.int64)] = th[sel]
             assert np.array_equal(chk, pk), "scatter table does not reproduce nlbac_mlp_pack for %s" % h.name
+        self.scatter_slots = S
         self._scatter = (tab, tab_t)
         return self._scatter
 

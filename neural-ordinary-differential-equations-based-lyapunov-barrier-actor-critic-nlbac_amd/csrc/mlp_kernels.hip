@@ -23,6 +23,7 @@
 #include <cstdlib>
 #include "common.h"
 #include "mlp_device.h"
+#include "rr_device.h"
 #include "dy_heads.h"
 
 struct MlpLaunch {
@@ -71,6 +72,28 @@ __global__ __launch_bounds__(256) void mlp_pack_kernel(const MlpLaunch L) {
                 const int nc = tc % NC, tile = tc / NC;
                 const int k = 32 * tile + (lane & 31), n = 8 * nc + 4 * (lane >> 5) + j;
                 P[i] = (n < hid && k < K) ? W[(long)n * K + k] : 0.f;
+            }
+        }
+    }
+    // RR packs (rr_device.h) of the hid x hid layers 1 .. nwide-1: float4 v of lane `lane` = the A-fragment values of
+    // MFMAs 4v .. 4v+3 in the chains' issue order; forward W[unit out][unit in], backward its transpose
+    if (net.rr_fwd_off >= 0) {
+        const int NB = (hid + 15) >> 4, R = (hid - 16 * (NB - 1)) >> 2, KS = hid >> 2, NM = NB * KS;
+        const long per_layer = rr_layer_floats(hid);
+        for (int l = 1; l < nwide; ++l) {
+            const float* W = net.params + net.w_off[l];
+            float* Pf = net.packed + net.rr_fwd_off + (long)(l - 1) * per_layer;
+            float* Pb = net.packed + net.rr_bwd_off + (long)(l - 1) * per_layer;
+            for (long i = gid; i < per_layer; i += stride) {
+                const int c = i & 3, lane = (i >> 2) & 63, v = (int)(i >> 8), m = 4 * v + c;
+                float vf = 0.f, vb = 0.f;
+                if (m < NM) {
+                    int jo, ks;
+                    rr_mfma_of(NB, KS, m, jo, ks);
+                    const int uo = rr_unit_out(NB, R, jo, lane & 15), ui = rr_unit_in(NB, R, ks, lane >> 4);
+                    if (uo >= 0) { vf = W[(long)uo * hid + ui]; vb = W[(long)ui * hid + uo]; }
+                }
+                Pf[i] = vf; Pb[i] = vb;
             }
         }
     }
@@ -802,6 +825,14 @@ extern "C" int nlbac_mlp_pack_layout(nlbac_mlp* net) {
             off += (long)(((K + 31) & ~31) >> 5) * (((hid + 7) & ~7) >> 3) * 256;
         }
     }
+    net->rr_fwd_off = net->rr_bwd_off = -1;
+    if (rr_width_ok(hid) && nwide >= 2) {
+        net->rr_fwd_off = (int)off;
+        off += (long)(nwide - 1) * rr_layer_floats(hid);
+        net->rr_bwd_off = (int)off;
+        off += (long)(nwide - 1) * rr_layer_floats(hid);
+    }
+    net->packed_floats = (int)off;
     return (int)off;
 }
 

@@ -18,42 +18,7 @@
 // per wave; f_net+g_net packed are 340 KB and would not fit the 160 KB LDS anyway.
 // Stage derivatives of the tile stay in LDS across stages (sK); everything the
 // backward needs (Y, K, g(x), post-ReLU activations) is written once, coalesced.
-#include "mlp_device.h"
-#include "ode_control.h"
-
-#define NODE_LDS_MAX (160 * 1024 - 64)   /* dynamic LDS per workgroup; the rest holds the static group-barrier counters */
-#define RK_MAX_STAGES 8
-#define RK_MAX_NS 8
-#define RK_MAX_NU 4
-#define RK_MAX_GOUT (RK_MAX_NS * RK_MAX_NU)
-
-struct NodeRkLaunch {
-    nlbac_mlp net[2];                 // f, g
-    const float* y0; const float* u;
-    int n, rpp, n_s, n_u;
-    int stage_begin, stage_end, S_total;
-    float beta[RK_MAX_STAGES][RK_MAX_STAGES];
-    float c_out[RK_MAX_STAGES]; int n_out;
-    float c_err[RK_MAX_STAGES]; int n_err;
-    const double* h_dev; int h_stride; float h_val[8];
-    float* K; float* Y; float* G;
-    float* acts[2]; long acts_ls[2];
-    int acts_bits;                    // acts hold bit-packed ReLU masks [layer][stage*n + row][col tile] (uint32)
-    float* out; float* err;
-    int ld;
-    int sw_off1;                      // float offset of g_net's output-layer block behind f_net's in LDS
-    // device-driven dopri5 chain (nlbac_rk_chain): problems whose solve is done are skipped; the step's buffers (K, Y,
-    // G, acts, err) are those of step slot C_NACC, `slot_floats` floats apart; a slot > 0 starts from its predecessor's
-    // last stage (y1 = Y[6], FSAL K[6]).  norm_mode >= 0: the scaled norms of nlbac_dopri_norm_control and the step
-    // controller run in this launch's epilogue (last workgroup of each problem).
-    const double* ctl; long slot_floats;
-    int norm_mode, n_slots; float rtol, atol; double t_end;
-    float* partials; unsigned* tickets; double* ctl_w; double* hslots;
-    double* alog; int alog_cap;       // attempt log [P][alog_cap][3] = (h tried, error ratio, accepted) or null
-    // nlbac_in_map: the solve's initial state is formed by this launch (stage 0 of a fresh step) from observation rows
-    // and written to y0 for the launches that follow; kind 1 = the Unicycle tasks' state (+ its look-ahead point)
-    int in_kind; const float* in_obs; int in_obs_ld; float in_l; float* in_ps; float* y0_w;
-};
+#include "node_rk_shared.h"
 
 // OCC 1: compiled for 4 waves per SIMD (128 VGPRs, a few spills) so that two workgroups share a CU and overlap their
 // per-tile latency chains - pays off only for launches with well over one tile per CU (measured: 32768 rows, mask mode,
@@ -384,26 +349,6 @@ __global__ __launch_bounds__(512, OCC ? 4 : 2) void node_rk_fwd_kernel(const Nod
 // Replaces the per-stage launch triple affine_bwd -> mlp_bwd_data[f,g] -> rk_stage_bwd.
 // With dz/dG given it also leaves every stage's pre-activation grads for nlbac_mlp_bwd_weights (NODE fit).
 // ---------------------------------------------------------------------------
-struct NodeRkBwdLaunch {
-    nlbac_mlp net[2];
-    const float* u; const float* G;
-    const float* acts[2]; long acts_ls[2];
-    int acts_bits;                    // acts hold bit-packed ReLU masks (see NodeRkLaunch)
-    float* dz[2]; float* dG;
-    float* dK; const float* dYup;
-    float* dy0; int dy0_in;
-    float* du; int du_acc;
-    int n, rpp, n_s, n_u, S_total, st_lo, st_hi, dx_stage0;
-    float beta[RK_MAX_STAGES][RK_MAX_STAGES];
-    const double* h_dev; int h_stride; float h_val[8];
-    int ld, sw_off1;
-    // device-driven chain: launch `back_idx` differentiates step slot C_NACC - back_idx of each problem (problems with
-    // fewer accepted steps are skipped); back_idx 0 is every problem's LAST step (dK / dy0 / dYup come from the
-    // interpolant's backward), the others start from the slot behind them: dK[6] = its dK[0] (FSAL), dYup = its dy0.
-    // Step sizes come from hslots[p][slot].
-    const double* ctl; long slot_floats; int back_idx, n_slots; const double* hslots;
-};
-
 template <int MODE, int BITS>
 __global__ __launch_bounds__(512) void node_rk_bwd_kernel(const NodeRkBwdLaunch L) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
@@ -671,6 +616,10 @@ extern "C" int nlbac_node_rk_bwd(const nlbac_mlp* f, const nlbac_mlp* g, const f
             for (int j = 0; j < n_stages_total; ++j) L.beta[i][j] = beta[i * n_stages_total + j];
     L.h_dev = h_dev; L.h_stride = h_dev_stride;
     for (int p = 0; p < P; ++p) L.h_val[p] = h_host ? h_host[p] : 0.f;
+    {   // nets up to 128 wide run on the register-resident kernels (node_rr_kernels.hip)
+        const int rr = nlbac_node_rr_bwd_launch(L, (hipStream_t)s);
+        if (rr <= 0) return rr;
+    }
     int w = ((f->hid > g->hid ? f->hid : g->hid) + 31) & ~31;
     L.ld = w + 4;
     L.sw_off1 = (((f->out_dim + f->in_dim) * f->hid) + 3) & ~3;
@@ -755,6 +704,10 @@ extern "C" int nlbac_node_rk_fwd(const nlbac_mlp* f, const nlbac_mlp* g, const f
         L.rtol = chain->rtol; L.atol = chain->atol; L.t_end = chain->t_end;
         L.partials = chain->partials; L.tickets = chain->tickets; L.ctl_w = chain->ctl_w; L.hslots = chain->hslots;
         L.alog = chain->alog; L.alog_cap = chain->alog_cap;
+    }
+    {   // nets up to 128 wide run on the register-resident kernels (node_rr_kernels.hip)
+        const int rr = nlbac_node_rr_fwd_launch(L, (hipStream_t)s);
+        if (rr <= 0) return rr;
     }
     // LDS tiles hold pad8(hid) columns (the next layer's K extent), row stride = 4 mod 8 dwords: two workgroups fit per CU
     int w = ((f->hid > g->hid ? f->hid : g->hid) + 7) & ~7;

@@ -1,0 +1,468 @@
+// What the two families of fused Runge-Kutta step kernels of the control-affine NODE  dx/dt = f(x) + g(x) u  share:
+// the launch descriptors and the per-tile bookkeeping around the layer chains (tile constants, stage algebra, step
+// outputs, the in-launch step control).  The families differ in how a 32-row tile's layer chains run:
+//   node_kernels.hip     LDS-tiled: 8 waves, activations in LDS ping-pong tiles, any width up to 256
+//   node_rr_kernels.hip  register-resident: 4 waves, one (net, 16 rows) chain per wave, widths <= 128
+// Reference: torchdiffeq.odeint at U/sac_cbf_clf/sac_cbf_clf.py:453,577 and U/sac_cbf_clf/model.py:252 over
+// NeuralODEModel.forward (model.py:208-217).
+#pragma once
+#include "mlp_device.h"
+#include "ode_control.h"
+
+#define NODE_LDS_MAX (160 * 1024 - 64)   /* dynamic LDS per workgroup; the rest holds the static group-barrier counters */
+#define RK_MAX_STAGES 8
+#define RK_MAX_NS 8
+#define RK_MAX_NU 4
+#define RK_MAX_GOUT (RK_MAX_NS * RK_MAX_NU)
+
+struct NodeRkLaunch {
+    nlbac_mlp net[2];                 // f, g
+    const float* y0; const float* u;
+    int n, rpp, n_s, n_u;
+    int stage_begin, stage_end, S_total;
+    float beta[RK_MAX_STAGES][RK_MAX_STAGES];
+    float c_out[RK_MAX_STAGES]; int n_out;
+    float c_err[RK_MAX_STAGES]; int n_err;
+    const double* h_dev; int h_stride; float h_val[8];
+    float* K; float* Y; float* G;
+    float* acts[2]; long acts_ls[2];
+    int acts_bits;                    // acts hold bit-packed ReLU masks [layer][stage*n + row][words per row] (uint32)
+    float* out; float* err;
+    int ld;
+    int sw_off1;                      // float offset of g_net's output-layer block behind f_net's in LDS
+    // device-driven dopri5 chain (nlbac_rk_chain): problems whose solve is done are skipped; the step's buffers (K, Y,
+    // G, acts, err) are those of step slot C_NACC, `slot_floats` floats apart; a slot > 0 starts from its predecessor's
+    // last stage (y1 = Y[6], FSAL K[6]).  norm_mode >= 0: the scaled norms of nlbac_dopri_norm_control and the step
+    // controller run in this launch's epilogue (last workgroup of each problem).
+    const double* ctl; long slot_floats;
+    int norm_mode, n_slots; float rtol, atol; double t_end;
+    float* partials; unsigned* tickets; double* ctl_w; double* hslots;
+    double* alog; int alog_cap;       // attempt log [P][alog_cap][3] = (h tried, error ratio, accepted) or null
+    // nlbac_in_map: the solve's initial state is formed by this launch (stage 0 of a fresh step) from observation rows
+    // and written to y0 for the launches that follow; kind 1 = the Unicycle tasks' state (+ its look-ahead point)
+    int in_kind; const float* in_obs; int in_obs_ld; float in_l; float* in_ps; float* y0_w;
+};
+
+struct NodeRkBwdLaunch {
+    nlbac_mlp net[2];
+    const float* u; const float* G;
+    const float* acts[2]; long acts_ls[2];
+    int acts_bits;                    // acts hold bit-packed ReLU masks (see NodeRkLaunch)
+    float* dz[2]; float* dG;
+    float* dK; const float* dYup;
+    float* dy0; int dy0_in;
+    float* du; int du_acc;
+    int n, rpp, n_s, n_u, S_total, st_lo, st_hi, dx_stage0;
+    float beta[RK_MAX_STAGES][RK_MAX_STAGES];
+    const double* h_dev; int h_stride; float h_val[8];
+    int ld, sw_off1;
+    // device-driven chain: launch `back_idx` differentiates step slot C_NACC - back_idx of each problem (problems with
+    // fewer accepted steps are skipped); back_idx 0 is every problem's LAST step (dK / dy0 / dYup come from the
+    // interpolant's backward), the others start from the slot behind them: dK[6] = its dK[0] (FSAL), dYup = its dy0.
+    // Step sizes come from hslots[p][slot].
+    const double* ctl; long slot_floats; int back_idx, n_slots; const double* hslots;
+};
+
+// The register-resident kernels (node_rr_kernels.hip): 0 = launched, 1 = these nets / this launch are not theirs (the
+// LDS-tiled kernels take it), < 0 = error.
+int nlbac_node_rr_fwd_launch(NodeRkLaunch& L, hipStream_t s);
+int nlbac_node_rr_bwd_launch(NodeRkBwdLaunch& L, hipStream_t s);
+bool nlbac_node_rr_eligible(const nlbac_mlp* f, const nlbac_mlp* g);
+
+// ---------------------------------------------------------------------------------------------------------------
+// forward: the small per-tile arrays in LDS
+// ---------------------------------------------------------------------------------------------------------------
+struct RkFwdTile {
+    float* sK;     // [stage][32][8]   stage derivatives
+    float* sY0;    // [32][8]          the step's initial state
+    float* sU;     // [32][4]          actions
+    float* sH;     // [32]             step size per row
+    float* sF;     // [32][8]          f(x) of the current stage
+    float* sG;     // [32][32]         g(x) of the current stage
+    __host__ __device__ __forceinline__ static constexpr int floats() {
+        return RK_MAX_STAGES * NLBAC_MLP_TILE * RK_MAX_NS + NLBAC_MLP_TILE * (RK_MAX_NS + RK_MAX_NU + 1 + RK_MAX_NS + RK_MAX_GOUT);
+    }
+    __device__ __forceinline__ void carve(float* p) {
+        sK = p;
+        sY0 = sK + RK_MAX_STAGES * NLBAC_MLP_TILE * RK_MAX_NS;
+        sU = sY0 + NLBAC_MLP_TILE * RK_MAX_NS;
+        sH = sU + NLBAC_MLP_TILE * RK_MAX_NU;
+        sF = sH + NLBAC_MLP_TILE;
+        sG = sF + NLBAC_MLP_TILE * RK_MAX_NS;
+    }
+};
+
+// where a tile's step lives: its problem, step slot and FSAL source (device-driven chain) — false: the problem is done
+struct RkFwdWhere {
+    int p_tile; long soff; bool fsal;
+    float *gK, *gY, *gG, *gErr; const float* gy0;
+};
+__device__ __forceinline__ bool rk_fwd_where(const NodeRkLaunch& L, int row0, RkFwdWhere& w) {
+    w.p_tile = row0 / L.rpp;
+    w.soff = 0;
+    w.fsal = false;
+    if (L.ctl) {
+        const double* c = L.ctl + (long)w.p_tile * NLBAC_DOPRI_CTL;
+        if (c[C_DONE] > 0.0) return false;              // (uniform) this problem's solve has finished
+        const int slot = (int)c[C_NACC];
+        w.soff = (long)slot * L.slot_floats;
+        w.fsal = slot > 0;
+    }
+    w.gK = L.K + w.soff;
+    w.gY = L.Y + w.soff;
+    w.gG = L.G + w.soff;
+    w.gErr = L.err ? L.err + w.soff : nullptr;
+    w.gy0 = w.fsal ? (w.gY - L.slot_floats) + (long)(L.S_total - 1) * L.n * L.n_s : L.y0;
+    return true;
+}
+
+// tile constants: y0 (or the in-map's state), u, h, already-known stages (FSAL / f0 from an earlier launch).
+// Contains barriers; ends with one.
+template <int NTHR>
+__device__ __forceinline__ void rk_fwd_tile_constants(const NodeRkLaunch& L, const RkFwdWhere& w, const RkFwdTile& T,
+                                                      int row0, int tid) {
+    const int n = L.n, ns = L.n_s, nu = L.n_u;
+    if (L.in_kind == 1 && !w.fsal) {
+        // same arithmetic as unicycle_state_kernel (the reference takes arctan2 on the host in float64 and casts back)
+        for (int idx = tid; idx < NLBAC_MLP_TILE * RK_MAX_NS; idx += NTHR) T.sY0[idx] = 0.f;
+        __syncthreads();
+        if (tid < NLBAC_MLP_TILE && row0 + tid < n) {
+            const int row = row0 + tid, i = row % L.rpp;
+            const float* o = L.in_obs + (long)i * L.in_obs_ld;
+            const float th = (float)atan2((double)o[3], (double)o[2]);
+            T.sY0[tid * RK_MAX_NS + 0] = o[0]; T.sY0[tid * RK_MAX_NS + 1] = o[1]; T.sY0[tid * RK_MAX_NS + 2] = th;
+            L.y0_w[(long)row * 3 + 0] = o[0]; L.y0_w[(long)row * 3 + 1] = o[1]; L.y0_w[(long)row * 3 + 2] = th;
+            if (L.in_ps && row < L.rpp) {
+                L.in_ps[i * 2 + 0] = o[0] + L.in_l * cosf(th);
+                L.in_ps[i * 2 + 1] = o[1] + L.in_l * sinf(th);
+            }
+        }
+    } else
+    for (int idx = tid; idx < NLBAC_MLP_TILE * RK_MAX_NS; idx += NTHR) {
+        const int m = idx >> 3, c = idx & 7, row = row0 + m;
+        T.sY0[idx] = (row < n && c < ns) ? w.gy0[(long)row * ns + c] : 0.f;
+    }
+    for (int idx = tid; idx < NLBAC_MLP_TILE * RK_MAX_NU; idx += NTHR) {
+        const int m = idx >> 2, c = idx & 3, row = row0 + m;
+        T.sU[idx] = (row < n && c < nu) ? L.u[(long)row * nu + c] : 0.f;
+    }
+    if (tid < NLBAC_MLP_TILE) {
+        const int p = min(row0 + tid, n - 1) / L.rpp;
+        T.sH[tid] = L.h_dev ? (float)L.h_dev[(long)p * L.h_stride] : L.h_val[p];
+    }
+    for (int idx = tid; idx < L.stage_begin * NLBAC_MLP_TILE * RK_MAX_NS; idx += NTHR) {
+        const int j = idx / (NLBAC_MLP_TILE * RK_MAX_NS), rem = idx - j * NLBAC_MLP_TILE * RK_MAX_NS;
+        const int m = rem >> 3, c = rem & 7, row = row0 + m;
+        float v = 0.f;
+        if (row < n && c < ns) {
+            if (w.fsal && j == 0) {       // first stage = the previous slot's last one; kept in this slot for the interpolant
+                v = (w.gK - L.slot_floats)[((long)(L.S_total - 1) * n + row) * ns + c];
+                w.gK[(long)row * ns + c] = v;
+            } else {
+                v = w.gK[((long)j * n + row) * ns + c];
+            }
+        }
+        T.sK[idx] = v;
+    }
+    __syncthreads();
+}
+
+// stage input  Y_st = y0 + h sum_j beta[st][j] K_j  of the launch's FIRST stage (same op order as rk_combine_kernel),
+// for the threads [t, t + nthr, ...) of one consumer: written to `in` (row stride LD, columns ns..inp-1 zero) and, by
+// the consumer that `owns` the global copy, to Y
+__device__ __forceinline__ void rk_fwd_first_input(const NodeRkLaunch& L, const RkFwdWhere& w, const RkFwdTile& T,
+                                                   int row0, int st, int inp, float* in, int LD, bool owns, int t,
+                                                   int nthr) {
+    const int n = L.n, ns = L.n_s;
+    for (int idx = t; idx < NLBAC_MLP_TILE * inp; idx += nthr) {
+        const int m = idx / inp, c = idx - m * inp;
+        float a = 0.f;
+        if (c < ns) {
+            a = T.sY0[m * RK_MAX_NS + c];
+            const float h = T.sH[m];
+            for (int j = 0; j < st; ++j)
+                if (L.beta[st][j] != 0.f) a = a + T.sK[(j * NLBAC_MLP_TILE + m) * RK_MAX_NS + c] * (L.beta[st][j] * h);
+            if (owns && row0 + m < n) w.gY[((long)st * n + row0 + m) * ns + c] = a;
+        }
+        in[m * LD + c] = a;
+    }
+}
+
+// k = f + g u   (same op order as affine_fwd_kernel), and — same thread, same (row, component) — the next stage's input
+// Y_{st+1} = y0 + h sum_j beta[st+1][j] K_j into in_f (and in_g when given; row stride LD, columns ns..inp-1 zeroed
+// again).  Call between two workgroup barriers: reads sF / sG of the stage, nothing else touches the input tiles.
+template <int NTHR>
+__device__ __forceinline__ void rk_fwd_combine(const NodeRkLaunch& L, const RkFwdWhere& w, const RkFwdTile& T, int row0,
+                                               int st, int inp, float* in_f, float* in_g, int LD, int tid) {
+    const int n = L.n, ns = L.n_s, nu = L.n_u;
+    const bool more = st + 1 < L.stage_end;
+    for (int idx = tid; idx < NLBAC_MLP_TILE * inp; idx += NTHR) {
+        const int m = idx / inp, c = idx - m * inp;
+        float y = 0.f;
+        if (c < ns) {
+            float a = T.sF[m * RK_MAX_NS + c];
+            for (int q = 0; q < nu; ++q) a += T.sG[m * RK_MAX_GOUT + c * nu + q] * T.sU[m * RK_MAX_NU + q];
+            T.sK[(st * NLBAC_MLP_TILE + m) * RK_MAX_NS + c] = a;
+            if (row0 + m < n) w.gK[((long)st * n + row0 + m) * ns + c] = a;
+            if (more) {
+                y = T.sY0[m * RK_MAX_NS + c];
+                const float h = T.sH[m];
+                for (int j = 0; j < st; ++j)
+                    if (L.beta[st + 1][j] != 0.f) y = y + T.sK[(j * NLBAC_MLP_TILE + m) * RK_MAX_NS + c] * (L.beta[st + 1][j] * h);
+                if (L.beta[st + 1][st] != 0.f) y = y + a * (L.beta[st + 1][st] * h);
+                if (row0 + m < n) w.gY[((long)(st + 1) * n + row0 + m) * ns + c] = y;
+            }
+        }
+        if (more) { in_f[m * LD + c] = y; if (in_g) in_g[m * LD + c] = y; }
+    }
+}
+
+// step outputs (solution / error combination) and, with norm_mode >= 0, the fused step control: this tile's partial
+// sums of the scaled norms (same per-entry arithmetic as dopri_norm_block), one ticket per problem; the last workgroup
+// of a problem sums the tile partials in a fixed order and runs the controller.  Contains a barrier when norm_mode >= 0
+// (every thread of the workgroup must call it).
+template <int NTHR>
+__device__ __forceinline__ void rk_fwd_outputs_and_control(const NodeRkLaunch& L, const RkFwdWhere& w, const RkFwdTile& T,
+                                                           int row0, int n_rows, int tid) {
+    const int n = L.n, ns = L.n_s, nu = L.n_u, p_tile = w.p_tile;
+    const float *sK = T.sK, *sY0 = T.sY0, *sU = T.sU, *sH = T.sH;
+    for (int idx = tid; idx < NLBAC_MLP_TILE * ns; idx += NTHR) {
+        const int m = idx / ns, r = idx - m * ns, row = row0 + m;
+        if (row >= n) continue;
+        const float h = sH[m];
+        if (L.out) {
+            float a = sY0[m * RK_MAX_NS + r];
+            for (int j = 0; j < L.n_out; ++j)
+                if (L.c_out[j] != 0.f) a = a + sK[(j * NLBAC_MLP_TILE + m) * RK_MAX_NS + r] * (L.c_out[j] * h);
+            L.out[(long)row * ns + r] = a;
+        }
+        if (w.gErr) {
+            float a = 0.f;
+            for (int j = 0; j < L.n_err; ++j)
+                if (L.c_err[j] != 0.f) a = a + sK[(j * NLBAC_MLP_TILE + m) * RK_MAX_NS + r] * (L.c_err[j] * h);
+            w.gErr[(long)row * ns + r] = a;
+        }
+    }
+    if (L.norm_mode < 0) return;
+    __shared__ unsigned s_last;
+    if (tid < 64) {
+        const int m = tid;
+        float v0 = 0.f, v1 = 0.f;
+        if (m < n_rows) {
+            const float h = sH[m];
+            for (int r = 0; r < ns; ++r) {
+                const float y = sY0[m * RK_MAX_NS + r];
+                if (L.norm_mode == 2) {
+                    float e = 0.f, y1 = y;
+                    for (int j = 0; j < L.n_err; ++j)
+                        if (L.c_err[j] != 0.f) e = e + sK[(j * NLBAC_MLP_TILE + m) * RK_MAX_NS + r] * (L.c_err[j] * h);
+                    const int sl = L.S_total - 1;         // y1 = the last stage's input
+                    for (int j = 0; j < sl; ++j)
+                        if (L.beta[sl][j] != 0.f) y1 = y1 + sK[(j * NLBAC_MLP_TILE + m) * RK_MAX_NS + r] * (L.beta[sl][j] * h);
+                    const float tol = L.atol + L.rtol * fmaxf(fabsf(y), fabsf(y1));
+                    const float q = e / tol;
+                    v0 += q * q;
+                } else {
+                    const float sc = L.atol + fabsf(y) * L.rtol;
+                    if (L.norm_mode == 0) {
+                        const float q0 = y / sc, q1 = sK[m * RK_MAX_NS + r] / sc;
+                        v0 += q0 * q0; v1 += q1 * q1;
+                    } else {
+                        const float q = (sK[(NLBAC_MLP_TILE + m) * RK_MAX_NS + r] - sK[m * RK_MAX_NS + r]) / sc;
+                        v0 += q * q;
+                    }
+                }
+            }
+            if (L.norm_mode == 0)
+                for (int c = 0; c < nu; ++c) {
+                    const float y = sU[m * RK_MAX_NU + c];
+                    const float q = y / (L.atol + fabsf(y) * L.rtol);
+                    v0 += q * q;
+                }
+        }
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) { v0 += __shfl_down(v0, off, 64); v1 += __shfl_down(v1, off, 64); }
+        if (tid == 0) {
+            const int nblk = (L.rpp + NLBAC_MLP_TILE - 1) / NLBAC_MLP_TILE;
+            const int blk = (row0 - p_tile * L.rpp) / NLBAC_MLP_TILE;
+            float* q = L.partials + ((long)p_tile * nblk + blk) * 2;
+            // No agent-scope fence here: on gfx950 a release at agent scope writes the XCD's whole L2 back, and this
+            // workgroup has just written the step's K / Y / masks (measured: +15 us on a one-stage launch, +30 us on an
+            // attempt).  The two partial sums go out as device-scope atomic exchanges — performed at the level all
+            // XCDs see — and the ticket is only taken once both have RETURNED; the last workgroup reads them with
+            // device-scope atomic loads.  Everything else this kernel wrote is for later launches (kernel boundary).
+            const float o0 = __hip_atomic_exchange(q + 0, v0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            const float o1 = __hip_atomic_exchange(q + 1, v1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            asm volatile("" ::"v"(o0), "v"(o1) : "memory");
+            const unsigned ticket = __hip_atomic_fetch_add(L.tickets + p_tile, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            s_last = (ticket == (unsigned)nblk - 1u) ? 1u : 0u;
+            if (s_last) __hip_atomic_store(L.tickets + p_tile, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+    }
+    __syncthreads();
+    if (!s_last || tid >= 64) return;
+    {
+        const int nblk = (L.rpp + NLBAC_MLP_TILE - 1) / NLBAC_MLP_TILE;
+        double d0 = 0.0, d1 = 0.0;
+        for (int b = tid; b < nblk; b += 64) {
+            const float* q = L.partials + ((long)p_tile * nblk + b) * 2;
+            d0 += (double)__hip_atomic_load(q + 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            d1 += (double)__hip_atomic_load(q + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) { d0 += __shfl_down(d0, off, 64); d1 += __shfl_down(d1, off, 64); }
+        if (tid == 0) {
+            const double cnt = (double)L.rpp * (double)(ns + nu);
+            double* c = L.ctl_w + (long)p_tile * NLBAC_DOPRI_CTL;
+            const int slot_before = (int)c[C_NACC];
+            const double h_try = c[C_H];
+            dopri_control_vals(sqrt(d0 / cnt), sqrt(d1 / cnt), p_tile, L.norm_mode, L.t_end, L.ctl_w, L.n_slots);
+            if (L.norm_mode == 2 && L.hslots && c[C_ACCEPT] > 0.0)
+                L.hslots[(long)p_tile * L.n_slots + slot_before] = h_try;      // step size of the accepted step in its slot
+            if (L.norm_mode == 2 && L.alog) {
+                const int k = (int)c[C_NSTEPS] - 1;
+                if (k >= 0 && k < L.alog_cap) {
+                    double* a = L.alog + ((long)p_tile * L.alog_cap + k) * 3;
+                    a[0] = h_try; a[1] = c[C_RATIO]; a[2] = c[C_ACCEPT];
+                }
+            }
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// backward: the small per-tile arrays in LDS
+// ---------------------------------------------------------------------------------------------------------------
+struct RkBwdTile {
+    float* sDK;    // [stage][32][8]   dL/dK_j
+    float* sU;     // [32][4]
+    float* sH;     // [32]
+    float* sDY0;   // [32][8]          running dy0
+    float* sDU;    // [32][4]          running du
+    float* sDX;    // [2][32][8]       dX of f_net / g_net for the current stage
+    __host__ __device__ __forceinline__ static constexpr int floats() {
+        return RK_MAX_STAGES * NLBAC_MLP_TILE * RK_MAX_NS + NLBAC_MLP_TILE * (RK_MAX_NU + 1 + RK_MAX_NS + RK_MAX_NU + 2 * RK_MAX_NS);
+    }
+    __device__ __forceinline__ void carve(float* p) {
+        sDK = p;
+        sU = sDK + RK_MAX_STAGES * NLBAC_MLP_TILE * RK_MAX_NS;
+        sH = sU + NLBAC_MLP_TILE * RK_MAX_NU;
+        sDY0 = sH + NLBAC_MLP_TILE;
+        sDU = sDY0 + NLBAC_MLP_TILE * RK_MAX_NS;
+        sDX = sDU + NLBAC_MLP_TILE * RK_MAX_NU;
+    }
+};
+
+struct RkBwdWhere {
+    long soff; int slot; bool chained, carry;
+    const float* gG; float* gdG; float* gdK; float* gdy0; const float* gdYup;
+    int st_lo; bool stage0_data;
+    __device__ __forceinline__ bool has_data(int st) const { return st >= st_lo && (st > 0 || stage0_data); }
+};
+__device__ __forceinline__ bool rk_bwd_where(const NodeRkBwdLaunch& L, int row0, RkBwdWhere& w) {
+    w.soff = 0;
+    w.slot = 0;
+    w.chained = L.ctl != nullptr;
+    if (w.chained) {
+        const int p_tile = row0 / L.rpp;
+        w.slot = (int)L.ctl[(long)p_tile * NLBAC_DOPRI_CTL + C_NACC] - L.back_idx;
+        if (w.slot < 0) return false;                       // (uniform) this problem took fewer steps
+        w.soff = (long)w.slot * L.slot_floats;
+    }
+    w.carry = w.chained && L.back_idx > 0;    // not the problem's last step: gradients arrive from the slot behind
+    w.gG = L.G + w.soff;
+    w.gdG = L.dG ? L.dG + w.soff : nullptr;
+    w.gdK = L.dK + w.soff;
+    w.gdy0 = L.dy0 ? L.dy0 + w.soff : nullptr;
+    w.gdYup = w.carry ? w.gdy0 + L.slot_floats : (L.dYup ? L.dYup + w.soff : nullptr);
+    w.st_lo = w.chained ? (w.slot == 0 ? 0 : 1) : L.st_lo;    // (a later step's stage 0 is its predecessor's last stage)
+    w.stage0_data = L.dx_stage0 || L.dz[0] != nullptr;
+    return true;
+}
+
+// u, running du / dy0, h, dK of the tile -> LDS.  No barrier inside.
+template <int NTHR>
+__device__ __forceinline__ void rk_bwd_tile_constants(const NodeRkBwdLaunch& L, const RkBwdWhere& w, const RkBwdTile& T,
+                                                      int row0, int tid) {
+    const int n = L.n, ns = L.n_s, nu = L.n_u;
+    for (int idx = tid; idx < NLBAC_MLP_TILE * RK_MAX_NU; idx += NTHR) {
+        const int m = idx >> 2, c = idx & 3, row = row0 + m;
+        const bool ok = row < n && c < nu;
+        T.sU[idx] = ok ? L.u[(long)row * nu + c] : 0.f;
+        T.sDU[idx] = (ok && L.du && L.du_acc) ? L.du[(long)row * nu + c] : 0.f;
+    }
+    for (int idx = tid; idx < NLBAC_MLP_TILE * RK_MAX_NS; idx += NTHR) {
+        const int m = idx >> 3, c = idx & 7, row = row0 + m;
+        T.sDY0[idx] = (row < n && c < ns && w.gdy0 && L.dy0_in && !w.carry) ? w.gdy0[(long)row * ns + c] : 0.f;
+    }
+    if (tid < NLBAC_MLP_TILE) {
+        const int p = min(row0 + tid, n - 1) / L.rpp;
+        T.sH[tid] = w.chained ? (float)L.hslots[(long)p * L.n_slots + w.slot]
+                              : (L.h_dev ? (float)L.h_dev[(long)p * L.h_stride] : L.h_val[p]);
+    }
+    for (int idx = tid; idx < L.st_hi * NLBAC_MLP_TILE * RK_MAX_NS; idx += NTHR) {
+        const int j = idx / (NLBAC_MLP_TILE * RK_MAX_NS), rem = idx - j * NLBAC_MLP_TILE * RK_MAX_NS;
+        const int m = rem >> 3, c = rem & 7, row = row0 + m;
+        float v = 0.f;
+        if (row < n && c < ns) {
+            if (!w.carry) v = w.gdK[((long)j * n + row) * ns + c];
+            else if (j == L.S_total - 1) v = (w.gdK + L.slot_floats)[(long)row * ns + c];     // FSAL: next slot's dK[0]
+        }
+        T.sDK[idx] = v;
+    }
+}
+
+// du += g(Y_st)^T dK_st for the tile's rows
+template <int NTHR>
+__device__ __forceinline__ void rk_bwd_du(const NodeRkBwdLaunch& L, const RkBwdWhere& w, const RkBwdTile& T, int row0,
+                                          int st, int tid) {
+    if (!L.du) return;
+    const int n = L.n, ns = L.n_s, nu = L.n_u, gout = ns * nu;
+    for (int idx = tid; idx < NLBAC_MLP_TILE * nu; idx += NTHR) {
+        const int m = idx / nu, c = idx - m * nu, row = min(row0 + m, n - 1);
+        float a = 0.f;
+        for (int r = 0; r < ns; ++r)
+            a += w.gG[((long)st * n + row) * gout + r * nu + c] * T.sDK[(st * NLBAC_MLP_TILE + m) * RK_MAX_NS + r];
+        T.sDU[m * RK_MAX_NU + c] = T.sDU[m * RK_MAX_NU + c] + 1.0f * a;
+    }
+}
+
+// the stage algebra once both nets' dX sit in sDX: dY = [dYup at the last stage] + dX_f + dX_g; dy0 += dY;
+// dK[j] += beta[st][j] h dY (j < st)
+template <int NTHR>
+__device__ __forceinline__ void rk_bwd_stage_algebra(const NodeRkBwdLaunch& L, const RkBwdWhere& w, const RkBwdTile& T,
+                                                     int row0, int st, int tid) {
+    const int n = L.n, ns = L.n_s;
+    for (int idx = tid; idx < NLBAC_MLP_TILE * ns; idx += NTHR) {
+        const int m = idx / ns, c = idx - m * ns, row = row0 + m;
+        float d = (w.gdYup && st == L.S_total - 1 && row < n) ? w.gdYup[(long)row * ns + c] : 0.f;
+        d += T.sDX[m * RK_MAX_NS + c];
+        d += T.sDX[(NLBAC_MLP_TILE + m) * RK_MAX_NS + c];
+        T.sDY0[m * RK_MAX_NS + c] = T.sDY0[m * RK_MAX_NS + c] + d;
+        const float h = T.sH[m];
+        for (int j = 0; j < st; ++j)
+            if (L.beta[st][j] != 0.f) T.sDK[(j * NLBAC_MLP_TILE + m) * RK_MAX_NS + c] += (L.beta[st][j] * h) * d;
+    }
+}
+
+// dK, dy0, du of the tile -> global
+template <int NTHR>
+__device__ __forceinline__ void rk_bwd_outputs(const NodeRkBwdLaunch& L, const RkBwdWhere& w, const RkBwdTile& T,
+                                               int row0, int tid) {
+    const int n = L.n, ns = L.n_s, nu = L.n_u;
+    for (int idx = tid; idx < L.st_hi * NLBAC_MLP_TILE * ns; idx += NTHR) {
+        const int j = idx / (NLBAC_MLP_TILE * ns), rem = idx - j * NLBAC_MLP_TILE * ns;
+        const int m = rem / ns, c = rem - m * ns, row = row0 + m;
+        if (row < n) w.gdK[((long)j * n + row) * ns + c] = T.sDK[(j * NLBAC_MLP_TILE + m) * RK_MAX_NS + c];
+    }
+    if (w.gdy0)
+        for (int idx = tid; idx < NLBAC_MLP_TILE * ns; idx += NTHR) {
+            const int m = idx / ns, c = idx - m * ns, row = row0 + m;
+            if (row < n) w.gdy0[(long)row * ns + c] = T.sDY0[m * RK_MAX_NS + c];
+        }
+    if (L.du)
+        for (int idx = tid; idx < NLBAC_MLP_TILE * nu; idx += NTHR) {
+            const int m = idx / nu, c = idx - m * nu, row = row0 + m;
+            if (row < n) L.du[(long)row * nu + c] = T.sDU[m * RK_MAX_NU + c];
+        }
+}

@@ -84,14 +84,20 @@ __global__ __launch_bounds__(256) void adam_step_kernel(float* __restrict__ p, f
 
 // One launch per optimiser step: ++step and its bias corrections (adam_prepare), the slab sum + Adam + Polyak update
 // (adam_step), and the refresh of the MFMA-fragment copies of the weights (mlp_pack) through a scatter table: for
-// parameter i, scat[2i], scat[2i+1] are the device addresses of its forward / backward fragment slots (0 = none;
+// parameter i, scat[SLOTS i + k] are the device addresses of its fragment slots (forward / backward pack, and the RR
+// packs of nets that have them: SLOTS = 2 or 4; 0 = none;
 // biases and skinny layers are read from the flat parameters).  Every workgroup derives the step constants from the
 // still un-incremented counter; the workgroup that finishes last publishes the new counter.
-__device__ __forceinline__ void scatter2(const unsigned long long* __restrict__ scat, long i, float val) {
-    const ulonglong2 ab = reinterpret_cast<const ulonglong2*>(scat)[i];          // both slots of parameter i: one load
-    if (ab.x) *reinterpret_cast<float*>(ab.x) = val;
-    if (ab.y) *reinterpret_cast<float*>(ab.y) = val;
+template <int SLOTS>
+__device__ __forceinline__ void scatter_n(const unsigned long long* __restrict__ scat, long i, float val) {
+#pragma unroll
+    for (int k = 0; k < SLOTS / 2; ++k) {
+        const ulonglong2 ab = reinterpret_cast<const ulonglong2*>(scat)[i * (SLOTS / 2) + k];   // two slots per load
+        if (ab.x) *reinterpret_cast<float*>(ab.x) = val;
+        if (ab.y) *reinterpret_cast<float*>(ab.y) = val;
+    }
 }
+#define scatter2 scatter_n<SLOTS>
 
 // sum of the gradient slabs at float4 index i, in slab order (the additions are sequential as before; the loads of
 // four slabs are issued together instead of one per loop trip - the trips were a chain of exposed memory latencies)
@@ -135,6 +141,7 @@ __device__ __forceinline__ void alpha_refresh(const AlphaRefresh& AR, long e, fl
         }
 }
 
+template <int SLOTS>
 __global__ __launch_bounds__(256) void adam_fused_kernel(float* __restrict__ p, float* __restrict__ m,
                                                          float* __restrict__ v, const float* __restrict__ grad,
                                                          int n_slabs, long slab_stride, long n, AdamState* st, double lr,
@@ -293,9 +300,12 @@ extern "C" int nlbac_adam_step(float* p, float* m, float* v, const float* grad, 
 
 extern "C" int nlbac_adam_fused(float* p, float* m, float* v, const float* grad, int n_slabs, long slab_stride, long n,
                                 void* state, double lr, float* target, float tau, const void* scatter,
-                                const void* scatter_target, int n_alpha, const long* alpha_off, float* const* alpha_dst,
-                                const float* mirror_src, float* mirror_dst, int n_mirror, nlbac_stream_t s) {
+                                const void* scatter_target, int scatter_slots, int n_alpha, const long* alpha_off,
+                                float* const* alpha_dst, const float* mirror_src, float* mirror_dst, int n_mirror,
+                                nlbac_stream_t s) {
     NLBAC_REQUIRE(p && m && v && grad && state, "nlbac_adam_fused: null pointer");
+    NLBAC_REQUIRE(scatter_slots == 2 || scatter_slots == 4 || (!scatter && !scatter_target),
+                  "nlbac_adam_fused: scatter tables hold 2 or 4 slots per parameter");
     NLBAC_REQUIRE(n_alpha >= 0 && n_alpha <= 2 && (n_alpha == 0 || (alpha_off && alpha_dst)), "nlbac_adam_fused: bad alpha refresh");
     AlphaRefresh AR;
     AR.off[0] = AR.off[1] = -1; AR.dst[0] = AR.dst[1] = nullptr;
@@ -310,9 +320,10 @@ extern "C" int nlbac_adam_fused(float* p, float* m, float* v, const float* grad,
                       slab_stride % 4 == 0 && ((uintptr_t)scatter | (uintptr_t)scatter_target) % 8 == 0,
                   "nlbac_adam_fused: buffers must be 16-byte aligned");
     NLBAC_REQUIRE(!scatter_target || (target && tau >= 0.f), "nlbac_adam_fused: scatter_target without a target");
-    hipLaunchKernelGGL(adam_fused_kernel, dim3(stream_grid(n, 4)), dim3(256), 0, (hipStream_t)s, p, m, v, grad, n_slabs,
-                       slab_stride, n, (AdamState*)state, lr, (tau >= 0.f) ? target : nullptr, tau,
-                       (const unsigned long long*)scatter, (const unsigned long long*)scatter_target, AR);
+    hipLaunchKernelGGL((scatter_slots == 4 ? adam_fused_kernel<4> : adam_fused_kernel<2>), dim3(stream_grid(n, 4)), dim3(256),
+                       0, (hipStream_t)s, p, m, v, grad, n_slabs, slab_stride, n, (AdamState*)state, lr,
+                       (tau >= 0.f) ? target : nullptr, tau, (const unsigned long long*)scatter,
+                       (const unsigned long long*)scatter_target, AR);
     NLBAC_CHECK_LAUNCH("nlbac_adam_fused");
     return 0;
 }

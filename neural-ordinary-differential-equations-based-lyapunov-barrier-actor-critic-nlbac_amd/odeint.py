@@ -118,7 +118,10 @@ class _StepWS:
         self.bits = bool(solver.fused and not solver.keep_acts)
         if self.bits:
             zi = lambda *s: self._store.zeros(*s, dtype=torch.int32)
-            self.wf, self.wg = (f.hid + 31) // 32, (g.hid + 31) // 32
+            # words per row and layer: one per 32 hidden units, or (register-resident kernels) one per lane quarter
+            lib = _lib.load()
+            self.wf = lib.nlbac_node_rk_mask_words(C.byref(f.desc), C.byref(g.desc), 0)
+            self.wg = lib.nlbac_node_rk_mask_words(C.byref(f.desc), C.byref(g.desc), 1)
             self.acts_f = zi(f.n_layers - 1, S * n, self.wf)
             self.acts_g = zi(g.n_layers - 1, S * n, self.wg)
         else:

@@ -319,8 +319,8 @@ class SAC_CBF_CLF(object):
                 before_step(a.grad.data_ptr())
             # mirror: (pinned host block) the step's last workgroup writes the scalars block to (see _returns)
             _lib.call("nlbac_adam_fused", a.theta.data_ptr(), a.m.data_ptr(), a.v.data_ptr(), a.grad.data_ptr(),
-                      n_slabs, a.n, a.n, a.state.data_ptr(), lr, target, tau, scat.data_ptr(), scat_t, n_al, al_off,
-                      al_dst, self.sc.data_ptr() if mirror is not None else None,
+                      n_slabs, a.n, a.n, a.state.data_ptr(), lr, target, tau, scat.data_ptr(), scat_t, a.scatter_slots,
+                      n_al, al_off, al_dst, self.sc.data_ptr() if mirror is not None else None,
                       mirror.data_ptr() if mirror is not None else None, SC.SC_SIZE if mirror is not None else 0, s)
             return
         n_extra = 0 if extra is None else extra.numel()
@@ -334,7 +334,8 @@ class SAC_CBF_CLF(object):
         if before_step is not None:
             before_step(xb.data_ptr())
         _lib.call("nlbac_adam_fused", a.theta.data_ptr(), a.m.data_ptr(), a.v.data_ptr(), xb.data_ptr(), 1, a.n, a.n,
-                  a.state.data_ptr(), lr, target, tau, scat.data_ptr(), scat_t, n_al, al_off, al_dst, None, None, 0, s)
+                  a.state.data_ptr(), lr, target, tau, scat.data_ptr(), scat_t, a.scatter_slots, n_al, al_off, al_dst, None,
+                  None, 0, s)
 
     # ------------------------------------------------------------------ utils
     def repack_all(self):

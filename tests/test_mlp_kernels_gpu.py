@@ -162,7 +162,7 @@ def test_multi_net_launch_and_adam_soft_update(fused):
             mdst = torch.zeros(37, dtype=torch.float32).pin_memory()
             _lib.call("nlbac_adam_fused", ar.theta.data_ptr(), ar.m.data_ptr(), ar.v.data_ptr(), ar.grad.data_ptr(),
                       ar.n_slabs, ar.n, ar.n, ar.state.data_ptr(), lr, ar.target.data_ptr(), tau, scat.data_ptr(),
-                      scat_t.data_ptr(), 0, None, None, msrc.data_ptr(), mdst.data_ptr(), 37, s)
+                      scat_t.data_ptr(), ar.scatter_slots, 0, None, None, msrc.data_ptr(), mdst.data_ptr(), 37, s)
             torch.cuda.synchronize()
             assert torch.equal(mdst, msrc.cpu()), "adam_fused did not mirror the scalars block to pinned memory"
 
