@@ -15,6 +15,7 @@
 #include "node_rk_shared.h"
 #include "rr_device.h"
 #include <cstdlib>
+#include <type_traits>
 
 // which output the A row hu = 4 q' + r' of the (single) output block computes, so that the result leaves lane (q, row)
 // with state component c = 4 r + q in register r (f_net) resp. g[c = 4 ks0 + q][u] in register e = ks0 nu + u (g_net):
@@ -29,10 +30,20 @@ __device__ __forceinline__ int rr_out_row(int grp, int hu, int ns, int nu) {
     return (rp < KS0 * nu && c < ns) ? c * nu + u : -1;
 }
 
+#ifdef RR_TIMING      // ablation build only: waves 0 (f_net) and 2 (g_net) of workgroup 0 stamp the shader clock into L.err (as int64)
+#define RSTAMP(slot_) if (L.err && blockIdx.x == 0 && lane == 0 && half == 0) reinterpret_cast<long long*>(L.err)[grp * 256 + (slot_)] = (long long)__builtin_readcyclecounter();
+#else
+#define RSTAMP(slot_)
+#endif
+
+#define RR_MAX_W 4        /* layer 0 + up to three hid x hid layers (n_layers <= 5: the reference's f_net) */
+
 template <int NB, int R, int BITS>
 __global__ __launch_bounds__(256) void node_rr_fwd_kernel(const NodeRkLaunch L) {
     using S = RRShape<NB, R>;
     constexpr int KS = S::KS, HID = S::HID;
+    constexpr int TB = NB - 2;                 // first block of a layer's last group, the "tail": its accumulators are
+    constexpr int NT = KS - 4 * TB;            // finished inside the NEXT product (NT values: 5 at hid 100, else 8)
     extern __shared__ __attribute__((aligned(16))) float smem[];
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -43,14 +54,25 @@ __global__ __launch_bounds__(256) void node_rr_fwd_kernel(const NodeRkLaunch L) 
     if (!rk_fwd_where(L, row0, w)) return;
     RkFwdTile T;
     T.carve(smem);
-    float* sYin = smem + RkFwdTile::floats();            // [32][8] the stage input, columns ns..7 zero
+    float* const sYin = smem + RkFwdTile::floats();      // [32][8] the stage input, columns ns..7 zero
+    float* const sW0 = sYin + NLBAC_MLP_TILE * 8;        // [net][k-step < 3][block < 8][lane]: layer 0's A fragments
     const nlbac_mlp& net = L.net[grp];
     const int nw = net.n_layers - 1;                     // layer 0 + (nw - 1) hid x hid layers, then the output layer
     const int n_rows = min(NLBAC_MLP_TILE, n - row0);
     const int q = lane >> 4, r16 = lane & 15;
     const int m = 16 * half + r16, grow = row0 + m;      // this lane's row: within the tile, global
     const bool row_ok = grow < n;
-    const int KS0 = (ns + 3) >> 2;                       // k-steps of layer 0 (1 or 2)
+    const int KS0 = (ns + 3) >> 2;                       // registers a lane needs for its row's state components (1 or 2)
+    const int KL0 = (ns + 4) >> 2;                       // k-steps of layer 0, which contracts [y | 1] with [W_0 | b_0] (1..3)
+
+    // ---- what the stage loop reads of the launch descriptor, once
+    const float* const params = net.params;
+    int boff[RR_MAX_W];
+#pragma unroll
+    for (int l = 0; l < RR_MAX_W; ++l) boff[l] = net.b_off[l];
+    float* const acts = L.acts[grp] ? L.acts[grp] + w.soff : nullptr;
+    const long acts_ls = L.acts_ls[grp];
+    const int stage_end = L.stage_end, S_last = L.S_total - 1;
 
     // ---- the wave's weight stream: hid x hid layers 1 .. nw-1, then layer 1 again (next stage)
     const __amdgpu_buffer_rsrc_t rs = rr_rsrc(net.packed, net.packed_floats);
@@ -59,22 +81,23 @@ __global__ __launch_bounds__(256) void node_rr_fwd_kernel(const NodeRkLaunch L) 
     RRGemm<S> gemm;
     gemm.prime(rs, voff, wbase);
 
-    // ---- constants of the launch in registers: layer 0's and the output layer's A fragments
-    float w0[2][NB];
-    {
-        const float* W0 = net.params + net.w_off[0];
+    // ---- constants of the launch: layer 0's A fragments (its bias rides in the k slot behind the last state component)
+    //      to LDS in fragment order, the output layer's into registers
+    if (half == 0) {
+        const float* W0 = params + net.w_off[0];
+        const float* b0 = params + boff[0];
 #pragma unroll
-        for (int k0 = 0; k0 < 2; ++k0)
+        for (int k0 = 0; k0 < 3; ++k0)
 #pragma unroll
             for (int jo = 0; jo < NB; ++jo) {
                 const int uo = rr_unit_out(NB, R, jo, r16), col = 4 * k0 + q;
-                w0[k0][jo] = (uo >= 0 && col < ns) ? W0[uo * ns + col] : 0.f;
+                sW0[((grp * 3 + k0) * 8 + jo) * 64 + lane] = (uo < 0 || col > ns) ? 0.f : (col < ns ? W0[uo * ns + col] : b0[uo]);
             }
     }
     float wo[KS];
-    const int orow = rr_out_row(grp, r16, ns, nu);
     {
-        const float* wrow = net.params + net.w_off[nw] + (long)max(orow, 0) * HID;
+        const int orow = rr_out_row(grp, r16, ns, nu);
+        const float* wrow = params + net.w_off[nw] + (long)max(orow, 0) * HID;
 #pragma unroll
         for (int jo = 0; jo < NB; ++jo) {
             const f32x4 v = rr_row_load<S>(wrow, jo, q);
@@ -82,10 +105,10 @@ __global__ __launch_bounds__(256) void node_rr_fwd_kernel(const NodeRkLaunch L) 
             for (int r = 0; r < ((jo < NB - 1) ? 4 : R); ++r) wo[4 * jo + r] = (orow >= 0) ? v[r] : 0.f;
         }
     }
-    // this lane's outputs of the output layer (register r): where they go in sF / sG (and G), their bias
+    // this lane's outputs of the output layer (register r): their LDS slot in sF / sG (-1: none), their bias
     int o_idx[4]; float o_bias[4];
     {
-        const float* bo = net.params + net.b_off[nw];
+        const float* bo = params + net.b_off[nw];
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
             int o = -1;
@@ -96,55 +119,135 @@ __global__ __launch_bounds__(256) void node_rr_fwd_kernel(const NodeRkLaunch L) 
         }
     }
 
+    RSTAMP(0)
     rk_fwd_tile_constants<256>(L, w, T, row0, tid);
+    RSTAMP(1)
 
-    for (int st = L.stage_begin; st < L.stage_end; ++st) {
+    for (int st = L.stage_begin; st < stage_end; ++st) {
+        const int sb = 2 + 8 * (st - L.stage_begin);
+        (void)sb;
         if (st == L.stage_begin) {
             rk_fwd_first_input(L, w, T, row0, st, 8, sYin, 8, true, tid, 256);
             __syncthreads();
         }
-        float H[KS];
-        f32x4 acc[NB];
-        // ---- layer 0: K = ns (one or two k-steps), straight from the stage input
+        RSTAMP(sb + 0)
+        // the next stage's tableau row (scalar loads from the kernel arguments, issued now: the combine step behind the
+        // layer chains was a chain of exposed load latencies)
+        float bn[RK_MAX_STAGES];
         {
-            const float y0 = sYin[m * 8 + q], y1 = sYin[m * 8 + 4 + q];
+            const int sn = min(st + 1, S_last);
 #pragma unroll
-            for (int jo = 0; jo < NB; ++jo) {
-                acc[jo] = __builtin_amdgcn_mfma_f32_16x16x4f32(w0[0][jo], y0, f32x4{0.f, 0.f, 0.f, 0.f}, 0, 0, 0);
-                if (KS0 > 1) acc[jo] = __builtin_amdgcn_mfma_f32_16x16x4f32(w0[1][jo], y1, acc[jo], 0, 0, 0);
-            }
+            for (int j = 0; j < RK_MAX_STAGES; ++j) bn[j] = L.beta[sn][j];
         }
-        for (int l = 0; l < nw; ++l) {
-            if (l > 0) {
-                const int cur = wbase + (l - 1) * S::LAYER_BYTES;
-                const int nxt = (l + 1 < nw) ? cur + S::LAYER_BYTES : wbase;
-                gemm.run(acc, H, rs, voff, cur, nxt);
+        const long srow = (long)st * n + grow;
+        float Ha[KS], Hb[KS];             // activations ping-pong between two register sets
+        f32x4 acc0[NB], acc[NB], bv[NB], bpre[3];
+        unsigned wd = 0u;                 // the mask word being assembled (values arrive in ascending register order)
+        constexpr int G0 = rr_group_first(NB);
+        // biases enter as the C operand of each block's first MFMA; those of a layer's first group of blocks are
+        // requested one product ahead (bpre), the others at the layer's start
+        auto prefetch_bias = [&](int l) __attribute__((always_inline)) {
+#pragma unroll
+            for (int jo = 0; jo < G0; ++jo) bpre[jo] = rr_bias<S>(params + boff[l], jo, q);
+        };
+        prefetch_bias(1);
+
+        // what the backward needs of a finished value goes out once: a mask bit (word per layer), or the activation itself
+        auto save_block = [&](int l, int jo, const float (&H)[KS]) __attribute__((always_inline)) {
+            if (BITS || !acts || !row_ok) return;
+            f32x4 hv{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int rr = 0; rr < ((jo < NB - 1) ? 4 : R); ++rr) hv[rr] = H[4 * jo + rr];
+            rr_row_store<S>(acts + (long)l * acts_ls + srow * HID, jo, q, hv);
+        };
+        auto save_word = [&](int l, unsigned word) __attribute__((always_inline)) {
+            if (BITS && acts && row_ok) reinterpret_cast<unsigned*>(acts + (long)l * acts_ls)[srow * 4 + q] = word;
+        };
+        // layer 0's value ks (no bias: folded into the product), finished just before layer 1's k-step ks reads it
+        auto pre_l0 = [&](int ks) __attribute__((always_inline)) {
+            const int jo = (ks < 4 * (NB - 1)) ? (ks >> 2) : NB - 1, r = ks - 4 * jo;
+            const float h = rr_relu(acc0[jo][r]);
+            Ha[ks] = h;
+            if (BITS) rr_mask_push(wd, h);
+            if (r == ((jo < NB - 1) ? 3 : R - 1)) save_block(0, jo, Ha);
+            if (ks == KS - 1) save_word(0, wd);
+        };
+        // the tail of hid x hid layer lp (blocks TB, TB+1 of `acc`), finished inside the product that follows it: value t
+        // at that product's k-step t (it is read at k-step 4 TB + t)
+        auto pre_tail = [&](int lp, float (&H)[KS], int t) __attribute__((always_inline)) {
+            if (t >= NT) return;
+            const int jo = TB + (t >> 2), r = t & 3;
+            const float h = rr_relu(acc[jo][r]);
+            H[4 * TB + t] = h;
+            if (BITS) rr_mask_push(wd, h);
+            if (t == 3 || t == NT - 1) save_block(lp, jo, H);
+            if (t == NT - 1) save_word(lp, wd);
+        };
+
+        // ---- layer 0: K = ns + 1 (one to three k-steps), straight from the stage input
+        {
+            float yv[3], a0[3][NB];
+#pragma unroll
+            for (int k0 = 0; k0 < 3; ++k0) {
+                const int col = 4 * k0 + q;
+                yv[k0] = (col < ns) ? sYin[m * 8 + min(col, 7)] : (col == ns ? 1.f : 0.f);
             }
-            // ---- bias + ReLU in place; what the backward needs goes out once: mask bits or the activations
-            const float* bias = net.params + net.b_off[l];
-            unsigned word = 0u;
-            float* arow = (!BITS && L.acts[grp]) ? L.acts[grp] + w.soff + (long)l * L.acts_ls[grp] + ((long)st * n + grow) * HID : nullptr;
 #pragma unroll
-            for (int jo = 0; jo < NB; ++jo) {
-                const f32x4 b = rr_bias<S>(bias, jo, q);
-                f32x4 hv{0.f, 0.f, 0.f, 0.f};
+            for (int jo = 0; jo < NB; ++jo) a0[0][jo] = sW0[((grp * 3 + 0) * 8 + jo) * 64 + lane];
+            if (KL0 == 1) {
 #pragma unroll
-                for (int r = 0; r < ((jo < NB - 1) ? 4 : R); ++r) {
-                    const float h = rr_relu(acc[jo][r] + b[r]);
-                    H[4 * jo + r] = h;
-                    hv[r] = h;
-                    if (BITS) word |= (__builtin_bit_cast(int, h) > 0 ? 1u : 0u) << (4 * jo + r);
+                for (int jo = 0; jo < NB; ++jo)
+                    acc0[jo] = __builtin_amdgcn_mfma_f32_16x16x4f32(a0[0][jo], yv[0], f32x4{0.f, 0.f, 0.f, 0.f}, 0, 0, 0);
+            } else {
+#pragma unroll
+                for (int jo = 0; jo < NB; ++jo) a0[1][jo] = sW0[((grp * 3 + 1) * 8 + jo) * 64 + lane];
+                if (KL0 == 2) {
+#pragma unroll
+                    for (int jo = 0; jo < NB; ++jo) {
+                        acc0[jo] = __builtin_amdgcn_mfma_f32_16x16x4f32(a0[0][jo], yv[0], f32x4{0.f, 0.f, 0.f, 0.f}, 0, 0, 0);
+                        acc0[jo] = __builtin_amdgcn_mfma_f32_16x16x4f32(a0[1][jo], yv[1], acc0[jo], 0, 0, 0);
+                    }
+                } else {
+#pragma unroll
+                    for (int jo = 0; jo < NB; ++jo) a0[2][jo] = sW0[((grp * 3 + 2) * 8 + jo) * 64 + lane];
+#pragma unroll
+                    for (int jo = 0; jo < NB; ++jo) {
+                        acc0[jo] = __builtin_amdgcn_mfma_f32_16x16x4f32(a0[0][jo], yv[0], f32x4{0.f, 0.f, 0.f, 0.f}, 0, 0, 0);
+                        acc0[jo] = __builtin_amdgcn_mfma_f32_16x16x4f32(a0[1][jo], yv[1], acc0[jo], 0, 0, 0);
+                        acc0[jo] = __builtin_amdgcn_mfma_f32_16x16x4f32(a0[2][jo], yv[2], acc0[jo], 0, 0, 0);
+                    }
                 }
-                if (!BITS && arow && row_ok) rr_row_store<S>(arow, jo, q, hv);
             }
-            if (BITS && L.acts[grp] && row_ok)
-                reinterpret_cast<unsigned*>(L.acts[grp] + w.soff + (long)l * L.acts_ls[grp])[((long)st * n + grow) * 4 + q] = word;
         }
-        // ---- output layer (<= 16 outputs: one block), to LDS for k = f + g u; g(x) also to global for the backward
-        {
-            f32x4 o{0.f, 0.f, 0.f, 0.f};
+        RSTAMP(sb + 1)
+
+        // ---- the hid x hid layers and the output layer, statically unrolled (lc: the layer index as a type): wide layer l
+        //      reads one activation set and writes the other
+        auto wide = [&](auto lc, float (&Hin)[KS], float (&Hout)[KS]) __attribute__((always_inline)) {
+            constexpr int l = decltype(lc)::value;
 #pragma unroll
-            for (int ks = 0; ks < KS; ++ks) o = __builtin_amdgcn_mfma_f32_16x16x4f32(wo[ks], H[ks], o, 0, 0, 0);
+            for (int jo = 0; jo < NB; ++jo) bv[jo] = (jo < G0) ? bpre[jo] : rr_bias<S>(params + boff[l], jo, q);
+            __builtin_amdgcn_sched_barrier(0);
+            const int cur = wbase + (l - 1) * S::LAYER_BYTES;
+            const int nxt = (l + 1 < nw) ? cur + S::LAYER_BYTES : wbase;
+            gemm.run(acc, bv, Hin, rs, voff, cur, nxt,
+                     [&](int ks) __attribute__((always_inline)) {
+                         if (l == 1) pre_l0(ks);
+                         else pre_tail(l - 1, Hin, ks);
+                     },
+                     [&](int jo, int r) __attribute__((always_inline)) {
+                         const float h = rr_relu(acc[jo][r]);
+                         Hout[4 * jo + r] = h;
+                         if (BITS) rr_mask_push(wd, h);
+                         if (r == 3) save_block(l, jo, Hout);
+                     },
+                     [&]() __attribute__((always_inline)) { if (l + 1 < nw) prefetch_bias(l + 1); });
+            RSTAMP(sb + 1 + l)
+        };
+        // output layer (<= 16 outputs: one block), to LDS for k = f + g u; g(x) also to global for the backward
+        auto outl = [&](auto lc, float (&Hin)[KS]) __attribute__((always_inline)) {
+            constexpr int l = decltype(lc)::value;            // (= nw: the layers before it are 0 .. l-1)
+            const f32x4 o = RRGemm<S>::block(wo, Hin, [&](int ks) __attribute__((always_inline)) { pre_tail(l - 1, Hin, ks); });
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
                 if (o_idx[r] < 0) continue;
@@ -155,11 +258,64 @@ __global__ __launch_bounds__(256) void node_rr_fwd_kernel(const NodeRkLaunch L) 
                     if (row_ok) w.gG[((long)st * n + grow) * gout + o_idx[r]] = val;
                 }
             }
+        };
+        using I1 = std::integral_constant<int, 1>; using I2 = std::integral_constant<int, 2>;
+        using I3 = std::integral_constant<int, 3>; using I4 = std::integral_constant<int, 4>;
+        // the reference's nets (U/sac_cbf_clf/model.py:186-206): f_net has three hid x hid layers, g_net two.  (One code
+        // path per depth: a third, for two-layer nets, cost 26 more VGPRs and accumulator-file spills in all of them.)
+        wide(I1{}, Ha, Hb);
+        wide(I2{}, Hb, Ha);
+        if (grp == 0) { wide(I3{}, Ha, Hb); outl(I4{}, Hb); }
+        else outl(I3{}, Ha);
+        RSTAMP(sb + 5)
+        __syncthreads();
+        RSTAMP(sb + 6)
+        // ---- k = f + g u (same op order as affine_fwd_kernel) and, same thread, the next stage's input
+        //      Y_{st+1} = y0 + h sum_j beta[st+1][j] K_j (same op order as rk_combine_kernel): one (row, component) per
+        //      thread, every LDS operand requested up front, no data-dependent branch
+        {
+            const int mm = tid >> 3, c = tid & 7;
+            const bool more = st + 1 < stage_end, cv = c < ns, rv = row0 + mm < n;
+            float a = T.sF[mm * RK_MAX_NS + c];
+            float gv[RK_MAX_NU], uv[RK_MAX_NU], kj[RK_MAX_STAGES - 1];
+#pragma unroll
+            for (int u = 0; u < RK_MAX_NU; ++u) {
+                gv[u] = T.sG[mm * RK_MAX_GOUT + min(c * nu + u, RK_MAX_GOUT - 1)];
+                uv[u] = T.sU[mm * RK_MAX_NU + u];
+            }
+#pragma unroll
+            for (int j = 0; j < RK_MAX_STAGES - 1; ++j) kj[j] = T.sK[(j * NLBAC_MLP_TILE + mm) * RK_MAX_NS + c];
+            float y = T.sY0[mm * RK_MAX_NS + c];
+            const float h = T.sH[mm];
+#pragma unroll
+            for (int u = 0; u < RK_MAX_NU; ++u) {
+                const float t = a + gv[u] * uv[u];
+                a = (u < nu) ? t : a;
+            }
+            float bst = 0.f;
+#pragma unroll
+            for (int j = 0; j < RK_MAX_STAGES - 1; ++j) {
+                const float t = y + kj[j] * (bn[j] * h);
+                y = (j < st && bn[j] != 0.f) ? t : y;
+                bst = (j == st) ? bn[j] : bst;
+            }
+            {
+                const float t = y + a * (bst * h);
+                y = (bst != 0.f) ? t : y;
+            }
+            if (cv) {
+                T.sK[(st * NLBAC_MLP_TILE + mm) * RK_MAX_NS + c] = a;
+                if (rv) w.gK[((long)st * n + row0 + mm) * ns + c] = a;
+                if (more && rv) w.gY[((long)(st + 1) * n + row0 + mm) * ns + c] = y;
+            }
+            if (more) sYin[mm * 8 + c] = cv ? y : 0.f;
         }
         __syncthreads();
-        rk_fwd_combine<256>(L, w, T, row0, st, 8, sYin, nullptr, 8, tid);
-        __syncthreads();
+        RSTAMP(sb + 7)
     }
+#ifdef RR_TIMING
+    if (L.err) return;
+#endif
     rk_fwd_outputs_and_control<256>(L, w, T, row0, n_rows, tid);
 }
 
@@ -171,7 +327,7 @@ __global__ __launch_bounds__(256) void node_rr_fwd_kernel(const NodeRkLaunch L) 
 template <int NB, int R, int BITS>
 __global__ __launch_bounds__(256) void node_rr_bwd_kernel(const NodeRkBwdLaunch L) {
     using S = RRShape<NB, R>;
-    constexpr int KS = S::KS, HID = S::HID;
+    constexpr int KS = S::KS, HID = S::HID, TB = NB - 2, NT = KS - 4 * TB;
     extern __shared__ __attribute__((aligned(16))) float smem[];
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -182,6 +338,7 @@ __global__ __launch_bounds__(256) void node_rr_bwd_kernel(const NodeRkBwdLaunch 
     if (!rk_bwd_where(L, row0, w)) return;
     RkBwdTile T;
     T.carve(smem);
+    float* const sWt = smem + RkBwdTile::floats();       // [net][k-step < 4][block < 8][lane]: W_out^T's A fragments
     const nlbac_mlp& net = L.net[grp];
     const int nw = net.n_layers - 1;
     const int q = lane >> 4, r16 = lane & 15;
@@ -192,17 +349,23 @@ __global__ __launch_bounds__(256) void node_rr_bwd_kernel(const NodeRkBwdLaunch 
     const int KSO = (grp == 0) ? KS0 : KS0 * nu;          // k-steps of the output layer's transposed product (<= 4)
     const bool keep_dz = L.dz[0] != nullptr;
 
+    // ---- what the stage loop reads of the launch descriptor, once
+    const float* const params = net.params;
+    const float* const acts = L.acts[grp] + w.soff;
+    float* const dz = keep_dz ? L.dz[grp] + w.soff : nullptr;
+    const long acts_ls = L.acts_ls[grp];
+    const int dx_stage0 = L.dx_stage0;
+
     // ---- weight stream: backward fragments of layers nw-1 .. 1, then nw-1 again (next stage)
     const __amdgpu_buffer_rsrc_t rs = rr_rsrc(net.packed, net.packed_floats);
     const int voff = lane * 16;
     const int wbase = net.rr_bwd_off * 4;
     RRGemm<S> gemm;
-    if (nw >= 2) gemm.prime(rs, voff, wbase + (nw - 2) * S::LAYER_BYTES);
+    gemm.prime(rs, voff, wbase + (nw - 2) * S::LAYER_BYTES);
 
-    // ---- constants in registers: W_out^T (A of the top product) and W_0^T (A of dX)
-    float wtop[4][NB];
-    {
-        const float* Wl = net.params + net.w_off[nw];
+    // ---- constants: W_out^T (A of the top product) to LDS in fragment order, W_0^T (A of dX) into registers
+    if (half == 0) {
+        const float* Wl = params + net.w_off[nw];
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
             int o = -1;
@@ -211,13 +374,13 @@ __global__ __launch_bounds__(256) void node_rr_bwd_kernel(const NodeRkBwdLaunch 
 #pragma unroll
             for (int jo = 0; jo < NB; ++jo) {
                 const int uo = rr_unit_out(NB, R, jo, r16);
-                wtop[e][jo] = (o >= 0 && uo >= 0) ? Wl[(long)o * HID + uo] : 0.f;
+                sWt[((grp * 4 + e) * 8 + jo) * 64 + lane] = (o >= 0 && uo >= 0) ? Wl[(long)o * HID + uo] : 0.f;
             }
         }
     }
     float w0t[KS];
     {
-        const float* W0 = net.params + net.w_off[0];
+        const float* W0 = params + net.w_off[0];
         const int c = 4 * (r16 & 3) + (r16 >> 2);          // A row 4 q' + r' computes dX component 4 r' + q'
         const bool ok = (r16 & 3) < KS0 && c < ns;
 #pragma unroll
@@ -250,60 +413,123 @@ __global__ __launch_bounds__(256) void node_rr_bwd_kernel(const NodeRkBwdLaunch 
         if (!data) continue;              // uniform: nothing below is needed for this stage
 
         const long srow = (long)st * n + growc;
-        float Z[KS];
-        f32x4 acc[NB];
-        // ---- top product: dz_top = mask_top * (W_out^T dy)
+        float Za[KS], Zb[KS];              // dz ping-pong between two register sets
+        f32x4 acct[NB], acc[NB], zero[NB];
 #pragma unroll
-        for (int jo = 0; jo < NB; ++jo) {
-            acc[jo] = f32x4{0.f, 0.f, 0.f, 0.f};
+        for (int jo = 0; jo < NB; ++jo) zero[jo] = f32x4{0.f, 0.f, 0.f, 0.f};
+        // ReLU masks of a layer's outputs for this lane's units: one word (mask mode) or the activations themselves,
+        // requested before the product they gate so that they land under it; `*t`: those of the pending tail / top product
+        unsigned mw = 0u, mwt = 0u;
+        f32x4 av[NB], avt[2];
+        auto fetch_masks = [&](int l) __attribute__((always_inline)) {
+            if (BITS) {        // (rows past the end contribute nothing: their word is cleared once)
+                mw = reinterpret_cast<const unsigned*>(acts + (long)l * acts_ls)[srow * 4 + q];
+                mw = row_ok ? mw : 0u;
+            }
+            else {
+                const float* arow = acts + (long)l * acts_ls + srow * HID;
+#pragma unroll
+                for (int jo = 0; jo < NB; ++jo) av[jo] = rr_row_load<S>(arow, jo, q);
+            }
+        };
+        auto save_block = [&](int l, int jo, const float (&Z)[KS]) __attribute__((always_inline)) {
+            if (BITS || !dz || !row_ok) return;
+            f32x4 zv{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int rr = 0; rr < ((jo < NB - 1) ? 4 : R); ++rr) zv[rr] = Z[4 * jo + rr];
+            rr_row_store<S>(dz + (long)l * acts_ls + ((long)st * n + grow) * HID, jo, q, zv);
+        };
+        // the top product's value ks (mask mode: finished just before the next product's k-step ks reads it)
+        auto pre_top = [&](int ks) __attribute__((always_inline)) {
+            const int jo = (ks < 4 * (NB - 1)) ? (ks >> 2) : NB - 1, r = ks - 4 * jo;
+            if (BITS) Za[ks] = rr_mask_gate<KS>(mwt, ks, acct[jo][r]);
+            else Za[ks] = (row_ok && av[jo][r] > 0.f) ? acct[jo][r] : 0.f;
+            if (r == ((jo < NB - 1) ? 3 : R - 1)) save_block(nw - 1, jo, Za);
+        };
+        // the tail (blocks TB, TB+1 of `acc`) of the product that produced dz of layer lp, finished inside the next one
+        auto pre_tail = [&](int lp, float (&Z)[KS], int t) __attribute__((always_inline)) {
+            if (t >= NT) return;
+            const int jo = TB + (t >> 2), r = t & 3;
+            if (BITS) Z[4 * TB + t] = rr_mask_gate<KS>(mwt, 4 * TB + t, acc[jo][r]);
+            else Z[4 * TB + t] = (row_ok && avt[jo - TB][r] > 0.f) ? acc[jo][r] : 0.f;
+            if (t == 3 || t == NT - 1) save_block(lp, jo, Z);
+        };
+
+        // ---- top product: dz_top = mask_top * (W_out^T dy)
+        fetch_masks(nw - 1);
+        {
+            float at[4][NB];
 #pragma unroll
             for (int e = 0; e < 4; ++e)
-                if (e < KSO) acc[jo] = __builtin_amdgcn_mfma_f32_16x16x4f32(wtop[e][jo], dy[e], acc[jo], 0, 0, 0);
-        }
-        for (int l = nw - 1; l >= 0; --l) {
-            if (l < nw - 1) {
-                // dz_l = mask_l * (W_{l+1}^T dz_{l+1})
-                const int cur = wbase + l * S::LAYER_BYTES;              // fragments of layer l + 1 sit at index l
-                const int nxt = (l >= 1) ? cur - S::LAYER_BYTES : wbase + (nw - 2) * S::LAYER_BYTES;
-                gemm.run(acc, Z, rs, voff, cur, nxt);
-            }
-            float* zrow = (keep_dz && !BITS) ? L.dz[grp] + w.soff + (long)l * L.acts_ls[grp] + ((long)st * n + grow) * HID : nullptr;
-            if (BITS) {
-                const unsigned word = reinterpret_cast<const unsigned*>(L.acts[grp] + w.soff + (long)l * L.acts_ls[grp])[srow * 4 + q];
 #pragma unroll
-                for (int jo = 0; jo < NB; ++jo)
-#pragma unroll
-                    for (int r = 0; r < ((jo < NB - 1) ? 4 : R); ++r)
-                        Z[4 * jo + r] = (row_ok && ((word >> (4 * jo + r)) & 1u)) ? acc[jo][r] : 0.f;
-            } else {
-                const float* arow = L.acts[grp] + w.soff + (long)l * L.acts_ls[grp] + srow * HID;
+                for (int jo = 0; jo < NB; ++jo) at[e][jo] = (e < 2 || KSO > 2) ? sWt[((grp * 4 + e) * 8 + jo) * 64 + lane] : 0.f;
+            if (KSO <= 2) {
 #pragma unroll
                 for (int jo = 0; jo < NB; ++jo) {
-                    const f32x4 a = rr_row_load<S>(arow, jo, q);
-                    f32x4 zv{0.f, 0.f, 0.f, 0.f};
+                    acct[jo] = __builtin_amdgcn_mfma_f32_16x16x4f32(at[0][jo], dy[0], f32x4{0.f, 0.f, 0.f, 0.f}, 0, 0, 0);
+                    acct[jo] = __builtin_amdgcn_mfma_f32_16x16x4f32(at[1][jo], dy[1], acct[jo], 0, 0, 0);
+                }
+            } else {
 #pragma unroll
-                    for (int r = 0; r < ((jo < NB - 1) ? 4 : R); ++r) {
-                        const float z = (row_ok && a[r] > 0.f) ? acc[jo][r] : 0.f;
-                        Z[4 * jo + r] = z;
-                        zv[r] = z;
-                    }
-                    if (zrow && row_ok) rr_row_store<S>(zrow, jo, q, zv);
+                for (int jo = 0; jo < NB; ++jo) {
+                    acct[jo] = __builtin_amdgcn_mfma_f32_16x16x4f32(at[0][jo], dy[0], f32x4{0.f, 0.f, 0.f, 0.f}, 0, 0, 0);
+                    acct[jo] = __builtin_amdgcn_mfma_f32_16x16x4f32(at[1][jo], dy[1], acct[jo], 0, 0, 0);
+                    acct[jo] = __builtin_amdgcn_mfma_f32_16x16x4f32(at[2][jo], dy[2], acct[jo], 0, 0, 0);
+                    acct[jo] = __builtin_amdgcn_mfma_f32_16x16x4f32(at[3][jo], dy[3], acct[jo], 0, 0, 0);
                 }
             }
         }
-        if (st == 0 && !L.dx_stage0) continue;       // only the dz of stage 0 were wanted
-
-        // ---- dX = W_0^T dz_0 (one block), then the stage algebra
-        {
-            f32x4 o{0.f, 0.f, 0.f, 0.f};
+#ifdef RR_BWD_NO_DEFER_TOP
+        constexpr bool defer_top = false;
+        mwt = mw;
+#else
+        constexpr bool defer_top = BITS != 0;
+#endif
+        if (!defer_top) {       // (activation mode keeps one set of mask registers: the top product is finished at once)
 #pragma unroll
-            for (int ks = 0; ks < KS; ++ks) o = __builtin_amdgcn_mfma_f32_16x16x4f32(w0t[ks], Z[ks], o, 0, 0, 0);
-#pragma unroll
-            for (int r = 0; r < 2; ++r) {
-                const int c = 4 * r + q;
-                if (r < KS0 && c < ns) T.sDX[(grp * NLBAC_MLP_TILE + m) * RK_MAX_NS + c] = o[r];
-            }
+            for (int ks = 0; ks < KS; ++ks) pre_top(ks);
         }
+        // ---- dz_{nw-1-p} = mask * (W_{nw-p}^T dz_{nw-p}), p = 1 .. nw-1, then dX = W_0^T dz_0 (one block); statically
+        //      unrolled (pc: the product index as a type): a product reads one dz set and writes the other
+        auto prod = [&](auto pc, float (&Zin)[KS], float (&Zout)[KS]) __attribute__((always_inline)) {
+            constexpr int p = decltype(pc)::value;
+            const int lo = nw - 1 - p;                            // the layer whose dz this product yields
+            mwt = mw; avt[0] = av[TB]; avt[1] = av[TB + 1];
+            fetch_masks(lo);
+            __builtin_amdgcn_sched_barrier(0);
+            const int cur = wbase + lo * S::LAYER_BYTES;              // fragments of layer lo + 1 sit at index lo
+            const int nxt = (lo >= 1) ? cur - S::LAYER_BYTES : wbase + (nw - 2) * S::LAYER_BYTES;
+            gemm.run(acc, zero, Zin, rs, voff, cur, nxt,
+                     [&](int ks) __attribute__((always_inline)) {
+                         if (p == 1) { if (defer_top) pre_top(ks); }
+                         else pre_tail(lo + 1, Zin, ks);
+                     },
+                     [&](int jo, int r) __attribute__((always_inline)) {
+                         if (BITS) Zout[4 * jo + r] = rr_mask_gate<KS>(mw, 4 * jo + r, acc[jo][r]);
+                         else Zout[4 * jo + r] = (row_ok && av[jo][r] > 0.f) ? acc[jo][r] : 0.f;
+                         if (r == 3) save_block(lo, jo, Zout);
+                     },
+                     [&]() __attribute__((always_inline)) {});
+        };
+        const bool skip_dx = (st == 0 && !dx_stage0);       // only the dz of stage 0 were wanted
+        auto dxl = [&](float (&Zin)[KS]) __attribute__((always_inline)) {
+            mwt = mw; avt[0] = av[TB]; avt[1] = av[TB + 1];
+            const f32x4 o = RRGemm<S>::block(w0t, Zin, [&](int ks) __attribute__((always_inline)) { pre_tail(0, Zin, ks); });
+            if (!skip_dx) {
+#pragma unroll
+                for (int r = 0; r < 2; ++r) {
+                    const int c = 4 * r + q;
+                    if (r < KS0 && c < ns) T.sDX[(grp * NLBAC_MLP_TILE + m) * RK_MAX_NS + c] = o[r];
+                }
+            }
+        };
+        using I1 = std::integral_constant<int, 1>; using I2 = std::integral_constant<int, 2>;
+        using I3 = std::integral_constant<int, 3>;
+        prod(I1{}, Za, Zb);                                   // (f_net: three hid x hid layers, g_net: two — see the forward)
+        prod(I2{}, Zb, Za);
+        if (grp == 0) { prod(I3{}, Za, Zb); dxl(Zb); }
+        else dxl(Za);
+        if (skip_dx) continue;
         __syncthreads();
         rk_bwd_stage_algebra<256>(L, w, T, row0, st, tid);
         __syncthreads();
@@ -329,7 +555,7 @@ static int rr_shape_index(int hid) { return hid == 64 ? 0 : (hid == 100 ? 1 : (h
 bool nlbac_node_rr_eligible(const nlbac_mlp* f, const nlbac_mlp* g) {
     if (!rr_enabled() || !f || !g) return false;
     if (f->hid != g->hid || rr_shape_index(f->hid) < 0) return false;
-    if (f->n_layers < 3 || g->n_layers < 3) return false;
+    if (f->n_layers != 5 || g->n_layers != 4) return false;      // the layer chains are unrolled for the reference's depths
     if (f->rr_fwd_off < 0 || g->rr_fwd_off < 0 || f->rr_bwd_off < 0 || g->rr_bwd_off < 0) return false;
     const int ns = f->in_dim, nu = g->out_dim / (ns > 0 ? ns : 1);
     if (ns < 1 || ns > RK_MAX_NS || nu < 1 || nu > RK_MAX_NU) return false;
@@ -350,7 +576,7 @@ int nlbac_node_rr_fwd_launch(NodeRkLaunch& L, hipStream_t s) {
     static const KernelF kf[3][2] = {{node_rr_fwd_kernel<4, 4, 0>, node_rr_fwd_kernel<4, 4, 1>},
                                      {node_rr_fwd_kernel<7, 1, 0>, node_rr_fwd_kernel<7, 1, 1>},
                                      {node_rr_fwd_kernel<8, 4, 0>, node_rr_fwd_kernel<8, 4, 1>}};
-    const size_t lds = (size_t)(RkFwdTile::floats() + NLBAC_MLP_TILE * 8) * sizeof(float);
+    const size_t lds = (size_t)(RkFwdTile::floats() + NLBAC_MLP_TILE * 8 + 2 * 3 * 8 * 64) * sizeof(float);
     const dim3 grid(nlbac_ceil_div(L.n, NLBAC_MLP_TILE));
     hipLaunchKernelGGL(kf[rr_shape_index(L.net[0].hid)][L.acts_bits ? 1 : 0], grid, dim3(256), lds, s, L);
     NLBAC_CHECK_LAUNCH("nlbac_node_rk_fwd(rr)");
@@ -363,7 +589,7 @@ int nlbac_node_rr_bwd_launch(NodeRkBwdLaunch& L, hipStream_t s) {
     static const KernelB kb[3][2] = {{node_rr_bwd_kernel<4, 4, 0>, node_rr_bwd_kernel<4, 4, 1>},
                                      {node_rr_bwd_kernel<7, 1, 0>, node_rr_bwd_kernel<7, 1, 1>},
                                      {node_rr_bwd_kernel<8, 4, 0>, node_rr_bwd_kernel<8, 4, 1>}};
-    const size_t lds = (size_t)RkBwdTile::floats() * sizeof(float);
+    const size_t lds = (size_t)(RkBwdTile::floats() + 2 * 4 * 8 * 64) * sizeof(float);
     const dim3 grid(nlbac_ceil_div(L.n, NLBAC_MLP_TILE));
     hipLaunchKernelGGL(kb[rr_shape_index(L.net[0].hid)][L.acts_bits ? 1 : 0], grid, dim3(256), lds, s, L);
     NLBAC_CHECK_LAUNCH("nlbac_node_rk_bwd(rr)");

@@ -27,8 +27,11 @@ typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
 
 #define RR_MAX_HID 128
 
+#ifndef RR_DEPTH_MAX
+#define RR_DEPTH_MAX 8       /* tools/micro/rr_chain.hip: 4 float4 in flight stream as fast as 11 or 22 */
+#endif
 __host__ __device__ constexpr int rr_pick_depth(int nv) {
-    for (int d = 12; d >= 4; --d)
+    for (int d = RR_DEPTH_MAX; d >= 4; --d)
         if (nv % d == 0) return d;
     return 1;
 }
@@ -58,16 +61,15 @@ __host__ __device__ __forceinline__ int rr_unit_out(int NB, int R, int jo, int h
     const int q = hu >> 2, r = hu & 3;
     return r < R ? 16 * (NB - 1) + R * q + r : -1;
 }
-// MFMA issue order of a layer: output blocks in groups of two (the last group has three when NB is odd), k-steps inner,
-// so two / three independent accumulator chains alternate (v_mfma_f32_16x16x4_f32: 32 cycles issue, 40 dependent)
+// MFMA issue order of a layer: output blocks in groups — the first of three blocks when NB is odd, pairs otherwise —
+// k-steps inner, so two / three independent accumulator chains alternate (v_mfma_f32_16x16x4_f32: 32 cycles issue, 40
+// dependent) and a finished group's bias / ReLU can be issued between the next group's MFMAs
+__host__ __device__ __forceinline__ constexpr int rr_group_first(int NB) { return (NB & 1) ? 3 : 2; }
 __host__ __device__ __forceinline__ void rr_mfma_of(int NB, int KS, int m, int& jo, int& ks) {
-    int g0 = 0;
-    for (;;) {
-        const int left = NB - g0, gn = (left == 3) ? 3 : (left < 2 ? left : 2);
-        if (m < gn * KS || left <= gn) { ks = m / gn; jo = g0 + m % gn; return; }
-        m -= gn * KS;
-        g0 += gn;
-    }
+    int g0 = 0, gn = rr_group_first(NB);
+    while (m >= gn * KS) { m -= gn * KS; g0 += gn; gn = 2; }
+    ks = m / gn;
+    jo = g0 + m % gn;
 }
 __host__ __device__ __forceinline__ bool rr_width_ok(int hid) { return hid % 4 == 0 && hid >= 20 && hid <= RR_MAX_HID; }
 // floats of one layer's RR pack
@@ -83,11 +85,47 @@ __device__ __forceinline__ __amdgpu_buffer_rsrc_t rr_rsrc(const float* base, int
     return __builtin_amdgcn_make_buffer_rsrc((void*)base, 0, floats * 4, 0x00020000);
 }
 
+// One mask bit shifted into a lane's word: word = (word << 1) | (h > 0) for a ReLU output h (a non-negative float: its
+// bit pattern is a non-negative integer, zero only for +0; the sign of its negation is the bit).  Two VALU instructions
+// (v_sub_u32, v_alignbit_b32).  After the KS values of a layer have been shifted in — in ascending order of their
+// register index k — value k's bit sits at position KS-1-k (rr_mask_on).
+__device__ __forceinline__ void rr_mask_push(unsigned& word, float h) {
+    const unsigned neg = 0u - __builtin_bit_cast(unsigned, h);
+    word = __builtin_amdgcn_alignbit(word, neg, 31);
+}
+// value k of a layer's KS gated by its mask word: v_bfe_i32 (all-ones / zero) + v_and_b32.  (x by value: clang's
+// __builtin_bit_cast applied directly to a vector-element lvalue reads element 0.)
+template <int KS>
+__device__ __forceinline__ float rr_mask_gate(unsigned word, int k, float x) {
+    const unsigned on = (unsigned)(((int)(word << (31 - (KS - 1 - k)))) >> 31);
+    return __builtin_bit_cast(float, __builtin_bit_cast(unsigned, x) & on);
+}
+
 // ReLU as an integer max: negative floats (and -0) are negative integers; one VALU op, no NaN canonicalisation
 __device__ __forceinline__ float rr_relu(float v) {
     const int i = __builtin_bit_cast(int, v);
     return __builtin_bit_cast(float, i > 0 ? i : 0);
 }
+
+// Empty volatile asm statements that "use and redefine" a value: volatile asms keep their program order among
+// themselves, so whatever produces the value stays before the statement and whatever consumes it after it.
+#ifdef RR_NO_PIN_S
+#define RR_PIN_S(x_)
+#else
+#define RR_PIN_S(x_) asm volatile("" : "+s"(x_));
+#endif
+#ifdef RR_ACC_VGPR          /* built with -mllvm -amdgpu-mfma-vgpr-form: accumulators live in the VGPR half */
+#define RR_ACC_C(x_) "+v"(x_)
+#else
+#define RR_ACC_C(x_) "+a"(x_)
+#endif
+#ifdef RR_NO_PIN_A
+#define RR_PIN_A2(a_, b_)
+#define RR_PIN_A3(a_, b_, c_)
+#else
+#define RR_PIN_A2(a_, b_) asm volatile("" : RR_ACC_C(a_), RR_ACC_C(b_));
+#define RR_PIN_A3(a_, b_, c_) asm volatile("" : RR_ACC_C(a_), RR_ACC_C(b_), RR_ACC_C(c_));
+#endif
 
 // ---------------------------------------------------------------------------------------------------------------------
 // One wave's hid x hid layer on its 16 rows:  acc[jo] (+)= sum_ks A(jo, ks) * H[ks]
@@ -102,19 +140,40 @@ struct RRGemm {
         for (int i = 0; i < S::D; ++i) wq[i] = rr_ldw(rs, voff, soff + i * 1024);
     }
 
-    // cur / nxt: byte offsets of this layer's fragments and of the layer that follows it in the wave's stream
-    __device__ __forceinline__ void run(f32x4 (&acc)[S::NB], const float (&H)[S::KS], __amdgpu_buffer_rsrc_t rs, int voff,
-                                        int cur, int nxt) {
+    // cur / nxt: byte offsets of this layer's fragments and of the layer that follows it in the wave's stream.
+    // Nothing but the MFMA stream is exposed: the per-value work around a product (bias, ReLU / mask, saving what the
+    // backward needs: ~6 VALU instructions per value) is issued between MFMAs, in gaps the matrix pipe leaves free —
+    //   pre(ks)     in the first group, before k-step ks reads H[ks]: finishes what the PREVIOUS product left pending
+    //               (its last group of blocks, or all of a short product's outputs), just in time;
+    //   fin(jo, r)  accumulator register r of output block jo, for every group but the last, one value per k-step of the
+    //               group that follows;
+    //   mid()       once, before the last group starts (prefetches for the next product);
+    // the last group's accumulators (blocks NB-2, NB-1) are left as they are for the next product's `pre`.
+    // Every one of those VALU instructions costs matrix-pipe time: v_mfma_f32_16x16x4_f32 runs at the f32 VECTOR rate —
+    // on the same FMA lanes — so a VALU instruction between two MFMAs is not hidden, it takes its ~4-5 cycles from the
+    // product (measured: 3 extra instructions per value = +800 cycles on a 5.6k-cycle layer).  Hence: accumulators in
+    // the VGPR half (no v_accvgpr_read), the bias as the first MFMA's C operand (no add), one integer max for the ReLU,
+    // two instructions for a mask bit.
+    template <class PRE, class FIN, class MID>
+    __device__ __forceinline__ void run(f32x4 (&acc)[S::NB], const f32x4 (&cinit)[S::NB], float (&H)[S::KS],
+                                        __amdgpu_buffer_rsrc_t rs, int voff, int cur, int nxt, PRE&& pre, FIN&& fin, MID&& mid) {
         constexpr int NB = S::NB, KS = S::KS, NM = S::NM, NV = S::NV, D = S::D;
-#pragma unroll
-        for (int j = 0; j < NB; ++j) acc[j] = f32x4{0.f, 0.f, 0.f, 0.f};
+        static_assert(KS >= 12 && NB >= 4, "a group's epilogue (<= 12 values) is spread over the next group's k-steps");
+        // (opaque to the optimiser: otherwise every load's scalar offset is hoisted out of the caller's stage loop as
+        // a loop invariant of its own — hundreds of live SGPRs, spilled — instead of one s_add next to the load)
+        asm volatile("" : "+s"(cur), "+s"(nxt));
         int m = 0;
 #pragma unroll
         for (int g0 = 0; g0 < NB;) {
-            constexpr int dummy = 0; (void)dummy;
-            const int left = NB - g0, gn = (left == 3) ? 3 : (left < 2 ? left : 2);
+            const int gn = (g0 == 0) ? rr_group_first(NB) : 2;
+            const int pn = (g0 == 0) ? 0 : ((g0 == rr_group_first(NB)) ? rr_group_first(NB) : 2), p0 = g0 - pn;   // previous group
+            if (g0 + gn == NB) mid();
+#pragma unroll
+            for (int jj = 0; jj < 3; ++jj)
+                if (jj < gn) acc[g0 + jj] = cinit[g0 + jj];          // (the first MFMA's C operand: the layer's bias, or zero)
 #pragma unroll
             for (int ks = 0; ks < KS; ++ks) {
+                if (g0 == 0) pre(ks);
 #pragma unroll
                 for (int jj = 0; jj < 3; ++jj) {
                     if (jj < gn) {
@@ -122,15 +181,36 @@ struct RRGemm {
                         acc[g0 + jj] = __builtin_amdgcn_mfma_f32_16x16x4f32(wq[v % D][c], H[ks], acc[g0 + jj], 0, 0, 0);
                         if (c == 3 || m == NM - 1) {          // slot v % D is free: refill with stream element v + D
                             const int vn = v + D;
-                            wq[v % D] = (vn < NV) ? rr_ldw(rs, voff, cur + vn * 1024) : rr_ldw(rs, voff, nxt + (vn - NV) * 1024);
+                            int so = (vn < NV) ? cur + vn * 1024 : nxt + (vn - NV) * 1024;
+                            RR_PIN_S(so)                         // (the load stays behind its slot's MFMAs: see RR_PIN_*)
+                            wq[v % D] = rr_ldw(rs, voff, so);
                             __builtin_amdgcn_sched_barrier(0);   // keep each refill right behind its slot's MFMAs
                         }
                         ++m;
                     }
                 }
+                // program-order anchors: MFMAs are pure to the optimiser, which otherwise sinks whole k-steps of them
+                // past the refills and the interleaved per-value work (19 loads in flight, 247 VGPRs)
+                if (gn == 3) { RR_PIN_A3(acc[g0], acc[g0 + 1], acc[g0 + 2]) } else { RR_PIN_A2(acc[g0], acc[g0 + 1]) }
+                if (ks < 4 * pn) fin(p0 + (ks >> 2), ks & 3);
             }
             g0 += gn;
         }
+    }
+
+    // a single-block product o = sum_ks a[ks] * H[ks] (output layers: <= 16 outputs) on two accumulator chains — one chain
+    // would run at the instruction's 40-cycle dependent latency instead of its 32-cycle issue rate —, with the same
+    // just-in-time `pre`
+    template <class PRE>
+    __device__ __forceinline__ static f32x4 block(const float (&a)[S::KS], float (&H)[S::KS], PRE&& pre) {
+        f32x4 o0{0.f, 0.f, 0.f, 0.f}, o1{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int ks = 0; ks < S::KS; ++ks) {
+            pre(ks);
+            if (ks & 1) o1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a[ks], H[ks], o1, 0, 0, 0);
+            else o0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a[ks], H[ks], o0, 0, 0, 0);
+        }
+        return o0 + o1;
     }
 };
 

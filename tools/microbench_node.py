@@ -13,6 +13,7 @@ n = int(sys.argv[1]) if len(sys.argv) > 1 else 8192
 y0 = (torch.rand(n, 3) * 4 - 2).cuda()
 u = (torch.rand(n, 2) * 2 - 1).cuda()
 sol = AffineNodeSolver(node, "cuda")
+sol.ctx = {}
 ws = sol._step_ws(n, 7, 0)
 ctl = sol._ctl(2)
 ctl[:, 0] = 0.02
