@@ -1110,6 +1110,11 @@ class AffineNodeSolver:
         bwd_weights(self._nets(), io, 2, n, self.ADJ_SUB_SLABS, par["NP"], self.device)
         _lib.call("nlbac_reduce_slabs", par["K"][st].data_ptr(), par["slabs"].data_ptr(), self.ADJ_SUB_SLABS,
                   par["NP"], par["NP"], stream_ptr())
+        if self.comm is not None and self.comm.world > 1:
+            # sample-sharded solve: the parameter adjoint is a sum over ALL rows, and its norm takes part in the step
+            # control — every rank must form it from the same (global) stage derivative, or the ranks' accept / done
+            # decisions part ways and their collectives no longer pair up
+            self.comm.all_reduce_(par["K"][st])
 
     def _adj_params_norm(self, par, mode, cp, h_host=None, c_sol=None):
         ctx = self.ctx
@@ -1255,7 +1260,10 @@ class AffineNodeSolver:
         s = stream_ptr()
         if self.adjoint:       # the adjoint solve has integrated the parameter adjoint already: one finished vector
             par = ctx["adj_par"]
-            _lib.call("nlbac_axpby", 1.0, par["grad"].data_ptr(), 0.0, None, arena.n, arena.grad.data_ptr(), s)
+            # (under data parallelism the stage derivatives were summed over the ranks already: every rank holds the
+            # global vector and hands 1 / world of it to the gradient all-reduce that follows)
+            world = self.comm.world if self.comm is not None else 1
+            _lib.call("nlbac_axpby", 1.0 / world, par["grad"].data_ptr(), 0.0, None, arena.n, arena.grad.data_ptr(), s)
             return 1
         n_used = 0
         for si, step in enumerate(ctx["steps"]):

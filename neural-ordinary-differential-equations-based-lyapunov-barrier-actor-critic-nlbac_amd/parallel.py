@@ -16,16 +16,18 @@ import torch
 
 
 class DataParallel:
-    def __init__(self, dist, group=None):
+    def __init__(self, dist, group=None, always_collective=False):
         self.dist, self.group = dist, group
         self.world = dist.get_world_size(group)
         self.rank = dist.get_rank(group)
         self.backend = dist.get_backend(group)
+        # True: issue the collective even in a one-rank group (tests: the RCCL code path on a single GPU)
+        self.always_collective = always_collective
 
     def all_reduce_(self, t):
         """In-place SUM over ranks.  gloo cannot reduce device tensors here: stage through the host
         (used by the CPU / single-GPU rehearsal tests only)."""
-        if self.world == 1:
+        if self.world == 1 and not self.always_collective:
             return t
         if t.is_cuda and self.backend == "gloo":
             h = t.detach().cpu()
@@ -36,7 +38,7 @@ class DataParallel:
         return t
 
     def broadcast_(self, t, src=0):
-        if self.world == 1:
+        if self.world == 1 and not self.always_collective:
             return t
         if t.is_cuda and self.backend == "gloo":
             h = t.detach().cpu()

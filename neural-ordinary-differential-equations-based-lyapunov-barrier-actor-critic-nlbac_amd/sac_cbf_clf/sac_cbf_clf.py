@@ -278,12 +278,12 @@ class SAC_CBF_CLF(object):
         return self.task.fit_solver
 
     # ------------------------------------------------------------ data parallel
-    def enable_data_parallel(self, dist, group=None):
+    def enable_data_parallel(self, dist, group=None, always_collective=False):
         """Shard minibatches over the ranks of ``dist`` (one process per GPU).  Every rank then passes its
         own rows to ``update_*``; losses are normalised by the global batch (``args.batch_size`` must be
         the global size) and gradients / constraint sums are all-reduced (nlbac_amd/parallel.py)."""
         from ..parallel import DataParallel
-        self.dp = DataParallel(dist, group)
+        self.dp = DataParallel(dist, group, always_collective)
         for ar in self.arenas:
             self.dp.broadcast_(ar.theta)
         self.ar_c.hard_update_target()

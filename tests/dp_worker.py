@@ -80,18 +80,67 @@ def run_cuda(dp, out, solver, env_name="Unicycle"):
     np.savez(out, **res)
 
 
+def oracle_case_inputs(env_name, agent, env, B, ci, updates, tr):
+    """The minibatch / noise / NODE rows of update ``ci`` of the oracle-checked cases (the pattern of
+    test_adjoint_gpu.test_update_with_adjoint_matches_the_oracle), identical in the workers and in the parent."""
+    rs = np.random.RandomState(ci)
+    idx, nidx = rs.choice(4096, B, replace=False), rs.choice(4096, 512, replace=False)
+    fields = synth.fields(env_name)
+    batch = {f: torch.tensor(tr[f][idx], dtype=torch.float32) for f in fields}
+    eps = [torch.from_numpy(e) for e in synth.normal_eps(agent.task.n_eps if agent is not None else 3, B, env.n_u, seed=ci)]
+    node = tuple(torch.tensor(tr[f][nidx], dtype=torch.float32) for f in ("obs", "action", "next_obs"))
+    return batch, eps, node
+
+
+ORACLE_CASE = dict(B=128, hidden=64, seed=0, updates=(0, 1, 20),
+                   gamma_b={"Pvtol": 0.8, "Unicycle": 50.0, "PvtolBarrier": 0.8, "QuadrotorLike": 1.0})
+
+
+def run_cuda_oracle_case(dp, out, solver, env_name, adjoint):
+    """Row shards of the oracle-checked updates (no reference fixture exists for them: the parent holds the results
+    against the single-device oracle): returned floats and post-update parameters."""
+    from test_agent_parity_gpu import make_agent
+    c = ORACLE_CASE
+    B = c["B"]
+    torch.cuda.set_device(0)
+    agent, env = make_agent(B, c["hidden"], c["seed"], solver, env_name, c["gamma_b"][env_name])
+    agent.adjoint = bool(adjoint)
+    agent.enable_data_parallel(dist)
+    tr = synth.transitions(env_name, 4096, seed=c["seed"] + 1, env=env)
+    fields = synth.fields(env_name)
+    res = {"n_eps": np.array(agent.task.n_eps)}
+    for ci, updates in enumerate(c["updates"]):
+        batch, eps, node = oracle_case_inputs(env_name, agent, env, B, ci, updates, tr)
+        lo, hi = dp.shard(B)
+        nlo, nhi = dp.shard(node[0].shape[0])
+        agent.set_noise([e[lo:hi] for e in eps])
+        host = tuple(batch[f][lo:hi].numpy() for f in fields)
+        node_np = tuple(t[nlo:nhi].numpy() for t in node) if updates % 10 == 0 else None
+        ret = agent.update_from_host(host, updates, node_np)
+        torch.cuda.synchronize()
+        p = "c%d_" % ci
+        res[p + "ret"] = np.array(ret)
+        for name, mod in (("critic", agent.critic), ("policy", agent.policy), ("node", agent.neural_ode_model)):
+            res[p + "p_" + name] = torch.cat([q.detach().reshape(-1) for q in mod.parameters()]).cpu().numpy()
+    np.savez(out, **res)
+
+
 if __name__ == "__main__":
     ap = argparse.ArgumentParser()
     ap.add_argument("--device", default="cpu")
     ap.add_argument("--out", required=True)
     ap.add_argument("--solver", default="euler")
     ap.add_argument("--env", default="Unicycle")
+    ap.add_argument("--oracle-case", action="store_true", help="the oracle-checked update pattern instead of a golden fixture's")
+    ap.add_argument("--adjoint", action="store_true")
     a = ap.parse_args()
     dist.init_process_group("gloo")
     dp = DataParallel(dist)
     out = "%s.rank%d.npz" % (a.out, dp.rank)
     if a.device == "cpu":
         run_cpu(dp, out)
+    elif a.oracle_case:
+        run_cuda_oracle_case(dp, out, a.solver, a.env, a.adjoint)
     else:
         run_cuda(dp, out, a.solver, a.env)
     dist.barrier()

@@ -94,3 +94,63 @@ def test_two_rank_sharded_update_matches_single_device_reference(tmp_path, env_n
     a, b = np.load(out + ".rank0.npz"), np.load(out + ".rank1.npz")
     for k in a.files:                                            # replicas stay bit-identical
         np.testing.assert_array_equal(a[k], b[k])
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("env_name,solver,adjoint", [("Pvtol", "dopri5", True), ("QuadrotorLike", "dopri5", False)],
+                         ids=["Pvtol-dopri5-adjoint", "QuadrotorLike-dopri5"])
+def test_two_rank_sharded_update_matches_single_device_oracle(tmp_path, env_name, solver, adjoint):
+    """BASELINE configs[3] (Pvtol, dopri5, adjoint backward: the adjoint's state / adjoint-state norms AND the parameter
+    adjoint's stage derivatives are all-reduced so that every rank takes the same step decisions) and configs[4]
+    (Quadrotor-like single-net NODE + learned barrier) on two ranks that share the test box's GPU, each with half of
+    the rows, against the single-device ORACLE on the whole batch (no reference fixture exists for either)."""
+    from oracle import nlbac_oracle as O
+    from dp_worker import ORACLE_CASE, oracle_case_inputs
+    from test_agent_parity_gpu import params_close
+    from nlbac_amd.envspec import make_env
+    out = str(tmp_path / "dporacle")
+    launch(2, ["--device", "cuda", "--out", out, "--solver", solver, "--env", env_name, "--oracle-case"]
+           + (["--adjoint"] if adjoint else []), timeout=900)
+    c = ORACLE_CASE
+    B, seed = c["B"], c["seed"]
+    torch.set_num_threads(4)
+    oargs = O.Args(batch_size=B, hidden_size=c["hidden"], seed=seed)
+    oargs.gamma_b = c["gamma_b"][env_name]
+    env = synth.fixture_env(env_name, seed)
+    kw = dict(adjoint=True) if adjoint else {}
+    oracle = O.make_oracle(env, oargs, synth.agent_weights(env_name, c["hidden"], seed), solver=solver, **kw)
+    tr = synth.transitions(env_name, 4096, seed=seed + 1, env=env)
+    res = [np.load(out + ".rank%d.npz" % r) for r in range(2)]
+
+    class _Eps:                      # (oracle_case_inputs only needs the number of noise draws of the task)
+        class task:
+            n_eps = int(res[0]["n_eps"])
+    lr = dict(critic=4e-4, policy=3e-4, node=1e-3)
+    for ci, updates in enumerate(c["updates"]):
+        batch, eps, node = oracle_case_inputs(env_name, _Eps, env, B, ci, updates, tr)
+        R = oracle.update(batch, eps, updates, node_batch=node if updates % 10 == 0 else None)
+        for r in range(2):
+            vec_close(res[r]["c%d_ret" % ci], R["ret"], 1e-4, "rank %d ret (update %d)" % (r, updates))
+            for name, osd in (("critic", oracle.critic), ("policy", oracle.policy), ("node", oracle.node)):
+                ov = torch.cat([osd[k].detach().reshape(-1) for k in osd])
+                params_close(res[r]["c%d_p_%s" % (ci, name)], ov, lr[name] * (ci + 1), "rank %d params %s (update %d)" % (r, name, updates))
+    for k in res[0].files:                                            # replicas stay bit-identical
+        np.testing.assert_array_equal(res[0][k], res[1][k])
+
+
+@pytest.mark.gpu
+def test_rccl_branch_of_the_exchange_layer_runs_on_one_gpu():
+    """``nccl`` (RCCL) initialised in a fresh process before any other GPU call, world size 1, the exchange layer's
+    one-rank short-cut switched off: device tensors go through ``all_reduce_`` / ``broadcast_`` on the RCCL branch (the
+    gloo tests stage through the host), and an agent in data-parallel mode broadcasts its arenas over it."""
+    import socket
+    import subprocess
+    import sys
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0", MASTER_ADDR="127.0.0.1")
+    r = subprocess.run([sys.executable, os.path.join(os.path.dirname(os.path.abspath(__file__)), "nccl_worker.py"), str(port)],
+                       capture_output=True, text=True, timeout=600, env=env)
+    assert r.returncode == 0 and "NCCL_OK" in r.stdout, (r.stdout[-2000:], r.stderr[-3000:])
