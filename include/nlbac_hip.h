@@ -71,6 +71,9 @@ typedef struct nlbac_mlp {
     int pf_off[NLBAC_MAX_LAYERS];
     int pb_off[NLBAC_MAX_LAYERS];
     int rr_fwd_off, rr_bwd_off, packed_floats;
+    int rr_kind;   /* 0 none; 1 "chain" packs (above); 2 "panel" packs: nets with ONE hid x hid layer (n_layers == 3) and
+                      hid % 32 == 0 get that layer as two panels of hid / 32 output blocks each (hid * hid floats per
+                      direction), streamed by the register-resident actor / critic kernels (csrc/mlp_rr_kernels.hip) */
 } nlbac_mlp;
 
 /* Per-launch tensors of one net.  Unused pointers are NULL. */

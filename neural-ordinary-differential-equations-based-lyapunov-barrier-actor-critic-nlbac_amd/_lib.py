@@ -30,7 +30,7 @@ class Mlp(C.Structure):
                 ("w_off", C.c_int * MAX_LAYERS), ("b_off", C.c_int * MAX_LAYERS),
                 ("packed", C.c_void_p),
                 ("pf_off", C.c_int * MAX_LAYERS), ("pb_off", C.c_int * MAX_LAYERS),
-                ("rr_fwd_off", C.c_int), ("rr_bwd_off", C.c_int), ("packed_floats", C.c_int)]
+                ("rr_fwd_off", C.c_int), ("rr_bwd_off", C.c_int), ("packed_floats", C.c_int), ("rr_kind", C.c_int)]
 
 
 class MlpIO(C.Structure):

@@ -25,16 +25,8 @@
 #include "mlp_device.h"
 #include "rr_device.h"
 #include "dy_heads.h"
+#include "mlp_launch.h"
 
-struct MlpLaunch {
-    nlbac_mlp net[NLBAC_MAX_NETS];
-    nlbac_mlp_io io[NLBAC_MAX_NETS];
-    int B;
-    int ld;          // LDS row stride in floats
-    int n_slabs;     // bwd_weights only
-    int rows_per_slab;
-    long slab_stride;
-};
 
 // ---------------------------------------------------------------------------
 // weight packing
@@ -77,7 +69,41 @@ __global__ __launch_bounds__(256) void mlp_pack_kernel(const MlpLaunch L) {
     }
     // RR packs (rr_device.h) of the hid x hid layers 1 .. nwide-1: float4 v of lane `lane` = the A-fragment values of
     // MFMAs 4v .. 4v+3 in the chains' issue order; forward W[unit out][unit in], backward its transpose
-    if (net.rr_fwd_off >= 0) {
+    if (net.rr_kind == RR_KIND_PANEL) {
+        // the one hid x hid layer as two panels (RRPanel): panel ch holds output blocks ch*NBH .. ch*NBH + NBH-1 in groups
+        // of two, k-steps inner; float4 v of lane `lane` = the A-fragment values of MFMAs 4v .. 4v+3
+        const int NBH = hid >> 5, KS = hid >> 2;
+        const float* W = net.params + net.w_off[1];
+        float* Pf = net.packed + net.rr_fwd_off;
+        float* Pb = net.packed + net.rr_bwd_off;
+        const long total = (long)hid * hid, per_panel = total >> 1;
+        for (long i = gid; i < total; i += stride) {
+            const int ch = (int)(i / per_panel);
+            const long ip = i - (long)ch * per_panel;
+            const int c = ip & 3, lane = (ip >> 2) & 63, v = (int)(ip >> 8), m = 4 * v + c;
+            const int g = m / (2 * KS), rem = m - g * 2 * KS, ks = rem >> 1, jj = rem & 1;
+            const int uo = 16 * (NBH * ch + 2 * g + jj) + (lane & 15), ui = 16 * (ks >> 2) + 4 * (lane >> 4) + (ks & 3);
+            Pf[i] = W[(long)uo * hid + ui];
+            Pb[i] = W[(long)ui * hid + uo];
+        }
+        // layer 0 as A fragments of [W_0 | b_0] over k-steps of [x | 1]: float4 ((k0 * NBA/4 + jo/4) * 64 + lane) holds
+        // the values of output blocks jo .. jo+3 for k-step k0 (row = lane & 15 of the block, column 4 k0 + (lane >> 4))
+        {
+            const int NBA = hid >> 4, idim = net.in_dim;
+            const float* W0 = net.params + net.w_off[0];
+            const float* b0 = net.params + net.b_off[0];
+            float* P0 = net.packed + net.rr_bwd_off + (long)hid * hid;
+            const long n0 = rr_panel_l0_floats(hid);
+            for (long i = gid; i < n0; i += stride) {
+                const int c = i & 3, lane = (i >> 2) & 63;
+                const long t = i >> 8;
+                const int j4 = (int)(t % (NBA >> 2)), k0 = (int)(t / (NBA >> 2));
+                const int uo = 16 * (4 * j4 + c) + (lane & 15), col = 4 * k0 + (lane >> 4);
+                P0[i] = (col < idim) ? W0[(long)uo * idim + col] : (col == idim ? b0[uo] : 0.f);
+            }
+        }
+    }
+    if (net.rr_kind == RR_KIND_CHAIN) {
         const int NB = (hid + 15) >> 4, R = (hid - 16 * (NB - 1)) >> 2, KS = hid >> 2, NM = NB * KS;
         const long per_layer = rr_layer_floats(hid);
         for (int l = 1; l < nwide; ++l) {
@@ -826,11 +852,18 @@ extern "C" int nlbac_mlp_pack_layout(nlbac_mlp* net) {
         }
     }
     net->rr_fwd_off = net->rr_bwd_off = -1;
-    if (rr_width_ok(hid) && nwide >= 2) {
+    net->rr_kind = rr_kind_of(net->n_layers, hid);
+    if (net->rr_kind == RR_KIND_CHAIN) {
         net->rr_fwd_off = (int)off;
         off += (long)(nwide - 1) * rr_layer_floats(hid);
         net->rr_bwd_off = (int)off;
         off += (long)(nwide - 1) * rr_layer_floats(hid);
+    } else if (net->rr_kind == RR_KIND_PANEL) {
+        net->rr_fwd_off = (int)off;
+        off += (long)hid * hid;
+        net->rr_bwd_off = (int)off;
+        off += (long)hid * hid;
+        off += (long)rr_panel_l0_floats(hid);         // layer 0's A fragments (with its bias column), behind the panels
     }
     net->packed_floats = (int)off;
     return (int)off;
@@ -852,6 +885,10 @@ static int mlp_fwd_launch(const nlbac_mlp* nets, const nlbac_mlp_io* io, int n_n
         NLBAC_REQUIRE(io[i].x0 && io[i].y, "%s: net %d needs x0 and y", who, i);
         NLBAC_REQUIRE(io[i].x0_dim == nets[i].in_dim || (io[i].x1 && io[i].x0_dim + io[i].x1_dim == nets[i].in_dim),
                       "%s: net %d input dims %d+%d != in_dim %d", who, i, io[i].x0_dim, io[i].x1_dim, nets[i].in_dim);
+    }
+    {   // nets with one hid x hid layer of 64 / 128 / 256 units run on the register-resident kernels (mlp_rr_kernels.hip)
+        const int rr = nlbac_mlp_rr_fwd_launch(L, n_nets, G, who, (hipStream_t)s);
+        if (rr <= 0) return rr;
     }
     const size_t lds = (size_t)2 * NLBAC_MLP_TILE * L.ld * sizeof(float);
     const dim3 grid(nlbac_ceil_div(B, NLBAC_MLP_TILE), n_nets);

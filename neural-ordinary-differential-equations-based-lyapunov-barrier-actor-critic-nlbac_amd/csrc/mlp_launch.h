@@ -1,0 +1,20 @@
+// The launch descriptor shared by the MLP kernel families (mlp_kernels.hip: LDS-tiled; mlp_rr_kernels.hip:
+// register-resident panels) and what the first hands to the second.
+#pragma once
+#include "common.h"
+#include "dy_heads.h"
+
+struct MlpLaunch {
+    nlbac_mlp net[NLBAC_MAX_NETS];
+    nlbac_mlp_io io[NLBAC_MAX_NETS];
+    int B;
+    int ld;          // LDS row stride in floats
+    int n_slabs;     // bwd_weights only
+    int rows_per_slab;
+    long slab_stride;
+};
+
+// The register-resident forward (mlp_rr_kernels.hip): 0 = launched, 1 = these nets are not its (the LDS-tiled kernels
+// take the launch), < 0 = error.
+int nlbac_mlp_rr_fwd_launch(const MlpLaunch& L, int n_nets, const nlbac_gauss_head& G, const char* who, hipStream_t s);
+bool nlbac_mlp_rr_eligible(const nlbac_mlp* nets, int n_nets);

@@ -242,3 +242,80 @@ __device__ __forceinline__ void rr_row_store(float* __restrict__ rowp, int jo, i
 #pragma unroll
     for (int r = 0; r < S::R; ++r) p[r] = v[r];
 }
+
+
+// ---------------------------------------------------------------------------------------------------------------------
+// A PANEL of a hid x hid layer for the 256-wide actor / critic nets (mlp_rr_kernels.hip): NBO output blocks (one half
+// of the layer's units: two waves share a 16-row tile's layer, each reading all KS k-steps of the input), in groups of
+// two, k-steps inner; the same hooks as RRGemm::run.  Fragment stream: the panel's NBO * KS / 4 float4 per lane, in
+// issue order ("panel pack", written by nlbac_mlp_pack).
+// ---------------------------------------------------------------------------------------------------------------------
+template <int NBO, int KS>
+struct RRPanel {
+    static constexpr int NM = NBO * KS, NV = NM / 4, D = rr_pick_depth(NV), BYTES = NV * 1024;
+    static_assert(NBO % 2 == 0 && KS % 4 == 0 && D >= 4, "panels hold an even number of 16-unit blocks");
+    f32x4 wq[D];
+
+    __device__ __forceinline__ void prime(__amdgpu_buffer_rsrc_t rs, int voff, int soff) {
+#pragma unroll
+        for (int i = 0; i < D; ++i) wq[i] = rr_ldw(rs, voff, soff + i * 1024);
+    }
+
+    // (the stream ends with the panel: the last D refills re-read its own head, harmlessly)
+    template <class PRE, class FIN>
+    __device__ __forceinline__ void run(f32x4 (&acc)[NBO], const f32x4 (&cinit)[NBO], float (&H)[KS],
+                                        __amdgpu_buffer_rsrc_t rs, int voff, int cur, PRE&& pre, FIN&& fin) {
+        asm volatile("" : "+s"(cur));
+        int m = 0;
+#pragma unroll
+        for (int g0 = 0; g0 < NBO; g0 += 2) {
+            acc[g0] = cinit[g0];
+            acc[g0 + 1] = cinit[g0 + 1];
+#pragma unroll
+            for (int ks = 0; ks < KS; ++ks) {
+                if (g0 == 0) pre(ks);
+#pragma unroll
+                for (int jj = 0; jj < 2; ++jj) {
+                    const int v = m >> 2, c = m & 3;
+                    acc[g0 + jj] = __builtin_amdgcn_mfma_f32_16x16x4f32(wq[v % D][c], H[ks], acc[g0 + jj], 0, 0, 0);
+                    if (c == 3) {
+                        const int vn = v + D;
+                        int so = cur + (vn < NV ? vn : vn - NV) * 1024;
+                        RR_PIN_S(so)
+                        wq[v % D] = rr_ldw(rs, voff, so);
+                        __builtin_amdgcn_sched_barrier(0);
+                    }
+                    ++m;
+                }
+                RR_PIN_A2(acc[g0], acc[g0 + 1])
+                if (g0 > 0 && ks < 8) fin(g0 - 2 + (ks >> 2), ks & 3);
+            }
+        }
+    }
+
+    // a single-block product over KSB k-steps of H starting at H[k0], two accumulator chains, just-in-time `pre`
+    template <int KSB, class PRE>
+    __device__ __forceinline__ static f32x4 block(const float (&a)[KSB], const float* H, PRE&& pre) {
+        f32x4 o0{0.f, 0.f, 0.f, 0.f}, o1{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int ks = 0; ks < KSB; ++ks) {
+            pre(ks);
+            if (ks & 1) o1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a[ks], H[ks], o1, 0, 0, 0);
+            else o0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a[ks], H[ks], o0, 0, 0, 0);
+        }
+        return o0 + o1;
+    }
+};
+
+// floats of a panel net's layer-0 fragment block: four k-steps (in_dim + 1 <= 16) x hid / 16 blocks x 64 lanes
+__host__ __device__ __forceinline__ long rr_panel_l0_floats(int hid) { return 4L * (hid >> 4) * 64; }
+
+// which nets get which RR pack (nlbac_mlp.rr_kind)
+#define RR_KIND_NONE 0
+#define RR_KIND_CHAIN 1      /* n_layers >= 4, hid <= 128: every hid x hid layer, RRGemm order (the NODE nets) */
+#define RR_KIND_PANEL 2      /* n_layers == 3, hid % 32 == 0: the one hid x hid layer as two panels (actor / critic nets) */
+__host__ __device__ __forceinline__ int rr_kind_of(int n_layers, int hid) {
+    if (n_layers >= 4 && rr_width_ok(hid)) return RR_KIND_CHAIN;
+    if (n_layers == 3 && hid % 64 == 0 && hid >= 64 && hid <= 256) return RR_KIND_PANEL;
+    return RR_KIND_NONE;
+}

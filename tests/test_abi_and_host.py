@@ -39,24 +39,26 @@ def test_library_exports_every_declared_symbol(lib):
 
 
 def test_ctypes_structs_match_header_sizes(lib):
-    # nlbac_mlp: 4 ints, ptr, 12 ints, ptr, 12 ints, 3 ints (+ 4 bytes of tail padding) ; nlbac_mlp_io per header
-    assert _lib.C.sizeof(_lib.Mlp) == 16 + 8 + 48 + 8 + 48 + 12 + 4
+    # nlbac_mlp: 4 ints, ptr, 12 ints, ptr, 12 ints, 4 ints ; nlbac_mlp_io per header
+    assert _lib.C.sizeof(_lib.Mlp) == 16 + 8 + 48 + 8 + 48 + 16
     io = _lib.MlpIO()
     assert _lib.C.sizeof(io) % 8 == 0
     net = _lib.Mlp()
     net.n_layers, net.in_dim, net.hid, net.out_dim = 3, 9, 256, 1
     n = lib.nlbac_mlp_pack_layout(_lib.C.byref(net))
     # layer0 fwd: 8 tiles x 2 chunks ; layer1 fwd: 8 x 32 ; layer1 bwd: 8 x 32  (x256 floats)
-    assert n == (8 * 2 + 8 * 32 + 8 * 32) * 256
+    assert n == (8 * 2 + 8 * 32 + 8 * 32) * 256 + 2 * 256 * 256 + 4 * 16 * 64      # (+ layer 0's fragments)
     assert net.pf_off[0] == 0 and net.pb_off[0] == -1 and net.pb_off[1] > net.pf_off[1] > 0
-    assert net.rr_fwd_off == -1 and net.rr_bwd_off == -1 and net.packed_floats == n     # 256 wide: no RR packs
+    # ... and, having ONE hid x hid layer of a width divisible by 32, the two panel packs of it (hid^2 floats each)
+    old = (8 * 2 + 8 * 32 + 8 * 32) * 256
+    assert net.rr_kind == 2 and net.rr_fwd_off == old and net.rr_bwd_off == old + 256 * 256 and net.packed_floats == n
     # a NODE-sized net (3 -> 100 -> 100 -> 100 -> 100 -> 3) also gets the RR packs of its three 100 x 100 layers:
     # 7 output blocks x 25 k-steps = 175 MFMAs = 44 float4 per lane and layer, forward and backward
     net = _lib.Mlp()
     net.n_layers, net.in_dim, net.hid, net.out_dim = 5, 3, 100, 3
     n = lib.nlbac_mlp_pack_layout(_lib.C.byref(net))
     old = (4 * 1 + 3 * (4 * 13 + 4 * 13)) * 256
-    assert net.rr_fwd_off == old and net.rr_bwd_off == old + 3 * 44 * 256 and n == old + 6 * 44 * 256 == net.packed_floats
+    assert net.rr_kind == 1 and net.rr_fwd_off == old and net.rr_bwd_off == old + 3 * 44 * 256 and n == old + 6 * 44 * 256 == net.packed_floats
 
 
 def test_integration_snippet_structs_match_the_compiled_header(tmp_path):

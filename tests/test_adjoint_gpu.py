@@ -96,7 +96,11 @@ def test_adjoint_of_a_rollout_matches_the_oracle(env_name, method, T):
         if method == "dopri5":      # the device took the oracle's step sequence
             st = info["adjoint_steps"]
             h_used, ratio, n_att = sol.ctx["adjoint_info"][0][p]
-            if same_sequence(n_att, st):
+            # (a sequence with an error ratio within 5 % of 1 holds an accept / reject decision that rounding can turn:
+            # the device may then take another sequence of the same length — both valid dopri5 runs, equal to solver
+            # tolerance only)
+            marginal = any(abs(r - 1.0) < 0.05 for _, r, _ in st)
+            if same_sequence(n_att, st) and not marginal:
                 # The last step size is h_k = 0.9 h_{k-1} ratio_{k-1}^(-1/5) down the attempts (and the Hairer guess
                 # before them): a relative error of an error ratio enters the next step size with the factor 1/5,
                 # and the ratio is a cancellation residue of the two embedded solutions — reproduced to 5e-2, the bar
