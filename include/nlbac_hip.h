@@ -567,6 +567,19 @@ int nlbac_adj_param_norm(int mode, const float *th0, const float *K, long k_stri
                          const int *seg_len, int n_seg, float rtol, float atol, const double *ctl, float *th1,
                          float *pseg, unsigned *ticket, float *pnorm, nlbac_stream_t s);
 
+/* The same adjoint for the single-net NODE  dx/dt = out_mu + out_sig * net(([x | c] - in_mu) * in_isig)  with carried
+ * inputs c (C/sac_cbf_clf/model.py:179-205; would-be call sites C/sac_cbf_clf/sac_cbf_clf.py:437,458,581,603; the
+ * normalised form is BASELINE configs[4]'s, norm as in nlbac_concat_rk_fwd or NULL), stage by stage on the MLP entry
+ * points: rows of z = [y | a_y | a_c], w = 2 n_s + n_c floats.  nlbac_concat_adj_in forms, from the stage points ZS, the
+ * net's input rows Xin (n, n_s + n_c) and the cotangent of its output Ay (n, n_s) = a_y (* out_sig); after
+ * nlbac_mlp_fwd (x0 = Xin -> fnet) and nlbac_mlp_bwd_data (dy = Ay -> dX), nlbac_concat_adj_out writes the stage
+ * derivative KZ row = [ -(out_mu + out_sig fnet) | dX[:, :n_s] in_isig | dX[:, n_s:] in_isig ].  The parameter
+ * adjoint's stage derivative is nlbac_mlp_bwd_weights on (Xin, Ay) and what the two launches kept. */
+int nlbac_concat_adj_in(const float *ZS, int w, const float *c, int n_s, int n_c, const float *norm, int n,
+                        float *Xin, float *Ay, nlbac_stream_t s);
+int nlbac_concat_adj_out(const float *fnet, const float *dX, int n_s, int n_c, const float *norm, int n, int w,
+                         float *KZ, nlbac_stream_t s);
+
 /* Strided block copy of 32-bit words: block b (block_len words) from src + b*src_stride to dst + b*dst_stride —
  * a row range of a stage-major solver buffer in one launch (hands a problem's first attempted dopri5 step to its
  * own solver when the problems of a joint solve stop agreeing on accept / done). */

@@ -120,6 +120,8 @@ _PROTOS = {
     "nlbac_adam_fused": [_P, _P, _P, _P, _I, _L, _L, _P, _D, _P, _F, _P, _P, _I, _I, C.POINTER(C.c_long),
                          C.POINTER(C.c_void_p), _P, _P, _I, _P],
     "nlbac_node_rk_mask_words": [C.POINTER(Mlp), C.POINTER(Mlp), _I],
+    "nlbac_concat_adj_in": [_P, _I, _P, _I, _I, _P, _I, _P, _P, _P],
+    "nlbac_concat_adj_out": [_P, _P, _I, _I, _P, _I, _I, _P, _P],
     "nlbac_reduce_slabs": [_P, _P, _I, _L, _L, _P],
     "nlbac_soft_update": [_P, _P, _L, _F, _P],
     "nlbac_gauss_sample_fwd": [_P, _I, _P, _P, _P, _I, _I, _P, _I, _P, _P],

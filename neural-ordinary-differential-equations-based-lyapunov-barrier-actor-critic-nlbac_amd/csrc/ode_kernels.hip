@@ -501,3 +501,61 @@ extern "C" int nlbac_dopri_interp_bwd(const float* dout, const float* h_host, co
     NLBAC_CHECK_LAUNCH("nlbac_dopri_interp_bwd");
     return 0;
 }
+
+
+// ---------------------------------------------------------------------------------------------------------------------
+// The adjoint of the single-net NODE  dx/dt = out_mu + out_sig * net(([x | c] - in_mu) * in_isig)  (c: carried inputs;
+// C/sac_cbf_clf/model.py:179-205; no normaliser: mu = 0, sig = 1), stage by stage on the MLP kernels: per stage of the
+// augmented system z = [y | a_y | a_c] (W = 2 n_s + n_c floats per row, integrated in s = t1 - t)
+//     nlbac_concat_adj_in   the net's input rows and the cotangent of its output from the stage point,
+//     nlbac_mlp_fwd / nlbac_mlp_bwd_data  (f and the vector-Jacobian product (d net / d input)^T a),
+//     nlbac_concat_adj_out  the stage derivative  dz/ds = [ -f | +J_y^T a_y | +J_c^T a_y ].
+// (torchdiffeq 0.2.3 OdeintAdjointMethod's augmented dynamics on a field whose carried columns have zero derivative.)
+// ---------------------------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void concat_adj_in_kernel(const float* __restrict__ ZS, int W, const float* __restrict__ c,
+                                                            int ns, int nc, const float* __restrict__ norm, int n,
+                                                            float* __restrict__ Xin, float* __restrict__ Ay) {
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    const int idim = ns + nc;
+    const float* z = ZS + (long)i * W;
+    for (int k = 0; k < idim; ++k) {
+        float v = (k < ns) ? z[k] : c[(long)i * nc + (k - ns)];
+        if (norm) v = (v - norm[k]) * norm[idim + k];
+        Xin[(long)i * idim + k] = v;
+    }
+    for (int r = 0; r < ns; ++r) Ay[(long)i * ns + r] = norm ? z[ns + r] * norm[2 * idim + ns + r] : z[ns + r];
+}
+
+__global__ __launch_bounds__(256) void concat_adj_out_kernel(const float* __restrict__ fnet, const float* __restrict__ dX,
+                                                             int ns, int nc, const float* __restrict__ norm, int n, int W,
+                                                             float* __restrict__ KZ) {
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    const int idim = ns + nc;
+    float* k = KZ + (long)i * W;
+    for (int r = 0; r < ns; ++r) {
+        const float f = fnet[(long)i * ns + r];
+        k[r] = -(norm ? norm[2 * idim + r] + norm[2 * idim + ns + r] * f : f);
+    }
+    for (int j = 0; j < idim; ++j) {
+        const float d = dX[(long)i * idim + j];
+        k[ns + j] = norm ? d * norm[idim + j] : d;
+    }
+}
+
+extern "C" int nlbac_concat_adj_in(const float* ZS, int w, const float* c, int n_s, int n_c, const float* norm, int n,
+                                   float* Xin, float* Ay, nlbac_stream_t s) {
+    NLBAC_REQUIRE(ZS && c && Xin && Ay && n >= 1 && n_s >= 1 && n_c >= 0 && w >= 2 * n_s + n_c, "nlbac_concat_adj_in: bad arguments");
+    hipLaunchKernelGGL(concat_adj_in_kernel, GRID1(n), ZS, w, c, n_s, n_c, norm, n, Xin, Ay);
+    NLBAC_CHECK_LAUNCH("nlbac_concat_adj_in");
+    return 0;
+}
+
+extern "C" int nlbac_concat_adj_out(const float* fnet, const float* dX, int n_s, int n_c, const float* norm, int n, int w,
+                                    float* KZ, nlbac_stream_t s) {
+    NLBAC_REQUIRE(fnet && dX && KZ && n >= 1 && w >= 2 * n_s + n_c, "nlbac_concat_adj_out: bad arguments");
+    hipLaunchKernelGGL(concat_adj_out_kernel, GRID1(n), fnet, dX, n_s, n_c, norm, n, w, KZ);
+    NLBAC_CHECK_LAUNCH("nlbac_concat_adj_out");
+    return 0;
+}

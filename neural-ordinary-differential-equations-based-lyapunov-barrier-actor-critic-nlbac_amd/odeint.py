@@ -1371,13 +1371,108 @@ class ConcatNodeSolver(AffineNodeSolver):
             self._net_arr = mlp_array([self.net.desc])
         return self._net_arr
 
-    def backward_adjoint(self, dout, need_du=True, need_params=False, need_dy0=False):
-        raise NotImplementedError("odeint_adjoint is built for the control-affine NODE (nlbac_node_adj_step); the "
-                                  "single-net NODE differentiates through the steps")
+    # -- continuous adjoint (odeint_adjoint) of the single-net field ---------------------------------------------
+    # The base class drives the solve (initial step, attempts, mixed norm, commit, interpolation, parameter-adjoint
+    # quadrature); what differs is one RK step of the augmented system z = [y | a_y | a_c] and the stage derivative of
+    # the parameter adjoint: stage by stage on the MLP entry points (nlbac_concat_adj_in -> nlbac_mlp_fwd ->
+    # nlbac_mlp_bwd_data -> nlbac_concat_adj_out), the RK combinations by nlbac_rk_combine on the w-wide rows.
+    def _adj_scratch(self, n, S):
+        net, ns, nc = self.net, self.n_s, self.n_u
+        return dict(ZS=self._buf("cadj_ZS", n, 2 * ns + nc), Xin=self._buf("cadj_Xin", n, net.in_dim),
+                    Ay=self._buf("cadj_Ay", n, ns), f=self._buf("cadj_f", n, ns), dX=self._buf("cadj_dX", n, net.in_dim),
+                    acts=self._buf("cadj_acts", net.n_layers - 1, n, net.hid))
+
+    def _adj_step(self, w, u, P, rpp, method, st0, st1, h_host=None, h_dev=None, ctl=None, c_out=None, c_err=None,
+                  keep=None):
+        """(Problems whose solve is done are recomputed to the same values — their control block, z0 and first stage no
+        longer change — instead of being skipped.)"""
+        n, W, ns, nc, net, s = P * rpp, w["W"], self.n_s, self.n_u, self.net, stream_ptr()
+        rows = TABLEAU[method]["beta"]
+        S = len(rows) + 1
+        sc = self._adj_scratch(n, S)
+        hh = fptr(*h_host) if h_host is not None else None
+        stride = _lib.DOPRI_CTL if h_dev else 0
+        norm = self.norm.data_ptr() if self.norm is not None else None
+        KZ = w["KZ"]
+        for st in range(st0, st1):
+            if st == 0:
+                ZS = w["Z0"]
+            else:
+                ZS = sc["ZS"]
+                _lib.call("nlbac_rk_combine", w["Z0"].data_ptr(), KZ.data_ptr(), st, fptr(*rows[st - 1]), hh, h_dev, stride,
+                          P, rpp, W, ZS.data_ptr(), s)
+            if keep:      # the parameter adjoint's quadrature reads every stage's net inputs / cotangents / activations
+                Xin, Ay = keep["Xin"][st], keep["Ay"][st]
+                acts, dz, ls = keep["acts"][:, st * n:], keep["dz"][:, st * n:], keep["ls"]
+            else:
+                Xin, Ay, acts, dz, ls = sc["Xin"], sc["Ay"], sc["acts"], None, n * net.hid
+            _lib.call("nlbac_concat_adj_in", ZS.data_ptr(), W, u.data_ptr(), ns, nc, norm, n, Xin.data_ptr(), Ay.data_ptr(), s)
+            io = io_array(1)
+            io[0].x0, io[0].x0_dim, io[0].x0_ld = Xin.data_ptr(), net.in_dim, net.in_dim
+            io[0].y, io[0].y_ld = sc["f"].data_ptr(), ns
+            io[0].acts, io[0].acts_ls = acts.data_ptr(), ls
+            _lib.call("nlbac_mlp_fwd", self._nets(), io, 1, n, s)
+            io[0].dy, io[0].dy_ld = Ay.data_ptr(), ns
+            io[0].dx, io[0].dx_ld = sc["dX"].data_ptr(), net.in_dim
+            if dz is not None:
+                io[0].dz = dz.data_ptr()
+            _lib.call("nlbac_mlp_bwd_data", self._nets(), io, 1, n, s)
+            _lib.call("nlbac_concat_adj_out", sc["f"].data_ptr(), sc["dX"].data_ptr(), ns, nc, norm, n, W, KZ[st].data_ptr(), s)
+            if keep:
+                self._adj_stage_dw(self._adj_par_cur, st)
+        if c_out is not None:
+            _lib.call("nlbac_rk_combine", w["Z0"].data_ptr(), KZ.data_ptr(), len(c_out), c_out, hh, h_dev, stride, P, rpp, W,
+                      w["Z1"].data_ptr(), s)
+        if c_err is not None:
+            _lib.call("nlbac_rk_combine", None, KZ.data_ptr(), len(c_err), c_err, hh, h_dev, stride, P, rpp, W,
+                      w["ERR"].data_ptr(), s)
+        self.nfe += st1 - st0
+
+    def _adj_params_begin(self, w, n, S):
+        ctx = self.ctx
+        assert ctx["P"] == 1, "parameter gradients are only taken on single-problem solves"
+        key = ("adj_par", n, S)
+        pool = self._scratch.setdefault(n, {})
+        par = pool.get(key)
+        if par is None:
+            net, ns, dev = self.net, self.n_s, self.device
+            z = lambda *s, dtype=torch.float32: torch.zeros(*s, dtype=dtype, device=dev)
+            arena = net.arena
+            NP = arena.n
+            keep = dict(Xin=z(S, n, net.in_dim), Ay=z(S, n, ns), acts=z(net.n_layers - 1, S * n, net.hid),
+                        dz=z(net.n_layers - 1, S * n, net.hid), ls=S * n * net.hid)
+            segs = [(arena.offset_of[id(p)], p.numel()) for p in self.node.parameters()]
+            par = pool[key] = dict(
+                keep=keep, NP=NP, K=z(S, NP), th0=z(NP), th1=z(NP), out=z(NP), slabs=z(self.ADJ_SUB_SLABS, NP),
+                seg_off=torch.tensor([o for o, _ in segs], dtype=torch.int32, device=dev),
+                seg_len=torch.tensor([l for _, l in segs], dtype=torch.int32, device=dev), n_seg=len(segs),
+                pseg=z(2 * len(segs)), ticket=z(1, dtype=torch.int32), pnorm=z(2), io={}, n=n, S=S, w=w)
+        _lib.call("nlbac_fill", par["th0"].data_ptr(), 0.0, par["NP"], stream_ptr())
+        par["grad"] = None
+        return par
+
+    def _adj_stage_dw(self, par, st):
+        """K_theta[st] = sum over the rows of stage ``st`` of (d net / d theta)^T (a_y out_sig) at the stage's
+        (normalised) inputs: nlbac_mlp_bwd_weights on what the step kept of that stage, then the slab sum."""
+        k, n, S, net = par["keep"], par["n"], par["S"], self.net
+        io = par["io"].get(st)
+        if io is None:
+            io = par["io"][st] = io_array(1)
+            io[0].x0, io[0].x0_dim, io[0].x0_ld = k["Xin"][st].data_ptr(), net.in_dim, net.in_dim
+            io[0].dy, io[0].dy_ld = k["Ay"][st].data_ptr(), self.n_s
+            io[0].acts, io[0].dz = k["acts"][:, st * n:].data_ptr(), k["dz"][:, st * n:].data_ptr()
+            io[0].acts_ls = S * n * net.hid
+            io[0].grad = par["slabs"].data_ptr()
+        bwd_weights(self._nets(), io, 1, n, self.ADJ_SUB_SLABS, par["NP"], self.device)
+        _lib.call("nlbac_reduce_slabs", par["K"][st].data_ptr(), par["slabs"].data_ptr(), self.ADJ_SUB_SLABS,
+                  par["NP"], par["NP"], stream_ptr())
+        if self.comm is not None and self.comm.world > 1:
+            self.comm.all_reduce_(par["K"][st])       # (see AffineNodeSolver._adj_stage_dw)
 
     def _rk_fused(self, ws, y0, u, P, rpp, method, st0, st1, h_host=None, h_dev=None, c_out=None, out=None,
                   c_err=None, err=None, save_acts=True, chain=None):
         beta, S = self._beta(method)
+        save_acts = save_acts and not self.adjoint       # (the adjoint re-computes every stage it differentiates)
         _lib.call("nlbac_concat_rk_fwd", C.byref(self.net.desc), y0.data_ptr(), u.data_ptr(), P, rpp, st0, st1, S, beta,
                   c_out, len(c_out) if c_out is not None else 0, c_err, len(c_err) if c_err is not None else 0,
                   fptr(*h_host) if h_host is not None else None, h_dev, _lib.DOPRI_CTL if h_dev else 0,
@@ -1449,6 +1544,8 @@ class ConcatNodeSolver(AffineNodeSolver):
 
     def accumulate_param_grads(self, arena, slabs_per_step):
         ctx = self.ctx
+        if self.adjoint:       # the adjoint solve has integrated the parameter adjoint already (see the base class)
+            return AffineNodeSolver.accumulate_param_grads(self, arena, slabs_per_step)
         n_used = 0
         for si, step in enumerate(ctx["steps"]):
             ws = step["ws"]

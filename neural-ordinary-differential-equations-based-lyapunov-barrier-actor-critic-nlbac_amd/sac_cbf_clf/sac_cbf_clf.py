@@ -258,9 +258,6 @@ class SAC_CBF_CLF(object):
 
     @adjoint.setter
     def adjoint(self, on):
-        from ..odeint import ConcatNodeSolver
-        if on and any(isinstance(sv, ConcatNodeSolver) for sv in self.task.solvers):
-            raise NotImplementedError("odeint_adjoint is built for the control-affine NODE copies")
         self._adjoint = bool(on)
         for sv in self.task.solvers:
             sv.adjoint = bool(on)

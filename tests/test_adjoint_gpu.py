@@ -242,3 +242,133 @@ def test_pvtol_full_size_dopri5_adjoint():
         vec_close(ga, R["g_policy"].numpy(), 2e-4, "policy gradient vs the oracle's adjoint (update %d)" % u)
         gd = flat_grad(direct, direct.ar_a, direct.policy).numpy()
         assert rel_l2(ga, gd) < 5e-3, "adjoint vs direct back-propagation: %.3e" % rel_l2(ga, gd)
+
+
+# ----------------------------------------------------------------------------------------------------------------------
+# The single-net NODE (SimulatedCars: dx/dt = net([x | action, time]); Quadrotor-like: the same with normalised inputs
+# and de-normalised outputs): its adjoint runs stage by stage on the MLP entry points (nlbac_concat_adj_in / _out).
+# ----------------------------------------------------------------------------------------------------------------------
+def _single_net(env_name):
+    from nlbac_amd.envspec import make_env
+    env = make_env(env_name, 0)
+    if env_name == "SimulatedCars":
+        return 10, 2, None
+    return 6, 2, env.node_normalizer
+
+
+def _oracle_single(W, norm, ns, nc, y0, c, T, dout, method, adjoint, with_params):
+    from oracle import nlbac_oracle as O
+    sd = {k: torch.tensor(v, requires_grad=True) for k, v in W.items()}
+    yy, cc = y0.clone().requires_grad_(True), c.clone().requires_grad_(True)
+    node = O.ConcatNode(sd, n_s=ns, n_carry=nc, norm=norm)
+    info = {}
+    if adjoint:
+        out = O.odeint_adjoint(node, torch.cat((yy, cc), 1), torch.tensor([0.0, T]), method=method, atol=1e-7, rtol=1e-5,
+                               info=info, adjoint_params=None if with_params else ())[-1][:, :ns]
+    else:
+        out = O.odeint(node, torch.cat((yy, cc), 1), torch.tensor([0.0, T]), method=method, atol=1e-7, rtol=1e-5)[-1][:, :ns]
+    g = torch.autograd.grad((out * dout).sum(), [yy, cc] + (list(sd.values()) if with_params else []))
+    gp = torch.cat([t.reshape(-1) for t in g[2:]]) if with_params else None
+    return out.detach(), g[0], g[1], gp, info
+
+
+@pytest.mark.parametrize("env_name", ["SimulatedCars", "QuadrotorLike"])
+@pytest.mark.parametrize("method", ["euler", "rk4", "dopri5"])
+@pytest.mark.parametrize("T", [0.02, 0.2])
+def test_adjoint_of_a_single_net_rollout_matches_the_oracle(env_name, method, T):
+    """Two problems, ragged last tile: d/dy0 and d/d(carried inputs) of the HIP adjoint against the oracle's adjoint per
+    problem (1e-4 where both take the same step sequence) and against direct back-propagation at solver tolerance; then
+    one problem with the parameter adjoint."""
+    from nlbac_amd.odeint import ConcatNodeSolver
+    ns, nc, norm = _single_net(env_name)
+    agent, env = make_agent(64, 64, 0, method, env_name, 1.0 if env_name == "QuadrotorLike" else 0.5)
+    W = synth.agent_weights(env_name, 64, 0)["node"]
+    gen = torch.Generator().manual_seed(7)
+    rpp = 77
+    tr = synth.transitions(env_name, 2 * rpp, seed=4, env=env)
+    y0 = torch.tensor(tr["obs"][:, :ns], dtype=torch.float32)
+    c = torch.rand(2 * rpp, nc, generator=gen) * 2 - 1
+    if env_name == "QuadrotorLike":
+        c = torch.tensor(tr["action"], dtype=torch.float32)
+    y0[rpp:] *= 1.5                                    # the second problem: its own step sequence
+    dout = torch.randn(2 * rpp, ns, generator=gen) / rpp
+    torch.set_num_threads(4)
+    sol = ConcatNodeSolver(agent.neural_ode_model, "cuda")
+    sol.adjoint, sol.keep_acts = True, False
+    out = sol.forward(y0.cuda(), c.cuda(), 2, rpp, method, T).clone()
+    dc, dy0 = sol.backward(dout.cuda(), need_du=True, need_dy0=True)
+    dc, dy0 = dc.cpu().numpy(), dy0.cpu().numpy()
+    for p in range(2):
+        rows = slice(p * rpp, (p + 1) * rpp)
+        out_o, dy0_o, dc_o, _, info = _oracle_single(W, norm, ns, nc, y0[rows], c[rows], T, dout[rows], method, True, False)
+        vec_close(out[rows].cpu().numpy(), out_o.numpy(), TOL, "x(T) problem %d" % p)
+        tol = TOL
+        if method == "dopri5":
+            st = info["adjoint_steps"]
+            h_used, ratio, n_att = sol.ctx["adjoint_info"][0][p]
+            if not (same_sequence(n_att, st) and not any(abs(r - 1.0) < 0.05 for _, r, _ in st)):
+                tol = 5e-3
+        vec_close(dy0[rows], dy0_o.numpy(), tol, "adjoint d/dy0 problem %d" % p)
+        vec_close(dc[rows], dc_o.numpy(), tol, "adjoint d/dc problem %d" % p)
+        _, gy, gc, _, _ = _oracle_single(W, norm, ns, nc, y0[rows], c[rows], T, dout[rows], method, False, False)
+        # (solver tolerance; over the long horizon the continuous adjoint integrates ACROSS the ReLU kinks that the
+        #  discrete gradient differentiates around: 2.2e-2 on the normalised net)
+        bar = {"euler": 0.2 if T < 0.1 else 0.6, "rk4": 1e-3 if T < 0.1 else 0.1, "dopri5": 5e-3 if T < 0.1 else 3e-2}[method]
+        # (the gradient w.r.t. the carried inputs is ~1000x smaller than d/dy0 here and carries the adjoint solve's
+        #  ABSOLUTE tolerance: the two are held to the bar as one vector)
+        both = lambda a, b: np.concatenate([np.asarray(a).reshape(-1), np.asarray(b).reshape(-1)])
+        assert rel_l2(both(dy0[rows], dc[rows]), both(gy.numpy(), gc.numpy())) < bar, (
+            rel_l2(dy0[rows], gy.numpy()), rel_l2(dc[rows], gc.numpy()))
+    # one problem with the parameter adjoint (the NODE fit's backward)
+    rows = slice(0, rpp)
+    sol.forward(y0[rows].cuda().contiguous(), c[rows].cuda().contiguous(), 1, rpp, method, T)
+    sol.backward(dout[rows].cuda().contiguous(), need_du=False, need_params=True)
+    ar = agent.ar_n
+    ar.grad.zero_()
+    used = sol.accumulate_param_grads(ar, 1)
+    gsum = ar.grad[:used].sum(0)
+    gp = torch.cat([gsum[ar.offset_of[id(q)]:ar.offset_of[id(q)] + q.numel()] for q in agent.neural_ode_model.parameters()])
+    _, _, _, gp_o, info = _oracle_single(W, norm, ns, nc, y0[rows], c[rows], T, dout[rows], method, True, True)
+    assert rel_l2(gp.cpu().numpy(), gp_o.numpy()) < (1e-3 if method != "dopri5" else 5e-3), rel_l2(gp.cpu().numpy(), gp_o.numpy())
+
+
+@pytest.mark.parametrize("env_name,solver", [("SimulatedCars", "rk4"), ("SimulatedCars", "dopri5"), ("QuadrotorLike", "dopri5")])
+def test_single_net_update_with_adjoint_matches_the_oracle(env_name, solver):
+    """Whole updates of the SimulatedCars / Quadrotor-like agents with every NODE solve differentiated by the adjoint
+    (two chained rollouts in SimulatedCars, the NODE fit with the parameter adjoint) against the oracle agent doing the
+    same."""
+    from oracle import nlbac_oracle as O
+    torch.set_num_threads(4)
+    B, seed, hidden = 128, 0, 64
+    gamma_b = {"SimulatedCars": 0.5, "QuadrotorLike": 1.0}[env_name]
+    agent, env = make_agent(B, hidden, seed, solver, env_name, gamma_b)
+    agent.adjoint = True
+    oargs = O.Args(batch_size=B, hidden_size=hidden, seed=seed)
+    oargs.gamma_b = gamma_b
+    oracle = O.make_oracle(synth.fixture_env(env_name, seed), oargs, synth.agent_weights(env_name, hidden, seed),
+                           solver=solver, adjoint=True)
+    tr = synth.transitions(env_name, 4096, seed=seed + 1, env=env)
+    fields = synth.fields(env_name)
+    node_fields = ("obs", "action", "next_obs", "t") if env_name == "SimulatedCars" else ("obs", "action", "next_obs")
+    lr = dict(critic=4e-4, policy=3e-4, node=1e-3)
+    for ci, updates in enumerate((0, 1, 20)):
+        rs = np.random.RandomState(ci)
+        idx, nidx = rs.choice(4096, B, replace=False), rs.choice(4096, 512, replace=False)
+        batch = {f: torch.tensor(tr[f][idx], dtype=torch.float32) for f in fields}
+        eps = [torch.from_numpy(e) for e in synth.normal_eps(agent.task.n_eps, B, env.n_u, seed=ci)]
+        with_fit = updates % 10 == 0
+        node = tuple(torch.tensor(tr[f][nidx], dtype=torch.float32) for f in node_fields)
+        R = oracle.update(batch, eps, updates, node_batch=node if with_fit else None)
+        agent.set_noise(eps)
+        ret = agent.update_from_host(tuple(batch[f].numpy() for f in fields), updates,
+                                     tuple(t.numpy() for t in node) if with_fit else None)
+        torch.cuda.synchronize()
+        vec_close(ret, R["ret"], TOL, "ret (update %d)" % updates)
+        vec_close(flat_grad(agent, agent.ar_a, agent.policy), R["g_policy"], 2e-4, "policy gradient through the adjoint (update %d)" % updates)
+        if with_fit:
+            gn = flat_grad(agent, agent.ar_n, agent.neural_ode_model)
+            assert rel_l2(gn.numpy(), R["g_node"].numpy()) < 2e-3, "NODE-fit gradient through the parameter adjoint"
+        for name, mod, osd in (("critic", agent.critic, oracle.critic), ("policy", agent.policy, oracle.policy),
+                               ("node", agent.neural_ode_model, oracle.node)):
+            ov = torch.cat([osd[k].detach().reshape(-1) for k in osd])
+            params_close(flat_params(mod), ov, lr[name] * (ci + 1), "params %s (update %d)" % (name, updates))
