@@ -459,11 +459,16 @@ int nlbac_concat_rk_fwd(const nlbac_mlp *net, const float *y0, const float *c, i
                         int stage_begin, int stage_end, int n_stages_total, const float *beta,
                         const float *c_out, int n_out, const float *c_err, int n_err, const float *h_host,
                         const double *h_dev, int h_dev_stride, float *K, float *Y, float *acts, long acts_ls,
+                        int acts_bits /* acts hold nlbac_concat_rk_mask_words() uint32 ReLU mask words per row and layer
+                                         instead of the activations (rollouts differentiated w.r.t. their inputs only) */,
                         float *out, float *err, const float *norm, float *Xn, const struct nlbac_rk_chain *chain,
                         nlbac_stream_t s);
+/* 4 when the net runs on the register-resident kernels (which can keep mask words), else 0 (activations only) */
+int nlbac_concat_rk_mask_words(const nlbac_mlp *net);
 int nlbac_concat_rk_bwd(const nlbac_mlp *net, int P, int rows_per_problem, int n_stages_total, int st_lo,
                         int st_hi, int dx_stage0, const float *beta, const float *h_host, const double *h_dev,
-                        int h_dev_stride, const float *acts, long acts_ls, float *dz, float *dK, const float *dYup,
+                        int h_dev_stride, const float *acts, long acts_ls, int acts_bits /* excludes dz */, float *dz,
+                        float *dK, const float *dYup,
                         float *dy0, int dy0_in, float *dc, int dc_acc, const float *norm, float *dyn,
                         const struct nlbac_rk_chain *chain, int back_idx, nlbac_stream_t s);
 /* dopri5 step control on the device.  ctl: per problem NLBAC_DOPRI_CTL doubles

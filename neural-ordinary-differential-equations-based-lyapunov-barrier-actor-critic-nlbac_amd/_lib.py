@@ -167,8 +167,9 @@ _PROTOS = {
     "nlbac_node_rk_bwd": [C.POINTER(Mlp), C.POINTER(Mlp), _P, _P, _I, _I, _I, _I, _I, _I, c_float_p, c_float_p, _P, _I,
                           _P, _L, _P, _L, _I, _P, _P, _P, _P, _P, _P, _I, _P, _I, C.POINTER(RkChain), _I, _P],
     "nlbac_concat_rk_fwd": [C.POINTER(Mlp), _P, _P, _I, _I, _I, _I, _I, c_float_p, c_float_p, _I, c_float_p, _I, c_float_p,
-                            _P, _I, _P, _P, _P, _L, _P, _P, _P, _P, C.POINTER(RkChain), _P],
-    "nlbac_concat_rk_bwd": [C.POINTER(Mlp), _I, _I, _I, _I, _I, _I, c_float_p, c_float_p, _P, _I, _P, _L, _P, _P, _P, _P,
+                            _P, _I, _P, _P, _P, _L, _I, _P, _P, _P, _P, C.POINTER(RkChain), _P],
+    "nlbac_concat_rk_mask_words": [C.POINTER(Mlp)],
+    "nlbac_concat_rk_bwd": [C.POINTER(Mlp), _I, _I, _I, _I, _I, _I, c_float_p, c_float_p, _P, _I, _P, _L, _I, _P, _P, _P, _P,
                             _I, _P, _I, _P, _P, C.POINTER(RkChain), _I, _P],
     "nlbac_node_adj_step": [C.POINTER(Mlp), C.POINTER(Mlp), _P, _I, _I, _I, _I, _I, c_float_p, c_float_p, _I, c_float_p,
                             _I, c_float_p, _P, _I, _P, _P, _P, _P, _P, _P, _P, _P, _L, _P, _L, _P, _P, _P],

@@ -10,38 +10,7 @@
 // 64 wide: two waves carry the MFMAs, all four share the VALU phases); several workgroups share a CU (LDS ~25 KB,
 // < 128 VGPRs), which is what hides the per-tile layer chain here.  Weights stream from their fragment-packed,
 // L2-resident copy straight into registers (WaveGemm), stage derivatives stay in LDS across stages.
-#include "mlp_device.h"
-#include "ode_control.h"
-
-#define CK_MAX_STAGES 8
-#define CK_NS 16          // LDS row stride of state-sized rows (n_s <= 16)
-#define CK_NC 4           // carried inputs per row (n_c <= 4)
-
-struct ConcatRkLaunch {
-    nlbac_mlp net;
-    const float* y0; const float* c;
-    int n, rpp, n_s, n_c;
-    int stage_begin, stage_end;
-    float beta[CK_MAX_STAGES][CK_MAX_STAGES];
-    float c_out[CK_MAX_STAGES]; int n_out;
-    float c_err[CK_MAX_STAGES]; int n_err;
-    const double* h_dev; int h_stride; float h_val[8];
-    float* K; float* Y;
-    float* acts; long acts_ls;
-    float* out; float* err;
-    // input normalisation / output de-normalisation of the field (the Quadrotor NODE, /root/reference/README.md:192):
-    // dx/dt = out_mu + out_sig * net(([x | c] - in_mu) * in_isig); norm = [in_mu | in_isig] (in_dim each) then
-    // [out_mu | out_sig] (n_s each), or null.  Xn: [stage][n][in_dim] normalised net inputs kept for the first layer's
-    // weight gradient (or null).
-    const float* norm; float* Xn;
-    int ld;
-    // device-driven dopri5 chain, as NodeRkLaunch (node_kernels.hip): step slots `slot_floats` apart, done problems
-    // skipped, FSAL from the previous slot, optional fused norm + controller epilogue
-    int S_total;
-    const double* ctl; long slot_floats;
-    int norm_mode, n_slots; float rtol, atol; double t_end;
-    float* partials; unsigned* tickets; double* ctl_w; double* hslots; double* alog; int alog_cap;
-};
+#include "concat_rk_shared.h"
 
 // NTHR = threads per workgroup.  Measured on the 64-wide reference net (two column tiles): 128-thread workgroups — only
 // the two MFMA-carrying waves, twice as many workgroups per CU — are 7-12 % SLOWER than 256: the VALU phases (stage
@@ -265,23 +234,6 @@ __global__ __launch_bounds__(NTHR) void concat_rk_fwd_kernel(const ConcatRkLaunc
 //     dY = [dYup at the last stage] + dX[:, :n_s];  dy0 += dY;  dK[j] += beta[st][j] h dY;  dc += dX[:, n_s:]
 // With dz given it also leaves every stage's pre-activation gradients for nlbac_mlp_bwd_weights (NODE fit).
 // ---------------------------------------------------------------------------
-struct ConcatRkBwdLaunch {
-    nlbac_mlp net;
-    const float* acts; long acts_ls;
-    float* dz;
-    float* dK; const float* dYup;
-    float* dy0; int dy0_in;
-    float* dc; int dc_acc;
-    int n, rpp, n_s, n_c, S_total, st_lo, st_hi, dx_stage0;
-    float beta[CK_MAX_STAGES][CK_MAX_STAGES];
-    const double* h_dev; int h_stride; float h_val[8];
-    const float* norm;                // as ConcatRkLaunch::norm
-    float* dyn;                       // [stage][n][n_s] gradient w.r.t. the net's own output (dK * out_sig), kept with dz
-    int ld;
-    // device-driven chain, as NodeRkBwdLaunch: launch back_idx differentiates slot C_NACC - back_idx of each problem
-    const double* ctl; long slot_floats; int back_idx, n_slots; const double* hslots;
-};
-
 template <int NTHR>
 __global__ __launch_bounds__(NTHR) void concat_rk_bwd_kernel(const ConcatRkBwdLaunch L) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
@@ -444,8 +396,8 @@ extern "C" int nlbac_concat_rk_fwd(const nlbac_mlp* net, const float* y0, const 
                                    int stage_begin, int stage_end, int n_stages_total, const float* beta,
                                    const float* c_out, int n_out, const float* c_err, int n_err, const float* h_host,
                                    const double* h_dev, int h_dev_stride, float* K, float* Y, float* acts, long acts_ls,
-                                   float* out, float* err, const float* norm, float* Xn, const nlbac_rk_chain* chain,
-                                   nlbac_stream_t s) {
+                                   int acts_bits, float* out, float* err, const float* norm, float* Xn,
+                                   const nlbac_rk_chain* chain, nlbac_stream_t s) {
     if (concat_check(net, P, rows_per_problem, n_stages_total, "nlbac_concat_rk_fwd")) return -1;
     NLBAC_REQUIRE(y0 && c && K && Y, "nlbac_concat_rk_fwd: null pointer");
     NLBAC_REQUIRE(stage_begin >= 0 && stage_begin < stage_end && stage_end <= n_stages_total,
@@ -467,7 +419,8 @@ extern "C" int nlbac_concat_rk_fwd(const nlbac_mlp* net, const float* y0, const 
     L.n_out = out ? n_out : 0; L.n_err = err ? n_err : 0;
     L.h_dev = h_dev; L.h_stride = h_dev_stride;
     for (int p = 0; p < P; ++p) L.h_val[p] = h_host ? h_host[p] : 0.f;
-    L.K = K; L.Y = Y; L.acts = acts; L.acts_ls = acts_ls;
+    L.K = K; L.Y = Y; L.acts = acts; L.acts_ls = acts_ls; L.acts_bits = acts_bits;
+    NLBAC_REQUIRE(!acts_bits || nlbac_concat_rr_eligible(net), "nlbac_concat_rk_fwd: mask words need the register-resident kernels (nlbac_concat_rk_mask_words)");
     L.out = out; L.err = err;
     NLBAC_REQUIRE(norm || !Xn, "nlbac_concat_rk_fwd: Xn goes with norm");
     L.norm = norm; L.Xn = Xn;
@@ -485,6 +438,10 @@ extern "C" int nlbac_concat_rk_fwd(const nlbac_mlp* net, const float* y0, const 
         L.partials = chain->partials; L.tickets = chain->tickets; L.ctl_w = chain->ctl_w; L.hslots = chain->hslots;
         L.alog = chain->alog; L.alog_cap = chain->alog_cap;
     }
+    {   // the reference's depth at widths 64 / 100 / 128 runs on the register-resident kernels (concat_rr_kernels.hip)
+        const int rr = nlbac_concat_rr_fwd_launch(L, (hipStream_t)s);
+        if (rr <= 0) return rr;
+    }
     const int in_p = (net->in_dim + 7) & ~7, hid_p = (net->hid + 7) & ~7;
     L.ld = (hid_p > in_p ? hid_p : in_p) + 4;
     const size_t lds = ((size_t)2 * NLBAC_MLP_TILE * L.ld + CK_MAX_STAGES * NLBAC_MLP_TILE * CK_NS +
@@ -498,8 +455,8 @@ extern "C" int nlbac_concat_rk_fwd(const nlbac_mlp* net, const float* y0, const 
 
 extern "C" int nlbac_concat_rk_bwd(const nlbac_mlp* net, int P, int rows_per_problem, int n_stages_total, int st_lo,
                                    int st_hi, int dx_stage0, const float* beta, const float* h_host,
-                                   const double* h_dev, int h_dev_stride, const float* acts, long acts_ls, float* dz,
-                                   float* dK, const float* dYup, float* dy0, int dy0_in, float* dc, int dc_acc,
+                                   const double* h_dev, int h_dev_stride, const float* acts, long acts_ls, int acts_bits,
+                                   float* dz, float* dK, const float* dYup, float* dy0, int dy0_in, float* dc, int dc_acc,
                                    const float* norm, float* dyn, const nlbac_rk_chain* chain, int back_idx,
                                    nlbac_stream_t s) {
     if (concat_check(net, P, rows_per_problem, n_stages_total, "nlbac_concat_rk_bwd")) return -1;
@@ -517,7 +474,8 @@ extern "C" int nlbac_concat_rk_bwd(const nlbac_mlp* net, int P, int rows_per_pro
         L.hslots = chain->hslots;
     }
     L.net = *net;
-    L.acts = acts; L.acts_ls = acts_ls; L.dz = dz;
+    L.acts = acts; L.acts_ls = acts_ls; L.acts_bits = acts_bits; L.dz = dz;
+    NLBAC_REQUIRE(!acts_bits || (nlbac_concat_rr_eligible(net) && !dz), "nlbac_concat_rk_bwd: mask words need the register-resident kernels and exclude dz");
     L.dK = dK; L.dYup = dYup; L.dy0 = dy0; L.dy0_in = dy0_in; L.dc = dc; L.dc_acc = dc_acc;
     L.n = P * rows_per_problem; L.rpp = rows_per_problem;
     L.n_s = net->out_dim; L.n_c = net->in_dim - net->out_dim;
@@ -530,6 +488,10 @@ extern "C" int nlbac_concat_rk_bwd(const nlbac_mlp* net, int P, int rows_per_pro
     NLBAC_REQUIRE(norm || !dyn, "nlbac_concat_rk_bwd: dyn goes with norm");
     NLBAC_REQUIRE(!norm || !dz || dyn, "nlbac_concat_rk_bwd: weight gradients of a normalised field need dyn");
     L.norm = norm; L.dyn = dyn;
+    {
+        const int rr = nlbac_concat_rr_bwd_launch(L, (hipStream_t)s);
+        if (rr <= 0) return rr;
+    }
     L.ld = ((net->hid + 31) & ~31) + 4;
     const size_t lds = ((size_t)2 * NLBAC_MLP_TILE * L.ld + CK_MAX_STAGES * NLBAC_MLP_TILE * CK_NS +
                         NLBAC_MLP_TILE * (1 + CK_NS + CK_NC + CK_NS + 16) +
@@ -538,4 +500,10 @@ extern "C" int nlbac_concat_rk_bwd(const nlbac_mlp* net, int P, int rows_per_pro
     hipLaunchKernelGGL(concat_rk_bwd_kernel<256>, dim3(nlbac_ceil_div(L.n, NLBAC_MLP_TILE)), dim3(256), lds, (hipStream_t)s, L);
     NLBAC_CHECK_LAUNCH("nlbac_concat_rk_bwd");
     return 0;
+}
+
+extern "C" int nlbac_concat_rk_mask_words(const nlbac_mlp* net) {
+    // uint32 words per row and layer of the ReLU masks nlbac_concat_rk_fwd can write instead of the activations
+    // (acts_bits): 4 when the net runs on the register-resident kernels, 0 = not available (activations only)
+    return (net && nlbac_concat_rr_eligible(net)) ? 4 : 0;
 }

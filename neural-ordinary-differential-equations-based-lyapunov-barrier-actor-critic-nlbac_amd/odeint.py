@@ -1317,7 +1317,16 @@ class _ConcatStepWS:
         z = self._store.zeros
         self.K = z(S, n, ns)
         self.Y = z(S, n, ns)
-        self.acts = z(net.n_layers - 1, S * n, net.hid)
+        # a rollout that is only differentiated w.r.t. its inputs keeps ReLU mask words instead of the activations, where
+        # the fused kernels can (the register-resident ones: nlbac_concat_rk_mask_words)
+        words = _lib.load().nlbac_concat_rk_mask_words(C.byref(net.desc)) if (solver.fused and not solver.keep_acts) else 0
+        self.bits = words > 0
+        if self.bits:
+            self.wa = words
+            self.acts = self._store.zeros(net.n_layers - 1, S * n, words, dtype=torch.int32)
+        else:
+            self.wa = net.hid
+            self.acts = z(net.n_layers - 1, S * n, net.hid)
         self.y1 = z(n, ns)
         self.err = z(n, ns)
         self.io_fwd, self.io_bwd = {}, {}
@@ -1477,10 +1486,10 @@ class ConcatNodeSolver(AffineNodeSolver):
                   c_out, len(c_out) if c_out is not None else 0, c_err, len(c_err) if c_err is not None else 0,
                   fptr(*h_host) if h_host is not None else None, h_dev, _lib.DOPRI_CTL if h_dev else 0,
                   ws.K.data_ptr(), ws.Y.data_ptr(), ws.acts.data_ptr() if save_acts else None,
-                  ws.S * P * rpp * self.net.hid, out.data_ptr() if out is not None else None,
+                  ws.S * P * rpp * ws.wa, 1 if ws.bits else 0, out.data_ptr() if out is not None else None,
                   err.data_ptr() if err is not None else None,
                   self.norm.data_ptr() if self.norm is not None else None,
-                  ws.Xn.data_ptr() if (self.norm is not None and save_acts) else None,
+                  ws.Xn.data_ptr() if (self.norm is not None and save_acts and self.keep_acts) else None,
                   C.byref(chain) if chain is not None else None, stream_ptr())
         self.nfe += st1 - st0
 
@@ -1490,7 +1499,7 @@ class ConcatNodeSolver(AffineNodeSolver):
         S = ws.S
         _lib.call("nlbac_concat_rk_bwd", C.byref(self.net.desc), P, rpp, S, 0 if first_eval else 1, S,
                   1 if need_dy0 else 0, beta_arr, h_host, h_dev, h_stride, ws.acts.data_ptr(),
-                  S * ws.n * self.net.hid, ws.dz.data_ptr() if need_params else None, ws.dK.data_ptr(),
+                  S * ws.n * ws.wa, 1 if ws.bits else 0, ws.dz.data_ptr() if need_params else None, ws.dK.data_ptr(),
                   top_up.data_ptr() if top_up is not None else None, ws.dy0.data_ptr(), 1,
                   du.data_ptr() if du is not None else None, 0 if last else 1,
                   self.norm.data_ptr() if self.norm is not None else None,

@@ -344,6 +344,7 @@ class CarsTask(_Task):
         a = self.agent
         self.solver1 = ConcatNodeSolver(a.neural_ode_model, a.device)     # x_t   -> x_t+1 (2B rows)
         self.solver2 = ConcatNodeSolver(a.neural_ode_model, a.device)     # x_t+1 -> x_t+2
+        self.solver1.keep_acts = self.solver2.keep_acts = False           # differentiated w.r.t. state / carried inputs only
         self.fit_solver = ConcatNodeSolver(a.neural_ode_model, a.device)
         self.solvers = [self.solver1, self.solver2, self.fit_solver]
 
@@ -733,6 +734,7 @@ class QuadrotorBarrierTask(PvtolBarrierTask):
     def setup(self):
         a = self.agent
         self.solver = ConcatNodeSolver(a.neural_ode_model, a.device)       # carried inputs = the action
+        self.solver.keep_acts = False                                      # differentiated w.r.t. the action only
         self.fit_solver = ConcatNodeSolver(a.neural_ode_model, a.device)
         self.solvers = [self.solver, self.fit_solver]
 
