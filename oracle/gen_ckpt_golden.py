@@ -7,7 +7,8 @@ reference agent (another seed) then restores them with the reference's ``load_we
 reference's loader leaves out) and runs one ``update_parameters``; its outputs go to ``ckpt_<env>/expected.npz``.  The
 build must load the same files (weights-only loader) and reproduce that update (tests/test_checkpoint_golden_gpu.py).
 
-Usage: python oracle/gen_ckpt_golden.py --env Unicycle|UnicycleBarrier
+Usage: python oracle/gen_ckpt_golden.py --env Unicycle|UnicycleBarrier|SimulatedCars|Pvtol|PvtolBarrier
+(one env per process: the five copies share module names)
 """
 import argparse
 import os
@@ -29,7 +30,7 @@ HIDDEN, B, SEED_A, SEED_B = 64, 64, 3, 5
 
 def main():
     ap = argparse.ArgumentParser()
-    ap.add_argument("--env", default="Unicycle", choices=["Unicycle", "UnicycleBarrier"])
+    ap.add_argument("--env", default="Unicycle", choices=["Unicycle", "UnicycleBarrier", "SimulatedCars", "Pvtol", "PvtolBarrier"])
     env_name = ap.parse_args().env
     M, S = G.import_reference(env_name)
     torch.set_num_threads(1)
@@ -74,7 +75,8 @@ def main():
     G.summarize("pre_critic_target", G.flat_params(b.critic_target), out)     # the loader leaves the targets alone
     G.summarize("pre_critic", G.flat_params(b.critic), out)
     try:
-        ret = b.update_parameters(G.FakeMemory(tr, idx, fields), B, 0, dyn, G.FakeMemory(tr, nidx, fields), 10)
+        extra = (0,) if env_name.startswith("Pvtol") else ()          # P / NP: trailing i_episode argument
+        ret = b.update_parameters(G.FakeMemory(tr, idx, fields), B, 0, dyn, G.FakeMemory(tr, nidx, fields), 10, *extra)
     finally:
         torch.distributions.Normal.rsample = orig
     out["ret"] = np.array(ret, dtype=np.float64)

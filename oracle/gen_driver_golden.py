@@ -33,6 +33,7 @@ from oracle.gen_golden import REFS  # noqa: E402
 # episodes / steps per episode of the trace, and the scripted agent's behaviour per env: the primary controller's
 # actions are chosen so that every hand-over rule fires (standing still -> "stuck", braking into the car behind, ...)
 SCRIPT = {
+    "SimulatedCarsHandover": dict(episodes=6, max_steps=90, start_steps=20),      # ScriptedCarsEnv below, not the simulator
     "Unicycle": dict(episodes=7, max_steps=160, start_steps=40),
     "UnicycleBarrier": dict(episodes=3, max_steps=120, start_steps=40),
     "SimulatedCars": dict(episodes=6, max_steps=300, start_steps=30),
@@ -95,6 +96,56 @@ class ScriptedAgent:
         pass
 
 
+class ScriptedCarsEnv:
+    """A stand-in for the SimulatedCars ENVIRONMENT whose observations follow a script instead of the car dynamics: the
+    reference simulator's 5th car keeps its own distance, so the hand-over condition of C/main.py:102-112 — 4th car
+    within 2.5 of the 5th WHILE the following distance to the 3rd is met (``info['reached']``) — never fires on it
+    (tests/golden/driver_SimulatedCars.npz: 0 backup steps).  Here the gaps are scripted so that every branch fires: a
+    hand-over ended by the 15-step cap, one ended after 5 steps by both gaps re-opening, a close approach WITHOUT
+    ``reached`` (no hand-over), and one that is cut off by the end of the episode.  Same 7-tuple as the reference's
+    ``SimulatedCarsEnv.step`` (next_obs, reward, constraint, cur_pos_vel_info, next_pos_vel_info, done, info)."""
+    dt = 0.02
+
+    def __init__(self, max_episode_steps=90):
+        self.max_episode_steps = max_episode_steps
+        lo, hi = np.array([-10.0]), np.array([10.0])
+        self.action_space = type("Box", (), dict(low=lo, high=hi, shape=(1,)))()
+        self.k = 0
+        self.episode = -1
+
+    @staticmethod
+    def gaps(k):
+        """(d34, d45, reached) after step k of an episode, in the units the driver compares with 2.5"""
+        if k == 10: return 9.5, 2.0, 1            # -> hand-over ...
+        if 10 < k < 40: return 2.0, 2.0, 1        # ... gaps never re-open: ended by the 15-step cap (and taken again)
+        if k == 45: return 9.5, 2.0, 0            # close, but the following distance is not met: no hand-over
+        if k == 50: return 9.5, 1.0, 1            # -> hand-over ...
+        if 50 < k < 53: return 2.0, 2.0, 1
+        if 53 <= k < 70: return 5.0, 5.0, 1       # ... both gaps open again: ended once 5 backup steps have passed
+        if k >= 85: return 9.5, 2.0, 1            # -> hand-over cut off by the end of the episode
+        return 9.5, 6.0, 0
+
+    def _obs(self, k):
+        d34, d45, _ = self.gaps(k)
+        p3 = 0.6 + 0.001 * k + 0.01 * self.episode
+        p4, p5 = p3 - d34 / 100.0, p3 - d34 / 100.0 - d45 / 100.0
+        return np.array([p3 + 0.2, 0.3, p3 + 0.1, 0.3, p3, 0.3 + 0.001 * k, p4, 0.29, p5, 0.28])
+
+    def reset(self):
+        self.k = 0
+        self.episode += 1
+        return self._obs(0)
+
+    def step(self, action):
+        cur = self._obs(self.k)
+        self.k += 1
+        nxt = self._obs(self.k)
+        _, _, reached = self.gaps(self.k)
+        done = self.k >= self.max_episode_steps
+        info = {"reached": reached, "num_safety_violation": 0, "safety_cost": 0.0}
+        return (nxt, -0.01 * self.k + float(action[0]) * 1e-3, 0.0, cur[4:8].copy(), nxt[4:8].copy(), done, info)
+
+
 class Recorder:
     """Replay stand-in that records what the driver pushes (and counts like ``len(ReplayMemory)``)."""
 
@@ -144,6 +195,10 @@ def stub_modules():
 
 
 def run(env_name):
+    scripted_env = env_name == "SimulatedCarsHandover"
+    out_name = env_name
+    if scripted_env:
+        env_name = "SimulatedCars"
     ref = REFS[env_name]
     stub_modules()
     sys.path.insert(0, ref)
@@ -168,7 +223,7 @@ def run(env_name):
             pass
     M.writer = W()
     M.prYellow = M.prGreen = lambda *a, **k: None
-    cfg = SCRIPT[env_name]
+    cfg = SCRIPT[out_name]
     recs = {"memory": None, "node": None}
 
     def make_memory(*a, **k):
@@ -179,7 +234,7 @@ def run(env_name):
     args = types.SimpleNamespace(env=env_name.replace("Barrier", ""), env_name=env_name.replace("Barrier", ""), seed=0, replay_size=1000, batch_size=16,
                                  updates_per_step=1, start_steps=cfg["start_steps"], max_episodes=cfg["episodes"],
                                  NODE_model_update_interval=10, output="/tmp", cuda=False)
-    env = M.build_env(args)
+    env = ScriptedCarsEnv(cfg["max_steps"]) if scripted_env else M.build_env(args)
     env.max_episode_steps = cfg["max_steps"]
     agent = ScriptedAgent(env_name, env.action_space, pattern=PATTERN)
     steps = []
@@ -212,7 +267,7 @@ def run(env_name):
             pushed[i] = 1
             j += 1
     assert j == len(mem.rows)
-    out = dict(meta_pattern=PATTERN, meta_env=env_name, meta_episodes=cfg["episodes"], meta_max_steps=cfg["max_steps"],
+    out = dict(meta_pattern=PATTERN, meta_env=out_name, meta_episodes=cfg["episodes"], meta_max_steps=cfg["max_steps"],
                meta_start_steps=cfg["start_steps"], meta_batch_size=args.batch_size,
                obs=np.stack([s[0] for s in steps]), reward=np.array([s[1] for s in steps]),
                constraint=np.array([s[2] for s in steps]), extra=np.array([s[3] for s in steps], dtype=np.float64),
@@ -224,7 +279,7 @@ def run(env_name):
                mem_t=np.array([r[1] for r in mem.rows]), mem_next_t=np.array([r[2] for r in mem.rows]),
                node_t=np.array([r[1] for r in node.rows]), mask=np.array([float(r[0][-1]) for r in node.rows]),
                updates=agent.updates)
-    path = os.path.join(ROOT, "tests", "golden", "driver_%s.npz" % env_name)
+    path = os.path.join(ROOT, "tests", "golden", "driver_%s.npz" % out_name)
     np.savez_compressed(path, **out)
     print(path, os.path.getsize(path), "bytes;", n, "steps;", int(out["backup"].sum()), "backup steps;",
           int(n - pushed.sum()), "kept out of memory; updates", agent.updates)

@@ -18,7 +18,7 @@ pytestmark = pytest.mark.gpu
 GOLD = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
 
 
-@pytest.mark.parametrize("env_name", ["Unicycle", "UnicycleBarrier"])
+@pytest.mark.parametrize("env_name", ["Unicycle", "UnicycleBarrier", "SimulatedCars", "Pvtol", "PvtolBarrier"])
 def test_reference_written_checkpoint_loads_and_reproduces_the_next_update(env_name):
     from oracle.nlbac_oracle import Args
     if env_name.endswith("Barrier"):
@@ -52,7 +52,8 @@ def test_reference_written_checkpoint_loads_and_reproduces_the_next_update(env_n
     tr = synth.transitions(env_name, 4096, seed=seed + 1, env=env)
     fields = synth.fields(env_name)
     agent.set_noise(synth.normal_eps(agent.task.n_eps, B, env.n_u, seed=9))
-    node = tuple(tr[f][g["nidx"]] for f in ("obs", "action", "next_obs"))
+    node_fields = ("obs", "action", "next_obs", "t") if env_name == "SimulatedCars" else ("obs", "action", "next_obs")
+    node = tuple(tr[f][g["nidx"]] for f in node_fields)
     ret = agent.update_from_host(tuple(tr[f][g["idx"]] for f in fields), 0, node)
     torch.cuda.synchronize()
     vec_close(ret, g["ret"], 1e-4, "returned floats after loading the reference's checkpoint")

@@ -5,7 +5,9 @@ which transitions were kept out of the controller replay, the time stamps both r
 through ``nlbac_amd.train.train`` on ``nlbac_amd.envs`` must reproduce the trace: the simulators to 1e-12, the
 driver's decisions exactly.  (SimulatedCars: the reference's hand-over condition — 4th car within 2.5 of the 5th while
 its distance to the 3rd is in range — is not reachable with the 5th car's own braking rule, so that trace pins the
-simulator, the time stamps and the absence of hand-overs.)"""
+simulator, the time stamps and the absence of hand-overs; the hand-over itself is pinned by
+``driver_SimulatedCarsHandover.npz``: the reference's loop on a scripted stand-in ENVIRONMENT whose gaps make every
+branch of C/main.py:102-112 fire.)"""
 import os
 import types
 
@@ -13,7 +15,7 @@ import numpy as np
 import pytest
 
 from nlbac_amd import envs, train
-from oracle.gen_driver_golden import Recorder, ScriptedAgent
+from oracle.gen_driver_golden import Recorder, ScriptedAgent, ScriptedCarsEnv
 
 GOLD = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
 
@@ -65,3 +67,31 @@ def test_driver_and_simulator_reproduce_the_reference_trace(name):
     np.testing.assert_array_equal([float(r[0][-1]) for r in node.rows], g["mask"])
     if name in ("Unicycle", "Pvtol"):
         assert g["backup"].sum() > 0 and (g["pushed"] == 0).sum() == g["backup"].sum()
+
+
+def test_cars_handover_reproduces_the_reference_loop():
+    """``_CarsHandover`` against the reference's own ``main.py::train`` (C/main.py:41-112) on ``ScriptedCarsEnv``: which
+    controller acted at every step (hand-overs ended by the 15-step cap, by both gaps re-opening after 5 steps, by the
+    end of the episode; a close approach without ``reached`` that must NOT hand over), which transitions were kept out
+    of the controller replay, the time stamps of both replays, the number of updates."""
+    g = np.load(os.path.join(GOLD, "driver_SimulatedCarsHandover.npz"))
+    env = ScriptedCarsEnv(int(g["meta_max_steps"]))
+    agent = ScriptedAgent("SimulatedCars", env.action_space, pattern=int(g["meta_pattern"]))
+    args = types.SimpleNamespace(env="SimulatedCars", batch_size=int(g["meta_batch_size"]), updates_per_step=1,
+                                 start_steps=int(g["meta_start_steps"]), max_episodes=int(g["meta_episodes"]),
+                                 NODE_model_update_interval=10, output=None, max_steps=0)
+    mem, node, trace = Recorder(), Recorder(), []
+    train.train(agent, env, None, args, mem, node, log=lambda *a: None, trace=trace)
+    assert g["backup"].sum() > 100 and len(trace) == len(g["backup"])
+    np.testing.assert_array_equal(agent.calls, g["backup"])
+    np.testing.assert_array_equal([int(b) for b, _ in trace], g["backup"])
+    np.testing.assert_array_equal([int(p) for _, p in trace], g["pushed"])
+    assert (g["pushed"] == 0).sum() == g["backup"].sum()
+    # every kind of ending occurs in the trace: runs of 15 backup steps (the cap) and shorter ones (gaps re-opened / episode end)
+    runs = np.diff(np.flatnonzero(np.diff(np.concatenate([[0], g["backup"], [0]]))).reshape(-1, 2), axis=1).reshape(-1)
+    assert (runs == 15).any() and (runs == 5).any(), runs
+    assert agent.updates == int(g["updates"])
+    np.testing.assert_allclose([r[1] for r in mem.rows], g["mem_t"], rtol=0, atol=1e-12)
+    np.testing.assert_allclose([r[2] for r in mem.rows], g["mem_next_t"], rtol=0, atol=1e-12)
+    np.testing.assert_allclose([r[1] for r in node.rows], g["node_t"], rtol=0, atol=1e-12)
+    np.testing.assert_array_equal([float(r[0][-1]) for r in node.rows], g["mask"])
