@@ -1020,6 +1020,8 @@ extern "C" int nlbac_mlp_bwd_weights(const nlbac_mlp* nets, const nlbac_mlp_io* 
         // nlbac_mlp_bwd_data has already left this net's partial sums in its block of ws (nlbac_mlp_io::skinny_ws)
         partials_ready = partials_ready && io[i].skinny_ws == ws + (long)i * S.net_stride;
     }
+    if (!partials_ready && nlbac_mlp_dw16_eligible(nets, n_nets, B))       // every layer's dW and db in one launch
+        return nlbac_mlp_dw16_launch(L, n_nets, (hipStream_t)s);
     if (max_blocks > 0) {
         bool narrow = true;
         int max_layers = 0;

@@ -18,3 +18,7 @@ struct MlpLaunch {
 // take the launch), < 0 = error.
 int nlbac_mlp_rr_fwd_launch(const MlpLaunch& L, int n_nets, const nlbac_gauss_head& G, const char* who, hipStream_t s);
 bool nlbac_mlp_rr_eligible(const nlbac_mlp* nets, int n_nets);
+
+// The one-launch weight/bias gradients of narrow nets (mlp_dw16_kernels.hip; NLBAC_MLP_DW16=0 keeps the older kernels).
+bool nlbac_mlp_dw16_eligible(const nlbac_mlp* nets, int n_nets, int B);
+int nlbac_mlp_dw16_launch(const MlpLaunch& L, int n_nets, hipStream_t s);

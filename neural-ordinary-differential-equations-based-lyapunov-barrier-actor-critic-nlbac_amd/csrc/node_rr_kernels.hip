@@ -153,12 +153,20 @@ __global__ __launch_bounds__(256) void node_rr_fwd_kernel(const NodeRkLaunch L) 
         prefetch_bias(1);
 
         // what the backward needs of a finished value goes out once: a mask bit (word per layer), or the activation itself
-        auto save_block = [&](int l, int jo, const float (&H)[KS]) __attribute__((always_inline)) {
+        // (activation mode) a finished layer's activations leave in ONE burst, issued where the product that consumes
+        // them starts its last group of blocks — by then the layer's pending tail is finished too.  Stores share the
+        // loads' in-order vmcnt queue: issued one by one between the fragment loads, each made the MFMAs behind it wait
+        // for its own trip to HBM; as a burst the trips overlap and the stream stalls once per layer.
+        auto save_layer = [&](int l, const float (&H)[KS]) __attribute__((always_inline)) {
             if (BITS || !acts || !row_ok) return;
-            f32x4 hv{0.f, 0.f, 0.f, 0.f};
+            float* rowp = acts + (long)l * acts_ls + srow * HID;
 #pragma unroll
-            for (int rr = 0; rr < ((jo < NB - 1) ? 4 : R); ++rr) hv[rr] = H[4 * jo + rr];
-            rr_row_store<S>(acts + (long)l * acts_ls + srow * HID, jo, q, hv);
+            for (int jo = 0; jo < NB; ++jo) {
+                f32x4 hv{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                for (int rr = 0; rr < ((jo < NB - 1) ? 4 : R); ++rr) hv[rr] = H[4 * jo + rr];
+                rr_row_store<S>(rowp, jo, q, hv);
+            }
         };
         auto save_word = [&](int l, unsigned word) __attribute__((always_inline)) {
             if (BITS && acts && row_ok) reinterpret_cast<unsigned*>(acts + (long)l * acts_ls)[srow * 4 + q] = word;
@@ -169,7 +177,6 @@ __global__ __launch_bounds__(256) void node_rr_fwd_kernel(const NodeRkLaunch L) 
             const float h = rr_relu(acc0[jo][r]);
             Ha[ks] = h;
             if (BITS) rr_mask_push(wd, h);
-            if (r == ((jo < NB - 1) ? 3 : R - 1)) save_block(0, jo, Ha);
             if (ks == KS - 1) save_word(0, wd);
         };
         // the tail of hid x hid layer lp (blocks TB, TB+1 of `acc`), finished inside the product that follows it: value t
@@ -180,7 +187,6 @@ __global__ __launch_bounds__(256) void node_rr_fwd_kernel(const NodeRkLaunch L) 
             const float h = rr_relu(acc[jo][r]);
             H[4 * TB + t] = h;
             if (BITS) rr_mask_push(wd, h);
-            if (t == 3 || t == NT - 1) save_block(lp, jo, H);
             if (t == NT - 1) save_word(lp, wd);
         };
 
@@ -239,15 +245,18 @@ __global__ __launch_bounds__(256) void node_rr_fwd_kernel(const NodeRkLaunch L) 
                          const float h = rr_relu(acc[jo][r]);
                          Hout[4 * jo + r] = h;
                          if (BITS) rr_mask_push(wd, h);
-                         if (r == 3) save_block(l, jo, Hout);
                      },
-                     [&]() __attribute__((always_inline)) { if (l + 1 < nw) prefetch_bias(l + 1); });
+                     [&]() __attribute__((always_inline)) {
+                         if (l + 1 < nw) prefetch_bias(l + 1);
+                         save_layer(l - 1, Hin);
+                     });
             RSTAMP(sb + 1 + l)
         };
         // output layer (<= 16 outputs: one block), to LDS for k = f + g u; g(x) also to global for the backward
         auto outl = [&](auto lc, float (&Hin)[KS]) __attribute__((always_inline)) {
             constexpr int l = decltype(lc)::value;            // (= nw: the layers before it are 0 .. l-1)
             const f32x4 o = RRGemm<S>::block(wo, Hin, [&](int ks) __attribute__((always_inline)) { pre_tail(l - 1, Hin, ks); });
+            save_layer(l - 1, Hin);
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
                 if (o_idx[r] < 0) continue;
@@ -420,8 +429,8 @@ __global__ __launch_bounds__(256) void node_rr_bwd_kernel(const NodeRkBwdLaunch 
         // ReLU masks of a layer's outputs for this lane's units: one word (mask mode) or the activations themselves,
         // requested before the product they gate so that they land under it; `*t`: those of the pending tail / top product
         unsigned mw = 0u, mwt = 0u;
-        f32x4 av[NB], avt[2];
-        auto fetch_masks = [&](int l) __attribute__((always_inline)) {
+        f32x4 avA[NB], avB[NB], avt[2];       // (activation mode) two sets: a product's masks are requested one product ahead
+        auto fetch_masks = [&](int l, f32x4 (&av)[NB]) __attribute__((always_inline)) {
             if (BITS) {        // (rows past the end contribute nothing: their word is cleared once)
                 mw = reinterpret_cast<const unsigned*>(acts + (long)l * acts_ls)[srow * 4 + q];
                 mw = row_ok ? mw : 0u;
@@ -432,31 +441,36 @@ __global__ __launch_bounds__(256) void node_rr_bwd_kernel(const NodeRkBwdLaunch 
                 for (int jo = 0; jo < NB; ++jo) av[jo] = rr_row_load<S>(arow, jo, q);
             }
         };
-        auto save_block = [&](int l, int jo, const float (&Z)[KS]) __attribute__((always_inline)) {
+        // (activation mode, weight gradients wanted) a finished dz leaves in one burst inside the product that consumes it,
+        // like the forward's activations (see there)
+        auto save_dz = [&](int l, const float (&Z)[KS]) __attribute__((always_inline)) {
             if (BITS || !dz || !row_ok) return;
-            f32x4 zv{0.f, 0.f, 0.f, 0.f};
+            float* rowp = dz + (long)l * acts_ls + ((long)st * n + grow) * HID;
 #pragma unroll
-            for (int rr = 0; rr < ((jo < NB - 1) ? 4 : R); ++rr) zv[rr] = Z[4 * jo + rr];
-            rr_row_store<S>(dz + (long)l * acts_ls + ((long)st * n + grow) * HID, jo, q, zv);
+            for (int jo = 0; jo < NB; ++jo) {
+                f32x4 zv{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                for (int rr = 0; rr < ((jo < NB - 1) ? 4 : R); ++rr) zv[rr] = Z[4 * jo + rr];
+                rr_row_store<S>(rowp, jo, q, zv);
+            }
         };
         // the top product's value ks (mask mode: finished just before the next product's k-step ks reads it)
         auto pre_top = [&](int ks) __attribute__((always_inline)) {
             const int jo = (ks < 4 * (NB - 1)) ? (ks >> 2) : NB - 1, r = ks - 4 * jo;
             if (BITS) Za[ks] = rr_mask_gate<KS>(mwt, ks, acct[jo][r]);
-            else Za[ks] = (row_ok && av[jo][r] > 0.f) ? acct[jo][r] : 0.f;
-            if (r == ((jo < NB - 1) ? 3 : R - 1)) save_block(nw - 1, jo, Za);
+            else Za[ks] = (row_ok && avA[jo][r] > 0.f) ? acct[jo][r] : 0.f;
         };
         // the tail (blocks TB, TB+1 of `acc`) of the product that produced dz of layer lp, finished inside the next one
-        auto pre_tail = [&](int lp, float (&Z)[KS], int t) __attribute__((always_inline)) {
+        auto pre_tail = [&](float (&Z)[KS], int t) __attribute__((always_inline)) {
             if (t >= NT) return;
             const int jo = TB + (t >> 2), r = t & 3;
             if (BITS) Z[4 * TB + t] = rr_mask_gate<KS>(mwt, 4 * TB + t, acc[jo][r]);
             else Z[4 * TB + t] = (row_ok && avt[jo - TB][r] > 0.f) ? acc[jo][r] : 0.f;
-            if (t == 3 || t == NT - 1) save_block(lp, jo, Z);
         };
 
-        // ---- top product: dz_top = mask_top * (W_out^T dy)
-        fetch_masks(nw - 1);
+        // ---- top product: dz_top = mask_top * (W_out^T dy); the first chain product's masks are requested with its own
+        fetch_masks(nw - 1, avA);
+        if (!BITS) fetch_masks(nw - 2, avB);
         {
             float at[4][NB];
 #pragma unroll
@@ -491,30 +505,35 @@ __global__ __launch_bounds__(256) void node_rr_bwd_kernel(const NodeRkBwdLaunch 
         }
         // ---- dz_{nw-1-p} = mask * (W_{nw-p}^T dz_{nw-p}), p = 1 .. nw-1, then dX = W_0^T dz_0 (one block); statically
         //      unrolled (pc: the product index as a type): a product reads one dz set and writes the other
-        auto prod = [&](auto pc, float (&Zin)[KS], float (&Zout)[KS]) __attribute__((always_inline)) {
+        // (avC: this product's masks — already requested; avN: where the next product's go)
+        auto prod = [&](auto pc, float (&Zin)[KS], float (&Zout)[KS], f32x4 (&avC)[NB], f32x4 (&avN)[NB]) __attribute__((always_inline)) {
             constexpr int p = decltype(pc)::value;
             const int lo = nw - 1 - p;                            // the layer whose dz this product yields
-            mwt = mw; avt[0] = av[TB]; avt[1] = av[TB + 1];
-            fetch_masks(lo);
+            mwt = mw;
+            if (BITS) fetch_masks(lo, avC);
             __builtin_amdgcn_sched_barrier(0);
             const int cur = wbase + lo * S::LAYER_BYTES;              // fragments of layer lo + 1 sit at index lo
             const int nxt = (lo >= 1) ? cur - S::LAYER_BYTES : wbase + (nw - 2) * S::LAYER_BYTES;
             gemm.run(acc, zero, Zin, rs, voff, cur, nxt,
                      [&](int ks) __attribute__((always_inline)) {
                          if (p == 1) { if (defer_top) pre_top(ks); }
-                         else pre_tail(lo + 1, Zin, ks);
+                         else pre_tail(Zin, ks);
                      },
                      [&](int jo, int r) __attribute__((always_inline)) {
                          if (BITS) Zout[4 * jo + r] = rr_mask_gate<KS>(mw, 4 * jo + r, acc[jo][r]);
-                         else Zout[4 * jo + r] = (row_ok && av[jo][r] > 0.f) ? acc[jo][r] : 0.f;
-                         if (r == 3) save_block(lo, jo, Zout);
+                         else Zout[4 * jo + r] = (row_ok && avC[jo][r] > 0.f) ? acc[jo][r] : 0.f;
                      },
-                     [&]() __attribute__((always_inline)) {});
+                     [&]() __attribute__((always_inline)) {
+                         save_dz(lo + 1, Zin);                        // (Zin is complete: its tail was finished in group 0)
+                         if (!BITS && lo >= 1) fetch_masks(lo - 1, avN);
+                     });
+            avt[0] = avC[TB]; avt[1] = avC[TB + 1];               // (this product's own tail is finished in the next one)
         };
         const bool skip_dx = (st == 0 && !dx_stage0);       // only the dz of stage 0 were wanted
         auto dxl = [&](float (&Zin)[KS]) __attribute__((always_inline)) {
-            mwt = mw; avt[0] = av[TB]; avt[1] = av[TB + 1];
-            const f32x4 o = RRGemm<S>::block(w0t, Zin, [&](int ks) __attribute__((always_inline)) { pre_tail(0, Zin, ks); });
+            mwt = mw;
+            const f32x4 o = RRGemm<S>::block(w0t, Zin, [&](int ks) __attribute__((always_inline)) { pre_tail(Zin, ks); });
+            save_dz(0, Zin);
             if (!skip_dx) {
 #pragma unroll
                 for (int r = 0; r < 2; ++r) {
@@ -525,9 +544,9 @@ __global__ __launch_bounds__(256) void node_rr_bwd_kernel(const NodeRkBwdLaunch 
         };
         using I1 = std::integral_constant<int, 1>; using I2 = std::integral_constant<int, 2>;
         using I3 = std::integral_constant<int, 3>;
-        prod(I1{}, Za, Zb);                                   // (f_net: three hid x hid layers, g_net: two — see the forward)
-        prod(I2{}, Zb, Za);
-        if (grp == 0) { prod(I3{}, Za, Zb); dxl(Zb); }
+        prod(I1{}, Za, Zb, avB, avA);                         // (f_net: three hid x hid layers, g_net: two — see the forward)
+        prod(I2{}, Zb, Za, avA, avB);
+        if (grp == 0) { prod(I3{}, Za, Zb, avB, avA); dxl(Zb); }
         else dxl(Za);
         if (skip_dx) continue;
         __syncthreads();

@@ -179,7 +179,8 @@ class SAC_CBF_CLF(object):
         dev = self.device
         self.ar_c = Arena(dev, self.n_grad_slabs, with_target=True)     # critic + Lyapunov (lr 4e-4)
         self.ar_a = Arena(dev, self.n_grad_slabs)                        # policies + log alphas (lr args.lr)
-        self.n_fit_slabs = int(getattr(args, "fit_grad_slabs", 48))      # per accepted RK step of a NODE fit (row slabs = workgroups)
+        self.n_fit_slabs = int(getattr(args, "fit_grad_slabs", 51))      # per accepted RK step of a NODE fit (row slabs = workgroups;
+        # f_net + g_net have five hid x hid layers: 5 x 51 = 255 long workgroups for 256 CUs, mlp_dw16_kernels.hip)
         self.ar_n = Arena(dev, self.n_fit_slabs * 2)                     # NODE (lr 1e-3)
         self.h_q1, self.h_q2 = self.critic.attach(self.ar_c)
         (self.h_l,) = self.lyapunovNet.attach(self.ar_c)
