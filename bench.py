@@ -296,6 +296,9 @@ def main():
     ap.add_argument("--adjoint", action="store_true",
                     help="differentiate every NODE solve by the continuous adjoint (odeint_adjoint; BASELINE configs[3])")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--dp-step-control", default="shard", choices=["shard", "global"],
+                    help="N > 1, dopri5: every rank controls the steps of its own rows (no collective inside a solve; "
+                         "default) or the error norms are all-reduced (the single-device decisions over the global batch)")
     ap.add_argument("--graphs", action="store_true",
                     help="replay the update as hipGraphs (measured equal to eager launches once descriptors are cached)")
     ap.add_argument("--profile-steps", type=int, default=20)
@@ -356,7 +359,7 @@ def main():
         agent.adjoint = a.adjoint
         agent.use_graphs = (world == 1) and a.graphs
         if world > 1:
-            agent.enable_data_parallel(dist)
+            agent.enable_data_parallel(dist, step_control=a.dp_step_control)
         dev = agent.device
         # the replay lives in HBM in the agent's row layout; minibatches are drawn and gathered on the device
         replay = DeviceReplayMemory(REPLAY_ROWS, 1234 + rank, agent, device_rng=True)
@@ -525,7 +528,8 @@ def main():
                                       WORKLOAD_NOTE[a.env], NODE_FIT_ROWS, NODE_FIT_INTERVAL, REPLAY_ROWS),
                        "solver": a.solver, "adjoint": bool(a.adjoint), "batch_per_gpu": B, "global_batch": GB,
                        "node_fit_rows_per_gpu": main_run["fit_rows_per_rank"],
-                       "parallelism": "dp%d" % world, "hipgraph": bool(agent.use_graphs),
+                       "parallelism": "dp%d" % world,
+                       "dp_step_control": (a.dp_step_control if world > 1 and a.solver == "dopri5" else None), "hipgraph": bool(agent.use_graphs),
                        "rollout_solver_stats": main_run["stats"], "last_losses": main_run["ret"],
                        "hbm_peak_allocated_bytes": int(torch.cuda.max_memory_allocated())},
             "roofline": roofline, "cpu_baseline": cpu, "node_odeint_fwd_bwd": ode_sub,

@@ -171,6 +171,10 @@ class AffineNodeSolver:
         self._children = {}    # per-problem solvers for batches whose problems diverge (dopri5)
         self.stats = dict(solves=0, single_step=0, multi_attempt=0, split=0)
         self.comm = None       # nlbac_amd.parallel.DataParallel: global dopri5 error norms
+        # > 1: every problem of a solve is cut into this many contiguous row groups, each an adaptive solve of its own
+        # (own error norm, step sizes and accept decisions) — what a sample-sharded run with per-shard step control
+        # (SAC_CBF_CLF.enable_data_parallel(step_control="shard")) computes on that many ranks, on one device
+        self.row_groups = 1
         self.adjoint = False   # True: ``backward`` is the continuous adjoint (odeint_adjoint); the forward keeps nothing
         self.generation = 0    # bumped whenever device buffers are freed or re-laid-out (owners of hipGraphs watch it)
         self.device_loop = True   # dopri5 attempts as a device-driven chain (no host decision per attempt)
@@ -256,6 +260,7 @@ class AffineNodeSolver:
         multi-problem dopri5 solve, the per-problem fallback solvers), so that the first multi-step or diverging solve
         of a run does not pay tens of milliseconds of allocation in the middle of training."""
         self._touch(n)
+        P *= self.row_groups
         if method != "dopri5":
             S = len(TABLEAU[method]["c_sol"])
             self._step_ws(n, S, 0).bwd(self)
@@ -395,6 +400,9 @@ class AffineNodeSolver:
         accept/reject decision of the first attempted step); euler/rk4 run to completion.  No host sync."""
         n = P * rpp
         assert y0.shape == (n, self.n_s) and u.shape == (n, self.n_u)
+        if self.row_groups > 1:
+            assert rpp % self.row_groups == 0, "row_groups must divide the rows of a problem"
+            P, rpp = P * self.row_groups, rpp // self.row_groups
         self._touch(n)
         self.stats["solves"] += 1
         self.ctx = dict(method=method, P=P, rpp=rpp, n=n, u=u, y0=y0, steps=[], t_end=float(dt), atol=atol,
@@ -1367,6 +1375,7 @@ class ConcatNodeSolver(AffineNodeSolver):
         self.keep_acts = True
         self.stats = dict(solves=0, single_step=0, multi_attempt=0, split=0)
         self.comm = None
+        self.row_groups = 1
         self.adjoint = False
         self.generation = 0
         self.device_loop = True

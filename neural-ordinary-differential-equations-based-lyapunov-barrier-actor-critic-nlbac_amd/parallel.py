@@ -8,7 +8,10 @@ sums, so the exchanges are fp32 SUM all-reduces of
   * 20 constraint / actor partial sums                  before the augmented-Lagrangian scalars,
   * the flat actor gradient                             before its Adam step,
   * the NODE-fit gradient (+1 loss sum)                 every NODE_model_update_interval updates,
-  * for dopri5: 2 floats per problem per norm           so all ranks share one step size / accept decision.
+  * for dopri5 with step_control="global": 2 floats per problem per norm, so all ranks share one step size /
+    accept decision (what the parity tests pin).  With step_control="shard" (bench.py's default for N > 1) every rank
+    controls the steps of its own rows and NO collective runs inside a solve: the solve is the single-device one with
+    ``row_groups = world`` (odeint.py), tests/test_data_parallel.py::test_two_rank_update_with_per_shard_step_control.
 Messages are <= 1.4 MB (latency-bound): one flat buffer per phase, no bucketing.
 The reference has no distributed path (its mpi4py helpers are dead code).
 """

@@ -276,19 +276,29 @@ class SAC_CBF_CLF(object):
         return self.task.fit_solver
 
     # ------------------------------------------------------------ data parallel
-    def enable_data_parallel(self, dist, group=None, always_collective=False):
+    def enable_data_parallel(self, dist, group=None, always_collective=False, step_control="global"):
         """Shard minibatches over the ranks of ``dist`` (one process per GPU).  Every rank then passes its
         own rows to ``update_*``; losses are normalised by the global batch (``args.batch_size`` must be
-        the global size) and gradients / constraint sums are all-reduced (nlbac_amd/parallel.py)."""
+        the global size) and gradients / constraint sums are all-reduced (nlbac_amd/parallel.py).
+
+        ``step_control`` (dopri5 only): "global" — the squared error norms of every attempted step are all-reduced, so
+        all ranks share the step sizes and accept decisions the single-device run over the global batch takes (what the
+        parity tests pin; one small collective per norm, inside the solve).  "shard" — every rank controls the steps of
+        its own rows: no collective inside a solve, the ranks' solves run free of each other and meet at the gradient
+        all-reduces only; the result is the single-device run with ``row_groups = world`` on its solvers (each shard an
+        adaptive solve of its own, as if the reference had been handed the shards one by one), not bit-comparable
+        with the global-norm run: the two differ by what a change of step size within rtol / atol changes."""
         from ..parallel import DataParallel
+        assert step_control in ("global", "shard")
         self.dp = DataParallel(dist, group, always_collective)
+        self.dp_step_control = step_control
         for ar in self.arenas:
             self.dp.broadcast_(ar.theta)
         self.ar_c.hard_update_target()
         self.dp.broadcast_(self.sc)
         self.repack_all()
         for sv in self.task.solvers:
-            sv.comm = self.dp
+            sv.comm = self.dp if step_control == "global" else None
         return self
 
     @property

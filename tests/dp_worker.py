@@ -96,7 +96,7 @@ ORACLE_CASE = dict(B=128, hidden=64, seed=0, updates=(0, 1, 20),
                    gamma_b={"Pvtol": 0.8, "Unicycle": 50.0, "PvtolBarrier": 0.8, "QuadrotorLike": 1.0})
 
 
-def run_cuda_oracle_case(dp, out, solver, env_name, adjoint):
+def run_cuda_oracle_case(dp, out, solver, env_name, adjoint, step_control="global"):
     """Row shards of the oracle-checked updates (no reference fixture exists for them: the parent holds the results
     against the single-device oracle): returned floats and post-update parameters."""
     from test_agent_parity_gpu import make_agent
@@ -105,7 +105,7 @@ def run_cuda_oracle_case(dp, out, solver, env_name, adjoint):
     torch.cuda.set_device(0)
     agent, env = make_agent(B, c["hidden"], c["seed"], solver, env_name, c["gamma_b"][env_name])
     agent.adjoint = bool(adjoint)
-    agent.enable_data_parallel(dist)
+    agent.enable_data_parallel(dist, step_control=step_control)
     tr = synth.transitions(env_name, 4096, seed=c["seed"] + 1, env=env)
     fields = synth.fields(env_name)
     res = {"n_eps": np.array(agent.task.n_eps)}
@@ -133,6 +133,7 @@ if __name__ == "__main__":
     ap.add_argument("--env", default="Unicycle")
     ap.add_argument("--oracle-case", action="store_true", help="the oracle-checked update pattern instead of a golden fixture's")
     ap.add_argument("--adjoint", action="store_true")
+    ap.add_argument("--step-control", default="global", help="dopri5 under data parallelism: global | shard")
     a = ap.parse_args()
     dist.init_process_group("gloo")
     dp = DataParallel(dist)
@@ -140,7 +141,7 @@ if __name__ == "__main__":
     if a.device == "cpu":
         run_cpu(dp, out)
     elif a.oracle_case:
-        run_cuda_oracle_case(dp, out, a.solver, a.env, a.adjoint)
+        run_cuda_oracle_case(dp, out, a.solver, a.env, a.adjoint, a.step_control)
     else:
         run_cuda(dp, out, a.solver, a.env)
     dist.barrier()

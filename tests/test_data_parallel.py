@@ -139,6 +139,68 @@ def test_two_rank_sharded_update_matches_single_device_oracle(tmp_path, env_name
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("env_name,adjoint", [("Unicycle", False), ("Pvtol", True)], ids=["Unicycle", "Pvtol-adjoint"])
+def test_two_rank_update_with_per_shard_step_control(tmp_path, env_name, adjoint):
+    """``enable_data_parallel(step_control="shard")``: every rank controls the dopri5 steps of its own rows and no
+    collective runs inside a solve.  What the two ranks compute is the single-device update whose solvers cut every
+    problem into two row groups with step control of their own (``row_groups = 2``) — same solves row for row, the
+    gradient sums differ by the summation order only (1e-5) — and it stays within the solver tolerance of the
+    global-norm run (the oracle on the whole batch: 2e-3 on the returned losses, not the 1e-4 parity bar, which belongs
+    to ``step_control="global"``)."""
+    from oracle import nlbac_oracle as O
+    from dp_worker import ORACLE_CASE, oracle_case_inputs
+    from test_agent_parity_gpu import make_agent
+    out = str(tmp_path / "dpshard")
+    launch(2, ["--device", "cuda", "--out", out, "--solver", "dopri5", "--env", env_name, "--oracle-case",
+               "--step-control", "shard"] + (["--adjoint"] if adjoint else []), timeout=900)
+    res = [np.load(out + ".rank%d.npz" % r) for r in range(2)]
+    c = ORACLE_CASE
+    B, seed = c["B"], c["seed"]
+    agent, env = make_agent(B, c["hidden"], seed, "dopri5", env_name, c["gamma_b"][env_name])
+    agent.adjoint = bool(adjoint)
+    for sv in agent.task.solvers:
+        # (the parameter adjoint of a NODE fit is one vector with one step control per solve: the adjoint fit cannot be
+        # cut into row groups on one device — for that case the fit's own shards are only held to the solver tolerance)
+        if not (adjoint and sv is agent.task.fit_solver):
+            sv.row_groups = 2
+    strict = not adjoint
+    torch.set_num_threads(4)
+    oargs = O.Args(batch_size=B, hidden_size=c["hidden"], seed=seed)
+    oargs.gamma_b = c["gamma_b"][env_name]
+    kw = dict(adjoint=True) if adjoint else {}
+    oracle = O.make_oracle(synth.fixture_env(env_name, seed), oargs, synth.agent_weights(env_name, c["hidden"], seed),
+                           solver="dopri5", **kw)
+    tr = synth.transitions(env_name, 4096, seed=seed + 1, env=env)
+    fields = synth.fields(env_name)
+    lr = dict(critic=4e-4, policy=3e-4, node=1e-3)
+    for ci, updates in enumerate(c["updates"]):
+        batch, eps, node = oracle_case_inputs(env_name, agent, env, B, ci, updates, tr)
+        agent.set_noise(eps)
+        node_np = tuple(t.numpy() for t in node) if updates % 10 == 0 else None
+        ret = np.array(agent.update_from_host(tuple(batch[f].numpy() for f in fields), updates, node_np))
+        torch.cuda.synchronize()
+        R = oracle.update(batch, eps, updates, node_batch=node if updates % 10 == 0 else None)
+        for r in range(2):
+            vec_close(res[r]["c%d_ret" % ci], ret, (1e-5 if ci == 0 else 1e-4) if strict else 2e-3,
+                      "rank %d ret vs row groups (update %d)" % (r, updates))
+            vec_close(res[r]["c%d_ret" % ci], R["ret"], 2e-3, "rank %d ret vs global-norm oracle (update %d)" % (r, updates))
+            for name, mod in (("critic", agent.critic), ("policy", agent.policy), ("node", agent.neural_ode_model)):
+                v = torch.cat([q.detach().reshape(-1) for q in mod.parameters()]).cpu().numpy()
+                # (Adam's first steps move every weight by ~lr whatever its gradient's size: a weight whose gradient is
+                # the cancellation residue of the batch sum lands up to 2 lr apart when the summation order changes —
+                # the policy's, at these first updates, in under 2 % of its entries; all others agree to 1e-5)
+                err = np.abs(res[r]["c%d_p_%s" % (ci, name)].astype(np.float64) - v)
+                # (first update; afterwards the few weights that did land apart feed the next update's every output)
+                if ci == 0 and (strict or name != "node"):
+                    assert (err > 1e-5 * np.abs(v).max()).mean() <= 2e-2, (name, updates, (err > 1e-5 * np.abs(v).max()).mean())
+                if strict or name != "node":
+                    assert np.linalg.norm(err) <= 1e-3 * np.linalg.norm(v.astype(np.float64)), (name, updates)
+                assert err.max() <= 2.1 * lr[name] * (ci + 1), (name, updates, err.max())
+    for k in res[0].files:                                            # replicas stay bit-identical
+        np.testing.assert_array_equal(res[0][k], res[1][k])
+
+
+@pytest.mark.gpu
 def test_rccl_branch_of_the_exchange_layer_runs_on_one_gpu():
     """``nccl`` (RCCL) initialised in a fresh process before any other GPU call, world size 1, the exchange layer's
     one-rank short-cut switched off: device tensors go through ``all_reduce_`` / ``broadcast_`` on the RCCL branch (the
