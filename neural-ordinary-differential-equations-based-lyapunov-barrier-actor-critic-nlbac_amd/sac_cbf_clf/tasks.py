@@ -50,6 +50,25 @@ class _Task:
             seen.add(key)
             solver.reserve(n, P, self.agent.solver)
 
+    def policy_sample(self, ws, key, nets, io, n_nets, B, heads, eps, n_u, action, action_ld, logp):
+        """pi(. | obs) of ``n_nets`` stacked policies on B rows each + GaussianPolicy.sample of every row (model.py:116-128):
+        one launch — the MLP launch applies the head itself (nlbac_gauss_head) — or, with the launch folds off
+        (NLBAC_FOLD=0), the forward and nlbac_gauss_sample_fwd on its (n_nets * B, 2 n_u) output ``heads``."""
+        a, s, pol = self.agent, stream_ptr(), self.agent.policy
+        p_scale, p_bias = pol.action_scale.data_ptr(), pol.action_bias.data_ptr()
+        if not a.fold_launches:
+            _lib.call("nlbac_mlp_fwd", nets, io, n_nets, B, s)
+            _lib.call("nlbac_gauss_sample_fwd", heads.data_ptr(), 2 * n_u, eps.data_ptr(), p_scale, p_bias, n_u, n_nets * B,
+                      action.data_ptr(), action_ld, logp.data_ptr(), s)
+            return
+        hs = ws.__dict__.setdefault("_gauss_heads", {})
+        gh = hs.get(key)
+        if gh is None:
+            gh = hs[key] = _lib.GaussHead()
+            gh.eps, gh.scale, gh.bias, gh.n_u = eps.data_ptr(), p_scale, p_bias, n_u
+            gh.action, gh.action_ld, gh.logp = action.data_ptr(), action_ld, logp.data_ptr()
+        _lib.call("nlbac_mlp_fwd_gauss", nets, io, n_nets, B, C.byref(gh), s)
+
     def n_pol_now(self, updates):
         return self.n_pol
 
@@ -301,9 +320,7 @@ class UnicycleBarrierTask(UnicycleTask):
         call("nlbac_unicycle_lookahead", x_next.data_ptr(), B, self.l_p, ws.ps_next.data_ptr(), s)
         call("nlbac_mlp_fwd", P.n_l, P.io_vn, 1, B, s)
         call("nlbac_unicycle_obs_fwd", x_next.data_ptr(), B, gx, gy, ws.obs_pred.data_ptr(), 7, s)
-        call("nlbac_mlp_fwd", P.n_pi, P.io_nx, 1, B, s)
-        call("nlbac_gauss_sample_fwd", ws.heads_nx.data_ptr(), 4, ws.eps[2].data_ptr(), pol.action_scale.data_ptr(),
-             pol.action_bias.data_ptr(), 2, B, ws.pi_next.data_ptr(), 2, ws.logp_nx.data_ptr(), s)
+        self.policy_sample(ws, "nx", P.n_pi, P.io_nx, 1, B, ws.heads_nx, ws.eps[2], 2, ws.pi_next, 2, ws.logp_nx)
         call("nlbac_mlp_fwd", P.n_bar, P.io_bn, 1, B, s)
         call("nlbac_barrier_constraints_fwd", ws.Bv.data_ptr(), ws.Bn.data_ptr(), ws.V.data_ptr(), ws.Vn.data_ptr(),
              dt, float(a.gamma_b), self.gamma_l, B, ws.matr.data_ptr(), ws.part_c.data_ptr(),
@@ -398,9 +415,7 @@ class CarsTask(_Task):
         ws.x1_2.copy_(x1)
         # u_(t+1) ~ pi(. | get_obs(x_t+1)), detached (C/sac_cbf_clf.py:441-451, 585-595)
         call("nlbac_cars_obs", ws.x1_2.data_ptr(), 2 * B, ws.obs1_2.data_ptr(), s)
-        call("nlbac_mlp_fwd", P.n_act, P.io_nx, 2, B, s)
-        call("nlbac_gauss_sample_fwd", ws.heads_nx.data_ptr(), 2, ws.eps[3:5].data_ptr(), pol.action_scale.data_ptr(),
-             pol.action_bias.data_ptr(), 1, 2 * B, ws.c2.data_ptr(), 2, ws.logp_nx.data_ptr(), s)
+        self.policy_sample(ws, "nx", P.n_act, P.io_nx, 2, B, ws.heads_nx, ws.eps[3:5], 1, ws.c2, 2, ws.logp_nx)
         x2 = self.solver2.forward(ws.x1_2, ws.c2, 2, B, a.solver, dt, a.atol, a.rtol)
         a.drain_fill()
         call("nlbac_mlp_fwd", P.n_l, P.io_v1, 1, B, s)
@@ -550,15 +565,11 @@ class PvtolTask(_Task):
         # u_(t+1), u_(t+2) ~ pi(. | get_obs(x)), detached (P:474-526)
         call("nlbac_pvtol_obs_fwd", ws.x1.data_ptr(), ws.op0.data_ptr(), B, follow, gx, gy, n, ws.obs1.data_ptr(), 11,
              ws.op1.data_ptr(), s)
-        call("nlbac_mlp_fwd", P.n_pols, P.io_nx[0], NP, B, s)
-        call("nlbac_gauss_sample_fwd", ws.heads_n1.data_ptr(), 4, ws.eps[3:3 + NP].data_ptr(), p_scale, p_bias, 2, n,
-             ws.a1.data_ptr(), 2, ws.logp_nx.data_ptr(), s)
+        self.policy_sample(ws, ("n1", NP), P.n_pols, P.io_nx[0], NP, B, ws.heads_n1, ws.eps[3:3 + NP], 2, ws.a1, 2, ws.logp_nx)
         ws.x2[:n].copy_(s2.forward(ws.x1[:n], ws.a1[:n], NP, B, a.solver, dt, a.atol, a.rtol))
         call("nlbac_pvtol_obs_fwd", ws.x2.data_ptr(), ws.op1.data_ptr(), n, follow, gx, gy, n, ws.obs2.data_ptr(), 11,
              ws.op2.data_ptr(), s)
-        call("nlbac_mlp_fwd", P.n_pols, P.io_nx[1], NP, B, s)
-        call("nlbac_gauss_sample_fwd", ws.heads_n2.data_ptr(), 4, ws.eps[5:5 + NP].data_ptr(), p_scale, p_bias, 2, n,
-             ws.a2.data_ptr(), 2, ws.logp_nx.data_ptr(), s)
+        self.policy_sample(ws, ("n2", NP), P.n_pols, P.io_nx[1], NP, B, ws.heads_n2, ws.eps[5:5 + NP], 2, ws.a2, 2, ws.logp_nx)
         ws.x3[:n].copy_(s3.forward(ws.x2[:n], ws.a2[:n], NP, B, a.solver, dt, a.atol, a.rtol))
         a.drain_fill()
         call("nlbac_mlp_fwd", P.n_l, P.io_v1, 1, B, s)
@@ -696,9 +707,7 @@ class PvtolBarrierTask(PvtolTask):
         call("nlbac_pvtol_obs_fwd", x1.data_ptr(), ws.op0.data_ptr(), B, follow, gx, gy, B, ws.obs_pred.data_ptr(), 11,
              None, s)
         call("nlbac_mlp_fwd", P.n_l, P.io_v1, 1, B, s)
-        call("nlbac_mlp_fwd", P.n_pi, P.io_nx, 1, B, s)
-        call("nlbac_gauss_sample_fwd", ws.heads_nx.data_ptr(), 4, ws.eps[2].data_ptr(), pol.action_scale.data_ptr(),
-             pol.action_bias.data_ptr(), 2, B, ws.pi_next.data_ptr(), 2, ws.logp_nx.data_ptr(), s)
+        self.policy_sample(ws, "nx", P.n_pi, P.io_nx, 1, B, ws.heads_nx, ws.eps[2], 2, ws.pi_next, 2, ws.logp_nx)
         call("nlbac_mlp_fwd", P.n_bar, P.io_bn, 1, B, s)
         call("nlbac_barrier_constraints_fwd", ws.Bv.data_ptr(), ws.Bn.data_ptr(), ws.V.data_ptr(), ws.V1.data_ptr(),
              1.0, float(a.gamma_b), self.gamma_l, B, ws.matr.data_ptr(), ws.part_c.data_ptr(),
@@ -797,9 +806,7 @@ class QuadrotorBarrierTask(PvtolBarrierTask):
         a.drain_fill()
         call("nlbac_copy_blocks", x1.data_ptr(), 6 * B, ws.obs_pred.data_ptr(), 6 * B, 6 * B, 1, s)   # obs' = x'
         call("nlbac_mlp_fwd", P.n_l, P.io_v1, 1, B, s)
-        call("nlbac_mlp_fwd", P.n_pi, P.io_nx, 1, B, s)
-        call("nlbac_gauss_sample_fwd", ws.heads_nx.data_ptr(), 4, ws.eps[2].data_ptr(), pol.action_scale.data_ptr(),
-             pol.action_bias.data_ptr(), 2, B, ws.pi_next.data_ptr(), 2, ws.logp_nx.data_ptr(), s)
+        self.policy_sample(ws, "nx", P.n_pi, P.io_nx, 1, B, ws.heads_nx, ws.eps[2], 2, ws.pi_next, 2, ws.logp_nx)
         call("nlbac_mlp_fwd", P.n_bar, P.io_bn, 1, B, s)
         call("nlbac_barrier_constraints_fwd", ws.Bv.data_ptr(), ws.Bn.data_ptr(), ws.V.data_ptr(), ws.V1.data_ptr(),
              1.0, float(a.gamma_b), self.gamma_l, B, ws.matr.data_ptr(), ws.part_c.data_ptr(),
