@@ -306,8 +306,12 @@ class UnicycleBarrierTask(UnicycleTask):
 
     def rollout_begin(self, ws, P):
         a, s = self.agent, stream_ptr()
-        _lib.call("nlbac_unicycle_state", ws.mb.data_ptr(), a.lay.LD, ws.B, self.l_p, ws.y0.data_ptr(), 1, None, s)
+        if self.solver.fused and a.fold_launches:       # (the state is formed by the rollout's first launch: UnicycleTask)
+            self.solver.set_in_map(1, ws.mb, a.lay.LD, self.l_p, None)
+        else:
+            _lib.call("nlbac_unicycle_state", ws.mb.data_ptr(), a.lay.LD, ws.B, self.l_p, ws.y0.data_ptr(), 1, None, s)
         self.reserve(self.solver, ws.B, 1)
+        self.solver._out_map = None
         self.solver.forward_begin(ws.y0, ws.pi2, 1, ws.B, a.solver, float(self.env.dt), a.atol, a.rtol)
 
     def loss_and_backward(self, ws, P, lam_upd, assume_single):
