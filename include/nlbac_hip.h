@@ -41,6 +41,12 @@ typedef void *nlbac_stream_t; /* hipStream_t */
 
 int nlbac_abi_version(void);
 const char *nlbac_last_error(void);
+/* Test hook (no reference counterpart): one launch of the last-workgroup election the fused loss / controller kernels
+ * rely on (csrc/common.h publish_and_elect: a gfx950-only ordering contract).  Workgroup b publishes n_vals values
+ * ((b * 31 + k * 7 + salt * 13) % 251); the elected workgroup leaves their sums over all workgroups in out[0..n_vals)
+ * and adds 1 to out[n_vals].  partials: n_blocks * n_vals floats; ticket: one zeroed unsigned (left zero again). */
+int nlbac_elect_selftest(float *partials, unsigned *ticket, float *out, int n_blocks, int n_vals, unsigned salt,
+                         nlbac_stream_t s);
 
 /* ------------------------------------------------------------------------
  * ReLU MLP:  in_dim -> hid -> ... -> hid -> out_dim   (n_layers Linear layers;

@@ -107,6 +107,7 @@ _P, _I, _F, _D, _L = C.c_void_p, C.c_int, C.c_float, C.c_double, C.c_long
 _PROTOS = {
     "nlbac_abi_version": [],
     "nlbac_last_error": [],
+    "nlbac_elect_selftest": [_P, _P, _P, _I, _I, C.c_uint, _P],
     "nlbac_mlp_pack_layout": [C.POINTER(Mlp)],
     "nlbac_mlp_pack": [C.POINTER(Mlp), _I, _P],
     "nlbac_mlp_fwd": [C.POINTER(Mlp), C.POINTER(MlpIO), _I, _I, _P],

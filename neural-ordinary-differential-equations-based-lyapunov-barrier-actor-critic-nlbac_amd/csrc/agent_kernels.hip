@@ -37,6 +37,7 @@ __device__ __forceinline__ bool publish_and_elect_n(float* dst, const float* val
         if ((int)threadIdx.x < n)
             old = __hip_atomic_exchange(dst + threadIdx.x, s_vals_n_[threadIdx.x], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         asm volatile("" ::"v"(old) : "memory");        // every lane's exchange has returned before the ticket is taken
+        elect_release_();
         if (threadIdx.x == 0) {
             const unsigned t = __hip_atomic_fetch_add(ticket, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             s_elect_n_ = (t == n_blocks - 1u) ? 1u : 0u;
@@ -44,7 +45,57 @@ __device__ __forceinline__ bool publish_and_elect_n(float* dst, const float* val
         }
     }
     __syncthreads();
+    if (s_elect_n_ != 0u) elect_acquire_();
     return s_elect_n_ != 0u;
+}
+
+// ---------------------------------------------------------------------------
+// Self-test of the election (common.h: the gfx950 contract).  Workgroup b publishes n_vals integers-as-floats that
+// depend on (b, k, salt) — a stale partial of an earlier launch (other salt) or a partial that had not landed when the
+// last ticket was drawn changes the sum — through publish_and_elect<4> (n_vals == 4) or the runtime-width variant; the
+// elected workgroup sums all workgroups' values with coherent loads, in order, into out[0..n_vals) and counts itself in
+// out[n_vals] (exactly one workgroup per launch must be elected).  Every workgroup first spends a block-dependent
+// number of cycles so that the tickets are drawn in a scrambled order.
+// ---------------------------------------------------------------------------
+__device__ __forceinline__ float elect_test_value(unsigned b, unsigned k, unsigned salt) {
+    return (float)((b * 31u + k * 7u + salt * 13u) % 251u);
+}
+__global__ __launch_bounds__(256) void elect_selftest_kernel(float* partials, unsigned* ticket, float* out, int n_vals,
+                                                             unsigned salt) {
+    const unsigned b = blockIdx.x;
+    const unsigned spin = ((b * 2654435761u) >> 24) * 8u;        // 0 .. 2040 cycles
+    const long long t0 = __builtin_readcyclecounter();
+    while (__builtin_readcyclecounter() - t0 < (long long)spin) {}
+    float v[64];
+#pragma unroll
+    for (int k = 0; k < 64; ++k) v[k] = (k < n_vals) ? elect_test_value(b, k, salt) : 0.f;
+    bool elected;
+    if (n_vals == 4) {
+        float v4[4] = {v[0], v[1], v[2], v[3]};
+        elected = publish_and_elect<4>(partials + (long)b * 4, v4, ticket, gridDim.x);
+    } else {
+        __shared__ float sv[64];
+        if (threadIdx.x == 0)
+            for (int k = 0; k < n_vals; ++k) sv[k] = elect_test_value(b, k, salt);
+        __syncthreads();
+        elected = publish_and_elect_n(partials + (long)b * n_vals, sv, n_vals, ticket, gridDim.x);
+    }
+    if (!elected) return;
+    if ((int)threadIdx.x < n_vals) {
+        float acc = 0.f;                                       // (integers below 2^24: exact in any order)
+        for (unsigned j = 0; j < gridDim.x; ++j) acc += coherent_load(partials + (long)j * n_vals + threadIdx.x);
+        out[threadIdx.x] = acc;
+    }
+    if (threadIdx.x == 0) atomicAdd(out + n_vals, 1.0f);
+}
+
+extern "C" int nlbac_elect_selftest(float* partials, unsigned* ticket, float* out, int n_blocks, int n_vals, unsigned salt,
+                                    nlbac_stream_t s) {
+    NLBAC_REQUIRE(partials && ticket && out, "nlbac_elect_selftest: null buffer");
+    NLBAC_REQUIRE(n_blocks >= 1 && n_vals >= 1 && n_vals <= 64, "nlbac_elect_selftest: n_blocks >= 1, 1 <= n_vals <= 64");
+    hipLaunchKernelGGL(elect_selftest_kernel, dim3(n_blocks), dim3(256), 0, (hipStream_t)s, partials, ticket, out, n_vals, salt);
+    NLBAC_CHECK_LAUNCH("nlbac_elect_selftest");
+    return 0;
 }
 // tail of a constraints_fwd kernel: plain partials, or (ticket) publish them and let the last workgroup run auglag
 #define CONSTRAINTS_TAIL(NCOLS_, V_)                                                              \

@@ -51,6 +51,31 @@ __device__ __forceinline__ void block_sum_256(float (&v)[NV], float* lds /* >= 4
 // own stores).  Wave 0 publishes thread 0's N partial results with device-scope atomic exchanges (performed at the
 // level every XCD sees), waits for them to return, then thread 0 takes a ticket; the block that draws the last ticket reads the
 // others' results with ``coherent_load``.  Returns the verdict in every thread of the block (contains a barrier).
+//
+// CONTRACT — gfx950 only.  The HIP / LLVM memory model gives no happens-before between a relaxed exchange, a relaxed
+// ticket and a relaxed load; what orders them here is the hardware and one compiler barrier:
+//   * an agent-scope atomic that RETURNS a value has been performed at the memory-side coherence point (beyond the
+//     XCDs' L2s) when its result arrives, and ``asm volatile("" :: "v"(old) : "memory")`` makes the wave wait for that
+//     result (s_waitcnt vmcnt(0)) and keeps the compiler from moving the ticket above it;
+//   * the ticket is an atomic at the same point, so the workgroup that draws the last one does so after every other
+//     workgroup's exchanges were performed there;
+//   * ``coherent_load`` (agent-scope atomic load: sc1) does not hit a stale line of the reading XCD's L2.
+// Any other target gets fences instead (NLBAC_ELECT_FENCED: release before the ticket, acquire in the elected block).
+// tests/test_elect_gpu.py drives nlbac_elect_selftest — thousands of workgroups over all XCDs, salted values, hundreds
+// of back-to-back launches — against host sums.
+#if defined(__HIP_DEVICE_COMPILE__) && !defined(__gfx950__)
+#define NLBAC_ELECT_FENCED 1
+#endif
+__device__ __forceinline__ void elect_release_() {
+#ifdef NLBAC_ELECT_FENCED
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+#endif
+}
+__device__ __forceinline__ void elect_acquire_() {
+#ifdef NLBAC_ELECT_FENCED
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+#endif
+}
 template <int N>
 __device__ __forceinline__ bool publish_and_elect(float* dst, const float (&vals)[N], unsigned* ticket, unsigned n_blocks) {
     __shared__ unsigned s_elect_;
@@ -66,6 +91,7 @@ __device__ __forceinline__ bool publish_and_elect(float* dst, const float (&vals
         float old = 0.f;
         if ((int)threadIdx.x < N) old = __hip_atomic_exchange(dst + threadIdx.x, mine, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         asm volatile("" ::"v"(old) : "memory");        // every exchange has returned before the ticket is taken
+        elect_release_();
         if (threadIdx.x == 0) {
             const unsigned t = __hip_atomic_fetch_add(ticket, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             s_elect_ = (t == n_blocks - 1u) ? 1u : 0u;
@@ -73,6 +99,7 @@ __device__ __forceinline__ bool publish_and_elect(float* dst, const float (&vals
         }
     }
     __syncthreads();
+    if (s_elect_ != 0u) elect_acquire_();
     return s_elect_ != 0u;
 }
 __device__ __forceinline__ float coherent_load(const float* p) {

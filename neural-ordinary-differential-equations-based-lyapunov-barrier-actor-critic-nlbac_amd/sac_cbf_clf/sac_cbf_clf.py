@@ -434,7 +434,10 @@ class SAC_CBF_CLF(object):
         parity; obs->state runs on the device.  ``i_episode`` is the Pvtol copy's trailing argument (P:181):
         its NODE fit stops after episode 100 (P:205)."""
         fit = updates % NODE_model_update_interval == 0 and self.task.fit_due(i_episode)
-        nb = min(NODE_memory.position, 32768) if fit else 0
+        # (sac_cbf_clf.py:205: min(NODE_memory.position, 32768).  ``position`` wraps with the ring: a replay that has just
+        #  wrapped reports 0 — the reference would then sample zero rows and fail — and the fit takes the filled size)
+        nb = min(NODE_memory.position or len(NODE_memory), 32768) if fit else 0
+        fit = fit and nb > 0
         if hasattr(memory, "sample_rows"):           # replay resident in HBM: gather on the device
             ws = self._workspace(batch_size)
             eps_ready = self._noise is None and getattr(memory, "device_rng", False)

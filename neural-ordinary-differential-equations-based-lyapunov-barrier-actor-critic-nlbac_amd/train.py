@@ -324,6 +324,9 @@ def train_vectorized(agent, env, args, n_steps, log=print, memory=None, check=No
     ret_sum = torch.zeros((), dtype=torch.float64, device=dev)
     n_done = torch.zeros((), dtype=torch.int64, device=dev)
     steps = updates = it = 0
+    if getattr(agent, "backup_policy", None) is not None:
+        log("vectorised: the backup controller is trained by every update but never acts (the hand-over heuristics are "
+            "per-episode host control flow): its replay distribution is the primary controller's, unlike the reference's")
     while steps < n_steps:
         if steps < args.start_steps:
             action = lo + (hi - lo) * torch.rand(N, lay.act_dim, generator=gen, device=dev)
@@ -356,8 +359,13 @@ def train_vectorized(agent, env, args, n_steps, log=print, memory=None, check=No
         steps += N
         it += 1
         if len(memory) > args.batch_size:
+            # the reference driver's trailing argument (P/main.py: the Pvtol copy stops fitting its NODE after episode
+            # 100): lanes finish episodes on their own, so the counter is finished episodes per lane, 1-based like the
+            # reference's.  (One scalar read; the update below waits for its own results anyway.)
+            i_episode = 1 + int(n_done) // N
             for _ in range(args.updates_per_step):
-                agent.update_parameters(memory, args.batch_size, updates, None, memory, args.NODE_model_update_interval)
+                agent.update_parameters(memory, args.batch_size, updates, None, memory, args.NODE_model_update_interval,
+                                        i_episode)
                 updates += 1
         env.reset(fin)                                         # (finished lanes start over; the others keep their state)
         obs = env.obs.to(torch.float32).clone()

@@ -61,3 +61,29 @@ def test_rows_are_the_transitions_and_runs_repeat(env_name):
     assert r0 == r1
     for x, y in zip(a0.arenas, a1.arenas):
         assert torch.equal(x.theta, y.theta), "two vectorised runs from the same seed differ"
+
+
+def test_pvtol_fit_stops_after_100_episodes_per_lane_and_a_wrapped_replay_still_fits():
+    """The driver hands ``update_parameters`` the reference's trailing ``i_episode`` (P/main.py; the Pvtol copy fits its
+    NODE up to episode 100, P/sac_cbf_clf.py:205) as finished episodes per lane; and a device replay whose ring has just
+    wrapped (``position`` back at 0) fits on its filled size instead of on zero rows."""
+    N = 16
+    agent, spec = make_agent(64, 64, 0, "euler", "Pvtol", 0.8)
+    env = denv.make("Pvtol", N, seed=0)
+    env.max_episode_steps = 2                       # 2-step episodes: 100 episodes per lane pass in 200 vector steps
+    args = types.SimpleNamespace(replay_size=1040, seed=0, start_steps=1 << 30, batch_size=64, updates_per_step=1,
+                                 NODE_model_update_interval=10)
+    seen = []
+    orig = agent.fit_node_rows
+    agent.fit_node_rows = lambda rows: (seen.append((len(seen), rows.shape[0])), orig(rows))[1]
+    episodes = []
+    upd = agent.update_parameters
+    agent.update_parameters = lambda *a: (episodes.append(a[-1]), upd(*a))[1]
+    # 1040-row ring, 16 rows per step: position is back at 0 after step 65 — whose update is number 60, a fit update
+    res = train_vectorized(agent, env, args, 260 * N, log=lambda *a: None)
+    assert res["episodes"] >= 125 * N
+    assert episodes[0] <= 4 and episodes == sorted(episodes) and episodes[-1] > 100       # (the first update comes at step 5)
+    n_fit_updates = sum(1 for k, e in enumerate(episodes) if k % 10 == 0 and e <= 100)
+    assert len(seen) == n_fit_updates and 0 < n_fit_updates < (len(episodes) + 9) // 10
+    assert all(n > 0 for _, n in seen)
+    assert any(n == 1040 for _, n in seen), "no fit ran on a just-wrapped ring (position 0): pick other sizes"
