@@ -446,13 +446,13 @@ def main():
         graphs_on = agent.use_graphs
         agent.use_graphs = False       # the event-timed pass launches the same kernels one by one
         stats0 = dict(agent.node_solver.stats)
-        fence()
+        torch.cuda.synchronize()
         t_pass = time.perf_counter()
         with KernelTimer() as kt:
             for i in range(a.profile_steps):
                 step(base + i)
-            fence()
-            t_pass = time.perf_counter() - t_pass
+            torch.cuda.synchronize()       # (not fence(): the other ranks run these updates without the timers and
+            t_pass = time.perf_counter() - t_pass      # meet this one at the barrier after the pass)
             ks = kt.summary()
         agent.use_graphs = graphs_on
         stats_pass = {k: v - stats0.get(k, 0) for k, v in agent.node_solver.stats.items()}

@@ -122,12 +122,15 @@ struct nlbac_dy_head;
  * entry points it replaces. */
 int nlbac_mlp_bwd_data_head(const nlbac_mlp *nets, const nlbac_mlp_io *io, int n_nets, int B,
                             const struct nlbac_dy_head *head, nlbac_stream_t s);
-/* Weight/bias gradients from x, dy, acts, dz.  The hidden->hidden matrices are
- * reduced per row range into n_slabs gradient slabs (slab s = rows
- * [s*rows_per_slab, ...), fully overwritten, deterministic); the skinny first/last
- * layers and all biases are reduced over all rows into slab 0 through the caller's
- * workspace `ws` (>= nlbac_mlp_bwd_weights_ws_floats() floats).  Slabs are summed
- * in order by nlbac_adam_step / nlbac_reduce_slabs. */
+/* Weight/bias gradients from x, dy, acts, dz, as n_slabs partial gradients the caller sums in order
+ * (nlbac_adam_fused / nlbac_adam_step / nlbac_reduce_slabs), deterministic.
+ * Nets wider than 112: the hidden->hidden matrices are reduced per row range into the slabs (slab s = rows
+ * [s*rows_per_slab, ...), fully overwritten); the skinny first/last layers and all biases are reduced over all rows
+ * into slab 0 through the caller's workspace `ws` (>= nlbac_mlp_bwd_weights_ws_floats() floats) — the other slabs'
+ * entries for them are not written (the caller keeps them zero).
+ * Nets of hid <= 112 (the NODEs) without nlbac_mlp_io::skinny_ws: EVERY gradient — biases and skinny layers too — is
+ * written to every slab (slab s = the 4-row k-steps 4s+w, 4s+w+4 n_slabs, ... of wave w: mlp_dw16_kernels.hip); `ws` is
+ * not used; rows * hid must stay below 2^29. */
 long nlbac_mlp_bwd_weights_ws_floats(const nlbac_mlp *nets, int n_nets, int B);
 int nlbac_mlp_bwd_weights(const nlbac_mlp *nets, const nlbac_mlp_io *io, int n_nets, int B,
                           int n_slabs, long slab_stride, float *ws, long ws_floats, nlbac_stream_t s);

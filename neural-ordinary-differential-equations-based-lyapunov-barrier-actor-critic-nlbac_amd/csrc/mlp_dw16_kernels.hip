@@ -229,13 +229,17 @@ bool nlbac_mlp_dw16_eligible(const nlbac_mlp* nets, int n_nets, int B) {
     static const bool on = [] { const char* e = getenv("NLBAC_MLP_DW16"); return !(e && e[0] == '0'); }();
     if (!on) return false;
     for (int i = 0; i < n_nets; ++i)
-        if (nets[i].hid > 112 || (long)B * nets[i].hid >= (1L << 29)) return false;     // (byte offsets are 32-bit)
+        if (nets[i].hid > 112) return false;
     return true;
 }
 
 int nlbac_mlp_dw16_launch(const MlpLaunch& L, int n_nets, hipStream_t s) {
     int max_hid = 0, max_layers = 0;
     for (int i = 0; i < n_nets; ++i) {
+        // (byte offsets into a layer's rows are 32-bit.  An error rather than the older kernels: those leave the skinny
+        // gradients in slab 0 only, and a caller that alternates between the two would sum stale partials)
+        NLBAC_REQUIRE((long)L.B * L.net[i].hid < (1L << 29), "nlbac_mlp_bwd_weights: %d rows x %d units exceed 2^29 elements per layer",
+                      L.B, L.net[i].hid);
         if (L.net[i].hid > max_hid) max_hid = L.net[i].hid;
         if (L.net[i].n_layers > max_layers) max_layers = L.net[i].n_layers;
     }

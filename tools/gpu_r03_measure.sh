@@ -40,5 +40,12 @@ fi
 if [ $PART = c ]; then
 bash tools/gpu_launch_table.sh r03
 cp gpurun_out/r03_launches.txt $O/launches_per_update.txt
+echo "== calibration: a register-resident layer chain alone on the chip"
+mkdir -p tools/micro/bin
+hipcc --offload-arch=gfx950 -O3 tools/micro/rr_chain.hip -o tools/micro/bin/rr_chain && tools/micro/bin/rr_chain > $O/calibration_rr_chain.txt 2>&1
+echo "== shader-clock stamps of the fused RK forward (the -DRR_TIMING build made in the build container)"
+V=$(echo neural-*-nlbac_amd/lib/variants/libnlbac_hip_rrtiming.so)
+NLBAC_HIP_LIB=$V python tools/phase_times_rr.py 8192 1 > $O/phase_times_node_rr_fwd.txt 2>&1
+NLBAC_HIP_LIB=$V python tools/phase_times_rr.py 32768 0 >> $O/phase_times_node_rr_fwd.txt 2>&1
 fi
 echo done

@@ -16,7 +16,7 @@ for s, e, name in seg:
     t[name] += e - s
 for name, v in sorted(t.items(), key=lambda kv: -kv[1]):
     print("%-46s %5.2f /update  %7.1f us/update  avg %.1f us" % (name, c[name] / n, v / n / 1e3, v / c[name] / 1e3))
-mf = ("mlp_", "node_rk", "concat_rk", "node_adj")
+mf = ("mlp_", "node_rk", "node_rr", "concat_rk", "concat_rr", "node_adj")
 print("updates %d..%d: span %.1f us/update, busy %.1f us/update, %.1f launches/update, of which not MFMA tile kernels: %.1f (%.1f us)"
       % (a, b, (seg[-1][1] - seg[0][0]) / n / 1e3, sum(t.values()) / n / 1e3, len(seg) / n,
          sum(v for k, v in c.items() if not k.startswith(mf)) / n, sum(v for k, v in t.items() if not k.startswith(mf)) / n / 1e3))
