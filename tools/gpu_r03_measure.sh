@@ -25,9 +25,11 @@ if [ $PART = b ]; then
 echo "== Pvtol B=16384 direct / adjoint"
 python bench.py --env Pvtol --batch 16384 --steps 60 --no-cpu-baseline > $O/bench_pvtol.json 2> $O/bench_pvtol.err
 python bench.py --env Pvtol --batch 16384 --adjoint --steps 60 --no-cpu-baseline > $O/bench_pvtol_adjoint.json 2> $O/bench_pvtol_adjoint.err
+fi
+if [ $PART = b2 ]; then
 echo "== 2 ranks sharing the card (gloo rehearsal of the N>1 line), per-shard and all-reduced step control"
 for M in shard global; do
-NLBAC_BENCH_BACKEND=gloo python -m torch.distributed.run --nnodes=1 --nproc-per-node 2 --master-addr 127.0.0.1 --master-port 29511 bench.py --gpus 2 --steps 40 --warmup 10 --no-cpu-baseline --dp-step-control $M > $O/bench_2rank_gloo_$M.json 2> $O/bench_2rank_gloo_$M.err || tail -5 $O/bench_2rank_gloo_$M.err
+NLBAC_BENCH_BACKEND=gloo timeout -k 10 300 python -m torch.distributed.run --nnodes=1 --nproc-per-node 2 --master-addr 127.0.0.1 --master-port 29511 bench.py --gpus 2 --steps 40 --warmup 10 --no-cpu-baseline --dp-step-control $M > $O/bench_2rank_gloo_$M.json 2> $O/bench_2rank_gloo_$M.err || tail -5 $O/bench_2rank_gloo_$M.err
 done
 echo "== micro-benchmarks"
 python tools/fit_span.py 32768 51 > $O/fit_span.txt 2>&1

@@ -50,4 +50,4 @@ for _ in range(20):
 ts.sort()
 gb = sum(2 * (nl - 1) * B * hid * 4 for _, _, nl in shapes) / 1e9
 print("bwd_weights rows %d slabs %d hid %d: median %.1f us  min %.1f us   (%.2f GB of dz + activations: %.2f TB/s)"
-      % (B, slabs, hid, ts[len(ts) // 2], ts[0], gb, gb / ts[len(ts) // 2] * 1e-6 * 1e9 / 1e3))
+      % (B, slabs, hid, ts[len(ts) // 2], ts[0], gb, gb / ts[len(ts) // 2] * 1e3))
