@@ -283,3 +283,14 @@ def test_dynamics_model_pvtol_returns_state_pair():
     np.testing.assert_allclose(np.cos(st[:, 2]), tr["obs"][:, 2], atol=1e-12)
     st_t, dyn_t = dm.get_state(torch.tensor(tr["obs"][0], dtype=torch.float32))
     assert st_t.shape == (7,) and dyn_t.shape == (6,) and st_t.dtype == torch.float32
+
+
+def test_graft_entry_build_is_the_drivers_build_check():
+    """``__graft_entry__.build()`` is what the driver runs as its "does it build" check: it must compile (incrementally
+    here), load the library and agree with the header's ABI version (it once compared against a literal that the
+    header had moved past)."""
+    import importlib
+    import sys
+    sys.path.insert(0, ROOT) if ROOT not in sys.path else None
+    g = importlib.import_module("__graft_entry__")
+    g.build()
