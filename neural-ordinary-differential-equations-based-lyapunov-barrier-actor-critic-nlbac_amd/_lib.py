@@ -233,6 +233,10 @@ def load():
     if not os.path.exists(LIB_PATH):
         raise NlbacError("HIP extension missing: %s (run __graft_entry__.build() / make -C %s); "
                          "there is no CPU fallback" % (LIB_PATH, CSRC))
+    # PyTorch first: its wheel carries its own libamdhip64.  Loaded after it, this library binds to that same runtime;
+    # loaded BEFORE it (nothing else of the package imports torch on the way here), it would pull the system's copy and
+    # the process would hold two HIP runtimes — the second one to initialise sees "no ROCm-capable device".
+    import torch  # noqa: F401
     lib = C.CDLL(LIB_PATH)
     for name, argtypes in _PROTOS.items():
         fn = getattr(lib, name)   # AttributeError if the symbol is not exported
