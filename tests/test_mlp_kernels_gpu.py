@@ -60,6 +60,10 @@ def torch_ref(ref, x, dy):
     (6, 100, 12, 4, 45, 0),      # Pvtol g_net
     (16, 64, 16, 3, 40, 0),      # widest skinny layers the weight-gradient kernel takes
     (3, 8, 2, 2, 5, 0),          # smallest legal net
+    (5, 80, 3, 4, 130, 3),       # 6-tile form of the one-launch weight gradients (dwordx4 + dwordx2 columns), split input
+    (4, 96, 5, 3, 61, 0),        # the widest 6-tile net, no hid x hid... one hid x hid layer, ragged rows (61 = 15 k-steps + 1)
+    (6, 112, 4, 4, 203, 0),      # the widest net the one-launch kernel takes (7 full tiles)
+    (3, 100, 3, 5, 1000, 0),     # f_net on more rows than slabs x waves x ring depth
 ])
 def test_mlp_fwd_bwd_matches_torch(in_dim, hid, out_dim, n_layers, B, split):
     from nlbac_amd import _lib, arena as A
@@ -262,3 +266,51 @@ def test_skinny_gradient_partials_from_the_data_backward_are_bit_identical(B, hi
                 assert torch.equal(torch.nan_to_num(ga), torch.nan_to_num(gb)) and \
                     torch.equal(torch.isnan(ga), torch.isnan(gb))
                 assert torch.isfinite(ga[0]).all()
+
+
+def test_one_launch_weight_gradients_of_nets_of_different_width_and_depth():
+    """``mlp_dw16_kernels.hip`` picks its tile count from the widest net of a launch and its layer slots from the
+    deepest: a 100-wide 5-layer net and a 64-wide 3-layer net in ONE ``nlbac_mlp_bwd_weights`` call (the narrower net's
+    lanes past its width read out of range = zeros; its missing layer slots return at once), against torch autograd."""
+    from nlbac_amd import _lib, arena as A
+    shapes = [(3, 100, 3, 5), (12, 64, 10, 3)]
+    B = 333
+    torch.manual_seed(5)
+    mods = [[nn.Linear(i, h)] + [nn.Linear(h, h) for _ in range(nl - 2)] + [nn.Linear(h, o)] for i, h, o, nl in shapes]
+    host = [[(l.weight.detach().clone(), l.bias.detach().clone()) for l in m] for m in mods]     # (bind() moves the parameters)
+    ar = A.Arena("cuda", n_slabs=6)
+    hs = [A.MlpHandle(ar, [(l.weight, l.bias) for l in m]) for m in mods]
+    ar.finalize()
+    for h in hs:
+        h.bind()
+    A.pack(hs)
+    nets = A.mlp_array([h.desc for h in hs])
+    io = A.io_array(2)
+    keep, refs = [], []
+    for k, ((idim, hid, odim, nl), m) in enumerate(zip(shapes, mods)):
+        x = torch.randn(B, idim, generator=torch.Generator().manual_seed(10 + k))
+        dy = torch.randn(B, odim, generator=torch.Generator().manual_seed(20 + k))
+        xd, dyd = x.cuda(), dy.cuda()
+        y = torch.empty(B, odim, device="cuda")
+        acts, dz = torch.empty(nl - 1, B, hid, device="cuda"), torch.empty(nl - 1, B, hid, device="cuda")
+        keep += [xd, dyd, y, acts, dz]
+        io[k].x0, io[k].x0_dim, io[k].x0_ld = xd.data_ptr(), idim, idim
+        io[k].y, io[k].y_ld = y.data_ptr(), odim
+        io[k].acts, io[k].dz = acts.data_ptr(), dz.data_ptr()
+        io[k].dy, io[k].dy_ld = dyd.data_ptr(), odim
+        io[k].grad = ar.grad.data_ptr()
+        refs.append(torch_ref(host[k], x, dy)[3])
+    ar.grad.fill_(float("nan"))
+    s = A.stream_ptr()
+    # (the two nets differ in depth, so the forward / data backward go net by net; the weight gradients in one call)
+    for k in range(2):
+        one_n, one_io = A.mlp_array([hs[k].desc]), A.io_array(1)
+        C.memmove(C.byref(one_io[0]), C.byref(io[k]), C.sizeof(io[k]))
+        _lib.call("nlbac_mlp_fwd", one_n, one_io, 1, B, s)
+        _lib.call("nlbac_mlp_bwd_data", one_n, one_io, 1, B, s)
+    A.bwd_weights(nets, io, 2, B, ar.n_slabs, ar.n, "cuda")
+    torch.cuda.synchronize()
+    for m, ref in zip(mods, refs):
+        for l, (gw, gb) in zip(m, ref):
+            vec_close(ar.grad_view(l.weight).cpu(), gw, TOL, "dW")
+            vec_close(ar.grad_view(l.bias).cpu(), gb, TOL, "db")
