@@ -294,3 +294,37 @@ def test_graft_entry_build_is_the_drivers_build_check():
     sys.path.insert(0, ROOT) if ROOT not in sys.path else None
     g = importlib.import_module("__graft_entry__")
     g.build()
+
+
+def test_pmc_summary_differences_two_run_lengths(tmp_path):
+    """tools/pmc_summary.py: per_update_bytes is the DIFFERENCE of two lean processes' counter totals over the difference
+    of their update counts — what a process does once (zero fills at allocation) must cancel and show up as
+    one_time_bytes; the read side is doubled (gfx950 tallies 128-byte requests at 64 bytes), KiB -> bytes."""
+    import csv
+    import json
+    import subprocess
+    import sys
+
+    def write(d, counter, rows):
+        os.makedirs(d, exist_ok=True)
+        with open(os.path.join(d, "run_counter_collection.csv"), "w", newline="") as fh:
+            w = csv.writer(fh)
+            w.writerow(["Kernel_Name", "Counter_Name", "Counter_Value"])
+            for name, n, kib in rows:
+                for _ in range(n):
+                    w.writerow([name, counter, kib])
+
+    k, fill = "void node_rr_fwd_kernel<7, 1, 1>(NodeRkLaunch)", "void at::native::fill_kernel<float>(float*)"
+    # per update: 2 launches of k reading 100 KiB (tallied as 50) and writing 10 KiB each; once per process: a 4000 KiB fill
+    for n_upd in (30, 50):
+        write(str(tmp_path / ("f%d" % n_upd)), "FETCH_SIZE", [(k, 2 * n_upd, 50.0), (fill, 1, 0.0)])
+        write(str(tmp_path / ("w%d" % n_upd)), "WRITE_SIZE", [(k, 2 * n_upd, 10.0), (fill, 1, 4000.0)])
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "pmc_summary.py"), str(tmp_path / "f50"), str(tmp_path / "w50"),
+                        "50", str(tmp_path / "f30"), str(tmp_path / "w30"), "30"], capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr[-2000:]
+    d = json.loads(r.stdout)
+    per_update = 2 * (2 * 50.0 + 10.0) * 1024
+    assert d["updates"] == 20 and abs(d["per_update_bytes"] - per_update) < 1e-6
+    assert abs(d["one_time_bytes"] - 4000.0 * 1024) < 1e-3
+    assert abs(d["kernels"]["node_rr_fwd_kernel"]["hbm_bytes_per_launch"] - (2 * 50.0 + 10.0) * 1024) < 1e-6
+    assert abs(d["per_update_by_kernel"]["node_rr_fwd_kernel"] - per_update) < 1e-6
