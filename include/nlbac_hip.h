@@ -32,7 +32,7 @@
 extern "C" {
 #endif
 
-#define NLBAC_ABI_VERSION 2 /* bumped whenever an exported signature or struct changes; nlbac_abi_version() returns it */
+#define NLBAC_ABI_VERSION 3 /* bumped whenever an exported signature or struct changes; nlbac_abi_version() returns it */
 #define NLBAC_MAX_LAYERS 6
 #define NLBAC_MAX_NETS 8
 #define NLBAC_MLP_TILE 32 /* samples per workgroup in the MLP kernels */
@@ -93,6 +93,9 @@ typedef struct nlbac_mlp_io {
     const float *dy; int dy_ld;         /* bwd in:  (B, out_dim)                    */
     float *dz;                          /* [n_layers-1][B][hid] pre-activation grads (bwd_data out, bwd_weights in) */
     float *dx; int dx_ld;               /* bwd_data out: (B, in_dim) or NULL        */
+    int dx_first;                       /* first input column dx is wanted for: columns [0, dx_first) of dx are NOT
+                                           written (the Q(s, pi) nets' gradient is consumed for the action columns only).
+                                           Sits in what was padding: sizeof and the other offsets are unchanged */
     float *grad;                        /* bwd_weights out: slab 0 of the flat grad (same offsets as params) */
     float *skinny_ws;                   /* or NULL.  This net's block of the nlbac_mlp_bwd_weights workspace (ws +
                                            i * ws_floats / n_nets): nlbac_mlp_bwd_data then leaves the per-32-row partial

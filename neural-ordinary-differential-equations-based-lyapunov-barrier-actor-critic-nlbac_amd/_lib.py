@@ -41,7 +41,7 @@ class MlpIO(C.Structure):
                 ("acts", C.c_void_p), ("acts_ls", C.c_long),
                 ("dy", C.c_void_p), ("dy_ld", C.c_int),
                 ("dz", C.c_void_p),
-                ("dx", C.c_void_p), ("dx_ld", C.c_int),
+                ("dx", C.c_void_p), ("dx_ld", C.c_int), ("dx_first", C.c_int),
                 ("grad", C.c_void_p),
                 ("skinny_ws", C.c_void_p)]
 
@@ -211,7 +211,7 @@ def build(verbose=False):
     return LIB_PATH
 
 
-ABI_VERSION = 2      # == NLBAC_ABI_VERSION of include/nlbac_hip.h (bumped with every signature / struct change)
+ABI_VERSION = 3      # == NLBAC_ABI_VERSION of include/nlbac_hip.h (bumped with every signature / struct change)
 
 
 def _stale_sources():

@@ -366,7 +366,7 @@ __global__ __launch_bounds__(256, 2) void mlp_bwd_data_kernel(const MlpLaunch L,
         const float* W = net.params + net.w_off[0];
         const int idim = net.in_dim;
         const int m = tid >> 3, part = tid & 7, row = row0 + m;
-        for (int i0 = 0; i0 < idim; i0 += 4) {
+        for (int i0 = io.dx_first; i0 < idim; i0 += 4) {      // (columns below dx_first are not wanted: nlbac_mlp_io)
             const int ni = min(4, idim - i0);
             float a[4] = {0.f, 0.f, 0.f, 0.f};
             const float* drow = in + m * LD;
@@ -929,6 +929,9 @@ static int mlp_bwd_data_launch(const nlbac_mlp* nets, const nlbac_mlp_io* io, in
     if (fill_launch(L, nets, io, n_nets, B, who)) return -1;
     for (int i = 0; i < n_nets; ++i)
         NLBAC_REQUIRE((io[i].dy || H.kind) && io[i].acts, "%s: net %d needs dy and acts", who, i);
+    for (int i = 0; i < n_nets; ++i)
+        NLBAC_REQUIRE(!io[i].dx || (io[i].dx_first >= 0 && io[i].dx_first < nets[i].in_dim),
+                      "%s: net %d: dx_first %d out of [0, in_dim %d)", who, i, io[i].dx_first, nets[i].in_dim);
     for (int i = 0; i < n_nets; ++i)
         NLBAC_REQUIRE(!io[i].skinny_ws || (B <= 32768 && io[i].x0 && io[i].dz && nets[i].hid <= 256),
                       "%s: net %d: skinny-gradient partials need x0, dz, hid <= 256 and B <= 32768", who, i);

@@ -676,6 +676,7 @@ class SAC_CBF_CLF(object):
             io[i].acts = ws.acts_q[i].data_ptr()
             io[i].dy, io[i].dy_ld = ws.dq_pi[i % 2, half * B:].data_ptr(), 1
             io[i].dx, io[i].dx_ld = ws.dxq[i % 2, half * B:].data_ptr(), Do + Da
+            io[i].dx_first = Do                                # (only dQ / da is consumed)
         self.task.value_now_io(ws, io, 2 * NP)
         self.task.extra_value_io(ws, io, 2 * NP + 1)
         self.task.plan(ws, P)

@@ -314,3 +314,35 @@ def test_one_launch_weight_gradients_of_nets_of_different_width_and_depth():
         for l, (gw, gb) in zip(m, ref):
             vec_close(ar.grad_view(l.weight).cpu(), gw, TOL, "dW")
             vec_close(ar.grad_view(l.bias).cpu(), gb, TOL, "db")
+
+
+def test_dx_first_limits_the_input_gradient_to_the_wanted_columns():
+    """``nlbac_mlp_io::dx_first``: the data backward writes dx for input columns >= dx_first only (the Q(s, pi) nets'
+    gradient is consumed for the action columns) — those columns equal the full gradient's, the others stay untouched."""
+    from nlbac_amd import _lib, arena as A
+    in_dim, hid, out_dim, B = 9, 256, 1, 200
+    ar, h, lins, ref = build(in_dim, hid, out_dim, 3, seed=11)
+    x = torch.randn(B, in_dim, generator=torch.Generator().manual_seed(1))
+    dy = torch.randn(B, out_dim, generator=torch.Generator().manual_seed(2))
+    _, _, dx_ref, _ = torch_ref(ref, x, dy)
+    xd, dyd = x.cuda(), dy.cuda()
+    y = torch.empty(B, out_dim, device="cuda")
+    acts, dz = torch.empty(2, B, hid, device="cuda"), torch.empty(2, B, hid, device="cuda")
+    nets, s = A.mlp_array([h.desc]), A.stream_ptr()
+    for first in (0, 4, 7, 8):
+        dx = torch.full((B, in_dim), float("nan"), device="cuda")
+        io = A.io_array(1)
+        io[0].x0, io[0].x0_dim, io[0].x0_ld = xd.data_ptr(), in_dim, in_dim
+        io[0].y, io[0].y_ld = y.data_ptr(), out_dim
+        io[0].acts, io[0].dz = acts.data_ptr(), dz.data_ptr()
+        io[0].dy, io[0].dy_ld = dyd.data_ptr(), out_dim
+        io[0].dx, io[0].dx_ld, io[0].dx_first = dx.data_ptr(), in_dim, first
+        _lib.call("nlbac_mlp_fwd", nets, io, 1, B, s)
+        _lib.call("nlbac_mlp_bwd_data", nets, io, 1, B, s)
+        torch.cuda.synchronize()
+        got = dx.cpu()
+        assert torch.isnan(got[:, :first]).all(), "columns below dx_first were written"
+        vec_close(got[:, first:], dx_ref[:, first:], TOL, "dx[:, %d:]" % first)
+    io[0].dx_first = in_dim
+    with pytest.raises(_lib.NlbacError):
+        _lib.call("nlbac_mlp_bwd_data", nets, io, 1, B, s)
