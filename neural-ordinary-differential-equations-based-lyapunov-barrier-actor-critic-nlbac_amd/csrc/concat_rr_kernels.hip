@@ -15,6 +15,13 @@
 #define CRR_MAX_IN 15       /* in_dim + the bias column <= 16: four k-steps of layer 0 */
 
 // this lane's state component in register r: c = 4 r + q (the layout of layer 0's B operand and of the output block)
+#ifdef RR_TIMING
+#define CSTAMP(slot_) if (L.err && blockIdx.x == 0 && lane == 0) reinterpret_cast<long long*>(L.err)[half * 256 + (slot_)] = (long long)__builtin_readcyclecounter();
+#define BSTAMP(slot_) if (L.dyn && !L.norm && blockIdx.x == 0 && lane == 0) reinterpret_cast<long long*>(L.dyn)[half * 256 + (slot_)] = (long long)__builtin_readcyclecounter();
+#else
+#define CSTAMP(slot_)
+#define BSTAMP(slot_)
+#endif
 template <int NB, int R, int BITS>
 __global__ __launch_bounds__(128) void concat_rr_fwd_kernel(const ConcatRkLaunch L) {
     using S = RRShape<NB, R>;
@@ -44,7 +51,7 @@ __global__ __launch_bounds__(128) void concat_rr_fwd_kernel(const ConcatRkLaunch
     const int n_rows = min(NLBAC_MLP_TILE, n - row0);
     const int q = lane >> 4, r16 = lane & 15, m = 16 * half + r16, grow = row0 + m;
     const bool row_ok = grow < n;
-    const int KS0 = (ns + 3) >> 2, KL0 = (idim + 4) >> 2;      // registers per row of state; k-steps of layer 0 over [x | c | 1]
+    const int KS0 = (ns + 3) >> 2;      // registers per row of state (layer 0 always runs four k-steps over [x | c | 1 | 0..])
     const float* const params = net.params;
     float* const acts = L.acts ? L.acts + soff : nullptr;
     const long acts_ls = L.acts_ls;
@@ -61,6 +68,7 @@ __global__ __launch_bounds__(128) void concat_rr_fwd_kernel(const ConcatRkLaunch
     const __amdgpu_buffer_rsrc_t rs = rr_rsrc(net.packed, net.packed_floats);
     const int voff = lane * 16, wbase = net.rr_fwd_off * 4;
     RRGemm<S> gemm;
+    CSTAMP(0)
     gemm.prime(rs, voff, wbase);
 
     // ---- constants: layer 0's A fragments over [x | c | 1] (bias in the column behind the inputs) -> LDS, the output
@@ -72,8 +80,9 @@ __global__ __launch_bounds__(128) void concat_rr_fwd_kernel(const ConcatRkLaunch
         for (int k0 = 0; k0 < 4; ++k0)
 #pragma unroll
             for (int jo = 0; jo < NB; ++jo) {
-                const int uo = rr_unit_out(NB, R, jo, r16), col = 4 * k0 + q;
-                sW0[(k0 * 8 + jo) * 64 + lane] = (uo < 0 || col > idim) ? 0.f : (col < idim ? W0[uo * idim + col] : b0[uo]);
+                const int uo = rr_unit_out(NB, R, jo, r16), col = 4 * k0 + q, uc = max(uo, 0);
+                const float vw = W0[uc * idim + min(col, idim - 1)], vb0 = b0[uc];
+                sW0[(k0 * 8 + jo) * 64 + lane] = (uo < 0 || col > idim) ? 0.f : (col < idim ? vw : vb0);
             }
     }
     float wo[KS];
@@ -88,79 +97,137 @@ __global__ __launch_bounds__(128) void concat_rr_fwd_kernel(const ConcatRkLaunch
             for (int r = 0; r < ((jo < NB - 1) ? 4 : R); ++r) wo[4 * jo + r] = ok ? v[r] : 0.f;
         }
     }
+    // (every load of the prologue is unconditional — clamped index, select afterwards — so that they are all in flight
+    // together: as guarded loads each was a branch and an L2 round trip of its own, 8k cycles before the first stage)
     float o_bias[4], o_mu[4], o_sig[4];
+    const float* const nrm_v = nrm ? nrm : params;        // (a readable address either way)
+    const int nrm_n = nrm ? 2 * idim + 2 * ns : 1;
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
-        const int c = 4 * r + q;
+        const int c = 4 * r + q, cc = min(c, ns - 1);
         const bool ok = r < KS0 && c < ns;
-        o_bias[r] = ok ? params[net.b_off[3] + c] : 0.f;
-        o_mu[r] = (ok && nrm) ? nrm[2 * idim + c] : 0.f;
-        o_sig[r] = (ok && nrm) ? nrm[2 * idim + ns + c] : 1.f;
+        const float vb = params[net.b_off[3] + cc];
+        const float vm = nrm_v[min(2 * idim + cc, nrm_n - 1)], vs = nrm_v[min(2 * idim + ns + cc, nrm_n - 1)];
+        o_bias[r] = ok ? vb : 0.f;
+        o_mu[r] = (ok && nrm) ? vm : 0.f;
+        o_sig[r] = (ok && nrm) ? vs : 1.f;
     }
     // this lane's input columns 4 k0 + q: where they come from, their normalisation
     float i_mu[4], i_isig[4];
 #pragma unroll
     for (int k0 = 0; k0 < 4; ++k0) {
-        const int col = 4 * k0 + q;
-        i_mu[k0] = (nrm && col < idim) ? nrm[col] : 0.f;
-        i_isig[k0] = (nrm && col < idim) ? nrm[idim + col] : 1.f;
+        const int col = 4 * k0 + q, cc = min(col, idim - 1);
+        const float vm = nrm_v[min(cc, nrm_n - 1)], vs = nrm_v[min(idim + cc, nrm_n - 1)];
+        i_mu[k0] = (nrm && col < idim) ? vm : 0.f;
+        i_isig[k0] = (nrm && col < idim) ? vs : 1.f;
     }
     // ---- this wave's rows of the tile constants
     for (int idx = lane; idx < 16 * CK_NS; idx += 64) {
         const int mm = 16 * half + idx / CK_NS, c = idx % CK_NS, row = row0 + mm;
-        sY0[mm * CK_NS + c] = (row < n && c < ns) ? gy0[(long)row * ns + c] : 0.f;
+        const float v = gy0[(long)min(row, n - 1) * ns + min(c, ns - 1)];
+        sY0[mm * CK_NS + c] = (row < n && c < ns) ? v : 0.f;
     }
     {
         const int mm = 16 * half + (lane >> 2), c = lane & 3, row = row0 + mm;
-        sC[mm * CK_NC + c] = (row < n && c < nc) ? L.c[(long)row * nc + c] : 0.f;
+        const float v = L.c[(long)min(row, n - 1) * nc + min(c, max(nc - 1, 0))];
+        sC[mm * CK_NC + c] = (row < n && c < nc) ? v : 0.f;
     }
     if (lane < 16) {
         const int p = min(row0 + 16 * half + lane, n - 1) / L.rpp;
         sH[16 * half + lane] = L.h_dev ? (float)L.h_dev[(long)p * L.h_stride] : L.h_val[p];
     }
-    for (int idx = lane; idx < L.stage_begin * 16 * CK_NS; idx += 64) {      // stages of an earlier launch
-        const int j = idx / (16 * CK_NS), rem = idx - j * 16 * CK_NS;
-        const int mm = 16 * half + rem / CK_NS, c = rem % CK_NS, row = row0 + mm;
-        float v = 0.f;
-        if (row < n && c < ns) {
-            if (fsal && j == 0) {       // first stage = the previous slot's last one; kept in this slot for the interpolant
-                v = (gK - L.slot_floats)[((long)(L.S_total - 1) * n + row) * ns + c];
-                gK[(long)row * ns + c] = v;
-            } else {
-                v = gK[((long)j * n + row) * ns + c];
+    if (L.stage_begin > 0) {      // stages of an earlier launch: all loads first, then the LDS (and FSAL) stores
+        constexpr int NIT = CK_MAX_STAGES * 16 * CK_NS / 64;
+        float vals[NIT];
+#pragma unroll
+        for (int it = 0; it < NIT; ++it) {
+            const int idx = lane + 64 * it;
+            const int j = idx / (16 * CK_NS), rem = idx - j * 16 * CK_NS;           // (j is uniform per iteration)
+            const int mm = 16 * half + rem / CK_NS, c = rem % CK_NS, row = row0 + mm;
+            const long rc = (long)min(row, n - 1) * ns + min(c, ns - 1);
+            float v = 0.f;
+            if (j < L.stage_begin) {
+                if (fsal && j == 0) v = (gK - L.slot_floats)[(long)(L.S_total - 1) * n * ns + rc];   // first stage = the previous slot's last
+                else v = gK[(long)j * n * ns + rc];
+            }
+            vals[it] = (row < n && c < ns) ? v : 0.f;
+        }
+#pragma unroll
+        for (int it = 0; it < NIT; ++it) {
+            const int idx = lane + 64 * it;
+            const int j = idx / (16 * CK_NS), rem = idx - j * 16 * CK_NS;
+            const int mm = 16 * half + rem / CK_NS, c = rem % CK_NS, row = row0 + mm;
+            if (j < L.stage_begin) {
+                sK[(j * NLBAC_MLP_TILE + mm) * CK_NS + c] = vals[it];
+                if (fsal && j == 0 && row < n && c < ns) gK[(long)row * ns + c] = vals[it];   // kept in this slot for the interpolant
             }
         }
-        sK[(j * NLBAC_MLP_TILE + mm) * CK_NS + c] = v;
+    }
+    // narrow nets keep both hid x hid layers' biases in registers for the whole launch: a bias load inside the stage loop
+    // queues behind the previous stage's stores (vmcnt is in order) and the layer's first MFMAs need it as their C operand
+    constexpr bool BRES = NB <= 4;
+    f32x4 bres[BRES ? 2 : 1][NB];
+    if (BRES) {
+#pragma unroll
+        for (int l = 0; l < 2; ++l)
+#pragma unroll
+            for (int jo = 0; jo < NB; ++jo) bres[BRES ? l : 0][jo] = rr_bias<S>(params + net.b_off[1 + l], jo, q);
     }
     __syncthreads();           // (sW0 is shared by the two waves; everything else above is the wave's own rows)
+    CSTAMP(1)
 
+    // (a stage's tableau row is a scalar load from the kernel arguments: requested one stage ahead, its latency — a
+    // scalar-cache miss per stage — is off the stage's critical path)
+    float bnext[CK_MAX_STAGES];
+#pragma unroll
+    for (int j = 0; j < CK_MAX_STAGES; ++j) bnext[j] = L.beta[L.stage_begin][j];
     for (int st = L.stage_begin; st < stage_end; ++st) {
+        const int sb = 2 + 8 * (st - L.stage_begin);
+        (void)sb;
+        CSTAMP(sb + 0)
         float bn[CK_MAX_STAGES];
 #pragma unroll
-        for (int j = 0; j < CK_MAX_STAGES; ++j) bn[j] = L.beta[st][j];
+        for (int j = 0; j < CK_MAX_STAGES; ++j) bn[j] = bnext[j];
+        {
+            const int sn = min(st + 1, L.S_total - 1);
+#pragma unroll
+            for (int j = 0; j < CK_MAX_STAGES; ++j) bnext[j] = L.beta[sn][j];
+        }
         const long srow = (long)st * n + grow;
         // ---- stage input [Y_st | c | 1] in registers,  Y_st = y0 + h sum_j beta[st][j] K_j  (rk_combine_kernel's op order)
-        float yv[4];
+        // What a stage leaves in global memory — Y_st, K_st, the layers' mask words — is stored in ONE burst at its end:
+        // vmcnt counts stores and loads in order, so a store issued between two weight-fragment loads makes the MFMAs
+        // behind the second one wait for the store's trip to HBM (a 64-wide layer is 2k cycles of MFMAs: one such wait
+        // per layer doubled it).  Behind the burst come the next stage's input and layer 0, which need no load.
+        float yv[4], ykeep[4] = {0.f, 0.f, 0.f, 0.f};
+        unsigned wsave0 = 0u, wsave1 = 0u, wsave2 = 0u;
         {
+            // (no data-dependent branch: every lane requests its operands with clamped indices, all reads in flight
+            // together, selects at the end — the per-column if / else ladder was four serialised LDS round trips)
             const float h = sH[m];
+            float y0v[4], cv[4], kv[4][CK_MAX_STAGES - 1];
+#pragma unroll
+            for (int k0 = 0; k0 < 4; ++k0) {
+                const int col = 4 * k0 + q, cs = min(col, ns - 1), cc = min(max(col - ns, 0), max(nc - 1, 0));
+                y0v[k0] = sY0[m * CK_NS + cs];
+                cv[k0] = sC[m * CK_NC + cc];
+#pragma unroll
+                for (int j = 0; j < CK_MAX_STAGES - 1; ++j) kv[k0][j] = sK[(j * NLBAC_MLP_TILE + m) * CK_NS + cs];
+            }
 #pragma unroll
             for (int k0 = 0; k0 < 4; ++k0) {
                 const int col = 4 * k0 + q;
-                float a = 0.f;
-                if (col < ns) {
-                    a = sY0[m * CK_NS + col];
+                float a = y0v[k0];
 #pragma unroll
-                    for (int j = 0; j < CK_MAX_STAGES - 1; ++j) {
-                        const float t = a + sK[(j * NLBAC_MLP_TILE + m) * CK_NS + col] * (bn[j] * h);
-                        a = (j < st && bn[j] != 0.f) ? t : a;
-                    }
-                    if (row_ok) gY[srow * ns + col] = a;
-                } else if (col < idim) {
-                    a = sC[m * CK_NC + (col - ns)];
+                for (int j = 0; j < CK_MAX_STAGES - 1; ++j) {
+                    const float t = a + kv[k0][j] * (bn[j] * h);
+                    a = (j < st && bn[j] != 0.f) ? t : a;
                 }
-                if (nrm && col < idim) {
-                    a = (a - i_mu[k0]) * i_isig[k0];
-                    if (gXn && row_ok) gXn[srow * idim + col] = a;
+                ykeep[k0] = a;
+                a = (col < ns) ? a : ((col < idim) ? cv[k0] : 0.f);
+                if (nrm) {
+                    a = (col < idim) ? (a - i_mu[k0]) * i_isig[k0] : a;
+                    if (gXn && row_ok && col < idim) gXn[srow * idim + col] = a;
                 }
                 yv[k0] = (col == idim) ? 1.f : a;
             }
@@ -168,6 +235,7 @@ __global__ __launch_bounds__(128) void concat_rr_fwd_kernel(const ConcatRkLaunch
         float Ha[KS], Hb[KS];
         f32x4 acc0[NB], acc[NB], bv[NB], bpre[3];
         auto prefetch_bias = [&](int l) __attribute__((always_inline)) {
+            if (BRES) return;
 #pragma unroll
             for (int jo = 0; jo < G0; ++jo) bpre[jo] = rr_bias<S>(params + net.b_off[l], jo, q);
         };
@@ -180,8 +248,8 @@ __global__ __launch_bounds__(128) void concat_rr_fwd_kernel(const ConcatRkLaunch
             for (int rr = 0; rr < ((jo < NB - 1) ? 4 : R); ++rr) hv[rr] = H[4 * jo + rr];
             rr_row_store<S>(acts + (long)l * acts_ls + srow * HID, jo, q, hv);
         };
-        auto save_word = [&](int l) __attribute__((always_inline)) {
-            if (BITS && acts && row_ok) reinterpret_cast<unsigned*>(acts + (long)l * acts_ls)[srow * 4 + q] = wd;
+        auto save_word = [&](int l) __attribute__((always_inline)) {       // (kept; stored with the stage's burst)
+            if (l == 0) wsave0 = wd; else if (l == 1) wsave1 = wd; else wsave2 = wd;
         };
         auto pre_l0 = [&](int ks) __attribute__((always_inline)) {
             const int jo = (ks < 4 * (NB - 1)) ? (ks >> 2) : NB - 1, r = ks - 4 * jo;
@@ -200,20 +268,30 @@ __global__ __launch_bounds__(128) void concat_rr_fwd_kernel(const ConcatRkLaunch
             if (t == 3 || t == NT - 1) save_block(lp, jo, H);
             if (t == NT - 1) save_word(lp);
         };
-        // ---- layer 0 (bias folded into the product)
+        CSTAMP(sb + 1)
+        // ---- layer 0 (bias folded into the product): always four k-steps — fragments and inputs past the width are zero —
+        //      with the k-step outside, so that the MFMAs of one block are NB issue slots apart and nothing branches
+        {
+            float a0[4][NB];
 #pragma unroll
-        for (int jo = 0; jo < NB; ++jo) {
-            f32x4 a = __builtin_amdgcn_mfma_f32_16x16x4f32(sW0[(0 * 8 + jo) * 64 + lane], yv[0], f32x4{0.f, 0.f, 0.f, 0.f}, 0, 0, 0);
-            if (KL0 > 1) a = __builtin_amdgcn_mfma_f32_16x16x4f32(sW0[(1 * 8 + jo) * 64 + lane], yv[1], a, 0, 0, 0);
-            if (KL0 > 2) a = __builtin_amdgcn_mfma_f32_16x16x4f32(sW0[(2 * 8 + jo) * 64 + lane], yv[2], a, 0, 0, 0);
-            if (KL0 > 3) a = __builtin_amdgcn_mfma_f32_16x16x4f32(sW0[(3 * 8 + jo) * 64 + lane], yv[3], a, 0, 0, 0);
-            acc0[jo] = a;
+            for (int k0 = 0; k0 < 4; ++k0)
+#pragma unroll
+                for (int jo = 0; jo < NB; ++jo) a0[k0][jo] = sW0[(k0 * 8 + jo) * 64 + lane];
+#pragma unroll
+            for (int jo = 0; jo < NB; ++jo)
+                acc0[jo] = __builtin_amdgcn_mfma_f32_16x16x4f32(a0[0][jo], yv[0], f32x4{0.f, 0.f, 0.f, 0.f}, 0, 0, 0);
+#pragma unroll
+            for (int k0 = 1; k0 < 4; ++k0)
+#pragma unroll
+                for (int jo = 0; jo < NB; ++jo)
+                    acc0[jo] = __builtin_amdgcn_mfma_f32_16x16x4f32(a0[k0][jo], yv[k0], acc0[jo], 0, 0, 0);
         }
         // ---- the two hid x hid layers, then the output layer (statically unrolled, as node_rr_kernels.hip)
         auto wide = [&](auto lc, float (&Hin)[KS], float (&Hout)[KS]) __attribute__((always_inline)) {
             constexpr int l = decltype(lc)::value;
 #pragma unroll
-            for (int jo = 0; jo < NB; ++jo) bv[jo] = (jo < G0) ? bpre[jo] : rr_bias<S>(params + net.b_off[l], jo, q);
+            for (int jo = 0; jo < NB; ++jo)
+                bv[jo] = BRES ? bres[BRES ? l - 1 : 0][jo] : ((jo < G0) ? bpre[jo] : rr_bias<S>(params + net.b_off[l], jo, q));
             __builtin_amdgcn_sched_barrier(0);
             const int cur = wbase + (l - 1) * S::LAYER_BYTES;
             const int nxt = (l == 1) ? cur + S::LAYER_BYTES : wbase;
@@ -230,8 +308,11 @@ __global__ __launch_bounds__(128) void concat_rr_fwd_kernel(const ConcatRkLaunch
                      },
                      [&]() __attribute__((always_inline)) { if (l == 1) prefetch_bias(2); });
         };
+        CSTAMP(sb + 2)
         wide(std::integral_constant<int, 1>{}, Ha, Hb);
+        CSTAMP(sb + 3)
         wide(std::integral_constant<int, 2>{}, Hb, Ha);
+        CSTAMP(sb + 4)
         {
             const f32x4 o = RRGemm<S>::block(wo, Ha, [&](int ks) __attribute__((always_inline)) { pre_tail(2, Ha, ks); });
 #pragma unroll
@@ -243,9 +324,21 @@ __global__ __launch_bounds__(128) void concat_rr_fwd_kernel(const ConcatRkLaunch
                     if (row_ok) gK[srow * ns + c] = val;
                 }
             }
+#pragma unroll
+            for (int k0 = 0; k0 < 4; ++k0)
+                if (row_ok && 4 * k0 + q < ns) gY[srow * ns + 4 * k0 + q] = ykeep[k0];
+            if (BITS && acts && row_ok) {
+                unsigned* wp = reinterpret_cast<unsigned*>(acts) + srow * 4 + q;
+                wp[0] = wsave0; wp[acts_ls] = wsave1; wp[2 * acts_ls] = wsave2;
+            }
         }
+        CSTAMP(sb + 5)
     }
     __syncthreads();
+    CSTAMP(2 + 8 * (stage_end - L.stage_begin))
+#ifdef RR_TIMING
+    if (L.err) return;
+#endif
 
     // ---- step outputs
     for (int idx = tid; idx < NLBAC_MLP_TILE * ns; idx += 128) {
@@ -401,6 +494,7 @@ __global__ __launch_bounds__(128) void concat_rr_bwd_kernel(const ConcatRkBwdLau
     const __amdgpu_buffer_rsrc_t rs = rr_rsrc(net.packed, net.packed_floats);
     const int voff = lane * 16, wbase = net.rr_bwd_off * 4;
     RRGemm<S> gemm;
+    BSTAMP(0)
     gemm.prime(rs, voff, wbase + S::LAYER_BYTES);           // (layer 2's fragments first, then layer 1's)
 
     if (half == 0) {
@@ -412,7 +506,8 @@ __global__ __launch_bounds__(128) void concat_rr_bwd_kernel(const ConcatRkBwdLau
 #pragma unroll
             for (int jo = 0; jo < NB; ++jo) {
                 const int uo = rr_unit_out(NB, R, jo, r16);
-                sWt[(e * 8 + jo) * 64 + lane] = (ok && uo >= 0) ? Wl[(long)c * HID + uo] : 0.f;
+                const float v = Wl[(long)min(c, ns - 1) * HID + max(uo, 0)];      // (unconditional: see the forward's prologue)
+                sWt[(e * 8 + jo) * 64 + lane] = (ok && uo >= 0) ? v : 0.f;
             }
         }
     }
@@ -421,61 +516,113 @@ __global__ __launch_bounds__(128) void concat_rr_bwd_kernel(const ConcatRkBwdLau
         const float* W0 = params + net.w_off[0];
         const bool ok = r16 < idim;
 #pragma unroll
-        for (int ks = 0; ks < KS; ++ks) w0t[ks] = ok ? W0[(long)rr_unit_in(NB, R, ks, q) * idim + r16] : 0.f;
+        for (int ks = 0; ks < KS; ++ks) {
+            const float v = W0[(long)rr_unit_in(NB, R, ks, q) * idim + min(r16, idim - 1)];
+            w0t[ks] = ok ? v : 0.f;
+        }
     }
     float o_sig[4], x_isig[4];
+    const float* const nrm_v = nrm ? nrm : params;
+    const int nrm_n = nrm ? 2 * idim + 2 * ns : 1;
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
         const int c = 4 * r + q;
-        o_sig[r] = (nrm && r < KS0 && c < ns) ? nrm[2 * idim + ns + c] : 1.f;
+        const float vs = nrm_v[min(2 * idim + ns + min(c, ns - 1), nrm_n - 1)];
+        o_sig[r] = (nrm && r < KS0 && c < ns) ? vs : 1.f;
         const int i = 4 * q + r;                     // dX leaves lane (q, row) with input column 4 q + r in register r
-        x_isig[r] = (nrm && i < idim) ? nrm[idim + i] : 1.f;
+        const float vi = nrm_v[min(idim + min(i, idim - 1), nrm_n - 1)];
+        x_isig[r] = (nrm && i < idim) ? vi : 1.f;
     }
     // ---- this wave's rows of the tile constants
-    {
+    {       // (uniform conditions branch; per-lane ones clamp the address and select: every load in flight at once)
         const int mm = 16 * half + (lane >> 2), c = lane & 3, row = row0 + mm;
-        sDC[mm * CK_NC + c] = (row < n && c < nc && L.dc && L.dc_acc) ? L.dc[(long)row * nc + c] : 0.f;
+        float v = 0.f;
+        if (L.dc && L.dc_acc) v = L.dc[(long)min(row, n - 1) * nc + min(c, max(nc - 1, 0))];
+        sDC[mm * CK_NC + c] = (row < n && c < nc) ? v : 0.f;
     }
-    for (int idx = lane; idx < 16 * CK_NS; idx += 64) {
-        const int mm = 16 * half + idx / CK_NS, c = idx % CK_NS, row = row0 + mm;
-        sDY0[mm * CK_NS + c] = (row < n && c < ns && gdy0 && L.dy0_in && !carry) ? gdy0[(long)row * ns + c] : 0.f;
+    {
+        const bool have = gdy0 && L.dy0_in && !carry;
+#pragma unroll
+        for (int it = 0; it < (16 * CK_NS + 63) / 64; ++it) {
+            const int idx = lane + 64 * it;
+            const int mm = 16 * half + idx / CK_NS, c = idx % CK_NS, row = row0 + mm;
+            float v = 0.f;
+            if (have) v = gdy0[(long)min(row, n - 1) * ns + min(c, ns - 1)];
+            if (idx < 16 * CK_NS) sDY0[mm * CK_NS + c] = (row < n && c < ns) ? v : 0.f;
+        }
     }
     if (lane < 16) {
         const int p = min(row0 + 16 * half + lane, n - 1) / L.rpp;
         sH[16 * half + lane] = chained ? (float)L.hslots[(long)p * L.n_slots + slot]
                                        : (L.h_dev ? (float)L.h_dev[(long)p * L.h_stride] : L.h_val[p]);
     }
-    for (int idx = lane; idx < L.st_hi * 16 * CK_NS; idx += 64) {
-        const int j = idx / (16 * CK_NS), rem = idx - j * 16 * CK_NS;
-        const int mm = 16 * half + rem / CK_NS, c = rem % CK_NS, row = row0 + mm;
-        float v = 0.f;
-        if (row < n && c < ns) {
-            if (!carry) v = gdK[((long)j * n + row) * ns + c];
-            else if (j == L.S_total - 1) v = (gdK + L.slot_floats)[(long)row * ns + c];     // FSAL: next slot's dK[0]
+    {   // dK of every stage into LDS: all loads first (a loop with a run-time bound and the LDS store behind each load
+        // was one global round trip per iteration: 16 in a row for rk4, most of the launch's prologue)
+        constexpr int NIT = CK_MAX_STAGES * 16 * CK_NS / 64;
+        float vals[NIT];
+#pragma unroll
+        for (int it = 0; it < NIT; ++it) {
+            const int idx = lane + 64 * it;
+            const int j = idx / (16 * CK_NS), rem = idx - j * 16 * CK_NS;           // (j is uniform: 16 * CK_NS is a multiple of 64)
+            const int mm = 16 * half + rem / CK_NS, c = rem % CK_NS, row = row0 + mm;
+            const long rc = (long)min(row, n - 1) * ns + min(c, ns - 1);
+            float v = 0.f;
+            if (j < L.st_hi) {
+                if (!carry) v = gdK[(long)j * n * ns + rc];
+                else if (j == L.S_total - 1) v = (gdK + L.slot_floats)[rc];     // FSAL: next slot's dK[0]
+            }
+            vals[it] = (row < n && c < ns) ? v : 0.f;
         }
-        sDK[(j * NLBAC_MLP_TILE + mm) * CK_NS + c] = v;
+#pragma unroll
+        for (int it = 0; it < NIT; ++it) {
+            const int idx = lane + 64 * it;
+            const int j = idx / (16 * CK_NS), rem = idx - j * 16 * CK_NS;
+            const int mm = 16 * half + rem / CK_NS, c = rem % CK_NS;
+            if (j < L.st_hi) sDK[(j * NLBAC_MLP_TILE + mm) * CK_NS + c] = vals[it];
+        }
     }
     __syncthreads();           // (sWt is shared by the two waves)
 
     f32x4 zero[NB];
 #pragma unroll
     for (int jo = 0; jo < NB; ++jo) zero[jo] = f32x4{0.f, 0.f, 0.f, 0.f};
+    // (mask mode) a stage's three mask words are requested while the stage before it runs: a load from HBM issued at the
+    // start of a product would hold back every fragment load behind it (vmcnt is in order) for longer than the product's
+    // own MFMAs take
+    unsigned mnext0 = 0u, mnext1 = 0u, mnext2 = 0u;
+    auto request_masks = [&](int stn) __attribute__((always_inline)) {
+        if (!BITS || stn < st_lo) return;
+        const unsigned* wp = reinterpret_cast<const unsigned*>(acts) + ((long)stn * n + growc) * 4 + q;
+        mnext0 = wp[0]; mnext1 = wp[acts_ls]; mnext2 = wp[2 * acts_ls];
+    };
+    request_masks(L.st_hi - 1);
+    float bnext[CK_MAX_STAGES];
+#pragma unroll
+    for (int j = 0; j < CK_MAX_STAGES; ++j) bnext[j] = L.beta[max(L.st_hi - 1, 0)][j];
     for (int st = L.st_hi - 1; st >= st_lo; --st) {
-        if (!crr_has_data(st)) continue;      // (uniform; the dyn of such a stage is not wanted either)
+        const unsigned mcur0 = mnext0, mcur1 = mnext1, mcur2 = mnext2;
+        request_masks(st - 1);
         float bn[CK_MAX_STAGES];
 #pragma unroll
-        for (int j = 0; j < CK_MAX_STAGES; ++j) bn[j] = L.beta[st][j];
+        for (int j = 0; j < CK_MAX_STAGES; ++j) bn[j] = bnext[j];
+        {
+            const int sn = max(st - 1, 0);          // (requested one stage ahead: see the forward)
+#pragma unroll
+            for (int j = 0; j < CK_MAX_STAGES; ++j) bnext[j] = L.beta[sn][j];
+        }
+        if (!crr_has_data(st)) continue;      // (uniform; the dyn of such a stage is not wanted either)
+        const int sbb = 2 + 8 * st;
+        (void)sbb;
+        BSTAMP(sbb + 0)
         const long srow = (long)st * n + growc;
         // ---- the output layer's gradient: dK (times out_sig), also kept for the weight gradients of a normalised field
         float dy[4];
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
             const int c = 4 * e + q;
-            float v = 0.f;
-            if (e < KS0 && c < ns) {
-                v = sDK[(st * NLBAC_MLP_TILE + m) * CK_NS + c] * o_sig[e];
-                if (gdyn && nrm && row_ok) gdyn[((long)st * n + grow) * ns + c] = v;
-            }
+            const float raw = sDK[(st * NLBAC_MLP_TILE + m) * CK_NS + min(c, ns - 1)];
+            const float v = (e < KS0 && c < ns) ? raw * o_sig[e] : 0.f;
+            if (gdyn && nrm && row_ok && e < KS0 && c < ns) gdyn[((long)st * n + grow) * ns + c] = v;
             dy[e] = v;
         }
         float Za[KS], Zb[KS];
@@ -483,7 +630,7 @@ __global__ __launch_bounds__(128) void concat_rr_bwd_kernel(const ConcatRkBwdLau
         unsigned mw = 0u, mwt = 0u;
         auto fetch_masks = [&](int l) __attribute__((always_inline)) {
             if (BITS) {
-                mw = reinterpret_cast<const unsigned*>(acts + (long)l * acts_ls)[srow * 4 + q];
+                mw = (l == 0) ? mcur0 : (l == 1 ? mcur1 : mcur2);
                 mw = row_ok ? mw : 0u;
             } else {
                 const float* arow = acts + (long)l * acts_ls + srow * HID;
@@ -507,13 +654,20 @@ __global__ __launch_bounds__(128) void concat_rr_bwd_kernel(const ConcatRkBwdLau
         };
         // ---- top product: dz_2 = mask_2 * (W_out^T dy), finished at once
         fetch_masks(2);
+        {       // (always four k-steps: fragments and dy past the width are zero; k-step outside, nothing branches)
+            float at[4][NB];
 #pragma unroll
-        for (int jo = 0; jo < NB; ++jo) {
-            f32x4 a = __builtin_amdgcn_mfma_f32_16x16x4f32(sWt[(0 * 8 + jo) * 64 + lane], dy[0], f32x4{0.f, 0.f, 0.f, 0.f}, 0, 0, 0);
-            if (KS0 > 1) a = __builtin_amdgcn_mfma_f32_16x16x4f32(sWt[(1 * 8 + jo) * 64 + lane], dy[1], a, 0, 0, 0);
-            if (KS0 > 2) a = __builtin_amdgcn_mfma_f32_16x16x4f32(sWt[(2 * 8 + jo) * 64 + lane], dy[2], a, 0, 0, 0);
-            if (KS0 > 3) a = __builtin_amdgcn_mfma_f32_16x16x4f32(sWt[(3 * 8 + jo) * 64 + lane], dy[3], a, 0, 0, 0);
-            acct[jo] = a;
+            for (int e = 0; e < 4; ++e)
+#pragma unroll
+                for (int jo = 0; jo < NB; ++jo) at[e][jo] = sWt[(e * 8 + jo) * 64 + lane];
+#pragma unroll
+            for (int jo = 0; jo < NB; ++jo)
+                acct[jo] = __builtin_amdgcn_mfma_f32_16x16x4f32(at[0][jo], dy[0], f32x4{0.f, 0.f, 0.f, 0.f}, 0, 0, 0);
+#pragma unroll
+            for (int e = 1; e < 4; ++e)
+#pragma unroll
+                for (int jo = 0; jo < NB; ++jo)
+                    acct[jo] = __builtin_amdgcn_mfma_f32_16x16x4f32(at[e][jo], dy[e], acct[jo], 0, 0, 0);
         }
 #pragma unroll
         for (int jo = 0; jo < NB; ++jo) {
@@ -542,29 +696,54 @@ __global__ __launch_bounds__(128) void concat_rr_bwd_kernel(const ConcatRkBwdLau
                      },
                      [&]() __attribute__((always_inline)) {});
         };
+        BSTAMP(sbb + 1)
         prod(std::integral_constant<int, 1>{}, Za, Zb);
+        BSTAMP(sbb + 2)
         prod(std::integral_constant<int, 2>{}, Zb, Za);
+        BSTAMP(sbb + 3)
         avt[0] = av[TB]; avt[1] = av[TB + 1]; mwt = mw;
         const f32x4 o = RRGemm<S>::block(w0t, Za, [&](int ks) __attribute__((always_inline)) { pre_tail(0, Za, ks); });
+        BSTAMP(sbb + 4)
         if (st == 0 && !dx_stage0) continue;       // only the dz of stage 0 were wanted (uniform)
-        // ---- dX (times in_isig): state columns -> the stage algebra, carried columns accumulate dc
+        // ---- dX (times in_isig): lane (q, row) holds input columns 4q + r of ITS row in register r — state columns go
+        //      into the stage algebra (dy0 += d, dK_j += beta[st][j] h d for the earlier stages j), carried columns into
+        //      dc — each (row, column) by the lane that holds it: every LDS operand requested up front with a clamped
+        //      address, updated values written back under the lane's own predicate (no loop over the tile, no branch
+        //      between the reads)
+        {
+            const float h = sH[m];
+            const bool up = gdYup && st == L.S_total - 1;       // (uniform)
+            float yv0[4], dcv[4], kvv[4][CK_MAX_STAGES - 1], gup[4];
 #pragma unroll
-        for (int r = 0; r < 4; ++r) sDX[m * 16 + 4 * q + r] = o[r] * x_isig[r];
-        for (int idx = lane; idx < 16 * nc; idx += 64) {
-            const int mm = 16 * half + idx / nc, c = idx % nc;
-            sDC[mm * CK_NC + c] += sDX[mm * 16 + ns + c];
-        }
-        for (int idx = lane; idx < 16 * ns; idx += 64) {
-            const int mm = 16 * half + idx / ns, c = idx % ns, row = row0 + mm;
-            float d = (gdYup && st == L.S_total - 1 && row < n) ? gdYup[(long)row * ns + c] : 0.f;
-            d += sDX[mm * 16 + c];
-            sDY0[mm * CK_NS + c] = sDY0[mm * CK_NS + c] + d;
-            const float h = sH[mm];
+            for (int r = 0; r < 4; ++r) {
+                const int i = 4 * q + r, cs = min(i, ns - 1), cc = min(max(i - ns, 0), max(nc - 1, 0));
+                yv0[r] = sDY0[m * CK_NS + cs];
+                dcv[r] = sDC[m * CK_NC + cc];
 #pragma unroll
-            for (int j = 0; j < CK_MAX_STAGES - 1; ++j)
-                if (j < st && bn[j] != 0.f) sDK[(j * NLBAC_MLP_TILE + mm) * CK_NS + c] += (bn[j] * h) * d;
+                for (int j = 0; j < CK_MAX_STAGES - 1; ++j) kvv[r][j] = sDK[(j * NLBAC_MLP_TILE + m) * CK_NS + cs];
+                gup[r] = up ? gdYup[(long)growc * ns + cs] : 0.f;
+            }
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int i = 4 * q + r;
+                const float dxv = o[r] * x_isig[r];
+                if (i < ns) {
+                    float d = (up && row_ok) ? gup[r] : 0.f;
+                    d += dxv;
+                    sDY0[m * CK_NS + i] = yv0[r] + d;
+#pragma unroll
+                    for (int j = 0; j < CK_MAX_STAGES - 1; ++j) {
+                        const float t = kvv[r][j] + (bn[j] * h) * d;
+                        sDK[(j * NLBAC_MLP_TILE + m) * CK_NS + i] = (j < st && bn[j] != 0.f) ? t : kvv[r][j];
+                    }
+                } else if (i < ns + nc) {
+                    sDC[m * CK_NC + (i - ns)] = dcv[r] + dxv;
+                }
+            }
         }
+        BSTAMP(sbb + 5)
     }
+    BSTAMP(1)
     // ---- this wave's rows of the results
     for (int idx = lane; idx < L.st_hi * 16 * ns; idx += 64) {
         const int j = idx / (16 * ns), rem = idx - j * 16 * ns;

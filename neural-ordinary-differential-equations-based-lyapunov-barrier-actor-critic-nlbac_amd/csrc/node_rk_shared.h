@@ -137,32 +137,64 @@ __device__ __forceinline__ void rk_fwd_tile_constants(const NodeRkLaunch& L, con
                 L.in_ps[i * 2 + 1] = o[1] + L.in_l * sinf(th);
             }
         }
-    } else
-    for (int idx = tid; idx < NLBAC_MLP_TILE * RK_MAX_NS; idx += NTHR) {
-        const int m = idx >> 3, c = idx & 7, row = row0 + m;
-        T.sY0[idx] = (row < n && c < ns) ? w.gy0[(long)row * ns + c] : 0.f;
     }
-    for (int idx = tid; idx < NLBAC_MLP_TILE * RK_MAX_NU; idx += NTHR) {
-        const int m = idx >> 2, c = idx & 3, row = row0 + m;
-        T.sU[idx] = (row < n && c < nu) ? L.u[(long)row * nu + c] : 0.f;
-    }
-    if (tid < NLBAC_MLP_TILE) {
-        const int p = min(row0 + tid, n - 1) / L.rpp;
-        T.sH[tid] = L.h_dev ? (float)L.h_dev[(long)p * L.h_stride] : L.h_val[p];
-    }
-    for (int idx = tid; idx < L.stage_begin * NLBAC_MLP_TILE * RK_MAX_NS; idx += NTHR) {
-        const int j = idx / (NLBAC_MLP_TILE * RK_MAX_NS), rem = idx - j * NLBAC_MLP_TILE * RK_MAX_NS;
-        const int m = rem >> 3, c = rem & 7, row = row0 + m;
-        float v = 0.f;
-        if (row < n && c < ns) {
-            if (w.fsal && j == 0) {       // first stage = the previous slot's last one; kept in this slot for the interpolant
-                v = (w.gK - L.slot_floats)[((long)(L.S_total - 1) * n + row) * ns + c];
-                w.gK[(long)row * ns + c] = v;
-            } else {
-                v = w.gK[((long)j * n + row) * ns + c];
+    // Every global load below is issued before the first LDS store that consumes one (clamped addresses, selects
+    // afterwards): written as "sX[idx] = cond ? load : 0" statement by statement — and as a loop with a run-time bound for
+    // the earlier stages — each was a global round trip of its own, several microseconds of a launch's prologue in a row.
+    {
+        constexpr int NY = (NLBAC_MLP_TILE * RK_MAX_NS + NTHR - 1) / NTHR, NU = (NLBAC_MLP_TILE * RK_MAX_NU + NTHR - 1) / NTHR;
+        constexpr int NK = (RK_MAX_STAGES * NLBAC_MLP_TILE * RK_MAX_NS + NTHR - 1) / NTHR;
+        const bool plain_y0 = !(L.in_kind == 1 && !w.fsal);
+        float vy[NY], vu[NU], vk[NK], vh = 0.f;
+#pragma unroll
+        for (int it = 0; it < NY; ++it) {
+            const int idx = tid + NTHR * it, m = (idx >> 3) & (NLBAC_MLP_TILE - 1), c = idx & 7;
+            vy[it] = plain_y0 ? w.gy0[(long)min(row0 + m, n - 1) * ns + min(c, ns - 1)] : 0.f;
+        }
+#pragma unroll
+        for (int it = 0; it < NU; ++it) {
+            const int idx = tid + NTHR * it, m = (idx >> 2) & (NLBAC_MLP_TILE - 1), c = idx & 3;
+            vu[it] = L.u[(long)min(row0 + m, n - 1) * nu + min(c, nu - 1)];
+        }
+        if (tid < NLBAC_MLP_TILE) {
+            const int p = min(row0 + tid, n - 1) / L.rpp;
+            vh = L.h_dev ? (float)L.h_dev[(long)p * L.h_stride] : L.h_val[p];
+        }
+#pragma unroll
+        for (int it = 0; it < NK; ++it) {
+            const int idx = tid + NTHR * it;
+            const int j = idx / (NLBAC_MLP_TILE * RK_MAX_NS), rem = idx - j * NLBAC_MLP_TILE * RK_MAX_NS;
+            const int m = rem >> 3, c = rem & 7;
+            const long rc = (long)min(row0 + m, n - 1) * ns + min(c, ns - 1);
+            float v = 0.f;
+            if (j < L.stage_begin) {          // (uniform per wave: a stage's block is a multiple of 64 entries)
+                if (w.fsal && j == 0) v = (w.gK - L.slot_floats)[(long)(L.S_total - 1) * n * ns + rc];   // first stage = the previous slot's last
+                else v = w.gK[(long)j * n * ns + rc];
+            }
+            vk[it] = v;
+        }
+#pragma unroll
+        for (int it = 0; it < NY; ++it) {
+            const int idx = tid + NTHR * it, m = idx >> 3, c = idx & 7;
+            if (plain_y0 && idx < NLBAC_MLP_TILE * RK_MAX_NS) T.sY0[idx] = (row0 + m < n && c < ns) ? vy[it] : 0.f;
+        }
+#pragma unroll
+        for (int it = 0; it < NU; ++it) {
+            const int idx = tid + NTHR * it, m = idx >> 2, c = idx & 3;
+            if (idx < NLBAC_MLP_TILE * RK_MAX_NU) T.sU[idx] = (row0 + m < n && c < nu) ? vu[it] : 0.f;
+        }
+        if (tid < NLBAC_MLP_TILE) T.sH[tid] = vh;
+#pragma unroll
+        for (int it = 0; it < NK; ++it) {
+            const int idx = tid + NTHR * it;
+            const int j = idx / (NLBAC_MLP_TILE * RK_MAX_NS), rem = idx - j * NLBAC_MLP_TILE * RK_MAX_NS;
+            const int m = rem >> 3, c = rem & 7, row = row0 + m;
+            if (j < L.stage_begin) {
+                const float v = (row < n && c < ns) ? vk[it] : 0.f;
+                T.sK[idx] = v;
+                if (w.fsal && j == 0 && row < n && c < ns) w.gK[(long)row * ns + c] = v;      // kept in this slot for the interpolant
             }
         }
-        T.sK[idx] = v;
     }
     __syncthreads();
 }
@@ -385,30 +417,62 @@ template <int NTHR>
 __device__ __forceinline__ void rk_bwd_tile_constants(const NodeRkBwdLaunch& L, const RkBwdWhere& w, const RkBwdTile& T,
                                                       int row0, int tid) {
     const int n = L.n, ns = L.n_s, nu = L.n_u;
-    for (int idx = tid; idx < NLBAC_MLP_TILE * RK_MAX_NU; idx += NTHR) {
-        const int m = idx >> 2, c = idx & 3, row = row0 + m;
-        const bool ok = row < n && c < nu;
-        T.sU[idx] = ok ? L.u[(long)row * nu + c] : 0.f;
-        T.sDU[idx] = (ok && L.du && L.du_acc) ? L.du[(long)row * nu + c] : 0.f;
+    // (all global loads first, then the LDS stores: see rk_fwd_tile_constants)
+    constexpr int NY = (NLBAC_MLP_TILE * RK_MAX_NS + NTHR - 1) / NTHR, NU = (NLBAC_MLP_TILE * RK_MAX_NU + NTHR - 1) / NTHR;
+    constexpr int NK = (RK_MAX_STAGES * NLBAC_MLP_TILE * RK_MAX_NS + NTHR - 1) / NTHR;
+    const bool du_in = L.du && L.du_acc, dy_in = w.gdy0 && L.dy0_in && !w.carry;
+    float vu[NU], vdu[NU], vy[NY], vk[NK], vh = 0.f;
+#pragma unroll
+    for (int it = 0; it < NU; ++it) {
+        const int idx = tid + NTHR * it, m = (idx >> 2) & (NLBAC_MLP_TILE - 1), c = idx & 3;
+        const long rc = (long)min(row0 + m, n - 1) * nu + min(c, nu - 1);
+        vu[it] = L.u[rc];
+        vdu[it] = du_in ? L.du[rc] : 0.f;
     }
-    for (int idx = tid; idx < NLBAC_MLP_TILE * RK_MAX_NS; idx += NTHR) {
-        const int m = idx >> 3, c = idx & 7, row = row0 + m;
-        T.sDY0[idx] = (row < n && c < ns && w.gdy0 && L.dy0_in && !w.carry) ? w.gdy0[(long)row * ns + c] : 0.f;
+#pragma unroll
+    for (int it = 0; it < NY; ++it) {
+        const int idx = tid + NTHR * it, m = (idx >> 3) & (NLBAC_MLP_TILE - 1), c = idx & 7;
+        vy[it] = dy_in ? w.gdy0[(long)min(row0 + m, n - 1) * ns + min(c, ns - 1)] : 0.f;
     }
     if (tid < NLBAC_MLP_TILE) {
         const int p = min(row0 + tid, n - 1) / L.rpp;
-        T.sH[tid] = w.chained ? (float)L.hslots[(long)p * L.n_slots + w.slot]
-                              : (L.h_dev ? (float)L.h_dev[(long)p * L.h_stride] : L.h_val[p]);
+        vh = w.chained ? (float)L.hslots[(long)p * L.n_slots + w.slot]
+                       : (L.h_dev ? (float)L.h_dev[(long)p * L.h_stride] : L.h_val[p]);
     }
-    for (int idx = tid; idx < L.st_hi * NLBAC_MLP_TILE * RK_MAX_NS; idx += NTHR) {
+#pragma unroll
+    for (int it = 0; it < NK; ++it) {
+        const int idx = tid + NTHR * it;
         const int j = idx / (NLBAC_MLP_TILE * RK_MAX_NS), rem = idx - j * NLBAC_MLP_TILE * RK_MAX_NS;
-        const int m = rem >> 3, c = rem & 7, row = row0 + m;
+        const int m = rem >> 3, c = rem & 7;
+        const long rc = (long)min(row0 + m, n - 1) * ns + min(c, ns - 1);
         float v = 0.f;
-        if (row < n && c < ns) {
-            if (!w.carry) v = w.gdK[((long)j * n + row) * ns + c];
-            else if (j == L.S_total - 1) v = (w.gdK + L.slot_floats)[(long)row * ns + c];     // FSAL: next slot's dK[0]
+        if (j < L.st_hi) {                    // (uniform per wave)
+            if (!w.carry) v = w.gdK[(long)j * n * ns + rc];
+            else if (j == L.S_total - 1) v = (w.gdK + L.slot_floats)[rc];     // FSAL: next slot's dK[0]
         }
-        T.sDK[idx] = v;
+        vk[it] = v;
+    }
+#pragma unroll
+    for (int it = 0; it < NU; ++it) {
+        const int idx = tid + NTHR * it, m = idx >> 2, c = idx & 3;
+        if (idx < NLBAC_MLP_TILE * RK_MAX_NU) {
+            const bool ok = row0 + m < n && c < nu;
+            T.sU[idx] = ok ? vu[it] : 0.f;
+            T.sDU[idx] = ok ? vdu[it] : 0.f;
+        }
+    }
+#pragma unroll
+    for (int it = 0; it < NY; ++it) {
+        const int idx = tid + NTHR * it, m = idx >> 3, c = idx & 7;
+        if (idx < NLBAC_MLP_TILE * RK_MAX_NS) T.sDY0[idx] = (row0 + m < n && c < ns) ? vy[it] : 0.f;
+    }
+    if (tid < NLBAC_MLP_TILE) T.sH[tid] = vh;
+#pragma unroll
+    for (int it = 0; it < NK; ++it) {
+        const int idx = tid + NTHR * it;
+        const int j = idx / (NLBAC_MLP_TILE * RK_MAX_NS), rem = idx - j * NLBAC_MLP_TILE * RK_MAX_NS;
+        const int m = rem >> 3, c = rem & 7;
+        if (j < L.st_hi) T.sDK[idx] = (row0 + m < n && c < ns) ? vk[it] : 0.f;
     }
 }
 
