@@ -188,11 +188,6 @@ __global__ __launch_bounds__(128) void concat_rr_fwd_kernel(const ConcatRkLaunch
         float bn[CK_MAX_STAGES];
 #pragma unroll
         for (int j = 0; j < CK_MAX_STAGES; ++j) bn[j] = bnext[j];
-        {
-            const int sn = min(st + 1, L.S_total - 1);
-#pragma unroll
-            for (int j = 0; j < CK_MAX_STAGES; ++j) bnext[j] = L.beta[sn][j];
-        }
         const long srow = (long)st * n + grow;
         // ---- stage input [Y_st | c | 1] in registers,  Y_st = y0 + h sum_j beta[st][j] K_j  (rk_combine_kernel's op order)
         // What a stage leaves in global memory — Y_st, K_st, the layers' mask words — is stored in ONE burst at its end:
@@ -293,6 +288,16 @@ __global__ __launch_bounds__(128) void concat_rr_fwd_kernel(const ConcatRkLaunch
             for (int jo = 0; jo < NB; ++jo)
                 bv[jo] = BRES ? bres[BRES ? l - 1 : 0][jo] : ((jo < G0) ? bpre[jo] : rr_bias<S>(params + net.b_off[l], jo, q));
             __builtin_amdgcn_sched_barrier(0);
+            if (l == 1) {
+                // the next stage's tableau row: a scalar load, requested HERE — behind the stage's last LDS wait (scalar
+                // and LDS loads share lgkmcnt and scalar loads return out of order, so a wait for LDS data is a wait
+                // for every scalar load in flight) and ahead of two layers of MFMAs that need neither
+                int sn = min(st + 1, L.S_total - 1);
+                asm volatile("" : "+s"(sn));
+#pragma unroll
+                for (int j = 0; j < CK_MAX_STAGES; ++j) bnext[j] = L.beta[sn][j];
+                __builtin_amdgcn_sched_barrier(0);
+            }
             const int cur = wbase + (l - 1) * S::LAYER_BYTES;
             const int nxt = (l == 1) ? cur + S::LAYER_BYTES : wbase;
             gemm.run(acc, bv, Hin, rs, voff, cur, nxt,
