@@ -399,26 +399,65 @@ __global__ __launch_bounds__(256) void node_rr_bwd_kernel(const NodeRkBwdLaunch 
     rk_bwd_tile_constants<256>(L, w, T, row0, tid);
     __syncthreads();
 
+    // g(Y_st) for the du term comes from global memory: this thread's values of a stage are requested while the stage
+    // before it runs (loads issued at the start of a stage would sit in front of the stage's first weight-fragment loads in
+    // the in-order vmcnt queue); the tableau row (scalar loads) likewise, behind the stage's first LDS wait
+    const bool du_thread = L.du && tid < NLBAC_MLP_TILE * nu;
+    const int du_m = du_thread ? tid / nu : 0, du_c = du_thread ? tid - du_m * nu : 0;
+    float gnext[RK_MAX_NS], bnext[RK_MAX_STAGES];
+    auto request_g = [&](int stn) __attribute__((always_inline)) {
+        if (!du_thread || stn < w.st_lo) return;
+        const float* gp = w.gG + ((long)stn * n + min(row0 + du_m, n - 1)) * gout + du_c;
+#pragma unroll
+        for (int r = 0; r < RK_MAX_NS; ++r) gnext[r] = gp[min(r, ns - 1) * nu];
+    };
+#pragma unroll
+    for (int r = 0; r < RK_MAX_NS; ++r) gnext[r] = 0.f;
+    request_g(L.st_hi - 1);
+#pragma unroll
+    for (int j = 0; j < RK_MAX_STAGES; ++j) bnext[j] = L.beta[max(L.st_hi - 1, 0)][j];
     for (int st = L.st_hi - 1; st >= w.st_lo; --st) {
         const bool data = w.has_data(st);
-        // ---- output-layer gradients: f: dK itself, g: dK u^T (also kept for the weight gradients), and du
-        float dy[4];
+        float gcur[RK_MAX_NS], bn[RK_MAX_STAGES];
 #pragma unroll
-        for (int e = 0; e < 4; ++e) {
-            float v = 0.f;
-            if (grp == 0) {
-                const int c = 4 * e + q;
-                if (e < KS0 && c < ns) v = T.sDK[(st * NLBAC_MLP_TILE + m) * RK_MAX_NS + c];
-            } else {
-                const int k0 = e / nu, u = e - k0 * nu, c = 4 * k0 + q;
-                if (e < KS0 * nu && c < ns) {
-                    v = T.sDK[(st * NLBAC_MLP_TILE + m) * RK_MAX_NS + c] * T.sU[m * RK_MAX_NU + u];
-                    if (w.gdG && row_ok) w.gdG[((long)st * n + grow) * gout + c * nu + u] = v;
-                }
+        for (int r = 0; r < RK_MAX_NS; ++r) gcur[r] = gnext[r];
+#pragma unroll
+        for (int j = 0; j < RK_MAX_STAGES; ++j) bn[j] = bnext[j];
+        request_g(st - 1);
+        // ---- output-layer gradients: f: dK itself, g: dK u^T (also kept for the weight gradients), and du — every LDS
+        //      operand requested with a clamped index, selects afterwards (no per-column branch)
+        float dy[4];
+        {
+            float dk[4], uu[4], dkd[RK_MAX_NS];
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const int k0 = (grp == 0) ? e : e / nu, u = (grp == 0) ? 0 : e - k0 * nu, c = 4 * k0 + q;
+                dk[e] = T.sDK[(st * NLBAC_MLP_TILE + m) * RK_MAX_NS + min(c, ns - 1)];
+                uu[e] = (grp == 0) ? 1.f : T.sU[m * RK_MAX_NU + min(u, nu - 1)];
             }
-            dy[e] = v;
+#pragma unroll
+            for (int r = 0; r < RK_MAX_NS; ++r) dkd[r] = T.sDK[(st * NLBAC_MLP_TILE + du_m) * RK_MAX_NS + r];
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const int k0 = (grp == 0) ? e : e / nu, u = (grp == 0) ? 0 : e - k0 * nu, c = 4 * k0 + q;
+                const bool ok = (grp == 0) ? (e < KS0 && c < ns) : (e < KS0 * nu && c < ns);
+                const float v = (grp == 0) ? dk[e] : dk[e] * uu[e];
+                dy[e] = ok ? v : 0.f;
+                if (grp != 0 && ok && w.gdG && row_ok) w.gdG[((long)st * n + grow) * gout + c * nu + u] = v;
+            }
+            if (du_thread) {        // du += g(Y_st)^T dK_st (rk_bwd_du's sum, same order)
+                float a = 0.f;
+#pragma unroll
+                for (int r = 0; r < RK_MAX_NS; ++r) a = (r < ns) ? a + gcur[r] * dkd[r] : a;
+                T.sDU[du_m * RK_MAX_NU + du_c] = T.sDU[du_m * RK_MAX_NU + du_c] + 1.0f * a;
+            }
+            {
+                int sn = max(st - 1, 0);
+                asm volatile("" : "+s"(sn));        // (issued here: behind the LDS wait above, see the forward)
+#pragma unroll
+                for (int j = 0; j < RK_MAX_STAGES; ++j) bnext[j] = L.beta[sn][j];
+            }
         }
-        rk_bwd_du<256>(L, w, T, row0, st, tid);
         if (!data) continue;              // uniform: nothing below is needed for this stage
 
         const long srow = (long)st * n + growc;
@@ -550,7 +589,30 @@ __global__ __launch_bounds__(256) void node_rr_bwd_kernel(const NodeRkBwdLaunch 
         else dxl(Za);
         if (skip_dx) continue;
         __syncthreads();
-        rk_bwd_stage_algebra<256>(L, w, T, row0, st, tid);
+        // ---- stage algebra (rk_bwd_stage_algebra's arithmetic): dY = [dYup at the last stage] + dX_f + dX_g; dy0 += dY;
+        //      dK_j += beta[st][j] h dY for j < st — one (row, component) per thread, every operand requested up front
+        if (tid < NLBAC_MLP_TILE * RK_MAX_NS) {
+            const int mm = tid >> 3, c = tid & 7, row = row0 + mm;
+            const bool cv = c < ns, up = w.gdYup && st == L.S_total - 1;
+            const float xf = T.sDX[mm * RK_MAX_NS + c], xg = T.sDX[(NLBAC_MLP_TILE + mm) * RK_MAX_NS + c];
+            const float y0 = T.sDY0[mm * RK_MAX_NS + c], h = T.sH[mm];
+            float kj[RK_MAX_STAGES - 1];
+#pragma unroll
+            for (int j = 0; j < RK_MAX_STAGES - 1; ++j) kj[j] = T.sDK[(j * NLBAC_MLP_TILE + mm) * RK_MAX_NS + c];
+            float d = 0.f;
+            if (up) d = w.gdYup[(long)min(row, n - 1) * ns + min(c, ns - 1)];      // (uniform branch)
+            d = (up && row < n) ? d : 0.f;
+            d += xf;
+            d += xg;
+            if (cv) {
+                T.sDY0[mm * RK_MAX_NS + c] = y0 + d;
+#pragma unroll
+                for (int j = 0; j < RK_MAX_STAGES - 1; ++j) {
+                    const float t = kj[j] + (bn[j] * h) * d;
+                    T.sDK[(j * NLBAC_MLP_TILE + mm) * RK_MAX_NS + c] = (j < st && bn[j] != 0.f) ? t : kj[j];
+                }
+            }
+        }
         __syncthreads();
     }
     __syncthreads();
