@@ -90,8 +90,10 @@ __global__ __launch_bounds__(256) void node_rr_fwd_kernel(const NodeRkLaunch L) 
         for (int k0 = 0; k0 < 3; ++k0)
 #pragma unroll
             for (int jo = 0; jo < NB; ++jo) {
-                const int uo = rr_unit_out(NB, R, jo, r16), col = 4 * k0 + q;
-                sW0[((grp * 3 + k0) * 8 + jo) * 64 + lane] = (uo < 0 || col > ns) ? 0.f : (col < ns ? W0[uo * ns + col] : b0[uo]);
+                // (unconditional loads, clamped index, select afterwards: a guarded load is a branch and a round trip of its own)
+                const int uo = rr_unit_out(NB, R, jo, r16), col = 4 * k0 + q, uc = max(uo, 0);
+                const float vw = W0[uc * ns + min(col, ns - 1)], vb = b0[uc];
+                sW0[((grp * 3 + k0) * 8 + jo) * 64 + lane] = (uo < 0 || col > ns) ? 0.f : (col < ns ? vw : vb);
             }
     }
     float wo[KS];
@@ -115,7 +117,8 @@ __global__ __launch_bounds__(256) void node_rr_fwd_kernel(const NodeRkLaunch L) 
             if (grp == 0) { const int c = 4 * r + q; if (r < KS0 && c < ns) o = c; }
             else { const int k0 = r / nu, u = r - k0 * nu, c = 4 * k0 + q; if (r < KS0 * nu && c < ns) o = c * nu + u; }
             o_idx[r] = o;
-            o_bias[r] = (o >= 0) ? bo[o] : 0.f;
+            const float vb = bo[max(o, 0)];
+            o_bias[r] = (o >= 0) ? vb : 0.f;
         }
     }
 
@@ -383,7 +386,8 @@ __global__ __launch_bounds__(256) void node_rr_bwd_kernel(const NodeRkBwdLaunch 
 #pragma unroll
             for (int jo = 0; jo < NB; ++jo) {
                 const int uo = rr_unit_out(NB, R, jo, r16);
-                sWt[((grp * 4 + e) * 8 + jo) * 64 + lane] = (o >= 0 && uo >= 0) ? Wl[(long)o * HID + uo] : 0.f;
+                const float vw = Wl[(long)max(o, 0) * HID + max(uo, 0)];
+                sWt[((grp * 4 + e) * 8 + jo) * 64 + lane] = (o >= 0 && uo >= 0) ? vw : 0.f;
             }
         }
     }
@@ -393,7 +397,10 @@ __global__ __launch_bounds__(256) void node_rr_bwd_kernel(const NodeRkBwdLaunch 
         const int c = 4 * (r16 & 3) + (r16 >> 2);          // A row 4 q' + r' computes dX component 4 r' + q'
         const bool ok = (r16 & 3) < KS0 && c < ns;
 #pragma unroll
-        for (int ks = 0; ks < KS; ++ks) w0t[ks] = ok ? W0[(long)rr_unit_in(NB, R, ks, q) * ns + c] : 0.f;
+        for (int ks = 0; ks < KS; ++ks) {
+            const float vw = W0[(long)rr_unit_in(NB, R, ks, q) * ns + min(c, ns - 1)];
+            w0t[ks] = ok ? vw : 0.f;
+        }
     }
 
     rk_bwd_tile_constants<256>(L, w, T, row0, tid);
