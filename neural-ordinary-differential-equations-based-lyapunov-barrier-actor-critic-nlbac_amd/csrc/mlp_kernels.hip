@@ -270,22 +270,31 @@ __global__ __launch_bounds__(256, 2) void mlp_bwd_data_kernel(const MlpLaunch L,
         if constexpr (MODE != 1) { if (two) bwd_prime<2>(wg2, net, wave, lane); }
         if constexpr (MODE != 2) { if (!two) bwd_prime<1>(wg1, net, wave, lane); }
     }
-    if (H.kind == 0 || (H.kind == 3 && (int)blockIdx.y >= 2 * H.n_prob)) {     // (kind 3: nets behind the Q pairs read io.dy)
-        for (int idx = tid; idx < NLBAC_MLP_TILE * 16; idx += 256) {
-            const int r = idx >> 4, c = idx & 15, row = row0 + r;
-            sdy[idx] = (row < B && c < net.out_dim) ? io.dy[(long)row * io.dy_ld + c] : 0.f;
+    // (the tile's dy and input rows: every global load issued before the first LDS store — clamped addresses, selects
+    // afterwards; as guarded loads in two-iteration loops they were up to six dependent round trips at the head of every
+    // tile's latency chain)
+    const bool plain_dy = H.kind == 0 || (H.kind == 3 && (int)blockIdx.y >= 2 * H.n_prob);     // (kind 3: nets behind the Q pairs read io.dy)
+    {
+        float vdy[2] = {0.f, 0.f}, vx0[2] = {0.f, 0.f}, vx1[2] = {0.f, 0.f};
+        const bool has_x1 = io.x1 != nullptr && io.x1_dim > 0;
+#pragma unroll
+        for (int it = 0; it < 2; ++it) {
+            const int idx = tid + 256 * it, r = idx >> 4, c = idx & 15;
+            const long row = min(row0 + r, B - 1);
+            if (plain_dy) vdy[it] = io.dy[row * io.dy_ld + min(c, net.out_dim - 1)];
+            if (sk) {
+                vx0[it] = io.x0[row * io.x0_ld + min(c, io.x0_dim - 1)];
+                if (has_x1) vx1[it] = io.x1[row * io.x1_ld + min(max(c - io.x0_dim, 0), io.x1_dim - 1)];
+            }
         }
-    } else {
-        dy_head_fill(H, blockIdx.y, row0, B, gridDim.x, sdy, sx, gridDim.y);     // (dy heads: dL/dy is produced here, dy_heads.h)
+        if (!plain_dy) dy_head_fill(H, blockIdx.y, row0, B, gridDim.x, sdy, sx, gridDim.y);     // (dy heads: dL/dy is produced here, dy_heads.h)
+#pragma unroll
+        for (int it = 0; it < 2; ++it) {
+            const int idx = tid + 256 * it, r = idx >> 4, c = idx & 15, row = row0 + r;
+            if (plain_dy) sdy[idx] = (row < B && c < net.out_dim) ? vdy[it] : 0.f;
+            if (sk) sx[idx] = (row < B && c < net.in_dim) ? (c < io.x0_dim ? vx0[it] : vx1[it]) : 0.f;
+        }
     }
-    if (sk)
-        for (int idx = tid; idx < NLBAC_MLP_TILE * 16; idx += 256) {
-            const int r = idx >> 4, i = idx & 15, row = row0 + r;
-            float v = 0.f;
-            if (row < B && i < net.in_dim)
-                v = (i < io.x0_dim) ? io.x0[(long)row * io.x0_ld + i] : io.x1[(long)row * io.x1_ld + (i - io.x0_dim)];
-            sx[idx] = v;
-        }
 
     {   // top (skinny) layer: thread = hidden column; ReLU masks are fetched up front (clamped, unconditional)
         const int k = tid, kc = min(k, hid - 1);
