@@ -346,3 +346,49 @@ def test_dx_first_limits_the_input_gradient_to_the_wanted_columns():
     io[0].dx_first = in_dim
     with pytest.raises(_lib.NlbacError):
         _lib.call("nlbac_mlp_bwd_data", nets, io, 1, B, s)
+
+
+def test_one_launch_weight_gradients_on_random_narrow_shapes():
+    """Seeded sweep over what ``mlp_dw16_kernels.hip`` has to cope with: widths 8 .. 112 (every tile form: 4 / 6 / 7 tiles,
+    partly filled last tiles), depths 2 .. 6, input / output widths 1 .. 16, split inputs, row counts that are not
+    multiples of 4, more slabs than k-steps — weight and bias gradients of every layer against torch autograd."""
+    from nlbac_amd import _lib, arena as A
+    rng = np.random.RandomState(123)
+    for case in range(24):
+        hid = int(rng.choice([8, 20, 36, 48, 64, 68, 80, 96, 100, 104, 112]))
+        n_layers = int(rng.randint(2, 7))
+        in_dim, out_dim = int(rng.randint(1, 17)), int(rng.randint(1, 17))
+        B = int(rng.choice([1, 3, 5, 31, 64, 77, 130, 257, 1001]))
+        n_slabs = int(rng.choice([1, 3, 8, 51]))
+        split = int(rng.randint(1, in_dim)) if in_dim > 1 and rng.rand() < 0.5 else 0
+        ar, h, lins, ref = build(in_dim, hid, out_dim, n_layers, seed=1000 + case, n_slabs=n_slabs)
+        g = torch.Generator().manual_seed(case)
+        x, dy = torch.randn(B, in_dim, generator=g), torch.randn(B, out_dim, generator=g)
+        _, _, _, grads_ref = torch_ref(ref, x, dy)
+        xd, dyd = x.cuda(), dy.cuda()
+        nw = n_layers - 1
+        y = torch.empty(B, out_dim, device="cuda")
+        acts, dz = torch.empty(nw, B, hid, device="cuda"), torch.empty(nw, B, hid, device="cuda")
+        io = A.io_array(1)
+        keep = [xd, dyd, y, acts, dz]
+        if split:
+            x0, x1 = xd[:, :split].contiguous(), xd[:, split:].contiguous()
+            keep += [x0, x1]
+            io[0].x0, io[0].x0_dim, io[0].x0_ld = x0.data_ptr(), split, split
+            io[0].x1, io[0].x1_dim, io[0].x1_ld = x1.data_ptr(), in_dim - split, in_dim - split
+        else:
+            io[0].x0, io[0].x0_dim, io[0].x0_ld = xd.data_ptr(), in_dim, in_dim
+        io[0].y, io[0].y_ld = y.data_ptr(), out_dim
+        io[0].acts, io[0].dz = acts.data_ptr(), dz.data_ptr()
+        io[0].dy, io[0].dy_ld = dyd.data_ptr(), out_dim
+        io[0].grad = ar.grad.data_ptr()
+        nets, s = A.mlp_array([h.desc]), A.stream_ptr()
+        ar.grad.fill_(float("nan"))
+        _lib.call("nlbac_mlp_fwd", nets, io, 1, B, s)
+        _lib.call("nlbac_mlp_bwd_data", nets, io, 1, B, s)
+        A.bwd_weights(nets, io, 1, B, ar.n_slabs, ar.n, "cuda")
+        torch.cuda.synchronize()
+        tag = "case %d: %d -> %d x%d -> %d, B %d, %d slabs, split %d" % (case, in_dim, hid, nw, out_dim, B, n_slabs, split)
+        for l, lin in enumerate(lins):
+            vec_close(ar.grad_view(lin.weight).cpu(), grads_ref[l][0], TOL, tag + " dW%d" % l)
+            vec_close(ar.grad_view(lin.bias).cpu(), grads_ref[l][1], TOL, tag + " db%d" % l)
