@@ -140,7 +140,11 @@ class SAC_CBF_CLF(object):
         hidden = args.hidden_size
         n_act = action_space.shape[0]
         self.num_inputs, self.n_act, self.hidden = num_inputs, n_act, hidden
-        self.n_grad_slabs = int(getattr(args, "grad_slabs", 8))
+        # gradient slabs of the actor / critic arenas (row ranges whose weight-gradient partials the optimiser sums).  8 for
+        # the usual batches; 16 from batch 16384 on: a slab is then still >= 1024 rows and mlp_bwd_wide has twice the
+        # workgroups (measured at B = 32768: 184 -> 159 us per launch; 128 x 128 output tiles instead — half the operand
+        # re-reads — were slower than that, 170 us, and were dropped)
+        self.n_grad_slabs = int(getattr(args, "grad_slabs", 16 if int(getattr(args, "batch_size", 0) or 0) >= 16384 else 8))
 
         # --- same construction order (and RNG consumption) as the reference ---
         self.critic = QNetwork(num_inputs, n_act, hidden)
