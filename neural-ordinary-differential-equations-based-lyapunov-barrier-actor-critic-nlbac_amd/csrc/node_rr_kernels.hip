@@ -411,7 +411,10 @@ __global__ __launch_bounds__(256) void node_rr_bwd_kernel(const NodeRkBwdLaunch 
     // the in-order vmcnt queue); the tableau row (scalar loads) likewise, behind the stage's first LDS wait
     const bool du_thread = L.du && tid < NLBAC_MLP_TILE * nu;
     const int du_m = du_thread ? tid / nu : 0, du_c = du_thread ? tid - du_m * nu : 0;
-    float gnext[RK_MAX_NS], bnext[RK_MAX_STAGES];
+    float gnext[RK_MAX_NS];
+    __shared__ float sBeta[RK_MAX_STAGES * RK_MAX_STAGES];      // the tableau, once: per-stage scalar loads of its rows from the
+    if (tid < RK_MAX_STAGES * RK_MAX_STAGES)                      // kernel arguments cost SGPRs (spills) and a wait per stage
+        sBeta[tid] = (&L.beta[0][0])[tid];
     auto request_g = [&](int stn) __attribute__((always_inline)) {
         if (!du_thread || stn < w.st_lo) return;
         const float* gp = w.gG + ((long)stn * n + min(row0 + du_m, n - 1)) * gout + du_c;
@@ -421,15 +424,11 @@ __global__ __launch_bounds__(256) void node_rr_bwd_kernel(const NodeRkBwdLaunch 
 #pragma unroll
     for (int r = 0; r < RK_MAX_NS; ++r) gnext[r] = 0.f;
     request_g(L.st_hi - 1);
-#pragma unroll
-    for (int j = 0; j < RK_MAX_STAGES; ++j) bnext[j] = L.beta[max(L.st_hi - 1, 0)][j];
     for (int st = L.st_hi - 1; st >= w.st_lo; --st) {
         const bool data = w.has_data(st);
-        float gcur[RK_MAX_NS], bn[RK_MAX_STAGES];
+        float gcur[RK_MAX_NS];
 #pragma unroll
         for (int r = 0; r < RK_MAX_NS; ++r) gcur[r] = gnext[r];
-#pragma unroll
-        for (int j = 0; j < RK_MAX_STAGES; ++j) bn[j] = bnext[j];
         request_g(st - 1);
         // ---- output-layer gradients: f: dK itself, g: dK u^T (also kept for the weight gradients), and du — every LDS
         //      operand requested with a clamped index, selects afterwards (no per-column branch)
@@ -457,12 +456,6 @@ __global__ __launch_bounds__(256) void node_rr_bwd_kernel(const NodeRkBwdLaunch 
 #pragma unroll
                 for (int r = 0; r < RK_MAX_NS; ++r) a = (r < ns) ? a + gcur[r] * dkd[r] : a;
                 T.sDU[du_m * RK_MAX_NU + du_c] = T.sDU[du_m * RK_MAX_NU + du_c] + 1.0f * a;
-            }
-            {
-                int sn = max(st - 1, 0);
-                asm volatile("" : "+s"(sn));        // (issued here: behind the LDS wait above, see the forward)
-#pragma unroll
-                for (int j = 0; j < RK_MAX_STAGES; ++j) bnext[j] = L.beta[sn][j];
             }
         }
         if (!data) continue;              // uniform: nothing below is needed for this stage
@@ -603,9 +596,12 @@ __global__ __launch_bounds__(256) void node_rr_bwd_kernel(const NodeRkBwdLaunch 
             const bool cv = c < ns, up = w.gdYup && st == L.S_total - 1;
             const float xf = T.sDX[mm * RK_MAX_NS + c], xg = T.sDX[(NLBAC_MLP_TILE + mm) * RK_MAX_NS + c];
             const float y0 = T.sDY0[mm * RK_MAX_NS + c], h = T.sH[mm];
-            float kj[RK_MAX_STAGES - 1];
+            float kj[RK_MAX_STAGES - 1], bn[RK_MAX_STAGES - 1];
 #pragma unroll
-            for (int j = 0; j < RK_MAX_STAGES - 1; ++j) kj[j] = T.sDK[(j * NLBAC_MLP_TILE + mm) * RK_MAX_NS + c];
+            for (int j = 0; j < RK_MAX_STAGES - 1; ++j) {
+                kj[j] = T.sDK[(j * NLBAC_MLP_TILE + mm) * RK_MAX_NS + c];
+                bn[j] = sBeta[st * RK_MAX_STAGES + j];
+            }
             float d = 0.f;
             if (up) d = w.gdYup[(long)min(row, n - 1) * ns + min(c, ns - 1)];      // (uniform branch)
             d = (up && row < n) ? d : 0.f;
