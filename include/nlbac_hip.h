@@ -32,7 +32,7 @@
 extern "C" {
 #endif
 
-#define NLBAC_ABI_VERSION 3 /* bumped whenever an exported signature or struct changes; nlbac_abi_version() returns it */
+#define NLBAC_ABI_VERSION 4 /* bumped whenever an exported signature or struct changes; nlbac_abi_version() returns it */
 #define NLBAC_MAX_LAYERS 6
 #define NLBAC_MAX_NETS 8
 #define NLBAC_MLP_TILE 32 /* samples per workgroup in the MLP kernels */
@@ -101,7 +101,16 @@ typedef struct nlbac_mlp_io {
                                            i * ws_floats / n_nets): nlbac_mlp_bwd_data then leaves the per-32-row partial
                                            sums of the bias / first- / last-layer gradients there (it has every dz tile
                                            in LDS anyway) and nlbac_mlp_bwd_weights only reduces them.  B <= 32768. */
+    unsigned *masks;                    /* or NULL (ABI 4).  [n_layers-1 = 2][B][8] ReLU mask words of the register-resident
+                                           kernels (3-layer nets of width 64 / 128 / 256: nlbac_mlp_masks_ok): the forward
+                                           writes them, the data backward gates with them instead of reading the saved
+                                           activation rows.  A net that is only differentiated w.r.t. its inputs (dx
+                                           wanted, no dz / weight gradients) may then pass acts == NULL: 64 B per row
+                                           instead of 8 * hid.  All nets of a data-backward launch have them, or none. */
 } nlbac_mlp_io;
+
+/* 1 when launches of these nets are served by the kernels that write / read nlbac_mlp_io::masks, else 0 */
+int nlbac_mlp_masks_ok(const nlbac_mlp *nets, int n_nets);
 
 /* number of floats nlbac_mlp_pack needs in `packed`, and the offsets it will use */
 int nlbac_mlp_pack_layout(nlbac_mlp *net /* in: n_layers,in_dim,hid ; out: pf_off,pb_off */);

@@ -43,7 +43,8 @@ class MlpIO(C.Structure):
                 ("dz", C.c_void_p),
                 ("dx", C.c_void_p), ("dx_ld", C.c_int), ("dx_first", C.c_int),
                 ("grad", C.c_void_p),
-                ("skinny_ws", C.c_void_p)]
+                ("skinny_ws", C.c_void_p),
+                ("masks", C.c_void_p)]
 
 
 class AuglagArgs(C.Structure):
@@ -112,6 +113,7 @@ _PROTOS = {
     "nlbac_mlp_pack": [C.POINTER(Mlp), _I, _P],
     "nlbac_mlp_fwd": [C.POINTER(Mlp), C.POINTER(MlpIO), _I, _I, _P],
     "nlbac_mlp_fwd_gauss": [C.POINTER(Mlp), C.POINTER(MlpIO), _I, _I, C.POINTER(GaussHead), _P],
+    "nlbac_mlp_masks_ok": [C.POINTER(Mlp), _I],
     "nlbac_mlp_bwd_data": [C.POINTER(Mlp), C.POINTER(MlpIO), _I, _I, _P],
     "nlbac_mlp_bwd_data_head": [C.POINTER(Mlp), C.POINTER(MlpIO), _I, _I, C.POINTER(DyHead), _P],
     "nlbac_mlp_bwd_weights_ws_floats": [C.POINTER(Mlp), _I, _I],
@@ -211,7 +213,7 @@ def build(verbose=False):
     return LIB_PATH
 
 
-ABI_VERSION = 3      # == NLBAC_ABI_VERSION of include/nlbac_hip.h (bumped with every signature / struct change)
+ABI_VERSION = 4      # == NLBAC_ABI_VERSION of include/nlbac_hip.h (bumped with every signature / struct change)
 
 
 def _stale_sources():

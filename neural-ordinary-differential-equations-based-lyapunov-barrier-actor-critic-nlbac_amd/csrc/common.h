@@ -102,6 +102,11 @@ __device__ __forceinline__ bool publish_and_elect(float* dst, const float (&vals
     if (s_elect_ != 0u) elect_acquire_();
     return s_elect_ != 0u;
 }
+// Workgroup barrier that orders LDS traffic only.  __syncthreads() also drains the wave's global loads AND stores
+// (s_waitcnt vmcnt(0)): behind a burst of stores that is the burst's whole trip to memory.
+__device__ __forceinline__ void lds_barrier() {
+    asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+}
 __device__ __forceinline__ float coherent_load(const float* p) {
     return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }

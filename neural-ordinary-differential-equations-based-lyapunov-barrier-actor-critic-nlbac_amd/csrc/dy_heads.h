@@ -94,11 +94,17 @@ __device__ __forceinline__ void elected_tile_sums(const float* partials, int n_t
     block_sum_256<NV>(v, red);
 }
 
+// Partial sums a tile's dy head leaves for the launch-wide election (kind 2: v0 = the tile's squared-error sum; kind 3:
+// v0, v1 = sums of (alpha logp - min q, logp)); valid in thread 0.
+struct DyHeadPending { float v0, v1; };
+
 // Fills sdy[32][16] (dL/dy of the tile's rows, zero padded) of net `inet` of the launch.  Called by all 256 threads of an
-// mlp_bwd_data workgroup before anything reads sdy; `red`: >= 16 floats of LDS scratch.
-__device__ __forceinline__ void dy_head_fill(const nlbac_dy_head& H, int inet, int row0, int B, int n_tiles, float* sdy,
-                                             float* red, int n_nets) {
+// mlp_bwd_data workgroup before anything reads sdy.  What the tile contributes to the launch's batch sums is returned in
+// `pend` for dy_head_finish — which may run at any later point of the kernel (the LDS-tiled kernel calls it right away;
+// the register-resident one at its very end, so that the atomics' round trip is off the tile's critical path).
+__device__ __forceinline__ void dy_head_rows(const nlbac_dy_head& H, int inet, int row0, int B, float* sdy, DyHeadPending& pend) {
     const int tid = threadIdx.x;
+    pend.v0 = pend.v1 = 0.f;
     if (H.kind == 1) {
         // GaussianPolicy.sample backward; net inet = controller inet, its rows are inet*B.. of the stacked arrays
         const float dlp = H.alpha[inet] * H.dlogp_mul;
@@ -118,8 +124,6 @@ __device__ __forceinline__ void dy_head_fill(const nlbac_dy_head& H, int inet, i
         }
     } else if (H.kind == 2) {
         // TD / Lyapunov targets; net 0 = Q1, 1 = Q2, 2 = Lyapunov critic (3 = the learned-barrier copies' BarrierNet).
-        // Every net's workgroup publishes its own squared-error sum of the tile; the last of the n_nets * n_tiles
-        // workgroups finishes the losses.
         float e2 = 0.f;
         for (int idx = tid; idx < NLBAC_MLP_TILE * 16; idx += 256) sdy[idx] = 0.f;
         __syncthreads();
@@ -148,23 +152,10 @@ __device__ __forceinline__ void dy_head_fill(const nlbac_dy_head& H, int inet, i
 #pragma unroll
             for (int off = 16; off > 0; off >>= 1) e2 += __shfl_down(e2, off, 64);
         }
-        const float v1[1] = {e2};
-        const int tile = row0 / NLBAC_MLP_TILE;
-        if (publish_and_elect<1>(H.partials + (long)tile * n_nets + inet, v1, H.ticket, (unsigned)(n_nets * n_tiles))) {
-            float s[3];
-            elected_tile_sums<3>(H.partials, n_tiles, n_nets, s, red);
-            if (tid < 3) H.out[tid] = s[tid] * H.mul;
-            if (n_nets == 4) {
-                float sx[1];
-                elected_tile_sums<1>(H.partials + 3, n_tiles, 4, sx, red);
-                if (tid == 0) H.out_x[0] = sx[0] * H.mul;
-            }
-        }
+        pend.v0 = e2;
     } else if (H.kind == 3) {
-        // min(Q1, Q2)(s, pi) branch gradients; net inet = (controller inet / 2, Q1 / Q2 = inet % 2); the Q1 workgroups
-        // publish the tile's sums of (alpha logp - min q, logp); the last of them finishes policy_loss_1 / alpha loss /
-        // d log_alpha of every controller (actor_scalars_one)
-        const int p = inet >> 1, which = inet & 1, n_prob = H.n_prob;
+        // min(Q1, Q2)(s, pi) branch gradients; net inet = (controller inet / 2, Q1 / Q2 = inet % 2)
+        const int p = inet >> 1, which = inet & 1;
         float v0 = 0.f, v1 = 0.f;
         for (int idx = tid; idx < NLBAC_MLP_TILE * 16; idx += 256) sdy[idx] = 0.f;
         __syncthreads();
@@ -180,13 +171,41 @@ __device__ __forceinline__ void dy_head_fill(const nlbac_dy_head& H, int inet, i
             v0 = H.alpha[p] * H.logp[r] - fminf(a, b);
             v1 = H.logp[r];
         }
-        if (which == 0) {
-            if (tid < 64) {
+        if (which == 0 && tid < 64) {
 #pragma unroll
-                for (int off = 16; off > 0; off >>= 1) { v0 += __shfl_down(v0, off, 64); v1 += __shfl_down(v1, off, 64); }
+            for (int off = 16; off > 0; off >>= 1) { v0 += __shfl_down(v0, off, 64); v1 += __shfl_down(v1, off, 64); }
+        }
+        pend.v0 = v0; pend.v1 = v1;
+    }
+}
+
+// The launch-wide half of a dy head: every designated workgroup publishes its tile's sums, the last one to arrive
+// finishes the batch quantities (publish_and_elect, common.h).  All 256 threads; `red`: >= 16 floats of LDS scratch that
+// nothing else uses until the call returns.
+__device__ __forceinline__ void dy_head_finish(const nlbac_dy_head& H, int inet, int row0, int n_tiles, float* red, int n_nets,
+                                               const DyHeadPending& pend) {
+    const int tid = threadIdx.x;
+    const int tile = row0 / NLBAC_MLP_TILE;
+    if (H.kind == 2) {
+        // every net's workgroup publishes its own squared-error sum of the tile; the last of the n_nets * n_tiles
+        // workgroups finishes the losses
+        const float v1[1] = {pend.v0};
+        if (publish_and_elect<1>(H.partials + (long)tile * n_nets + inet, v1, H.ticket, (unsigned)(n_nets * n_tiles))) {
+            float s[3];
+            elected_tile_sums<3>(H.partials, n_tiles, n_nets, s, red);
+            if (tid < 3) H.out[tid] = s[tid] * H.mul;
+            if (n_nets == 4) {
+                float sx[1];
+                elected_tile_sums<1>(H.partials + 3, n_tiles, 4, sx, red);
+                if (tid == 0) H.out_x[0] = sx[0] * H.mul;
             }
-            const float v2[2] = {v0, v1};
-            const int tile = row0 / NLBAC_MLP_TILE;
+        }
+    } else if (H.kind == 3) {
+        // the Q1 workgroups publish the tile's sums of (alpha logp - min q, logp); the last of them finishes
+        // policy_loss_1 / alpha loss / d log_alpha of every controller (actor_scalars_one)
+        const int p = inet >> 1, which = inet & 1, n_prob = H.n_prob;
+        if (which == 0) {
+            const float v2[2] = {pend.v0, pend.v1};
             if (publish_and_elect<2>(H.partials + ((long)p * n_tiles + tile) * 2, v2, H.ticket, (unsigned)(n_prob * n_tiles))) {
                 for (int pp = 0; pp < n_prob; ++pp) {
                     float s[2];
@@ -198,4 +217,11 @@ __device__ __forceinline__ void dy_head_fill(const nlbac_dy_head& H, int inet, i
             }
         }
     }
+}
+
+__device__ __forceinline__ void dy_head_fill(const nlbac_dy_head& H, int inet, int row0, int B, int n_tiles, float* sdy,
+                                             float* red, int n_nets) {
+    DyHeadPending pend;
+    dy_head_rows(H, inet, row0, B, sdy, pend);
+    dy_head_finish(H, inet, row0, n_tiles, red, n_nets, pend);
 }

@@ -101,6 +101,27 @@ __global__ __launch_bounds__(256) void mlp_pack_kernel(const MlpLaunch L) {
                 const int uo = 16 * (4 * j4 + c) + (lane & 15), col = 4 * k0 + (lane >> 4);
                 P0[i] = (col < idim) ? W0[(long)uo * idim + col] : (col == idim ? b0[uo] : 0.f);
             }
+            // what the register-resident data backward (mlp_rr_bwd_kernel) reads, behind layer 0's fragments:
+            // the last layer as A fragments of W_L^T over k-steps of dy — float4 ((k0 * NBA/4 + j4) * 64 + lane), component
+            // c = W_L[4 k0 + (lane >> 4)][16 (4 j4 + c) + (lane & 15)] —
+            const int nw = net.n_layers - 1, odim = net.out_dim;
+            const float* WL = net.params + net.w_off[nw];
+            float* PT = P0 + n0;
+            for (long i = gid; i < n0; i += stride) {
+                const int c = i & 3, lane = (i >> 2) & 63;
+                const long t = i >> 8;
+                const int j4 = (int)(t % (NBA >> 2)), k0 = (int)(t / (NBA >> 2));
+                const int o = 4 * k0 + (lane >> 4), u = 16 * (4 * j4 + c) + (lane & 15);
+                PT[i] = (o < odim) ? WL[(long)o * hid + u] : 0.f;
+            }
+            // and layer 0 as A fragments of W_0^T (dx = dz0 W_0) — float4 (jb * 64 + lane), component
+            // r = W_0[16 jb + 4 (lane >> 4) + r][lane & 15]
+            float* PX = PT + n0;
+            for (long i = gid; i < n0; i += stride) {
+                const int r = i & 3, lane = (i >> 2) & 63, jb = (int)(i >> 8);
+                const int u = 16 * jb + 4 * (lane >> 4) + r, ii = lane & 15;
+                PX[i] = (ii < idim) ? W0[(long)u * idim + ii] : 0.f;
+            }
         }
     }
     if (net.rr_kind == RR_KIND_CHAIN) {
@@ -872,7 +893,8 @@ extern "C" int nlbac_mlp_pack_layout(nlbac_mlp* net) {
         off += (long)hid * hid;
         net->rr_bwd_off = (int)off;
         off += (long)hid * hid;
-        off += (long)rr_panel_l0_floats(hid);         // layer 0's A fragments (with its bias column), behind the panels
+        off += 3L * rr_panel_l0_floats(hid);          // behind the panels: layer 0's A fragments (with its bias column), the
+                                                      // last layer's and layer 0's transposed fragments (data backward)
     }
     net->packed_floats = (int)off;
     return (int)off;
@@ -899,6 +921,9 @@ static int mlp_fwd_launch(const nlbac_mlp* nets, const nlbac_mlp_io* io, int n_n
         const int rr = nlbac_mlp_rr_fwd_launch(L, n_nets, G, who, (hipStream_t)s);
         if (rr <= 0) return rr;
     }
+    for (int i = 0; i < n_nets; ++i)
+        NLBAC_REQUIRE(!io[i].masks, "%s: net %d: ReLU mask words are written by the register-resident kernels only "
+                      "(nlbac_mlp_masks_ok)", who, i);
     const size_t lds = (size_t)2 * NLBAC_MLP_TILE * L.ld * sizeof(float);
     const dim3 grid(nlbac_ceil_div(B, NLBAC_MLP_TILE), n_nets);
     switch (tile_mode(nets, n_nets)) {
@@ -936,14 +961,22 @@ static int mlp_bwd_data_launch(const nlbac_mlp* nets, const nlbac_mlp_io* io, in
                                const char* who, nlbac_stream_t s) {
     MlpLaunch L;
     if (fill_launch(L, nets, io, n_nets, B, who)) return -1;
-    for (int i = 0; i < n_nets; ++i)
-        NLBAC_REQUIRE((io[i].dy || H.kind) && io[i].acts, "%s: net %d needs dy and acts", who, i);
+    for (int i = 0; i < n_nets; ++i) {
+        NLBAC_REQUIRE((io[i].dy || H.kind) && (io[i].acts || io[i].masks), "%s: net %d needs dy and acts (or masks)", who, i);
+        NLBAC_REQUIRE(!io[i].skinny_ws || io[i].acts, "%s: net %d: skinny-gradient partials need acts", who, i);
+    }
     for (int i = 0; i < n_nets; ++i)
         NLBAC_REQUIRE(!io[i].dx || (io[i].dx_first >= 0 && io[i].dx_first < nets[i].in_dim),
                       "%s: net %d: dx_first %d out of [0, in_dim %d)", who, i, io[i].dx_first, nets[i].in_dim);
     for (int i = 0; i < n_nets; ++i)
         NLBAC_REQUIRE(!io[i].skinny_ws || (B <= 32768 && io[i].x0 && io[i].dz && nets[i].hid <= 256),
                       "%s: net %d: skinny-gradient partials need x0, dz, hid <= 256 and B <= 32768", who, i);
+    {   // nets with one hid x hid layer of 64 / 128 / 256 units run on the register-resident kernel (mlp_rr_kernels.hip)
+        const int rr = nlbac_mlp_rr_bwd_launch(L, n_nets, H, who, (hipStream_t)s);
+        if (rr <= 0) return rr;
+    }
+    for (int i = 0; i < n_nets; ++i)
+        NLBAC_REQUIRE(io[i].acts, "%s: net %d: the LDS-tiled kernel gates with the saved activations (acts), not mask words", who, i);
     const size_t lds = ((size_t)2 * NLBAC_MLP_TILE * L.ld + 2 * NLBAC_MLP_TILE * 16) * sizeof(float);
     const dim3 grid(nlbac_ceil_div(B, NLBAC_MLP_TILE), n_nets);
     switch (tile_mode(nets, n_nets)) {

@@ -684,8 +684,37 @@ class SAC_CBF_CLF(object):
         self.task.value_now_io(ws, io, 2 * NP)
         self.task.extra_value_io(ws, io, 2 * NP + 1)
         self.task.plan(ws, P)
+        self._masks_for_dx_only_nets(ws, P)
         ws.plan[NP] = P
         return P
+
+    def _masks_for_dx_only_nets(self, ws, P):
+        """Where the register-resident MLP kernels serve the heads, every forward that saves something for a backward
+        also leaves ReLU mask words (``nlbac_mlp_io::masks``, 64 B per row) and every data backward gates with them
+        instead of loading the activation rows (24 float4 per lane at the head of each tile's critical path).  Nets that
+        are only differentiated w.r.t. their inputs (Q(s, pi), V(p(x')), the barrier on predicted states: dx wanted, no
+        dz / weight gradients) then keep nothing else — their activation buffer is dropped from the descriptors: the
+        forward's 2 KB-per-row store burst goes.  Works on the finished launch descriptors: an activation buffer that no
+        descriptor pairs with a dz buffer is such a net's."""
+        if not self.fold_launches or not _lib.load().nlbac_mlp_masks_ok(mlp_array([h.desc for h in self.h_crit + self.h_pols]),
+                                                                       len(self.h_crit) + len(self.h_pols)):
+            return
+        arrays = [v for v in P.__dict__.values() if isinstance(v, C.Array) and getattr(v, "_type_", None) is _lib.MlpIO]
+        arrays += [g[3] for g in P.act_groups]
+        rows = set()
+        for arr in arrays:
+            for e in arr:
+                if e.acts and (e.dz or e.grad or e.skinny_ws):
+                    rows.add(e.acts)
+        bufs = ws.__dict__.setdefault("_mask_bufs", {})
+        for arr in arrays:
+            for e in arr:
+                if e.acts:
+                    if e.acts not in bufs:
+                        bufs[e.acts] = torch.zeros(2, ws.B, 8, dtype=torch.int32, device=self.device)
+                    e.masks = bufs[e.acts].data_ptr()
+                    if e.acts not in rows:
+                        e.acts = None
 
     def auglag_fused(self, ws, n_cbf, lam_upd):
         """The (fused, ticket, sc) tail of a ``*_constraints_fwd`` call: on one GPU the launch's last workgroup runs the

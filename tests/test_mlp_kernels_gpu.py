@@ -392,3 +392,81 @@ def test_one_launch_weight_gradients_on_random_narrow_shapes():
         for l, lin in enumerate(lins):
             vec_close(ar.grad_view(lin.weight).cpu(), grads_ref[l][0], TOL, tag + " dW%d" % l)
             vec_close(ar.grad_view(lin.bias).cpu(), grads_ref[l][1], TOL, tag + " db%d" % l)
+
+
+@pytest.mark.parametrize("in_dim,hid,out_dim,B,keep_rows", [
+    (9, 256, 1, 4096, False),     # Q(s, pi): differentiated w.r.t. its inputs only
+    (2, 256, 1, 77, False),       # V(p(x')), ragged rows
+    (7, 256, 4, 100, True),       # mask words AND activation rows (a net whose weight gradients are wanted too)
+    (13, 128, 2, 333, False),     # two panels sharing... one word per panel at width 128
+    (5, 64, 3, 50, True),
+    (11, 256, 12, 65, False),     # out_dim > 4: the four-k-step form of the top product
+])
+def test_relu_mask_words_replace_the_saved_activation_rows(in_dim, hid, out_dim, B, keep_rows):
+    """``nlbac_mlp_io::masks``: the register-resident forward leaves ReLU mask words (64 B per row), the data backward
+    gates with them — with ``acts == NULL`` for nets that want dx only, or next to the rows.  dx (and dz, where rows are
+    kept) against torch autograd; the words themselves against the activations' signs."""
+    from nlbac_amd import _lib, arena as A
+    ar, h, lins, ref = build(in_dim, hid, out_dim, 3, seed=B)
+    nets, s = A.mlp_array([h.desc]), A.stream_ptr()
+    assert _lib.load().nlbac_mlp_masks_ok(nets, 1) == 1
+    g = torch.Generator().manual_seed(B + 1)
+    x, dy = torch.randn(B, in_dim, generator=g), torch.randn(B, out_dim, generator=g)
+    x[B // 2] = 0.0                                   # a row of zeros: relu'(0) = 0 must hold bit for bit (zero biases apart)
+    y_ref, acts_ref, dx_ref, _ = torch_ref(ref, x, dy)
+    xd, dyd = x.cuda(), dy.cuda()
+    y = torch.full((B, out_dim), float("nan"), device="cuda")
+    masks = torch.full((2, B, 8), -1, dtype=torch.int32, device="cuda")
+    acts = torch.full((2, B, hid), float("nan"), device="cuda")
+    dz = torch.full((2, B, hid), float("nan"), device="cuda")
+    dx = torch.full((B, in_dim), float("nan"), device="cuda")
+    io = A.io_array(1)
+    io[0].x0, io[0].x0_dim, io[0].x0_ld = xd.data_ptr(), in_dim, in_dim
+    io[0].y, io[0].y_ld = y.data_ptr(), out_dim
+    io[0].masks = masks.data_ptr()
+    io[0].dy, io[0].dy_ld = dyd.data_ptr(), out_dim
+    io[0].dx, io[0].dx_ld = dx.data_ptr(), in_dim
+    if keep_rows:
+        io[0].acts, io[0].dz = acts.data_ptr(), dz.data_ptr()
+    _lib.call("nlbac_mlp_fwd", nets, io, 1, B, s)
+    _lib.call("nlbac_mlp_bwd_data", nets, io, 1, B, s)
+    torch.cuda.synchronize()
+    vec_close(y.cpu(), y_ref, TOL, "y")
+    vec_close(dx.cpu(), dx_ref, TOL, "dx")
+    # the words: unit 16 (NBH w + j) + 4 q + r of row b, layer l <-> bit 4 NBH - 1 - (4 j + r) of masks[l, b, 2 q + w]
+    nbh = hid // 32
+    m = masks.cpu().numpy().astype(np.uint32)
+    u = np.arange(hid)
+    blk, q, r = u // 16, (u % 16) // 4, u % 4
+    w, j = blk // nbh, blk % nbh
+    bit = 4 * nbh - 1 - (4 * j + r)
+    for l in range(2):
+        got = (m[l][:, 2 * q + w] >> bit) & 1
+        want = (acts_ref[l].numpy() > 0).astype(np.uint32)
+        margin = np.abs(acts_ref[l].numpy())
+        bad = (got != want) & (margin > 1e-6)         # (a pre-activation within rounding of zero may land on either side)
+        assert not bad.any(), "layer %d: %d mask bits differ from the activations' signs" % (l, bad.sum())
+    if keep_rows:
+        for l in range(2):
+            vec_close(acts[l].cpu(), acts_ref[l], TOL, "acts%d" % l)
+        assert torch.isfinite(dz).all()
+    else:
+        assert torch.isnan(acts).all() and torch.isnan(dz).all(), "rows were written although acts / dz were not passed"
+
+
+def test_mask_words_need_the_register_resident_kernels():
+    """A net the register-resident kernels do not take (100 wide) reports so, and a launch that passes mask words for it
+    fails with an error instead of running ungated."""
+    from nlbac_amd import _lib, arena as A
+    ar, h, lins, ref = build(3, 100, 3, 3, seed=1)
+    nets, s = A.mlp_array([h.desc]), A.stream_ptr()
+    assert _lib.load().nlbac_mlp_masks_ok(nets, 1) == 0
+    B = 40
+    x, y = torch.randn(B, 3, device="cuda"), torch.empty(B, 3, device="cuda")
+    masks = torch.zeros(2, B, 8, dtype=torch.int32, device="cuda")
+    io = A.io_array(1)
+    io[0].x0, io[0].x0_dim, io[0].x0_ld = x.data_ptr(), 3, 3
+    io[0].y, io[0].y_ld = y.data_ptr(), 3
+    io[0].masks = masks.data_ptr()
+    with pytest.raises(_lib.NlbacError):
+        _lib.call("nlbac_mlp_fwd", nets, io, 1, B, s)
