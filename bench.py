@@ -368,15 +368,29 @@ def main():
         fit_local = max(1, NODE_FIT_ROWS // world) if strong else NODE_FIT_ROWS     # (strong: the fit batch is sharded too)
         fit_rows = torch.empty(fit_local, agent.lay.LD, device=dev)
 
-        def step(i, sync=True):
+        def draw():
             replay.sample_rows(B, out=ws.mb, eps_out=ws.eps)       # index draw + gather + policy noise: one launch
+
+        def step(i, sync=True):
+            # (the minibatch is drawn by the agent through ``prefetch``: this update's unless the previous call already
+            #  queued it — with the policy forward — behind its last launch, before blocking on the returned floats:
+            #  SAC_CBF_CLF.update_on_device.  Same draws in the same order as drawing here.)
             if i % NODE_FIT_INTERVAL == 0:
+                if ws.__dict__.get("_prefetched") is None:
+                    agent.update_prefetch(ws, i, draw)             # (first update: keep the order minibatch, fit rows)
                 agent.fit_node_rows(replay.sample_rows(fit_local, out=fit_rows))
-            return agent.update_on_device(ws, i, sync=sync, eps_ready=True)
+            return agent.update_on_device(ws, i, sync=sync, prefetch=draw)
+
+        def drop_prefetch():
+            """Forget a queued draw (and rewind the replay's draw counter: the next call draws the same rows again)."""
+            if ws.__dict__.get("_prefetched") is not None:
+                ws._prefetched = None
+                replay._draws -= 1
 
         for i in range(warmup):
             step(i)
         fence()
+        drop_prefetch()
         snap = io.BytesIO()            # agent + replay-draw state at the start of the timed region (replayed below)
         agent.save_checkpoint(snap)
         draws0 = replay._draws
@@ -399,6 +413,7 @@ def main():
         #      them can run; the headline above keeps the reference's blocking return
         snap.seek(0)
         agent.load_checkpoint(snap)
+        ws._prefetched = None
         replay._draws = draws0
         fence()
         t0 = time.perf_counter()

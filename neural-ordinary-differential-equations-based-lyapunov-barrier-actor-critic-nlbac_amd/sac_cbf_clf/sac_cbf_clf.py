@@ -754,9 +754,28 @@ class SAC_CBF_CLF(object):
              self.task.ratio_mode, self.task.backup_mode if NP == 2 else 0, 0.01, self.task.lam_hi,
              self.sc.data_ptr(), s)
 
-    def update_on_device(self, ws, updates, sync=True, eps_ready=False):
+    def update_on_device(self, ws, updates, sync=True, eps_ready=False, prefetch=None):
         """Minibatch already in ``ws.mb``; returns the reference's 6 floats.  ``eps_ready``: ``ws.eps`` already holds
-        this update's N(0,1) draws (``DeviceReplayMemory.sample_rows(..., eps_out=ws.eps)``)."""
+        this update's N(0,1) draws (``DeviceReplayMemory.sample_rows(..., eps_out=ws.eps)``).
+
+        ``prefetch``: a callable that draws a minibatch into ``ws.mb`` / ``ws.eps`` with device launches only
+        (``lambda: replay.sample_rows(B, out=ws.mb, eps_out=ws.eps)``); the caller then never draws itself.  This update's
+        rows are drawn by it unless the previous call already has: behind its last launch (the actors' optimiser step —
+        nothing reads ``ws.mb`` after it) every update queues the NEXT update's draw and policy forward before the host
+        blocks on the six returned floats, so the update boundary — the host waking up, returning to its loop and coming
+        back with the first launches, ~30 us of idle GPU otherwise — is covered by ~30 us of queued work.  The draw sees
+        the replay as of the end of this update: a driver that pushes transitions between two updates and wants them
+        eligible at once does not pass ``prefetch``."""
+        pre = ws.__dict__.get("_prefetched")
+        ws._prefetched = None
+        if prefetch is not None:
+            eps_ready = True
+            if pre is None or pre[0] != updates:
+                pre = None
+                prefetch()
+        else:
+            pre = None
+        ws._pre_now, ws._prefetch_fn, ws._sync = pre, prefetch, sync
         if self._noise is not None:
             assert len(self._noise) == self.task.n_eps, "set_noise needs %d draws" % self.task.n_eps
             order = self.task.eps_order or range(self.task.n_eps)     # device slot -> reference draw index
@@ -768,6 +787,8 @@ class SAC_CBF_CLF(object):
         soft = (updates % self.target_update_interval == 0)
         lam_upd = 1 if updates % self.Lagrangian_multiplier_update_interval == 0 else 0
         NP = ws.np_now = self.task.n_pol_now(updates)
+        ws.updates_now = updates
+        assert ws._pre_now is None or ws._pre_now[1] == NP
         ws.blam_upd = self.task.backup_lam_due(updates, self.Lagrangian_multiplier_update_interval)
         # where the update's last launch (the actors' optimiser step) leaves the scalars block for the host: straight
         # in pinned memory, so that no copy launch sits between that step and the host's wait.  Not under hipGraph
@@ -814,13 +835,13 @@ class SAC_CBF_CLF(object):
                 self._sc_flip = k
                 self._sc_pin[k].copy_(self.sc, non_blocking=True)
             prev, self._sc_lag = self._sc_lag, k
-            self._sc_ev[k].record()
+            if mirrored is None:
+                self._sc_ev[k].record()
             if prev is None:
                 return None
             self._sc_ev[prev].synchronize()
             h = self._sc_pin[prev].numpy().copy()
         elif mirrored is not None:
-            self._sc_ev[mirrored].record()
             self._sc_ev[mirrored].synchronize()
             h = self._sc_pin[mirrored].numpy().copy()
         else:
@@ -837,14 +858,33 @@ class SAC_CBF_CLF(object):
         NP = ws.np_now
         P = self._plan(ws, NP)
         LD = P.LD
-        sc = self.sc.data_ptr()
-        call = _lib.call
-        pol = self.policy
-        p_scale, p_bias = pol.action_scale.data_ptr(), pol.action_bias.data_ptr()
 
         # ---- A. targets (no grad): pi(s'), Q_target(s', a'), L_target(c') ; critic / Lyapunov forward
-        # (the actors' forward on s does not depend on the critic step below: it shares pi(s')'s launch, and all
-        #  (1+NP)*B samples are drawn by one launch - eps[0 .. NP] are contiguous)
+        if ws.__dict__.get("_pre_now") is None:       # (else: queued behind the previous update's last launch, see prefetch)
+            self._policy_forward(ws, P, NP)
+        # the rollout of the learned dynamics needs only pi(s) and the NODE: its first attempted step goes in here,
+        # so that the critic phase below is queued behind it while the host waits for the accept decision
+        self.task.rollout_begin(ws, P)
+        # The rest of part 1 does not depend on the rollout.  It is cut into three pieces that the solvers pull in one
+        # at a time just before each wait for an accept decision (``before_wait``), so that every attempted step —
+        # the second of a two-step solve, the second and third solve of Pvtol's chain — has work queued behind it;
+        # whatever is left goes in when the rollout is finished (``drain_fill``, called by the task).
+        self._fill = collections.deque((lambda: self._part1_targets(ws, P, B, G, LD, s),
+                                        lambda: self._part1_critic_step(ws, P, B, soft),
+                                        lambda: self._part1_actor_q(ws, P, B, G, NP, s)))
+        self._fill_first = True
+        if ws.__dict__.get("_pre_now") is not None:
+            self._fill.popleft()                # (targets + critic data backward: queued with the prefetch)
+        if self.solver != "dopri5" or torch.cuda.is_current_stream_capturing():
+            self.drain_fill()                   # no waits on this path (fixed-step solver / graph capture)
+
+    def _policy_forward(self, ws, P, NP):
+        """pi(s') and the actors on s.  (The actors' forward on s does not depend on the critic step: it shares pi(s')'s
+        launch, and all (1+NP)*B samples are drawn by one launch - eps[0 .. NP] are contiguous.)"""
+        B, A = ws.B, self.lay.act_dim
+        s, call = stream_ptr(), _lib.call
+        pol = self.policy
+        p_scale, p_bias = pol.action_scale.data_ptr(), pol.action_bias.data_ptr()
         if self.fold_launches:      # (the samples are drawn by the policy launch itself: nlbac_gauss_head)
             gh = P.__dict__.get("head_pol3")
             if gh is None:
@@ -856,24 +896,42 @@ class SAC_CBF_CLF(object):
             call("nlbac_mlp_fwd", P.n_pol3, P.io_pol3, 1 + NP, B, s)
             call("nlbac_gauss_sample_fwd", ws.heads3.data_ptr(), 2 * A, ws.eps.data_ptr(), p_scale, p_bias, A, (1 + NP) * B,
                  ws.act3.data_ptr(), A, ws.logp3.data_ptr(), s)
-        # the rollout of the learned dynamics needs only pi(s) and the NODE: its first attempted step goes in here,
-        # so that the critic phase below is queued behind it while the host waits for the accept decision
-        self.task.rollout_begin(ws, P)
-        # The rest of part 1 does not depend on the rollout.  It is cut into three pieces that the solvers pull in one
-        # at a time just before each wait for an accept decision (``before_wait``), so that every attempted step —
-        # the second of a two-step solve, the second and third solve of Pvtol's chain — has work queued behind it;
-        # whatever is left goes in when the rollout is finished (``drain_fill``, called by the task).
-        self._fill = collections.deque((lambda: self._part1_targets(ws, P, B, G, LD, s),
-                                        lambda: self._part1_critic_step(ws, P, B, soft),
-                                        lambda: self._part1_actor_q(ws, P, B, G, NP, s)))
-        if self.solver != "dopri5" or torch.cuda.is_current_stream_capturing():
-            self.drain_fill()                   # no waits on this path (fixed-step solver / graph capture)
+
+    def _prefetch_next(self, ws, updates):
+        """Behind this update's last launch: the next update's minibatch draw and first launches (update_on_device)."""
+        fn = ws.__dict__.get("_prefetch_fn")
+        if fn is None or self._graphs_on() or self.world != 1 or self._noise is not None:
+            return
+        if ws._sync and self.__dict__.get("_mirror") is None:
+            return      # (the returned floats would be copied BEHIND the queued launches, whose dy head rewrites the losses)
+        fn()
+        NP = self.task.n_pol_now(updates + 1)
+        self._prefetch_launches(ws, NP)
+        ws._prefetched = (updates + 1, NP)
+
+    def update_prefetch(self, ws, updates, prefetch):
+        """Draw update ``updates``'s minibatch (``prefetch``, see update_on_device) and queue its policy forward now — what
+        every update does for its successor; for callers that need the draw to come before something else they queue."""
+        if self._graphs_on() or self.world != 1:
+            return
+        prefetch()
+        NP = self.task.n_pol_now(updates)
+        self._prefetch_launches(ws, NP)
+        ws._prefetched = (updates, NP)
+
+    def _prefetch_launches(self, ws, NP):
+        """What of an update needs nothing but its minibatch and the parameters as the previous update left them: the
+        policy forward, then the target / critic forward and the critics' data backward (~95 us of launches: more than
+        the host needs to come round to the next update)."""
+        P = self._plan(ws, NP)
+        self._policy_forward(ws, P, NP)
+        self._part1_targets(ws, P, ws.B, ws.B * self.world, P.LD, stream_ptr())
 
     def _fill_one(self):
         """Called by a solver just before it waits for an accept decision: queue the next piece(s) of part 1 behind the
         attempted step.  The first wait of an update gets two (the host needs ~100 us of queued work to read the
         decision and launch what follows without the stream running dry), later ones one each."""
-        k = 2 if len(self._fill) == 3 else 1
+        k, self._fill_first = (2 if self.__dict__.get("_fill_first", True) else 1), False
         while k and self._fill:
             self._fill.popleft()()
             k -= 1
@@ -1037,6 +1095,8 @@ class SAC_CBF_CLF(object):
             self._adam(a, self.lr, a.n_slabs, before_step=alpha_grads, alpha=refresh, mirror=mir[1] if mir else None)
             if mir:
                 self._mirror_done = mir[0]
+                self._sc_ev[mir[0]].record()     # (here, not in _returns: what _prefetch_next queues is not waited for)
+        self._prefetch_next(ws, ws.updates_now)
 
     # ------------------------------------------------------------ checkpoints
     def save_model(self, output):
