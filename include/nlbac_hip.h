@@ -98,7 +98,7 @@ typedef struct nlbac_mlp_io {
                                            Sits in what was padding: sizeof and the other offsets are unchanged */
     float *grad;                        /* bwd_weights out: slab 0 of the flat grad (same offsets as params) */
     float *skinny_ws;                   /* or NULL.  This net's block of the nlbac_mlp_bwd_weights workspace (ws +
-                                           i * ws_floats / n_nets): nlbac_mlp_bwd_data then leaves the per-32-row partial
+                                           i * ws_floats / n_nets): nlbac_mlp_bwd_data then leaves the per-16-row partial
                                            sums of the bias / first- / last-layer gradients there (it has every dz tile
                                            in LDS anyway) and nlbac_mlp_bwd_weights only reduces them.  B <= 32768. */
     unsigned *masks;                    /* or NULL (ABI 4).  [n_layers-1 = 2][B][8] ReLU mask words of the register-resident
@@ -234,7 +234,7 @@ int nlbac_actor_q_terms(const float *q1, const float *q2, const float *logp, con
  *   kind 3  nlbac_actor_q_terms     net i = (controller i / 2, Q1 / Q2 = i % 2) for i < 2 n_prob, nets behind them take
  *                                   io[i].dy as in nlbac_mlp_bwd_data (an independent backward sharing the launch);
  *                                   + nlbac_actor_scalars via `actor`
- * partials: n_nets * n_tiles (kind 2) / 2 * n_prob * n_tiles (kind 3) floats, n_tiles = ceil(B / 32); ticket: a zeroed
+ * partials: n_nets * n_tiles (kind 2) / 2 * n_prob * n_tiles (kind 3) floats, n_tiles = ceil(B / 16) (the finest tile of the kernels that serve the launch); ticket: a zeroed
  * uint32, left zeroed. */
 typedef struct nlbac_dy_head {
     int kind, B_norm;

@@ -13,6 +13,7 @@ LIB_PATH = os.environ.get("NLBAC_HIP_LIB") or os.path.join(_HERE, "lib", "libnlb
 CSRC = os.path.join(_HERE, "csrc")
 
 MAX_LAYERS, MAX_NETS, MLP_TILE = 6, 8, 32
+MLP_TILE_MIN = 16      # rows per workgroup of the finest MLP kernels: what per-tile partial buffers (nlbac_dy_head) are sized by
 SC_SIZE, DOPRI_CTL = 128, 16
 
 c_float_p = C.POINTER(C.c_float)

@@ -102,13 +102,15 @@ struct DyHeadPending { float v0, v1; };
 // mlp_bwd_data workgroup before anything reads sdy.  What the tile contributes to the launch's batch sums is returned in
 // `pend` for dy_head_finish — which may run at any later point of the kernel (the LDS-tiled kernel calls it right away;
 // the register-resident one at its very end, so that the atomics' round trip is off the tile's critical path).
+// TILE: rows of the workgroup's tile (32: the LDS-tiled and half-panel kernels; 16: the quarter-panel kernels).
+template <int TILE = NLBAC_MLP_TILE>
 __device__ __forceinline__ void dy_head_rows(const nlbac_dy_head& H, int inet, int row0, int B, float* sdy, DyHeadPending& pend) {
     const int tid = threadIdx.x;
     pend.v0 = pend.v1 = 0.f;
     if (H.kind == 1) {
         // GaussianPolicy.sample backward; net inet = controller inet, its rows are inet*B.. of the stacked arrays
         const float dlp = H.alpha[inet] * H.dlogp_mul;
-        for (int idx = tid; idx < NLBAC_MLP_TILE * 16; idx += 256) {
+        for (int idx = tid; idx < TILE * 16; idx += 256) {
             const int r = idx >> 4, c = idx & 15, row = row0 + r;
             float v = 0.f;
             if (row < B && c < 2 * H.n_u) {
@@ -125,9 +127,9 @@ __device__ __forceinline__ void dy_head_rows(const nlbac_dy_head& H, int inet, i
     } else if (H.kind == 2) {
         // TD / Lyapunov targets; net 0 = Q1, 1 = Q2, 2 = Lyapunov critic (3 = the learned-barrier copies' BarrierNet).
         float e2 = 0.f;
-        for (int idx = tid; idx < NLBAC_MLP_TILE * 16; idx += 256) sdy[idx] = 0.f;
+        for (int idx = tid; idx < TILE * 16; idx += 256) sdy[idx] = 0.f;
         __syncthreads();
-        if (tid < NLBAC_MLP_TILE && row0 + tid < B) {
+        if (tid < TILE && row0 + tid < B) {
             const int i = row0 + tid;
             const float mk = H.mask[(long)i * H.rcm_ld];
             float y;
@@ -157,9 +159,9 @@ __device__ __forceinline__ void dy_head_rows(const nlbac_dy_head& H, int inet, i
         // min(Q1, Q2)(s, pi) branch gradients; net inet = (controller inet / 2, Q1 / Q2 = inet % 2)
         const int p = inet >> 1, which = inet & 1;
         float v0 = 0.f, v1 = 0.f;
-        for (int idx = tid; idx < NLBAC_MLP_TILE * 16; idx += 256) sdy[idx] = 0.f;
+        for (int idx = tid; idx < TILE * 16; idx += 256) sdy[idx] = 0.f;
         __syncthreads();
-        if (tid < NLBAC_MLP_TILE && row0 + tid < B) {
+        if (tid < TILE && row0 + tid < B) {
             const long r = (long)p * B + row0 + tid;
             const float a = H.qa[r], b = H.qb[r];
             const float g = -(1.0f / (float)H.B_norm);
@@ -182,10 +184,11 @@ __device__ __forceinline__ void dy_head_rows(const nlbac_dy_head& H, int inet, i
 // The launch-wide half of a dy head: every designated workgroup publishes its tile's sums, the last one to arrive
 // finishes the batch quantities (publish_and_elect, common.h).  All 256 threads; `red`: >= 16 floats of LDS scratch that
 // nothing else uses until the call returns.
+template <int TILE = NLBAC_MLP_TILE>
 __device__ __forceinline__ void dy_head_finish(const nlbac_dy_head& H, int inet, int row0, int n_tiles, float* red, int n_nets,
                                                const DyHeadPending& pend) {
     const int tid = threadIdx.x;
-    const int tile = row0 / NLBAC_MLP_TILE;
+    const int tile = row0 / TILE;
     if (H.kind == 2) {
         // every net's workgroup publishes its own squared-error sum of the tile; the last of the n_nets * n_tiles
         // workgroups finishes the losses

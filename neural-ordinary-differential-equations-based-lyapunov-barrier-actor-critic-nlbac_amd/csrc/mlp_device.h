@@ -339,7 +339,7 @@ __device__ __forceinline__ void bwd_wide_layers(WaveGemm<NTW, D>& wg, const nlba
                                                 int LD, float*& in, float*& out, const float* acts_tile,
                                                 float* dz_tile, long ls, int n_rows, int row_clamp,
                                                 int n_run = -1, bool wrap = false, int nthr = 256,
-                                                GroupBar* gb = nullptr, float* colsum = nullptr) {
+                                                GroupBar* gb = nullptr, float* colsum = nullptr, long colsum_step = 0) {
     const int hid = net.hid, KC = pad8(hid) >> 3, nwide = net.n_layers - 1, half = lane >> 5;
     if (n_run < 0) n_run = nwide - 1;          // lock-step iterations (>= nwide-1 when groups differ in depth)
     for (int it = 0; it < n_run; ++it) {
@@ -401,12 +401,16 @@ __device__ __forceinline__ void bwd_wide_layers(WaveGemm<NTW, D>& wg, const nlba
             // dz[j-1] now sits complete in `in`: stream it out while the next layer's GEMM runs (mask mode keeps no dz)
             if constexpr (BITS == 0) {
                 if (dz_tile) tile_to_global(in, LD, dz_tile + (long)(j - 1) * ls, hid, n_rows, wave * 64 + lane, nthr);
-                if (colsum) {      // bias-gradient partial of layer j-1: this thread's column over the tile's rows, in order
+                if (colsum) {      // bias-gradient partials of layer j-1: this thread's column over the tile's rows, in order,
+                                   // one per 16 rows (NLBAC_SK_CHUNK), colsum_step floats apart
                     const int col = wave * 64 + lane;
-                    float a = 0.f;
-                    if (col < hid)
-                        for (int m = 0; m < NLBAC_MLP_TILE; ++m) a += in[m * LD + col];
-                    colsum[(long)(j - 1) * 256] = a;
+#pragma unroll
+                    for (int hh = 0; hh < NLBAC_MLP_TILE / 16; ++hh) {
+                        float a = 0.f;
+                        if (col < hid)
+                            for (int m = 0; m < 16; ++m) a += in[(hh * 16 + m) * LD + col];
+                        colsum[hh * colsum_step + (long)(j - 1) * 256] = a;
+                    }
                 }
             }
         }

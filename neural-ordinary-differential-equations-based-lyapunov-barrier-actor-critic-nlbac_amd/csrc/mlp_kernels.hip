@@ -280,9 +280,10 @@ __global__ __launch_bounds__(256, 2) void mlp_bwd_data_kernel(const MlpLaunch L,
     float* sx = sdy + NLBAC_MLP_TILE * 16;         // [32][16] input rows (only for the skinny-gradient partials)
     // skinny-gradient partials of this 32-row tile (= one chunk of mlp_bwd_skinny_partial_kernel, same sums in the same
     // order): thread = hidden column, quantity q at w[q * 256]
+    // (one set per NLBAC_SK_CHUNK = 16 rows: this tile leaves two; w = the first, the second wstep floats behind it)
     const bool sk = io.skinny_ws != nullptr && io.dz != nullptr;
-    float* w = sk ? io.skinny_ws + (long)blockIdx.x * ((net.n_layers - 1) + net.in_dim + net.out_dim + 1) * 256 + tid
-                  : nullptr;
+    const long wstep = (long)((net.n_layers - 1) + net.in_dim + net.out_dim + 1) * 256;
+    float* w = sk ? io.skinny_ws + (long)blockIdx.x * (NLBAC_MLP_TILE / NLBAC_SK_CHUNK) * wstep + tid : nullptr;
 
     const bool active = wave < NT, two = (MODE == 2) || (MODE == 0 && (wave + 4) < NT);
     WaveGemm<(MODE == 1) ? 1 : 2> wg2;      // MODE 1 never touches wg2 / MODE 2 never touches wg1:
@@ -347,25 +348,32 @@ __global__ __launch_bounds__(256, 2) void mlp_bwd_data_kernel(const MlpLaunch L,
         if (sk) {      // last layer: dW_L[o][k] = sum_m dy[m][o] a_L[m][k] (av holds the activations), db_L[o] = sum_m dy[m][o]
             const int idim = net.in_dim, odim = net.out_dim;
             const bool live = k < hid;
-            for (int o = 0; o < odim; ++o) {
-                float a = 0.f;
 #pragma unroll
-                for (int m = 0; m < NLBAC_MLP_TILE; ++m) a = __builtin_fmaf(sdy[m * 16 + o], av[m], a);   // (fused, as
-                                                               // mlp_bwd_skinny_partial_kernel's contracted multiply-adds)
-                w[(long)(nwide + idim + o) * 256] = live ? a : 0.f;
+            for (int hh = 0; hh < NLBAC_MLP_TILE / NLBAC_SK_CHUNK; ++hh) {
+                const int m0 = hh * NLBAC_SK_CHUNK;
+                for (int o = 0; o < odim; ++o) {
+                    float a = 0.f;
+#pragma unroll
+                    for (int m = 0; m < NLBAC_SK_CHUNK; ++m) a = __builtin_fmaf(sdy[(m0 + m) * 16 + o], av[m0 + m], a);   // (fused, as
+                                                                   // mlp_bwd_skinny_partial_kernel's contracted multiply-adds)
+                    w[hh * wstep + (long)(nwide + idim + o) * 256] = live ? a : 0.f;
+                }
+                float bl = 0.f;
+                if (k < 16)
+                    for (int m = 0; m < NLBAC_SK_CHUNK; ++m) bl += sdy[(m0 + m) * 16 + k];
+                w[hh * wstep + (long)(nwide + idim + odim) * 256] = bl;
             }
-            float bl = 0.f;
-            if (k < 16)
-                for (int m = 0; m < NLBAC_MLP_TILE; ++m) bl += sdy[m * 16 + k];
-            w[(long)(nwide + idim + odim) * 256] = bl;
         }
     }
     __syncthreads();
     if (sk) {          // bias gradient of the top hidden layer: column sum of the finished dz tile
-        float a = 0.f;
-        if (tid < hid)
-            for (int m = 0; m < NLBAC_MLP_TILE; ++m) a += in[m * LD + tid];
-        w[(long)(nwide - 1) * 256] = a;
+#pragma unroll
+        for (int hh = 0; hh < NLBAC_MLP_TILE / NLBAC_SK_CHUNK; ++hh) {
+            float a = 0.f;
+            if (tid < hid)
+                for (int m = 0; m < NLBAC_SK_CHUNK; ++m) a += in[(hh * NLBAC_SK_CHUNK + m) * LD + tid];
+            w[hh * wstep + (long)(nwide - 1) * 256] = a;
+        }
     }
     if (io.dz)       // the top layer's dz leaves from the finished LDS tile (coalesced, overlaps the first GEMM)
         tile_to_global(in, LD, io.dz + (long)(nwide - 1) * ls + (long)row0 * hid, hid, min(NLBAC_MLP_TILE, B - row0), tid, 256);
@@ -374,22 +382,26 @@ __global__ __launch_bounds__(256, 2) void mlp_bwd_data_kernel(const MlpLaunch L,
         const int n_rows = min(NLBAC_MLP_TILE, B - row0);
         const float* acts_tile = io.acts + (long)row0 * hid;
         float* dz_tile = io.dz ? io.dz + (long)row0 * hid : nullptr;
-        if constexpr (MODE == 2) bwd_wide_layers<2>(wg2, net, active, wave, lane, LD, in, out, acts_tile, dz_tile, ls, n_rows, n_rows - 1, -1, false, 256, nullptr, w);
-        else if constexpr (MODE == 1) bwd_wide_layers<1>(wg1, net, active, wave, lane, LD, in, out, acts_tile, dz_tile, ls, n_rows, n_rows - 1, -1, false, 256, nullptr, w);
+        if constexpr (MODE == 2) bwd_wide_layers<2>(wg2, net, active, wave, lane, LD, in, out, acts_tile, dz_tile, ls, n_rows, n_rows - 1, -1, false, 256, nullptr, w, wstep);
+        else if constexpr (MODE == 1) bwd_wide_layers<1>(wg1, net, active, wave, lane, LD, in, out, acts_tile, dz_tile, ls, n_rows, n_rows - 1, -1, false, 256, nullptr, w, wstep);
         else {
-            if (two) bwd_wide_layers<2>(wg2, net, active, wave, lane, LD, in, out, acts_tile, dz_tile, ls, n_rows, n_rows - 1, -1, false, 256, nullptr, w);
-            else bwd_wide_layers<1>(wg1, net, active, wave, lane, LD, in, out, acts_tile, dz_tile, ls, n_rows, n_rows - 1, -1, false, 256, nullptr, w);
+            if (two) bwd_wide_layers<2>(wg2, net, active, wave, lane, LD, in, out, acts_tile, dz_tile, ls, n_rows, n_rows - 1, -1, false, 256, nullptr, w, wstep);
+            else bwd_wide_layers<1>(wg1, net, active, wave, lane, LD, in, out, acts_tile, dz_tile, ls, n_rows, n_rows - 1, -1, false, 256, nullptr, w, wstep);
         }
     }
 
     if (sk) {      // first layer: dW_0[k][i] = sum_m dz0[m][k] x[m][i]
         const int idim = net.in_dim;
         const bool live = tid < hid;
-        for (int i = 0; i < idim; ++i) {
-            float a = 0.f;
-            if (live)
-                for (int m = 0; m < NLBAC_MLP_TILE; ++m) a = __builtin_fmaf(in[m * LD + tid], sx[m * 16 + i], a);
-            w[(long)(nwide + i) * 256] = a;
+#pragma unroll
+        for (int hh = 0; hh < NLBAC_MLP_TILE / NLBAC_SK_CHUNK; ++hh) {
+            const int m0 = hh * NLBAC_SK_CHUNK;
+            for (int i = 0; i < idim; ++i) {
+                float a = 0.f;
+                if (live)
+                    for (int m = 0; m < NLBAC_SK_CHUNK; ++m) a = __builtin_fmaf(in[(m0 + m) * LD + tid], sx[(m0 + m) * 16 + i], a);
+                w[hh * wstep + (long)(nwide + i) * 256] = a;
+            }
         }
     }
     if (io.dx) {   // dx[m][i] = sum_n dz0[m][n] W0[n][i]
@@ -1021,13 +1033,16 @@ extern "C" int nlbac_mlp_bwd_data_head(const nlbac_mlp* nets, const nlbac_mlp_io
 }
 
 // rows per partial-sum chunk of the skinny-gradient reduction: short chunks so that >= 1 workgroup per CU streams
-// rows concurrently (the loop is latency bound), capped at 1024 chunks
-static inline int skinny_rows_per_chunk(int B) { return (B + 1023) / 1024 > 32 ? (B + 1023) / 1024 : 32; }
+// rows concurrently (the loop is latency bound), capped at 2048 chunks; up to B = 32768 the chunk is the data backward's
+// finest tile (NLBAC_SK_CHUNK rows), whose partial sums nlbac_mlp_bwd_data can leave itself
+static inline int skinny_rows_per_chunk(int B) { return (B + 2047) / 2048 > NLBAC_SK_CHUNK ? (B + 2047) / 2048 : NLBAC_SK_CHUNK; }
 
 extern "C" long nlbac_mlp_bwd_weights_ws_floats(const nlbac_mlp* nets, int n_nets, int B) {
     long per_net = 0;
     const int rpc = skinny_rows_per_chunk(B);
-    const int n_chunks = (B + rpc - 1) / rpc;
+    int n_chunks = (B + rpc - 1) / rpc;
+    if (rpc == NLBAC_SK_CHUNK) n_chunks = (n_chunks + 1) & ~1;      // (the 32-row kernels write two chunks per tile, the last one
+                                                                    //  of a ragged batch possibly past ceil(B / 16): zeros)
     for (int i = 0; i < n_nets; ++i) {
         const long nq = (nets[i].n_layers - 1) + nets[i].in_dim + nets[i].out_dim + 1;
         if (nq * 256 * n_chunks > per_net) per_net = nq * 256 * n_chunks;
@@ -1059,7 +1074,7 @@ extern "C" int nlbac_mlp_bwd_weights(const nlbac_mlp* nets, const nlbac_mlp_io* 
     S.rows_per_chunk = skinny_rows_per_chunk(B);
     S.n_chunks = (B + S.rows_per_chunk - 1) / S.rows_per_chunk;
     S.net_stride = need / n_nets;
-    bool all_narrow = true, partials_ready = S.rows_per_chunk == NLBAC_MLP_TILE, reduced = false;
+    bool all_narrow = true, partials_ready = S.rows_per_chunk == NLBAC_SK_CHUNK, reduced = false;
     for (int i = 0; i < n_nets; ++i) {
         all_narrow = all_narrow && nets[i].hid <= 128;
         // nlbac_mlp_bwd_data has already left this net's partial sums in its block of ws (nlbac_mlp_io::skinny_ws)

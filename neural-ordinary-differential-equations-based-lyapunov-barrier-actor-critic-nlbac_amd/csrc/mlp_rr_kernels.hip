@@ -385,49 +385,56 @@ __global__ __launch_bounds__(256, 2) void mlp_rr_bwd_kernel(const MlpLaunch L, c
         }
     }
     if (sk) {      // thread = hidden column k; the sums and their order are mlp_bwd_skinny_partial_kernel's (row after row,
-                   // fused multiply-adds): the column's 32 values in registers, the rows' x / dy as broadcast float4 reads
-        float* w = io.skinny_ws + (long)blockIdx.x * (2 + idim + odim + 1) * 256 + tid;
+                   // fused multiply-adds), one set per NLBAC_SK_CHUNK = 16 rows: the column's values in registers, the rows'
+                   // x / dy as broadcast float4 reads
         const bool live = tid < HID;
-        float z0[NLBAC_MLP_TILE];
-        float b0 = 0.f, b1 = 0.f;
 #pragma unroll
-        for (int mm = 0; mm < NLBAC_MLP_TILE; ++mm) { z0[mm] = sZ0[mm * LDZ + kcol]; b1 += sZ1[mm * LDZ + kcol]; }
+        for (int hh = 0; hh < NLBAC_MLP_TILE / NLBAC_SK_CHUNK; ++hh) {
+            constexpr int CH = NLBAC_SK_CHUNK;
+            float* w = io.skinny_ws + ((long)blockIdx.x * (NLBAC_MLP_TILE / CH) + hh) * (2 + idim + odim + 1) * 256 + tid;
+            const float* z1p = sZ1 + hh * CH * LDZ, * z0p = sZ0 + hh * CH * LDZ;
+            const float* xp = sx + hh * CH * 16, * dyp = sdy + hh * CH * 16;
+            float z0[CH];
+            float b0 = 0.f, b1 = 0.f;
 #pragma unroll
-        for (int mm = 0; mm < NLBAC_MLP_TILE; ++mm) b0 += z0[mm];
-        w[0] = live ? b0 : 0.f;
-        w[256] = live ? b1 : 0.f;
-        for (int i0 = 0; i0 < idim; i0 += 4) {    // dW_0[k][i] = sum_m dz0[m][k] x[m][i]
-            float a[4] = {0.f, 0.f, 0.f, 0.f};
+            for (int mm = 0; mm < CH; ++mm) { z0[mm] = z0p[mm * LDZ + kcol]; b1 += z1p[mm * LDZ + kcol]; }
 #pragma unroll
-            for (int mm = 0; mm < NLBAC_MLP_TILE; ++mm) {
-                const f32x4 xv = *reinterpret_cast<const f32x4*>(sx + mm * 16 + i0);
+            for (int mm = 0; mm < CH; ++mm) b0 += z0[mm];
+            w[0] = live ? b0 : 0.f;
+            w[256] = live ? b1 : 0.f;
+            for (int i0 = 0; i0 < idim; i0 += 4) {    // dW_0[k][i] = sum_m dz0[m][k] x[m][i]
+                float a[4] = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-                for (int c = 0; c < 4; ++c) a[c] = __builtin_fmaf(z0[mm], xv[c], a[c]);
+                for (int mm = 0; mm < CH; ++mm) {
+                    const f32x4 xv = *reinterpret_cast<const f32x4*>(xp + mm * 16 + i0);
+#pragma unroll
+                    for (int c = 0; c < 4; ++c) a[c] = __builtin_fmaf(z0[mm], xv[c], a[c]);
+                }
+                // (all four chains are wanted as they stand, interleaved: behind the `i0 + c < idim` guards below the
+                //  compiler sinks each into its own block — serial chains of dependent FMAs instead of one pass)
+                asm volatile("" : "+v"(a[0]), "+v"(a[1]), "+v"(a[2]), "+v"(a[3]));
+#pragma unroll
+                for (int c = 0; c < 4; ++c)
+                    if (i0 + c < idim) w[(long)(2 + i0 + c) * 256] = live ? a[c] : 0.f;
             }
-            // (all four chains are wanted as they stand, interleaved: behind the `i0 + c < idim` guards below the compiler
-            //  sinks each into its own block — four serial chains of 32 dependent FMAs instead of one pass of 128)
-            asm volatile("" : "+v"(a[0]), "+v"(a[1]), "+v"(a[2]), "+v"(a[3]));
+            for (int o0 = 0; o0 < odim; o0 += 4) {    // dW_2[o][k] = sum_m dy[m][o] a1[m][k]
+                float a[4] = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-            for (int c = 0; c < 4; ++c)
-                if (i0 + c < idim) w[(long)(2 + i0 + c) * 256] = live ? a[c] : 0.f;
-        }
-        for (int o0 = 0; o0 < odim; o0 += 4) {    // dW_2[o][k] = sum_m dy[m][o] a1[m][k]
-            float a[4] = {0.f, 0.f, 0.f, 0.f};
+                for (int mm = 0; mm < CH; ++mm) {
+                    const f32x4 dv = *reinterpret_cast<const f32x4*>(dyp + mm * 16 + o0);
 #pragma unroll
-            for (int mm = 0; mm < NLBAC_MLP_TILE; ++mm) {
-                const f32x4 dv = *reinterpret_cast<const f32x4*>(sdy + mm * 16 + o0);
+                    for (int c = 0; c < 4; ++c) a[c] = __builtin_fmaf(dv[c], av[hh * CH + mm], a[c]);
+                }
+                asm volatile("" : "+v"(a[0]), "+v"(a[1]), "+v"(a[2]), "+v"(a[3]));
 #pragma unroll
-                for (int c = 0; c < 4; ++c) a[c] = __builtin_fmaf(dv[c], av[mm], a[c]);
+                for (int c = 0; c < 4; ++c)
+                    if (o0 + c < odim) w[(long)(2 + idim + o0 + c) * 256] = live ? a[c] : 0.f;
             }
-            asm volatile("" : "+v"(a[0]), "+v"(a[1]), "+v"(a[2]), "+v"(a[3]));
-#pragma unroll
-            for (int c = 0; c < 4; ++c)
-                if (o0 + c < odim) w[(long)(2 + idim + o0 + c) * 256] = live ? a[c] : 0.f;
+            float bl = 0.f;
+            if (tid < 16)
+                for (int mm = 0; mm < CH; ++mm) bl += dyp[mm * 16 + tid];
+            w[(long)(2 + idim + odim) * 256] = bl;
         }
-        float bl = 0.f;
-        if (tid < 16)
-            for (int mm = 0; mm < NLBAC_MLP_TILE; ++mm) bl += sdy[mm * 16 + tid];
-        w[(long)(2 + idim + odim) * 256] = bl;
     }
     BSTAMP(6)
     // ---- the dy head's batch sums: published / finished here, off the tile's critical path
@@ -456,6 +463,10 @@ bool nlbac_mlp_rr_eligible(const nlbac_mlp* nets, int n_nets) {
 
 int nlbac_mlp_rr_fwd_launch(const MlpLaunch& L, int n_nets, const nlbac_gauss_head& G, const char* who, hipStream_t s) {
     if (!nlbac_mlp_rr_eligible(L.net, n_nets)) return 1;
+    {
+        const int rq = nlbac_mlp_rrq_fwd_launch(L, n_nets, G, who, s);      // (hid 128 / 256: the quarter-panel kernels)
+        if (rq <= 0) return rq;
+    }
     const int hid = L.net[0].hid;
     bool bits = false;
     for (int i = 0; i < n_nets; ++i) bits = bits || L.io[i].masks != nullptr;
@@ -482,6 +493,10 @@ static bool mrr_bwd_enabled() {
 
 int nlbac_mlp_rr_bwd_launch(const MlpLaunch& L, int n_nets, const nlbac_dy_head& H, const char* who, hipStream_t s) {
     if (!mrr_bwd_enabled() || !nlbac_mlp_rr_eligible(L.net, n_nets)) return 1;
+    {
+        const int rq = nlbac_mlp_rrq_bwd_launch(L, n_nets, H, who, s);
+        if (rq <= 0) return rq;
+    }
     const int hid = L.net[0].hid;
     bool sk = false, wide_out = false;
     int n_bits = 0;

@@ -30,8 +30,8 @@ typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
 #ifndef RR_DEPTH_MAX
 #define RR_DEPTH_MAX 8       /* tools/micro/rr_chain.hip: 4 float4 in flight stream as fast as 11 or 22 */
 #endif
-__host__ __device__ constexpr int rr_pick_depth(int nv) {
-    for (int d = RR_DEPTH_MAX; d >= 4; --d)
+__host__ __device__ constexpr int rr_pick_depth(int nv, int dmax = RR_DEPTH_MAX) {
+    for (int d = dmax; d >= 4; --d)
         if (nv % d == 0) return d;
     return 1;
 }
@@ -250,9 +250,10 @@ __device__ __forceinline__ void rr_row_store(float* __restrict__ rowp, int jo, i
 // two, k-steps inner; the same hooks as RRGemm::run.  Fragment stream: the panel's NBO * KS / 4 float4 per lane, in
 // issue order ("panel pack", written by nlbac_mlp_pack).
 // ---------------------------------------------------------------------------------------------------------------------
-template <int NBO, int KS>
+// DMAX: float4 of the stream in flight per lane at most (kernels that share a SIMD between three waves keep 4)
+template <int NBO, int KS, int DMAX = RR_DEPTH_MAX>
 struct RRPanel {
-    static constexpr int NM = NBO * KS, NV = NM / 4, D = rr_pick_depth(NV), BYTES = NV * 1024;
+    static constexpr int NM = NBO * KS, NV = NM / 4, D = rr_pick_depth(NV, DMAX), BYTES = NV * 1024;
     static_assert(NBO % 2 == 0 && KS % 4 == 0 && D >= 4, "panels hold an even number of 16-unit blocks");
     f32x4 wq[D];
 

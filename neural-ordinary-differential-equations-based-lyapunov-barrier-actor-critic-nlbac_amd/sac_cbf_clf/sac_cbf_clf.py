@@ -88,8 +88,8 @@ class _Workspace:
         self.dz_c = z(3 + NX, 2, B, H)
         self.nblk = (B + 255) // 256
         self.part_td = z(self.nblk, 3)
-        self.n_tiles = (B + _lib.MLP_TILE - 1) // _lib.MLP_TILE
-        self.part_td32 = z(self.n_tiles, 4)            # per-32-row-tile sums of the fused dy heads (nlbac_dy_head)
+        self.n_tiles = (B + _lib.MLP_TILE_MIN - 1) // _lib.MLP_TILE_MIN
+        self.part_td32 = z(self.n_tiles, 4)            # per-tile sums of the fused dy heads (nlbac_dy_head; 16-row tiles at most)
         self.part_tdx = z(max(NX, 1), self.nblk)
         self.heads2, self.pi2, self.logp2 = self.heads3[B:], self.act3[B:], self.logp3[B:]
         self.acts_p = z(NP, 2, B, H)

@@ -398,7 +398,7 @@ def test_one_launch_weight_gradients_on_random_narrow_shapes():
     (9, 256, 1, 4096, False),     # Q(s, pi): differentiated w.r.t. its inputs only
     (2, 256, 1, 77, False),       # V(p(x')), ragged rows
     (7, 256, 4, 100, True),       # mask words AND activation rows (a net whose weight gradients are wanted too)
-    (13, 128, 2, 333, False),     # two panels sharing... one word per panel at width 128
+    (13, 128, 2, 333, False),     # width 128: two blocks per quarter
     (5, 64, 3, 50, True),
     (11, 256, 12, 65, False),     # out_dim > 4: the four-k-step form of the top product
 ])
@@ -433,15 +433,23 @@ def test_relu_mask_words_replace_the_saved_activation_rows(in_dim, hid, out_dim,
     torch.cuda.synchronize()
     vec_close(y.cpu(), y_ref, TOL, "y")
     vec_close(dx.cpu(), dx_ref, TOL, "dx")
-    # the words: unit 16 (NBH w + j) + 4 q + r of row b, layer l <-> bit 4 NBH - 1 - (4 j + r) of masks[l, b, 2 q + w]
-    nbh = hid // 32
-    m = masks.cpu().numpy().astype(np.uint32)
+    # the bits.  Width 64 (half-panel kernels): unit 16 (NBH w + j) + 4 q + r of row b, layer l <-> bit 4 NBH - 1 - (4 j + r)
+    # of the uint32 masks[l, b, 2 q + w]; widths 128 / 256 (quarter-panel kernels): unit 16 (NBQ cq + j) + 4 q + r <-> bit
+    # 4 NBQ - 1 - (4 j + r) of the uint16 at [l, b, q, cq]
     u = np.arange(hid)
     blk, q, r = u // 16, (u % 16) // 4, u % 4
-    w, j = blk // nbh, blk % nbh
-    bit = 4 * nbh - 1 - (4 * j + r)
+    if hid == 64:
+        nbh = hid // 32
+        m = masks.cpu().numpy().astype(np.uint32)
+        w, j = blk // nbh, blk % nbh
+        slot, bit = 2 * q + w, 4 * nbh - 1 - (4 * j + r)
+    else:
+        nbq = hid // 64
+        m = masks.cpu().numpy().view(np.uint16).reshape(2, B, 16).astype(np.uint32)
+        cq, j = blk // nbq, blk % nbq
+        slot, bit = 4 * q + cq, 4 * nbq - 1 - (4 * j + r)
     for l in range(2):
-        got = (m[l][:, 2 * q + w] >> bit) & 1
+        got = (m[l][:, slot] >> bit) & 1
         want = (acts_ref[l].numpy() > 0).astype(np.uint32)
         margin = np.abs(acts_ref[l].numpy())
         bad = (got != want) & (margin > 1e-6)         # (a pre-activation within rounding of zero may land on either side)
