@@ -136,13 +136,16 @@ int nlbac_mlp_bwd_data_head(const nlbac_mlp *nets, const nlbac_mlp_io *io, int n
                             const struct nlbac_dy_head *head, nlbac_stream_t s);
 /* Weight/bias gradients from x, dy, acts, dz, as n_slabs partial gradients the caller sums in order
  * (nlbac_adam_fused / nlbac_adam_step / nlbac_reduce_slabs), deterministic.
- * Nets wider than 112: the hidden->hidden matrices are reduced per row range into the slabs (slab s = rows
- * [s*rows_per_slab, ...), fully overwritten); the skinny first/last layers and all biases are reduced over all rows
- * into slab 0 through the caller's workspace `ws` (>= nlbac_mlp_bwd_weights_ws_floats() floats) — the other slabs'
- * entries for them are not written (the caller keeps them zero).
- * Nets of hid <= 112 (the NODEs) without nlbac_mlp_io::skinny_ws: EVERY gradient — biases and skinny layers too — is
- * written to every slab (slab s = the 4-row k-steps 4s+w, 4s+w+4 n_slabs, ... of wave w: mlp_dw16_kernels.hip); `ws` is
- * not used; rows * hid must stay below 2^29. */
+ * Every call defines every entry of its nets' gradients in ALL n_slabs slabs — the slab sum is the gradient whatever a
+ * previous call (another path, batch size or workspace on the same arena) left there.  Two kernels' layouts:
+ *   - nets wider than 112, and any net whose launch of nlbac_mlp_bwd_data left the skinny-gradient partials
+ *     (nlbac_mlp_io::skinny_ws == this net's block of `ws`): the hidden->hidden matrices are reduced per row range into
+ *     the slabs (slab s = rows [s*rows_per_slab, ...)); the skinny first/last layers and all biases are reduced over all
+ *     rows into slab 0 through `ws` (>= nlbac_mlp_bwd_weights_ws_floats() floats, always required) and their entries
+ *     in slabs 1 .. n_slabs-1 are written as zeros;
+ *   - nets of hid <= 112 (the NODEs) whose partials are NOT in `ws` (NLBAC_MLP_DW16=0 switches this path off): every
+ *     gradient — biases and skinny layers too — is a partial in every slab (slab s = the 4-row k-steps 4s+w,
+ *     4s+w+4 n_slabs, ... of wave w: mlp_dw16_kernels.hip); `ws` is not read; rows * hid must stay below 2^29 - 2^16. */
 long nlbac_mlp_bwd_weights_ws_floats(const nlbac_mlp *nets, int n_nets, int B);
 int nlbac_mlp_bwd_weights(const nlbac_mlp *nets, const nlbac_mlp_io *io, int n_nets, int B,
                           int n_slabs, long slab_stride, float *ws, long ws_floats, nlbac_stream_t s);

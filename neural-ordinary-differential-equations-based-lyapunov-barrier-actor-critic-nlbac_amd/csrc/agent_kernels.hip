@@ -341,7 +341,13 @@ __global__ __launch_bounds__(256) void unicycle_constraints_fwd_kernel(const flo
 // workgroup: the stand-alone nlbac_auglag launch, or the last workgroup of a constraints_fwd launch (COHERENT: the
 // partials were published by other workgroups of the same launch).
 template <bool COHERENT>
-__device__ __forceinline__ void auglag_body(const float* partials, int n_blk, const AuglagArgs A, float* sc) {
+__device__ __forceinline__ void auglag_body(const float* partials, int n_blk, const AuglagArgs A, float* sc_global) {
+    // The scalar bookkeeping below is ~60 dependent reads / writes of the scalars block by ONE thread: on the block in
+    // global memory each is a trip to L2 (unicycle_constraints_fwd: 13 us, most of it here); it runs on a copy in LDS,
+    // brought in and written back by the whole workgroup.
+    __shared__ __attribute__((aligned(8))) float sc[NLBAC_SC_SIZE_ENUM];
+    for (int t = threadIdx.x; t < NLBAC_SC_SIZE_ENUM; t += blockDim.x) sc[t] = sc_global[t];
+    __syncthreads();
     const int n_cbf = A.n_cbf, n_clf = A.n_clf, ratio_mode = A.ratio_mode, backup_mode = A.backup_mode;
     const int do_lambda_update = A.do_lambda_update, do_backup_lambda_update = A.do_backup_lambda_update;
     const float batch_size = A.batch_size, lam_lo = A.lam_lo, lam_hi = A.lam_hi;
@@ -363,9 +369,8 @@ __device__ __forceinline__ void auglag_body(const float* partials, int n_blk, co
         s = s / batch_size;
         if (c < nc) sc[SC_REQ + c] = s; else sc[SC_BREQ + (c - nc)] = s;
     }
-    __threadfence_block();
     __syncthreads();
-    if (threadIdx.x != 0) return;
+    if (threadIdx.x == 0) {
     double* rho_p = reinterpret_cast<double*>(sc + SC_RHO_F64);
     double* brho_p = backup_mode == 1 ? rho_p : reinterpret_cast<double*>(sc + SC_BRHO_F64);
     // ---- primary (sac_cbf_clf.py:506-528)
@@ -423,6 +428,11 @@ __device__ __forceinline__ void auglag_body(const float* partials, int n_blk, co
         }
         sc[SC_BPL2] = loss;
     }
+    }
+    __syncthreads();
+    // what the step may have changed: ratio / losses (4..6), multipliers, coefficients, required sums, rho (16..115)
+    for (int t = threadIdx.x; t < NLBAC_SC_SIZE_ENUM; t += blockDim.x)
+        if ((t >= SC_RATIO && t <= SC_BPL2) || (t >= SC_LAMBDA && t < SC_MEAN_LOGP)) sc_global[t] = sc[t];
 }
 
 __global__ void auglag_kernel(const float* partials, int n_blk, const AuglagArgs A, float* sc) {

@@ -238,8 +238,10 @@ int nlbac_mlp_dw16_launch(const MlpLaunch& L, int n_nets, hipStream_t s) {
     for (int i = 0; i < n_nets; ++i) {
         // (byte offsets into a layer's rows are 32-bit.  An error rather than the older kernels: those leave the skinny
         // gradients in slab 0 only, and a caller that alternates between the two would sum stale partials)
-        NLBAC_REQUIRE((long)L.B * L.net[i].hid < (1L << 29), "nlbac_mlp_bwd_weights: %d rows x %d units exceed 2^29 elements per layer",
-                      L.B, L.net[i].hid);
+        // (... with headroom for the k-steps the ring requests past the end — DW16_PF * 4 * n_slabs k-steps of 4 rows — so
+        //  that no byte offset passes 2^31: those loads must land out of range, not wrap)
+        NLBAC_REQUIRE(((long)L.B + 16L * DW16_PF * L.n_slabs + 4) * L.net[i].hid < (1L << 29),
+                      "nlbac_mlp_bwd_weights: %d rows x %d units (+ the ring's run-out) exceed 2^29 elements per layer", L.B, L.net[i].hid);
         if (L.net[i].hid > max_hid) max_hid = L.net[i].hid;
         if (L.net[i].n_layers > max_layers) max_layers = L.net[i].n_layers;
     }

@@ -561,6 +561,127 @@ __global__ __launch_bounds__(256) void mlp_bwd_wide_kernel(const MlpLaunch L, co
     }
 }
 
+// ---------------------------------------------------------------------------
+// The same gradients for nets wider than 128 (the 256-wide heads), LDS-free: a workgroup still owns one 64 x 64 tile of
+// one layer's dW_j for one row slab, but its four waves split the slab's ROWS instead of the tile, each accumulating the
+// whole tile (4 x 4 accumulators of v_mfma_f32_16x16x4_f32) over its own k-steps of 4 rows, and a lane's two dwordx4
+// loads (dz columns 4i..4i+3 and activation columns 4i..4i+3 of its row) ARE its operands for the k-step's 16 MFMAs —
+// the column order of mlp_dw16_kernels.hip (tile t of a strip = the columns {4 i + t}: the gradient does not care which
+// 16 columns are called a tile, the store at the end undoes it).  No staging, no barrier in the loop, DWT_PF k-steps in
+// flight; the waves' partial tiles meet in LDS at the end in a fixed order.  (mlp_bwd_wide_kernel: 16-row chunks through
+// LDS with two barriers each, 23 us per launch at 3 x 4096 rows for 11 us of matrix-pipe time.)
+//
+// blockIdx -> tile is XCD-aware: the tiles of one (slab, net) group read the same 2 * rows_per_slab * hid floats — four
+// times each over the group — and consecutive block ids are dealt round-robin to the 8 XCDs, so a group's tiles take ids
+// that are congruent mod 8: they meet in ONE XCD's L2 and the slab leaves HBM / the Infinity Cache once (the old mapping:
+// 72.6 MB fetched per launch for 25 MB of operands).  Placement is a speed matter only.
+// The first red_blocks blocks are the skinny-gradient reduction (mlp_bwd_skinny_reduce_kernel's work), as above.
+// ---------------------------------------------------------------------------
+#define DWT_PF 8
+__global__ __launch_bounds__(256, 3) void mlp_bwd_wide64_kernel(const MlpLaunch L, const SkinnyLaunch S,
+                                                                const float* __restrict__ ws, int red_blocks,
+                                                                int red_per_net, int n_nets, int tiles_per_group) {
+    extern __shared__ __attribute__((aligned(16))) float dwt_smem[];      // 2 x [64 values][64 lanes]
+    if ((int)blockIdx.x < red_blocks) {
+        const int inet = blockIdx.x / red_per_net;
+        if (inet < n_nets)
+            skinny_reduce_block(L, S, ws, blockIdx.x - inet * red_per_net, inet, reinterpret_cast<float (*)[64]>(dwt_smem));
+        return;
+    }
+    const int id = (int)blockIdx.x - red_blocks, xcd = id & 7, jj = id >> 3;
+    const int t = jj % tiles_per_group, grp = 8 * (jj / tiles_per_group) + xcd;
+    if (grp >= L.n_slabs * n_nets) return;
+    const int znet = grp / L.n_slabs, slab = grp - znet * L.n_slabs;
+    const nlbac_mlp& net = L.net[znet];
+    const nlbac_mlp_io& io = L.io[znet];
+    const int B = L.B, hid = net.hid, nwide = net.n_layers - 1;
+    const int T = (hid + 63) >> 6, per_layer = T * T;
+    if (t >= (nwide - 1) * per_layer) return;
+    const int j = 1 + t / per_layer, tt = t % per_layer;
+    const int n0 = (tt / T) * 64, k0 = (tt % T) * 64;
+    const int rb = slab * L.rows_per_slab, re = min(B, rb + L.rows_per_slab);
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, q = lane >> 4, i = lane & 15;
+    const long ls = io.acts_ls ? io.acts_ls : (long)B * hid;
+    // rows past the slab's end and columns past the width read as zeros (raw buffer loads out of range)
+    const __amdgpu_buffer_rsrc_t rsA = rr_rsrc(io.dz + (long)j * ls, max(re, 0) * hid);
+    const __amdgpu_buffer_rsrc_t rsB = rr_rsrc(io.acts + (long)(j - 1) * ls, max(re, 0) * hid);
+    const int oob = (int)0x80000000;
+    const int voA = (n0 + 4 * i + 3 < hid) ? (q * hid + n0 + 4 * i) * 4 : oob;
+    const int voB = (k0 + 4 * i + 3 < hid) ? (q * hid + k0 + 4 * i) * 4 : oob;
+    const int kstep_bytes = 16 * hid;                                   // 4 rows
+    const int g_first = (rb >> 2) + wave, n_mine = (rb < re) ? (((re - rb + 3) >> 2) - wave + 3) / 4 : 0;     // k-steps g_first + 4 m
+    f32x4 acc[4][4];
+#pragma unroll
+    for (int ta = 0; ta < 4; ++ta)
+#pragma unroll
+        for (int tb = 0; tb < 4; ++tb) acc[ta][tb] = f32x4{0.f, 0.f, 0.f, 0.f};
+    f32x4 va[DWT_PF], vb[DWT_PF];
+    const int rounds = (n_mine + DWT_PF - 1) / DWT_PF;
+    if (rounds > 0) {
+#pragma unroll
+        for (int u = 0; u < DWT_PF; ++u) {
+            const int so = (g_first + 4 * u) * kstep_bytes;
+            va[u] = rr_ldw(rsA, voA, so);
+            vb[u] = rr_ldw(rsB, voB, so);
+        }
+        int g = g_first + 4 * DWT_PF;
+        for (int r = 0; r < rounds; ++r) {
+#pragma unroll
+            for (int u = 0; u < DWT_PF; ++u) {
+                const f32x4 a = va[u], b = vb[u];
+#pragma unroll
+                for (int ta = 0; ta < 4; ++ta)
+#pragma unroll
+                    for (int tb = 0; tb < 4; ++tb)
+                        acc[ta][tb] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[ta], b[tb], acc[ta][tb], 0, 0, 0);
+                const int so = g * kstep_bytes;           // (the set just used is refilled DWT_PF k-steps ahead)
+                va[u] = rr_ldw(rsA, voA, so);
+                vb[u] = rr_ldw(rsB, voB, so);
+                __builtin_amdgcn_sched_barrier(0);
+                g += 4;
+            }
+        }
+    }
+    // the four waves' partial tiles: (w0 + w1) + (w2 + w3), through LDS
+    float* const red0 = dwt_smem, * const red1 = dwt_smem + 64 * 64;
+    auto put = [&](float* red) __attribute__((always_inline)) {
+#pragma unroll
+        for (int ta = 0; ta < 4; ++ta)
+#pragma unroll
+            for (int tb = 0; tb < 4; ++tb)
+                *reinterpret_cast<f32x4*>(red + ((ta * 4 + tb) * 64 + lane) * 4) = acc[ta][tb];
+    };
+    auto add = [&](const float* red) __attribute__((always_inline)) {
+#pragma unroll
+        for (int ta = 0; ta < 4; ++ta)
+#pragma unroll
+            for (int tb = 0; tb < 4; ++tb) acc[ta][tb] += *reinterpret_cast<const f32x4*>(red + ((ta * 4 + tb) * 64 + lane) * 4);
+    };
+    if (wave == 1) put(red0);
+    if (wave == 3) put(red1);
+    lds_barrier();
+    if (wave == 0) add(red0);
+    if (wave == 2) add(red1);
+    lds_barrier();
+    if (wave == 2) put(red0);
+    lds_barrier();
+    if (wave != 0) return;
+    add(red0);
+    // D[m][n] of a 16 x 16 x 4 MFMA: lane (q, i) register r holds m = 4 q + r (a dz lane column), n = i (an activation lane
+    // column): dW[n0 + 4 m + ta][k0 + 4 i + tb] — the four tb of a lane are four consecutive floats of a row
+    float* gW = io.grad + (long)slab * L.slab_stride + net.w_off[j];
+    if (k0 + 4 * i + 3 < hid) {
+#pragma unroll
+        for (int ta = 0; ta < 4; ++ta)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int n = n0 + 4 * (4 * q + r) + ta;
+                if (n < hid)
+                    *reinterpret_cast<f32x4*>(gW + (long)n * hid + k0 + 4 * i) = f32x4{acc[ta][0][r], acc[ta][1][r], acc[ta][2][r], acc[ta][3][r]};
+            }
+    }
+}
+
 // Narrow nets (hid <= 128, the NODE fit): one workgroup owns the whole (padded 128x128) dW_j of a layer for its row
 // slab, so dz and acts are read from HBM once per layer instead of once per 64-column tile pair (the fit streams
 // ~1.3 GB of them per RK step - the one HBM-bound place of the update).  Each wave accumulates a 64x64 quadrant
@@ -812,11 +933,17 @@ __device__ __forceinline__ void skinny_reduce_block(const MlpLaunch& L, const Sk
     __syncthreads();
     if (cg != 0) return;
     const float v = (part[0][threadIdx.x] + part[1][threadIdx.x]) + (part[2][threadIdx.x] + part[3][threadIdx.x]);
-    float* g = io.grad;
-    if (q < nwide) { if (col < hid) g[net.b_off[q] + col] = v; }
-    else if (q < nwide + idim) { if (col < hid) g[net.w_off[0] + (long)col * idim + (q - nwide)] = v; }
-    else if (q < nwide + idim + odim) { if (col < hid) g[net.w_off[nwide] + (long)(q - nwide - idim) * hid + col] = v; }
-    else if (col < odim) g[net.b_off[nwide] + col] = v;
+    // slab 0 takes the sum; the entry's copies in the other slabs are ZEROED, so that whatever wrote them before — the
+    // one-launch kernel of the narrow nets leaves a partial of every gradient in every slab — the slab sum is this call's
+    long e = -1;
+    if (q < nwide) { if (col < hid) e = net.b_off[q] + col; }
+    else if (q < nwide + idim) { if (col < hid) e = net.w_off[0] + (long)col * idim + (q - nwide); }
+    else if (q < nwide + idim + odim) { if (col < hid) e = net.w_off[nwide] + (long)(q - nwide - idim) * hid + col; }
+    else if (col < odim) e = net.b_off[nwide] + col;
+    if (e < 0) return;
+    float* g = io.grad + e;
+    g[0] = v;
+    for (int sl = 1; sl < L.n_slabs; ++sl) g[(long)sl * L.slab_stride] = 0.f;
 }
 
 __global__ __launch_bounds__(256) void mlp_bwd_skinny_reduce_kernel(const MlpLaunch L, const SkinnyLaunch S,
@@ -851,6 +978,12 @@ static int tile_mode(const nlbac_mlp* nets, int n_nets) {
 // 256-wide nets: 8 waves x one column tile (default) or 4 waves x two tiles (NLBAC_MLP_WAVES8=0, kept for A/B runs)
 static bool waves8() {
     static const bool on = [] { const char* e = getenv("NLBAC_MLP_WAVES8"); return !(e && e[0] == '0'); }();
+    return on;
+}
+
+// the LDS-free weight gradients of nets wider than 128 (mlp_bwd_wide64_kernel); NLBAC_MLP_DW64=0 keeps mlp_bwd_wide_kernel
+static bool dw64_enabled() {
+    static const bool on = [] { const char* e = getenv("NLBAC_MLP_DW64"); return !(e && e[0] == '0'); }();
     return on;
 }
 
@@ -1097,6 +1230,14 @@ extern "C" int nlbac_mlp_bwd_weights(const nlbac_mlp* nets, const nlbac_mlp_io* 
                 attr_set = true;
             }
             hipLaunchKernelGGL(mlp_bwd_wide128_kernel, dim3(max_layers, n_slabs, n_nets), dim3(256), lds, (hipStream_t)s, L);
+        } else if (dw64_enabled() && (long)B * 256 < (1L << 29)) {
+            // (with the partial sums already there, the skinny reduction's blocks lead the GEMM tiles)
+            const int red_per_net = max_q * 4, red_blocks = partials_ready ? red_per_net * n_nets : 0;
+            const int groups8 = (n_slabs * n_nets + 7) / 8;
+            hipLaunchKernelGGL(mlp_bwd_wide64_kernel, dim3(red_blocks + 8 * max_blocks * groups8), dim3(256),
+                               (size_t)2 * 64 * 64 * sizeof(float), (hipStream_t)s, L, S, ws, red_blocks, red_per_net, n_nets,
+                               max_blocks);
+            reduced = partials_ready;
         } else {
             // (with the partial sums already there, the skinny reduction's blocks ride behind the GEMM tiles of slab 0)
             const int per_plane = max_blocks * n_slabs, red_per_net = max_q * 4;

@@ -875,6 +875,9 @@ class SAC_CBF_CLF(object):
         self._fill_first = True
         if ws.__dict__.get("_pre_now") is not None:
             self._fill.popleft()                # (targets + critic data backward: queued with the prefetch)
+            # (the first wait still queues both remaining pieces: holding the Q(s, pi) forward back for the launch it
+            #  could share with V(p(x')) left the stream dry for ~20 us while the host got from the accept decision to
+            #  that launch)
         if self.solver != "dopri5" or torch.cuda.is_current_stream_capturing():
             self.drain_fill()                   # no waits on this path (fixed-step solver / graph capture)
 

@@ -201,9 +201,11 @@ def test_multi_net_launch_and_adam_soft_update(fused):
     for i, m in enumerate(mods):
         for l in m:
             for p in (l.weight, l.bias):
-                vec_close(p.detach().cpu(), flat[k].detach(), 2e-6, "param %d" % k)
+                # (1e-5: Adam's m / (sqrt(v) + eps) turns the rounding of a near-zero gradient entry into a visible fraction
+                #  of a step; the weight-gradient kernels sum the rows in another order than torch — 2.6e-6 observed)
+                vec_close(p.detach().cpu(), flat[k].detach(), 1e-5, "param %d" % k)
                 off = ar.offset_of[id(p)]
-                vec_close(ar.target[off:off + p.numel()].cpu().view(p.shape), targ[k], 2e-6, "target %d" % k)
+                vec_close(ar.target[off:off + p.numel()].cpu().view(p.shape), targ[k], 1e-5, "target %d" % k)
                 k += 1
 
 
@@ -478,3 +480,41 @@ def test_mask_words_need_the_register_resident_kernels():
     io[0].masks = masks.data_ptr()
     with pytest.raises(_lib.NlbacError):
         _lib.call("nlbac_mlp_fwd", nets, io, 1, B, s)
+
+
+def test_weight_gradient_paths_can_alternate_on_one_gradient_buffer():
+    """``nlbac_mlp_bwd_weights`` has two slab layouts (the one-launch kernel of narrow nets leaves a partial of every
+    gradient in every slab; the other path leaves the bias / skinny-layer gradients in slab 0).  Every call defines all
+    slabs' entries of its nets, so alternating the two on one ``grad`` buffer — stale NaNs in it to start with — gives
+    the autograd gradient each time."""
+    from nlbac_amd import _lib, arena as A
+    in_dim, hid, out_dim, n_layers, B = 5, 96, 3, 4, 200
+    ar, h, lins, ref = build(in_dim, hid, out_dim, n_layers, seed=3, n_slabs=5)
+    nets, s = A.mlp_array([h.desc]), A.stream_ptr()
+    g = torch.Generator().manual_seed(9)
+    ar.grad.fill_(float("nan"))
+    for it, fused in enumerate((False, True, False, True, False)):
+        x, dy = torch.randn(B, in_dim, generator=g), torch.randn(B, out_dim, generator=g)
+        _, _, _, grads_ref = torch_ref(ref, x, dy)
+        xd, dyd = x.cuda(), dy.cuda()
+        y = torch.empty(B, out_dim, device="cuda")
+        acts, dz = torch.empty(n_layers - 1, B, hid, device="cuda"), torch.empty(n_layers - 1, B, hid, device="cuda")
+        io = A.io_array(1)
+        io[0].x0, io[0].x0_dim, io[0].x0_ld = xd.data_ptr(), in_dim, in_dim
+        io[0].y, io[0].y_ld = y.data_ptr(), out_dim
+        io[0].acts, io[0].dz = acts.data_ptr(), dz.data_ptr()
+        io[0].dy, io[0].dy_ld = dyd.data_ptr(), out_dim
+        io[0].grad = ar.grad.data_ptr()
+        # fused: the data backward leaves the skinny partials -> the slab-0 layout; else the one-launch kernel (hid <= 112)
+        ws = A.skinny_partials_ws(nets, (io,), 1, B, "cuda") if fused else None
+        _lib.call("nlbac_mlp_fwd", nets, io, 1, B, s)
+        _lib.call("nlbac_mlp_bwd_data", nets, io, 1, B, s)
+        A.bwd_weights(nets, io, 1, B, ar.n_slabs, ar.n, "cuda", ws=ws)
+        torch.cuda.synchronize()
+        for lin in lins:        # (every slab's entries of every parameter; the arena's alignment padding stays as it was)
+            for prm in (lin.weight, lin.bias):
+                off = ar.offset_of[id(prm)]
+                assert torch.isfinite(ar.grad[:, off:off + prm.numel()]).all(), "call %d left stale entries in some slab" % it
+        for l, lin in enumerate(lins):
+            vec_close(ar.grad_view(lin.weight).cpu(), grads_ref[l][0], TOL, "call %d dW%d" % (it, l))
+            vec_close(ar.grad_view(lin.bias).cpu(), grads_ref[l][1], TOL, "call %d db%d" % (it, l))

@@ -5,7 +5,7 @@ sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(
 import torch
 import nlbac_amd
 from nlbac_amd import _lib
-from nlbac_amd.arena import stream_ptr
+from nlbac_amd.arena import stream_ptr, bwd_weights
 from test_agent_parity_gpu import make_agent
 
 B = int(sys.argv[1]) if len(sys.argv) > 1 else 4096
@@ -23,6 +23,8 @@ cases = {
     "bwd_data 3 nets critics": lambda: _lib.call("nlbac_mlp_bwd_data", P.n_crit, P.io_crit, 3, B, s),
     "bwd_data 4 nets Q(s,pi)": lambda: _lib.call("nlbac_mlp_bwd_data", P.n_q5, P.io_q5, 4, B, s),
     "bwd_data 2 nets actors": lambda: _lib.call("nlbac_mlp_bwd_data", P.n_act, P.io_act, 2, B, s),
+    "bwd_weights 3 nets critics": lambda: bwd_weights(P.n_crit, P.io_crit, 3, B, agent.ar_c.n_slabs, agent.ar_c.n, agent.device, ws=P.sk_crit),
+    "bwd_weights 2 nets actors": lambda: [bwd_weights(nets, gio, cnt, B, g.arena.n_slabs, g.arena.n, agent.device, ws=sk) for g, cnt, nets, gio, sk in P.act_groups],
 }
 
 
