@@ -47,7 +47,8 @@ def test_ctypes_structs_match_header_sizes(lib):
     net.n_layers, net.in_dim, net.hid, net.out_dim = 3, 9, 256, 1
     n = lib.nlbac_mlp_pack_layout(_lib.C.byref(net))
     # layer0 fwd: 8 tiles x 2 chunks ; layer1 fwd: 8 x 32 ; layer1 bwd: 8 x 32  (x256 floats)
-    assert n == (8 * 2 + 8 * 32 + 8 * 32) * 256 + 2 * 256 * 256 + 4 * 16 * 64      # (+ layer 0's fragments)
+    # (+ three fragment blocks behind the panels: layer 0 forward, last layer and layer 0 transposed for the data backward)
+    assert n == (8 * 2 + 8 * 32 + 8 * 32) * 256 + 2 * 256 * 256 + 3 * 4 * 16 * 64
     assert net.pf_off[0] == 0 and net.pb_off[0] == -1 and net.pb_off[1] > net.pf_off[1] > 0
     # ... and, having ONE hid x hid layer of a width divisible by 32, the two panel packs of it (hid^2 floats each)
     old = (8 * 2 + 8 * 32 + 8 * 32) * 256
@@ -90,7 +91,7 @@ def test_every_ctypes_struct_of_the_binding_matches_the_header(tmp_path):
     import ctypes as C
     import subprocess
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    pairs = [("nlbac_mlp", _lib.Mlp, None), ("nlbac_mlp_io", _lib.MlpIO, "skinny_ws"),
+    pairs = [("nlbac_mlp", _lib.Mlp, None), ("nlbac_mlp_io", _lib.MlpIO, "masks"),
              ("nlbac_auglag_args", _lib.AuglagArgs, "lam_hi"), ("nlbac_actor_scalar_args", _lib.ActorScalarArgs, "sc"),
              ("nlbac_rk_chain", _lib.RkChain, "ctl_host"), ("nlbac_in_map", _lib.InMap, "ps"),
              ("nlbac_out_map", _lib.OutMap, "x"), ("nlbac_gauss_head", _lib.GaussHead, "logp"),
