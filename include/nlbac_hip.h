@@ -237,8 +237,9 @@ int nlbac_actor_q_terms(const float *q1, const float *q2, const float *logp, con
  *   kind 3  nlbac_actor_q_terms     net i = (controller i / 2, Q1 / Q2 = i % 2) for i < 2 n_prob, nets behind them take
  *                                   io[i].dy as in nlbac_mlp_bwd_data (an independent backward sharing the launch);
  *                                   + nlbac_actor_scalars via `actor`
- * partials: n_nets * n_tiles (kind 2) / 2 * n_prob * n_tiles (kind 3) floats, n_tiles = ceil(B / 16) (the finest tile of the kernels that serve the launch); ticket: a zeroed
- * uint32, left zeroed. */
+ * partials: n_nets * n_tiles (kind 2) / 2 * n_prob * n_tiles (kind 3) floats, n_tiles = ceil(B / 16) (the finest tile
+ * of the kernels that serve the launch); ticket: 1 + ceil(n / 16) zeroed uint32 for the n = n_nets * n_tiles (kind 2) /
+ * n_prob * n_tiles (kind 3) workgroups that take part in the two-level election, left zeroed. */
 typedef struct nlbac_dy_head {
     int kind, B_norm;
     /* 1 */

@@ -73,6 +73,9 @@ __global__ __launch_bounds__(256) void elect_selftest_kernel(float* partials, un
     if (n_vals == 4) {
         float v4[4] = {v[0], v[1], v[2], v[3]};
         elected = publish_and_elect<4>(partials + (long)b * 4, v4, ticket, gridDim.x);
+    } else if (n_vals == 2) {      // the two-level election of the dy heads (ticket: 1 + ceil(n_blocks / 16) words)
+        float v2[2] = {v[0], v[1]};
+        elected = publish_and_elect_grouped<2>(partials + (long)b * 2, v2, ticket, b, gridDim.x);
     } else {
         __shared__ float sv[64];
         if (threadIdx.x == 0)

@@ -107,6 +107,48 @@ __device__ __forceinline__ bool publish_and_elect(float* dst, const float (&vals
 __device__ __forceinline__ void lds_barrier() {
     asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
 }
+// The same election for launches of many workgroups: ONE ticket word takes ~88 atomics per microsecond, so the 768
+// workgroups of a three-net quarter-panel launch that all finish together queued ~9 us at it (mlp_rrq_bwd with the TD
+// head: 31 us in the update against 21 with plain dy).  Two levels: workgroup b takes a ticket of its group's word
+// (ELECT_GROUP consecutive indices share one), the last of a group takes one of the top word, the last there is elected.
+// tickets: 1 + ceil(n_blocks / ELECT_GROUP) zeroed words (left zero again).  Ordering: as above, level by level — a
+// group's last ticket is drawn after every member's exchanges were performed, the top word's last after every group's.
+#define ELECT_GROUP 16
+template <int N>
+__device__ __forceinline__ bool publish_and_elect_grouped(float* dst, const float (&vals)[N], unsigned* tickets, unsigned index,
+                                                          unsigned n_blocks) {
+    __shared__ unsigned s_elect_g_;
+    if (threadIdx.x < 64) {
+        float mine = 0.f;
+#pragma unroll
+        for (int k = 0; k < N; ++k) {
+            const float bk = __shfl(vals[k], 0, 64);
+            if ((int)threadIdx.x == k) mine = bk;
+        }
+        float old = 0.f;
+        if ((int)threadIdx.x < N) old = __hip_atomic_exchange(dst + threadIdx.x, mine, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        asm volatile("" ::"v"(old) : "memory");        // every exchange has returned before the ticket is taken
+        elect_release_();
+        if (threadIdx.x == 0) {
+            const unsigned grp = index / ELECT_GROUP, n_groups = (n_blocks + ELECT_GROUP - 1) / ELECT_GROUP;
+            const unsigned in_group = min((unsigned)ELECT_GROUP, n_blocks - grp * ELECT_GROUP);
+            unsigned elected = 0u;
+            const unsigned t1 = __hip_atomic_fetch_add(tickets + 1 + grp, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if (t1 == in_group - 1u) {
+                __hip_atomic_store(tickets + 1 + grp, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                const unsigned t2 = __hip_atomic_fetch_add(tickets, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                if (t2 == n_groups - 1u) {
+                    __hip_atomic_store(tickets, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    elected = 1u;
+                }
+            }
+            s_elect_g_ = elected;
+        }
+    }
+    __syncthreads();
+    if (s_elect_g_ != 0u) elect_acquire_();
+    return s_elect_g_ != 0u;
+}
 __device__ __forceinline__ float coherent_load(const float* p) {
     return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }

@@ -193,7 +193,8 @@ __device__ __forceinline__ void dy_head_finish(const nlbac_dy_head& H, int inet,
         // every net's workgroup publishes its own squared-error sum of the tile; the last of the n_nets * n_tiles
         // workgroups finishes the losses
         const float v1[1] = {pend.v0};
-        if (publish_and_elect<1>(H.partials + (long)tile * n_nets + inet, v1, H.ticket, (unsigned)(n_nets * n_tiles))) {
+        if (publish_and_elect_grouped<1>(H.partials + (long)tile * n_nets + inet, v1, H.ticket, (unsigned)(tile * n_nets + inet),
+                                         (unsigned)(n_nets * n_tiles))) {
             float s[3];
             elected_tile_sums<3>(H.partials, n_tiles, n_nets, s, red);
             if (tid < 3) H.out[tid] = s[tid] * H.mul;
@@ -209,7 +210,8 @@ __device__ __forceinline__ void dy_head_finish(const nlbac_dy_head& H, int inet,
         const int p = inet >> 1, which = inet & 1, n_prob = H.n_prob;
         if (which == 0) {
             const float v2[2] = {pend.v0, pend.v1};
-            if (publish_and_elect<2>(H.partials + ((long)p * n_tiles + tile) * 2, v2, H.ticket, (unsigned)(n_prob * n_tiles))) {
+            if (publish_and_elect_grouped<2>(H.partials + ((long)p * n_tiles + tile) * 2, v2, H.ticket, (unsigned)(p * n_tiles + tile),
+                                             (unsigned)(n_prob * n_tiles))) {
                 for (int pp = 0; pp < n_prob; ++pp) {
                     float s[2];
                     elected_tile_sums<2>(H.partials + (long)pp * n_tiles * 2, n_tiles, 2, s, red);

@@ -38,12 +38,20 @@ __device__ __forceinline__ int rr_out_row(int grp, int hu, int ns, int nu) {
 
 #define RR_MAX_W 4        /* layer 0 + up to three hid x hid layers (n_layers <= 5: the reference's f_net) */
 
-template <int NB, int R, int BITS>
+// SPLIT: f_net has one hid x hid layer more than g_net (U/sac_cbf_clf/model.py:186-206), so its waves ran ~175 MFMAs per
+// stage longer and g_net's waited a quarter of every stage at the stage barrier.  With SPLIT the g_net wave of each half
+// tile takes over the upper groups of output blocks of f_net's LAST hid x hid layer: the f_net wave hands its layer-2
+// activations over through LDS (behind a flag only the two waves touch), both compute their blocks and their part of
+// f_net's output layer, and the two partial outputs meet in the stage's k = f + g u step.
+template <int NB, int R, int BITS, int SPLIT>
 __global__ __launch_bounds__(256) void node_rr_fwd_kernel(const NodeRkLaunch L) {
     using S = RRShape<NB, R>;
     constexpr int KS = S::KS, HID = S::HID;
     constexpr int TB = NB - 2;                 // first block of a layer's last group, the "tail": its accumulators are
     constexpr int NT = KS - 4 * TB;            // finished inside the NEXT product (NT values: 5 at hid 100, else 8)
+    constexpr int MF = rr_split_m<S>();        // (SPLIT) f_net's last layer: MFMAs [0, MF) stay with its wave, [MF, NM) go
+    using PF = RRPart<S, 0, MF>;
+    using PG = RRPart<S, MF, S::NM>;
     extern __shared__ __attribute__((aligned(16))) float smem[];
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -56,6 +64,11 @@ __global__ __launch_bounds__(256) void node_rr_fwd_kernel(const NodeRkLaunch L) 
     T.carve(smem);
     float* const sYin = smem + RkFwdTile::floats();      // [32][8] the stage input, columns ns..7 zero
     float* const sW0 = sYin + NLBAC_MLP_TILE * 8;        // [net][k-step < 3][block < 8][lane]: layer 0's A fragments
+    // (SPLIT) the hand-over between a half tile's f_net and g_net waves
+    float* const sX = sW0 + 2 * 3 * 8 * 64;              // [half][KS][lane] f_net's layer-2 activations
+    float* const sF2 = sX + 2 * KS * 64;                 // [32][8] the g_net wave's part of f(x)
+    unsigned* const sMw = reinterpret_cast<unsigned*>(sF2 + NLBAC_MLP_TILE * RK_MAX_NS);      // [half][f, g][lane] mask-word parts
+    int* const sFlag = reinterpret_cast<int*>(sMw + 2 * 2 * 64);                               // [half] stage + 1 once sX is there
     const nlbac_mlp& net = L.net[grp];
     const int nw = net.n_layers - 1;                     // layer 0 + (nw - 1) hid x hid layers, then the output layer
     const int n_rows = min(NLBAC_MLP_TILE, n - row0);
@@ -122,6 +135,31 @@ __global__ __launch_bounds__(256) void node_rr_fwd_kernel(const NodeRkLaunch L) 
         }
     }
 
+    // (SPLIT) what the g_net wave needs of f_net: its pack, its last layer's bias, its output layer's A fragments for the
+    // k-steps the wave's blocks yield, the output slots (f_net's mapping of o_idx above)
+    const nlbac_mlp& netF = L.net[0];
+    const __amdgpu_buffer_rsrc_t rsF = rr_rsrc(netF.packed, netF.packed_floats);
+    const int curF3 = netF.rr_fwd_off * 4 + 2 * S::LAYER_BYTES;          // byte offset of f_net's layer-3 stream
+    float wof[KS];
+    int of_idx[4];
+    if constexpr (SPLIT != 0) {
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks) wof[ks] = 0.f;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) { const int c = 4 * r + q; of_idx[r] = (r < KS0 && c < ns) ? c : -1; }
+        if (grp == 1) {
+            const int orow = rr_out_row(0, r16, ns, nu);
+            const float* wrow = netF.params + netF.w_off[4] + (long)max(orow, 0) * HID;
+#pragma unroll
+            for (int jo = PG::J0; jo < NB; ++jo) {
+                const f32x4 v = rr_row_load<S>(wrow, jo, q);
+#pragma unroll
+                for (int r = 0; r < ((jo < NB - 1) ? 4 : R); ++r) wof[4 * jo + r] = (orow >= 0) ? v[r] : 0.f;
+            }
+        }
+        if (tid < 2) sFlag[tid] = 0;
+    }
+
     RSTAMP(0)
     rk_fwd_tile_constants<256>(L, w, T, row0, tid);
     RSTAMP(1)
@@ -154,6 +192,12 @@ __global__ __launch_bounds__(256) void node_rr_fwd_kernel(const NodeRkLaunch L) 
             for (int jo = 0; jo < G0; ++jo) bpre[jo] = rr_bias<S>(params + boff[l], jo, q);
         };
         prefetch_bias(1);
+        // (SPLIT) both waves' queues for their ranges of f_net's last layer: requested now, consumed two layers later
+        PF partF; PG partG;
+        if constexpr (SPLIT != 0) {
+            if (grp == 0) partF.prime(rs, voff, curF3);
+            else partG.prime(rsF, voff, curF3);
+        }
 
         // what the backward needs of a finished value goes out once: a mask bit (word per layer), or the activation itself
         // (activation mode) a finished layer's activations leave in ONE burst, issued where the product that consumes
@@ -238,7 +282,8 @@ __global__ __launch_bounds__(256) void node_rr_fwd_kernel(const NodeRkLaunch L) 
             for (int jo = 0; jo < NB; ++jo) bv[jo] = (jo < G0) ? bpre[jo] : rr_bias<S>(params + boff[l], jo, q);
             __builtin_amdgcn_sched_barrier(0);
             const int cur = wbase + (l - 1) * S::LAYER_BYTES;
-            const int nxt = (l + 1 < nw) ? cur + S::LAYER_BYTES : wbase;
+            // (SPLIT: f_net's layer 3 has queues of its own — behind layer 2 the main stream goes on with the next stage)
+            const int nxt = (l + 1 < nw && !(SPLIT != 0 && grp == 0 && l == 2)) ? cur + S::LAYER_BYTES : wbase;
             gemm.run(acc, bv, Hin, rs, voff, cur, nxt,
                      [&](int ks) __attribute__((always_inline)) {
                          if (l == 1) pre_l0(ks);
@@ -277,8 +322,83 @@ __global__ __launch_bounds__(256) void node_rr_fwd_kernel(const NodeRkLaunch L) 
         // path per depth: a third, for two-layer nets, cost 26 more VGPRs and accumulator-file spills in all of them.)
         wide(I1{}, Ha, Hb);
         wide(I2{}, Hb, Ha);
-        if (grp == 0) { wide(I3{}, Ha, Hb); outl(I4{}, Hb); }
-        else outl(I3{}, Ha);
+        if constexpr (SPLIT == 0) {
+            if (grp == 0) { wide(I3{}, Ha, Hb); outl(I4{}, Hb); }
+            else outl(I3{}, Ha);
+        } else {
+            // one part of f_net's output layer over the k-steps [K0, K1) of the wave's blocks -> LDS (the f_net wave's with
+            // the bias, into sF; the g_net wave's into sF2)
+            auto out_part = [&](const f32x4& o, float* dst, bool with_bias) __attribute__((always_inline)) {
+#pragma unroll
+                for (int r = 0; r < 4; ++r)
+                    if (of_idx[r] >= 0) dst[m * RK_MAX_NS + of_idx[r]] = with_bias ? o[r] + o_bias[r] : o[r];
+            };
+            auto save_rows = [&](int l, const float (&H)[KS], int j0, int j1) __attribute__((always_inline)) {
+                float* const actsF = L.acts[0] ? L.acts[0] + w.soff : nullptr;
+                if (BITS || !actsF || !row_ok) return;
+                float* rowp = actsF + (long)l * L.acts_ls[0] + srow * HID;
+#pragma unroll
+                for (int jo = 0; jo < NB; ++jo) {
+                    if (jo < j0 || jo >= j1) continue;
+                    f32x4 hv{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                    for (int rr = 0; rr < ((jo < NB - 1) ? 4 : R); ++rr) hv[rr] = H[4 * jo + rr];
+                    rr_row_store<S>(rowp, jo, q, hv);
+                }
+            };
+            unsigned wp = 0u;                  // this wave's part of layer 3's mask word
+            if (grp == 0) {
+                // layer 2 is finished now (its tail is not deferred: the g_net wave waits for ALL of it), handed over, then
+                // the blocks [0, PF::J1) of layer 3 and their part of the output layer
+#pragma unroll
+                for (int t = 0; t < NT; ++t) pre_tail(2, Ha, t);
+#pragma unroll
+                for (int ks = 0; ks < KS; ++ks) sX[(half * KS + ks) * 64 + lane] = Ha[ks];
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                __hip_atomic_store(sFlag + half, st + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+#pragma unroll
+                for (int jo = 0; jo < NB; ++jo) bv[jo] = rr_bias<S>(params + boff[3], jo, q);
+                auto fin3 = [&](int jo, int r) __attribute__((always_inline)) {
+                    const float h = rr_relu(acc[jo][r]);
+                    Hb[4 * jo + r] = h;
+                    if (BITS) rr_mask_push(wp, h);
+                };
+                partF.run(acc, bv, Ha, rs, voff, curF3, [&](int) __attribute__((always_inline)) {}, fin3);
+                RSTAMP(sb + 4)
+                save_layer(2, Ha);
+                const f32x4 o = PF::block(wo, Hb, [&](int ks) __attribute__((always_inline)) {
+                    if (ks >= 4 * PF::JT) fin3(PF::JT + ((ks - 4 * PF::JT) >> 2), (ks - 4 * PF::JT) & 3);
+                });
+                save_rows(3, Hb, 0, PF::J1);
+                out_part(o, T.sF, true);
+                if (BITS) sMw[(half * 2 + 0) * 64 + lane] = wp << (KS - PF::K1);
+            } else {
+                outl(I3{}, Ha);
+                // f_net's layer-2 activations of the same rows, once its wave has put them there
+                while (__hip_atomic_load(sFlag + half, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) != st + 1) __builtin_amdgcn_s_sleep(1);
+                asm volatile("" ::: "memory");
+#pragma unroll
+                for (int ks = 0; ks < KS; ++ks) Hb[ks] = sX[(half * KS + ks) * 64 + lane];
+                RSTAMP(sb + 4)
+#pragma unroll
+                for (int jo = 0; jo < NB; ++jo) bv[jo] = (jo >= PG::J0) ? rr_bias<S>(netF.params + netF.b_off[3], jo, q) : f32x4{0.f, 0.f, 0.f, 0.f};
+                auto fin3 = [&](int jo, int r) __attribute__((always_inline)) {
+                    const float h = rr_relu(acc[jo][r]);
+                    Ha[4 * jo + r] = h;
+                    if (BITS) rr_mask_push(wp, h);
+                };
+                partG.run(acc, bv, Hb, rsF, voff, curF3, [&](int) __attribute__((always_inline)) {}, fin3);
+                const f32x4 o = PG::block(wof, Ha, [&](int ks) __attribute__((always_inline)) {
+                    if (ks >= 4 * PG::JT) {
+                        const int t = ks - 4 * PG::JT, jo = PG::JT + (t >> 2), r = t & 3;
+                        if (jo < NB - 1 || r < R) fin3(jo, r);
+                    }
+                });
+                save_rows(3, Ha, PG::J0, NB);
+                out_part(o, sF2, false);
+                if (BITS) sMw[(half * 2 + 1) * 64 + lane] = wp;
+            }
+        }
         RSTAMP(sb + 5)
         __syncthreads();
         RSTAMP(sb + 6)
@@ -289,6 +409,7 @@ __global__ __launch_bounds__(256) void node_rr_fwd_kernel(const NodeRkLaunch L) 
             const int mm = tid >> 3, c = tid & 7;
             const bool more = st + 1 < stage_end, cv = c < ns, rv = row0 + mm < n;
             float a = T.sF[mm * RK_MAX_NS + c];
+            if constexpr (SPLIT != 0) a += sF2[mm * RK_MAX_NS + c];
             float gv[RK_MAX_NU], uv[RK_MAX_NU], kj[RK_MAX_STAGES - 1];
 #pragma unroll
             for (int u = 0; u < RK_MAX_NU; ++u) {
@@ -322,6 +443,11 @@ __global__ __launch_bounds__(256) void node_rr_fwd_kernel(const NodeRkLaunch L) 
             }
             if (more) sYin[mm * 8 + c] = cv ? y : 0.f;
         }
+        if constexpr (SPLIT != 0 && BITS != 0) {      // layer 3's mask word: the two waves' parts, stored by the f_net wave
+            if (grp == 0 && L.acts[0] && row_ok)
+                reinterpret_cast<unsigned*>(L.acts[0] + w.soff + 3 * L.acts_ls[0])[srow * 4 + q] =
+                    sMw[(half * 2 + 0) * 64 + lane] | sMw[(half * 2 + 1) * 64 + lane];
+        }
         __syncthreads();
         RSTAMP(sb + 7)
     }
@@ -336,10 +462,16 @@ __global__ __launch_bounds__(256) void node_rr_fwd_kernel(const NodeRkLaunch L) 
 // operand of one transposed block product, then dz_{l-1} = mask_{l-1} * (W_l^T dz_l) down the chain in registers (the
 // backward RR pack), then dX = W_0^T dz_0; the two nets meet in the stage algebra (rk_bwd_stage_algebra).
 // ---------------------------------------------------------------------------------------------------------------------
-template <int NB, int R, int BITS>
+// SPLIT (see the forward): f_net's chain has one product more than g_net's — its FIRST, dz_2 = mask_2 * (W_3^T dz_3).  The
+// g_net wave of the half tile computes the lower groups of output blocks of that product before its own chain starts
+// (dz_3 comes over through LDS behind a flag, the blocks go back the same way), the f_net wave the upper groups.
+template <int NB, int R, int BITS, int SPLIT>
 __global__ __launch_bounds__(256) void node_rr_bwd_kernel(const NodeRkBwdLaunch L) {
     using S = RRShape<NB, R>;
     constexpr int KS = S::KS, HID = S::HID, TB = NB - 2, NT = KS - 4 * TB;
+    constexpr int MB = rr_split_m<S>();        // (SPLIT) f_net's first product: MFMAs [0, MB) go to the g_net wave
+    using PG = RRPart<S, 0, MB>;
+    using PF = RRPart<S, MB, S::NM>;
     extern __shared__ __attribute__((aligned(16))) float smem[];
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -351,6 +483,10 @@ __global__ __launch_bounds__(256) void node_rr_bwd_kernel(const NodeRkBwdLaunch 
     RkBwdTile T;
     T.carve(smem);
     float* const sWt = smem + RkBwdTile::floats();       // [net][k-step < 4][block < 8][lane]: W_out^T's A fragments
+    // (SPLIT) the hand-over between a half tile's f_net and g_net waves
+    float* const sX = sWt + 2 * 4 * 8 * 64;              // [half][KS][lane] f_net's dz_3
+    float* const sX2 = sX + 2 * KS * 64;                 // [half][PG::K1][lane] the g_net wave's blocks of dz_2
+    int* const sFlag = reinterpret_cast<int*>(sX2 + 2 * 16 * 64);      // [2][half]: sX / sX2 are there for stage key
     const nlbac_mlp& net = L.net[grp];
     const int nw = net.n_layers - 1;
     const int q = lane >> 4, r16 = lane & 15;
@@ -373,7 +509,13 @@ __global__ __launch_bounds__(256) void node_rr_bwd_kernel(const NodeRkBwdLaunch 
     const int voff = lane * 16;
     const int wbase = net.rr_bwd_off * 4;
     RRGemm<S> gemm;
-    gemm.prime(rs, voff, wbase + (nw - 2) * S::LAYER_BYTES);
+    // (SPLIT: f_net's first product has queues of its own — its main stream starts with the second)
+    const int first_l = (SPLIT != 0 && grp == 0) ? nw - 3 : nw - 2;
+    gemm.prime(rs, voff, wbase + first_l * S::LAYER_BYTES);
+    const nlbac_mlp& netF = L.net[0];
+    const __amdgpu_buffer_rsrc_t rsF = rr_rsrc(netF.packed, netF.packed_floats);
+    const int curB3 = netF.rr_bwd_off * 4 + 2 * S::LAYER_BYTES;          // byte offset of W_3^T's stream (f_net)
+    if (SPLIT != 0 && tid < 4) sFlag[tid] = 0;
 
     // ---- constants: W_out^T (A of the top product) to LDS in fragment order, W_0^T (A of dX) into registers
     if (half == 0) {
@@ -552,7 +694,7 @@ __global__ __launch_bounds__(256) void node_rr_bwd_kernel(const NodeRkBwdLaunch 
             if (BITS) fetch_masks(lo, avC);
             __builtin_amdgcn_sched_barrier(0);
             const int cur = wbase + lo * S::LAYER_BYTES;              // fragments of layer lo + 1 sit at index lo
-            const int nxt = (lo >= 1) ? cur - S::LAYER_BYTES : wbase + (nw - 2) * S::LAYER_BYTES;
+            const int nxt = (lo >= 1) ? cur - S::LAYER_BYTES : wbase + first_l * S::LAYER_BYTES;
             gemm.run(acc, zero, Zin, rs, voff, cur, nxt,
                      [&](int ks) __attribute__((always_inline)) {
                          if (p == 1) { if (defer_top) pre_top(ks); }
@@ -583,10 +725,82 @@ __global__ __launch_bounds__(256) void node_rr_bwd_kernel(const NodeRkBwdLaunch 
         };
         using I1 = std::integral_constant<int, 1>; using I2 = std::integral_constant<int, 2>;
         using I3 = std::integral_constant<int, 3>;
-        prod(I1{}, Za, Zb, avB, avA);                         // (f_net: three hid x hid layers, g_net: two — see the forward)
-        prod(I2{}, Zb, Za, avA, avB);
-        if (grp == 0) { prod(I3{}, Za, Zb, avB, avA); dxl(Zb); }
-        else dxl(Za);
+        if constexpr (SPLIT == 0) {
+            prod(I1{}, Za, Zb, avB, avA);                     // (f_net: three hid x hid layers, g_net: two — see the forward)
+            prod(I2{}, Zb, Za, avA, avB);
+            if (grp == 0) { prod(I3{}, Za, Zb, avB, avA); dxl(Zb); }
+            else dxl(Za);
+        } else {
+            const int key = L.st_hi - st;                     // (1, 2, ...: what the flags count)
+            const float* const actsF = L.acts[0] + w.soff;
+            if (grp == 0) {
+                // dz_3 complete (the top product is not deferred here), handed over; then the upper groups of dz_2's blocks
+                if (defer_top) {
+                    mwt = mw;
+#pragma unroll
+                    for (int ks = 0; ks < KS; ++ks) pre_top(ks);
+                }
+#pragma unroll
+                for (int ks = 0; ks < KS; ++ks) sX[(half * KS + ks) * 64 + lane] = Za[ks];
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                __hip_atomic_store(sFlag + half, key, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                PF partF;
+                partF.prime(rs, voff, curB3);
+                if (BITS) fetch_masks(2, avB);                // (activation mode: layer 2's rows are in avB already)
+                partF.run(acc, zero, Za, rs, voff, curB3, [&](int) __attribute__((always_inline)) {},
+                          [&](int jo, int r) __attribute__((always_inline)) {
+                              if (BITS) Zb[4 * jo + r] = rr_mask_gate<KS>(mw, 4 * jo + r, acc[jo][r]);
+                              else Zb[4 * jo + r] = (row_ok && avB[jo][r] > 0.f) ? acc[jo][r] : 0.f;
+                          });
+                save_dz(3, Za);
+                if (!BITS) fetch_masks(1, avA);
+                avt[0] = avB[TB]; avt[1] = avB[TB + 1];
+                // the lower blocks, from the g_net wave
+                while (__hip_atomic_load(sFlag + 2 + half, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) != key) __builtin_amdgcn_s_sleep(1);
+                asm volatile("" ::: "memory");
+#pragma unroll
+                for (int k = 0; k < PG::K1; ++k) Zb[k] = sX2[(half * 16 + k) * 64 + lane];
+                prod(I2{}, Zb, Za, avA, avB);
+                prod(I3{}, Za, Zb, avB, avA);
+                dxl(Zb);
+            } else {
+                // the lower groups of blocks of f_net's dz_2 for the same rows, before this wave's own chain
+                unsigned mwF = 0u;
+                f32x4 avF[PG::J1];
+                if (BITS) {
+                    mwF = reinterpret_cast<const unsigned*>(actsF + 2 * L.acts_ls[0])[srow * 4 + q];
+                    mwF = row_ok ? mwF : 0u;
+                } else {
+                    const float* arow = actsF + 2 * L.acts_ls[0] + srow * HID;
+#pragma unroll
+                    for (int jo = 0; jo < PG::J1; ++jo) avF[jo] = rr_row_load<S>(arow, jo, q);
+                }
+                PG partG;
+                partG.prime(rsF, voff, curB3);
+                while (__hip_atomic_load(sFlag + half, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) != key) __builtin_amdgcn_s_sleep(1);
+                asm volatile("" ::: "memory");
+#pragma unroll
+                for (int ks = 0; ks < KS; ++ks) Zb[ks] = sX[(half * KS + ks) * 64 + lane];
+                partG.run(acc, zero, Zb, rsF, voff, curB3, [&](int) __attribute__((always_inline)) {},
+                          [&](int, int) __attribute__((always_inline)) {});
+                // (all of the range's blocks are still pending when it is a single group; with two groups the first was
+                //  never finished by a hook either: every block is gated here)
+#pragma unroll
+                for (int jo = 0; jo < PG::J1; ++jo)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        float v;
+                        if (BITS) v = rr_mask_gate<KS>(mwF, 4 * jo + r, acc[jo][r]);
+                        else v = (row_ok && avF[jo][r] > 0.f) ? acc[jo][r] : 0.f;
+                        sX2[(half * 16 + 4 * jo + r) * 64 + lane] = v;
+                    }
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                __hip_atomic_store(sFlag + 2 + half, key, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                prod(I1{}, Za, Zb, avB, avA);
+                prod(I2{}, Zb, Za, avA, avB);
+                dxl(Za);
+            }
+        }
         if (skip_dx) continue;
         __syncthreads();
         // ---- stage algebra (rk_bwd_stage_algebra's arithmetic): dY = [dYup at the last stage] + dX_f + dX_g; dy0 += dY;
@@ -654,15 +868,25 @@ extern "C" int nlbac_node_rk_mask_words(const nlbac_mlp* f, const nlbac_mlp* g, 
     return (net->hid + 31) >> 5;
 }
 
+// the f_net / g_net wave balance (SPLIT, see the kernels); NLBAC_NODE_SPLIT=0 keeps one net per wave
+static bool rr_split() {
+    static const bool on = [] { const char* e = getenv("NLBAC_NODE_SPLIT"); return !(e && e[0] == '0'); }();
+    return on;
+}
+
 int nlbac_node_rr_fwd_launch(NodeRkLaunch& L, hipStream_t s) {
     if (!nlbac_node_rr_eligible(&L.net[0], &L.net[1])) return 1;
     using KernelF = void (*)(const NodeRkLaunch);
-    static const KernelF kf[3][2] = {{node_rr_fwd_kernel<4, 4, 0>, node_rr_fwd_kernel<4, 4, 1>},
-                                     {node_rr_fwd_kernel<7, 1, 0>, node_rr_fwd_kernel<7, 1, 1>},
-                                     {node_rr_fwd_kernel<8, 4, 0>, node_rr_fwd_kernel<8, 4, 1>}};
-    const size_t lds = (size_t)(RkFwdTile::floats() + NLBAC_MLP_TILE * 8 + 2 * 3 * 8 * 64) * sizeof(float);
+    static const KernelF kf[2][3][2] = {{{node_rr_fwd_kernel<4, 4, 0, 0>, node_rr_fwd_kernel<4, 4, 1, 0>},
+                                         {node_rr_fwd_kernel<7, 1, 0, 0>, node_rr_fwd_kernel<7, 1, 1, 0>},
+                                         {node_rr_fwd_kernel<8, 4, 0, 0>, node_rr_fwd_kernel<8, 4, 1, 0>}},
+                                        {{node_rr_fwd_kernel<4, 4, 0, 1>, node_rr_fwd_kernel<4, 4, 1, 1>},
+                                         {node_rr_fwd_kernel<7, 1, 0, 1>, node_rr_fwd_kernel<7, 1, 1, 1>},
+                                         {node_rr_fwd_kernel<8, 4, 0, 1>, node_rr_fwd_kernel<8, 4, 1, 1>}}};
+    const size_t lds = (size_t)(RkFwdTile::floats() + NLBAC_MLP_TILE * 8 + 2 * 3 * 8 * 64 +
+                                2 * 32 * 64 + NLBAC_MLP_TILE * RK_MAX_NS + 2 * 2 * 64 + 4) * sizeof(float);
     const dim3 grid(nlbac_ceil_div(L.n, NLBAC_MLP_TILE));
-    hipLaunchKernelGGL(kf[rr_shape_index(L.net[0].hid)][L.acts_bits ? 1 : 0], grid, dim3(256), lds, s, L);
+    hipLaunchKernelGGL(kf[rr_split() ? 1 : 0][rr_shape_index(L.net[0].hid)][L.acts_bits ? 1 : 0], grid, dim3(256), lds, s, L);
     NLBAC_CHECK_LAUNCH("nlbac_node_rk_fwd(rr)");
     return 0;
 }
@@ -670,12 +894,15 @@ int nlbac_node_rr_fwd_launch(NodeRkLaunch& L, hipStream_t s) {
 int nlbac_node_rr_bwd_launch(NodeRkBwdLaunch& L, hipStream_t s) {
     if (!nlbac_node_rr_eligible(&L.net[0], &L.net[1])) return 1;
     using KernelB = void (*)(const NodeRkBwdLaunch);
-    static const KernelB kb[3][2] = {{node_rr_bwd_kernel<4, 4, 0>, node_rr_bwd_kernel<4, 4, 1>},
-                                     {node_rr_bwd_kernel<7, 1, 0>, node_rr_bwd_kernel<7, 1, 1>},
-                                     {node_rr_bwd_kernel<8, 4, 0>, node_rr_bwd_kernel<8, 4, 1>}};
-    const size_t lds = (size_t)(RkBwdTile::floats() + 2 * 4 * 8 * 64) * sizeof(float);
+    static const KernelB kb[2][3][2] = {{{node_rr_bwd_kernel<4, 4, 0, 0>, node_rr_bwd_kernel<4, 4, 1, 0>},
+                                         {node_rr_bwd_kernel<7, 1, 0, 0>, node_rr_bwd_kernel<7, 1, 1, 0>},
+                                         {node_rr_bwd_kernel<8, 4, 0, 0>, node_rr_bwd_kernel<8, 4, 1, 0>}},
+                                        {{node_rr_bwd_kernel<4, 4, 0, 1>, node_rr_bwd_kernel<4, 4, 1, 1>},
+                                         {node_rr_bwd_kernel<7, 1, 0, 1>, node_rr_bwd_kernel<7, 1, 1, 1>},
+                                         {node_rr_bwd_kernel<8, 4, 0, 1>, node_rr_bwd_kernel<8, 4, 1, 1>}}};
+    const size_t lds = (size_t)(RkBwdTile::floats() + 2 * 4 * 8 * 64 + 2 * 32 * 64 + 2 * 16 * 64 + 4) * sizeof(float);
     const dim3 grid(nlbac_ceil_div(L.n, NLBAC_MLP_TILE));
-    hipLaunchKernelGGL(kb[rr_shape_index(L.net[0].hid)][L.acts_bits ? 1 : 0], grid, dim3(256), lds, s, L);
+    hipLaunchKernelGGL(kb[rr_split() ? 1 : 0][rr_shape_index(L.net[0].hid)][L.acts_bits ? 1 : 0], grid, dim3(256), lds, s, L);
     NLBAC_CHECK_LAUNCH("nlbac_node_rk_bwd(rr)");
     return 0;
 }

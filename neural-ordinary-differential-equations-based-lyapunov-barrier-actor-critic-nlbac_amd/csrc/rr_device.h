@@ -214,6 +214,88 @@ struct RRGemm {
     }
 };
 
+// ---------------------------------------------------------------------------------------------------------------------
+// A contiguous range [M0, M1) of a layer's MFMA stream — whole groups of output blocks, all KS k-steps — with a weight
+// queue of its own: two waves share ONE hid x hid product by output blocks (node_rr_kernels.hip: the g_net wave of a tile
+// takes over part of f_net's last layer, whose waves would otherwise run one layer longer than g_net's).  Same hooks as
+// RRGemm::run; the range's last group of blocks is left pending for the caller (the next product's `pre`).
+// ---------------------------------------------------------------------------------------------------------------------
+template <class S, int M0, int M1>
+struct RRPart {
+    static constexpr int NB = S::NB, KS = S::KS, G0 = rr_group_first(NB), D = 4;
+    static constexpr int V0 = M0 >> 2, V1 = (M1 + 3) >> 2;                  // float4 of the layer's stream the range touches
+    static constexpr int block_of(int m) { return m < G0 * KS ? 0 : G0 + 2 * ((m - G0 * KS) / (2 * KS)); }
+    static constexpr int J0 = block_of(M0), J1 = (M1 >= S::NM) ? NB : block_of(M1);   // its output blocks [J0, J1)
+    static constexpr int K0 = 4 * J0, K1 = (J1 == NB) ? KS : 4 * J1;         // the values (next layer's k-steps) it yields
+    static constexpr int JT = (J1 - J0 > G0 || J0 > 0) ? J1 - 2 : J0;         // first block of its last group
+    static_assert(M0 % KS == 0 && M1 % KS == 0 && M0 < M1 && M1 <= S::NM, "a range is whole groups of blocks");
+    f32x4 wq[D];
+
+    // cur: byte offset of the LAYER's stream (wave-uniform)
+    __device__ __forceinline__ void prime(__amdgpu_buffer_rsrc_t rs, int voff, int cur) {
+#pragma unroll
+        for (int i = 0; i < D; ++i) wq[i] = (V0 + i < V1) ? rr_ldw(rs, voff, cur + (V0 + i) * 1024) : f32x4{0.f, 0.f, 0.f, 0.f};
+    }
+
+    template <class PRE, class FIN>
+    __device__ __forceinline__ void run(f32x4 (&acc)[NB], const f32x4 (&cinit)[NB], float (&H)[KS], __amdgpu_buffer_rsrc_t rs,
+                                        int voff, int cur, PRE&& pre, FIN&& fin) {
+        asm volatile("" : "+s"(cur));
+        int m = M0;
+#pragma unroll
+        for (int g0 = J0; g0 < J1;) {
+            const int gn = (g0 == 0) ? G0 : 2;
+            const int pn = (g0 == J0) ? 0 : ((g0 == G0) ? G0 : 2), p0 = g0 - pn;     // previous group of the range
+#pragma unroll
+            for (int jj = 0; jj < 3; ++jj)
+                if (jj < gn) acc[g0 + jj] = cinit[g0 + jj];
+#pragma unroll
+            for (int ks = 0; ks < KS; ++ks) {
+                if (g0 == J0) pre(ks);
+#pragma unroll
+                for (int jj = 0; jj < 3; ++jj) {
+                    if (jj < gn) {
+                        const int v = m >> 2, c = m & 3;
+                        acc[g0 + jj] = __builtin_amdgcn_mfma_f32_16x16x4f32(wq[(v - V0) % D][c], H[ks], acc[g0 + jj], 0, 0, 0);
+                        if (c == 3 || m == M1 - 1) {
+                            const int vn = v + D;
+                            if (vn < V1) {
+                                int so = cur + vn * 1024;
+                                RR_PIN_S(so)
+                                wq[(v - V0) % D] = rr_ldw(rs, voff, so);
+                            }
+                            __builtin_amdgcn_sched_barrier(0);
+                        }
+                        ++m;
+                    }
+                }
+                if (gn == 3) { RR_PIN_A3(acc[g0], acc[g0 + 1], acc[g0 + 2]) } else { RR_PIN_A2(acc[g0], acc[g0 + 1]) }
+                if (ks < 4 * pn) fin(p0 + (ks >> 2), ks & 3);
+            }
+            g0 += gn;
+        }
+    }
+
+    // the single-block product over the range's values: o = sum_{ks in [K0, K1)} a[ks] * H[ks], two accumulator chains
+    template <class PRE>
+    __device__ __forceinline__ static f32x4 block(const float (&a)[KS], float (&H)[KS], PRE&& pre) {
+        f32x4 o0{0.f, 0.f, 0.f, 0.f}, o1{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int ks = K0; ks < K1; ++ks) {
+            pre(ks);
+            if (ks & 1) o1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a[ks], H[ks], o1, 0, 0, 0);
+            else o0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a[ks], H[ks], o0, 0, 0, 0);
+        }
+        return o0 + o1;
+    }
+};
+// where a layer's stream is cut for two waves: the first floor(groups / 2) groups of blocks
+template <class S>
+constexpr int rr_split_m() {
+    constexpr int G0 = rr_group_first(S::NB), groups = 1 + (S::NB - G0) / 2, first = groups / 2;
+    return first == 0 ? 0 : (G0 + 2 * (first - 1)) * S::KS;
+}
+
 // this lane's 4 bias values of output block jo (zeros for padding rows)
 template <class S>
 __device__ __forceinline__ f32x4 rr_bias(const float* __restrict__ b, int jo, int q) {

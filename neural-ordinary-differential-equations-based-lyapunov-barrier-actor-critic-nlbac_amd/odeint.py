@@ -16,6 +16,7 @@ launch (``nlbac_mlp_fwd``) plus two per-row algebra kernels; the step-size
 controller runs on the device and the host reads one 128-byte control block
 per attempted step.
 """
+import os
 import ctypes as C
 
 import torch
@@ -43,6 +44,10 @@ TABLEAU = {
     "probe": dict(beta=[[1.0]], c_sol=None),
 }
 
+
+# How small results reach the host (the dopri5 control block here, the update's scalars block in sac_cbf_clf.py):
+# "kernel" — the producing kernel writes pinned host memory itself; "side" — an async copy on a side stream behind an event.
+HOST_COPY = os.environ.get("NLBAC_HOST_COPY", "kernel")
 
 class _Carver:
     """Hands out the buffers of ONE step slot: consecutive 16-byte-aligned pieces of a flat float32 slice.  Every slot
@@ -667,7 +672,9 @@ class AffineNodeSolver:
         c.ctl_w, c.hslots = ctl.data_ptr(), hs.data_ptr()
         c.alog, c.alog_cap = self._buf("alog", P, self.ALOG_CAP, 3, dtype=torch.float64).data_ptr(), self.ALOG_CAP
         # the controller leaves the host's copy of the control block in pinned memory itself (see _ctl_posted)
-        c.ctl_host = None if torch.cuda.is_current_stream_capturing() else self._ctl_io(P)[1].data_ptr()
+        # ... unless host_copy == "side": a kernel that writes host memory holds the stream until the write has crossed PCIe
+        # (~5 us before the next launch may start); a copy on the side stream does not
+        c.ctl_host = None if (torch.cuda.is_current_stream_capturing() or HOST_COPY == "side") else self._ctl_io(P)[1].data_ptr()
         # Where the norm + controller run.  Fused into the RK launch's epilogue (last workgroup of a problem) for the two
         # one-stage launches of the initial-step selection: same GPU time as a launch of their own (26.7 us against
         # 18 + 9), one launch less each.  NOT for an attempted step: the epilogue's device-scope atomics queue behind the
@@ -722,7 +729,7 @@ class AffineNodeSolver:
                            chain=ch)
             self._chain_control(ws0, pool, ch, st["y0"], u, 2, P, rpp)
         st["attempts"] += k
-        if self.comm is not None and self.comm.world > 1:
+        if (self.comm is not None and self.comm.world > 1) or HOST_COPY == "side":
             self._ctl_post(P)        # (the all-reduced controller is nlbac_dopri_control: it leaves no host copy)
         else:
             self._ctl_posted(P)

@@ -30,6 +30,7 @@ import torch
 import torch.nn as nn
 
 from .. import _lib
+from ..odeint import HOST_COPY
 from ..arena import Arena, bwd_weights, io_array, mlp_array, pack, skinny_partials_ws, stream_ptr
 from . import _layout as SC
 from .model import BarrierNetwork, GaussianPolicy, LyaNetwork, QNetwork
@@ -90,6 +91,9 @@ class _Workspace:
         self.part_td = z(self.nblk, 3)
         self.n_tiles = (B + _lib.MLP_TILE_MIN - 1) // _lib.MLP_TILE_MIN
         self.part_td32 = z(self.n_tiles, 4)            # per-tile sums of the fused dy heads (nlbac_dy_head; 16-row tiles at most)
+        # tickets of the heads' two-level elections: 1 + ceil(workgroups / 16) words each (TD head: <= 4 nets; actor head)
+        self.tickets_td = torch.zeros(2 + self.n_tiles * 4 // 16 + 1, dtype=torch.int32, device=dev)
+        self.tickets_q = torch.zeros(2 + self.n_tiles * NP // 16 + 1, dtype=torch.int32, device=dev)
         self.part_tdx = z(max(NX, 1), self.nblk)
         self.heads2, self.pi2, self.logp2 = self.heads3[B:], self.act3[B:], self.logp3[B:]
         self.acts_p = z(NP, 2, B, H)
@@ -961,7 +965,7 @@ class SAC_CBF_CLF(object):
                 for k in range(3):
                     H.q[k], H.dq[k] = q[3 + k].data_ptr(), ws.dq3[k].data_ptr()
                 H.next_q, H.next_l = ws.next_q.data_ptr(), ws.next_l.data_ptr()
-                H.partials, H.ticket = ws.part_td32.data_ptr(), self._tickets.data_ptr()
+                H.partials, H.ticket = ws.part_td32.data_ptr(), ws.tickets_td.data_ptr()
                 H.mul, H.out = 1.0 / G, sc + 4 * SC.SC_QF1
                 if self.h_extra:        # BarrierNet TD step (NU/sac_cbf_clf.py:224-233): the launch's 4th net
                     H.xt, H.xq, H.dxq = q[6].data_ptr(), q[7].data_ptr(), ws.dq3[3].data_ptr()
@@ -1028,7 +1032,7 @@ class SAC_CBF_CLF(object):
                     off = g.la_off + k * g.la_stride
                     H.actor.log_alpha[g.first + k] = g.arena.theta.data_ptr() + 4 * off
                     H.actor.g_log_alpha[g.first + k] = g.arena.grad.data_ptr() + 4 * off
-            H.partials, H.ticket = ws.part_q32.data_ptr(), self._tickets.data_ptr() + 4 * 8
+            H.partials, H.ticket = ws.part_q32.data_ptr(), ws.tickets_q.data_ptr()
         return H
 
     def _upd_part2(self, ws, lam_upd, assume_single):
@@ -1095,8 +1099,21 @@ class SAC_CBF_CLF(object):
                        [sc + 4 * (SC.SC_ALPHA + g.first + k) for k in range(cnt)]) if tune else None
             last = g is P.act_groups[-1][0]
             mir = self.__dict__.get("_mirror") if last else None
-            self._adam(a, self.lr, a.n_slabs, before_step=alpha_grads, alpha=refresh, mirror=mir[1] if mir else None)
-            if mir:
+            side = mir is not None and HOST_COPY == "side"
+            self._adam(a, self.lr, a.n_slabs, before_step=alpha_grads, alpha=refresh, mirror=mir[1] if (mir and not side) else None)
+            if side:
+                # the scalars block reaches the host by a copy on a side stream: a kernel that writes host memory holds
+                # the launch stream until the write has crossed PCIe (~5 us before the prefetched launches could start)
+                st = self.__dict__.get("_sc_side")
+                if st is None:
+                    st = self._sc_side = (torch.cuda.Stream(device=self.device), torch.cuda.Event())
+                st[1].record()
+                st[0].wait_event(st[1])
+                with torch.cuda.stream(st[0]):
+                    mir[1].copy_(self.sc, non_blocking=True)
+                    self._sc_ev[mir[0]].record()
+                self._mirror_done = mir[0]
+            elif mir:
                 self._mirror_done = mir[0]
                 self._sc_ev[mir[0]].record()     # (here, not in _returns: what _prefetch_next queues is not waited for)
         self._prefetch_next(ws, ws.updates_now)

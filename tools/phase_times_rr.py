@@ -33,7 +33,10 @@ for st0, st1 in ((1, 7), (0, 1)):
         a = t[grp * 256: grp * 256 + 256]
         base = a[0]
         print(" %s: tile constants %d" % (name, a[1] - a[0]))
-        nl = 4 if grp == 0 else 3
+        # (with the f / g split, NLBAC_NODE_SPLIT != 0: "L3" is the wave's part of f_net's last layer for the f_net wave, and
+        #  g_net's output layer + the wait for f_net's layer-2 activations for the g_net wave; "out" the part itself + output)
+        split = os.environ.get("NLBAC_NODE_SPLIT", "1") != "0"
+        nl = 4 if (grp == 0 or split) else 3
         for k in range(st1 - st0):
             sb = 2 + 8 * k
             parts = ["start %6d" % (a[sb] - base), "L0 %5d" % (a[sb + 1] - a[sb])]
