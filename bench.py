@@ -105,6 +105,35 @@ def launch_flops(name, args):
     return total
 
 
+class FlopCounter:
+    """Executed algorithmic FLOP of the MFMA kernel families, counted on the host as the launches go by — no events, no
+    device work: what the replay of the timed region runs under (identical updates, so its count IS the timed region's)."""
+    FAM = {"nlbac_mlp_bwd_data_head": "nlbac_mlp_bwd_data", "nlbac_mlp_fwd_gauss": "nlbac_mlp_fwd"}
+
+    def __init__(self):
+        self.flop, self.launches, self._cache, self._orig = 0, 0, {}, _lib.call
+
+    def __enter__(self):
+        names = set(KernelTimer.NAMES)
+
+        def call(name, *args):
+            fam = self.FAM.get(name, name)
+            if fam in names:
+                # (descriptor arrays are built once per plan: their identity + the integer arguments name the launch)
+                key = (fam,) + tuple(a if isinstance(a, int) else id(a) for a in args[:10])
+                fl = self._cache.get(key)
+                if fl is None:
+                    fl = self._cache[key] = launch_flops(fam, args)
+                self.flop += fl
+                self.launches += 1
+            self._orig(name, *args)
+        _lib.call = call
+        return self
+
+    def __exit__(self, *a):
+        _lib.call = self._orig
+
+
 class KernelTimer:
     """HIP events (torch.cuda.Event on the launch stream) around every launch of the MLP kernels."""
     NAMES = ("nlbac_mlp_fwd", "nlbac_mlp_bwd_data", "nlbac_mlp_bwd_weights", "nlbac_node_rk_fwd", "nlbac_node_rk_bwd",
@@ -349,7 +378,7 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         return float(t)
 
-    def measure(B, global_B, steps, warmup, extras, strong=False):
+    def measure(B, global_B, steps, warmup, extras, strong=False, dp_step_control=None):
         """One agent at ``B`` rows per rank (losses normalised by ``global_B``): warm-up, the timed region bracketed by
         barrier + synchronize, max over ranks.  ``extras``: also the pipelined replay / event-timed pass / sub-metric."""
         args = Args(global_B)                                         # global batch in the loss normalisation
@@ -359,7 +388,7 @@ def main():
         agent.adjoint = a.adjoint
         agent.use_graphs = (world == 1) and a.graphs
         if world > 1:
-            agent.enable_data_parallel(dist, step_control=a.dp_step_control)
+            agent.enable_data_parallel(dist, step_control=dp_step_control or a.dp_step_control)
         dev = agent.device
         # the replay lives in HBM in the agent's row layout; minibatches are drawn and gathered on the device
         replay = DeviceReplayMemory(REPLAY_ROWS, 1234 + rank, agent, device_rng=True)
@@ -417,10 +446,13 @@ def main():
         replay._draws = draws0
         fence()
         t0 = time.perf_counter()
-        for i in range(steps):
-            step(warmup + i, sync="lagged")
+        with FlopCounter() as fc:
+            for i in range(steps):
+                step(warmup + i, sync="lagged")
         fence()
         el2 = max_over_ranks(time.perf_counter() - t0)
+        res["timed_region_flop_per_update"] = fc.flop / steps      # (the replay runs the timed region's updates again)
+        res["timed_region_mfma_launches_per_update"] = fc.launches / steps
         res["pipelined"] = {"value": global_B * steps / el2, "unit": "samples/s", "ms_per_step": 1e3 * el2 / steps,
                             "steps": steps,
                             "note": "the timed region replayed from the same state with the returned losses read one "
@@ -453,6 +485,19 @@ def main():
         other = {"scaling": kind, "value": o["value"], "unit": "samples/s", "ms_per_step": o["ms"],
                  "batch_per_gpu": o["B"], "global_batch": o["global_B"], "node_fit_rows_per_gpu": o["fit_rows_per_rank"],
                  "rollout_solver_stats": o["stats"]}
+        del o
+    # ... and, for dopri5, the same line under the OTHER step control: "global" (error norms all-reduced: every rank takes
+    # the accept / reject decisions and step sizes the single-device run over the global batch takes — the computation
+    # the N = 1 line and the parity tests run) next to "shard" (every rank controls its own rows' steps: no collective
+    # inside a solve; a different computation within solver tolerance, see README).  Whoever reads a scaling curve off
+    # these lines has both.
+    other_ctl = None
+    if world > 1 and not a.lean and a.solver == "dopri5":
+        alt = "global" if a.dp_step_control == "shard" else "shard"
+        o = measure(B, GB, a.steps, a.warmup, extras=False, strong=strong_first, dp_step_control=alt)
+        other_ctl = {"dp_step_control": alt, "value": o["value"], "unit": "samples/s", "ms_per_step": o["ms"],
+                     "batch_per_gpu": o["B"], "global_batch": o["global_B"], "rollout_solver_stats": o["stats"],
+                     "matches_single_device_decisions": alt == "global"}
         del o
 
     # ---- roofline of the dominant kernel: separate pass, HIP events around each MLP launch ----------
@@ -491,14 +536,30 @@ def main():
         flop_upd = sum(v["flops"] for v in ks.values()) / a.profile_steps
         busy_ms = sum(v["ms"] for v in ks.values()) / a.profile_steps
         pass_ms = 1e3 * t_pass / a.profile_steps
-        roofline["update"] = dict(window="event-timed pass: the %d updates after the timed region" % a.profile_steps,
-                                  executed_mfma_kernel_flop_per_update=flop_upd, ms_per_update=pass_ms,
-                                  achieved=flop_upd / (pass_ms * 1e-3) / 1e12, unit="TFLOP/s",
-                                  frac=flop_upd / (pass_ms * 1e-3) / 1e12 / PEAK_F32_MFMA_TFLOPS,
-                                  mfma_kernel_ms_per_update=busy_ms,
-                                  frac_of_kernel_time=flop_upd / (busy_ms * 1e-3) / 1e12 / PEAK_F32_MFMA_TFLOPS,
-                                  solver_stats=stats_pass,
-                                  node_fits=sum(1 for i in range(a.profile_steps) if (base + i) % NODE_FIT_INTERVAL == 0))
+        event_pass = dict(window="event-timed pass: the %d updates after the timed region, every MFMA launch bracketed by "
+                                 "two event records (they cost the stream ~0.4 ms per update: a lower bound)" % a.profile_steps,
+                          executed_mfma_kernel_flop_per_update=flop_upd, ms_per_update=pass_ms,
+                          achieved=flop_upd / (pass_ms * 1e-3) / 1e12, unit="TFLOP/s",
+                          frac=flop_upd / (pass_ms * 1e-3) / 1e12 / PEAK_F32_MFMA_TFLOPS,
+                          mfma_kernel_ms_per_update=busy_ms,
+                          frac_of_kernel_time=flop_upd / (busy_ms * 1e-3) / 1e12 / PEAK_F32_MFMA_TFLOPS,
+                          solver_stats=stats_pass,
+                          node_fits=sum(1 for i in range(a.profile_steps) if (base + i) % NODE_FIT_INTERVAL == 0))
+        # The whole update against the MFMA roof over the TIMED REGION itself (numerator and denominator of one window,
+        # unperturbed): the FLOP its MFMA launches executed — counted on the host, launch by launch, while the pipelined
+        # replay runs the very same updates again from the same state (FlopCounter; every attempted dopri5 step and every
+        # NODE fit of the region is in it) — over the region's wall time.
+        fl_t = main_run.get("timed_region_flop_per_update")
+        if fl_t:
+            roofline["update"] = dict(window="the timed region (%d updates): executed MFMA-kernel FLOP counted on the host over the "
+                                             "identical replay, divided by the region's wall time" % a.steps,
+                                      executed_mfma_kernel_flop_per_update=fl_t, ms_per_update=main_run["ms"],
+                                      achieved=fl_t / (main_run["ms"] * 1e-3) / 1e12, unit="TFLOP/s",
+                                      frac=fl_t / (main_run["ms"] * 1e-3) / 1e12 / PEAK_F32_MFMA_TFLOPS,
+                                      mfma_launches_per_update=main_run["timed_region_mfma_launches_per_update"],
+                                      solver_stats=main_run["stats"], event_pass=event_pass)
+        else:
+            roofline["update"] = event_pass
     elif a.profile_steps:
         for i in range(a.profile_steps):
             step(base + i)
@@ -552,6 +613,8 @@ def main():
         }
         if other is not None:
             out[other["scaling"]] = other
+        if other_ctl is not None:
+            out["other_step_control"] = other_ctl
         if cpu:
             out["speedup_vs_cpu_baseline"] = value / cpu["value"]
         print(json.dumps(out))

@@ -26,12 +26,16 @@ class DataParallel:
         self.backend = dist.get_backend(group)
         # True: issue the collective even in a one-rank group (tests: the RCCL code path on a single GPU)
         self.always_collective = always_collective
+        # what went over the wire: (calls, bytes) per collective kind, for tests and bench lines to count per update
+        self.stats = {"all_reduce": [0, 0], "broadcast": [0, 0]}
 
     def all_reduce_(self, t):
         """In-place SUM over ranks.  gloo cannot reduce device tensors here: stage through the host
         (used by the CPU / single-GPU rehearsal tests only)."""
         if self.world == 1 and not self.always_collective:
             return t
+        self.stats["all_reduce"][0] += 1
+        self.stats["all_reduce"][1] += t.numel() * t.element_size()
         if t.is_cuda and self.backend == "gloo":
             h = t.detach().cpu()
             self.dist.all_reduce(h, op=self.dist.ReduceOp.SUM, group=self.group)
@@ -43,6 +47,8 @@ class DataParallel:
     def broadcast_(self, t, src=0):
         if self.world == 1 and not self.always_collective:
             return t
+        self.stats["broadcast"][0] += 1
+        self.stats["broadcast"][1] += t.numel() * t.element_size()
         if t.is_cuda and self.backend == "gloo":
             h = t.detach().cpu()
             self.dist.broadcast(h, src=src, group=self.group)

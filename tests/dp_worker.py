@@ -116,10 +116,12 @@ def run_cuda_oracle_case(dp, out, solver, env_name, adjoint, step_control="globa
         agent.set_noise([e[lo:hi] for e in eps])
         host = tuple(batch[f][lo:hi].numpy() for f in fields)
         node_np = tuple(t[nlo:nhi].numpy() for t in node) if updates % 10 == 0 else None
+        n0, b0 = agent.dp.stats["all_reduce"]
         ret = agent.update_from_host(host, updates, node_np)
         torch.cuda.synchronize()
         p = "c%d_" % ci
         res[p + "ret"] = np.array(ret)
+        res[p + "collectives"] = np.array([agent.dp.stats["all_reduce"][0] - n0, agent.dp.stats["all_reduce"][1] - b0])
         for name, mod in (("critic", agent.critic), ("policy", agent.policy), ("node", agent.neural_ode_model)):
             res[p + "p_" + name] = torch.cat([q.detach().reshape(-1) for q in mod.parameters()]).cpu().numpy()
     np.savez(out, **res)

@@ -198,6 +198,16 @@ def test_two_rank_update_with_per_shard_step_control(tmp_path, env_name, adjoint
                 assert err.max() <= 2.1 * lr[name] * (ci + 1), (name, updates, err.max())
     for k in res[0].files:                                            # replicas stay bit-identical
         np.testing.assert_array_equal(res[0][k], res[1][k])
+    # exchanges per update under per-shard step control: NONE inside a solve.  What is left is what the dependencies
+    # force — the critic gradient (+ loss sums) before its Adam step, the constraint / actor sums before the
+    # augmented-Lagrangian scalars (nonlinear in the global value), the actors' gradient before theirs — plus, on a
+    # NODE-fit update, the fit's gradient (+ its loss sum): a collective of its own because the rollout, which is queued
+    # before the critic exchange exists, needs the stepped NODE.
+    for ci, updates in enumerate(c["updates"]):
+        n, nbytes = (int(x) for x in res[0]["c%d_collectives" % ci])
+        print("update %d: %d all-reduces, %d bytes" % (updates, n, nbytes))
+        n_fit = 1 if updates % 10 == 0 else 0
+        assert n <= 3 + len(agent.actor_groups) - 1 + n_fit, (updates, n)
 
 
 @pytest.mark.gpu
