@@ -876,8 +876,10 @@ class SAC_CBF_CLF(object):
         self._fill = collections.deque((lambda: self._part1_targets(ws, P, B, G, LD, s),
                                         lambda: self._part1_critic_step(ws, P, B, soft),
                                         lambda: self._part1_actor_q(ws, P, B, G, NP, s)))
-        self._fill_first = True
-        if ws.__dict__.get("_pre_now") is not None:
+        # how many pieces the first wait pulls: a rollout of ONE adaptive solve gets them all at once (the host needs
+        # ~100 us of queued work to read the decision and come back); chained solves (SimulatedCars 2, Pvtol 3) one per wait
+        self._fill_first = self.task.rollout_waits == 1
+        if ws.__dict__.get("_pre_now") is not None and ws._pre_now[2]:
             self._fill.popleft()                # (targets + critic data backward: queued with the prefetch)
             # (the first wait still queues both remaining pieces: holding the Q(s, pi) forward back for the launch it
             #  could share with V(p(x')) left the stream dry for ~20 us while the host got from the accept decision to
@@ -913,8 +915,7 @@ class SAC_CBF_CLF(object):
             return      # (the returned floats would be copied BEHIND the queued launches, whose dy head rewrites the losses)
         fn()
         NP = self.task.n_pol_now(updates + 1)
-        self._prefetch_launches(ws, NP)
-        ws._prefetched = (updates + 1, NP)
+        ws._prefetched = (updates + 1, NP, self._prefetch_launches(ws, NP))
 
     def update_prefetch(self, ws, updates, prefetch):
         """Draw update ``updates``'s minibatch (``prefetch``, see update_on_device) and queue its policy forward now — what
@@ -923,8 +924,7 @@ class SAC_CBF_CLF(object):
             return
         prefetch()
         NP = self.task.n_pol_now(updates)
-        self._prefetch_launches(ws, NP)
-        ws._prefetched = (updates, NP)
+        ws._prefetched = (updates, NP, self._prefetch_launches(ws, NP))
 
     def _prefetch_launches(self, ws, NP):
         """What of an update needs nothing but its minibatch and the parameters as the previous update left them: the
@@ -932,7 +932,14 @@ class SAC_CBF_CLF(object):
         the host needs to come round to the next update)."""
         P = self._plan(ws, NP)
         self._policy_forward(ws, P, NP)
+        # (a rollout of three chained solves keeps the targets piece for its waits: each solve's accept decision is a
+        #  host round trip, and a piece of independent work queued behind every one of them is worth more than a longer
+        #  head start — the policy forward alone covers the update boundary at those batch sizes.  Returns whether the
+        #  targets piece went out.)
+        if self.task.rollout_waits >= 3:
+            return False
         self._part1_targets(ws, P, ws.B, ws.B * self.world, P.LD, stream_ptr())
+        return True
 
     def _fill_one(self):
         """Called by a solver just before it waits for an accept decision: queue the next piece(s) of part 1 behind the

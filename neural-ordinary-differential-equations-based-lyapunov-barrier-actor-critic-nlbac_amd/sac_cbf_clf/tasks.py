@@ -24,6 +24,7 @@ from .model import NeuralODEModel
 
 class _Task:
     name = None
+    rollout_waits = 1        # adaptive solves chained inside one update's rollout: each ends in a host wait (dopri5)
     obs_dim = act_dim = lya_dim = n_s = 0
     n_eps = 3                 # N(0,1) draws per update: next-obs sample, obs sample, backup sample [, ...]
     lam_hi = 400.0
@@ -346,6 +347,7 @@ class CarsTask(_Task):
     """SimulatedCars: two-step rollout of a non-affine NODE on [x, u, t]; the second action is re-sampled from
     the (detached) predicted observation and carries no gradient; relative-degree-2 CBFs between cars 3-4 and
     4-5, CLF on (x3, v3, x4, v4)."""
+    rollout_waits = 2
     name = "SimulatedCars"
     obs_dim, act_dim, lya_dim, n_s = 10, 1, 4, 10
     n_eps = 5
@@ -466,6 +468,7 @@ class PvtolTask(_Task):
     operator's position follows the predicted x, relative-degree-3 CBFs (5 hazards, 2 operator distances, y_max,
     y_min) + CLF on the predicted observation.  The backup controller is trained every ``backup_update_interval``
     updates (P:282) with its own augmented term and Adam state."""
+    rollout_waits = 3
     name = "Pvtol"
     obs_dim, act_dim, lya_dim, n_s = 11, 2, 11, 6
     n_eps = 7
@@ -549,9 +552,12 @@ class PvtolTask(_Task):
     def rollout_begin(self, ws, P):
         a, s = self.agent, stream_ptr()
         B, NP = ws.B, P.NP
-        _lib.call("nlbac_pvtol_state", ws.mb.data_ptr(), a.lay.LD, B, ws.st6.data_ptr(), ws.op0.data_ptr(), s)
+        # the state, once per controller's rows of the rollout's initial state (st6 = the first block: no D2D copies —
+        # a torch .copy_ is ~20 us of host time, more than the 5 us launch it replaces)
+        ws.st6 = ws.y0[:B]
         for p in range(NP):
-            ws.y0[p * B:(p + 1) * B].copy_(ws.st6)
+            _lib.call("nlbac_pvtol_state", ws.mb.data_ptr(), a.lay.LD, B, ws.y0[p * B:].data_ptr(),
+                      ws.op0.data_ptr() if p == 0 else None, s)
         for sv in self.steps:
             self.reserve(sv, NP * B, NP)
         self.steps[0].forward_begin(ws.y0[:NP * B], ws.pi2[:NP * B], NP, B, a.solver, float(self.env.dt), a.atol,
@@ -565,16 +571,18 @@ class PvtolTask(_Task):
         p_scale, p_bias = pol.action_scale.data_ptr(), pol.action_bias.data_ptr()
         follow, (gx, gy) = float(env.safety_operator_follow), self.GOAL
         s1, s2, s3 = self.steps
-        ws.x1[:n].copy_(s1.forward_finish())
+        # (x_t+1 .. x_t+3 are read where the solvers left them — three solvers, three output buffers, none re-used before
+        #  the update ends: no D2D copies between the chained solves)
+        ws.x1 = s1.forward_finish()
         # u_(t+1), u_(t+2) ~ pi(. | get_obs(x)), detached (P:474-526)
         call("nlbac_pvtol_obs_fwd", ws.x1.data_ptr(), ws.op0.data_ptr(), B, follow, gx, gy, n, ws.obs1.data_ptr(), 11,
              ws.op1.data_ptr(), s)
         self.policy_sample(ws, ("n1", NP), P.n_pols, P.io_nx[0], NP, B, ws.heads_n1, ws.eps[3:3 + NP], 2, ws.a1, 2, ws.logp_nx)
-        ws.x2[:n].copy_(s2.forward(ws.x1[:n], ws.a1[:n], NP, B, a.solver, dt, a.atol, a.rtol))
+        ws.x2 = s2.forward(ws.x1[:n], ws.a1[:n], NP, B, a.solver, dt, a.atol, a.rtol)
         call("nlbac_pvtol_obs_fwd", ws.x2.data_ptr(), ws.op1.data_ptr(), n, follow, gx, gy, n, ws.obs2.data_ptr(), 11,
              ws.op2.data_ptr(), s)
         self.policy_sample(ws, ("n2", NP), P.n_pols, P.io_nx[1], NP, B, ws.heads_n2, ws.eps[5:5 + NP], 2, ws.a2, 2, ws.logp_nx)
-        ws.x3[:n].copy_(s3.forward(ws.x2[:n], ws.a2[:n], NP, B, a.solver, dt, a.atol, a.rtol))
+        ws.x3 = s3.forward(ws.x2[:n], ws.a2[:n], NP, B, a.solver, dt, a.atol, a.rtol)
         a.drain_fill()
         call("nlbac_mlp_fwd", P.n_l, P.io_v1, 1, B, s)
         hz = self.hazards.data_ptr()
@@ -626,6 +634,7 @@ class PvtolBarrierTask(PvtolTask):
     """Learned-barrier-certificate Pvtol (NP/sac_cbf_clf/sac_cbf_clf.py:334-480): one controller, one NODE step, the
     learned CBF term on get_obs(x') with a re-sampled detached next action, CLF (V' - V)/1 + 0.1 V on the predicted
     observation, ratio clamped at 0.002."""
+    rollout_waits = 1
     name = "PvtolBarrier"
     n_pol, backup_mode, has_signal, n_extra_critics = 1, 0, True, 1
     n_eps, eps_order = 3, None

@@ -49,3 +49,26 @@ for rnd in range(5):
 for k, v in res.items():
     v = sorted(v)
     print("%-28s median %.1f us  min %.1f us" % (k, v[len(v) // 2], v[0]))
+
+# ---- the same launches with the caches as the update leaves them: a 96 MB streaming kernel in front of every launch (what
+#      the head kernels' activation / dz traffic does to the XCDs' L2s), timed alone with events
+scratch = torch.empty(24 * 1024 * 1024, device="cuda")
+
+
+def timeit_cold(fn, iters=30):
+    ts = []
+    for _ in range(iters):
+        scratch.add_(1.0)
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        fn()
+        e1.record()
+        torch.cuda.synchronize()
+        ts.append(e0.elapsed_time(e1) * 1e3)
+    ts.sort()
+    return ts[len(ts) // 2], ts[0]
+
+
+for k, fn in variants.items():
+    med, mn = timeit_cold(fn)
+    print("%-28s behind a 96 MB stream: median %.1f us  min %.1f us (event pair around ONE launch: ~+3 us)" % (k, med, mn))
