@@ -39,7 +39,12 @@ def test_one_process_line_has_the_contract_keys():
     r = d["roofline"]
     assert r["bound"] == "mfma" and 0 < r["frac"] < 1 and abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-9
     u = r["update"]
-    assert 0 < u["frac"] < 1 and u["solver_stats"]["solves"] == 10 and "window" in u
+    # (round 4: the update's roofline is taken over the timed region itself — its 20 solves —, the event-timed pass
+    #  that follows the region rides along as `event_pass`)
+    assert 0 < u["frac"] < 1 and u["solver_stats"]["solves"] == 20 and "window" in u
+    assert abs(u["frac"] - u["executed_mfma_kernel_flop_per_update"] / (d["ms_per_step"] * 1e-3) / 1e12 / r["peak"]) < 1e-9
+    e = u["event_pass"]
+    assert 0 < e["frac"] <= u["frac"] * 1.05 and e["solver_stats"]["solves"] == 10 and "window" in e
     assert abs(d["value"] - d["config"]["global_batch"] * 1e3 / d["ms_per_step"]) < 1e-3 * d["value"]
 
 
@@ -52,3 +57,6 @@ def test_two_rank_rehearsal_finishes(mode):
     assert d["n_gpus"] == 2 and d["scaling"] == "weak" and d["config"]["dp_step_control"] == mode
     assert d["config"]["global_batch"] == 2 * d["config"]["batch_per_gpu"] and d["value"] > 0
     assert d["strong"]["scaling"] == "strong" and d["strong"]["global_batch"] == d["config"]["batch_per_gpu"]
+    o = d["other_step_control"]          # the same line under the other dopri5 step control
+    assert o["dp_step_control"] == ("global" if mode == "shard" else "shard") and o["value"] > 0
+    assert o["matches_single_device_decisions"] == (mode == "shard")
