@@ -13,35 +13,7 @@
 // cotangent a_x -> top layer -> backward chain -> dX = J^T a_x -> k_a.  HBM traffic per row and stage: nothing in mask
 // mode (the adjoint of a rollout: 2W floats in, 2W out per STEP); with parameter gradients wanted the activations and
 // pre-activation gradients of the stage go out once for nlbac_mlp_bwd_weights (memory O(one step), not O(steps)).
-#include "mlp_device.h"
-#include "ode_control.h"
-
-#define ADJ_LDS_MAX (160 * 1024 - 64)
-#define ADJ_MAX_STAGES 8
-#define ADJ_MAX_NS 8
-#define ADJ_MAX_NU 4
-#define ADJ_WP 24                /* padded width of a row of z = [y(ns) | a_x(ns) | a_u(nu)] in LDS */
-#define ADJ_MAX_GOUT 32
-
-struct NodeAdjLaunch {
-    nlbac_mlp net[2];                 // f, g
-    const float* u;                   // [n][nu]
-    const float* Z0;                  // [n][W]   state at the step start
-    float* KZ;                        // [S][n][W] stage derivatives (s-time); stages < st_lo are read, the others written
-    float* Z1; float* ERR;            // [n][W] step result / error estimate, or null
-    float* ZS;                        // [S][n][W] stage inputs, kept for the weight gradients (or null)
-    float* dG;                        // [S][n][ns*nu] output-layer gradient of g_net (with ZS)
-    float* acts[2]; long acts_ls[2];  // [layer][S*n][hid] activations of the stage (with ZS), else null: masks in LDS
-    float* dz[2];
-    int n, rpp, n_s, n_u, W;
-    int st_lo, st_hi, S_total;
-    float beta[ADJ_MAX_STAGES][ADJ_MAX_STAGES];
-    float c_out[ADJ_MAX_STAGES]; int n_out;
-    float c_err[ADJ_MAX_STAGES]; int n_err;
-    const double* h_dev; int h_stride; float h_val[8];
-    const double* ctl;                // rows of problems whose C_DONE is set are left alone (device-driven step chain)
-    int ld, sw_off1, mask_words;      // mask_words: uint32 words of one group's LDS mask store
-};
+#include "node_adj_shared.h"
 
 // MODE 1: both nets <= 4 column tiles, 2: both 8, 0: mixed.  KEEP 0: ReLU masks in LDS (no weight gradients),
 // 1: activations / dz / stage inputs to global memory for nlbac_mlp_bwd_weights.
@@ -319,6 +291,10 @@ extern "C" int nlbac_node_adj_step(const nlbac_mlp* f, const nlbac_mlp* g, const
             for (int m = 0; m < 3; ++m)
                 (void)hipFuncSetAttribute((const void*)k[b][m], hipFuncAttributeMaxDynamicSharedMemorySize, ADJ_LDS_MAX);
         attr_set = true;
+    }
+    if (!keep) {       // the reference's NODE shapes, masks only: the register-resident kernel (node_adj_rr_kernels.hip)
+        const int rr = nlbac_node_adj_rr_launch(L, (hipStream_t)s);
+        if (rr <= 0) return rr;
     }
     const int mode = (ntf <= 4 && ntg <= 4) ? 1 : ((ntf == 8 && ntg == 8) ? 2 : 0);
     const dim3 grid(nlbac_ceil_div(L.n, NLBAC_MLP_TILE));

@@ -886,7 +886,9 @@ int nlbac_node_rr_fwd_launch(NodeRkLaunch& L, hipStream_t s) {
     const size_t lds = (size_t)(RkFwdTile::floats() + NLBAC_MLP_TILE * 8 + 2 * 3 * 8 * 64 +
                                 2 * 32 * 64 + NLBAC_MLP_TILE * RK_MAX_NS + 2 * 2 * 64 + 4) * sizeof(float);
     const dim3 grid(nlbac_ceil_div(L.n, NLBAC_MLP_TILE));
-    hipLaunchKernelGGL(kf[rr_split() ? 1 : 0][rr_shape_index(L.net[0].hid)][L.acts_bits ? 1 : 0], grid, dim3(256), lds, s, L);
+    // (the forward is split in mask mode only: with activation rows kept — the NODE fit, 32768 rows, two workgroups per
+    //  CU — the two waves' store bursts and the hand-over cost more than the balance gains: 140 against 124 us per launch)
+    hipLaunchKernelGGL(kf[(rr_split() && L.acts_bits) ? 1 : 0][rr_shape_index(L.net[0].hid)][L.acts_bits ? 1 : 0], grid, dim3(256), lds, s, L);
     NLBAC_CHECK_LAUNCH("nlbac_node_rk_fwd(rr)");
     return 0;
 }
