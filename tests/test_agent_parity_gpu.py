@@ -352,8 +352,11 @@ def test_fused_rk_step_kernel_matches_per_stage_launches(solver, rows):
     out = sol.forward(y0, u, 2, rows, solver, 0.02).clone()
     du, dy0 = sol.backward(dout, need_du=True, need_dy0=True)
     assert sol.ctx["steps"][-1]["ws"].bits and sol.ctx["steps"][-1]["ws"].acts_f.dtype == torch.int32
+    # (not bit for bit since round 4: in mask mode the g_net wave of a half tile takes over part of f_net's last layer and
+    #  f_net's output layer is summed in two parts — node_rr_kernels.hip, SPLIT —, in activation mode the forward is not
+    #  split: the same fp32 arithmetic in another summation order)
     for a, b, name in zip(res[1][:3], (out, du, dy0), ("out", "du", "dy0")):
-        assert torch.equal(a, b), "mask mode differs from activation mode: " + name
+        vec_close(b.cpu().numpy(), a.cpu().numpy(), 2e-6, "mask mode vs activation mode: " + name)
 
 
 def test_hipgraphs_with_alternating_batch_sizes_stay_correct():
