@@ -184,7 +184,7 @@ def pmc_traffic(kernel, env_name, solver, B):
     tools/pmc_summary.py).  Counters cannot be collected from inside the timed process, so this is read from
     profiles/; None when no pass exists for the workload."""
     here = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles")
-    for r in ("r03", "r02", "r01"):
+    for r in ("r04", "r03", "r02", "r01"):
         path = os.path.join(here, "%s_pmc_hbm_traffic_%s_%s_B%d.json" % (r, env_name.lower(), solver, B))
         if os.path.exists(path):
             k = json.load(open(path))["kernels"].get(kernel.split("+")[0])
@@ -214,7 +214,7 @@ def pmc_update_traffic(env_name, solver, B, adjoint=False):
     """HBM bytes per update (all kernels) from the committed counter passes of this workload (tools/gpu_pmc.sh writes
     ``per_update_bytes`` from a lean run of exactly warmup + steps updates), or None."""
     tag = "%s_%s_B%d%s" % (env_name.lower(), solver, B, "_adjoint" if adjoint else "")
-    for r in ("r03", "r02"):
+    for r in ("r04", "r03", "r02"):
         path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "%s_pmc_hbm_traffic_%s.json" % (r, tag))
         if os.path.exists(path):
             return json.load(open(path)).get("per_update_bytes")
@@ -517,10 +517,10 @@ def main():
         agent.use_graphs = graphs_on
         stats_pass = {k: v - stats0.get(k, 0) for k, v in agent.node_solver.stats.items()}
         dom = max(ks, key=lambda k: ks[k]["ms"])
-        kname = {"nlbac_mlp_fwd": "mlp_rr_fwd_kernel", "nlbac_mlp_bwd_data": "mlp_bwd_data_kernel",
-                 "nlbac_mlp_bwd_weights": "mlp_bwd_wide_kernel+mlp_bwd_skinny_partial/reduce_kernel",
+        kname = {"nlbac_mlp_fwd": "mlp_rrq_fwd_kernel", "nlbac_mlp_bwd_data": "mlp_rrq_bwd_kernel",
+                 "nlbac_mlp_bwd_weights": "mlp_bwd_wide64_kernel",
                  "nlbac_node_rk_fwd": "node_rr_fwd_kernel", "nlbac_node_rk_bwd": "node_rr_bwd_kernel",
-                 "nlbac_node_adj_step": "node_adj_kernel",
+                 "nlbac_node_adj_step": "node_adj_rr_kernel",
                  "nlbac_concat_rk_fwd": "concat_rr_fwd_kernel", "nlbac_concat_rk_bwd": "concat_rr_bwd_kernel"}[dom]
         roofline = dict(bound="mfma", kernel=kname, achieved=ks[dom]["tflops"], peak=PEAK_F32_MFMA_TFLOPS,
                         unit="TFLOP/s", frac=ks[dom]["tflops"] / PEAK_F32_MFMA_TFLOPS,

@@ -36,9 +36,23 @@ def timeit(fn, iters=50):
     return e0.elapsed_time(e1) / iters * 1e3
 
 
+sol_m = AffineNodeSolver(node, "cuda")          # mask mode: what the update's rollouts run (ReLU mask words, f / g split)
+sol_m.keep_acts = False
+sol_m.ctx = {}
+ws_m = sol_m._step_ws(n, 7, 0)
+ctl_m = sol_m._ctl(2)
+ctl_m[:, 0] = 0.02
+
+
+def run_m(st0=1, st1=7):
+    sol_m._rk_fused(ws_m, y0, u, 2, n // 2, "dopri5", st0, st1, h_dev=ctl_m.data_ptr(), save_acts=True)
+
+
 variants = {
+    "6 stages, mask words": lambda: run_m(),
     "6 stages, acts saved": lambda: run(True),
     "6 stages, no acts": lambda: run(False),
+    "1 stage, mask words": lambda: run_m(0, 1),
     "1 stage, acts saved": lambda: run(True, 0, 1),
     "1 stage, no acts": lambda: run(False, 0, 1),
 }
