@@ -445,12 +445,16 @@ def main():
         ws._prefetched = None
         replay._draws = draws0
         fence()
+        stats1 = dict(agent.node_solver.stats)
         t0 = time.perf_counter()
         with FlopCounter() as fc:
             for i in range(steps):
                 step(warmup + i, sync="lagged")
         fence()
         el2 = max_over_ranks(time.perf_counter() - t0)
+        again = {k: v - stats1.get(k, 0) for k, v in agent.node_solver.stats.items()}
+        same = all(again.get(k, 0) == v for k, v in stats.items() if k != "node_fits")
+        res["replay_same_solver_steps"] = bool(same)      # (deterministic kernels: the replay IS the region; reported, not assumed)
         res["timed_region_flop_per_update"] = fc.flop / steps      # (the replay runs the timed region's updates again)
         res["timed_region_mfma_launches_per_update"] = fc.launches / steps
         res["pipelined"] = {"value": global_B * steps / el2, "unit": "samples/s", "ms_per_step": 1e3 * el2 / steps,
@@ -557,7 +561,9 @@ def main():
                                       achieved=fl_t / (main_run["ms"] * 1e-3) / 1e12, unit="TFLOP/s",
                                       frac=fl_t / (main_run["ms"] * 1e-3) / 1e12 / PEAK_F32_MFMA_TFLOPS,
                                       mfma_launches_per_update=main_run["timed_region_mfma_launches_per_update"],
-                                      solver_stats=main_run["stats"], event_pass=event_pass)
+                                      solver_stats=main_run["stats"],
+                                      replay_same_solver_steps=main_run.get("replay_same_solver_steps"),
+                                      event_pass=event_pass)
         else:
             roofline["update"] = event_pass
     elif a.profile_steps:
