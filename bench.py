@@ -85,6 +85,10 @@ def launch_flops(name, args):
             m = _layer_macs(net)
             per += sum(m) + m[-1] + sum(m[1:-1]) + m[0]
         return 2 * P * rpp * (st_hi - st_lo) * (per + 3 * g.out_dim)
+    if name == "nlbac_concat_adj_step":   # (net, c, P, rpp, st_lo, st_hi, ...): every stage = net eval + its data backward
+        net, P, rpp, st_lo, st_hi = args[0]._obj, args[2], args[3], args[4], args[5]
+        m = _layer_macs(net)
+        return 2 * P * rpp * (st_hi - st_lo) * (sum(m) + m[-1] + sum(m[1:-1]) + m[0])
     if name == "nlbac_concat_rk_fwd":     # (net, y0, c, P, rpp, st0, st1, ...): stages x rows x NODE eval
         net, P, rpp, st0, st1 = args[0]._obj, args[3], args[4], args[5], args[6]
         return 2 * P * rpp * (st1 - st0) * sum(_layer_macs(net))
@@ -137,7 +141,7 @@ class FlopCounter:
 class KernelTimer:
     """HIP events (torch.cuda.Event on the launch stream) around every launch of the MLP kernels."""
     NAMES = ("nlbac_mlp_fwd", "nlbac_mlp_bwd_data", "nlbac_mlp_bwd_weights", "nlbac_node_rk_fwd", "nlbac_node_rk_bwd",
-             "nlbac_node_adj_step", "nlbac_concat_rk_fwd", "nlbac_concat_rk_bwd")
+             "nlbac_node_adj_step", "nlbac_concat_rk_fwd", "nlbac_concat_rk_bwd", "nlbac_concat_adj_step")
 
     def __init__(self):
         self.records = {n: [] for n in self.NAMES}
@@ -525,7 +529,8 @@ def main():
                  "nlbac_mlp_bwd_weights": "mlp_bwd_wide64_kernel",
                  "nlbac_node_rk_fwd": "node_rr_fwd_kernel", "nlbac_node_rk_bwd": "node_rr_bwd_kernel",
                  "nlbac_node_adj_step": "node_adj_rr_kernel",
-                 "nlbac_concat_rk_fwd": "concat_rr_fwd_kernel", "nlbac_concat_rk_bwd": "concat_rr_bwd_kernel"}[dom]
+                 "nlbac_concat_rk_fwd": "concat_rr_fwd_kernel", "nlbac_concat_rk_bwd": "concat_rr_bwd_kernel",
+                 "nlbac_concat_adj_step": "concat_adj_rr_kernel"}[dom]
         roofline = dict(bound="mfma", kernel=kname, achieved=ks[dom]["tflops"], peak=PEAK_F32_MFMA_TFLOPS,
                         unit="TFLOP/s", frac=ks[dom]["tflops"] / PEAK_F32_MFMA_TFLOPS,
                         traffic=pmc_traffic(kname, a.env, a.solver, B),

@@ -32,7 +32,7 @@
 extern "C" {
 #endif
 
-#define NLBAC_ABI_VERSION 4 /* bumped whenever an exported signature or struct changes; nlbac_abi_version() returns it */
+#define NLBAC_ABI_VERSION 5 /* bumped whenever an exported signature or struct changes; nlbac_abi_version() returns it */
 #define NLBAC_MAX_LAYERS 6
 #define NLBAC_MAX_NETS 8
 #define NLBAC_MLP_TILE 32 /* samples per workgroup in the MLP kernels */
@@ -609,6 +609,22 @@ int nlbac_concat_adj_in(const float *ZS, int w, const float *c, int n_s, int n_c
                         float *Xin, float *Ay, nlbac_stream_t s);
 int nlbac_concat_adj_out(const float *fnet, const float *dX, int n_s, int n_c, const float *norm, int n, int w,
                          float *KZ, nlbac_stream_t s);
+/* ONE launch per attempted RK step of that system (ABI 5; north_star: "one fused kernel per integrator step"): stages
+ * [st_lo, st_hi) of the step — per stage the stage point, the net's forward on it and the vector-Jacobian product of
+ * a_y through it, i.e. the five launches above — for nets of the reference's depth (in -> hid -> hid -> hid -> out) and
+ * width 64 / 100 / 128 (nlbac_concat_adj_step_ok(net) != 0; other shapes take the stage-by-stage path and this entry
+ * point refuses them).  Arguments as nlbac_node_adj_step: KZ [n_stages_total][n][w] (stages < st_lo are read),
+ * Z1 = Z0 + h sum c_out[j] KZ_j and ERR = h sum c_err[j] KZ_j when given, beta [n_stages_total][n_stages_total], rows of
+ * problems whose `done` is set in ctl are left untouched.  With Xin [S][n][in_dim], Ay [S][n][n_s], acts / dz
+ * [layer][S*n][hid] (layer stride acts_ls floats; all four or none) every evaluated stage's net inputs, output
+ * cotangent, activations and pre-activation gradients are kept for nlbac_mlp_bwd_weights (the parameter adjoint's stage
+ * derivative); without them nothing but KZ / Z1 / ERR is written. */
+int nlbac_concat_adj_step_ok(const nlbac_mlp *net);
+int nlbac_concat_adj_step(const nlbac_mlp *net, const float *c, int P, int rows_per_problem, int st_lo, int st_hi,
+                          int n_stages_total, const float *beta, const float *c_out, int n_out, const float *c_err,
+                          int n_err, const float *h_host, const double *h_dev, int h_dev_stride, const double *ctl,
+                          const float *Z0, float *KZ, float *Z1, float *ERR, const float *norm, float *Xin, float *Ay,
+                          float *acts, long acts_ls, float *dz, nlbac_stream_t s);
 
 /* Strided block copy of 32-bit words: block b (block_len words) from src + b*src_stride to dst + b*dst_stride —
  * a row range of a stage-major solver buffer in one launch (hands a problem's first attempted dopri5 step to its

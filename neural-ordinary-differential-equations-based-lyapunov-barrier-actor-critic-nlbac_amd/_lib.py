@@ -126,6 +126,9 @@ _PROTOS = {
     "nlbac_node_rk_mask_words": [C.POINTER(Mlp), C.POINTER(Mlp), _I],
     "nlbac_concat_adj_in": [_P, _I, _P, _I, _I, _P, _I, _P, _P, _P],
     "nlbac_concat_adj_out": [_P, _P, _I, _I, _P, _I, _I, _P, _P],
+    "nlbac_concat_adj_step_ok": [C.POINTER(Mlp)],
+    "nlbac_concat_adj_step": [C.POINTER(Mlp), _P, _I, _I, _I, _I, _I, _P, _P, _I, _P, _I, _P, _P, _I, _P, _P, _P, _P, _P,
+                              _P, _P, _P, _P, _L, _P, _P],
     "nlbac_reduce_slabs": [_P, _P, _I, _L, _L, _P],
     "nlbac_soft_update": [_P, _P, _L, _F, _P],
     "nlbac_gauss_sample_fwd": [_P, _I, _P, _P, _P, _I, _I, _P, _I, _P, _P],
@@ -214,7 +217,7 @@ def build(verbose=False):
     return LIB_PATH
 
 
-ABI_VERSION = 4      # == NLBAC_ABI_VERSION of include/nlbac_hip.h (bumped with every signature / struct change)
+ABI_VERSION = 5      # == NLBAC_ABI_VERSION of include/nlbac_hip.h (bumped with every signature / struct change)
 
 
 def _stale_sources():

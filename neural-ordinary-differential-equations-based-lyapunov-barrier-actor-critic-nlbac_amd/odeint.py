@@ -1407,10 +1407,34 @@ class ConcatNodeSolver(AffineNodeSolver):
                     Ay=self._buf("cadj_Ay", n, ns), f=self._buf("cadj_f", n, ns), dX=self._buf("cadj_dX", n, net.in_dim),
                     acts=self._buf("cadj_acts", net.n_layers - 1, n, net.hid))
 
+    def _adj_fused(self):
+        """One nlbac_concat_adj_step launch per attempted step (the reference's depth at widths 64 / 100 / 128);
+        ``adj_fused = False`` keeps the stage-by-stage launches (other shapes; the cross-check)."""
+        f = self.__dict__.get("adj_fused")
+        if f is None:
+            f = self.adj_fused = bool(_lib.load().nlbac_concat_adj_step_ok(C.byref(self.net.desc)))
+        return f
+
     def _adj_step(self, w, u, P, rpp, method, st0, st1, h_host=None, h_dev=None, ctl=None, c_out=None, c_err=None,
                   keep=None):
-        """(Problems whose solve is done are recomputed to the same values — their control block, z0 and first stage no
-        longer change — instead of being skipped.)"""
+        """(Stage by stage: problems whose solve is done are recomputed to the same values — their control block, z0
+        and first stage no longer change — instead of being skipped; the fused launch leaves their rows alone.)"""
+        if self._adj_fused():
+            beta, S = self._beta(method)
+            k = keep or {}
+            dp = lambda t: t.data_ptr() if t is not None else None
+            _lib.call("nlbac_concat_adj_step", C.byref(self.net.desc), u.data_ptr(), P, rpp, st0, st1, S, beta,
+                      c_out, len(c_out) if c_out is not None else 0, c_err, len(c_err) if c_err is not None else 0,
+                      fptr(*h_host) if h_host is not None else None, h_dev, _lib.DOPRI_CTL if h_dev else 0, ctl,
+                      w["Z0"].data_ptr(), w["KZ"].data_ptr(), w["Z1"].data_ptr() if c_out is not None else None,
+                      w["ERR"].data_ptr() if c_err is not None else None,
+                      self.norm.data_ptr() if self.norm is not None else None, dp(k.get("Xin")), dp(k.get("Ay")),
+                      dp(k.get("acts")), k.get("ls", 0), dp(k.get("dz")), stream_ptr())
+            self.nfe += st1 - st0
+            if keep:
+                for st in range(st0, st1):
+                    self._adj_stage_dw(self._adj_par_cur, st)
+            return
         n, W, ns, nc, net, s = P * rpp, w["W"], self.n_s, self.n_u, self.net, stream_ptr()
         rows = TABLEAU[method]["beta"]
         S = len(rows) + 1

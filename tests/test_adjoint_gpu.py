@@ -246,7 +246,8 @@ def test_pvtol_full_size_dopri5_adjoint():
 
 # ----------------------------------------------------------------------------------------------------------------------
 # The single-net NODE (SimulatedCars: dx/dt = net([x | action, time]); Quadrotor-like: the same with normalised inputs
-# and de-normalised outputs): its adjoint runs stage by stage on the MLP entry points (nlbac_concat_adj_in / _out).
+# and de-normalised outputs): one nlbac_concat_adj_step launch per attempted step (stage by stage on the MLP entry
+# points for other shapes, and as the cross-check).
 # ----------------------------------------------------------------------------------------------------------------------
 def _single_net(env_name):
     from nlbac_amd.envspec import make_env
@@ -311,10 +312,16 @@ def test_adjoint_of_a_single_net_rollout_matches_the_oracle(env_name, method, T)
         # (the adjoint recomputes the field along ITS trajectory from y(T): a row whose trajectory passes a ReLU kink
         #  within the 1e-6 by which the device's y(T) differs from the oracle's takes the other branch there — single
         #  rows, bounded by one unit's share; every other row is held to tol)
-        for name, a, b in (("d/dy0", dy0[rows], dy0_o.numpy()), ("d/dc", dc[rows], dc_o.numpy())):
+        #  The one escape hatch for a larger deviation is the oracle's own answer: a row whose ORACLE gradient moves by
+        #  more than tol when y0 is nudged by 3e-6 (relative; both signs) sits on such a kink and is only counted.
+        nudged = [_oracle_single(W, norm, ns, nc, y0[rows] * (1.0 + sgn * 3e-6), c[rows], T, dout[rows], method, True, False)[1:3]
+                  for sgn in (1.0, -1.0)]
+        for k, (name, a, b) in enumerate((("d/dy0", dy0[rows], dy0_o.numpy()), ("d/dc", dc[rows], dc_o.numpy()))):
             e = np.abs(np.asarray(a, dtype=np.float64) - b).max(1) / np.abs(b).max()
-            assert (e > tol).mean() <= 0.02 and e.max() <= 5e-3 and np.median(e) <= tol / 10, (
-                "adjoint %s problem %d: %d rows beyond %.0e, worst %.3e" % (name, p, int((e > tol).sum()), tol, e.max()))
+            on_kink = np.max([np.abs(g[k].numpy() - b).max(1) for g in nudged], 0) / np.abs(b).max() > tol
+            assert (e > tol).mean() <= 0.02 and e[~on_kink].max() <= 5e-3 and np.median(e) <= tol / 10, (
+                "adjoint %s problem %d: %d rows beyond %.0e (%d of them on a kink of the oracle's own gradient), worst "
+                "elsewhere %.3e" % (name, p, int((e > tol).sum()), tol, int((on_kink & (e > tol)).sum()), e[~on_kink].max()))
         _, gy, gc, _, _ = _oracle_single(W, norm, ns, nc, y0[rows], c[rows], T, dout[rows], method, False, False)
         # (solver tolerance; over the long horizon the continuous adjoint integrates ACROSS the ReLU kinks that the
         #  discrete gradient differentiates around: 2.2e-2 on the normalised net)
@@ -334,7 +341,70 @@ def test_adjoint_of_a_single_net_rollout_matches_the_oracle(env_name, method, T)
     gsum = ar.grad[:used].sum(0)
     gp = torch.cat([gsum[ar.offset_of[id(q)]:ar.offset_of[id(q)] + q.numel()] for q in agent.neural_ode_model.parameters()])
     _, _, _, gp_o, info = _oracle_single(W, norm, ns, nc, y0[rows], c[rows], T, dout[rows], method, True, True)
-    assert rel_l2(gp.cpu().numpy(), gp_o.numpy()) < (1e-3 if method != "dopri5" else 5e-3), rel_l2(gp.cpu().numpy(), gp_o.numpy())
+    bar = 1e-3 if method != "dopri5" else 5e-3
+    # (a sum over all rows: ONE row on a ReLU kink — see above — moves it by that row's share; the comparison cannot be
+    #  tighter than the oracle's own answer is under the same 3e-6 nudge of y0)
+    for sgn in (1.0, -1.0):
+        gp_n = _oracle_single(W, norm, ns, nc, y0[rows] * (1.0 + sgn * 3e-6), c[rows], T, dout[rows], method, True, True)[3]
+        bar = max(bar, 2.0 * rel_l2(gp_n.numpy(), gp_o.numpy()))
+    assert rel_l2(gp.cpu().numpy(), gp_o.numpy()) < bar, (rel_l2(gp.cpu().numpy(), gp_o.numpy()), bar)
+
+
+@pytest.mark.parametrize("env_name", ["SimulatedCars", "QuadrotorLike"])
+@pytest.mark.parametrize("node_hidden", [64, 100, 128])
+@pytest.mark.parametrize("method", ["rk4", "dopri5"])
+def test_fused_single_net_adjoint_step_matches_the_stage_by_stage_launches(env_name, node_hidden, method):
+    """nlbac_concat_adj_step (one launch per attempted step, register-resident chains) against the five launches per
+    stage it replaces, on the same solver object: two problems with a ragged last tile (d/dy0, d/dc), then one problem
+    with the parameter adjoint (the kept rows feed nlbac_mlp_bwd_weights)."""
+    from nlbac_amd.odeint import ConcatNodeSolver
+    from nlbac_amd.sac_cbf_clf.model import NeuralODEModel
+    from nlbac_amd.envspec import make_env
+    ns, nc, norm = _single_net(env_name)
+    torch.manual_seed(11)
+    env = make_env(env_name, 0)
+    node = NeuralODEModel(ns + nc, ns, hidden_dim=node_hidden,
+                          normalizer=env.node_normalizer if env_name == "QuadrotorLike" else None)
+    node.device_handles()               # (a model built outside an agent: an arena of its own, packs written)
+    gen = torch.Generator().manual_seed(3)
+    # (a freshly initialised net is a stiff field: over T = 0.2 dopri5 takes ~60 attempts and the accept / reject
+    #  sequence is sensitive to the last bit; T = 0.02 keeps it to a handful)
+    rpp, T = 77, (0.02 if method == "dopri5" else 0.2)
+    tr = synth.transitions(env_name, 2 * rpp, seed=4, env=env)
+    y0 = torch.tensor(tr["obs"][:, :ns], dtype=torch.float32)
+    c = torch.rand(2 * rpp, nc, generator=gen) * 2 - 1
+    y0[rpp:] *= 1.5
+    dout = torch.randn(2 * rpp, ns, generator=gen) / rpp
+    res = {}
+    for fused in (True, False):
+        sol = ConcatNodeSolver(node, "cuda")
+        assert sol._adj_fused(), "nlbac_concat_adj_step_ok refuses a %d-wide 4-layer net" % node_hidden
+        sol.adj_fused = fused
+        sol.adjoint, sol.keep_acts = True, False
+        sol.forward(y0.cuda(), c.cuda(), 2, rpp, method, T)
+        dc, dy0 = sol.backward(dout.cuda(), need_du=True, need_dy0=True)
+        info = sol.ctx.get("adjoint_info")
+        rows = slice(0, rpp)
+        sol.forward(y0[rows].cuda().contiguous(), c[rows].cuda().contiguous(), 1, rpp, method, T)
+        sol.backward(dout[rows].cuda().contiguous(), need_du=False, need_params=True)
+        gp = sol.ctx["adj_par"]["grad"].clone()
+        res[fused] = (dc.cpu().numpy().copy(), dy0.cpu().numpy().copy(), gp.cpu().numpy(), info, sol.ctx.get("adjoint_info"))
+    (dc_f, dy_f, gp_f, info_f, ipar_f), (dc_s, dy_s, gp_s, info_s, ipar_s) = res[True], res[False]
+    if method == "dopri5":
+        assert [a[2] for a in info_f[0]] == [a[2] for a in info_s[0]], "attempt counts differ: %r / %r" % (info_f, info_s)
+    # (same arithmetic up to the summation order of the register-resident products: 1e-5 of the largest entry; single
+    #  rows next to a ReLU kink may take the other branch, as in the oracle test above)
+    flipped = False
+    for name, a, b in (("d/dy0", dy_f, dy_s), ("d/dc", dc_f, dc_s)):
+        e = np.abs(a.astype(np.float64) - b).max(1) / np.abs(b).max()
+        assert (e > 1e-5).mean() <= 0.02 and e.max() <= 5e-2, "%s: %d rows beyond 1e-5, worst %.3e" % (name, int((e > 1e-5).sum()), e.max())
+        flipped = flipped or bool((e[:rpp] > 1e-5).any())
+    # (the parameter adjoint sums over the rows of problem 0: 1e-4 when none of them took another branch
+    #  and the two solves took the same attempts; a solve whose accept / reject sequence differs — the parameter norm
+    #  joins the step control: ~25 attempts on this field — agrees at solver tolerance)
+    same = method != "dopri5" or [a[2] for a in ipar_f[0]] == [a[2] for a in ipar_s[0]]
+    assert rel_l2(gp_f, gp_s) < (1e-4 if (same and not flipped) else 5e-3), "parameter adjoint: %.3e (flipped rows: %s; attempts %r / %r)" % (
+        rel_l2(gp_f, gp_s), flipped, ipar_f, ipar_s)
 
 
 @pytest.mark.parametrize("env_name,solver", [("SimulatedCars", "rk4"), ("SimulatedCars", "dopri5"), ("QuadrotorLike", "dopri5")])
