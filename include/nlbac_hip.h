@@ -32,7 +32,7 @@
 extern "C" {
 #endif
 
-#define NLBAC_ABI_VERSION 5 /* bumped whenever an exported signature or struct changes; nlbac_abi_version() returns it */
+#define NLBAC_ABI_VERSION 6 /* bumped whenever an exported signature or struct changes; nlbac_abi_version() returns it */
 #define NLBAC_MAX_LAYERS 6
 #define NLBAC_MAX_NETS 8
 #define NLBAC_MLP_TILE 32 /* samples per workgroup in the MLP kernels */
@@ -434,7 +434,24 @@ typedef struct nlbac_rk_chain {
     int alog_cap;
     double *ctl_host; /* or NULL: pinned HOST memory, [P][NLBAC_DOPRI_CTL]; nlbac_dopri_norm_control's controller leaves
                          a copy of each block it updates there (no copy launch between the decision and the host) */
+    /* ABI 6 — the interpolation at t_end inside the RK launches (nlbac_rk_interp_ok(f, g) != 0: the register-resident
+     * kernels), instead of nlbac_dopri_interp_fwd / _bwd as launches of their own:
+     *   forward (an attempt launch, stages 1..6): interp_out (n, n_s) or NULL — an attempt whose step reaches t_end
+     *     (ctl: t + h >= t_end) also writes the interpolant at t_end for its rows, and with interp_kind == 1 the
+     *     out-map's look-ahead point (interp_l, interp_p (n, 2)); a rejected attempt's values are overwritten by the
+     *     attempt that is accepted.  Same arithmetic as nlbac_dopri_interp_fwd: same bits.
+     *   backward (launch back_idx 0): interp_bwd != 0 — dK / dy0 / dy1 of each problem's last step are formed by the
+     *     launch itself from interp_dout (n, n_s) = d loss / d y(t_end), or with interp_kind == 1 from interp_dp
+     *     (+ interp_dp2, may be NULL) and the solve's output interp_x, as nlbac_dopri_interp_bwd would (dYup and the
+     *     contents of dK / dy0 of that slot are then not read). */
+    float *interp_out;
+    int interp_kind; float interp_l; float *interp_p;
+    int interp_bwd;
+    const float *interp_dout, *interp_dp, *interp_dp2, *interp_x;
 } nlbac_rk_chain;
+/* 1 when the fused RK kernels that serve these nets evaluate nlbac_rk_chain::interp_* (g == NULL: the single-net
+ * kernels of nlbac_concat_rk_fwd / _bwd, which take interp_out / interp_dout only — no out-map) */
+int nlbac_rk_interp_ok(const nlbac_mlp *f, const nlbac_mlp *g);
 /* Optional: the solve's initial state is FORMED by the launch that evaluates stage 0 (and written to y0 for the launches
  * that follow) instead of by a launch of its own.  kind 1 = the Unicycle tasks' state map (sac_cbf_clf.py:400-408
  * `get_state`: (x, y, arctan2(sin, cos)) of observation row `row % rows_per_problem`, float64 arctan2 as the reference's

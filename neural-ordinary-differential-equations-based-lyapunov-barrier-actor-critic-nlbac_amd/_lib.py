@@ -89,7 +89,10 @@ class RkChain(C.Structure):
     _fields_ = [("ctl", C.c_void_p), ("slot_floats", C.c_long), ("norm_mode", C.c_int), ("n_slots", C.c_int),
                 ("rtol", C.c_float), ("atol", C.c_float), ("t_end", C.c_double), ("partials", C.c_void_p),
                 ("tickets", C.c_void_p), ("ctl_w", C.c_void_p), ("hslots", C.c_void_p), ("alog", C.c_void_p),
-                ("alog_cap", C.c_int), ("ctl_host", C.c_void_p)]
+                ("alog_cap", C.c_int), ("ctl_host", C.c_void_p),
+                ("interp_out", C.c_void_p), ("interp_kind", C.c_int), ("interp_l", C.c_float), ("interp_p", C.c_void_p),
+                ("interp_bwd", C.c_int), ("interp_dout", C.c_void_p), ("interp_dp", C.c_void_p),
+                ("interp_dp2", C.c_void_p), ("interp_x", C.c_void_p)]
 
 
 class InMap(C.Structure):
@@ -127,6 +130,7 @@ _PROTOS = {
     "nlbac_concat_adj_in": [_P, _I, _P, _I, _I, _P, _I, _P, _P, _P],
     "nlbac_concat_adj_out": [_P, _P, _I, _I, _P, _I, _I, _P, _P],
     "nlbac_concat_adj_step_ok": [C.POINTER(Mlp)],
+    "nlbac_rk_interp_ok": [C.POINTER(Mlp), C.POINTER(Mlp)],
     "nlbac_concat_adj_step": [C.POINTER(Mlp), _P, _I, _I, _I, _I, _I, _P, _P, _I, _P, _I, _P, _P, _I, _P, _P, _P, _P, _P,
                               _P, _P, _P, _P, _L, _P, _P],
     "nlbac_reduce_slabs": [_P, _P, _I, _L, _L, _P],
@@ -217,7 +221,7 @@ def build(verbose=False):
     return LIB_PATH
 
 
-ABI_VERSION = 5      # == NLBAC_ABI_VERSION of include/nlbac_hip.h (bumped with every signature / struct change)
+ABI_VERSION = 6      # == NLBAC_ABI_VERSION of include/nlbac_hip.h (bumped with every signature / struct change)
 
 
 def _stale_sources():

@@ -437,11 +437,17 @@ extern "C" int nlbac_concat_rk_fwd(const nlbac_mlp* net, const float* y0, const 
         L.rtol = chain->rtol; L.atol = chain->atol; L.t_end = chain->t_end;
         L.partials = chain->partials; L.tickets = chain->tickets; L.ctl_w = chain->ctl_w; L.hslots = chain->hslots;
         L.alog = chain->alog; L.alog_cap = chain->alog_cap;
+        if (chain->interp_out) {
+            NLBAC_REQUIRE(chain->ctl && stage_end == n_stages_total && n_stages_total == 7 && chain->interp_kind == 0,
+                          "nlbac_concat_rk_fwd: interp_out goes with an attempt launch of a device-driven dopri5 chain (no out map)");
+            L.ip_out = chain->interp_out;
+        }
     }
     {   // the reference's depth at widths 64 / 100 / 128 runs on the register-resident kernels (concat_rr_kernels.hip)
         const int rr = nlbac_concat_rr_fwd_launch(L, (hipStream_t)s);
         if (rr <= 0) return rr;
     }
+    NLBAC_REQUIRE(!L.ip_out, "nlbac_concat_rk_fwd: interp_out needs the register-resident kernels (nlbac_rk_interp_ok)");
     const int in_p = (net->in_dim + 7) & ~7, hid_p = (net->hid + 7) & ~7;
     L.ld = (hid_p > in_p ? hid_p : in_p) + 4;
     const size_t lds = ((size_t)2 * NLBAC_MLP_TILE * L.ld + CK_MAX_STAGES * NLBAC_MLP_TILE * CK_NS +
@@ -472,6 +478,11 @@ extern "C" int nlbac_concat_rk_bwd(const nlbac_mlp* net, int P, int rows_per_pro
                       "nlbac_concat_rk_bwd: incomplete chain description");
         L.ctl = chain->ctl; L.slot_floats = chain->slot_floats; L.back_idx = back_idx; L.n_slots = chain->n_slots;
         L.hslots = chain->hslots;
+        if (chain->interp_bwd && back_idx == 0) {
+            NLBAC_REQUIRE(n_stages_total == 7 && st_hi == 7 && chain->interp_kind == 0 && chain->interp_dout,
+                          "nlbac_concat_rk_bwd: interp_bwd goes with a dopri5 step and interp_dout (no out map)");
+            L.ip_on = 1; L.ip_dout = chain->interp_dout;
+        }
     }
     L.net = *net;
     L.acts = acts; L.acts_ls = acts_ls; L.acts_bits = acts_bits; L.dz = dz;
@@ -494,6 +505,7 @@ extern "C" int nlbac_concat_rk_bwd(const nlbac_mlp* net, int P, int rows_per_pro
         const int rr = nlbac_concat_rr_bwd_launch(L, (hipStream_t)s);
         if (rr <= 0) return rr;
     }
+    NLBAC_REQUIRE(!L.ip_on, "nlbac_concat_rk_bwd: interp_bwd needs the register-resident kernels (nlbac_rk_interp_ok)");
     L.ld = ((net->hid + 31) & ~31) + 4;
     const size_t lds = ((size_t)2 * NLBAC_MLP_TILE * L.ld + CK_MAX_STAGES * NLBAC_MLP_TILE * CK_NS +
                         NLBAC_MLP_TILE * (1 + CK_NS + CK_NC + CK_NS + 16) +

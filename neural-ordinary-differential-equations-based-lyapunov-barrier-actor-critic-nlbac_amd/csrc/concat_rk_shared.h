@@ -34,6 +34,7 @@ struct ConcatRkLaunch {
     const double* ctl; long slot_floats;
     int norm_mode, n_slots; float rtol, atol; double t_end;
     float* partials; unsigned* tickets; double* ctl_w; double* hslots; double* alog; int alog_cap;
+    float* ip_out;                    // as NodeRkLaunch::ip_out (nlbac_rk_chain::interp_out; no out-map for this field)
 };
 
 struct ConcatRkBwdLaunch {
@@ -52,6 +53,7 @@ struct ConcatRkBwdLaunch {
     int ld;
     // device-driven chain, as NodeRkBwdLaunch: launch back_idx differentiates slot C_NACC - back_idx of each problem
     const double* ctl; long slot_floats; int back_idx, n_slots; const double* hslots;
+    int ip_on; const float* ip_dout;  // as NodeRkBwdLaunch::ip_* (nlbac_rk_chain::interp_dout)
 };
 
 

@@ -33,13 +33,19 @@ __global__ __launch_bounds__(128) void concat_rr_fwd_kernel(const ConcatRkLaunch
     const int row0 = blockIdx.x * NLBAC_MLP_TILE;
     const int p_tile = row0 / L.rpp;
     long soff = 0;
-    bool fsal = false;
+    bool fsal = false, ip = false;
+    float ip_x = 0.f;
     if (L.ctl) {
         const double* c = L.ctl + (long)p_tile * NLBAC_DOPRI_CTL;
         if (c[C_DONE] > 0.0) return;              // (uniform) this problem's solve has finished
         const int slot = (int)c[C_NACC];
         soff = (long)slot * L.slot_floats;
         fsal = slot > 0;
+        if (L.ip_out) {          // this attempt reaches t_end: it also evaluates the solve's result (node_rk_shared.h::rk_fwd_where)
+            const double t = c[C_T], hd = c[C_H];
+            ip = t + hd >= L.t_end;
+            ip_x = (float)((L.t_end - t) / hd);
+        }
     }
     float* const gK = L.K + soff;
     float* const gY = L.Y + soff;
@@ -363,6 +369,19 @@ __global__ __launch_bounds__(128) void concat_rr_fwd_kernel(const ConcatRkLaunch
             gErr[(long)row * ns + r] = a;
         }
     }
+    if (ip && tid < n_rows) {      // the interpolant at t_end, should this attempt be accepted: one thread per row
+        const int mm = tid, row = row0 + mm, sl = L.S_total - 1;
+        const float h = sH[mm];
+        for (int r = 0; r < ns; ++r) {
+            const float a0 = sY0[mm * CK_NS + r];
+            float a1 = a0, k[7];
+            for (int j = 0; j < sl; ++j)
+                if (L.beta[sl][j] != 0.f) a1 = a1 + sK[(j * NLBAC_MLP_TILE + mm) * CK_NS + r] * (L.beta[sl][j] * h);
+#pragma unroll
+            for (int j = 0; j < 7; ++j) k[j] = sK[(j * NLBAC_MLP_TILE + mm) * CK_NS + r];
+            L.ip_out[(long)row * ns + r] = dopri_interp_value(a0, a1, k, h, ip_x);
+        }
+    }
     // ---- fused step control (as concat_rk_fwd_kernel): tile partial sums, one ticket per problem, last workgroup = controller
     if (L.norm_mode < 0) return;
     __shared__ unsigned s_last;
@@ -467,6 +486,7 @@ __global__ __launch_bounds__(128) void concat_rr_bwd_kernel(const ConcatRkBwdLau
         soff = (long)slot * L.slot_floats;
     }
     const bool carry = chained && L.back_idx > 0;
+    const bool ip = L.ip_on && chained && !carry;      // dK / dy0 / dy1 of the last step from d loss / d y(t_end): no interp launch
     float* const gdK = L.dK + soff;
     float* const gdy0 = L.dy0 ? L.dy0 + soff : nullptr;
     float* const gdyn = L.dyn ? L.dyn + soff : nullptr;
@@ -491,6 +511,7 @@ __global__ __launch_bounds__(128) void concat_rr_bwd_kernel(const ConcatRkBwdLau
     float* sDC = sDY0 + NLBAC_MLP_TILE * CK_NS;                     // [32][CK_NC] running d carried
     float* sDX = sDC + NLBAC_MLP_TILE * CK_NC;                      // [32][16] dX of the current stage (input columns)
     float* sWt = sDX + NLBAC_MLP_TILE * 16;                         // [k-step < 4][block < 8][lane]: W_out^T's A fragments
+    float* sDYup = sWt + 4 * 8 * 64;                                // [32][CK_NS] dL/dy1 when the launch forms it itself (ip)
 
     const int st_lo = chained ? (slot == 0 ? 0 : 1) : L.st_lo;
     const bool stage0_data = dx_stage0 || keep_dz;
@@ -545,7 +566,24 @@ __global__ __launch_bounds__(128) void concat_rr_bwd_kernel(const ConcatRkBwdLau
         if (L.dc && L.dc_acc) v = L.dc[(long)min(row, n - 1) * nc + min(c, max(nc - 1, 0))];
         sDC[mm * CK_NC + c] = (row < n && c < nc) ? v : 0.f;
     }
-    {
+    if (ip) {       // (uniform) the interpolant's backward for this wave's rows (ode_kernels.hip::dopri_interp_bwd_kernel's arithmetic)
+#pragma unroll
+        for (int it = 0; it < (16 * CK_NS + 63) / 64; ++it) {
+            const int idx = lane + 64 * it;
+            const int mm = 16 * half + idx / CK_NS, c = idx % CK_NS, row = row0 + mm, rowc = min(row, n - 1), p = rowc / L.rpp;
+            const float hh = (float)L.ctl[(long)p * NLBAC_DOPRI_CTL + C_HUSED], xx = (float)L.ctl[(long)p * NLBAC_DOPRI_CTL + C_X];
+            const float g = L.ip_dout[(long)rowc * ns + min(c, ns - 1)];
+            float d0v, d1v, dk[7];
+            dopri_interp_grad(g, hh, xx, d0v, d1v, dk);
+            const bool ok = row < n && c < ns;
+            if (idx < 16 * CK_NS) {
+                sDY0[mm * CK_NS + c] = ok ? d0v : 0.f;
+                sDYup[mm * CK_NS + c] = ok ? d1v : 0.f;
+#pragma unroll
+                for (int j = 0; j < 7; ++j) sDK[(j * NLBAC_MLP_TILE + mm) * CK_NS + c] = ok ? dk[j] : 0.f;
+            }
+        }
+    } else {
         const bool have = gdy0 && L.dy0_in && !carry;
 #pragma unroll
         for (int it = 0; it < (16 * CK_NS + 63) / 64; ++it) {
@@ -561,7 +599,7 @@ __global__ __launch_bounds__(128) void concat_rr_bwd_kernel(const ConcatRkBwdLau
         sH[16 * half + lane] = chained ? (float)L.hslots[(long)p * L.n_slots + slot]
                                        : (L.h_dev ? (float)L.h_dev[(long)p * L.h_stride] : L.h_val[p]);
     }
-    {   // dK of every stage into LDS: all loads first (a loop with a run-time bound and the LDS store behind each load
+    if (!ip) {   // dK of every stage into LDS: all loads first (a loop with a run-time bound and the LDS store behind each load
         // was one global round trip per iteration: 16 in a row for rk4, most of the launch's prologue)
         constexpr int NIT = CK_MAX_STAGES * 16 * CK_NS / 64;
         float vals[NIT];
@@ -717,7 +755,7 @@ __global__ __launch_bounds__(128) void concat_rr_bwd_kernel(const ConcatRkBwdLau
         //      between the reads)
         {
             const float h = sH[m];
-            const bool up = gdYup && st == L.S_total - 1;       // (uniform)
+            const bool up = (gdYup || ip) && st == L.S_total - 1;       // (uniform)
             float yv0[4], dcv[4], kvv[4][CK_MAX_STAGES - 1], gup[4];
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
@@ -726,7 +764,7 @@ __global__ __launch_bounds__(128) void concat_rr_bwd_kernel(const ConcatRkBwdLau
                 dcv[r] = sDC[m * CK_NC + cc];
 #pragma unroll
                 for (int j = 0; j < CK_MAX_STAGES - 1; ++j) kvv[r][j] = sDK[(j * NLBAC_MLP_TILE + m) * CK_NS + cs];
-                gup[r] = up ? gdYup[(long)growc * ns + cs] : 0.f;
+                gup[r] = up ? (ip ? sDYup[m * CK_NS + cs] : gdYup[(long)growc * ns + cs]) : 0.f;
             }
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
@@ -800,7 +838,7 @@ int nlbac_concat_rr_bwd_launch(ConcatRkBwdLaunch& L, hipStream_t s) {
     static const KernelB kb[3][2] = {{concat_rr_bwd_kernel<4, 4, 0>, concat_rr_bwd_kernel<4, 4, 1>},
                                      {concat_rr_bwd_kernel<7, 1, 0>, concat_rr_bwd_kernel<7, 1, 1>},
                                      {concat_rr_bwd_kernel<8, 4, 0>, concat_rr_bwd_kernel<8, 4, 1>}};
-    const size_t lds = (size_t)(CK_MAX_STAGES * NLBAC_MLP_TILE * CK_NS + NLBAC_MLP_TILE * (1 + CK_NS + CK_NC + 16) + 4 * 8 * 64) * sizeof(float);
+    const size_t lds = (size_t)(CK_MAX_STAGES * NLBAC_MLP_TILE * CK_NS + NLBAC_MLP_TILE * (1 + CK_NS + CK_NC + 16 + CK_NS) + 4 * 8 * 64) * sizeof(float);
     hipLaunchKernelGGL(kb[crr_shape_index(L.net.hid)][L.acts_bits ? 1 : 0], dim3(nlbac_ceil_div(L.n, NLBAC_MLP_TILE)), dim3(128), lds, s, L);
     NLBAC_CHECK_LAUNCH("nlbac_concat_rk_bwd(rr)");
     return 0;

@@ -601,6 +601,13 @@ extern "C" int nlbac_node_rk_bwd(const nlbac_mlp* f, const nlbac_mlp* g, const f
                       "nlbac_node_rk_bwd: incomplete chain description");
         L.ctl = chain->ctl; L.slot_floats = chain->slot_floats; L.back_idx = back_idx; L.n_slots = chain->n_slots;
         L.hslots = chain->hslots;
+        if (chain->interp_bwd && back_idx == 0) {
+            NLBAC_REQUIRE(n_stages_total == 7 && st_hi == 7, "nlbac_node_rk_bwd: interp_bwd goes with a dopri5 step");
+            NLBAC_REQUIRE(chain->interp_kind == 1 ? (f->in_dim == 3 && chain->interp_dp && chain->interp_x) : (chain->interp_dout != nullptr),
+                          "nlbac_node_rk_bwd: interp_bwd needs interp_dout, or out map 1 with interp_dp and interp_x (n_s == 3)");
+            L.ip_on = 1; L.ip_kind = chain->interp_kind; L.ip_l = chain->interp_l; L.ip_dout = chain->interp_dout;
+            L.ip_dp = chain->interp_dp; L.ip_dp2 = chain->interp_dp2; L.ip_x = chain->interp_x;
+        }
     }
     L.net[0] = *f; L.net[1] = *g;
     L.u = u; L.G = G;
@@ -620,6 +627,7 @@ extern "C" int nlbac_node_rk_bwd(const nlbac_mlp* f, const nlbac_mlp* g, const f
         const int rr = nlbac_node_rr_bwd_launch(L, (hipStream_t)s);
         if (rr <= 0) return rr;
     }
+    NLBAC_REQUIRE(!L.ip_on, "nlbac_node_rk_bwd: interp_bwd needs the register-resident kernels (nlbac_rk_interp_ok)");
     int w = ((f->hid > g->hid ? f->hid : g->hid) + 31) & ~31;
     L.ld = w + 4;
     L.sw_off1 = (((f->out_dim + f->in_dim) * f->hid) + 3) & ~3;
@@ -704,11 +712,19 @@ extern "C" int nlbac_node_rk_fwd(const nlbac_mlp* f, const nlbac_mlp* g, const f
         L.rtol = chain->rtol; L.atol = chain->atol; L.t_end = chain->t_end;
         L.partials = chain->partials; L.tickets = chain->tickets; L.ctl_w = chain->ctl_w; L.hslots = chain->hslots;
         L.alog = chain->alog; L.alog_cap = chain->alog_cap;
+        if (chain->interp_out) {
+            NLBAC_REQUIRE(chain->ctl && stage_end == n_stages_total && n_stages_total == 7,
+                          "nlbac_node_rk_fwd: interp_out goes with an attempt launch of a device-driven dopri5 chain");
+            NLBAC_REQUIRE(chain->interp_kind == 0 || (chain->interp_kind == 1 && f->in_dim == 3 && chain->interp_p),
+                          "nlbac_node_rk_fwd: out map 1 needs n_s == 3 and interp_p");
+            L.ip_out = chain->interp_out; L.ip_kind = chain->interp_kind; L.ip_l = chain->interp_l; L.ip_p = chain->interp_p;
+        }
     }
     {   // nets up to 128 wide run on the register-resident kernels (node_rr_kernels.hip)
         const int rr = nlbac_node_rr_fwd_launch(L, (hipStream_t)s);
         if (rr <= 0) return rr;
     }
+    NLBAC_REQUIRE(!L.ip_out, "nlbac_node_rk_fwd: interp_out needs the register-resident kernels (nlbac_rk_interp_ok)");
     // LDS tiles hold pad8(hid) columns (the next layer's K extent), row stride = 4 mod 8 dwords: two workgroups fit per CU
     int w = ((f->hid > g->hid ? f->hid : g->hid) + 7) & ~7;
     L.ld = w + 4;
@@ -742,4 +758,10 @@ extern "C" int nlbac_node_rk_fwd(const nlbac_mlp* f, const nlbac_mlp* g, const f
     hipLaunchKernelGGL(kf[occ][acts_bits ? 1 : 0][mode], grid, dim3(512), lds, (hipStream_t)s, L);
     NLBAC_CHECK_LAUNCH("nlbac_node_rk_fwd");
     return 0;
+}
+
+bool nlbac_concat_rr_eligible(const nlbac_mlp* net);      // (concat_rr_kernels.hip)
+extern "C" int nlbac_rk_interp_ok(const nlbac_mlp* f, const nlbac_mlp* g) {
+    if (!f) return 0;
+    return (g ? nlbac_node_rr_eligible(f, g) : nlbac_concat_rr_eligible(f)) ? 1 : 0;
 }

@@ -41,6 +41,10 @@ struct NodeRkLaunch {
     // nlbac_in_map: the solve's initial state is formed by this launch (stage 0 of a fresh step) from observation rows
     // and written to y0 for the launches that follow; kind 1 = the Unicycle tasks' state (+ its look-ahead point)
     int in_kind; const float* in_obs; int in_obs_ld; float in_l; float* in_ps; float* y0_w;
+    // nlbac_rk_chain::interp_*: an attempt whose step reaches t_end also evaluates the solve's result — the interpolant
+    // at t_end, and the owner's out-map of it — for its rows (register-resident kernels; what nlbac_dopri_interp_fwd
+    // does as a launch of its own after the accept decision; a rejected attempt's values are overwritten by the next)
+    float* ip_out; int ip_kind; float ip_l; float* ip_p;
 };
 
 struct NodeRkBwdLaunch {
@@ -61,6 +65,10 @@ struct NodeRkBwdLaunch {
     // interpolant's backward), the others start from the slot behind them: dK[6] = its dK[0] (FSAL), dYup = its dy0.
     // Step sizes come from hslots[p][slot].
     const double* ctl; long slot_floats; int back_idx, n_slots; const double* hslots;
+    // nlbac_rk_chain::interp_*: launch back_idx 0 forms dK / dy0 / dy1 of each problem's last step itself, from
+    // d loss / d y(t_end) (ip_dout) or, with the out-map, from d loss / d p (ip_dp [+ ip_dp2]) and the solve's output
+    // ip_x — what nlbac_dopri_interp_bwd does as a launch of its own (register-resident kernels)
+    int ip_on, ip_kind; float ip_l; const float *ip_dout, *ip_dp, *ip_dp2, *ip_x;
 };
 
 // The register-resident kernels (node_rr_kernels.hip): 0 = launched, 1 = these nets / this launch are not theirs (the
@@ -96,17 +104,25 @@ struct RkFwdTile {
 struct RkFwdWhere {
     int p_tile; long soff; bool fsal;
     float *gK, *gY, *gG, *gErr; const float* gy0;
+    bool ip; float ip_x;         // this attempt reaches t_end: evaluate the interpolant at abscissa ip_x (nlbac_rk_chain::interp_out)
 };
 __device__ __forceinline__ bool rk_fwd_where(const NodeRkLaunch& L, int row0, RkFwdWhere& w) {
     w.p_tile = row0 / L.rpp;
     w.soff = 0;
     w.fsal = false;
+    w.ip = false;
+    w.ip_x = 0.f;
     if (L.ctl) {
         const double* c = L.ctl + (long)w.p_tile * NLBAC_DOPRI_CTL;
         if (c[C_DONE] > 0.0) return false;              // (uniform) this problem's solve has finished
         const int slot = (int)c[C_NACC];
         w.soff = (long)slot * L.slot_floats;
         w.fsal = slot > 0;
+        if (L.ip_out) {          // the controller's own test and abscissa (ode_control.h: accept && t + h >= t_end -> C_X)
+            const double t = c[C_T], h = c[C_H];
+            w.ip = t + h >= L.t_end;
+            w.ip_x = (float)((L.t_end - t) / h);
+        }
     }
     w.gK = L.K + w.soff;
     w.gY = L.Y + w.soff;
@@ -275,6 +291,37 @@ __device__ __forceinline__ void rk_fwd_outputs_and_control(const NodeRkLaunch& L
             w.gErr[(long)row * ns + r] = a;
         }
     }
+    if (w.ip) {      // (uniform per tile) the solve's result, should this attempt be accepted: one (row, component) per thread
+        static_assert(NTHR >= NLBAC_MLP_TILE * RK_MAX_NS, "one (row, component) per thread");
+        const int m = tid >> 3, r = tid & 7, row = row0 + m, sl = L.S_total - 1;
+        if (tid < NLBAC_MLP_TILE * RK_MAX_NS && r < ns) {
+            const float h = sH[m];
+            const float a0 = sY0[m * RK_MAX_NS + r];
+            float k[7], bl[RK_MAX_STAGES];
+#pragma unroll
+            for (int j = 0; j < 7; ++j) k[j] = sK[(j * NLBAC_MLP_TILE + m) * RK_MAX_NS + r];
+#pragma unroll
+            for (int j = 0; j < RK_MAX_STAGES; ++j) bl[j] = L.beta[sl][j];
+            float a1 = a0;                            // y1 = the last stage's input (the expression that wrote Y[6])
+#pragma unroll
+            for (int j = 0; j < 6; ++j) {
+                const float t = a1 + k[j] * (bl[j] * h);
+                a1 = (j < sl && bl[j] != 0.f) ? t : a1;
+            }
+            const float o = dopri_interp_value(a0, a1, k, h, w.ip_x);
+            if (row < n) L.ip_out[(long)row * ns + r] = o;
+            T.sF[m * RK_MAX_NS + r] = o;              // (f(x) of the last stage is no longer needed)
+        }
+        if (L.ip_kind == 1) {
+            __syncthreads();
+            if (tid < 2 * NLBAC_MLP_TILE) {          // the look-ahead point: component `which` of row mm
+                const int mm = tid >> 1, which = tid & 1, rw = row0 + mm;
+                const float th = T.sF[mm * RK_MAX_NS + 2];
+                const float v = T.sF[mm * RK_MAX_NS + which] + L.ip_l * (which ? sinf(th) : cosf(th));
+                if (rw < n) L.ip_p[(long)rw * 2 + which] = v;
+            }
+        }
+    }
     if (L.norm_mode < 0) return;
     __shared__ unsigned s_last;
     if (tid < 64) {
@@ -372,8 +419,9 @@ struct RkBwdTile {
     float* sDY0;   // [32][8]          running dy0
     float* sDU;    // [32][4]          running du
     float* sDX;    // [2][32][8]       dX of f_net / g_net for the current stage
+    float* sDYup;  // [32][8]          dL/dy1 of the step when the launch forms it itself (nlbac_rk_chain::interp_*)
     __host__ __device__ __forceinline__ static constexpr int floats() {
-        return RK_MAX_STAGES * NLBAC_MLP_TILE * RK_MAX_NS + NLBAC_MLP_TILE * (RK_MAX_NU + 1 + RK_MAX_NS + RK_MAX_NU + 2 * RK_MAX_NS);
+        return RK_MAX_STAGES * NLBAC_MLP_TILE * RK_MAX_NS + NLBAC_MLP_TILE * (RK_MAX_NU + 1 + RK_MAX_NS + RK_MAX_NU + 2 * RK_MAX_NS + RK_MAX_NS);
     }
     __device__ __forceinline__ void carve(float* p) {
         sDK = p;
@@ -382,11 +430,13 @@ struct RkBwdTile {
         sDY0 = sH + NLBAC_MLP_TILE;
         sDU = sDY0 + NLBAC_MLP_TILE * RK_MAX_NS;
         sDX = sDU + NLBAC_MLP_TILE * RK_MAX_NU;
+        sDYup = sDX + 2 * NLBAC_MLP_TILE * RK_MAX_NS;
     }
 };
 
 struct RkBwdWhere {
     long soff; int slot; bool chained, carry;
+    bool ip;       // this launch forms the step's dK / dy0 / dy1 from the gradient of the solve's result (interpolant backward)
     const float* gG; float* gdG; float* gdK; float* gdy0; const float* gdYup;
     int st_lo; bool stage0_data;
     __device__ __forceinline__ bool has_data(int st) const { return st >= st_lo && (st > 0 || stage0_data); }
@@ -402,6 +452,7 @@ __device__ __forceinline__ bool rk_bwd_where(const NodeRkBwdLaunch& L, int row0,
         w.soff = (long)w.slot * L.slot_floats;
     }
     w.carry = w.chained && L.back_idx > 0;    // not the problem's last step: gradients arrive from the slot behind
+    w.ip = L.ip_on && w.chained && !w.carry;
     w.gG = L.G + w.soff;
     w.gdG = L.dG ? L.dG + w.soff : nullptr;
     w.gdK = L.dK + w.soff;
@@ -420,8 +471,24 @@ __device__ __forceinline__ void rk_bwd_tile_constants(const NodeRkBwdLaunch& L, 
     // (all global loads first, then the LDS stores: see rk_fwd_tile_constants)
     constexpr int NY = (NLBAC_MLP_TILE * RK_MAX_NS + NTHR - 1) / NTHR, NU = (NLBAC_MLP_TILE * RK_MAX_NU + NTHR - 1) / NTHR;
     constexpr int NK = (RK_MAX_STAGES * NLBAC_MLP_TILE * RK_MAX_NS + NTHR - 1) / NTHR;
-    const bool du_in = L.du && L.du_acc, dy_in = w.gdy0 && L.dy0_in && !w.carry;
+    const bool du_in = L.du && L.du_acc, dy_in = w.gdy0 && L.dy0_in && !w.carry && !w.ip;
     float vu[NU], vdu[NU], vy[NY], vk[NK], vh = 0.f;
+    float ip_g = 0.f, ip_h = 0.f, ip_xx = 0.f;
+    if (w.ip) {      // (uniform) this thread's (row, component) of d loss / d y(t_end): every load up front with the others
+        static_assert(NTHR == NLBAC_MLP_TILE * RK_MAX_NS, "one (row, component) per thread");
+        const int m = tid >> 3, c = tid & 7, row = min(row0 + m, n - 1), p = row / L.rpp;
+        ip_h = (float)L.ctl[(long)p * NLBAC_DOPRI_CTL + C_HUSED];
+        ip_xx = (float)L.ctl[(long)p * NLBAC_DOPRI_CTL + C_X];
+        if (L.ip_kind == 1) {        // out-map 1 (ode_kernels.hip::dopri_interp_bwd_kernel's arithmetic)
+            float d0 = L.ip_dp[(long)row * 2 + 0], d1 = L.ip_dp[(long)row * 2 + 1];
+            if (L.ip_dp2) { d0 += L.ip_dp2[(long)row * 2 + 0]; d1 += L.ip_dp2[(long)row * 2 + 1]; }
+            const float th = L.ip_x[(long)row * ns + 2];
+            const float g2 = L.ip_l * (-sinf(th) * d0 + cosf(th) * d1);
+            ip_g = c == 0 ? d0 : (c == 1 ? d1 : (c == 2 ? g2 : 0.f));
+        } else {
+            ip_g = L.ip_dout[(long)row * ns + min(c, ns - 1)];
+        }
+    }
 #pragma unroll
     for (int it = 0; it < NU; ++it) {
         const int idx = tid + NTHR * it, m = (idx >> 2) & (NLBAC_MLP_TILE - 1), c = idx & 3;
@@ -446,11 +513,21 @@ __device__ __forceinline__ void rk_bwd_tile_constants(const NodeRkBwdLaunch& L, 
         const int m = rem >> 3, c = rem & 7;
         const long rc = (long)min(row0 + m, n - 1) * ns + min(c, ns - 1);
         float v = 0.f;
-        if (j < L.st_hi) {                    // (uniform per wave)
+        if (j < L.st_hi && !w.ip) {           // (uniform per wave)
             if (!w.carry) v = w.gdK[(long)j * n * ns + rc];
             else if (j == L.S_total - 1) v = (w.gdK + L.slot_floats)[rc];     // FSAL: next slot's dK[0]
         }
         vk[it] = v;
+    }
+    if (w.ip) {
+        float d0v, d1v, dk[7];
+        dopri_interp_grad(ip_g, ip_h, ip_xx, d0v, d1v, dk);
+        const bool ok = row0 + (tid >> 3) < n && (tid & 7) < ns;
+        vy[0] = d0v;
+        T.sDYup[tid] = ok ? d1v : 0.f;
+#pragma unroll
+        for (int it = 0; it < NK; ++it)
+            if (it < 7) vk[it] = dk[it];
     }
 #pragma unroll
     for (int it = 0; it < NU; ++it) {
@@ -499,7 +576,8 @@ __device__ __forceinline__ void rk_bwd_stage_algebra(const NodeRkBwdLaunch& L, c
     const int n = L.n, ns = L.n_s;
     for (int idx = tid; idx < NLBAC_MLP_TILE * ns; idx += NTHR) {
         const int m = idx / ns, c = idx - m * ns, row = row0 + m;
-        float d = (w.gdYup && st == L.S_total - 1 && row < n) ? w.gdYup[(long)row * ns + c] : 0.f;
+        float d = (w.gdYup && !w.ip && st == L.S_total - 1 && row < n) ? w.gdYup[(long)row * ns + c] : 0.f;
+        if (w.ip && st == L.S_total - 1) d = T.sDYup[m * RK_MAX_NS + c];
         d += T.sDX[m * RK_MAX_NS + c];
         d += T.sDX[(NLBAC_MLP_TILE + m) * RK_MAX_NS + c];
         T.sDY0[m * RK_MAX_NS + c] = T.sDY0[m * RK_MAX_NS + c] + d;

@@ -807,7 +807,7 @@ __global__ __launch_bounds__(256) void node_rr_bwd_kernel(const NodeRkBwdLaunch 
         //      dK_j += beta[st][j] h dY for j < st — one (row, component) per thread, every operand requested up front
         if (tid < NLBAC_MLP_TILE * RK_MAX_NS) {
             const int mm = tid >> 3, c = tid & 7, row = row0 + mm;
-            const bool cv = c < ns, up = w.gdYup && st == L.S_total - 1;
+            const bool cv = c < ns, up = (w.gdYup || w.ip) && st == L.S_total - 1;
             const float xf = T.sDX[mm * RK_MAX_NS + c], xg = T.sDX[(NLBAC_MLP_TILE + mm) * RK_MAX_NS + c];
             const float y0 = T.sDY0[mm * RK_MAX_NS + c], h = T.sH[mm];
             float kj[RK_MAX_STAGES - 1], bn[RK_MAX_STAGES - 1];
@@ -817,7 +817,7 @@ __global__ __launch_bounds__(256) void node_rr_bwd_kernel(const NodeRkBwdLaunch 
                 bn[j] = sBeta[st * RK_MAX_STAGES + j];
             }
             float d = 0.f;
-            if (up) d = w.gdYup[(long)min(row, n - 1) * ns + min(c, ns - 1)];      // (uniform branch)
+            if (up) d = w.ip ? T.sDYup[mm * RK_MAX_NS + c] : w.gdYup[(long)min(row, n - 1) * ns + min(c, ns - 1)];      // (uniform branch)
             d = (up && row < n) ? d : 0.f;
             d += xf;
             d += xg;

@@ -54,3 +54,54 @@ __device__ __forceinline__ void dopri_control_vals(double n0, double n1, int p, 
         }
     }
 }
+
+// ---------------------------------------------------------------------------------------------------------------------
+// The 4th-order interpolant of an accepted dopri5 step (torchdiffeq _interp_fit / _interp_evaluate with the mid-point
+// coefficients DPS_C_MID), one state component:  y(t0 + x h) = a0 + x (d + x (c + x (b + x a))).  Shared by the
+// interpolation launches (ode_kernels.hip) and the RK kernels that evaluate it themselves (nlbac_rk_chain::interp_*):
+// the same expressions, so the same bits.
+// ---------------------------------------------------------------------------------------------------------------------
+#define DPM0 (6025192743.0 / 30085553152.0 / 2.0)
+#define DPM2 (51252292925.0 / 65400821598.0 / 2.0)
+#define DPM3 (-2691868925.0 / 45128329728.0 / 2.0)
+#define DPM4 (187940372067.0 / 1594534317056.0 / 2.0)
+#define DPM5 (-1776094331.0 / 19743644256.0 / 2.0)
+#define DPM6 (11237099.0 / 235043384.0 / 2.0)
+
+// k[j]: the step's stage derivatives K_0..K_6 of this component; a0 = y0, a1 = y1 (the step's result)
+// (no multiply-add contraction inside: a, b, c cancel terms of size 32 |y| down to O(h^2), and whether the compiler
+// fuses a given multiply into the neighbouring add depends on the code around the inlined body — 6e-6 between two call sites)
+__device__ __forceinline__ float dopri_interp_value(float a0, float a1, const float (&k)[7], float h, float x) {
+#pragma clang fp contract(off)
+    const float cm[7] = {(float)DPM0, 0.f, (float)DPM2, (float)DPM3, (float)DPM4, (float)DPM5, (float)DPM6};
+    float ym = a0;
+#pragma unroll
+    for (int j = 0; j < 7; ++j)
+        if (cm[j] != 0.f) ym = ym + k[j] * (cm[j] * h);
+    const float f0 = k[0], f1 = k[6];
+    const float a = 2.f * h * (f1 - f0) - 8.f * (a1 + a0) + 16.f * ym;
+    const float b = h * (5.f * f0 - 3.f * f1) + 18.f * a0 + 14.f * a1 - 32.f * ym;
+    const float c = h * (f1 - 4.f * f0) - 11.f * a0 - 5.f * a1 + 16.f * ym;
+    const float d = h * f0;
+    return a0 + x * (d + x * (c + x * (b + x * a)));
+}
+
+// its backward for one component: g = d loss / d y(t0 + x h)  ->  d loss / d y0, d y1, d K_0..K_6
+__device__ __forceinline__ void dopri_interp_grad(float g, float h, float x, float& dy0, float& dy1, float (&dk)[7]) {
+#pragma clang fp contract(off)
+    const float cm[7] = {(float)DPM0, 0.f, (float)DPM2, (float)DPM3, (float)DPM4, (float)DPM5, (float)DPM6};
+    const float x2 = x * x, x3 = x2 * x, x4 = x2 * x2;
+    const float A = x4 * g, Bc = x3 * g, C = x2 * g, D = x * g;
+    const float ym = 16.f * A - 32.f * Bc + 16.f * C;
+    dy0 = g - 8.f * A + 18.f * Bc - 11.f * C + ym;
+    dy1 = -8.f * A + 14.f * Bc - 5.f * C;
+    const float f0b = h * (-2.f * A + 5.f * Bc - 4.f * C + D);
+    const float f1b = h * (2.f * A - 3.f * Bc + C);
+#pragma unroll
+    for (int j = 0; j < 7; ++j) {
+        float v = (cm[j] * h) * ym;
+        if (j == 0) v += f0b;
+        if (j == 6) v += f1b;
+        dk[j] = v;
+    }
+}

@@ -252,13 +252,6 @@ __global__ __launch_bounds__(256) void dopri_norm_control_kernel(const float* a,
     }
 }
 
-#define DPM0 (6025192743.0 / 30085553152.0 / 2.0)
-#define DPM2 (51252292925.0 / 65400821598.0 / 2.0)
-#define DPM3 (-2691868925.0 / 45128329728.0 / 2.0)
-#define DPM4 (187940372067.0 / 1594534317056.0 / 2.0)
-#define DPM5 (-1776094331.0 / 19743644256.0 / 2.0)
-#define DPM6 (11237099.0 / 235043384.0 / 2.0)
-
 struct InterpArg { float h[MAX_PROBLEMS]; float x[MAX_PROBLEMS]; const double* ctl; long slot_floats; };
 
 // device-driven chain: the last accepted step of problem p lives in step slot C_NACC (0 without slots)
@@ -297,19 +290,11 @@ __global__ __launch_bounds__(256) void dopri_interp_fwd_kernel(const float* y0, 
         K += (long)slot * ia.slot_floats;
         if (slot > 0) y0 = y1 - ia.slot_floats;       // (y1 points at the slot's last stage input: the predecessor's is its y0)
     }
-    const float cm[7] = {(float)DPM0, 0.f, (float)DPM2, (float)DPM3, (float)DPM4, (float)DPM5, (float)DPM6};
     for (int r = 0; r < n_s; ++r) {
-        const float a0 = y0[(long)i * n_s + r], a1 = y1[(long)i * n_s + r];
-        float ym = a0;
+        float k[7];
 #pragma unroll
-        for (int j = 0; j < 7; ++j)
-            if (cm[j] != 0.f) ym = ym + K[((long)j * n + i) * n_s + r] * (cm[j] * h);
-        const float f0 = K[(long)i * n_s + r], f1 = K[((long)6 * n + i) * n_s + r];
-        const float a = 2.f * h * (f1 - f0) - 8.f * (a1 + a0) + 16.f * ym;
-        const float b = h * (5.f * f0 - 3.f * f1) + 18.f * a0 + 14.f * a1 - 32.f * ym;
-        const float c = h * (f1 - 4.f * f0) - 11.f * a0 - 5.f * a1 + 16.f * ym;
-        const float d = h * f0;
-        out[(long)i * n_s + r] = a0 + x * (d + x * (c + x * (b + x * a)));
+        for (int j = 0; j < 7; ++j) k[j] = K[((long)j * n + i) * n_s + r];
+        out[(long)i * n_s + r] = dopri_interp_value(y0[(long)i * n_s + r], y1[(long)i * n_s + r], k, h, x);
     }
     if (om.kind == 1) {
         const float th = out[(long)i * n_s + 2];
@@ -330,8 +315,6 @@ __global__ __launch_bounds__(256) void dopri_interp_bwd_kernel(const float* dout
         const long off = (long)interp_slot(ia, i / rpp) * ia.slot_floats;
         dy0 += off; dy1 += off; dK += off;
     }
-    const float cm[7] = {(float)DPM0, 0.f, (float)DPM2, (float)DPM3, (float)DPM4, (float)DPM5, (float)DPM6};
-    const float x2 = x * x, x3 = x2 * x, x4 = x2 * x2;
     float gm[3] = {0.f, 0.f, 0.f};
     if (om.kind == 1) {
         float d0 = om.dp[i * 2 + 0], d1 = om.dp[i * 2 + 1];
@@ -341,19 +324,12 @@ __global__ __launch_bounds__(256) void dopri_interp_bwd_kernel(const float* dout
     }
     for (int r = 0; r < n_s; ++r) {
         const float g = (om.kind == 1) ? gm[r] : dout[(long)i * n_s + r];
-        const float A = x4 * g, Bc = x3 * g, C = x2 * g, D = x * g;
-        const float ym = 16.f * A - 32.f * Bc + 16.f * C;
-        dy0[(long)i * n_s + r] = g - 8.f * A + 18.f * Bc - 11.f * C + ym;
-        dy1[(long)i * n_s + r] = -8.f * A + 14.f * Bc - 5.f * C;
-        const float f0b = h * (-2.f * A + 5.f * Bc - 4.f * C + D);
-        const float f1b = h * (2.f * A - 3.f * Bc + C);
+        float d0v, d1v, dk[7];
+        dopri_interp_grad(g, h, x, d0v, d1v, dk);
+        dy0[(long)i * n_s + r] = d0v;
+        dy1[(long)i * n_s + r] = d1v;
 #pragma unroll
-        for (int j = 0; j < 7; ++j) {
-            float v = (cm[j] * h) * ym;
-            if (j == 0) v += f0b;
-            if (j == 6) v += f1b;
-            dK[((long)j * n + i) * n_s + r] = v;
-        }
+        for (int j = 0; j < 7; ++j) dK[((long)j * n + i) * n_s + r] = dk[j];
     }
 }
 

@@ -657,6 +657,21 @@ class AffineNodeSolver:
         om.x = self.ctx["out"].data_ptr()
         return om
 
+    def _interp_nets(self):
+        return C.byref(self.f.desc), C.byref(self.g.desc)
+
+    def _interp_fold(self):
+        """The interpolation at t_end is evaluated by the attempt launches themselves and its backward by the last step's
+        backward launch (nlbac_rk_chain::interp_*; the register-resident kernels): no nlbac_dopri_interp_fwd / _bwd
+        launches.  ``interp_fold = False`` (NLBAC_INTERP_FOLD=0) keeps the two launches — the cross-check."""
+        on = self.__dict__.get("interp_fold")
+        if on is None:
+            on = self.interp_fold = os.environ.get("NLBAC_INTERP_FOLD", "1") != "0"
+        ok = self.__dict__.get("_interp_ok")
+        if ok is None:
+            ok = self._interp_ok = bool(_lib.load().nlbac_rk_interp_ok(*self._interp_nets()))
+        return on and ok and self.fused
+
     def _chain_ok(self, P, rpp):
         return bool(self.device_loop and self.fused and (P == 1 or rpp % _lib.MLP_TILE == 0))
 
@@ -715,7 +730,14 @@ class AffineNodeSolver:
         self._chain_control(ws0, pool, ch[0], y0, u, 0, P, rpp)
         self._rk_fused(ws0, y0, u, P, rpp, "probe", 1, 2, h_dev=cp + 8 * 6, save_acts=False, chain=ch[1])
         self._chain_control(ws0, pool, ch[1], y0, u, 1, P, rpp)
-        ctx["chain"] = dict(pool=pool, ws0=ws0, ch=ch[2], attempts=0, y0=y0)
+        ip, om = self._interp_fold(), self._out_map_fwd(n)
+        if ip and om is not None and isinstance(self, ConcatNodeSolver):
+            ip = False                # (the single-net kernels evaluate no out-map)
+        if ip:
+            ch[2].interp_out = self._buf("dopri_out", n, self.n_s).data_ptr()
+            if om is not None:
+                ch[2].interp_kind, ch[2].interp_l, ch[2].interp_p = om.kind, om.l, om.p
+        ctx["chain"] = dict(pool=pool, ws0=ws0, ch=ch[2], attempts=0, y0=y0, ip=ip, ip_om=om is not None)
         self._chain_attempts(max(1, int(self.__dict__.get("_chain_len", 1))))
 
     def _chain_attempts(self, k):
@@ -757,12 +779,16 @@ class AffineNodeSolver:
                 raise _lib.NlbacError("dopri5: max_num_steps exceeded")
             self._chain_attempts(2)
         out = self._buf("dopri_out", n, ns)
-        # (the owner's map of the output — the Unicycle tasks' look-ahead point — is evaluated by this launch)
-        om = self._out_map_fwd(n)
-        _lib.call("nlbac_dopri_interp_fwd", ctx["y0"].data_ptr(), ws0.Y[6].data_ptr(), ws0.K.data_ptr(), None, None,
-                  ctl.data_ptr(), P, rpp, ns, out.data_ptr(), pool.slot_floats, C.byref(om) if om is not None else None,
-                  stream_ptr())
-        ctx["out_mapped"] = om is not None
+        if st.get("ip"):
+            # the attempt that finished each problem has written its rows of `out` (and of the owner's map) itself
+            ctx["out_mapped"] = st["ip_om"]
+        else:
+            # (the owner's map of the output — the Unicycle tasks' look-ahead point — is evaluated by this launch)
+            om = self._out_map_fwd(n)
+            _lib.call("nlbac_dopri_interp_fwd", ctx["y0"].data_ptr(), ws0.Y[6].data_ptr(), ws0.K.data_ptr(), None, None,
+                      ctl.data_ptr(), P, rpp, ns, out.data_ptr(), pool.slot_floats, C.byref(om) if om is not None else None,
+                      stream_ptr())
+            ctx["out_mapped"] = om is not None
         if c is not None:
             nst = [int(c[p, 10]) for p in range(P)]
             nacc = [int(c[p, 12]) for p in range(P)]
@@ -803,11 +829,20 @@ class AffineNodeSolver:
         du = self._buf("du", n, nu) if need_du else None
         om = self._out_map_bwd(n) if dout is None else None
         assert dout is not None or om is not None, "backward(None) needs an output map (set_out_map) with its gradients"
-        _lib.call("nlbac_dopri_interp_bwd", dout.data_ptr() if dout is not None else None, None, None, ctl.data_ptr(), P,
-                  rpp, ns, ws0.dy0.data_ptr(), ws0.dy1.data_ptr(), ws0.dK.data_ptr(), pool.slot_floats,
-                  C.byref(om) if om is not None else None, s)
         bch = _lib.RkChain()
         bch.ctl, bch.slot_floats, bch.n_slots, bch.hslots, bch.norm_mode = ch.ctl_w, pool.slot_floats, pool.n_slots, ch.hslots, -1
+        if st.get("ip") and not (om is not None and isinstance(self, ConcatNodeSolver)):
+            # the backward of the interpolant is the prologue of each problem's last-step launch (back_idx 0)
+            bch.interp_bwd = 1
+            if om is not None:
+                bch.interp_kind, bch.interp_l, bch.interp_dp, bch.interp_dp2, bch.interp_x = om.kind, om.l, om.dp, om.dp2, om.x
+            else:
+                assert dout.is_contiguous() and dout.shape == (n, ns)
+                bch.interp_dout = dout.data_ptr()
+        else:
+            _lib.call("nlbac_dopri_interp_bwd", dout.data_ptr() if dout is not None else None, None, None, ctl.data_ptr(), P,
+                      rpp, ns, ws0.dy0.data_ptr(), ws0.dy1.data_ptr(), ws0.dK.data_ptr(), pool.slot_floats,
+                      C.byref(om) if om is not None else None, s)
         for b in range(nb):
             self._rk_fused_bwd(ws0, u, P, rpp, "dopri5", True, need_dy0, need_params, None, None, 0, ws0.dy1, du,
                                b == 0, chain=bch, back_idx=b)
@@ -1395,6 +1430,9 @@ class ConcatNodeSolver(AffineNodeSolver):
         if self._net_arr is None:
             self._net_arr = mlp_array([self.net.desc])
         return self._net_arr
+
+    def _interp_nets(self):
+        return C.byref(self.net.desc), None
 
     # -- continuous adjoint (odeint_adjoint) of the single-net field ---------------------------------------------
     # The base class drives the solve (initial step, attempts, mixed norm, commit, interpolation, parameter-adjoint

@@ -45,6 +45,8 @@ class _Task:
 
     def reserve(self, solver, n, P):
         """Pre-allocate a solver's buffers for (n rows, P problems, the agent's current method) once."""
+        if not self.agent.fold_launches:
+            solver.interp_fold = False        # (NLBAC_FOLD=0: the interpolation launches too, as every other folded step)
         key = (id(solver), n, P, self.agent.solver)
         seen = self.__dict__.setdefault("_reserved", set())
         if key not in seen:

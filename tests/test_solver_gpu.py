@@ -293,3 +293,45 @@ def test_single_net_solver_chain_matches_oracle(T):
     assert np.linalg.norm(a - b) / np.linalg.norm(b) <= 5e-3
     if T > 0.1:
         assert len(sol.ctx["steps"]) >= 2, "the long horizon must need several accepted steps"
+
+
+@pytest.mark.parametrize("kind", ["affine", "single-net"])
+@pytest.mark.parametrize("T", [0.02, 0.3])
+def test_interpolation_inside_the_rk_launches_matches_the_interpolation_launches(kind, T):
+    """nlbac_rk_chain::interp_*: the attempt that finishes a problem writes the interpolant at t_end itself, the last
+    step's backward launch forms dK / dy0 / dy1 itself — against nlbac_dopri_interp_fwd / _bwd as launches of their own
+    (``interp_fold = False``) on the same inputs: two problems with their own step sequences (T = 0.3: several step
+    slots), identical arithmetic, so identical bits."""
+    from nlbac_amd.odeint import AffineNodeSolver, ConcatNodeSolver
+    gen = torch.Generator().manual_seed(5)
+    rpp = 96
+    if kind == "affine":
+        agent, env = make_agent(64, 64, 0, "dopri5")
+        y0 = torch.cat([torch.rand(2 * rpp, 2, generator=gen) * 4 - 2, torch.rand(2 * rpp, 1, generator=gen) * 6 - 3], 1)
+        u = (torch.rand(2 * rpp, 2, generator=gen) * 2 - 1) * torch.tensor([3.5, 12.0])
+        u[rpp:] *= 5.0
+        cls, ns = AffineNodeSolver, 3
+    else:
+        agent, env = make_agent(64, 64, 0, "dopri5", "SimulatedCars")
+        y0 = torch.rand(2 * rpp, 10, generator=gen) * 2 - 1
+        u = torch.rand(2 * rpp, 2, generator=gen) * 2 - 1
+        y0[rpp:] *= 2.0
+        cls, ns = ConcatNodeSolver, 10
+    dout = torch.randn(2 * rpp, ns, generator=gen)
+    res = []
+    for fold in (True, False):
+        sol = cls(agent.neural_ode_model, "cuda")
+        sol.keep_acts = False
+        assert sol._interp_fold(), "nlbac_rk_interp_ok refuses the reference's NODE shape"
+        sol.interp_fold = fold
+        out = sol.forward(y0.cuda(), u.cuda(), 2, rpp, "dopri5", T).clone()
+        assert sol.ctx.get("chain") and bool(sol.ctx["chain"]["ip"]) == fold
+        du, dy0 = sol.backward(dout.cuda(), need_du=True, need_dy0=True)
+        res.append((out, du.clone(), dy0.clone(), [len([a for a in sol.ctx["info"] if a[p] is not None]) for p in range(2)]))
+    (o1, du1, dy1, n1), (o0, du0, dy0_, n0) = res
+    assert n1 == n0
+    if T > 0.1:
+        assert max(n1) > 1, "the long horizon was meant to take several steps"
+    assert torch.equal(o1, o0), "x(t_end): %.3e" % float((o1 - o0).abs().max())
+    assert torch.equal(du1, du0), "d/du: %.3e" % float((du1 - du0).abs().max())
+    assert torch.equal(dy1, dy0_), "d/dy0: %.3e" % float((dy1 - dy0_).abs().max())

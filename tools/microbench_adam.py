@@ -6,7 +6,7 @@ sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(
 import torch
 import nlbac_amd
 from nlbac_amd import _lib
-from nlbac_amd._lib import stream_ptr
+from nlbac_amd.arena import stream_ptr
 from test_agent_parity_gpu import make_agent
 
 B = int(sys.argv[1]) if len(sys.argv) > 1 else 4096
