@@ -32,7 +32,7 @@
 extern "C" {
 #endif
 
-#define NLBAC_ABI_VERSION 6 /* bumped whenever an exported signature or struct changes; nlbac_abi_version() returns it */
+#define NLBAC_ABI_VERSION 7 /* bumped whenever an exported signature or struct changes; nlbac_abi_version() returns it */
 #define NLBAC_MAX_LAYERS 6
 #define NLBAC_MAX_NETS 8
 #define NLBAC_MLP_TILE 32 /* samples per workgroup in the MLP kernels */
@@ -258,6 +258,14 @@ typedef struct nlbac_dy_head {
     nlbac_actor_scalar_args actor;
     /* 2, 3 */
     float *partials; unsigned *ticket; float mul; float *out;
+    /* 3, optional (ABI 7; cb_kind != 0): the net right behind the Q pairs (index 2 n_prob) takes its dL/dy from the
+     * task's constraint backward, evaluated by its workgroups for their rows instead of by a launch of its own.
+     * cb_kind 1 = nlbac_unicycle_constraints_bwd (same arithmetic, same outputs left in memory: cb_dps_next (2B, 2)
+     * and cb_dV (B) = that net's dL/dy; io[2 n_prob].dy is not read). */
+    int cb_kind, cb_nh;
+    const float *cb_ps_next, *cb_matr, *cb_bmatr, *cb_hazards, *cb_sc;
+    float cb_dt, cb_batch;
+    float *cb_dps_next, *cb_dV;
 } nlbac_dy_head;
 /* policy_loss_1, alpha_loss into sc; d alpha_loss / d log_alpha into g_log_alpha
  * (sac_cbf_clf.py:292-308) for problems first_problem .. first_problem+P-1 (0 primary, 1 backup);

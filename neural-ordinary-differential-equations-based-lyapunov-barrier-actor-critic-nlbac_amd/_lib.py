@@ -81,7 +81,10 @@ class DyHead(C.Structure):
                 ("out_x", C.c_void_p),
                 ("qa", C.c_void_p), ("qb", C.c_void_p), ("logp", C.c_void_p), ("dqa", C.c_void_p), ("dqb", C.c_void_p),
                 ("n_prob", C.c_int), ("actor", ActorScalarArgs),
-                ("partials", C.c_void_p), ("ticket", C.c_void_p), ("mul", C.c_float), ("out", C.c_void_p)]
+                ("partials", C.c_void_p), ("ticket", C.c_void_p), ("mul", C.c_float), ("out", C.c_void_p),
+                ("cb_kind", C.c_int), ("cb_nh", C.c_int), ("cb_ps_next", C.c_void_p), ("cb_matr", C.c_void_p),
+                ("cb_bmatr", C.c_void_p), ("cb_hazards", C.c_void_p), ("cb_sc", C.c_void_p), ("cb_dt", C.c_float),
+                ("cb_batch", C.c_float), ("cb_dps_next", C.c_void_p), ("cb_dV", C.c_void_p)]
 
 
 class RkChain(C.Structure):
@@ -221,7 +224,7 @@ def build(verbose=False):
     return LIB_PATH
 
 
-ABI_VERSION = 6      # == NLBAC_ABI_VERSION of include/nlbac_hip.h (bumped with every signature / struct change)
+ABI_VERSION = 7      # == NLBAC_ABI_VERSION of include/nlbac_hip.h (bumped with every signature / struct change)
 
 
 def _stale_sources():

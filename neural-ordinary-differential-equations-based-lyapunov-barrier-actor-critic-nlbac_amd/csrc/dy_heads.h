@@ -155,6 +155,47 @@ __device__ __forceinline__ void dy_head_rows(const nlbac_dy_head& H, int inet, i
             for (int off = 16; off > 0; off >>= 1) e2 += __shfl_down(e2, off, 64);
         }
         pend.v0 = e2;
+    } else if (H.kind == 3 && inet >= 2 * H.n_prob) {
+        // the net behind the Q pairs: its dL/dy is the constraint backward's dV_next (cb_kind 1:
+        // unicycle_constraints_bwd_kernel's arithmetic, agent_kernels.hip — d ps_next of both controllers from the CBF
+        // terms, dV_next from the CLF term), one thread per row of the tile
+        // Two phases so that every global load of the tile is in flight at once: (row, hazard, controller) per thread
+        // forms that hazard's addend, then one thread per row sums the addends in hazard order (the launch's order).
+        __shared__ float s_cb[TILE * 2 * 16 * 2];
+        const int NH = H.cb_nh;
+        const float* sc = H.cb_sc;
+        for (int idx = tid; idx < TILE * 16; idx += 256) sdy[idx] = 0.f;
+        for (int t = tid; t < TILE * 2 * NH; t += 256) {
+            const int r = t / (2 * NH), rem = t - r * 2 * NH, h = rem >> 1, which = rem & 1, i = min(row0 + r, B - 1);
+            const float hx = H.cb_hazards[h * 2], hy = H.cb_hazards[h * 2 + 1];
+            const long pr = which ? (long)(B + i) : (long)i;
+            const float n0 = H.cb_ps_next[pr * 2], n1 = H.cb_ps_next[pr * 2 + 1];
+            const float term = which ? H.cb_bmatr[(long)i * NH + h] : H.cb_matr[(long)i * (NH + 1) + h];
+            const float coef = sc[(which ? SC_BCOEF : SC_COEF) + h];
+            const float g = -((coef / H.cb_batch) / H.cb_dt);
+            const bool on = term > 0.f;
+            s_cb[((r * 2 + which) * 16 + h) * 2 + 0] = on ? g * (n0 - hx) : 0.f;
+            s_cb[((r * 2 + which) * 16 + h) * 2 + 1] = on ? g * (n1 - hy) : 0.f;
+        }
+        float lya = 0.f, cl = 0.f;
+        if (tid < TILE) {
+            lya = H.cb_matr[(long)min(row0 + tid, B - 1) * (NH + 1) + NH];
+            cl = sc[SC_COEF + NH];
+        }
+        __syncthreads();
+        if (tid < TILE && row0 + tid < B) {
+            const int i = row0 + tid;
+            float d0 = 0.f, d1 = 0.f, e0 = 0.f, e1 = 0.f;
+            for (int h = 0; h < NH; ++h) {       // (an inactive term's addend is +0: the sum is the launch's, term by term)
+                d0 += s_cb[((tid * 2 + 0) * 16 + h) * 2 + 0]; d1 += s_cb[((tid * 2 + 0) * 16 + h) * 2 + 1];
+                e0 += s_cb[((tid * 2 + 1) * 16 + h) * 2 + 0]; e1 += s_cb[((tid * 2 + 1) * 16 + h) * 2 + 1];
+            }
+            H.cb_dps_next[i * 2] = d0; H.cb_dps_next[i * 2 + 1] = d1;
+            H.cb_dps_next[(long)(B + i) * 2] = e0; H.cb_dps_next[(long)(B + i) * 2 + 1] = e1;
+            const float dv = (lya > 0.f) ? ((cl / H.cb_batch) / H.cb_dt) : 0.f;
+            H.cb_dV[i] = dv;
+            sdy[tid * 16] = dv;
+        }
     } else if (H.kind == 3) {
         // min(Q1, Q2)(s, pi) branch gradients; net inet = (controller inet / 2, Q1 / Q2 = inet % 2)
         const int p = inet >> 1, which = inet & 1;
@@ -208,7 +249,7 @@ __device__ __forceinline__ void dy_head_finish(const nlbac_dy_head& H, int inet,
         // the Q1 workgroups publish the tile's sums of (alpha logp - min q, logp); the last of them finishes
         // policy_loss_1 / alpha loss / d log_alpha of every controller (actor_scalars_one)
         const int p = inet >> 1, which = inet & 1, n_prob = H.n_prob;
-        if (which == 0) {
+        if (which == 0 && inet < 2 * n_prob) {        // (the net behind the Q pairs — cb_kind — has no batch sums)
             const float v2[2] = {pend.v0, pend.v1};
             if (publish_and_elect_grouped<2>(H.partials + ((long)p * n_tiles + tile) * 2, v2, H.ticket, (unsigned)(p * n_tiles + tile),
                                              (unsigned)(n_prob * n_tiles))) {

@@ -295,7 +295,8 @@ __global__ __launch_bounds__(256, 2) void mlp_bwd_data_kernel(const MlpLaunch L,
     // (the tile's dy and input rows: every global load issued before the first LDS store — clamped addresses, selects
     // afterwards; as guarded loads in two-iteration loops they were up to six dependent round trips at the head of every
     // tile's latency chain)
-    const bool plain_dy = H.kind == 0 || (H.kind == 3 && (int)blockIdx.y >= 2 * H.n_prob);     // (kind 3: nets behind the Q pairs read io.dy)
+    // (kind 3: nets behind the Q pairs read io.dy — but for the first of them when the head evaluates the constraint backward: cb_kind)
+    const bool plain_dy = H.kind == 0 || (H.kind == 3 && (int)blockIdx.y >= 2 * H.n_prob && !(H.cb_kind && (int)blockIdx.y == 2 * H.n_prob));
     {
         float vdy[2] = {0.f, 0.f}, vx0[2] = {0.f, 0.f}, vx1[2] = {0.f, 0.f};
         const bool has_x1 = io.x1 != nullptr && io.x1_dim > 0;
@@ -1160,7 +1161,13 @@ extern "C" int nlbac_mlp_bwd_data_head(const nlbac_mlp* nets, const nlbac_mlp_io
         for (int p = 0; p < H.n_prob; ++p)
             NLBAC_REQUIRE(H.actor.log_alpha[p] && H.actor.g_log_alpha[p], "%s: actor head: missing log_alpha pointers", who);
         for (int i = 0; i < 2 * H.n_prob; ++i) NLBAC_REQUIRE(nets[i].out_dim == 1, "%s: actor head: scalar nets", who);
-        for (int i = 2 * H.n_prob; i < n_nets; ++i) NLBAC_REQUIRE(io[i].dy, "%s: net %d needs dy", who, i);
+        for (int i = 2 * H.n_prob + (H.cb_kind ? 1 : 0); i < n_nets; ++i) NLBAC_REQUIRE(io[i].dy, "%s: net %d needs dy", who, i);
+        if (H.cb_kind) {
+            NLBAC_REQUIRE(H.cb_kind == 1 && n_nets > 2 * H.n_prob && nets[2 * H.n_prob].out_dim == 1 && H.cb_nh >= 1 && H.cb_nh <= 16 &&
+                              H.cb_ps_next && H.cb_matr && H.cb_bmatr && H.cb_hazards && H.cb_sc && H.cb_dps_next && H.cb_dV &&
+                              H.cb_dt > 0.f && H.cb_batch > 0.f,
+                          "%s: actor head: the constraint backward (cb_kind 1) needs a scalar net behind the Q pairs and all of its pointers", who);
+        }
     }
     return mlp_bwd_data_launch(nets, io, n_nets, B, H, who, s);
 }

@@ -244,7 +244,8 @@ __global__ __launch_bounds__(256, 3) void mlp_rrq_bwd_kernel(const MlpLaunch L, 
     }
 
     // ---- dL/dy (and, for the skinny partials, the input rows) of the tile -> LDS
-    const bool plain_dy = H.kind == 0 || (H.kind == 3 && (int)blockIdx.y >= 2 * H.n_prob);     // (kind 3: nets behind the Q pairs read io.dy)
+    // (kind 3: nets behind the Q pairs read io.dy — but for the first of them when the head evaluates the constraint backward: cb_kind)
+    const bool plain_dy = H.kind == 0 || (H.kind == 3 && (int)blockIdx.y >= 2 * H.n_prob && !(H.cb_kind && (int)blockIdx.y == 2 * H.n_prob));
     DyHeadPending pend;
     pend.v0 = pend.v1 = 0.f;
     {

@@ -205,15 +205,24 @@ class UnicycleTask(_Task):
              ws.Vn.data_ptr(), self.hazards.data_ptr(), self.num_cbfs, r_coll, dt, float(a.gamma_b), self.gamma_l, B,
              ws.matr.data_ptr(), ws.bmatr.data_ptr(), ws.part_c.data_ptr(), *a.auglag_fused(ws, self.num_cbfs, lam_upd), s)
         a.auglag(ws, self.num_cbfs, lam_upd)
-        call("nlbac_unicycle_constraints_bwd", ws.ps_next2.data_ptr(), ws.matr.data_ptr(), ws.bmatr.data_ptr(),
-             self.hazards.data_ptr(), self.num_cbfs, dt, float(a.batch_size), B, sc, ws.dps_next2.data_ptr(),
-             ws.dVn.data_ptr(), s)
-        if a.world == 1 and a.fold_launches:       # dV_next -> d ps_next (rows [0,B)), together with the Q(s, pi) nets' dx
+        if a.world == 1 and a.fold_launches:
+            # dV_next -> d ps_next (rows [0,B)), together with the Q(s, pi) nets' dx; the constraint backward itself (d ps_next
+            # of both controllers from the CBF terms, dV_next from the CLF term) is the prologue of V's workgroups in that
+            # launch (nlbac_dy_head::cb_kind 1): no nlbac_unicycle_constraints_bwd launch
             NP = ws.np_now
-            call("nlbac_mlp_bwd_data_head", P.n_q5v, P.io_q5v, 2 * NP + 1, B,
-                 C.byref(a._actor_q_head(ws, P, NP, B * a.world)), s)
+            H = P.__dict__.get("head_actor_q_cb")
+            if H is None:
+                H = P.head_actor_q_cb = _lib.DyHead.from_buffer_copy(a._actor_q_head(ws, P, NP, B * a.world))
+                H.cb_kind, H.cb_nh = 1, self.num_cbfs
+                H.cb_ps_next, H.cb_matr, H.cb_bmatr = ws.ps_next2.data_ptr(), ws.matr.data_ptr(), ws.bmatr.data_ptr()
+                H.cb_hazards, H.cb_sc, H.cb_dt, H.cb_batch = self.hazards.data_ptr(), sc, dt, float(a.batch_size)
+                H.cb_dps_next, H.cb_dV = ws.dps_next2.data_ptr(), ws.dVn.data_ptr()
+            call("nlbac_mlp_bwd_data_head", P.n_q5v, P.io_q5v, 2 * NP + 1, B, C.byref(H), s)
             ws.q5_bwd_done = True
         else:
+            call("nlbac_unicycle_constraints_bwd", ws.ps_next2.data_ptr(), ws.matr.data_ptr(), ws.bmatr.data_ptr(),
+                 self.hazards.data_ptr(), self.num_cbfs, dt, float(a.batch_size), B, sc, ws.dps_next2.data_ptr(),
+                 ws.dVn.data_ptr(), s)
             call("nlbac_mlp_bwd_data", P.n_l, P.io_vn, 1, B, s)
         if mapped:
             du2, _ = self.solver.backward(None, need_du=True)
