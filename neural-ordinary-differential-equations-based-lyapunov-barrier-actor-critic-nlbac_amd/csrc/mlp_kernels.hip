@@ -42,7 +42,7 @@ __global__ __launch_bounds__(256) void mlp_pack_kernel(const MlpLaunch L) {
     for (int l = 0; l < nwide; ++l) {
         const int K = (l == 0) ? net.in_dim : hid;
         const float* W = net.params + net.w_off[l];
-        {   // forward pack: tiles over N=hid, chunks over K
+        if (net.pf_off[l] >= 0) {   // forward pack: tiles over N=hid, chunks over K
             const int KC = pad8(K) >> 3, NT = pad32(hid) >> 5;
             float* P = net.packed + net.pf_off[l];
             const long total = (long)NT * KC * 256;
@@ -1018,7 +1018,9 @@ extern "C" int nlbac_mlp_pack_layout(nlbac_mlp* net) {
     const int nwide = net->n_layers - 1, hid = net->hid;
     long off = 0;
     for (int l = 0; l < NLBAC_MAX_LAYERS; ++l) { net->pf_off[l] = -1; net->pb_off[l] = -1; }
-    for (int l = 0; l < nwide; ++l) {
+    // (nets whose every launch runs on the register-resident kernels get no 32x32x2 packs: pf_off / pb_off stay -1)
+    const bool tile_packs = !nlbac_mlp_rr_serves_shape(net->n_layers, net->in_dim, hid, net->out_dim);
+    for (int l = 0; l < nwide && tile_packs; ++l) {
         const int K = (l == 0) ? net->in_dim : hid;
         net->pf_off[l] = (int)off;
         off += (long)(((hid + 31) & ~31) >> 5) * (((K + 7) & ~7) >> 3) * 256;
@@ -1070,6 +1072,9 @@ static int mlp_fwd_launch(const nlbac_mlp* nets, const nlbac_mlp_io* io, int n_n
     for (int i = 0; i < n_nets; ++i)
         NLBAC_REQUIRE(!io[i].masks, "%s: net %d: ReLU mask words are written by the register-resident kernels only "
                       "(nlbac_mlp_masks_ok)", who, i);
+    for (int i = 0; i < n_nets; ++i)
+        NLBAC_REQUIRE(nets[i].pf_off[0] >= 0, "%s: net %d has no 32x32x2 packs (its launches run on the register-resident kernels: "
+                      "all nets of a launch must then have its width)", who, i);
     const size_t lds = (size_t)2 * NLBAC_MLP_TILE * L.ld * sizeof(float);
     const dim3 grid(nlbac_ceil_div(B, NLBAC_MLP_TILE), n_nets);
     switch (tile_mode(nets, n_nets)) {
@@ -1123,6 +1128,9 @@ static int mlp_bwd_data_launch(const nlbac_mlp* nets, const nlbac_mlp_io* io, in
     }
     for (int i = 0; i < n_nets; ++i)
         NLBAC_REQUIRE(io[i].acts, "%s: net %d: the LDS-tiled kernel gates with the saved activations (acts), not mask words", who, i);
+    for (int i = 0; i < n_nets; ++i)
+        NLBAC_REQUIRE(nets[i].pf_off[0] >= 0, "%s: net %d has no 32x32x2 packs (its launches run on the register-resident kernels: "
+                      "all nets of a launch must then have its width)", who, i);
     const size_t lds = ((size_t)2 * NLBAC_MLP_TILE * L.ld + 2 * NLBAC_MLP_TILE * 16) * sizeof(float);
     const dim3 grid(nlbac_ceil_div(B, NLBAC_MLP_TILE), n_nets);
     switch (tile_mode(nets, n_nets)) {

@@ -22,6 +22,7 @@ struct MlpLaunch {
 // take the launch), < 0 = error.
 int nlbac_mlp_rr_fwd_launch(const MlpLaunch& L, int n_nets, const nlbac_gauss_head& G, const char* who, hipStream_t s);
 bool nlbac_mlp_rr_eligible(const nlbac_mlp* nets, int n_nets);
+bool nlbac_mlp_rr_serves_shape(int n_layers, int in_dim, int hid, int out_dim);
 // The register-resident data backward of the same nets (NLBAC_MLP_RR_BWD=0 keeps the LDS-tiled kernel): same return values.
 int nlbac_mlp_rr_bwd_launch(const MlpLaunch& L, int n_nets, const nlbac_dy_head& H, const char* who, hipStream_t s);
 

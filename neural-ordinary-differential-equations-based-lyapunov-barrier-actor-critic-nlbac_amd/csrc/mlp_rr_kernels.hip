@@ -492,6 +492,16 @@ static bool mrr_bwd_enabled() {
     return on;
 }
 
+// Every launch of a net of this shape — forward and data backward — is served by the register-resident kernels (so its
+// 32x32x2 fragment packs are never read: nlbac_mlp_pack_layout then leaves them out, and the optimiser has half as many
+// fragment slots to refresh per weight).  Shape and the process-wide switches only: the per-launch conditions of
+// nlbac_mlp_rr_eligible beyond them compare the nets of ONE launch (equal widths), and a launch that mixes widths is
+// refused by the LDS-tiled launcher for such a net instead of reading packs that do not exist.
+bool nlbac_mlp_rr_serves_shape(int n_layers, int in_dim, int hid, int out_dim) {
+    return mrr_enabled() && mrr_bwd_enabled() && rr_kind_of(n_layers, hid) == RR_KIND_PANEL &&
+           (hid == 64 || hid == 128 || hid == 256) && in_dim <= MRR_MAX_IN && out_dim <= 16;
+}
+
 int nlbac_mlp_rr_bwd_launch(const MlpLaunch& L, int n_nets, const nlbac_dy_head& H, const char* who, hipStream_t s) {
     if (!mrr_bwd_enabled() || !nlbac_mlp_rr_eligible(L.net, n_nets)) return 1;
     {

@@ -46,12 +46,20 @@ def test_ctypes_structs_match_header_sizes(lib):
     net = _lib.Mlp()
     net.n_layers, net.in_dim, net.hid, net.out_dim = 3, 9, 256, 1
     n = lib.nlbac_mlp_pack_layout(_lib.C.byref(net))
-    # layer0 fwd: 8 tiles x 2 chunks ; layer1 fwd: 8 x 32 ; layer1 bwd: 8 x 32  (x256 floats)
-    # (+ three fragment blocks behind the panels: layer 0 forward, last layer and layer 0 transposed for the data backward)
-    assert n == (8 * 2 + 8 * 32 + 8 * 32) * 256 + 2 * 256 * 256 + 3 * 4 * 16 * 64
+    # ONE hid x hid layer of width 64 / 128 / 256, <= 15 inputs, <= 16 outputs: every launch of the net runs on the
+    # register-resident kernels, so it has NO 32x32x2 packs (pf_off / pb_off = -1; the optimiser refreshes two fragment
+    # slots per weight instead of four) — the two panel packs of the hid x hid layer (hid^2 floats each) and three
+    # fragment blocks behind them: layer 0 forward, last layer and layer 0 transposed for the data backward
+    assert n == 2 * 256 * 256 + 3 * 4 * 16 * 64
+    assert all(net.pf_off[l] == -1 and net.pb_off[l] == -1 for l in range(3))
+    assert net.rr_kind == 2 and net.rr_fwd_off == 0 and net.rr_bwd_off == 256 * 256 and net.packed_floats == n
+    # a 3-layer net the register-resident kernels do not take (20 inputs) keeps the tile packs:
+    # layer0 fwd: 8 tiles x 3 chunks ; layer1 fwd: 8 x 32 ; layer1 bwd: 8 x 32  (x256 floats), the panels behind them
+    net = _lib.Mlp()
+    net.n_layers, net.in_dim, net.hid, net.out_dim = 3, 20, 256, 1
+    n = lib.nlbac_mlp_pack_layout(_lib.C.byref(net))
+    old = (8 * 3 + 8 * 32 + 8 * 32) * 256
     assert net.pf_off[0] == 0 and net.pb_off[0] == -1 and net.pb_off[1] > net.pf_off[1] > 0
-    # ... and, having ONE hid x hid layer of a width divisible by 32, the two panel packs of it (hid^2 floats each)
-    old = (8 * 2 + 8 * 32 + 8 * 32) * 256
     assert net.rr_kind == 2 and net.rr_fwd_off == old and net.rr_bwd_off == old + 256 * 256 and net.packed_floats == n
     # a NODE-sized net (3 -> 100 -> 100 -> 100 -> 100 -> 3) also gets the RR packs of its three 100 x 100 layers:
     # 7 output blocks x 25 k-steps = 175 MFMAs = 44 float4 per lane and layer, forward and backward
