@@ -124,9 +124,30 @@ int nlbac_mlp_fwd(const nlbac_mlp *nets, const nlbac_mlp_io *io, int n_nets, int
 typedef struct nlbac_gauss_head {
     const float *eps, *scale, *bias; int n_u;
     float *action; int action_ld; float *logp;
+    /* ABI 7 — optional "constraint head" (cf_kind != 0; nlbac_mlp_fwd_head): net cf_net of the launch is the Lyapunov
+     * critic evaluated on the predicted look-ahead points, y = V(p(x')), and each of its workgroups goes on, for its
+     * rows, with the task's constraint terms — what *_constraints_fwd does as a launch of its own: the terms (kept for
+     * the backward), the relu-filtered column sums per tile, and, in the workgroup elected last, the augmented-
+     * Lagrangian step on the finished sums (nlbac_auglag).  cf_kind 1 = nlbac_unicycle_constraints_fwd (cf_nh == 7
+     * hazards; same arguments: ps (B,2), ps_next (2B,2), V (B), hazards, r2 = r_coll^2, dt, gamma_b, gamma_l, matr
+     * (B,8), bmatr (B,7)); cf_partials [n_tiles][15] with n_tiles = ceil(B / 16), cf_tickets 1 + ceil(n_tiles / 16)
+     * zeroed uint32 (left zeroed), cf_auglag_* = the nlbac_auglag_args (backup_mode != 0: 15 columns), cf_sc the
+     * scalars block.  Row arithmetic as the launch it replaces; the column sums are taken per 16-row tile (to rounding). */
+    int cf_kind, cf_net, cf_nh;
+    const float *cf_ps, *cf_ps_next, *cf_V, *cf_hazards;
+    float cf_r2, cf_dt, cf_gamma_b, cf_gamma_l;
+    float *cf_matr, *cf_bmatr, *cf_partials; unsigned *cf_tickets;
+    int cf_n_cbf, cf_n_clf; float cf_batch_size; int cf_do_lambda_update, cf_do_backup_lambda_update, cf_ratio_mode, cf_backup_mode;
+    float cf_lam_lo, cf_lam_hi;
+    float *cf_sc;
 } nlbac_gauss_head;
 int nlbac_mlp_fwd_gauss(const nlbac_mlp *nets, const nlbac_mlp_io *io, int n_nets, int B,
                         const nlbac_gauss_head *head, nlbac_stream_t s);
+/* nlbac_mlp_fwd with a constraint head (head->eps == NULL: no Gaussian sample).  nlbac_mlp_fwd_head_ok(nets, n_nets) != 0:
+ * the launch is served by the kernels that evaluate it (the quarter-panel ones: 3-layer nets of width 128 / 256). */
+int nlbac_mlp_fwd_head_ok(const nlbac_mlp *nets, int n_nets);
+int nlbac_mlp_fwd_head(const nlbac_mlp *nets, const nlbac_mlp_io *io, int n_nets, int B,
+                       const nlbac_gauss_head *head, nlbac_stream_t s);
 /* dz (all wide layers) and optionally dx from dy and the saved activations. */
 int nlbac_mlp_bwd_data(const nlbac_mlp *nets, const nlbac_mlp_io *io, int n_nets, int B, nlbac_stream_t s);
 struct nlbac_dy_head;

@@ -64,7 +64,14 @@ class ActorScalarArgs(C.Structure):
 class GaussHead(C.Structure):
     """``struct nlbac_gauss_head``"""
     _fields_ = [("eps", C.c_void_p), ("scale", C.c_void_p), ("bias", C.c_void_p), ("n_u", C.c_int),
-                ("action", C.c_void_p), ("action_ld", C.c_int), ("logp", C.c_void_p)]
+                ("action", C.c_void_p), ("action_ld", C.c_int), ("logp", C.c_void_p),
+                ("cf_kind", C.c_int), ("cf_net", C.c_int), ("cf_nh", C.c_int),
+                ("cf_ps", C.c_void_p), ("cf_ps_next", C.c_void_p), ("cf_V", C.c_void_p), ("cf_hazards", C.c_void_p),
+                ("cf_r2", C.c_float), ("cf_dt", C.c_float), ("cf_gamma_b", C.c_float), ("cf_gamma_l", C.c_float),
+                ("cf_matr", C.c_void_p), ("cf_bmatr", C.c_void_p), ("cf_partials", C.c_void_p), ("cf_tickets", C.c_void_p),
+                ("cf_n_cbf", C.c_int), ("cf_n_clf", C.c_int), ("cf_batch_size", C.c_float),
+                ("cf_do_lambda_update", C.c_int), ("cf_do_backup_lambda_update", C.c_int), ("cf_ratio_mode", C.c_int),
+                ("cf_backup_mode", C.c_int), ("cf_lam_lo", C.c_float), ("cf_lam_hi", C.c_float), ("cf_sc", C.c_void_p)]
 
 
 class DyHead(C.Structure):
@@ -121,6 +128,8 @@ _PROTOS = {
     "nlbac_mlp_fwd": [C.POINTER(Mlp), C.POINTER(MlpIO), _I, _I, _P],
     "nlbac_mlp_fwd_gauss": [C.POINTER(Mlp), C.POINTER(MlpIO), _I, _I, C.POINTER(GaussHead), _P],
     "nlbac_mlp_masks_ok": [C.POINTER(Mlp), _I],
+    "nlbac_mlp_fwd_head_ok": [C.POINTER(Mlp), _I],
+    "nlbac_mlp_fwd_head": [C.POINTER(Mlp), C.POINTER(MlpIO), _I, _I, C.POINTER(GaussHead), _P],
     "nlbac_mlp_bwd_data": [C.POINTER(Mlp), C.POINTER(MlpIO), _I, _I, _P],
     "nlbac_mlp_bwd_data_head": [C.POINTER(Mlp), C.POINTER(MlpIO), _I, _I, C.POINTER(DyHead), _P],
     "nlbac_mlp_bwd_weights_ws_floats": [C.POINTER(Mlp), _I, _I],

@@ -15,10 +15,7 @@
 #include "scalars.h"
 #include "dy_heads.h"
 
-struct AuglagArgs {        // nlbac_auglag's scalar arguments, by value (nlbac_auglag_args in the header)
-    int n_cbf, n_clf; float batch_size; int do_lambda_update, do_backup_lambda_update, ratio_mode, backup_mode;
-    float lam_lo, lam_hi;
-};
+#include "auglag_device.h"
 
 template <bool COHERENT>
 __device__ __forceinline__ void auglag_body(const float* partials, int n_blk, const AuglagArgs A, float* sc);
@@ -337,105 +334,11 @@ __global__ __launch_bounds__(256) void unicycle_constraints_fwd_kernel(const flo
     CONSTRAINTS_TAIL(2 * NH + 1, v)
 }
 
-// Augmented-Lagrangian scalars.  One wave: lanes sum the partial columns, lane 0 does the scalar bookkeeping.
-// backup_mode: 0 no backup controller (learned-barrier copies), 1 backup shares rho with the primary
-// (Unicycle / SimulatedCars), 2 backup keeps its own rho (Pvtol); lambda clamp [lam_lo, lam_hi].
-// required_matrix sums, ratio, lambda / rho updates and loss coefficients (sac_cbf_clf.py:502-528, 623-638) by ONE
-// workgroup: the stand-alone nlbac_auglag launch, or the last workgroup of a constraints_fwd launch (COHERENT: the
-// partials were published by other workgroups of the same launch).
 template <bool COHERENT>
 __device__ __forceinline__ void auglag_body(const float* partials, int n_blk, const AuglagArgs A, float* sc_global) {
-    // The scalar bookkeeping below is ~60 dependent reads / writes of the scalars block by ONE thread: on the block in
-    // global memory each is a trip to L2 (unicycle_constraints_fwd: 13 us, most of it here); it runs on a copy in LDS,
-    // brought in and written back by the whole workgroup.
     __shared__ __attribute__((aligned(8))) float sc[NLBAC_SC_SIZE_ENUM];
-    for (int t = threadIdx.x; t < NLBAC_SC_SIZE_ENUM; t += blockDim.x) sc[t] = sc_global[t];
-    __syncthreads();
-    const int n_cbf = A.n_cbf, n_clf = A.n_clf, ratio_mode = A.ratio_mode, backup_mode = A.backup_mode;
-    const int do_lambda_update = A.do_lambda_update, do_backup_lambda_update = A.do_backup_lambda_update;
-    const float batch_size = A.batch_size, lam_lo = A.lam_lo, lam_hi = A.lam_hi;
-    const int nc = n_cbf + n_clf, ncol = nc + (backup_mode ? n_cbf : 0);
-    // the other workgroups' partial sums come in with ONE round of device-scope loads (every thread a few), staged in
-    // LDS, then column c is summed in block order by thread c — n_blk dependent loads per column took ~0.6 us each
-    // (16 blocks: unicycle_constraints_fwd 15 us, two thirds of it here)
     __shared__ float s_stage[128 * 36];
-    const int n_all = n_blk * ncol;
-    const bool staged = COHERENT && n_all <= 128 * 36;
-    if (staged) {
-        for (int idx = threadIdx.x; idx < n_all; idx += blockDim.x) s_stage[idx] = coherent_load(partials + idx);
-        __syncthreads();
-    }
-    for (int c = threadIdx.x; c < ncol; c += blockDim.x) {
-        float s = 0.f;
-        for (int b = 0; b < n_blk; ++b)
-            s += staged ? s_stage[b * ncol + c] : (COHERENT ? coherent_load(partials + (long)b * ncol + c) : partials[(long)b * ncol + c]);
-        s = s / batch_size;
-        if (c < nc) sc[SC_REQ + c] = s; else sc[SC_BREQ + (c - nc)] = s;
-    }
-    __syncthreads();
-    if (threadIdx.x == 0) {
-    double* rho_p = reinterpret_cast<double*>(sc + SC_RHO_F64);
-    double* brho_p = backup_mode == 1 ? rho_p : reinterpret_cast<double*>(sc + SC_BRHO_F64);
-    // ---- primary (sac_cbf_clf.py:506-528)
-    {
-        const float* req = sc + SC_REQ;
-        float* lam = sc + SC_LAMBDA;
-        double ratio = 1.0;
-        if (n_clf && ratio_mode) {
-            float m = 0.f;
-            for (int c = 0; c < n_cbf; ++c) m += req[c];
-            m = fabsf(m / (float)n_cbf);
-            float r = m / fabsf(req[nc - 1]);
-            if (ratio_mode == 2) r = fmaxf(r, 0.002f);
-            ratio = (double)r;
-        }
-        sc[SC_RATIO] = (float)ratio;
-        double rho = *rho_p;
-        if (do_lambda_update)
-            for (int c = 0; c < nc; ++c)
-                lam[c] = fminf(fmaxf(lam[c] + (float)rho * req[c], lam_lo), lam_hi);
-        rho = fmin(rho * 1.0005, 200.0);
-        *rho_p = rho;
-        const float ch = (float)(rho / 2.0);
-        float loss = 0.f;
-        for (int c = 0; c < n_cbf; ++c) {
-            const float g = req[c];
-            loss += lam[c] * g + ch * g * g;
-            sc[SC_COEF + c] = lam[c] + (ch * g + ch * g);
-        }
-        if (n_clf) {
-            const float g = req[nc - 1];
-            const float l1 = (float)((double)lam[nc - 1] * ratio);
-            const float c2 = (float)(ratio * ratio * rho / 2.0);
-            loss += l1 * g + c2 * g * g;
-            sc[SC_COEF + nc - 1] = l1 + (c2 * g + c2 * g);
-        }
-        sc[SC_PL2] = loss;
-    }
-    // ---- backup (sac_cbf_clf.py:623-638)
-    if (backup_mode) {
-        const float* req = sc + SC_BREQ;
-        float* lam = sc + SC_BLAMBDA;
-        double rho = *brho_p;
-        if (do_backup_lambda_update)
-            for (int c = 0; c < n_cbf; ++c)
-                lam[c] = fminf(fmaxf(lam[c] + (float)rho * req[c], lam_lo), lam_hi);
-        rho = fmin(rho * 1.0005, 200.0);
-        *brho_p = rho;
-        const float ch = (float)(rho / 2.0);
-        float loss = 0.f;
-        for (int c = 0; c < n_cbf; ++c) {
-            const float g = req[c];
-            loss += lam[c] * g + ch * g * g;
-            sc[SC_BCOEF + c] = lam[c] + (ch * g + ch * g);
-        }
-        sc[SC_BPL2] = loss;
-    }
-    }
-    __syncthreads();
-    // what the step may have changed: ratio / losses (4..6), multipliers, coefficients, required sums, rho (16..115)
-    for (int t = threadIdx.x; t < NLBAC_SC_SIZE_ENUM; t += blockDim.x)
-        if ((t >= SC_RATIO && t <= SC_BPL2) || (t >= SC_LAMBDA && t < SC_MEAN_LOGP)) sc_global[t] = sc[t];
+    auglag_body_at<COHERENT>(partials, n_blk, A, sc_global, sc, s_stage, 128 * 36);
 }
 
 __global__ void auglag_kernel(const float* partials, int n_blk, const AuglagArgs A, float* sc) {

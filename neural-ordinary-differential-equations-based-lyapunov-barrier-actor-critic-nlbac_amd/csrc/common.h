@@ -149,6 +149,35 @@ __device__ __forceinline__ bool publish_and_elect_grouped(float* dst, const floa
     if (s_elect_g_ != 0u) elect_acquire_();
     return s_elect_g_ != 0u;
 }
+// The same with the n (<= 64) values already spread over the lanes of wave 0 (lane k < n holds value k in `mine`).
+__device__ __forceinline__ bool publish_and_elect_grouped_lanes(float* dst, float mine, int n, unsigned* tickets, unsigned index,
+                                                                unsigned n_blocks) {
+    __shared__ unsigned s_elect_gl_;
+    if (threadIdx.x < 64) {
+        float old = 0.f;
+        if ((int)threadIdx.x < n) old = __hip_atomic_exchange(dst + threadIdx.x, mine, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        asm volatile("" ::"v"(old) : "memory");        // every exchange has returned before the ticket is taken
+        elect_release_();
+        if (threadIdx.x == 0) {
+            const unsigned grp = index / ELECT_GROUP, n_groups = (n_blocks + ELECT_GROUP - 1) / ELECT_GROUP;
+            const unsigned in_group = min((unsigned)ELECT_GROUP, n_blocks - grp * ELECT_GROUP);
+            unsigned elected = 0u;
+            const unsigned t1 = __hip_atomic_fetch_add(tickets + 1 + grp, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if (t1 == in_group - 1u) {
+                __hip_atomic_store(tickets + 1 + grp, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                const unsigned t2 = __hip_atomic_fetch_add(tickets, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                if (t2 == n_groups - 1u) {
+                    __hip_atomic_store(tickets, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    elected = 1u;
+                }
+            }
+            s_elect_gl_ = elected;
+        }
+    }
+    __syncthreads();
+    if (s_elect_gl_ != 0u) elect_acquire_();
+    return s_elect_gl_ != 0u;
+}
 __device__ __forceinline__ float coherent_load(const float* p) {
     return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }

@@ -1108,6 +1108,25 @@ extern "C" int nlbac_mlp_fwd_gauss(const nlbac_mlp* nets, const nlbac_mlp_io* io
     return mlp_fwd_launch(nets, io, n_nets, B, *head, who, s);
 }
 
+extern "C" int nlbac_mlp_fwd_head_ok(const nlbac_mlp* nets, int n_nets) {
+    return (nets && n_nets >= 1 && nlbac_mlp_rrq_eligible(nets, n_nets)) ? 1 : 0;
+}
+
+extern "C" int nlbac_mlp_fwd_head(const nlbac_mlp* nets, const nlbac_mlp_io* io, int n_nets, int B,
+                                  const nlbac_gauss_head* head, nlbac_stream_t s) {
+    const char* who = "nlbac_mlp_fwd_head";
+    NLBAC_REQUIRE(head && head->cf_kind == 1 && !head->eps, "%s: a constraint head (cf_kind 1) without a Gaussian sample", who);
+    const nlbac_gauss_head& G = *head;
+    NLBAC_REQUIRE(nlbac_mlp_fwd_head_ok(nets, n_nets), "%s: these nets' forward does not evaluate constraint heads (nlbac_mlp_fwd_head_ok)", who);
+    NLBAC_REQUIRE(G.cf_net >= 0 && G.cf_net < n_nets && nets[G.cf_net].out_dim == 1 && G.cf_nh == 7,
+                  "%s: cf_net must be a scalar net of the launch, cf_nh == 7", who);
+    NLBAC_REQUIRE(G.cf_ps && G.cf_ps_next && G.cf_V && G.cf_hazards && G.cf_matr && G.cf_bmatr && G.cf_partials && G.cf_tickets &&
+                      G.cf_sc && G.cf_dt > 0.f && G.cf_batch_size > 0.f, "%s: constraint head: null pointer / bad scalars", who);
+    NLBAC_REQUIRE(G.cf_n_cbf == G.cf_nh && G.cf_n_clf == 1 && G.cf_backup_mode >= 1 && G.cf_backup_mode <= 2,
+                  "%s: constraint head 1 publishes 2 n_hz + 1 columns (n_cbf == n_hz, one CLF term, a backup controller)", who);
+    return mlp_fwd_launch(nets, io, n_nets, B, G, who, s);
+}
+
 static int mlp_bwd_data_launch(const nlbac_mlp* nets, const nlbac_mlp_io* io, int n_nets, int B, const nlbac_dy_head& H,
                                const char* who, nlbac_stream_t s) {
     MlpLaunch L;

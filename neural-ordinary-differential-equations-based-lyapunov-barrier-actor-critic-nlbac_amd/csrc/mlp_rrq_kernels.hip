@@ -18,6 +18,7 @@
 // ((layer * B + row) * 4 + q) * 4 + cq — value t = 4 j + r (block j of the quarter, register r) at bit 4 NBQ - 1 - t.
 #include "mlp_launch.h"
 #include "rr_device.h"
+#include "auglag_device.h"
 #include <cstdlib>
 
 #define QT 16               /* rows per workgroup */
@@ -63,6 +64,21 @@ __global__ __launch_bounds__(256, 3) void mlp_rrq_fwd_kernel(const MlpLaunch L, 
     const int ub = 16 * NBQ * cq;                         // first unit of this wave's quarter
 
     QFSTAMP(0)
+    // ---- constraint head (the end of the kernel): its operands are requested now — they do not depend on this forward —
+    //      so that their trip to memory is not part of the tile's tail: (row, hazard) per thread, the CLF rows behind them
+    const bool cf_on = G.cf_kind == 1 && (int)blockIdx.y == G.cf_net;      // (uniform per workgroup)
+    float cfv[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    if (cf_on) {
+        if (tid < QT * 7) {
+            const int r = tid / 7, h = tid - r * 7, i = min(row0 + r, B - 1);
+            cfv[0] = G.cf_ps[i * 2]; cfv[1] = G.cf_ps[i * 2 + 1];
+            cfv[2] = G.cf_ps_next[i * 2]; cfv[3] = G.cf_ps_next[i * 2 + 1];
+            cfv[4] = G.cf_ps_next[(long)(B + i) * 2]; cfv[5] = G.cf_ps_next[(long)(B + i) * 2 + 1];
+            cfv[6] = G.cf_hazards[h * 2]; cfv[7] = G.cf_hazards[h * 2 + 1];
+        } else if (tid >= 128 && tid < 128 + QT) {
+            cfv[0] = G.cf_V[min(row0 + tid - 128, B - 1)];
+        }
+    }
     // ---- the quarter's weight stream: panel cq / 2, its first or second half
     const __amdgpu_buffer_rsrc_t rs = rr_rsrc(net.packed, net.packed_floats);
     const int voff = lane * 16;
@@ -155,6 +171,7 @@ __global__ __launch_bounds__(256, 3) void mlp_rrq_fwd_kernel(const MlpLaunch L, 
             y[o] = ((sO[tid * 16 + o] + sO[(QT + tid) * 16 + o]) + (sO[(2 * QT + tid) * 16 + o] + sO[(3 * QT + tid) * 16 + o])) + bo[o];
         if (G.eps)
             gauss_fwd_row(y, G.eps, G.scale, G.bias, G.n_u, (long)blockIdx.y * B + row, G.action, G.action_ld, G.logp);
+        if (G.cf_kind) sH[tid] = y[0];        // (V(p(x')) of the row, for the constraint head below; sH is free by now)
     }
     // ---- what the backward needs, the kernel's last instructions (nothing waits for the stores): this quarter of the
     //      activation rows of both layers, and / or its mask bits
@@ -175,6 +192,70 @@ __global__ __launch_bounds__(256, 3) void mlp_rrq_fwd_kernel(const MlpLaunch L, 
         }
     }
     QFSTAMP(5)
+    // ---- constraint head (nlbac_gauss_head::cf_kind 1: unicycle_constraints_fwd_kernel's row arithmetic, agent_kernels.hip):
+    //      the CBF terms of both controllers and the CLF term of the tile's rows — (row, hazard) per thread —, their
+    //      relu-filtered column sums over the tile, published; the workgroup elected last runs the augmented-Lagrangian step
+    if (cf_on) {
+        constexpr int NH = 7, NC = 2 * NH + 1;
+        float* const sVn = sH;                                // [16]
+        float* const sT = sH + 16;                            // [16][16]: relu(term) of (row, column < NC)
+        lds_barrier();
+        if (tid < QT * NH) {
+            const int r = tid / NH, h = tid - r * NH, i = min(row0 + r, B - 1);
+            const float p0 = cfv[0], p1 = cfv[1], n0 = cfv[2], n1 = cfv[3], b0 = cfv[4], b1 = cfv[5], hx = cfv[6], hy = cfv[7];
+            const float hs = 0.5f * (((p0 - hx) * (p0 - hx) + (p1 - hy) * (p1 - hy)) - G.cf_r2);
+            const float hn = 0.5f * (((n0 - hx) * (n0 - hx) + (n1 - hy) * (n1 - hy)) - G.cf_r2);
+            const float hb = 0.5f * (((b0 - hx) * (b0 - hx) + (b1 - hy) * (b1 - hy)) - G.cf_r2);
+            const float t = -((hn - hs) / G.cf_dt) - G.cf_gamma_b * hs;
+            const float tb = -((hb - hs) / G.cf_dt) - G.cf_gamma_b * hs;
+            const bool ok = row0 + r < B;
+            if (ok) {
+                G.cf_matr[(long)i * (NH + 1) + h] = t;
+                G.cf_bmatr[(long)i * NH + h] = tb;
+            }
+            sT[r * 16 + h] = (ok && t > 0.f) ? t : 0.f;
+            sT[r * 16 + NH + 1 + h] = (ok && tb > 0.f) ? tb : 0.f;
+        } else if (tid >= 128 && tid < 128 + QT) {
+            const int r = tid - 128, i = min(row0 + r, B - 1);
+            const float vv = cfv[0];
+            const float lya = ((sVn[r] - vv) / G.cf_dt) + G.cf_gamma_l * vv;
+            const bool ok = row0 + r < B;
+            if (ok) G.cf_matr[(long)i * (NH + 1) + NH] = lya;
+            sT[r * 16 + NH] = (ok && lya > 0.f) ? lya : 0.f;
+        }
+        lds_barrier();
+        float mine = 0.f;
+        if (tid < NC)
+            for (int r = 0; r < QT; ++r) mine += sT[r * 16 + tid];
+        const unsigned tile = blockIdx.x, n_tiles = gridDim.x;
+        if (publish_and_elect_grouped_lanes(G.cf_partials + (long)tile * NC, mine, NC, G.cf_tickets, tile, n_tiles)) {
+            // the elected workgroup: the scalars block into LDS (the layer-0 exchange tile is free), every thread sums the
+            // tiles t, t + 256, ... of all columns, a fixed tree over the workgroup (whichever workgroup was elected: the
+            // same sums), then the augmented-Lagrangian bookkeeping
+            const AuglagArgs A = {G.cf_n_cbf, G.cf_n_clf, G.cf_batch_size, G.cf_do_lambda_update, G.cf_do_backup_lambda_update,
+                                  G.cf_ratio_mode, G.cf_backup_mode, G.cf_lam_lo, G.cf_lam_hi};
+            float* const scl = sH;
+            float* const red = sH + NLBAC_SC_SIZE_ENUM;       // 4 * NC floats
+            for (int t = tid; t < NLBAC_SC_SIZE_ENUM; t += 256) scl[t] = G.cf_sc[t];
+            float v[NC];
+#pragma unroll
+            for (int c = 0; c < NC; ++c) v[c] = 0.f;
+            for (unsigned b = tid; b < n_tiles; b += 256)
+#pragma unroll
+                for (int c = 0; c < NC; ++c) v[c] += coherent_load(G.cf_partials + (long)b * NC + c);
+            block_sum_256<NC>(v, red);
+            const int nc = A.n_cbf + A.n_clf;
+            if (tid == 0) {
+#pragma unroll
+                for (int c = 0; c < NC; ++c) {
+                    const float sv = v[c] / A.batch_size;
+                    if (c < nc) scl[SC_REQ + c] = sv; else scl[SC_BREQ + (c - nc)] = sv;
+                }
+            }
+            __syncthreads();
+            auglag_finish_at(A, G.cf_sc, scl);
+        }
+    }
 }
 
 // ---------------------------------------------------------------------------------------------------------------------

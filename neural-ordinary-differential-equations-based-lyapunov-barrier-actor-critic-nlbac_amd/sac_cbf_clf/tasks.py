@@ -126,6 +126,10 @@ class UnicycleTask(_Task):
         ws.ps_next2, ws.dps_next2, ws.dps_v2 = z(2 * B, 2), z(2 * B, 2), z(2 * B, 2)
         ws.matr, ws.bmatr = z(B, self.num_cbfs + 1), z(B, self.num_cbfs)
         ws.part_c = z(ws.nblk, 2 * self.num_cbfs + 1)
+        # (the constraint head of the V(p(x')) forward: column sums per 16-row tile, two-level election)
+        n16 = (B + 15) // 16
+        ws.part_c16 = z(n16, 2 * self.num_cbfs + 1)
+        ws.tickets_c = torch.zeros(2 + n16 // 16 + 1, dtype=torch.int32, device=self.agent.device)
         ws.dx_next2 = z(2 * B, 3)
 
     def plan(self, ws, P):
@@ -190,20 +194,38 @@ class UnicycleTask(_Task):
         B, sc, dt = ws.B, a.sc.data_ptr(), float(self.env.dt)
         x_next2 = self.solver.forward_finish(assume_single_step=assume_single)
         mapped = self.solver.out_mapped
-        merged = mapped and a.world == 1 and a.fold_launches and not a.h_extra and len(a._fill) == 1
+        # the constraint terms ride in V(p(x'))'s own launch where its kernels evaluate them (below); that launch is then
+        # never merged with the pending Q(s, pi) forward: V(c), which the CLF term needs, would be computed by another
+        # net's workgroups of the same launch — and eager and captured updates keep the same launches' arithmetic
+        use_head = self._constraint_head_ok(P.n_l, 1, ws)
+        merged = mapped and a.world == 1 and a.fold_launches and not a.h_extra and len(a._fill) == 1 and not use_head
         if merged:
             a._fill.clear()      # (the pending piece is exactly the Q(s, pi) forward: it rides with V(p(x')) below)
         a.drain_fill()           # what is left of part 1 (critic step, Q(s, pi)): everything below uses the stepped nets
         if not mapped:
             call("nlbac_unicycle_lookahead", x_next2.data_ptr(), 2 * B, self.l_p, ws.ps_next2.data_ptr(), s)
-        if merged:
-            call("nlbac_mlp_fwd", P.n_q5f, P.io_q5f, P.n_q5_count + 1, B, s)
-        else:
-            call("nlbac_mlp_fwd", P.n_l, P.io_vn, 1, B, s)
         r_coll = 1.05 * float(self.env.hazards_radius)
-        call("nlbac_unicycle_constraints_fwd", ws.ps.data_ptr(), ws.ps_next2.data_ptr(), ws.V.data_ptr(),
-             ws.Vn.data_ptr(), self.hazards.data_ptr(), self.num_cbfs, r_coll, dt, float(a.gamma_b), self.gamma_l, B,
-             ws.matr.data_ptr(), ws.bmatr.data_ptr(), ws.part_c.data_ptr(), *a.auglag_fused(ws, self.num_cbfs, lam_upd), s)
+        nets, io, cnt = (P.n_q5f, P.io_q5f, P.n_q5_count + 1) if merged else (P.n_l, P.io_vn, 1)
+        if use_head:
+            # the constraint terms, their column sums and the augmented-Lagrangian step are the epilogue of V(p(x'))'s
+            # workgroups in this launch (nlbac_gauss_head::cf_kind 1): no nlbac_unicycle_constraints_fwd launch
+            A = a.auglag_fused(ws, self.num_cbfs, lam_upd)[0]._obj
+            G = _lib.GaussHead()
+            G.cf_kind, G.cf_net, G.cf_nh = 1, cnt - 1, self.num_cbfs
+            G.cf_ps, G.cf_ps_next, G.cf_V, G.cf_hazards = ws.ps.data_ptr(), ws.ps_next2.data_ptr(), ws.V.data_ptr(), self.hazards.data_ptr()
+            rc = float(np.float32(r_coll))           # (r_coll^2 as nlbac_unicycle_constraints_fwd forms it from its float argument)
+            G.cf_r2, G.cf_dt, G.cf_gamma_b, G.cf_gamma_l = float(np.float32(rc * rc)), dt, float(a.gamma_b), self.gamma_l
+            G.cf_matr, G.cf_bmatr = ws.matr.data_ptr(), ws.bmatr.data_ptr()
+            G.cf_partials, G.cf_tickets, G.cf_sc = ws.part_c16.data_ptr(), ws.tickets_c.data_ptr(), sc
+            G.cf_n_cbf, G.cf_n_clf, G.cf_batch_size = A.n_cbf, A.n_clf, A.batch_size
+            G.cf_do_lambda_update, G.cf_do_backup_lambda_update = A.do_lambda_update, A.do_backup_lambda_update
+            G.cf_ratio_mode, G.cf_backup_mode, G.cf_lam_lo, G.cf_lam_hi = A.ratio_mode, A.backup_mode, A.lam_lo, A.lam_hi
+            call("nlbac_mlp_fwd_head", nets, io, cnt, B, C.byref(G), s)
+        else:
+            call("nlbac_mlp_fwd", nets, io, cnt, B, s)
+            call("nlbac_unicycle_constraints_fwd", ws.ps.data_ptr(), ws.ps_next2.data_ptr(), ws.V.data_ptr(),
+                 ws.Vn.data_ptr(), self.hazards.data_ptr(), self.num_cbfs, r_coll, dt, float(a.gamma_b), self.gamma_l, B,
+                 ws.matr.data_ptr(), ws.bmatr.data_ptr(), ws.part_c.data_ptr(), *a.auglag_fused(ws, self.num_cbfs, lam_upd), s)
         a.auglag(ws, self.num_cbfs, lam_upd)
         if a.world == 1 and a.fold_launches:
             # dV_next -> d ps_next (rows [0,B)), together with the Q(s, pi) nets' dx; the constraint backward itself (d ps_next
@@ -231,6 +253,17 @@ class UnicycleTask(_Task):
                  self.l_p, ws.dx_next2.data_ptr(), s)
             du2, _ = self.solver.backward(ws.dx_next2, need_du=True)
         return du2, self.act_dim
+
+    def _constraint_head_ok(self, nets, cnt, ws):
+        """Single GPU, launch folds on, both controllers in the update, and the forward kernels that serve these nets
+        evaluate constraint heads (``nlbac_mlp_fwd_head_ok``)."""
+        a = self.agent
+        if not (a.world == 1 and a.fold_launches and ws.np_now == 2 and self.num_cbfs == 7):
+            return False
+        ok = self.__dict__.get("_cf_ok")
+        if ok is None:
+            ok = self._cf_ok = bool(_lib.load().nlbac_mlp_fwd_head_ok(nets, cnt))
+        return ok
 
     def first_step_done(self):
         return self.solver.first_step_done()
