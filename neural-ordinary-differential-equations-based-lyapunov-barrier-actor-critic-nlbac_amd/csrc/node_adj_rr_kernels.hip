@@ -21,7 +21,9 @@ bool nlbac_node_rr_eligible(const nlbac_mlp* f, const nlbac_mlp* g);      // (no
 
 #define ARR_MAX_W 4        /* layer 0 + up to three hid x hid layers */
 
-template <int NB, int R>
+// KEEP (the NODE fit's parameter quadrature): every evaluated stage's inputs, the output-layer gradient of g_net, the
+// activations and the pre-activation gradients additionally go out as rows, for nlbac_mlp_bwd_weights.
+template <int NB, int R, int KEEP>
 __global__ __launch_bounds__(256) void node_adj_rr_kernel(const NodeAdjLaunch L) {
     using S = RRShape<NB, R>;
     constexpr int KS = S::KS, HID = S::HID, TB = NB - 2, NT = KS - 4 * TB, G0 = rr_group_first(NB);
@@ -166,8 +168,12 @@ __global__ __launch_bounds__(256) void node_adj_rr_kernel(const NodeAdjLaunch L)
             for (int j = 0; j < st; ++j)
                 if (L.beta[st][j] != 0.f) a = a + sKZ[(j * NLBAC_MLP_TILE + mm) * ADJ_WP + c] * (L.beta[st][j] * h);
             sZS[idx] = a;
+            if (KEEP && c < W && sLive[mm] != 0.f) L.ZS[((long)st * n + row0 + mm) * W + c] = a;
         }
         __syncthreads();
+        const long srow = (long)st * n + grow;
+        const bool keep_row = KEEP && row_ok && sLive[m] != 0.f;
+        (void)srow; (void)keep_row;
 
         // =========================== forward chain ===========================
         float Ha[KS], Hb[KS];
@@ -187,11 +193,19 @@ __global__ __launch_bounds__(256) void node_adj_rr_kernel(const NodeAdjLaunch L)
             for (int ll = 0; ll < ARR_MAX_W; ++ll)
                 if (ll == l) mreg[ll] = row_ok ? word : 0u;
         };
+        auto save_rows = [&](float* base, int l, int jo, const float (&H)[KS]) __attribute__((always_inline)) {
+            if (!keep_row) return;
+            f32x4 hv{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int rr = 0; rr < ((jo < NB - 1) ? 4 : R); ++rr) hv[rr] = H[4 * jo + rr];
+            rr_row_store<S>(base + (long)l * L.acts_ls[grp] + srow * HID, jo, q, hv);
+        };
         auto pre_l0 = [&](int ks) __attribute__((always_inline)) {
             const int jo = (ks < 4 * (NB - 1)) ? (ks >> 2) : NB - 1, r = ks - 4 * jo;
             const float h = rr_relu(acc0[jo][r]);
             Ha[ks] = h;
             rr_mask_push(wd, h);
+            if (KEEP && r == ((jo < NB - 1) ? 3 : R - 1)) save_rows(L.acts[grp], 0, jo, Ha);
             if (ks == KS - 1) keep_word(0, wd);
         };
         auto pre_tail_f = [&](int lp, float (&H)[KS], int t) __attribute__((always_inline)) {
@@ -200,6 +214,7 @@ __global__ __launch_bounds__(256) void node_adj_rr_kernel(const NodeAdjLaunch L)
             const float h = rr_relu(acc[jo][r]);
             H[4 * TB + t] = h;
             rr_mask_push(wd, h);
+            if (KEEP && (t == 3 || t == NT - 1)) save_rows(L.acts[grp], lp, jo, H);
             if (t == NT - 1) keep_word(lp, wd);
         };
         {   // layer 0: K = ns + 1 (one to three k-steps), straight from the stage input's y part
@@ -237,6 +252,7 @@ __global__ __launch_bounds__(256) void node_adj_rr_kernel(const NodeAdjLaunch L)
                          const float h = rr_relu(acc[jo][r]);
                          Hout[4 * jo + r] = h;
                          rr_mask_push(wd, h);
+                         if (KEEP && r == 3) save_rows(L.acts[grp], l, jo, Hout);
                      },
                      [&]() __attribute__((always_inline)) {
                          if (l + 1 < nw) prefetch_bias(l + 1);
@@ -285,6 +301,7 @@ __global__ __launch_bounds__(256) void node_adj_rr_kernel(const NodeAdjLaunch L)
             const float ax = sZS[m * ADJ_WP + ns + min(c, ns - 1)];
             const float uu = (grp == 0) ? 1.f : sU[m * ADJ_MAX_NU + min(u, nu - 1)];
             dy[e] = ok ? ((grp == 0) ? ax : ax * uu) : 0.f;
+            if (KEEP && grp == 1 && ok && keep_row) L.dG[srow * (ns * nu) + c * nu + u] = dy[e];
         }
         float Za[KS], Zb[KS];
         f32x4 acct[NB], zero[NB];
@@ -301,11 +318,14 @@ __global__ __launch_bounds__(256) void node_adj_rr_kernel(const NodeAdjLaunch L)
         auto pre_top = [&](int ks) __attribute__((always_inline)) {
             const int jo = (ks < 4 * (NB - 1)) ? (ks >> 2) : NB - 1, r = ks - 4 * jo;
             Za[ks] = rr_mask_gate<KS>(mwt, ks, acct[jo][r]);
+            if (KEEP && r == ((jo < NB - 1) ? 3 : R - 1)) save_rows(L.dz[grp], nw - 1, jo, Za);
         };
+        int tail_layer = 0;          // (the layer whose dz the pending tail belongs to)
         auto pre_tail_b = [&](float (&Z)[KS], int t) __attribute__((always_inline)) {
             if (t >= NT) return;
             const int jo = TB + (t >> 2), r = t & 3;
             Z[4 * TB + t] = rr_mask_gate<KS>(mwt, 4 * TB + t, acc[jo][r]);
+            if (KEEP && (t == 3 || t == NT - 1)) save_rows(L.dz[grp], tail_layer, jo, Z);
         };
         mw = word_of(nw - 1);
         {   // top product: dz_top = mask_top * (W_out^T dy)
@@ -340,8 +360,10 @@ __global__ __launch_bounds__(256) void node_adj_rr_kernel(const NodeAdjLaunch L)
                      },
                      [&](int jo, int r) __attribute__((always_inline)) {
                          Zout[4 * jo + r] = rr_mask_gate<KS>(mw, 4 * jo + r, acc[jo][r]);
+                         if (KEEP && r == 3) save_rows(L.dz[grp], lo, jo, Zout);
                      },
                      [&]() __attribute__((always_inline)) {});
+            tail_layer = lo;          // (this product's own tail is finished inside the next one)
         };
         auto dxl = [&](float (&Zin)[KS]) __attribute__((always_inline)) {
             mwt = mw;
@@ -396,11 +418,18 @@ static bool adj_rr_enabled() {
     return on;
 }
 
+static bool adj_rr_keep_enabled() {
+    static const bool on = [] { const char* e = getenv("NLBAC_ADJ_RR_KEEP"); return !(e && e[0] == '0'); }();
+    return on;
+}
+
 int nlbac_node_adj_rr_launch(NodeAdjLaunch& L, hipStream_t s) {
-    if (!adj_rr_enabled() || L.ZS != nullptr || !nlbac_node_rr_eligible(&L.net[0], &L.net[1])) return 1;
+    const bool keep = L.ZS != nullptr;
+    if (!adj_rr_enabled() || (keep && !adj_rr_keep_enabled()) || !nlbac_node_rr_eligible(&L.net[0], &L.net[1])) return 1;
     using Kernel = void (*)(const NodeAdjLaunch);
     const int hid = L.net[0].hid;
-    const Kernel k = hid == 64 ? node_adj_rr_kernel<4, 4> : (hid == 100 ? node_adj_rr_kernel<7, 1> : node_adj_rr_kernel<8, 4>);
+    const Kernel k = keep ? (hid == 64 ? node_adj_rr_kernel<4, 4, 1> : (hid == 100 ? node_adj_rr_kernel<7, 1, 1> : node_adj_rr_kernel<8, 4, 1>))
+                          : (hid == 64 ? node_adj_rr_kernel<4, 4, 0> : (hid == 100 ? node_adj_rr_kernel<7, 1, 0> : node_adj_rr_kernel<8, 4, 0>));
     const size_t lds = (size_t)((ADJ_MAX_STAGES + 2) * NLBAC_MLP_TILE * ADJ_WP +
                                 NLBAC_MLP_TILE * (ADJ_MAX_NU + 1 + 1 + ADJ_MAX_NS + ADJ_MAX_GOUT + 2 * ADJ_MAX_NS) +
                                 2 * 3 * 8 * 64 + 2 * 4 * 8 * 64) * sizeof(float);

@@ -292,7 +292,7 @@ extern "C" int nlbac_node_adj_step(const nlbac_mlp* f, const nlbac_mlp* g, const
                 (void)hipFuncSetAttribute((const void*)k[b][m], hipFuncAttributeMaxDynamicSharedMemorySize, ADJ_LDS_MAX);
         attr_set = true;
     }
-    if (!keep) {       // the reference's NODE shapes, masks only: the register-resident kernel (node_adj_rr_kernels.hip)
+    {       // the reference's NODE shapes: the register-resident kernel (node_adj_rr_kernels.hip), with or without kept rows
         const int rr = nlbac_node_adj_rr_launch(L, (hipStream_t)s);
         if (rr <= 0) return rr;
     }
