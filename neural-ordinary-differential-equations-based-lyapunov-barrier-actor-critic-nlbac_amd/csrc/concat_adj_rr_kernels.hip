@@ -42,15 +42,17 @@ struct ConcatAdjLaunch {
     const double* ctl;                // rows of problems whose C_DONE is set are left alone
 };
 
-template <int NB, int R, int KEEP>
-__global__ __launch_bounds__(128) void concat_adj_rr_kernel(const ConcatAdjLaunch L) {
+// NW: waves per workgroup (2 or 4), as concat_rr_kernels.hip: four-wave workgroups put one wave on every SIMD.
+template <int NB, int R, int KEEP, int NW>
+__global__ __launch_bounds__(64 * NW) void concat_adj_rr_kernel(const ConcatAdjLaunch L) {
+    constexpr int TILE = 16 * NW;
     using S = RRShape<NB, R>;
     constexpr int KS = S::KS, HID = S::HID, TB = NB - 2, NT = KS - 4 * TB, G0 = rr_group_first(NB);
     extern __shared__ __attribute__((aligned(16))) float smem[];
     const int tid = threadIdx.x, lane = tid & 63;
     const int half = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int n = L.n, ns = L.n_s, nc = L.n_c, W = L.W, WP = L.WP;
-    const int row0 = blockIdx.x * NLBAC_MLP_TILE;
+    const int row0 = blockIdx.x * TILE;
     const nlbac_mlp& net = L.net;
     const int idim = net.in_dim;
     const int q = lane >> 4, r16 = lane & 15, m = 16 * half + r16, grow = row0 + m;
@@ -61,11 +63,11 @@ __global__ __launch_bounds__(128) void concat_adj_rr_kernel(const ConcatAdjLaunc
     const int S_total = L.S_total;
 
     float* const sKZ = smem;                                        // [stage][32][WP]
-    float* const sZ0 = sKZ + S_total * NLBAC_MLP_TILE * WP;         // [32][WP]
-    float* const sC = sZ0 + NLBAC_MLP_TILE * WP;                    // [32][CK_NC]
-    float* const sH = sC + NLBAC_MLP_TILE * CK_NC;                  // [32]
-    float* const sLive = sH + NLBAC_MLP_TILE;                       // [32]
-    float* const sW0 = sLive + NLBAC_MLP_TILE;                      // [k-step < 4][block < 8][lane]: layer 0's A fragments
+    float* const sZ0 = sKZ + S_total * TILE * WP;         // [32][WP]
+    float* const sC = sZ0 + TILE * WP;                    // [32][CK_NC]
+    float* const sH = sC + TILE * CK_NC;                  // [32]
+    float* const sLive = sH + TILE;                       // [32]
+    float* const sW0 = sLive + TILE;                      // [k-step < 4][block < 8][lane]: layer 0's A fragments
     float* const sWt = sW0 + 4 * 8 * 64;                            // [k-step < 4][block < 8][lane]: W_out^T's A fragments
 
     // ---- the wave's weight stream: forward fragments of layers 1, 2, backward fragments of layers 2, 1, round and round
@@ -166,7 +168,7 @@ __global__ __launch_bounds__(128) void concat_adj_rr_kernel(const ConcatAdjLaunc
         const int j = idx / (16 * WP), rem = idx - j * 16 * WP;
         const int mm = 16 * half + rem / WP, c = rem % WP, row = row0 + mm;
         const float v = L.KZ[((long)j * n + min(row, n - 1)) * W + min(c, W - 1)];
-        sKZ[(j * NLBAC_MLP_TILE + mm) * WP + c] = (row < n && c < W) ? v : 0.f;
+        sKZ[(j * TILE + mm) * WP + c] = (row < n && c < W) ? v : 0.f;
     }
     // narrow nets keep both hid x hid layers' biases in registers (concat_rr_kernels.hip: BRES)
     constexpr bool BRES = NB <= 4;
@@ -207,8 +209,8 @@ __global__ __launch_bounds__(128) void concat_adj_rr_kernel(const ConcatAdjLaunc
 #pragma unroll
                 for (int j = 0; j < CK_MAX_STAGES - 1; ++j) {
                     const int jj = min(j, S_total - 1);
-                    ky[k0][j] = sKZ[(jj * NLBAC_MLP_TILE + m) * WP + cs];
-                    ka[k0][j] = sKZ[(jj * NLBAC_MLP_TILE + m) * WP + ns + cs];
+                    ky[k0][j] = sKZ[(jj * TILE + m) * WP + cs];
+                    ka[k0][j] = sKZ[(jj * TILE + m) * WP + ns + cs];
                 }
             }
 #pragma unroll
@@ -324,7 +326,7 @@ __global__ __launch_bounds__(128) void concat_adj_rr_kernel(const ConcatAdjLaunc
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
                 const int c = 4 * r + q;
-                if (r < KS0 && c < ns) sKZ[(st * NLBAC_MLP_TILE + m) * WP + c] = -((o[r] + o_bias[r]) * o_sig[r] + o_mu[r]);
+                if (r < KS0 && c < ns) sKZ[(st * TILE + m) * WP + c] = -((o[r] + o_bias[r]) * o_sig[r] + o_mu[r]);
             }
         }
 
@@ -393,7 +395,7 @@ __global__ __launch_bounds__(128) void concat_adj_rr_kernel(const ConcatAdjLaunc
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
                 const int i = 4 * q + r;
-                if (i < idim) sKZ[(st * NLBAC_MLP_TILE + m) * WP + ns + i] = o[r] * x_isig[r];
+                if (i < idim) sKZ[(st * TILE + m) * WP + ns + i] = o[r] * x_isig[r];
             }
         }
     }
@@ -402,7 +404,7 @@ __global__ __launch_bounds__(128) void concat_adj_rr_kernel(const ConcatAdjLaunc
     for (int idx = lane; idx < (L.st_hi - L.st_lo) * 16 * W; idx += 64) {
         const int j = L.st_lo + idx / (16 * W), rem = idx % (16 * W);
         const int mm = 16 * half + rem / W, c = rem % W;
-        if (sLive[mm] != 0.f) L.KZ[((long)j * n + row0 + mm) * W + c] = sKZ[(j * NLBAC_MLP_TILE + mm) * WP + c];
+        if (sLive[mm] != 0.f) L.KZ[((long)j * n + row0 + mm) * W + c] = sKZ[(j * TILE + mm) * WP + c];
     }
     if (L.Z1 || L.ERR)
         for (int idx = lane; idx < 16 * W; idx += 64) {
@@ -412,13 +414,13 @@ __global__ __launch_bounds__(128) void concat_adj_rr_kernel(const ConcatAdjLaunc
             if (L.Z1) {
                 float a = sZ0[mm * WP + c];
                 for (int j = 0; j < L.n_out; ++j)
-                    if (L.c_out[j] != 0.f) a = a + sKZ[(j * NLBAC_MLP_TILE + mm) * WP + c] * (L.c_out[j] * h);
+                    if (L.c_out[j] != 0.f) a = a + sKZ[(j * TILE + mm) * WP + c] * (L.c_out[j] * h);
                 L.Z1[(long)row * W + c] = a;
             }
             if (L.ERR) {
                 float a = 0.f;
                 for (int j = 0; j < L.n_err; ++j)
-                    if (L.c_err[j] != 0.f) a = a + sKZ[(j * NLBAC_MLP_TILE + mm) * WP + c] * (L.c_err[j] * h);
+                    if (L.c_err[j] != 0.f) a = a + sKZ[(j * TILE + mm) * WP + c] * (L.c_err[j] * h);
                 L.ERR[(long)row * W + c] = a;
             }
         }
@@ -474,12 +476,26 @@ extern "C" int nlbac_concat_adj_step(const nlbac_mlp* net, const float* c, int P
     for (int p = 0; p < P; ++p) L.h_val[p] = h_host ? h_host[p] : 0.f;
     L.ctl = ctl;
     using Kernel = void (*)(const ConcatAdjLaunch);
-    static const Kernel kt[3][2] = {{concat_adj_rr_kernel<4, 4, 0>, concat_adj_rr_kernel<4, 4, 1>},
-                                    {concat_adj_rr_kernel<7, 1, 0>, concat_adj_rr_kernel<7, 1, 1>},
-                                    {concat_adj_rr_kernel<8, 4, 0>, concat_adj_rr_kernel<8, 4, 1>}};
+    static const Kernel kt[2][3][2] = {{{concat_adj_rr_kernel<4, 4, 0, 2>, concat_adj_rr_kernel<4, 4, 1, 2>},
+                                        {concat_adj_rr_kernel<7, 1, 0, 2>, concat_adj_rr_kernel<7, 1, 1, 2>},
+                                        {concat_adj_rr_kernel<8, 4, 0, 2>, concat_adj_rr_kernel<8, 4, 1, 2>}},
+                                       {{concat_adj_rr_kernel<4, 4, 0, 4>, concat_adj_rr_kernel<4, 4, 1, 4>},
+                                        {concat_adj_rr_kernel<7, 1, 0, 4>, concat_adj_rr_kernel<7, 1, 1, 4>},
+                                        {concat_adj_rr_kernel<8, 4, 0, 4>, concat_adj_rr_kernel<8, 4, 1, 4>}}};
     const int shape = net->hid == 64 ? 0 : (net->hid == 100 ? 1 : 2);
-    const size_t lds = (size_t)((n_stages_total + 1) * NLBAC_MLP_TILE * L.WP + NLBAC_MLP_TILE * (CK_NC + 2) + 2 * 4 * 8 * 64) * sizeof(float);
-    hipLaunchKernelGGL(kt[shape][keep ? 1 : 0], dim3(nlbac_ceil_div(L.n, NLBAC_MLP_TILE)), dim3(128), lds, (hipStream_t)s, L);
+    // (rows of done problems are skipped per row, nothing else is per tile: a tile may straddle problems)
+    static const int forced_nw = [] { const char* e = getenv("NLBAC_CONCAT_NW"); return e ? atoi(e) : 0; }();
+    const int nw = forced_nw == 2 ? 2 : 4, tile = 16 * nw;
+    const size_t lds = (size_t)((n_stages_total + 1) * tile * L.WP + tile * (CK_NC + 2) + 2 * 4 * 8 * 64) * sizeof(float);
+    const Kernel k = kt[nw == 4][shape][keep ? 1 : 0];
+    if (lds > 64 * 1024) {
+        static bool attr_set[2][3][2] = {};
+        if (!attr_set[nw == 4][shape][keep ? 1 : 0]) {
+            (void)hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 64);
+            attr_set[nw == 4][shape][keep ? 1 : 0] = true;
+        }
+    }
+    hipLaunchKernelGGL(k, dim3(nlbac_ceil_div(L.n, tile)), dim3(64 * nw), lds, (hipStream_t)s, L);
     NLBAC_CHECK_LAUNCH("nlbac_concat_adj_step");
     return 0;
 }

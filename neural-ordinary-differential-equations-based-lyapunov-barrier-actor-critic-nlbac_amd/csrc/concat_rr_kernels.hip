@@ -22,15 +22,20 @@
 #define CSTAMP(slot_)
 #define BSTAMP(slot_)
 #endif
-template <int NB, int R, int BITS>
-__global__ __launch_bounds__(128) void concat_rr_fwd_kernel(const ConcatRkLaunch L) {
+// NW: waves per workgroup (2 or 4: 32- or 64-row tiles).  Four where the problems' row counts allow it (a tile must not
+// straddle two problems of a device-driven chain): of two 2-wave workgroups on one CU the hardware puts two waves on the
+// same SIMD and leaves one SIMD empty (tools/micro/wave_place.hip: 512 workgroups x 128 threads use 768 of the 1024 SIMDs,
+// 256 of them twice) — the doubled-up waves ran a stage in 11-13k cycles against 8.2k, and the launch waits for them.
+template <int NB, int R, int BITS, int NW>
+__global__ __launch_bounds__(64 * NW) void concat_rr_fwd_kernel(const ConcatRkLaunch L) {
+    constexpr int TILE = 16 * NW, NTHR = 64 * NW;
     using S = RRShape<NB, R>;
     constexpr int KS = S::KS, HID = S::HID, TB = NB - 2, NT = KS - 4 * TB, G0 = rr_group_first(NB);
     extern __shared__ __attribute__((aligned(16))) float smem[];
     const int tid = threadIdx.x, lane = tid & 63;
     const int half = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int n = L.n, ns = L.n_s, nc = L.n_c;
-    const int row0 = blockIdx.x * NLBAC_MLP_TILE;
+    const int row0 = blockIdx.x * TILE;
     const int p_tile = row0 / L.rpp;
     long soff = 0;
     bool fsal = false, ip = false;
@@ -54,7 +59,7 @@ __global__ __launch_bounds__(128) void concat_rr_fwd_kernel(const ConcatRkLaunch
     const float* const gy0 = fsal ? (gY - L.slot_floats) + (long)(L.S_total - 1) * n * ns : L.y0;
     const nlbac_mlp& net = L.net;
     const int idim = net.in_dim;
-    const int n_rows = min(NLBAC_MLP_TILE, n - row0);
+    const int n_rows = min(TILE, n - row0);
     const int q = lane >> 4, r16 = lane & 15, m = 16 * half + r16, grow = row0 + m;
     const bool row_ok = grow < n;
     const int KS0 = (ns + 3) >> 2;      // registers per row of state (layer 0 always runs four k-steps over [x | c | 1 | 0..])
@@ -65,10 +70,10 @@ __global__ __launch_bounds__(128) void concat_rr_fwd_kernel(const ConcatRkLaunch
     const int stage_end = L.stage_end;
 
     float* sK = smem;                                               // [stage][32][CK_NS]
-    float* sY0 = sK + CK_MAX_STAGES * NLBAC_MLP_TILE * CK_NS;       // [32][CK_NS]
-    float* sC = sY0 + NLBAC_MLP_TILE * CK_NS;                       // [32][CK_NC]
-    float* sH = sC + NLBAC_MLP_TILE * CK_NC;                        // [32]
-    float* sW0 = sH + NLBAC_MLP_TILE;                               // [k-step < 4][block < 8][lane]: layer 0's A fragments
+    float* sY0 = sK + CK_MAX_STAGES * TILE * CK_NS;       // [32][CK_NS]
+    float* sC = sY0 + TILE * CK_NS;                       // [32][CK_NC]
+    float* sH = sC + TILE * CK_NC;                        // [32]
+    float* sW0 = sH + TILE;                               // [k-step < 4][block < 8][lane]: layer 0's A fragments
 
     // ---- the wave's weight stream: hid x hid layers 1, 2, then 1 again (next stage)
     const __amdgpu_buffer_rsrc_t rs = rr_rsrc(net.packed, net.packed_floats);
@@ -164,7 +169,7 @@ __global__ __launch_bounds__(128) void concat_rr_fwd_kernel(const ConcatRkLaunch
             const int j = idx / (16 * CK_NS), rem = idx - j * 16 * CK_NS;
             const int mm = 16 * half + rem / CK_NS, c = rem % CK_NS, row = row0 + mm;
             if (j < L.stage_begin) {
-                sK[(j * NLBAC_MLP_TILE + mm) * CK_NS + c] = vals[it];
+                sK[(j * TILE + mm) * CK_NS + c] = vals[it];
                 if (fsal && j == 0 && row < n && c < ns) gK[(long)row * ns + c] = vals[it];   // kept in this slot for the interpolant
             }
         }
@@ -213,7 +218,7 @@ __global__ __launch_bounds__(128) void concat_rr_fwd_kernel(const ConcatRkLaunch
                 y0v[k0] = sY0[m * CK_NS + cs];
                 cv[k0] = sC[m * CK_NC + cc];
 #pragma unroll
-                for (int j = 0; j < CK_MAX_STAGES - 1; ++j) kv[k0][j] = sK[(j * NLBAC_MLP_TILE + m) * CK_NS + cs];
+                for (int j = 0; j < CK_MAX_STAGES - 1; ++j) kv[k0][j] = sK[(j * TILE + m) * CK_NS + cs];
             }
 #pragma unroll
             for (int k0 = 0; k0 < 4; ++k0) {
@@ -331,7 +336,7 @@ __global__ __launch_bounds__(128) void concat_rr_fwd_kernel(const ConcatRkLaunch
                 const int c = 4 * r + q;
                 if (r < KS0 && c < ns) {
                     const float val = (o[r] + o_bias[r]) * o_sig[r] + o_mu[r];
-                    sK[(st * NLBAC_MLP_TILE + m) * CK_NS + c] = val;
+                    sK[(st * TILE + m) * CK_NS + c] = val;
                     if (row_ok) gK[srow * ns + c] = val;
                 }
             }
@@ -352,20 +357,20 @@ __global__ __launch_bounds__(128) void concat_rr_fwd_kernel(const ConcatRkLaunch
 #endif
 
     // ---- step outputs
-    for (int idx = tid; idx < NLBAC_MLP_TILE * ns; idx += 128) {
+    for (int idx = tid; idx < TILE * ns; idx += NTHR) {
         const int mm = idx / ns, r = idx - mm * ns, row = row0 + mm;
         if (row >= n) continue;
         const float h = sH[mm];
         if (L.out) {
             float a = sY0[mm * CK_NS + r];
             for (int j = 0; j < L.n_out; ++j)
-                if (L.c_out[j] != 0.f) a = a + sK[(j * NLBAC_MLP_TILE + mm) * CK_NS + r] * (L.c_out[j] * h);
+                if (L.c_out[j] != 0.f) a = a + sK[(j * TILE + mm) * CK_NS + r] * (L.c_out[j] * h);
             L.out[(long)row * ns + r] = a;
         }
         if (gErr) {
             float a = 0.f;
             for (int j = 0; j < L.n_err; ++j)
-                if (L.c_err[j] != 0.f) a = a + sK[(j * NLBAC_MLP_TILE + mm) * CK_NS + r] * (L.c_err[j] * h);
+                if (L.c_err[j] != 0.f) a = a + sK[(j * TILE + mm) * CK_NS + r] * (L.c_err[j] * h);
             gErr[(long)row * ns + r] = a;
         }
     }
@@ -376,9 +381,9 @@ __global__ __launch_bounds__(128) void concat_rr_fwd_kernel(const ConcatRkLaunch
             const float a0 = sY0[mm * CK_NS + r];
             float a1 = a0, k[7];
             for (int j = 0; j < sl; ++j)
-                if (L.beta[sl][j] != 0.f) a1 = a1 + sK[(j * NLBAC_MLP_TILE + mm) * CK_NS + r] * (L.beta[sl][j] * h);
+                if (L.beta[sl][j] != 0.f) a1 = a1 + sK[(j * TILE + mm) * CK_NS + r] * (L.beta[sl][j] * h);
 #pragma unroll
-            for (int j = 0; j < 7; ++j) k[j] = sK[(j * NLBAC_MLP_TILE + mm) * CK_NS + r];
+            for (int j = 0; j < 7; ++j) k[j] = sK[(j * TILE + mm) * CK_NS + r];
             L.ip_out[(long)row * ns + r] = dopri_interp_value(a0, a1, k, h, ip_x);
         }
     }
@@ -395,10 +400,10 @@ __global__ __launch_bounds__(128) void concat_rr_fwd_kernel(const ConcatRkLaunch
                 if (L.norm_mode == 2) {
                     float e = 0.f, y1 = y;
                     for (int j = 0; j < L.n_err; ++j)
-                        if (L.c_err[j] != 0.f) e = e + sK[(j * NLBAC_MLP_TILE + mm) * CK_NS + r] * (L.c_err[j] * h);
+                        if (L.c_err[j] != 0.f) e = e + sK[(j * TILE + mm) * CK_NS + r] * (L.c_err[j] * h);
                     const int sl = L.S_total - 1;
                     for (int j = 0; j < sl; ++j)
-                        if (L.beta[sl][j] != 0.f) y1 = y1 + sK[(j * NLBAC_MLP_TILE + mm) * CK_NS + r] * (L.beta[sl][j] * h);
+                        if (L.beta[sl][j] != 0.f) y1 = y1 + sK[(j * TILE + mm) * CK_NS + r] * (L.beta[sl][j] * h);
                     const float qq = e / (L.atol + L.rtol * fmaxf(fabsf(y), fabsf(y1)));
                     v0 += qq * qq;
                 } else {
@@ -407,7 +412,7 @@ __global__ __launch_bounds__(128) void concat_rr_fwd_kernel(const ConcatRkLaunch
                         const float q0 = y / sc, q1 = sK[mm * CK_NS + r] / sc;
                         v0 += q0 * q0; v1 += q1 * q1;
                     } else {
-                        const float qq = (sK[(NLBAC_MLP_TILE + mm) * CK_NS + r] - sK[mm * CK_NS + r]) / sc;
+                        const float qq = (sK[(TILE + mm) * CK_NS + r] - sK[mm * CK_NS + r]) / sc;
                         v0 += qq * qq;
                     }
                 }
@@ -422,8 +427,8 @@ __global__ __launch_bounds__(128) void concat_rr_fwd_kernel(const ConcatRkLaunch
 #pragma unroll
         for (int off = 32; off > 0; off >>= 1) { v0 += __shfl_down(v0, off, 64); v1 += __shfl_down(v1, off, 64); }
         if (tid == 0) {
-            const int nblk = (L.rpp + NLBAC_MLP_TILE - 1) / NLBAC_MLP_TILE;
-            const int blk = (row0 - p_tile * L.rpp) / NLBAC_MLP_TILE;
+            const int nblk = (L.rpp + TILE - 1) / TILE;
+            const int blk = (row0 - p_tile * L.rpp) / TILE;
             float* pq = L.partials + ((long)p_tile * nblk + blk) * 2;
             const float o0 = __hip_atomic_exchange(pq + 0, v0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             const float o1 = __hip_atomic_exchange(pq + 1, v1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -436,7 +441,7 @@ __global__ __launch_bounds__(128) void concat_rr_fwd_kernel(const ConcatRkLaunch
     __syncthreads();
     if (!s_last || tid >= 64) return;
     {
-        const int nblk = (L.rpp + NLBAC_MLP_TILE - 1) / NLBAC_MLP_TILE;
+        const int nblk = (L.rpp + TILE - 1) / TILE;
         double d0 = 0.0, d1 = 0.0;
         for (int b = tid; b < nblk; b += 64) {
             const float* pq = L.partials + ((long)p_tile * nblk + b) * 2;
@@ -468,15 +473,16 @@ __global__ __launch_bounds__(128) void concat_rr_fwd_kernel(const ConcatRkLaunch
 // block product, dz runs down the chain in registers (backward RR pack), dX = W_0^T dz_0 is one more block product whose
 // state columns feed the stage algebra and whose carried columns accumulate dc — all on the wave's own 16 rows.
 // ---------------------------------------------------------------------------------------------------------------------
-template <int NB, int R, int BITS>
-__global__ __launch_bounds__(128) void concat_rr_bwd_kernel(const ConcatRkBwdLaunch L) {
+template <int NB, int R, int BITS, int NW>
+__global__ __launch_bounds__(64 * NW) void concat_rr_bwd_kernel(const ConcatRkBwdLaunch L) {
+    constexpr int TILE = 16 * NW;
     using S = RRShape<NB, R>;
     constexpr int KS = S::KS, HID = S::HID, TB = NB - 2, NT = KS - 4 * TB;
     extern __shared__ __attribute__((aligned(16))) float smem[];
     const int tid = threadIdx.x, lane = tid & 63;
     const int half = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int n = L.n, ns = L.n_s, nc = L.n_c;
-    const int row0 = blockIdx.x * NLBAC_MLP_TILE;
+    const int row0 = blockIdx.x * TILE;
     long soff = 0;
     int slot = 0;
     const bool chained = L.ctl != nullptr;
@@ -506,11 +512,11 @@ __global__ __launch_bounds__(128) void concat_rr_bwd_kernel(const ConcatRkBwdLau
     const int dx_stage0 = L.dx_stage0;
 
     float* sDK = smem;                                              // [stage][32][CK_NS]
-    float* sH = sDK + CK_MAX_STAGES * NLBAC_MLP_TILE * CK_NS;       // [32]
-    float* sDY0 = sH + NLBAC_MLP_TILE;                              // [32][CK_NS] running dy0
-    float* sDC = sDY0 + NLBAC_MLP_TILE * CK_NS;                     // [32][CK_NC] running d carried
-    float* sDX = sDC + NLBAC_MLP_TILE * CK_NC;                      // [32][16] dX of the current stage (input columns)
-    float* sWt = sDX + NLBAC_MLP_TILE * 16;                         // [k-step < 4][block < 8][lane]: W_out^T's A fragments
+    float* sH = sDK + CK_MAX_STAGES * TILE * CK_NS;       // [32]
+    float* sDY0 = sH + TILE;                              // [32][CK_NS] running dy0
+    float* sDC = sDY0 + TILE * CK_NS;                     // [32][CK_NC] running d carried
+    float* sDX = sDC + TILE * CK_NC;                      // [32][16] dX of the current stage (input columns)
+    float* sWt = sDX + TILE * 16;                         // [k-step < 4][block < 8][lane]: W_out^T's A fragments
     float* sDYup = sWt + 4 * 8 * 64;                                // [32][CK_NS] dL/dy1 when the launch forms it itself (ip)
 
     const int st_lo = chained ? (slot == 0 ? 0 : 1) : L.st_lo;
@@ -580,7 +586,7 @@ __global__ __launch_bounds__(128) void concat_rr_bwd_kernel(const ConcatRkBwdLau
                 sDY0[mm * CK_NS + c] = ok ? d0v : 0.f;
                 sDYup[mm * CK_NS + c] = ok ? d1v : 0.f;
 #pragma unroll
-                for (int j = 0; j < 7; ++j) sDK[(j * NLBAC_MLP_TILE + mm) * CK_NS + c] = ok ? dk[j] : 0.f;
+                for (int j = 0; j < 7; ++j) sDK[(j * TILE + mm) * CK_NS + c] = ok ? dk[j] : 0.f;
             }
         }
     } else {
@@ -621,7 +627,7 @@ __global__ __launch_bounds__(128) void concat_rr_bwd_kernel(const ConcatRkBwdLau
             const int idx = lane + 64 * it;
             const int j = idx / (16 * CK_NS), rem = idx - j * 16 * CK_NS;
             const int mm = 16 * half + rem / CK_NS, c = rem % CK_NS;
-            if (j < L.st_hi) sDK[(j * NLBAC_MLP_TILE + mm) * CK_NS + c] = vals[it];
+            if (j < L.st_hi) sDK[(j * TILE + mm) * CK_NS + c] = vals[it];
         }
     }
     __syncthreads();           // (sWt is shared by the two waves)
@@ -663,7 +669,7 @@ __global__ __launch_bounds__(128) void concat_rr_bwd_kernel(const ConcatRkBwdLau
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
             const int c = 4 * e + q;
-            const float raw = sDK[(st * NLBAC_MLP_TILE + m) * CK_NS + min(c, ns - 1)];
+            const float raw = sDK[(st * TILE + m) * CK_NS + min(c, ns - 1)];
             const float v = (e < KS0 && c < ns) ? raw * o_sig[e] : 0.f;
             if (gdyn && nrm && row_ok && e < KS0 && c < ns) gdyn[((long)st * n + grow) * ns + c] = v;
             dy[e] = v;
@@ -763,7 +769,7 @@ __global__ __launch_bounds__(128) void concat_rr_bwd_kernel(const ConcatRkBwdLau
                 yv0[r] = sDY0[m * CK_NS + cs];
                 dcv[r] = sDC[m * CK_NC + cc];
 #pragma unroll
-                for (int j = 0; j < CK_MAX_STAGES - 1; ++j) kvv[r][j] = sDK[(j * NLBAC_MLP_TILE + m) * CK_NS + cs];
+                for (int j = 0; j < CK_MAX_STAGES - 1; ++j) kvv[r][j] = sDK[(j * TILE + m) * CK_NS + cs];
                 gup[r] = up ? (ip ? sDYup[m * CK_NS + cs] : gdYup[(long)growc * ns + cs]) : 0.f;
             }
 #pragma unroll
@@ -777,7 +783,7 @@ __global__ __launch_bounds__(128) void concat_rr_bwd_kernel(const ConcatRkBwdLau
 #pragma unroll
                     for (int j = 0; j < CK_MAX_STAGES - 1; ++j) {
                         const float t = kvv[r][j] + (bn[j] * h) * d;
-                        sDK[(j * NLBAC_MLP_TILE + m) * CK_NS + i] = (j < st && bn[j] != 0.f) ? t : kvv[r][j];
+                        sDK[(j * TILE + m) * CK_NS + i] = (j < st && bn[j] != 0.f) ? t : kvv[r][j];
                     }
                 } else if (i < ns + nc) {
                     sDC[m * CK_NC + (i - ns)] = dcv[r] + dxv;
@@ -791,7 +797,7 @@ __global__ __launch_bounds__(128) void concat_rr_bwd_kernel(const ConcatRkBwdLau
     for (int idx = lane; idx < L.st_hi * 16 * ns; idx += 64) {
         const int j = idx / (16 * ns), rem = idx - j * 16 * ns;
         const int mm = 16 * half + rem / ns, c = rem % ns, row = row0 + mm;
-        if (row < n) gdK[((long)j * n + row) * ns + c] = sDK[(j * NLBAC_MLP_TILE + mm) * CK_NS + c];
+        if (row < n) gdK[((long)j * n + row) * ns + c] = sDK[(j * TILE + mm) * CK_NS + c];
     }
     if (gdy0)
         for (int idx = lane; idx < 16 * ns; idx += 64) {
@@ -820,14 +826,25 @@ static bool crr_eligible(const nlbac_mlp& net) {
            net.rr_fwd_off >= 0 && net.rr_bwd_off >= 0 && net.in_dim <= CRR_MAX_IN && net.out_dim <= CK_NS;
 }
 
+// waves per workgroup: four (64-row tiles) unless a tile would then straddle two problems; NLBAC_CONCAT_NW=2 keeps two
+static int crr_waves(int n, int rpp) {
+    static const int forced = [] { const char* e = getenv("NLBAC_CONCAT_NW"); return e ? atoi(e) : 0; }();
+    if (forced == 2) return 2;
+    return (rpp >= n || rpp % 64 == 0) ? 4 : 2;
+}
+
 int nlbac_concat_rr_fwd_launch(ConcatRkLaunch& L, hipStream_t s) {
     if (!crr_eligible(L.net)) return 1;
     using KernelF = void (*)(const ConcatRkLaunch);
-    static const KernelF kf[3][2] = {{concat_rr_fwd_kernel<4, 4, 0>, concat_rr_fwd_kernel<4, 4, 1>},
-                                     {concat_rr_fwd_kernel<7, 1, 0>, concat_rr_fwd_kernel<7, 1, 1>},
-                                     {concat_rr_fwd_kernel<8, 4, 0>, concat_rr_fwd_kernel<8, 4, 1>}};
-    const size_t lds = (size_t)(CK_MAX_STAGES * NLBAC_MLP_TILE * CK_NS + NLBAC_MLP_TILE * (CK_NS + CK_NC + 1) + 4 * 8 * 64) * sizeof(float);
-    hipLaunchKernelGGL(kf[crr_shape_index(L.net.hid)][L.acts_bits ? 1 : 0], dim3(nlbac_ceil_div(L.n, NLBAC_MLP_TILE)), dim3(128), lds, s, L);
+    static const KernelF kf[2][3][2] = {{{concat_rr_fwd_kernel<4, 4, 0, 2>, concat_rr_fwd_kernel<4, 4, 1, 2>},
+                                         {concat_rr_fwd_kernel<7, 1, 0, 2>, concat_rr_fwd_kernel<7, 1, 1, 2>},
+                                         {concat_rr_fwd_kernel<8, 4, 0, 2>, concat_rr_fwd_kernel<8, 4, 1, 2>}},
+                                        {{concat_rr_fwd_kernel<4, 4, 0, 4>, concat_rr_fwd_kernel<4, 4, 1, 4>},
+                                         {concat_rr_fwd_kernel<7, 1, 0, 4>, concat_rr_fwd_kernel<7, 1, 1, 4>},
+                                         {concat_rr_fwd_kernel<8, 4, 0, 4>, concat_rr_fwd_kernel<8, 4, 1, 4>}}};
+    const int nw = crr_waves(L.n, L.rpp), tile = 16 * nw;
+    const size_t lds = (size_t)(CK_MAX_STAGES * tile * CK_NS + tile * (CK_NS + CK_NC + 1) + 4 * 8 * 64) * sizeof(float);
+    hipLaunchKernelGGL(kf[nw == 4][crr_shape_index(L.net.hid)][L.acts_bits ? 1 : 0], dim3(nlbac_ceil_div(L.n, tile)), dim3(64 * nw), lds, s, L);
     NLBAC_CHECK_LAUNCH("nlbac_concat_rk_fwd(rr)");
     return 0;
 }
@@ -835,11 +852,15 @@ int nlbac_concat_rr_fwd_launch(ConcatRkLaunch& L, hipStream_t s) {
 int nlbac_concat_rr_bwd_launch(ConcatRkBwdLaunch& L, hipStream_t s) {
     if (!crr_eligible(L.net)) return 1;
     using KernelB = void (*)(const ConcatRkBwdLaunch);
-    static const KernelB kb[3][2] = {{concat_rr_bwd_kernel<4, 4, 0>, concat_rr_bwd_kernel<4, 4, 1>},
-                                     {concat_rr_bwd_kernel<7, 1, 0>, concat_rr_bwd_kernel<7, 1, 1>},
-                                     {concat_rr_bwd_kernel<8, 4, 0>, concat_rr_bwd_kernel<8, 4, 1>}};
-    const size_t lds = (size_t)(CK_MAX_STAGES * NLBAC_MLP_TILE * CK_NS + NLBAC_MLP_TILE * (1 + CK_NS + CK_NC + 16 + CK_NS) + 4 * 8 * 64) * sizeof(float);
-    hipLaunchKernelGGL(kb[crr_shape_index(L.net.hid)][L.acts_bits ? 1 : 0], dim3(nlbac_ceil_div(L.n, NLBAC_MLP_TILE)), dim3(128), lds, s, L);
+    static const KernelB kb[2][3][2] = {{{concat_rr_bwd_kernel<4, 4, 0, 2>, concat_rr_bwd_kernel<4, 4, 1, 2>},
+                                         {concat_rr_bwd_kernel<7, 1, 0, 2>, concat_rr_bwd_kernel<7, 1, 1, 2>},
+                                         {concat_rr_bwd_kernel<8, 4, 0, 2>, concat_rr_bwd_kernel<8, 4, 1, 2>}},
+                                        {{concat_rr_bwd_kernel<4, 4, 0, 4>, concat_rr_bwd_kernel<4, 4, 1, 4>},
+                                         {concat_rr_bwd_kernel<7, 1, 0, 4>, concat_rr_bwd_kernel<7, 1, 1, 4>},
+                                         {concat_rr_bwd_kernel<8, 4, 0, 4>, concat_rr_bwd_kernel<8, 4, 1, 4>}}};
+    const int nw = crr_waves(L.n, L.rpp), tile = 16 * nw;
+    const size_t lds = (size_t)(CK_MAX_STAGES * tile * CK_NS + tile * (1 + CK_NS + CK_NC + 16 + CK_NS) + 4 * 8 * 64) * sizeof(float);
+    hipLaunchKernelGGL(kb[nw == 4][crr_shape_index(L.net.hid)][L.acts_bits ? 1 : 0], dim3(nlbac_ceil_div(L.n, tile)), dim3(64 * nw), lds, s, L);
     NLBAC_CHECK_LAUNCH("nlbac_concat_rk_bwd(rr)");
     return 0;
 }
