@@ -6,7 +6,9 @@
 #include "ode_control.h"
 
 #define CK_MAX_STAGES 8
-#define CK_NS 16          // LDS row stride of state-sized rows (n_s <= 16)
+#define CK_NS 16          // widest state (n_s <= 16); LDS row stride of state-sized rows in the LDS-tiled kernels
+#define CK_LD 17          // the same rows in the register-resident kernels: lane (q, row) reads component 4 k + q of ITS row, so
+                          // sixteen lanes walk the rows of one column — a stride of 16 floats put them on two banks (8-way conflict)
 #define CK_NC 4           // carried inputs per row (n_c <= 4)
 
 struct ConcatRkLaunch {

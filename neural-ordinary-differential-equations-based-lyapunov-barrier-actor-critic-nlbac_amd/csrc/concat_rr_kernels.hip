@@ -70,8 +70,8 @@ __global__ __launch_bounds__(64 * NW) void concat_rr_fwd_kernel(const ConcatRkLa
     const int stage_end = L.stage_end;
 
     float* sK = smem;                                               // [stage][32][CK_NS]
-    float* sY0 = sK + CK_MAX_STAGES * TILE * CK_NS;       // [32][CK_NS]
-    float* sC = sY0 + TILE * CK_NS;                       // [32][CK_NC]
+    float* sY0 = sK + CK_MAX_STAGES * TILE * CK_LD;       // [32][CK_NS]
+    float* sC = sY0 + TILE * CK_LD;                       // [32][CK_NC]
     float* sH = sC + TILE * CK_NC;                        // [32]
     float* sW0 = sH + TILE;                               // [k-step < 4][block < 8][lane]: layer 0's A fragments
 
@@ -136,7 +136,7 @@ __global__ __launch_bounds__(64 * NW) void concat_rr_fwd_kernel(const ConcatRkLa
     for (int idx = lane; idx < 16 * CK_NS; idx += 64) {
         const int mm = 16 * half + idx / CK_NS, c = idx % CK_NS, row = row0 + mm;
         const float v = gy0[(long)min(row, n - 1) * ns + min(c, ns - 1)];
-        sY0[mm * CK_NS + c] = (row < n && c < ns) ? v : 0.f;
+        sY0[mm * CK_LD + c] = (row < n && c < ns) ? v : 0.f;
     }
     {
         const int mm = 16 * half + (lane >> 2), c = lane & 3, row = row0 + mm;
@@ -169,7 +169,7 @@ __global__ __launch_bounds__(64 * NW) void concat_rr_fwd_kernel(const ConcatRkLa
             const int j = idx / (16 * CK_NS), rem = idx - j * 16 * CK_NS;
             const int mm = 16 * half + rem / CK_NS, c = rem % CK_NS, row = row0 + mm;
             if (j < L.stage_begin) {
-                sK[(j * TILE + mm) * CK_NS + c] = vals[it];
+                sK[(j * TILE + mm) * CK_LD + c] = vals[it];
                 if (fsal && j == 0 && row < n && c < ns) gK[(long)row * ns + c] = vals[it];   // kept in this slot for the interpolant
             }
         }
@@ -215,10 +215,10 @@ __global__ __launch_bounds__(64 * NW) void concat_rr_fwd_kernel(const ConcatRkLa
 #pragma unroll
             for (int k0 = 0; k0 < 4; ++k0) {
                 const int col = 4 * k0 + q, cs = min(col, ns - 1), cc = min(max(col - ns, 0), max(nc - 1, 0));
-                y0v[k0] = sY0[m * CK_NS + cs];
+                y0v[k0] = sY0[m * CK_LD + cs];
                 cv[k0] = sC[m * CK_NC + cc];
 #pragma unroll
-                for (int j = 0; j < CK_MAX_STAGES - 1; ++j) kv[k0][j] = sK[(j * TILE + m) * CK_NS + cs];
+                for (int j = 0; j < CK_MAX_STAGES - 1; ++j) kv[k0][j] = sK[(j * TILE + m) * CK_LD + cs];
             }
 #pragma unroll
             for (int k0 = 0; k0 < 4; ++k0) {
@@ -336,7 +336,7 @@ __global__ __launch_bounds__(64 * NW) void concat_rr_fwd_kernel(const ConcatRkLa
                 const int c = 4 * r + q;
                 if (r < KS0 && c < ns) {
                     const float val = (o[r] + o_bias[r]) * o_sig[r] + o_mu[r];
-                    sK[(st * TILE + m) * CK_NS + c] = val;
+                    sK[(st * TILE + m) * CK_LD + c] = val;
                     if (row_ok) gK[srow * ns + c] = val;
                 }
             }
@@ -362,15 +362,15 @@ __global__ __launch_bounds__(64 * NW) void concat_rr_fwd_kernel(const ConcatRkLa
         if (row >= n) continue;
         const float h = sH[mm];
         if (L.out) {
-            float a = sY0[mm * CK_NS + r];
+            float a = sY0[mm * CK_LD + r];
             for (int j = 0; j < L.n_out; ++j)
-                if (L.c_out[j] != 0.f) a = a + sK[(j * TILE + mm) * CK_NS + r] * (L.c_out[j] * h);
+                if (L.c_out[j] != 0.f) a = a + sK[(j * TILE + mm) * CK_LD + r] * (L.c_out[j] * h);
             L.out[(long)row * ns + r] = a;
         }
         if (gErr) {
             float a = 0.f;
             for (int j = 0; j < L.n_err; ++j)
-                if (L.c_err[j] != 0.f) a = a + sK[(j * TILE + mm) * CK_NS + r] * (L.c_err[j] * h);
+                if (L.c_err[j] != 0.f) a = a + sK[(j * TILE + mm) * CK_LD + r] * (L.c_err[j] * h);
             gErr[(long)row * ns + r] = a;
         }
     }
@@ -378,12 +378,12 @@ __global__ __launch_bounds__(64 * NW) void concat_rr_fwd_kernel(const ConcatRkLa
         const int mm = tid, row = row0 + mm, sl = L.S_total - 1;
         const float h = sH[mm];
         for (int r = 0; r < ns; ++r) {
-            const float a0 = sY0[mm * CK_NS + r];
+            const float a0 = sY0[mm * CK_LD + r];
             float a1 = a0, k[7];
             for (int j = 0; j < sl; ++j)
-                if (L.beta[sl][j] != 0.f) a1 = a1 + sK[(j * TILE + mm) * CK_NS + r] * (L.beta[sl][j] * h);
+                if (L.beta[sl][j] != 0.f) a1 = a1 + sK[(j * TILE + mm) * CK_LD + r] * (L.beta[sl][j] * h);
 #pragma unroll
-            for (int j = 0; j < 7; ++j) k[j] = sK[(j * TILE + mm) * CK_NS + r];
+            for (int j = 0; j < 7; ++j) k[j] = sK[(j * TILE + mm) * CK_LD + r];
             L.ip_out[(long)row * ns + r] = dopri_interp_value(a0, a1, k, h, ip_x);
         }
     }
@@ -396,23 +396,23 @@ __global__ __launch_bounds__(64 * NW) void concat_rr_fwd_kernel(const ConcatRkLa
         if (mm < n_rows) {
             const float h = sH[mm];
             for (int r = 0; r < ns; ++r) {
-                const float y = sY0[mm * CK_NS + r];
+                const float y = sY0[mm * CK_LD + r];
                 if (L.norm_mode == 2) {
                     float e = 0.f, y1 = y;
                     for (int j = 0; j < L.n_err; ++j)
-                        if (L.c_err[j] != 0.f) e = e + sK[(j * TILE + mm) * CK_NS + r] * (L.c_err[j] * h);
+                        if (L.c_err[j] != 0.f) e = e + sK[(j * TILE + mm) * CK_LD + r] * (L.c_err[j] * h);
                     const int sl = L.S_total - 1;
                     for (int j = 0; j < sl; ++j)
-                        if (L.beta[sl][j] != 0.f) y1 = y1 + sK[(j * TILE + mm) * CK_NS + r] * (L.beta[sl][j] * h);
+                        if (L.beta[sl][j] != 0.f) y1 = y1 + sK[(j * TILE + mm) * CK_LD + r] * (L.beta[sl][j] * h);
                     const float qq = e / (L.atol + L.rtol * fmaxf(fabsf(y), fabsf(y1)));
                     v0 += qq * qq;
                 } else {
                     const float sc = L.atol + fabsf(y) * L.rtol;
                     if (L.norm_mode == 0) {
-                        const float q0 = y / sc, q1 = sK[mm * CK_NS + r] / sc;
+                        const float q0 = y / sc, q1 = sK[mm * CK_LD + r] / sc;
                         v0 += q0 * q0; v1 += q1 * q1;
                     } else {
-                        const float qq = (sK[(TILE + mm) * CK_NS + r] - sK[mm * CK_NS + r]) / sc;
+                        const float qq = (sK[(TILE + mm) * CK_LD + r] - sK[mm * CK_LD + r]) / sc;
                         v0 += qq * qq;
                     }
                 }
@@ -512,9 +512,9 @@ __global__ __launch_bounds__(64 * NW) void concat_rr_bwd_kernel(const ConcatRkBw
     const int dx_stage0 = L.dx_stage0;
 
     float* sDK = smem;                                              // [stage][32][CK_NS]
-    float* sH = sDK + CK_MAX_STAGES * TILE * CK_NS;       // [32]
+    float* sH = sDK + CK_MAX_STAGES * TILE * CK_LD;       // [32]
     float* sDY0 = sH + TILE;                              // [32][CK_NS] running dy0
-    float* sDC = sDY0 + TILE * CK_NS;                     // [32][CK_NC] running d carried
+    float* sDC = sDY0 + TILE * CK_LD;                     // [32][CK_NC] running d carried
     float* sDX = sDC + TILE * CK_NC;                      // [32][16] dX of the current stage (input columns)
     float* sWt = sDX + TILE * 16;                         // [k-step < 4][block < 8][lane]: W_out^T's A fragments
     float* sDYup = sWt + 4 * 8 * 64;                                // [32][CK_NS] dL/dy1 when the launch forms it itself (ip)
@@ -574,7 +574,7 @@ __global__ __launch_bounds__(64 * NW) void concat_rr_bwd_kernel(const ConcatRkBw
     }
     if (ip) {       // (uniform) the interpolant's backward for this wave's rows (ode_kernels.hip::dopri_interp_bwd_kernel's arithmetic)
 #pragma unroll
-        for (int it = 0; it < (16 * CK_NS + 63) / 64; ++it) {
+        for (int it = 0; it < (16 * CK_LD + 63) / 64; ++it) {
             const int idx = lane + 64 * it;
             const int mm = 16 * half + idx / CK_NS, c = idx % CK_NS, row = row0 + mm, rowc = min(row, n - 1), p = rowc / L.rpp;
             const float hh = (float)L.ctl[(long)p * NLBAC_DOPRI_CTL + C_HUSED], xx = (float)L.ctl[(long)p * NLBAC_DOPRI_CTL + C_X];
@@ -583,21 +583,21 @@ __global__ __launch_bounds__(64 * NW) void concat_rr_bwd_kernel(const ConcatRkBw
             dopri_interp_grad(g, hh, xx, d0v, d1v, dk);
             const bool ok = row < n && c < ns;
             if (idx < 16 * CK_NS) {
-                sDY0[mm * CK_NS + c] = ok ? d0v : 0.f;
-                sDYup[mm * CK_NS + c] = ok ? d1v : 0.f;
+                sDY0[mm * CK_LD + c] = ok ? d0v : 0.f;
+                sDYup[mm * CK_LD + c] = ok ? d1v : 0.f;
 #pragma unroll
-                for (int j = 0; j < 7; ++j) sDK[(j * TILE + mm) * CK_NS + c] = ok ? dk[j] : 0.f;
+                for (int j = 0; j < 7; ++j) sDK[(j * TILE + mm) * CK_LD + c] = ok ? dk[j] : 0.f;
             }
         }
     } else {
         const bool have = gdy0 && L.dy0_in && !carry;
 #pragma unroll
-        for (int it = 0; it < (16 * CK_NS + 63) / 64; ++it) {
+        for (int it = 0; it < (16 * CK_LD + 63) / 64; ++it) {
             const int idx = lane + 64 * it;
             const int mm = 16 * half + idx / CK_NS, c = idx % CK_NS, row = row0 + mm;
             float v = 0.f;
             if (have) v = gdy0[(long)min(row, n - 1) * ns + min(c, ns - 1)];
-            if (idx < 16 * CK_NS) sDY0[mm * CK_NS + c] = (row < n && c < ns) ? v : 0.f;
+            if (idx < 16 * CK_NS) sDY0[mm * CK_LD + c] = (row < n && c < ns) ? v : 0.f;
         }
     }
     if (lane < 16) {
@@ -627,7 +627,7 @@ __global__ __launch_bounds__(64 * NW) void concat_rr_bwd_kernel(const ConcatRkBw
             const int idx = lane + 64 * it;
             const int j = idx / (16 * CK_NS), rem = idx - j * 16 * CK_NS;
             const int mm = 16 * half + rem / CK_NS, c = rem % CK_NS;
-            if (j < L.st_hi) sDK[(j * TILE + mm) * CK_NS + c] = vals[it];
+            if (j < L.st_hi) sDK[(j * TILE + mm) * CK_LD + c] = vals[it];
         }
     }
     __syncthreads();           // (sWt is shared by the two waves)
@@ -669,7 +669,7 @@ __global__ __launch_bounds__(64 * NW) void concat_rr_bwd_kernel(const ConcatRkBw
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
             const int c = 4 * e + q;
-            const float raw = sDK[(st * TILE + m) * CK_NS + min(c, ns - 1)];
+            const float raw = sDK[(st * TILE + m) * CK_LD + min(c, ns - 1)];
             const float v = (e < KS0 && c < ns) ? raw * o_sig[e] : 0.f;
             if (gdyn && nrm && row_ok && e < KS0 && c < ns) gdyn[((long)st * n + grow) * ns + c] = v;
             dy[e] = v;
@@ -766,11 +766,11 @@ __global__ __launch_bounds__(64 * NW) void concat_rr_bwd_kernel(const ConcatRkBw
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
                 const int i = 4 * q + r, cs = min(i, ns - 1), cc = min(max(i - ns, 0), max(nc - 1, 0));
-                yv0[r] = sDY0[m * CK_NS + cs];
+                yv0[r] = sDY0[m * CK_LD + cs];
                 dcv[r] = sDC[m * CK_NC + cc];
 #pragma unroll
-                for (int j = 0; j < CK_MAX_STAGES - 1; ++j) kvv[r][j] = sDK[(j * TILE + m) * CK_NS + cs];
-                gup[r] = up ? (ip ? sDYup[m * CK_NS + cs] : gdYup[(long)growc * ns + cs]) : 0.f;
+                for (int j = 0; j < CK_MAX_STAGES - 1; ++j) kvv[r][j] = sDK[(j * TILE + m) * CK_LD + cs];
+                gup[r] = up ? (ip ? sDYup[m * CK_LD + cs] : gdYup[(long)growc * ns + cs]) : 0.f;
             }
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
@@ -779,11 +779,11 @@ __global__ __launch_bounds__(64 * NW) void concat_rr_bwd_kernel(const ConcatRkBw
                 if (i < ns) {
                     float d = (up && row_ok) ? gup[r] : 0.f;
                     d += dxv;
-                    sDY0[m * CK_NS + i] = yv0[r] + d;
+                    sDY0[m * CK_LD + i] = yv0[r] + d;
 #pragma unroll
                     for (int j = 0; j < CK_MAX_STAGES - 1; ++j) {
                         const float t = kvv[r][j] + (bn[j] * h) * d;
-                        sDK[(j * TILE + m) * CK_NS + i] = (j < st && bn[j] != 0.f) ? t : kvv[r][j];
+                        sDK[(j * TILE + m) * CK_LD + i] = (j < st && bn[j] != 0.f) ? t : kvv[r][j];
                     }
                 } else if (i < ns + nc) {
                     sDC[m * CK_NC + (i - ns)] = dcv[r] + dxv;
@@ -797,12 +797,12 @@ __global__ __launch_bounds__(64 * NW) void concat_rr_bwd_kernel(const ConcatRkBw
     for (int idx = lane; idx < L.st_hi * 16 * ns; idx += 64) {
         const int j = idx / (16 * ns), rem = idx - j * 16 * ns;
         const int mm = 16 * half + rem / ns, c = rem % ns, row = row0 + mm;
-        if (row < n) gdK[((long)j * n + row) * ns + c] = sDK[(j * TILE + mm) * CK_NS + c];
+        if (row < n) gdK[((long)j * n + row) * ns + c] = sDK[(j * TILE + mm) * CK_LD + c];
     }
     if (gdy0)
         for (int idx = lane; idx < 16 * ns; idx += 64) {
             const int mm = 16 * half + idx / ns, c = idx % ns, row = row0 + mm;
-            if (row < n) gdy0[(long)row * ns + c] = sDY0[mm * CK_NS + c];
+            if (row < n) gdy0[(long)row * ns + c] = sDY0[mm * CK_LD + c];
         }
     if (L.dc)
         for (int idx = lane; idx < 16 * nc; idx += 64) {
@@ -843,7 +843,7 @@ int nlbac_concat_rr_fwd_launch(ConcatRkLaunch& L, hipStream_t s) {
                                          {concat_rr_fwd_kernel<7, 1, 0, 4>, concat_rr_fwd_kernel<7, 1, 1, 4>},
                                          {concat_rr_fwd_kernel<8, 4, 0, 4>, concat_rr_fwd_kernel<8, 4, 1, 4>}}};
     const int nw = crr_waves(L.n, L.rpp), tile = 16 * nw;
-    const size_t lds = (size_t)(CK_MAX_STAGES * tile * CK_NS + tile * (CK_NS + CK_NC + 1) + 4 * 8 * 64) * sizeof(float);
+    const size_t lds = (size_t)(CK_MAX_STAGES * tile * CK_LD + tile * (CK_LD + CK_NC + 1) + 4 * 8 * 64) * sizeof(float);
     hipLaunchKernelGGL(kf[nw == 4][crr_shape_index(L.net.hid)][L.acts_bits ? 1 : 0], dim3(nlbac_ceil_div(L.n, tile)), dim3(64 * nw), lds, s, L);
     NLBAC_CHECK_LAUNCH("nlbac_concat_rk_fwd(rr)");
     return 0;
@@ -859,7 +859,7 @@ int nlbac_concat_rr_bwd_launch(ConcatRkBwdLaunch& L, hipStream_t s) {
                                          {concat_rr_bwd_kernel<7, 1, 0, 4>, concat_rr_bwd_kernel<7, 1, 1, 4>},
                                          {concat_rr_bwd_kernel<8, 4, 0, 4>, concat_rr_bwd_kernel<8, 4, 1, 4>}}};
     const int nw = crr_waves(L.n, L.rpp), tile = 16 * nw;
-    const size_t lds = (size_t)(CK_MAX_STAGES * tile * CK_NS + tile * (1 + CK_NS + CK_NC + 16 + CK_NS) + 4 * 8 * 64) * sizeof(float);
+    const size_t lds = (size_t)(CK_MAX_STAGES * tile * CK_LD + tile * (1 + CK_LD + CK_NC + 16 + CK_LD) + 4 * 8 * 64) * sizeof(float);
     hipLaunchKernelGGL(kb[nw == 4][crr_shape_index(L.net.hid)][L.acts_bits ? 1 : 0], dim3(nlbac_ceil_div(L.n, tile)), dim3(64 * nw), lds, s, L);
     NLBAC_CHECK_LAUNCH("nlbac_concat_rk_bwd(rr)");
     return 0;
