@@ -84,13 +84,14 @@ __global__ __launch_bounds__(64 * NW) void concat_rr_fwd_kernel(const ConcatRkLa
 
     // ---- constants: layer 0's A fragments over [x | c | 1] (bias in the column behind the inputs) -> LDS, the output
     //      layer's into registers (A row 4 q' + r' computes state component 4 r' + q')
-    if (half == 0) {
+    {       // (the workgroup's waves share the job: k-step k0 by wave k0 mod NW)
         const float* W0 = params + net.w_off[0];
         const float* b0 = params + net.b_off[0];
 #pragma unroll
-        for (int k0 = 0; k0 < 4; ++k0)
+        for (int kk = 0; kk < 4 / NW; ++kk)
 #pragma unroll
             for (int jo = 0; jo < NB; ++jo) {
+                const int k0 = half + NW * kk;
                 const int uo = rr_unit_out(NB, R, jo, r16), col = 4 * k0 + q, uc = max(uo, 0);
                 const float vw = W0[uc * idim + min(col, idim - 1)], vb0 = b0[uc];
                 sW0[(k0 * 8 + jo) * 64 + lane] = (uo < 0 || col > idim) ? 0.f : (col < idim ? vw : vb0);
@@ -529,10 +530,11 @@ __global__ __launch_bounds__(64 * NW) void concat_rr_bwd_kernel(const ConcatRkBw
     BSTAMP(0)
     gemm.prime(rs, voff, wbase + S::LAYER_BYTES);           // (layer 2's fragments first, then layer 1's)
 
-    if (half == 0) {
+    {       // (k-step e by wave e mod NW)
         const float* Wl = params + net.w_off[3];
 #pragma unroll
-        for (int e = 0; e < 4; ++e) {
+        for (int ee = 0; ee < 4 / NW; ++ee) {
+            const int e = half + NW * ee;
             const int c = 4 * e + q;
             const bool ok = e < KS0 && c < ns;
 #pragma unroll
