@@ -32,7 +32,7 @@
 extern "C" {
 #endif
 
-#define NLBAC_ABI_VERSION 7 /* bumped whenever an exported signature or struct changes; nlbac_abi_version() returns it */
+#define NLBAC_ABI_VERSION 8 /* bumped whenever an exported signature or struct changes; nlbac_abi_version() returns it */
 #define NLBAC_MAX_LAYERS 6
 #define NLBAC_MAX_NETS 8
 #define NLBAC_MLP_TILE 32 /* samples per workgroup in the MLP kernels */
@@ -611,7 +611,12 @@ int nlbac_node_adj_step(const nlbac_mlp *f, const nlbac_mlp *g, const float *u, 
                         const float *c_err, int n_err, const float *h_host, const double *h_dev, int h_dev_stride,
                         const double *ctl, const float *Z0, float *KZ, float *Z1, float *ERR, float *ZS, float *dG,
                         float *acts_f, long acts_f_ls, float *acts_g, long acts_g_ls, float *dz_f, float *dz_g,
-                        nlbac_stream_t s);
+                        float *interp_out /* ABI 8; or NULL */, double t_end, nlbac_stream_t s);
+/* interp_out [n][W] (with ctl, an attempt launch of dopri5: st_hi == n_stages_total == 7, Z1 given; nlbac_node_adj_interp_ok
+ * says whether the kernel that serves the nets evaluates it): a problem whose attempted step reaches t_end (ctl: t + h >=
+ * t_end) also gets the interpolant of z at t_end written for its rows — what nlbac_dopri_interp_fwd(Z0, Z1, KZ, ctl, .., W)
+ * does as a launch of its own after the accept decision; a rejected attempt's values are overwritten by the next. */
+int nlbac_node_adj_interp_ok(const nlbac_mlp *f, const nlbac_mlp *g);
 /* Z[row] = [y | a_x | 0]  and  (dy0, du) = (Z[:, n_s:2n_s], Z[:, 2n_s:])  (either output may be NULL) */
 int nlbac_adj_pack(const float *y, const float *a_x, int n_s, int n_u, int n, float *Z, nlbac_stream_t s);
 int nlbac_adj_unpack(const float *Z, int n_s, int n_u, int n, float *dy0, float *du, nlbac_stream_t s);
@@ -623,7 +628,10 @@ int nlbac_adj_unpack(const float *Z, int n_s, int n_u, int n, float *dy0, float 
  * done is skipped in mode 2. */
 int nlbac_adj_norm_control(const float *a, const float *b, const float *Z0, const float *Z1, const float *u, int mode,
                            float rtol, float atol, int n_s, int n_u, int rows_per_problem, int P, double t_end,
-                           const float *pnorm, float *partials, unsigned *tickets, double *ctl, nlbac_stream_t s);
+                           const float *pnorm, float *partials, unsigned *tickets, double *ctl,
+                           double *ctl_host /* ABI 8; or NULL: pinned HOST memory [P][NLBAC_DOPRI_CTL], the controller
+                                               leaves a copy of each block it updates there (with tickets only) */,
+                           nlbac_stream_t s);
 int nlbac_adj_control(const float *partials, int n_blk_per_problem, int mode, int n_s, int n_u, int rows_per_problem,
                       int P, double t_end, const float *pnorm, double *ctl, nlbac_stream_t s);
 /* After an attempted step, on the device: rows (w floats each) of problems whose step was accepted and whose solve
@@ -670,7 +678,8 @@ int nlbac_concat_adj_step(const nlbac_mlp *net, const float *c, int P, int rows_
                           int n_stages_total, const float *beta, const float *c_out, int n_out, const float *c_err,
                           int n_err, const float *h_host, const double *h_dev, int h_dev_stride, const double *ctl,
                           const float *Z0, float *KZ, float *Z1, float *ERR, const float *norm, float *Xin, float *Ay,
-                          float *acts, long acts_ls, float *dz, nlbac_stream_t s);
+                          float *acts, long acts_ls, float *dz, float *interp_out /* ABI 8, as nlbac_node_adj_step; or NULL */,
+                          double t_end, nlbac_stream_t s);
 
 /* Strided block copy of 32-bit words: block b (block_len words) from src + b*src_stride to dst + b*dst_stride —
  * a row range of a stage-major solver buffer in one launch (hands a problem's first attempted dopri5 step to its

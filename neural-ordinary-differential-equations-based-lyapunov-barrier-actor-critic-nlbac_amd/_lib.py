@@ -144,7 +144,8 @@ _PROTOS = {
     "nlbac_concat_adj_step_ok": [C.POINTER(Mlp)],
     "nlbac_rk_interp_ok": [C.POINTER(Mlp), C.POINTER(Mlp)],
     "nlbac_concat_adj_step": [C.POINTER(Mlp), _P, _I, _I, _I, _I, _I, _P, _P, _I, _P, _I, _P, _P, _I, _P, _P, _P, _P, _P,
-                              _P, _P, _P, _P, _L, _P, _P],
+                              _P, _P, _P, _P, _L, _P, _P, _D, _P],
+    "nlbac_node_adj_interp_ok": [C.POINTER(Mlp), C.POINTER(Mlp)],
     "nlbac_reduce_slabs": [_P, _P, _I, _L, _L, _P],
     "nlbac_soft_update": [_P, _P, _L, _F, _P],
     "nlbac_gauss_sample_fwd": [_P, _I, _P, _P, _P, _I, _I, _P, _I, _P, _P],
@@ -195,10 +196,10 @@ _PROTOS = {
     "nlbac_concat_rk_bwd": [C.POINTER(Mlp), _I, _I, _I, _I, _I, _I, c_float_p, c_float_p, _P, _I, _P, _L, _I, _P, _P, _P, _P,
                             _I, _P, _I, _P, _P, C.POINTER(RkChain), _I, _P],
     "nlbac_node_adj_step": [C.POINTER(Mlp), C.POINTER(Mlp), _P, _I, _I, _I, _I, _I, c_float_p, c_float_p, _I, c_float_p,
-                            _I, c_float_p, _P, _I, _P, _P, _P, _P, _P, _P, _P, _P, _L, _P, _L, _P, _P, _P],
+                            _I, c_float_p, _P, _I, _P, _P, _P, _P, _P, _P, _P, _P, _L, _P, _L, _P, _P, _P, _D, _P],
     "nlbac_adj_pack": [_P, _P, _I, _I, _I, _P, _P],
     "nlbac_adj_unpack": [_P, _I, _I, _I, _P, _P, _P],
-    "nlbac_adj_norm_control": [_P, _P, _P, _P, _P, _I, _F, _F, _I, _I, _I, _I, _D, _P, _P, _P, _P, _P],
+    "nlbac_adj_norm_control": [_P, _P, _P, _P, _P, _I, _F, _F, _I, _I, _I, _I, _D, _P, _P, _P, _P, _P, _P],
     "nlbac_adj_control": [_P, _I, _I, _I, _I, _I, _I, _D, _P, _P, _P],
     "nlbac_adj_param_norm": [_I, _P, _P, _L, _I, c_float_p, c_float_p, c_float_p, _P, _P, _P, _I, _F, _F, _P, _P, _P, _P, _P,
                              _P],
@@ -233,7 +234,7 @@ def build(verbose=False):
     return LIB_PATH
 
 
-ABI_VERSION = 7      # == NLBAC_ABI_VERSION of include/nlbac_hip.h (bumped with every signature / struct change)
+ABI_VERSION = 8      # == NLBAC_ABI_VERSION of include/nlbac_hip.h (bumped with every signature / struct change)
 
 
 def _stale_sources():

@@ -40,6 +40,7 @@ struct ConcatAdjLaunch {
     float c_err[CK_MAX_STAGES]; int n_err;
     const double* h_dev; int h_stride; float h_val[8];
     const double* ctl;                // rows of problems whose C_DONE is set are left alone
+    float* ip_out; double t_end;      // the interpolant of z at t_end, should this attempt finish the solve (as NodeAdjLaunch)
 };
 
 // NW: waves per workgroup (2 or 4), as concat_rr_kernels.hip: four-wave workgroups put one wave on every SIMD.
@@ -423,6 +424,20 @@ __global__ __launch_bounds__(64 * NW) void concat_adj_rr_kernel(const ConcatAdjL
                     if (L.c_err[j] != 0.f) a = a + sKZ[(j * TILE + mm) * WP + c] * (L.c_err[j] * h);
                 L.ERR[(long)row * W + c] = a;
             }
+            if (L.ip_out) {       // (node_adj_rr_kernels.hip: the interpolant at t_end on z1 = the value written to Z1 above)
+                const int p = row / L.rpp;
+                const double t = L.ctl[(long)p * NLBAC_DOPRI_CTL + C_T], hd = L.ctl[(long)p * NLBAC_DOPRI_CTL + C_H];
+                if (t + hd >= L.t_end) {
+                    const float x = (float)((L.t_end - t) / hd);
+                    const float a0 = sZ0[mm * WP + c];
+                    float a1 = a0, k[7];
+                    for (int j = 0; j < L.n_out; ++j)
+                        if (L.c_out[j] != 0.f) a1 = a1 + sKZ[(j * TILE + mm) * WP + c] * (L.c_out[j] * h);
+#pragma unroll
+                    for (int j = 0; j < 7; ++j) k[j] = sKZ[(j * TILE + mm) * WP + c];
+                    L.ip_out[(long)row * W + c] = dopri_interp_value(a0, a1, k, h, x);
+                }
+            }
         }
 }
 
@@ -441,7 +456,7 @@ extern "C" int nlbac_concat_adj_step(const nlbac_mlp* net, const float* c, int P
                                      const float* c_err, int n_err, const float* h_host, const double* h_dev,
                                      int h_dev_stride, const double* ctl, const float* Z0, float* KZ, float* Z1, float* ERR,
                                      const float* norm, float* Xin, float* Ay, float* acts, long acts_ls, float* dz,
-                                     nlbac_stream_t s) {
+                                     float* interp_out, double t_end, nlbac_stream_t s) {
     NLBAC_REQUIRE(net && P >= 1 && P <= 8 && rows_per_problem >= 1, "nlbac_concat_adj_step: bad problem sizes");
     NLBAC_REQUIRE(nlbac_concat_adj_step_ok(net),
                   "nlbac_concat_adj_step: the net is not in -> hid -> hid -> hid -> out with hid in {64, 100, 128} "
@@ -475,6 +490,11 @@ extern "C" int nlbac_concat_adj_step(const nlbac_mlp* net, const float* c, int P
     L.h_dev = h_dev; L.h_stride = h_dev_stride;
     for (int p = 0; p < P; ++p) L.h_val[p] = h_host ? h_host[p] : 0.f;
     L.ctl = ctl;
+    if (interp_out) {
+        NLBAC_REQUIRE(ctl && h_dev && Z1 && st_hi == n_stages_total && n_stages_total == 7,
+                      "nlbac_concat_adj_step: interp_out goes with an attempt launch of a device-driven dopri5 solve");
+        L.ip_out = interp_out; L.t_end = t_end;
+    }
     using Kernel = void (*)(const ConcatAdjLaunch);
     static const Kernel kt[2][3][2] = {{{concat_adj_rr_kernel<4, 4, 0, 2>, concat_adj_rr_kernel<4, 4, 1, 2>},
                                         {concat_adj_rr_kernel<7, 1, 0, 2>, concat_adj_rr_kernel<7, 1, 1, 2>},

@@ -410,6 +410,23 @@ __global__ __launch_bounds__(256) void node_adj_rr_kernel(const NodeAdjLaunch L)
                 if (L.c_err[j] != 0.f) a = a + sKZ[(j * NLBAC_MLP_TILE + mm) * ADJ_WP + c] * (L.c_err[j] * h);
             L.ERR[(long)row * W + c] = a;
         }
+        if (L.ip_out) {
+            // the interpolant of z at t_end, should this attempt be accepted and finish the problem's solve (the
+            // controller's own test and abscissa: ode_control.h; dopri_interp_fwd_kernel's arithmetic on z1 = the value
+            // written to Z1 above)
+            const int p = row / L.rpp;
+            const double t = L.ctl[(long)p * NLBAC_DOPRI_CTL + C_T], hd = L.ctl[(long)p * NLBAC_DOPRI_CTL + C_H];
+            if (t + hd >= L.t_end) {
+                const float x = (float)((L.t_end - t) / hd);
+                const float a0 = sZ0[mm * ADJ_WP + c];
+                float a1 = a0, k[7];
+                for (int j = 0; j < L.n_out; ++j)
+                    if (L.c_out[j] != 0.f) a1 = a1 + sKZ[(j * NLBAC_MLP_TILE + mm) * ADJ_WP + c] * (L.c_out[j] * h);
+#pragma unroll
+                for (int j = 0; j < 7; ++j) k[j] = sKZ[(j * NLBAC_MLP_TILE + mm) * ADJ_WP + c];
+                L.ip_out[(long)row * W + c] = dopri_interp_value(a0, a1, k, h, x);
+            }
+        }
     }
 }
 
@@ -437,4 +454,8 @@ int nlbac_node_adj_rr_launch(NodeAdjLaunch& L, hipStream_t s) {
     hipLaunchKernelGGL(k, grid, dim3(256), lds, s, L);
     NLBAC_CHECK_LAUNCH("nlbac_node_adj_step(rr)");
     return 0;
+}
+
+extern "C" int nlbac_node_adj_interp_ok(const nlbac_mlp* f, const nlbac_mlp* g) {
+    return (f && g && adj_rr_enabled() && nlbac_node_rr_eligible(f, g)) ? 1 : 0;
 }

@@ -30,6 +30,7 @@ struct NodeAdjLaunch {
     const double* h_dev; int h_stride; float h_val[8];
     const double* ctl;                // rows of problems whose C_DONE is set are left alone (device-driven step chain)
     int ld, sw_off1, mask_words;      // mask_words: uint32 words of one group's LDS mask store
+    float* ip_out; double t_end;      // (register-resident kernel) the interpolant of z at t_end, should this attempt finish the solve
 };
 
 

@@ -237,7 +237,8 @@ extern "C" int nlbac_node_adj_step(const nlbac_mlp* f, const nlbac_mlp* g, const
                                    int n_out, const float* c_err, int n_err, const float* h_host, const double* h_dev,
                                    int h_dev_stride, const double* ctl, const float* Z0, float* KZ, float* Z1,
                                    float* ERR, float* ZS, float* dG, float* acts_f, long acts_f_ls, float* acts_g,
-                                   long acts_g_ls, float* dz_f, float* dz_g, nlbac_stream_t s) {
+                                   long acts_g_ls, float* dz_f, float* dz_g, float* interp_out, double t_end,
+                                   nlbac_stream_t s) {
     NLBAC_REQUIRE(f && g && u && Z0 && KZ, "nlbac_node_adj_step: null pointer");
     NLBAC_REQUIRE(P >= 1 && P <= 8 && rows_per_problem >= 1, "nlbac_node_adj_step: bad problem sizes");
     NLBAC_REQUIRE(n_stages_total >= 1 && n_stages_total <= ADJ_MAX_STAGES && st_lo >= 0 && st_lo < st_hi &&
@@ -292,10 +293,16 @@ extern "C" int nlbac_node_adj_step(const nlbac_mlp* f, const nlbac_mlp* g, const
                 (void)hipFuncSetAttribute((const void*)k[b][m], hipFuncAttributeMaxDynamicSharedMemorySize, ADJ_LDS_MAX);
         attr_set = true;
     }
+    if (interp_out) {
+        NLBAC_REQUIRE(ctl && h_dev && Z1 && st_hi == n_stages_total && n_stages_total == 7,
+                      "nlbac_node_adj_step: interp_out goes with an attempt launch of a device-driven dopri5 solve");
+        L.ip_out = interp_out; L.t_end = t_end;
+    }
     {       // the reference's NODE shapes: the register-resident kernel (node_adj_rr_kernels.hip), with or without kept rows
         const int rr = nlbac_node_adj_rr_launch(L, (hipStream_t)s);
         if (rr <= 0) return rr;
     }
+    NLBAC_REQUIRE(!interp_out, "nlbac_node_adj_step: interp_out needs the register-resident kernel (nlbac_node_adj_interp_ok)");
     const int mode = (ntf <= 4 && ntg <= 4) ? 1 : ((ntf == 8 && ntg == 8) ? 2 : 0);
     const dim3 grid(nlbac_ceil_div(L.n, NLBAC_MLP_TILE));
     hipLaunchKernelGGL(k[keep ? 1 : 0][mode], grid, dim3(512), lds, (hipStream_t)s, L);
@@ -348,7 +355,7 @@ extern "C" int nlbac_adj_unpack(const float* Z, int n_s, int n_u, int n, float* 
 // The carried controls count as state columns of y with zero derivative / error (as in the reference's [x, u] state).
 __device__ __forceinline__ void adj_norm_block(const float* a, const float* b, const float* Z0, const float* Z1,
                                                const float* u, int mode, float rtol, float atol, int ns, int nu,
-                                               int rpp, float* partials) {
+                                               int rpp, float* partials, bool publish = false) {
     __shared__ float red[16];
     const int p = blockIdx.y, W = 2 * ns + nu;
     const int i = blockIdx.x * 256 + threadIdx.x;
@@ -381,8 +388,23 @@ __device__ __forceinline__ void adj_norm_block(const float* a, const float* b, c
             }
     }
     block_sum_256<4>(v, red);
-    if (threadIdx.x == 0)
-        for (int k = 0; k < 4; ++k) partials[((long)p * gridDim.x + blockIdx.x) * 4 + k] = v[k];
+    float* q = partials + ((long)p * gridDim.x + blockIdx.x) * 4;
+    if (!publish) {
+        if (threadIdx.x == 0)
+            for (int k = 0; k < 4; ++k) q[k] = v[k];
+        return;
+    }
+    // for a reader in another workgroup of THIS launch: the four sums leave as device-scope atomic exchanges, one wave
+    // instruction, and have returned when this function does — no agent-scope fence, which on gfx950 writes the XCD's L2
+    // back (common.h::publish_and_elect; the fenced form made this launch 13 us against the forward controller's 9)
+    if (threadIdx.x < 64) {
+        float old = 0.f;
+        if (threadIdx.x < 4) {
+            const float mine = threadIdx.x == 0 ? v[0] : (threadIdx.x == 1 ? v[1] : (threadIdx.x == 2 ? v[2] : v[3]));
+            old = __hip_atomic_exchange(q + threadIdx.x, mine, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+        asm volatile("" ::"v"(old) : "memory");
+    }
 }
 
 __device__ __forceinline__ void adj_control_one(const double (&s)[4], int p, int mode, int ns, int nu, int rpp,
@@ -399,22 +421,22 @@ __global__ __launch_bounds__(256) void adj_norm_control_kernel(const float* a, c
                                                                const float* Z1, const float* u, int mode, float rtol,
                                                                float atol, int ns, int nu, int rpp, double t_end,
                                                                const float* pnorm, float* partials, unsigned* tickets,
-                                                               double* ctl) {
+                                                               double* ctl, double* ctl_host) {
     const int p = blockIdx.y, nblk = (int)gridDim.x;
     if (mode == 2 && ctl[(long)p * NLBAC_DOPRI_CTL + C_DONE] > 0.0) return;
-    adj_norm_block(a, b, Z0, Z1, u, mode, rtol, atol, ns, nu, rpp, partials);
+    adj_norm_block(a, b, Z0, Z1, u, mode, rtol, atol, ns, nu, rpp, partials, tickets != nullptr);
     if (!tickets) return;                              // two-call form (data parallel): nlbac_adj_control follows
     __shared__ unsigned s_last;
     __shared__ double s_red[4][256];
-    if (threadIdx.x == 0) {
-        __threadfence();
-        const unsigned ticket = __hip_atomic_fetch_add(tickets + p, 1u, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT);
+    if (threadIdx.x == 0) {                            // (this block's sums have been performed device-wide: see adj_norm_block)
+        elect_release_();
+        const unsigned ticket = __hip_atomic_fetch_add(tickets + p, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         s_last = (ticket == gridDim.x - 1) ? 1u : 0u;
         if (s_last) __hip_atomic_store(tickets + p, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
     __syncthreads();
     if (!s_last) return;
-    __threadfence();
+    elect_acquire_();
     double v[4] = {0.0, 0.0, 0.0, 0.0};
     for (int bb = threadIdx.x; bb < nblk; bb += 256) {
         const float* q = partials + ((long)p * nblk + bb) * 4;
@@ -430,6 +452,9 @@ __global__ __launch_bounds__(256) void adj_norm_control_kernel(const float* a, c
     if (threadIdx.x == 0) {
         const double s[4] = {s_red[0][0], s_red[1][0], s_red[2][0], s_red[3][0]};
         adj_control_one(s, p, mode, ns, nu, rpp, t_end, pnorm, ctl);
+        // the host's copy of this problem's block (pinned memory the device writes directly, as dopri_norm_control_kernel)
+        if (ctl_host)
+            for (int k = 0; k < NLBAC_DOPRI_CTL; ++k) ctl_host[(long)p * NLBAC_DOPRI_CTL + k] = ctl[(long)p * NLBAC_DOPRI_CTL + k];
     }
 }
 
@@ -448,13 +473,13 @@ __global__ void adj_control_kernel(const float* partials, int nblk, int mode, in
 extern "C" int nlbac_adj_norm_control(const float* a, const float* b, const float* Z0, const float* Z1, const float* u,
                                       int mode, float rtol, float atol, int n_s, int n_u, int rows_per_problem, int P,
                                       double t_end, const float* pnorm, float* partials, unsigned* tickets, double* ctl,
-                                      nlbac_stream_t s) {
+                                      double* ctl_host, nlbac_stream_t s) {
     NLBAC_REQUIRE(a && Z0 && partials && ctl && mode >= 0 && mode <= 2, "nlbac_adj_norm_control: bad arguments");
     NLBAC_REQUIRE((mode != 0 || u) && (mode != 1 || b) && (mode != 2 || Z1), "nlbac_adj_norm_control: missing operand");
     NLBAC_REQUIRE(P >= 1 && P <= 8, "nlbac_adj_norm_control: P %d out of range", P);
     hipLaunchKernelGGL(adj_norm_control_kernel, dim3(nlbac_ceil_div(rows_per_problem, 256), P), dim3(256), 0,
                        (hipStream_t)s, a, b, Z0, Z1, u, mode, rtol, atol, n_s, n_u, rows_per_problem, t_end, pnorm,
-                       partials, tickets, ctl);
+                       partials, tickets, ctl, tickets ? ctl_host : nullptr);
     NLBAC_CHECK_LAUNCH("nlbac_adj_norm_control");
     return 0;
 }

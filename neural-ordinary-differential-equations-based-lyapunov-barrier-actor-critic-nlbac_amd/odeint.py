@@ -664,9 +664,7 @@ class AffineNodeSolver:
         """The interpolation at t_end is evaluated by the attempt launches themselves and its backward by the last step's
         backward launch (nlbac_rk_chain::interp_*; the register-resident kernels): no nlbac_dopri_interp_fwd / _bwd
         launches.  ``interp_fold = False`` (NLBAC_INTERP_FOLD=0) keeps the two launches — the cross-check."""
-        on = self.__dict__.get("interp_fold")
-        if on is None:
-            on = self.interp_fold = os.environ.get("NLBAC_INTERP_FOLD", "1") != "0"
+        on = self._interp_fold_on()
         ok = self.__dict__.get("_interp_ok")
         if ok is None:
             ok = self._interp_ok = bool(_lib.load().nlbac_rk_interp_ok(*self._interp_nets()))
@@ -1074,8 +1072,22 @@ class AffineNodeSolver:
             w = pool[key] = dict(Z0=z(n, W), Z1=z(n, W), KZ=z(S, n, W), ERR=z(n, W), OUT=z(n, W), W=W)
         return w
 
+    def _adj_interp_fold(self):
+        """The attempt launches of the adjoint solve write the interpolant of z at t_end themselves (no
+        nlbac_dopri_interp_fwd launch behind the solve) where the kernel that serves the nets does so."""
+        ok = self.__dict__.get("_adj_ip_ok")
+        if ok is None:
+            ok = self._adj_ip_ok = bool(_lib.load().nlbac_node_adj_interp_ok(C.byref(self.f.desc), C.byref(self.g.desc)))
+        return ok and self._interp_fold_on()
+
+    def _interp_fold_on(self):
+        on = self.__dict__.get("interp_fold")
+        if on is None:
+            on = self.interp_fold = os.environ.get("NLBAC_INTERP_FOLD", "1") != "0"
+        return on
+
     def _adj_step(self, w, u, P, rpp, method, st0, st1, h_host=None, h_dev=None, ctl=None, c_out=None, c_err=None,
-                  keep=None):
+                  keep=None, interp=False):
         beta, S = self._beta(method)
         f, g = self.f, self.g
         k = keep or {}
@@ -1086,7 +1098,7 @@ class AffineNodeSolver:
                   w["Z0"].data_ptr(), w["KZ"].data_ptr(), w["Z1"].data_ptr() if c_out is not None else None,
                   w["ERR"].data_ptr() if c_err is not None else None, dp(k.get("ZS")), dp(k.get("dG")),
                   dp(k.get("acts_f")), k.get("ls_f", 0), dp(k.get("acts_g")), k.get("ls_g", 0), dp(k.get("dz_f")),
-                  dp(k.get("dz_g")), stream_ptr())
+                  dp(k.get("dz_g")), w["OUT"].data_ptr() if interp else None, self.ctx["t_end"], stream_ptr())
         self.nfe += st1 - st0
         if keep:
             for st in range(st0, st1):
@@ -1101,7 +1113,7 @@ class AffineNodeSolver:
         if self.comm is not None and self.comm.world > 1:
             _lib.call("nlbac_adj_norm_control", dp(a), dp(b), w["Z0"].data_ptr(), w["Z1"].data_ptr(), dp(u), mode,
                       ctx["rtol"], ctx["atol"], ns, nu, rpp, P, ctx["t_end"], None, part.data_ptr(), None,
-                      ctl.data_ptr(), s)
+                      ctl.data_ptr(), None, s)
             sums = self._buf("adj_psum", P, 1, 4)
             for p in range(P):
                 _lib.call("nlbac_sum_partials", part[p].data_ptr(), nblk, 4, 1.0, sums[p].data_ptr(), s)
@@ -1110,9 +1122,15 @@ class AffineNodeSolver:
                       dp(pnorm), ctl.data_ptr(), s)
             return
         tickets = self._buf("adj_tickets", P, dtype=torch.int32)
+        # (an attempt's controller leaves the host's copy of the control block in pinned memory itself: no copy launch
+        #  between the decision and the host; see _ctl_posted)
+        host = None
+        if mode == 2 and not torch.cuda.is_current_stream_capturing() and HOST_COPY != "side":
+            host = self._ctl_io(P)[1].data_ptr()
+        ctx["adj_ctl_host"] = host is not None
         _lib.call("nlbac_adj_norm_control", dp(a), dp(b), w["Z0"].data_ptr(), w["Z1"].data_ptr(), dp(u), mode,
                   ctx["rtol"], ctx["atol"], ns, nu, rpp, P, ctx["t_end"], dp(pnorm), part.data_ptr(),
-                  tickets.data_ptr(), ctl.data_ptr(), s)
+                  tickets.data_ptr(), ctl.data_ptr(), host, s)
 
     # -- parameter adjoint (a quadrature beside the per-row state; single-problem solves) -----------------
     ADJ_SUB_SLABS = 40       # row slabs of one stage's weight-gradient GEMM (workgroups: layers x slabs x nets)
@@ -1241,6 +1259,7 @@ class AffineNodeSolver:
         c_sol, c_err = self._coef("sol"), self._coef("err")
         chain = max(1, int(self.__dict__.get("_adj_chain", 1)))
         attempts = 0
+        ip = self._adj_interp_fold()
         while True:
             for i in range(chain):
                 if attempts:
@@ -1249,11 +1268,14 @@ class AffineNodeSolver:
                               KZ[0].data_ptr(), KZ[6].data_ptr(), s)
                     if par:
                         self._adj_params_commit(par, cp)
-                self._adj_step(w, u, P, rpp, "dopri5", 1, S, h_dev=cp, ctl=cp, c_out=c_sol, c_err=c_err, keep=keep)
+                self._adj_step(w, u, P, rpp, "dopri5", 1, S, h_dev=cp, ctl=cp, c_out=c_sol, c_err=c_err, keep=keep, interp=ip)
                 pn = self._adj_params_norm(par, 2, cp) if par else None
                 self._adj_norm_control(w["ERR"], None, w, None, 2, P, rpp, ctl, pn)
                 attempts += 1
-            self._ctl_post(P, ctl)
+            if ctx.get("adj_ctl_host"):
+                self._ctl_posted(P)
+            else:
+                self._ctl_post(P, ctl)
             c = self._ctl_read(P) if ctx.get("ctl_pending") == P else ctl.cpu()
             if all(bool(c[p, 4] > 0) for p in range(P)):
                 break
@@ -1263,9 +1285,11 @@ class AffineNodeSolver:
         used = int(max(float(c[p, 10]) for p in range(P)))       # C_NSTEPS: attempts of the slowest problem
         self._adj_chain = max(1, used)
         ctx["adjoint_info"] = [[(float(c[p, 11]), float(c[p, 2]), int(c[p, 10])) for p in range(P)]]
-        # the interpolant of the last accepted step at t0 (steps are not clipped), all columns of z at once
-        _lib.call("nlbac_dopri_interp_fwd", w["Z0"].data_ptr(), w["Z1"].data_ptr(), KZ.data_ptr(), None, None, cp, P,
-                  rpp, w["W"], w["OUT"].data_ptr(), 0, None, s)
+        # the interpolant of the last accepted step at t0 (steps are not clipped), all columns of z at once: written by
+        # the attempt that finished each problem (interp), or by a launch of its own
+        if not ip:
+            _lib.call("nlbac_dopri_interp_fwd", w["Z0"].data_ptr(), w["Z1"].data_ptr(), KZ.data_ptr(), None, None, cp, P,
+                      rpp, w["W"], w["OUT"].data_ptr(), 0, None, s)
         if par:
             self._adj_params_finish(par, cp)
         return w["OUT"]
@@ -1453,8 +1477,11 @@ class ConcatNodeSolver(AffineNodeSolver):
             f = self.adj_fused = bool(_lib.load().nlbac_concat_adj_step_ok(C.byref(self.net.desc)))
         return f
 
+    def _adj_interp_fold(self):
+        return self._adj_fused() and self._interp_fold_on()
+
     def _adj_step(self, w, u, P, rpp, method, st0, st1, h_host=None, h_dev=None, ctl=None, c_out=None, c_err=None,
-                  keep=None):
+                  keep=None, interp=False):
         """(Stage by stage: problems whose solve is done are recomputed to the same values — their control block, z0
         and first stage no longer change — instead of being skipped; the fused launch leaves their rows alone.)"""
         if self._adj_fused():
@@ -1467,7 +1494,8 @@ class ConcatNodeSolver(AffineNodeSolver):
                       w["Z0"].data_ptr(), w["KZ"].data_ptr(), w["Z1"].data_ptr() if c_out is not None else None,
                       w["ERR"].data_ptr() if c_err is not None else None,
                       self.norm.data_ptr() if self.norm is not None else None, dp(k.get("Xin")), dp(k.get("Ay")),
-                      dp(k.get("acts")), k.get("ls", 0), dp(k.get("dz")), stream_ptr())
+                      dp(k.get("acts")), k.get("ls", 0), dp(k.get("dz")), w["OUT"].data_ptr() if interp else None,
+                      self.ctx["t_end"], stream_ptr())
             self.nfe += st1 - st0
             if keep:
                 for st in range(st0, st1):
