@@ -323,6 +323,9 @@ def train_vectorized(agent, env, args, n_steps, log=print, memory=None, check=No
     ep_ret = torch.zeros(N, dtype=torch.float64, device=dev)
     ret_sum = torch.zeros((), dtype=torch.float64, device=dev)
     n_done = torch.zeros((), dtype=torch.int64, device=dev)
+    # (does the task's NODE-fit schedule look at the episode count?  The Pvtol copy's does: tasks.PvtolTask.fit_due)
+    from .sac_cbf_clf.tasks import _Task
+    needs_episode = type(agent.task).fit_due is not _Task.fit_due
     steps = updates = it = 0
     if getattr(agent, "backup_policy", None) is not None:
         log("vectorised: the backup controller is trained by every update but never acts (the hand-over heuristics are "
@@ -361,8 +364,11 @@ def train_vectorized(agent, env, args, n_steps, log=print, memory=None, check=No
         if len(memory) > args.batch_size:
             # the reference driver's trailing argument (P/main.py: the Pvtol copy stops fitting its NODE after episode
             # 100): lanes finish episodes on their own, so the counter is finished episodes per lane, 1-based like the
-            # reference's.  (One scalar read; the update below waits for its own results anyway.)
-            i_episode = 1 + int(n_done) // N
+            # reference's.  Only a task whose fit schedule depends on it pays the scalar read-back (a host sync), and only
+            # on the iterations whose update can fit the NODE at all.
+            i_episode = None
+            if needs_episode and any((updates + k) % args.NODE_model_update_interval == 0 for k in range(args.updates_per_step)):
+                i_episode = 1 + int(n_done) // N
             for _ in range(args.updates_per_step):
                 agent.update_parameters(memory, args.batch_size, updates, None, memory, args.NODE_model_update_interval,
                                         i_episode)

@@ -82,8 +82,13 @@ def test_pvtol_fit_stops_after_100_episodes_per_lane_and_a_wrapped_replay_still_
     # 1040-row ring, 16 rows per step: position is back at 0 after step 65 — whose update is number 60, a fit update
     res = train_vectorized(agent, env, args, 260 * N, log=lambda *a: None)
     assert res["episodes"] >= 125 * N
+    # the episode counter is read back (a host sync) only for the updates whose number makes a NODE fit possible; the
+    # others pass None (the agent looks at it on fit updates only)
+    assert all((e is not None) == (k % 10 == 0) for k, e in enumerate(episodes))
+    n_updates = len(episodes)
+    episodes = [e for e in episodes if e is not None]      # (one per fit-capable update: every 10th)
     assert episodes[0] <= 4 and episodes == sorted(episodes) and episodes[-1] > 100       # (the first update comes at step 5)
-    n_fit_updates = sum(1 for k, e in enumerate(episodes) if k % 10 == 0 and e <= 100)
-    assert len(seen) == n_fit_updates and 0 < n_fit_updates < (len(episodes) + 9) // 10
+    n_fit_updates = sum(1 for e in episodes if e <= 100)
+    assert len(seen) == n_fit_updates and 0 < n_fit_updates < (n_updates + 9) // 10
     assert all(n > 0 for _, n in seen)
     assert any(n == 1040 for _, n in seen), "no fit ran on a just-wrapped ring (position 0): pick other sizes"
