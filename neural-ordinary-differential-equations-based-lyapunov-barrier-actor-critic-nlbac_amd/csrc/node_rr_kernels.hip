@@ -86,6 +86,10 @@ __global__ __launch_bounds__(256) void node_rr_fwd_kernel(const NodeRkLaunch L) 
     float* const acts = L.acts[grp] ? L.acts[grp] + w.soff : nullptr;
     const long acts_ls = L.acts_ls[grp];
     const int stage_end = L.stage_end, S_last = L.S_total - 1;
+    // the initial-step probe with its norm fused into this launch (norm_mode 1): nothing it would leave in memory — the
+    // probe point, its derivative, g there — is read by anyone (the norm comes from LDS, the step's stage 1 overwrites
+    // them), and stores in front of the epilogue's atomics are waited for there (vmcnt is in order)
+    const bool quiet = L.norm_mode == 1;
 
     // ---- the wave's weight stream: hid x hid layers 1 .. nw-1, then layer 1 again (next stage)
     const __amdgpu_buffer_rsrc_t rs = rr_rsrc(net.packed, net.packed_floats);
@@ -168,7 +172,7 @@ __global__ __launch_bounds__(256) void node_rr_fwd_kernel(const NodeRkLaunch L) 
         const int sb = 2 + 8 * (st - L.stage_begin);
         (void)sb;
         if (st == L.stage_begin) {
-            rk_fwd_first_input(L, w, T, row0, st, 8, sYin, 8, true, tid, 256);
+            rk_fwd_first_input(L, w, T, row0, st, 8, sYin, 8, !quiet, tid, 256);
             __syncthreads();
         }
         RSTAMP(sb + 0)
@@ -312,7 +316,7 @@ __global__ __launch_bounds__(256) void node_rr_fwd_kernel(const NodeRkLaunch L) 
                 if (grp == 0) T.sF[m * RK_MAX_NS + o_idx[r]] = val;
                 else {
                     T.sG[m * RK_MAX_GOUT + o_idx[r]] = val;
-                    if (row_ok) w.gG[((long)st * n + grow) * gout + o_idx[r]] = val;
+                    if (row_ok && !quiet) w.gG[((long)st * n + grow) * gout + o_idx[r]] = val;
                 }
             }
         };
@@ -438,7 +442,7 @@ __global__ __launch_bounds__(256) void node_rr_fwd_kernel(const NodeRkLaunch L) 
             }
             if (cv) {
                 T.sK[(st * NLBAC_MLP_TILE + mm) * RK_MAX_NS + c] = a;
-                if (rv) w.gK[((long)st * n + row0 + mm) * ns + c] = a;
+                if (rv && !quiet) w.gK[((long)st * n + row0 + mm) * ns + c] = a;
                 if (more && rv) w.gY[((long)(st + 1) * n + row0 + mm) * ns + c] = y;
             }
             if (more) sYin[mm * 8 + c] = cv ? y : 0.f;
