@@ -32,6 +32,7 @@ __global__ __launch_bounds__(256) void node_adj_rr_kernel(const NodeAdjLaunch L)
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int grp = wave >> 1, half = wave & 1;
     const int n = L.n, ns = L.n_s, nu = L.n_u, W = L.W;
+    const int WP = L.ld;          // LDS row stride of a row of z: W | 1 (odd: the lanes of a column walk distinct banks)
     const int row0 = blockIdx.x * NLBAC_MLP_TILE;
     const nlbac_mlp& net = L.net[grp];
     const int nw = net.n_layers - 1;
@@ -43,9 +44,9 @@ __global__ __launch_bounds__(256) void node_adj_rr_kernel(const NodeAdjLaunch L)
 
     // ---- LDS
     float* const sKZ = smem;                                              // [stage][32][WP]
-    float* const sZ0 = sKZ + ADJ_MAX_STAGES * NLBAC_MLP_TILE * ADJ_WP;    // [32][WP]
-    float* const sZS = sZ0 + NLBAC_MLP_TILE * ADJ_WP;                     // [32][WP] stage input
-    float* const sU = sZS + NLBAC_MLP_TILE * ADJ_WP;                      // [32][4]
+    float* const sZ0 = sKZ + L.S_total * NLBAC_MLP_TILE * WP;    // [32][WP]
+    float* const sZS = sZ0 + NLBAC_MLP_TILE * WP;                     // [32][WP] stage input
+    float* const sU = sZS + NLBAC_MLP_TILE * WP;                      // [32][4]
     float* const sH = sU + NLBAC_MLP_TILE * ADJ_MAX_NU;                   // [32]
     float* const sLive = sH + NLBAC_MLP_TILE;                             // [32]
     float* const sF = sLive + NLBAC_MLP_TILE;                             // [32][8]
@@ -135,8 +136,8 @@ __global__ __launch_bounds__(256) void node_adj_rr_kernel(const NodeAdjLaunch L)
     }
 
     // ---- the tile's rows of the step: z0, u, h, liveness, the stage derivatives an earlier launch left
-    for (int idx = tid; idx < NLBAC_MLP_TILE * ADJ_WP; idx += 256) {
-        const int mm = idx / ADJ_WP, c = idx - mm * ADJ_WP, row = row0 + mm;
+    for (int idx = tid; idx < NLBAC_MLP_TILE * WP; idx += 256) {
+        const int mm = idx / WP, c = idx - mm * WP, row = row0 + mm;
         sZ0[idx] = (row < n && c < W) ? L.Z0[(long)row * W + c] : 0.f;
     }
     if (tid < NLBAC_MLP_TILE * ADJ_MAX_NU) {
@@ -151,9 +152,9 @@ __global__ __launch_bounds__(256) void node_adj_rr_kernel(const NodeAdjLaunch L)
         sLive[tid] = live ? 1.f : 0.f;
         if (live) s_any = 1;
     }
-    for (int idx = tid; idx < L.st_lo * NLBAC_MLP_TILE * ADJ_WP; idx += 256) {
-        const int j = idx / (NLBAC_MLP_TILE * ADJ_WP), rem = idx - j * NLBAC_MLP_TILE * ADJ_WP;
-        const int mm = rem / ADJ_WP, c = rem - mm * ADJ_WP, row = row0 + mm;
+    for (int idx = tid; idx < L.st_lo * NLBAC_MLP_TILE * WP; idx += 256) {
+        const int j = idx / (NLBAC_MLP_TILE * WP), rem = idx - j * NLBAC_MLP_TILE * WP;
+        const int mm = rem / WP, c = rem - mm * WP, row = row0 + mm;
         sKZ[idx] = (row < n && c < W) ? L.KZ[((long)j * n + row) * W + c] : 0.f;
     }
     __syncthreads();
@@ -161,12 +162,12 @@ __global__ __launch_bounds__(256) void node_adj_rr_kernel(const NodeAdjLaunch L)
 
     for (int st = L.st_lo; st < L.st_hi; ++st) {
         // ---- stage input  Z_st = Z0 + h sum_j beta[st][j] K_j  (all of z: y feeds the nets, a_x is the cotangent)
-        for (int idx = tid; idx < NLBAC_MLP_TILE * ADJ_WP; idx += 256) {
-            const int mm = idx / ADJ_WP, c = idx - mm * ADJ_WP;
+        for (int idx = tid; idx < NLBAC_MLP_TILE * WP; idx += 256) {
+            const int mm = idx / WP, c = idx - mm * WP;
             float a = sZ0[idx];
             const float h = sH[mm];
             for (int j = 0; j < st; ++j)
-                if (L.beta[st][j] != 0.f) a = a + sKZ[(j * NLBAC_MLP_TILE + mm) * ADJ_WP + c] * (L.beta[st][j] * h);
+                if (L.beta[st][j] != 0.f) a = a + sKZ[(j * NLBAC_MLP_TILE + mm) * WP + c] * (L.beta[st][j] * h);
             sZS[idx] = a;
             if (KEEP && c < W && sLive[mm] != 0.f) L.ZS[((long)st * n + row0 + mm) * W + c] = a;
         }
@@ -222,7 +223,7 @@ __global__ __launch_bounds__(256) void node_adj_rr_kernel(const NodeAdjLaunch L)
 #pragma unroll
             for (int k0 = 0; k0 < 3; ++k0) {
                 const int col = 4 * k0 + q;
-                yv[k0] = (col < ns) ? sZS[m * ADJ_WP + min(col, ns - 1)] : (col == ns ? 1.f : 0.f);
+                yv[k0] = (col < ns) ? sZS[m * WP + min(col, ns - 1)] : (col == ns ? 1.f : 0.f);
             }
 #pragma unroll
             for (int k0 = 0; k0 < 3; ++k0)
@@ -282,13 +283,13 @@ __global__ __launch_bounds__(256) void node_adj_rr_kernel(const NodeAdjLaunch L)
             const int mm = idx / ns, r = idx - mm * ns;
             float a = sF[mm * ADJ_MAX_NS + r];
             for (int c = 0; c < nu; ++c) a += sG[mm * ADJ_MAX_GOUT + r * nu + c] * sU[mm * ADJ_MAX_NU + c];
-            sKZ[(st * NLBAC_MLP_TILE + mm) * ADJ_WP + r] = -a;
+            sKZ[(st * NLBAC_MLP_TILE + mm) * WP + r] = -a;
         }
         for (int idx = tid; idx < NLBAC_MLP_TILE * nu; idx += 256) {
             const int mm = idx / nu, c = idx - mm * nu;
             float a = 0.f;
-            for (int r = 0; r < ns; ++r) a += sG[mm * ADJ_MAX_GOUT + r * nu + c] * sZS[mm * ADJ_WP + ns + r];
-            sKZ[(st * NLBAC_MLP_TILE + mm) * ADJ_WP + 2 * ns + c] = a;
+            for (int r = 0; r < ns; ++r) a += sG[mm * ADJ_MAX_GOUT + r * nu + c] * sZS[mm * WP + ns + r];
+            sKZ[(st * NLBAC_MLP_TILE + mm) * WP + 2 * ns + c] = a;
         }
 
         // =========================== backward chain ===========================
@@ -298,7 +299,7 @@ __global__ __launch_bounds__(256) void node_adj_rr_kernel(const NodeAdjLaunch L)
         for (int e = 0; e < 4; ++e) {
             const int k0 = (grp == 0) ? e : e / nu, u = (grp == 0) ? 0 : e - k0 * nu, c = 4 * k0 + q;
             const bool ok = (grp == 0) ? (e < KS0 && c < ns) : (e < KS0 * nu && c < ns);
-            const float ax = sZS[m * ADJ_WP + ns + min(c, ns - 1)];
+            const float ax = sZS[m * WP + ns + min(c, ns - 1)];
             const float uu = (grp == 0) ? 1.f : sU[m * ADJ_MAX_NU + min(u, nu - 1)];
             dy[e] = ok ? ((grp == 0) ? ax : ax * uu) : 0.f;
             if (KEEP && grp == 1 && ok && keep_row) L.dG[srow * (ns * nu) + c * nu + u] = dy[e];
@@ -383,13 +384,13 @@ __global__ __launch_bounds__(256) void node_adj_rr_kernel(const NodeAdjLaunch L)
         // ---- k_ax = dX_f + dX_g; the stage's derivative row goes out
         for (int idx = tid; idx < NLBAC_MLP_TILE * ns; idx += 256) {
             const int mm = idx / ns, c = idx - mm * ns;
-            sKZ[(st * NLBAC_MLP_TILE + mm) * ADJ_WP + ns + c] =
+            sKZ[(st * NLBAC_MLP_TILE + mm) * WP + ns + c] =
                 sDX[mm * ADJ_MAX_NS + c] + sDX[(NLBAC_MLP_TILE + mm) * ADJ_MAX_NS + c];
         }
         __syncthreads();
         for (int idx = tid; idx < NLBAC_MLP_TILE * W; idx += 256) {
             const int mm = idx / W, c = idx - mm * W;
-            if (sLive[mm] != 0.f) L.KZ[((long)st * n + row0 + mm) * W + c] = sKZ[(st * NLBAC_MLP_TILE + mm) * ADJ_WP + c];
+            if (sLive[mm] != 0.f) L.KZ[((long)st * n + row0 + mm) * W + c] = sKZ[(st * NLBAC_MLP_TILE + mm) * WP + c];
         }
     }
 
@@ -399,15 +400,15 @@ __global__ __launch_bounds__(256) void node_adj_rr_kernel(const NodeAdjLaunch L)
         if (sLive[mm] == 0.f) continue;
         const float h = sH[mm];
         if (L.Z1) {
-            float a = sZ0[mm * ADJ_WP + c];
+            float a = sZ0[mm * WP + c];
             for (int j = 0; j < L.n_out; ++j)
-                if (L.c_out[j] != 0.f) a = a + sKZ[(j * NLBAC_MLP_TILE + mm) * ADJ_WP + c] * (L.c_out[j] * h);
+                if (L.c_out[j] != 0.f) a = a + sKZ[(j * NLBAC_MLP_TILE + mm) * WP + c] * (L.c_out[j] * h);
             L.Z1[(long)row * W + c] = a;
         }
         if (L.ERR) {
             float a = 0.f;
             for (int j = 0; j < L.n_err; ++j)
-                if (L.c_err[j] != 0.f) a = a + sKZ[(j * NLBAC_MLP_TILE + mm) * ADJ_WP + c] * (L.c_err[j] * h);
+                if (L.c_err[j] != 0.f) a = a + sKZ[(j * NLBAC_MLP_TILE + mm) * WP + c] * (L.c_err[j] * h);
             L.ERR[(long)row * W + c] = a;
         }
         if (L.ip_out) {
@@ -418,12 +419,12 @@ __global__ __launch_bounds__(256) void node_adj_rr_kernel(const NodeAdjLaunch L)
             const double t = L.ctl[(long)p * NLBAC_DOPRI_CTL + C_T], hd = L.ctl[(long)p * NLBAC_DOPRI_CTL + C_H];
             if (t + hd >= L.t_end) {
                 const float x = (float)((L.t_end - t) / hd);
-                const float a0 = sZ0[mm * ADJ_WP + c];
+                const float a0 = sZ0[mm * WP + c];
                 float a1 = a0, k[7];
                 for (int j = 0; j < L.n_out; ++j)
-                    if (L.c_out[j] != 0.f) a1 = a1 + sKZ[(j * NLBAC_MLP_TILE + mm) * ADJ_WP + c] * (L.c_out[j] * h);
+                    if (L.c_out[j] != 0.f) a1 = a1 + sKZ[(j * NLBAC_MLP_TILE + mm) * WP + c] * (L.c_out[j] * h);
 #pragma unroll
-                for (int j = 0; j < 7; ++j) k[j] = sKZ[(j * NLBAC_MLP_TILE + mm) * ADJ_WP + c];
+                for (int j = 0; j < 7; ++j) k[j] = sKZ[(j * NLBAC_MLP_TILE + mm) * WP + c];
                 L.ip_out[(long)row * W + c] = dopri_interp_value(a0, a1, k, h, x);
             }
         }
@@ -447,7 +448,8 @@ int nlbac_node_adj_rr_launch(NodeAdjLaunch& L, hipStream_t s) {
     const int hid = L.net[0].hid;
     const Kernel k = keep ? (hid == 64 ? node_adj_rr_kernel<4, 4, 1> : (hid == 100 ? node_adj_rr_kernel<7, 1, 1> : node_adj_rr_kernel<8, 4, 1>))
                           : (hid == 64 ? node_adj_rr_kernel<4, 4, 0> : (hid == 100 ? node_adj_rr_kernel<7, 1, 0> : node_adj_rr_kernel<8, 4, 0>));
-    const size_t lds = (size_t)((ADJ_MAX_STAGES + 2) * NLBAC_MLP_TILE * ADJ_WP +
+    L.ld = L.W | 1;
+    const size_t lds = (size_t)((L.S_total + 2) * NLBAC_MLP_TILE * L.ld +
                                 NLBAC_MLP_TILE * (ADJ_MAX_NU + 1 + 1 + ADJ_MAX_NS + ADJ_MAX_GOUT + 2 * ADJ_MAX_NS) +
                                 2 * 3 * 8 * 64 + 2 * 4 * 8 * 64) * sizeof(float);
     const dim3 grid(nlbac_ceil_div(L.n, NLBAC_MLP_TILE));

@@ -149,6 +149,8 @@ class SAC_CBF_CLF(object):
         # workgroups (measured at B = 32768: 184 -> 159 us per launch; 128 x 128 output tiles instead — half the operand
         # re-reads — were slower than that, 170 us, and were dropped)
         self.n_grad_slabs = int(getattr(args, "grad_slabs", 16 if int(getattr(args, "batch_size", 0) or 0) >= 16384 else 8))
+        if os.environ.get("NLBAC_GRAD_SLABS"):           # (experiments)
+            self.n_grad_slabs = int(os.environ["NLBAC_GRAD_SLABS"])
 
         # --- same construction order (and RNG consumption) as the reference ---
         self.critic = QNetwork(num_inputs, n_act, hidden)
