@@ -32,7 +32,7 @@
 extern "C" {
 #endif
 
-#define NLBAC_ABI_VERSION 8 /* bumped whenever an exported signature or struct changes; nlbac_abi_version() returns it */
+#define NLBAC_ABI_VERSION 9 /* bumped whenever an exported signature or struct changes; nlbac_abi_version() returns it */
 #define NLBAC_MAX_LAYERS 6
 #define NLBAC_MAX_NETS 8
 #define NLBAC_MLP_TILE 32 /* samples per workgroup in the MLP kernels */
@@ -498,6 +498,24 @@ int nlbac_node_rk_fwd(const nlbac_mlp *f, const nlbac_mlp *g, const float *y0, c
                       float *G, float *acts_f, long acts_f_ls, float *acts_g, long acts_g_ls, int acts_bits,
                       float *out, float *err, const nlbac_rk_chain *chain,
                       const nlbac_in_map *in_map /* or NULL; y0 is then written, not read */, nlbac_stream_t s);
+/* ABI 9 — the three launches that open a dopri5 solve on the device-driven chain (stage 0 + Hairer's first guess; the
+ * probe f(y0 + h0 f0) + the initial step size; the first attempted step, stages 1..6) as ONE persistent launch: the same
+ * kernel code three times with a per-problem wait in between (the workgroup that runs a phase's fused controller
+ * releases the others).  nlbac_node_rk_fwd_begin_ok: the register-resident kernels serve the nets, tiles do not straddle
+ * problems and P * rows_per_problem <= 8192 (every workgroup must be resident at once).  Measured: 108 us against 105 us for the
+ * three launches at 8192 rows — the host side uses it only on request (NLBAC_NODE_PERSIST=1).
+ * Arguments as the three nlbac_node_rk_fwd calls it replaces: beta = dopri5's [7][7], c_err / err = the error estimate
+ * of the attempt, acts_* = the mask-word buffers (acts_bits), chain = the attempt's description (ctl == ctl_w: the control
+ * blocks; partials / tickets serve the fused norms of the first two phases; interp_* as for any attempt), in_map for
+ * stage 0.  gen: P uint32 (zero before their first use), target: a value >= 1 not used on these words before, nor
+ * target + 1.  The attempt's norm + controller remain the caller's nlbac_dopri_norm_control launch.  A workgroup that
+ * waits ~1 s in vain sets ctl[13] (C_OVF) = 3 and the launch ends: results are then invalid. */
+int nlbac_node_rk_fwd_begin_ok(const nlbac_mlp *f, const nlbac_mlp *g, int P, int rows_per_problem);
+int nlbac_node_rk_fwd_begin(const nlbac_mlp *f, const nlbac_mlp *g, float *y0, const float *u, int P,
+                            int rows_per_problem, const float *beta, const float *c_err, int n_err, float *K, float *Y,
+                            float *G, float *acts_f, long acts_f_ls, float *acts_g, long acts_g_ls, float *err,
+                            const nlbac_rk_chain *chain, const nlbac_in_map *in_map, unsigned *gen, unsigned target,
+                            nlbac_stream_t s);
 /* uint32 words per row and layer of the bit-packed ReLU masks (acts_bits) that nlbac_node_rk_fwd writes and
  * nlbac_node_rk_bwd reads for net `which` (0: f, 1: g) of this pair: ceil(hid / 32) for the LDS-tiled kernels, 4 (one
  * word per lane quarter) when the pair runs on the register-resident kernels. */

@@ -143,6 +143,9 @@ _PROTOS = {
     "nlbac_concat_adj_out": [_P, _P, _I, _I, _P, _I, _I, _P, _P],
     "nlbac_concat_adj_step_ok": [C.POINTER(Mlp)],
     "nlbac_rk_interp_ok": [C.POINTER(Mlp), C.POINTER(Mlp)],
+    "nlbac_node_rk_fwd_begin_ok": [C.POINTER(Mlp), C.POINTER(Mlp), _I, _I],
+    "nlbac_node_rk_fwd_begin": [C.POINTER(Mlp), C.POINTER(Mlp), _P, _P, _I, _I, c_float_p, c_float_p, _I, _P, _P, _P, _P, _L,
+                                _P, _L, _P, C.POINTER(RkChain), C.POINTER(InMap), _P, C.c_uint, _P],
     "nlbac_concat_adj_step": [C.POINTER(Mlp), _P, _I, _I, _I, _I, _I, _P, _P, _I, _P, _I, _P, _P, _I, _P, _P, _P, _P, _P,
                               _P, _P, _P, _P, _L, _P, _P, _D, _P],
     "nlbac_node_adj_interp_ok": [C.POINTER(Mlp), C.POINTER(Mlp)],
@@ -234,7 +237,7 @@ def build(verbose=False):
     return LIB_PATH
 
 
-ABI_VERSION = 8      # == NLBAC_ABI_VERSION of include/nlbac_hip.h (bumped with every signature / struct change)
+ABI_VERSION = 9      # == NLBAC_ABI_VERSION of include/nlbac_hip.h (bumped with every signature / struct change)
 
 
 def _stale_sources():

@@ -655,14 +655,12 @@ extern "C" int nlbac_node_rk_bwd(const nlbac_mlp* f, const nlbac_mlp* g, const f
 }
 
 // ---------------------------------------------------------------------------
-extern "C" int nlbac_node_rk_fwd(const nlbac_mlp* f, const nlbac_mlp* g, const float* y0, const float* u, int P,
-                                 int rows_per_problem, int stage_begin, int stage_end, int n_stages_total,
-                                 const float* beta /* [n_stages_total][n_stages_total] row-major */,
-                                 const float* c_out, int n_out, const float* c_err, int n_err,
-                                 const float* h_host, const double* h_dev, int h_dev_stride, float* K, float* Y,
-                                 float* G, float* acts_f, long acts_f_ls, float* acts_g, long acts_g_ls,
-                                 int acts_bits, float* out, float* err, const nlbac_rk_chain* chain,
-                                 const nlbac_in_map* in_map, nlbac_stream_t s) {
+static int rk_fwd_fill(NodeRkLaunch& L, const nlbac_mlp* f, const nlbac_mlp* g, const float* y0, const float* u, int P,
+                       int rows_per_problem, int stage_begin, int stage_end, int n_stages_total, const float* beta,
+                       const float* c_out, int n_out, const float* c_err, int n_err, const float* h_host,
+                       const double* h_dev, int h_dev_stride, float* K, float* Y, float* G, float* acts_f,
+                       long acts_f_ls, float* acts_g, long acts_g_ls, int acts_bits, float* out, float* err,
+                       const nlbac_rk_chain* chain, const nlbac_in_map* in_map) {
     NLBAC_REQUIRE(f && g && y0 && u && K && Y && G, "nlbac_node_rk_fwd: null pointer");
     NLBAC_REQUIRE(P >= 1 && P <= 8 && rows_per_problem >= 1, "nlbac_node_rk_fwd: bad problem sizes");
     NLBAC_REQUIRE(n_stages_total >= 1 && n_stages_total <= RK_MAX_STAGES && stage_begin >= 0 &&
@@ -673,7 +671,6 @@ extern "C" int nlbac_node_rk_fwd(const nlbac_mlp* f, const nlbac_mlp* g, const f
     NLBAC_REQUIRE(f->hid % 4 == 0 && g->hid % 4 == 0 && f->hid <= 256 && g->hid <= 256, "nlbac_node_rk_fwd: bad hid");
     NLBAC_REQUIRE(h_dev || h_host, "nlbac_node_rk_fwd: no step size");
     NLBAC_REQUIRE(n_out <= n_stages_total && n_err <= n_stages_total, "nlbac_node_rk_fwd: bad coefficient counts");
-    NodeRkLaunch L;
     memset(&L, 0, sizeof(L));
     L.net[0] = *f; L.net[1] = *g;
     L.y0 = y0; L.u = u;
@@ -720,6 +717,21 @@ extern "C" int nlbac_node_rk_fwd(const nlbac_mlp* f, const nlbac_mlp* g, const f
             L.ip_out = chain->interp_out; L.ip_kind = chain->interp_kind; L.ip_l = chain->interp_l; L.ip_p = chain->interp_p;
         }
     }
+    return 0;
+}
+
+extern "C" int nlbac_node_rk_fwd(const nlbac_mlp* f, const nlbac_mlp* g, const float* y0, const float* u, int P,
+                                 int rows_per_problem, int stage_begin, int stage_end, int n_stages_total,
+                                 const float* beta /* [n_stages_total][n_stages_total] row-major */,
+                                 const float* c_out, int n_out, const float* c_err, int n_err,
+                                 const float* h_host, const double* h_dev, int h_dev_stride, float* K, float* Y,
+                                 float* G, float* acts_f, long acts_f_ls, float* acts_g, long acts_g_ls,
+                                 int acts_bits, float* out, float* err, const nlbac_rk_chain* chain,
+                                 const nlbac_in_map* in_map, nlbac_stream_t s) {
+    NodeRkLaunch L;
+    if (rk_fwd_fill(L, f, g, y0, u, P, rows_per_problem, stage_begin, stage_end, n_stages_total, beta, c_out, n_out, c_err,
+                    n_err, h_host, h_dev, h_dev_stride, K, Y, G, acts_f, acts_f_ls, acts_g, acts_g_ls, acts_bits, out, err,
+                    chain, in_map)) return -1;
     {   // nets up to 128 wide run on the register-resident kernels (node_rr_kernels.hip)
         const int rr = nlbac_node_rr_fwd_launch(L, (hipStream_t)s);
         if (rr <= 0) return rr;
@@ -757,6 +769,53 @@ extern "C" int nlbac_node_rk_fwd(const nlbac_mlp* f, const nlbac_mlp* g, const f
     const dim3 grid(n_tiles);
     hipLaunchKernelGGL(kf[occ][acts_bits ? 1 : 0][mode], grid, dim3(512), lds, (hipStream_t)s, L);
     NLBAC_CHECK_LAUNCH("nlbac_node_rk_fwd");
+    return 0;
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
+// The three launches that open a dopri5 solve on the device-driven chain as ONE persistent launch (node_rr_kernels.hip:
+// node_rr_fwd_begin_kernel).  What the host would pass to the three nlbac_node_rk_fwd calls is derived here:
+//   A  stage 0 of the step (with the in-map), norm mode 0 -> Hairer's first guess C_H0;
+//   B  the probe f(y0 + h0 f0): tableau [[1]], step size C_H0, no masks kept, norm mode 1 -> the initial step C_H;
+//   C  the first attempted step, stages 1..6 with step size C_H, error estimate, interpolation at t_end (chain->interp_*);
+//      its norm + controller stay the separate slot-aware launch (nlbac_dopri_norm_control), as for every attempt.
+// chain: the attempt's description (ctl = ctl_w = the control blocks, partials / tickets for the fused norms of A and B).
+// gen: P uint32, zero before the first use; target: any value > 0 that no earlier launch on these words used + 2.
+// ---------------------------------------------------------------------------------------------------------------------
+extern "C" int nlbac_node_rk_fwd_begin_ok(const nlbac_mlp* f, const nlbac_mlp* g, int P, int rows_per_problem) {
+    if (!f || !g || !nlbac_node_rr_eligible(f, g)) return 0;
+    // every workgroup of the launch must be resident at once: one 32-row tile per CU
+    return ((P == 1 || rows_per_problem % NLBAC_MLP_TILE == 0) && (long)P * rows_per_problem <= 256L * NLBAC_MLP_TILE) ? 1 : 0;
+}
+
+extern "C" int nlbac_node_rk_fwd_begin(const nlbac_mlp* f, const nlbac_mlp* g, float* y0, const float* u, int P,
+                                       int rows_per_problem, const float* beta /* dopri5: [7][7] */, const float* c_err,
+                                       int n_err, float* K, float* Y, float* G, float* acts_f, long acts_f_ls,
+                                       float* acts_g, long acts_g_ls, float* err, const nlbac_rk_chain* chain,
+                                       const nlbac_in_map* in_map, unsigned* gen, unsigned target, nlbac_stream_t s) {
+    const char* who = "nlbac_node_rk_fwd_begin";
+    NLBAC_REQUIRE(chain && chain->ctl && chain->ctl_w == chain->ctl && chain->partials && chain->tickets && gen && target >= 1u &&
+                      target < 0xFFFFFFF0u && err && c_err && acts_f && acts_g,
+                  "%s: needs the control blocks, partials, tickets, the error buffer, mask buffers and the generation words", who);
+    NLBAC_REQUIRE(nlbac_node_rk_fwd_begin_ok(f, g, P, rows_per_problem), "%s: not available for these nets / sizes (nlbac_node_rk_fwd_begin_ok)", who);
+    double* ctl = chain->ctl_w;
+    nlbac_rk_chain ca = *chain, cb = *chain, cc = *chain;
+    ca.ctl = nullptr; ca.norm_mode = 0; ca.interp_out = nullptr; ca.interp_bwd = 0;
+    cb.ctl = nullptr; cb.norm_mode = 1; cb.interp_out = nullptr; cb.interp_bwd = 0;
+    cc.norm_mode = -1;
+    static const float probe_beta[4] = {0.f, 0.f, 1.f, 0.f};      // [[0, 0], [1, 0]]
+    NodeRkLaunch LA, LB, LC;
+    if (rk_fwd_fill(LA, f, g, y0, u, P, rows_per_problem, 0, 1, 7, beta, nullptr, 0, nullptr, 0, nullptr, ctl + C_H,
+                    NLBAC_DOPRI_CTL, K, Y, G, acts_f, acts_f_ls, acts_g, acts_g_ls, 1, nullptr, nullptr, &ca, in_map)) return -1;
+    if (rk_fwd_fill(LB, f, g, y0, u, P, rows_per_problem, 1, 2, 2, probe_beta, nullptr, 0, nullptr, 0, nullptr, ctl + C_H0,
+                    NLBAC_DOPRI_CTL, K, Y, G, nullptr, acts_f_ls, nullptr, acts_g_ls, 1, nullptr, nullptr, &cb, nullptr)) return -1;
+    if (rk_fwd_fill(LC, f, g, y0, u, P, rows_per_problem, 1, 7, 7, beta, nullptr, 0, c_err, n_err, nullptr, ctl + C_H,
+                    NLBAC_DOPRI_CTL, K, Y, G, acts_f, acts_f_ls, acts_g, acts_g_ls, 1, nullptr, err, &cc, nullptr)) return -1;
+    LA.pers_gen = gen; LA.pers_target = target;      LA.coh = 0;
+    LB.pers_gen = gen; LB.pers_target = target + 1u; LB.coh = 1;
+    LC.pers_gen = nullptr;                           LC.coh = 1;
+    const int rr = nlbac_node_rr_fwd_begin_launch(LA, LB, LC, (hipStream_t)s);
+    NLBAC_REQUIRE(rr == 0, "%s: the register-resident kernels do not take this launch", who);
     return 0;
 }
 

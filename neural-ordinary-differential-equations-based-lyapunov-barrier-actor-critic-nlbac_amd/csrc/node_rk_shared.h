@@ -45,6 +45,11 @@ struct NodeRkLaunch {
     // at t_end, and the owner's out-map of it — for its rows (register-resident kernels; what nlbac_dopri_interp_fwd
     // does as a launch of its own after the accept decision; a rejected attempt's values are overwritten by the next)
     float* ip_out; int ip_kind; float ip_l; float* ip_p;
+    // nlbac_node_rk_fwd_begin (the three launches that open a dopri5 solve as ONE persistent launch, register-resident
+    // kernels): pers_gen [P] — the workgroup that runs a fused controller publishes the control block at device scope and
+    // stores pers_target there, the other workgroups of the problem wait for it before their next phase; coh: this phase
+    // reads the control block (h, slot, done) past the non-coherent caches (another workgroup of THIS launch wrote it)
+    unsigned* pers_gen; unsigned pers_target; int coh;
 };
 
 struct NodeRkBwdLaunch {
@@ -75,6 +80,7 @@ struct NodeRkBwdLaunch {
 // LDS-tiled kernels take it), < 0 = error.
 int nlbac_node_rr_fwd_launch(NodeRkLaunch& L, hipStream_t s);
 int nlbac_node_rr_bwd_launch(NodeRkBwdLaunch& L, hipStream_t s);
+int nlbac_node_rr_fwd_begin_launch(NodeRkLaunch& LA, NodeRkLaunch& LB, NodeRkLaunch& LC, hipStream_t s);
 bool nlbac_node_rr_eligible(const nlbac_mlp* f, const nlbac_mlp* g);
 
 // ---------------------------------------------------------------------------------------------------------------
@@ -106,6 +112,9 @@ struct RkFwdWhere {
     float *gK, *gY, *gG, *gErr; const float* gy0;
     bool ip; float ip_x;         // this attempt reaches t_end: evaluate the interpolant at abscissa ip_x (nlbac_rk_chain::interp_out)
 };
+__device__ __forceinline__ double rk_ctl_load(const double* p, bool coh) {
+    return coh ? __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : *p;
+}
 __device__ __forceinline__ bool rk_fwd_where(const NodeRkLaunch& L, int row0, RkFwdWhere& w) {
     w.p_tile = row0 / L.rpp;
     w.soff = 0;
@@ -114,12 +123,13 @@ __device__ __forceinline__ bool rk_fwd_where(const NodeRkLaunch& L, int row0, Rk
     w.ip_x = 0.f;
     if (L.ctl) {
         const double* c = L.ctl + (long)w.p_tile * NLBAC_DOPRI_CTL;
-        if (c[C_DONE] > 0.0) return false;              // (uniform) this problem's solve has finished
-        const int slot = (int)c[C_NACC];
+        const bool coh = L.coh != 0;
+        if (rk_ctl_load(c + C_DONE, coh) > 0.0) return false;              // (uniform) this problem's solve has finished
+        const int slot = (int)rk_ctl_load(c + C_NACC, coh);
         w.soff = (long)slot * L.slot_floats;
         w.fsal = slot > 0;
         if (L.ip_out) {          // the controller's own test and abscissa (ode_control.h: accept && t + h >= t_end -> C_X)
-            const double t = c[C_T], h = c[C_H];
+            const double t = rk_ctl_load(c + C_T, coh), h = rk_ctl_load(c + C_H, coh);
             w.ip = t + h >= L.t_end;
             w.ip_x = (float)((L.t_end - t) / h);
         }
@@ -174,7 +184,7 @@ __device__ __forceinline__ void rk_fwd_tile_constants(const NodeRkLaunch& L, con
         }
         if (tid < NLBAC_MLP_TILE) {
             const int p = min(row0 + tid, n - 1) / L.rpp;
-            vh = L.h_dev ? (float)L.h_dev[(long)p * L.h_stride] : L.h_val[p];
+            vh = L.h_dev ? (float)rk_ctl_load(L.h_dev + (long)p * L.h_stride, L.coh != 0) : L.h_val[p];
         }
 #pragma unroll
         for (int it = 0; it < NK; ++it) {
@@ -393,6 +403,10 @@ __device__ __forceinline__ void rk_fwd_outputs_and_control(const NodeRkLaunch& L
         if (tid == 0) {
             const double cnt = (double)L.rpp * (double)(ns + nu);
             double* c = L.ctl_w + (long)p_tile * NLBAC_DOPRI_CTL;
+            if (L.coh && L.norm_mode == 1) {      // (persistent launch: what the previous phase's controller — possibly on
+                c[C_H0] = rk_ctl_load(c + C_H0, true);     //  another XCD — left there: read past this XCD's L2)
+                c[C_D1] = rk_ctl_load(c + C_D1, true);
+            }
             const int slot_before = (int)c[C_NACC];
             const double h_try = c[C_H];
             dopri_control_vals(sqrt(d0 / cnt), sqrt(d1 / cnt), p_tile, L.norm_mode, L.t_end, L.ctl_w, L.n_slots);
@@ -405,8 +419,40 @@ __device__ __forceinline__ void rk_fwd_outputs_and_control(const NodeRkLaunch& L
                     a[0] = h_try; a[1] = c[C_RATIO]; a[2] = c[C_ACCEPT];
                 }
             }
+            if (L.pers_gen) {
+                // persistent launch: the other workgroups of this problem go on with the next phase once they see
+                // pers_target.  What they read of the control block leaves through device-scope exchanges (performed
+                // beyond the XCDs' L2s when they return — no agent-scope fence, which would write this XCD's L2 back),
+                // the flag is stored behind them.
+                double olds = 0.0;
+#pragma unroll
+                for (int k = 0; k < 16; ++k) olds += __hip_atomic_exchange(c + k, c[k], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                asm volatile("" ::"v"(olds) : "memory");
+                __hip_atomic_store(L.pers_gen + p_tile, L.pers_target, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            }
         }
     }
+}
+
+// persistent launch: wait until this problem's controller of the phase just finished has released it (rk_fwd_outputs_and_control).
+// Bounded: a workgroup that never sees the flag (which needs every workgroup of the launch to be resident — the host only
+// asks for this launch where that holds) gives up after ~1 s, marks the solve (C_OVF = 3) and the caller returns.
+__device__ __forceinline__ bool rk_fwd_grid_wait(const NodeRkLaunch& L, int row0) {
+    __shared__ int s_ok_;
+    const int p = row0 / L.rpp;
+    if (threadIdx.x == 0) {
+        int ok = 0;
+        for (long it = 0; it < (1L << 23); ++it) {
+            if (__hip_atomic_load(L.pers_gen + p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == L.pers_target) { ok = 1; break; }
+            __builtin_amdgcn_s_sleep(8);
+        }
+        if (!ok) L.ctl_w[(long)p * NLBAC_DOPRI_CTL + C_OVF] = 3.0;
+        s_ok_ = ok;
+    }
+    __syncthreads();
+    const bool r = s_ok_ != 0;
+    __syncthreads();
+    return r;
 }
 
 // ---------------------------------------------------------------------------------------------------------------

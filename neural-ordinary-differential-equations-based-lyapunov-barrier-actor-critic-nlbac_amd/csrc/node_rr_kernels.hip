@@ -38,13 +38,23 @@ __device__ __forceinline__ int rr_out_row(int grp, int hu, int ns, int nu) {
 
 #define RR_MAX_W 4        /* layer 0 + up to three hid x hid layers (n_layers <= 5: the reference's f_net) */
 
+#ifdef RR_TIMING      // ablation build only: the backward's stamps go to a device symbol (nlbac_debug_bwd_stamps reads it back)
+__device__ long long g_bwd_stamps[2 * 256];
+#define BWSTAMP(slot_) if (blockIdx.x == 0 && lane == 0 && half == 0) g_bwd_stamps[grp * 256 + (slot_)] = (long long)__builtin_readcyclecounter();
+extern "C" int nlbac_debug_bwd_stamps(long long* out) {
+    return hipMemcpyFromSymbol(out, HIP_SYMBOL(g_bwd_stamps), sizeof(long long) * 2 * 256) == hipSuccess ? 0 : -1;
+}
+#else
+#define BWSTAMP(slot_)
+#endif
+
 // SPLIT: f_net has one hid x hid layer more than g_net (U/sac_cbf_clf/model.py:186-206), so its waves ran ~175 MFMAs per
 // stage longer and g_net's waited a quarter of every stage at the stage barrier.  With SPLIT the g_net wave of each half
 // tile takes over the upper groups of output blocks of f_net's LAST hid x hid layer: the f_net wave hands its layer-2
 // activations over through LDS (behind a flag only the two waves touch), both compute their blocks and their part of
 // f_net's output layer, and the two partial outputs meet in the stage's k = f + g u step.
 template <int NB, int R, int BITS, int SPLIT>
-__global__ __launch_bounds__(256) void node_rr_fwd_kernel(const NodeRkLaunch L) {
+__device__ __forceinline__ void node_rr_fwd_body(const NodeRkLaunch& L) {
     using S = RRShape<NB, R>;
     constexpr int KS = S::KS, HID = S::HID;
     constexpr int TB = NB - 2;                 // first block of a layer's last group, the "tail": its accumulators are
@@ -461,6 +471,29 @@ __global__ __launch_bounds__(256) void node_rr_fwd_kernel(const NodeRkLaunch L) 
     rk_fwd_outputs_and_control<256>(L, w, T, row0, n_rows, tid);
 }
 
+template <int NB, int R, int BITS, int SPLIT>
+__global__ __launch_bounds__(256) void node_rr_fwd_kernel(const NodeRkLaunch L) {
+    node_rr_fwd_body<NB, R, BITS, SPLIT>(L);
+}
+
+// The three launches that open a dopri5 solve — f0 = field(y0) with Hairer's first guess, the probe f(y0 + h0 f0) with
+// the initial step size, the first attempted step (stages 1..6) — as ONE launch (nlbac_node_rk_fwd_begin): the same code
+// three times, a per-problem wait in between (rk_fwd_grid_wait: the workgroup that ran the phase's controller releases
+// the others).  What it was meant to save is two launches' dispatch, prologue and cold weights (f0 + probe cost 44 us in
+// the update for two stage evaluations of 8.7 us) — measured, it saves nothing: 108 us against 105 (the cost of the
+// one-stage launches is their norm's election, and the waits here are the same elections).  Kept behind
+// NLBAC_NODE_PERSIST=1, tested against the three launches (bit-identical).  Needs every workgroup of the launch resident
+// at once: <= 8192 rows.
+template <int NB, int R, int SPLIT>
+__global__ __launch_bounds__(256) void node_rr_fwd_begin_kernel(const NodeRkLaunch LA, const NodeRkLaunch LB, const NodeRkLaunch LC) {
+    const int row0 = blockIdx.x * NLBAC_MLP_TILE;
+    node_rr_fwd_body<NB, R, 1, SPLIT>(LA);
+    if (!rk_fwd_grid_wait(LA, row0)) return;
+    node_rr_fwd_body<NB, R, 1, SPLIT>(LB);
+    if (!rk_fwd_grid_wait(LB, row0)) return;
+    node_rr_fwd_body<NB, R, 1, SPLIT>(LC);
+}
+
 // ---------------------------------------------------------------------------------------------------------------------
 // Backward of the same step, same wave roles.  Per stage (descending): the output layer's gradient enters as the B
 // operand of one transposed block product, then dz_{l-1} = mask_{l-1} * (W_l^T dz_l) down the chain in registers (the
@@ -549,8 +582,10 @@ __global__ __launch_bounds__(256) void node_rr_bwd_kernel(const NodeRkBwdLaunch 
         }
     }
 
+    BWSTAMP(0)
     rk_bwd_tile_constants<256>(L, w, T, row0, tid);
     __syncthreads();
+    BWSTAMP(1)
 
     // g(Y_st) for the du term comes from global memory: this thread's values of a stage are requested while the stage
     // before it runs (loads issued at the start of a stage would sit in front of the stage's first weight-fragment loads in
@@ -571,6 +606,9 @@ __global__ __launch_bounds__(256) void node_rr_bwd_kernel(const NodeRkBwdLaunch 
     for (int r = 0; r < RK_MAX_NS; ++r) gnext[r] = 0.f;
     request_g(L.st_hi - 1);
     for (int st = L.st_hi - 1; st >= w.st_lo; --st) {
+        const int sbw = 2 + 8 * st;
+        (void)sbw;
+        BWSTAMP(sbw + 0)
         const bool data = w.has_data(st);
         float gcur[RK_MAX_NS];
 #pragma unroll
@@ -605,6 +643,7 @@ __global__ __launch_bounds__(256) void node_rr_bwd_kernel(const NodeRkBwdLaunch 
             }
         }
         if (!data) continue;              // uniform: nothing below is needed for this stage
+        BWSTAMP(sbw + 1)
 
         const long srow = (long)st * n + growc;
         float Za[KS], Zb[KS];              // dz ping-pong between two register sets
@@ -729,6 +768,7 @@ __global__ __launch_bounds__(256) void node_rr_bwd_kernel(const NodeRkBwdLaunch 
         };
         using I1 = std::integral_constant<int, 1>; using I2 = std::integral_constant<int, 2>;
         using I3 = std::integral_constant<int, 3>;
+        BWSTAMP(sbw + 2)
         if constexpr (SPLIT == 0) {
             prod(I1{}, Za, Zb, avB, avA);                     // (f_net: three hid x hid layers, g_net: two — see the forward)
             prod(I2{}, Zb, Za, avA, avB);
@@ -764,8 +804,10 @@ __global__ __launch_bounds__(256) void node_rr_bwd_kernel(const NodeRkBwdLaunch 
                 asm volatile("" ::: "memory");
 #pragma unroll
                 for (int k = 0; k < PG::K1; ++k) Zb[k] = sX2[(half * 16 + k) * 64 + lane];
+                BWSTAMP(sbw + 3)
                 prod(I2{}, Zb, Za, avA, avB);
                 prod(I3{}, Za, Zb, avB, avA);
+                BWSTAMP(sbw + 4)
                 dxl(Zb);
             } else {
                 // the lower groups of blocks of f_net's dz_2 for the same rows, before this wave's own chain
@@ -800,13 +842,17 @@ __global__ __launch_bounds__(256) void node_rr_bwd_kernel(const NodeRkBwdLaunch 
                     }
                 asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
                 __hip_atomic_store(sFlag + 2 + half, key, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                BWSTAMP(sbw + 3)
                 prod(I1{}, Za, Zb, avB, avA);
                 prod(I2{}, Zb, Za, avA, avB);
+                BWSTAMP(sbw + 4)
                 dxl(Za);
             }
         }
+        BWSTAMP(sbw + 5)
         if (skip_dx) continue;
         __syncthreads();
+        BWSTAMP(sbw + 6)
         // ---- stage algebra (rk_bwd_stage_algebra's arithmetic): dY = [dYup at the last stage] + dX_f + dX_g; dy0 += dY;
         //      dK_j += beta[st][j] h dY for j < st — one (row, component) per thread, every operand requested up front
         if (tid < NLBAC_MLP_TILE * RK_MAX_NS) {
@@ -835,8 +881,10 @@ __global__ __launch_bounds__(256) void node_rr_bwd_kernel(const NodeRkBwdLaunch 
             }
         }
         __syncthreads();
+        BWSTAMP(sbw + 7)
     }
     __syncthreads();
+    BWSTAMP(2 + 8 * 7)
     rk_bwd_outputs<256>(L, w, T, row0, tid);
 }
 
@@ -894,6 +942,20 @@ int nlbac_node_rr_fwd_launch(NodeRkLaunch& L, hipStream_t s) {
     //  CU — the two waves' store bursts and the hand-over cost more than the balance gains: 140 against 124 us per launch)
     hipLaunchKernelGGL(kf[(rr_split() && L.acts_bits) ? 1 : 0][rr_shape_index(L.net[0].hid)][L.acts_bits ? 1 : 0], grid, dim3(256), lds, s, L);
     NLBAC_CHECK_LAUNCH("nlbac_node_rk_fwd(rr)");
+    return 0;
+}
+
+// 0 = launched, 1 = not these nets' launch
+int nlbac_node_rr_fwd_begin_launch(NodeRkLaunch& LA, NodeRkLaunch& LB, NodeRkLaunch& LC, hipStream_t s) {
+    if (!nlbac_node_rr_eligible(&LA.net[0], &LA.net[1]) || !LA.acts_bits) return 1;
+    using Kernel3 = void (*)(const NodeRkLaunch, const NodeRkLaunch, const NodeRkLaunch);
+    static const Kernel3 k3[2][3] = {{node_rr_fwd_begin_kernel<4, 4, 0>, node_rr_fwd_begin_kernel<7, 1, 0>, node_rr_fwd_begin_kernel<8, 4, 0>},
+                                     {node_rr_fwd_begin_kernel<4, 4, 1>, node_rr_fwd_begin_kernel<7, 1, 1>, node_rr_fwd_begin_kernel<8, 4, 1>}};
+    const size_t lds = (size_t)(RkFwdTile::floats() + NLBAC_MLP_TILE * 8 + 2 * 3 * 8 * 64 +
+                                2 * 32 * 64 + NLBAC_MLP_TILE * RK_MAX_NS + 2 * 2 * 64 + 4) * sizeof(float);
+    const dim3 grid(nlbac_ceil_div(LA.n, NLBAC_MLP_TILE));
+    hipLaunchKernelGGL(k3[rr_split() ? 1 : 0][rr_shape_index(LA.net[0].hid)], grid, dim3(256), lds, s, LA, LB, LC);
+    NLBAC_CHECK_LAUNCH("nlbac_node_rk_fwd_begin(rr)");
     return 0;
 }
 

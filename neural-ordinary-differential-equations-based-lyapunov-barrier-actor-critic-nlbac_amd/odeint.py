@@ -723,11 +723,6 @@ class AffineNodeSolver:
         ctl = self._ctl(P)
         cp = ctl.data_ptr()
         ch = [self._chain(ws0, pool, P, rpp, m, read_ctl=(m == 2)) for m in (0, 1, 2)]
-        # f0 + Hairer's first guess, the probe f(y0 + h0 f0) + the initial step: one launch each (norms fused)
-        self._rk_fused(ws0, y0, u, P, rpp, "dopri5", 0, 1, h_dev=cp, chain=ch[0])
-        self._chain_control(ws0, pool, ch[0], y0, u, 0, P, rpp)
-        self._rk_fused(ws0, y0, u, P, rpp, "probe", 1, 2, h_dev=cp + 8 * 6, save_acts=False, chain=ch[1])
-        self._chain_control(ws0, pool, ch[1], y0, u, 1, P, rpp)
         ip, om = self._interp_fold(), self._out_map_fwd(n)
         if ip and om is not None and isinstance(self, ConcatNodeSolver):
             ip = False                # (the single-net kernels evaluate no out-map)
@@ -736,17 +731,69 @@ class AffineNodeSolver:
             if om is not None:
                 ch[2].interp_kind, ch[2].interp_l, ch[2].interp_p = om.kind, om.l, om.p
         ctx["chain"] = dict(pool=pool, ws0=ws0, ch=ch[2], attempts=0, y0=y0, ip=ip, ip_om=om is not None)
-        self._chain_attempts(max(1, int(self.__dict__.get("_chain_len", 1))))
+        k = max(1, int(self.__dict__.get("_chain_len", 1)))
+        if self._begin_persistent(ws0, ch, y0, u, P, rpp):
+            # f0, the probe and the first attempted step were ONE launch (nlbac_node_rk_fwd_begin); the attempt's norm +
+            # controller and any further attempts follow as usual
+            self._chain_attempts(k, first_rk_done=True)
+            return
+        # f0 + Hairer's first guess, the probe f(y0 + h0 f0) + the initial step: one launch each (norms fused)
+        self._rk_fused(ws0, y0, u, P, rpp, "dopri5", 0, 1, h_dev=cp, chain=ch[0])
+        self._chain_control(ws0, pool, ch[0], y0, u, 0, P, rpp)
+        self._rk_fused(ws0, y0, u, P, rpp, "probe", 1, 2, h_dev=cp + 8 * 6, save_acts=False, chain=ch[1])
+        self._chain_control(ws0, pool, ch[1], y0, u, 1, P, rpp)
+        self._chain_attempts(k)
 
-    def _chain_attempts(self, k):
+    def _begin_persistent(self, ws0, ch, y0, u, P, rpp):
+        """f0 + first guess, probe + initial step and the first attempted step as ONE persistent launch
+        (nlbac_node_rk_fwd_begin) where the kernels and the sizes allow it: single GPU (the first two norms are fused:
+        no all-reduce in between), mask words (rollouts), every workgroup resident at once (<= 8192 rows).
+        OFF unless ``persistent = True`` / NLBAC_NODE_PERSIST=1: measured on MI355X it does not win — 108 us against
+        23.6 + 20.7 + 60.9 = 105 us for the three launches at 8192 rows (profiles/r04: what the one-stage launches cost
+        beyond their stage is not dispatch but the norm's election — partial sums, ticket, the controller, the release —
+        ~10 us of serial round trips each, and the persistent launch has the same two)."""
+        if not (self.fused and (self.comm is None or self.comm.world == 1) and ws0.bits and not self.adjoint):
+            return False
+        on = self.__dict__.get("persistent")
+        if on is None:
+            on = os.environ.get("NLBAC_NODE_PERSIST", "0") == "1"
+        if not on:
+            return False
+        key = (P, rpp)
+        ok = self.__dict__.setdefault("_pers_ok", {}).get(key)
+        if ok is None:
+            ok = self._pers_ok[key] = bool(_lib.load().nlbac_node_rk_fwd_begin_ok(C.byref(self.f.desc), C.byref(self.g.desc), P, rpp))
+        if not ok or ch[0].norm_mode != 0 or ch[1].norm_mode != 1:       # (the first two norms must be the fused ones)
+            return False
+        n = P * rpp
+        im = None
+        if self.ctx.pop("in_map_pending", None):
+            m, im = self._in_map, _lib.InMap()
+            im.kind, im.obs, im.obs_ld, im.l = m["kind"], m["obs"].data_ptr(), m["obs_ld"], m["l"]
+            im.ps = m["ps"].data_ptr() if m["ps"] is not None else None
+        c = _lib.RkChain.from_buffer_copy(ch[2])
+        c.partials, c.tickets = ch[0].partials, ch[0].tickets       # (the fused norms of the first two phases)
+        gen = self._buf("pers_gen", 8, dtype=torch.int32)
+        self._pers_id = self.__dict__.get("_pers_id", 0) + 1
+        beta, S = self._beta("dopri5")
+        cerr = self._coef("err")
+        _lib.call("nlbac_node_rk_fwd_begin", C.byref(self.f.desc), C.byref(self.g.desc), y0.data_ptr(), u.data_ptr(), P, rpp,
+                  beta, cerr, len(cerr), ws0.K.data_ptr(), ws0.Y.data_ptr(), ws0.gout.data_ptr(),
+                  ws0.acts_f.data_ptr(), ws0.S * n * ws0.wf, ws0.acts_g.data_ptr(), ws0.S * n * ws0.wg, ws0.err.data_ptr(),
+                  C.byref(c), C.byref(im) if im is not None else None, gen.data_ptr(), 2 * self._pers_id, stream_ptr())
+        self.nfe += 8
+        return True
+
+    def _chain_attempts(self, k, first_rk_done=False):
         ctx = self.ctx
         st = ctx["chain"]
         P, rpp, u = ctx["P"], ctx["rpp"], ctx["u"]
         ws0, pool, ch = st["ws0"], st["pool"], st["ch"]
         cp = self._ctl(P).data_ptr()
-        for _ in range(k):
-            self._rk_fused(ws0, st["y0"], u, P, rpp, "dopri5", 1, 7, h_dev=cp, c_err=self._coef("err"), err=ws0.err,
-                           chain=ch)
+        for i in range(k):
+            if not (first_rk_done and i == 0):
+                self._rk_fused(ws0, st["y0"], u, P, rpp, "dopri5", 1, 7, h_dev=cp, c_err=self._coef("err"), err=ws0.err,
+                               chain=ch)
             self._chain_control(ws0, pool, ch, st["y0"], u, 2, P, rpp)
         st["attempts"] += k
         if (self.comm is not None and self.comm.world > 1) or HOST_COPY == "side":
@@ -1457,6 +1504,9 @@ class ConcatNodeSolver(AffineNodeSolver):
 
     def _interp_nets(self):
         return C.byref(self.net.desc), None
+
+    def _begin_persistent(self, ws0, ch, y0, u, P, rpp):
+        return False
 
     # -- continuous adjoint (odeint_adjoint) of the single-net field ---------------------------------------------
     # The base class drives the solve (initial step, attempts, mixed norm, commit, interpolation, parameter-adjoint

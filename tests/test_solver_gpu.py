@@ -335,3 +335,31 @@ def test_interpolation_inside_the_rk_launches_matches_the_interpolation_launches
     assert torch.equal(o1, o0), "x(t_end): %.3e" % float((o1 - o0).abs().max())
     assert torch.equal(du1, du0), "d/du: %.3e" % float((du1 - du0).abs().max())
     assert torch.equal(dy1, dy0_), "d/dy0: %.3e" % float((dy1 - dy0_).abs().max())
+
+
+@pytest.mark.parametrize("T", [0.02, 0.3])
+def test_persistent_opening_launch_matches_the_three_launches(T):
+    """nlbac_node_rk_fwd_begin (f0 + first guess, probe + initial step, first attempted step in ONE persistent launch with a
+    per-problem wait between the phases) against the three launches it replaces: the same kernel code on the same data,
+    so the same bits — solution, gradients, step sizes — for two problems with their own step sequences."""
+    from nlbac_amd.odeint import AffineNodeSolver
+    agent, env = make_agent(64, 64, 0, "dopri5")
+    gen = torch.Generator().manual_seed(9)
+    rpp = 256
+    y0 = torch.cat([torch.rand(2 * rpp, 2, generator=gen) * 4 - 2, torch.rand(2 * rpp, 1, generator=gen) * 6 - 3], 1)
+    u = (torch.rand(2 * rpp, 2, generator=gen) * 2 - 1) * torch.tensor([3.5, 12.0])
+    u[rpp:] *= 5.0
+    dout = torch.randn(2 * rpp, 3, generator=gen)
+    res = []
+    for pers in (True, False):
+        sol = AffineNodeSolver(agent.neural_ode_model, "cuda")
+        sol.keep_acts = False
+        sol.persistent = pers
+        for _ in range(3):          # (several solves on one solver: the generation words are reused with new targets)
+            out = sol.forward(y0.cuda(), u.cuda(), 2, rpp, "dopri5", T).clone()
+            du, dy0 = sol.backward(dout.cuda(), need_du=True, need_dy0=True)
+        assert bool(sol.__dict__.get("_pers_id")) == pers, "the persistent launch was %staken" % ("not " if pers else "")
+        res.append((out, du.clone(), dy0.clone(), sol.ctx["info"]))
+    (o1, du1, dy1, i1), (o0, du0, dy0_, i0) = res
+    assert i1 == i0, (i1, i0)
+    assert torch.equal(o1, o0) and torch.equal(du1, du0) and torch.equal(dy1, dy0_)
