@@ -32,7 +32,7 @@
 extern "C" {
 #endif
 
-#define NLBAC_ABI_VERSION 9 /* bumped whenever an exported signature or struct changes; nlbac_abi_version() returns it */
+#define NLBAC_ABI_VERSION 10 /* bumped whenever an exported signature or struct changes; nlbac_abi_version() returns it */
 #define NLBAC_MAX_LAYERS 6
 #define NLBAC_MAX_NETS 8
 #define NLBAC_MLP_TILE 32 /* samples per workgroup in the MLP kernels */
@@ -477,6 +477,11 @@ typedef struct nlbac_rk_chain {
     int interp_kind; float interp_l; float *interp_p;
     int interp_bwd;
     const float *interp_dout, *interp_dp, *interp_dp2, *interp_x;
+    /* ABI 10 — ctl_seq > 0: the copy in ctl_host is written as a sequence lock the host can poll instead of waiting on
+     * an event behind the launch: slot 15 of the HOST block <- -ctl_seq, the other fields, slot 15 <- +ctl_seq, with
+     * system-scope release fences between (a reader takes slot 15, the block, slot 15 again and accepts equal positive
+     * stamps).  0: plain copy. */
+    double ctl_seq;
 } nlbac_rk_chain;
 /* 1 when the fused RK kernels that serve these nets evaluate nlbac_rk_chain::interp_* (g == NULL: the single-net
  * kernels of nlbac_concat_rk_fwd / _bwd, which take interp_out / interp_dout only — no out-map) */
@@ -649,6 +654,7 @@ int nlbac_adj_norm_control(const float *a, const float *b, const float *Z0, cons
                            const float *pnorm, float *partials, unsigned *tickets, double *ctl,
                            double *ctl_host /* ABI 8; or NULL: pinned HOST memory [P][NLBAC_DOPRI_CTL], the controller
                                                leaves a copy of each block it updates there (with tickets only) */,
+                           double host_seq /* ABI 10; > 0: that copy as a sequence lock, see nlbac_rk_chain::ctl_seq */,
                            nlbac_stream_t s);
 int nlbac_adj_control(const float *partials, int n_blk_per_problem, int mode, int n_s, int n_u, int rows_per_problem,
                       int P, double t_end, const float *pnorm, double *ctl, nlbac_stream_t s);

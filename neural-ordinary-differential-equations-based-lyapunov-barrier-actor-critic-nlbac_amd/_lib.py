@@ -102,7 +102,7 @@ class RkChain(C.Structure):
                 ("alog_cap", C.c_int), ("ctl_host", C.c_void_p),
                 ("interp_out", C.c_void_p), ("interp_kind", C.c_int), ("interp_l", C.c_float), ("interp_p", C.c_void_p),
                 ("interp_bwd", C.c_int), ("interp_dout", C.c_void_p), ("interp_dp", C.c_void_p),
-                ("interp_dp2", C.c_void_p), ("interp_x", C.c_void_p)]
+                ("interp_dp2", C.c_void_p), ("interp_x", C.c_void_p), ("ctl_seq", C.c_double)]
 
 
 class InMap(C.Structure):
@@ -202,7 +202,7 @@ _PROTOS = {
                             _I, c_float_p, _P, _I, _P, _P, _P, _P, _P, _P, _P, _P, _L, _P, _L, _P, _P, _P, _D, _P],
     "nlbac_adj_pack": [_P, _P, _I, _I, _I, _P, _P],
     "nlbac_adj_unpack": [_P, _I, _I, _I, _P, _P, _P],
-    "nlbac_adj_norm_control": [_P, _P, _P, _P, _P, _I, _F, _F, _I, _I, _I, _I, _D, _P, _P, _P, _P, _P, _P],
+    "nlbac_adj_norm_control": [_P, _P, _P, _P, _P, _I, _F, _F, _I, _I, _I, _I, _D, _P, _P, _P, _P, _P, _D, _P],
     "nlbac_adj_control": [_P, _I, _I, _I, _I, _I, _I, _D, _P, _P, _P],
     "nlbac_adj_param_norm": [_I, _P, _P, _L, _I, c_float_p, c_float_p, c_float_p, _P, _P, _P, _I, _F, _F, _P, _P, _P, _P, _P,
                              _P],
@@ -237,7 +237,7 @@ def build(verbose=False):
     return LIB_PATH
 
 
-ABI_VERSION = 9      # == NLBAC_ABI_VERSION of include/nlbac_hip.h (bumped with every signature / struct change)
+ABI_VERSION = 10      # == NLBAC_ABI_VERSION of include/nlbac_hip.h (bumped with every signature / struct change)
 
 
 def _stale_sources():

@@ -421,7 +421,7 @@ __global__ __launch_bounds__(256) void adj_norm_control_kernel(const float* a, c
                                                                const float* Z1, const float* u, int mode, float rtol,
                                                                float atol, int ns, int nu, int rpp, double t_end,
                                                                const float* pnorm, float* partials, unsigned* tickets,
-                                                               double* ctl, double* ctl_host) {
+                                                               double* ctl, double* ctl_host, double host_seq) {
     const int p = blockIdx.y, nblk = (int)gridDim.x;
     if (mode == 2 && ctl[(long)p * NLBAC_DOPRI_CTL + C_DONE] > 0.0) return;
     adj_norm_block(a, b, Z0, Z1, u, mode, rtol, atol, ns, nu, rpp, partials, tickets != nullptr);
@@ -453,8 +453,7 @@ __global__ __launch_bounds__(256) void adj_norm_control_kernel(const float* a, c
         const double s[4] = {s_red[0][0], s_red[1][0], s_red[2][0], s_red[3][0]};
         adj_control_one(s, p, mode, ns, nu, rpp, t_end, pnorm, ctl);
         // the host's copy of this problem's block (pinned memory the device writes directly, as dopri_norm_control_kernel)
-        if (ctl_host)
-            for (int k = 0; k < NLBAC_DOPRI_CTL; ++k) ctl_host[(long)p * NLBAC_DOPRI_CTL + k] = ctl[(long)p * NLBAC_DOPRI_CTL + k];
+        if (ctl_host) ctl_host_post(ctl_host + (long)p * NLBAC_DOPRI_CTL, ctl + (long)p * NLBAC_DOPRI_CTL, host_seq);
     }
 }
 
@@ -473,13 +472,13 @@ __global__ void adj_control_kernel(const float* partials, int nblk, int mode, in
 extern "C" int nlbac_adj_norm_control(const float* a, const float* b, const float* Z0, const float* Z1, const float* u,
                                       int mode, float rtol, float atol, int n_s, int n_u, int rows_per_problem, int P,
                                       double t_end, const float* pnorm, float* partials, unsigned* tickets, double* ctl,
-                                      double* ctl_host, nlbac_stream_t s) {
+                                      double* ctl_host, double host_seq, nlbac_stream_t s) {
     NLBAC_REQUIRE(a && Z0 && partials && ctl && mode >= 0 && mode <= 2, "nlbac_adj_norm_control: bad arguments");
     NLBAC_REQUIRE((mode != 0 || u) && (mode != 1 || b) && (mode != 2 || Z1), "nlbac_adj_norm_control: missing operand");
     NLBAC_REQUIRE(P >= 1 && P <= 8, "nlbac_adj_norm_control: P %d out of range", P);
     hipLaunchKernelGGL(adj_norm_control_kernel, dim3(nlbac_ceil_div(rows_per_problem, 256), P), dim3(256), 0,
                        (hipStream_t)s, a, b, Z0, Z1, u, mode, rtol, atol, n_s, n_u, rows_per_problem, t_end, pnorm,
-                       partials, tickets, ctl, tickets ? ctl_host : nullptr);
+                       partials, tickets, ctl, tickets ? ctl_host : nullptr, host_seq);
     NLBAC_CHECK_LAUNCH("nlbac_adj_norm_control");
     return 0;
 }

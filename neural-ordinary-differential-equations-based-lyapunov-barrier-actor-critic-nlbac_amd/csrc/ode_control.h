@@ -8,6 +8,28 @@ enum { C_H = 0, C_T = 1, C_RATIO = 2, C_ACCEPT = 3, C_DONE = 4, C_X = 5, C_H0 = 
        C_NACC = 12,    // accepted steps so far = index of the step slot the current attempt works in (device-driven chain)
        C_OVF = 13 };   // the solve ran out of step slots (it is stopped: C_DONE is set with it; the host restarts it)
 
+enum { C_SEQ = 15 };   // HOST copy only: the stamp of the launch that wrote the block (ctl_host_post); the device block's slot is unused
+
+// One problem's control block into the host's copy (pinned, fine-grained memory the device writes directly), as a
+// sequence lock the host can poll without an event: stamp <- -seq, fields, stamp <- +seq.  Every store is a
+// system-scope (write-through) store and each group waits for its acknowledgements before the next is issued — the
+// order the host sees; no release fence (a system-scope fence writes back the XCD's whole L2: the RK launch's rows are
+// dirty in it, and none of that is the host's business).  seq = 0: plain copy (the host reads behind an event).
+__device__ __forceinline__ void ctl_host_post(double* dst, const double* src, double seq) {
+    if (seq <= 0.0) {
+        for (int k = 0; k < NLBAC_DOPRI_CTL; ++k) dst[k] = src[k];
+        return;
+    }
+    double v[NLBAC_DOPRI_CTL];
+    for (int k = 0; k < NLBAC_DOPRI_CTL; ++k) v[k] = src[k];
+    __hip_atomic_store(dst + C_SEQ, -seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    for (int k = 0; k < NLBAC_DOPRI_CTL; ++k)
+        if (k != C_SEQ) __hip_atomic_store(dst + k, v[k], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __hip_atomic_store(dst + C_SEQ, seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+}
+
 // The controller of problem p on finished norms (torchdiffeq _select_initial_step / _compute_error_ratio /
 // _optimal_step_size with safety 0.9, ifactor 10, dfactor 0.2; steps are not clipped to t_end).
 //  mode 0: n0 = ||y0/scale||, n1 = ||f0/scale||          -> C_H0 (first guess), resets C_T / C_NSTEPS / C_DONE

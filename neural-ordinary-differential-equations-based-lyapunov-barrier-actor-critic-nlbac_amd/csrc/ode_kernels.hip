@@ -198,7 +198,7 @@ __global__ __launch_bounds__(256) void dopri_norm_control_kernel(const float* a,
                                                                  float* partials, unsigned* tickets, double* ctl,
                                                                  const double* slot_ctl, long slot_floats, int n_slots,
                                                                  double* hslots, double* alog, int alog_cap,
-                                                                 double* ctl_host) {
+                                                                 double* ctl_host, double host_seq) {
     // device-driven chain (slot_ctl): a finished problem is left alone by all of its blocks
     if (slot_ctl && mode == 2 && slot_ctl[(long)blockIdx.y * NLBAC_DOPRI_CTL + C_DONE] > 0.0) return;
     dopri_norm_block(a, b, y0, y1, u, mode, rtol, atol, n_s, n_u, rpp, partials, slot_ctl, slot_floats, true);
@@ -246,9 +246,8 @@ __global__ __launch_bounds__(256) void dopri_norm_control_kernel(const float* a,
             }
         }
         // the host's copy of this problem's block (pinned memory the device writes directly): what a copy launch on a
-        // side stream did before; the host waits on an event behind this launch
-        if (ctl_host)
-            for (int k = 0; k < NLBAC_DOPRI_CTL; ++k) ctl_host[(long)p * NLBAC_DOPRI_CTL + k] = c[k];
+        // side stream did before; the host waits on an event behind this launch, or (host_seq) polls the block's stamp
+        if (ctl_host) ctl_host_post(ctl_host + (long)p * NLBAC_DOPRI_CTL, c, host_seq);
     }
 }
 
@@ -414,7 +413,7 @@ extern "C" int nlbac_dopri_norm_control(const float* a, const float* b, const fl
                        (hipStream_t)s, a, b, y0, y1, u, mode, rtol, atol, n_s, n_u, rows_per_problem, t_end, partials,
                        tickets, ctl, (chain && mode == 2) ? chain->ctl : nullptr, chain ? chain->slot_floats : 0,
                        chain ? chain->n_slots : 0, chain ? chain->hslots : nullptr, chain ? chain->alog : nullptr,
-                       chain ? chain->alog_cap : 0, chain ? chain->ctl_host : nullptr);
+                       chain ? chain->alog_cap : 0, chain ? chain->ctl_host : nullptr, chain ? chain->ctl_seq : 0.0);
     NLBAC_CHECK_LAUNCH("nlbac_dopri_norm_control");
     return 0;
 }

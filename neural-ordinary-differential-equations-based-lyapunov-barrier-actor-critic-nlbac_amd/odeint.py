@@ -48,6 +48,10 @@ TABLEAU = {
 # How small results reach the host (the dopri5 control block here, the update's scalars block in sac_cbf_clf.py):
 # "kernel" — the producing kernel writes pinned host memory itself; "side" — an async copy on a side stream behind an event.
 HOST_COPY = os.environ.get("NLBAC_HOST_COPY", "kernel")
+# How the host learns that a controller launch has left its decision in the pinned control block: by polling the block's
+# stamp (a sequence lock the launch writes, nlbac_rk_chain::ctl_seq) or ("0") by an event behind the launch.
+CTL_POLL = os.environ.get("NLBAC_CTL_POLL", "1") != "0"
+_SEQ = [0]
 
 class _Carver:
     """Hands out the buffers of ONE step slot: consecutive 16-byte-aligned pieces of a flat float32 slice.  Every slot
@@ -475,6 +479,7 @@ class AffineNodeSolver:
         if torch.cuda.is_current_stream_capturing():
             return
         side, pin = self._ctl_io(P)
+        self.ctx["ctl_seq"] = None        # (a copy, read behind its event: nothing to poll)
         ev_a, ev_b = self._ev_ctl
         ev_a.record()
         side.wait_event(ev_a)
@@ -489,8 +494,46 @@ class AffineNodeSolver:
         if torch.cuda.is_current_stream_capturing():
             return
         self._ctl_io(P)
-        self._ev_ctl[1].record()
+        if self.ctx.get("ctl_seq") is None:
+            self._ev_ctl[1].record()     # (stamped blocks are polled: no event, no marker on the launch stream)
         self.ctx["ctl_pending"] = P
+
+    def _seq_next(self, first_of_solve=False):
+        """Stamp for the next controller launch that writes the host's copy (``CTL_POLL``); ctx["ctl_seq"] = (stamp of the
+        solve's first such launch, stamp of its latest).  None when the block is read behind an event."""
+        if not CTL_POLL or torch.cuda.is_current_stream_capturing() or HOST_COPY == "side":
+            self.ctx["ctl_seq"] = None
+            return 0.0
+        _SEQ[0] += 1                 # (one counter per process: solvers share pinned blocks, see _solve_split)
+        rng = self.ctx.get("ctl_seq")
+        self.ctx["ctl_seq"] = (_SEQ[0] if (first_of_solve or rng is None) else rng[0], _SEQ[0])
+        return float(_SEQ[0])
+
+    def _ctl_poll(self, P, first, last, patience=0.05):
+        """Wait for the stamped control blocks of the launch with stamp ``last``: a problem's block is complete when it
+        carries that stamp — or an earlier one of the same solve with the done flag (launches skip finished problems).
+        Sequence-lock read: stamp, block, stamp.  After ``patience`` seconds of spinning the launch stream is drained
+        (everything queued has then run) and the block must be there."""
+        import time
+        arr = self._ctl_pin[P].numpy()          # (the same memory)
+        t0 = drained = None
+        n = 0
+        while True:
+            s1 = arr[:, 15].copy()
+            c = arr.copy()
+            if all(c[p, 15] == s1[p] and (s1[p] == last or (first <= s1[p] < last and c[p, 4] > 0)) for p in range(P)):
+                return torch.from_numpy(c)
+            n += 1
+            if n & 63 == 0:
+                now = time.perf_counter()
+                if t0 is None:
+                    t0 = now
+                elif drained:
+                    raise _lib.NlbacError("control block %r never reached stamp %d (solve from %d)" % (s1, last, first))
+                elif now - t0 > patience:
+                    torch.cuda.current_stream().synchronize()
+                    drained = True
+                    self.stats["poll_drained"] = self.stats.get("poll_drained", 0) + 1
 
     def _ctl_io(self, P):
         """(side stream, pinned block for P problems) of the control-block read-back, created on first use."""
@@ -509,6 +552,9 @@ class AffineNodeSolver:
             hook = self.__dict__.get("before_wait")
             if hook is not None:
                 hook()                   # (the owner queues independent work behind the attempt before the host blocks)
+            rng = self.ctx.get("ctl_seq")
+            if rng is not None:
+                return self._ctl_poll(P, *rng)
             self._ev_ctl[1].synchronize()
             return self._ctl_pin[P].clone()
         return self._ctl(P).cpu()
@@ -712,12 +758,15 @@ class AffineNodeSolver:
         elif mode == 1:
             self._norm_control(ws0.K[1], ws0.K[0], y0, None, None, 1, P, rpp)
         else:
+            if chain.ctl_host and not (self.comm is not None and self.comm.world > 1):
+                chain.ctl_seq = self._seq_next()
             self._norm_control(ws0.err, None, y0, ws0.Y[6], None, 2, P, rpp, slot_ctl=ctl.data_ptr(),
                                slot_floats=pool.slot_floats, chain=chain)
 
     def _dopri_begin_chain(self, y0, u, P, rpp, min_slots=1):
         n, S = P * rpp, 7
         ctx = self.ctx
+        ctx["ctl_seq"] = None         # (stamps of this solve's controller launches start here: _seq_next)
         pool = self._pool(n, S, min_slots)
         ws0 = pool.ws(n, 0)
         ctl = self._ctl(P)
@@ -1160,7 +1209,7 @@ class AffineNodeSolver:
         if self.comm is not None and self.comm.world > 1:
             _lib.call("nlbac_adj_norm_control", dp(a), dp(b), w["Z0"].data_ptr(), w["Z1"].data_ptr(), dp(u), mode,
                       ctx["rtol"], ctx["atol"], ns, nu, rpp, P, ctx["t_end"], None, part.data_ptr(), None,
-                      ctl.data_ptr(), None, s)
+                      ctl.data_ptr(), None, 0.0, s)
             sums = self._buf("adj_psum", P, 1, 4)
             for p in range(P):
                 _lib.call("nlbac_sum_partials", part[p].data_ptr(), nblk, 4, 1.0, sums[p].data_ptr(), s)
@@ -1171,13 +1220,14 @@ class AffineNodeSolver:
         tickets = self._buf("adj_tickets", P, dtype=torch.int32)
         # (an attempt's controller leaves the host's copy of the control block in pinned memory itself: no copy launch
         #  between the decision and the host; see _ctl_posted)
-        host = None
+        host, seq = None, 0.0
         if mode == 2 and not torch.cuda.is_current_stream_capturing() and HOST_COPY != "side":
             host = self._ctl_io(P)[1].data_ptr()
+            seq = self._seq_next()
         ctx["adj_ctl_host"] = host is not None
         _lib.call("nlbac_adj_norm_control", dp(a), dp(b), w["Z0"].data_ptr(), w["Z1"].data_ptr(), dp(u), mode,
                   ctx["rtol"], ctx["atol"], ns, nu, rpp, P, ctx["t_end"], dp(pnorm), part.data_ptr(),
-                  tickets.data_ptr(), ctl.data_ptr(), host, s)
+                  tickets.data_ptr(), ctl.data_ptr(), host, seq, s)
 
     # -- parameter adjoint (a quadrature beside the per-row state; single-problem solves) -----------------
     ADJ_SUB_SLABS = 40       # row slabs of one stage's weight-gradient GEMM (workgroups: layers x slabs x nets)
@@ -1296,6 +1346,7 @@ class AffineNodeSolver:
         cp = ctl.data_ptr()
         KZ = w["KZ"]
         keep = par and par["keep"]
+        ctx["ctl_seq"] = None         # (the adjoint solve's own range of stamps: _seq_next)
         # f0 = G(z(t1)) and Hairer's initial step
         self._adj_step(w, u, P, rpp, "dopri5", 0, 1, h_host=[0.0] * P, keep=keep)
         pn = self._adj_params_norm(par, 0, cp) if par else None
