@@ -32,7 +32,7 @@
 extern "C" {
 #endif
 
-#define NLBAC_ABI_VERSION 10 /* bumped whenever an exported signature or struct changes; nlbac_abi_version() returns it */
+#define NLBAC_ABI_VERSION 11 /* bumped whenever an exported signature or struct changes; nlbac_abi_version() returns it */
 #define NLBAC_MAX_LAYERS 6
 #define NLBAC_MAX_NETS 8
 #define NLBAC_MLP_TILE 32 /* samples per workgroup in the MLP kernels */
@@ -482,6 +482,16 @@ typedef struct nlbac_rk_chain {
      * system-scope release fences between (a reader takes slot 15, the block, slot 15 again and accepts equal positive
      * stamps).  0: plain copy. */
     double ctl_seq;
+    /* ABI 11 — the fused norm of a launch without its election (the kernels of nlbac_rk_interp_ok(f, g), g != NULL).
+     * norm_defer != 0 (with norm_mode 0 or 1): the launch's epilogue only leaves its tiles' partial sums in `partials`
+     *   (plain stores; tickets is not used, the control block is not touched).
+     * norm_pre = 1 + mode (1: mode 0, 2: mode 1), in the NEXT launch on the stream: every workgroup sums
+     *   partials_pre (= the previous launch's `partials`; not this launch's) for its problem in the fixed order, runs
+     *   that mode's controller and takes ITS step size (mode 0: the first guess, mode 1: the initial step) instead of
+     *   h_host / h_dev; the problem's first tile updates ctl_w exactly as the fused / separate controller would.
+     *   With interp_out the reach-t_end test uses that step size.  Same arithmetic in the same order: same bits. */
+    int norm_defer, norm_pre;
+    const float *partials_pre;
 } nlbac_rk_chain;
 /* 1 when the fused RK kernels that serve these nets evaluate nlbac_rk_chain::interp_* (g == NULL: the single-net
  * kernels of nlbac_concat_rk_fwd / _bwd, which take interp_out / interp_dout only — no out-map) */

@@ -102,7 +102,8 @@ class RkChain(C.Structure):
                 ("alog_cap", C.c_int), ("ctl_host", C.c_void_p),
                 ("interp_out", C.c_void_p), ("interp_kind", C.c_int), ("interp_l", C.c_float), ("interp_p", C.c_void_p),
                 ("interp_bwd", C.c_int), ("interp_dout", C.c_void_p), ("interp_dp", C.c_void_p),
-                ("interp_dp2", C.c_void_p), ("interp_x", C.c_void_p), ("ctl_seq", C.c_double)]
+                ("interp_dp2", C.c_void_p), ("interp_x", C.c_void_p), ("ctl_seq", C.c_double),
+                ("norm_defer", C.c_int), ("norm_pre", C.c_int), ("partials_pre", C.c_void_p)]
 
 
 class InMap(C.Structure):
@@ -237,7 +238,7 @@ def build(verbose=False):
     return LIB_PATH
 
 
-ABI_VERSION = 10      # == NLBAC_ABI_VERSION of include/nlbac_hip.h (bumped with every signature / struct change)
+ABI_VERSION = 11      # == NLBAC_ABI_VERSION of include/nlbac_hip.h (bumped with every signature / struct change)
 
 
 def _stale_sources():

@@ -700,7 +700,7 @@ static int rk_fwd_fill(NodeRkLaunch& L, const nlbac_mlp* f, const nlbac_mlp* g, 
     if (chain) {
         NLBAC_REQUIRE(P == 1 || rows_per_problem % NLBAC_MLP_TILE == 0,
                       "nlbac_node_rk_fwd: a chained launch needs rows_per_problem %% 32 == 0 (tiles must not straddle problems)");
-        NLBAC_REQUIRE(chain->norm_mode < 0 || (chain->norm_mode <= 2 && chain->partials && chain->tickets && chain->ctl_w),
+        NLBAC_REQUIRE(chain->norm_mode < 0 || (chain->norm_mode <= 2 && chain->partials && (chain->tickets || chain->norm_defer) && chain->ctl_w),
                       "nlbac_node_rk_fwd: fused step control needs partials, tickets and the control block");
         NLBAC_REQUIRE(chain->norm_mode != 2 || (err && n_err > 0), "nlbac_node_rk_fwd: norm mode 2 needs the error coefficients");
         NLBAC_REQUIRE(!chain->ctl || chain->slot_floats >= 0, "nlbac_node_rk_fwd: bad slot stride");
@@ -709,6 +709,17 @@ static int rk_fwd_fill(NodeRkLaunch& L, const nlbac_mlp* f, const nlbac_mlp* g, 
         L.rtol = chain->rtol; L.atol = chain->atol; L.t_end = chain->t_end;
         L.partials = chain->partials; L.tickets = chain->tickets; L.ctl_w = chain->ctl_w; L.hslots = chain->hslots;
         L.alog = chain->alog; L.alog_cap = chain->alog_cap;
+        if (chain->norm_defer || chain->norm_pre) {
+            NLBAC_REQUIRE(nlbac_node_rr_eligible(f, g),
+                          "nlbac_node_rk_fwd: norm_defer / norm_pre need the register-resident kernels (nlbac_rk_interp_ok)");
+            NLBAC_REQUIRE(!chain->norm_defer || chain->norm_mode == 0 || chain->norm_mode == 1,
+                          "nlbac_node_rk_fwd: norm_defer goes with norm mode 0 or 1");
+            NLBAC_REQUIRE(chain->norm_pre >= 0 && chain->norm_pre <= 2 && (!chain->norm_pre || (chain->partials_pre && chain->ctl_w)),
+                          "nlbac_node_rk_fwd: norm_pre is 0, 1 or 2 and needs partials_pre and the control block");
+            NLBAC_REQUIRE(!chain->norm_pre || chain->partials_pre != chain->partials,
+                          "nlbac_node_rk_fwd: the partial sums read and written by one launch must be two arrays");
+            L.norm_defer = chain->norm_defer ? 1 : 0; L.norm_pre = chain->norm_pre; L.partials_pre = chain->partials_pre;
+        }
         if (chain->interp_out) {
             NLBAC_REQUIRE(chain->ctl && stage_end == n_stages_total && n_stages_total == 7,
                           "nlbac_node_rk_fwd: interp_out goes with an attempt launch of a device-driven dopri5 chain");

@@ -50,6 +50,11 @@ struct NodeRkLaunch {
     // stores pers_target there, the other workgroups of the problem wait for it before their next phase; coh: this phase
     // reads the control block (h, slot, done) past the non-coherent caches (another workgroup of THIS launch wrote it)
     unsigned* pers_gen; unsigned pers_target; int coh;
+    // nlbac_rk_chain::norm_defer / norm_pre: the fused norm WITHOUT its election.  norm_defer: the epilogue only leaves
+    // this tile's partial sums (plain stores); norm_pre = 1 + mode: every workgroup of THIS launch sums the partials the
+    // previous launch left (partials_pre, the same fixed order) and runs that mode's controller itself before its first
+    // stage — the step size it yields is this launch's; the problem's first tile writes the control block.
+    int norm_defer, norm_pre; const float* partials_pre;
 };
 
 struct NodeRkBwdLaunch {
@@ -111,6 +116,7 @@ struct RkFwdWhere {
     int p_tile; long soff; bool fsal;
     float *gK, *gY, *gG, *gErr; const float* gy0;
     bool ip; float ip_x;         // this attempt reaches t_end: evaluate the interpolant at abscissa ip_x (nlbac_rk_chain::interp_out)
+    double h_pre;                // norm_pre: the step size this launch's own controller produced (rk_fwd_norm_pre)
 };
 __device__ __forceinline__ double rk_ctl_load(const double* p, bool coh) {
     return coh ? __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : *p;
@@ -121,6 +127,7 @@ __device__ __forceinline__ bool rk_fwd_where(const NodeRkLaunch& L, int row0, Rk
     w.fsal = false;
     w.ip = false;
     w.ip_x = 0.f;
+    w.h_pre = 0.0;
     if (L.ctl) {
         const double* c = L.ctl + (long)w.p_tile * NLBAC_DOPRI_CTL;
         const bool coh = L.coh != 0;
@@ -128,7 +135,7 @@ __device__ __forceinline__ bool rk_fwd_where(const NodeRkLaunch& L, int row0, Rk
         const int slot = (int)rk_ctl_load(c + C_NACC, coh);
         w.soff = (long)slot * L.slot_floats;
         w.fsal = slot > 0;
-        if (L.ip_out) {          // the controller's own test and abscissa (ode_control.h: accept && t + h >= t_end -> C_X)
+        if (L.ip_out && !L.norm_pre) {      // the controller's own test and abscissa (ode_control.h: accept && t + h >= t_end -> C_X)
             const double t = rk_ctl_load(c + C_T, coh), h = rk_ctl_load(c + C_H, coh);
             w.ip = t + h >= L.t_end;
             w.ip_x = (float)((L.t_end - t) / h);
@@ -140,6 +147,50 @@ __device__ __forceinline__ bool rk_fwd_where(const NodeRkLaunch& L, int row0, Rk
     w.gErr = L.err ? L.err + w.soff : nullptr;
     w.gy0 = w.fsal ? (w.gY - L.slot_floats) + (long)(L.S_total - 1) * L.n * L.n_s : L.y0;
     return true;
+}
+
+// nlbac_rk_chain::norm_pre: the controller of the norm whose tile partials the previous launch left, run by every
+// workgroup for its own problem: the sums in the order the elected workgroup of the fused form takes them (same bits),
+// dopri_control_vals on a private copy of the block; the problem's first tile runs it on the block itself, for the
+// launches that follow.  What a launch saves this way is the previous launch's election: two device-scope atomic round
+// trips per workgroup behind its stores, the last workgroup's sums and controller with the whole chip idle, ~10 us per
+// one-stage launch; what it pays is this reduction (L2-resident loads, one fp64 pow) under its own prologue's loads.
+// Contains a barrier.
+template <int NTHR>
+__device__ __forceinline__ void rk_fwd_norm_pre(const NodeRkLaunch& L, RkFwdWhere& w, int row0, int tid) {
+    __shared__ double s_hpre_[2];
+    const int mode = L.norm_pre - 1, p = w.p_tile;
+    if (tid < 64) {
+        const int nblk = (L.rpp + NLBAC_MLP_TILE - 1) / NLBAC_MLP_TILE;
+        double d0 = 0.0, d1 = 0.0;
+        for (int b = tid; b < nblk; b += 64) {
+            const float* q = L.partials_pre + ((long)p * nblk + b) * 2;
+            d0 += (double)q[0];
+            d1 += (double)q[1];
+        }
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) { d0 += __shfl_down(d0, off, 64); d1 += __shfl_down(d1, off, 64); }
+        if (tid == 0) {
+            const double cnt = (double)L.rpp * (double)(L.n_s + L.n_u);
+            const double n0 = sqrt(d0 / cnt), n1 = sqrt(d1 / cnt);
+            double* c = L.ctl_w + (long)p * NLBAC_DOPRI_CTL;
+            double loc[NLBAC_DOPRI_CTL];
+#pragma unroll
+            for (int k = 0; k < NLBAC_DOPRI_CTL; ++k) loc[k] = 0.0;
+            if (mode == 1) { loc[C_H0] = c[C_H0]; loc[C_D1] = c[C_D1]; }     // (what mode 1 reads: the previous launch's first tile wrote them)
+            dopri_control_vals(n0, n1, 0, mode, L.t_end, loc, L.n_slots);
+            if (row0 == p * L.rpp) dopri_control_vals(n0, n1, p, mode, L.t_end, L.ctl_w, L.n_slots);
+            s_hpre_[0] = mode == 0 ? loc[C_H0] : loc[C_H];
+            s_hpre_[1] = mode == 0 ? 0.0 : c[C_T];
+        }
+    }
+    __syncthreads();
+    w.h_pre = s_hpre_[0];
+    if (L.ip_out) {
+        const double t = s_hpre_[1], h = w.h_pre;
+        w.ip = t + h >= L.t_end;
+        w.ip_x = (float)((L.t_end - t) / h);
+    }
 }
 
 // tile constants: y0 (or the in-map's state), u, h, already-known stages (FSAL / f0 from an earlier launch).
@@ -185,6 +236,7 @@ __device__ __forceinline__ void rk_fwd_tile_constants(const NodeRkLaunch& L, con
         if (tid < NLBAC_MLP_TILE) {
             const int p = min(row0 + tid, n - 1) / L.rpp;
             vh = L.h_dev ? (float)rk_ctl_load(L.h_dev + (long)p * L.h_stride, L.coh != 0) : L.h_val[p];
+            if (L.norm_pre) vh = (float)w.h_pre;
         }
 #pragma unroll
         for (int it = 0; it < NK; ++it) {
@@ -375,6 +427,8 @@ __device__ __forceinline__ void rk_fwd_outputs_and_control(const NodeRkLaunch& L
             const int nblk = (L.rpp + NLBAC_MLP_TILE - 1) / NLBAC_MLP_TILE;
             const int blk = (row0 - p_tile * L.rpp) / NLBAC_MLP_TILE;
             float* q = L.partials + ((long)p_tile * nblk + blk) * 2;
+            if (L.norm_defer) { q[0] = v0; q[1] = v1; }        // (the next launch sums them: rk_fwd_norm_pre)
+            else {
             // No agent-scope fence here: on gfx950 a release at agent scope writes the XCD's whole L2 back, and this
             // workgroup has just written the step's K / Y / masks (measured: +15 us on a one-stage launch, +30 us on an
             // attempt).  The two partial sums go out as device-scope atomic exchanges — performed at the level all
@@ -386,8 +440,10 @@ __device__ __forceinline__ void rk_fwd_outputs_and_control(const NodeRkLaunch& L
             const unsigned ticket = __hip_atomic_fetch_add(L.tickets + p_tile, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             s_last = (ticket == (unsigned)nblk - 1u) ? 1u : 0u;
             if (s_last) __hip_atomic_store(L.tickets + p_tile, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            }
         }
     }
+    if (L.norm_defer) return;                  // (uniform)
     __syncthreads();
     if (!s_last || tid >= 64) return;
     {

@@ -786,12 +786,37 @@ class AffineNodeSolver:
             # controller and any further attempts follow as usual
             self._chain_attempts(k, first_rk_done=True)
             return
+        if self._norm_defer_ok(ch):
+            # The norms of f0 and of the probe without their elections (nlbac_rk_chain::norm_defer / norm_pre): each
+            # launch leaves its tiles' partial sums, the NEXT launch's workgroups sum them and run the controller
+            # themselves under their prologue's loads.
+            nblk = (rpp + _lib.MLP_TILE - 1) // _lib.MLP_TILE
+            part0, part1 = self._buf("cpart", P, nblk, 2).data_ptr(), self._buf("cpart1", P, nblk, 2).data_ptr()
+            ch[0].norm_defer, ch[0].partials = 1, part0
+            ch[1].norm_pre, ch[1].partials_pre, ch[1].norm_defer, ch[1].partials = 1, part0, 1, part1
+            first = _lib.RkChain.from_buffer_copy(ch[2])
+            first.norm_pre, first.partials_pre = 2, part1
+            ctx["chain"]["ch_first"] = first        # (the first attempted step only: later attempts get their step size from the controller launch)
         # f0 + Hairer's first guess, the probe f(y0 + h0 f0) + the initial step: one launch each (norms fused)
         self._rk_fused(ws0, y0, u, P, rpp, "dopri5", 0, 1, h_dev=cp, chain=ch[0])
         self._chain_control(ws0, pool, ch[0], y0, u, 0, P, rpp)
         self._rk_fused(ws0, y0, u, P, rpp, "probe", 1, 2, h_dev=cp + 8 * 6, save_acts=False, chain=ch[1])
         self._chain_control(ws0, pool, ch[1], y0, u, 1, P, rpp)
         self._chain_attempts(k)
+
+    def _norm_defer_ok(self, ch):
+        """The election-free form of the two fused norms that open a dopri5 solve: where those norms are fused at all (one
+        GPU) and the register-resident kernels serve the nets.  ``norm_defer = False`` (NLBAC_NORM_DEFER=0): the fused
+        norms with their elections — the cross-check."""
+        on = self.__dict__.get("norm_defer")
+        if on is None:
+            on = self.norm_defer = os.environ.get("NLBAC_NORM_DEFER", "1") != "0"
+        if not on or ch[0].norm_mode != 0 or ch[1].norm_mode != 1 or self._interp_nets()[1] is None:
+            return False
+        ok = self.__dict__.get("_interp_ok")
+        if ok is None:
+            ok = self._interp_ok = bool(_lib.load().nlbac_rk_interp_ok(*self._interp_nets()))
+        return bool(ok and self.fused)
 
     def _begin_persistent(self, ws0, ch, y0, u, P, rpp):
         """f0 + first guess, probe + initial step and the first attempted step as ONE persistent launch
@@ -842,7 +867,7 @@ class AffineNodeSolver:
         for i in range(k):
             if not (first_rk_done and i == 0):
                 self._rk_fused(ws0, st["y0"], u, P, rpp, "dopri5", 1, 7, h_dev=cp, c_err=self._coef("err"), err=ws0.err,
-                               chain=ch)
+                               chain=st.pop("ch_first", None) or ch)
             self._chain_control(ws0, pool, ch, st["y0"], u, 2, P, rpp)
         st["attempts"] += k
         if (self.comm is not None and self.comm.world > 1) or HOST_COPY == "side":

@@ -363,3 +363,34 @@ def test_persistent_opening_launch_matches_the_three_launches(T):
     (o1, du1, dy1, i1), (o0, du0, dy0_, i0) = res
     assert i1 == i0, (i1, i0)
     assert torch.equal(o1, o0) and torch.equal(du1, du0) and torch.equal(dy1, dy0_)
+
+
+@pytest.mark.parametrize("T", [0.02, 0.3])
+def test_election_free_opening_norms_match_the_fused_norms(T):
+    """nlbac_rk_chain::norm_defer / norm_pre (f0 and the probe leave their tiles' partial sums, the next launch's
+    workgroups sum them and run the controller themselves) against the fused norms with their last-workgroup elections:
+    the same sums in the same order and the same controller arithmetic, so the same bits — solution, gradients, step
+    sizes, control block — for two problems with their own step sequences."""
+    from nlbac_amd.odeint import AffineNodeSolver
+    agent, env = make_agent(64, 64, 0, "dopri5")
+    gen = torch.Generator().manual_seed(11)
+    rpp = 256
+    y0 = torch.cat([torch.rand(2 * rpp, 2, generator=gen) * 4 - 2, torch.rand(2 * rpp, 1, generator=gen) * 6 - 3], 1)
+    u = (torch.rand(2 * rpp, 2, generator=gen) * 2 - 1) * torch.tensor([3.5, 12.0])
+    u[rpp:] *= 5.0
+    dout = torch.randn(2 * rpp, 3, generator=gen)
+    res = []
+    for defer in (True, False):
+        sol = AffineNodeSolver(agent.neural_ode_model, "cuda")
+        sol.keep_acts = False
+        sol.norm_defer = defer
+        for _ in range(2):
+            out = sol.forward(y0.cuda(), u.cuda(), 2, rpp, "dopri5", T).clone()
+            du, dy0 = sol.backward(dout.cuda(), need_du=True, need_dy0=True)
+        used = any(k[0] == "cpart1" for pool in sol._scratch.values() for k in pool if isinstance(k, tuple))
+        assert used == defer, "the election-free norms were %staken" % ("not " if defer else "")
+        res.append((out, du.clone(), dy0.clone(), sol.ctx["info"], sol._ctl(2).clone()))
+    (o1, du1, dy1, i1, c1), (o0, du0, dy0_, i0, c0) = res
+    assert i1 == i0, (i1, i0)
+    assert torch.equal(c1, c0), (c1, c0)
+    assert torch.equal(o1, o0) and torch.equal(du1, du0) and torch.equal(dy1, dy0_)
