@@ -32,7 +32,7 @@
 extern "C" {
 #endif
 
-#define NLBAC_ABI_VERSION 11 /* bumped whenever an exported signature or struct changes; nlbac_abi_version() returns it */
+#define NLBAC_ABI_VERSION 12 /* bumped whenever an exported signature or struct changes; nlbac_abi_version() returns it */
 #define NLBAC_MAX_LAYERS 6
 #define NLBAC_MAX_NETS 8
 #define NLBAC_MLP_TILE 32 /* samples per workgroup in the MLP kernels */
@@ -357,6 +357,11 @@ int nlbac_cars_constraints_bwd(const float *matr, const float *bmatr, float gamm
 /* dst[row][col0+c] += src[row][c] */
 int nlbac_add_cols(float *dst, int dst_ld, int col0, const float *src, int src_ld, int ncols, int n,
                    nlbac_stream_t s);
+/* ABI 12 — dst (n x ld, dense) <- (dst + src on columns [col0, col0 + ncols) of rows < n_src) + add (n x ld): nlbac_add_cols
+ * and the nlbac_axpby(1, dst, 1, add) behind it as one launch (SimulatedCars: the gradient w.r.t. x_t+1 from the
+ * constraints, from V(x_t+1) and from the second solve; C/sac_cbf_clf.py:412-555 autograd accumulates the same three) */
+int nlbac_add_cols_plus(float *dst, int ld, int col0, const float *src, int src_ld, int ncols, int n_src,
+                        const float *add, int n, nlbac_stream_t s);
 
 /* Learned barrier certificate (NU = neural_barrier_certificate/.../Unicycle_RL_training).
  * td_value: y = signal + mask*gamma*next_target, dpred = 2 (pred - y)/B_norm, per-block squared-error partials

@@ -175,6 +175,7 @@ _PROTOS = {
     "nlbac_cars_constraints_fwd": [_P, _P, _P, _P, _P, _F, _F, _F, _I, _P, _P, _P, C.POINTER(AuglagArgs), _P, _P, _P],
     "nlbac_cars_constraints_bwd": [_P, _P, _F, _F, _I, _P, _P, _P, _P, _P],
     "nlbac_add_cols": [_P, _I, _I, _P, _I, _I, _I, _P],
+    "nlbac_add_cols_plus": [_P, _I, _I, _P, _I, _I, _I, _P, _I, _P],
     "nlbac_pvtol_state": [_P, _I, _I, _P, _P, _P],
     "nlbac_pvtol_obs_fwd": [_P, _P, _I, _F, _F, _F, _I, _P, _I, _P, _P],
     "nlbac_pvtol_obs_bwd": [_P, _P, _I, _F, _F, _F, _I, _P, _I, _P],
@@ -238,7 +239,7 @@ def build(verbose=False):
     return LIB_PATH
 
 
-ABI_VERSION = 11      # == NLBAC_ABI_VERSION of include/nlbac_hip.h (bumped with every signature / struct change)
+ABI_VERSION = 12      # == NLBAC_ABI_VERSION of include/nlbac_hip.h (bumped with every signature / struct change)
 
 
 def _stale_sources():

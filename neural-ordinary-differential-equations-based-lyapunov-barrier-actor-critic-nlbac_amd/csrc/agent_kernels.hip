@@ -492,6 +492,17 @@ __global__ __launch_bounds__(256) void add_cols_kernel(float* dst, int dst_ld, i
     for (int c = 0; c < ncols; ++c) dst[(long)i * dst_ld + col0 + c] += src[(long)i * src_ld + c];
 }
 
+// dst (n x ld) <- (dst + src on its column block, rows < n_src) + add: add_cols and the axpby behind it as one launch
+__global__ __launch_bounds__(256) void add_cols_plus_kernel(float* dst, int ld, int col0, const float* src, int src_ld,
+                                                            int ncols, int n_src, const float* add, long total) {
+    const long i = (long)blockIdx.x * 256 + threadIdx.x;
+    if (i >= total) return;
+    const int row = (int)(i / ld), c = (int)(i - (long)row * ld);
+    float v = dst[i];
+    if (row < n_src && c >= col0 && c < col0 + ncols) v += src[(long)row * src_ld + (c - col0)];
+    dst[i] = v + add[i];
+}
+
 // MSE (mean over n*d) partial sums and gradient
 __global__ __launch_bounds__(256) void mse_kernel(const float* pred, int pred_ld, const float* target, int target_ld,
                                                   int n, int n_norm, int d, float* dpred, int dpred_ld,
@@ -732,6 +743,17 @@ extern "C" int nlbac_add_cols(float* dst, int dst_ld, int col0, const float* src
     NLBAC_REQUIRE(dst && src && ncols >= 1, "nlbac_add_cols: bad arguments");
     hipLaunchKernelGGL(add_cols_kernel, GRID1(n), dst, dst_ld, col0, src, src_ld, ncols, n);
     NLBAC_CHECK_LAUNCH("nlbac_add_cols");
+    return 0;
+}
+
+extern "C" int nlbac_add_cols_plus(float* dst, int ld, int col0, const float* src, int src_ld, int ncols, int n_src,
+                                   const float* add, int n, nlbac_stream_t s) {
+    NLBAC_REQUIRE(dst && src && add && ncols >= 1 && col0 >= 0 && col0 + ncols <= ld && n_src <= n,
+                  "nlbac_add_cols_plus: bad arguments");
+    const long total = (long)n * ld;
+    hipLaunchKernelGGL(add_cols_plus_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, (hipStream_t)s, dst, ld,
+                       col0, src, src_ld, ncols, n_src, add, total);
+    NLBAC_CHECK_LAUNCH("nlbac_add_cols_plus");
     return 0;
 }
 

@@ -290,6 +290,14 @@ class AffineNodeSolver:
                 k.before_wait = self.__dict__.get("before_wait")
                 k.reserve(n // P, 1, method, steps)
 
+    def _out_buf(self, n, fallback=None):
+        """Where the solve's result goes: the caller's tensor (``out_into``, when it has the solve's shape — the next
+        launches read it there, no copy) or a solver-owned buffer."""
+        t = self.__dict__.get("out_into")
+        if t is not None and tuple(t.shape) == (n, self.n_s) and t.is_contiguous():
+            return t
+        return fallback if fallback is not None else self._buf("dopri_out", n, self.n_s)
+
     def _buf(self, name, *shape, dtype=torch.float32):
         """Named scratch buffer of the current solve size (dropped with that size's workspaces, see ``_touch``)."""
         pool = self._scratch.setdefault(self.__dict__.get("_cur_n", 0), {})
@@ -424,9 +432,10 @@ class AffineNodeSolver:
             ws = self._step_ws(n, S, 0)
             h = [float(dt)] * P
             if self.fused:
-                self._rk_fused(ws, y0, u, P, rpp, method, 0, S, h_host=h, c_out=fptr(*tab["c_sol"]), out=ws.y1)
+                out = self._out_buf(n, ws.y1)
+                self._rk_fused(ws, y0, u, P, rpp, method, 0, S, h_host=h, c_out=fptr(*tab["c_sol"]), out=out)
                 self.ctx["steps"].append(dict(ws=ws, h=h, first=True))
-                self.ctx["out"] = ws.y1
+                self.ctx["out"] = out
                 return
             ws.Y[0].copy_(y0)
             for st in range(S):
@@ -776,7 +785,7 @@ class AffineNodeSolver:
         if ip and om is not None and isinstance(self, ConcatNodeSolver):
             ip = False                # (the single-net kernels evaluate no out-map)
         if ip:
-            ch[2].interp_out = self._buf("dopri_out", n, self.n_s).data_ptr()
+            ch[2].interp_out = self._out_buf(n).data_ptr()
             if om is not None:
                 ch[2].interp_kind, ch[2].interp_l, ch[2].interp_p = om.kind, om.l, om.p
         ctx["chain"] = dict(pool=pool, ws0=ws0, ch=ch[2], attempts=0, y0=y0, ip=ip, ip_om=om is not None)
@@ -897,7 +906,7 @@ class AffineNodeSolver:
             if st["attempts"] >= 1000:
                 raise _lib.NlbacError("dopri5: max_num_steps exceeded")
             self._chain_attempts(2)
-        out = self._buf("dopri_out", n, ns)
+        out = self._out_buf(n)
         if st.get("ip"):
             # the attempt that finished each problem has written its rows of `out` (and of the owner's map) itself
             ctx["out_mapped"] = st["ip_om"]
@@ -975,7 +984,7 @@ class AffineNodeSolver:
         P, rpp, n, ns = ctx["P"], ctx["rpp"], ctx["n"], self.n_s
         ws = self._step_ws(n, 7, 0)
         ctl = self._ctl(P)
-        out = self._buf("dopri_out", n, ns)       # (y1 is the input of stage 6: read in place, no copy)
+        out = self._out_buf(n)       # (y1 is the input of stage 6: read in place, no copy)
         _lib.call("nlbac_dopri_interp_fwd", ctx["y0"].data_ptr(), ws.Y[6].data_ptr(), ws.K.data_ptr(), None, None,
                   ctl.data_ptr(), P, rpp, ns, out.data_ptr(), 0, None, stream_ptr())
         step = dict(ws=ws, first=True, dev=True)
@@ -1018,7 +1027,7 @@ class AffineNodeSolver:
                 if done[0]:
                     x = [float(c[p, 5]) for p in range(P)]
                     steps[-1]["x"] = x
-                    out = self._buf("dopri_out", n, ns)
+                    out = self._out_buf(n)
                     _lib.call("nlbac_dopri_interp_fwd", cur_y0.data_ptr(), ws.Y[6].data_ptr(), ws.K.data_ptr(),
                               fptr(*steps[-1]["h"]), fptr(*x), None, P, rpp, ns, out.data_ptr(), 0, None, s)
                     ctx.update(steps=steps, out=out, info=info)
@@ -1069,7 +1078,7 @@ class AffineNodeSolver:
         ctx = self.ctx
         self.stats["split"] += 1
         P, rpp, n = ctx["P"], ctx["rpp"], ctx["n"]
-        out = self._buf("dopri_out", n, self.n_s)
+        out = self._out_buf(n)
         kids, info = [], []
         for p in range(P):
             if p not in self._children:

@@ -455,6 +455,7 @@ class CarsTask(_Task):
         # state, its primary / backup copies and the carried [action, time] inputs of both steps: one launch
         _lib.call("nlbac_cars_rollout_inputs", ws.mb.data_ptr(), lay.LD, lay.t, lay.nt, ws.pi2.data_ptr(), B,
                   ws.state.data_ptr(), ws.y0_2.data_ptr(), ws.c1.data_ptr(), ws.c2.data_ptr(), s)
+        self.solver1.out_into = ws.x1_2 if a.fold_launches else None     # x_t+1 lands where the next launches read it
         self.solver1.forward_begin(ws.y0_2, ws.c1, 2, B, a.solver, float(self.env.dt), a.atol, a.rtol)
 
     def loss_and_backward(self, ws, P, lam_upd, assume_single):
@@ -462,7 +463,8 @@ class CarsTask(_Task):
         B, sc, dt = ws.B, a.sc.data_ptr(), float(self.env.dt)
         pol = a.policy
         x1 = self.solver1.forward_finish()
-        ws.x1_2.copy_(x1)
+        if x1.data_ptr() != ws.x1_2.data_ptr():
+            ws.x1_2.copy_(x1)         # (normally the solver has written there itself: out_into, rollout_begin)
         # u_(t+1) ~ pi(. | get_obs(x_t+1)), detached (C/sac_cbf_clf.py:441-451, 585-595)
         call("nlbac_cars_obs", ws.x1_2.data_ptr(), 2 * B, ws.obs1_2.data_ptr(), s)
         self.policy_sample(ws, "nx", P.n_act, P.io_nx, 2, B, ws.heads_nx, ws.eps[3:5], 1, ws.c2, 2, ws.logp_nx)
@@ -476,10 +478,10 @@ class CarsTask(_Task):
         call("nlbac_cars_constraints_bwd", ws.matr.data_ptr(), ws.bmatr.data_ptr(), float(a.gamma_b),
              float(a.batch_size), B, sc, ws.dx1.data_ptr(), ws.dx2.data_ptr(), ws.dV1.data_ptr(), s)
         call("nlbac_mlp_bwd_data", P.n_l, P.io_v1, 1, B, s)               # dV1 -> d x1[0:B, 4:8]
-        call("nlbac_add_cols", ws.dx1.data_ptr(), 10, 4, ws.dlya.data_ptr(), 4, 4, B, s)
         # x_t+2 depends on the first action only through x_t+1
         _, dy0 = self.solver2.backward(ws.dx2, need_du=False, need_dy0=True)
-        call("nlbac_axpby", 1.0, ws.dx1.data_ptr(), 1.0, dy0.data_ptr(), 2 * B * 10, ws.dx1.data_ptr(), s)
+        # d/dx_t+1: the constraints' own (dx1) + V(x_t+1)'s on columns 4..7 of the primary rows + the second solve's
+        call("nlbac_add_cols_plus", ws.dx1.data_ptr(), 10, 4, ws.dlya.data_ptr(), 4, 4, B, dy0.data_ptr(), 2 * B, s)
         dc, _ = self.solver1.backward(ws.dx1, need_du=True)               # (2B, 2): d/d[action, time]
         return dc, 2
 
