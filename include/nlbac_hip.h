@@ -32,7 +32,7 @@
 extern "C" {
 #endif
 
-#define NLBAC_ABI_VERSION 12 /* bumped whenever an exported signature or struct changes; nlbac_abi_version() returns it */
+#define NLBAC_ABI_VERSION 13 /* bumped whenever an exported signature or struct changes; nlbac_abi_version() returns it */
 #define NLBAC_MAX_LAYERS 6
 #define NLBAC_MAX_NETS 8
 #define NLBAC_MLP_TILE 32 /* samples per workgroup in the MLP kernels */
@@ -91,6 +91,11 @@ typedef struct nlbac_mlp_io {
     long acts_ls;                       /* layer stride of acts/dz in floats; 0 = B*hid.  Lets several
                                            launches (RK stages) fill row blocks of one [layer][rows][hid] buffer */
     const float *dy; int dy_ld;         /* bwd in:  (B, out_dim)                    */
+    int dz_first;                       /* ABI 13 (in what was padding).  dz rows of layers [0, dz_first) are not wanted:
+                                           with skinny_ws the data backward leaves layer 0's weight / bias gradients
+                                           as partial sums, and nlbac_mlp_bwd_weights reads dz from layer 1 on — 1 saves
+                                           the (B, hid) store of layer 0 (a third of the launch's bytes at hid 256).
+                                           Honoured by the kernels that can (others store every layer); 0: all */
     float *dz;                          /* [n_layers-1][B][hid] pre-activation grads (bwd_data out, bwd_weights in) */
     float *dx; int dx_ld;               /* bwd_data out: (B, in_dim) or NULL        */
     int dx_first;                       /* first input column dx is wanted for: columns [0, dx_first) of dx are NOT

@@ -40,7 +40,7 @@ class MlpIO(C.Structure):
                 ("x1", C.c_void_p), ("x1_dim", C.c_int), ("x1_ld", C.c_int),
                 ("y", C.c_void_p), ("y_ld", C.c_int),
                 ("acts", C.c_void_p), ("acts_ls", C.c_long),
-                ("dy", C.c_void_p), ("dy_ld", C.c_int),
+                ("dy", C.c_void_p), ("dy_ld", C.c_int), ("dz_first", C.c_int),
                 ("dz", C.c_void_p),
                 ("dx", C.c_void_p), ("dx_ld", C.c_int), ("dx_first", C.c_int),
                 ("grad", C.c_void_p),
@@ -239,7 +239,7 @@ def build(verbose=False):
     return LIB_PATH
 
 
-ABI_VERSION = 12      # == NLBAC_ABI_VERSION of include/nlbac_hip.h (bumped with every signature / struct change)
+ABI_VERSION = 13      # == NLBAC_ABI_VERSION of include/nlbac_hip.h (bumped with every signature / struct change)
 
 
 def _stale_sources():

@@ -247,6 +247,7 @@ def pack(handles, target=False):
 
 
 _BW_WS = {}
+DZ_SKIP0 = __import__("os").environ.get("NLBAC_DZ_SKIP0", "1") != "0"
 
 
 def skinny_partials_ws(nets, io_sets, n_nets, B, device):
@@ -261,6 +262,7 @@ def skinny_partials_ws(nets, io_sets, n_nets, B, device):
     for i in range(n_nets):
         for io in io_sets:
             io[i].skinny_ws = ws.data_ptr() + 4 * i * (need // n_nets)
+            io[i].dz_first = 1 if DZ_SKIP0 else 0      # (layer 0's gradients travel as those partial sums: its dz rows are not read)
     return ws
 
 

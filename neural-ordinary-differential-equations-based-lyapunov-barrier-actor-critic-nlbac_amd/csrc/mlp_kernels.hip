@@ -1247,6 +1247,9 @@ extern "C" int nlbac_mlp_bwd_weights(const nlbac_mlp* nets, const nlbac_mlp_io* 
         // nlbac_mlp_bwd_data has already left this net's partial sums in its block of ws (nlbac_mlp_io::skinny_ws)
         partials_ready = partials_ready && io[i].skinny_ws == ws + (long)i * S.net_stride;
     }
+    for (int i = 0; i < n_nets; ++i)
+        NLBAC_REQUIRE(io[i].dz_first == 0 || partials_ready,
+                      "nlbac_mlp_bwd_weights: dz_first > 0 (layer 0's dz rows were not stored) needs the data backward's partial sums");
     if (!partials_ready && nlbac_mlp_dw16_eligible(nets, n_nets, B))       // every layer's dW and db in one launch
         return nlbac_mlp_dw16_launch(L, n_nets, (hipStream_t)s);
     if (max_blocks > 0) {

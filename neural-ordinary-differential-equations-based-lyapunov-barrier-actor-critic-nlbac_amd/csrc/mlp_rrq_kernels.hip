@@ -290,6 +290,7 @@ __global__ __launch_bounds__(256, 3) void mlp_rrq_bwd_kernel(const MlpLaunch L, 
     const int idim = net.in_dim, odim = net.out_dim;
     const long ls = io.acts_ls ? io.acts_ls : (long)B * HID;
     const bool sk = io.skinny_ws != nullptr && io.dz != nullptr;
+    const bool skip0 = sk && io.dz_first > 0;
     const int ub = 16 * NBQ * cq;
     QBSTAMP(0)
 
@@ -419,7 +420,8 @@ __global__ __launch_bounds__(256, 3) void mlp_rrq_bwd_kernel(const MlpLaunch L, 
 #pragma unroll
         for (int j = 0; j < NBQ; ++j) {
             *reinterpret_cast<f32x4*>(z0p + ls + 16 * j) = f32x4{H1q[4 * j], H1q[4 * j + 1], H1q[4 * j + 2], H1q[4 * j + 3]};
-            *reinterpret_cast<f32x4*>(z0p + 16 * j) = f32x4{Hz[4 * j], Hz[4 * j + 1], Hz[4 * j + 2], Hz[4 * j + 3]};
+            // (layer 0's rows only where somebody reads them: with the skinny partials below nobody does, nlbac_mlp_io::dz_first)
+            if (!skip0) *reinterpret_cast<f32x4*>(z0p + 16 * j) = f32x4{Hz[4 * j], Hz[4 * j + 1], Hz[4 * j + 2], Hz[4 * j + 3]};
         }
     }
     if (sk) {
