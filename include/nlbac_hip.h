@@ -32,7 +32,7 @@
 extern "C" {
 #endif
 
-#define NLBAC_ABI_VERSION 13 /* bumped whenever an exported signature or struct changes; nlbac_abi_version() returns it */
+#define NLBAC_ABI_VERSION 14 /* bumped whenever an exported signature or struct changes; nlbac_abi_version() returns it */
 #define NLBAC_MAX_LAYERS 6
 #define NLBAC_MAX_NETS 8
 #define NLBAC_MLP_TILE 32 /* samples per workgroup in the MLP kernels */
@@ -493,8 +493,9 @@ typedef struct nlbac_rk_chain {
      * stamps).  0: plain copy. */
     double ctl_seq;
     /* ABI 11 — the fused norm of a launch without its election (the kernels of nlbac_rk_interp_ok(f, g), g != NULL).
-     * norm_defer != 0 (with norm_mode 0 or 1): the launch's epilogue only leaves its tiles' partial sums in `partials`
-     *   (plain stores; tickets is not used, the control block is not touched).
+     * norm_defer != 0 (with a norm_mode): the launch's epilogue only leaves its tiles' partial sums in `partials`
+     *   (plain stores; tickets is not used, the control block is not touched).  Modes 0 / 1 are finished by the next
+     *   launch (norm_pre), mode 2 by nlbac_dopri_control_tiles.
      * norm_pre = 1 + mode (1: mode 0, 2: mode 1), in the NEXT launch on the stream: every workgroup sums
      *   partials_pre (= the previous launch's `partials`; not this launch's) for its problem in the fixed order, runs
      *   that mode's controller and takes ITS step size (mode 0: the first guess, mode 1: the initial step) instead of
@@ -610,6 +611,12 @@ int nlbac_dopri_control(const float *partials, int n_blk_per_problem, int mode, 
                         int n_slots /* 0: no step slots; > 0: chained (a finished solve is left alone in mode 2) */,
                         double *hslots /* or NULL: [P][n_slots] accepted step sizes */,
                         double *alog /* or NULL: attempt log, see nlbac_rk_chain */, int alog_cap, nlbac_stream_t s);
+/* ABI 14 — the controller of an attempted step whose RK launch ran norm mode 2 with norm_defer (its tiles' partial sums
+ * are in chain->partials): sums them per problem in the fused form's order and does what nlbac_dopri_norm_control's
+ * controller does with `chain` (step slots, attempt log, ctl_host / ctl_seq); finished problems are skipped.  A 64-thread
+ * workgroup per problem instead of a pass over the error rows and an election. */
+int nlbac_dopri_control_tiles(const struct nlbac_rk_chain *chain, int n_s, int n_u, int rows_per_problem, int P,
+                              nlbac_stream_t s);
 /* y(t_end) from the accepted step's stages (4th-order interpolant, x=(t_end-t)/h) and its backward
  * (writes dy0, dy1, dK[0..6]).  h and x come from the device control block `ctl` (h_used, x) when it is
  * non-NULL — hipGraph-replay safe — else from the host arrays. */

@@ -212,6 +212,7 @@ _PROTOS = {
     "nlbac_dopri_norm_partials": [_P, _P, _P, _P, _P, _I, _F, _F, _I, _I, _I, _I, _P, _P, _L, _P],
     "nlbac_dopri_norm_control": [_P, _P, _P, _P, _P, _I, _F, _F, _I, _I, _I, _I, _D, _P, _P, _P, C.POINTER(RkChain), _P],
     "nlbac_dopri_control": [_P, _I, _I, _I, _I, _I, _I, _D, _P, _I, _P, _P, _I, _P],
+    "nlbac_dopri_control_tiles": [C.POINTER(RkChain), _I, _I, _I, _I, _P],
     "nlbac_dopri_interp_fwd": [_P, _P, _P, c_float_p, c_float_p, _P, _I, _I, _I, _P, _L, C.POINTER(OutMap), _P],
     "nlbac_dopri_interp_bwd": [_P, c_float_p, c_float_p, _P, _I, _I, _I, _P, _P, _P, _L, C.POINTER(OutMap), _P],
     "nlbac_unicycle_env_step": [_I, c_double_p, _I] + [_P, _I] + [_P] * 13,
@@ -239,7 +240,7 @@ def build(verbose=False):
     return LIB_PATH
 
 
-ABI_VERSION = 13      # == NLBAC_ABI_VERSION of include/nlbac_hip.h (bumped with every signature / struct change)
+ABI_VERSION = 14      # == NLBAC_ABI_VERSION of include/nlbac_hip.h (bumped with every signature / struct change)
 
 
 def _stale_sources():

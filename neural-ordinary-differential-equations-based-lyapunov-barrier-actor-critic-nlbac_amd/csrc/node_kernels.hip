@@ -712,8 +712,8 @@ static int rk_fwd_fill(NodeRkLaunch& L, const nlbac_mlp* f, const nlbac_mlp* g, 
         if (chain->norm_defer || chain->norm_pre) {
             NLBAC_REQUIRE(nlbac_node_rr_eligible(f, g),
                           "nlbac_node_rk_fwd: norm_defer / norm_pre need the register-resident kernels (nlbac_rk_interp_ok)");
-            NLBAC_REQUIRE(!chain->norm_defer || chain->norm_mode == 0 || chain->norm_mode == 1,
-                          "nlbac_node_rk_fwd: norm_defer goes with norm mode 0 or 1");
+            NLBAC_REQUIRE(!chain->norm_defer || (chain->norm_mode >= 0 && chain->norm_mode <= 2),
+                          "nlbac_node_rk_fwd: norm_defer goes with a norm mode");
             NLBAC_REQUIRE(chain->norm_pre >= 0 && chain->norm_pre <= 2 && (!chain->norm_pre || (chain->partials_pre && chain->ctl_w)),
                           "nlbac_node_rk_fwd: norm_pre is 0, 1 or 2 and needs partials_pre and the control block");
             NLBAC_REQUIRE(!chain->norm_pre || chain->partials_pre != chain->partials,

@@ -351,6 +351,18 @@ __device__ __forceinline__ void rk_fwd_outputs_and_control(const NodeRkLaunch& L
             for (int j = 0; j < L.n_err; ++j)
                 if (L.c_err[j] != 0.f) a = a + sK[(j * NLBAC_MLP_TILE + m) * RK_MAX_NS + r] * (L.c_err[j] * h);
             w.gErr[(long)row * ns + r] = a;
+            if (L.norm_mode == 2) {
+                // the error norm's term of this (row, component) — one per thread here; the row sums follow below (one
+                // thread per row doing all of its components' 13-term chains in a row cost the attempt launch 4 us)
+                const float y = sY0[m * RK_MAX_NS + r];
+                float y1 = y;
+                const int sl = L.S_total - 1;         // y1 = the last stage's input
+                for (int j = 0; j < sl; ++j)
+                    if (L.beta[sl][j] != 0.f) y1 = y1 + sK[(j * NLBAC_MLP_TILE + m) * RK_MAX_NS + r] * (L.beta[sl][j] * h);
+                const float tol = L.atol + L.rtol * fmaxf(fabsf(y), fabsf(y1));
+                const float q = a / tol;
+                T.sG[m * RK_MAX_NS + r] = q * q;      // (g(x) of the last stage is no longer needed)
+            }
         }
     }
     if (w.ip) {      // (uniform per tile) the solve's result, should this attempt be accepted: one (row, component) per thread
@@ -386,23 +398,15 @@ __device__ __forceinline__ void rk_fwd_outputs_and_control(const NodeRkLaunch& L
     }
     if (L.norm_mode < 0) return;
     __shared__ unsigned s_last;
+    if (L.norm_mode == 2) __syncthreads();         // (uniform) the terms in sG
     if (tid < 64) {
         const int m = tid;
         float v0 = 0.f, v1 = 0.f;
         if (m < n_rows) {
-            const float h = sH[m];
             for (int r = 0; r < ns; ++r) {
                 const float y = sY0[m * RK_MAX_NS + r];
                 if (L.norm_mode == 2) {
-                    float e = 0.f, y1 = y;
-                    for (int j = 0; j < L.n_err; ++j)
-                        if (L.c_err[j] != 0.f) e = e + sK[(j * NLBAC_MLP_TILE + m) * RK_MAX_NS + r] * (L.c_err[j] * h);
-                    const int sl = L.S_total - 1;         // y1 = the last stage's input
-                    for (int j = 0; j < sl; ++j)
-                        if (L.beta[sl][j] != 0.f) y1 = y1 + sK[(j * NLBAC_MLP_TILE + m) * RK_MAX_NS + r] * (L.beta[sl][j] * h);
-                    const float tol = L.atol + L.rtol * fmaxf(fabsf(y), fabsf(y1));
-                    const float q = e / tol;
-                    v0 += q * q;
+                    v0 += T.sG[m * RK_MAX_NS + r];
                 } else {
                     const float sc = L.atol + fabsf(y) * L.rtol;
                     if (L.norm_mode == 0) {

@@ -190,6 +190,40 @@ __global__ void dopri_control_kernel(const float* partials, int nblk, int mode, 
     }
 }
 
+// The controller of an attempted step on the tile partials its RK launch left (nlbac_rk_chain::norm_defer with norm
+// mode 2): one wave per problem, the sums in the order the fused form's elected workgroup takes them (same bits), then
+// everything dopri_norm_control_kernel's last thread does — step slots, attempt log, the host's copy.
+__global__ __launch_bounds__(64) void dopri_control_tiles_kernel(const float* partials, int nblk, int n_s, int n_u, int rpp,
+                                                                 double t_end, double* ctl, int n_slots, double* hslots,
+                                                                 double* alog, int alog_cap, double* ctl_host,
+                                                                 double host_seq) {
+    const int p = blockIdx.x, tid = threadIdx.x;
+    double* c = ctl + (long)p * NLBAC_DOPRI_CTL;
+    if (c[C_DONE] > 0.0) return;                  // (a finished solve is left alone: its tiles wrote nothing)
+    double d0 = 0.0, d1 = 0.0;
+    for (int b = tid; b < nblk; b += 64) {
+        const float* q = partials + ((long)p * nblk + b) * 2;
+        d0 += (double)q[0];
+        d1 += (double)q[1];
+    }
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) { d0 += __shfl_down(d0, off, 64); d1 += __shfl_down(d1, off, 64); }
+    if (tid != 0) return;
+    const int slot_before = (int)c[C_NACC];
+    const double h_try = c[C_H];
+    const double cnt = (double)rpp * (double)(n_s + n_u);
+    dopri_control_vals(sqrt(d0 / cnt), sqrt(d1 / cnt), p, 2, t_end, ctl, n_slots > 0 ? n_slots : (1 << 30));
+    if (hslots && c[C_ACCEPT] > 0.0) hslots[(long)p * n_slots + slot_before] = h_try;
+    if (alog) {
+        const int k = (int)c[C_NSTEPS] - 1;
+        if (k >= 0 && k < alog_cap) {
+            double* al = alog + ((long)p * alog_cap + k) * 3;
+            al[0] = h_try; al[1] = c[C_RATIO]; al[2] = c[C_ACCEPT];
+        }
+    }
+    if (ctl_host) ctl_host_post(ctl_host + (long)p * NLBAC_DOPRI_CTL, c, host_seq);
+}
+
 // norm + controller in one launch: the workgroup that finishes a problem's sums last (a ticket counter per problem,
 // left at zero again for the next launch) runs that problem's controller
 __global__ __launch_bounds__(256) void dopri_norm_control_kernel(const float* a, const float* b, const float* y0,
@@ -426,6 +460,21 @@ extern "C" int nlbac_dopri_control(const float* partials, int n_blk_per_problem,
     hipLaunchKernelGGL(dopri_control_kernel, dim3(P), dim3(64), 0, (hipStream_t)s, partials, n_blk_per_problem, mode,
                        n_s, n_u, rows_per_problem, t_end, ctl, n_slots, hslots, alog, alog_cap);
     NLBAC_CHECK_LAUNCH("nlbac_dopri_control");
+    return 0;
+}
+
+extern "C" int nlbac_dopri_control_tiles(const nlbac_rk_chain* chain, int n_s, int n_u, int rows_per_problem, int P,
+                                         nlbac_stream_t s) {
+    NLBAC_REQUIRE(chain && chain->partials && chain->ctl_w && chain->norm_mode == 2 && chain->norm_defer,
+                  "nlbac_dopri_control_tiles: needs the chain of an attempt launch with norm mode 2 and norm_defer");
+    NLBAC_REQUIRE(P >= 1 && P <= MAX_PROBLEMS && (P == 1 || rows_per_problem % NLBAC_MLP_TILE == 0),
+                  "nlbac_dopri_control_tiles: bad problem sizes");
+    NLBAC_REQUIRE(!chain->hslots || chain->n_slots >= 1, "nlbac_dopri_control_tiles: hslots needs n_slots");
+    hipLaunchKernelGGL(dopri_control_tiles_kernel, dim3(P), dim3(64), 0, (hipStream_t)s, chain->partials,
+                       nlbac_ceil_div(rows_per_problem, NLBAC_MLP_TILE), n_s, n_u, rows_per_problem, chain->t_end,
+                       chain->ctl_w, chain->n_slots, chain->hslots, chain->alog, chain->alog_cap, chain->ctl_host,
+                       chain->ctl_seq);
+    NLBAC_CHECK_LAUNCH("nlbac_dopri_control_tiles");
     return 0;
 }
 

@@ -52,6 +52,7 @@ HOST_COPY = os.environ.get("NLBAC_HOST_COPY", "kernel")
 # stamp (a sequence lock the launch writes, nlbac_rk_chain::ctl_seq) or ("0") by an event behind the launch.
 CTL_POLL = os.environ.get("NLBAC_CTL_POLL", "1") != "0"
 _SEQ = [0]
+NORM_DEFER_ATTEMPT = os.environ.get("NLBAC_NORM_DEFER_ATTEMPT", "1") != "0"
 
 class _Carver:
     """Hands out the buffers of ONE step slot: consecutive 16-byte-aligned pieces of a flat float32 slice.  Every slot
@@ -759,7 +760,13 @@ class AffineNodeSolver:
     def _chain_control(self, ws0, pool, chain, y0, u, mode, P, rpp):
         """the scaled norm + step controller as launches of their own (slot-aware), where the RK launch did not run them
         in its epilogue (see ``_chain``)"""
+        if chain.norm_mode >= 0 and not (mode == 2 and chain.norm_defer):
+            return
         if chain.norm_mode >= 0:
+            # an attempt whose RK launch left its tiles' partial sums (norm_defer): one small workgroup per problem
+            if chain.ctl_host:
+                chain.ctl_seq = self._seq_next()
+            _lib.call("nlbac_dopri_control_tiles", C.byref(chain), self.n_s, self.n_u, rpp, P, stream_ptr())
             return
         ctl = self._ctl(P)
         if mode == 0:
@@ -803,6 +810,11 @@ class AffineNodeSolver:
             part0, part1 = self._buf("cpart", P, nblk, 2).data_ptr(), self._buf("cpart1", P, nblk, 2).data_ptr()
             ch[0].norm_defer, ch[0].partials = 1, part0
             ch[1].norm_pre, ch[1].partials_pre, ch[1].norm_defer, ch[1].partials = 1, part0, 1, part1
+            if self.__dict__.get("norm_defer_attempt", NORM_DEFER_ATTEMPT):
+                # ... and the attempts': the RK launch leaves the error norm's tile partials, the controller launch is one
+                # 64-thread workgroup per problem (nlbac_dopri_control_tiles) instead of a pass over the error rows
+                ch[2].norm_mode, ch[2].norm_defer = 2, 1
+                ch[2].partials = self._buf("cpart2", P, nblk, 2).data_ptr()
             first = _lib.RkChain.from_buffer_copy(ch[2])
             first.norm_pre, first.partials_pre = 2, part1
             ctx["chain"]["ch_first"] = first        # (the first attempted step only: later attempts get their step size from the controller launch)
@@ -879,8 +891,9 @@ class AffineNodeSolver:
                                chain=st.pop("ch_first", None) or ch)
             self._chain_control(ws0, pool, ch, st["y0"], u, 2, P, rpp)
         st["attempts"] += k
-        if (self.comm is not None and self.comm.world > 1) or HOST_COPY == "side":
-            self._ctl_post(P)        # (the all-reduced controller is nlbac_dopri_control: it leaves no host copy)
+        if (self.comm is not None and self.comm.world > 1) or HOST_COPY == "side" or (ch.norm_mode == 2 and not ch.norm_defer):
+            self._ctl_post(P)        # (the all-reduced controller is nlbac_dopri_control: it leaves no host copy; nor does
+                                     #  the RK launch's own epilogue, FUSED_NORM_MODES with 2)
         else:
             self._ctl_posted(P)
 

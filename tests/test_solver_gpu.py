@@ -355,6 +355,7 @@ def test_persistent_opening_launch_matches_the_three_launches(T):
         sol = AffineNodeSolver(agent.neural_ode_model, "cuda")
         sol.keep_acts = False
         sol.persistent = pers
+        sol.norm_defer_attempt = False      # (the persistent launch keeps the attempt's norm as the launch over the error rows)
         for _ in range(3):          # (several solves on one solver: the generation words are reused with new targets)
             out = sol.forward(y0.cuda(), u.cuda(), 2, rpp, "dopri5", T).clone()
             du, dy0 = sol.backward(dout.cuda(), need_du=True, need_dy0=True)
@@ -365,12 +366,15 @@ def test_persistent_opening_launch_matches_the_three_launches(T):
     assert torch.equal(o1, o0) and torch.equal(du1, du0) and torch.equal(dy1, dy0_)
 
 
+@pytest.mark.parametrize("attempts", [False, True])
 @pytest.mark.parametrize("T", [0.02, 0.3])
-def test_election_free_opening_norms_match_the_fused_norms(T):
+def test_election_free_opening_norms_match_the_fused_norms(T, attempts):
     """nlbac_rk_chain::norm_defer / norm_pre (f0 and the probe leave their tiles' partial sums, the next launch's
     workgroups sum them and run the controller themselves) against the fused norms with their last-workgroup elections:
     the same sums in the same order and the same controller arithmetic, so the same bits — solution, gradients, step
-    sizes, control block — for two problems with their own step sequences."""
+    sizes, control block — for two problems with their own step sequences.  ``attempts``: the attempted steps' error norm
+    the same way (tile partials from the RK launch + nlbac_dopri_control_tiles) against its fused form (norm mode 2 in
+    the RK launch's epilogue, which sums the same tile partials in the same order)."""
     from nlbac_amd.odeint import AffineNodeSolver
     agent, env = make_agent(64, 64, 0, "dopri5")
     gen = torch.Generator().manual_seed(11)
@@ -384,11 +388,16 @@ def test_election_free_opening_norms_match_the_fused_norms(T):
         sol = AffineNodeSolver(agent.neural_ode_model, "cuda")
         sol.keep_acts = False
         sol.norm_defer = defer
+        sol.norm_defer_attempt = attempts
+        if attempts and not defer:
+            sol.FUSED_NORM_MODES = (0, 1, 2)
         for _ in range(2):
             out = sol.forward(y0.cuda(), u.cuda(), 2, rpp, "dopri5", T).clone()
             du, dy0 = sol.backward(dout.cuda(), need_du=True, need_dy0=True)
         used = any(k[0] == "cpart1" for pool in sol._scratch.values() for k in pool if isinstance(k, tuple))
         assert used == defer, "the election-free norms were %staken" % ("not " if defer else "")
+        used2 = any(k[0] == "cpart2" for pool in sol._scratch.values() for k in pool if isinstance(k, tuple))
+        assert used2 == (defer and attempts)
         res.append((out, du.clone(), dy0.clone(), sol.ctx["info"], sol._ctl(2).clone()))
     (o1, du1, dy1, i1, c1), (o0, du0, dy0_, i0, c0) = res
     assert i1 == i0, (i1, i0)
