@@ -9,12 +9,13 @@ export TMPDIR=/tmp
 rocprofv3 --kernel-trace --output-format csv -d $D -o run -- python3 bench.py --lean --no-cpu-baseline --steps 60 --warmup 20 "$@" > $D/bench.json 2> $D/bench.err || { tail -5 $D/bench.err; exit 1; }
 F=$(find $D -name "*kernel_trace.csv" | head -1)
 python3 tools/update_table.py $F 61 69 > $D/table.txt
+python3 tools/gap_report.py $F 61 69 > $D/gap_report.txt 2>&1 || true
 python3 - $F > $D/one_update.txt <<'PY'
 import csv, sys
 rows = list(csv.DictReader(open(sys.argv[1])))
 ks = sorted((int(r["Start_Timestamp"]), int(r["End_Timestamp"]), r["Kernel_Name"].split("(")[0].replace("void ", "")[:60]) for r in rows)
 marks = [i for i, k in enumerate(ks) if k[2].startswith("sample_rows")]
-for u in (63, 64):
+for u in [int(x) for x in __import__("os").environ.get("TRACE_UPDATES", "63,64").split(",")]:
     seg = ks[marks[u]:marks[u + 1]]
     t0 = seg[0][0]
     prev = t0
