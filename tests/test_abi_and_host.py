@@ -337,3 +337,50 @@ def test_pmc_summary_differences_two_run_lengths(tmp_path):
     assert abs(d["one_time_bytes"] - 4000.0 * 1024) < 1e-3
     assert abs(d["kernels"]["node_rr_fwd_kernel"]["hbm_bytes_per_launch"] - (2 * 50.0 + 10.0) * 1024) < 1e-6
     assert abs(d["per_update_by_kernel"]["node_rr_fwd_kernel"] - per_update) < 1e-6
+
+
+def test_host_reader_of_the_stamped_control_block():
+    """``AffineNodeSolver._ctl_poll`` (host side of nlbac_rk_chain::ctl_seq, no GPU needed): a problem's block is complete
+    when it carries the stamp of the launch waited for — or an earlier stamp of the same solve with the done flag (launches
+    skip finished problems); a block whose stamp is negative (a writer is in the middle of it), older than the solve or
+    not yet there is waited for; torn reads (stamp changes under the copy) are retried."""
+    import threading
+    import time
+    from nlbac_amd.odeint import AffineNodeSolver
+
+    class Fake:
+        stats = {}
+        _ctl_poll = AffineNodeSolver._ctl_poll
+
+    f = Fake()
+    pin = torch.zeros(2, _lib.DOPRI_CTL, dtype=torch.float64)
+    f._ctl_pin = {2: pin}
+    arr = pin.numpy()
+    # both problems carry the stamp waited for
+    arr[:, 15] = 7.0
+    arr[:, 0] = (0.25, 0.5)
+    c = f._ctl_poll(2, 7, 7)
+    assert c[0, 0] == 0.25 and c[1, 0] == 0.5 and c.data_ptr() != pin.data_ptr()
+    # problem 1 finished two launches ago (done flag, stamp 5 of the same solve 4..7): accepted as it stands
+    arr[1, 15], arr[1, 4] = 5.0, 1.0
+    c = f._ctl_poll(2, 4, 7)
+    assert c[1, 15] == 5.0 and c[1, 4] == 1.0
+    # ... but not a done block of an EARLIER solve (stamp 3 < first 4), and not a block being written (negative stamp):
+    # the reader waits until the writer has finished
+    arr[1, 15] = 3.0
+
+    def writer():
+        time.sleep(0.01)
+        arr[1, 15] = -7.0          # the launch's first store
+        time.sleep(0.01)
+        arr[1, 4], arr[1, 0] = 0.0, 0.125
+        time.sleep(0.005)
+        arr[1, 15] = 7.0
+
+    t = threading.Thread(target=writer)
+    t0 = time.perf_counter()
+    t.start()
+    c = f._ctl_poll(2, 4, 7, patience=5.0)
+    t.join()
+    assert time.perf_counter() - t0 >= 0.02
+    assert c[1, 15] == 7.0 and c[1, 0] == 0.125 and c[1, 4] == 0.0

@@ -36,3 +36,27 @@ def test_elected_sums_match_the_host_over_many_launches(n_blocks, n_vals):
     for i in range(launches):
         assert res[i, n_vals] == 1.0, "launch %d: %g workgroups were elected" % (i, res[i, n_vals])
         np.testing.assert_array_equal(res[i, :n_vals], expected(n_blocks, n_vals, 1000 + i), "launch %d" % i)
+
+
+def test_add_cols_plus_is_add_cols_followed_by_the_sum():
+    """nlbac_add_cols_plus (SimulatedCars: the three gradients w.r.t. x_t+1 in one launch) == nlbac_add_cols followed by
+    nlbac_axpby(1, dst, 1, add), bit for bit."""
+    import torch
+    from nlbac_amd import _lib
+    from nlbac_amd.arena import stream_ptr
+    g = torch.Generator().manual_seed(3)
+    n, ld, B = 2 * 777, 10, 777
+    dst = torch.randn(n, ld, generator=g).cuda()
+    src = torch.randn(B, 4, generator=g).cuda()
+    add = torch.randn(n, ld, generator=g).cuda()
+    a, b = dst.clone(), dst.clone()
+    s = stream_ptr()
+    _lib.call("nlbac_add_cols", a.data_ptr(), ld, 4, src.data_ptr(), 4, 4, B, s)
+    _lib.call("nlbac_axpby", 1.0, a.data_ptr(), 1.0, add.data_ptr(), n * ld, a.data_ptr(), s)
+    _lib.call("nlbac_add_cols_plus", b.data_ptr(), ld, 4, src.data_ptr(), 4, 4, B, add.data_ptr(), n, s)
+    torch.cuda.synchronize()
+    assert torch.equal(a, b)
+    ref = dst.clone()
+    ref[:B, 4:8] += src
+    ref += add
+    assert torch.equal(b, ref)

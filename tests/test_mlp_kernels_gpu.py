@@ -518,3 +518,61 @@ def test_weight_gradient_paths_can_alternate_on_one_gradient_buffer():
         for l, lin in enumerate(lins):
             vec_close(ar.grad_view(lin.weight).cpu(), grads_ref[l][0], TOL, "call %d dW%d" % (it, l))
             vec_close(ar.grad_view(lin.bias).cpu(), grads_ref[l][1], TOL, "call %d db%d" % (it, l))
+
+
+@pytest.mark.parametrize("B,hid", [(4096, 256), (100, 256), (1000, 128)])
+def test_layer0_dz_rows_are_not_stored_when_their_gradients_travel_as_partial_sums(B, hid):
+    """``nlbac_mlp_io::dz_first = 1`` with ``skinny_ws`` (3-layer heads on the quarter-panel kernels): the data backward
+    leaves layer 0's weight / bias gradients as partial sums and does not write its dz rows — the weight backward reads
+    dz from layer 1 on — so every gradient is bit-identical to the run that stores them, and the rows stay untouched."""
+    from nlbac_amd import _lib, arena as A
+    in_dim, out_dim = 9, 1
+    torch.manual_seed(B + hid)
+    mods = [[nn.Linear(in_dim, hid), nn.Linear(hid, hid), nn.Linear(hid, out_dim)] for _ in range(2)]
+    ar = A.Arena("cuda", n_slabs=4)
+    hs = [A.MlpHandle(ar, [(l.weight, l.bias) for l in m]) for m in mods]
+    ar.finalize()
+    for h in hs:
+        h.bind()
+    A.pack(hs)
+    nets = A.mlp_array([h.desc for h in hs])
+    s = A.stream_ptr()
+    keep, out = [], []
+    for first in (0, 1):
+        io = A.io_array(2)
+        dzs = []
+        for i in range(2):
+            x = torch.randn(B, in_dim, generator=torch.Generator().manual_seed(10 + i)).cuda()
+            dy = torch.randn(B, out_dim, generator=torch.Generator().manual_seed(20 + i)).cuda()
+            y, acts = torch.empty(B, out_dim, device="cuda"), torch.empty(2, B, hid, device="cuda")
+            dz = torch.full((2, B, hid), float("nan"), device="cuda")
+            dx = torch.empty(B, in_dim, device="cuda")
+            keep += [x, dy, y, acts, dz, dx]
+            dzs.append(dz)
+            io[i].x0, io[i].x0_dim, io[i].x0_ld = x.data_ptr(), in_dim, in_dim
+            io[i].y, io[i].y_ld = y.data_ptr(), out_dim
+            io[i].acts, io[i].dz = acts.data_ptr(), dz.data_ptr()
+            io[i].dy, io[i].dy_ld = dy.data_ptr(), out_dim
+            io[i].dx, io[i].dx_ld = dx.data_ptr(), in_dim
+            io[i].grad = ar.grad.data_ptr()
+        ws = A.skinny_partials_ws(nets, (io,), 2, B, "cuda")
+        assert ws is not None
+        for i in range(2):
+            io[i].dz_first = first
+        ar.grad.fill_(float("nan"))
+        _lib.call("nlbac_mlp_fwd", nets, io, 2, B, s)
+        _lib.call("nlbac_mlp_bwd_data", nets, io, 2, B, s)
+        A.bwd_weights(nets, io, 2, B, ar.n_slabs, ar.n, "cuda", ws=ws)
+        torch.cuda.synchronize()
+        keep.append(ws)
+        out.append((ar.grad.clone(), [d.clone() for d in dzs], dx.clone()))
+    (g0, dz0, dx0), (g1, dz1, dx1) = out
+    assert torch.equal(torch.nan_to_num(g0), torch.nan_to_num(g1)) and torch.equal(torch.isnan(g0), torch.isnan(g1))
+    assert torch.equal(dx0, dx1)
+    for a, b in zip(dz0, dz1):
+        assert torch.isfinite(a).all() and torch.equal(a[1], b[1])
+        assert torch.isnan(b[0]).all(), "layer 0's dz rows were written although dz_first = 1"
+    # without the partial sums the weight backward needs those rows: it must refuse
+    io[0].skinny_ws = None
+    with pytest.raises(_lib.NlbacError):
+        A.bwd_weights(nets, io, 2, B, ar.n_slabs, ar.n, "cuda")
