@@ -228,6 +228,9 @@ __device__ __forceinline__ void dy_head_rows(const nlbac_dy_head& H, int inet, i
 template <int TILE = NLBAC_MLP_TILE>
 __device__ __forceinline__ void dy_head_finish(const nlbac_dy_head& H, int inet, int row0, int n_tiles, float* red, int n_nets,
                                                const DyHeadPending& pend) {
+#ifdef EXP_NO_DY_FINISH       /* ablation (timing only: the batch sums are not formed): what the elections cost a launch */
+    return;
+#endif
     const int tid = threadIdx.x;
     const int tile = row0 / TILE;
     if (H.kind == 2) {
