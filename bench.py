@@ -430,10 +430,15 @@ def main():
         fence()
         stats0 = dict(agent.node_solver.stats)
         t0 = time.perf_counter()
+        marks = []
         for i in range(steps):
             ret = step(warmup + i)
+            marks.append(time.perf_counter())       # (the step has returned its six floats: the host clock, no extra sync)
         fence()
         elapsed = max_over_ranks(time.perf_counter() - t0)
+        if os.environ.get("NLBAC_BENCH_STEP_TIMES") == "1" and rank == 0:
+            log("per-step ms (host clock at each step's return): " +
+                " ".join("%.3f" % (1e3 * (b - a)) for a, b in zip([t0] + marks[:-1], marks)))
         stats = {k: v - stats0.get(k, 0) for k, v in agent.node_solver.stats.items()}      # of the timed region alone
         stats["node_fits"] = sum(1 for i in range(steps) if (warmup + i) % NODE_FIT_INTERVAL == 0)
         res = dict(agent=agent, B=B, global_B=global_B, elapsed=elapsed, value=global_B * steps / elapsed,
