@@ -47,6 +47,7 @@ class _Task:
         """Pre-allocate a solver's buffers for (n rows, P problems, the agent's current method) once."""
         if not self.agent.fold_launches:
             solver.interp_fold = False        # (NLBAC_FOLD=0: the interpolation launches too, as every other folded step)
+            solver.norm_defer = False         # ... and the norms with their elections / as a launch over the error rows
         key = (id(solver), n, P, self.agent.solver)
         seen = self.__dict__.setdefault("_reserved", set())
         if key not in seen:

@@ -288,7 +288,9 @@ def test_folded_launches_match_the_launches_they_replace(env_name, solver):
     written to pinned memory by the kernels) against the same update with every step as the launch of its own
     (``fold_launches = False``): identical row arithmetic, so the per-row outputs left in memory are bit-identical on the
     first update (up to the contraction of the look-ahead map's multiply-adds); the batch sums are taken in a different order (per 32-row tile instead of per 256-row block), so the
-    losses, the temperatures' gradient and — through it — the parameters agree to rounding."""
+    losses, the temperatures' gradient and — through it — the parameters agree to rounding.  With the folds off the dopri5
+    solves also run their norms the classical way (fused with an election for f0 / the probe, a launch over the error
+    rows for an attempt: ``solver.norm_defer = False``, tasks.reserve) and their interpolation as launches."""
     B, hidden, seed = 256, 256, 0
     gamma_b = {"Unicycle": 50.0, "Pvtol": 0.8, "UnicycleBarrier": 5.0}[env_name]
     fields = synth.fields(env_name)
