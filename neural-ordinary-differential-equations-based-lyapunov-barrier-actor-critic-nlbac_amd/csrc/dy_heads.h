@@ -228,8 +228,11 @@ __device__ __forceinline__ void dy_head_rows(const nlbac_dy_head& H, int inet, i
 template <int TILE = NLBAC_MLP_TILE>
 __device__ __forceinline__ void dy_head_finish(const nlbac_dy_head& H, int inet, int row0, int n_tiles, float* red, int n_nets,
                                                const DyHeadPending& pend) {
-#ifdef EXP_NO_DY_FINISH       /* ablation (timing only: the batch sums are not formed): what the elections cost a launch */
-    return;
+#ifdef EXP_NO_DY_FINISH       /* ablation (timing only: the batch sums are not formed; 1: none, 2 / 3: not that kind's): what
+                                 the elections cost the update — kind 2 (critic losses) 5.2 us, kind 3 (alpha terms) 4.3 us of
+                                 550 at B = 4096, MI355X; summing the tile partials in the optimiser launch instead would
+                                 give back about two thirds of that */
+    if (EXP_NO_DY_FINISH == 1 || EXP_NO_DY_FINISH == H.kind) return;
 #endif
     const int tid = threadIdx.x;
     const int tile = row0 / TILE;
