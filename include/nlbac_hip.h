@@ -32,7 +32,7 @@
 extern "C" {
 #endif
 
-#define NLBAC_ABI_VERSION 14 /* bumped whenever an exported signature or struct changes; nlbac_abi_version() returns it */
+#define NLBAC_ABI_VERSION 15 /* bumped whenever an exported signature or struct changes; nlbac_abi_version() returns it */
 #define NLBAC_MAX_LAYERS 6
 #define NLBAC_MAX_NETS 8
 #define NLBAC_MLP_TILE 32 /* samples per workgroup in the MLP kernels */
@@ -266,6 +266,18 @@ int nlbac_actor_q_terms(const float *q1, const float *q2, const float *logp, con
  * partials: n_nets * n_tiles (kind 2) / 2 * n_prob * n_tiles (kind 3) floats, n_tiles = ceil(B / 16) (the finest tile
  * of the kernels that serve the launch); ticket: 1 + ceil(n / 16) zeroed uint32 for the n = n_nets * n_tiles (kind 2) /
  * n_prob * n_tiles (kind 3) workgroups that take part in the two-level election, left zeroed. */
+/* ABI 15 — the batch sums of a kind-2 / kind-3 head without the election that ends their launch: the head's workgroups
+ * only leave their tile partials (nlbac_dy_head::sums_defer), and a LATER data-backward launch finishes them as a job of
+ * one of its workgroups (nlbac_dy_head::finish[j]: workgroup (tile j, net 0) after its own work) — the same sums in the
+ * same order, the same outputs (kind 2: out[0..2] (, out_x[0]); kind 3: nlbac_actor_scalars via `actor`). */
+typedef struct nlbac_head_sums {
+    int kind;                  /* 0: no job; 2 / 3: the kind of the head whose partials these are */
+    int n_nets;                /* kind 2: the nets of that launch (3 or 4); kind 3: its n_prob */
+    const float *partials;     /* that head's `partials` */
+    const unsigned *n_tiles;   /* that head's `sums_tiles`: the tile count of the kernel that served it */
+    float mul; float *out; float *out_x;           /* kind 2 */
+    int B_norm; nlbac_actor_scalar_args actor;      /* kind 3 */
+} nlbac_head_sums;
 typedef struct nlbac_dy_head {
     int kind, B_norm;
     /* 1 */
@@ -292,6 +304,11 @@ typedef struct nlbac_dy_head {
     const float *cb_ps_next, *cb_matr, *cb_bmatr, *cb_hazards, *cb_sc;
     float cb_dt, cb_batch;
     float *cb_dps_next, *cb_dV;
+    /* ABI 15 (see nlbac_head_sums).  sums_defer != 0 (kinds 2, 3): partial sums only — plain stores, `ticket` unused —
+     * and the launch's tile count in sums_tiles[0]; finish[j].kind != 0 (any kind of head): this launch finishes the
+     * partials an EARLIER launch on the stream left. */
+    int sums_defer; unsigned *sums_tiles;
+    nlbac_head_sums finish[2];
 } nlbac_dy_head;
 /* policy_loss_1, alpha_loss into sc; d alpha_loss / d log_alpha into g_log_alpha
  * (sac_cbf_clf.py:292-308) for problems first_problem .. first_problem+P-1 (0 primary, 1 backup);

@@ -225,50 +225,90 @@ __device__ __forceinline__ void dy_head_rows(const nlbac_dy_head& H, int inet, i
 // The launch-wide half of a dy head: every designated workgroup publishes its tile's sums, the last one to arrive
 // finishes the batch quantities (publish_and_elect, common.h).  All 256 threads; `red`: >= 16 floats of LDS scratch that
 // nothing else uses until the call returns.
+// The batch sums of a kind-2 / kind-3 head from its tile partials: what the elected workgroup of the head's own launch
+// does, or — nlbac_dy_head::sums_defer — a workgroup of a later launch (dy_head_jobs).  All 256 threads.
+__device__ __forceinline__ void head_sums_finish(const nlbac_head_sums& J, int n_tiles, float* red) {
+    const int tid = threadIdx.x;
+    if (J.kind == 2) {
+        float s[3];
+        elected_tile_sums<3>(J.partials, n_tiles, J.n_nets, s, red);
+        if (tid < 3) J.out[tid] = s[tid] * J.mul;
+        if (J.n_nets == 4) {
+            float sx[1];
+            elected_tile_sums<1>(J.partials + 3, n_tiles, 4, sx, red);
+            if (tid == 0) J.out_x[0] = sx[0] * J.mul;
+        }
+    } else if (J.kind == 3) {
+        for (int pp = 0; pp < J.n_nets; ++pp) {
+            float s[2];
+            elected_tile_sums<2>(J.partials + (long)pp * n_tiles * 2, n_tiles, 2, s, red);
+            if (tid == 0)
+                actor_scalars_one(s[0], s[1], pp, J.B_norm, J.actor.target_entropy, J.actor.log_alpha[pp],
+                                  J.actor.g_log_alpha[pp], J.actor.sc);
+        }
+    }
+}
+
 template <int TILE = NLBAC_MLP_TILE>
 __device__ __forceinline__ void dy_head_finish(const nlbac_dy_head& H, int inet, int row0, int n_tiles, float* red, int n_nets,
                                                const DyHeadPending& pend) {
 #ifdef EXP_NO_DY_FINISH       /* ablation (timing only: the batch sums are not formed; 1: none, 2 / 3: not that kind's): what
                                  the elections cost the update — kind 2 (critic losses) 5.2 us, kind 3 (alpha terms) 4.3 us of
-                                 550 at B = 4096, MI355X; summing the tile partials in the optimiser launch instead would
-                                 give back about two thirds of that */
+                                 550 at B = 4096, MI355X */
     if (EXP_NO_DY_FINISH == 1 || EXP_NO_DY_FINISH == H.kind) return;
 #endif
     const int tid = threadIdx.x;
     const int tile = row0 / TILE;
     if (H.kind == 2) {
         // every net's workgroup publishes its own squared-error sum of the tile; the last of the n_nets * n_tiles
-        // workgroups finishes the losses
+        // workgroups finishes the losses — or (sums_defer) a workgroup of a later launch does
+        if (H.sums_defer) {
+            if (tid == 0) {
+                H.partials[(long)tile * n_nets + inet] = pend.v0;
+                if (tile == 0 && inet == 0) H.sums_tiles[0] = (unsigned)n_tiles;
+            }
+            return;
+        }
         const float v1[1] = {pend.v0};
         if (publish_and_elect_grouped<1>(H.partials + (long)tile * n_nets + inet, v1, H.ticket, (unsigned)(tile * n_nets + inet),
                                          (unsigned)(n_nets * n_tiles))) {
-            float s[3];
-            elected_tile_sums<3>(H.partials, n_tiles, n_nets, s, red);
-            if (tid < 3) H.out[tid] = s[tid] * H.mul;
-            if (n_nets == 4) {
-                float sx[1];
-                elected_tile_sums<1>(H.partials + 3, n_tiles, 4, sx, red);
-                if (tid == 0) H.out_x[0] = sx[0] * H.mul;
-            }
+            nlbac_head_sums J;
+            J.kind = 2; J.n_nets = n_nets; J.partials = H.partials; J.mul = H.mul; J.out = H.out; J.out_x = H.out_x;
+            head_sums_finish(J, n_tiles, red);
         }
     } else if (H.kind == 3) {
         // the Q1 workgroups publish the tile's sums of (alpha logp - min q, logp); the last of them finishes
         // policy_loss_1 / alpha loss / d log_alpha of every controller (actor_scalars_one)
         const int p = inet >> 1, which = inet & 1, n_prob = H.n_prob;
         if (which == 0 && inet < 2 * n_prob) {        // (the net behind the Q pairs — cb_kind — has no batch sums)
+            if (H.sums_defer) {
+                if (tid == 0) {
+                    float* q = H.partials + ((long)p * n_tiles + tile) * 2;
+                    q[0] = pend.v0; q[1] = pend.v1;
+                    if (tile == 0 && inet == 0) H.sums_tiles[0] = (unsigned)n_tiles;
+                }
+                return;
+            }
             const float v2[2] = {pend.v0, pend.v1};
             if (publish_and_elect_grouped<2>(H.partials + ((long)p * n_tiles + tile) * 2, v2, H.ticket, (unsigned)(p * n_tiles + tile),
                                              (unsigned)(n_prob * n_tiles))) {
-                for (int pp = 0; pp < n_prob; ++pp) {
-                    float s[2];
-                    elected_tile_sums<2>(H.partials + (long)pp * n_tiles * 2, n_tiles, 2, s, red);
-                    if (tid == 0)
-                        actor_scalars_one(s[0], s[1], pp, H.B_norm, H.actor.target_entropy, H.actor.log_alpha[pp],
-                                          H.actor.g_log_alpha[pp], H.actor.sc);
-                }
+                nlbac_head_sums J;
+                J.kind = 3; J.n_nets = n_prob; J.partials = H.partials; J.B_norm = H.B_norm; J.actor = H.actor;
+                head_sums_finish(J, n_tiles, red);
             }
         }
     }
+}
+
+// nlbac_dy_head::finish: the sums an earlier launch deferred, by workgroup (tile j, net 0) of this one.  Every thread of
+// every workgroup calls it at the END of the kernel (contains a barrier for the workgroups that have a job; uniform).
+__device__ __forceinline__ void dy_head_jobs(const nlbac_dy_head& H, int tile, int inet, int n_tiles_launch, float* red) {
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+        if (H.finish[j].kind != 0 && inet == 0 && tile == (j < n_tiles_launch ? j : 0)) {
+            __syncthreads();                            // (red is free: every earlier use of the scratch is done)
+            head_sums_finish(H.finish[j], (int)H.finish[j].n_tiles[0], red);
+        }
 }
 
 __device__ __forceinline__ void dy_head_fill(const nlbac_dy_head& H, int inet, int row0, int B, int n_tiles, float* sdy,

@@ -431,6 +431,8 @@ __global__ __launch_bounds__(256, 2) void mlp_bwd_data_kernel(const MlpLaunch L,
             }
         }
     }
+    // ---- batch sums an earlier launch's head left to this one (nlbac_dy_head::finish)
+    dy_head_jobs(H, (int)blockIdx.x, (int)blockIdx.y, (int)gridDim.x, sx);
 }
 
 // ---------------------------------------------------------------------------
@@ -1195,6 +1197,17 @@ extern "C" int nlbac_mlp_bwd_data_head(const nlbac_mlp* nets, const nlbac_mlp_io
                               H.cb_dt > 0.f && H.cb_batch > 0.f,
                           "%s: actor head: the constraint backward (cb_kind 1) needs a scalar net behind the Q pairs and all of its pointers", who);
         }
+    }
+    NLBAC_REQUIRE(!H.sums_defer || ((H.kind == 2 || H.kind == 3) && H.sums_tiles), "%s: sums_defer goes with kind 2 / 3 and sums_tiles", who);
+    for (int j = 0; j < 2; ++j) {
+        const nlbac_head_sums& J = H.finish[j];
+        if (!J.kind) continue;
+        NLBAC_REQUIRE((J.kind == 2 || J.kind == 3) && J.partials && J.n_tiles, "%s: finish[%d]: kind 2 / 3 with partials and n_tiles", who, j);
+        NLBAC_REQUIRE(J.kind != 2 || ((J.n_nets == 3 || J.n_nets == 4) && J.out && (J.n_nets == 3 || J.out_x)), "%s: finish[%d]: td sums need out (and out_x with 4 nets)", who, j);
+        NLBAC_REQUIRE(J.kind != 3 || (J.n_nets >= 1 && J.n_nets <= 2 && J.B_norm >= 1 && J.actor.sc), "%s: finish[%d]: actor sums need n_prob, B_norm and the scalars block", who, j);
+        if (J.kind == 3)
+            for (int p = 0; p < J.n_nets; ++p)
+                NLBAC_REQUIRE(J.actor.log_alpha[p] && J.actor.g_log_alpha[p], "%s: finish[%d]: missing log_alpha pointers", who, j);
     }
     return mlp_bwd_data_launch(nets, io, n_nets, B, H, who, s);
 }

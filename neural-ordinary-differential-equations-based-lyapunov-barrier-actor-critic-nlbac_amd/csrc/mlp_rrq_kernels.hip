@@ -487,6 +487,8 @@ __global__ __launch_bounds__(256, 3) void mlp_rrq_bwd_kernel(const MlpLaunch L, 
         __syncthreads();                           // (sx is the election's scratch: every read of it above is done)
         dy_head_finish<QT>(H, blockIdx.y, row0, gridDim.x, sx, gridDim.y, pend);
     }
+    // ---- batch sums an earlier launch's head left to this one (nlbac_dy_head::finish)
+    dy_head_jobs(H, (int)blockIdx.x, (int)blockIdx.y, (int)gridDim.x, sx);
 }
 
 // ---------------------------------------------------------------------------------------------------------------------

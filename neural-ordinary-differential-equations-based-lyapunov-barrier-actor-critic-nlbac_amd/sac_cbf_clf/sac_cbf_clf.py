@@ -94,6 +94,7 @@ class _Workspace:
         # tickets of the heads' two-level elections: 1 + ceil(workgroups / 16) words each (TD head: <= 4 nets; actor head)
         self.tickets_td = torch.zeros(2 + self.n_tiles * 4 // 16 + 1, dtype=torch.int32, device=dev)
         self.tickets_q = torch.zeros(2 + self.n_tiles * NP // 16 + 1, dtype=torch.int32, device=dev)
+        self.sums_tiles = torch.zeros(4, dtype=torch.int32, device=dev)    # nlbac_dy_head::sums_tiles of the td / actor-q heads
         self.part_tdx = z(max(NX, 1), self.nblk)
         self.heads2, self.pi2, self.logp2 = self.heads3[B:], self.act3[B:], self.logp3[B:]
         self.acts_p = z(NP, 2, B, H)
@@ -976,6 +977,10 @@ class SAC_CBF_CLF(object):
                 H.next_q, H.next_l = ws.next_q.data_ptr(), ws.next_l.data_ptr()
                 H.partials, H.ticket = ws.part_td32.data_ptr(), ws.tickets_td.data_ptr()
                 H.mul, H.out = 1.0 / G, sc + 4 * SC.SC_QF1
+                if self._sums_defer():
+                    # no election at the end of this launch: its tiles leave their squared-error sums, a workgroup of
+                    # the actors' data backward (the last MLP launch of the update) adds them up (nlbac_head_sums)
+                    H.sums_defer, H.sums_tiles = 1, ws.sums_tiles.data_ptr()
                 if self.h_extra:        # BarrierNet TD step (NU/sac_cbf_clf.py:224-233): the launch's 4th net
                     H.xt, H.xq, H.dxq = q[6].data_ptr(), q[7].data_ptr(), ws.dq3[3].data_ptr()
                     H.xsig, H.xsig_ld = ws.mb.data_ptr() + 4 * self.lay.sig, LD
@@ -1042,7 +1047,19 @@ class SAC_CBF_CLF(object):
                     H.actor.log_alpha[g.first + k] = g.arena.theta.data_ptr() + 4 * off
                     H.actor.g_log_alpha[g.first + k] = g.arena.grad.data_ptr() + 4 * off
             H.partials, H.ticket = ws.part_q32.data_ptr(), ws.tickets_q.data_ptr()
+            if self._sums_defer():
+                H.sums_defer, H.sums_tiles = 1, ws.sums_tiles.data_ptr() + 4      # (as the td head's, see _part1_targets)
         return H
+
+    def _sums_defer(self):
+        """The batch sums of the td / actor-q dy heads are finished by a workgroup of the actors' data backward instead of
+        by an election at the end of their own launches (nlbac_dy_head::sums_defer / finish): single GPU with the launch
+        folds (the heads exist and the actors' backward follows them in every update).  ``sums_defer = False``
+        (NLBAC_SUMS_DEFER=0): the elections."""
+        on = self.__dict__.get("sums_defer")
+        if on is None:
+            on = self.sums_defer = os.environ.get("NLBAC_SUMS_DEFER", "1") != "0"
+        return bool(on and self.world == 1 and self.fold_launches)
 
     def _upd_part2(self, ws, lam_upd, assume_single):
         """Constraints, augmented-Lagrangian scalars, the whole actor backward and the actor Adam step."""
@@ -1082,6 +1099,20 @@ class SAC_CBF_CLF(object):
             H.da[1], H.da_ld[1] = ws.dxq[1].data_ptr() + 4 * Do, D
             H.alpha, H.dlogp_mul = sc + 4 * SC.SC_ALPHA, 1.0 / G
             H.dheads, H.dheads_ld = ws.dheads2.data_ptr(), 2 * A
+            # the sums the td head and the actor-q head of this update left as tile partials (sums_defer): two workgroups
+            # of this launch finish them — before the Adam step that reads d log_alpha and mirrors the losses
+            J = 0
+            for src in (P.__dict__.get("head_td"), P.__dict__.get("head_actor_q")):
+                if src is None or not src.sums_defer:
+                    continue
+                F = H.finish[J]
+                F.kind, F.partials, F.n_tiles = src.kind, src.partials, src.sums_tiles
+                if src.kind == 2:
+                    F.n_nets, F.mul, F.out, F.out_x = len(self.h_crit), src.mul, src.out, src.out_x
+                else:
+                    F.n_nets, F.B_norm = src.n_prob, src.B_norm
+                    C.memmove(C.byref(F.actor), C.byref(src.actor), C.sizeof(_lib.ActorScalarArgs))
+                J += 1
         if H is not False:
             H.da[2], H.da_ld[2] = du2.data_ptr(), du_ld
             call("nlbac_mlp_bwd_data_head", P.n_act, P.io_act, NP, B, C.byref(H), s)

@@ -281,6 +281,36 @@ def test_hipgraph_replay_is_bit_identical_to_eager(solver):
     assert torch.equal(a0.sc, a1.sc)
 
 
+@pytest.mark.parametrize("env_name,B", [("Unicycle", 256), ("Unicycle", 8), ("UnicycleBarrier", 128), ("Pvtol", 128)])
+def test_deferred_head_sums_match_the_elections(env_name, B):
+    """nlbac_dy_head::sums_defer / finish (the td head's and the actor-q head's batch sums finished by two workgroups of
+    the actors' data backward instead of by elections at the end of their own launches): the same tile partials summed
+    in the same order, so the returned losses, the temperatures' gradient and every parameter match bit for bit —
+    B = 8: one 16-row tile, both jobs on the launch's only tile; UnicycleBarrier: four critic nets (out_x)."""
+    hidden, seed = 256, 0
+    gamma_b = {"Unicycle": 50.0, "Pvtol": 0.8, "UnicycleBarrier": 5.0}[env_name]
+    fields = synth.fields(env_name)
+    runs = []
+    for defer in (True, False):
+        agent, env = make_agent(B, hidden, seed, "euler", env_name, gamma_b)
+        agent.sums_defer = defer
+        tr = synth.transitions(env_name, 4096, seed=3, env=env)
+        rs = np.random.RandomState(5)
+        rets = []
+        for updates in range(4):
+            idx = rs.choice(4096, B, replace=False)
+            agent.set_noise(synth.normal_eps(agent.task.n_eps, B, env.n_u, seed=updates))
+            rets.append(agent.update_from_host(tuple(tr[f][idx] for f in fields), updates + 1, None))
+        torch.cuda.synchronize()
+        runs.append((agent, rets))
+    (a0, r0), (a1, r1) = runs
+    np.testing.assert_array_equal(np.array(r0), np.array(r1))
+    for x, y in zip(a0.arenas, a1.arenas):
+        assert torch.equal(x.theta, y.theta) and torch.equal(x.m, y.m)
+    assert torch.equal(a0.sc, a1.sc)
+    assert int(a0._ws[B].sums_tiles[0]) > 0 and int(a1._ws[B].sums_tiles[0]) == 0, "the deferred form was not the one that ran"
+
+
 @pytest.mark.parametrize("env_name,solver", [("Unicycle", "dopri5"), ("Unicycle", "euler"), ("Pvtol", "dopri5"),
                                              ("UnicycleBarrier", "dopri5")])
 def test_folded_launches_match_the_launches_they_replace(env_name, solver):
