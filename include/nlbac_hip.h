@@ -32,7 +32,7 @@
 extern "C" {
 #endif
 
-#define NLBAC_ABI_VERSION 15 /* bumped whenever an exported signature or struct changes; nlbac_abi_version() returns it */
+#define NLBAC_ABI_VERSION 16 /* bumped whenever an exported signature or struct changes; nlbac_abi_version() returns it */
 #define NLBAC_MAX_LAYERS 6
 #define NLBAC_MAX_NETS 8
 #define NLBAC_MLP_TILE 32 /* samples per workgroup in the MLP kernels */
@@ -145,6 +145,10 @@ typedef struct nlbac_gauss_head {
     int cf_n_cbf, cf_n_clf; float cf_batch_size; int cf_do_lambda_update, cf_do_backup_lambda_update, cf_ratio_mode, cf_backup_mode;
     float cf_lam_lo, cf_lam_hi;
     float *cf_sc;
+    /* ABI 16 — cf_defer != 0: no election and no augmented-Lagrangian step in this launch: the tiles' column sums go to
+     * cf_partials as plain stores, the launch's tile count to cf_tiles[0]; the consumers sum them themselves
+     * (nlbac_dy_head::cb_defer; nlbac_head_sums kind 4 commits the step).  cf_tickets is not used. */
+    int cf_defer; unsigned *cf_tiles;
 } nlbac_gauss_head;
 int nlbac_mlp_fwd_gauss(const nlbac_mlp *nets, const nlbac_mlp_io *io, int n_nets, int B,
                         const nlbac_gauss_head *head, nlbac_stream_t s);
@@ -266,17 +270,28 @@ int nlbac_actor_q_terms(const float *q1, const float *q2, const float *logp, con
  * partials: n_nets * n_tiles (kind 2) / 2 * n_prob * n_tiles (kind 3) floats, n_tiles = ceil(B / 16) (the finest tile
  * of the kernels that serve the launch); ticket: 1 + ceil(n / 16) zeroed uint32 for the n = n_nets * n_tiles (kind 2) /
  * n_prob * n_tiles (kind 3) workgroups that take part in the two-level election, left zeroed. */
+typedef struct nlbac_auglag_args { /* nlbac_auglag's scalar arguments */
+    int n_cbf, n_clf;
+    float batch_size;
+    int do_lambda_update, do_backup_lambda_update, ratio_mode, backup_mode;
+    float lam_lo, lam_hi;
+} nlbac_auglag_args;
 /* ABI 15 — the batch sums of a kind-2 / kind-3 head without the election that ends their launch: the head's workgroups
  * only leave their tile partials (nlbac_dy_head::sums_defer), and a LATER data-backward launch finishes them as a job of
  * one of its workgroups (nlbac_dy_head::finish[j]: workgroup (tile j, net 0) after its own work) — the same sums in the
  * same order, the same outputs (kind 2: out[0..2] (, out_x[0]); kind 3: nlbac_actor_scalars via `actor`). */
 typedef struct nlbac_head_sums {
-    int kind;                  /* 0: no job; 2 / 3: the kind of the head whose partials these are */
+    int kind;                  /* 0: no job; 2 / 3: the kind of the head whose partials these are; 4 (ABI 16): commit the
+                                  augmented-Lagrangian step an earlier launch ran on a private copy of the scalars block
+                                  (nlbac_dy_head::cb_defer left it in cb_stage = `partials` here): the entries the step
+                                  changes are copied to `sc` — the one place its new multipliers / rho become visible */
     int n_nets;                /* kind 2: the nets of that launch (3 or 4); kind 3: its n_prob */
     const float *partials;     /* that head's `partials` */
     const unsigned *n_tiles;   /* that head's `sums_tiles`: the tile count of the kernel that served it */
     float mul; float *out; float *out_x;           /* kind 2 */
     int B_norm; nlbac_actor_scalar_args actor;      /* kind 3 */
+    float *sc;                                      /* kind 4 (partials = the staged block, NLBAC scalars-block sized; n_tiles,
+                                                       n_nets unused) */
 } nlbac_head_sums;
 typedef struct nlbac_dy_head {
     int kind, B_norm;
@@ -308,7 +323,14 @@ typedef struct nlbac_dy_head {
      * and the launch's tile count in sums_tiles[0]; finish[j].kind != 0 (any kind of head): this launch finishes the
      * partials an EARLIER launch on the stream left. */
     int sums_defer; unsigned *sums_tiles;
-    nlbac_head_sums finish[2];
+    nlbac_head_sums finish[3];
+    /* ABI 16 — cb_defer != 0 (with cb_kind): the constraint head of the forward launch left its tiles' column sums
+     * (nlbac_gauss_head::cf_defer) and ran no augmented-Lagrangian step: every workgroup of the net behind the Q pairs
+     * sums them (cb_partials, cb_tiles = that head's cf_partials / cf_tiles) and runs nlbac_auglag with cb_auglag on a
+     * PRIVATE copy of the scalars block cb_sc, which this launch only reads; the loss coefficients it needs come from
+     * that copy.  The workgroup of the net's first tile leaves the stepped copy in cb_stage (a scalars-block sized
+     * array); a finish job of kind 4 in a LATER launch commits it to the block. */
+    int cb_defer; const float *cb_partials; const unsigned *cb_tiles; nlbac_auglag_args cb_auglag; float *cb_stage;
 } nlbac_dy_head;
 /* policy_loss_1, alpha_loss into sc; d alpha_loss / d log_alpha into g_log_alpha
  * (sac_cbf_clf.py:292-308) for problems first_problem .. first_problem+P-1 (0 primary, 1 backup);
@@ -332,12 +354,6 @@ int nlbac_unicycle_lookahead_bwd(const float *x, const float *dps, const float *
 /* CBF/CLF terms, relu filter and column partial sums (sac_cbf_clf.py:471-504, 596-621).
  * ps (B,2); ps_next (2B,2): primary rows then backup rows.  matr (B,n_hz+1) and bmatr (B,n_hz)
  * are kept for the backward.  partials [ceil(B/256)][2*n_hz+1]. */
-typedef struct nlbac_auglag_args { /* nlbac_auglag's scalar arguments */
-    int n_cbf, n_clf;
-    float batch_size;
-    int do_lambda_update, do_backup_lambda_update, ratio_mode, backup_mode;
-    float lam_lo, lam_hi;
-} nlbac_auglag_args;
 /* Every *_constraints_fwd takes a trailing (fused, ticket, sc): with fused != NULL (single GPU) its last workgroup
  * runs nlbac_auglag itself on the partial sums of this launch (ticket: a zeroed uint32, left zeroed) — one launch
  * less per update, same arithmetic. */

@@ -71,14 +71,15 @@ class GaussHead(C.Structure):
                 ("cf_matr", C.c_void_p), ("cf_bmatr", C.c_void_p), ("cf_partials", C.c_void_p), ("cf_tickets", C.c_void_p),
                 ("cf_n_cbf", C.c_int), ("cf_n_clf", C.c_int), ("cf_batch_size", C.c_float),
                 ("cf_do_lambda_update", C.c_int), ("cf_do_backup_lambda_update", C.c_int), ("cf_ratio_mode", C.c_int),
-                ("cf_backup_mode", C.c_int), ("cf_lam_lo", C.c_float), ("cf_lam_hi", C.c_float), ("cf_sc", C.c_void_p)]
+                ("cf_backup_mode", C.c_int), ("cf_lam_lo", C.c_float), ("cf_lam_hi", C.c_float), ("cf_sc", C.c_void_p),
+                ("cf_defer", C.c_int), ("cf_tiles", C.c_void_p)]
 
 
 class HeadSums(C.Structure):
     """``struct nlbac_head_sums``"""
     _fields_ = [("kind", C.c_int), ("n_nets", C.c_int), ("partials", C.c_void_p), ("n_tiles", C.c_void_p),
                 ("mul", C.c_float), ("out", C.c_void_p), ("out_x", C.c_void_p), ("B_norm", C.c_int),
-                ("actor", ActorScalarArgs)]
+                ("actor", ActorScalarArgs), ("sc", C.c_void_p)]
 
 
 class DyHead(C.Structure):
@@ -99,7 +100,9 @@ class DyHead(C.Structure):
                 ("cb_kind", C.c_int), ("cb_nh", C.c_int), ("cb_ps_next", C.c_void_p), ("cb_matr", C.c_void_p),
                 ("cb_bmatr", C.c_void_p), ("cb_hazards", C.c_void_p), ("cb_sc", C.c_void_p), ("cb_dt", C.c_float),
                 ("cb_batch", C.c_float), ("cb_dps_next", C.c_void_p), ("cb_dV", C.c_void_p),
-                ("sums_defer", C.c_int), ("sums_tiles", C.c_void_p), ("finish", HeadSums * 2)]
+                ("sums_defer", C.c_int), ("sums_tiles", C.c_void_p), ("finish", HeadSums * 3),
+                ("cb_defer", C.c_int), ("cb_partials", C.c_void_p), ("cb_tiles", C.c_void_p), ("cb_auglag", AuglagArgs),
+                ("cb_stage", C.c_void_p)]
 
 
 class RkChain(C.Structure):
@@ -248,7 +251,7 @@ def build(verbose=False):
     return LIB_PATH
 
 
-ABI_VERSION = 15      # == NLBAC_ABI_VERSION of include/nlbac_hip.h (bumped with every signature / struct change)
+ABI_VERSION = 16      # == NLBAC_ABI_VERSION of include/nlbac_hip.h (bumped with every signature / struct change)
 
 
 def _stale_sources():

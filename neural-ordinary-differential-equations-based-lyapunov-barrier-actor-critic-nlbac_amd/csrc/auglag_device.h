@@ -17,7 +17,7 @@ struct AuglagArgs {        // nlbac_auglag's scalar arguments, by value (nlbac_a
 // required_matrix sums, ratio, lambda / rho updates and loss coefficients (sac_cbf_clf.py:502-528, 623-638) by ONE
 // workgroup: the stand-alone nlbac_auglag launch, or the last workgroup of a constraints_fwd launch (COHERENT: the
 // partials were published by other workgroups of the same launch).
-__device__ __forceinline__ void auglag_finish_at(const AuglagArgs A, float* sc_global, float* sc);
+__device__ __forceinline__ void auglag_finish_at(const AuglagArgs A, float* sc_global, float* sc, bool write_back = true);
 
 // sc: NLBAC_SC_SIZE_ENUM floats of LDS (8-byte aligned), stage: stage_cap floats of LDS (>= one block's columns) — scratch
 // of the calling workgroup, free for the duration of the call.  All threads of the workgroup call it.
@@ -62,7 +62,9 @@ __device__ __forceinline__ void auglag_body_at(const float* partials, int n_blk,
 // The second half: the scalar bookkeeping on required sums that are already in the LDS copy `sc` of the scalars block
 // (sc[SC_REQ + c], sc[SC_BREQ + c], divided by the batch size), and the write-back.  All threads; starts at a point where
 // every thread's writes to `sc` are complete (the caller's barrier).
-__device__ __forceinline__ void auglag_finish_at(const AuglagArgs A, float* sc_global, float* sc) {
+// write_back = false: the step stays in the LDS copy (a workgroup that only needs the step's coefficients, while another
+// launch commits it: nlbac_dy_head::cb_defer).
+__device__ __forceinline__ void auglag_finish_at(const AuglagArgs A, float* sc_global, float* sc, bool write_back) {
     const int n_cbf = A.n_cbf, n_clf = A.n_clf, ratio_mode = A.ratio_mode, backup_mode = A.backup_mode;
     const int do_lambda_update = A.do_lambda_update, do_backup_lambda_update = A.do_backup_lambda_update;
     const float lam_lo = A.lam_lo, lam_hi = A.lam_hi;
@@ -127,8 +129,40 @@ __device__ __forceinline__ void auglag_finish_at(const AuglagArgs A, float* sc_g
     }
     }
     __syncthreads();
+    if (!write_back) return;
     // what the step may have changed: ratio / losses (4..6), multipliers, coefficients, required sums, rho (16..115)
     for (int t = threadIdx.x; t < NLBAC_SC_SIZE_ENUM; t += blockDim.x)
         if ((t >= SC_RATIO && t <= SC_BPL2) || (t >= SC_LAMBDA && t < SC_MEAN_LOGP)) sc_global[t] = sc[t];
+}
+
+// The step on the per-TILE column sums a constraint head left (mlp_rrq_kernels.hip; NC columns = n_cbf + n_clf + n_cbf):
+// the scalars block into the LDS copy `scl` (NLBAC_SC_SIZE_ENUM floats), every thread sums the tiles t, t + 256, ... of
+// all columns, a fixed tree over the workgroup (red: 4 * NC floats) — whichever workgroup runs it, the same sums —, then
+// the bookkeeping.  COHERENT: the sums were published by other workgroups of this launch.  All 256 threads.
+template <int NC, bool COHERENT>
+__device__ __forceinline__ void auglag_from_tiles(const float* partials, unsigned n_tiles, const AuglagArgs A,
+                                                  float* sc_global, float* scl, float* red, bool write_back) {
+    const int tid = threadIdx.x;
+    for (int t = tid; t < NLBAC_SC_SIZE_ENUM; t += 256) scl[t] = sc_global[t];
+    float v[NC];
+#pragma unroll
+    for (int c = 0; c < NC; ++c) v[c] = 0.f;
+    for (unsigned b = tid; b < n_tiles; b += 256)
+#pragma unroll
+        for (int c = 0; c < NC; ++c) {
+            const float* q = partials + (long)b * NC + c;
+            v[c] += COHERENT ? coherent_load(q) : *q;
+        }
+    block_sum_256<NC>(v, red);
+    const int nc = A.n_cbf + A.n_clf;
+    if (tid == 0) {
+#pragma unroll
+        for (int c = 0; c < NC; ++c) {
+            const float sv = v[c] / A.batch_size;
+            if (c < nc) scl[SC_REQ + c] = sv; else scl[SC_BREQ + (c - nc)] = sv;
+        }
+    }
+    __syncthreads();
+    auglag_finish_at(A, sc_global, scl, write_back);
 }
 

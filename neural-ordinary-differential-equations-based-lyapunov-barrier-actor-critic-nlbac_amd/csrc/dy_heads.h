@@ -11,6 +11,7 @@
 //   policy_loss_1 / alpha loss       U/sac_cbf_clf/sac_cbf_clf.py:258-273, 292-308
 #pragma once
 #include "common.h"
+#include "auglag_device.h"
 #include "scalars.h"
 
 #define LOG_SIG_MAX 2.0f
@@ -85,12 +86,16 @@ __device__ __forceinline__ void gauss_bwd_one(const float* heads, int heads_ld, 
 // Sum of n_tiles partials (stride floats apart) read past the non-coherent caches: thread t takes tiles t, t + 256, ...
 // in order, then the fixed tree of block_sum_256 — the result does not depend on which workgroup was elected.
 template <int NV>
-__device__ __forceinline__ void elected_tile_sums(const float* partials, int n_tiles, int stride, float (&v)[NV], float* red) {
+__device__ __forceinline__ void elected_tile_sums(const float* partials, int n_tiles, int stride, float (&v)[NV], float* red,
+                                                  bool coherent = true) {
 #pragma unroll
     for (int k = 0; k < NV; ++k) v[k] = 0.f;
     for (int b = threadIdx.x; b < n_tiles; b += 256)
 #pragma unroll
-        for (int k = 0; k < NV; ++k) v[k] += coherent_load(partials + (long)b * stride + k);
+        for (int k = 0; k < NV; ++k) {      // (coherent: published by other workgroups of THIS launch; else an earlier launch's)
+            const float* q = partials + (long)b * stride + k;
+            v[k] += coherent ? coherent_load(q) : *q;
+        }
     block_sum_256<NV>(v, red);
 }
 
@@ -162,8 +167,21 @@ __device__ __forceinline__ void dy_head_rows(const nlbac_dy_head& H, int inet, i
         // Two phases so that every global load of the tile is in flight at once: (row, hazard, controller) per thread
         // forms that hazard's addend, then one thread per row sums the addends in hazard order (the launch's order).
         __shared__ float s_cb[TILE * 2 * 16 * 2];
+        __shared__ float s_ag[NLBAC_SC_SIZE_ENUM + 4 * 15];
         const int NH = H.cb_nh;
         const float* sc = H.cb_sc;
+        if (H.cb_defer) {      // (uniform) the forward's constraint head left its tiles' column sums and ran no step: this
+            //                    workgroup runs it on a private copy of the block — which this launch only reads — and takes
+            //                    the coefficients from there; a later launch commits it (nlbac_head_sums kind 4)
+            const AuglagArgs A = {H.cb_auglag.n_cbf, H.cb_auglag.n_clf, H.cb_auglag.batch_size, H.cb_auglag.do_lambda_update,
+                                  H.cb_auglag.do_backup_lambda_update, H.cb_auglag.ratio_mode, H.cb_auglag.backup_mode,
+                                  H.cb_auglag.lam_lo, H.cb_auglag.lam_hi};
+            auglag_from_tiles<15, false>(H.cb_partials, H.cb_tiles[0], A, const_cast<float*>(H.cb_sc), s_ag,
+                                         s_ag + NLBAC_SC_SIZE_ENUM, false);
+            sc = s_ag;
+            if (row0 == 0)      // the first tile leaves the stepped block for the job that commits it (nlbac_head_sums 4)
+                for (int t = tid; t < NLBAC_SC_SIZE_ENUM; t += 256) H.cb_stage[t] = s_ag[t];
+        }
         for (int idx = tid; idx < TILE * 16; idx += 256) sdy[idx] = 0.f;
         for (int t = tid; t < TILE * 2 * NH; t += 256) {
             const int r = t / (2 * NH), rem = t - r * 2 * NH, h = rem >> 1, which = rem & 1, i = min(row0 + r, B - 1);
@@ -227,25 +245,29 @@ __device__ __forceinline__ void dy_head_rows(const nlbac_dy_head& H, int inet, i
 // nothing else uses until the call returns.
 // The batch sums of a kind-2 / kind-3 head from its tile partials: what the elected workgroup of the head's own launch
 // does, or — nlbac_dy_head::sums_defer — a workgroup of a later launch (dy_head_jobs).  All 256 threads.
-__device__ __forceinline__ void head_sums_finish(const nlbac_head_sums& J, int n_tiles, float* red) {
+__device__ __forceinline__ void head_sums_finish(const nlbac_head_sums& J, int n_tiles, float* red, bool coh = true) {
     const int tid = threadIdx.x;
     if (J.kind == 2) {
         float s[3];
-        elected_tile_sums<3>(J.partials, n_tiles, J.n_nets, s, red);
+        elected_tile_sums<3>(J.partials, n_tiles, J.n_nets, s, red, coh);
         if (tid < 3) J.out[tid] = s[tid] * J.mul;
         if (J.n_nets == 4) {
             float sx[1];
-            elected_tile_sums<1>(J.partials + 3, n_tiles, 4, sx, red);
+            elected_tile_sums<1>(J.partials + 3, n_tiles, 4, sx, red, coh);
             if (tid == 0) J.out_x[0] = sx[0] * J.mul;
         }
     } else if (J.kind == 3) {
         for (int pp = 0; pp < J.n_nets; ++pp) {
             float s[2];
-            elected_tile_sums<2>(J.partials + (long)pp * n_tiles * 2, n_tiles, 2, s, red);
+            elected_tile_sums<2>(J.partials + (long)pp * n_tiles * 2, n_tiles, 2, s, red, coh);
             if (tid == 0)
                 actor_scalars_one(s[0], s[1], pp, J.B_norm, J.actor.target_entropy, J.actor.log_alpha[pp],
                                   J.actor.g_log_alpha[pp], J.actor.sc);
         }
+    } else if (J.kind == 4) {
+        // commit the augmented-Lagrangian step an earlier launch staged: the entries the step may change (auglag_finish_at)
+        for (int t = tid; t < NLBAC_SC_SIZE_ENUM; t += 256)
+            if ((t >= SC_RATIO && t <= SC_BPL2) || (t >= SC_LAMBDA && t < SC_MEAN_LOGP)) J.sc[t] = J.partials[t];
     }
 }
 
@@ -304,10 +326,10 @@ __device__ __forceinline__ void dy_head_finish(const nlbac_dy_head& H, int inet,
 // every workgroup calls it at the END of the kernel (contains a barrier for the workgroups that have a job; uniform).
 __device__ __forceinline__ void dy_head_jobs(const nlbac_dy_head& H, int tile, int inet, int n_tiles_launch, float* red) {
 #pragma unroll
-    for (int j = 0; j < 2; ++j)
+    for (int j = 0; j < 3; ++j)
         if (H.finish[j].kind != 0 && inet == 0 && tile == (j < n_tiles_launch ? j : 0)) {
             __syncthreads();                            // (red is free: every earlier use of the scratch is done)
-            head_sums_finish(H.finish[j], (int)H.finish[j].n_tiles[0], red);
+            head_sums_finish(H.finish[j], H.finish[j].kind == 4 ? 0 : (int)H.finish[j].n_tiles[0], red, false);
         }
 }
 

@@ -1122,7 +1122,8 @@ extern "C" int nlbac_mlp_fwd_head(const nlbac_mlp* nets, const nlbac_mlp_io* io,
     NLBAC_REQUIRE(nlbac_mlp_fwd_head_ok(nets, n_nets), "%s: these nets' forward does not evaluate constraint heads (nlbac_mlp_fwd_head_ok)", who);
     NLBAC_REQUIRE(G.cf_net >= 0 && G.cf_net < n_nets && nets[G.cf_net].out_dim == 1 && G.cf_nh == 7,
                   "%s: cf_net must be a scalar net of the launch, cf_nh == 7", who);
-    NLBAC_REQUIRE(G.cf_ps && G.cf_ps_next && G.cf_V && G.cf_hazards && G.cf_matr && G.cf_bmatr && G.cf_partials && G.cf_tickets &&
+    NLBAC_REQUIRE(!G.cf_defer || G.cf_tiles, "%s: cf_defer needs cf_tiles", who);
+    NLBAC_REQUIRE(G.cf_ps && G.cf_ps_next && G.cf_V && G.cf_hazards && G.cf_matr && G.cf_bmatr && G.cf_partials && (G.cf_tickets || G.cf_defer) &&
                       G.cf_sc && G.cf_dt > 0.f && G.cf_batch_size > 0.f, "%s: constraint head: null pointer / bad scalars", who);
     NLBAC_REQUIRE(G.cf_n_cbf == G.cf_nh && G.cf_n_clf == 1 && G.cf_backup_mode >= 1 && G.cf_backup_mode <= 2,
                   "%s: constraint head 1 publishes 2 n_hz + 1 columns (n_cbf == n_hz, one CLF term, a backup controller)", who);
@@ -1199,10 +1200,14 @@ extern "C" int nlbac_mlp_bwd_data_head(const nlbac_mlp* nets, const nlbac_mlp_io
         }
     }
     NLBAC_REQUIRE(!H.sums_defer || ((H.kind == 2 || H.kind == 3) && H.sums_tiles), "%s: sums_defer goes with kind 2 / 3 and sums_tiles", who);
-    for (int j = 0; j < 2; ++j) {
+    NLBAC_REQUIRE(!H.cb_defer || (H.cb_kind == 1 && H.cb_nh == 7 && H.cb_partials && H.cb_tiles && H.cb_stage && H.cb_auglag.n_cbf == 7 &&
+                                  H.cb_auglag.n_clf == 1 && H.cb_auglag.backup_mode != 0 && H.cb_auglag.batch_size > 0.f),
+                  "%s: cb_defer goes with cb_kind 1 (7 hazards, CLF term, backup controller) and needs cb_partials / cb_tiles / cb_auglag", who);
+    for (int j = 0; j < 3; ++j) {
         const nlbac_head_sums& J = H.finish[j];
         if (!J.kind) continue;
-        NLBAC_REQUIRE((J.kind == 2 || J.kind == 3) && J.partials && J.n_tiles, "%s: finish[%d]: kind 2 / 3 with partials and n_tiles", who, j);
+        NLBAC_REQUIRE(J.kind >= 2 && J.kind <= 4 && J.partials && (J.n_tiles || J.kind == 4), "%s: finish[%d]: kind 2 / 3 / 4 with partials (and n_tiles)", who, j);
+        NLBAC_REQUIRE(J.kind != 4 || J.sc, "%s: finish[%d]: the commit job needs sc", who, j);
         NLBAC_REQUIRE(J.kind != 2 || ((J.n_nets == 3 || J.n_nets == 4) && J.out && (J.n_nets == 3 || J.out_x)), "%s: finish[%d]: td sums need out (and out_x with 4 nets)", who, j);
         NLBAC_REQUIRE(J.kind != 3 || (J.n_nets >= 1 && J.n_nets <= 2 && J.B_norm >= 1 && J.actor.sc), "%s: finish[%d]: actor sums need n_prob, B_norm and the scalars block", who, j);
         if (J.kind == 3)

@@ -228,32 +228,17 @@ __global__ __launch_bounds__(256, 3) void mlp_rrq_fwd_kernel(const MlpLaunch L, 
         if (tid < NC)
             for (int r = 0; r < QT; ++r) mine += sT[r * 16 + tid];
         const unsigned tile = blockIdx.x, n_tiles = gridDim.x;
-        if (publish_and_elect_grouped_lanes(G.cf_partials + (long)tile * NC, mine, NC, G.cf_tickets, tile, n_tiles)) {
-            // the elected workgroup: the scalars block into LDS (the layer-0 exchange tile is free), every thread sums the
-            // tiles t, t + 256, ... of all columns, a fixed tree over the workgroup (whichever workgroup was elected: the
-            // same sums), then the augmented-Lagrangian bookkeeping
-            const AuglagArgs A = {G.cf_n_cbf, G.cf_n_clf, G.cf_batch_size, G.cf_do_lambda_update, G.cf_do_backup_lambda_update,
-                                  G.cf_ratio_mode, G.cf_backup_mode, G.cf_lam_lo, G.cf_lam_hi};
-            float* const scl = sH;
-            float* const red = sH + NLBAC_SC_SIZE_ENUM;       // 4 * NC floats
-            for (int t = tid; t < NLBAC_SC_SIZE_ENUM; t += 256) scl[t] = G.cf_sc[t];
-            float v[NC];
-#pragma unroll
-            for (int c = 0; c < NC; ++c) v[c] = 0.f;
-            for (unsigned b = tid; b < n_tiles; b += 256)
-#pragma unroll
-                for (int c = 0; c < NC; ++c) v[c] += coherent_load(G.cf_partials + (long)b * NC + c);
-            block_sum_256<NC>(v, red);
-            const int nc = A.n_cbf + A.n_clf;
-            if (tid == 0) {
-#pragma unroll
-                for (int c = 0; c < NC; ++c) {
-                    const float sv = v[c] / A.batch_size;
-                    if (c < nc) scl[SC_REQ + c] = sv; else scl[SC_BREQ + (c - nc)] = sv;
-                }
-            }
-            __syncthreads();
-            auglag_finish_at(A, G.cf_sc, scl);
+        const AuglagArgs A = {G.cf_n_cbf, G.cf_n_clf, G.cf_batch_size, G.cf_do_lambda_update, G.cf_do_backup_lambda_update,
+                              G.cf_ratio_mode, G.cf_backup_mode, G.cf_lam_lo, G.cf_lam_hi};
+        if (G.cf_defer) {
+            // no election: the tile's column sums go out as they are; the workgroups that need the step's coefficients
+            // sum them themselves (nlbac_dy_head::cb_defer), a later launch commits the step (nlbac_head_sums kind 4)
+            if (tid < NC) G.cf_partials[(long)tile * NC + tid] = mine;
+            if (tile == 0 && tid == 0) G.cf_tiles[0] = n_tiles;
+        } else if (publish_and_elect_grouped_lanes(G.cf_partials + (long)tile * NC, mine, NC, G.cf_tickets, tile, n_tiles)) {
+            // the elected workgroup: the scalars block into LDS (the layer-0 exchange tile is free), the tiles' sums, then
+            // the augmented-Lagrangian bookkeeping (auglag_device.h)
+            auglag_from_tiles<NC, true>(G.cf_partials, n_tiles, A, G.cf_sc, sH, sH + NLBAC_SC_SIZE_ENUM, true);
         }
     }
 }
@@ -278,8 +263,12 @@ __global__ __launch_bounds__(256, 3) void mlp_rrq_bwd_kernel(const MlpLaunch L, 
     float* const sO = sx + QT * 16;                       // [4][16][16] the quarters' parts of dx
     float* const sZ1 = sO + 4 * QT * 16;                  // [16][LDH] dz1: the quarters' exchange (and its column sums)
     float* const sZ0 = sZ1 + QT * LDH;                    // [16][LDH] dz0 (skinny partials only)
-    const nlbac_mlp& net = L.net[blockIdx.y];
-    const nlbac_mlp_io& io = L.io[blockIdx.y];
+    // which net this workgroup serves.  With nlbac_dy_head::cb_defer the net behind the Q pairs goes FIRST: its workgroups
+    // carry the private augmented-Lagrangian step (~4 us more); dispatched first they keep their slots longer and the
+    // launch's second round lands on the other slots — last, they would end the launch that much later
+    const int by = H.cb_defer ? (int)((blockIdx.y + 2u * (unsigned)H.n_prob) % gridDim.y) : (int)blockIdx.y;
+    const nlbac_mlp& net = L.net[by];
+    const nlbac_mlp_io& io = L.io[by];
     const int B = L.B;
     const int tid = threadIdx.x, lane = tid & 63;
     const int cq = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -327,7 +316,7 @@ __global__ __launch_bounds__(256, 3) void mlp_rrq_bwd_kernel(const MlpLaunch L, 
 
     // ---- dL/dy (and, for the skinny partials, the input rows) of the tile -> LDS
     // (kind 3: nets behind the Q pairs read io.dy — but for the first of them when the head evaluates the constraint backward: cb_kind)
-    const bool plain_dy = H.kind == 0 || (H.kind == 3 && (int)blockIdx.y >= 2 * H.n_prob && !(H.cb_kind && (int)blockIdx.y == 2 * H.n_prob));
+    const bool plain_dy = H.kind == 0 || (H.kind == 3 && by >= 2 * H.n_prob && !(H.cb_kind && by == 2 * H.n_prob));
     DyHeadPending pend;
     pend.v0 = pend.v1 = 0.f;
     {
@@ -339,7 +328,7 @@ __global__ __launch_bounds__(256, 3) void mlp_rrq_bwd_kernel(const MlpLaunch L, 
             vx0 = io.x0[row * io.x0_ld + min(c, io.x0_dim - 1)];
             if (io.x1 != nullptr && io.x1_dim > 0) vx1 = io.x1[row * io.x1_ld + min(max(c - io.x0_dim, 0), io.x1_dim - 1)];
         }
-        if (!plain_dy) dy_head_rows<QT>(H, blockIdx.y, row0, B, sdy, pend);
+        if (!plain_dy) dy_head_rows<QT>(H, by, row0, B, sdy, pend);
         if (plain_dy) sdy[tid] = (row0 + r < B && c < odim) ? vdy : 0.f;
         if (sk) sx[tid] = (row0 + r < B && c < idim) ? (c < io.x0_dim ? vx0 : vx1) : 0.f;
     }
@@ -485,10 +474,10 @@ __global__ __launch_bounds__(256, 3) void mlp_rrq_bwd_kernel(const MlpLaunch L, 
     // ---- the dy head's batch sums: published / finished here, off the tile's critical path
     if (!plain_dy && H.kind != 1) {
         __syncthreads();                           // (sx is the election's scratch: every read of it above is done)
-        dy_head_finish<QT>(H, blockIdx.y, row0, gridDim.x, sx, gridDim.y, pend);
+        dy_head_finish<QT>(H, by, row0, gridDim.x, sx, gridDim.y, pend);
     }
     // ---- batch sums an earlier launch's head left to this one (nlbac_dy_head::finish)
-    dy_head_jobs(H, (int)blockIdx.x, (int)blockIdx.y, (int)gridDim.x, sx);
+    dy_head_jobs(H, (int)blockIdx.x, by, (int)gridDim.x, sx);
 }
 
 // ---------------------------------------------------------------------------------------------------------------------

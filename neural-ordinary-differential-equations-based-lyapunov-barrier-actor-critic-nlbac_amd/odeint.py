@@ -471,7 +471,9 @@ class AffineNodeSolver:
         c = self._ctl_read(P)
         self.ctx["ctl_host"] = c
         if self.ctx.get("chain"):       # device-driven chain: every problem finished within the attempts enqueued
-            ok = all(bool(c[p, 4] > 0) and not bool(c[p, 13] > 0) for p in range(P))
+            cl = c.tolist()             # (plain floats: element-wise reads of a tensor cost microseconds each, on the host's
+            #                              way from the accept decision to the launches that wait for it)
+            ok = all(cl[p][4] > 0 and not cl[p][13] > 0 for p in range(P))
             if not ok:                  # a captured chain that is too short: later captures enqueue more attempts
                 self._chain_len = int(max(float(c[p, 10]) for p in range(P))) + 1
                 self.generation += 1
@@ -528,11 +530,13 @@ class AffineNodeSolver:
         arr = self._ctl_pin[P].numpy()          # (the same memory)
         t0 = drained = None
         n = 0
+        stamps = arr[:, 15]
         while True:
-            s1 = arr[:, 15].copy()
-            c = arr.copy()
-            if all(c[p, 15] == s1[p] and (s1[p] == last or (first <= s1[p] < last and c[p, 4] > 0)) for p in range(P)):
-                return torch.from_numpy(c)
+            s1 = stamps.tolist()                       # (stamp, block, stamp: the sequence lock's read side)
+            if all(x == last or first <= x < last for x in s1):
+                c = arr.copy()
+                if all(c[p, 15] == s1[p] and (s1[p] == last or c[p, 4] > 0) for p in range(P)):
+                    return torch.from_numpy(c)
             n += 1
             if n & 63 == 0:
                 now = time.perf_counter()
@@ -908,13 +912,14 @@ class AffineNodeSolver:
             c = ctx.pop("ctl_host", None)
             if c is None:
                 c = self._ctl_read(P)               # the one host wait per CHAIN of attempts
-            if any(bool(c[p, 13] > 0) for p in range(P)):
+            c = c.tolist()                          # (plain floats: see first_step_done)
+            if any(c[p][13] > 0 for p in range(P)):
                 # out of step slots: the solve was stopped; start it again in a pool with room for twice as many steps
                 self._dopri_begin_chain(ctx["y0"], ctx["u"], P, rpp, min_slots=2 * pool.n_slots)
                 st = ctx["chain"]
                 pool, ws0 = st["pool"], st["ws0"]
                 continue
-            if all(bool(c[p, 4] > 0) for p in range(P)):
+            if all(c[p][4] > 0 for p in range(P)):
                 break
             if st["attempts"] >= 1000:
                 raise _lib.NlbacError("dopri5: max_num_steps exceeded")
@@ -931,8 +936,8 @@ class AffineNodeSolver:
                       stream_ptr())
             ctx["out_mapped"] = om is not None
         if c is not None:
-            nst = [int(c[p, 10]) for p in range(P)]
-            nacc = [int(c[p, 12]) for p in range(P)]
+            nst = [int(c[p][10]) for p in range(P)]
+            nacc = [int(c[p][12]) for p in range(P)]
             self._chain_len = max(1, max(nst))
             key = "single_step" if max(nst) == 1 else "multi_attempt"
             self.stats[key] += 1
@@ -942,7 +947,7 @@ class AffineNodeSolver:
                 row = []
                 for p in range(P):
                     if alog is None:
-                        row.append((float(c[p, 11]), float(c[p, 2]), True))
+                        row.append((c[p][11], c[p][2], True))
                     elif k < nst[p]:
                         row.append((float(alog[p, k, 0]), float(alog[p, k, 1]), bool(alog[p, k, 2] > 0)))
                     else:

@@ -95,6 +95,7 @@ class _Workspace:
         self.tickets_td = torch.zeros(2 + self.n_tiles * 4 // 16 + 1, dtype=torch.int32, device=dev)
         self.tickets_q = torch.zeros(2 + self.n_tiles * NP // 16 + 1, dtype=torch.int32, device=dev)
         self.sums_tiles = torch.zeros(4, dtype=torch.int32, device=dev)    # nlbac_dy_head::sums_tiles of the td / actor-q heads
+        self.sc_stage = z(SC.SC_SIZE)                                        # nlbac_dy_head::cb_stage
         self.part_tdx = z(max(NX, 1), self.nblk)
         self.heads2, self.pi2, self.logp2 = self.heads3[B:], self.act3[B:], self.logp3[B:]
         self.acts_p = z(NP, 2, B, H)
@@ -1113,6 +1114,14 @@ class SAC_CBF_CLF(object):
                     F.n_nets, F.B_norm = src.n_prob, src.B_norm
                     C.memmove(C.byref(F.actor), C.byref(src.actor), C.sizeof(_lib.ActorScalarArgs))
                 J += 1
+        if H is not False:
+            # (per call: the step's lambda-update flags change from update to update) the augmented-Lagrangian step a
+            # constraint head deferred (tasks.py: cf_job) is committed by this launch
+            job = P.__dict__.get("cf_job")
+            F = H.finish[2]
+            F.kind = 4 if job else 0
+            if job:
+                F.partials, F.sc = job[4], job[3]        # (the stepped block the constraint backward staged)
         if H is not False:
             H.da[2], H.da_ld[2] = du2.data_ptr(), du_ld
             call("nlbac_mlp_bwd_data_head", P.n_act, P.io_act, NP, B, C.byref(H), s)

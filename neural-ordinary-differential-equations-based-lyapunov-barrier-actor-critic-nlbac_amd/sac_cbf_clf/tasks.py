@@ -207,20 +207,31 @@ class UnicycleTask(_Task):
             call("nlbac_unicycle_lookahead", x_next2.data_ptr(), 2 * B, self.l_p, ws.ps_next2.data_ptr(), s)
         r_coll = 1.05 * float(self.env.hazards_radius)
         nets, io, cnt = (P.n_q5f, P.io_q5f, P.n_q5_count + 1) if merged else (P.n_l, P.io_vn, 1)
+        P.cf_job = None
         if use_head:
             # the constraint terms, their column sums and the augmented-Lagrangian step are the epilogue of V(p(x'))'s
             # workgroups in this launch (nlbac_gauss_head::cf_kind 1): no nlbac_unicycle_constraints_fwd launch
             A = a.auglag_fused(ws, self.num_cbfs, lam_upd)[0]._obj
-            G = _lib.GaussHead()
-            G.cf_kind, G.cf_net, G.cf_nh = 1, cnt - 1, self.num_cbfs
-            G.cf_ps, G.cf_ps_next, G.cf_V, G.cf_hazards = ws.ps.data_ptr(), ws.ps_next2.data_ptr(), ws.V.data_ptr(), self.hazards.data_ptr()
-            rc = float(np.float32(r_coll))           # (r_coll^2 as nlbac_unicycle_constraints_fwd forms it from its float argument)
-            G.cf_r2, G.cf_dt, G.cf_gamma_b, G.cf_gamma_l = float(np.float32(rc * rc)), dt, float(a.gamma_b), self.gamma_l
-            G.cf_matr, G.cf_bmatr = ws.matr.data_ptr(), ws.bmatr.data_ptr()
-            G.cf_partials, G.cf_tickets, G.cf_sc = ws.part_c16.data_ptr(), ws.tickets_c.data_ptr(), sc
-            G.cf_n_cbf, G.cf_n_clf, G.cf_batch_size = A.n_cbf, A.n_clf, A.batch_size
+            G = P.__dict__.get("cf_head")       # (built once per plan: ~40 ctypes field stores sit between the accept
+            if G is None:                       #  decision and this launch; only the lambda-update flags change per update)
+                G = P.cf_head = _lib.GaussHead()
+                G.cf_kind, G.cf_net, G.cf_nh = 1, cnt - 1, self.num_cbfs
+                G.cf_ps, G.cf_ps_next, G.cf_V, G.cf_hazards = ws.ps.data_ptr(), ws.ps_next2.data_ptr(), ws.V.data_ptr(), self.hazards.data_ptr()
+                rc = float(np.float32(r_coll))           # (r_coll^2 as nlbac_unicycle_constraints_fwd forms it from its float argument)
+                G.cf_r2, G.cf_dt, G.cf_gamma_b, G.cf_gamma_l = float(np.float32(rc * rc)), dt, float(a.gamma_b), self.gamma_l
+                G.cf_matr, G.cf_bmatr = ws.matr.data_ptr(), ws.bmatr.data_ptr()
+                G.cf_partials, G.cf_tickets, G.cf_sc = ws.part_c16.data_ptr(), ws.tickets_c.data_ptr(), sc
+                G.cf_n_cbf, G.cf_n_clf, G.cf_batch_size = A.n_cbf, A.n_clf, A.batch_size
+                G.cf_ratio_mode, G.cf_backup_mode, G.cf_lam_lo, G.cf_lam_hi = A.ratio_mode, A.backup_mode, A.lam_lo, A.lam_hi
+            assert G.cf_net == cnt - 1
             G.cf_do_lambda_update, G.cf_do_backup_lambda_update = A.do_lambda_update, A.do_backup_lambda_update
-            G.cf_ratio_mode, G.cf_backup_mode, G.cf_lam_lo, G.cf_lam_hi = A.ratio_mode, A.backup_mode, A.lam_lo, A.lam_hi
+            cf_defer = a._sums_defer()
+            if cf_defer:
+                # ... without the election and the step: the tiles' column sums go out, the workgroups of the constraint
+                # backward (below) sum them and run the step on a private copy of the scalars block, a workgroup of the
+                # actors' data backward commits it (nlbac_gauss_head::cf_defer, nlbac_dy_head::cb_defer, nlbac_head_sums 4)
+                G.cf_defer, G.cf_tiles = 1, ws.sums_tiles.data_ptr() + 8
+                P.cf_job = (ws.part_c16.data_ptr(), ws.sums_tiles.data_ptr() + 8, A, sc, ws.sc_stage.data_ptr())
             call("nlbac_mlp_fwd_head", nets, io, cnt, B, C.byref(G), s)
         else:
             call("nlbac_mlp_fwd", nets, io, cnt, B, s)
@@ -240,6 +251,11 @@ class UnicycleTask(_Task):
                 H.cb_ps_next, H.cb_matr, H.cb_bmatr = ws.ps_next2.data_ptr(), ws.matr.data_ptr(), ws.bmatr.data_ptr()
                 H.cb_hazards, H.cb_sc, H.cb_dt, H.cb_batch = self.hazards.data_ptr(), sc, dt, float(a.batch_size)
                 H.cb_dps_next, H.cb_dV = ws.dps_next2.data_ptr(), ws.dVn.data_ptr()
+            job = P.__dict__.get("cf_job") if use_head else None
+            H.cb_defer = 1 if job else 0
+            if job:
+                H.cb_partials, H.cb_tiles, H.cb_stage = job[0], job[1], job[4]
+                C.memmove(C.byref(H.cb_auglag), C.byref(job[2]), C.sizeof(_lib.AuglagArgs))
             call("nlbac_mlp_bwd_data_head", P.n_q5v, P.io_q5v, 2 * NP + 1, B, C.byref(H), s)
             ws.q5_bwd_done = True
         else:

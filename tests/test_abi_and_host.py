@@ -35,7 +35,7 @@ def test_library_exports_every_declared_symbol(lib):
     for n in names:
         assert hasattr(lib, n), "libnlbac_hip.so does not export %s" % n
     assert set(names) == set(_lib.EXPORTS), set(names) ^ set(_lib.EXPORTS)
-    assert lib.nlbac_abi_version() == _lib.ABI_VERSION == 15
+    assert lib.nlbac_abi_version() == _lib.ABI_VERSION == 16
 
 
 def test_ctypes_structs_match_header_sizes(lib):
