@@ -286,7 +286,10 @@ def test_deferred_head_sums_match_the_elections(env_name, B):
     """nlbac_dy_head::sums_defer / finish (the td head's and the actor-q head's batch sums finished by two workgroups of
     the actors' data backward instead of by elections at the end of their own launches): the same tile partials summed
     in the same order, so the returned losses, the temperatures' gradient and every parameter match bit for bit —
-    B = 8: one 16-row tile, both jobs on the launch's only tile; UnicycleBarrier: four critic nets (out_x)."""
+    B = 8: one 16-row tile, every job on the launch's only tile; UnicycleBarrier: four critic nets (out_x).  Unicycle: the
+    constraint head the same way (nlbac_gauss_head::cf_defer: tile column sums out; nlbac_dy_head::cb_defer: the constraint
+    backward's workgroups run the augmented-Lagrangian step privately; job kind 4 commits the staged block) against its
+    election + in-launch step: multipliers, rho and coefficients in the scalars block bit for bit."""
     hidden, seed = 256, 0
     gamma_b = {"Unicycle": 50.0, "Pvtol": 0.8, "UnicycleBarrier": 5.0}[env_name]
     fields = synth.fields(env_name)
@@ -297,10 +300,10 @@ def test_deferred_head_sums_match_the_elections(env_name, B):
         tr = synth.transitions(env_name, 4096, seed=3, env=env)
         rs = np.random.RandomState(5)
         rets = []
-        for updates in range(4):
+        for updates in (7, 8, 9, 16):          # (8, 16: the multipliers are stepped — the staged block carries new lambdas)
             idx = rs.choice(4096, B, replace=False)
             agent.set_noise(synth.normal_eps(agent.task.n_eps, B, env.n_u, seed=updates))
-            rets.append(agent.update_from_host(tuple(tr[f][idx] for f in fields), updates + 1, None))
+            rets.append(agent.update_from_host(tuple(tr[f][idx] for f in fields), updates, None))
         torch.cuda.synchronize()
         runs.append((agent, rets))
     (a0, r0), (a1, r1) = runs
