@@ -196,7 +196,7 @@ __device__ __forceinline__ void rk_fwd_norm_pre(const NodeRkLaunch& L, RkFwdWher
 // tile constants: y0 (or the in-map's state), u, h, already-known stages (FSAL / f0 from an earlier launch).
 // Contains barriers; ends with one.
 template <int NTHR>
-__device__ __forceinline__ void rk_fwd_tile_constants(const NodeRkLaunch& L, const RkFwdWhere& w, const RkFwdTile& T,
+__device__ __forceinline__ void rk_fwd_tile_constants(const NodeRkLaunch& L, RkFwdWhere& w, const RkFwdTile& T,
                                                       int row0, int tid) {
     const int n = L.n, ns = L.n_s, nu = L.n_u;
     if (L.in_kind == 1 && !w.fsal) {
@@ -236,7 +236,6 @@ __device__ __forceinline__ void rk_fwd_tile_constants(const NodeRkLaunch& L, con
         if (tid < NLBAC_MLP_TILE) {
             const int p = min(row0 + tid, n - 1) / L.rpp;
             vh = L.h_dev ? (float)rk_ctl_load(L.h_dev + (long)p * L.h_stride, L.coh != 0) : L.h_val[p];
-            if (L.norm_pre) vh = (float)w.h_pre;
         }
 #pragma unroll
         for (int it = 0; it < NK; ++it) {
@@ -250,6 +249,12 @@ __device__ __forceinline__ void rk_fwd_tile_constants(const NodeRkLaunch& L, con
                 else v = w.gK[(long)j * n * ns + rc];
             }
             vk[it] = v;
+        }
+        // nlbac_rk_chain::norm_pre: the step size of this launch comes from the previous launch's tile partials — summed
+        // HERE, behind the row loads above (their trips to memory overlap; in front of them the two latencies added up)
+        if (L.norm_pre) {
+            rk_fwd_norm_pre<NTHR>(L, w, row0, tid);
+            vh = (float)w.h_pre;
         }
 #pragma unroll
         for (int it = 0; it < NY; ++it) {

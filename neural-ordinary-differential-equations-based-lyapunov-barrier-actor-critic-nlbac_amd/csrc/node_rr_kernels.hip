@@ -175,7 +175,6 @@ __device__ __forceinline__ void node_rr_fwd_body(const NodeRkLaunch& L) {
     }
 
     RSTAMP(0)
-    if (L.norm_pre) rk_fwd_norm_pre<256>(L, w, row0, tid);      // (behind the prologue's loads: they are in flight)
     rk_fwd_tile_constants<256>(L, w, T, row0, tid);
     RSTAMP(1)
 
