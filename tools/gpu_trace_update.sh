@@ -15,7 +15,11 @@ import csv, sys
 rows = list(csv.DictReader(open(sys.argv[1])))
 ks = sorted((int(r["Start_Timestamp"]), int(r["End_Timestamp"]), r["Kernel_Name"].split("(")[0].replace("void ", "")[:60]) for r in rows)
 marks = [i for i, k in enumerate(ks) if k[2].startswith("sample_rows")]
-for u in [int(x) for x in __import__("os").environ.get("TRACE_UPDATES", "63,64").split(",")]:
+import os
+want = [int(x) for x in os.environ.get("TRACE_UPDATES", "63,64").split(",")]
+if os.environ.get("TRACE_FIND"):       # the first segment behind mark 40 that holds a kernel of this name (e.g. a NODE fit's)
+    want = [u for u in range(40, len(marks) - 1) if any(os.environ["TRACE_FIND"] in k[2] for k in ks[marks[u]:marks[u + 1]])][:1]
+for u in want:
     seg = ks[marks[u]:marks[u + 1]]
     t0 = seg[0][0]
     prev = t0
